@@ -1,0 +1,389 @@
+"""ctypes binding of the CPU restatement (oracle/fk_oracle.c) and helpers around the
+reference build in oracle/_ref.
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Product code under fastk_amd/ must never import this module.
+"""
+import ctypes as C
+import hashlib
+import os
+import struct
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "_build", "libfkoracle.so")
+REF_DIR = os.path.join(HERE, "_ref")
+REFERENCE_SRC = "/root/reference"
+
+
+def build(ref=True):
+    """Compile the restatement and, when the reference sources are present, oracle/_ref."""
+    subprocess.check_call(["make", "-s", "-C", HERE, "all"])
+    if ref and os.path.isdir(REFERENCE_SRC):
+        subprocess.check_call(["make", "-s", "-C", HERE, "ref"])
+
+
+class OrcParams(C.Structure):
+    _fields_ = [(n, C.c_int) for n in
+                ("kmer", "min_len", "max_super", "smer", "slen_bits", "slen_bytes",
+                 "kmer_bytes", "smer_bytes", "smer_word", "kmer_word")] + [("tran", C.c_int * 4)]
+
+
+class OrcResult(C.Structure):
+    _fields_ = [("hist", C.c_int64 * 0x8000), ("max_inst", C.c_int64), ("ninst", C.c_int64),
+                ("nsuper", C.c_int64), ("ndistinct_super", C.c_int64),
+                ("nweighted", C.c_int64), ("ndistinct", C.c_int64), ("ntable", C.c_int64),
+                ("table", C.POINTER(C.c_uint8)), ("wfirst", C.c_int64 * 256)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build(ref=False)
+        L = C.CDLL(LIB_PATH)
+        L.orc_params_init.argtypes = [C.POINTER(OrcParams), C.c_int, C.c_int]
+        L.orc_train_tran.argtypes = [C.POINTER(OrcParams), C.c_char_p, C.c_int64]
+        L.orc_distribute_block.restype = C.c_int64
+        L.orc_distribute_block.argtypes = [C.POINTER(OrcParams), C.c_void_p, C.c_void_p, C.c_int64,
+                                           C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
+                                           C.POINTER(C.c_int64)]
+        L.orc_msd_sort.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int]
+        L.orc_lsd_sort.restype = C.c_void_p
+        L.orc_lsd_sort.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        L.orc_kmer_list.restype = C.c_int64
+        L.orc_kmer_list.argtypes = [C.POINTER(OrcParams), C.c_void_p, C.c_int64,
+                                    C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
+                                    C.POINTER(C.c_int64)]
+        L.orc_count_sorted.argtypes = [C.POINTER(OrcParams), C.c_void_p, C.c_int64, C.c_int,
+                                       C.POINTER(OrcResult)]
+        L.orc_fastk.argtypes = [C.POINTER(OrcParams), C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
+                                C.c_int, C.POINTER(OrcResult)]
+        L.orc_brute.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
+                                C.POINTER(OrcResult)]
+        L.orc_result_free.argtypes = [C.POINTER(OrcResult)]
+        L.orc_hist_bytes.restype = C.c_int64
+        L.orc_hist_bytes.argtypes = [C.c_int, C.POINTER(OrcResult), C.c_void_p]
+        L.orc_table_split.argtypes = [C.POINTER(OrcParams), C.POINTER(OrcResult), C.c_int,
+                                      C.POINTER(C.c_int)]
+        L.orc_idx_bytes.restype = C.c_int
+        L.orc_idx_bytes.argtypes = [C.c_int, C.c_int64]
+        L.orc_write_outputs.argtypes = [C.POINTER(OrcParams), C.POINTER(OrcResult), C.c_int,
+                                        C.c_int, C.POINTER(C.c_int), C.c_char_p, C.c_char_p]
+        L.orc_synth_block.restype = C.c_void_p
+        L.orc_synth_block.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64,
+                                      C.c_int64, C.c_void_p]
+        L.orc_load_fastx.restype = C.c_void_p
+        L.orc_load_fastx.argtypes = [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+        L.free = C.CDLL(None).free
+        L.free.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def params(kmer, pad=0):
+    P = OrcParams()
+    lib().orc_params_init(C.byref(P), kmer, pad)
+    return P
+
+
+# --------------------------------------------------------------------------- inputs
+
+def block_from_reads(reads):
+    """DATA_BLOCK-style (FastK.h:87-98) buffer from a list of str/bytes reads."""
+    bs = [r.encode() if isinstance(r, str) else bytes(r) for r in reads]
+    boff = np.zeros(len(bs) + 1, dtype=np.int64)
+    np.cumsum([len(b) + 1 for b in bs], out=boff[1:])
+    bases = np.frombuffer(b"".join(b + b"\0" for b in bs), dtype=np.uint8).copy()
+    if bases.size == 0:
+        bases = np.zeros(1, dtype=np.uint8)
+    return bases, boff
+
+
+def synth_block(seed, genome_len, read_len, err_ppm, first_read, nreads):
+    L = lib()
+    boff = np.zeros(nreads + 1, dtype=np.int64)
+    p = L.orc_synth_block(seed, genome_len, read_len, err_ppm, first_read, nreads,
+                          boff.ctypes.data)
+    n = int(boff[nreads])
+    bases = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n,)).copy()
+    L.free(p)
+    return bases, boff
+
+
+def load_fastx(path):
+    L = lib()
+    bp = C.c_void_p()
+    nr = C.c_int64()
+    p = L.orc_load_fastx(path.encode(), C.byref(bp), C.byref(nr))
+    if not p:
+        raise IOError(path)
+    boff = np.ctypeslib.as_array(C.cast(bp, C.POINTER(C.c_int64)), shape=(nr.value + 1,)).copy()
+    n = int(boff[-1])
+    bases = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(max(n, 1),)).copy()
+    L.free(p)
+    L.free(bp)
+    return bases, boff
+
+
+def write_fasta(path, bases, boff, width=0):
+    with open(path, "wb") as f:
+        for i in range(len(boff) - 1):
+            s = bases[boff[i]:boff[i + 1] - 1].tobytes()
+            f.write(b">r%d\n" % i)
+            if width:
+                for o in range(0, len(s), width):
+                    f.write(s[o:o + width] + b"\n")
+            else:
+                f.write(s + b"\n")
+
+
+def write_fastq(path, bases, boff):
+    with open(path, "wb") as f:
+        for i in range(len(boff) - 1):
+            s = bases[boff[i]:boff[i + 1] - 1].tobytes()
+            f.write(b"@r%d\n" % i + s + b"\n+\n" + b"I" * len(s) + b"\n")
+
+
+# --------------------------------------------------------------------------- whole path
+
+class Result:
+    """hist / table of one run, in numpy form."""
+
+    def __init__(self, kmer, R, kmer_word):
+        self.kmer = kmer
+        self.hist = np.ctypeslib.as_array(R.hist).copy()
+        self.max_inst = int(R.max_inst)
+        self.ninst = int(R.ninst)
+        self.nsuper = int(R.nsuper)
+        self.ndistinct_super = int(R.ndistinct_super)
+        self.nweighted = int(R.nweighted)
+        self.ndistinct = int(R.ndistinct)
+        self.ntable = int(R.ntable)
+        self.wfirst = np.ctypeslib.as_array(R.wfirst).copy()
+        if R.ntable > 0:
+            self.table = np.ctypeslib.as_array(R.table, shape=(R.ntable, kmer_word)).copy()
+        else:
+            self.table = np.zeros((0, kmer_word), dtype=np.uint8)
+
+    def hist_bytes(self):
+        return hist_file_bytes(self.kmer, self.hist, self.max_inst)
+
+
+def hist_file_bytes(kmer, hist, max_inst):
+    """.hist encoding (count.c:1893-1910): int k, int 1, int 0x7fff, i64 hist[1], i64 max_inst,
+    i64 hist[1..0x7fff]."""
+    h = np.asarray(hist, dtype=np.int64)
+    return (struct.pack("<iii", kmer, 1, 0x7fff) + struct.pack("<qq", int(h[1]), int(max_inst))
+            + h[1:0x8000].tobytes())
+
+
+def fastk(kmer, bases, boff, cutoff=1, bc_prefix=0, train=True, pad=0):
+    L = lib()
+    P = params(kmer, pad)
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    boff = np.ascontiguousarray(boff, dtype=np.int64)
+    if train:
+        L.orc_train_tran(C.byref(P), bases.ctypes.data_as(C.c_char_p), int(boff[-1]))
+    R = OrcResult()
+    L.orc_fastk(C.byref(P), bases.ctypes.data, boff.ctypes.data, len(boff) - 1, bc_prefix, cutoff,
+                C.byref(R))
+    out = Result(kmer, R, P.kmer_word)
+    out.params = P
+    L.orc_result_free(C.byref(R))
+    return out
+
+
+def brute(kmer, bases, boff, cutoff=1, bc_prefix=0):
+    L = lib()
+    P = params(kmer)
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    boff = np.ascontiguousarray(boff, dtype=np.int64)
+    R = OrcResult()
+    L.orc_brute(kmer, bases.ctypes.data, boff.ctypes.data, len(boff) - 1, bc_prefix, cutoff,
+                C.byref(R))
+    out = Result(kmer, R, P.kmer_word)
+    out.params = P
+    L.orc_result_free(C.byref(R))
+    return out
+
+
+def table_split(P, res, nthreads):
+    R = OrcResult()
+    R.nweighted = res.nweighted
+    for i in range(256):
+        R.wfirst[i] = int(res.wfirst[i])
+    sp = (C.c_int * nthreads)()
+    lib().orc_table_split(C.byref(P), C.byref(R), nthreads, sp)
+    return list(sp)
+
+
+def idx_bytes(kmer, ntable):
+    return lib().orc_idx_bytes(kmer, ntable)
+
+
+def write_outputs(res, cutoff, nthreads, outdir, root, split=None):
+    """Write .hist / .ktab files from a Result with the oracle's writers."""
+    L = lib()
+    P = res.params
+    R = OrcResult()
+    for i in range(0x8000):
+        R.hist[i] = int(res.hist[i])
+    R.max_inst = res.max_inst
+    R.nweighted = res.nweighted
+    R.ntable = res.ntable
+    for i in range(256):
+        R.wfirst[i] = int(res.wfirst[i])
+    tab = np.ascontiguousarray(res.table)
+    R.table = tab.ctypes.data_as(C.POINTER(C.c_uint8))
+    sp = None
+    if split is not None:
+        sp = (C.c_int * nthreads)(*split)
+    rc = L.orc_write_outputs(C.byref(P), C.byref(R), cutoff, nthreads, sp, outdir.encode(),
+                             root.encode())
+    if rc != 0:
+        raise IOError("orc_write_outputs failed")
+
+
+# --------------------------------------------------------------------------- stage helpers
+
+def distribute(P, bases, boff, bc_prefix=0):
+    L = lib()
+    out = C.c_void_p()
+    n = C.c_int64(0)
+    cap = C.c_int64(0)
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    boff = np.ascontiguousarray(boff, dtype=np.int64)
+    inst = L.orc_distribute_block(C.byref(P), bases.ctypes.data, boff.ctypes.data, len(boff) - 1,
+                                  bc_prefix, C.byref(out), C.byref(n), C.byref(cap))
+    if n.value:
+        recs = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)),
+                                     shape=(n.value, P.smer_word)).copy()
+    else:
+        recs = np.zeros((0, P.smer_word), dtype=np.uint8)
+    if out.value:
+        L.free(out)
+    return recs, int(inst)
+
+
+def msd_sort(recs, ksize):
+    a = np.ascontiguousarray(recs).copy()
+    if a.shape[0]:
+        lib().orc_msd_sort(a.ctypes.data, a.shape[0], a.shape[1], ksize)
+    return a
+
+
+def lsd_sort(recs, byte_list):
+    a = np.ascontiguousarray(recs).copy()
+    t = np.empty_like(a)
+    bl = (C.c_int * (len(byte_list) + 1))(*(list(byte_list) + [-1]))
+    if a.shape[0] == 0:
+        return a
+    p = lib().orc_lsd_sort(a.shape[0], a.ctypes.data, t.ctypes.data, a.shape[1], bl)
+    return a if p == a.ctypes.data else t
+
+
+def kmer_list(P, sorted_smers):
+    L = lib()
+    out = C.c_void_p()
+    ovf = C.c_int64()
+    nd = C.c_int64()
+    s = np.ascontiguousarray(sorted_smers)
+    w = L.orc_kmer_list(C.byref(P), s.ctypes.data, s.shape[0], C.byref(out), C.byref(ovf),
+                        C.byref(nd))
+    if w:
+        recs = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)),
+                                     shape=(w, P.kmer_word)).copy()
+    else:
+        recs = np.zeros((0, P.kmer_word), dtype=np.uint8)
+    L.free(out)
+    return recs, int(ovf.value), int(nd.value)
+
+
+def count_sorted(P, sorted_kmers, cutoff):
+    L = lib()
+    R = OrcResult()
+    s = np.ascontiguousarray(sorted_kmers)
+    L.orc_count_sorted(C.byref(P), s.ctypes.data, s.shape[0], cutoff, C.byref(R))
+    out = Result(P.kmer, R, P.kmer_word)
+    out.params = P
+    L.orc_result_free(C.byref(R))
+    return out
+
+
+# --------------------------------------------------------------------------- .ktab / .hist readers
+
+def read_hist(path):
+    b = open(path, "rb").read()
+    k, lo, hi = struct.unpack_from("<iii", b, 0)
+    ilow, ihigh = struct.unpack_from("<qq", b, 12)
+    h = np.frombuffer(b, dtype=np.int64, offset=28, count=hi - lo + 1)
+    return dict(kmer=k, low=lo, high=hi, ilow=ilow, ihigh=ihigh, hist=h, raw=b)
+
+
+def read_ktab(path_root):
+    """Read <dir>/<root>.ktab + hidden parts.  Returns dict with header fields, per-part record
+    arrays, the full (kmer bytes + count) table and the canonical stream of SURVEY.md section 4
+    (stub index from byte 16 + part payloads from byte 12)."""
+    d, root = os.path.split(path_root)
+    d = d or "."
+    stub = open(os.path.join(d, root + ".ktab"), "rb").read()
+    k, nparts, minval, ib = struct.unpack_from("<iiii", stub, 0)
+    idx = np.frombuffer(stub, dtype=np.int64, offset=16, count=1 << (8 * ib))
+    kb = (2 * k + 7) >> 3
+    pw = kb + 2 - ib
+    parts = []
+    payload = []
+    for t in range(1, nparts + 1):
+        pb = open(os.path.join(d, ".%s.ktab.%d" % (root, t)), "rb").read()
+        pk, n = struct.unpack_from("<iq", pb, 0)
+        assert pk == k and len(pb) == 12 + n * pw, (pk, k, len(pb), n, pw)
+        parts.append(np.frombuffer(pb, dtype=np.uint8, offset=12).reshape(n, pw))
+        payload.append(pb[12:])
+    suffix = np.concatenate(parts) if parts else np.zeros((0, pw), dtype=np.uint8)
+    nels = suffix.shape[0]
+    # rebuild prefixes from the cumulative index
+    counts = np.diff(np.concatenate([[0], idx]))
+    pre = np.repeat(np.arange(len(idx), dtype=np.int64), counts)
+    full = np.zeros((nels, kb + 2), dtype=np.uint8)
+    for b in range(ib):
+        full[:, b] = (pre >> (8 * (ib - 1 - b))) & 0xff
+    full[:, ib:] = suffix
+    stream = stub[16:] + b"".join(payload)
+    return dict(kmer=k, nparts=nparts, minval=minval, ibytes=ib, index=idx, parts=parts,
+                table=full, nels=nels, stream_sha256=hashlib.sha256(stream).hexdigest(),
+                part_sizes=[p.shape[0] for p in parts])
+
+
+def table_stream_sha256(kmer, table, ib=None):
+    """Canonical stream digest computed from a full table (n, KMER_BYTES+2) array."""
+    n = table.shape[0]
+    if ib is None:
+        ib = idx_bytes(kmer, n)
+    pre = np.zeros(n, dtype=np.int64)
+    for b in range(ib):
+        pre = (pre << 8) | table[:, b].astype(np.int64)
+    idx = np.cumsum(np.bincount(pre, minlength=1 << (8 * ib))).astype(np.int64)
+    stream = idx.tobytes() + np.ascontiguousarray(table[:, ib:]).tobytes()
+    return hashlib.sha256(stream).hexdigest()
+
+
+# --------------------------------------------------------------------------- reference binary
+
+def have_ref():
+    return os.path.exists(os.path.join(REF_DIR, "FastK"))
+
+
+def run_ref_fastk(fastx_path, kmer, cutoff, nthreads, workdir, extra=()):
+    """Run the reference FastK (oracle/_ref/FastK) on a file; outputs land next to the input."""
+    cmd = [os.path.join(REF_DIR, "FastK"), "-k%d" % kmer, "-T%d" % nthreads, "-P" + workdir]
+    if cutoff > 0:
+        cmd.append("-t%d" % cutoff)
+    cmd += list(extra) + [fastx_path]
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                   cwd=workdir)
