@@ -49,13 +49,21 @@ void orc_params_init(orc_params *P, int kmer, int pad)
 /* ---------------------------------------------------------------------------------------
  * base mapping by frequency rank                          split.c:95-112 (counts), 529-575
  */
-void orc_train_tran(orc_params *P, const char *bases, int64_t len)
+void orc_train_tran(orc_params *P, const char *bases, const int64_t *boff, int64_t nreads,
+                    int nthreads)
 { int64_t freq[256], f4[4];
-  int64_t i;
+  int64_t i, stripe0;
   int     a, b;
 
+  /* Per-thread byte counts over read stripes [nreads*t/T, nreads*(t+1)/T) (split.c:95-112,
+     507-512) are summed INTO thread 0's own vector starting from j = 0 (split.c:536-539), so
+     stripe 0 is counted twice.  The ranking below therefore depends on -T exactly as the
+     reference's does. */
   memset(freq,0,sizeof(freq));
-  for (i = 0; i < len; i++)
+  for (i = boff[0]; i < boff[nreads]; i++)
+    freq[(uint8_t) bases[i]] += 1;
+  stripe0 = (nthreads > 1) ? (nreads * 1) / nthreads : nreads;
+  for (i = boff[0]; i < boff[stripe0]; i++)
     freq[(uint8_t) bases[i]] += 1;
   f4[0] = freq['a'] + freq['A'];
   f4[1] = freq['c'] + freq['C'];

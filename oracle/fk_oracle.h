@@ -49,13 +49,15 @@ typedef struct
 /* widths for k with PAD extra minimizer bases (FastK.c:417,446-468; split.c:617-628) */
 void orc_params_init(orc_params *P, int kmer, int pad);
 
-/* base-frequency ranking -> tran[] (split.c:95-112,529-575); freq over `len` bytes of text */
-void orc_train_tran(orc_params *P, const char *bases, int64_t len);
+/* base-frequency ranking -> tran[] (split.c:95-112,529-575) over the training block; depends on
+   the thread count because the reference counts thread 0's read stripe twice (split.c:536-539) */
+void orc_train_tran(orc_params *P, const char *bases, const int64_t *boff, int64_t nreads,
+                    int nthreads);
 
 /* Distribute one block of 0-terminated reads into fixed-width super-mer records
    (split.c:1016-1393 + count.c:165-313 layout).  bases/boff as in DATA_BLOCK
    (FastK.h:87-98): read i is bases[boff[i] .. boff[i+1]-1) followed by a 0 byte.
-   Appends to *out (realloc'd), *nout/*cap in records.  Returns k-mer instances emitted. */
+   Appends to *out (realloc'd), nout/cap in records.  Returns k-mer instances emitted. */
 int64_t orc_distribute_block(const orc_params *P, const char *bases, const int64_t *boff,
                              int64_t nreads, int bc_prefix,
                              uint8_t **out, int64_t *nout, int64_t *cap);

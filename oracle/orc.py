@@ -48,7 +48,7 @@ def lib():
             build(ref=False)
         L = C.CDLL(LIB_PATH)
         L.orc_params_init.argtypes = [C.POINTER(OrcParams), C.c_int, C.c_int]
-        L.orc_train_tran.argtypes = [C.POINTER(OrcParams), C.c_char_p, C.c_int64]
+        L.orc_train_tran.argtypes = [C.POINTER(OrcParams), C.c_void_p, C.c_void_p, C.c_int64, C.c_int]
         L.orc_distribute_block.restype = C.c_int64
         L.orc_distribute_block.argtypes = [C.POINTER(OrcParams), C.c_void_p, C.c_void_p, C.c_int64,
                                            C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
@@ -183,13 +183,13 @@ def hist_file_bytes(kmer, hist, max_inst):
             + h[1:0x8000].tobytes())
 
 
-def fastk(kmer, bases, boff, cutoff=1, bc_prefix=0, train=True, pad=0):
+def fastk(kmer, bases, boff, cutoff=1, bc_prefix=0, train=True, pad=0, nthreads=4):
     L = lib()
     P = params(kmer, pad)
     bases = np.ascontiguousarray(bases, dtype=np.uint8)
     boff = np.ascontiguousarray(boff, dtype=np.int64)
     if train:
-        L.orc_train_tran(C.byref(P), bases.ctypes.data_as(C.c_char_p), int(boff[-1]))
+        L.orc_train_tran(C.byref(P), bases.ctypes.data, boff.ctypes.data, len(boff) - 1, nthreads)
     R = OrcResult()
     L.orc_fastk(C.byref(P), bases.ctypes.data, boff.ctypes.data, len(boff) - 1, bc_prefix, cutoff,
                 C.byref(R))

@@ -1,0 +1,141 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory by running the REFERENCE FastK
+(oracle/_ref/FastK, built from /root/reference by oracle/Makefile) on deterministic inputs.
+
+Run from the repo root in the build container (needs /root/reference):
+    python tests/golden/make_golden.py
+
+Each case <name> produces
+    <name>.json      input description + expected results from the reference:
+                     sparse .hist (nonzero bins, ilow, ihigh, sha256 of the 262,164 file bytes),
+                     .ktab header fields, nels, part sizes, sha256 of the canonical stream
+                     (stub index from byte 16 + part payloads from byte 12), sha256 of every file
+    <name>.fa.gz     the input reads, only for hand-built edge-case inputs (synthetic inputs are
+                     regenerated from include/fk_synth.h parameters)
+    <name>.table.gz  the full (k-mer bytes, count) table, only for small cases
+Fixtures are data (inputs + expected outputs); no reference source text is stored.
+"""
+import gzip
+import hashlib
+import json
+import os
+import random
+import shutil
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import orc  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def edge_reads(seed, k):
+    """Both strands, N's (single and runs), reads < k, == k, k+1, lowercase/uppercase,
+    a read duplicated 40,000 times (weight clipping + saturation) and poly-A reads."""
+    rnd = random.Random(seed)
+    g = "".join(rnd.choice("acgt") for _ in range(5000))
+    comp = {"a": "t", "c": "g", "g": "c", "t": "a", "n": "n"}
+    reads = []
+    for _ in range(3000):
+        L = rnd.choice([30, k - 1, k, k + 1, 100, 151, 400])
+        s = rnd.randrange(0, len(g) - L)
+        r = g[s:s + L]
+        if rnd.random() < 0.5:
+            r = "".join(comp[c] for c in reversed(r))
+        r = list(r)
+        for j in range(len(r)):
+            if rnd.random() < 0.002:
+                r[j] = rnd.choice("acgt")
+        if rnd.random() < 0.1:
+            r[rnd.randrange(len(r))] = "N"
+        if rnd.random() < 0.03:
+            a = rnd.randrange(len(r))
+            for j in range(a, min(len(r), a + rnd.randrange(1, 80))):
+                r[j] = "n"
+        r = "".join(r)
+        if rnd.random() < 0.3:
+            r = r.upper()
+        reads.append(r)
+    reads += [g[100:160]] * 40000
+    reads += ["a" * 120] * 500
+    return reads
+
+
+CASES = [
+    # name, kind, k, cutoff, threads, spec
+    dict(name="edge_k40_t1_T4", kind="edge", k=40, cutoff=1, T=4, seed=47, fmt="fasta"),
+    dict(name="edge_k51_t1_T4", kind="edge", k=51, cutoff=1, T=4, seed=58, fmt="fastq"),
+    dict(name="edge_k40_t4_T1", kind="edge", k=40, cutoff=4, T=1, seed=47, fmt="fasta"),
+    dict(name="edge_k21_t2_T3", kind="edge", k=21, cutoff=2, T=3, seed=28, fmt="fasta"),
+    dict(name="synth_illumina_k40_t1_T4", kind="synth", k=40, cutoff=1, T=4, fmt="fastq",
+         synth=dict(seed=11, genome_len=200000, read_len=150, err_ppm=1000, nreads=20000)),
+    dict(name="synth_illumina_k51_t1_T4", kind="synth", k=51, cutoff=1, T=4, fmt="fasta",
+         synth=dict(seed=12, genome_len=200000, read_len=150, err_ppm=1000, nreads=20000)),
+    dict(name="synth_hifi_k40_t4_T8", kind="synth", k=40, cutoff=4, T=8, fmt="fasta",
+         synth=dict(seed=13, genome_len=100000, read_len=15000, err_ppm=2000, nreads=333)),
+    dict(name="synth_tiny_k40_t1_T2", kind="synth", k=40, cutoff=1, T=2, fmt="fasta",
+         synth=dict(seed=14, genome_len=3000, read_len=100, err_ppm=5000, nreads=300)),
+]
+
+
+def sha(b):
+    return hashlib.sha256(b).hexdigest()
+
+
+def main():
+    if not orc.have_ref():
+        orc.build(ref=True)
+    for case in CASES:
+        name = case["name"]
+        k = case["k"]
+        if case["kind"] == "edge":
+            reads = edge_reads(case["seed"], k)
+            bases, boff = orc.block_from_reads(reads)
+            with gzip.GzipFile(os.path.join(HERE, name + ".fa.gz"), "wb", mtime=0) as f:
+                for i, r in enumerate(reads):
+                    f.write(b">r%d\n%s\n" % (i, r.encode()))
+        else:
+            s = case["synth"]
+            bases, boff = orc.synth_block(s["seed"], s["genome_len"], s["read_len"], s["err_ppm"],
+                                          0, s["nreads"])
+        d = tempfile.mkdtemp(prefix="fkgold")
+        path = os.path.join(d, "x." + case["fmt"])
+        if case["fmt"] == "fasta":
+            orc.write_fasta(path, bases, boff, width=0 if case["kind"] == "edge" else 100)
+        else:
+            orc.write_fastq(path, bases, boff)
+        orc.run_ref_fastk(path, k, case["cutoff"], case["T"], d)
+        h = orc.read_hist(os.path.join(d, "x.hist"))
+        t = orc.read_ktab(os.path.join(d, "x"))
+        nz = np.nonzero(h["hist"])[0]
+        files = ["x.hist", "x.ktab"] + [".x.ktab.%d" % (i + 1) for i in range(case["T"])]
+        exp = dict(
+            hist_sha256=sha(h["raw"]), hist_len=len(h["raw"]), ilow=int(h["ilow"]),
+            ihigh=int(h["ihigh"]),
+            hist_nonzero=[[int(i) + h["low"], int(h["hist"][i])] for i in nz],
+            ktab=dict(kmer=t["kmer"], nparts=t["nparts"], minval=t["minval"], ibytes=t["ibytes"],
+                      nels=t["nels"], part_sizes=t["part_sizes"],
+                      stream_sha256=t["stream_sha256"],
+                      first=[t["table"][i].tobytes().hex() for i in range(min(8, t["nels"]))],
+                      last=[t["table"][i].tobytes().hex()
+                            for i in range(max(0, t["nels"] - 8), t["nels"])]),
+            file_sha256={f: sha(open(os.path.join(d, f), "rb").read()) for f in files},
+        )
+        meta = dict(case)
+        meta["expected"] = exp
+        meta["generated_by"] = "tests/golden/make_golden.py with oracle/_ref/FastK (reference build)"
+        with open(os.path.join(HERE, name + ".json"), "w") as f:
+            json.dump(meta, f, indent=1, sort_keys=True)
+        if t["nels"] <= 40000:
+            with gzip.GzipFile(os.path.join(HERE, name + ".table.gz"), "wb", mtime=0) as f:
+                f.write(np.ascontiguousarray(t["table"]).tobytes())
+        shutil.rmtree(d)
+        print(name, "nels", t["nels"], "parts", t["part_sizes"], "ihigh", h["ihigh"])
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,72 @@
+"""Shared helpers for the tests: golden-case loading and result comparison."""
+import glob
+import gzip
+import json
+import os
+
+import numpy as np
+
+from oracle import orc
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden_names(kind=None):
+    out = []
+    for p in sorted(glob.glob(os.path.join(GOLDEN, "*.json"))):
+        c = json.load(open(p))
+        if kind is None or c["kind"] == kind:
+            out.append(c["name"])
+    return out
+
+
+def load_case(name):
+    """Return (case dict, bases, boff) for a golden fixture."""
+    case = json.load(open(os.path.join(GOLDEN, name + ".json")))
+    if case["kind"] == "edge":
+        reads = []
+        with gzip.open(os.path.join(GOLDEN, name + ".fa.gz"), "rb") as f:
+            for line in f:
+                if not line.startswith(b">"):
+                    reads.append(line.rstrip(b"\n"))
+        bases, boff = orc.block_from_reads(reads)
+    else:
+        s = case["synth"]
+        bases, boff = orc.synth_block(s["seed"], s["genome_len"], s["read_len"], s["err_ppm"], 0,
+                                      s["nreads"])
+    return case, bases, boff
+
+
+def golden_table(name, kmer):
+    p = os.path.join(GOLDEN, name + ".table.gz")
+    if not os.path.exists(p):
+        return None
+    kw = ((2 * kmer + 7) >> 3) + 2
+    return np.frombuffer(gzip.open(p, "rb").read(), dtype=np.uint8).reshape(-1, kw)
+
+
+def expected_hist(case):
+    h = np.zeros(0x8000, dtype=np.int64)
+    for i, v in case["expected"]["hist_nonzero"]:
+        h[i] = v
+    return h
+
+
+def check_against_golden(case, hist, max_inst, table, name=None):
+    """hist: int64[0x8000] (index = count), table: (n, KMER_BYTES+2) uint8 sorted entries."""
+    import hashlib
+    exp = case["expected"]
+    k = case["k"]
+    eh = expected_hist(case)
+    assert np.array_equal(np.asarray(hist)[1:], eh[1:]), "histogram differs from reference"
+    assert int(max_inst) == exp["ihigh"], "ihighcnt differs from reference"
+    raw = orc.hist_file_bytes(k, hist, max_inst)
+    assert len(raw) == exp["hist_len"] == 262164
+    assert hashlib.sha256(raw).hexdigest() == exp["hist_sha256"], ".hist bytes differ"
+    kt = exp["ktab"]
+    assert table.shape[0] == kt["nels"], "table entry count differs"
+    assert orc.idx_bytes(k, table.shape[0]) == kt["ibytes"]
+    assert orc.table_stream_sha256(k, table) == kt["stream_sha256"], ".ktab canonical stream differs"
+    gt = golden_table(name or case["name"], k)
+    if gt is not None:
+        assert np.array_equal(table, gt), "table entries differ from reference"
