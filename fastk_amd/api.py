@@ -1,0 +1,275 @@
+"""ctypes host mirror of the C-ABI in include/fastk_amd.h.
+
+Thin by design: it loads fastk_amd/lib/libfastk_amd.so (hand-written HIP for gfx950) and exposes
+the same entry points with numpy-friendly arguments.  There is no CPU path: if the library is
+missing or no MI355X is visible, calls raise FastKError.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libfastk_amd.so")
+HIST_BINS = 0x8000
+
+EXPORTS = [
+    "fk_get_widths", "fk_default_params", "fk_create", "fk_destroy", "fk_last_error",
+    "fk_set_stream", "fk_synchronize", "fk_push_block", "fk_push_device", "fk_finish",
+    "fk_write_hist", "fk_write_ktab", "fk_split_supermers", "fk_lsd_sort_records",
+    "fk_msd_sort_records", "fk_expand_kmers", "fk_count_kmers", "fk_synth_reads",
+    "fk_device_alloc", "fk_device_free", "fk_copy_to_device", "fk_copy_to_host",
+    "fk_get_sort_stats", "fk_version", "fk_count_device_reads",
+]
+
+
+class FastKError(RuntimeError):
+    pass
+
+
+class Widths(C.Structure):
+    _fields_ = [(n, C.c_int) for n in
+                ("kmer", "min_len", "max_super", "smer_bytes", "slen_bytes", "smer_word",
+                 "kmer_bytes", "kmer_word", "smer_stride", "kmer_stride")]
+
+
+class Params(C.Structure):
+    _fields_ = [("kmer", C.c_int), ("table_cutoff", C.c_int), ("nthreads", C.c_int),
+                ("bc_prefix", C.c_int), ("device", C.c_int), ("nbuckets", C.c_int),
+                ("hbm_budget", C.c_int64)]
+
+
+class CResult(C.Structure):
+    _fields_ = [("hist", C.c_int64 * HIST_BINS), ("max_inst", C.c_int64), ("ninst", C.c_int64),
+                ("nsuper", C.c_int64), ("ndistinct_super", C.c_int64), ("nweighted", C.c_int64),
+                ("ndistinct", C.c_int64), ("ntable", C.c_int64),
+                ("table", C.POINTER(C.c_uint8)), ("wfirst", C.c_int64 * 256),
+                ("ms_split", C.c_double), ("ms_sort_super", C.c_double), ("ms_expand", C.c_double),
+                ("ms_sort_kmer", C.c_double), ("ms_count", C.c_double), ("ms_total", C.c_double)]
+
+
+class SortStats(C.Structure):
+    _fields_ = [("passes", C.c_int), ("nelem", C.c_int64), ("rsize", C.c_int),
+                ("pass_ms_total", C.c_double), ("hist_ms", C.c_double)]
+
+
+_lib = None
+
+
+def load_library():
+    """Load libfastk_amd.so; fail loudly when the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FastKError("%s is missing: build it with `make -C fastk_amd/csrc` "
+                         "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i64, ci = C.c_void_p, C.c_int64, C.c_int
+    L.fk_get_widths.argtypes = [ci, C.POINTER(Widths)]
+    L.fk_default_params.argtypes = [C.POINTER(Params)]
+    L.fk_default_params.restype = None
+    L.fk_create.argtypes = [C.POINTER(Params), C.POINTER(vp)]
+    L.fk_destroy.argtypes = [vp]
+    L.fk_destroy.restype = None
+    L.fk_last_error.argtypes = [vp]
+    L.fk_last_error.restype = C.c_char_p
+    L.fk_set_stream.argtypes = [vp, vp]
+    L.fk_synchronize.argtypes = [vp]
+    L.fk_push_block.argtypes = [vp, vp, vp, ci, ci, ci]
+    L.fk_push_device.argtypes = [vp, vp, i64]
+    L.fk_finish.argtypes = [vp, C.POINTER(CResult)]
+    L.fk_count_device_reads.argtypes = [vp, vp, i64, ci, C.POINTER(CResult)]
+    L.fk_write_hist.argtypes = [C.POINTER(CResult), ci, C.c_char_p]
+    L.fk_write_ktab.argtypes = [C.POINTER(CResult), ci, ci, ci, C.c_char_p, C.c_char_p]
+    L.fk_split_supermers.argtypes = [vp, vp, i64, vp, i64, C.POINTER(i64), C.POINTER(i64), vp]
+    L.fk_lsd_sort_records.argtypes = [vp, i64, vp, vp, ci, C.POINTER(ci), C.POINTER(vp)]
+    L.fk_msd_sort_records.argtypes = [vp, vp, vp, i64, ci, ci, C.POINTER(vp)]
+    L.fk_expand_kmers.argtypes = [vp, vp, i64, vp, i64, C.POINTER(i64), C.POINTER(i64),
+                                  C.POINTER(i64)]
+    L.fk_count_kmers.argtypes = [vp, vp, i64, ci, vp, C.POINTER(i64), C.POINTER(i64), vp, i64,
+                                 C.POINTER(i64)]
+    L.fk_synth_reads.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64,
+                                 i64, vp]
+    L.fk_device_alloc.argtypes = [vp, i64, C.POINTER(vp)]
+    L.fk_device_free.argtypes = [vp, vp]
+    L.fk_copy_to_device.argtypes = [vp, vp, vp, i64]
+    L.fk_copy_to_host.argtypes = [vp, vp, vp, i64]
+    L.fk_get_sort_stats.argtypes = [vp, C.POINTER(SortStats)]
+    L.fk_version.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def widths(kmer):
+    w = Widths()
+    if load_library().fk_get_widths(kmer, C.byref(w)) != 0:
+        raise FastKError("unsupported k = %d" % kmer)
+    return w
+
+
+class Result:
+    """fk_result copied into numpy arrays."""
+
+    def __init__(self, cres, kmer_word):
+        self.hist = np.ctypeslib.as_array(cres.hist).copy()
+        for f in ("max_inst", "ninst", "nsuper", "ndistinct_super", "nweighted", "ndistinct",
+                  "ntable"):
+            setattr(self, f, int(getattr(cres, f)))
+        self.wfirst = np.ctypeslib.as_array(cres.wfirst).copy()
+        self.ms = {k: float(getattr(cres, "ms_" + k))
+                   for k in ("split", "sort_super", "expand", "sort_kmer", "count", "total")}
+        if self.ntable > 0 and cres.table:
+            self.table = np.ctypeslib.as_array(cres.table, shape=(self.ntable, kmer_word)).copy()
+        else:
+            self.table = np.zeros((0, kmer_word), dtype=np.uint8)
+        self._c = cres
+
+
+class DeviceBuffer:
+    """HBM allocation owned by a Context."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx = ctx
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        ctx._ck(ctx.L.fk_device_alloc(ctx.h, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, arr):
+        a = np.ascontiguousarray(arr)
+        assert a.nbytes <= self.nbytes
+        self.ctx._ck(self.ctx.L.fk_copy_to_device(self.ctx.h, self.ptr, a.ctypes.data, a.nbytes))
+        return self
+
+    def download(self, nbytes=None, dtype=np.uint8, ptr=None):
+        n = self.nbytes if nbytes is None else int(nbytes)
+        out = np.empty(n, dtype=np.uint8)
+        if n:
+            self.ctx._ck(self.ctx.L.fk_copy_to_host(self.ctx.h, out.ctypes.data,
+                                                    self.ptr if ptr is None else ptr, n))
+        return out.view(dtype)
+
+    def free(self):
+        if self.ptr:
+            self.ctx.L.fk_device_free(self.ctx.h, self.ptr)
+            self.ptr = None
+
+
+class Context:
+    """fk_ctx wrapper: one per process / GPU."""
+
+    def __init__(self, kmer=40, table_cutoff=0, nthreads=4, bc_prefix=0, device=0, nbuckets=1):
+        self.L = load_library()
+        p = Params()
+        self.L.fk_default_params(C.byref(p))
+        p.kmer, p.table_cutoff, p.nthreads = kmer, table_cutoff, nthreads
+        p.bc_prefix, p.device, p.nbuckets = bc_prefix, device, nbuckets
+        self.params = p
+        self.h = C.c_void_p()
+        rc = self.L.fk_create(C.byref(p), C.byref(self.h))
+        if rc != 0:
+            raise FastKError("fk_create failed (%d): %s" %
+                             (rc, self.L.fk_last_error(None).decode()))
+        self.w = widths(kmer)
+        self.kmer = kmer
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise FastKError("libfastk_amd error %d: %s" %
+                             (rc, self.L.fk_last_error(self.h).decode()))
+
+    def close(self):
+        if self.h:
+            self.L.fk_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_stream(self, stream_ptr):
+        self._ck(self.L.fk_set_stream(self.h, stream_ptr))
+
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    # ---- whole path -------------------------------------------------------------------
+    def push_block(self, bases, boff, rem=0, tid=0):
+        """bases: uint8 array of 0-terminated reads, boff: int32 offsets (DATA_BLOCK, FastK.h:87)."""
+        b = np.ascontiguousarray(bases, dtype=np.uint8)
+        o = np.ascontiguousarray(boff, dtype=np.int32)
+        self._ck(self.L.fk_push_block(self.h, b.ctypes.data, o.ctypes.data, len(o) - 1, rem, tid))
+
+    def push_device(self, ptr, nbytes):
+        self._ck(self.L.fk_push_device(self.h, ptr, nbytes))
+
+    def finish(self):
+        r = CResult()
+        self._ck(self.L.fk_finish(self.h, C.byref(r)))
+        return Result(r, self.w.kmer_word)
+
+    def count_device_reads(self, ptr, nbytes, fetch_table=False):
+        r = CResult()
+        self._ck(self.L.fk_count_device_reads(self.h, ptr, nbytes, 1 if fetch_table else 0,
+                                              C.byref(r)))
+        return Result(r, self.w.kmer_word)
+
+    def write_hist(self, res, path):
+        self._ck(self.L.fk_write_hist(C.byref(res._c), self.kmer, path.encode()))
+
+    def write_ktab(self, res, outdir, root, nthreads=None):
+        # res._c.table points into ctx-owned memory that is valid until the next finish
+        self._ck(self.L.fk_write_ktab(C.byref(res._c), self.kmer, self.params.table_cutoff,
+                                      nthreads or self.params.nthreads, outdir.encode(),
+                                      root.encode()))
+
+    # ---- stages -----------------------------------------------------------------------
+    def synth_reads(self, seed, genome_len, read_len, err_ppm, first_read, nreads, buf=None):
+        n = nreads * (read_len + 1)
+        buf = buf or self.alloc(n + 64)
+        self._ck(self.L.fk_synth_reads(self.h, seed, genome_len, read_len, err_ppm, first_read,
+                                       nreads, buf.ptr))
+        self._ck(self.L.fk_synchronize(self.h))
+        return buf, n
+
+    def split(self, reads_ptr, nbytes, out_ptr=None, cap=0):
+        ns, ni = C.c_int64(), C.c_int64()
+        bc = (C.c_int64 * 256)()
+        self._ck(self.L.fk_split_supermers(self.h, reads_ptr, nbytes, out_ptr, cap, C.byref(ns),
+                                           C.byref(ni), bc))
+        return ns.value, ni.value, list(bc)[:self.params.nbuckets]
+
+    def lsd_sort(self, src_ptr, trg_ptr, nelem, rsize, byte_list):
+        bl = (C.c_int * (len(byte_list) + 1))(*(list(byte_list) + [-1]))
+        res = C.c_void_p()
+        self._ck(self.L.fk_lsd_sort_records(self.h, nelem, src_ptr, trg_ptr, rsize, bl,
+                                            C.byref(res)))
+        return res.value
+
+    def msd_sort(self, arr_ptr, tmp_ptr, nelem, rsize, ksize):
+        res = C.c_void_p()
+        self._ck(self.L.fk_msd_sort_records(self.h, arr_ptr, tmp_ptr, nelem, rsize, ksize,
+                                            C.byref(res)))
+        return res.value
+
+    def sort_stats(self):
+        st = SortStats()
+        self._ck(self.L.fk_get_sort_stats(self.h, C.byref(st)))
+        return dict(passes=st.passes, nelem=st.nelem, rsize=st.rsize,
+                    pass_ms_total=st.pass_ms_total, hist_ms=st.hist_ms)
+
+    def expand(self, smers_ptr, nsuper, out_ptr=None, cap=0):
+        nw, nd, ov = C.c_int64(), C.c_int64(), C.c_int64()
+        self._ck(self.L.fk_expand_kmers(self.h, smers_ptr, nsuper, out_ptr, cap, C.byref(nw),
+                                        C.byref(nd), C.byref(ov)))
+        return nw.value, nd.value, ov.value
+
+    def count(self, kmers_ptr, nweighted, cutoff, table_ptr=None, cap=0):
+        hist = np.zeros(HIST_BINS, dtype=np.int64)
+        mi, nd, nt = C.c_int64(0), C.c_int64(), C.c_int64()
+        self._ck(self.L.fk_count_kmers(self.h, kmers_ptr, nweighted, cutoff, hist.ctypes.data,
+                                       C.byref(mi), C.byref(nd), table_ptr, cap, C.byref(nt)))
+        return hist, mi.value, nd.value, nt.value

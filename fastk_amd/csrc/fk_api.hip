@@ -1,0 +1,701 @@
+// fk_api.hip -- C-ABI of libfastk_amd.so (see include/fastk_amd.h): context, streaming
+// interface, whole-path driver, output encodings.
+#include "fk_common.h"
+#include "../../include/fk_synth.h"
+
+#include <pthread.h>
+#include <stdarg.h>
+#include <fcntl.h>
+#include <unistd.h>
+#include <algorithm>
+
+static char g_last_error[512] = "";
+
+void fk_set_error(fk_ctx *ctx, const char *fmt, ...)
+{ va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
+  va_end(ap);
+  if (ctx != NULL)
+    memcpy(ctx->err, g_last_error, sizeof(ctx->err));
+}
+
+extern "C" const char *fk_last_error(const fk_ctx *ctx)
+{ return (ctx != NULL ? ctx->err : g_last_error); }
+
+extern "C" const char *fk_version(void)
+{ return ("fastk_amd 0.1 (gfx950)"); }
+
+// ---- widths: FastK.c:417,446-468 with PAD_LEN = MIN_LEN = 5 (split.c:56) ------------------------
+extern "C" int fk_get_widths(int kmer, fk_widths *w)
+{ if (w == NULL || kmer < 5)
+    return (FK_EINVAL);
+  int v, bits = 0;
+  w->kmer       = kmer;
+  w->min_len    = 5;
+  w->max_super  = kmer - 4;
+  for (v = w->max_super; v > 0; v >>= 1)
+    bits += 1;
+  w->slen_bytes = (bits + 7) >> 3;
+  w->smer_bytes = (2 * (w->max_super + kmer - 1) + 7) >> 3;
+  w->smer_word  = w->smer_bytes + w->slen_bytes;
+  w->kmer_bytes = (2 * kmer + 7) >> 3;
+  w->kmer_word  = w->kmer_bytes + 2;
+  w->smer_stride = (w->smer_word + 3) & ~3;
+  w->kmer_stride = (w->kmer_word + 3) & ~3;
+  return (FK_OK);
+}
+
+extern "C" void fk_default_params(fk_params *p)
+{ memset(p, 0, sizeof(*p));
+  p->kmer = 40;            // FastK.c:232
+  p->table_cutoff = 0;
+  p->nthreads = 4;         // FastK.c:234
+  p->bc_prefix = 0;
+  p->device = 0;
+  p->nbuckets = 1;
+  p->hbm_budget = 0;
+}
+
+// ---- minimizer order: pseudo-random ranking of the 1024 5-mers, canonical over both strands -----
+static void build_minimizer_tables(uint16_t *mtab, uint8_t *mbucket, int nbuckets)
+{ std::pair<uint64_t, int> order[1024];
+  int rank[1024];
+  for (int v = 0; v < 1024; v++)
+    order[v] = std::make_pair(fk_mix64(0x6b6d6572ull + (uint64_t) v), v);
+  std::sort(order, order + 1024);
+  for (int r = 0; r < 1024; r++)
+    rank[order[r].second] = r;
+  for (int v = 0; v < 1024; v++)
+    { int rc = 0;
+      for (int j = 0; j < 5; j++)
+        rc |= (3 - ((v >> (2 * j)) & 3)) << (2 * (4 - j));
+      const int a = rank[v], b = rank[rc];
+      mtab[v] = (uint16_t) ((std::min(a, b) << 1) | (b < a ? 1 : 0));
+    }
+  for (int r = 0; r < 1024; r++)
+    mbucket[r] = (uint8_t) (r % nbuckets);
+}
+
+extern "C" int fk_create(const fk_params *p, fk_ctx **out)
+{ if (p == NULL || out == NULL)
+    return (FK_EINVAL);
+  *out = NULL;
+  fk_ctx *ctx = (fk_ctx *) calloc(1, sizeof(fk_ctx));
+  if (ctx == NULL)
+    return (FK_ENOMEM);
+  ctx->prm = *p;
+  if (ctx->prm.nbuckets < 1) ctx->prm.nbuckets = 1;
+  if (ctx->prm.nthreads < 1) ctx->prm.nthreads = 1;
+  if (ctx->prm.nbuckets > 256 || fk_get_widths(p->kmer, &ctx->wid) != FK_OK || p->kmer > 128
+      || p->kmer < 8)
+    { fk_set_error(NULL, "fk_create: unsupported parameters (k=%d nbuckets=%d)", p->kmer,
+                   p->nbuckets);
+      free(ctx);
+      return (FK_EINVAL);
+    }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    { fk_set_error(NULL, "fk_create: no HIP device visible (this library has no CPU path)");
+      free(ctx);
+      return (FK_ENODEVICE);
+    }
+  ctx->device = p->device;
+  if (hipSetDevice(ctx->device) != hipSuccess)
+    { fk_set_error(NULL, "fk_create: cannot select device %d", ctx->device);
+      free(ctx);
+      return (FK_ENODEVICE);
+    }
+  { hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess
+        && strstr(prop.gcnArchName, "gfx950") == NULL)
+      { fk_set_error(NULL, "fk_create: device %d is %s; this library is built for gfx950 only",
+                     ctx->device, prop.gcnArchName);
+        free(ctx);
+        return (FK_ENODEVICE);
+      }
+  }
+#define CK(call) do { if ((call) != hipSuccess) { fk_set_error(NULL, "fk_create: %s failed", #call); \
+                                                    fk_destroy(ctx); return (FK_EHIP); } } while (0)
+  CK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  ctx->own_stream = true;
+  CK(hipEventCreate(&ctx->ev0));
+  CK(hipEventCreate(&ctx->ev1));
+  CK(hipEventCreate(&ctx->stage_ev[0]));
+  CK(hipEventCreate(&ctx->stage_ev[1]));
+  CK(hipMalloc((void **) &ctx->d_mrank, 1024 * sizeof(uint16_t)));
+  CK(hipMalloc((void **) &ctx->d_mbucket, 1024));
+  CK(hipMalloc((void **) &ctx->d_scratch, 65536));
+  CK(hipHostMalloc((void **) &ctx->h_scratch, 65536 + 32 * 256 * 8, hipHostMallocDefault));
+  CK(hipMalloc((void **) &ctx->d_digit_hist, 32 * 256 * sizeof(u64)));
+  CK(hipMalloc((void **) &ctx->d_ticket, 64 * sizeof(u32)));
+  { uint16_t mtab[1024];
+    build_minimizer_tables(mtab, ctx->h_mbucket, ctx->prm.nbuckets);
+    CK(hipMemcpy(ctx->d_mrank, mtab, sizeof(mtab), hipMemcpyHostToDevice));
+    CK(hipMemcpy(ctx->d_mbucket, ctx->h_mbucket, 1024, hipMemcpyHostToDevice));
+  }
+#undef CK
+  pthread_mutex_t *m = (pthread_mutex_t *) malloc(sizeof(pthread_mutex_t));
+  pthread_mutex_init(m, NULL);
+  ctx->push_lock = m;
+  *out = ctx;
+  return (FK_OK);
+}
+
+extern "C" void fk_destroy(fk_ctx *ctx)
+{ if (ctx == NULL)
+    return;
+  hipSetDevice(ctx->device);
+  if (ctx->stream != NULL)
+    hipStreamSynchronize(ctx->stream);
+  hipFree(ctx->d_mrank); hipFree(ctx->d_mbucket); hipFree(ctx->d_scratch);
+  if (ctx->h_scratch) hipHostFree(ctx->h_scratch);
+  hipFree(ctx->d_digit_hist); hipFree(ctx->d_status); hipFree(ctx->d_ticket);
+  hipFree(ctx->d_reads);
+  for (int i = 0; i < 2; i++)
+    { if (ctx->h_stage[i]) hipHostFree(ctx->h_stage[i]);
+      if (ctx->stage_ev[i]) hipEventDestroy(ctx->stage_ev[i]);
+    }
+  if (ctx->ev0) hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) hipEventDestroy(ctx->ev1);
+  if (ctx->own_stream && ctx->stream != NULL)
+    hipStreamDestroy(ctx->stream);
+  free(ctx->h_table);
+  if (ctx->push_lock)
+    { pthread_mutex_destroy((pthread_mutex_t *) ctx->push_lock);
+      free(ctx->push_lock);
+    }
+  free(ctx);
+}
+
+extern "C" int fk_set_stream(fk_ctx *ctx, void *hip_stream)
+{ if (ctx == NULL) return (FK_EINVAL);
+  if (ctx->own_stream && ctx->stream != NULL)
+    { hipStreamSynchronize(ctx->stream);
+      hipStreamDestroy(ctx->stream);
+    }
+  ctx->stream = (hipStream_t) hip_stream;
+  ctx->own_stream = false;
+  return (FK_OK);
+}
+
+extern "C" int fk_synchronize(fk_ctx *ctx)
+{ if (ctx == NULL) return (FK_EINVAL);
+  FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return (FK_OK);
+}
+
+// ---- utilities ----------------------------------------------------------------------------------
+extern "C" int fk_device_alloc(fk_ctx *ctx, int64_t nbytes, void **d_ptr)
+{ if (ctx == NULL || d_ptr == NULL || nbytes < 0) return (FK_EINVAL);
+  *d_ptr = NULL;
+  FK_HIP(ctx, hipSetDevice(ctx->device));
+  FK_HIP(ctx, hipMalloc(d_ptr, (size_t) (nbytes > 0 ? nbytes : 16)));
+  return (FK_OK);
+}
+
+extern "C" int fk_device_free(fk_ctx *ctx, void *d_ptr)
+{ if (ctx == NULL) return (FK_EINVAL);
+  FK_HIP(ctx, hipFree(d_ptr));
+  return (FK_OK);
+}
+
+extern "C" int fk_copy_to_device(fk_ctx *ctx, void *d_dst, const void *src, int64_t nbytes)
+{ if (ctx == NULL) return (FK_EINVAL);
+  FK_HIP(ctx, hipMemcpyAsync(d_dst, src, (size_t) nbytes, hipMemcpyHostToDevice, ctx->stream));
+  FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return (FK_OK);
+}
+
+extern "C" int fk_copy_to_host(fk_ctx *ctx, void *dst, const void *d_src, int64_t nbytes)
+{ if (ctx == NULL) return (FK_EINVAL);
+  FK_HIP(ctx, hipMemcpyAsync(dst, d_src, (size_t) nbytes, hipMemcpyDeviceToHost, ctx->stream));
+  FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return (FK_OK);
+}
+
+extern "C" int fk_get_sort_stats(fk_ctx *ctx, fk_sort_stats *st)
+{ if (ctx == NULL || st == NULL) return (FK_EINVAL);
+  *st = ctx->sort_stats;
+  return (FK_OK);
+}
+
+// ---- synthetic reads (include/fk_synth.h), one thread per base ----------------------------------
+__global__ __launch_bounds__(256) void k_synth(fk_synth_spec sp, uint64_t first_read, int64_t nreads,
+                                               unsigned char *out)
+{ const int64_t stride = (int64_t) sp.read_len + 1;
+  const int64_t total  = nreads * stride;
+  for (int64_t g = (int64_t) blockIdx.x * 256 + threadIdx.x; g < total;
+       g += (int64_t) gridDim.x * 256)
+    { const int64_t r = g / stride;
+      const uint32_t j = (uint32_t) (g - r * stride);
+      unsigned char c = 0;
+      if (j < sp.read_len)
+        { uint64_t start; uint32_t strand;
+          fk_synth_place(&sp, first_read + (uint64_t) r, &start, &strand);
+          const uint32_t b = fk_synth_base(&sp, first_read + (uint64_t) r, j, start, strand);
+          c = (unsigned char) ("acgt"[b]);
+        }
+      out[g] = c;
+    }
+}
+
+int fkx_synth(fk_ctx *ctx, uint64_t seed, uint64_t genome_len, uint32_t read_len,
+              uint32_t err_ppm, uint64_t first_read, int64_t nreads, void *d_bases)
+{ if (read_len == 0 || genome_len < read_len)
+    { fk_set_error(ctx, "fk_synth_reads: genome shorter than a read");
+      return (FK_EINVAL);
+    }
+  fk_synth_spec sp;
+  sp.seed = seed; sp.genome_len = genome_len; sp.read_len = read_len; sp.err_ppm = err_ppm;
+  const int64_t total = nreads * ((int64_t) read_len + 1);
+  int64_t nb = (total + 255) / 256;
+  if (nb > 65536) nb = 65536;
+  if (nb > 0)
+    { hipLaunchKernelGGL(k_synth, dim3((unsigned) nb), dim3(256), 0, ctx->stream, sp, first_read,
+                         nreads, (unsigned char *) d_bases);
+      FK_LAUNCH_CHECK(ctx);
+    }
+  return (FK_OK);
+}
+
+extern "C" int fk_synth_reads(fk_ctx *ctx, uint64_t seed, uint64_t genome_len, uint32_t read_len,
+                              uint32_t err_ppm, uint64_t first_read, int64_t nreads, void *d_bases)
+{ if (ctx == NULL || d_bases == NULL || nreads < 0) return (FK_EINVAL);
+  return fkx_synth(ctx, seed, genome_len, read_len, err_ppm, first_read, nreads, d_bases);
+}
+
+// ---- stage interface ----------------------------------------------------------------------------
+extern "C" int fk_split_supermers(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out,
+                                  int64_t cap, int64_t *nsuper, int64_t *ninst,
+                                  int64_t *bucket_counts)
+{ if (ctx == NULL || d_bases == NULL || nbytes < 0) return (FK_EINVAL);
+  if (((uintptr_t) d_bases & 15) != 0)
+    { fk_set_error(ctx, "fk_split_supermers: read buffer must be 16-byte aligned");
+      return (FK_EINVAL);
+    }
+  return fkx_split(ctx, d_bases, nbytes, d_out, cap, nsuper, ninst, bucket_counts);
+}
+
+extern "C" int fk_lsd_sort_records(fk_ctx *ctx, int64_t nelem, void *d_src, void *d_trg, int rsize,
+                                   const int *bytes, void **result)
+{ if (ctx == NULL || bytes == NULL || result == NULL || nelem < 0) return (FK_EINVAL);
+  int nb = 0;
+  while (bytes[nb] >= 0)
+    nb += 1;
+  return fkx_lsd_sort(ctx, nelem, d_src, d_trg, rsize, bytes, nb, result);
+}
+
+extern "C" int fk_msd_sort_records(fk_ctx *ctx, void *d_array, void *d_tmp, int64_t nelem, int rsize,
+                                   int ksize, void **result)
+{ if (ctx == NULL || result == NULL || nelem < 0 || ksize < 0 || ksize > rsize || ksize > 60)
+    return (FK_EINVAL);
+  int bytes[64];
+  for (int i = 0; i < ksize; i++)
+    bytes[i] = ksize - 1 - i;      // least significant key byte first
+  return fkx_lsd_sort(ctx, nelem, d_array, d_tmp, rsize, bytes, ksize, result);
+}
+
+extern "C" int fk_expand_kmers(fk_ctx *ctx, const void *d_smers, int64_t nsuper, void *d_out,
+                               int64_t cap, int64_t *nweighted, int64_t *ndistinct,
+                               int64_t *overflow)
+{ int64_t a, b, c;
+  if (ctx == NULL || nsuper < 0) return (FK_EINVAL);
+  return fkx_expand(ctx, d_smers, nsuper, d_out, cap, nweighted ? nweighted : &a,
+                    ndistinct ? ndistinct : &b, overflow ? overflow : &c);
+}
+
+extern "C" int fk_count_kmers(fk_ctx *ctx, const void *d_kmers, int64_t nweighted, int cutoff,
+                              int64_t *hist, int64_t *max_inst, int64_t *ndistinct, void *d_table,
+                              int64_t cap, int64_t *ntable)
+{ if (ctx == NULL || hist == NULL || max_inst == NULL || nweighted < 0) return (FK_EINVAL);
+  return fkx_count(ctx, d_kmers, nweighted, cutoff, hist, max_inst, ndistinct, d_table, cap, ntable);
+}
+
+// ---- streaming interface ------------------------------------------------------------------------
+static int reserve_reads(fk_ctx *ctx, int64_t extra)
+{ const int64_t need = ctx->reads_len + extra + 64;
+  if (need <= ctx->reads_cap)
+    return (FK_OK);
+  int64_t ncap = std::max<int64_t>(need, ctx->reads_cap * 2);
+  ncap = std::max<int64_t>(ncap, 64ll << 20);
+  char *nbuf = NULL;
+  FK_HIP(ctx, hipMalloc((void **) &nbuf, (size_t) ncap));
+  if (ctx->reads_len > 0)
+    { FK_HIP(ctx, hipMemcpyAsync(nbuf, ctx->d_reads, (size_t) ctx->reads_len,
+                                 hipMemcpyDeviceToDevice, ctx->stream));
+      FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+  if (ctx->d_reads != NULL)
+    FK_HIP(ctx, hipFree(ctx->d_reads));
+  ctx->d_reads = nbuf;
+  ctx->reads_cap = ncap;
+  return (FK_OK);
+}
+
+extern "C" int fk_push_block(fk_ctx *ctx, const char *bases, const int32_t *boff, int nreads,
+                             int rem, int tid)
+{ (void) rem; (void) tid;
+  if (ctx == NULL || bases == NULL || boff == NULL || nreads < 0) return (FK_EINVAL);
+  if (nreads == 0)
+    return (FK_OK);
+  const int64_t len = (int64_t) boff[nreads] - boff[0];
+  int rc = FK_OK;
+  pthread_mutex_lock((pthread_mutex_t *) ctx->push_lock);
+  do
+    { hipSetDevice(ctx->device);
+      if ((rc = reserve_reads(ctx, len)) != FK_OK)
+        break;
+      const int si = ctx->stage_idx;
+      if (ctx->stage_cap < len)
+        { for (int i = 0; i < 2; i++)
+            { if (ctx->h_stage[i])
+                { hipEventSynchronize(ctx->stage_ev[i]);
+                  hipHostFree(ctx->h_stage[i]);
+                  ctx->h_stage[i] = NULL;
+                }
+            }
+          ctx->stage_cap = std::max<int64_t>(len, 4ll << 20);
+          for (int i = 0; i < 2; i++)
+            if (hipHostMalloc((void **) &ctx->h_stage[i], (size_t) ctx->stage_cap,
+                              hipHostMallocDefault) != hipSuccess)
+              { fk_set_error(ctx, "fk_push_block: cannot allocate pinned staging");
+                rc = FK_ENOMEM;
+              }
+          if (rc != FK_OK)
+            break;
+        }
+      if (hipEventSynchronize(ctx->stage_ev[si]) != hipSuccess)
+        { rc = FK_EHIP; break; }
+      char *st = ctx->h_stage[si];
+      memcpy(st, bases + boff[0], (size_t) len);
+      if (ctx->prm.bc_prefix > 0)           // -bc: the skipped prefix can never be inside a k-mer
+        for (int i = 0; i < nreads; i++)
+          { const int64_t o = boff[i] - boff[0];
+            const int64_t e = boff[i + 1] - boff[0] - 1;
+            for (int64_t j = o; j < e && j < o + ctx->prm.bc_prefix; j++)
+              st[j] = 0;
+          }
+      if (hipMemcpyAsync(ctx->d_reads + ctx->reads_len, st, (size_t) len, hipMemcpyHostToDevice,
+                         ctx->stream) != hipSuccess
+          || hipEventRecord(ctx->stage_ev[si], ctx->stream) != hipSuccess)
+        { fk_set_error(ctx, "fk_push_block: host to device copy failed");
+          rc = FK_EHIP;
+          break;
+        }
+      ctx->reads_len += len;
+      ctx->stage_idx ^= 1;
+    }
+  while (0);
+  pthread_mutex_unlock((pthread_mutex_t *) ctx->push_lock);
+  return (rc);
+}
+
+extern "C" int fk_push_device(fk_ctx *ctx, const void *d_bases, int64_t nbytes)
+{ if (ctx == NULL || d_bases == NULL || nbytes < 0) return (FK_EINVAL);
+  if (ctx->prm.bc_prefix > 0)
+    { fk_set_error(ctx, "fk_push_device: -bc needs read offsets; use fk_push_block");
+      return (FK_EUNSUPPORTED);
+    }
+  int rc;
+  pthread_mutex_lock((pthread_mutex_t *) ctx->push_lock);
+  if ((rc = reserve_reads(ctx, nbytes + 1)) == FK_OK)
+    { if (hipMemcpyAsync(ctx->d_reads + ctx->reads_len, d_bases, (size_t) nbytes,
+                         hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess
+          || hipMemsetAsync(ctx->d_reads + ctx->reads_len + nbytes, 0, 1, ctx->stream) != hipSuccess)
+        { fk_set_error(ctx, "fk_push_device: device copy failed");
+          rc = FK_EHIP;
+        }
+      else
+        ctx->reads_len += nbytes + 1;
+    }
+  pthread_mutex_unlock((pthread_mutex_t *) ctx->push_lock);
+  return (rc);
+}
+
+// ---- whole path: split -> sort -> expand -> sort -> count ----------------------------------------
+struct DevBuf
+{ void *p;
+  DevBuf() : p(NULL) {}
+  ~DevBuf() { if (p) hipFree(p); }
+};
+
+static double ms_between(hipEvent_t a, hipEvent_t b)
+{ float ms = 0.f;
+  hipEventElapsedTime(&ms, a, b);
+  return (double) ms;
+}
+
+int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, fk_result *res,
+                 bool fetch_table)
+{ const fk_widths &w = ctx->wid;
+  hipStream_t s = ctx->stream;
+  hipEvent_t ev[6];
+  int rc = FK_OK;
+
+  memset(res, 0, sizeof(*res));
+  for (int i = 0; i < 6; i++)
+    if (hipEventCreate(&ev[i]) != hipSuccess)
+      { fk_set_error(ctx, "fk_finish: cannot create events");
+        return (FK_EHIP);
+      }
+  do
+    { DevBuf sm_a, sm_b, km_a, km_b, tab;
+      int64_t ns = 0, ni = 0;
+
+      hipEventRecord(ev[0], s);
+      // split (count, then emit)
+      if ((rc = fkx_split(ctx, d_reads, nbytes, NULL, 0, &ns, &ni, NULL)) != FK_OK) break;
+      res->nsuper = ns;
+      res->ninst = ni;
+      if (ns > 0)
+        { if (hipMalloc(&sm_a.p, (size_t) ns * w.smer_stride) != hipSuccess
+              || hipMalloc(&sm_b.p, (size_t) ns * w.smer_stride) != hipSuccess)
+            { fk_set_error(ctx, "fk_finish: out of HBM for %lld super-mers", (long long) ns);
+              rc = FK_ENOMEM; break;
+            }
+          if ((rc = fkx_split(ctx, d_reads, nbytes, sm_a.p, ns, &ns, &ni, NULL)) != FK_OK) break;
+        }
+      hipEventRecord(ev[1], s);
+
+      // super-mer sort (key = whole record, MSDsort.c:458 called with ksize = SMER_WORD)
+      void *sm_sorted = sm_a.p;
+      { int bytes[64];
+        for (int i = 0; i < w.smer_word; i++)
+          bytes[i] = w.smer_word - 1 - i;
+        if ((rc = fkx_lsd_sort(ctx, ns, sm_a.p, sm_b.p, w.smer_stride, bytes, w.smer_word,
+                               &sm_sorted)) != FK_OK)
+          break;
+      }
+      hipEventRecord(ev[2], s);
+
+      // weighted k-mer list
+      int64_t nw = 0, nd = 0, ovf = 0;
+      if ((rc = fkx_expand(ctx, sm_sorted, ns, NULL, 0, &nw, &nd, &ovf)) != FK_OK) break;
+      res->nweighted = nw;
+      res->ndistinct_super = nd;
+      // the scratch super-mer buffer is no longer needed
+      { void *other = (sm_sorted == sm_a.p) ? sm_b.p : sm_a.p;
+        if (other) hipFree(other);
+        if (sm_sorted == sm_a.p) sm_b.p = NULL; else sm_a.p = NULL;
+      }
+      if (nw > 0)
+        { if (hipMalloc(&km_a.p, (size_t) nw * w.kmer_stride) != hipSuccess)
+            { fk_set_error(ctx, "fk_finish: out of HBM for %lld weighted k-mers", (long long) nw);
+              rc = FK_ENOMEM; break;
+            }
+          if ((rc = fkx_expand(ctx, sm_sorted, ns, km_a.p, nw, &nw, &nd, &ovf)) != FK_OK) break;
+        }
+      if (sm_a.p) { hipFree(sm_a.p); sm_a.p = NULL; }
+      if (sm_b.p) { hipFree(sm_b.p); sm_b.p = NULL; }
+      hipEventRecord(ev[3], s);
+
+      // weighted k-mer sort (key = KMER_BYTES, MSDsort.c:536)
+      void *km_sorted = km_a.p;
+      if (nw > 0)
+        { if (hipMalloc(&km_b.p, (size_t) nw * w.kmer_stride) != hipSuccess)
+            { fk_set_error(ctx, "fk_finish: out of HBM for the k-mer sort buffer");
+              rc = FK_ENOMEM; break;
+            }
+          int bytes[64];
+          for (int i = 0; i < w.kmer_bytes; i++)
+            bytes[i] = w.kmer_bytes - 1 - i;
+          if ((rc = fkx_lsd_sort(ctx, nw, km_a.p, km_b.p, w.kmer_stride, bytes, w.kmer_bytes,
+                                 &km_sorted)) != FK_OK)
+            break;
+          // first-byte census of the weighted k-mers = Kparts (count.c:1527-1535)
+          for (int x = 0; x < 256; x++)
+            res->wfirst[x] = (int64_t) ctx->h_scratch[x];
+        }
+      hipEventRecord(ev[4], s);
+
+      // count + table: the idle half of the k-mer ping-pong pair receives the table
+      int64_t nt = 0, ndk = 0;
+      const int cutoff = ctx->prm.table_cutoff;
+      void *other = (km_sorted == km_a.p) ? km_b.p : km_a.p;
+      if ((rc = fkx_count(ctx, km_sorted, nw, cutoff, res->hist, &res->max_inst, &ndk,
+                          cutoff > 0 ? other : NULL, nw, &nt)) != FK_OK)
+        break;
+      res->max_inst += ovf;                                  // count.c:1551
+      res->ndistinct = ndk;
+      res->ntable = (cutoff > 0) ? nt : 0;
+      if (cutoff > 0 && nt > 0)
+        {
+          if (fetch_table)
+            { const int64_t bytes = nt * w.kmer_word;
+              if (ctx->h_table_cap < bytes)
+                { free(ctx->h_table);
+                  ctx->h_table = (uint8_t *) malloc((size_t) bytes);
+                  ctx->h_table_cap = bytes;
+                  if (ctx->h_table == NULL)
+                    { ctx->h_table_cap = 0; rc = FK_ENOMEM; break; }
+                }
+              if (w.kmer_word == w.kmer_stride)
+                { if (hipMemcpyAsync(ctx->h_table, other, (size_t) bytes, hipMemcpyDeviceToHost, s)
+                      != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+                    { rc = FK_EHIP; break; }
+                }
+              else
+                { uint8_t *tmp = (uint8_t *) malloc((size_t) nt * w.kmer_stride);
+                  if (tmp == NULL) { rc = FK_ENOMEM; break; }
+                  if (hipMemcpyAsync(tmp, other, (size_t) nt * w.kmer_stride, hipMemcpyDeviceToHost,
+                                     s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+                    { free(tmp); rc = FK_EHIP; break; }
+                  for (int64_t i = 0; i < nt; i++)
+                    { memcpy(ctx->h_table + i * w.kmer_word, tmp + i * w.kmer_stride, w.kmer_bytes);
+                      memcpy(ctx->h_table + i * w.kmer_word + w.kmer_bytes,
+                             tmp + i * w.kmer_stride + w.kmer_stride - 2, 2);
+                    }
+                  free(tmp);
+                }
+              res->table = ctx->h_table;
+            }
+        }
+      hipEventRecord(ev[5], s);
+      if (hipStreamSynchronize(s) != hipSuccess) { rc = FK_EHIP; break; }
+      res->ms_split      = ms_between(ev[0], ev[1]);
+      res->ms_sort_super = ms_between(ev[1], ev[2]);
+      res->ms_expand     = ms_between(ev[2], ev[3]);
+      res->ms_sort_kmer  = ms_between(ev[3], ev[4]);
+      res->ms_count      = ms_between(ev[4], ev[5]);
+      res->ms_total      = ms_between(ev[0], ev[5]);
+    }
+  while (0);
+  for (int i = 0; i < 6; i++)
+    hipEventDestroy(ev[i]);
+  if (rc == FK_EHIP && ctx->err[0] == 0)
+    fk_set_error(ctx, "fk_finish: HIP failure: %s", hipGetErrorString(hipGetLastError()));
+  return (rc);
+}
+
+extern "C" int fk_finish(fk_ctx *ctx, fk_result *res)
+{ if (ctx == NULL || res == NULL) return (FK_EINVAL);
+  FK_HIP(ctx, hipSetDevice(ctx->device));
+  FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return fkx_pipeline(ctx, ctx->d_reads, ctx->reads_len, res, true);
+}
+
+/* Same pipeline on a caller-owned device buffer, table left out unless asked (bench path). */
+extern "C" int fk_count_device_reads(fk_ctx *ctx, const void *d_bases, int64_t nbytes, int fetch_table,
+                                     fk_result *res)
+{ if (ctx == NULL || res == NULL || d_bases == NULL) return (FK_EINVAL);
+  if (((uintptr_t) d_bases & 15) != 0)
+    { fk_set_error(ctx, "fk_count_device_reads: read buffer must be 16-byte aligned");
+      return (FK_EINVAL);
+    }
+  FK_HIP(ctx, hipSetDevice(ctx->device));
+  return fkx_pipeline(ctx, d_bases, nbytes, res, fetch_table != 0);
+}
+
+// ---- encodings ----------------------------------------------------------------------------------
+static int write_all(int fd, const void *p, size_t n)
+{ const uint8_t *b = (const uint8_t *) p;
+  while (n > 0)
+    { ssize_t wr = write(fd, b, n);
+      if (wr < 0) return (-1);
+      b += wr; n -= (size_t) wr;
+    }
+  return (0);
+}
+
+// .hist: int k; int 1; int 0x7fff; int64 hist[1]; int64 max_inst; int64 hist[1..0x7fff]
+// (count.c:1893-1910, README.md:936-961)
+extern "C" int fk_write_hist(const fk_result *res, int kmer, const char *path)
+{ if (res == NULL || path == NULL) return (FK_EINVAL);
+  int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+  if (fd < 0)
+    { fk_set_error(NULL, "Cannot open %s for writing", path);
+      return (FK_EINVAL);
+    }
+  int32_t h[3] = { kmer, 1, 0x7fff };
+  int bad = write_all(fd, h, 12) | write_all(fd, &res->hist[1], 8) | write_all(fd, &res->max_inst, 8)
+          | write_all(fd, &res->hist[1], 8 * 0x7fff);
+  close(fd);
+  if (bad)
+    { fk_set_error(NULL, "Cannot write to %s.  Enough disk space?", path);
+      return (FK_EINVAL);
+    }
+  return (FK_OK);
+}
+
+// .ktab stub + hidden parts (table.c:162-342, 485-498, README.md:965-1006).  Part t holds the
+// first-byte range [split[t], split[t+1]) chosen by the reference's rule (MSDsort.c:330-352 over
+// the weighted k-mer first-byte census, count.c:1560-1565).
+extern "C" int fk_write_ktab(const fk_result *res, int kmer, int table_cutoff, int nthreads,
+                             const char *dir, const char *root)
+{ if (res == NULL || dir == NULL || root == NULL || nthreads < 1 || table_cutoff < 1)
+    return (FK_EINVAL);
+  fk_widths w;
+  if (fk_get_widths(kmer, &w) != FK_OK) return (FK_EINVAL);
+  if (res->ntable > 0 && res->table == NULL) return (FK_EINVAL);
+  const int KW = w.kmer_word;
+  int ib;                                                   // count.c:1620-1626
+  if (res->ntable > 0x4000000ll && kmer >= 12) ib = 3;
+  else if (res->ntable >= 0x40000ll && kmer >= 8) ib = 2;
+  else ib = 1;
+
+  int *split = (int *) malloc(sizeof(int) * (nthreads + 1));
+  { int64_t asize = res->nweighted * KW, sum = 0, thr = asize / nthreads;
+    int n = 0, beg = 0;
+    for (int x = 0; x < 256; x++)
+      { sum += res->wfirst[x] * KW;
+        if (sum >= thr && n < nthreads)
+          { split[n++] = beg;
+            thr = (asize * (n + 1)) / nthreads;
+            beg = x + 1;
+          }
+      }
+    while (n < nthreads)
+      split[n++] = 256;
+    split[nthreads] = 256;
+  }
+
+  const int64_t nidx = 1ll << (8 * ib);
+  int64_t *idx = (int64_t *) calloc((size_t) nidx, sizeof(int64_t));
+  char name[4096];
+  int rc = FK_OK;
+  int64_t lo = 0;
+  for (int t = 0; t < nthreads && rc == FK_OK; t++)
+    { int64_t hi = lo;
+      while (hi < res->ntable && res->table[hi * KW] < split[t + 1])
+        hi += 1;
+      const int64_t n = hi - lo;
+      snprintf(name, sizeof(name), "%s/.%s.ktab.%d", dir, root, t + 1);
+      int fd = open(name, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+      if (fd < 0) { rc = FK_EINVAL; break; }
+      const int pw = KW - ib;
+      uint8_t *buf = (uint8_t *) malloc((size_t) (n > 0 ? n : 1) * pw);
+      for (int64_t i = lo; i < hi; i++)
+        { const uint8_t *rec = res->table + i * KW;
+          int64_t pre = 0;
+          for (int b = 0; b < ib; b++)
+            pre = (pre << 8) | rec[b];
+          idx[pre] += 1;
+          memcpy(buf + (i - lo) * pw, rec + ib, pw);
+        }
+      if (write_all(fd, &kmer, 4) | write_all(fd, &n, 8) | write_all(fd, buf, (size_t) n * pw))
+        rc = FK_EINVAL;
+      free(buf);
+      close(fd);
+      lo = hi;
+    }
+  if (rc == FK_OK)
+    { for (int64_t i = 1; i < nidx; i++)
+        idx[i] += idx[i - 1];
+      snprintf(name, sizeof(name), "%s/%s.ktab", dir, root);
+      int fd = open(name, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+      if (fd < 0)
+        rc = FK_EINVAL;
+      else
+        { int32_t h[4] = { kmer, nthreads, table_cutoff, ib };
+          if (write_all(fd, h, 16) | write_all(fd, idx, (size_t) nidx * 8))
+            rc = FK_EINVAL;
+          close(fd);
+        }
+    }
+  if (rc != FK_OK)
+    fk_set_error(NULL, "Cannot write to %s.  Enough disk space?", name);
+  free(idx);
+  free(split);
+  return (rc);
+}

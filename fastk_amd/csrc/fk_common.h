@@ -1,0 +1,138 @@
+// fk_common.h -- shared declarations for the gfx950 k-mer counting library (internal).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/fastk_amd.h"
+
+#define FK_WAVE 64
+
+typedef unsigned long long u64;
+typedef unsigned int       u32;
+
+struct fk_ctx
+{ fk_params  prm;
+  fk_widths  wid;
+  int        device;
+  hipStream_t stream;
+  bool       own_stream;
+  char       err[512];
+
+  // minimizer scheme (device tables)
+  uint16_t  *d_mrank;     // [1024] rank of every 5-mer under the hashed order
+  uint8_t   *d_mbucket;   // [1024] bucket of a minimizer RANK
+  uint8_t    h_mbucket[1024];
+
+  // small device scratch (counters, histograms)
+  u64       *d_scratch;   // 64 KB
+  u64       *h_scratch;   // pinned mirror
+
+  // radix sort workspace
+  u64       *d_digit_hist; // [32*256]
+  u64       *d_status;     // look-back status words
+  int64_t    status_cap;   // in u64 words
+  u32       *d_ticket;     // [64] tile tickets
+  fk_sort_stats sort_stats;
+
+  // streaming interface state
+  char      *d_reads;      // pushed reads (HBM)
+  int64_t    reads_len, reads_cap;
+  char      *h_stage[2];   // pinned staging for fk_push_block
+  int64_t    stage_cap;
+  int        stage_idx;
+  hipEvent_t stage_ev[2];
+  uint8_t   *h_table;      // result table (host)
+  int64_t    h_table_cap;
+  void      *push_lock;    // pthread mutex
+
+  hipEvent_t ev0, ev1;
+};
+
+void fk_set_error(fk_ctx *ctx, const char *fmt, ...);
+
+#define FK_HIP(ctx, call)                                                             \
+  do { hipError_t e_ = (call);                                                        \
+       if (e_ != hipSuccess)                                                          \
+         { fk_set_error(ctx, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),   \
+                        __FILE__, __LINE__);                                          \
+           return (e_ == hipErrorOutOfMemory ? FK_ENOMEM : FK_EHIP);                  \
+         }                                                                            \
+     } while (0)
+
+#define FK_LAUNCH_CHECK(ctx)  FK_HIP(ctx, hipGetLastError())
+
+// stage entry points implemented in the per-stage .hip files (C++ linkage, internal)
+int fkx_lsd_sort(fk_ctx *ctx, int64_t nelem, void *d_src, void *d_trg, int rsize,
+                 const int *bytes, int nbytes, void **result);
+int fkx_split(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int64_t cap,
+              int64_t *nsuper, int64_t *ninst, int64_t *bucket_counts);
+int fkx_expand(fk_ctx *ctx, const void *d_smers, int64_t nsuper, void *d_out, int64_t cap,
+               int64_t *nweighted, int64_t *ndistinct, int64_t *overflow);
+int fkx_count(fk_ctx *ctx, const void *d_kmers, int64_t nweighted, int cutoff,
+              int64_t *hist, int64_t *max_inst, int64_t *ndistinct,
+              void *d_table, int64_t cap, int64_t *ntable);
+int fkx_synth(fk_ctx *ctx, uint64_t seed, uint64_t genome_len, uint32_t read_len,
+              uint32_t err_ppm, uint64_t first_read, int64_t nreads, void *d_bases);
+
+// ---------------------------------------------------------------------------------------
+// device helpers
+
+#ifdef __HIPCC__
+
+__device__ __forceinline__ u32 fk_lane() { return (threadIdx.x & 63u); }
+
+__device__ __forceinline__ u64 fk_lanemask_lt()
+{ u32 l = fk_lane();
+  return (l == 0 ? 0ull : (~0ull >> (64 - l)));
+}
+
+// exclusive scan of one value per thread over a 256-thread block; returns exclusive prefix,
+// *total gets the block sum.  tmp: 8 u32 of LDS.
+template <typename T>
+__device__ __forceinline__ T fk_block_exscan_256(T v, T *tmp, T *total)
+{ const u32 lane = fk_lane();
+  const u32 wave = threadIdx.x >> 6;
+  T x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1)
+    { T y = __shfl_up(x, o, 64);
+      if ((int) lane >= o) x += y;
+    }
+  if (lane == 63) tmp[wave] = x;
+  __syncthreads();
+  T base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 4; w++)
+    { T t = tmp[w];
+      if ((u32) w < wave) base += t;
+      tot += t;
+    }
+  __syncthreads();
+  *total = tot;
+  return (base + x - v);
+}
+
+// exclusive scan of u32 per-tile counts into u64 offsets (single workgroup; one copy per TU)
+static __global__ __launch_bounds__(256) void k_exscan_tiles(const u32 *__restrict__ in, int64_t n,
+                                                      u64 *__restrict__ out, u64 *__restrict__ total)
+{ __shared__ u64 tmp[8];
+  u64 carry = 0;
+  for (int64_t b = 0; b < n; b += 256)
+    { const int64_t i = b + threadIdx.x;
+      const u64 v = (i < n) ? (u64) in[i] : 0ull;
+      u64 tot;
+      const u64 ex = fk_block_exscan_256<u64>(v, tmp, &tot);
+      if (i < n)
+        out[i] = carry + ex;
+      carry += tot;
+    }
+  if (threadIdx.x == 0)
+    *total = carry;
+}
+
+
+#endif

@@ -1,0 +1,378 @@
+// fk_split.hip -- reads -> 2-bit packed, strand-canonical super-mer records, bucketed by minimizer.
+//
+// Replaces Distribute_Block + Stuff_Seq (split.c:1016-1393, 864-989) and the unpacking half,
+// supermer_list_thread (count.c:165-313): the bit-stuffed ".T" spill format only exists to save
+// disk, so the kernel writes the fixed-width records the sort consumes directly.
+//
+// The reference walks every read sequentially with a history-dependent tie rule (strict < on
+// arrival, <= on a forced rescan, split.c:1110,1149,1310).  Which k-mers share a super-mer never
+// changes .hist or the .ktab canonical stream, so the device uses a rule that is a
+// pure function of the window and therefore position-parallel:
+//   * the read buffer is treated as one flat byte string; any byte that is not acgtACGT (read
+//     terminators, N, newlines) invalidates the k-mers that cover it -- exactly the k-mers the
+//     reference skips (split.c:1079, 1124-1128, 1323-1330);
+//   * minimizer of a k-mer = smallest canonical 5-mer of its K-4 5-mer starts under a fixed
+//     pseudo-random order, leftmost on ties (min over packed (rank,position) keys);
+//   * a super-mer = maximal run of consecutive valid k-mers with the same minimizer POSITION, cut
+//     at tile edges; it holds at most K-4 = MAX_SUPER k-mers, so the record widths are FastK's;
+//   * the record is reverse-complemented when the minimizer lies on the - strand (split.c:1281),
+//     so the two strands of a locus give byte-identical records;
+//   * bucket = f(minimizer value): equal canonical k-mers always share a bucket.
+#include "fk_common.h"
+
+#define SP_THREADS 256
+#define SP_CH      16                      // k-mer starts per thread
+#define SP_TILE    (SP_THREADS * SP_CH)    // 4096 k-mer starts per workgroup
+#define SP_MAXK    128
+#define SP_WORDS   (SP_TILE / 16 + SP_MAXK / 16 + 2)   // packed words incl. halo and guard
+#define SP_KEYS    (SP_TILE + SP_MAXK)
+
+struct SplitArgs
+{ const unsigned char *bases;
+  int64_t   nbytes;
+  int       kmer;
+  int       smer_bytes;
+  int       sww;            // record stride in dwords
+  int       nbuckets;
+  const uint16_t *mtab;     // [1024] (canonical rank << 1) | flip
+  const uint8_t  *mbucket;  // [1024] bucket of a canonical rank
+  u64      *counts;         // [nbuckets] records per bucket (count mode)  + [256] = instances
+  u64      *cursor;         // [nbuckets] running write cursors (emit mode), pre-set to bucket bases
+  u32      *out;
+  int64_t   cap;
+  u32      *overflowed;
+};
+
+__device__ __forceinline__ u32 sp_window(const u32 *arr, int off)
+{ // 16 bases (32 bits) starting at base offset `off` of an MSB-first packed array
+  const u32 hi = arr[off >> 4];
+  const u32 lo = arr[(off >> 4) + 1];
+  const int sh = 2 * (off & 15);
+  return (sh == 0) ? hi : ((hi << sh) | (lo >> (32 - sh)));
+}
+
+template <bool EMIT>
+__global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
+{ __shared__ u32      fwd[SP_WORDS];
+  __shared__ u32      rcw[SP_WORDS];
+  __shared__ uint16_t inv16[SP_WORDS];
+  __shared__ uint16_t wpre[SP_WORDS];
+  __shared__ u32      keys[SP_KEYS];
+  __shared__ uint16_t mtab[1024];
+  __shared__ uint8_t  mbucket[1024];
+  __shared__ u32      lastkey[SP_THREADS];
+  __shared__ uint16_t sbits[SP_THREADS + 16];
+  __shared__ uint16_t vbits[SP_THREADS + 16];
+  __shared__ u32      slist[EMIT ? SP_TILE : 1];
+  __shared__ u32      bcnt[256];
+  __shared__ u32      bcnt2[256];
+  __shared__ u64      bbase[256];
+  __shared__ u32      tmp32[8];
+
+  const int     tid = threadIdx.x;
+  const int     K   = a.kmer;
+  const int     W   = K - 4;                       // 5-mer starts per k-mer = MAX_SUPER
+  const int64_t t0  = (int64_t) blockIdx.x * SP_TILE;
+  const int     nw  = SP_TILE / 16 + (K + 14) / 16; // words that hold real bases
+  const int     R   = nw * 16;                     // bases covered by the packed arrays
+
+  for (int i = tid; i < 1024; i += SP_THREADS)
+    { mtab[i]    = a.mtab[i];
+      mbucket[i] = a.mbucket[i];
+    }
+  bcnt[tid] = 0;
+  bcnt2[tid] = 0;
+
+  // ---- 1. ASCII -> 2-bit codes (MSB first) + invalid masks -------------------------------
+  for (int q = tid; q < SP_WORDS; q += SP_THREADS)
+    { u32 word = 0, bad = 0xffffu;
+      if (q < nw)
+        { const int64_t g = t0 + (int64_t) q * 16;
+          unsigned char c[16];
+          if (g + 16 <= a.nbytes)
+            { const uint4 v = *(const uint4 *) (a.bases + g);
+              *(uint4 *) c = v;
+            }
+          else
+            {
+#pragma unroll
+              for (int j = 0; j < 16; j++)
+                c[j] = (g + j < a.nbytes) ? a.bases[g + j] : 0;
+            }
+          bad = 0;
+#pragma unroll
+          for (int j = 0; j < 16; j++)
+            { const u32 ch = c[j];
+              const u32 x  = (ch >> 1) & 3u;
+              const u32 u  = ch & 0xDFu;
+              const bool ok = (u == 0x41u) | (u == 0x43u) | (u == 0x47u) | (u == 0x54u);
+              word |= (x ^ (x >> 1)) << (30 - 2 * j);
+              bad  |= (ok ? 0u : 1u) << j;
+            }
+        }
+      fwd[q]   = word;
+      inv16[q] = (uint16_t) bad;
+    }
+  __syncthreads();
+
+  // reverse-complement strand, same packing: rc base p' = R-1-p
+  for (int q = tid; q < SP_WORDS; q += SP_THREADS)
+    { u32 x = 0;
+      if (q < nw)
+        { const u32 y = __builtin_bitreverse32(fwd[nw - 1 - q]);
+          x = ~(((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1));
+        }
+      rcw[q] = x;
+    }
+  // exclusive count of invalid bases before each packed word
+  { u32 tot;
+    const u32 mine = __popc((u32) inv16[tid]);
+    const u32 ex   = fk_block_exscan_256<u32>(mine, tmp32, &tot);
+    wpre[tid] = (uint16_t) ex;
+    if (tid == 0)
+      { u32 run = tot;
+        for (int q = SP_THREADS; q < SP_WORDS; q++)
+          { wpre[q] = (uint16_t) run;
+            run += __popc((u32) inv16[q]);
+          }
+      }
+  }
+  // ---- 2. canonical 5-mer keys: (rank << 14 | position) << 1 | flip ------------------------
+  for (int j = tid; j < SP_TILE + W; j += SP_THREADS)
+    { const u32 v = sp_window(fwd, j) >> 22;
+      const u32 m = mtab[v];
+      keys[j] = (((m >> 1) << 14) | (u32) j) << 1 | (m & 1u);
+    }
+  __syncthreads();
+
+  // ---- 3. sliding-window minimum for the thread's 16 k-mer starts ------------------------
+  const int i0 = tid * SP_CH;
+  u32 mk[SP_CH];
+  if (W >= SP_CH)
+    { u32 core = 0xffffffffu;
+      for (int j = i0 + SP_CH - 1; j <= i0 + W - 1; j++)
+        core = min(core, keys[j]);
+      u32 run = 0xffffffffu;
+      mk[SP_CH - 1] = core;
+#pragma unroll
+      for (int c = SP_CH - 2; c >= 0; c--)
+        { run = min(run, keys[i0 + c]);
+          mk[c] = min(core, run);
+        }
+      run = 0xffffffffu;
+#pragma unroll
+      for (int c = 1; c < SP_CH; c++)
+        { run = min(run, keys[i0 + W - 1 + c]);
+          mk[c] = min(mk[c], run);
+        }
+    }
+  else
+    {
+#pragma unroll
+      for (int c = 0; c < SP_CH; c++)
+        { u32 m = 0xffffffffu;
+          for (int j = 0; j < W; j++)
+            m = min(m, keys[i0 + c + j]);
+          mk[c] = m;
+        }
+    }
+
+  // ---- 4. validity of each k-mer: no invalid base in [i, i+K) ------------------------------
+  u32 vmask = 0;
+#pragma unroll
+  for (int c = 0; c < SP_CH; c++)
+    { const int i = i0 + c;
+      const int e = i + K;
+      const u32 ci = wpre[i >> 4] + __popc((u32) inv16[i >> 4] & ((1u << (i & 15)) - 1u));
+      const u32 ce = wpre[e >> 4] + __popc((u32) inv16[e >> 4] & ((1u << (e & 15)) - 1u));
+      vmask |= (ci == ce ? 1u : 0u) << c;
+    }
+  lastkey[tid] = mk[SP_CH - 1];
+  vbits[tid]   = (uint16_t) vmask;
+  if (tid < 16)
+    { vbits[SP_THREADS + tid] = 0;        // nothing is valid past the tile
+      sbits[SP_THREADS + tid] = 0;
+    }
+  __syncthreads();
+
+  // ---- 5. super-mer starts: valid and (first of tile | previous invalid | new minimizer) ---
+  u32 smask = 0;
+  { u32  pk = (tid > 0) ? lastkey[tid - 1] : 0xffffffffu;
+    bool pv = (tid > 0) ? ((vbits[tid - 1] >> (SP_CH - 1)) & 1u) : false;
+#pragma unroll
+    for (int c = 0; c < SP_CH; c++)
+      { const bool v = (vmask >> c) & 1u;
+        if (v && (!pv || (mk[c] >> 1) != (pk >> 1)))
+          smask |= 1u << c;
+        pv = v;
+        pk = mk[c];
+      }
+  }
+  sbits[tid] = (uint16_t) smask;
+
+  u32 nstart_total;
+  const u32 sidx0 = fk_block_exscan_256<u32>(__popc(smask), tmp32, &nstart_total);
+  // (the scan's barriers also publish sbits)
+
+  if (tid == 0)
+    { u32 inst = 0;
+      (void) inst;
+    }
+  { // instances = valid k-mers in the tile
+    u32 tot;
+    (void) fk_block_exscan_256<u32>(__popc(vmask), tmp32, &tot);
+    if (tid == 0 && tot != 0)
+      atomicAdd(&a.counts[256], (u64) tot);
+  }
+
+  // ---- 6. one entry per super-mer: position, length, flip, rank ---------------------------
+  { u32 k = sidx0;
+#pragma unroll
+    for (int c = 0; c < SP_CH; c++)
+      if ((smask >> c) & 1u)
+        { const int i = i0 + c;
+          // next boundary (start or invalid) after i; bit SP_TILE is a sentinel (all invalid)
+          int n = 0;
+          { int p = i + 1;
+            while (true)
+              { const int q = p >> 4;
+                u32 bnd = ((u32) sbits[q] | (~(u32) vbits[q] & 0xffffu)) >> (p & 15);
+                if (bnd != 0)
+                  { n = p + (__ffs(bnd) - 1) - i;
+                    break;
+                  }
+                p = (q + 1) << 4;
+              }
+          }
+          const u32 key  = mk[c];
+          const u32 rank = key >> 15;
+          const u32 b    = mbucket[rank];
+          atomicAdd(&bcnt[b], 1u);
+          if (EMIT)
+            slist[k] = (u32) i | ((key & 1u) << 12) | ((u32) n << 13) | (rank << 20);
+          k += 1;
+        }
+  }
+  __syncthreads();
+
+  if (!EMIT)
+    { if (tid < a.nbuckets && bcnt[tid] != 0)
+        atomicAdd(&a.counts[tid], (u64) bcnt[tid]);
+      return;
+    }
+
+  if (tid < a.nbuckets && bcnt[tid] != 0)
+    bbase[tid] = atomicAdd(&a.cursor[tid], (u64) bcnt[tid]);
+  __syncthreads();
+
+  // ---- 7. build and write the records -----------------------------------------------------
+  const int sww = a.sww;
+  const int lenw = a.smer_bytes >> 2;
+  const int lensh = 24 - 8 * (a.smer_bytes & 3);
+  for (u32 s = tid; s < nstart_total; s += SP_THREADS)
+    { const u32 e    = slist[s];
+      const int i    = e & 0xfffu;
+      const u32 flip = (e >> 12) & 1u;
+      const int n    = (e >> 13) & 0x7fu;
+      const u32 rank = e >> 20;
+      const u32 b    = mbucket[rank];
+      const u64 slot = bbase[b] + atomicAdd(&bcnt2[b], 1u);
+      if ((int64_t) slot >= a.cap)
+        { *a.overflowed = 1;
+          continue;
+        }
+      const int  L   = n - 1 + K;
+      const u32 *arr = flip ? rcw : fwd;
+      const int  st  = flip ? (R - (i + L)) : i;
+      u32 *dst = a.out + slot * sww;
+      for (int q = 0; q < sww; q++)
+        { u32 x = 0;
+          const int rem = L - 16 * q;
+          if (rem > 0)
+            { x = sp_window(arr, st + 16 * q);
+              if (rem < 16)
+                x &= ~(0xffffffffu >> (2 * rem));
+            }
+          if (q == lenw)
+            x |= ((u32) (n - 1)) << lensh;
+          dst[q] = __builtin_bswap32(x);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+int fkx_split(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int64_t cap,
+              int64_t *nsuper, int64_t *ninst, int64_t *bucket_counts)
+{ hipStream_t s = ctx->stream;
+  const int   K = ctx->prm.kmer;
+  const int   nb = ctx->prm.nbuckets;
+  u64 *d_counts = ctx->d_scratch;            // [0..255] buckets, [256] instances
+  u64 *d_cursor = ctx->d_scratch + 512;      // [0..255]
+  u32 *d_ovf    = (u32 *) (ctx->d_scratch + 1024);
+
+  if (K < 8 || K > SP_MAXK)
+    { fk_set_error(ctx, "k = %d outside the supported range [8,%d]", K, SP_MAXK);
+      return (FK_EUNSUPPORTED);
+    }
+  if (nsuper) *nsuper = 0;
+  if (ninst) *ninst = 0;
+  if (bucket_counts)
+    for (int b = 0; b < nb; b++)
+      bucket_counts[b] = 0;
+  if (nbytes < K)
+    return (FK_OK);
+
+  SplitArgs a;
+  a.bases = (const unsigned char *) d_bases;
+  a.nbytes = nbytes;
+  a.kmer = K;
+  a.smer_bytes = ctx->wid.smer_bytes;
+  a.sww = ctx->wid.smer_stride / 4;
+  a.nbuckets = nb;
+  a.mtab = ctx->d_mrank;
+  a.mbucket = ctx->d_mbucket;
+  a.counts = d_counts;
+  a.cursor = d_cursor;
+  a.out = (u32 *) d_out;
+  a.cap = cap;
+  a.overflowed = d_ovf;
+
+  const int64_t nstarts = nbytes - K + 1;
+  const int64_t ntiles  = (nstarts + SP_TILE - 1) / SP_TILE;
+
+  FK_HIP(ctx, hipMemsetAsync(ctx->d_scratch, 0, 1032 * sizeof(u64), s));
+  hipLaunchKernelGGL(k_split<false>, dim3((unsigned) ntiles), dim3(SP_THREADS), 0, s, a);
+  FK_LAUNCH_CHECK(ctx);
+  FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch, d_counts, 257 * sizeof(u64), hipMemcpyDeviceToHost, s));
+  FK_HIP(ctx, hipStreamSynchronize(s));
+
+  int64_t tot = 0;
+  u64     base[256];
+  for (int b = 0; b < nb; b++)
+    { base[b] = (u64) tot;
+      tot += (int64_t) ctx->h_scratch[b];
+      if (bucket_counts)
+        bucket_counts[b] = (int64_t) ctx->h_scratch[b];
+    }
+  if (nsuper) *nsuper = tot;
+  if (ninst) *ninst = (int64_t) ctx->h_scratch[256];
+  if (cap == 0 || d_out == NULL)
+    return (FK_OK);
+  if (cap < tot)
+    { fk_set_error(ctx, "super-mer buffer too small: %lld records needed, %lld given",
+                   (long long) tot, (long long) cap);
+      return (FK_EINVAL);
+    }
+
+  FK_HIP(ctx, hipMemcpyAsync(d_cursor, base, nb * sizeof(u64), hipMemcpyHostToDevice, s));
+  FK_HIP(ctx, hipStreamSynchronize(s));      // base[] lives on this stack frame
+  hipLaunchKernelGGL(k_split<true>, dim3((unsigned) ntiles), dim3(SP_THREADS), 0, s, a);
+  FK_LAUNCH_CHECK(ctx);
+  FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch, d_ovf, sizeof(u32), hipMemcpyDeviceToHost, s));
+  FK_HIP(ctx, hipStreamSynchronize(s));
+  if (*(u32 *) ctx->h_scratch != 0)
+    { fk_set_error(ctx, "internal: super-mer emit overflowed its buffer");
+      return (FK_EHIP);
+    }
+  return (FK_OK);
+}

@@ -1,0 +1,189 @@
+/* fastk_amd.h -- C-ABI of the MI355X (gfx950) k-mer counting engine.
+ *
+ * Drop-in boundary for ONE path of FastK: split -> super-mer sort -> weighted k-mer list ->
+ * k-mer sort -> count -> .hist / .ktab payloads.  Every entry point below replaces a stage
+ * interface of the reference (file:line into thegenemyers/FASTK) and is what a maintainer
+ * would bind from FastK's C host code.  Plain pointers and sizes only;
+ * all functions return 0 on success or a negative FK_E* code, and fk_last_error() gives
+ * the text the host prints before Clean_Exit(1) (FastK.c:181-221 convention).
+ *
+ * Pointers named d_* are device (HBM) pointers; everything else is host memory.
+ * All byte layouts are the reference's (little-endian host, count.c:179-185):
+ *   super-mer record  [SMER_BYTES 2-bit bases, 4/byte MSB first, zero padded][SLEN_BYTES n-1]
+ *                     (count.c:226-251), device stride fk_widths.smer_stride (rounded to 4)
+ *   k-mer record      [KMER_BYTES canonical 2-bit bases][pad][uint16 weight/count]
+ *                     (count.c:497-512), device stride fk_widths.kmer_stride (rounded to 4)
+ *   table entry       [KMER_BYTES][uint16 count], TMER_WORD bytes, host side (count.c:564-616)
+ */
+#ifndef FASTK_AMD_H
+#define FASTK_AMD_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FK_OK            0
+#define FK_EINVAL       -1   /* bad argument                                   */
+#define FK_ENOMEM       -2   /* host or HBM allocation failed                  */
+#define FK_EHIP         -3   /* a HIP runtime call or kernel failed            */
+#define FK_EUNSUPPORTED -4   /* legal in FastK but not built yet (see DESIGN)  */
+#define FK_ENODEVICE    -5   /* no gfx950 device visible                       */
+#define FK_ESTATE       -6   /* call order violated                            */
+
+#define FK_HIST_BINS  0x8000 /* count.c:1205 counts[0x8000]                    */
+
+typedef struct fk_ctx fk_ctx;
+
+/* Record widths implied by k (FastK.c:417,446-468 with PAD_LEN = 5: MAX_SUPER = k-4). */
+typedef struct
+  { int kmer;
+    int min_len;       /* minimizer length (5, split.c:56)                    */
+    int max_super;     /* MAX_SUPER                                           */
+    int smer_bytes;    /* SMER_BYTES                                          */
+    int slen_bytes;    /* SLEN_BYTES                                          */
+    int smer_word;     /* SMER_WORD  (reference record width, bytes)          */
+    int kmer_bytes;    /* KMER_BYTES                                          */
+    int kmer_word;     /* KMER_WORD = TMER_WORD (reference width, bytes)      */
+    int smer_stride;   /* device stride of a super-mer record (multiple of 4) */
+    int kmer_stride;   /* device stride of a k-mer record (multiple of 4)     */
+  } fk_widths;
+
+int fk_get_widths(int kmer, fk_widths *w);
+
+/* Options that exist on FastK's command line (FastK.c:34-37,250-319). */
+typedef struct
+  { int     kmer;          /* -k (default 40)                                            */
+    int     table_cutoff;  /* -t<n>: 0 = no table, else keep k-mers with count >= n      */
+    int     nthreads;      /* -T: number of .ktab parts / first-byte ranges in outputs   */
+    int     bc_prefix;     /* -bc<n>: ignore this many leading bases of every read       */
+    int     device;        /* HIP device ordinal for this process (one process per GPU)  */
+    int     nbuckets;      /* super-mer buckets for sharding (1 = no sharding), <= 256   */
+    int64_t hbm_budget;    /* bytes of HBM the context may use, 0 = 80% of free memory   */
+  } fk_params;
+
+void fk_default_params(fk_params *p);
+
+/* Context: owns the HIP stream, staging buffers and all HBM arenas.
+   Replaces the globals of FastK.h:34-83 plus the SORT_PATH temp files (split.c:1454). */
+int         fk_create(const fk_params *p, fk_ctx **ctx);
+void        fk_destroy(fk_ctx *ctx);
+const char *fk_last_error(const fk_ctx *ctx);   /* ctx may be NULL: last global error */
+
+/* Use an externally owned HIP stream (e.g. torch's current stream) for all launches. */
+int fk_set_stream(fk_ctx *ctx, void *hip_stream);
+int fk_synchronize(fk_ctx *ctx);
+
+/* ---- whole-path streaming interface ------------------------------------------------------
+ * fk_push_block replaces  void Distribute_Block(DATA_BLOCK *block, int tid)  (FastK.h:123,
+ * split.c:1016): same data as DATA_BLOCK (FastK.h:87-98): nreads 0-terminated reads
+ * concatenated in bases, read i at bases+boff[i], boff[nreads] = total bytes; rem>0 means the
+ * last read continues in the next block with a K-1 base overlap (io.c:557-570).
+ * Thread-safe for distinct tid (split.c:1007-1014). */
+int fk_push_block(fk_ctx *ctx, const char *bases, const int32_t *boff, int nreads, int rem,
+                  int tid);
+
+/* Same, for reads already resident in HBM (any byte that is not acgtACGT separates reads). */
+int fk_push_device(fk_ctx *ctx, const void *d_bases, int64_t nbytes);
+
+typedef struct
+  { int64_t  hist[FK_HIST_BINS]; /* hist[c] = # distinct k-mers with count c (c>=1), count.c:1543-1553 */
+    int64_t  max_inst;           /* instances of k-mers with count >= 0x7fff  (.hist ihighcnt)        */
+    int64_t  ninst;              /* valid k-mer instances                 (split.c:1638 "Sum")        */
+    int64_t  nsuper;             /* super-mers                                                         */
+    int64_t  ndistinct_super;    /* distinct super-mers                                                */
+    int64_t  nweighted;          /* weighted k-mers            (count.c:1823 "wgt'd k-mers")           */
+    int64_t  ndistinct;          /* distinct k-mers                                                    */
+    int64_t  ntable;             /* table entries (count >= table_cutoff)                              */
+    const uint8_t *table;        /* host, ntable entries of kmer_word bytes, sorted; owned by ctx      */
+    int64_t  wfirst[256];        /* weighted k-mers per canonical first byte (Kparts, count.c:1527)    */
+    double   ms_split, ms_sort_super, ms_expand, ms_sort_kmer, ms_count, ms_total;  /* device time   */
+  } fk_result;
+
+/* Replaces Sorting() + the merge of Merge_Tables() (count.c:1202, table.c:346): runs the
+   device pipeline over everything pushed so far.  table memory stays valid until
+   fk_destroy or the next fk_finish. */
+int fk_finish(fk_ctx *ctx, fk_result *res);
+
+/* The same pipeline on reads that are already resident in HBM and stay owned by the caller
+   (16-byte aligned; any byte that is not acgtACGT separates reads).  fetch_table = 0 leaves
+   the table in HBM and only reports ntable (bench path: nothing crosses PCIe but counters). */
+int fk_count_device_reads(fk_ctx *ctx, const void *d_bases, int64_t nbytes, int fetch_table,
+                          fk_result *res);
+
+/* .hist / .ktab writers with the reference encodings (count.c:1893-1910, table.c:162-342,
+   485-498).  Part boundaries follow the reference's rule (MSDsort.c:330-352 on wfirst). */
+int fk_write_hist(const fk_result *res, int kmer, const char *path);
+int fk_write_ktab(const fk_result *res, int kmer, int table_cutoff, int nthreads,
+                  const char *dir, const char *root);
+
+/* ---- stage interface on device buffers ---------------------------------------------------*/
+
+/* Split: reads -> super-mer records.  Replaces Distribute_Block + supermer_list_thread
+   (split.c:1016-1393, count.c:165-313).  d_out must hold cap records of smer_stride bytes;
+   when nbuckets > 1 records are grouped by bucket and counts[b] receives each bucket's size
+   (bucket = f(canonical minimizer), so equal k-mers share a bucket, FastK.h:3-7).
+   cap == 0 only counts.  *nsuper is the total number of records needed. */
+int fk_split_supermers(fk_ctx *ctx, const void *d_bases, int64_t nbytes,
+                       void *d_out, int64_t cap, int64_t *nsuper, int64_t *ninst,
+                       int64_t *bucket_counts);
+
+/* Stable LSD byte radix sort; same contract as
+     void *LSD_Sort(int64 nelem, void *src, void *trg, int rsize, int *bytes)   (FastK.h:154,
+   LSDsort.c:115): bytes[] is a -1 terminated list, least significant first; *result receives
+   whichever of d_src/d_trg holds the sorted records.  rsize must be a multiple of 4. */
+int fk_lsd_sort_records(fk_ctx *ctx, int64_t nelem, void *d_src, void *d_trg, int rsize,
+                        const int *bytes, void **result);
+
+/* Sort records on key bytes [0,ksize), most significant first; same result as
+     Supermer_Sort / Weighted_Kmer_Sort(array,nelem,rsize,ksize,...)   (FastK.h:145-151,
+   MSDsort.c:458,536) without the run-head byte trick: the sorted records end up in
+   *result (d_array or d_tmp).  rsize must be a multiple of 4. */
+int fk_msd_sort_records(fk_ctx *ctx, void *d_array, void *d_tmp, int64_t nelem, int rsize,
+                        int ksize, void **result);
+
+/* Weighted k-mer list from SORTED super-mers.  Replaces count_smers + kmer_list_thread
+   (MSDsort.c:381-456, count.c:339-542).  Call with d_out == NULL to size: *nweighted and
+   *ndistinct are set.  *overflow as count.c:455-458. */
+int fk_expand_kmers(fk_ctx *ctx, const void *d_smers, int64_t nsuper, void *d_out, int64_t cap,
+                    int64_t *nweighted, int64_t *ndistinct, int64_t *overflow);
+
+/* Count SORTED weighted k-mers.  Replaces hist_kmers + table_write_thread
+   (MSDsort.c:491-509, count.c:564-616).  hist (host, FK_HIST_BINS) and *max_inst are
+   ACCUMULATED; d_table (may be NULL when cutoff == 0) receives *ntable records of
+   kmer_stride bytes [KMER_BYTES][pad][u16 count] with count >= cutoff, in sorted order. */
+int fk_count_kmers(fk_ctx *ctx, const void *d_kmers, int64_t nweighted, int cutoff,
+                   int64_t *hist, int64_t *max_inst, int64_t *ndistinct,
+                   void *d_table, int64_t cap, int64_t *ntable);
+
+/* ---- utilities ---------------------------------------------------------------------------*/
+
+/* Fill d_bases with synthetic reads first_read .. first_read+nreads-1 of include/fk_synth.h,
+   each followed by a 0 byte (DATA_BLOCK layout): nreads*(read_len+1) bytes. */
+int fk_synth_reads(fk_ctx *ctx, uint64_t seed, uint64_t genome_len, uint32_t read_len,
+                   uint32_t err_ppm, uint64_t first_read, int64_t nreads, void *d_bases);
+
+int   fk_device_alloc(fk_ctx *ctx, int64_t nbytes, void **d_ptr);
+int   fk_device_free(fk_ctx *ctx, void *d_ptr);
+int   fk_copy_to_device(fk_ctx *ctx, void *d_dst, const void *src, int64_t nbytes);
+int   fk_copy_to_host(fk_ctx *ctx, void *dst, const void *d_src, int64_t nbytes);
+
+/* Per-kernel device time of the most recent sort call, for roofline accounting:
+   passes executed, records, record width (reference bytes), total ms over the passes. */
+typedef struct
+  { int     passes;
+    int64_t nelem;
+    int     rsize;
+    double  pass_ms_total;   /* sum of radix-pass kernel durations (HIP events on ctx stream) */
+    double  hist_ms;         /* digit histogram kernel                                         */
+  } fk_sort_stats;
+int fk_get_sort_stats(fk_ctx *ctx, fk_sort_stats *st);
+
+const char *fk_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,225 @@
+"""Parity of the HIP path (through the C-ABI, libfastk_amd.so) against the CPU oracle and the
+golden vectors captured from the reference.  Needs a real MI355X: run with -m gpu."""
+import numpy as np
+import pytest
+
+import fastk_amd
+from oracle import orc
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx40():
+    c = fastk_amd.Context(kmer=40, table_cutoff=1, nthreads=4)
+    yield c
+    c.close()
+
+
+def _pad(recs, stride):
+    """reference-width records -> device stride (k-mer count moves to the last two bytes)."""
+    n, w = recs.shape
+    if w == stride:
+        return np.ascontiguousarray(recs)
+    out = np.zeros((n, stride), dtype=np.uint8)
+    out[:, :w] = recs
+    return out
+
+
+def _pad_kmers(recs, kb, stride):
+    n, w = recs.shape
+    if w == stride:
+        return np.ascontiguousarray(recs)
+    out = np.zeros((n, stride), dtype=np.uint8)
+    out[:, :kb] = recs[:, :kb]
+    out[:, stride - 2:] = recs[:, kb:kb + 2]
+    return out
+
+
+def _unpad_kmers(recs, kb):
+    n, s = recs.shape
+    if s == kb + 2:
+        return recs
+    out = np.zeros((n, kb + 2), dtype=np.uint8)
+    out[:, :kb] = recs[:, :kb]
+    out[:, kb:] = recs[:, s - 2:]
+    return out
+
+
+# ------------------------------------------------------------------------------ radix engine
+
+@pytest.mark.parametrize("rsize,n,seed", [(12, 1000, 1), (12, 300001, 2), (20, 123457, 3),
+                                          (16, 50000, 4), (8, 77777, 5), (28, 40000, 6),
+                                          (4, 100000, 7), (12, 0, 8), (12, 1, 9)])
+def test_lsd_sort_bit_exact(ctx40, rsize, n, seed):
+    rng = np.random.default_rng(seed)
+    recs = rng.integers(0, 256, size=(n, rsize), dtype=np.uint8)
+    if n > 10:
+        recs[:, 1] = rng.integers(0, 3, size=n)      # few-valued digit
+        recs[:, 2] = 7                                # constant digit (pass is skipped)
+        recs[: n // 2] = recs[n // 2: 2 * (n // 2)]   # many duplicates
+    byte_list = list(range(min(rsize, 10) - 1, -1, -1))
+    a = ctx40.alloc(max(recs.nbytes, 16)).upload(recs)
+    b = ctx40.alloc(max(recs.nbytes, 16))
+    res = ctx40.lsd_sort(a.ptr, b.ptr, n, rsize, byte_list)
+    got = a.download(recs.nbytes, ptr=res).reshape(n, rsize)
+    exp = orc.lsd_sort(recs, byte_list)
+    assert np.array_equal(got, exp)
+    a.free(); b.free()
+
+
+def test_lsd_sort_is_stable_on_partial_keys(ctx40):
+    """Sorting on two bytes only must keep the input order of equal keys (LSDsort.c contract)."""
+    rng = np.random.default_rng(11)
+    n, rsize = 200000, 12
+    recs = rng.integers(0, 256, size=(n, rsize), dtype=np.uint8)
+    recs[:, 5] = rng.integers(0, 4, size=n)
+    a = ctx40.alloc(recs.nbytes).upload(recs)
+    b = ctx40.alloc(recs.nbytes)
+    res = ctx40.lsd_sort(a.ptr, b.ptr, n, rsize, [5, 0])
+    got = a.download(recs.nbytes, ptr=res).reshape(n, rsize)
+    assert np.array_equal(got, orc.lsd_sort(recs, [5, 0]))
+    a.free(); b.free()
+
+
+def test_msd_sort_matches_oracle_msd(ctx40):
+    rng = np.random.default_rng(12)
+    n, rsize, ksize = 150000, 20, 20
+    recs = rng.integers(0, 4, size=(n, rsize), dtype=np.uint8)     # heavy ties
+    a = ctx40.alloc(recs.nbytes).upload(recs)
+    b = ctx40.alloc(recs.nbytes)
+    res = ctx40.msd_sort(a.ptr, b.ptr, n, rsize, ksize)
+    got = a.download(recs.nbytes, ptr=res).reshape(n, rsize)
+    assert np.array_equal(got, orc.msd_sort(recs, ksize))
+    a.free(); b.free()
+
+
+# ------------------------------------------------------------------------------ stages
+
+@pytest.mark.parametrize("name", ["edge_k40_t1_T4", "synth_illumina_k40_t1_T4",
+                                  "synth_hifi_k40_t4_T8", "edge_k51_t1_T4", "edge_k21_t2_T3"])
+def test_split_covers_every_kmer_exactly_once(name):
+    """GPU super-mers, finished by the ORACLE's sort/expand/count, must give the reference's
+    histogram and table: every valid k-mer instance is in exactly one well-formed record."""
+    case, bases, boff = util.load_case(name)
+    k = case["k"]
+    with fastk_amd.Context(kmer=k, table_cutoff=case["cutoff"]) as ctx:
+        w = ctx.w
+        rd = ctx.alloc(len(bases) + 64).upload(bases)
+        ns, ni, _ = ctx.split(rd.ptr, len(bases))
+        out = ctx.alloc(max(ns, 1) * w.smer_stride)
+        ns2, ni2, _ = ctx.split(rd.ptr, len(bases), out.ptr, ns)
+        assert (ns2, ni2) == (ns, ni)
+        recs = out.download(ns * w.smer_stride).reshape(ns, w.smer_stride)[:, :w.smer_word]
+    exp = orc.fastk(k, bases, boff, cutoff=case["cutoff"])
+    assert ni == exp.ninst
+    P = orc.params(k)
+    assert (P.smer_word, P.kmer_word) == (w.smer_word, w.kmer_word)
+    lens = recs[:, w.smer_bytes].astype(int) + 1
+    assert lens.sum() == ni and lens.max() <= w.max_super
+    ss = orc.msd_sort(np.ascontiguousarray(recs), P.smer_word)
+    kl, ovf, nd = orc.kmer_list(P, ss)
+    ks = orc.msd_sort(kl, P.kmer_bytes)
+    res = orc.count_sorted(P, ks, case["cutoff"])
+    util.check_against_golden(case, res.hist, res.max_inst + ovf, res.table)
+
+
+@pytest.mark.parametrize("name", ["edge_k40_t1_T4", "synth_tiny_k40_t1_T2", "edge_k51_t1_T4",
+                                  "edge_k21_t2_T3"])
+def test_expand_bit_exact(name):
+    case, bases, boff = util.load_case(name)
+    k = case["k"]
+    P = orc.params(k)
+    smers, _ = orc.distribute(P, bases, boff)
+    ss = orc.msd_sort(smers, P.smer_word)
+    exp, eovf, end = orc.kmer_list(P, ss)
+    with fastk_amd.Context(kmer=k) as ctx:
+        w = ctx.w
+        dev = _pad(ss, w.smer_stride)
+        a = ctx.alloc(max(dev.nbytes, 16)).upload(dev)
+        nw, nd, _ = ctx.expand(a.ptr, len(ss))
+        assert (nw, nd) == (len(exp), end)
+        o = ctx.alloc(max(nw, 1) * w.kmer_stride)
+        nw2, nd2, ovf = ctx.expand(a.ptr, len(ss), o.ptr, nw)
+        got = o.download(nw * w.kmer_stride).reshape(nw, w.kmer_stride)
+    assert ovf == eovf
+    assert np.array_equal(_unpad_kmers(got, w.kmer_bytes), exp)
+
+
+@pytest.mark.parametrize("name", ["edge_k40_t1_T4", "edge_k40_t4_T1", "edge_k51_t1_T4",
+                                  "synth_illumina_k40_t1_T4"])
+def test_count_bit_exact(name):
+    case, bases, boff = util.load_case(name)
+    k, cutoff = case["k"], case["cutoff"]
+    P = orc.params(k)
+    smers, _ = orc.distribute(P, bases, boff)
+    kl, ovf, _ = orc.kmer_list(P, orc.msd_sort(smers, P.smer_word))
+    ks = orc.msd_sort(kl, P.kmer_bytes)
+    with fastk_amd.Context(kmer=k, table_cutoff=cutoff) as ctx:
+        w = ctx.w
+        dev = _pad_kmers(ks, w.kmer_bytes, w.kmer_stride)
+        a = ctx.alloc(dev.nbytes).upload(dev)
+        t = ctx.alloc(dev.nbytes)
+        hist, mi, nd, nt = ctx.count(a.ptr, len(ks), cutoff, t.ptr, len(ks))
+        tab = _unpad_kmers(t.download(nt * w.kmer_stride).reshape(nt, w.kmer_stride), w.kmer_bytes)
+    util.check_against_golden(case, hist, mi + ovf, tab)
+
+
+# ------------------------------------------------------------------------------ whole path
+
+@pytest.mark.parametrize("name", util.golden_names())
+def test_pipeline_matches_reference_golden(name, tmp_path):
+    case, bases, boff = util.load_case(name)
+    k = case["k"]
+    with fastk_amd.Context(kmer=k, table_cutoff=case["cutoff"], nthreads=case["T"]) as ctx:
+        # feed in several DATA_BLOCK-sized pieces, like io.c does
+        nreads = len(boff) - 1
+        step = max(1, nreads // 7)
+        for s in range(0, nreads, step):
+            e = min(nreads, s + step)
+            ctx.push_block(bases[boff[s]:boff[e]], (boff[s:e + 1] - boff[s]).astype(np.int32))
+        res = ctx.finish()
+        util.check_against_golden(case, res.hist, res.max_inst, res.table)
+        ctx.write_hist(res, str(tmp_path / "x.hist"))
+        ctx.write_ktab(res, str(tmp_path), "x")
+    import hashlib
+    exp = case["expected"]
+    assert hashlib.sha256(open(tmp_path / "x.hist", "rb").read()).hexdigest() == exp["hist_sha256"]
+    t = orc.read_ktab(str(tmp_path / "x"))
+    assert t["stream_sha256"] == exp["ktab"]["stream_sha256"]
+    assert (t["kmer"], t["nparts"], t["minval"], t["ibytes"], t["nels"]) == \
+        (k, case["T"], case["cutoff"], exp["ktab"]["ibytes"], exp["ktab"]["nels"])
+
+
+def test_empty_and_degenerate_inputs():
+    with fastk_amd.Context(kmer=40, table_cutoff=1) as ctx:
+        res = ctx.finish()
+        assert res.ninst == 0 and res.ntable == 0 and res.hist.sum() == 0
+    for reads in (["acgt"], ["a" * 39], ["n" * 100], ["acgtacgtacgtacgtacgtacgtacgtacgtacgtacgt"]):
+        bases, boff = orc.block_from_reads(reads)
+        exp = orc.fastk(40, bases, boff, cutoff=1)
+        with fastk_amd.Context(kmer=40, table_cutoff=1) as ctx:
+            ctx.push_block(bases, boff.astype(np.int32))
+            res = ctx.finish()
+        assert res.ninst == exp.ninst and res.ntable == exp.ntable
+        assert np.array_equal(res.hist[1:], exp.hist[1:])
+        assert np.array_equal(res.table, exp.table)
+
+
+def test_device_synth_matches_host_generator(ctx40):
+    buf, n = ctx40.synth_reads(99, 50000, 150, 3000, 17, 500)
+    got = buf.download(n)
+    exp, _ = orc.synth_block(99, 50000, 150, 3000, 17, 500)
+    assert np.array_equal(got, exp)
+    buf.free()
+
+
+def test_bc_prefix_matches_oracle():
+    case, bases, boff = util.load_case("synth_tiny_k40_t1_T2")
+    exp = orc.fastk(40, bases, boff, cutoff=1, bc_prefix=12)
+    with fastk_amd.Context(kmer=40, table_cutoff=1, bc_prefix=12) as ctx:
+        ctx.push_block(bases, boff.astype(np.int32))
+        res = ctx.finish()
+    assert res.ninst == exp.ninst
+    assert np.array_equal(res.hist[1:], exp.hist[1:]) and np.array_equal(res.table, exp.table)
