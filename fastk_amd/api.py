@@ -19,7 +19,7 @@ EXPORTS = [
     "fk_write_hist", "fk_write_ktab", "fk_split_supermers", "fk_lsd_sort_records",
     "fk_msd_sort_records", "fk_expand_kmers", "fk_count_kmers", "fk_synth_reads",
     "fk_device_alloc", "fk_device_free", "fk_copy_to_device", "fk_copy_to_host",
-    "fk_get_sort_stats", "fk_version", "fk_count_device_reads",
+    "fk_get_sort_stats", "fk_version", "fk_count_device_reads", "fk_count_device_supermers",
 ]
 
 
@@ -45,7 +45,9 @@ class CResult(C.Structure):
                 ("ndistinct", C.c_int64), ("ntable", C.c_int64),
                 ("table", C.POINTER(C.c_uint8)), ("wfirst", C.c_int64 * 256),
                 ("ms_split", C.c_double), ("ms_sort_super", C.c_double), ("ms_expand", C.c_double),
-                ("ms_sort_kmer", C.c_double), ("ms_count", C.c_double), ("ms_total", C.c_double)]
+                ("ms_sort_kmer", C.c_double), ("ms_count", C.c_double), ("ms_total", C.c_double),
+                ("passes_super", C.c_int), ("passes_kmer", C.c_int),
+                ("ms_pass_super", C.c_double), ("ms_pass_kmer", C.c_double)]
 
 
 class SortStats(C.Structure):
@@ -80,6 +82,7 @@ def load_library():
     L.fk_push_device.argtypes = [vp, vp, i64]
     L.fk_finish.argtypes = [vp, C.POINTER(CResult)]
     L.fk_count_device_reads.argtypes = [vp, vp, i64, ci, C.POINTER(CResult)]
+    L.fk_count_device_supermers.argtypes = [vp, vp, i64, ci, C.POINTER(CResult)]
     L.fk_write_hist.argtypes = [C.POINTER(CResult), ci, C.c_char_p]
     L.fk_write_ktab.argtypes = [C.POINTER(CResult), ci, ci, ci, C.c_char_p, C.c_char_p]
     L.fk_split_supermers.argtypes = [vp, vp, i64, vp, i64, C.POINTER(i64), C.POINTER(i64), vp]
@@ -119,6 +122,8 @@ class Result:
         self.wfirst = np.ctypeslib.as_array(cres.wfirst).copy()
         self.ms = {k: float(getattr(cres, "ms_" + k))
                    for k in ("split", "sort_super", "expand", "sort_kmer", "count", "total")}
+        self.passes_super, self.passes_kmer = int(cres.passes_super), int(cres.passes_kmer)
+        self.ms_pass_super, self.ms_pass_kmer = float(cres.ms_pass_super), float(cres.ms_pass_kmer)
         if self.ntable > 0 and cres.table:
             self.table = np.ctypeslib.as_array(cres.table, shape=(self.ntable, kmer_word)).copy()
         else:
@@ -215,6 +220,12 @@ class Context:
         r = CResult()
         self._ck(self.L.fk_count_device_reads(self.h, ptr, nbytes, 1 if fetch_table else 0,
                                               C.byref(r)))
+        return Result(r, self.w.kmer_word)
+
+    def count_device_supermers(self, ptr, nsuper, fetch_table=False):
+        r = CResult()
+        self._ck(self.L.fk_count_device_supermers(self.h, ptr, nsuper, 1 if fetch_table else 0,
+                                                  C.byref(r)))
         return Result(r, self.w.kmer_word)
 
     def write_hist(self, res, path):

@@ -20,6 +20,26 @@ void fk_set_error(fk_ctx *ctx, const char *fmt, ...)
     memcpy(ctx->err, g_last_error, sizeof(ctx->err));
 }
 
+void *fk_slot(fk_ctx *ctx, int slot, int64_t nbytes)
+{ if (nbytes < 16) nbytes = 16;
+  if (ctx->slot_cap[slot] >= nbytes)
+    return (ctx->slot_ptr[slot]);
+  if (ctx->slot_ptr[slot] != NULL)
+    { hipFree(ctx->slot_ptr[slot]);
+      ctx->slot_ptr[slot] = NULL;
+      ctx->slot_cap[slot] = 0;
+    }
+  void *p = NULL;
+  if (hipMalloc(&p, (size_t) nbytes) != hipSuccess)
+    { fk_set_error(ctx, "out of HBM: cannot allocate %lld bytes (arena slot %d)",
+                   (long long) nbytes, slot);
+      return (NULL);
+    }
+  ctx->slot_ptr[slot] = p;
+  ctx->slot_cap[slot] = nbytes;
+  return (p);
+}
+
 extern "C" const char *fk_last_error(const fk_ctx *ctx)
 { return (ctx != NULL ? ctx->err : g_last_error); }
 
@@ -152,6 +172,9 @@ extern "C" void fk_destroy(fk_ctx *ctx)
   if (ctx->h_scratch) hipHostFree(ctx->h_scratch);
   hipFree(ctx->d_digit_hist); hipFree(ctx->d_status); hipFree(ctx->d_ticket);
   hipFree(ctx->d_reads);
+  for (int i = 0; i < FK_NSLOTS; i++)
+    if (ctx->slot_ptr[i] != NULL)
+      hipFree(ctx->slot_ptr[i]);
   for (int i = 0; i < 2; i++)
     { if (ctx->h_stage[i]) hipHostFree(ctx->h_stage[i]);
       if (ctx->stage_ev[i]) hipEventDestroy(ctx->stage_ev[i]);
@@ -274,7 +297,7 @@ extern "C" int fk_split_supermers(fk_ctx *ctx, const void *d_bases, int64_t nbyt
     { fk_set_error(ctx, "fk_split_supermers: read buffer must be 16-byte aligned");
       return (FK_EINVAL);
     }
-  return fkx_split(ctx, d_bases, nbytes, d_out, cap, nsuper, ninst, bucket_counts);
+  return fkx_split(ctx, d_bases, nbytes, d_out, cap, nsuper, ninst, bucket_counts, false);
 }
 
 extern "C" int fk_lsd_sort_records(fk_ctx *ctx, int64_t nelem, void *d_src, void *d_trg, int rsize,
@@ -414,20 +437,16 @@ extern "C" int fk_push_device(fk_ctx *ctx, const void *d_bases, int64_t nbytes)
 }
 
 // ---- whole path: split -> sort -> expand -> sort -> count ----------------------------------------
-struct DevBuf
-{ void *p;
-  DevBuf() : p(NULL) {}
-  ~DevBuf() { if (p) hipFree(p); }
-};
-
 static double ms_between(hipEvent_t a, hipEvent_t b)
 { float ms = 0.f;
   hipEventElapsedTime(&ms, a, b);
   return (double) ms;
 }
 
-int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, fk_result *res,
-                 bool fetch_table)
+// d_smers_in != NULL: start from caller-owned super-mer records (sharded path, after the exchange);
+// the caller's buffer is used as one half of the sort's ping-pong pair and is clobbered.
+int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers_in,
+                 int64_t nsmers_in, fk_result *res, bool fetch_table)
 { const fk_widths &w = ctx->wid;
   hipStream_t s = ctx->stream;
   hipEvent_t ev[6];
@@ -440,32 +459,42 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, fk_result *re
         return (FK_EHIP);
       }
   do
-    { DevBuf sm_a, sm_b, km_a, km_b, tab;
+    { void *sm_a = NULL, *sm_b = NULL, *km_a = NULL, *km_b = NULL;
       int64_t ns = 0, ni = 0;
+      int64_t bcounts[256];
 
       hipEventRecord(ev[0], s);
-      // split (count, then emit)
-      if ((rc = fkx_split(ctx, d_reads, nbytes, NULL, 0, &ns, &ni, NULL)) != FK_OK) break;
-      res->nsuper = ns;
-      res->ninst = ni;
-      if (ns > 0)
-        { if (hipMalloc(&sm_a.p, (size_t) ns * w.smer_stride) != hipSuccess
-              || hipMalloc(&sm_b.p, (size_t) ns * w.smer_stride) != hipSuccess)
-            { fk_set_error(ctx, "fk_finish: out of HBM for %lld super-mers", (long long) ns);
-              rc = FK_ENOMEM; break;
-            }
-          if ((rc = fkx_split(ctx, d_reads, nbytes, sm_a.p, ns, &ns, &ni, NULL)) != FK_OK) break;
+      void *sm_in = d_smers_in;
+      if (d_smers_in != NULL)
+        { ns = nsmers_in;
+          res->nsuper = ns;
         }
+      else
+        { // split: count, then emit
+          if ((rc = fkx_split(ctx, d_reads, nbytes, NULL, 0, &ns, &ni, bcounts, false)) != FK_OK) break;
+          res->nsuper = ns;
+          res->ninst = ni;
+          if (ns > 0)
+            { if ((sm_a = fk_slot(ctx, FK_SLOT_SM_A, ns * w.smer_stride)) == NULL)
+                { rc = FK_ENOMEM; break; }
+              if ((rc = fkx_split(ctx, d_reads, nbytes, sm_a, ns, &ns, &ni, bcounts, true)) != FK_OK) break;
+            }
+          sm_in = sm_a;
+        }
+      if (ns > 0 && (sm_b = fk_slot(ctx, FK_SLOT_SM_B, ns * w.smer_stride)) == NULL)
+        { rc = FK_ENOMEM; break; }
       hipEventRecord(ev[1], s);
 
       // super-mer sort (key = whole record, MSDsort.c:458 called with ksize = SMER_WORD)
-      void *sm_sorted = sm_a.p;
+      void *sm_sorted = sm_in;
       { int bytes[64];
         for (int i = 0; i < w.smer_word; i++)
           bytes[i] = w.smer_word - 1 - i;
-        if ((rc = fkx_lsd_sort(ctx, ns, sm_a.p, sm_b.p, w.smer_stride, bytes, w.smer_word,
+        if ((rc = fkx_lsd_sort(ctx, ns, sm_in, sm_b, w.smer_stride, bytes, w.smer_word,
                                &sm_sorted)) != FK_OK)
           break;
+        res->passes_super  = ctx->sort_stats.passes;
+        res->ms_pass_super = ctx->sort_stats.pass_ms_total;
       }
       hipEventRecord(ev[2], s);
 
@@ -474,35 +503,26 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, fk_result *re
       if ((rc = fkx_expand(ctx, sm_sorted, ns, NULL, 0, &nw, &nd, &ovf)) != FK_OK) break;
       res->nweighted = nw;
       res->ndistinct_super = nd;
-      // the scratch super-mer buffer is no longer needed
-      { void *other = (sm_sorted == sm_a.p) ? sm_b.p : sm_a.p;
-        if (other) hipFree(other);
-        if (sm_sorted == sm_a.p) sm_b.p = NULL; else sm_a.p = NULL;
-      }
       if (nw > 0)
-        { if (hipMalloc(&km_a.p, (size_t) nw * w.kmer_stride) != hipSuccess)
-            { fk_set_error(ctx, "fk_finish: out of HBM for %lld weighted k-mers", (long long) nw);
-              rc = FK_ENOMEM; break;
-            }
-          if ((rc = fkx_expand(ctx, sm_sorted, ns, km_a.p, nw, &nw, &nd, &ovf)) != FK_OK) break;
+        { if ((km_a = fk_slot(ctx, FK_SLOT_KM_A, nw * w.kmer_stride)) == NULL)
+            { rc = FK_ENOMEM; break; }
+          if ((rc = fkx_expand(ctx, sm_sorted, ns, km_a, nw, &nw, &nd, &ovf)) != FK_OK) break;
         }
-      if (sm_a.p) { hipFree(sm_a.p); sm_a.p = NULL; }
-      if (sm_b.p) { hipFree(sm_b.p); sm_b.p = NULL; }
       hipEventRecord(ev[3], s);
 
       // weighted k-mer sort (key = KMER_BYTES, MSDsort.c:536)
-      void *km_sorted = km_a.p;
+      void *km_sorted = km_a;
       if (nw > 0)
-        { if (hipMalloc(&km_b.p, (size_t) nw * w.kmer_stride) != hipSuccess)
-            { fk_set_error(ctx, "fk_finish: out of HBM for the k-mer sort buffer");
-              rc = FK_ENOMEM; break;
-            }
+        { if ((km_b = fk_slot(ctx, FK_SLOT_KM_B, nw * w.kmer_stride)) == NULL)
+            { rc = FK_ENOMEM; break; }
           int bytes[64];
           for (int i = 0; i < w.kmer_bytes; i++)
             bytes[i] = w.kmer_bytes - 1 - i;
-          if ((rc = fkx_lsd_sort(ctx, nw, km_a.p, km_b.p, w.kmer_stride, bytes, w.kmer_bytes,
+          if ((rc = fkx_lsd_sort(ctx, nw, km_a, km_b, w.kmer_stride, bytes, w.kmer_bytes,
                                  &km_sorted)) != FK_OK)
             break;
+          res->passes_kmer  = ctx->sort_stats.passes;
+          res->ms_pass_kmer = ctx->sort_stats.pass_ms_total;
           // first-byte census of the weighted k-mers = Kparts (count.c:1527-1535)
           for (int x = 0; x < 256; x++)
             res->wfirst[x] = (int64_t) ctx->h_scratch[x];
@@ -512,7 +532,7 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, fk_result *re
       // count + table: the idle half of the k-mer ping-pong pair receives the table
       int64_t nt = 0, ndk = 0;
       const int cutoff = ctx->prm.table_cutoff;
-      void *other = (km_sorted == km_a.p) ? km_b.p : km_a.p;
+      void *other = (km_sorted == km_a) ? km_b : km_a;
       if ((rc = fkx_count(ctx, km_sorted, nw, cutoff, res->hist, &res->max_inst, &ndk,
                           cutoff > 0 ? other : NULL, nw, &nt)) != FK_OK)
         break;
@@ -572,7 +592,7 @@ extern "C" int fk_finish(fk_ctx *ctx, fk_result *res)
 { if (ctx == NULL || res == NULL) return (FK_EINVAL);
   FK_HIP(ctx, hipSetDevice(ctx->device));
   FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return fkx_pipeline(ctx, ctx->d_reads, ctx->reads_len, res, true);
+  return fkx_pipeline(ctx, ctx->d_reads, ctx->reads_len, NULL, 0, res, true);
 }
 
 /* Same pipeline on a caller-owned device buffer, table left out unless asked (bench path). */
@@ -584,7 +604,18 @@ extern "C" int fk_count_device_reads(fk_ctx *ctx, const void *d_bases, int64_t n
       return (FK_EINVAL);
     }
   FK_HIP(ctx, hipSetDevice(ctx->device));
-  return fkx_pipeline(ctx, d_bases, nbytes, res, fetch_table != 0);
+  return fkx_pipeline(ctx, d_bases, nbytes, NULL, 0, res, fetch_table != 0);
+}
+
+/* Sort + expand + sort + count over super-mer records that are already in HBM (the records a
+   rank owns after the bucket exchange).  d_smers is clobbered. */
+extern "C" int fk_count_device_supermers(fk_ctx *ctx, void *d_smers, int64_t nsuper, int fetch_table,
+                                         fk_result *res)
+{ if (ctx == NULL || res == NULL || nsuper < 0 || (d_smers == NULL && nsuper > 0)) return (FK_EINVAL);
+  static char dummy[16];
+  FK_HIP(ctx, hipSetDevice(ctx->device));
+  return fkx_pipeline(ctx, NULL, 0, nsuper > 0 ? d_smers : (void *) dummy, nsuper, res,
+                      fetch_table != 0);
 }
 
 // ---- encodings ----------------------------------------------------------------------------------

@@ -14,6 +14,8 @@
 typedef unsigned long long u64;
 typedef unsigned int       u32;
 
+#define FK_NSLOTS 16
+
 struct fk_ctx
 { fk_params  prm;
   fk_widths  wid;
@@ -50,7 +52,18 @@ struct fk_ctx
   void      *push_lock;    // pthread mutex
 
   hipEvent_t ev0, ev1;
+
+  // HBM arena: one cached allocation per purpose, grown on demand and kept until fk_destroy,
+  // so that a repeated workload performs no hipMalloc/hipFree inside the hot path
+  void      *slot_ptr[FK_NSLOTS];
+  int64_t    slot_cap[FK_NSLOTS];
 };
+
+enum { FK_SLOT_SM_A = 0, FK_SLOT_SM_B, FK_SLOT_KM_A, FK_SLOT_KM_B, FK_SLOT_EX_HEADS, FK_SLOT_EX_KMERS,
+       FK_SLOT_EX_KOFF, FK_SLOT_CT_ENT, FK_SLOT_CT_OFF, FK_SLOT_CT_HIST };
+
+// returns a device buffer of at least nbytes for the given purpose (NULL + error set on failure)
+void *fk_slot(fk_ctx *ctx, int slot, int64_t nbytes);
 
 void fk_set_error(fk_ctx *ctx, const char *fmt, ...);
 
@@ -69,7 +82,7 @@ void fk_set_error(fk_ctx *ctx, const char *fmt, ...);
 int fkx_lsd_sort(fk_ctx *ctx, int64_t nelem, void *d_src, void *d_trg, int rsize,
                  const int *bytes, int nbytes, void **result);
 int fkx_split(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int64_t cap,
-              int64_t *nsuper, int64_t *ninst, int64_t *bucket_counts);
+              int64_t *nsuper, int64_t *ninst, int64_t *bucket_counts, bool counts_known);
 int fkx_expand(fk_ctx *ctx, const void *d_smers, int64_t nsuper, void *d_out, int64_t cap,
                int64_t *nweighted, int64_t *ndistinct, int64_t *overflow);
 int fkx_count(fk_ctx *ctx, const void *d_kmers, int64_t nweighted, int cutoff,

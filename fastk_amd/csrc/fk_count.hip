@@ -144,11 +144,11 @@ static int count_t(fk_ctx *ctx, void *d_kmers, int64_t n, int cutoff, int64_t *h
   if (n == 0)
     return (FK_OK);
 
-  u32 *d_ent = NULL;
-  u64 *d_off = NULL, *d_hist = NULL;
-  FK_HIP(ctx, hipMalloc((void **) &d_ent, (size_t) ntiles * 4));
-  FK_HIP(ctx, hipMalloc((void **) &d_off, (size_t) ntiles * 8));
-  FK_HIP(ctx, hipMalloc((void **) &d_hist, (size_t) (FK_HIST_BINS + 8) * 8));
+  u32 *d_ent  = (u32 *) fk_slot(ctx, FK_SLOT_CT_ENT, ntiles * 4);
+  u64 *d_off  = (u64 *) fk_slot(ctx, FK_SLOT_CT_OFF, ntiles * 8);
+  u64 *d_hist = (u64 *) fk_slot(ctx, FK_SLOT_CT_HIST, (FK_HIST_BINS + 8) * 8);
+  if (d_ent == NULL || d_off == NULL || d_hist == NULL)
+    return (FK_ENOMEM);
   u64 *d_scal = d_hist + FK_HIST_BINS;     // [0] max_inst [1] distinct [2] total entries
   u64 *h = (u64 *) malloc((FK_HIST_BINS + 8) * 8);
 
@@ -188,7 +188,6 @@ static int count_t(fk_ctx *ctx, void *d_kmers, int64_t n, int cutoff, int64_t *h
   if (rc == FK_EHIP)
     fk_set_error(ctx, "count: HIP failure: %s", hipGetErrorString(hipGetLastError()));
   free(h);
-  hipFree(d_ent); hipFree(d_off); hipFree(d_hist);
   return (rc);
 }
 

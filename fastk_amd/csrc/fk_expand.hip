@@ -235,11 +235,11 @@ static int expand_t(fk_ctx *ctx, const void *d_smers, int64_t n, void *d_out, in
   if (n == 0)
     return (FK_OK);
 
-  u32 *d_heads = NULL, *d_kmers = NULL;
-  u64 *d_koff = NULL;
-  FK_HIP(ctx, hipMalloc((void **) &d_heads, (size_t) ntiles * 4));
-  FK_HIP(ctx, hipMalloc((void **) &d_kmers, (size_t) ntiles * 4));
-  FK_HIP(ctx, hipMalloc((void **) &d_koff, (size_t) ntiles * 8));
+  u32 *d_heads = (u32 *) fk_slot(ctx, FK_SLOT_EX_HEADS, ntiles * 4);
+  u32 *d_kmers = (u32 *) fk_slot(ctx, FK_SLOT_EX_KMERS, ntiles * 4);
+  u64 *d_koff  = (u64 *) fk_slot(ctx, FK_SLOT_EX_KOFF, ntiles * 8);
+  if (d_heads == NULL || d_kmers == NULL || d_koff == NULL)
+    return (FK_ENOMEM);
   u64 *d_tot = ctx->d_scratch;     // [0] k-mers, [1] heads (via second scan), [2] overflow
 
   int rc = FK_OK;
@@ -293,7 +293,6 @@ static int expand_t(fk_ctx *ctx, const void *d_smers, int64_t n, void *d_out, in
   while (0);
   if (rc == FK_EHIP)
     fk_set_error(ctx, "expand: HIP failure: %s", hipGetErrorString(hipGetLastError()));
-  hipFree(d_heads); hipFree(d_kmers); hipFree(d_koff);
   return (rc);
 }
 

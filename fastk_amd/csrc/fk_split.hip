@@ -301,8 +301,10 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
+// counts_known: bucket_counts[] (and *nsuper, *ninst) hold the result of an earlier counting call
+// on the same input, so only the emit kernel runs.
 int fkx_split(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int64_t cap,
-              int64_t *nsuper, int64_t *ninst, int64_t *bucket_counts)
+              int64_t *nsuper, int64_t *ninst, int64_t *bucket_counts, bool counts_known)
 { hipStream_t s = ctx->stream;
   const int   K = ctx->prm.kmer;
   const int   nb = ctx->prm.nbuckets;
@@ -314,11 +316,15 @@ int fkx_split(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int
     { fk_set_error(ctx, "k = %d outside the supported range [8,%d]", K, SP_MAXK);
       return (FK_EUNSUPPORTED);
     }
-  if (nsuper) *nsuper = 0;
-  if (ninst) *ninst = 0;
-  if (bucket_counts)
-    for (int b = 0; b < nb; b++)
-      bucket_counts[b] = 0;
+  if (counts_known && (bucket_counts == NULL || d_out == NULL))
+    return (FK_EINVAL);
+  if (!counts_known)
+    { if (nsuper) *nsuper = 0;
+      if (ninst) *ninst = 0;
+      if (bucket_counts)
+        for (int b = 0; b < nb; b++)
+          bucket_counts[b] = 0;
+    }
   if (nbytes < K)
     return (FK_OK);
 
@@ -341,21 +347,27 @@ int fkx_split(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int
   const int64_t ntiles  = (nstarts + SP_TILE - 1) / SP_TILE;
 
   FK_HIP(ctx, hipMemsetAsync(ctx->d_scratch, 0, 1032 * sizeof(u64), s));
-  hipLaunchKernelGGL(k_split<false>, dim3((unsigned) ntiles), dim3(SP_THREADS), 0, s, a);
-  FK_LAUNCH_CHECK(ctx);
-  FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch, d_counts, 257 * sizeof(u64), hipMemcpyDeviceToHost, s));
-  FK_HIP(ctx, hipStreamSynchronize(s));
-
   int64_t tot = 0;
-  u64     base[256];
-  for (int b = 0; b < nb; b++)
-    { base[b] = (u64) tot;
-      tot += (int64_t) ctx->h_scratch[b];
-      if (bucket_counts)
-        bucket_counts[b] = (int64_t) ctx->h_scratch[b];
+  u64    *base = ctx->h_scratch + 512;          // pinned, so the async upload below is safe
+  if (!counts_known)
+    { hipLaunchKernelGGL(k_split<false>, dim3((unsigned) ntiles), dim3(SP_THREADS), 0, s, a);
+      FK_LAUNCH_CHECK(ctx);
+      FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch, d_counts, 257 * sizeof(u64), hipMemcpyDeviceToHost, s));
+      FK_HIP(ctx, hipStreamSynchronize(s));
+      for (int b = 0; b < nb; b++)
+        { base[b] = (u64) tot;
+          tot += (int64_t) ctx->h_scratch[b];
+          if (bucket_counts)
+            bucket_counts[b] = (int64_t) ctx->h_scratch[b];
+        }
+      if (nsuper) *nsuper = tot;
+      if (ninst) *ninst = (int64_t) ctx->h_scratch[256];
     }
-  if (nsuper) *nsuper = tot;
-  if (ninst) *ninst = (int64_t) ctx->h_scratch[256];
+  else
+    for (int b = 0; b < nb; b++)
+      { base[b] = (u64) tot;
+        tot += bucket_counts[b];
+      }
   if (cap == 0 || d_out == NULL)
     return (FK_OK);
   if (cap < tot)
@@ -365,7 +377,6 @@ int fkx_split(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int
     }
 
   FK_HIP(ctx, hipMemcpyAsync(d_cursor, base, nb * sizeof(u64), hipMemcpyHostToDevice, s));
-  FK_HIP(ctx, hipStreamSynchronize(s));      // base[] lives on this stack frame
   hipLaunchKernelGGL(k_split<true>, dim3((unsigned) ntiles), dim3(SP_THREADS), 0, s, a);
   FK_LAUNCH_CHECK(ctx);
   FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch, d_ovf, sizeof(u32), hipMemcpyDeviceToHost, s));

@@ -100,6 +100,8 @@ typedef struct
     const uint8_t *table;        /* host, ntable entries of kmer_word bytes, sorted; owned by ctx      */
     int64_t  wfirst[256];        /* weighted k-mers per canonical first byte (Kparts, count.c:1527)    */
     double   ms_split, ms_sort_super, ms_expand, ms_sort_kmer, ms_count, ms_total;  /* device time   */
+    int      passes_super, passes_kmer;   /* radix digit passes executed by the two sorts              */
+    double   ms_pass_super, ms_pass_kmer; /* summed duration of those pass kernels (HIP events)        */
   } fk_result;
 
 /* Replaces Sorting() + the merge of Merge_Tables() (count.c:1202, table.c:346): runs the
@@ -112,6 +114,12 @@ int fk_finish(fk_ctx *ctx, fk_result *res);
    the table in HBM and only reports ntable (bench path: nothing crosses PCIe but counters). */
 int fk_count_device_reads(fk_ctx *ctx, const void *d_bases, int64_t nbytes, int fetch_table,
                           fk_result *res);
+
+/* Sort + expand + sort + count over super-mer records already in HBM: what a rank runs on the
+   records it owns after the bucket exchange (the .T file shuffle of split.c:1263 <-> count.c:1347).
+   d_smers (nsuper records of smer_stride bytes) is clobbered. */
+int fk_count_device_supermers(fk_ctx *ctx, void *d_smers, int64_t nsuper, int fetch_table,
+                              fk_result *res);
 
 /* .hist / .ktab writers with the reference encodings (count.c:1893-1910, table.c:162-342,
    485-498).  Part boundaries follow the reference's rule (MSDsort.c:330-352 on wfirst). */
