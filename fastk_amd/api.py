@@ -19,7 +19,7 @@ EXPORTS = [
     "fk_write_hist", "fk_write_ktab", "fk_split_supermers", "fk_lsd_sort_records",
     "fk_msd_sort_records", "fk_expand_kmers", "fk_count_kmers", "fk_synth_reads",
     "fk_device_alloc", "fk_device_free", "fk_copy_to_device", "fk_copy_to_host",
-    "fk_get_sort_stats", "fk_version", "fk_count_device_reads", "fk_count_device_supermers",
+    "fk_get_sort_stats", "fk_version", "fk_count_device_reads", "fk_count_device_supermers", "fk_debug_set",
 ]
 
 
@@ -99,6 +99,7 @@ def load_library():
     L.fk_copy_to_device.argtypes = [vp, vp, vp, i64]
     L.fk_copy_to_host.argtypes = [vp, vp, vp, i64]
     L.fk_get_sort_stats.argtypes = [vp, C.POINTER(SortStats)]
+    L.fk_debug_set.argtypes = [vp, C.c_char_p, i64]
     L.fk_version.restype = C.c_char_p
     _lib = L
     return L

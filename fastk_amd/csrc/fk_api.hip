@@ -237,6 +237,21 @@ extern "C" int fk_copy_to_host(fk_ctx *ctx, void *dst, const void *d_src, int64_
   return (FK_OK);
 }
 
+/* Measurement aids for profiles/ (never used by the product path): "radix_variant" 0/1/2 selects
+   ablated radix-pass kernels whose OUTPUT IS WRONG but whose duration isolates one cost. */
+extern "C" int fk_debug_set(fk_ctx *ctx, const char *key, int64_t value)
+{ if (ctx == NULL || key == NULL) return (FK_EINVAL);
+  if (strcmp(key, "radix_variant") == 0)
+    { ctx->dbg_radix_variant = (int) value;
+      return (FK_OK);
+    }
+  if (strcmp(key, "radix_items") == 0)
+    { ctx->dbg_radix_items = (int) value;
+      return (FK_OK);
+    }
+  return (FK_EINVAL);
+}
+
 extern "C" int fk_get_sort_stats(fk_ctx *ctx, fk_sort_stats *st)
 { if (ctx == NULL || st == NULL) return (FK_EINVAL);
   *st = ctx->sort_stats;

@@ -55,6 +55,8 @@ struct fk_ctx
 
   // HBM arena: one cached allocation per purpose, grown on demand and kept until fk_destroy,
   // so that a repeated workload performs no hipMalloc/hipFree inside the hot path
+  int        dbg_radix_variant;   // measurement aids, see fk_debug_set
+  int        dbg_radix_items;
   void      *slot_ptr[FK_NSLOTS];
   int64_t    slot_cap[FK_NSLOTS];
 };

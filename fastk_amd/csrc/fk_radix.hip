@@ -20,10 +20,10 @@
 #define RX_WAVES   4
 
 template <int RW> struct RxCfg
-{ // tile of ~48 KB so that three workgroups share a CU's 160 KB of LDS
-  static constexpr int ITEMS = (RW <= 3) ? 15 : (RW == 4) ? 11 : (RW == 5) ? 9 : (RW == 6) ? 7
-                             : (RW == 7) ? 6 : 5;
-  static constexpr int TILE  = RX_THREADS * ITEMS;
+{ // default records per thread: a tile of ~36 KB plus its permutation and histograms lets three
+  // workgroups share a CU's 160 KB of LDS
+  static constexpr int ITEMS = (RW <= 2) ? 16 : (RW == 3) ? 12 : (RW == 4) ? 9 : (RW == 5) ? 8
+                             : (RW == 6) ? 6 : 4;
 };
 
 #define ST_AGG  1ull
@@ -63,35 +63,49 @@ __global__ __launch_bounds__(RX_THREADS) void k_digit_hist(const u32 *__restrict
 
 // ---------------------------------------------------------------------------------------------
 // one stable 8-bit digit pass
-template <int RW>
+// VARIANT is a measurement aid (fk_debug_set "radix_variant"); only 0 produces a sorted result:
+//   1 = no look-back (offsets interpolated from the global histogram: real store pattern, no waits)
+//   2 = no ranking, no look-back (tile streamed through LDS, linear store)
+//   3 = real ranking and LDS permutation, no look-back, linear store
+//   4 = as 1, but every XCD works on one contiguous range of tiles (L2 write-combining test)
+template <int RW, int ITEMS, int VARIANT>
 __global__ __launch_bounds__(RX_THREADS) void k_radix_pass(const u32 *__restrict__ src,
                                                            u32 *__restrict__ dst, int64_t n,
                                                            int byte_idx,
                                                            const u64 *__restrict__ ghist,
                                                            u64 *status, u32 *ticket, u32 epoch)
-{ constexpr int ITEMS = RxCfg<RW>::ITEMS;
-  constexpr int TILE  = RxCfg<RW>::TILE;
+{ constexpr int TILE = RX_THREADS * ITEMS;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  u32      *recs     = (u32 *) smem;                                   // TILE*RW
+  u32      *recs     = (u32 *) smem;                                   // TILE*RW, never reordered
   int64_t  *goff     = (int64_t *) (smem + (size_t) TILE * RW * 4);    // 256
   u64      *tmp64    = (u64 *) (goff + 256);                           // 8
-  volatile u32 *whist = (volatile u32 *) (tmp64 + 8);                  // 4*256
-  u32      *binstart = (u32 *) (whist + RX_WAVES * 256);               // 256
+  u32      *whist    = (u32 *) (tmp64 + 8);                            // 4*256
+  u32      *binstart = whist + RX_WAVES * 256;                         // 256
   u32      *tmp32    = binstart + 256;                                 // 8
-  u32      *s_tile   = tmp32 + 8;                                      // 1
+  u32      *s_tile   = tmp32 + 8;                                      // 4 (keeps perm 16-B aligned)
+  uint16_t *perm     = (uint16_t *) (s_tile + 4);                      // TILE: sorted slot -> record
 
   const int tid  = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
 
   if (tid == 0)
-    *s_tile = atomicAdd(ticket, 1u);
+    { if (VARIANT == 4)
+        { // measurement: XCD x (= blockIdx % 8, observed dispatch) takes a contiguous range of tiles
+          const u32 per = (gridDim.x + 7) / 8;
+          *s_tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+        }
+      else
+        *s_tile = atomicAdd(ticket, 1u);
+    }
   for (int i = tid; i < RX_WAVES * 256; i += RX_THREADS)
     whist[i] = 0;
   __syncthreads();
 
   const u32     tile   = *s_tile;
+  if (VARIANT == 4 && tile >= gridDim.x)
+    return;
   const int64_t tstart = (int64_t) tile * TILE;
   const int     tn     = (n - tstart < TILE) ? (int) (n - tstart) : TILE;
   const int     ndw    = tn * RW;
@@ -99,33 +113,44 @@ __global__ __launch_bounds__(RX_THREADS) void k_radix_pass(const u32 *__restrict
   { const u32   *gsrc = src + tstart * RW;
     const uint4 *g4   = (const uint4 *) gsrc;
     uint4       *l4   = (uint4 *) recs;
-    const int    n4   = ndw >> 2;
-    for (int i = tid; i < n4; i += RX_THREADS)
-      l4[i] = g4[i];
-    for (int i = (n4 << 2) + tid; i < ndw; i += RX_THREADS)
-      recs[i] = gsrc[i];
+    if (tn == TILE)
+      { // full tile: every 16-byte load is issued before the first LDS write, so the workgroup
+        // keeps its whole tile in flight instead of one load per thread at a time
+        static_assert((ITEMS * RW) % 4 == 0, "tile must be a whole number of 16-byte loads per thread");
+        constexpr int NV = ITEMS * RW / 4;
+        uint4 v[NV];
+#pragma unroll
+        for (int k = 0; k < NV; k++)
+          v[k] = g4[tid + k * RX_THREADS];
+#pragma unroll
+        for (int k = 0; k < NV; k++)
+          l4[tid + k * RX_THREADS] = v[k];
+      }
+    else
+      { const int n4 = ndw >> 2;
+        for (int i = tid; i < n4; i += RX_THREADS)
+          l4[i] = g4[i];
+        for (int i = (n4 << 2) + tid; i < ndw; i += RX_THREADS)
+          recs[i] = gsrc[i];
+      }
   }
   __syncthreads();
 
-  u32 rec[ITEMS][RW];
-  u32 dig[ITEMS];
-  u32 rnk[ITEMS];
   const int  wbase = wave * 64 * ITEMS;
   const u64  lt    = fk_lanemask_lt();
   const unsigned char *lbytes = (const unsigned char *) smem;
 
+  // (a) digit of each record, its match mask inside the wave, and ONE LDS atomic per distinct
+  //     digit per item.  The atomics are issued back to back without waiting for their results:
+  //     a wave's LDS operations execute in order, so item i sees the counts of items < i and the
+  //     ranks are stable.  info = d | below << 8 | leader << 16
+  u32 info[ITEMS];
+  u32 old[ITEMS];
 #pragma unroll
   for (int it = 0; it < ITEMS; it++)
     { const int  r     = wbase + it * 64 + lane;
       const bool valid = (r < tn);
-      u32 d = 0;
-      if (valid)
-        {
-#pragma unroll
-          for (int w = 0; w < RW; w++)
-            rec[it][w] = recs[r * RW + w];
-          d = lbytes[r * RW * 4 + byte_idx];
-        }
+      const u32  d     = valid ? (u32) lbytes[r * RW * 4 + byte_idx] : 0u;
       u64 mask = __ballot(valid);
 #pragma unroll
       for (int b = 0; b < 8; b++)
@@ -133,15 +158,22 @@ __global__ __launch_bounds__(RX_THREADS) void k_radix_pass(const u32 *__restrict
           const u64  bm  = __ballot(bit);
           mask &= bit ? bm : ~bm;
         }
-      const u32 below = (u32) __popcll(mask & lt);
-      const u32 cnt   = (u32) __popcll(mask);
-      u32 base = 0;
-      if (valid)
-        base = whist[wave * 256 + d];
-      if (valid && below == 0)
-        whist[wave * 256 + d] = base + cnt;
-      dig[it] = d;
-      rnk[it] = base + below;
+      const u32 below  = (u32) __popcll(mask & lt);
+      const u32 leader = valid ? (u32) (__ffsll((unsigned long long) mask) - 1) : (u32) lane;
+      info[it] = d | (below << 8) | (leader << 16);
+      old[it] = 0;
+      if (VARIANT != 2 && valid && below == 0)
+        old[it] = atomicAdd(&whist[wave * 256 + d], (u32) __popcll(mask));
+    }
+  if (VARIANT != 2)
+    {
+      // (c) the leader's base reaches the other lanes of its digit through the LDS crossbar
+#pragma unroll
+      for (int it = 0; it < ITEMS; it++)
+        { const u32 e    = info[it];
+          const u32 base = (u32) __shfl((int) old[it], (int) ((e >> 16) & 0xffu), 64);
+          info[it] = (e & 0xffu) | ((base + ((e >> 8) & 0xffu)) << 8);     // d | rank-in-wave << 8
+        }
     }
   __syncthreads();
 
@@ -157,11 +189,18 @@ __global__ __launch_bounds__(RX_THREADS) void k_radix_pass(const u32 *__restrict
     u32 tsum;
     const u32 bstart = fk_block_exscan_256<u32>(total, tmp32, &tsum);
     u64 gsum;
-    const u64 gbase  = fk_block_exscan_256<u64>(ghist[tid], tmp64, &gsum);
+    const u64 gcnt   = ghist[tid];
+    const u64 gbase  = fk_block_exscan_256<u64>(gcnt, tmp64, &gsum);
     binstart[tid] = bstart;
 
     u64 excl = 0;
-    if (tile == 0)
+    if (VARIANT == 1 || VARIANT == 4)
+      { excl = (gcnt * (u64) tile) / (u64) gridDim.x;
+        if (excl + total > gcnt) excl = (gcnt > total) ? gcnt - total : 0;
+      }
+    else if (VARIANT != 0)
+      excl = 0;
+    else if (tile == 0)
       __hip_atomic_store(&status[tid], st_pack(epoch, ST_PFX, total), __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
     else
@@ -189,39 +228,44 @@ __global__ __launch_bounds__(RX_THREADS) void k_radix_pass(const u32 *__restrict
   }
   __syncthreads();
 
-  // reorder the tile by digit inside LDS (all records are in registers by now)
+  // sorted slot -> source record (the records themselves stay where the load put them)
 #pragma unroll
   for (int it = 0; it < ITEMS; it++)
     { const int r = wbase + it * 64 + lane;
       if (r < tn)
-        { const u32 d   = dig[it];
-          const u32 pos = binstart[d] + whist[wave * 256 + d] + rnk[it];
-#pragma unroll
-          for (int w = 0; w < RW; w++)
-            recs[pos * RW + w] = rec[it][w];
+        { const u32 e   = info[it];
+          const u32 d   = e & 0xffu;
+          const u32 pos = (VARIANT == 2) ? (u32) r : binstart[d] + whist[wave * 256 + d] + (e >> 8);
+          perm[pos] = (uint16_t) r;
         }
     }
   __syncthreads();
 
   // every bin's run leaves as consecutive dwords
+#pragma unroll 4
   for (int j = tid; j < ndw; j += RX_THREADS)
-    { const int p = j / RW;
-      const int w = j - p * RW;
-      const u32 d = lbytes[p * RW * 4 + byte_idx];
-      const int64_t g = (goff[d] + p) * RW + w;
-      dst[g] = recs[j];
+    { const int p   = j / RW;
+      const int w   = j - p * RW;
+      const int sr  = perm[p];
+      const u32 d   = lbytes[sr * RW * 4 + byte_idx];
+      int64_t g = (goff[d] + p) * RW + w;
+      if (VARIANT == 2 || VARIANT == 3)
+        g = (tstart + p) * RW + w;
+      if ((VARIANT == 1 || VARIANT == 4) && (g < 0 || g >= n * RW))
+        g = (tstart + p) * RW + w;
+      dst[g] = recs[sr * RW + w];
     }
 }
 
-template <int RW> static size_t rx_lds_bytes()
-{ return ((size_t) RxCfg<RW>::TILE * RW * 4 + 256 * 8 + 8 * 8 + RX_WAVES * 256 * 4 + 256 * 4 + 8 * 4
-          + 16);
+template <int RW, int ITEMS> static size_t rx_lds_bytes()
+{ return ((size_t) RX_THREADS * ITEMS * RW * 4 + 256 * 8 + 8 * 8 + RX_WAVES * 256 * 4 + 256 * 4
+          + 8 * 4 + 16 + (size_t) RX_THREADS * ITEMS * 2 + 16);
 }
 
-template <int RW>
+template <int RW, int ITEMS>
 static int lsd_sort_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, const int *bytes,
                       int nbytes, void **result)
-{ constexpr int TILE = RxCfg<RW>::TILE;
+{ constexpr int TILE = RX_THREADS * ITEMS;
   const int64_t ntiles = (n + TILE - 1) / TILE;
   hipStream_t   s = ctx->stream;
   u32 want = 0;
@@ -274,14 +318,7 @@ static int lsd_sort_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, const in
     ctx->sort_stats.hist_ms = ms;
   }
 
-  static bool attr_set = false;
-  if (!attr_set)
-    { FK_HIP(ctx, hipFuncSetAttribute((const void *) k_radix_pass<RW>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int) rx_lds_bytes<RW>()));
-      attr_set = true;
-    }
-
+  const size_t lds_bytes = rx_lds_bytes<RW, ITEMS>();
   u32 *src = (u32 *) d_src, *trg = (u32 *) d_trg;
   int  passes = 0;
   FK_HIP(ctx, hipEventRecord(ctx->ev0, s));
@@ -293,10 +330,17 @@ static int lsd_sort_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, const in
           constant = true;
       if (constant)
         continue;        // every record carries the same digit: the pass is the identity
-      hipLaunchKernelGGL(k_radix_pass<RW>, dim3((unsigned) ntiles), dim3(RX_THREADS),
-                         rx_lds_bytes<RW>(), s, (const u32 *) src, trg, n, bytes[i],
-                         (const u64 *) (ctx->d_digit_hist + (size_t) bytes[i] * 256),
-                         ctx->d_status, ctx->d_ticket + passes, (u32) (passes + 1));
+#define RX_LAUNCH(V)                                                                              \
+      hipLaunchKernelGGL((k_radix_pass<RW, ITEMS, V>), dim3((unsigned) ntiles), dim3(RX_THREADS),    \
+                         lds_bytes, s, (const u32 *) src, trg, n, bytes[i],                         \
+                         (const u64 *) (ctx->d_digit_hist + (size_t) bytes[i] * 256),               \
+                         ctx->d_status, ctx->d_ticket + passes, (u32) (passes + 1))
+      if (ctx->dbg_radix_variant == 1) RX_LAUNCH(1);
+      else if (ctx->dbg_radix_variant == 2) RX_LAUNCH(2);
+      else if (ctx->dbg_radix_variant == 3) RX_LAUNCH(3);
+      else if (ctx->dbg_radix_variant == 4) RX_LAUNCH(4);
+      else RX_LAUNCH(0);
+#undef RX_LAUNCH
       FK_LAUNCH_CHECK(ctx);
       passes += 1;
       u32 *t = src; src = trg; trg = t;
@@ -318,14 +362,25 @@ int fkx_lsd_sort(fk_ctx *ctx, int64_t nelem, void *d_src, void *d_trg, int rsize
     { fk_set_error(ctx, "record size %d not supported (multiple of 4, <= 32)", rsize);
       return (FK_EUNSUPPORTED);
     }
+  const int it = ctx->dbg_radix_items;      // measurement aid: alternative tile sizes for R = 12, 20
+#define RX_CASE(RW) return lsd_sort_t<RW, RxCfg<RW>::ITEMS>(ctx, nelem, d_src, d_trg, bytes, nbytes, result)
   switch (rsize >> 2)
-  { case 1: return lsd_sort_t<1>(ctx, nelem, d_src, d_trg, bytes, nbytes, result);
-    case 2: return lsd_sort_t<2>(ctx, nelem, d_src, d_trg, bytes, nbytes, result);
-    case 3: return lsd_sort_t<3>(ctx, nelem, d_src, d_trg, bytes, nbytes, result);
-    case 4: return lsd_sort_t<4>(ctx, nelem, d_src, d_trg, bytes, nbytes, result);
-    case 5: return lsd_sort_t<5>(ctx, nelem, d_src, d_trg, bytes, nbytes, result);
-    case 6: return lsd_sort_t<6>(ctx, nelem, d_src, d_trg, bytes, nbytes, result);
-    case 7: return lsd_sort_t<7>(ctx, nelem, d_src, d_trg, bytes, nbytes, result);
-    default: return lsd_sort_t<8>(ctx, nelem, d_src, d_trg, bytes, nbytes, result);
+  { case 1: RX_CASE(1);
+    case 2: RX_CASE(2);
+    case 3:
+      if (it == 8)  return lsd_sort_t<3, 8>(ctx, nelem, d_src, d_trg, bytes, nbytes, result);
+      if (it == 16) return lsd_sort_t<3, 16>(ctx, nelem, d_src, d_trg, bytes, nbytes, result);
+      if (it == 20) return lsd_sort_t<3, 20>(ctx, nelem, d_src, d_trg, bytes, nbytes, result);
+      RX_CASE(3);
+    case 4: RX_CASE(4);
+    case 5:
+      if (it == 8)  return lsd_sort_t<5, 4>(ctx, nelem, d_src, d_trg, bytes, nbytes, result);
+      if (it == 16) return lsd_sort_t<5, 12>(ctx, nelem, d_src, d_trg, bytes, nbytes, result);
+      if (it == 20) return lsd_sort_t<5, 16>(ctx, nelem, d_src, d_trg, bytes, nbytes, result);
+      RX_CASE(5);
+    case 6: RX_CASE(6);
+    case 7: RX_CASE(7);
+    default: RX_CASE(8);
   }
+#undef RX_CASE
 }

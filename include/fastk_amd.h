@@ -189,6 +189,10 @@ typedef struct
   } fk_sort_stats;
 int fk_get_sort_stats(fk_ctx *ctx, fk_sort_stats *st);
 
+/* Measurement aid for profiles/: selects ablated kernel variants; results are
+   invalid while a non-zero variant is set.  The product path never calls it. */
+int fk_debug_set(fk_ctx *ctx, const char *key, int64_t value);
+
 const char *fk_version(void);
 
 #ifdef __cplusplus
