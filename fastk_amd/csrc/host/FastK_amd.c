@@ -1,0 +1,241 @@
+/* FastK_amd.c -- host driver with FastK's command line over libfastk_amd.so.
+ *
+ *   FastK_amd [-k<int(40)>] [-t[<int(1)>]] [-bc<int>] [-v] [-N<path_name>] [-P<dir>] [-M<int>]
+ *             [-T<int(4)>] <source>[.fa|.fasta|.fq|.fastq][.gz] ...
+ *
+ * Same flags, defaults, output names and encodings as the reference driver (FastK.c:34-37,
+ * 250-319, 361-409): <root>.hist always, <root>.ktab + hidden .<root>.ktab.<1..T> with -t.
+ * The host side is plain C: it parses FASTA/FASTQ with the reference's line rules
+ * (io.c:678-734: FASTQ strictly 4-line, FASTA possibly multi-line, every non-newline byte of a
+ * sequence line is a base), cuts the input into DATA_BLOCK-shaped blocks (FastK.h:87-98; a read
+ * longer than a block continues in the next one with a K-1 base overlap, io.c:557-570) and hands
+ * them to fk_push_block -- the call that replaces Distribute_Block (FastK.h:123).  Everything
+ * per-base and per-record runs on the GPU inside the library.
+ *
+ * Accepted for compatibility and ignored: -P (no temporary files exist), -M (HBM is sized by the
+ * library).  Not built yet and rejected with a message: -p (profiles), -c (homopolymer
+ * compression), BAM/SAM/CRAM/Dazzler inputs.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <ctype.h>
+#include <zlib.h>
+
+#include "../../../include/fastk_amd.h"
+
+#define BLOCK_BYTES (8 << 20)
+#define BLOCK_READS 100000
+
+static char *Prog_Name = "FastK_amd";
+
+static int       KMER = 40, NTHREADS = 4, DO_TABLE = 0, BC_PREFIX = 0, VERBOSE = 0;
+static char     *OUT_NAME = NULL;
+
+typedef struct
+  { fk_ctx  *ctx;
+    char    *bases;
+    int32_t *boff;
+    int      nreads;
+    int64_t  olen;
+    int64_t  totbps, totrds;
+  } Feeder;
+
+static void die(fk_ctx *ctx, const char *what)
+{ fprintf(stderr,"%s: %s: %s\n",Prog_Name,what,fk_last_error(ctx));
+  if (ctx != NULL)
+    fk_destroy(ctx);
+  exit (1);
+}
+
+static void flush_block(Feeder *f, int rem)
+{ if (f->nreads == 0)
+    return;
+  f->boff[f->nreads] = (int32_t) f->olen;
+  if (fk_push_block(f->ctx,f->bases,f->boff,f->nreads,rem,0) != FK_OK)
+    die(f->ctx,"fk_push_block");
+  f->nreads  = 0;
+  f->olen    = 0;
+  f->boff[0] = 0;
+}
+
+static inline void add_base(Feeder *f, int c)
+{ if (f->olen >= BLOCK_BYTES-2)
+    { /* the read is longer than a block: close it here, continue with a K-1 overlap */
+      char keep[256];
+      int  ov = KMER-1;
+      int64_t start = f->boff[f->nreads];
+      if (f->olen - start < ov)
+        ov = (int) (f->olen - start);
+      memcpy(keep,f->bases+f->olen-ov,ov);
+      f->bases[f->olen++] = 0;
+      f->nreads += 1;
+      flush_block(f,1);
+      f->boff[0] = 0;
+      memcpy(f->bases,keep,ov);
+      f->olen = ov;
+    }
+  f->bases[f->olen++] = (char) c;
+  f->totbps += 1;
+}
+
+static inline void end_read(Feeder *f)
+{ f->bases[f->olen++] = 0;
+  f->nreads += 1;
+  f->totrds += 1;
+  f->boff[f->nreads] = (int32_t) f->olen;
+  if (f->olen > BLOCK_BYTES - (1 << 20) || f->nreads >= BLOCK_READS)
+    flush_block(f,0);
+}
+
+/* returns 1 for FASTQ, 0 for FASTA, -1 unknown; sets *root (malloc'd) and *dir */
+static int classify(const char *path, char **root, char **dir)
+{ static const char *suf[] = { ".fastq.gz", ".fasta.gz", ".fq.gz", ".fa.gz", ".fastq", ".fasta",
+                               ".fq", ".fa", NULL };
+  static const int   isq[] = { 1, 0, 1, 0, 1, 0, 1, 0 };
+  const char *slash = strrchr(path,'/');
+  const char *base  = slash ? slash+1 : path;
+  size_t      bl    = strlen(base);
+  int i;
+
+  for (i = 0; suf[i] != NULL; i++)
+    { size_t sl = strlen(suf[i]);
+      if (bl > sl && strcmp(base+bl-sl,suf[i]) == 0)
+        { *root = strndup(base,bl-sl);
+          *dir  = slash ? strndup(path,(size_t) (slash-path)) : strdup(".");
+          return (isq[i]);
+        }
+    }
+  return (-1);
+}
+
+static void scan_file(Feeder *f, const char *path, int fastq)
+{ gzFile  in = gzopen(path,"rb");
+  static unsigned char buf[1 << 20];
+  int     state = 0;    /* 0 record start, 1 header, 2 fastq seq, 3 '+' line, 4 quality, 5 fasta seq, 6 fasta eol */
+  int     n, i;
+
+  if (in == NULL)
+    { fprintf(stderr,"%s: Cannot open %s for reading\n",Prog_Name,path);
+      exit (1);
+    }
+  gzbuffer(in,1 << 20);
+  while ((n = gzread(in,buf,sizeof(buf))) > 0)
+    for (i = 0; i < n; i++)
+      { int c = buf[i];
+        switch (state)
+        { case 0: state = 1; break;
+          case 1: if (c == '\n') state = fastq ? 2 : 5; break;
+          case 2: if (c != '\n') add_base(f,c); else { end_read(f); state = 3; } break;
+          case 3: if (c == '\n') state = 4; break;
+          case 4: if (c == '\n') state = 0; break;
+          case 6: if (c == '>') { end_read(f); state = 1; }
+                  else if (c != '\n') { add_base(f,c); state = 5; }
+                  break;
+          case 5: if (c == '\n') state = 6; else add_base(f,c); break;
+        }
+      }
+  if (state == 6)
+    end_read(f);
+  gzclose(in);
+}
+
+int main(int argc, char *argv[])
+{ fk_params  prm;
+  fk_ctx    *ctx;
+  fk_result *res;
+  Feeder     feed;
+  char      *root = NULL, *dir = NULL, name[4096];
+  int        i, j, nfiles;
+
+  for (i = j = 1; i < argc; i++)
+    if (argv[i][0] == '-')
+      switch (argv[i][1])
+      { case 'k': KMER = atoi(argv[i]+2); break;
+        case 'T': NTHREADS = atoi(argv[i]+2); break;
+        case 't': DO_TABLE = (argv[i][2] == '\0') ? 1 : atoi(argv[i]+2); break;
+        case 'b':
+          if (argv[i][2] != 'c')
+            { fprintf(stderr,"\n%s: -%s is not a legal optional argument\n",Prog_Name,argv[i]); exit (1); }
+          BC_PREFIX = atoi(argv[i]+3);
+          break;
+        case 'v': VERBOSE = 1; break;
+        case 'N': OUT_NAME = argv[i]+2; break;
+        case 'P': case 'M': break;
+        case 'p': case 'c':
+          fprintf(stderr,"%s: option %s is not built in this engine yet (see DESIGN.md)\n",Prog_Name,argv[i]);
+          exit (1);
+        default:
+          fprintf(stderr,"\n%s: %s is not a legal optional argument\n",Prog_Name,argv[i]);
+          exit (1);
+      }
+    else
+      argv[j++] = argv[i];
+  nfiles = j-1;
+  if (nfiles < 1 || KMER <= 0 || NTHREADS <= 0 || DO_TABLE < 0 || BC_PREFIX < 0)
+    { fprintf(stderr,"\nUsage: %s [-k<int(40)>] [-t[<int(1)>]] [-bc<int>] [-v] [-N<path_name>]\n",Prog_Name);
+      fprintf(stderr,"       %*s [-P<dir>] [-M<int>] [-T<int(4)>] <source>[.fa|.fasta|.fq|.fastq][.gz] ...\n",
+              (int) strlen(Prog_Name),"");
+      exit (1);
+    }
+
+  fk_default_params(&prm);
+  prm.kmer = KMER; prm.table_cutoff = DO_TABLE; prm.nthreads = NTHREADS; prm.bc_prefix = BC_PREFIX;
+  if (fk_create(&prm,&ctx) != FK_OK)
+    die(NULL,"fk_create");
+
+  memset(&feed,0,sizeof(feed));
+  feed.ctx   = ctx;
+  feed.bases = malloc(BLOCK_BYTES+16);
+  feed.boff  = malloc(sizeof(int32_t)*(BLOCK_READS+2));
+  res        = malloc(sizeof(fk_result));
+  if (feed.bases == NULL || feed.boff == NULL || res == NULL)
+    { fprintf(stderr,"%s: Out of memory\n",Prog_Name); exit (1); }
+  feed.boff[0] = 0;
+
+  for (i = 1; i <= nfiles; i++)
+    { char *r, *d;
+      int   q = classify(argv[i],&r,&d);
+      if (q < 0)
+        { fprintf(stderr,"%s: %s is not a .fa/.fasta/.fq/.fastq[.gz] file (other inputs are not built)\n",
+                  Prog_Name,argv[i]);
+          exit (1);
+        }
+      if (i == 1)
+        { root = r; dir = d; }            /* outputs take the first file's root, FastK.c:402-405 */
+      else
+        { free(r); free(d); }
+      scan_file(&feed,argv[i],q);
+    }
+  flush_block(&feed,0);
+  if (OUT_NAME != NULL)                   /* -N, FastK.c:406-409 */
+    { char *slash = strrchr(OUT_NAME,'/');
+      free(root); free(dir);
+      root = strdup(slash ? slash+1 : OUT_NAME);
+      dir  = slash ? strndup(OUT_NAME,(size_t) (slash-OUT_NAME)) : strdup(".");
+    }
+
+  if (fk_finish(ctx,res) != FK_OK)
+    die(ctx,"fk_finish");
+
+  if (VERBOSE)
+    { fprintf(stderr,"\n  There are %lld reads totalling %lld bps\n",(long long) feed.totrds,(long long) feed.totbps);
+      fprintf(stderr,"  %lld %d-mers in %lld super-mers (%lld distinct), %lld weighted k-mers, %lld distinct\n",
+              (long long) res->ninst,KMER,(long long) res->nsuper,(long long) res->ndistinct_super,
+              (long long) res->nweighted,(long long) res->ndistinct);
+      fprintf(stderr,"  Device ms: split %.2f  sort %.2f  expand %.2f  sort %.2f  count %.2f  total %.2f\n",
+              res->ms_split,res->ms_sort_super,res->ms_expand,res->ms_sort_kmer,res->ms_count,res->ms_total);
+      if (DO_TABLE > 0)
+        fprintf(stderr,"  There are %lld %d-mers that occur %d-or-more times\n",(long long) res->ntable,KMER,DO_TABLE);
+    }
+
+  snprintf(name,sizeof(name),"%s/%s.hist",dir,root);
+  if (fk_write_hist(res,KMER,name) != FK_OK)
+    die(ctx,"writing .hist");
+  if (DO_TABLE > 0 && fk_write_ktab(res,KMER,DO_TABLE,NTHREADS,dir,root) != FK_OK)
+    die(ctx,"writing .ktab");
+
+  fk_destroy(ctx);
+  free(feed.bases); free(feed.boff); free(res); free(root); free(dir);
+  exit (0);
+}

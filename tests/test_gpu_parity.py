@@ -223,3 +223,40 @@ def test_bc_prefix_matches_oracle():
         res = ctx.finish()
     assert res.ninst == exp.ninst
     assert np.array_equal(res.hist[1:], exp.hist[1:]) and np.array_equal(res.table, exp.table)
+
+
+# ------------------------------------------------------------------------------ C host driver
+
+@pytest.mark.parametrize("name,fmt,gz", [("edge_k40_t1_T4", "fasta", False),
+                                         ("synth_illumina_k51_t1_T4", "fastq", True),
+                                         ("synth_hifi_k40_t4_T8", "fasta", False)])
+def test_cli_outputs_match_reference(name, fmt, gz, tmp_path):
+    """fastk_amd/bin/FastK_amd (C host over the C-ABI) with FastK's flags: .hist bytes and the
+    .ktab canonical stream equal the reference's; the reference-built Tabex/Histex accept them."""
+    import gzip, hashlib, os, subprocess
+    case, bases, boff = util.load_case(name)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "fastk_amd", "bin", "FastK_amd")
+    assert os.path.exists(exe), "build fastk_amd/csrc first"
+    path = str(tmp_path / ("reads." + fmt))
+    (orc.write_fasta if fmt == "fasta" else orc.write_fastq)(path, bases, boff)
+    if fmt == "fasta" and name.startswith("synth_hifi"):
+        orc.write_fasta(path, bases, boff, width=80)          # multi-line FASTA
+    if gz:
+        with open(path, "rb") as f, gzip.open(path + ".gz", "wb") as g:
+            g.write(f.read())
+        os.remove(path)
+        path += ".gz"
+    subprocess.run([exe, "-k%d" % case["k"], "-t%d" % case["cutoff"], "-T%d" % case["T"], "-v", path],
+                   check=True, cwd=str(tmp_path))
+    exp = case["expected"]
+    hist = open(tmp_path / "reads.hist", "rb").read()
+    assert hashlib.sha256(hist).hexdigest() == exp["hist_sha256"]
+    t = orc.read_ktab(str(tmp_path / "reads"))
+    assert t["stream_sha256"] == exp["ktab"]["stream_sha256"]
+    assert (t["nparts"], t["minval"], t["ibytes"], t["nels"]) == \
+        (case["T"], case["cutoff"], exp["ktab"]["ibytes"], exp["ktab"]["nels"])
+    tabex = os.path.join(orc.REF_DIR, "Tabex")
+    if os.path.exists(tabex):
+        out = subprocess.run([tabex, "-C", str(tmp_path / "reads")], capture_output=True, text=True)
+        assert "Table is OK" in out.stdout + out.stderr

@@ -1,0 +1,103 @@
+"""The N>1 path on CPU: world_size-2 gloo run of fastk_amd.shard.count_sharded with a checker
+engine built from the oracle (tests may use the oracle; the product engine is HipEngine).
+Verifies the exchange logic: bucket -> rank routing, all-to-all-v sizes, histogram all-reduce."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import orc
+from tests import util
+
+
+class OracleEngine:
+    """split / count stages on CPU tensors using the oracle; bucket = f(minimizer of the super-mer)
+    so that equal canonical k-mers always land in the same bucket (FastK.h:3-7)."""
+
+    def __init__(self, kmer, world, cutoff):
+        self.P = orc.params(kmer)
+        self.world = world
+        self.cutoff = cutoff
+        self.stride = self.P.smer_word
+
+    def _bucket(self, rec):
+        P = self.P
+        n = int(rec[P.smer_bytes]) + 1
+        L = n - 1 + P.kmer
+        codes = [(int(rec[i >> 2]) >> (6 - 2 * (i & 3))) & 3 for i in range(L)]
+        best = None
+        for j in range(L - 4):
+            f = 0
+            r = 0
+            for t in range(5):
+                f = f * 4 + codes[j + t]
+                r = r * 4 + (3 - codes[j + 4 - t])
+            v = min(f, r)
+            best = v if best is None else min(best, v)
+        return (best * 2654435761 >> 7) % self.world
+
+    def split(self, reads):
+        bases = reads.numpy()
+        ends = np.nonzero(bases == 0)[0]
+        boff = np.concatenate([[0], ends + 1]).astype(np.int64)
+        recs, ninst = orc.distribute(self.P, bases, boff)
+        b = np.array([self._bucket(r) for r in recs], dtype=np.int64)
+        order = np.argsort(b, kind="stable")
+        counts = np.bincount(b, minlength=self.world).tolist()
+        out = torch.from_numpy(np.ascontiguousarray(recs[order]).reshape(-1))
+        return out, counts, ninst
+
+    def count_supermers(self, recs, nsuper):
+        P = self.P
+        a = recs.numpy().reshape(nsuper, P.smer_word)
+        ss = orc.msd_sort(a, P.smer_word)
+        kl, ovf, nd = orc.kmer_list(P, ss)
+        ks = orc.msd_sort(kl, P.kmer_bytes)
+        res = orc.count_sorted(P, ks, self.cutoff)
+        return dict(hist=res.hist, max_inst=res.max_inst + ovf, nweighted=len(kl),
+                    ndistinct=res.ndistinct, ntable=res.ntable, result=res)
+
+
+def _worker(rank, world, port, name, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from fastk_amd import shard
+    case, bases, boff = util.load_case(name)
+    nreads = len(boff) - 1
+    lo, hi = rank * nreads // world, (rank + 1) * nreads // world
+    mine = torch.from_numpy(bases[boff[lo]:boff[hi]].copy())
+    eng = OracleEngine(case["k"], world, case["cutoff"])
+    out = shard.count_sharded(eng, mine)
+    tabs = [None] * world
+    dist.all_gather_object(tabs, out["local"]["result"].table)
+    if rank == 0:
+        q.put(dict(hist=out["hist"], max_inst=out["max_inst"], ninst=out["ninst"],
+                   ntable=out["ntable"], ndistinct=out["ndistinct"], tables=tabs))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["synth_tiny_k40_t1_T2", "edge_k21_t2_T3"])
+def test_two_rank_shard_matches_golden(name):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, name, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    case, bases, boff = util.load_case(name)
+    exp = orc.fastk(case["k"], bases, boff, cutoff=case["cutoff"])
+    assert got["ninst"] == exp.ninst
+    assert got["ndistinct"] == exp.ndistinct and got["ntable"] == exp.ntable
+    # ranks hold disjoint k-mer sets; their merged tables are the reference table
+    merged = np.concatenate([t for t in got["tables"] if len(t)])
+    order = np.lexsort(merged[:, :orc.params(case["k"]).kmer_bytes].T[::-1])
+    util.check_against_golden(case, got["hist"], got["max_inst"], merged[order])
