@@ -19,7 +19,7 @@ EXPORTS = [
     "fk_write_hist", "fk_write_ktab", "fk_split_supermers", "fk_lsd_sort_records",
     "fk_msd_sort_records", "fk_expand_kmers", "fk_count_kmers", "fk_synth_reads",
     "fk_device_alloc", "fk_device_free", "fk_copy_to_device", "fk_copy_to_host",
-    "fk_get_sort_stats", "fk_version", "fk_count_device_reads", "fk_count_device_supermers", "fk_debug_set",
+    "fk_get_sort_stats", "fk_version", "fk_count_device_reads", "fk_count_device_supermers", "fk_debug_set", "fk_group_records",
 ]
 
 
@@ -87,6 +87,7 @@ def load_library():
     L.fk_write_ktab.argtypes = [C.POINTER(CResult), ci, ci, ci, C.c_char_p, C.c_char_p]
     L.fk_split_supermers.argtypes = [vp, vp, i64, vp, i64, C.POINTER(i64), C.POINTER(i64), vp]
     L.fk_lsd_sort_records.argtypes = [vp, i64, vp, vp, ci, C.POINTER(ci), C.POINTER(vp)]
+    L.fk_group_records.argtypes = [vp, i64, vp, vp, ci, C.POINTER(vp)]
     L.fk_msd_sort_records.argtypes = [vp, vp, vp, i64, ci, ci, C.POINTER(vp)]
     L.fk_expand_kmers.argtypes = [vp, vp, i64, vp, i64, C.POINTER(i64), C.POINTER(i64),
                                   C.POINTER(i64)]
@@ -259,6 +260,11 @@ class Context:
         res = C.c_void_p()
         self._ck(self.L.fk_lsd_sort_records(self.h, nelem, src_ptr, trg_ptr, rsize, bl,
                                             C.byref(res)))
+        return res.value
+
+    def group(self, src_ptr, trg_ptr, nelem, rsize):
+        res = C.c_void_p()
+        self._ck(self.L.fk_group_records(self.h, nelem, src_ptr, trg_ptr, rsize, C.byref(res)))
         return res.value
 
     def msd_sort(self, arr_ptr, tmp_ptr, nelem, rsize, ksize):

@@ -29,6 +29,9 @@ void *fk_slot(fk_ctx *ctx, int slot, int64_t nbytes)
       ctx->slot_ptr[slot] = NULL;
       ctx->slot_cap[slot] = 0;
     }
+  // a little headroom, so that run-to-run jitter of data-dependent sizes (hash collisions in the
+  // super-mer grouping change W by a few records) does not re-allocate multi-GB buffers
+  nbytes += nbytes / 32 + (1 << 20);
   void *p = NULL;
   if (hipMalloc(&p, (size_t) nbytes) != hipSuccess)
     { fk_set_error(ctx, "out of HBM: cannot allocate %lld bytes (arena slot %d)",
@@ -334,6 +337,12 @@ extern "C" int fk_msd_sort_records(fk_ctx *ctx, void *d_array, void *d_tmp, int6
   return fkx_lsd_sort(ctx, nelem, d_array, d_tmp, rsize, bytes, ksize, result);
 }
 
+extern "C" int fk_group_records(fk_ctx *ctx, int64_t nelem, void *d_src, void *d_trg, int rsize,
+                                void **result)
+{ if (ctx == NULL || result == NULL || nelem < 0) return (FK_EINVAL);
+  return fkx_group(ctx, nelem, d_src, d_trg, rsize, result);
+}
+
 extern "C" int fk_expand_kmers(fk_ctx *ctx, const void *d_smers, int64_t nsuper, void *d_out,
                                int64_t cap, int64_t *nweighted, int64_t *ndistinct,
                                int64_t *overflow)
@@ -500,13 +509,10 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
         { rc = FK_ENOMEM; break; }
       hipEventRecord(ev[1], s);
 
-      // super-mer sort (key = whole record, MSDsort.c:458 called with ksize = SMER_WORD)
+      // super-mer "sort": only has to bring identical records together (Supermer_Sort's output is
+      // consumed by the run-length pass of count.c:421-426), so five hashed digit passes suffice
       void *sm_sorted = sm_in;
-      { int bytes[64];
-        for (int i = 0; i < w.smer_word; i++)
-          bytes[i] = w.smer_word - 1 - i;
-        if ((rc = fkx_lsd_sort(ctx, ns, sm_in, sm_b, w.smer_stride, bytes, w.smer_word,
-                               &sm_sorted)) != FK_OK)
+      { if ((rc = fkx_group(ctx, ns, sm_in, sm_b, w.smer_stride, &sm_sorted)) != FK_OK)
           break;
         res->passes_super  = ctx->sort_stats.passes;
         res->ms_pass_super = ctx->sort_stats.pass_ms_total;

@@ -83,6 +83,7 @@ void fk_set_error(fk_ctx *ctx, const char *fmt, ...);
 // stage entry points implemented in the per-stage .hip files (C++ linkage, internal)
 int fkx_lsd_sort(fk_ctx *ctx, int64_t nelem, void *d_src, void *d_trg, int rsize,
                  const int *bytes, int nbytes, void **result);
+int fkx_group(fk_ctx *ctx, int64_t nelem, void *d_src, void *d_trg, int rsize, void **result);
 int fkx_split(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int64_t cap,
               int64_t *nsuper, int64_t *ninst, int64_t *bucket_counts, bool counts_known);
 int fkx_expand(fk_ctx *ctx, const void *d_smers, int64_t nsuper, void *d_out, int64_t cap,

@@ -34,6 +34,48 @@ __device__ __forceinline__ u64 st_pack(u32 epoch, u64 flag, u64 val)
 { return (((u64) epoch) << 56) | (flag << 54) | val; }
 
 // ---------------------------------------------------------------------------------------------
+// 64-bit mix of a whole record, for GROUPING identical records (fkx_group): the digit of pass p is
+// byte p of the hash, so five passes make identical records adjacent whatever their width.
+template <int RW>
+__device__ __forceinline__ u32 rx_hash_digit(const u32 *r, int byte_idx)
+{ u32 a = 0x9E3779B9u, b = 0x85EBCA6Bu;
+#pragma unroll
+  for (int w = 0; w < RW; w++)
+    { a = (a ^ r[w]) * 0xCC9E2D51u;
+      a = (a << 15) | (a >> 17);
+      b = (b + r[w]) * 0x1B873593u;
+      b = ((b << 13) | (b >> 19)) ^ a;
+    }
+  a ^= b >> 16; a *= 0x85EBCA6Bu;
+  b ^= a >> 13; b *= 0xC2B2AE35u;
+  a ^= b >> 15;
+  const u32 x = (byte_idx < 4) ? b : a;
+  return (x >> (8 * (byte_idx & 3))) & 0xffu;
+}
+
+template <int RW>
+__global__ __launch_bounds__(RX_THREADS) void k_hash_hist(const u32 *__restrict__ src, int64_t n,
+                                                          int nbytes, u64 *__restrict__ out)
+{ __shared__ u32 h[8 * 256];
+  for (int i = threadIdx.x; i < 8 * 256; i += RX_THREADS)
+    h[i] = 0;
+  __syncthreads();
+  for (int64_t i = (int64_t) blockIdx.x * RX_THREADS + threadIdx.x; i < n;
+       i += (int64_t) gridDim.x * RX_THREADS)
+    { u32 r[RW];
+#pragma unroll
+      for (int w = 0; w < RW; w++)
+        r[w] = src[i * RW + w];
+      for (int b = 0; b < nbytes; b++)
+        atomicAdd(&h[b * 256 + rx_hash_digit<RW>(r, b)], 1u);
+    }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 8 * 256; i += RX_THREADS)
+    if (h[i] != 0)
+      atomicAdd(&out[i], (u64) h[i]);
+}
+
+// ---------------------------------------------------------------------------------------------
 // digit histograms for every byte of the record selected in `want`
 template <int RW>
 __global__ __launch_bounds__(RX_THREADS) void k_digit_hist(const u32 *__restrict__ src, int64_t n,
@@ -68,7 +110,7 @@ __global__ __launch_bounds__(RX_THREADS) void k_digit_hist(const u32 *__restrict
 //   2 = no ranking, no look-back (tile streamed through LDS, linear store)
 //   3 = real ranking and LDS permutation, no look-back, linear store
 //   4 = as 1, but every XCD works on one contiguous range of tiles (L2 write-combining test)
-template <int RW, int ITEMS, int VARIANT>
+template <int RW, int ITEMS, int VARIANT, bool HASHED>
 __global__ __launch_bounds__(RX_THREADS) void k_radix_pass(const u32 *__restrict__ src,
                                                            u32 *__restrict__ dst, int64_t n,
                                                            int byte_idx,
@@ -85,6 +127,7 @@ __global__ __launch_bounds__(RX_THREADS) void k_radix_pass(const u32 *__restrict
   u32      *tmp32    = binstart + 256;                                 // 8
   u32      *s_tile   = tmp32 + 8;                                      // 4 (keeps perm 16-B aligned)
   uint16_t *perm     = (uint16_t *) (s_tile + 4);                      // TILE: sorted slot -> record
+  u32      *perm32   = (u32 *) (s_tile + 4);                           // HASHED: record | digit << 16
 
   const int tid  = threadIdx.x;
   const int lane = tid & 63;
@@ -150,7 +193,8 @@ __global__ __launch_bounds__(RX_THREADS) void k_radix_pass(const u32 *__restrict
   for (int it = 0; it < ITEMS; it++)
     { const int  r     = wbase + it * 64 + lane;
       const bool valid = (r < tn);
-      const u32  d     = valid ? (u32) lbytes[r * RW * 4 + byte_idx] : 0u;
+      const u32  d     = !valid ? 0u : HASHED ? rx_hash_digit<RW>(recs + r * RW, byte_idx)
+                                              : (u32) lbytes[r * RW * 4 + byte_idx];
       u64 mask = __ballot(valid);
 #pragma unroll
       for (int b = 0; b < 8; b++)
@@ -236,7 +280,10 @@ __global__ __launch_bounds__(RX_THREADS) void k_radix_pass(const u32 *__restrict
         { const u32 e   = info[it];
           const u32 d   = e & 0xffu;
           const u32 pos = (VARIANT == 2) ? (u32) r : binstart[d] + whist[wave * 256 + d] + (e >> 8);
-          perm[pos] = (uint16_t) r;
+          if (HASHED)
+            perm32[pos] = (u32) r | (d << 16);
+          else
+            perm[pos] = (uint16_t) r;
         }
     }
   __syncthreads();
@@ -246,8 +293,17 @@ __global__ __launch_bounds__(RX_THREADS) void k_radix_pass(const u32 *__restrict
   for (int j = tid; j < ndw; j += RX_THREADS)
     { const int p   = j / RW;
       const int w   = j - p * RW;
-      const int sr  = perm[p];
-      const u32 d   = lbytes[sr * RW * 4 + byte_idx];
+      int sr;
+      u32 d;
+      if (HASHED)
+        { const u32 e = perm32[p];
+          sr = (int) (e & 0xffffu);
+          d  = e >> 16;
+        }
+      else
+        { sr = perm[p];
+          d  = lbytes[sr * RW * 4 + byte_idx];
+        }
       int64_t g = (goff[d] + p) * RW + w;
       if (VARIANT == 2 || VARIANT == 3)
         g = (tstart + p) * RW + w;
@@ -257,12 +313,13 @@ __global__ __launch_bounds__(RX_THREADS) void k_radix_pass(const u32 *__restrict
     }
 }
 
-template <int RW, int ITEMS> static size_t rx_lds_bytes()
+template <int RW, int ITEMS> static size_t rx_lds_bytes(bool hashed)
 { return ((size_t) RX_THREADS * ITEMS * RW * 4 + 256 * 8 + 8 * 8 + RX_WAVES * 256 * 4 + 256 * 4
-          + 8 * 4 + 16 + (size_t) RX_THREADS * ITEMS * 2 + 16);
+          + 8 * 4 + 16 + (size_t) RX_THREADS * ITEMS * (hashed ? 4 : 2) + 16);
 }
 
-template <int RW, int ITEMS>
+// hashed: bytes[] index the record hash (rx_hash_digit) instead of the record itself
+template <int RW, int ITEMS, bool HASHED>
 static int lsd_sort_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, const int *bytes,
                       int nbytes, void **result)
 { constexpr int TILE = RX_THREADS * ITEMS;
@@ -283,7 +340,7 @@ static int lsd_sort_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, const in
       return (FK_EINVAL);
     }
   for (int i = 0; i < nbytes; i++)
-    { if (bytes[i] < 0 || bytes[i] >= RW * 4)
+    { if (bytes[i] < 0 || bytes[i] >= (HASHED ? 8 : RW * 4))
         { fk_set_error(ctx, "key byte %d outside record of %d bytes", bytes[i], RW * 4);
           return (FK_EINVAL);
         }
@@ -305,12 +362,16 @@ static int lsd_sort_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, const in
   FK_HIP(ctx, hipEventRecord(ctx->ev0, s));
   { int64_t nb = (n + RX_THREADS - 1) / RX_THREADS;
     if (nb > 1024) nb = 1024;
-    hipLaunchKernelGGL(k_digit_hist<RW>, dim3((unsigned) nb), dim3(RX_THREADS), 0, s,
-                       (const u32 *) d_src, n, want, ctx->d_digit_hist);
+    if (HASHED)
+      hipLaunchKernelGGL(k_hash_hist<RW>, dim3((unsigned) nb), dim3(RX_THREADS), 0, s,
+                         (const u32 *) d_src, n, 8, ctx->d_digit_hist);
+    else
+      hipLaunchKernelGGL(k_digit_hist<RW>, dim3((unsigned) nb), dim3(RX_THREADS), 0, s,
+                         (const u32 *) d_src, n, want, ctx->d_digit_hist);
     FK_LAUNCH_CHECK(ctx);
   }
   FK_HIP(ctx, hipEventRecord(ctx->ev1, s));
-  FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch, ctx->d_digit_hist, (size_t) RW * 4 * 256 * 8,
+  FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch, ctx->d_digit_hist, (size_t) (HASHED ? 8 : RW * 4) * 256 * 8,
                              hipMemcpyDeviceToHost, s));
   FK_HIP(ctx, hipStreamSynchronize(s));
   { float ms = 0.f;
@@ -318,7 +379,7 @@ static int lsd_sort_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, const in
     ctx->sort_stats.hist_ms = ms;
   }
 
-  const size_t lds_bytes = rx_lds_bytes<RW, ITEMS>();
+  const size_t lds_bytes = rx_lds_bytes<RW, ITEMS>(HASHED);
   u32 *src = (u32 *) d_src, *trg = (u32 *) d_trg;
   int  passes = 0;
   FK_HIP(ctx, hipEventRecord(ctx->ev0, s));
@@ -331,7 +392,7 @@ static int lsd_sort_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, const in
       if (constant)
         continue;        // every record carries the same digit: the pass is the identity
 #define RX_LAUNCH(V)                                                                              \
-      hipLaunchKernelGGL((k_radix_pass<RW, ITEMS, V>), dim3((unsigned) ntiles), dim3(RX_THREADS),    \
+      hipLaunchKernelGGL((k_radix_pass<RW, ITEMS, V, HASHED>), dim3((unsigned) ntiles), dim3(RX_THREADS), \
                          lds_bytes, s, (const u32 *) src, trg, n, bytes[i],                         \
                          (const u64 *) (ctx->d_digit_hist + (size_t) bytes[i] * 256),               \
                          ctx->d_status, ctx->d_ticket + passes, (u32) (passes + 1))
@@ -356,31 +417,42 @@ static int lsd_sort_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, const in
   return (FK_OK);
 }
 
-int fkx_lsd_sort(fk_ctx *ctx, int64_t nelem, void *d_src, void *d_trg, int rsize,
-                 const int *bytes, int nbytes, void **result)
+template <bool HASHED>
+static int sort_dispatch(fk_ctx *ctx, int64_t nelem, void *d_src, void *d_trg, int rsize,
+                         const int *bytes, int nbytes, void **result)
 { if (rsize <= 0 || (rsize & 3) != 0 || rsize > 32)
     { fk_set_error(ctx, "record size %d not supported (multiple of 4, <= 32)", rsize);
       return (FK_EUNSUPPORTED);
     }
   const int it = ctx->dbg_radix_items;      // measurement aid: alternative tile sizes for R = 12, 20
-#define RX_CASE(RW) return lsd_sort_t<RW, RxCfg<RW>::ITEMS>(ctx, nelem, d_src, d_trg, bytes, nbytes, result)
+#define RX_CASE(RW) return lsd_sort_t<RW, RxCfg<RW>::ITEMS, HASHED>(ctx, nelem, d_src, d_trg, bytes, nbytes, result)
   switch (rsize >> 2)
   { case 1: RX_CASE(1);
     case 2: RX_CASE(2);
     case 3:
-      if (it == 8)  return lsd_sort_t<3, 8>(ctx, nelem, d_src, d_trg, bytes, nbytes, result);
-      if (it == 16) return lsd_sort_t<3, 16>(ctx, nelem, d_src, d_trg, bytes, nbytes, result);
-      if (it == 20) return lsd_sort_t<3, 20>(ctx, nelem, d_src, d_trg, bytes, nbytes, result);
+      if (!HASHED && it == 8)  return lsd_sort_t<3, 8, HASHED>(ctx, nelem, d_src, d_trg, bytes, nbytes, result);
+      if (!HASHED && it == 16) return lsd_sort_t<3, 16, HASHED>(ctx, nelem, d_src, d_trg, bytes, nbytes, result);
       RX_CASE(3);
     case 4: RX_CASE(4);
     case 5:
-      if (it == 8)  return lsd_sort_t<5, 4>(ctx, nelem, d_src, d_trg, bytes, nbytes, result);
-      if (it == 16) return lsd_sort_t<5, 12>(ctx, nelem, d_src, d_trg, bytes, nbytes, result);
-      if (it == 20) return lsd_sort_t<5, 16>(ctx, nelem, d_src, d_trg, bytes, nbytes, result);
+      if (!HASHED && it == 16) return lsd_sort_t<5, 12, HASHED>(ctx, nelem, d_src, d_trg, bytes, nbytes, result);
       RX_CASE(5);
     case 6: RX_CASE(6);
     case 7: RX_CASE(7);
     default: RX_CASE(8);
   }
 #undef RX_CASE
+}
+
+int fkx_lsd_sort(fk_ctx *ctx, int64_t nelem, void *d_src, void *d_trg, int rsize,
+                 const int *bytes, int nbytes, void **result)
+{ return sort_dispatch<false>(ctx, nelem, d_src, d_trg, rsize, bytes, nbytes, result); }
+
+// Make identical records adjacent: five stable digit passes over a 40-bit hash of the whole record.
+// This is all the super-mer "sort" has to achieve (count.c:421-426 only run-length encodes
+// duplicates); records that collide in 40 bits merely stay un-merged, which the weighted k-mer
+// stage absorbs because it sums weights per k-mer anyway.
+int fkx_group(fk_ctx *ctx, int64_t nelem, void *d_src, void *d_trg, int rsize, void **result)
+{ static const int bytes[5] = { 0, 1, 2, 3, 4 };
+  return sort_dispatch<true>(ctx, nelem, d_src, d_trg, rsize, bytes, 5, result);
 }

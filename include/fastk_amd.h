@@ -152,7 +152,15 @@ int fk_lsd_sort_records(fk_ctx *ctx, int64_t nelem, void *d_src, void *d_trg, in
 int fk_msd_sort_records(fk_ctx *ctx, void *d_array, void *d_tmp, int64_t nelem, int rsize,
                         int ksize, void **result);
 
-/* Weighted k-mer list from SORTED super-mers.  Replaces count_smers + kmer_list_thread
+/* Bring identical records together (stable, deterministic for a given input order): five digit
+   passes over a 40-bit hash of the whole record.  This is the only property of Supermer_Sort's
+   output that the next stage uses (the run-length pass of count.c:421-426); records whose hashes
+   collide simply stay un-merged, which cannot change any count because the weighted k-mer stage
+   sums weights per k-mer.  The pipeline uses this instead of a 20-byte lexicographic sort. */
+int fk_group_records(fk_ctx *ctx, int64_t nelem, void *d_src, void *d_trg, int rsize,
+                     void **result);
+
+/* Weighted k-mer list from GROUPED (or sorted) super-mers.  Replaces count_smers + kmer_list_thread
    (MSDsort.c:381-456, count.c:339-542).  Call with d_out == NULL to size: *nweighted and
    *ndistinct are set.  *overflow as count.c:455-458. */
 int fk_expand_kmers(fk_ctx *ctx, const void *d_smers, int64_t nsuper, void *d_out, int64_t cap,

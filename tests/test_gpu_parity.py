@@ -260,3 +260,21 @@ def test_cli_outputs_match_reference(name, fmt, gz, tmp_path):
     if os.path.exists(tabex):
         out = subprocess.run([tabex, "-C", str(tmp_path / "reads")], capture_output=True, text=True)
         assert "Table is OK" in out.stdout + out.stderr
+
+
+def test_group_records_brings_duplicates_together(ctx40):
+    """fk_group_records: a permutation of the input in which equal records are adjacent."""
+    rng = np.random.default_rng(21)
+    n, rsize = 300000, 20
+    distinct = rng.integers(0, 256, size=(20000, rsize), dtype=np.uint8)
+    recs = distinct[rng.integers(0, len(distinct), size=n)]
+    a = ctx40.alloc(recs.nbytes).upload(recs)
+    b = ctx40.alloc(recs.nbytes)
+    res = ctx40.group(a.ptr, b.ptr, n, rsize)
+    got = a.download(recs.nbytes, ptr=res).reshape(n, rsize)
+    # same multiset
+    assert np.array_equal(orc.msd_sort(got, rsize), orc.msd_sort(recs, rsize))
+    # number of runs == number of distinct records (no 40-bit collision expected at this size)
+    runs = 1 + int(np.any(got[1:] != got[:-1], axis=1).sum())
+    assert runs == len(np.unique(recs, axis=0))
+    a.free(); b.free()
