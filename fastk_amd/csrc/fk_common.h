@@ -132,6 +132,39 @@ __device__ __forceinline__ T fk_block_exscan_256(T v, T *tmp, T *total)
   return (base + x - v);
 }
 
+// Stage `ndw` dwords from 16-byte aligned global memory into 16-byte aligned LDS with a 256-thread
+// block.  NV = ceil(max ndw / 1024).  Every 16-byte load is issued before the first LDS write (a
+// plain copy loop with a run-time trip count compiles to load / wait / store per iteration, i.e.
+// one HBM latency per 16 bytes and thread).  SWAP: byte-swap every dword on the way.
+template <int NV, bool SWAP>
+__device__ __forceinline__ void fk_stage16(u32 *lds, const u32 *g, int ndw)
+{ const uint4 *g4 = (const uint4 *) g;
+  uint4       *l4 = (uint4 *) lds;
+  const int    n4 = ndw >> 2;
+  if (n4 > 0)
+    { uint4 v[NV];
+#pragma unroll
+      for (int k = 0; k < NV; k++)
+        { const int i = (int) threadIdx.x + k * 256;
+          v[k] = g4[i < n4 ? i : n4 - 1];
+        }
+#pragma unroll
+      for (int k = 0; k < NV; k++)
+        { const int i = (int) threadIdx.x + k * 256;
+          if (i < n4)
+            { uint4 x = v[k];
+              if (SWAP)
+                { x.x = __builtin_bswap32(x.x); x.y = __builtin_bswap32(x.y);
+                  x.z = __builtin_bswap32(x.z); x.w = __builtin_bswap32(x.w);
+                }
+              l4[i] = x;
+            }
+        }
+    }
+  for (int i = (n4 << 2) + (int) threadIdx.x; i < ndw; i += 256)
+    lds[i] = SWAP ? __builtin_bswap32(g[i]) : g[i];
+}
+
 // exclusive scan of u32 per-tile counts into u64 offsets (single workgroup; one copy per TU)
 static __global__ __launch_bounds__(256) void k_exscan_tiles(const u32 *__restrict__ in, int64_t n,
                                                       u64 *__restrict__ out, u64 *__restrict__ total)

@@ -65,13 +65,12 @@ __global__ __launch_bounds__(EX_THREADS) void k_ex_expand(const u32 *__restrict_
                                                           const u64 *__restrict__ tile_koff,
                                                           u32 *__restrict__ out,
                                                           u64 *__restrict__ overflow)
-{ __shared__ u32 recs[EX_TILE * RW];     // big-endian value words
+{ __shared__ __attribute__((aligned(16))) u32 recs[EX_TILE * RW];     // big-endian value words
   __shared__ u32 tmp[8];
 
   const int64_t t0 = (int64_t) blockIdx.x * EX_TILE;
   const int     tn = (n - t0 < EX_TILE) ? (int) (n - t0) : EX_TILE;
-  for (int j = threadIdx.x; j < tn * RW; j += EX_THREADS)
-    recs[j] = __builtin_bswap32(sm[t0 * RW + j]);
+  fk_stage16<(EX_TILE * RW + 1023) / 1024, true>(recs, sm + t0 * RW, tn * RW);
   __syncthreads();
 
   const int  pad   = 32 * KN - 2 * kmer;           // unused low bits of the last k-mer word

@@ -26,6 +26,7 @@
 #define SP_MAXK    128
 #define SP_WORDS   (SP_TILE / 16 + SP_MAXK / 16 + 2)   // packed words incl. halo and guard
 #define SP_KEYS    (SP_TILE + SP_MAXK)
+#define SP_KIDX(i) ((i) + ((i) >> 4))     // one pad word per 16 keys: thread t's chunk starts at bank 17t
 
 struct SplitArgs
 { const unsigned char *bases;
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
   __shared__ u32      rcw[SP_WORDS];
   __shared__ uint16_t inv16[SP_WORDS];
   __shared__ uint16_t wpre[SP_WORDS];
-  __shared__ u32      keys[SP_KEYS];
+  __shared__ u32      keys[SP_KEYS + SP_KEYS / 16 + 1];
   __shared__ uint16_t mtab[1024];
   __shared__ uint8_t  mbucket[1024];
   __shared__ u32      lastkey[SP_THREADS];
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
   for (int j = tid; j < SP_TILE + W; j += SP_THREADS)
     { const u32 v = sp_window(fwd, j) >> 22;
       const u32 m = mtab[v];
-      keys[j] = (((m >> 1) << 14) | (u32) j) << 1 | (m & 1u);
+      keys[SP_KIDX(j)] = (((m >> 1) << 14) | (u32) j) << 1 | (m & 1u);
     }
   __syncthreads();
 
@@ -151,18 +152,18 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
   if (W >= SP_CH)
     { u32 core = 0xffffffffu;
       for (int j = i0 + SP_CH - 1; j <= i0 + W - 1; j++)
-        core = min(core, keys[j]);
+        core = min(core, keys[SP_KIDX(j)]);
       u32 run = 0xffffffffu;
       mk[SP_CH - 1] = core;
 #pragma unroll
       for (int c = SP_CH - 2; c >= 0; c--)
-        { run = min(run, keys[i0 + c]);
+        { run = min(run, keys[SP_KIDX(i0 + c)]);
           mk[c] = min(core, run);
         }
       run = 0xffffffffu;
 #pragma unroll
       for (int c = 1; c < SP_CH; c++)
-        { run = min(run, keys[i0 + W - 1 + c]);
+        { run = min(run, keys[SP_KIDX(i0 + W - 1 + c)]);
           mk[c] = min(mk[c], run);
         }
     }
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
       for (int c = 0; c < SP_CH; c++)
         { u32 m = 0xffffffffu;
           for (int j = 0; j < W; j++)
-            m = min(m, keys[i0 + c + j]);
+            m = min(m, keys[SP_KIDX(i0 + c + j)]);
           mk[c] = m;
         }
     }
