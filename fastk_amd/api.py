@@ -20,6 +20,7 @@ EXPORTS = [
     "fk_msd_sort_records", "fk_expand_kmers", "fk_count_kmers", "fk_synth_reads",
     "fk_device_alloc", "fk_device_free", "fk_copy_to_device", "fk_copy_to_host",
     "fk_get_sort_stats", "fk_version", "fk_count_device_reads", "fk_count_device_supermers", "fk_debug_set", "fk_group_records",
+    "fk_count_presorted_kmers",
 ]
 
 
@@ -93,6 +94,8 @@ def load_library():
                                   C.POINTER(i64)]
     L.fk_count_kmers.argtypes = [vp, vp, i64, ci, vp, C.POINTER(i64), C.POINTER(i64), vp, i64,
                                  C.POINTER(i64)]
+    L.fk_count_presorted_kmers.argtypes = [vp, vp, i64, ci, ci, vp, C.POINTER(i64), C.POINTER(i64), vp,
+                                           i64, C.POINTER(i64)]
     L.fk_synth_reads.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64,
                                  i64, vp]
     L.fk_device_alloc.argtypes = [vp, i64, C.POINTER(vp)]
@@ -285,9 +288,17 @@ class Context:
                                         C.byref(nd), C.byref(ov)))
         return nw.value, nd.value, ov.value
 
-    def count(self, kmers_ptr, nweighted, cutoff, table_ptr=None, cap=0):
+    def count(self, kmers_ptr, nweighted, cutoff, table_ptr=None, cap=0, sorted_bytes=None):
         hist = np.zeros(HIST_BINS, dtype=np.int64)
         mi, nd, nt = C.c_int64(0), C.c_int64(), C.c_int64()
-        self._ck(self.L.fk_count_kmers(self.h, kmers_ptr, nweighted, cutoff, hist.ctypes.data,
-                                       C.byref(mi), C.byref(nd), table_ptr, cap, C.byref(nt)))
+        if sorted_bytes is None:
+            rc = self.L.fk_count_kmers(self.h, kmers_ptr, nweighted, cutoff, hist.ctypes.data,
+                                       C.byref(mi), C.byref(nd), table_ptr, cap, C.byref(nt))
+        else:
+            rc = self.L.fk_count_presorted_kmers(self.h, kmers_ptr, nweighted, cutoff, sorted_bytes,
+                                                 hist.ctypes.data, C.byref(mi), C.byref(nd),
+                                                 table_ptr, cap, C.byref(nt))
+            if rc == -6:
+                return None
+        self._ck(rc)
         return hist, mi.value, nd.value, nt.value

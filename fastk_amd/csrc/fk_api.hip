@@ -356,7 +356,19 @@ extern "C" int fk_count_kmers(fk_ctx *ctx, const void *d_kmers, int64_t nweighte
                               int64_t *hist, int64_t *max_inst, int64_t *ndistinct, void *d_table,
                               int64_t cap, int64_t *ntable)
 { if (ctx == NULL || hist == NULL || max_inst == NULL || nweighted < 0) return (FK_EINVAL);
-  return fkx_count(ctx, d_kmers, nweighted, cutoff, hist, max_inst, ndistinct, d_table, cap, ntable);
+  return fkx_count(ctx, d_kmers, nweighted, cutoff, ctx->wid.kmer_bytes, hist, max_inst, ndistinct,
+                   d_table, cap, ntable);
+}
+
+extern "C" int fk_count_presorted_kmers(fk_ctx *ctx, const void *d_kmers, int64_t nweighted, int cutoff,
+                                        int sorted_bytes, int64_t *hist, int64_t *max_inst,
+                                        int64_t *ndistinct, void *d_table, int64_t cap, int64_t *ntable)
+{ if (ctx == NULL || hist == NULL || max_inst == NULL || nweighted < 0 || sorted_bytes < 1)
+    return (FK_EINVAL);
+  if (sorted_bytes > ctx->wid.kmer_bytes)
+    sorted_bytes = ctx->wid.kmer_bytes;
+  return fkx_count(ctx, d_kmers, nweighted, cutoff, sorted_bytes, hist, max_inst, ndistinct, d_table,
+                   cap, ntable);
 }
 
 // ---- streaming interface ------------------------------------------------------------------------
@@ -461,6 +473,11 @@ extern "C" int fk_push_device(fk_ctx *ctx, const void *d_bases, int64_t nbytes)
 }
 
 // ---- whole path: split -> sort -> expand -> sort -> count ----------------------------------------
+// 64 = disabled: sort every key byte.  A shorter prefix (fk_count_presorted_kmers) does not pay on
+// read data: one-substitution error k-mers share long prefixes with their true k-mer, so about half
+// of all prefix runs are heterogeneous and would need a local sort (measured).
+#define FK_PREFIX_BYTES 64
+
 static double ms_between(hipEvent_t a, hipEvent_t b)
 { float ms = 0.f;
   hipEventElapsedTime(&ms, a, b);
@@ -531,15 +548,19 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
         }
       hipEventRecord(ev[3], s);
 
-      // weighted k-mer sort (key = KMER_BYTES, MSDsort.c:536)
+      // weighted k-mer sort.  The reference sorts all KMER_BYTES (MSDsort.c:536); here four stable
+      // digit passes order the list on its first FK_PREFIX_BYTES key bytes and the count kernel
+      // resolves the few prefix runs that hold more than one k-mer inside LDS.  If some run cannot
+      // be resolved there (FK_ESTATE), the remaining digit passes are executed and the count repeats.
       void *km_sorted = km_a;
+      int   sorted_bytes = (w.kmer_bytes < FK_PREFIX_BYTES) ? w.kmer_bytes : FK_PREFIX_BYTES;
       if (nw > 0)
         { if ((km_b = fk_slot(ctx, FK_SLOT_KM_B, nw * w.kmer_stride)) == NULL)
             { rc = FK_ENOMEM; break; }
           int bytes[64];
-          for (int i = 0; i < w.kmer_bytes; i++)
-            bytes[i] = w.kmer_bytes - 1 - i;
-          if ((rc = fkx_lsd_sort(ctx, nw, km_a, km_b, w.kmer_stride, bytes, w.kmer_bytes,
+          for (int i = 0; i < sorted_bytes; i++)
+            bytes[i] = sorted_bytes - 1 - i;
+          if ((rc = fkx_lsd_sort(ctx, nw, km_a, km_b, w.kmer_stride, bytes, sorted_bytes,
                                  &km_sorted)) != FK_OK)
             break;
           res->passes_kmer  = ctx->sort_stats.passes;
@@ -554,8 +575,24 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
       int64_t nt = 0, ndk = 0;
       const int cutoff = ctx->prm.table_cutoff;
       void *other = (km_sorted == km_a) ? km_b : km_a;
-      if ((rc = fkx_count(ctx, km_sorted, nw, cutoff, res->hist, &res->max_inst, &ndk,
-                          cutoff > 0 ? other : NULL, nw, &nt)) != FK_OK)
+      rc = fkx_count(ctx, km_sorted, nw, cutoff, sorted_bytes, res->hist, &res->max_inst, &ndk,
+                     cutoff > 0 ? other : NULL, nw, &nt);
+      if (rc == FK_ESTATE)
+        { int bytes[64];
+          for (int i = 0; i < w.kmer_bytes; i++)
+            bytes[i] = w.kmer_bytes - 1 - i;
+          void *full = km_sorted;
+          if ((rc = fkx_lsd_sort(ctx, nw, km_sorted, other, w.kmer_stride, bytes, w.kmer_bytes,
+                                 &full)) != FK_OK)
+            break;
+          res->passes_kmer  += ctx->sort_stats.passes;
+          res->ms_pass_kmer += ctx->sort_stats.pass_ms_total;
+          other = (full == km_sorted) ? other : km_sorted;
+          km_sorted = full;
+          rc = fkx_count(ctx, km_sorted, nw, cutoff, w.kmer_bytes, res->hist, &res->max_inst, &ndk,
+                         cutoff > 0 ? other : NULL, nw, &nt);
+        }
+      if (rc != FK_OK)
         break;
       res->max_inst += ovf;                                  // count.c:1551
       res->ndistinct = ndk;

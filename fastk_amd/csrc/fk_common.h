@@ -88,7 +88,7 @@ int fkx_split(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int
               int64_t *nsuper, int64_t *ninst, int64_t *bucket_counts, bool counts_known);
 int fkx_expand(fk_ctx *ctx, const void *d_smers, int64_t nsuper, void *d_out, int64_t cap,
                int64_t *nweighted, int64_t *ndistinct, int64_t *overflow);
-int fkx_count(fk_ctx *ctx, const void *d_kmers, int64_t nweighted, int cutoff,
+int fkx_count(fk_ctx *ctx, const void *d_kmers, int64_t nweighted, int cutoff, int sorted_bytes,
               int64_t *hist, int64_t *max_inst, int64_t *ndistinct,
               void *d_table, int64_t cap, int64_t *ntable);
 int fkx_synth(fk_ctx *ctx, uint64_t seed, uint64_t genome_len, uint32_t read_len,

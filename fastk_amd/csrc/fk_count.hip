@@ -15,6 +15,8 @@
 #define CT_TILE    (CT_THREADS * CT_ITEMS)
 #define CT_LOWBINS 4096
 #define CT_AHEAD   255
+#define CT_FIXCAP  1024    // heterogeneous prefix runs repaired per tile
+#define CT_MAXFIX  192     // longest heterogeneous prefix run one thread insertion-sorts
 
 // key comparison through per-word masks (all ones / partial last word / zero): branch-free
 template <int KW> struct CtMask { u32 m[KW]; };
@@ -39,54 +41,189 @@ __device__ __forceinline__ bool ct_same_key(const u32 *a, const u32 *b, const Ct
   return (diff == 0);
 }
 
+// lexicographic order of two keys (memory-order bytes): big-endian word compare under the masks
+template <int KW>
+__device__ __forceinline__ bool ct_key_less(const u32 *a, const u32 *b, const CtMask<KW> &k)
+{ bool less = false, decided = false;
+#pragma unroll
+  for (int w = 0; w < KW; w++)
+    { const u32 x = __builtin_bswap32(a[w] & k.m[w]);
+      const u32 y = __builtin_bswap32(b[w] & k.m[w]);
+      if (!decided && x != y)
+        { less = (x < y);
+          decided = true;
+        }
+    }
+  return less;
+}
+
 // TABLE = false: histogram, max_inst, distinct count and the number of table entries per tile.
 // TABLE = true : the same walk again (cheap: it runs in LDS), this time compacting the entries with
 //                count >= cutoff into the table at the offsets the tile scan produced.
+// PREFIX = true: the input is sorted on its first `prefix_bytes` key bytes only (four LSD passes
+//                instead of KMER_BYTES).  A run of equal prefixes almost always holds ONE k-mer (its
+//                duplicates); the few runs that hold several are insertion-sorted inside LDS by the
+//                thread that owns their first record, so the walk below still sees sorted keys.  A
+//                prefix run belongs to the tile that contains its first record, tail included.
+//                Runs that do not fit the LDS window and are not homogeneous raise *unresolved and
+//                the host falls back to the remaining digit passes.
 // The input is never modified (the reference stores the total into the run head, MSDsort.c:507;
 // on the GPU that would be 244 M scattered 4-byte writes into 13 GB).
-template <int KW, bool TABLE>
+template <int KW, bool TABLE, bool PREFIX>
 __global__ __launch_bounds__(CT_THREADS) void k_ct_count(const u32 *__restrict__ km, int64_t n,
-                                                         int kmer_bytes, int cutoff,
+                                                         int kmer_bytes, int prefix_bytes, int cutoff,
                                                          u64 *__restrict__ hist,
-                                                         u64 *__restrict__ scal,   // [0] max_inst [1] distinct
+                                                         u64 *__restrict__ scal,   // [0] max_inst [1] distinct [3] unresolved
                                                          u32 *__restrict__ tile_entries,
                                                          const u64 *__restrict__ tile_off,
                                                          u32 *__restrict__ table)
-{ __shared__ u32 low[TABLE ? 1 : CT_LOWBINS];
+{ constexpr int WIN = CT_TILE + CT_AHEAD;                // records visible to a tile
+  constexpr int NIT = PREFIX ? (WIN + CT_THREADS - 1) / CT_THREADS : CT_ITEMS;
+  __shared__ u32 low[TABLE ? 1 : CT_LOWBINS];
   __shared__ u32 tmp[8];
   __shared__ u32 s_run;
-  __shared__ __attribute__((aligned(16))) u32 recs[(CT_TILE + CT_AHEAD + 1) * KW];  // tile + look-ahead
+  __shared__ int s_first, s_end;                         // PREFIX: owned range [s_first, s_end)
+  __shared__ u32 s_nfix;
+  __shared__ u32 fixq[PREFIX ? CT_FIXCAP : 1];           // heterogeneous runs: start << 12 | length
+  __shared__ __attribute__((aligned(16))) u32 recs[(WIN + 1) * KW];  // tile + look-ahead
   __shared__ u32 prev[KW];                               // the record before the tile
   if (!TABLE)
     for (int i = threadIdx.x; i < CT_LOWBINS; i += CT_THREADS)
       low[i] = 0;
   if (threadIdx.x == 0)
-    s_run = 0;
+    { s_run = 0;
+      s_first = WIN + 1;
+      s_end = WIN + 1;
+      s_nfix = 0;
+    }
 
   const CtMask<KW> kmask = ct_make_mask<KW>(kmer_bytes);
+  const CtMask<KW> pmask = ct_make_mask<KW>(PREFIX ? prefix_bytes : kmer_bytes);
   const int cw  = (KW * 4 - 2) >> 2;
   const int csh = 8 * ((KW * 4 - 2) & 3);
 
   const int64_t t0 = (int64_t) blockIdx.x * CT_TILE;
   // stage records [t0, t0+CT_TILE+CT_AHEAD) so that run heads walk forward in LDS
-  int64_t gend = t0 + CT_TILE + CT_AHEAD;
+  int64_t gend = t0 + WIN;
   if (gend > n) gend = n;
   const int nl = (int) (gend - t0);                      // records staged
-  fk_stage16<((CT_TILE + CT_AHEAD) * KW + 1023) / 1024, false>(recs, km + t0 * KW, nl * KW);
+  fk_stage16<(WIN * KW + 1023) / 1024, false>(recs, km + t0 * KW, nl * KW);
   if (t0 > 0 && threadIdx.x < KW)
     prev[threadIdx.x] = km[(t0 - 1) * KW + threadIdx.x];
   __syncthreads();
+
+  int own_lo = 0, own_hi = (nl < CT_TILE) ? nl : CT_TILE;
+  if (PREFIX)
+    { // ---- fix-up --------------------------------------------------------------------------
+      // per record, in parallel: does it open a prefix run (phead), or does it continue a prefix
+      // run with a DIFFERENT k-mer than its predecessor (evidence that the run is heterogeneous)?
+#pragma unroll 1
+      for (int it = 0; it < NIT; it++)
+        { const int l = it * CT_THREADS + threadIdx.x;
+          bool phead = false, evid = false;
+          if (l < nl)
+            { const u32 *r  = recs + l * KW;
+              const u32 *rp = (l > 0) ? r - KW : prev;
+              if (t0 + l == 0)
+                phead = true;
+              else
+                { phead = !ct_same_key<KW>(r, rp, pmask);
+                  evid  = !phead && !ct_same_key<KW>(r, rp, kmask);
+                }
+            }
+          // first prefix head inside the tile / first one in the look-ahead: one atomic per wave
+          const u64 hm = __ballot(phead);
+          if (hm != 0 && fk_lane() == 0)
+            { const int first = (it * CT_THREADS + (int) (threadIdx.x & ~63u)) + (__ffsll((unsigned long long) hm) - 1);
+              if (first < CT_TILE)
+                atomicMin(&s_first, first);
+              // the wave's lanes are consecutive records: find its first head at or past CT_TILE
+              const int wbeg = it * CT_THREADS + (int) (threadIdx.x & ~63u);
+              u64 hm2 = hm;
+              if (wbeg < CT_TILE)
+                hm2 = (CT_TILE - wbeg >= 64) ? 0ull : (hm >> (CT_TILE - wbeg)) << (CT_TILE - wbeg);
+              if (hm2 != 0)
+                atomicMin(&s_end, wbeg + (__ffsll((unsigned long long) hm2) - 1));
+            }
+          if (evid)
+            { // rare: locate the run; only its FIRST evidence record queues the repair
+              int  sidx = l - 1;
+              bool first = true, found = false;
+              while (sidx >= 0)
+                { const u32 *q  = recs + sidx * KW;
+                  const u32 *qp = (sidx > 0) ? q - KW : prev;
+                  const bool ph = (t0 + sidx == 0) || !ct_same_key<KW>(q, qp, pmask);
+                  if (ph)
+                    { found = true;
+                      break;
+                    }
+                  if (!ct_same_key<KW>(q, qp, kmask))
+                    { first = false;
+                      break;
+                    }
+                  sidx -= 1;
+                }
+              if (first && found && sidx < CT_TILE)     // run owned by this tile
+                { int e = l + 1;
+                  while (e < nl && ct_same_key<KW>(recs + e * KW, recs + l * KW, pmask))
+                    e += 1;
+                  bool bad = (e - sidx > CT_MAXFIX);
+                  if (e == nl && t0 + nl < n
+                      && ct_same_key<KW>(km + (t0 + nl) * KW, recs + l * KW, pmask))
+                    bad = true;                           // run leaves the LDS window
+                  if (!bad)
+                    { const u32 slot = atomicAdd(&s_nfix, 1u);
+                      if (slot < CT_FIXCAP)
+                        fixq[slot] = ((u32) sidx << 12) | (u32) (e - sidx);
+                      else
+                        bad = true;
+                    }
+                  if (bad)
+                    atomicAdd(&scal[3], 1ull);
+                }
+            }
+        }
+      __syncthreads();
+      // insertion sort of the queued runs, one thread per run (runs are disjoint)
+      const u32 nfix = (s_nfix < CT_FIXCAP) ? s_nfix : CT_FIXCAP;
+      for (u32 f = threadIdx.x; f < nfix; f += CT_THREADS)
+        { const int l = (int) (fixq[f] >> 12);
+          const int m = (int) (fixq[f] & 0xfffu);
+          for (int a = 1; a < m; a++)
+            { u32 hold[KW];
+#pragma unroll
+              for (int w = 0; w < KW; w++)
+                hold[w] = recs[(l + a) * KW + w];
+              int b = a;
+              while (b > 0 && ct_key_less<KW>(hold, recs + (l + b - 1) * KW, kmask))
+                {
+#pragma unroll
+                  for (int w = 0; w < KW; w++)
+                    recs[(l + b) * KW + w] = recs[(l + b - 1) * KW + w];
+                  b -= 1;
+                }
+#pragma unroll
+              for (int w = 0; w < KW; w++)
+                recs[(l + b) * KW + w] = hold[w];
+            }
+        }
+      __syncthreads();
+      own_lo = s_first;
+      own_hi = (s_end < nl) ? s_end : nl;
+      if (own_lo > CT_TILE)
+        own_lo = own_hi = 0;                   // no run starts in this tile: nothing is owned
+    }
 
   const u64 base = TABLE ? tile_off[blockIdx.x] : 0ull;
   u32 entries = 0, distinct = 0;
   u64 maxi = 0;
 #pragma unroll 1
-  for (int it = 0; it < CT_ITEMS; it++)
+  for (int it = 0; it < NIT; it++)
     { const int     l = it * CT_THREADS + threadIdx.x;
       const int64_t i = t0 + l;
       u32  mycnt = 0;                     // 0 = this lane holds no run head
       const u32 *r = recs + l * KW;
-      if (i < n)
+      if (l >= own_lo && l < own_hi)
         { const bool head = (i == 0) || !ct_same_key<KW>(r, (l > 0) ? r - KW : prev, kmask);
           if (head)
             { u64 cnt = (r[cw] >> csh) & 0xffffu;
@@ -164,8 +301,10 @@ __global__ __launch_bounds__(CT_THREADS) void k_ct_count(const u32 *__restrict__
     atomicAdd(&scal[0], maxi);
 }
 
+// sorted_bytes < KMER_BYTES: the records are ordered on their first sorted_bytes key bytes only;
+// returns FK_ESTATE (nothing accumulated) when some prefix run could not be resolved inside LDS.
 template <int KW>
-static int count_t(fk_ctx *ctx, void *d_kmers, int64_t n, int cutoff, int64_t *hist,
+static int count_t(fk_ctx *ctx, void *d_kmers, int64_t n, int cutoff, int sorted_bytes, int64_t *hist,
                    int64_t *max_inst, int64_t *ndistinct, void *d_table, int64_t cap,
                    int64_t *ntable)
 { hipStream_t s = ctx->stream;
@@ -188,15 +327,25 @@ static int count_t(fk_ctx *ctx, void *d_kmers, int64_t n, int cutoff, int64_t *h
   do
     { if (h == NULL) { rc = FK_ENOMEM; break; }
       if (hipMemsetAsync(d_hist, 0, (FK_HIST_BINS + 8) * 8, s) != hipSuccess) { rc = FK_EHIP; break; }
-      hipLaunchKernelGGL((k_ct_count<KW, false>), dim3((unsigned) ntiles), dim3(CT_THREADS), 0, s,
-                         (const u32 *) d_kmers, n, ctx->wid.kmer_bytes, cutoff, d_hist, d_scal, d_ent,
-                         (const u64 *) NULL, (u32 *) NULL);
+      const bool prefix = (sorted_bytes < ctx->wid.kmer_bytes);
+      if (prefix)
+        hipLaunchKernelGGL((k_ct_count<KW, false, true>), dim3((unsigned) ntiles), dim3(CT_THREADS), 0, s,
+                           (const u32 *) d_kmers, n, ctx->wid.kmer_bytes, sorted_bytes, cutoff, d_hist,
+                           d_scal, d_ent, (const u64 *) NULL, (u32 *) NULL);
+      else
+        hipLaunchKernelGGL((k_ct_count<KW, false, false>), dim3((unsigned) ntiles), dim3(CT_THREADS), 0, s,
+                           (const u32 *) d_kmers, n, ctx->wid.kmer_bytes, sorted_bytes, cutoff, d_hist,
+                           d_scal, d_ent, (const u64 *) NULL, (u32 *) NULL);
       hipLaunchKernelGGL(k_exscan_tiles, dim3(1), dim3(256), 0, s, (const u32 *) d_ent, ntiles,
                          d_off, d_scal + 2);
       if (hipGetLastError() != hipSuccess) { rc = FK_EHIP; break; }
       if (hipMemcpyAsync(h, d_hist, (FK_HIST_BINS + 8) * 8, hipMemcpyDeviceToHost, s) != hipSuccess
           || hipStreamSynchronize(s) != hipSuccess)
         { rc = FK_EHIP; break; }
+      if (h[FK_HIST_BINS + 3] != 0)
+        { rc = FK_ESTATE;          // heterogeneous prefix run outside the LDS window: caller sorts on
+          break;
+        }
       for (int i = 1; i < FK_HIST_BINS; i++)
         hist[i] += (int64_t) h[i];
       *max_inst += (int64_t) h[FK_HIST_BINS + 0];
@@ -211,9 +360,14 @@ static int count_t(fk_ctx *ctx, void *d_kmers, int64_t n, int cutoff, int64_t *h
           rc = FK_EINVAL;
           break;
         }
-      hipLaunchKernelGGL((k_ct_count<KW, true>), dim3((unsigned) ntiles), dim3(CT_THREADS), 0, s,
-                         (const u32 *) d_kmers, n, ctx->wid.kmer_bytes, cutoff, d_hist, d_scal, d_ent,
-                         (const u64 *) d_off, (u32 *) d_table);
+      if (prefix)
+        hipLaunchKernelGGL((k_ct_count<KW, true, true>), dim3((unsigned) ntiles), dim3(CT_THREADS), 0, s,
+                           (const u32 *) d_kmers, n, ctx->wid.kmer_bytes, sorted_bytes, cutoff, d_hist,
+                           d_scal, d_ent, (const u64 *) d_off, (u32 *) d_table);
+      else
+        hipLaunchKernelGGL((k_ct_count<KW, true, false>), dim3((unsigned) ntiles), dim3(CT_THREADS), 0, s,
+                           (const u32 *) d_kmers, n, ctx->wid.kmer_bytes, sorted_bytes, cutoff, d_hist,
+                           d_scal, d_ent, (const u64 *) d_off, (u32 *) d_table);
       if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
         { rc = FK_EHIP; break; }
     }
@@ -224,15 +378,15 @@ static int count_t(fk_ctx *ctx, void *d_kmers, int64_t n, int cutoff, int64_t *h
   return (rc);
 }
 
-int fkx_count(fk_ctx *ctx, const void *d_kmers, int64_t nweighted, int cutoff,
+int fkx_count(fk_ctx *ctx, const void *d_kmers, int64_t nweighted, int cutoff, int sorted_bytes,
               int64_t *hist, int64_t *max_inst, int64_t *ndistinct,
               void *d_table, int64_t cap, int64_t *ntable)
 { switch (ctx->wid.kmer_stride >> 2)
-  { case 1: return count_t<1>(ctx, (void *) d_kmers, nweighted, cutoff, hist, max_inst, ndistinct, d_table, cap, ntable);
-    case 2: return count_t<2>(ctx, (void *) d_kmers, nweighted, cutoff, hist, max_inst, ndistinct, d_table, cap, ntable);
-    case 3: return count_t<3>(ctx, (void *) d_kmers, nweighted, cutoff, hist, max_inst, ndistinct, d_table, cap, ntable);
-    case 4: return count_t<4>(ctx, (void *) d_kmers, nweighted, cutoff, hist, max_inst, ndistinct, d_table, cap, ntable);
-    case 5: return count_t<5>(ctx, (void *) d_kmers, nweighted, cutoff, hist, max_inst, ndistinct, d_table, cap, ntable);
+  { case 1: return count_t<1>(ctx, (void *) d_kmers, nweighted, cutoff, sorted_bytes, hist, max_inst, ndistinct, d_table, cap, ntable);
+    case 2: return count_t<2>(ctx, (void *) d_kmers, nweighted, cutoff, sorted_bytes, hist, max_inst, ndistinct, d_table, cap, ntable);
+    case 3: return count_t<3>(ctx, (void *) d_kmers, nweighted, cutoff, sorted_bytes, hist, max_inst, ndistinct, d_table, cap, ntable);
+    case 4: return count_t<4>(ctx, (void *) d_kmers, nweighted, cutoff, sorted_bytes, hist, max_inst, ndistinct, d_table, cap, ntable);
+    case 5: return count_t<5>(ctx, (void *) d_kmers, nweighted, cutoff, sorted_bytes, hist, max_inst, ndistinct, d_table, cap, ntable);
     default:
       fk_set_error(ctx, "k-mer stride %d not built", ctx->wid.kmer_stride);
       return (FK_EUNSUPPORTED);

@@ -193,8 +193,10 @@ __global__ __launch_bounds__(RX_THREADS) void k_radix_pass(const u32 *__restrict
   for (int it = 0; it < ITEMS; it++)
     { const int  r     = wbase + it * 64 + lane;
       const bool valid = (r < tn);
-      const u32  d     = !valid ? 0u : HASHED ? rx_hash_digit<RW>(recs + r * RW, byte_idx)
-                                              : (u32) lbytes[r * RW * 4 + byte_idx];
+      u32 d = !valid ? 0u : HASHED ? rx_hash_digit<RW>(recs + r * RW, byte_idx)
+                                   : (u32) lbytes[r * RW * 4 + byte_idx];
+      if (VARIANT == 5) d &= 0x7fu;          // measurement: 128 / 64 bins (longer runs per bin)
+      if (VARIANT == 6) d &= 0x3fu;
       u64 mask = __ballot(valid);
 #pragma unroll
       for (int b = 0; b < 8; b++)
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(RX_THREADS) void k_radix_pass(const u32 *__restrict
     binstart[tid] = bstart;
 
     u64 excl = 0;
-    if (VARIANT == 1 || VARIANT == 4)
+    if (VARIANT == 1 || VARIANT >= 4)
       { excl = (gcnt * (u64) tile) / (u64) gridDim.x;
         if (excl + total > gcnt) excl = (gcnt > total) ? gcnt - total : 0;
       }
@@ -303,11 +305,19 @@ __global__ __launch_bounds__(RX_THREADS) void k_radix_pass(const u32 *__restrict
       else
         { sr = perm[p];
           d  = lbytes[sr * RW * 4 + byte_idx];
+          if (VARIANT == 5) d &= 0x7fu;
+          if (VARIANT == 6) d &= 0x3fu;
         }
       int64_t g = (goff[d] + p) * RW + w;
       if (VARIANT == 2 || VARIANT == 3)
         g = (tstart + p) * RW + w;
-      if ((VARIANT == 1 || VARIANT == 4) && (g < 0 || g >= n * RW))
+      if (VARIANT == 7)
+        { // measurement: same 256 short runs, but shuffled inside the tile's own 36 KB window
+          int q = (int) (((d * 37u) & 255u) * (u32) ITEMS) + (p - (int) binstart[d]);
+          if (q >= tn) q = tn - 1;
+          g = (tstart + q) * RW + w;
+        }
+      if ((VARIANT == 1 || VARIANT >= 4) && (g < 0 || g >= n * RW))
         g = (tstart + p) * RW + w;
       dst[g] = recs[sr * RW + w];
     }
@@ -400,6 +410,9 @@ static int lsd_sort_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, const in
       else if (ctx->dbg_radix_variant == 2) RX_LAUNCH(2);
       else if (ctx->dbg_radix_variant == 3) RX_LAUNCH(3);
       else if (ctx->dbg_radix_variant == 4) RX_LAUNCH(4);
+      else if (ctx->dbg_radix_variant == 5) RX_LAUNCH(5);
+      else if (ctx->dbg_radix_variant == 6) RX_LAUNCH(6);
+      else if (ctx->dbg_radix_variant == 7) RX_LAUNCH(7);
       else RX_LAUNCH(0);
 #undef RX_LAUNCH
       FK_LAUNCH_CHECK(ctx);

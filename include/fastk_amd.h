@@ -174,6 +174,14 @@ int fk_count_kmers(fk_ctx *ctx, const void *d_kmers, int64_t nweighted, int cuto
                    int64_t *hist, int64_t *max_inst, int64_t *ndistinct,
                    void *d_table, int64_t cap, int64_t *ntable);
 
+/* As fk_count_kmers, for a list that is sorted on its first sorted_bytes key bytes only (what
+   four digit passes give): the rare runs of equal prefixes that hold several k-mers are resolved
+   inside LDS.  Returns FK_ESTATE, with nothing accumulated, if some run cannot be resolved there;
+   the caller then finishes the sort and calls fk_count_kmers. */
+int fk_count_presorted_kmers(fk_ctx *ctx, const void *d_kmers, int64_t nweighted, int cutoff,
+                             int sorted_bytes, int64_t *hist, int64_t *max_inst,
+                             int64_t *ndistinct, void *d_table, int64_t cap, int64_t *ntable);
+
 /* ---- utilities ---------------------------------------------------------------------------*/
 
 /* Fill d_bases with synthetic reads first_read .. first_read+nreads-1 of include/fk_synth.h,

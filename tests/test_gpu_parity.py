@@ -278,3 +278,54 @@ def test_group_records_brings_duplicates_together(ctx40):
     runs = 1 + int(np.any(got[1:] != got[:-1], axis=1).sum())
     assert runs == len(np.unique(recs, axis=0))
     a.free(); b.free()
+
+
+# ------------------------------------------------------------------------------ prefix-sorted count
+
+def _shuffle_within_prefix(ks, nbytes, seed):
+    """Keep the order of the first nbytes key bytes, shuffle records inside equal-prefix runs."""
+    rng = np.random.default_rng(seed)
+    pre = np.zeros(len(ks), dtype=np.int64)
+    for b in range(nbytes):
+        pre = (pre << 8) | ks[:, b].astype(np.int64)
+    order = np.lexsort((rng.random(len(ks)), pre))
+    return np.ascontiguousarray(ks[order])
+
+
+@pytest.mark.parametrize("name,nbytes", [("edge_k40_t1_T4", 4), ("synth_illumina_k40_t1_T4", 4),
+                                         ("edge_k51_t1_T4", 4), ("synth_illumina_k40_t1_T4", 2),
+                                         ("edge_k21_t2_T3", 3)])
+def test_count_on_prefix_sorted_input(name, nbytes):
+    """k-mers ordered on their first bytes only (what four digit passes give): the count kernel
+    must resolve heterogeneous prefix runs in LDS and still reproduce the reference exactly, or
+    report FK_ESTATE (then the caller sorts on) -- never a wrong answer."""
+    case, bases, boff = util.load_case(name)
+    k, cutoff = case["k"], case["cutoff"]
+    P = orc.params(k)
+    smers, _ = orc.distribute(P, bases, boff)
+    kl, ovf, _ = orc.kmer_list(P, orc.msd_sort(smers, P.smer_word))
+    ks = _shuffle_within_prefix(orc.msd_sort(kl, P.kmer_bytes), nbytes, 5)
+    with fastk_amd.Context(kmer=k, table_cutoff=cutoff) as ctx:
+        w = ctx.w
+        dev = _pad_kmers(ks, w.kmer_bytes, w.kmer_stride)
+        a = ctx.alloc(dev.nbytes).upload(dev)
+        t = ctx.alloc(dev.nbytes)
+        out = ctx.count(a.ptr, len(ks), cutoff, t.ptr, len(ks), sorted_bytes=nbytes)
+        if out is None:
+            assert nbytes < 4, "a 4-byte prefix must be resolvable on these inputs"
+            return
+        hist, mi, nd, nt = out
+        tab = _unpad_kmers(t.download(nt * w.kmer_stride).reshape(nt, w.kmer_stride), w.kmer_bytes)
+    util.check_against_golden(case, hist, mi + ovf, tab)
+
+
+def test_count_reports_unresolvable_prefix_runs(ctx40):
+    """2,000 distinct k-mers sharing one 4-byte prefix, in random order: too long to fix in LDS."""
+    rng = np.random.default_rng(3)
+    n = 2000
+    recs = np.zeros((n, 12), dtype=np.uint8)
+    recs[:, 4:10] = rng.integers(0, 256, size=(n, 6))
+    recs[:, 10] = 1
+    a = ctx40.alloc(recs.nbytes).upload(recs)
+    assert ctx40.count(a.ptr, n, 1, None, 0, sorted_bytes=4) is None
+    a.free()

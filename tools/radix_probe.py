@@ -28,7 +28,7 @@ def main():
     items = int(sys.argv[4]) if len(sys.argv) > 4 else 0
     ctx._ck(ctx.L.fk_debug_set(ctx.h, b"radix_items", items))
     out["items"] = items
-    for variant in (0, 1, 2, 3, 4):
+    for variant in (0, 1, 3, 7):
         ctx._ck(ctx.L.fk_debug_set(ctx.h, b"radix_variant", variant))
         best = None
         for rep in range(3):
