@@ -248,6 +248,10 @@ extern "C" int fk_debug_set(fk_ctx *ctx, const char *key, int64_t value)
     { ctx->dbg_radix_variant = (int) value;
       return (FK_OK);
     }
+  if (strcmp(key, "radix_engine") == 0)
+    { ctx->dbg_radix_engine = (int) value;
+      return (FK_OK);
+    }
   if (strcmp(key, "radix_items") == 0)
     { ctx->dbg_radix_items = (int) value;
       return (FK_OK);

@@ -57,12 +57,14 @@ struct fk_ctx
   // so that a repeated workload performs no hipMalloc/hipFree inside the hot path
   int        dbg_radix_variant;   // measurement aids, see fk_debug_set
   int        dbg_radix_items;
+  int        dbg_radix_engine;    // 1 = look-back engine instead of the stream engine
   void      *slot_ptr[FK_NSLOTS];
   int64_t    slot_cap[FK_NSLOTS];
 };
 
 enum { FK_SLOT_SM_A = 0, FK_SLOT_SM_B, FK_SLOT_KM_A, FK_SLOT_KM_B, FK_SLOT_EX_HEADS, FK_SLOT_EX_KMERS,
-       FK_SLOT_EX_KOFF, FK_SLOT_CT_ENT, FK_SLOT_CT_OFF, FK_SLOT_CT_HIST };
+       FK_SLOT_EX_KOFF, FK_SLOT_CT_ENT, FK_SLOT_CT_OFF, FK_SLOT_CT_HIST, FK_SLOT_DIG_A, FK_SLOT_DIG_B,
+       FK_SLOT_RX_TILE, FK_SLOT_RX_CHUNK, FK_SLOT_RX_SUPER };
 
 // returns a device buffer of at least nbytes for the given purpose (NULL + error set on failure)
 void *fk_slot(fk_ctx *ctx, int slot, int64_t nbytes);

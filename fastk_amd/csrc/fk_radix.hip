@@ -22,8 +22,7 @@
 template <int RW> struct RxCfg
 { // default records per thread: a tile of ~36 KB plus its permutation and histograms lets three
   // workgroups share a CU's 160 KB of LDS
-  static constexpr int ITEMS = (RW <= 2) ? 16 : (RW == 3) ? 12 : (RW == 4) ? 9 : (RW == 5) ? 8
-                             : (RW == 6) ? 6 : 4;
+  static constexpr int ITEMS = (RW <= 2) ? 16 : (RW == 3) ? 12 : (RW == 4) ? 8 : (RW == 5) ? 8 : 4;
 };
 
 #define ST_AGG  1ull
@@ -55,7 +54,8 @@ __device__ __forceinline__ u32 rx_hash_digit(const u32 *r, int byte_idx)
 
 template <int RW>
 __global__ __launch_bounds__(RX_THREADS) void k_hash_hist(const u32 *__restrict__ src, int64_t n,
-                                                          int nbytes, u64 *__restrict__ out)
+                                                          int nbytes, u64 *__restrict__ out,
+                                                          uint8_t *__restrict__ dig, int dig_byte)
 { __shared__ u32 h[8 * 256];
   for (int i = threadIdx.x; i < 8 * 256; i += RX_THREADS)
     h[i] = 0;
@@ -68,6 +68,8 @@ __global__ __launch_bounds__(RX_THREADS) void k_hash_hist(const u32 *__restrict_
         r[w] = src[i * RW + w];
       for (int b = 0; b < nbytes; b++)
         atomicAdd(&h[b * 256 + rx_hash_digit<RW>(r, b)], 1u);
+      if (dig != NULL)
+        dig[i] = (uint8_t) rx_hash_digit<RW>(r, dig_byte);
     }
   __syncthreads();
   for (int i = threadIdx.x; i < 8 * 256; i += RX_THREADS)
@@ -79,7 +81,8 @@ __global__ __launch_bounds__(RX_THREADS) void k_hash_hist(const u32 *__restrict_
 // digit histograms for every byte of the record selected in `want`
 template <int RW>
 __global__ __launch_bounds__(RX_THREADS) void k_digit_hist(const u32 *__restrict__ src, int64_t n,
-                                                           u32 want, u64 *__restrict__ out)
+                                                           u32 want, u64 *__restrict__ out,
+                                                           uint8_t *__restrict__ dig, int dig_byte)
 { __shared__ u32 h[RW * 4 * 256];
   for (int i = threadIdx.x; i < RW * 4 * 256; i += RX_THREADS)
     h[i] = 0;
@@ -96,6 +99,13 @@ __global__ __launch_bounds__(RX_THREADS) void k_digit_hist(const u32 *__restrict
         for (int b = 0; b < 4; b++)
           if (want & (1u << (w * 4 + b)))
             atomicAdd(&h[(w * 4 + b) * 256 + ((r[w] >> (8 * b)) & 0xffu)], 1u);
+      if (dig != NULL)
+        {
+#pragma unroll
+          for (int w = 0; w < RW; w++)
+            if ((dig_byte >> 2) == w)
+              dig[i] = (uint8_t) ((r[w] >> (8 * (dig_byte & 3))) & 0xffu);
+        }
     }
   __syncthreads();
   for (int i = threadIdx.x; i < RW * 4 * 256; i += RX_THREADS)
@@ -323,6 +333,281 @@ __global__ __launch_bounds__(RX_THREADS) void k_radix_pass(const u32 *__restrict
     }
 }
 
+// =============================================================================================
+// Dependency-free digit pass ("stream" engine, the default).
+//
+// The look-back above costs ~30 % of a pass on this chip (status words cross eight non-coherent
+// XCD L2s) and forces tiles to be taken in ticket order.  Here every pass ALSO writes, next to each
+// record's new position, the digit the NEXT pass will sort on (one byte per record).  The next pass
+// then gets its per-tile bin offsets without touching the records and without any inter-workgroup
+// dependency:
+//   k_rx_tilehist   reads the n-byte digit stream; per chunk of RX_CH tiles it writes, per tile and
+//                   bin, the running count inside the chunk (u16) and the chunk totals (u32)
+//   k_rx_chunkscan  running totals of chunks inside a super-chunk of RX_SC chunks (u32) + super totals
+//   k_rx_superscan  exclusive scan over super-chunks and bins -> absolute bases (u64)
+//   k_rx_scatter    load tile, rank (as above), offset = super + chunk + tile prefix, scatter, and
+//                   emit the next digit stream.  Workgroup b works on tile (b%8)*ceil(T/8) + b/8,
+//                   so each XCD (b % 8 under the observed dispatch) streams one contiguous range of
+//                   tiles and neighbouring bin runs meet in the same L2.
+// HBM bytes per pass: 2*n*R (records) + 2*n (digit stream) + ~1.4 % tables.
+#define RX_CH 16
+#define RX_SC 256
+
+template <int ITEMS>
+__global__ __launch_bounds__(RX_THREADS) void k_rx_tilehist(const uint8_t *__restrict__ dig, int64_t n,
+                                                            uint16_t *__restrict__ tilepfx,
+                                                            u32 *__restrict__ chunktot)
+{ constexpr int TILE = RX_THREADS * ITEMS;
+  constexpr int NW   = ITEMS / 4;
+  __shared__ u32 h[256];
+  const int     tid   = threadIdx.x;
+  const int64_t tile0 = (int64_t) blockIdx.x * RX_CH;
+  u32 run = 0;
+  h[tid] = 0;
+  __syncthreads();
+
+  u32 cur[NW], nxt[NW];
+  auto load = [&](int64_t tile, u32 *v)
+    { const int64_t base = tile * TILE + (int64_t) tid * ITEMS;
+#pragma unroll
+      for (int k = 0; k < NW; k++)
+        { const int64_t o = base + 4 * k;
+          u32 x = 0;
+          if (o + 4 <= n)
+            x = *(const u32 *) (dig + o);
+          else
+            for (int b = 0; b < 4; b++)
+              if (o + b < n)
+                x |= ((u32) dig[o + b]) << (8 * b);
+          v[k] = x;
+        }
+    };
+  load(tile0, cur);
+  for (int t = 0; t < RX_CH; t++)
+    { const int64_t tile = tile0 + t;
+      if (tile * TILE >= n)
+        break;
+      if (t + 1 < RX_CH && (tile + 1) * TILE < n)
+        load(tile + 1, nxt);
+      const int64_t base = tile * TILE + (int64_t) tid * ITEMS;
+#pragma unroll
+      for (int k = 0; k < NW; k++)
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+          if (base + 4 * k + b < n)
+            atomicAdd(&h[(cur[k] >> (8 * b)) & 0xffu], 1u);
+      __syncthreads();
+      tilepfx[tile * 256 + tid] = (uint16_t) run;
+      run += h[tid];
+      h[tid] = 0;
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < NW; k++)
+        cur[k] = nxt[k];
+    }
+  chunktot[(int64_t) blockIdx.x * 256 + tid] = run;
+}
+
+__global__ __launch_bounds__(RX_THREADS) void k_rx_chunkscan(const u32 *__restrict__ chunktot,
+                                                             int64_t nchunks,
+                                                             u32 *__restrict__ chunkpfx,
+                                                             u64 *__restrict__ supertot)
+{ const int     tid = threadIdx.x;
+  const int64_t c0  = (int64_t) blockIdx.x * RX_SC;
+  u32 run = 0;
+  for (int j = 0; j < RX_SC; j += 8)
+    { u32 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++)
+        v[k] = (c0 + j + k < nchunks) ? chunktot[(c0 + j + k) * 256 + tid] : 0u;
+#pragma unroll
+      for (int k = 0; k < 8; k++)
+        if (c0 + j + k < nchunks)
+          { chunkpfx[(c0 + j + k) * 256 + tid] = run;
+            run += v[k];
+          }
+    }
+  supertot[(int64_t) blockIdx.x * 256 + tid] = run;
+}
+
+__global__ __launch_bounds__(RX_THREADS) void k_rx_superscan(const u64 *__restrict__ ghist,
+                                                             const u64 *__restrict__ supertot,
+                                                             int64_t nsuper, u64 *__restrict__ superpfx)
+{ __shared__ u64 tmp[8];
+  const int tid = threadIdx.x;
+  u64 gsum;
+  u64 run = fk_block_exscan_256<u64>(ghist[tid], tmp, &gsum);
+  for (int64_t sc = 0; sc < nsuper; sc++)
+    { superpfx[sc * 256 + tid] = run;
+      run += supertot[sc * 256 + tid];
+    }
+}
+
+template <int RW, int ITEMS, bool HASHED>
+__global__ __launch_bounds__(RX_THREADS) void k_rx_scatter(const u32 *__restrict__ src,
+                                                           u32 *__restrict__ dst, int64_t n,
+                                                           int byte_idx, int next_byte,
+                                                           const uint16_t *__restrict__ tilepfx,
+                                                           const u32 *__restrict__ chunkpfx,
+                                                           const u64 *__restrict__ superpfx,
+                                                           uint8_t *__restrict__ nextdig,
+                                                           int64_t ntiles)
+{ constexpr int TILE = RX_THREADS * ITEMS;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u32      *recs     = (u32 *) smem;                                   // TILE*RW, never reordered
+  int64_t  *goff     = (int64_t *) (smem + (size_t) TILE * RW * 4);    // 256
+  u64      *tmp64    = (u64 *) (goff + 256);                           // 8
+  u32      *whist    = (u32 *) (tmp64 + 8);                            // 4*256
+  u32      *binstart = whist + RX_WAVES * 256;                         // 256
+  u32      *tmp32    = binstart + 256;                                 // 8
+  u32      *pad      = tmp32 + 8;                                      // 4
+  uint16_t *perm     = (uint16_t *) (pad + 4);                         // TILE: sorted slot -> record
+  u32      *perm32   = (u32 *) (pad + 4);                              // HASHED: record | digit << 16
+
+  const int tid  = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+
+  const int64_t per  = (ntiles + 7) >> 3;
+  const int64_t tile = (int64_t) (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (tile >= ntiles)
+    return;
+  for (int i = tid; i < RX_WAVES * 256; i += RX_THREADS)
+    whist[i] = 0;
+
+  const int64_t tstart = tile * TILE;
+  const int     tn     = (n - tstart < TILE) ? (int) (n - tstart) : TILE;
+  const int     ndw    = tn * RW;
+
+  { const u32   *gsrc = src + tstart * RW;
+    const uint4 *g4   = (const uint4 *) gsrc;
+    uint4       *l4   = (uint4 *) recs;
+    if (tn == TILE)
+      { static_assert((ITEMS * RW) % 4 == 0, "tile must be a whole number of 16-byte loads per thread");
+        constexpr int NV = ITEMS * RW / 4;
+        uint4 v[NV];
+#pragma unroll
+        for (int k = 0; k < NV; k++)
+          v[k] = g4[tid + k * RX_THREADS];
+#pragma unroll
+        for (int k = 0; k < NV; k++)
+          l4[tid + k * RX_THREADS] = v[k];
+      }
+    else
+      { const int n4 = ndw >> 2;
+        for (int i = tid; i < n4; i += RX_THREADS)
+          l4[i] = g4[i];
+        for (int i = (n4 << 2) + tid; i < ndw; i += RX_THREADS)
+          recs[i] = gsrc[i];
+      }
+  }
+  // this tile's bin offsets do not depend on any other workgroup
+  const u64 gpre = superpfx[(tile / (RX_CH * RX_SC)) * 256 + tid]
+                 + (u64) chunkpfx[(tile / RX_CH) * 256 + tid] + (u64) tilepfx[tile * 256 + tid];
+  __syncthreads();
+
+  const int  wbase = wave * 64 * ITEMS;
+  const u64  lt    = fk_lanemask_lt();
+  const unsigned char *lbytes = (const unsigned char *) smem;
+
+  u32 info[ITEMS];
+  u32 old[ITEMS];
+#pragma unroll
+  for (int it = 0; it < ITEMS; it++)
+    { const int  r     = wbase + it * 64 + lane;
+      const bool valid = (r < tn);
+      const u32  d     = !valid ? 0u : HASHED ? rx_hash_digit<RW>(recs + r * RW, byte_idx)
+                                              : (u32) lbytes[r * RW * 4 + byte_idx];
+      u64 mask = __ballot(valid);
+#pragma unroll
+      for (int b = 0; b < 8; b++)
+        { const bool bit = (d >> b) & 1u;
+          const u64  bm  = __ballot(bit);
+          mask &= bit ? bm : ~bm;
+        }
+      const u32 below  = (u32) __popcll(mask & lt);
+      const u32 leader = valid ? (u32) (__ffsll((unsigned long long) mask) - 1) : (u32) lane;
+      info[it] = d | (below << 8) | (leader << 16);
+      old[it] = 0;
+      if (valid && below == 0)
+        old[it] = atomicAdd(&whist[wave * 256 + d], (u32) __popcll(mask));
+    }
+#pragma unroll
+  for (int it = 0; it < ITEMS; it++)
+    { const u32 e    = info[it];
+      const u32 base = (u32) __shfl((int) old[it], (int) ((e >> 16) & 0xffu), 64);
+      info[it] = (e & 0xffu) | ((base + ((e >> 8) & 0xffu)) << 8);     // d | rank-in-wave << 8
+    }
+  __syncthreads();
+
+  { u32 run = 0;
+#pragma unroll
+    for (int w = 0; w < RX_WAVES; w++)
+      { const u32 t = whist[w * 256 + tid];
+        whist[w * 256 + tid] = run;
+        run += t;
+      }
+    u32 tsum;
+    const u32 bstart = fk_block_exscan_256<u32>(run, tmp32, &tsum);
+    binstart[tid] = bstart;
+    goff[tid] = (int64_t) gpre - (int64_t) bstart;
+  }
+  __syncthreads();
+
+#pragma unroll
+  for (int it = 0; it < ITEMS; it++)
+    { const int r = wbase + it * 64 + lane;
+      if (r < tn)
+        { const u32 e   = info[it];
+          const u32 d   = e & 0xffu;
+          const u32 pos = binstart[d] + whist[wave * 256 + d] + (e >> 8);
+          if (HASHED)
+            perm32[pos] = (u32) r | (d << 16);
+          else
+            perm[pos] = (uint16_t) r;
+        }
+    }
+  __syncthreads();
+
+#pragma unroll 4
+  for (int j = tid; j < ndw; j += RX_THREADS)
+    { const int p = j / RW;
+      const int w = j - p * RW;
+      int sr;
+      u32 d;
+      if (HASHED)
+        { const u32 e = perm32[p];
+          sr = (int) (e & 0xffffu);
+          d  = e >> 16;
+        }
+      else
+        { sr = perm[p];
+          d  = lbytes[sr * RW * 4 + byte_idx];
+        }
+      dst[(goff[d] + p) * RW + w] = recs[sr * RW + w];
+    }
+
+  // the digit the next pass sorts on, stored at each record's new position
+  if (next_byte >= 0)
+    for (int p = tid; p < tn; p += RX_THREADS)
+      { int sr;
+        u32 d;
+        if (HASHED)
+          { const u32 e = perm32[p];
+            sr = (int) (e & 0xffffu);
+            d  = e >> 16;
+          }
+        else
+          { sr = perm[p];
+            d  = lbytes[sr * RW * 4 + byte_idx];
+          }
+        const u32 nd = HASHED ? rx_hash_digit<RW>(recs + sr * RW, next_byte)
+                              : (u32) lbytes[sr * RW * 4 + next_byte];
+        nextdig[goff[d] + p] = (uint8_t) nd;
+      }
+}
+
 template <int RW, int ITEMS> static size_t rx_lds_bytes(bool hashed)
 { return ((size_t) RX_THREADS * ITEMS * RW * 4 + 256 * 8 + 8 * 8 + RX_WAVES * 256 * 4 + 256 * 4
           + 8 * 4 + 16 + (size_t) RX_THREADS * ITEMS * (hashed ? 4 : 2) + 16);
@@ -374,10 +659,10 @@ static int lsd_sort_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, const in
     if (nb > 1024) nb = 1024;
     if (HASHED)
       hipLaunchKernelGGL(k_hash_hist<RW>, dim3((unsigned) nb), dim3(RX_THREADS), 0, s,
-                         (const u32 *) d_src, n, 8, ctx->d_digit_hist);
+                         (const u32 *) d_src, n, 8, ctx->d_digit_hist, (uint8_t *) NULL, 0);
     else
       hipLaunchKernelGGL(k_digit_hist<RW>, dim3((unsigned) nb), dim3(RX_THREADS), 0, s,
-                         (const u32 *) d_src, n, want, ctx->d_digit_hist);
+                         (const u32 *) d_src, n, want, ctx->d_digit_hist, (uint8_t *) NULL, 0);
     FK_LAUNCH_CHECK(ctx);
   }
   FK_HIP(ctx, hipEventRecord(ctx->ev1, s));
@@ -430,6 +715,126 @@ static int lsd_sort_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, const in
   return (FK_OK);
 }
 
+template <int RW, int ITEMS, bool HASHED>
+static int lsd_sort_stream_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, const int *bytes,
+                             int nbytes, void **result)
+{ constexpr int TILE = RX_THREADS * ITEMS;
+  const int64_t ntiles  = (n + TILE - 1) / TILE;
+  const int64_t nchunks = (ntiles + RX_CH - 1) / RX_CH;
+  const int64_t nsuper  = (nchunks + RX_SC - 1) / RX_SC;
+  hipStream_t   s = ctx->stream;
+  u32 want = 0;
+
+  ctx->sort_stats.passes = 0;
+  ctx->sort_stats.nelem  = n;
+  ctx->sort_stats.rsize  = RW * 4;
+  ctx->sort_stats.pass_ms_total = 0.;
+  ctx->sort_stats.hist_ms = 0.;
+  *result = d_src;
+  if (n == 0 || nbytes == 0)
+    return (FK_OK);
+  if (nbytes > 60)
+    { fk_set_error(ctx, "too many key bytes (%d)", nbytes);
+      return (FK_EINVAL);
+    }
+  for (int i = 0; i < nbytes; i++)
+    { if (bytes[i] < 0 || bytes[i] >= (HASHED ? 8 : RW * 4))
+        { fk_set_error(ctx, "key byte %d outside record of %d bytes", bytes[i], RW * 4);
+          return (FK_EINVAL);
+        }
+      want |= (1u << bytes[i]);
+    }
+
+  uint8_t  *dig_a = (uint8_t *) fk_slot(ctx, FK_SLOT_DIG_A, n + 64);
+  uint8_t  *dig_b = (uint8_t *) fk_slot(ctx, FK_SLOT_DIG_B, n + 64);
+  uint16_t *tilepfx  = (uint16_t *) fk_slot(ctx, FK_SLOT_RX_TILE, ntiles * 256 * 2);
+  u32      *chunktot = (u32 *) fk_slot(ctx, FK_SLOT_RX_CHUNK, nchunks * 256 * 4 * 2);
+  u64      *supertot = (u64 *) fk_slot(ctx, FK_SLOT_RX_SUPER, nsuper * 256 * 8 * 2);
+  if (dig_a == NULL || dig_b == NULL || tilepfx == NULL || chunktot == NULL || supertot == NULL)
+    return (FK_ENOMEM);
+  u32 *chunkpfx = chunktot + nchunks * 256;
+  u64 *superpfx = supertot + nsuper * 256;
+
+  FK_HIP(ctx, hipMemsetAsync(ctx->d_digit_hist, 0, 32 * 256 * sizeof(u64), s));
+  FK_HIP(ctx, hipEventRecord(ctx->ev0, s));
+  { int64_t nb = (n + RX_THREADS - 1) / RX_THREADS;
+    if (nb > 2048) nb = 2048;
+    // the first executed pass is not known before the histograms are: emit the stream of bytes[0]
+    // and re-emit below in the (rare) case that this digit turns out to be constant
+    if (HASHED)
+      hipLaunchKernelGGL(k_hash_hist<RW>, dim3((unsigned) nb), dim3(RX_THREADS), 0, s,
+                         (const u32 *) d_src, n, 8, ctx->d_digit_hist, dig_a, bytes[0]);
+    else
+      hipLaunchKernelGGL(k_digit_hist<RW>, dim3((unsigned) nb), dim3(RX_THREADS), 0, s,
+                         (const u32 *) d_src, n, want, ctx->d_digit_hist, dig_a, bytes[0]);
+    FK_LAUNCH_CHECK(ctx);
+  }
+  FK_HIP(ctx, hipEventRecord(ctx->ev1, s));
+  FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch, ctx->d_digit_hist, (size_t) (HASHED ? 8 : RW * 4) * 256 * 8,
+                             hipMemcpyDeviceToHost, s));
+  FK_HIP(ctx, hipStreamSynchronize(s));
+  { float ms = 0.f;
+    FK_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    ctx->sort_stats.hist_ms = ms;
+  }
+
+  int run[64], nrun = 0;                 // the passes that actually permute something
+  for (int i = 0; i < nbytes; i++)
+    { const u64 *h = ctx->h_scratch + (size_t) bytes[i] * 256;
+      bool constant = false;
+      for (int x = 0; x < 256; x++)
+        if (h[x] == (u64) n)
+          constant = true;
+      if (!constant)
+        run[nrun++] = bytes[i];
+    }
+  if (nrun == 0)
+    return (FK_OK);
+  if (run[0] != bytes[0])
+    { int64_t nb = (n + RX_THREADS - 1) / RX_THREADS;
+      if (nb > 2048) nb = 2048;
+      FK_HIP(ctx, hipMemsetAsync(ctx->d_digit_hist + 24 * 256, 0, 8 * 256 * sizeof(u64), s));
+      if (HASHED)
+        hipLaunchKernelGGL(k_hash_hist<RW>, dim3((unsigned) nb), dim3(RX_THREADS), 0, s,
+                           (const u32 *) d_src, n, 0, ctx->d_digit_hist + 24 * 256, dig_a, run[0]);
+      else
+        hipLaunchKernelGGL(k_digit_hist<RW>, dim3((unsigned) nb), dim3(RX_THREADS), 0, s,
+                           (const u32 *) d_src, n, 0u, ctx->d_digit_hist + 24 * 256, dig_a, run[0]);
+      FK_LAUNCH_CHECK(ctx);
+    }
+
+  const size_t lds_bytes = rx_lds_bytes<RW, ITEMS>(HASHED);
+  u32 *src = (u32 *) d_src, *trg = (u32 *) d_trg;
+  uint8_t *dcur = dig_a, *dnext = dig_b;
+  const unsigned sgrid = (unsigned) (((ntiles + 7) / 8) * 8);
+  FK_HIP(ctx, hipEventRecord(ctx->ev0, s));
+  for (int i = 0; i < nrun; i++)
+    { const int nextb = (i + 1 < nrun) ? run[i + 1] : -1;
+      hipLaunchKernelGGL(k_rx_tilehist<ITEMS>, dim3((unsigned) nchunks), dim3(RX_THREADS), 0, s,
+                         (const uint8_t *) dcur, n, tilepfx, chunktot);
+      hipLaunchKernelGGL(k_rx_chunkscan, dim3((unsigned) nsuper), dim3(RX_THREADS), 0, s,
+                         (const u32 *) chunktot, nchunks, chunkpfx, supertot);
+      hipLaunchKernelGGL(k_rx_superscan, dim3(1), dim3(RX_THREADS), 0, s,
+                         (const u64 *) (ctx->d_digit_hist + (size_t) run[i] * 256),
+                         (const u64 *) supertot, nsuper, superpfx);
+      hipLaunchKernelGGL((k_rx_scatter<RW, ITEMS, HASHED>), dim3(sgrid), dim3(RX_THREADS), lds_bytes, s,
+                         (const u32 *) src, trg, n, run[i], nextb, (const uint16_t *) tilepfx,
+                         (const u32 *) chunkpfx, (const u64 *) superpfx, dnext, ntiles);
+      FK_LAUNCH_CHECK(ctx);
+      u32 *t = src; src = trg; trg = t;
+      uint8_t *d = dcur; dcur = dnext; dnext = d;
+    }
+  FK_HIP(ctx, hipEventRecord(ctx->ev1, s));
+  FK_HIP(ctx, hipStreamSynchronize(s));
+  { float ms = 0.f;
+    FK_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    ctx->sort_stats.pass_ms_total = ms;
+    ctx->sort_stats.passes = nrun;
+  }
+  *result = (void *) src;
+  return (FK_OK);
+}
+
 template <bool HASHED>
 static int sort_dispatch(fk_ctx *ctx, int64_t nelem, void *d_src, void *d_trg, int rsize,
                          const int *bytes, int nbytes, void **result)
@@ -438,7 +843,9 @@ static int sort_dispatch(fk_ctx *ctx, int64_t nelem, void *d_src, void *d_trg, i
       return (FK_EUNSUPPORTED);
     }
   const int it = ctx->dbg_radix_items;      // measurement aid: alternative tile sizes for R = 12, 20
-#define RX_CASE(RW) return lsd_sort_t<RW, RxCfg<RW>::ITEMS, HASHED>(ctx, nelem, d_src, d_trg, bytes, nbytes, result)
+  const bool lookback = (ctx->dbg_radix_engine == 1 || ctx->dbg_radix_variant != 0 || it != 0);
+#define RX_CASE(RW) return (lookback ? lsd_sort_t<RW, RxCfg<RW>::ITEMS, HASHED>(ctx, nelem, d_src, d_trg, bytes, nbytes, result) \
+                              : lsd_sort_stream_t<RW, RxCfg<RW>::ITEMS, HASHED>(ctx, nelem, d_src, d_trg, bytes, nbytes, result))
   switch (rsize >> 2)
   { case 1: RX_CASE(1);
     case 2: RX_CASE(2);
