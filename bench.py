@@ -164,23 +164,33 @@ def main():
     ms_step = 1e3 * dt / args.steps
     value = ninst / (dt / args.steps)
 
-    # roofline of the dominant kernel: one 8-bit digit pass over the weighted k-mer records.
-    # algorithmic bytes per launch = 2 * n * R (read once + write once at the reference width)
+    # roofline of the dominant kernel: k_rx_scatter on the weighted k-mer records, one stable 8-bit
+    # digit pass per launch.  Algorithmic bytes per launch = 2 * n * R (records read once and written
+    # once at the reference width R = KMER_WORD); duration = HIP event pair around every scatter
+    # launch on the library's stream, averaged over the launches of the last step.  pass_total adds
+    # the per-pass helper kernels (digit-stream histogram + two scans) that feed it.
     w = ctx.w
     n_pass = loc.nweighted
-    avg_ms = loc.ms_pass_kmer / max(loc.passes_kmer, 1)
-    achieved = (2.0 * n_pass * w.kmer_word) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+    npk = max(loc.passes_kmer, 1)
+    avg_ms = loc.ms_scatter_kmer / npk
+    avg_pass_ms = loc.ms_pass_kmer / npk
+    gbs = lambda nrec, width, ms: round((2.0 * nrec * width) / (ms * 1e-3) / 1e9, 1) if ms > 0 else 0.0
+    achieved = gbs(n_pass, w.kmer_word, avg_ms)
+    nps = max(loc.passes_super, 1)
+    roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
-                    kernel="k_radix_pass<3> (k-mer records, R=%d B)" % w.kmer_word,
+                    kernel="k_rx_scatter<3,12> (weighted k-mer records, R=%d B)" % w.kmer_word,
                     records_per_launch=int(n_pass), launches_per_step=int(loc.passes_kmer),
                     avg_launch_ms=round(avg_ms, 4),
+                    pass_total=dict(avg_ms=round(avg_pass_ms, 4),
+                                    achieved=gbs(n_pass, w.kmer_word, avg_pass_ms),
+                                    note="scatter + k_rx_tilehist + k_rx_chunkscan + k_rx_superscan"),
                     supermer_pass=dict(
+                        kernel="k_rx_scatter<5,8,hashed> (super-mer records, R=%d B)" % w.smer_word,
                         records=int(loc.nsuper), launches=int(loc.passes_super),
-                        avg_launch_ms=round(loc.ms_pass_super / max(loc.passes_super, 1), 4),
-                        achieved=round((2.0 * loc.nsuper * w.smer_word)
-                                       / (loc.ms_pass_super / max(loc.passes_super, 1) * 1e-3) / 1e9, 1)
-                        if loc.ms_pass_super > 0 else 0.0))
+                        avg_launch_ms=round(loc.ms_scatter_super / nps, 4),
+                        achieved=gbs(loc.nsuper, w.smer_word, loc.ms_scatter_super / nps),
+                        pass_total_achieved=gbs(loc.nsuper, w.smer_word, loc.ms_pass_super / nps)))
 
     out = dict(metric="canonical k-mers/sec (k=40, whole hot path, reads resident in HBM)",
                value=value, unit="k-mers/s", n_gpus=world, steps=args.steps, warmup=args.warmup,

@@ -48,12 +48,14 @@ class CResult(C.Structure):
                 ("ms_split", C.c_double), ("ms_sort_super", C.c_double), ("ms_expand", C.c_double),
                 ("ms_sort_kmer", C.c_double), ("ms_count", C.c_double), ("ms_total", C.c_double),
                 ("passes_super", C.c_int), ("passes_kmer", C.c_int),
-                ("ms_pass_super", C.c_double), ("ms_pass_kmer", C.c_double)]
+                ("ms_pass_super", C.c_double), ("ms_pass_kmer", C.c_double),
+                ("ms_scatter_super", C.c_double), ("ms_scatter_kmer", C.c_double)]
 
 
 class SortStats(C.Structure):
     _fields_ = [("passes", C.c_int), ("nelem", C.c_int64), ("rsize", C.c_int),
-                ("pass_ms_total", C.c_double), ("hist_ms", C.c_double)]
+                ("pass_ms_total", C.c_double), ("scatter_ms_total", C.c_double),
+                ("hist_ms", C.c_double)]
 
 
 _lib = None
@@ -129,6 +131,8 @@ class Result:
                    for k in ("split", "sort_super", "expand", "sort_kmer", "count", "total")}
         self.passes_super, self.passes_kmer = int(cres.passes_super), int(cres.passes_kmer)
         self.ms_pass_super, self.ms_pass_kmer = float(cres.ms_pass_super), float(cres.ms_pass_kmer)
+        self.ms_scatter_super = float(cres.ms_scatter_super)
+        self.ms_scatter_kmer = float(cres.ms_scatter_kmer)
         if self.ntable > 0 and cres.table:
             self.table = np.ctypeslib.as_array(cres.table, shape=(self.ntable, kmer_word)).copy()
         else:
@@ -280,7 +284,8 @@ class Context:
         st = SortStats()
         self._ck(self.L.fk_get_sort_stats(self.h, C.byref(st)))
         return dict(passes=st.passes, nelem=st.nelem, rsize=st.rsize,
-                    pass_ms_total=st.pass_ms_total, hist_ms=st.hist_ms)
+                    pass_ms_total=st.pass_ms_total, scatter_ms_total=st.scatter_ms_total,
+                    hist_ms=st.hist_ms)
 
     def expand(self, smers_ptr, nsuper, out_ptr=None, cap=0):
         nw, nd, ov = C.c_int64(), C.c_int64(), C.c_int64()

@@ -184,6 +184,8 @@ extern "C" void fk_destroy(fk_ctx *ctx)
     }
   if (ctx->ev0) hipEventDestroy(ctx->ev0);
   if (ctx->ev1) hipEventDestroy(ctx->ev1);
+  for (int i = 0; i < 128; i++)
+    if (ctx->pass_ev[i]) hipEventDestroy(ctx->pass_ev[i]);
   if (ctx->own_stream && ctx->stream != NULL)
     hipStreamDestroy(ctx->stream);
   free(ctx->h_table);
@@ -537,6 +539,7 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
           break;
         res->passes_super  = ctx->sort_stats.passes;
         res->ms_pass_super = ctx->sort_stats.pass_ms_total;
+        res->ms_scatter_super = ctx->sort_stats.scatter_ms_total;
       }
       hipEventRecord(ev[2], s);
 
@@ -569,6 +572,7 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
             break;
           res->passes_kmer  = ctx->sort_stats.passes;
           res->ms_pass_kmer = ctx->sort_stats.pass_ms_total;
+          res->ms_scatter_kmer = ctx->sort_stats.scatter_ms_total;
           // first-byte census of the weighted k-mers = Kparts (count.c:1527-1535)
           for (int x = 0; x < 256; x++)
             res->wfirst[x] = (int64_t) ctx->h_scratch[x];
@@ -591,6 +595,7 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
             break;
           res->passes_kmer  += ctx->sort_stats.passes;
           res->ms_pass_kmer += ctx->sort_stats.pass_ms_total;
+          res->ms_scatter_kmer += ctx->sort_stats.scatter_ms_total;
           other = (full == km_sorted) ? other : km_sorted;
           km_sorted = full;
           rc = fkx_count(ctx, km_sorted, nw, cutoff, w.kmer_bytes, res->hist, &res->max_inst, &ndk,

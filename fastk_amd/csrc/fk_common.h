@@ -52,6 +52,7 @@ struct fk_ctx
   void      *push_lock;    // pthread mutex
 
   hipEvent_t ev0, ev1;
+  hipEvent_t pass_ev[128];       // begin/end of each scatter launch of the current sort
 
   // HBM arena: one cached allocation per purpose, grown on demand and kept until fk_destroy,
   // so that a repeated workload performs no hipMalloc/hipFree inside the hot path

@@ -709,6 +709,7 @@ static int lsd_sort_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, const in
   { float ms = 0.f;
     FK_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     ctx->sort_stats.pass_ms_total = ms;
+    ctx->sort_stats.scatter_ms_total = ms;
     ctx->sort_stats.passes = passes;
   }
   *result = (void *) src;
@@ -729,6 +730,7 @@ static int lsd_sort_stream_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, c
   ctx->sort_stats.nelem  = n;
   ctx->sort_stats.rsize  = RW * 4;
   ctx->sort_stats.pass_ms_total = 0.;
+  ctx->sort_stats.scatter_ms_total = 0.;
   ctx->sort_stats.hist_ms = 0.;
   *result = d_src;
   if (n == 0 || nbytes == 0)
@@ -809,6 +811,11 @@ static int lsd_sort_stream_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, c
   const unsigned sgrid = (unsigned) (((ntiles + 7) / 8) * 8);
   FK_HIP(ctx, hipEventRecord(ctx->ev0, s));
   for (int i = 0; i < nrun; i++)
+    if (ctx->pass_ev[2 * i] == NULL)
+      { FK_HIP(ctx, hipEventCreate(&ctx->pass_ev[2 * i]));
+        FK_HIP(ctx, hipEventCreate(&ctx->pass_ev[2 * i + 1]));
+      }
+  for (int i = 0; i < nrun; i++)
     { const int nextb = (i + 1 < nrun) ? run[i + 1] : -1;
       hipLaunchKernelGGL(k_rx_tilehist<ITEMS>, dim3((unsigned) nchunks), dim3(RX_THREADS), 0, s,
                          (const uint8_t *) dcur, n, tilepfx, chunktot);
@@ -817,9 +824,11 @@ static int lsd_sort_stream_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, c
       hipLaunchKernelGGL(k_rx_superscan, dim3(1), dim3(RX_THREADS), 0, s,
                          (const u64 *) (ctx->d_digit_hist + (size_t) run[i] * 256),
                          (const u64 *) supertot, nsuper, superpfx);
+      FK_HIP(ctx, hipEventRecord(ctx->pass_ev[2 * i], s));
       hipLaunchKernelGGL((k_rx_scatter<RW, ITEMS, HASHED>), dim3(sgrid), dim3(RX_THREADS), lds_bytes, s,
                          (const u32 *) src, trg, n, run[i], nextb, (const uint16_t *) tilepfx,
                          (const u32 *) chunkpfx, (const u64 *) superpfx, dnext, ntiles);
+      FK_HIP(ctx, hipEventRecord(ctx->pass_ev[2 * i + 1], s));
       FK_LAUNCH_CHECK(ctx);
       u32 *t = src; src = trg; trg = t;
       uint8_t *d = dcur; dcur = dnext; dnext = d;
@@ -830,6 +839,12 @@ static int lsd_sort_stream_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, c
     FK_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     ctx->sort_stats.pass_ms_total = ms;
     ctx->sort_stats.passes = nrun;
+    double sc = 0.;
+    for (int i = 0; i < nrun; i++)
+      { FK_HIP(ctx, hipEventElapsedTime(&ms, ctx->pass_ev[2 * i], ctx->pass_ev[2 * i + 1]));
+        sc += ms;
+      }
+    ctx->sort_stats.scatter_ms_total = sc;
   }
   *result = (void *) src;
   return (FK_OK);

@@ -101,7 +101,8 @@ typedef struct
     int64_t  wfirst[256];        /* weighted k-mers per canonical first byte (Kparts, count.c:1527)    */
     double   ms_split, ms_sort_super, ms_expand, ms_sort_kmer, ms_count, ms_total;  /* device time   */
     int      passes_super, passes_kmer;   /* radix digit passes executed by the two sorts              */
-    double   ms_pass_super, ms_pass_kmer; /* summed duration of those pass kernels (HIP events)        */
+    double   ms_pass_super, ms_pass_kmer; /* summed duration of all kernels of those passes            */
+    double   ms_scatter_super, ms_scatter_kmer; /* summed duration of the scatter kernels alone        */
   } fk_result;
 
 /* Replaces Sorting() + the merge of Merge_Tables() (count.c:1202, table.c:346): runs the
@@ -200,7 +201,8 @@ typedef struct
   { int     passes;
     int64_t nelem;
     int     rsize;
-    double  pass_ms_total;   /* sum of radix-pass kernel durations (HIP events on ctx stream) */
+    double  pass_ms_total;   /* all kernels of the digit passes (HIP events on the ctx stream)    */
+    double  scatter_ms_total;/* the scatter kernels alone (k_rx_scatter), event pair per launch   */
     double  hist_ms;         /* digit histogram kernel                                         */
   } fk_sort_stats;
 int fk_get_sort_stats(fk_ctx *ctx, fk_sort_stats *st);
