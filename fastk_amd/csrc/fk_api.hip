@@ -508,7 +508,6 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
   do
     { void *sm_a = NULL, *sm_b = NULL, *km_a = NULL, *km_b = NULL;
       int64_t ns = 0, ni = 0;
-      int64_t bcounts[256];
 
       hipEventRecord(ev[0], s);
       void *sm_in = d_smers_in;
@@ -517,15 +516,10 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
           res->nsuper = ns;
         }
       else
-        { // split: count, then emit
-          if ((rc = fkx_split(ctx, d_reads, nbytes, NULL, 0, &ns, &ni, bcounts, false)) != FK_OK) break;
+        { // split (sampled capacity + one emit pass; exact count-then-emit when sharding)
+          if ((rc = fkx_split_fast(ctx, d_reads, nbytes, &sm_a, &ns, &ni)) != FK_OK) break;
           res->nsuper = ns;
           res->ninst = ni;
-          if (ns > 0)
-            { if ((sm_a = fk_slot(ctx, FK_SLOT_SM_A, ns * w.smer_stride)) == NULL)
-                { rc = FK_ENOMEM; break; }
-              if ((rc = fkx_split(ctx, d_reads, nbytes, sm_a, ns, &ns, &ni, bcounts, true)) != FK_OK) break;
-            }
           sm_in = sm_a;
         }
       if (ns > 0 && (sm_b = fk_slot(ctx, FK_SLOT_SM_B, ns * w.smer_stride)) == NULL)

@@ -89,6 +89,8 @@ int fkx_lsd_sort(fk_ctx *ctx, int64_t nelem, void *d_src, void *d_trg, int rsize
 int fkx_group(fk_ctx *ctx, int64_t nelem, void *d_src, void *d_trg, int rsize, void **result);
 int fkx_split(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int64_t cap,
               int64_t *nsuper, int64_t *ninst, int64_t *bucket_counts, bool counts_known);
+int fkx_split_fast(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void **d_out, int64_t *nsuper,
+                   int64_t *ninst);
 int fkx_expand(fk_ctx *ctx, const void *d_smers, int64_t nsuper, void *d_out, int64_t cap,
                int64_t *nweighted, int64_t *ndistinct, int64_t *overflow);
 int fkx_count(fk_ctx *ctx, const void *d_kmers, int64_t nweighted, int cutoff, int sorted_bytes,
@@ -168,23 +170,45 @@ __device__ __forceinline__ void fk_stage16(u32 *lds, const u32 *g, int ndw)
     lds[i] = SWAP ? __builtin_bswap32(g[i]) : g[i];
 }
 
-// exclusive scan of u32 per-tile counts into u64 offsets (single workgroup; one copy per TU)
+// exclusive scan of u32 per-tile counts into u64 offsets (single workgroup; one copy per TU).
+// Each thread owns 16 consecutive counts per round, so a round covers 4096 tiles.
 static __global__ __launch_bounds__(256) void k_exscan_tiles(const u32 *__restrict__ in, int64_t n,
-                                                      u64 *__restrict__ out, u64 *__restrict__ total)
+                                                             u64 *__restrict__ out, u64 *__restrict__ total)
 { __shared__ u64 tmp[8];
   u64 carry = 0;
-  for (int64_t b = 0; b < n; b += 256)
-    { const int64_t i = b + threadIdx.x;
-      const u64 v = (i < n) ? (u64) in[i] : 0ull;
+  for (int64_t b = 0; b < n; b += 4096)
+    { const int64_t i0 = b + (int64_t) threadIdx.x * 16;
+      u32 v[16];
+      if (i0 + 16 <= n)
+        {
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+            { const uint4 x = *(const uint4 *) (in + i0 + 4 * k);
+              v[4 * k] = x.x; v[4 * k + 1] = x.y; v[4 * k + 2] = x.z; v[4 * k + 3] = x.w;
+            }
+        }
+      else
+        {
+#pragma unroll
+          for (int k = 0; k < 16; k++)
+            v[k] = (i0 + k < n) ? in[i0 + k] : 0u;
+        }
+      u64 mine = 0;
+#pragma unroll
+      for (int k = 0; k < 16; k++)
+        mine += v[k];
       u64 tot;
-      const u64 ex = fk_block_exscan_256<u64>(v, tmp, &tot);
-      if (i < n)
-        out[i] = carry + ex;
+      u64 run = carry + fk_block_exscan_256<u64>(mine, tmp, &tot);
+#pragma unroll
+      for (int k = 0; k < 16; k++)
+        { if (i0 + k < n)
+            out[i0 + k] = run;
+          run += v[k];
+        }
       carry += tot;
     }
   if (threadIdx.x == 0)
     *total = carry;
 }
-
 
 #endif

@@ -42,6 +42,7 @@ struct SplitArgs
   u32      *out;
   int64_t   cap;
   u32      *overflowed;
+  int       tile_stride;    // count mode: visit every tile_stride-th tile only (sampling)
 };
 
 __device__ __forceinline__ u32 sp_window(const u32 *arr, int off)
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
   const int     tid = threadIdx.x;
   const int     K   = a.kmer;
   const int     W   = K - 4;                       // 5-mer starts per k-mer = MAX_SUPER
-  const int64_t t0  = (int64_t) blockIdx.x * SP_TILE;
+  const int64_t t0  = (int64_t) blockIdx.x * a.tile_stride * SP_TILE;
   const int     nw  = SP_TILE / 16 + (K + 14) / 16; // words that hold real bases
   const int     R   = nw * 16;                     // bases covered by the packed arrays
 
@@ -343,6 +344,7 @@ int fkx_split(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int
   a.out = (u32 *) d_out;
   a.cap = cap;
   a.overflowed = d_ovf;
+  a.tile_stride = 1;
 
   const int64_t nstarts = nbytes - K + 1;
   const int64_t ntiles  = (nstarts + SP_TILE - 1) / SP_TILE;
@@ -387,4 +389,79 @@ int fkx_split(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int
       return (FK_EHIP);
     }
   return (FK_OK);
+}
+
+// Single-bucket fast path of the pipeline: size the output from a 1/32 sample of the tiles, emit
+// once with overflow detection, and only if the estimate was too small fall back to the exact
+// count-then-emit of fkx_split.  *d_out is the arena slot that received the records.
+int fkx_split_fast(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void **d_out, int64_t *nsuper,
+                   int64_t *ninst)
+{ hipStream_t s = ctx->stream;
+  const int   K = ctx->prm.kmer;
+  u64 *d_counts = ctx->d_scratch;
+  u64 *d_cursor = ctx->d_scratch + 512;
+  u32 *d_ovf    = (u32 *) (ctx->d_scratch + 1024);
+  const int stride = ctx->wid.smer_stride;
+
+  *nsuper = 0; *ninst = 0; *d_out = NULL;
+  if (K < 8 || K > SP_MAXK)
+    { fk_set_error(ctx, "k = %d outside the supported range [8,%d]", K, SP_MAXK);
+      return (FK_EUNSUPPORTED);
+    }
+  if (nbytes < K)
+    return (FK_OK);
+  if (ctx->prm.nbuckets == 1)
+    { SplitArgs a;
+      a.bases = (const unsigned char *) d_bases;
+      a.nbytes = nbytes;
+      a.kmer = K;
+      a.smer_bytes = ctx->wid.smer_bytes;
+      a.sww = stride / 4;
+      a.nbuckets = 1;
+      a.mtab = ctx->d_mrank;
+      a.mbucket = ctx->d_mbucket;
+      a.counts = d_counts;
+      a.cursor = d_cursor;
+      a.overflowed = d_ovf;
+      const int64_t nstarts = nbytes - K + 1;
+      const int64_t ntiles  = (nstarts + SP_TILE - 1) / SP_TILE;
+      const int     sample  = 32;
+      if (ntiles >= 64 * sample)
+        { FK_HIP(ctx, hipMemsetAsync(ctx->d_scratch, 0, 1032 * sizeof(u64), s));
+          a.out = NULL; a.cap = 0; a.tile_stride = sample;
+          hipLaunchKernelGGL(k_split<false>, dim3((unsigned) (ntiles / sample)), dim3(SP_THREADS), 0, s, a);
+          FK_LAUNCH_CHECK(ctx);
+          FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch, d_counts, sizeof(u64), hipMemcpyDeviceToHost, s));
+          FK_HIP(ctx, hipStreamSynchronize(s));
+          const double per_tile = (double) ctx->h_scratch[0] / (double) (ntiles / sample);
+          int64_t cap = (int64_t) (per_tile * (double) ntiles * 1.03) + 65536;
+          void *out = fk_slot(ctx, FK_SLOT_SM_A, cap * stride);
+          if (out == NULL)
+            return (FK_ENOMEM);
+          cap = ctx->slot_cap[FK_SLOT_SM_A] / stride;          // use the headroom too
+          FK_HIP(ctx, hipMemsetAsync(ctx->d_scratch, 0, 1032 * sizeof(u64), s));
+          a.out = (u32 *) out; a.cap = cap; a.tile_stride = 1;
+          hipLaunchKernelGGL(k_split<true>, dim3((unsigned) ntiles), dim3(SP_THREADS), 0, s, a);
+          FK_LAUNCH_CHECK(ctx);
+          FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch, ctx->d_scratch, 1032 * sizeof(u64),
+                                     hipMemcpyDeviceToHost, s));
+          FK_HIP(ctx, hipStreamSynchronize(s));
+          if (*(u32 *) (ctx->h_scratch + 1024) == 0)
+            { *nsuper = (int64_t) ctx->h_scratch[512];           // the cursor = records written
+              *ninst  = (int64_t) ctx->h_scratch[256];
+              *d_out  = out;
+              return (FK_OK);
+            }
+          // estimate too small (very uneven input): exact path below
+        }
+    }
+  int64_t bc[256];
+  int rc = fkx_split(ctx, d_bases, nbytes, NULL, 0, nsuper, ninst, bc, false);
+  if (rc != FK_OK || *nsuper == 0)
+    return (rc);
+  void *out = fk_slot(ctx, FK_SLOT_SM_A, *nsuper * stride);
+  if (out == NULL)
+    return (FK_ENOMEM);
+  *d_out = out;
+  return fkx_split(ctx, d_bases, nbytes, out, *nsuper, nsuper, ninst, bc, true);
 }
