@@ -59,25 +59,39 @@ __device__ __forceinline__ u32 ex_revpairs(u32 x)
   return ((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1);
 }
 
+// 32 bits starting at bit offset `bit` of a record stored as big-endian value words in LDS
+__device__ __forceinline__ u32 ex_bits(const u32 *rec, int bit)
+{ const u32 hi = rec[bit >> 5];
+  const u32 lo = rec[(bit >> 5) + 1];
+  const int sh = bit & 31;
+  return (sh == 0) ? hi : ((hi << sh) | (lo >> (32 - sh)));
+}
+
+// Phase 1 (one thread per record): run heads, their multiplicity (walk forward in LDS, count.c:421-426)
+// and the offset of their first k-mer inside the tile.  Phase 2 (one thread per OUTPUT k-mer, so every
+// lane works and stores are consecutive 12-byte records): find the head by binary search over the
+// offsets, cut the 2K-bit window out of the super-mer, build its reverse complement, keep the smaller.
 template <int RW, int KN>     // KN = words holding a k-mer
 __global__ __launch_bounds__(EX_THREADS) void k_ex_expand(const u32 *__restrict__ sm, int64_t n,
                                                           int kmer, int len_byte, int ow,
                                                           const u64 *__restrict__ tile_koff,
                                                           u32 *__restrict__ out,
                                                           u64 *__restrict__ overflow)
-{ __shared__ __attribute__((aligned(16))) u32 recs[EX_TILE * RW];     // big-endian value words
+{ __shared__ __attribute__((aligned(16))) u32 recs[(EX_TILE + 1) * RW];   // big-endian value words (+1 guard)
+  __shared__ u32 hoff[EX_TILE + 1];      // first k-mer of head h inside the tile
+  __shared__ uint16_t hrec[EX_TILE];     // record index of head h
+  __shared__ uint16_t hct[EX_TILE];      // its clipped multiplicity
   __shared__ u32 tmp[8];
+  __shared__ u32 s_runk, s_runh;
 
   const int64_t t0 = (int64_t) blockIdx.x * EX_TILE;
   const int     tn = (n - t0 < EX_TILE) ? (int) (n - t0) : EX_TILE;
   fk_stage16<(EX_TILE * RW + 1023) / 1024, true>(recs, sm + t0 * RW, tn * RW);
+  if (threadIdx.x < RW)
+    recs[tn * RW + threadIdx.x] = 0;               // guard word read by ex_bits at the last record
+  if (threadIdx.x == 0)
+    { s_runk = 0; s_runh = 0; }
   __syncthreads();
-
-  const int  pad   = 32 * KN - 2 * kmer;           // unused low bits of the last k-mer word
-  const u32  lastm = (pad == 0) ? 0xffffffffu : ~((1u << pad) - 1u);
-  const int  cw    = (ow * 4 - 2) >> 2;            // word and shift of the uint16 weight
-  const int  csh   = 8 * ((ow * 4 - 2) & 3);
-  const u64  kbase = tile_koff[blockIdx.x];
 
 #pragma unroll 1
   for (int it = 0; it < EX_ITEMS; it++)
@@ -101,60 +115,75 @@ __global__ __launch_bounds__(EX_THREADS) void k_ex_expand(const u32 *__restrict_
           if (head)
             nk = ((recs[l * RW + (len_byte >> 2)] >> (24 - 8 * (len_byte & 3))) & 0xffu) + 1u;
         }
-      u32 tot;
-      const u32 ex = fk_block_exscan_256<u32>(nk, tmp, &tot);
-      // earlier iterations of this tile
-      __shared__ u32 s_run;
-      if (threadIdx.x == 0 && it == 0)
-        s_run = 0;
-      __syncthreads();
-      const u32 run = s_run;
+      u32 totk, toth;
+      const u32 exk = fk_block_exscan_256<u32>(nk, tmp, &totk);
+      const u32 exh = fk_block_exscan_256<u32>(head ? 1u : 0u, tmp, &toth);
+      const u32 runk = s_runk, runh = s_runh;
       __syncthreads();
       if (threadIdx.x == 0)
-        s_run = run + tot;
+        { s_runk = runk + totk; s_runh = runh + toth; }
 
-      if (!head)
-        continue;
-
-      // multiplicity: walk forward while the next record is identical (count.c:421-426)
-      const int64_t i = t0 + l;
-      u32 mine[RW];
+      if (head)
+        { // multiplicity: walk forward while the next record is identical
+          const int64_t i = t0 + l;
+          u32 mine[RW];
 #pragma unroll
-      for (int w = 0; w < RW; w++)
-        mine[w] = recs[l * RW + w];
-      int64_t ct = 1;
-      { int64_t j = i + 1;
-        int     lj = l + 1;
-        while (j < n)
-          { bool same = true;
-            if (lj < tn)
-              {
+          for (int w = 0; w < RW; w++)
+            mine[w] = recs[l * RW + w];
+          int64_t ct = 1;
+          int64_t j = i + 1;
+          int     lj = l + 1;
+          bool open = true;
+          while (open && j < n && lj < tn)
+            { bool same = true;
 #pragma unroll
-                for (int w = 0; w < RW; w++)
-                  same &= (recs[lj * RW + w] == mine[w]);
-              }
-            else
-              {
+              for (int w = 0; w < RW; w++)
+                same &= (recs[lj * RW + w] == mine[w]);
+              if (same) { ct += 1; j += 1; lj += 1; }
+              else open = false;
+            }
+          while (open && j < n)
+            { bool same = true;
 #pragma unroll
-                for (int w = 0; w < RW; w++)
-                  same &= (__builtin_bswap32(sm[j * RW + w]) == mine[w]);
-              }
-            if (!same)
-              break;
-            ct += 1; j += 1; lj += 1;
-          }
-      }
-      if (ct >= 0x8000)
-        { atomicAdd(overflow, (u64) (ct - 0x7fff) * (u64) nk);
-          ct = 0x7fff;
+              for (int w = 0; w < RW; w++)
+                same &= (__builtin_bswap32(sm[j * RW + w]) == mine[w]);
+              if (same) { ct += 1; j += 1; }
+              else open = false;
+            }
+          if (ct >= 0x8000)                          // count.c:455-458
+            { atomicAdd(overflow, (u64) (ct - 0x7fff) * (u64) nk);
+              ct = 0x7fff;
+            }
+          hoff[runh + exh] = runk + exk;
+          hrec[runh + exh] = (uint16_t) l;
+          hct[runh + exh]  = (uint16_t) ct;
         }
+    }
+  __syncthreads();
 
-      // forward window f[] (left aligned) and its reverse complement r[]
-      const u32 *rec = recs + l * RW;
+  const u32 nh    = s_runh;
+  const u32 ktile = s_runk;
+  const int pad   = 32 * KN - 2 * kmer;           // unused low bits of the last k-mer word
+  const u32 lastm = (pad == 0) ? 0xffffffffu : ~((1u << pad) - 1u);
+  const int cw    = (ow * 4 - 2) >> 2;            // word and shift of the uint16 weight
+  const int csh   = 8 * ((ow * 4 - 2) & 3);
+  u32 *gout = out + tile_koff[blockIdx.x] * (u64) ow;
+
+  for (u32 j = threadIdx.x; j < ktile; j += EX_THREADS)
+    { // head of output k-mer j: last h with hoff[h] <= j
+      u32 lo = 0, hi = nh;
+      while (hi - lo > 1)
+        { const u32 mid = (lo + hi) >> 1;
+          if (hoff[mid] <= j) lo = mid; else hi = mid;
+        }
+      const u32  o   = j - hoff[lo];
+      const u32 *rec = recs + (u32) hrec[lo] * RW;
+      const u32  ct  = hct[lo];
+
       u32 f[KN], r[KN];
 #pragma unroll
       for (int q = 0; q < KN; q++)
-        f[q] = rec[q];
+        f[q] = ex_bits(rec, 2 * (int) o + 32 * q);
       f[KN - 1] &= lastm;
       { u32 t[KN];
 #pragma unroll
@@ -162,59 +191,34 @@ __global__ __launch_bounds__(EX_THREADS) void k_ex_expand(const u32 *__restrict_
           { u32 c = ~f[KN - 1 - q];
             if (q == 0)
               c &= lastm;
-            t[q] = ex_revpairs(c);
+            const u32 y = __builtin_bitreverse32(c);
+            t[q] = ((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1);
           }
-        // t has `pad` leading zero bits: shift the multiword value left by pad
 #pragma unroll
         for (int q = 0; q < KN; q++)
-          { const u32 hi = t[q];
-            const u32 lo = (q + 1 < KN) ? t[q + 1] : 0u;
-            r[q] = (pad == 0) ? hi : ((hi << pad) | (lo >> (32 - pad)));
+          { const u32 h2 = t[q];
+            const u32 l2 = (q + 1 < KN) ? t[q + 1] : 0u;
+            r[q] = (pad == 0) ? h2 : ((h2 << pad) | (l2 >> (32 - pad)));
           }
       }
-
-      u32 *dst = out + (kbase + run + ex) * (u64) ow;
-      for (u32 o = 0; o < nk; o++)
-        { if (o > 0)
-            { // slide: new base is base index o+kmer-1 of the super-mer
-              const int bit = 2 * ((int) o + kmer - 1);
-              const u32 nb  = (rec[bit >> 5] >> (30 - (bit & 31))) & 3u;
+      bool use_f = false, decided = false;         // count.c:484-495: forward iff strictly smaller
 #pragma unroll
-              for (int q = 0; q < KN; q++)
-                { const u32 lo = (q + 1 < KN) ? f[q + 1] : 0u;
-                  f[q] = (f[q] << 2) | (lo >> 30);
-                }
-              f[KN - 1] |= nb << pad;
-#pragma unroll
-              for (int q = KN - 1; q >= 0; q--)
-                { const u32 hi = (q > 0) ? r[q - 1] : 0u;
-                  r[q] = (r[q] >> 2) | (hi << 30);
-                }
-              r[KN - 1] &= lastm;
-              r[0] |= (3u - nb) << 30;
-            }
-          bool use_f = true;          // count.c:484-495: forward iff strictly smaller
-          bool decided = false;
-#pragma unroll
-          for (int q = 0; q < KN; q++)
-            if (!decided && f[q] != r[q])
-              { use_f = (f[q] < r[q]);
-                decided = true;
-              }
-          if (!decided)
-            use_f = false;
+      for (int q = 0; q < KN; q++)
+        if (!decided && f[q] != r[q])
+          { use_f = (f[q] < r[q]);
+            decided = true;
+          }
+      u32 *dst = gout + j * (u32) ow;
 #pragma unroll 1
-          for (int q = 0; q < ow; q++)
-            { u32 x = 0;
+      for (int q = 0; q < ow; q++)
+        { u32 x = 0;
 #pragma unroll
-              for (int z = 0; z < KN; z++)
-                if (q == z)
-                  x = __builtin_bswap32(use_f ? f[z] : r[z]);
-              if (q == cw)
-                x |= ((u32) ct) << csh;
-              dst[q] = x;
-            }
-          dst += ow;
+          for (int z = 0; z < KN; z++)
+            if (q == z)
+              x = __builtin_bswap32(use_f ? f[z] : r[z]);
+          if (q == cw)
+            x |= ct << csh;
+          dst[q] = x;
         }
     }
 }
