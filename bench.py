@@ -177,8 +177,21 @@ def main():
     gbs = lambda nrec, width, ms: round((2.0 * nrec * width) / (ms * 1e-3) / 1e9, 1) if ms > 0 else 0.0
     achieved = gbs(n_pass, w.kmer_word, avg_ms)
     nps = max(loc.passes_super, 1)
+    # HBM traffic per launch from PMC counters cannot be collected by this process; it comes from
+    # the committed rocprofv3 passes over this same command (profiles/r01_pmc_traffic.json) and is
+    # only reported when the workload (records per launch) is the profiled one.
+    traffic = None
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        ke = pm["kernels"]["k_rx_scatter<3,12,false>"]
+        if abs(ke["records_per_launch"] - n_pass) <= 1e-3 * n_pass and w.kmer_word == 12:
+            traffic = ke["traffic_bytes"]
+    except Exception:
+        traffic = None
     roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
+                    traffic_unit="bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_traffic.json)",
+                    algorithmic_bytes=2.0 * n_pass * w.kmer_word,
                     kernel="k_rx_scatter<3,12> (weighted k-mer records, R=%d B)" % w.kmer_word,
                     records_per_launch=int(n_pass), launches_per_step=int(loc.passes_kmer),
                     avg_launch_ms=round(avg_ms, 4),

@@ -301,6 +301,164 @@ __global__ __launch_bounds__(CT_THREADS) void k_ct_count(const u32 *__restrict__
     atomicAdd(&scal[0], maxi);
 }
 
+// Fully sorted input, every lane busy: a wave looks at 64 consecutive records at a time; run heads
+// come from one ballot, the weights are prefix-summed across the wave, and a head's total inside
+// its 64-record segment is a difference of two prefix sums.  A run that reaches the end of its
+// segment picks up the leading non-head weights of the following segments (kept in LDS), and only
+// a run that leaves the tile's look-ahead window walks on in global memory.
+template <int KW, bool TABLE>
+__global__ __launch_bounds__(CT_THREADS) void k_ct_fast(const u32 *__restrict__ km, int64_t n,
+                                                        int kmer_bytes, int cutoff,
+                                                        u64 *__restrict__ hist,
+                                                        u64 *__restrict__ scal,
+                                                        u32 *__restrict__ tile_entries,
+                                                        const u64 *__restrict__ tile_off,
+                                                        u32 *__restrict__ table)
+{ constexpr int WIN  = CT_TILE + CT_AHEAD + 1;           // 2304 records = 36 segments of 64
+  constexpr int NSEG = WIN / 64;
+  constexpr int NIT  = WIN / CT_THREADS;                 // 9
+  __shared__ u32 low[TABLE ? 1 : CT_LOWBINS];
+  __shared__ u32 tmp[8];
+  __shared__ u32 s_run;
+  __shared__ __attribute__((aligned(16))) u32 recs[(WIN + 1) * KW];
+  __shared__ u32 prev[KW];
+  __shared__ u32 part[WIN];                              // head: run sum inside its segment | open << 31
+  __shared__ u32 lead[NSEG + 1];                         // weights before the first head of a segment
+  __shared__ u32 nohead[NSEG + 1];
+  if (!TABLE)
+    for (int i = threadIdx.x; i < CT_LOWBINS; i += CT_THREADS)
+      low[i] = 0;
+  if (threadIdx.x == 0)
+    s_run = 0;
+
+  const CtMask<KW> kmask = ct_make_mask<KW>(kmer_bytes);
+  const int cw  = (KW * 4 - 2) >> 2;
+  const int csh = 8 * ((KW * 4 - 2) & 3);
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+
+  const int64_t t0 = (int64_t) blockIdx.x * CT_TILE;
+  int64_t gend = t0 + WIN;
+  if (gend > n) gend = n;
+  const int nl = (int) (gend - t0);
+  fk_stage16<(WIN * KW + 1023) / 1024, false>(recs, km + t0 * KW, nl * KW);
+  if (t0 > 0 && threadIdx.x < KW)
+    prev[threadIdx.x] = km[(t0 - 1) * KW + threadIdx.x];
+  __syncthreads();
+
+  // ---- phase 1: per 64-record segment -----------------------------------------------------
+#pragma unroll 1
+  for (int it = 0; it < NIT; it++)
+    { const int l = it * CT_THREADS + threadIdx.x;
+      bool head = false;
+      u32  wt = 0;
+      if (l < nl)
+        { const u32 *r = recs + l * KW;
+          head = (t0 + l == 0) || !ct_same_key<KW>(r, (l > 0) ? r - KW : prev, kmask);
+          wt = (r[cw] >> csh) & 0xffffu;
+        }
+      const u64 hm = __ballot(head);
+      u32 S = wt;                                   // inclusive prefix sum over the wave
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1)
+        { const u32 y = (u32) __shfl_up((int) S, o, 64);
+          if (lane >= o) S += y;
+        }
+      const u64 above = (lane == 63) ? 0ull : (hm >> (lane + 1));
+      const int e     = (above != 0) ? lane + 1 + (__ffsll((unsigned long long) above) - 1) : 64;
+      const u32 Se    = (u32) __shfl((int) S, e - 1, 64);
+      const int first = (hm != 0) ? (__ffsll((unsigned long long) hm) - 1) : 64;
+      const u32 Sl    = (u32) __shfl((int) S, (first > 0 ? first : 1) - 1, 64);
+      if (l < WIN)
+        part[l] = head ? ((Se - S + wt) | ((e == 64) ? 0x80000000u : 0u)) : 0u;
+      if (lane == 0)
+        { const int sg = it * (CT_THREADS / 64) + wave;
+          lead[sg]   = (first == 0) ? 0u : Sl;
+          nohead[sg] = (hm == 0) ? 1u : 0u;
+        }
+    }
+  __syncthreads();
+
+  // ---- phase 2: totals, histogram, table -------------------------------------------------------
+  const int nseg = (nl + 63) >> 6;
+  const u64 base = TABLE ? tile_off[blockIdx.x] : 0ull;
+  u32 entries = 0, distinct = 0;
+  u64 maxi = 0;
+#pragma unroll 1
+  for (int it = 0; it < CT_ITEMS; it++)
+    { const int l = it * CT_THREADS + threadIdx.x;
+      const u32 *r = recs + l * KW;
+      u32 mycnt = 0;
+      const u32 v = (l < nl) ? part[l] : 0u;
+      if (v != 0)
+        { u64 cnt = v & 0x7fffffffu;
+          if (v >> 31)
+            { int sg = (l >> 6) + 1;
+              bool open = true;
+              while (open && sg < nseg)
+                { cnt += lead[sg];
+                  open = (nohead[sg] != 0);
+                  sg += 1;
+                }
+              if (open)                               // run leaves the window: rare
+                for (int64_t j = t0 + nl; j < n; j++)
+                  { const u32 *q = km + j * KW;
+                    if (!ct_same_key<KW>(r, q, kmask))
+                      break;
+                    cnt += (q[cw] >> csh) & 0xffffu;
+                  }
+            }
+          distinct += 1;
+          if (cnt >= 0x7fff)                                     // MSDsort.c:498-506
+            { maxi += cnt;
+              cnt = 0x7fff;
+            }
+          mycnt = (u32) cnt;
+        }
+      const bool take = (cutoff > 0 && mycnt >= (u32) cutoff);
+      if (!TABLE)
+        { if (take)
+            entries += 1;
+          if (mycnt != 0)
+            { if (mycnt < CT_LOWBINS)
+                atomicAdd(&low[mycnt], 1u);
+              else
+                atomicAdd(&hist[mycnt], 1ull);
+            }
+        }
+      else
+        { u32 tot;
+          const u32 ex  = fk_block_exscan_256<u32>(take ? 1u : 0u, tmp, &tot);
+          const u32 run = s_run;
+          __syncthreads();
+          if (threadIdx.x == 0)
+            s_run = run + tot;
+          if (take)
+            { u32 *dst = table + (base + run + ex) * KW;
+#pragma unroll
+              for (int w = 0; w < KW; w++)
+                dst[w] = (w == cw) ? ((r[w] & ~(0xffffu << csh)) | (mycnt << csh)) : r[w];
+            }
+        }
+    }
+  if (TABLE)
+    return;
+  __syncthreads();
+  for (int i = threadIdx.x; i < CT_LOWBINS; i += CT_THREADS)
+    if (low[i] != 0)
+      atomicAdd(&hist[i], (u64) low[i]);
+  u32 te, td;
+  (void) fk_block_exscan_256<u32>(entries, tmp, &te);
+  (void) fk_block_exscan_256<u32>(distinct, tmp, &td);
+  if (threadIdx.x == 0)
+    { tile_entries[blockIdx.x] = te;
+      if (td != 0)
+        atomicAdd(&scal[1], (u64) td);
+    }
+  if (maxi != 0)
+    atomicAdd(&scal[0], maxi);
+}
+
 // sorted_bytes < KMER_BYTES: the records are ordered on their first sorted_bytes key bytes only;
 // returns FK_ESTATE (nothing accumulated) when some prefix run could not be resolved inside LDS.
 template <int KW>
@@ -333,8 +491,8 @@ static int count_t(fk_ctx *ctx, void *d_kmers, int64_t n, int cutoff, int sorted
                            (const u32 *) d_kmers, n, ctx->wid.kmer_bytes, sorted_bytes, cutoff, d_hist,
                            d_scal, d_ent, (const u64 *) NULL, (u32 *) NULL);
       else
-        hipLaunchKernelGGL((k_ct_count<KW, false, false>), dim3((unsigned) ntiles), dim3(CT_THREADS), 0, s,
-                           (const u32 *) d_kmers, n, ctx->wid.kmer_bytes, sorted_bytes, cutoff, d_hist,
+        hipLaunchKernelGGL((k_ct_fast<KW, false>), dim3((unsigned) ntiles), dim3(CT_THREADS), 0, s,
+                           (const u32 *) d_kmers, n, ctx->wid.kmer_bytes, cutoff, d_hist,
                            d_scal, d_ent, (const u64 *) NULL, (u32 *) NULL);
       hipLaunchKernelGGL(k_exscan_tiles, dim3(1), dim3(256), 0, s, (const u32 *) d_ent, ntiles,
                          d_off, d_scal + 2);
@@ -365,8 +523,8 @@ static int count_t(fk_ctx *ctx, void *d_kmers, int64_t n, int cutoff, int sorted
                            (const u32 *) d_kmers, n, ctx->wid.kmer_bytes, sorted_bytes, cutoff, d_hist,
                            d_scal, d_ent, (const u64 *) d_off, (u32 *) d_table);
       else
-        hipLaunchKernelGGL((k_ct_count<KW, true, false>), dim3((unsigned) ntiles), dim3(CT_THREADS), 0, s,
-                           (const u32 *) d_kmers, n, ctx->wid.kmer_bytes, sorted_bytes, cutoff, d_hist,
+        hipLaunchKernelGGL((k_ct_fast<KW, true>), dim3((unsigned) ntiles), dim3(CT_THREADS), 0, s,
+                           (const u32 *) d_kmers, n, ctx->wid.kmer_bytes, cutoff, d_hist,
                            d_scal, d_ent, (const u64 *) d_off, (u32 *) d_table);
       if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
         { rc = FK_EHIP; break; }
