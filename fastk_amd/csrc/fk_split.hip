@@ -60,12 +60,12 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
   __shared__ uint16_t inv16[SP_WORDS];
   __shared__ uint16_t wpre[SP_WORDS];
   __shared__ u32      keys[SP_KEYS + SP_KEYS / 16 + 1];
+  u32 *slist = keys;          // the keys are dead once every thread has its window minima (step 3)
   __shared__ uint16_t mtab[1024];
   __shared__ uint8_t  mbucket[1024];
   __shared__ u32      lastkey[SP_THREADS];
   __shared__ uint16_t sbits[SP_THREADS + 16];
   __shared__ uint16_t vbits[SP_THREADS + 16];
-  __shared__ u32      slist[EMIT ? SP_TILE : 1];
   __shared__ u32      bcnt[256];
   __shared__ u32      bcnt2[256];
   __shared__ u64      bbase[256];
@@ -140,10 +140,16 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
       }
   }
   // ---- 2. canonical 5-mer keys: (rank << 14 | position) << 1 | flip ------------------------
-  for (int j = tid; j < SP_TILE + W; j += SP_THREADS)
-    { const u32 v = sp_window(fwd, j) >> 22;
-      const u32 m = mtab[v];
-      keys[SP_KIDX(j)] = (((m >> 1) << 14) | (u32) j) << 1 | (m & 1u);
+  //      one thread rolls a 64-bit window over the 16 positions of a packed word
+  for (int q = tid; 16 * q < SP_TILE + W; q += SP_THREADS)
+    { const u64 x = (((u64) fwd[q]) << 32) | (u64) fwd[q + 1];
+#pragma unroll
+      for (int c = 0; c < 16; c++)
+        { const int j = 16 * q + c;
+          const u32 v = (u32) (x >> (54 - 2 * c)) & 0x3ffu;
+          const u32 m = mtab[v];
+          keys[SP_KIDX(j)] = (((m >> 1) << 14) | (u32) j) << 1 | (m & 1u);
+        }
     }
   __syncthreads();
 
@@ -180,15 +186,20 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
     }
 
   // ---- 4. validity of each k-mer: no invalid base in [i, i+K) ------------------------------
+  //      prefix counts of invalid bases; the 16 window ends of a thread touch two packed words
   u32 vmask = 0;
+  { const u32 w0 = wpre[tid], m0 = inv16[tid];
+    const int qe = tid + (K >> 4);
+    const u32 we0 = wpre[qe], me0 = inv16[qe], we1 = wpre[qe + 1], me1 = inv16[qe + 1];
 #pragma unroll
-  for (int c = 0; c < SP_CH; c++)
-    { const int i = i0 + c;
-      const int e = i + K;
-      const u32 ci = wpre[i >> 4] + __popc((u32) inv16[i >> 4] & ((1u << (i & 15)) - 1u));
-      const u32 ce = wpre[e >> 4] + __popc((u32) inv16[e >> 4] & ((1u << (e & 15)) - 1u));
-      vmask |= (ci == ce ? 1u : 0u) << c;
-    }
+    for (int c = 0; c < SP_CH; c++)
+      { const int  eo  = c + (K & 15);                     // offset of the window end from word qe
+        const u32  ci  = w0 + __popc(m0 & ((1u << c) - 1u));
+        const bool hi  = (eo >= 16);
+        const u32  ce  = (hi ? we1 : we0) + __popc((hi ? me1 : me0) & ((1u << (eo & 15)) - 1u));
+        vmask |= (ci == ce ? 1u : 0u) << c;
+      }
+  }
   lastkey[tid] = mk[SP_CH - 1];
   vbits[tid]   = (uint16_t) vmask;
   if (tid < 16)
