@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--cpu-sample-mbp", type=float, default=20.0,
                     help="genome size of the bounded CPU-baseline sample (same coverage/shape)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-shard", action="store_true",
+                    help="run the sharded (all-to-all) path even on one GPU: exercises RCCL + shard.py")
     return ap.parse_args()
 
 
@@ -106,9 +108,13 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    sharded = world > 1 or args.force_shard
+    if sharded:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if "MASTER_ADDR" not in os.environ:
+            os.environ["MASTER_ADDR"] = "127.0.0.1"
+            os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
 
     L = args.read_len
     glen = int(args.genome_mbp * 1e6) * world
@@ -127,13 +133,13 @@ def main():
     engine = shard.HipEngine(ctx, dev)
 
     def step():
-        if world == 1:
+        if not sharded:
             return ctx.count_device_reads(reads.data_ptr(), nbytes, fetch_table=False)
         return shard.count_sharded(engine, reads[:nbytes])
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if sharded:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -146,12 +152,12 @@ def main():
         last = step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if sharded:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    if world == 1:
+    if not sharded:
         loc = last
         ninst, nsuper, nweighted, ndistinct = last.ninst, last.nsuper, last.nweighted, last.ndistinct
     else:
@@ -222,7 +228,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out))
     ctx.close()
-    if world > 1:
+    if sharded:
         dist.destroy_process_group()
 
 

@@ -20,7 +20,7 @@ EXPORTS = [
     "fk_msd_sort_records", "fk_expand_kmers", "fk_count_kmers", "fk_synth_reads",
     "fk_device_alloc", "fk_device_free", "fk_copy_to_device", "fk_copy_to_host",
     "fk_get_sort_stats", "fk_version", "fk_count_device_reads", "fk_count_device_supermers", "fk_debug_set", "fk_group_records",
-    "fk_count_presorted_kmers",
+    "fk_count_presorted_kmers", "fk_split_supermers_emit",
 ]
 
 
@@ -89,6 +89,7 @@ def load_library():
     L.fk_write_hist.argtypes = [C.POINTER(CResult), ci, C.c_char_p]
     L.fk_write_ktab.argtypes = [C.POINTER(CResult), ci, ci, ci, C.c_char_p, C.c_char_p]
     L.fk_split_supermers.argtypes = [vp, vp, i64, vp, i64, C.POINTER(i64), C.POINTER(i64), vp]
+    L.fk_split_supermers_emit.argtypes = [vp, vp, i64, vp, i64, vp]
     L.fk_lsd_sort_records.argtypes = [vp, i64, vp, vp, ci, C.POINTER(ci), C.POINTER(vp)]
     L.fk_group_records.argtypes = [vp, i64, vp, vp, ci, C.POINTER(vp)]
     L.fk_msd_sort_records.argtypes = [vp, vp, vp, i64, ci, ci, C.POINTER(vp)]
@@ -261,6 +262,10 @@ class Context:
         self._ck(self.L.fk_split_supermers(self.h, reads_ptr, nbytes, out_ptr, cap, C.byref(ns),
                                            C.byref(ni), bc))
         return ns.value, ni.value, list(bc)[:self.params.nbuckets]
+
+    def split_emit(self, reads_ptr, nbytes, out_ptr, cap, counts):
+        bc = (C.c_int64 * 256)(*counts)
+        self._ck(self.L.fk_split_supermers_emit(self.h, reads_ptr, nbytes, out_ptr, cap, bc))
 
     def lsd_sort(self, src_ptr, trg_ptr, nelem, rsize, byte_list):
         bl = (C.c_int * (len(byte_list) + 1))(*(list(byte_list) + [-1]))

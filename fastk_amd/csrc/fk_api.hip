@@ -324,6 +324,31 @@ extern "C" int fk_split_supermers(fk_ctx *ctx, const void *d_bases, int64_t nbyt
   return fkx_split(ctx, d_bases, nbytes, d_out, cap, nsuper, ninst, bucket_counts, false);
 }
 
+/* Emit only: bucket_counts[] holds the result of an earlier fk_split_supermers(cap = 0) call on the
+   same input, so the counting kernel is not run again. */
+extern "C" int fk_split_supermers_emit(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out,
+                                       int64_t cap, const int64_t *bucket_counts)
+{ if (ctx == NULL || d_bases == NULL || d_out == NULL || bucket_counts == NULL || nbytes < 0)
+    return (FK_EINVAL);
+  if (((uintptr_t) d_bases & 15) != 0)
+    { fk_set_error(ctx, "fk_split_supermers_emit: read buffer must be 16-byte aligned");
+      return (FK_EINVAL);
+    }
+  int64_t bc[256], ns = 0, ni = 0;
+  for (int b = 0; b < ctx->prm.nbuckets; b++)
+    { bc[b] = bucket_counts[b];
+      ns += bc[b];
+    }
+  if (cap < ns)
+    { fk_set_error(ctx, "fk_split_supermers_emit: buffer holds %lld records, %lld needed",
+                   (long long) cap, (long long) ns);
+      return (FK_EINVAL);
+    }
+  if (ns == 0)
+    return (FK_OK);
+  return fkx_split(ctx, d_bases, nbytes, d_out, cap, &ns, &ni, bc, true);
+}
+
 extern "C" int fk_lsd_sort_records(fk_ctx *ctx, int64_t nelem, void *d_src, void *d_trg, int rsize,
                                    const int *bytes, void **result)
 { if (ctx == NULL || bytes == NULL || result == NULL || nelem < 0) return (FK_EINVAL);

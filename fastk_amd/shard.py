@@ -31,13 +31,53 @@ class HipEngine:
         n = reads.numel()
         ns, ni, counts = self.ctx.split(reads.data_ptr(), n)
         recs = torch.empty(max(ns, 1) * self.stride, dtype=torch.uint8, device=self.device)
-        self.ctx.split(reads.data_ptr(), n, recs.data_ptr(), ns)
+        if ns:
+            self.ctx.split_emit(reads.data_ptr(), n, recs.data_ptr(), ns, counts)
         return recs[: ns * self.stride], counts, ni
 
     def count_supermers(self, recs, nsuper):
         res = self.ctx.count_device_supermers(recs.data_ptr() if nsuper else None, nsuper)
         return dict(hist=res.hist, max_inst=res.max_inst, nweighted=res.nweighted,
                     ndistinct=res.ndistinct, ntable=res.ntable, result=res)
+
+
+# One all_to_all_single call moves at most this many bytes between any pair of ranks: element counts
+# beyond 2^31 are not safe in every layer underneath (observed: a 4.7 GB self-exchange lost records).
+MAX_PAIR_BYTES = 1 << 30
+
+
+def _exchange_records(recs, inbox, send_n, recv_n, stride, group):
+    """all-to-all-v of fixed-width records in rounds of bounded size.  recs holds the outgoing records
+    grouped by destination rank, inbox receives them grouped by source rank."""
+    world = len(send_n)
+    dev = recs.device
+    per = max(1, MAX_PAIR_BYTES // stride)                     # records per pair and round
+    most = torch.tensor([max(send_n + [0])], dtype=torch.int64, device=dev)
+    dist.all_reduce(most, op=dist.ReduceOp.MAX, group=group)
+    rounds = max(1, -(-int(most.item()) // per))
+    s_off = [0] * world
+    r_off = [0] * world
+    for i in range(1, world):
+        s_off[i] = s_off[i - 1] + send_n[i - 1]
+        r_off[i] = r_off[i - 1] + recv_n[i - 1]
+    if rounds == 1:
+        dist.all_to_all_single(inbox, recs, output_split_sizes=[c * stride for c in recv_n],
+                               input_split_sizes=[c * stride for c in send_n], group=group)
+        return
+    for r in range(rounds):
+        sl = [max(0, min(per, send_n[d] - r * per)) for d in range(world)]
+        rl = [max(0, min(per, recv_n[d] - r * per)) for d in range(world)]
+        out_parts = [recs[(s_off[d] + r * per) * stride:(s_off[d] + r * per + sl[d]) * stride]
+                     for d in range(world)]
+        sbuf = torch.cat(out_parts) if sum(sl) else recs[:0]
+        rbuf = torch.empty(sum(rl) * stride, dtype=torch.uint8, device=dev)
+        dist.all_to_all_single(rbuf, sbuf, output_split_sizes=[c * stride for c in rl],
+                               input_split_sizes=[c * stride for c in sl], group=group)
+        o = 0
+        for d in range(world):
+            inbox[(r_off[d] + r * per) * stride:(r_off[d] + r * per + rl[d]) * stride] = \
+                rbuf[o:o + rl[d] * stride]
+            o += rl[d] * stride
 
 
 def count_sharded(engine, reads, group=None):
@@ -54,22 +94,25 @@ def count_sharded(engine, reads, group=None):
     send = torch.tensor(counts, dtype=torch.int64, device=dev)
     recv = torch.empty_like(send)
     dist.all_to_all_single(recv, send, group=group)
-    send_l = [int(c) * stride for c in counts]
-    recv_l = [int(c) * stride for c in recv.tolist()]
-    nrecv = sum(recv_l) // stride
-    inbox = torch.empty(max(sum(recv_l), 1), dtype=torch.uint8, device=dev)[: sum(recv_l)]
-    dist.all_to_all_single(inbox, recs, output_split_sizes=recv_l, input_split_sizes=send_l,
-                           group=group)
+    send_n = [int(c) for c in counts]
+    recv_n = [int(c) for c in recv.tolist()]
+    nrecv = sum(recv_n)
+    inbox = torch.empty(max(nrecv, 1) * stride, dtype=torch.uint8, device=dev)[: nrecv * stride]
+    _exchange_records(recs, inbox, send_n, recv_n, stride, group)
     del recs
 
     loc = engine.count_supermers(inbox, nrecv)
 
     tot = torch.zeros(HIST_BINS + 8, dtype=torch.int64, device=dev)
     tot[:HIST_BINS] = torch.from_numpy(np.asarray(loc["hist"], dtype=np.int64)).to(dev)
-    extra = [loc["max_inst"], ninst, nrecv, loc["nweighted"], loc["ndistinct"], loc["ntable"]]
-    tot[HIST_BINS:HIST_BINS + 6] = torch.tensor(extra, dtype=torch.int64, device=dev)
+    extra = [loc["max_inst"], ninst, nrecv, loc["nweighted"], loc["ndistinct"], loc["ntable"],
+             sum(send_n)]
+    tot[HIST_BINS:HIST_BINS + 7] = torch.tensor(extra, dtype=torch.int64, device=dev)
     dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=group)
     t = tot.cpu().numpy()
+    if int(t[HIST_BINS + 2]) != int(t[HIST_BINS + 6]):
+        raise RuntimeError("super-mer exchange lost records: %d sent, %d received"
+                           % (int(t[HIST_BINS + 6]), int(t[HIST_BINS + 2])))
     return dict(hist=t[:HIST_BINS].copy(), max_inst=int(t[HIST_BINS]), ninst=int(t[HIST_BINS + 1]),
                 nsuper=int(t[HIST_BINS + 2]), nweighted=int(t[HIST_BINS + 3]),
                 ndistinct=int(t[HIST_BINS + 4]), ntable=int(t[HIST_BINS + 5]), local=loc)

@@ -139,6 +139,11 @@ int fk_split_supermers(fk_ctx *ctx, const void *d_bases, int64_t nbytes,
                        void *d_out, int64_t cap, int64_t *nsuper, int64_t *ninst,
                        int64_t *bucket_counts);
 
+/* Second half of fk_split_supermers for callers that sized their buffer from a cap == 0 call:
+   bucket_counts[] is that call's result; only the emit kernel runs. */
+int fk_split_supermers_emit(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out,
+                            int64_t cap, const int64_t *bucket_counts);
+
 /* Stable LSD byte radix sort; same contract as
      void *LSD_Sort(int64 nelem, void *src, void *trg, int rsize, int *bytes)   (FastK.h:154,
    LSDsort.c:115): bytes[] is a -1 terminated list, least significant first; *result receives

@@ -329,3 +329,21 @@ def test_count_reports_unresolvable_prefix_runs(ctx40):
     a = ctx40.alloc(recs.nbytes).upload(recs)
     assert ctx40.count(a.ptr, n, 1, None, 0, sorted_bytes=4) is None
     a.free()
+
+
+def test_sharded_path_on_one_gpu_matches_plain_path():
+    """bench.py --force-shard runs split -> RCCL all-to-all-v (one rank) -> count through
+    fastk_amd.shard.HipEngine; totals must equal the single-context pipeline's."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for extra in ([], ["--force-shard"]):
+        cmd = [sys.executable, os.path.join(root, "bench.py"), "--genome-mbp", "2", "--steps", "1",
+               "--warmup", "0", "--no-cpu-baseline"] + extra
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
+        p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        line = [x for x in p.stdout.splitlines() if x.startswith("{")][-1]
+        outs.append(json.loads(line)["config"])
+    for key in ("kmer_instances", "supermers", "distinct_kmers"):
+        assert outs[0][key] == outs[1][key], key

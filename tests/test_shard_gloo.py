@@ -66,6 +66,7 @@ def _worker(rank, world, port, name, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from fastk_amd import shard
+    shard.MAX_PAIR_BYTES = 4096       # force the multi-round exchange
     case, bases, boff = util.load_case(name)
     nreads = len(boff) - 1
     lo, hi = rank * nreads // world, (rank + 1) * nreads // world
