@@ -132,10 +132,10 @@ def main():
     torch.cuda.synchronize()
     engine = shard.HipEngine(ctx, dev)
 
-    def step():
+    def step(verify=False):
         if not sharded:
             return ctx.count_device_reads(reads.data_ptr(), nbytes, fetch_table=False)
-        return shard.count_sharded(engine, reads[:nbytes])
+        return shard.count_sharded(engine, reads[:nbytes], verify=verify)
 
     def barrier():
         torch.cuda.synchronize()
@@ -145,7 +145,7 @@ def main():
 
     last = None
     for _ in range(args.warmup):
-        last = step()
+        last = step(verify=True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):

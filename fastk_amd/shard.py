@@ -80,8 +80,10 @@ def _exchange_records(recs, inbox, send_n, recv_n, stride, group):
             o += rl[d] * stride
 
 
-def count_sharded(engine, reads, group=None):
+def count_sharded(engine, reads, group=None, verify=False):
     """Run the sharded path; every rank returns the same global totals.
+
+    verify=True adds a checksum of the exchanged payload (used by bench.py's warm-up steps).
 
     Returns dict(hist int64[0x8000], max_inst, ninst, nsuper, nweighted, ndistinct, ntable,
     local=<this rank's engine result>)."""
@@ -99,6 +101,12 @@ def count_sharded(engine, reads, group=None):
     nrecv = sum(recv_n)
     inbox = torch.empty(max(nrecv, 1) * stride, dtype=torch.uint8, device=dev)[: nrecv * stride]
     _exchange_records(recs, inbox, send_n, recv_n, stride, group)
+    if verify:
+        # payload check: the byte sum of everything sent equals the byte sum of everything received
+        chk = torch.stack([recs.sum(dtype=torch.int64), inbox.sum(dtype=torch.int64)])
+        dist.all_reduce(chk, op=dist.ReduceOp.SUM, group=group)
+        if int(chk[0].item()) != int(chk[1].item()):
+            raise RuntimeError("super-mer exchange corrupted the payload (checksums differ)")
     del recs
 
     loc = engine.count_supermers(inbox, nrecv)

@@ -72,7 +72,7 @@ def _worker(rank, world, port, name, q):
     lo, hi = rank * nreads // world, (rank + 1) * nreads // world
     mine = torch.from_numpy(bases[boff[lo]:boff[hi]].copy())
     eng = OracleEngine(case["k"], world, case["cutoff"])
-    out = shard.count_sharded(eng, mine)
+    out = shard.count_sharded(eng, mine, verify=True)
     tabs = [None] * world
     dist.all_gather_object(tabs, out["local"]["result"].table)
     if rank == 0:
