@@ -15,6 +15,7 @@
 #define CT_TILE    (CT_THREADS * CT_ITEMS)
 #define CT_LOWBINS 4096
 #define CT_AHEAD   255
+#define CT_TPB     8       // tiles per workgroup in k_ct_fast (one histogram flush per workgroup)
 #define CT_FIXCAP  1024    // heterogeneous prefix runs repaired per tile
 #define CT_MAXFIX  192     // longest heterogeneous prefix run one thread insertion-sorts
 
@@ -337,7 +338,18 @@ __global__ __launch_bounds__(CT_THREADS) void k_ct_fast(const u32 *__restrict__ 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
 
-  const int64_t t0 = (int64_t) blockIdx.x * CT_TILE;
+  u32 entries = 0, distinct = 0;
+  u64 maxi = 0;
+#pragma unroll 1
+  for (int tb = 0; tb < CT_TPB; tb++)
+  {
+  const int64_t tileno = (int64_t) blockIdx.x * CT_TPB + tb;
+  const int64_t t0 = tileno * CT_TILE;
+  if (t0 >= n)
+    break;
+  __syncthreads();                                       // LDS of the previous tile is free
+  if (threadIdx.x == 0)
+    s_run = 0;
   int64_t gend = t0 + WIN;
   if (gend > n) gend = n;
   const int nl = (int) (gend - t0);
@@ -381,9 +393,8 @@ __global__ __launch_bounds__(CT_THREADS) void k_ct_fast(const u32 *__restrict__ 
 
   // ---- phase 2: totals, histogram, table -------------------------------------------------------
   const int nseg = (nl + 63) >> 6;
-  const u64 base = TABLE ? tile_off[blockIdx.x] : 0ull;
-  u32 entries = 0, distinct = 0;
-  u64 maxi = 0;
+  const u64 base = TABLE ? tile_off[tileno] : 0ull;
+  u32 tentries = 0;
 #pragma unroll 1
   for (int it = 0; it < CT_ITEMS; it++)
     { const int l = it * CT_THREADS + threadIdx.x;
@@ -418,7 +429,7 @@ __global__ __launch_bounds__(CT_THREADS) void k_ct_fast(const u32 *__restrict__ 
       const bool take = (cutoff > 0 && mycnt >= (u32) cutoff);
       if (!TABLE)
         { if (take)
-            entries += 1;
+            tentries += 1;
           if (mycnt != 0)
             { if (mycnt < CT_LOWBINS)
                 atomicAdd(&low[mycnt], 1u);
@@ -441,20 +452,25 @@ __global__ __launch_bounds__(CT_THREADS) void k_ct_fast(const u32 *__restrict__ 
             }
         }
     }
+  if (!TABLE)
+    { u32 te;
+      (void) fk_block_exscan_256<u32>(tentries, tmp, &te);
+      if (threadIdx.x == 0)
+        tile_entries[tileno] = te;
+    }
+  (void) entries;
+  }   // tiles of this workgroup
   if (TABLE)
     return;
   __syncthreads();
+  // one histogram flush per CT_TPB tiles (global 64-bit atomics are the expensive part)
   for (int i = threadIdx.x; i < CT_LOWBINS; i += CT_THREADS)
     if (low[i] != 0)
       atomicAdd(&hist[i], (u64) low[i]);
-  u32 te, td;
-  (void) fk_block_exscan_256<u32>(entries, tmp, &te);
+  u32 td;
   (void) fk_block_exscan_256<u32>(distinct, tmp, &td);
-  if (threadIdx.x == 0)
-    { tile_entries[blockIdx.x] = te;
-      if (td != 0)
-        atomicAdd(&scal[1], (u64) td);
-    }
+  if (threadIdx.x == 0 && td != 0)
+    atomicAdd(&scal[1], (u64) td);
   if (maxi != 0)
     atomicAdd(&scal[0], maxi);
 }
@@ -491,7 +507,7 @@ static int count_t(fk_ctx *ctx, void *d_kmers, int64_t n, int cutoff, int sorted
                            (const u32 *) d_kmers, n, ctx->wid.kmer_bytes, sorted_bytes, cutoff, d_hist,
                            d_scal, d_ent, (const u64 *) NULL, (u32 *) NULL);
       else
-        hipLaunchKernelGGL((k_ct_fast<KW, false>), dim3((unsigned) ntiles), dim3(CT_THREADS), 0, s,
+        hipLaunchKernelGGL((k_ct_fast<KW, false>), dim3((unsigned) ((ntiles + CT_TPB - 1) / CT_TPB)), dim3(CT_THREADS), 0, s,
                            (const u32 *) d_kmers, n, ctx->wid.kmer_bytes, cutoff, d_hist,
                            d_scal, d_ent, (const u64 *) NULL, (u32 *) NULL);
       hipLaunchKernelGGL(k_exscan_tiles, dim3(1), dim3(256), 0, s, (const u32 *) d_ent, ntiles,
@@ -523,7 +539,7 @@ static int count_t(fk_ctx *ctx, void *d_kmers, int64_t n, int cutoff, int sorted
                            (const u32 *) d_kmers, n, ctx->wid.kmer_bytes, sorted_bytes, cutoff, d_hist,
                            d_scal, d_ent, (const u64 *) d_off, (u32 *) d_table);
       else
-        hipLaunchKernelGGL((k_ct_fast<KW, true>), dim3((unsigned) ntiles), dim3(CT_THREADS), 0, s,
+        hipLaunchKernelGGL((k_ct_fast<KW, true>), dim3((unsigned) ((ntiles + CT_TPB - 1) / CT_TPB)), dim3(CT_THREADS), 0, s,
                            (const u32 *) d_kmers, n, ctx->wid.kmer_bytes, cutoff, d_hist,
                            d_scal, d_ent, (const u64 *) d_off, (u32 *) d_table);
       if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
