@@ -77,6 +77,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
   const int64_t t0  = (int64_t) blockIdx.x * a.tile_stride * SP_TILE;
   const int     nw  = SP_TILE / 16 + (K + 14) / 16; // words that hold real bases
   const int     R   = nw * 16;                     // bases covered by the packed arrays
+  const bool    one = (a.nbuckets == 1);           // single bucket: no per-record LDS atomics
 
   for (int i = tid; i < 1024; i += SP_THREADS)
     { mtab[i]    = a.mtab[i];
@@ -227,15 +228,11 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
   const u32 sidx0 = fk_block_exscan_256<u32>(__popc(smask), tmp32, &nstart_total);
   // (the scan's barriers also publish sbits)
 
-  if (tid == 0)
-    { u32 inst = 0;
-      (void) inst;
-    }
-  { // instances = valid k-mers in the tile
+  { // instances = valid k-mers in the tile, spread over 64 counters (summed by the host)
     u32 tot;
     (void) fk_block_exscan_256<u32>(__popc(vmask), tmp32, &tot);
     if (tid == 0 && tot != 0)
-      atomicAdd(&a.counts[256], (u64) tot);
+      atomicAdd(&a.counts[256 + (blockIdx.x & 63)], (u64) tot);
   }
 
   // ---- 6. one entry per super-mer: position, length, flip, rank ---------------------------
@@ -259,13 +256,15 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
           }
           const u32 key  = mk[c];
           const u32 rank = key >> 15;
-          const u32 b    = mbucket[rank];
-          atomicAdd(&bcnt[b], 1u);
+          if (!one)
+            atomicAdd(&bcnt[mbucket[rank]], 1u);
           if (EMIT)
             slist[k] = (u32) i | ((key & 1u) << 12) | ((u32) n << 13) | (rank << 20);
           k += 1;
         }
   }
+  if (one && tid == 0)
+    bcnt[0] = nstart_total;
   __syncthreads();
 
   if (!EMIT)
@@ -288,8 +287,8 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
       const u32 flip = (e >> 12) & 1u;
       const int n    = (e >> 13) & 0x7fu;
       const u32 rank = e >> 20;
-      const u32 b    = mbucket[rank];
-      const u64 slot = bbase[b] + atomicAdd(&bcnt2[b], 1u);
+      const u32 b    = one ? 0u : mbucket[rank];
+      const u64 slot = bbase[b] + (one ? s : atomicAdd(&bcnt2[b], 1u));
       if ((int64_t) slot >= a.cap)
         { *a.overflowed = 1;
           continue;
@@ -366,7 +365,7 @@ int fkx_split(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int
   if (!counts_known)
     { hipLaunchKernelGGL(k_split<false>, dim3((unsigned) ntiles), dim3(SP_THREADS), 0, s, a);
       FK_LAUNCH_CHECK(ctx);
-      FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch, d_counts, 257 * sizeof(u64), hipMemcpyDeviceToHost, s));
+      FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch, d_counts, 320 * sizeof(u64), hipMemcpyDeviceToHost, s));
       FK_HIP(ctx, hipStreamSynchronize(s));
       for (int b = 0; b < nb; b++)
         { base[b] = (u64) tot;
@@ -375,7 +374,12 @@ int fkx_split(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int
             bucket_counts[b] = (int64_t) ctx->h_scratch[b];
         }
       if (nsuper) *nsuper = tot;
-      if (ninst) *ninst = (int64_t) ctx->h_scratch[256];
+      if (ninst)
+        { int64_t t = 0;
+          for (int x = 0; x < 64; x++)
+            t += (int64_t) ctx->h_scratch[256 + x];
+          *ninst = t;
+        }
     }
   else
     for (int b = 0; b < nb; b++)
@@ -459,7 +463,11 @@ int fkx_split_fast(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void **d_ou
           FK_HIP(ctx, hipStreamSynchronize(s));
           if (*(u32 *) (ctx->h_scratch + 1024) == 0)
             { *nsuper = (int64_t) ctx->h_scratch[512];           // the cursor = records written
-              *ninst  = (int64_t) ctx->h_scratch[256];
+              { int64_t t = 0;
+                for (int x = 0; x < 64; x++)
+                  t += (int64_t) ctx->h_scratch[256 + x];
+                *ninst = t;
+              }
               *d_out  = out;
               return (FK_OK);
             }
