@@ -49,7 +49,8 @@ class CResult(C.Structure):
                 ("ms_sort_kmer", C.c_double), ("ms_count", C.c_double), ("ms_total", C.c_double),
                 ("passes_super", C.c_int), ("passes_kmer", C.c_int),
                 ("ms_pass_super", C.c_double), ("ms_pass_kmer", C.c_double),
-                ("ms_scatter_super", C.c_double), ("ms_scatter_kmer", C.c_double)]
+                ("ms_scatter_super", C.c_double), ("ms_scatter_kmer", C.c_double),
+                ("ncollapsed", C.c_int64), ("passes_final", C.c_int), ("ms_pass_final", C.c_double)]
 
 
 class SortStats(C.Structure):
@@ -134,6 +135,8 @@ class Result:
         self.ms_pass_super, self.ms_pass_kmer = float(cres.ms_pass_super), float(cres.ms_pass_kmer)
         self.ms_scatter_super = float(cres.ms_scatter_super)
         self.ms_scatter_kmer = float(cres.ms_scatter_kmer)
+        self.ncollapsed = int(cres.ncollapsed)
+        self.passes_final, self.ms_pass_final = int(cres.passes_final), float(cres.ms_pass_final)
         if self.ntable > 0 and cres.table:
             self.table = np.ctypeslib.as_array(cres.table, shape=(self.ntable, kmer_word)).copy()
         else:

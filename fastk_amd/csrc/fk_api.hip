@@ -371,7 +371,7 @@ extern "C" int fk_msd_sort_records(fk_ctx *ctx, void *d_array, void *d_tmp, int6
 extern "C" int fk_group_records(fk_ctx *ctx, int64_t nelem, void *d_src, void *d_trg, int rsize,
                                 void **result)
 { if (ctx == NULL || result == NULL || nelem < 0) return (FK_EINVAL);
-  return fkx_group(ctx, nelem, d_src, d_trg, rsize, result);
+  return fkx_group(ctx, nelem, d_src, d_trg, rsize, rsize, 5, result);
 }
 
 extern "C" int fk_expand_kmers(fk_ctx *ctx, const void *d_smers, int64_t nsuper, void *d_out,
@@ -508,6 +508,7 @@ extern "C" int fk_push_device(fk_ctx *ctx, const void *d_bases, int64_t nbytes)
 // read data: one-substitution error k-mers share long prefixes with their true k-mer, so about half
 // of all prefix runs are heterogeneous and would need a local sort (measured).
 #define FK_PREFIX_BYTES 64
+#define FK_GROUP_PASSES 4
 
 static double ms_between(hipEvent_t a, hipEvent_t b)
 { float ms = 0.f;
@@ -554,7 +555,7 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
       // super-mer "sort": only has to bring identical records together (Supermer_Sort's output is
       // consumed by the run-length pass of count.c:421-426), so five hashed digit passes suffice
       void *sm_sorted = sm_in;
-      { if ((rc = fkx_group(ctx, ns, sm_in, sm_b, w.smer_stride, &sm_sorted)) != FK_OK)
+      { if ((rc = fkx_group(ctx, ns, sm_in, sm_b, w.smer_stride, w.smer_stride, 5, &sm_sorted)) != FK_OK)
           break;
         res->passes_super  = ctx->sort_stats.passes;
         res->ms_pass_super = ctx->sort_stats.pass_ms_total;
@@ -574,25 +575,40 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
         }
       hipEventRecord(ev[3], s);
 
-      // weighted k-mer sort.  The reference sorts all KMER_BYTES (MSDsort.c:536); here four stable
-      // digit passes order the list on its first FK_PREFIX_BYTES key bytes and the count kernel
-      // resolves the few prefix runs that hold more than one k-mer inside LDS.  If some run cannot
-      // be resolved there (FK_ESTATE), the remaining digit passes are executed and the count repeats.
+      // weighted k-mer stage.  The reference sorts all W weighted records on KMER_BYTES
+      // (MSDsort.c:536).  Only the DISTINCT k-mers have to end up in lexicographic order, so the
+      // device first groups the W records by a 32-bit hash of the key (4 digit passes), collapses
+      // every run into one record (weights summed, clipped like count.c:455-458), and then runs
+      // the KMER_BYTES-pass sort on the ~W/4.4 collapsed records.  Keys whose hashes collide just
+      // stay split; the final count sums them after the real sort.
       void *km_sorted = km_a;
-      int   sorted_bytes = (w.kmer_bytes < FK_PREFIX_BYTES) ? w.kmer_bytes : FK_PREFIX_BYTES;
+      int   sorted_bytes = w.kmer_bytes;
+      int64_t nc = nw, ovf2 = 0;
       if (nw > 0)
         { if ((km_b = fk_slot(ctx, FK_SLOT_KM_B, nw * w.kmer_stride)) == NULL)
             { rc = FK_ENOMEM; break; }
-          int bytes[64];
-          for (int i = 0; i < sorted_bytes; i++)
-            bytes[i] = sorted_bytes - 1 - i;
-          if ((rc = fkx_lsd_sort(ctx, nw, km_a, km_b, w.kmer_stride, bytes, sorted_bytes,
-                                 &km_sorted)) != FK_OK)
+          void *grouped = km_a;
+          if ((rc = fkx_group(ctx, nw, km_a, km_b, w.kmer_stride, w.kmer_bytes, FK_GROUP_PASSES,
+                              &grouped)) != FK_OK)
             break;
           res->passes_kmer  = ctx->sort_stats.passes;
           res->ms_pass_kmer = ctx->sort_stats.pass_ms_total;
           res->ms_scatter_kmer = ctx->sort_stats.scatter_ms_total;
-          // first-byte census of the weighted k-mers = Kparts (count.c:1527-1535)
+          void *cbuf = (grouped == km_a) ? km_b : km_a;
+          if ((rc = fkx_collapse(ctx, grouped, nw, cbuf, nw, &nc, &ovf2)) != FK_OK)
+            break;
+          int bytes[64];
+          for (int i = 0; i < w.kmer_bytes; i++)
+            bytes[i] = w.kmer_bytes - 1 - i;
+          km_sorted = cbuf;
+          if ((rc = fkx_lsd_sort(ctx, nc, cbuf, grouped, w.kmer_stride, bytes, w.kmer_bytes,
+                                 &km_sorted)) != FK_OK)
+            break;
+          res->passes_final  = ctx->sort_stats.passes;
+          res->ms_pass_final = ctx->sort_stats.pass_ms_total;
+          res->ncollapsed    = nc;
+          km_a = cbuf; km_b = grouped;                 // the pair now in use
+          // first-byte census of the (collapsed) k-mers, for the .ktab part boundaries
           for (int x = 0; x < 256; x++)
             res->wfirst[x] = (int64_t) ctx->h_scratch[x];
         }
@@ -602,8 +618,8 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
       int64_t nt = 0, ndk = 0;
       const int cutoff = ctx->prm.table_cutoff;
       void *other = (km_sorted == km_a) ? km_b : km_a;
-      rc = fkx_count(ctx, km_sorted, nw, cutoff, sorted_bytes, res->hist, &res->max_inst, &ndk,
-                     cutoff > 0 ? other : NULL, nw, &nt);
+      rc = fkx_count(ctx, km_sorted, nc, cutoff, sorted_bytes, res->hist, &res->max_inst, &ndk,
+                     cutoff > 0 ? other : NULL, nc, &nt);
       if (rc == FK_ESTATE)
         { int bytes[64];
           for (int i = 0; i < w.kmer_bytes; i++)
@@ -622,7 +638,7 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
         }
       if (rc != FK_OK)
         break;
-      res->max_inst += ovf;                                  // count.c:1551
+      res->max_inst += ovf + ovf2;                           // count.c:1551
       res->ndistinct = ndk;
       res->ntable = (cutoff > 0) ? nt : 0;
       if (cutoff > 0 && nt > 0)
@@ -752,7 +768,10 @@ extern "C" int fk_write_ktab(const fk_result *res, int kmer, int table_cutoff, i
   else ib = 1;
 
   int *split = (int *) malloc(sizeof(int) * (nthreads + 1));
-  { int64_t asize = res->nweighted * KW, sum = 0, thr = asize / nthreads;
+  { int64_t asize = 0, sum = 0;
+    for (int x = 0; x < 256; x++)
+      asize += res->wfirst[x] * KW;
+    int64_t thr = asize / nthreads;
     int n = 0, beg = 0;
     for (int x = 0; x < 256; x++)
       { sum += res->wfirst[x] * KW;

@@ -86,7 +86,8 @@ void fk_set_error(fk_ctx *ctx, const char *fmt, ...);
 // stage entry points implemented in the per-stage .hip files (C++ linkage, internal)
 int fkx_lsd_sort(fk_ctx *ctx, int64_t nelem, void *d_src, void *d_trg, int rsize,
                  const int *bytes, int nbytes, void **result);
-int fkx_group(fk_ctx *ctx, int64_t nelem, void *d_src, void *d_trg, int rsize, void **result);
+int fkx_group(fk_ctx *ctx, int64_t nelem, void *d_src, void *d_trg, int rsize, int key_bytes,
+              int npasses, void **result);
 int fkx_split(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int64_t cap,
               int64_t *nsuper, int64_t *ninst, int64_t *bucket_counts, bool counts_known);
 int fkx_split_fast(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void **d_out, int64_t *nsuper,
@@ -96,6 +97,8 @@ int fkx_expand(fk_ctx *ctx, const void *d_smers, int64_t nsuper, void *d_out, in
 int fkx_count(fk_ctx *ctx, const void *d_kmers, int64_t nweighted, int cutoff, int sorted_bytes,
               int64_t *hist, int64_t *max_inst, int64_t *ndistinct,
               void *d_table, int64_t cap, int64_t *ntable);
+int fkx_collapse(fk_ctx *ctx, const void *d_kmers, int64_t n, void *d_out, int64_t cap,
+                 int64_t *nout, int64_t *overflow);
 int fkx_synth(fk_ctx *ctx, uint64_t seed, uint64_t genome_len, uint32_t read_len,
               uint32_t err_ppm, uint64_t first_read, int64_t nreads, void *d_bases);
 

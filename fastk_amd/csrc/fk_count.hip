@@ -314,8 +314,11 @@ __global__ __launch_bounds__(CT_THREADS) void k_ct_fast(const u32 *__restrict__ 
                                                         u64 *__restrict__ scal,
                                                         u32 *__restrict__ tile_entries,
                                                         const u64 *__restrict__ tile_off,
-                                                        u32 *__restrict__ table)
-{ constexpr int WIN  = CT_TILE + CT_AHEAD + 1;           // 2304 records = 36 segments of 64
+                                                        u32 *__restrict__ table, int collapse)
+{ // collapse != 0: the input is only GROUPED (equal k-mers adjacent); every run becomes one record
+  // carrying its weight sum clipped to 0x7fff, the clipped remainder goes to scal[4] (the same
+  // accounting as count.c:455-458); no histogram is taken -- that happens after the real sort.
+  constexpr int WIN  = CT_TILE + CT_AHEAD + 1;           // 2304 records = 36 segments of 64
   constexpr int NSEG = WIN / 64;
   constexpr int NIT  = WIN / CT_THREADS;                 // 9
   __shared__ u32 low[TABLE ? 1 : CT_LOWBINS];
@@ -420,17 +423,23 @@ __global__ __launch_bounds__(CT_THREADS) void k_ct_fast(const u32 *__restrict__ 
                   }
             }
           distinct += 1;
-          if (cnt >= 0x7fff)                                     // MSDsort.c:498-506
+          if (collapse)
+            { if (cnt > 0x7fff)
+                { maxi += cnt - 0x7fff;
+                  cnt = 0x7fff;
+                }
+            }
+          else if (cnt >= 0x7fff)                                // MSDsort.c:498-506
             { maxi += cnt;
               cnt = 0x7fff;
             }
           mycnt = (u32) cnt;
         }
-      const bool take = (cutoff > 0 && mycnt >= (u32) cutoff);
+      const bool take = collapse ? (mycnt != 0) : (cutoff > 0 && mycnt >= (u32) cutoff);
       if (!TABLE)
         { if (take)
             tentries += 1;
-          if (mycnt != 0)
+          if (mycnt != 0 && !collapse)
             { if (mycnt < CT_LOWBINS)
                 atomicAdd(&low[mycnt], 1u);
               else
@@ -461,6 +470,11 @@ __global__ __launch_bounds__(CT_THREADS) void k_ct_fast(const u32 *__restrict__ 
   (void) entries;
   }   // tiles of this workgroup
   if (TABLE)
+    { if (collapse && maxi != 0)
+        atomicAdd(&scal[4], maxi);
+      return;
+    }
+  if (collapse)
     return;
   __syncthreads();
   // one histogram flush per CT_TPB tiles (global 64-bit atomics are the expensive part)
@@ -509,7 +523,7 @@ static int count_t(fk_ctx *ctx, void *d_kmers, int64_t n, int cutoff, int sorted
       else
         hipLaunchKernelGGL((k_ct_fast<KW, false>), dim3((unsigned) ((ntiles + CT_TPB - 1) / CT_TPB)), dim3(CT_THREADS), 0, s,
                            (const u32 *) d_kmers, n, ctx->wid.kmer_bytes, cutoff, d_hist,
-                           d_scal, d_ent, (const u64 *) NULL, (u32 *) NULL);
+                           d_scal, d_ent, (const u64 *) NULL, (u32 *) NULL, 0);
       hipLaunchKernelGGL(k_exscan_tiles, dim3(1), dim3(256), 0, s, (const u32 *) d_ent, ntiles,
                          d_off, d_scal + 2);
       if (hipGetLastError() != hipSuccess) { rc = FK_EHIP; break; }
@@ -541,7 +555,7 @@ static int count_t(fk_ctx *ctx, void *d_kmers, int64_t n, int cutoff, int sorted
       else
         hipLaunchKernelGGL((k_ct_fast<KW, true>), dim3((unsigned) ((ntiles + CT_TPB - 1) / CT_TPB)), dim3(CT_THREADS), 0, s,
                            (const u32 *) d_kmers, n, ctx->wid.kmer_bytes, cutoff, d_hist,
-                           d_scal, d_ent, (const u64 *) d_off, (u32 *) d_table);
+                           d_scal, d_ent, (const u64 *) d_off, (u32 *) d_table, 0);
       if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
         { rc = FK_EHIP; break; }
     }
@@ -561,6 +575,59 @@ int fkx_count(fk_ctx *ctx, const void *d_kmers, int64_t nweighted, int cutoff, i
     case 3: return count_t<3>(ctx, (void *) d_kmers, nweighted, cutoff, sorted_bytes, hist, max_inst, ndistinct, d_table, cap, ntable);
     case 4: return count_t<4>(ctx, (void *) d_kmers, nweighted, cutoff, sorted_bytes, hist, max_inst, ndistinct, d_table, cap, ntable);
     case 5: return count_t<5>(ctx, (void *) d_kmers, nweighted, cutoff, sorted_bytes, hist, max_inst, ndistinct, d_table, cap, ntable);
+    default:
+      fk_set_error(ctx, "k-mer stride %d not built", ctx->wid.kmer_stride);
+      return (FK_EUNSUPPORTED);
+  }
+}
+
+// Grouped weighted k-mers -> one record per run with the weight sum (clipped, remainder in *overflow).
+template <int KW>
+static int collapse_t(fk_ctx *ctx, const void *d_kmers, int64_t n, void *d_out, int64_t cap,
+                      int64_t *nout, int64_t *overflow)
+{ hipStream_t s = ctx->stream;
+  const int64_t ntiles = (n + CT_TILE - 1) / CT_TILE;
+  *nout = 0; *overflow = 0;
+  if (n == 0)
+    return (FK_OK);
+  u32 *d_ent  = (u32 *) fk_slot(ctx, FK_SLOT_CT_ENT, ntiles * 4);
+  u64 *d_off  = (u64 *) fk_slot(ctx, FK_SLOT_CT_OFF, ntiles * 8);
+  u64 *d_hist = (u64 *) fk_slot(ctx, FK_SLOT_CT_HIST, (FK_HIST_BINS + 8) * 8);
+  if (d_ent == NULL || d_off == NULL || d_hist == NULL)
+    return (FK_ENOMEM);
+  u64 *d_scal = d_hist + FK_HIST_BINS;
+  const unsigned grid = (unsigned) ((ntiles + CT_TPB - 1) / CT_TPB);
+  FK_HIP(ctx, hipMemsetAsync(d_scal, 0, 8 * 8, s));
+  hipLaunchKernelGGL((k_ct_fast<KW, false>), dim3(grid), dim3(CT_THREADS), 0, s, (const u32 *) d_kmers, n,
+                     ctx->wid.kmer_bytes, 1, d_hist, d_scal, d_ent, (const u64 *) NULL, (u32 *) NULL, 1);
+  hipLaunchKernelGGL(k_exscan_tiles, dim3(1), dim3(256), 0, s, (const u32 *) d_ent, ntiles, d_off,
+                     d_scal + 2);
+  FK_LAUNCH_CHECK(ctx);
+  FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch, d_scal, 8 * 8, hipMemcpyDeviceToHost, s));
+  FK_HIP(ctx, hipStreamSynchronize(s));
+  *nout = (int64_t) ctx->h_scratch[2];
+  if (cap < *nout)
+    { fk_set_error(ctx, "collapse buffer too small: %lld records needed, %lld given",
+                   (long long) *nout, (long long) cap);
+      return (FK_EINVAL);
+    }
+  hipLaunchKernelGGL((k_ct_fast<KW, true>), dim3(grid), dim3(CT_THREADS), 0, s, (const u32 *) d_kmers, n,
+                     ctx->wid.kmer_bytes, 1, d_hist, d_scal, d_ent, (const u64 *) d_off, (u32 *) d_out, 1);
+  FK_LAUNCH_CHECK(ctx);
+  FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch, d_scal, 8 * 8, hipMemcpyDeviceToHost, s));
+  FK_HIP(ctx, hipStreamSynchronize(s));
+  *overflow = (int64_t) ctx->h_scratch[4];
+  return (FK_OK);
+}
+
+int fkx_collapse(fk_ctx *ctx, const void *d_kmers, int64_t n, void *d_out, int64_t cap,
+                 int64_t *nout, int64_t *overflow)
+{ switch (ctx->wid.kmer_stride >> 2)
+  { case 1: return collapse_t<1>(ctx, d_kmers, n, d_out, cap, nout, overflow);
+    case 2: return collapse_t<2>(ctx, d_kmers, n, d_out, cap, nout, overflow);
+    case 3: return collapse_t<3>(ctx, d_kmers, n, d_out, cap, nout, overflow);
+    case 4: return collapse_t<4>(ctx, d_kmers, n, d_out, cap, nout, overflow);
+    case 5: return collapse_t<5>(ctx, d_kmers, n, d_out, cap, nout, overflow);
     default:
       fk_set_error(ctx, "k-mer stride %d not built", ctx->wid.kmer_stride);
       return (FK_EUNSUPPORTED);

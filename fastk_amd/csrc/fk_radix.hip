@@ -36,13 +36,18 @@ __device__ __forceinline__ u64 st_pack(u32 epoch, u64 flag, u64 val)
 // 64-bit mix of a whole record, for GROUPING identical records (fkx_group): the digit of pass p is
 // byte p of the hash, so five passes make identical records adjacent whatever their width.
 template <int RW>
-__device__ __forceinline__ u32 rx_hash_digit(const u32 *r, int byte_idx)
-{ u32 a = 0x9E3779B9u, b = 0x85EBCA6Bu;
+__device__ __forceinline__ u32 rx_hash_digit(const u32 *r, int byte_idx, int hbytes)
+{ // only the first hbytes bytes of the record enter the hash (all of a super-mer record; the
+  // KMER_BYTES key of a weighted k-mer record, so that equal k-mers with different weights meet)
+  const int full = hbytes >> 2;
+  const u32 last = (hbytes & 3) ? ((1u << (8 * (hbytes & 3))) - 1u) : 0u;
+  u32 a = 0x9E3779B9u, b = 0x85EBCA6Bu;
 #pragma unroll
   for (int w = 0; w < RW; w++)
-    { a = (a ^ r[w]) * 0xCC9E2D51u;
+    { const u32 x = (w < full) ? r[w] : (w == full) ? (r[w] & last) : 0u;
+      a = (a ^ x) * 0xCC9E2D51u;
       a = (a << 15) | (a >> 17);
-      b = (b + r[w]) * 0x1B873593u;
+      b = (b + x) * 0x1B873593u;
       b = ((b << 13) | (b >> 19)) ^ a;
     }
   a ^= b >> 16; a *= 0x85EBCA6Bu;
@@ -55,7 +60,8 @@ __device__ __forceinline__ u32 rx_hash_digit(const u32 *r, int byte_idx)
 template <int RW>
 __global__ __launch_bounds__(RX_THREADS) void k_hash_hist(const u32 *__restrict__ src, int64_t n,
                                                           int nbytes, u64 *__restrict__ out,
-                                                          uint8_t *__restrict__ dig, int dig_byte)
+                                                          uint8_t *__restrict__ dig, int dig_byte,
+                                                          int hbytes)
 { __shared__ u32 h[8 * 256];
   for (int i = threadIdx.x; i < 8 * 256; i += RX_THREADS)
     h[i] = 0;
@@ -67,9 +73,9 @@ __global__ __launch_bounds__(RX_THREADS) void k_hash_hist(const u32 *__restrict_
       for (int w = 0; w < RW; w++)
         r[w] = src[i * RW + w];
       for (int b = 0; b < nbytes; b++)
-        atomicAdd(&h[b * 256 + rx_hash_digit<RW>(r, b)], 1u);
+        atomicAdd(&h[b * 256 + rx_hash_digit<RW>(r, b, hbytes)], 1u);
       if (dig != NULL)
-        dig[i] = (uint8_t) rx_hash_digit<RW>(r, dig_byte);
+        dig[i] = (uint8_t) rx_hash_digit<RW>(r, dig_byte, hbytes);
     }
   __syncthreads();
   for (int i = threadIdx.x; i < 8 * 256; i += RX_THREADS)
@@ -203,7 +209,7 @@ __global__ __launch_bounds__(RX_THREADS) void k_radix_pass(const u32 *__restrict
   for (int it = 0; it < ITEMS; it++)
     { const int  r     = wbase + it * 64 + lane;
       const bool valid = (r < tn);
-      u32 d = !valid ? 0u : HASHED ? rx_hash_digit<RW>(recs + r * RW, byte_idx)
+      u32 d = !valid ? 0u : HASHED ? rx_hash_digit<RW>(recs + r * RW, byte_idx, RW * 4)
                                    : (u32) lbytes[r * RW * 4 + byte_idx];
       if (VARIANT == 5) d &= 0x7fu;          // measurement: 128 / 64 bins (longer runs per bin)
       if (VARIANT == 6) d &= 0x3fu;
@@ -450,8 +456,9 @@ __global__ __launch_bounds__(RX_THREADS) void k_rx_scatter(const u32 *__restrict
                                                            const uint16_t *__restrict__ tilepfx,
                                                            const u32 *__restrict__ chunkpfx,
                                                            const u64 *__restrict__ superpfx,
+                                                           const uint8_t *__restrict__ curdig,
                                                            uint8_t *__restrict__ nextdig,
-                                                           int64_t ntiles)
+                                                           int64_t ntiles, int hbytes)
 { constexpr int TILE = RX_THREADS * ITEMS;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -463,7 +470,7 @@ __global__ __launch_bounds__(RX_THREADS) void k_rx_scatter(const u32 *__restrict
   u32      *tmp32    = binstart + 256;                                 // 8
   u32      *pad      = tmp32 + 8;                                      // 4
   uint16_t *perm     = (uint16_t *) (pad + 4);                         // TILE: sorted slot -> record
-  u32      *perm32   = (u32 *) (pad + 4);                              // HASHED: record | digit << 16
+  uint8_t  *tdig     = (uint8_t *) (perm + TILE);                      // TILE: this pass's digit per record
 
   const int tid  = threadIdx.x;
   const int lane = tid & 63;
@@ -502,6 +509,17 @@ __global__ __launch_bounds__(RX_THREADS) void k_rx_scatter(const u32 *__restrict
           recs[i] = gsrc[i];
       }
   }
+  // the digits of this pass come from the stream the previous pass (or the histogram kernel) wrote
+  if (tn == TILE)
+    { const u32 *gd = (const u32 *) (curdig + tstart) + tid * (ITEMS / 4);
+      u32 *ld = (u32 *) tdig + tid * (ITEMS / 4);
+#pragma unroll
+      for (int k = 0; k < ITEMS / 4; k++)
+        ld[k] = gd[k];
+    }
+  else
+    for (int i = tid; i < tn; i += RX_THREADS)
+      tdig[i] = curdig[tstart + i];
   // this tile's bin offsets do not depend on any other workgroup
   const u64 gpre = superpfx[(tile / (RX_CH * RX_SC)) * 256 + tid]
                  + (u64) chunkpfx[(tile / RX_CH) * 256 + tid] + (u64) tilepfx[tile * 256 + tid];
@@ -517,8 +535,7 @@ __global__ __launch_bounds__(RX_THREADS) void k_rx_scatter(const u32 *__restrict
   for (int it = 0; it < ITEMS; it++)
     { const int  r     = wbase + it * 64 + lane;
       const bool valid = (r < tn);
-      const u32  d     = !valid ? 0u : HASHED ? rx_hash_digit<RW>(recs + r * RW, byte_idx)
-                                              : (u32) lbytes[r * RW * 4 + byte_idx];
+      const u32  d     = valid ? (u32) tdig[r] : 0u;
       u64 mask = __ballot(valid);
 #pragma unroll
       for (int b = 0; b < 8; b++)
@@ -562,10 +579,7 @@ __global__ __launch_bounds__(RX_THREADS) void k_rx_scatter(const u32 *__restrict
         { const u32 e   = info[it];
           const u32 d   = e & 0xffu;
           const u32 pos = binstart[d] + whist[wave * 256 + d] + (e >> 8);
-          if (HASHED)
-            perm32[pos] = (u32) r | (d << 16);
-          else
-            perm[pos] = (uint16_t) r;
+          perm[pos] = (uint16_t) r;
         }
     }
   __syncthreads();
@@ -574,35 +588,17 @@ __global__ __launch_bounds__(RX_THREADS) void k_rx_scatter(const u32 *__restrict
   for (int j = tid; j < ndw; j += RX_THREADS)
     { const int p = j / RW;
       const int w = j - p * RW;
-      int sr;
-      u32 d;
-      if (HASHED)
-        { const u32 e = perm32[p];
-          sr = (int) (e & 0xffffu);
-          d  = e >> 16;
-        }
-      else
-        { sr = perm[p];
-          d  = lbytes[sr * RW * 4 + byte_idx];
-        }
+      const int sr = perm[p];
+      const u32 d  = tdig[sr];
       dst[(goff[d] + p) * RW + w] = recs[sr * RW + w];
     }
 
   // the digit the next pass sorts on, stored at each record's new position
   if (next_byte >= 0)
     for (int p = tid; p < tn; p += RX_THREADS)
-      { int sr;
-        u32 d;
-        if (HASHED)
-          { const u32 e = perm32[p];
-            sr = (int) (e & 0xffffu);
-            d  = e >> 16;
-          }
-        else
-          { sr = perm[p];
-            d  = lbytes[sr * RW * 4 + byte_idx];
-          }
-        const u32 nd = HASHED ? rx_hash_digit<RW>(recs + sr * RW, next_byte)
+      { const int sr = perm[p];
+        const u32 d  = tdig[sr];
+        const u32 nd = HASHED ? rx_hash_digit<RW>(recs + sr * RW, next_byte, hbytes)
                               : (u32) lbytes[sr * RW * 4 + next_byte];
         nextdig[goff[d] + p] = (uint8_t) nd;
       }
@@ -611,6 +607,11 @@ __global__ __launch_bounds__(RX_THREADS) void k_rx_scatter(const u32 *__restrict
 template <int RW, int ITEMS> static size_t rx_lds_bytes(bool hashed)
 { return ((size_t) RX_THREADS * ITEMS * RW * 4 + 256 * 8 + 8 * 8 + RX_WAVES * 256 * 4 + 256 * 4
           + 8 * 4 + 16 + (size_t) RX_THREADS * ITEMS * (hashed ? 4 : 2) + 16);
+}
+
+template <int RW, int ITEMS> static size_t rx_stream_lds_bytes()
+{ return ((size_t) RX_THREADS * ITEMS * RW * 4 + 256 * 8 + 8 * 8 + RX_WAVES * 256 * 4 + 256 * 4
+          + 8 * 4 + 16 + (size_t) RX_THREADS * ITEMS * 3 + 16);
 }
 
 // hashed: bytes[] index the record hash (rx_hash_digit) instead of the record itself
@@ -659,7 +660,7 @@ static int lsd_sort_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, const in
     if (nb > 1024) nb = 1024;
     if (HASHED)
       hipLaunchKernelGGL(k_hash_hist<RW>, dim3((unsigned) nb), dim3(RX_THREADS), 0, s,
-                         (const u32 *) d_src, n, 8, ctx->d_digit_hist, (uint8_t *) NULL, 0);
+                         (const u32 *) d_src, n, 8, ctx->d_digit_hist, (uint8_t *) NULL, 0, RW * 4);
     else
       hipLaunchKernelGGL(k_digit_hist<RW>, dim3((unsigned) nb), dim3(RX_THREADS), 0, s,
                          (const u32 *) d_src, n, want, ctx->d_digit_hist, (uint8_t *) NULL, 0);
@@ -718,7 +719,7 @@ static int lsd_sort_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, const in
 
 template <int RW, int ITEMS, bool HASHED>
 static int lsd_sort_stream_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, const int *bytes,
-                             int nbytes, void **result)
+                             int nbytes, void **result, int hbytes)
 { constexpr int TILE = RX_THREADS * ITEMS;
   const int64_t ntiles  = (n + TILE - 1) / TILE;
   const int64_t nchunks = (ntiles + RX_CH - 1) / RX_CH;
@@ -765,7 +766,7 @@ static int lsd_sort_stream_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, c
     // and re-emit below in the (rare) case that this digit turns out to be constant
     if (HASHED)
       hipLaunchKernelGGL(k_hash_hist<RW>, dim3((unsigned) nb), dim3(RX_THREADS), 0, s,
-                         (const u32 *) d_src, n, 8, ctx->d_digit_hist, dig_a, bytes[0]);
+                         (const u32 *) d_src, n, 8, ctx->d_digit_hist, dig_a, bytes[0], hbytes);
     else
       hipLaunchKernelGGL(k_digit_hist<RW>, dim3((unsigned) nb), dim3(RX_THREADS), 0, s,
                          (const u32 *) d_src, n, want, ctx->d_digit_hist, dig_a, bytes[0]);
@@ -798,14 +799,14 @@ static int lsd_sort_stream_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, c
       FK_HIP(ctx, hipMemsetAsync(ctx->d_digit_hist + 24 * 256, 0, 8 * 256 * sizeof(u64), s));
       if (HASHED)
         hipLaunchKernelGGL(k_hash_hist<RW>, dim3((unsigned) nb), dim3(RX_THREADS), 0, s,
-                           (const u32 *) d_src, n, 0, ctx->d_digit_hist + 24 * 256, dig_a, run[0]);
+                           (const u32 *) d_src, n, 0, ctx->d_digit_hist + 24 * 256, dig_a, run[0], hbytes);
       else
         hipLaunchKernelGGL(k_digit_hist<RW>, dim3((unsigned) nb), dim3(RX_THREADS), 0, s,
                            (const u32 *) d_src, n, 0u, ctx->d_digit_hist + 24 * 256, dig_a, run[0]);
       FK_LAUNCH_CHECK(ctx);
     }
 
-  const size_t lds_bytes = rx_lds_bytes<RW, ITEMS>(HASHED);
+  const size_t lds_bytes = rx_stream_lds_bytes<RW, ITEMS>();
   u32 *src = (u32 *) d_src, *trg = (u32 *) d_trg;
   uint8_t *dcur = dig_a, *dnext = dig_b;
   const unsigned sgrid = (unsigned) (((ntiles + 7) / 8) * 8);
@@ -827,7 +828,8 @@ static int lsd_sort_stream_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, c
       FK_HIP(ctx, hipEventRecord(ctx->pass_ev[2 * i], s));
       hipLaunchKernelGGL((k_rx_scatter<RW, ITEMS, HASHED>), dim3(sgrid), dim3(RX_THREADS), lds_bytes, s,
                          (const u32 *) src, trg, n, run[i], nextb, (const uint16_t *) tilepfx,
-                         (const u32 *) chunkpfx, (const u64 *) superpfx, dnext, ntiles);
+                         (const u32 *) chunkpfx, (const u64 *) superpfx, (const uint8_t *) dcur, dnext, ntiles,
+                         hbytes);
       FK_HIP(ctx, hipEventRecord(ctx->pass_ev[2 * i + 1], s));
       FK_LAUNCH_CHECK(ctx);
       u32 *t = src; src = trg; trg = t;
@@ -852,7 +854,7 @@ static int lsd_sort_stream_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, c
 
 template <bool HASHED>
 static int sort_dispatch(fk_ctx *ctx, int64_t nelem, void *d_src, void *d_trg, int rsize,
-                         const int *bytes, int nbytes, void **result)
+                         const int *bytes, int nbytes, void **result, int hbytes)
 { if (rsize <= 0 || (rsize & 3) != 0 || rsize > 32)
     { fk_set_error(ctx, "record size %d not supported (multiple of 4, <= 32)", rsize);
       return (FK_EUNSUPPORTED);
@@ -860,7 +862,7 @@ static int sort_dispatch(fk_ctx *ctx, int64_t nelem, void *d_src, void *d_trg, i
   const int it = ctx->dbg_radix_items;      // measurement aid: alternative tile sizes for R = 12, 20
   const bool lookback = (ctx->dbg_radix_engine == 1 || ctx->dbg_radix_variant != 0 || it != 0);
 #define RX_CASE(RW) return (lookback ? lsd_sort_t<RW, RxCfg<RW>::ITEMS, HASHED>(ctx, nelem, d_src, d_trg, bytes, nbytes, result) \
-                              : lsd_sort_stream_t<RW, RxCfg<RW>::ITEMS, HASHED>(ctx, nelem, d_src, d_trg, bytes, nbytes, result))
+                              : lsd_sort_stream_t<RW, RxCfg<RW>::ITEMS, HASHED>(ctx, nelem, d_src, d_trg, bytes, nbytes, result, hbytes))
   switch (rsize >> 2)
   { case 1: RX_CASE(1);
     case 2: RX_CASE(2);
@@ -881,13 +883,21 @@ static int sort_dispatch(fk_ctx *ctx, int64_t nelem, void *d_src, void *d_trg, i
 
 int fkx_lsd_sort(fk_ctx *ctx, int64_t nelem, void *d_src, void *d_trg, int rsize,
                  const int *bytes, int nbytes, void **result)
-{ return sort_dispatch<false>(ctx, nelem, d_src, d_trg, rsize, bytes, nbytes, result); }
+{ return sort_dispatch<false>(ctx, nelem, d_src, d_trg, rsize, bytes, nbytes, result, rsize); }
 
 // Make identical records adjacent: five stable digit passes over a 40-bit hash of the whole record.
 // This is all the super-mer "sort" has to achieve (count.c:421-426 only run-length encodes
 // duplicates); records that collide in 40 bits merely stay un-merged, which the weighted k-mer
 // stage absorbs because it sums weights per k-mer anyway.
-int fkx_group(fk_ctx *ctx, int64_t nelem, void *d_src, void *d_trg, int rsize, void **result)
-{ static const int bytes[5] = { 0, 1, 2, 3, 4 };
-  return sort_dispatch<true>(ctx, nelem, d_src, d_trg, rsize, bytes, 5, result);
+int fkx_group(fk_ctx *ctx, int64_t nelem, void *d_src, void *d_trg, int rsize, int key_bytes,
+              int npasses, void **result)
+{ static const int bytes[8] = { 0, 1, 2, 3, 4, 5, 6, 7 };
+  if (npasses < 1 || npasses > 8 || key_bytes < 1 || key_bytes > rsize)
+    return (FK_EINVAL);
+  const bool lookback = (ctx->dbg_radix_engine == 1 || ctx->dbg_radix_variant != 0 || ctx->dbg_radix_items != 0);
+  if (lookback && key_bytes != rsize)
+    { fk_set_error(ctx, "the look-back engine hashes whole records only");
+      return (FK_EUNSUPPORTED);
+    }
+  return sort_dispatch<true>(ctx, nelem, d_src, d_trg, rsize, bytes, npasses, result, key_bytes);
 }

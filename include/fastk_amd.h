@@ -98,11 +98,14 @@ typedef struct
     int64_t  ndistinct;          /* distinct k-mers                                                    */
     int64_t  ntable;             /* table entries (count >= table_cutoff)                              */
     const uint8_t *table;        /* host, ntable entries of kmer_word bytes, sorted; owned by ctx      */
-    int64_t  wfirst[256];        /* weighted k-mers per canonical first byte (Kparts, count.c:1527)    */
+    int64_t  wfirst[256];        /* sorted k-mer records per first byte (role of Kparts, count.c:1527) */
     double   ms_split, ms_sort_super, ms_expand, ms_sort_kmer, ms_count, ms_total;  /* device time   */
     int      passes_super, passes_kmer;   /* radix digit passes executed by the two sorts              */
     double   ms_pass_super, ms_pass_kmer; /* summed duration of all kernels of those passes            */
     double   ms_scatter_super, ms_scatter_kmer; /* summed duration of the scatter kernels alone        */
+    int64_t  ncollapsed;                  /* records left after collapsing grouped weighted k-mers     */
+    int      passes_final;                /* digit passes of the final KMER_BYTES sort over ncollapsed */
+    double   ms_pass_final;
   } fk_result;
 
 /* Replaces Sorting() + the merge of Merge_Tables() (count.c:1202, table.c:346): runs the
