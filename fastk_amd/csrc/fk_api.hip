@@ -504,11 +504,11 @@ extern "C" int fk_push_device(fk_ctx *ctx, const void *d_bases, int64_t nbytes)
 }
 
 // ---- whole path: split -> sort -> expand -> sort -> count ----------------------------------------
-// 64 = disabled: sort every key byte.  A shorter prefix (fk_count_presorted_kmers) does not pay on
+#define FK_GROUP_PASSES 4
+#define FK_PREFIX_BYTES 64
+// FK_PREFIX_BYTES 64 = disabled: sort every key byte.  A shorter prefix (fk_count_presorted_kmers) does not pay on
 // read data: one-substitution error k-mers share long prefixes with their true k-mer, so about half
 // of all prefix runs are heterogeneous and would need a local sort (measured).
-#define FK_PREFIX_BYTES 64
-#define FK_GROUP_PASSES 4
 
 static double ms_between(hipEvent_t a, hipEvent_t b)
 { float ms = 0.f;
@@ -555,7 +555,7 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
       // super-mer "sort": only has to bring identical records together (Supermer_Sort's output is
       // consumed by the run-length pass of count.c:421-426), so five hashed digit passes suffice
       void *sm_sorted = sm_in;
-      { if ((rc = fkx_group(ctx, ns, sm_in, sm_b, w.smer_stride, w.smer_stride, 5, &sm_sorted)) != FK_OK)
+      { if ((rc = fkx_group(ctx, ns, sm_in, sm_b, w.smer_stride, w.smer_stride, FK_GROUP_PASSES, &sm_sorted)) != FK_OK)
           break;
         res->passes_super  = ctx->sort_stats.passes;
         res->ms_pass_super = ctx->sort_stats.pass_ms_total;

@@ -766,7 +766,7 @@ static int lsd_sort_stream_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, c
     // and re-emit below in the (rare) case that this digit turns out to be constant
     if (HASHED)
       hipLaunchKernelGGL(k_hash_hist<RW>, dim3((unsigned) nb), dim3(RX_THREADS), 0, s,
-                         (const u32 *) d_src, n, 8, ctx->d_digit_hist, dig_a, bytes[0], hbytes);
+                         (const u32 *) d_src, n, nbytes, ctx->d_digit_hist, dig_a, bytes[0], hbytes);
     else
       hipLaunchKernelGGL(k_digit_hist<RW>, dim3((unsigned) nb), dim3(RX_THREADS), 0, s,
                          (const u32 *) d_src, n, want, ctx->d_digit_hist, dig_a, bytes[0]);
