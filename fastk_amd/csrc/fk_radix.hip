@@ -885,7 +885,7 @@ int fkx_lsd_sort(fk_ctx *ctx, int64_t nelem, void *d_src, void *d_trg, int rsize
                  const int *bytes, int nbytes, void **result)
 { return sort_dispatch<false>(ctx, nelem, d_src, d_trg, rsize, bytes, nbytes, result, rsize); }
 
-// Make identical records adjacent: five stable digit passes over a 40-bit hash of the whole record.
+// Make records with identical first key_bytes adjacent: npasses stable digit passes over a hash of them.
 // This is all the super-mer "sort" has to achieve (count.c:421-426 only run-length encodes
 // duplicates); records that collide in 40 bits merely stay un-merged, which the weighted k-mer
 // stage absorbs because it sums weights per k-mer anyway.

@@ -161,11 +161,12 @@ int fk_lsd_sort_records(fk_ctx *ctx, int64_t nelem, void *d_src, void *d_trg, in
 int fk_msd_sort_records(fk_ctx *ctx, void *d_array, void *d_tmp, int64_t nelem, int rsize,
                         int ksize, void **result);
 
-/* Bring identical records together (stable, deterministic for a given input order): five digit
-   passes over a 40-bit hash of the whole record.  This is the only property of Supermer_Sort's
+/* Bring identical records together (stable, deterministic for a given input order): four digit
+   passes over a 32-bit hash of the whole record.  This is the only property of Supermer_Sort's
    output that the next stage uses (the run-length pass of count.c:421-426); records whose hashes
    collide simply stay un-merged, which cannot change any count because the weighted k-mer stage
-   sums weights per k-mer.  The pipeline uses this instead of a 20-byte lexicographic sort. */
+   sums weights per k-mer.  The pipeline uses this instead of a 20-byte lexicographic sort (and, keyed on the k-mer
+   bytes only, to group weighted k-mers before they are collapsed and really sorted). */
 int fk_group_records(fk_ctx *ctx, int64_t nelem, void *d_src, void *d_trg, int rsize,
                      void **result);
 
