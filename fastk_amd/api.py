@@ -20,7 +20,7 @@ EXPORTS = [
     "fk_msd_sort_records", "fk_expand_kmers", "fk_count_kmers", "fk_synth_reads",
     "fk_device_alloc", "fk_device_free", "fk_copy_to_device", "fk_copy_to_host",
     "fk_get_sort_stats", "fk_version", "fk_count_device_reads", "fk_count_device_supermers", "fk_debug_set", "fk_group_records",
-    "fk_count_presorted_kmers", "fk_split_supermers_emit",
+    "fk_count_presorted_kmers", "fk_split_supermers_emit", "fk_split_plan", "fk_split_planned",
 ]
 
 
@@ -91,6 +91,8 @@ def load_library():
     L.fk_write_ktab.argtypes = [C.POINTER(CResult), ci, ci, ci, C.c_char_p, C.c_char_p]
     L.fk_split_supermers.argtypes = [vp, vp, i64, vp, i64, C.POINTER(i64), C.POINTER(i64), vp]
     L.fk_split_supermers_emit.argtypes = [vp, vp, i64, vp, i64, vp]
+    L.fk_split_plan.argtypes = [vp, vp, i64, C.POINTER(i64), vp]
+    L.fk_split_planned.argtypes = [vp, vp, i64, vp, i64, vp, vp, C.POINTER(i64)]
     L.fk_lsd_sort_records.argtypes = [vp, i64, vp, vp, ci, C.POINTER(ci), C.POINTER(vp)]
     L.fk_group_records.argtypes = [vp, i64, vp, vp, ci, C.POINTER(vp)]
     L.fk_msd_sort_records.argtypes = [vp, vp, vp, i64, ci, ci, C.POINTER(vp)]
@@ -265,6 +267,23 @@ class Context:
         self._ck(self.L.fk_split_supermers(self.h, reads_ptr, nbytes, out_ptr, cap, C.byref(ns),
                                            C.byref(ni), bc))
         return ns.value, ni.value, list(bc)[:self.params.nbuckets]
+
+    def split_plan(self, reads_ptr, nbytes):
+        cap = C.c_int64()
+        offs = (C.c_int64 * 257)()
+        self._ck(self.L.fk_split_plan(self.h, reads_ptr, nbytes, C.byref(cap), offs))
+        return cap.value, list(offs)[:self.params.nbuckets + 1]
+
+    def split_planned(self, reads_ptr, nbytes, out_ptr, cap, offsets):
+        """Returns (counts, ninst) or None when a planned region overflowed (FK_ESTATE)."""
+        offs = (C.c_int64 * 257)(*offsets)
+        cnt = (C.c_int64 * 256)()
+        ni = C.c_int64()
+        rc = self.L.fk_split_planned(self.h, reads_ptr, nbytes, out_ptr, cap, offs, cnt, C.byref(ni))
+        if rc == -6:
+            return None
+        self._ck(rc)
+        return list(cnt)[:self.params.nbuckets], ni.value
 
     def split_emit(self, reads_ptr, nbytes, out_ptr, cap, counts):
         bc = (C.c_int64 * 256)(*counts)

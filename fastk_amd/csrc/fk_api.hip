@@ -96,8 +96,23 @@ static void build_minimizer_tables(uint16_t *mtab, uint8_t *mbucket, int nbucket
       const int a = rank[v], b = rank[rc];
       mtab[v] = (uint16_t) ((std::min(a, b) << 1) | (b < a ? 1 : 0));
     }
+  // Buckets must carry equal loads (one bucket = one GPU).  A smaller rank wins more windows, so the
+  // load of a rank falls monotonically with its value: deal the canonical ranks (the values that
+  // actually occur as a minimum of a 5-mer and its reverse complement) out in serpentine order.
+  bool used[1024];
   for (int r = 0; r < 1024; r++)
-    mbucket[r] = (uint8_t) (r % nbuckets);
+    used[r] = false;
+  for (int v = 0; v < 1024; v++)
+    used[mtab[v] >> 1] = true;
+  int p = 0;
+  for (int r = 0; r < 1024; r++)
+    { mbucket[r] = 0;
+      if (!used[r])
+        continue;
+      const int q = p % (2 * nbuckets);
+      mbucket[r] = (uint8_t) (q < nbuckets ? q : 2 * nbuckets - 1 - q);
+      p += 1;
+    }
 }
 
 extern "C" int fk_create(const fk_params *p, fk_ctx **out)
@@ -347,6 +362,28 @@ extern "C" int fk_split_supermers_emit(fk_ctx *ctx, const void *d_bases, int64_t
   if (ns == 0)
     return (FK_OK);
   return fkx_split(ctx, d_bases, nbytes, d_out, cap, &ns, &ni, bc, true);
+}
+
+/* One-pass bucketed split for the sharded path: fk_split_plan sizes padded per-bucket regions from
+   a tile sample (offsets[nbuckets+1], *cap records in total); fk_split_planned emits into them and
+   reports the real per-bucket counts.  FK_ESTATE = a region overflowed: use the exact
+   fk_split_supermers(cap = 0) + fk_split_supermers_emit pair instead. */
+extern "C" int fk_split_plan(fk_ctx *ctx, const void *d_bases, int64_t nbytes, int64_t *cap,
+                             int64_t *offsets)
+{ if (ctx == NULL || d_bases == NULL || cap == NULL || offsets == NULL || nbytes < 0) return (FK_EINVAL);
+  return fkx_split_plan(ctx, d_bases, nbytes, cap, offsets);
+}
+
+extern "C" int fk_split_planned(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out,
+                                int64_t cap, const int64_t *offsets, int64_t *counts, int64_t *ninst)
+{ if (ctx == NULL || d_bases == NULL || d_out == NULL || offsets == NULL || counts == NULL
+      || ninst == NULL || nbytes < 0)
+    return (FK_EINVAL);
+  if (((uintptr_t) d_bases & 15) != 0)
+    { fk_set_error(ctx, "fk_split_planned: read buffer must be 16-byte aligned");
+      return (FK_EINVAL);
+    }
+  return fkx_split_planned(ctx, d_bases, nbytes, d_out, cap, offsets, counts, ninst);
 }
 
 extern "C" int fk_lsd_sort_records(fk_ctx *ctx, int64_t nelem, void *d_src, void *d_trg, int rsize,

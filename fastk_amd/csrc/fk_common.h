@@ -90,6 +90,9 @@ int fkx_group(fk_ctx *ctx, int64_t nelem, void *d_src, void *d_trg, int rsize, i
               int npasses, void **result);
 int fkx_split(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int64_t cap,
               int64_t *nsuper, int64_t *ninst, int64_t *bucket_counts, bool counts_known);
+int fkx_split_plan(fk_ctx *ctx, const void *d_bases, int64_t nbytes, int64_t *cap, int64_t *offsets);
+int fkx_split_planned(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int64_t cap,
+                      const int64_t *offsets, int64_t *counts, int64_t *ninst);
 int fkx_split_fast(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void **d_out, int64_t *nsuper,
                    int64_t *ninst);
 int fkx_expand(fk_ctx *ctx, const void *d_smers, int64_t nsuper, void *d_out, int64_t cap,

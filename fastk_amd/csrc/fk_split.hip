@@ -39,6 +39,7 @@ struct SplitArgs
   const uint8_t  *mbucket;  // [1024] bucket of a canonical rank
   u64      *counts;         // [nbuckets] records per bucket (count mode)  + [256] = instances
   u64      *cursor;         // [nbuckets] running write cursors (emit mode), pre-set to bucket bases
+  const u64 *limit;         // [nbuckets] end of each bucket's region (NULL: only `cap` bounds the output)
   u32      *out;
   int64_t   cap;
   u32      *overflowed;
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
       const u32 rank = e >> 20;
       const u32 b    = one ? 0u : mbucket[rank];
       const u64 slot = bbase[b] + (one ? s : atomicAdd(&bcnt2[b], 1u));
-      if ((int64_t) slot >= a.cap)
+      if ((int64_t) slot >= a.cap || (a.limit != NULL && slot >= a.limit[b]))
         { *a.overflowed = 1;
           continue;
         }
@@ -355,6 +356,7 @@ int fkx_split(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int
   a.cap = cap;
   a.overflowed = d_ovf;
   a.tile_stride = 1;
+  a.limit = NULL;
 
   const int64_t nstarts = nbytes - K + 1;
   const int64_t ntiles  = (nstarts + SP_TILE - 1) / SP_TILE;
@@ -437,6 +439,7 @@ int fkx_split_fast(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void **d_ou
       a.mbucket = ctx->d_mbucket;
       a.counts = d_counts;
       a.cursor = d_cursor;
+      a.limit = NULL;
       a.overflowed = d_ovf;
       const int64_t nstarts = nbytes - K + 1;
       const int64_t ntiles  = (nstarts + SP_TILE - 1) / SP_TILE;
@@ -483,4 +486,114 @@ int fkx_split_fast(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void **d_ou
     return (FK_ENOMEM);
   *d_out = out;
   return fkx_split(ctx, d_bases, nbytes, out, *nsuper, nsuper, ninst, bc, true);
+}
+
+// Sampled plan for the bucketed (sharded) split: estimated records per bucket from a 1/32 tile
+// sample, padded by 5 %; region b starts at offsets[b].  Returns the total capacity needed.
+int fkx_split_plan(fk_ctx *ctx, const void *d_bases, int64_t nbytes, int64_t *cap,
+                   int64_t *offsets)
+{ hipStream_t s = ctx->stream;
+  const int   K = ctx->prm.kmer;
+  const int   nb = ctx->prm.nbuckets;
+  *cap = 0;
+  for (int b = 0; b <= nb; b++)
+    offsets[b] = 0;
+  if (K < 8 || K > SP_MAXK)
+    { fk_set_error(ctx, "k = %d outside the supported range [8,%d]", K, SP_MAXK);
+      return (FK_EUNSUPPORTED);
+    }
+  if (nbytes < K)
+    return (FK_OK);
+  const int64_t nstarts = nbytes - K + 1;
+  const int64_t ntiles  = (nstarts + SP_TILE - 1) / SP_TILE;
+  int sample = 32;
+  while (sample > 1 && ntiles / sample < 64)
+    sample >>= 1;
+  SplitArgs a;
+  a.bases = (const unsigned char *) d_bases;
+  a.nbytes = nbytes;
+  a.kmer = K;
+  a.smer_bytes = ctx->wid.smer_bytes;
+  a.sww = ctx->wid.smer_stride / 4;
+  a.nbuckets = nb;
+  a.mtab = ctx->d_mrank;
+  a.mbucket = ctx->d_mbucket;
+  a.counts = ctx->d_scratch;
+  a.cursor = ctx->d_scratch + 512;
+  a.limit = NULL;
+  a.out = NULL; a.cap = 0;
+  a.overflowed = (u32 *) (ctx->d_scratch + 1024);
+  a.tile_stride = sample;
+  FK_HIP(ctx, hipMemsetAsync(ctx->d_scratch, 0, 1032 * sizeof(u64), s));
+  hipLaunchKernelGGL(k_split<false>, dim3((unsigned) (ntiles / sample)), dim3(SP_THREADS), 0, s, a);
+  FK_LAUNCH_CHECK(ctx);
+  FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch, ctx->d_scratch, 256 * sizeof(u64), hipMemcpyDeviceToHost, s));
+  FK_HIP(ctx, hipStreamSynchronize(s));
+  const double scale = (double) ntiles / (double) (ntiles / sample);
+  int64_t tot = 0;
+  for (int b = 0; b < nb; b++)
+    { offsets[b] = tot;
+      tot += (int64_t) ((double) ctx->h_scratch[b] * scale * 1.05) + 8192;
+    }
+  offsets[nb] = tot;
+  *cap = tot;
+  return (FK_OK);
+}
+
+// Emit into the planned regions; counts[b] receives what bucket b really holds.
+// FK_ESTATE: some region was too small (very uneven input) -- use the exact two-call path.
+int fkx_split_planned(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int64_t cap,
+                      const int64_t *offsets, int64_t *counts, int64_t *ninst)
+{ hipStream_t s = ctx->stream;
+  const int   K = ctx->prm.kmer;
+  const int   nb = ctx->prm.nbuckets;
+  for (int b = 0; b < nb; b++)
+    counts[b] = 0;
+  *ninst = 0;
+  if (nbytes < K)
+    return (FK_OK);
+  if (offsets[nb] > cap)
+    { fk_set_error(ctx, "planned split needs %lld records, buffer holds %lld",
+                   (long long) offsets[nb], (long long) cap);
+      return (FK_EINVAL);
+    }
+  const int64_t nstarts = nbytes - K + 1;
+  const int64_t ntiles  = (nstarts + SP_TILE - 1) / SP_TILE;
+  u64 *h = ctx->h_scratch + 512;                     // pinned
+  for (int b = 0; b < nb; b++)
+    { h[b] = (u64) offsets[b];                       // cursors start at the region starts
+      h[256 + b] = (u64) offsets[b + 1];             // limits
+    }
+  FK_HIP(ctx, hipMemsetAsync(ctx->d_scratch, 0, 1032 * sizeof(u64), s));
+  FK_HIP(ctx, hipMemcpyAsync(ctx->d_scratch + 512, h, 512 * sizeof(u64), hipMemcpyHostToDevice, s));
+  SplitArgs a;
+  a.bases = (const unsigned char *) d_bases;
+  a.nbytes = nbytes;
+  a.kmer = K;
+  a.smer_bytes = ctx->wid.smer_bytes;
+  a.sww = ctx->wid.smer_stride / 4;
+  a.nbuckets = nb;
+  a.mtab = ctx->d_mrank;
+  a.mbucket = ctx->d_mbucket;
+  a.counts = ctx->d_scratch;
+  a.cursor = ctx->d_scratch + 512;
+  a.limit = ctx->d_scratch + 768;
+  a.out = (u32 *) d_out; a.cap = cap;
+  a.overflowed = (u32 *) (ctx->d_scratch + 1024);
+  a.tile_stride = 1;
+  hipLaunchKernelGGL(k_split<true>, dim3((unsigned) ntiles), dim3(SP_THREADS), 0, s, a);
+  FK_LAUNCH_CHECK(ctx);
+  FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch, ctx->d_scratch, 1032 * sizeof(u64), hipMemcpyDeviceToHost, s));
+  FK_HIP(ctx, hipStreamSynchronize(s));
+  if (*(u32 *) (ctx->h_scratch + 1024) != 0)
+    { fk_set_error(ctx, "planned split: a bucket region was too small");
+      return (FK_ESTATE);
+    }
+  for (int b = 0; b < nb; b++)
+    counts[b] = (int64_t) ctx->h_scratch[512 + b] - offsets[b];
+  int64_t t = 0;
+  for (int x = 0; x < 64; x++)
+    t += (int64_t) ctx->h_scratch[256 + x];
+  *ninst = t;
+  return (FK_OK);
 }

@@ -27,13 +27,24 @@ class HipEngine:
         self.stride = ctx.w.smer_stride
 
     def split(self, reads):
-        """reads: uint8 tensor in HBM.  Returns (records uint8 tensor, per-bucket counts, ninst)."""
+        """reads: uint8 tensor in HBM.  Returns (records uint8 tensor, per-bucket counts, per-bucket
+        record offsets into that tensor, ninst).  One emit pass into sampled, padded regions; the
+        exact count-then-emit pair is the fallback when a region overflows."""
         n = reads.numel()
+        cap, offs = self.ctx.split_plan(reads.data_ptr(), n)
+        recs = torch.empty(max(cap, 1) * self.stride, dtype=torch.uint8, device=self.device)
+        got = self.ctx.split_planned(reads.data_ptr(), n, recs.data_ptr(), cap, offs) if cap else ([0] * (len(offs) - 1), 0)
+        if got is not None:
+            counts, ni = got
+            return recs, counts, offs[:-1], ni
         ns, ni, counts = self.ctx.split(reads.data_ptr(), n)
         recs = torch.empty(max(ns, 1) * self.stride, dtype=torch.uint8, device=self.device)
         if ns:
             self.ctx.split_emit(reads.data_ptr(), n, recs.data_ptr(), ns, counts)
-        return recs[: ns * self.stride], counts, ni
+        offs = [0]
+        for c in counts[:-1]:
+            offs.append(offs[-1] + c)
+        return recs, counts, offs, ni
 
     def count_supermers(self, recs, nsuper):
         res = self.ctx.count_device_supermers(recs.data_ptr() if nsuper else None, nsuper)
@@ -46,7 +57,7 @@ class HipEngine:
 MAX_PAIR_BYTES = 1 << 30
 
 
-def _exchange_records(recs, inbox, send_n, recv_n, stride, group):
+def _exchange_records(recs, inbox, send_n, recv_n, stride, group, s_off=None):
     """all-to-all-v of fixed-width records in rounds of bounded size.  recs holds the outgoing records
     grouped by destination rank, inbox receives them grouped by source rank."""
     world = len(send_n)
@@ -55,13 +66,18 @@ def _exchange_records(recs, inbox, send_n, recv_n, stride, group):
     most = torch.tensor([max(send_n + [0])], dtype=torch.int64, device=dev)
     dist.all_reduce(most, op=dist.ReduceOp.MAX, group=group)
     rounds = max(1, -(-int(most.item()) // per))
-    s_off = [0] * world
+    contiguous = s_off is None
+    if contiguous:
+        s_off = [0] * world
+        for i in range(1, world):
+            s_off[i] = s_off[i - 1] + send_n[i - 1]
     r_off = [0] * world
     for i in range(1, world):
-        s_off[i] = s_off[i - 1] + send_n[i - 1]
         r_off[i] = r_off[i - 1] + recv_n[i - 1]
-    if rounds == 1:
-        dist.all_to_all_single(inbox, recs, output_split_sizes=[c * stride for c in recv_n],
+    contiguous = contiguous or all(s_off[i] == s_off[i - 1] + send_n[i - 1] for i in range(1, world))
+    if rounds == 1 and contiguous and s_off[0] == 0:
+        dist.all_to_all_single(inbox, recs[: sum(send_n) * stride],
+                               output_split_sizes=[c * stride for c in recv_n],
                                input_split_sizes=[c * stride for c in send_n], group=group)
         return
     for r in range(rounds):
@@ -89,7 +105,7 @@ def count_sharded(engine, reads, group=None, verify=False):
     local=<this rank's engine result>)."""
     world = dist.get_world_size(group)
     stride = engine.stride
-    recs, counts, ninst = engine.split(reads)
+    recs, counts, s_off, ninst = engine.split(reads)
     assert len(counts) == world, "context must be created with nbuckets == world size"
     dev = recs.device
 
@@ -100,10 +116,12 @@ def count_sharded(engine, reads, group=None, verify=False):
     recv_n = [int(c) for c in recv.tolist()]
     nrecv = sum(recv_n)
     inbox = torch.empty(max(nrecv, 1) * stride, dtype=torch.uint8, device=dev)[: nrecv * stride]
-    _exchange_records(recs, inbox, send_n, recv_n, stride, group)
+    _exchange_records(recs, inbox, send_n, recv_n, stride, group, s_off)
     if verify:
         # payload check: the byte sum of everything sent equals the byte sum of everything received
-        chk = torch.stack([recs.sum(dtype=torch.int64), inbox.sum(dtype=torch.int64)])
+        sent = sum(recs[o * stride:(o + c) * stride].sum(dtype=torch.int64)
+                   for o, c in zip(s_off, send_n)) + torch.zeros((), dtype=torch.int64, device=dev)
+        chk = torch.stack([sent, inbox.sum(dtype=torch.int64)])
         dist.all_reduce(chk, op=dist.ReduceOp.SUM, group=group)
         if int(chk[0].item()) != int(chk[1].item()):
             raise RuntimeError("super-mer exchange corrupted the payload (checksums differ)")

@@ -147,6 +147,14 @@ int fk_split_supermers(fk_ctx *ctx, const void *d_bases, int64_t nbytes,
 int fk_split_supermers_emit(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out,
                             int64_t cap, const int64_t *bucket_counts);
 
+/* One-pass bucketed split (sharded path): fk_split_plan sizes padded per-bucket regions from a 1/32
+   tile sample -- offsets[0..nbuckets] in records, *cap = offsets[nbuckets]; fk_split_planned emits
+   bucket b at d_out + offsets[b] records and reports the real counts[b] and *ninst.  It returns
+   FK_ESTATE when a region overflowed (very uneven input): then use the exact pair above. */
+int fk_split_plan(fk_ctx *ctx, const void *d_bases, int64_t nbytes, int64_t *cap, int64_t *offsets);
+int fk_split_planned(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int64_t cap,
+                     const int64_t *offsets, int64_t *counts, int64_t *ninst);
+
 /* Stable LSD byte radix sort; same contract as
      void *LSD_Sort(int64 nelem, void *src, void *trg, int rsize, int *bytes)   (FastK.h:154,
    LSDsort.c:115): bytes[] is a -1 terminated list, least significant first; *result receives

@@ -384,3 +384,30 @@ def test_bucketed_split_keeps_equal_kmers_together(name, nb):
     # disjoint buckets: no k-mer twice in the merged table
     assert not np.any(np.all(merged[1:, :P.kmer_bytes] == merged[:-1, :P.kmer_bytes], axis=1))
     util.check_against_golden(case, hist, max_inst, merged)
+
+
+def test_planned_bucketed_split_matches_exact_counts():
+    """fk_split_plan + fk_split_planned (one emit pass into sampled, padded regions) must deliver the
+    same per-bucket multisets as the exact count-then-emit pair."""
+    case, bases, boff = util.load_case("synth_illumina_k40_t1_T4")
+    with fastk_amd.Context(kmer=40, nbuckets=4) as ctx:
+        w = ctx.w
+        rd = ctx.alloc(len(bases) + 64).upload(bases)
+        ns, ni, counts = ctx.split(rd.ptr, len(bases))
+        exact = ctx.alloc(ns * w.smer_stride)
+        ctx.split_emit(rd.ptr, len(bases), exact.ptr, ns, counts)
+        ex = exact.download(ns * w.smer_stride).reshape(ns, w.smer_stride)
+        cap, offs = ctx.split_plan(rd.ptr, len(bases))
+        assert cap >= ns and len(offs) == 5
+        buf = ctx.alloc(cap * w.smer_stride)
+        got = ctx.split_planned(rd.ptr, len(bases), buf.ptr, cap, offs)
+        assert got is not None
+        pcounts, pni = got
+        assert pcounts == counts and pni == ni
+        pl = buf.download(cap * w.smer_stride).reshape(cap, w.smer_stride)
+    lo = 0
+    for b, c in enumerate(counts):
+        a = orc.msd_sort(np.ascontiguousarray(ex[lo:lo + c]), w.smer_stride)
+        p = orc.msd_sort(np.ascontiguousarray(pl[offs[b]:offs[b] + c]), w.smer_stride)
+        assert np.array_equal(a, p), b
+        lo += c

@@ -48,7 +48,10 @@ class OracleEngine:
         order = np.argsort(b, kind="stable")
         counts = np.bincount(b, minlength=self.world).tolist()
         out = torch.from_numpy(np.ascontiguousarray(recs[order]).reshape(-1))
-        return out, counts, ninst
+        offs = [0]
+        for c in counts[:-1]:
+            offs.append(offs[-1] + c)
+        return out, counts, offs, ninst
 
     def count_supermers(self, recs, nsuper):
         P = self.P
