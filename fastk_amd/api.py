@@ -37,7 +37,7 @@ class Widths(C.Structure):
 class Params(C.Structure):
     _fields_ = [("kmer", C.c_int), ("table_cutoff", C.c_int), ("nthreads", C.c_int),
                 ("bc_prefix", C.c_int), ("device", C.c_int), ("nbuckets", C.c_int),
-                ("hbm_budget", C.c_int64)]
+                ("hbm_budget", C.c_int64), ("exact_parts", C.c_int)]
 
 
 class CResult(C.Structure):
@@ -179,12 +179,14 @@ class DeviceBuffer:
 class Context:
     """fk_ctx wrapper: one per process / GPU."""
 
-    def __init__(self, kmer=40, table_cutoff=0, nthreads=4, bc_prefix=0, device=0, nbuckets=1):
+    def __init__(self, kmer=40, table_cutoff=0, nthreads=4, bc_prefix=0, device=0, nbuckets=1,
+                 exact_parts=False):
         self.L = load_library()
         p = Params()
         self.L.fk_default_params(C.byref(p))
         p.kmer, p.table_cutoff, p.nthreads = kmer, table_cutoff, nthreads
         p.bc_prefix, p.device, p.nbuckets = bc_prefix, device, nbuckets
+        p.exact_parts = 1 if exact_parts else 0
         self.params = p
         self.h = C.c_void_p()
         rc = self.L.fk_create(C.byref(p), C.byref(self.h))

@@ -204,6 +204,7 @@ extern "C" void fk_destroy(fk_ctx *ctx)
   if (ctx->own_stream && ctx->stream != NULL)
     hipStreamDestroy(ctx->stream);
   free(ctx->h_table);
+  free(ctx->h_roff);
   if (ctx->push_lock)
     { pthread_mutex_destroy((pthread_mutex_t *) ctx->push_lock);
       free(ctx->push_lock);
@@ -496,7 +497,16 @@ extern "C" int fk_push_block(fk_ctx *ctx, const char *bases, const int32_t *boff
         { rc = FK_EHIP; break; }
       char *st = ctx->h_stage[si];
       memcpy(st, bases + boff[0], (size_t) len);
-      if (ctx->prm.bc_prefix > 0)           // -bc: the skipped prefix can never be inside a k-mer
+      if (ctx->prm.exact_parts)
+        { if (ctx->nroff + nreads + 1 > ctx->roff_cap)
+            { ctx->roff_cap = std::max<int64_t>(ctx->nroff + nreads + 1, ctx->roff_cap * 2 + 1024);
+              ctx->h_roff = (int64_t *) realloc(ctx->h_roff, sizeof(int64_t) * (size_t) ctx->roff_cap);
+              if (ctx->h_roff == NULL) { rc = FK_ENOMEM; break; }
+            }
+          for (int i = 0; i < nreads; i++)
+            ctx->h_roff[ctx->nroff++] = ctx->reads_len + (boff[i] - boff[0]);
+        }
+      else if (ctx->prm.bc_prefix > 0)      // -bc: the skipped prefix can never be inside a k-mer
         for (int i = 0; i < nreads; i++)
           { const int64_t o = boff[i] - boff[0];
             const int64_t e = boff[i + 1] - boff[0] - 1;
@@ -520,8 +530,8 @@ extern "C" int fk_push_block(fk_ctx *ctx, const char *bases, const int32_t *boff
 
 extern "C" int fk_push_device(fk_ctx *ctx, const void *d_bases, int64_t nbytes)
 { if (ctx == NULL || d_bases == NULL || nbytes < 0) return (FK_EINVAL);
-  if (ctx->prm.bc_prefix > 0)
-    { fk_set_error(ctx, "fk_push_device: -bc needs read offsets; use fk_push_block");
+  if (ctx->prm.bc_prefix > 0 || ctx->prm.exact_parts)
+    { fk_set_error(ctx, "fk_push_device: -bc and exact_parts need read offsets; use fk_push_block");
       return (FK_EUNSUPPORTED);
     }
   int rc;
@@ -556,7 +566,8 @@ static double ms_between(hipEvent_t a, hipEvent_t b)
 // d_smers_in != NULL: start from caller-owned super-mer records (sharded path, after the exchange);
 // the caller's buffer is used as one half of the sort's ping-pong pair and is clobbered.
 int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers_in,
-                 int64_t nsmers_in, fk_result *res, bool fetch_table)
+                 int64_t nsmers_in, fk_result *res, bool fetch_table, int64_t *h_roff = NULL,
+                 int64_t nreads = 0)
 { const fk_widths &w = ctx->wid;
   hipStream_t s = ctx->stream;
   hipEvent_t ev[6];
@@ -579,7 +590,27 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
           res->nsuper = ns;
         }
       else
-        { // split (sampled capacity + one emit pass; exact count-then-emit when sharding)
+        { if (h_roff != NULL)
+            { // exact_parts: the reference's own rule, so that Table_Split falls where it does there
+              h_roff[nreads] = nbytes;
+              int64_t train = 0, olen = 0;                 // Get_First_Block(io, 1e9), io.c:2606-2630
+              const int64_t maxrds = 1000000000ll / 150, omax = 1000000000ll + maxrds;
+              while (train < nreads)
+                { olen += h_roff[train + 1] - h_roff[train];
+                  train += 1;
+                  if (olen > omax - 100000 || train >= maxrds)
+                    break;
+                }
+              int tran[4];
+              if ((rc = fkx_train_tran(ctx, d_reads, h_roff, train, ctx->prm.nthreads, tran)) != FK_OK) break;
+              int64_t *d_roff = (int64_t *) fk_slot(ctx, FK_SLOT_ROFF, (nreads + 1) * 8);
+              if (d_roff == NULL) { rc = FK_ENOMEM; break; }
+              if (hipMemcpyAsync(d_roff, h_roff, (size_t) (nreads + 1) * 8, hipMemcpyHostToDevice, s) != hipSuccess)
+                { rc = FK_EHIP; break; }
+              if ((rc = fkx_split_exact(ctx, d_reads, d_roff, nreads, tran, &sm_a, &ns, &ni)) != FK_OK) break;
+            }
+          else
+          // split (sampled capacity + one emit pass; exact count-then-emit when sharding)
           if ((rc = fkx_split_fast(ctx, d_reads, nbytes, &sm_a, &ns, &ni)) != FK_OK) break;
           res->nsuper = ns;
           res->ninst = ni;
@@ -610,6 +641,10 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
             { rc = FK_ENOMEM; break; }
           if ((rc = fkx_expand(ctx, sm_sorted, ns, km_a, nw, &nw, &nd, &ovf)) != FK_OK) break;
         }
+      int64_t exact_census[256];
+      if (h_roff != NULL && nw > 0
+          && (rc = fkx_first_byte_census(ctx, km_a, nw, w.kmer_stride, exact_census)) != FK_OK)
+        break;
       hipEventRecord(ev[3], s);
 
       // weighted k-mer stage.  The reference sorts all W weighted records on KMER_BYTES
@@ -647,7 +682,7 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
           km_a = cbuf; km_b = grouped;                 // the pair now in use
           // first-byte census of the (collapsed) k-mers, for the .ktab part boundaries
           for (int x = 0; x < 256; x++)
-            res->wfirst[x] = (int64_t) ctx->h_scratch[x];
+            res->wfirst[x] = (h_roff != NULL) ? exact_census[x] : (int64_t) ctx->h_scratch[x];
         }
       hipEventRecord(ev[4], s);
 
@@ -731,6 +766,17 @@ extern "C" int fk_finish(fk_ctx *ctx, fk_result *res)
 { if (ctx == NULL || res == NULL) return (FK_EINVAL);
   FK_HIP(ctx, hipSetDevice(ctx->device));
   FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->prm.exact_parts)
+    { if (ctx->h_roff == NULL && ctx->reads_len > 0)
+        { fk_set_error(ctx, "exact_parts needs reads pushed with fk_push_block");
+          return (FK_ESTATE);
+        }
+      if (ctx->h_roff == NULL)
+        { ctx->h_roff = (int64_t *) malloc(sizeof(int64_t) * 4);
+          ctx->roff_cap = 4;
+        }
+      return fkx_pipeline(ctx, ctx->d_reads, ctx->reads_len, NULL, 0, res, true, ctx->h_roff, ctx->nroff);
+    }
   return fkx_pipeline(ctx, ctx->d_reads, ctx->reads_len, NULL, 0, res, true);
 }
 

@@ -14,7 +14,7 @@
 typedef unsigned long long u64;
 typedef unsigned int       u32;
 
-#define FK_NSLOTS 16
+#define FK_NSLOTS 24
 
 struct fk_ctx
 { fk_params  prm;
@@ -50,6 +50,8 @@ struct fk_ctx
   uint8_t   *h_table;      // result table (host)
   int64_t    h_table_cap;
   void      *push_lock;    // pthread mutex
+  int64_t   *h_roff;       // exact_parts: byte offset of every pushed read (+ end), host
+  int64_t    nroff, roff_cap;
 
   hipEvent_t ev0, ev1;
   hipEvent_t pass_ev[128];       // begin/end of each scatter launch of the current sort
@@ -65,7 +67,7 @@ struct fk_ctx
 
 enum { FK_SLOT_SM_A = 0, FK_SLOT_SM_B, FK_SLOT_KM_A, FK_SLOT_KM_B, FK_SLOT_EX_HEADS, FK_SLOT_EX_KMERS,
        FK_SLOT_EX_KOFF, FK_SLOT_CT_ENT, FK_SLOT_CT_OFF, FK_SLOT_CT_HIST, FK_SLOT_DIG_A, FK_SLOT_DIG_B,
-       FK_SLOT_RX_TILE, FK_SLOT_RX_CHUNK, FK_SLOT_RX_SUPER };
+       FK_SLOT_RX_TILE, FK_SLOT_RX_CHUNK, FK_SLOT_RX_SUPER, FK_SLOT_ROFF };
 
 // returns a device buffer of at least nbytes for the given purpose (NULL + error set on failure)
 void *fk_slot(fk_ctx *ctx, int slot, int64_t nbytes);
@@ -93,6 +95,11 @@ int fkx_split(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int
 int fkx_split_plan(fk_ctx *ctx, const void *d_bases, int64_t nbytes, int64_t *cap, int64_t *offsets);
 int fkx_split_planned(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int64_t cap,
                       const int64_t *offsets, int64_t *counts, int64_t *ninst);
+int fkx_train_tran(fk_ctx *ctx, const void *d_bases, const int64_t *h_roff, int64_t train_reads,
+                   int nthreads, int *tran);
+int fkx_split_exact(fk_ctx *ctx, const void *d_bases, const int64_t *d_roff, int64_t nreads,
+                    const int *tran, void **d_out, int64_t *nsuper, int64_t *ninst);
+int fkx_first_byte_census(fk_ctx *ctx, const void *d_recs, int64_t n, int rsize, int64_t *census);
 int fkx_split_fast(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void **d_out, int64_t *nsuper,
                    int64_t *ninst);
 int fkx_expand(fk_ctx *ctx, const void *d_smers, int64_t nsuper, void *d_out, int64_t cap,

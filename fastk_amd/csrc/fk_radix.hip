@@ -901,3 +901,32 @@ int fkx_group(fk_ctx *ctx, int64_t nelem, void *d_src, void *d_trg, int rsize, i
     }
   return sort_dispatch<true>(ctx, nelem, d_src, d_trg, rsize, bytes, npasses, result, key_bytes);
 }
+
+// census[x] = records whose byte 0 is x (the role of Kparts, count.c:1527-1535, for exact_parts)
+template <int RW>
+static int census_t(fk_ctx *ctx, const void *d_recs, int64_t n, int64_t *census)
+{ hipStream_t s = ctx->stream;
+  FK_HIP(ctx, hipMemsetAsync(ctx->d_digit_hist, 0, 256 * sizeof(u64), s));
+  int64_t nb = (n + RX_THREADS - 1) / RX_THREADS;
+  if (nb > 2048) nb = 2048;
+  if (nb > 0)
+    hipLaunchKernelGGL(k_digit_hist<RW>, dim3((unsigned) nb), dim3(RX_THREADS), 0, s, (const u32 *) d_recs, n,
+                       1u, ctx->d_digit_hist, (uint8_t *) NULL, 0);
+  FK_LAUNCH_CHECK(ctx);
+  FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch, ctx->d_digit_hist, 256 * sizeof(u64), hipMemcpyDeviceToHost, s));
+  FK_HIP(ctx, hipStreamSynchronize(s));
+  for (int x = 0; x < 256; x++)
+    census[x] = (int64_t) ctx->h_scratch[x];
+  return (FK_OK);
+}
+
+int fkx_first_byte_census(fk_ctx *ctx, const void *d_recs, int64_t n, int rsize, int64_t *census)
+{ switch (rsize >> 2)
+  { case 1: return census_t<1>(ctx, d_recs, n, census);
+    case 2: return census_t<2>(ctx, d_recs, n, census);
+    case 3: return census_t<3>(ctx, d_recs, n, census);
+    case 4: return census_t<4>(ctx, d_recs, n, census);
+    case 5: return census_t<5>(ctx, d_recs, n, census);
+    default: return (FK_EUNSUPPORTED);
+  }
+}

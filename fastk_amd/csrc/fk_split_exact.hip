@@ -1,0 +1,278 @@
+// fk_split_exact.hip -- the reference's OWN super-mer rule, one thread per read.
+//
+// The position-parallel splitter (fk_split.hip) is free to cut super-mers differently because no
+// count depends on the cuts.  One thing does: the first-byte boundaries of the hidden .ktab part
+// files come from the first-byte census of bucket 0's weighted k-mer list (Table_Split,
+// count.c:1560-1565; msd_sort's thread ranges, MSDsort.c:330-352), i.e. from the exact multiset of
+// DISTINCT super-mers.  With fk_params.exact_parts = 1 the pipeline therefore replays
+// Distribute_Block itself (split.c:1016-1393): rolling canonical 5-mer under the frequency-ranked
+// base order (Tran/Cran, split.c:529-575, 630-639), strict < on arrival, <= on the forced rescan
+// after MAX_SUPER k-mers, the clipping around non-ACGT bases (split.c:1167-1232) and the
+// end-of-read flush (split.c:1342-1347) -- sequentially per read, as the reference must, with
+// reads spread over threads.  Valid for the case the reference handles with one bucket and the
+// unpadded trie (NPARTS = 1, PAD = 0: every input whose k-mers fit -M), and for blocks cut like
+// io.c cuts them.  A compatibility mode: ~10x slower than the default splitter.
+#include "fk_common.h"
+
+#define XS_THREADS 128
+#define XS_RING    256          // >= 2 * nextpow2(K) for K <= 128 (MOD_LEN, FastK.c:446-450)
+
+struct ExactArgs
+{ const unsigned char *bases;
+  const int64_t *roff;          // [nreads+1] read r = bases[roff[r] .. roff[r+1]-1), then a 0 byte
+  int64_t   nreads;
+  int       kmer;
+  int       bc_prefix;
+  int       tran[4];            // rank of a,c,g,t
+  int       smer_bytes;
+  int       sww;
+  u32      *cnt;                // [nreads] super-mers of each read (count pass)
+  const u64 *off;               // [nreads] first record of each read (emit pass)
+  u32      *out;
+  u64      *inst;               // [64] valid k-mer instances, spread
+};
+
+__device__ __forceinline__ int xs_code(unsigned ch)
+{ const unsigned u = ch & 0xDFu;
+  const bool ok = (u == 0x41u) | (u == 0x43u) | (u == 0x47u) | (u == 0x54u);
+  const unsigned x = (ch >> 1) & 3u;
+  return ok ? (int) (x ^ (x >> 1)) : 4;
+}
+
+template <bool EMIT>
+__global__ __launch_bounds__(XS_THREADS) void k_split_exact(ExactArgs a)
+{ const int64_t r = (int64_t) blockIdx.x * XS_THREADS + threadIdx.x;
+  if (r >= a.nreads)
+    return;
+  const int K   = a.kmer;
+  const int KM1 = K - 1;
+  const int MS  = K - 4;                                  // MAX_SUPER at PAD = 0
+  const unsigned char *s = a.bases + a.roff[r] + a.bc_prefix;
+  const int q = (int) (a.roff[r + 1] - a.roff[r]) - 1 - a.bc_prefix;     // split.c:1077-1079
+  if (q < K)
+    { if (!EMIT) a.cnt[r] = 0;
+      return;
+    }
+  int rmsk = 1;
+  while (rmsk < K) rmsk <<= 1;
+  rmsk = 2 * rmsk - 1;
+
+  unsigned short ring[XS_RING];           // (min(c,u) << 1) | (u < c)
+  const int t0 = a.tran[0], t1 = a.tran[1], t2 = a.tran[2], t3 = a.tran[3];
+  auto fwv = [&](int code) -> unsigned { return (unsigned) (code == 1 ? t1 : code == 2 ? t2 : code == 3 ? t3 : t0); };
+  auto rcv = [&](int code) -> unsigned { return (unsigned) (code == 1 ? t2 : code == 2 ? t1 : code == 3 ? t0 : t3) << 8; };
+
+  u32 nrec = 0;
+  u64 ninst = 0;
+  const u64 obase = EMIT ? a.off[r] : 0ull;
+  const int lenw  = a.smer_bytes >> 2;
+  const int lensh = 24 - 8 * (a.smer_bytes & 3);
+
+  auto emit = [&](int first_end, int n, int flip)
+    { // k-mers ending at first_end .. first_end+n-1: bases s[first_end-KM1 .. first_end+n-1]
+      if (EMIT)
+        { const unsigned char *b = s + (first_end - KM1);
+          const int L = n - 1 + K;
+          u32 *dst = a.out + (obase + nrec) * (u64) a.sww;
+          for (int w = 0; w < a.sww; w++)
+            { u32 x = 0;
+              for (int j = 0; j < 16; j++)
+                { const int i = 16 * w + j;
+                  if (i < L)
+                    { const int c = flip ? 3 - xs_code(b[L - 1 - i]) : xs_code(b[i]);
+                      x |= ((u32) (c & 3)) << (30 - 2 * j);
+                    }
+                }
+              if (w == lenw)
+                x |= ((u32) (n - 1)) << lensh;
+              dst[w] = __builtin_bswap32(x);
+            }
+        }
+      nrec += 1;
+      ninst += (u64) n;
+    };
+
+  unsigned c = 0, u = 0, mp = 0, mc = 1024;
+  int m = 0, p;
+  int ilo = -1, ihi = -1, phi = -1;
+  for (p = 0; p < K; p++)                                   // split.c:1096-1134
+    { const int code = xs_code(s[p]);
+      c = ((c << 2) | fwv(code)) & 1023u;
+      u = (u >> 2) | rcv(code);
+      if (p >= 4)
+        { const unsigned fl = (u < c);
+          mp = fl ? u : c;
+          ring[p & rmsk] = (unsigned short) ((mp << 1) | fl);
+          if (mp < mc)
+            { m = p; mc = mp; }
+        }
+      if (code >= 4)
+        { if (p > ihi)
+            ilo = KM1;
+          ihi = p + K;
+        }
+    }
+
+  int  last = KM1;
+  bool done = false;
+  for (p = K; !done; p++)                                   // split.c:1136-1347
+    { int  code = 0;
+      bool closing, force;
+      if (p < q)
+        { code = xs_code(s[p]);
+          c = ((c << 2) | fwv(code)) & 1023u;
+          u = (u >> 2) | rcv(code);
+          const unsigned fl = (u < c);
+          mp = fl ? u : c;
+          ring[p & rmsk] = (unsigned short) ((mp << 1) | fl);
+          force   = (p - m >= MS);
+          closing = force || (mp < mc);
+        }
+      else                                                   // end-of-read flush, split.c:1342-1347
+        { if (ihi == q)
+            break;
+          mp = mc;
+          force = closing = true;
+          done = true;
+        }
+      if (closing)
+        { int n;
+          if (ihi >= last)                                   // split.c:1167-1232
+            { if (ihi <= p)
+                { last = ihi; ihi = -1; n = p - last; }
+              else
+                { if (phi > last)
+                    { last = phi; phi = -1; }
+                  n = ilo - last;
+                }
+            }
+          else
+            n = p - last;
+          if (n > 0)
+            emit(last, n, ring[m & rmsk] & 1);
+          if (done)
+            break;
+          if (force)                                         // split.c:1304-1320
+            { m += 1;
+              mc = ring[m & rmsk] >> 1;
+              for (int j = m + 1; j <= p; j++)
+                { const unsigned v = ring[j & rmsk] >> 1;
+                  if (v <= mc)
+                    { m = j; mc = v; }
+                }
+            }
+          else
+            { m = p; mc = mp; }
+          last = p;
+        }
+      if (code >= 4)                                         // split.c:1323-1330
+        { if (p > ihi)
+            { phi = ihi; ilo = p; }
+          ihi = p + K;
+        }
+    }
+
+  if (!EMIT)
+    a.cnt[r] = nrec;
+  if (ninst != 0)
+    atomicAdd(&a.inst[r & 63], ninst);
+}
+
+// byte histogram of bases[lo,hi)                                       frequency_thread, split.c:95-112
+__global__ __launch_bounds__(256) void k_base_freq(const unsigned char *__restrict__ bases, int64_t lo,
+                                                   int64_t hi, u64 *__restrict__ out)
+{ __shared__ u32 h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  for (int64_t i = lo + (int64_t) blockIdx.x * 256 + threadIdx.x; i < hi; i += (int64_t) gridDim.x * 256)
+    atomicAdd(&h[bases[i]], 1u);
+  __syncthreads();
+  if (h[threadIdx.x] != 0)
+    atomicAdd(&out[threadIdx.x], (u64) h[threadIdx.x]);
+}
+
+// Tran ranking as Determine_Scheme computes it (split.c:529-575), including its quirk: the per-thread
+// byte counts are summed INTO thread 0's own vector from j = 0 (split.c:536-539), so read stripe 0 of
+// the training block counts twice.  train_reads = reads of the first block (Get_First_Block).
+int fkx_train_tran(fk_ctx *ctx, const void *d_bases, const int64_t *h_roff, int64_t train_reads,
+                   int nthreads, int *tran)
+{ hipStream_t s = ctx->stream;
+  u64 *d_f = ctx->d_scratch + 2048;
+  for (int i = 0; i < 4; i++)
+    tran[i] = i;
+  if (train_reads <= 0)
+    return (FK_OK);
+  FK_HIP(ctx, hipMemsetAsync(d_f, 0, 256 * sizeof(u64), s));
+  const int64_t lo = h_roff[0], hi = h_roff[train_reads];
+  const int64_t stripe0 = (nthreads > 1) ? train_reads / nthreads : train_reads;
+  hipLaunchKernelGGL(k_base_freq, dim3(2048), dim3(256), 0, s, (const unsigned char *) d_bases, lo, hi, d_f);
+  hipLaunchKernelGGL(k_base_freq, dim3(2048), dim3(256), 0, s, (const unsigned char *) d_bases, lo,
+                     h_roff[stripe0], d_f);
+  FK_LAUNCH_CHECK(ctx);
+  FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch, d_f, 256 * sizeof(u64), hipMemcpyDeviceToHost, s));
+  FK_HIP(ctx, hipStreamSynchronize(s));
+  const u64 *f = ctx->h_scratch;
+  const u64 f4[4] = { f['a'] + f['A'], f['c'] + f['C'], f['g'] + f['G'], f['t'] + f['T'] };
+  for (int a = 0; a < 4; a++)
+    { int rank = 0;
+      for (int b = 0; b < 4; b++)
+        if (f4[b] < f4[a] || (f4[b] == f4[a] && b < a))
+          rank += 1;
+      tran[a] = rank;
+    }
+  return (FK_OK);
+}
+
+int fkx_split_exact(fk_ctx *ctx, const void *d_bases, const int64_t *d_roff, int64_t nreads,
+                    const int *tran, void **d_out, int64_t *nsuper, int64_t *ninst)
+{ hipStream_t s = ctx->stream;
+  *nsuper = 0; *ninst = 0; *d_out = NULL;
+  if (nreads == 0)
+    return (FK_OK);
+  if (ctx->prm.kmer > 128 || ctx->prm.kmer < 8)
+    return (FK_EUNSUPPORTED);
+  u32 *d_cnt = (u32 *) fk_slot(ctx, FK_SLOT_EX_HEADS, nreads * 4);
+  u64 *d_off = (u64 *) fk_slot(ctx, FK_SLOT_EX_KOFF, nreads * 8);
+  if (d_cnt == NULL || d_off == NULL)
+    return (FK_ENOMEM);
+  u64 *d_inst = ctx->d_scratch + 2048;          // [64] instances, [64] = total records
+  ExactArgs a;
+  a.bases = (const unsigned char *) d_bases;
+  a.roff = d_roff;
+  a.nreads = nreads;
+  a.kmer = ctx->prm.kmer;
+  a.bc_prefix = ctx->prm.bc_prefix;              // exact mode keeps the prefix bytes and skips them here
+  for (int i = 0; i < 4; i++)
+    a.tran[i] = tran[i];
+  a.smer_bytes = ctx->wid.smer_bytes;
+  a.sww = ctx->wid.smer_stride / 4;
+  a.cnt = d_cnt;
+  a.off = d_off;
+  a.out = NULL;
+  a.inst = d_inst;
+  const unsigned grid = (unsigned) ((nreads + XS_THREADS - 1) / XS_THREADS);
+  FK_HIP(ctx, hipMemsetAsync(d_inst, 0, 72 * sizeof(u64), s));
+  hipLaunchKernelGGL(k_split_exact<false>, dim3(grid), dim3(XS_THREADS), 0, s, a);
+  hipLaunchKernelGGL(k_exscan_tiles, dim3(1), dim3(256), 0, s, (const u32 *) d_cnt, nreads, d_off,
+                     d_inst + 64);
+  FK_LAUNCH_CHECK(ctx);
+  FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch, d_inst, 72 * sizeof(u64), hipMemcpyDeviceToHost, s));
+  FK_HIP(ctx, hipStreamSynchronize(s));
+  const int64_t ns = (int64_t) ctx->h_scratch[64];
+  int64_t ni = 0;
+  for (int x = 0; x < 64; x++)
+    ni += (int64_t) ctx->h_scratch[x];
+  *nsuper = ns;
+  *ninst = ni;
+  if (ns == 0)
+    return (FK_OK);
+  void *out = fk_slot(ctx, FK_SLOT_SM_A, ns * ctx->wid.smer_stride);
+  if (out == NULL)
+    return (FK_ENOMEM);
+  a.out = (u32 *) out;
+  FK_HIP(ctx, hipMemsetAsync(d_inst, 0, 72 * sizeof(u64), s));
+  hipLaunchKernelGGL(k_split_exact<true>, dim3(grid), dim3(XS_THREADS), 0, s, a);
+  FK_LAUNCH_CHECK(ctx);
+  *d_out = out;
+  return (FK_OK);
+}

@@ -62,6 +62,11 @@ typedef struct
     int     device;        /* HIP device ordinal for this process (one process per GPU)  */
     int     nbuckets;      /* super-mer buckets for sharding (1 = no sharding), <= 256   */
     int64_t hbm_budget;    /* bytes of HBM the context may use, 0 = 80% of free memory   */
+    int     exact_parts;   /* 1: replay the reference's own super-mer rule (split.c:1016-1393)
+                              so that the hidden .ktab part files get the reference's first-byte
+                              boundaries (Table_Split, count.c:1560-1565) -- byte-identical files
+                              whenever the reference would use one bucket (k-mers fit -M);
+                              needs fk_push_block (read offsets); ~10x slower split           */
   } fk_params;
 
 void fk_default_params(fk_params *p);

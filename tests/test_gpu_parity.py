@@ -411,3 +411,28 @@ def test_planned_bucketed_split_matches_exact_counts():
         p = orc.msd_sort(np.ascontiguousarray(pl[offs[b]:offs[b] + c]), w.smer_stride)
         assert np.array_equal(a, p), b
         lo += c
+
+
+# ------------------------------------------------------------------------------ exact part files
+
+@pytest.mark.parametrize("name", util.golden_names())
+def test_exact_parts_mode_reproduces_reference_files(name, tmp_path):
+    """exact_parts=1 replays the reference's own super-mer rule on the GPU, so the weighted k-mer
+    first-byte census -- and with it every hidden .ktab part boundary -- is the reference's:
+    all output files are byte-identical to reference FastK's (sha256 from tests/golden)."""
+    import hashlib
+    case, bases, boff = util.load_case(name)
+    k, T = case["k"], case["T"]
+    with fastk_amd.Context(kmer=k, table_cutoff=case["cutoff"], nthreads=T, exact_parts=True) as ctx:
+        nreads = len(boff) - 1
+        step = max(1, nreads // 3)
+        for s in range(0, nreads, step):
+            e = min(nreads, s + step)
+            ctx.push_block(bases[boff[s]:boff[e]], (boff[s:e + 1] - boff[s]).astype(np.int32))
+        res = ctx.finish()
+        util.check_against_golden(case, res.hist, res.max_inst, res.table)
+        ctx.write_hist(res, str(tmp_path / "x.hist"))
+        ctx.write_ktab(res, str(tmp_path), "x")
+    for fname, digest in case["expected"]["file_sha256"].items():
+        got = hashlib.sha256(open(tmp_path / fname, "rb").read()).hexdigest()
+        assert got == digest, fname
