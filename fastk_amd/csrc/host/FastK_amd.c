@@ -1,6 +1,6 @@
 /* FastK_amd.c -- host driver with FastK's command line over libfastk_amd.so.
  *
- *   FastK_amd [-k<int(40)>] [-t[<int(1)>]] [-bc<int>] [-v] [-N<path_name>] [-P<dir>] [-M<int>]
+ *   FastK_amd [-k<int(40)>] [-t[<int(1)>]] [-bc<int>] [-v] [-x] [-N<path_name>] [-P<dir>] [-M<int>]
  *             [-T<int(4)>] <source>[.fa|.fasta|.fq|.fastq][.gz] ...
  *
  * Same flags, defaults, output names and encodings as the reference driver (FastK.c:34-37,
@@ -11,6 +11,10 @@
  * longer than a block continues in the next one with a K-1 base overlap, io.c:557-570) and hands
  * them to fk_push_block -- the call that replaces Distribute_Block (FastK.h:123).  Everything
  * per-base and per-record runs on the GPU inside the library.
+ *
+ * -x (extension, no reference counterpart): exact part files -- replays the reference's own super-mer
+ * rule so that the hidden .ktab parts are cut at the reference's first bytes (fk_params.exact_parts);
+ * without it the table's canonical stream is identical but the part boundaries are our own.
  *
  * Accepted for compatibility and ignored: -P (no temporary files exist), -M (HBM is sized by the
  * library).  Not built yet and rejected with a message: -p (profiles), -c (homopolymer
@@ -29,7 +33,7 @@
 
 static char *Prog_Name = "FastK_amd";
 
-static int       KMER = 40, NTHREADS = 4, DO_TABLE = 0, BC_PREFIX = 0, VERBOSE = 0;
+static int       KMER = 40, NTHREADS = 4, DO_TABLE = 0, BC_PREFIX = 0, VERBOSE = 0, EXACT = 0;
 static char     *OUT_NAME = NULL;
 
 typedef struct
@@ -160,6 +164,7 @@ int main(int argc, char *argv[])
           BC_PREFIX = atoi(argv[i]+3);
           break;
         case 'v': VERBOSE = 1; break;
+        case 'x': EXACT = 1; break;
         case 'N': OUT_NAME = argv[i]+2; break;
         case 'P': case 'M': break;
         case 'p': case 'c':
@@ -173,7 +178,7 @@ int main(int argc, char *argv[])
       argv[j++] = argv[i];
   nfiles = j-1;
   if (nfiles < 1 || KMER <= 0 || NTHREADS <= 0 || DO_TABLE < 0 || BC_PREFIX < 0)
-    { fprintf(stderr,"\nUsage: %s [-k<int(40)>] [-t[<int(1)>]] [-bc<int>] [-v] [-N<path_name>]\n",Prog_Name);
+    { fprintf(stderr,"\nUsage: %s [-k<int(40)>] [-t[<int(1)>]] [-bc<int>] [-v] [-x] [-N<path_name>]\n",Prog_Name);
       fprintf(stderr,"       %*s [-P<dir>] [-M<int>] [-T<int(4)>] <source>[.fa|.fasta|.fq|.fastq][.gz] ...\n",
               (int) strlen(Prog_Name),"");
       exit (1);
@@ -181,6 +186,7 @@ int main(int argc, char *argv[])
 
   fk_default_params(&prm);
   prm.kmer = KMER; prm.table_cutoff = DO_TABLE; prm.nthreads = NTHREADS; prm.bc_prefix = BC_PREFIX;
+  prm.exact_parts = EXACT;
   if (fk_create(&prm,&ctx) != FK_OK)
     die(NULL,"fk_create");
 

@@ -260,6 +260,12 @@ def test_cli_outputs_match_reference(name, fmt, gz, tmp_path):
     if os.path.exists(tabex):
         out = subprocess.run([tabex, "-C", str(tmp_path / "reads")], capture_output=True, text=True)
         assert "Table is OK" in out.stdout + out.stderr
+    # -x: every file, hidden parts included, is byte-identical to the reference's
+    subprocess.run([exe, "-k%d" % case["k"], "-t%d" % case["cutoff"], "-T%d" % case["T"], "-x", path],
+                   check=True, cwd=str(tmp_path))
+    for fname, digest in exp["file_sha256"].items():
+        mine = fname.replace("x.", "reads.", 1) if fname.startswith("x.") else fname.replace(".x.", ".reads.", 1)
+        assert hashlib.sha256(open(tmp_path / mine, "rb").read()).hexdigest() == digest, fname
 
 
 def test_group_records_brings_duplicates_together(ctx40):
