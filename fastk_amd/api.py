@@ -21,6 +21,7 @@ EXPORTS = [
     "fk_device_alloc", "fk_device_free", "fk_copy_to_device", "fk_copy_to_host",
     "fk_get_sort_stats", "fk_version", "fk_count_device_reads", "fk_count_device_supermers", "fk_debug_set", "fk_group_records",
     "fk_count_presorted_kmers", "fk_split_supermers_emit", "fk_split_plan", "fk_split_planned",
+    "fk_train_block",
 ]
 
 
@@ -83,6 +84,7 @@ def load_library():
     L.fk_set_stream.argtypes = [vp, vp]
     L.fk_synchronize.argtypes = [vp]
     L.fk_push_block.argtypes = [vp, vp, vp, ci, ci, ci]
+    L.fk_train_block.argtypes = [vp, vp, vp, ci]
     L.fk_push_device.argtypes = [vp, vp, i64]
     L.fk_finish.argtypes = [vp, C.POINTER(CResult)]
     L.fk_count_device_reads.argtypes = [vp, vp, i64, ci, C.POINTER(CResult)]

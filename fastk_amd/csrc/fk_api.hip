@@ -528,6 +528,31 @@ extern "C" int fk_push_block(fk_ctx *ctx, const char *bases, const int32_t *boff
   return (rc);
 }
 
+extern "C" int fk_train_block(fk_ctx *ctx, const char *bases, const int32_t *boff, int nreads)
+{ if (ctx == NULL || bases == NULL || boff == NULL || nreads < 0) return (FK_EINVAL);
+  // frequency_thread x NTHREADS summed into thread 0's vector from j = 0 (split.c:95-112,536-539):
+  // every byte once, read stripe 0 twice
+  int64_t freq[256];
+  memset(freq, 0, sizeof(freq));
+  const int T = ctx->prm.nthreads;
+  const int64_t stripe0 = (T > 1) ? ((int64_t) nreads * 1) / T : nreads;
+  for (int64_t i = boff[0]; i < boff[nreads]; i++)
+    freq[(unsigned char) bases[i]] += 1;
+  for (int64_t i = boff[0]; i < boff[stripe0]; i++)
+    freq[(unsigned char) bases[i]] += 1;
+  const int64_t f4[4] = { freq['a'] + freq['A'], freq['c'] + freq['C'], freq['g'] + freq['G'],
+                          freq['t'] + freq['T'] };
+  for (int a = 0; a < 4; a++)
+    { int rank = 0;
+      for (int b = 0; b < 4; b++)
+        if (f4[b] < f4[a] || (f4[b] == f4[a] && b < a))
+          rank += 1;
+      ctx->tran[a] = rank;
+    }
+  ctx->have_tran = 1;
+  return (FK_OK);
+}
+
 extern "C" int fk_push_device(fk_ctx *ctx, const void *d_bases, int64_t nbytes)
 { if (ctx == NULL || d_bases == NULL || nbytes < 0) return (FK_EINVAL);
   if (ctx->prm.bc_prefix > 0 || ctx->prm.exact_parts)
@@ -602,7 +627,10 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
                     break;
                 }
               int tran[4];
-              if ((rc = fkx_train_tran(ctx, d_reads, h_roff, train, ctx->prm.nthreads, tran)) != FK_OK) break;
+              if (ctx->have_tran)
+                for (int x = 0; x < 4; x++)
+                  tran[x] = ctx->tran[x];
+              else if ((rc = fkx_train_tran(ctx, d_reads, h_roff, train, ctx->prm.nthreads, tran)) != FK_OK) break;
               int64_t *d_roff = (int64_t *) fk_slot(ctx, FK_SLOT_ROFF, (nreads + 1) * 8);
               if (d_roff == NULL) { rc = FK_ENOMEM; break; }
               if (hipMemcpyAsync(d_roff, h_roff, (size_t) (nreads + 1) * 8, hipMemcpyHostToDevice, s) != hipSuccess)

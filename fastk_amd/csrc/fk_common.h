@@ -52,6 +52,7 @@ struct fk_ctx
   void      *push_lock;    // pthread mutex
   int64_t   *h_roff;       // exact_parts: byte offset of every pushed read (+ end), host
   int64_t    nroff, roff_cap;
+  int        have_tran, tran[4];   // exact_parts: ranking from fk_train_block
 
   hipEvent_t ev0, ev1;
   hipEvent_t pass_ev[128];       // begin/end of each scatter launch of the current sort

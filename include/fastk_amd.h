@@ -90,6 +90,12 @@ int fk_synchronize(fk_ctx *ctx);
 int fk_push_block(fk_ctx *ctx, const char *bases, const int32_t *boff, int nreads, int rem,
                   int tid);
 
+/* exact_parts only: hand over the training block the reference derives its base ranking from
+   (what Determine_Scheme(DATA_BLOCK *) receives, split.c:491-575).  Optional: without it the
+   ranking is taken from the first reads pushed, which is the same set when blocks are pushed in
+   file order by one thread. */
+int fk_train_block(fk_ctx *ctx, const char *bases, const int32_t *boff, int nreads);
+
 /* Same, for reads already resident in HBM (any byte that is not acgtACGT separates reads). */
 int fk_push_device(fk_ctx *ctx, const void *d_bases, int64_t nbytes);
 

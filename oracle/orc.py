@@ -23,6 +23,8 @@ def build(ref=True):
     subprocess.check_call(["make", "-s", "-C", HERE, "all"])
     if ref and os.path.isdir(REFERENCE_SRC):
         subprocess.check_call(["make", "-s", "-C", HERE, "ref"])
+        if os.path.exists(os.path.join(os.path.dirname(HERE), "fastk_amd", "lib", "libfastk_amd.so")):
+            subprocess.check_call(["make", "-s", "-C", HERE, "ref_gpu"])
 
 
 class OrcParams(C.Structure):

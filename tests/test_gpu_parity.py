@@ -442,3 +442,24 @@ def test_exact_parts_mode_reproduces_reference_files(name, tmp_path):
     for fname, digest in case["expected"]["file_sha256"].items():
         got = hashlib.sha256(open(tmp_path / fname, "rb").read()).hexdigest()
         assert got == digest, fname
+
+
+@pytest.mark.parametrize("name,fmt", [("edge_k40_t1_T4", "fasta"), ("synth_illumina_k51_t1_T4", "fasta"),
+                                      ("synth_hifi_k40_t4_T8", "fasta")])
+def test_reference_main_over_gpu_shim(name, fmt, tmp_path):
+    """oracle/_ref/FastK_gpu = the REFERENCE's own main(), option parser and multi-threaded input layer
+    (FastK.c, io.c compiled where they lie) linked against libfastk_amd.so through the INTEGRATION.md
+    shim.  Its output files must be the reference's, byte for byte."""
+    import hashlib, os, subprocess
+    exe = os.path.join(orc.REF_DIR, "FastK_gpu")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/FastK_gpu not built (needs the reference sources at build time)")
+    case, bases, boff = util.load_case(name)
+    path = str(tmp_path / ("x." + fmt))
+    orc.write_fasta(path, bases, boff, width=0 if case["kind"] == "edge" else 100)
+    subprocess.run([exe, "-k%d" % case["k"], "-t%d" % case["cutoff"], "-T%d" % case["T"],
+                    "-P" + str(tmp_path), path], check=True, cwd=str(tmp_path),
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    for fname, digest in case["expected"]["file_sha256"].items():
+        got = hashlib.sha256(open(tmp_path / fname, "rb").read()).hexdigest()
+        assert got == digest, fname
