@@ -1,9 +1,9 @@
 /* gpu_path.c -- the shim of INTEGRATION.md, compilable: it replaces split.c, count.c, table.c and
  * MSDsort.c in a build of the REFERENCE FastK (FastK.c, io.c, merge.c, LSDsort.c, libfastk.c stay
  * as they are), so that the reference's own main(), option parsing and input layer drive the GPU
- * path through the C-ABI.  Built only where the reference sources are present
- * (make -C oracle ref_gpu -> oracle/_ref/FastK_gpu); used by tests/test_gpu_parity.py as the
- * end-to-end drop-in check.
+ * path through the C-ABI.  Built only where the reference sources are present (target ref_gpu of
+ * the test-infrastructure Makefile); tests/test_gpu_parity.py runs the result as the end-to-end
+ * drop-in check.
  */
 #include <stdio.h>
 #include <stdlib.h>
