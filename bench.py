@@ -170,8 +170,8 @@ def main():
     ms_step = 1e3 * dt / args.steps
     value = ninst / (dt / args.steps)
 
-    # roofline of the dominant kernel: k_rx_scatter on the W weighted k-mer records (the grouping
-    # passes; digit = byte of a 32-bit hash of the key), one stable 8-bit digit pass per launch.  Algorithmic bytes per launch = 2 * n * R (records read once and written
+    # roofline of the dominant kernel: k_rx_scatter on the W weighted k-mer records (the four
+    # least-significant key-byte passes that run before collapsing), one stable 8-bit digit pass per launch.  Algorithmic bytes per launch = 2 * n * R (records read once and written
     # once at the reference width R = KMER_WORD); duration = HIP event pair around every scatter
     # launch on the library's stream, averaged over the launches of the last step.  pass_total adds
     # the per-pass helper kernels (digit-stream histogram + two scans) that feed it.
@@ -198,7 +198,7 @@ def main():
                     frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
                     traffic_unit="bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_traffic.json)",
                     algorithmic_bytes=2.0 * n_pass * w.kmer_word,
-                    kernel="k_rx_scatter<3,12,hashed> (weighted k-mer records, R=%d B)" % w.kmer_word,
+                    kernel="k_rx_scatter<3,12> (weighted k-mer records, R=%d B)" % w.kmer_word,
                     records_per_launch=int(n_pass), launches_per_step=int(loc.passes_kmer),
                     avg_launch_ms=round(avg_ms, 4),
                     pass_total=dict(avg_ms=round(avg_pass_ms, 4),

@@ -576,7 +576,8 @@ extern "C" int fk_push_device(fk_ctx *ctx, const void *d_bases, int64_t nbytes)
 }
 
 // ---- whole path: split -> sort -> expand -> sort -> count ----------------------------------------
-#define FK_GROUP_PASSES 4
+#define FK_GROUP_PASSES 4      // hashed digit passes that group super-mers
+#define FK_LOW_BYTES    4      // key bytes sorted over all W records before equal neighbours are collapsed
 #define FK_PREFIX_BYTES 64
 // FK_PREFIX_BYTES 64 = disabled: sort every key byte.  A shorter prefix (fk_count_presorted_kmers) does not pay on
 // read data: one-substitution error k-mers share long prefixes with their true k-mer, so about half
@@ -675,40 +676,49 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
         break;
       hipEventRecord(ev[3], s);
 
-      // weighted k-mer stage.  The reference sorts all W weighted records on KMER_BYTES
-      // (MSDsort.c:536).  Only the DISTINCT k-mers have to end up in lexicographic order, so the
-      // device first groups the W records by a 32-bit hash of the key (4 digit passes), collapses
-      // every run into one record (weights summed, clipped like count.c:455-458), and then runs
-      // the KMER_BYTES-pass sort on the ~W/4.4 collapsed records.  Keys whose hashes collide just
-      // stay split; the final count sums them after the real sort.
+      // weighted k-mer stage.  The reference runs all KMER_BYTES digit passes over the W weighted
+      // records (MSDsort.c:536).  Here the LSD sort is interrupted after the FK_LOW_BYTES least
+      // significant key bytes: equal k-mers that are adjacent by then are collapsed into one record
+      // (weights summed, clipped like count.c:455-458) -- the collapse keeps the order, so the
+      // remaining passes simply continue the same LSD sort on ~3x fewer records.  k-mers that were
+      // not adjacent yet meet at the end and are summed by the count kernel.
       void *km_sorted = km_a;
       int   sorted_bytes = w.kmer_bytes;
       int64_t nc = nw, ovf2 = 0;
       if (nw > 0)
         { if ((km_b = fk_slot(ctx, FK_SLOT_KM_B, nw * w.kmer_stride)) == NULL)
             { rc = FK_ENOMEM; break; }
-          void *grouped = km_a;
-          if ((rc = fkx_group(ctx, nw, km_a, km_b, w.kmer_stride, w.kmer_bytes, FK_GROUP_PASSES,
-                              &grouped)) != FK_OK)
-            break;
-          res->passes_kmer  = ctx->sort_stats.passes;
-          res->ms_pass_kmer = ctx->sort_stats.pass_ms_total;
-          res->ms_scatter_kmer = ctx->sort_stats.scatter_ms_total;
-          void *cbuf = (grouped == km_a) ? km_b : km_a;
-          if ((rc = fkx_collapse(ctx, grouped, nw, cbuf, nw, &nc, &ovf2)) != FK_OK)
-            break;
+          const int nlow = (w.kmer_bytes > FK_LOW_BYTES + 1) ? FK_LOW_BYTES : 0;
           int bytes[64];
-          for (int i = 0; i < w.kmer_bytes; i++)
-            bytes[i] = w.kmer_bytes - 1 - i;
-          km_sorted = cbuf;
-          if ((rc = fkx_lsd_sort(ctx, nc, cbuf, grouped, w.kmer_stride, bytes, w.kmer_bytes,
-                                 &km_sorted)) != FK_OK)
+          void *low = km_a;
+          if (nlow > 0)
+            { for (int i = 0; i < nlow; i++)
+                bytes[i] = w.kmer_bytes - 1 - i;
+              if ((rc = fkx_lsd_sort(ctx, nw, km_a, km_b, w.kmer_stride, bytes, nlow, &low)) != FK_OK)
+                break;
+              res->passes_kmer  = ctx->sort_stats.passes;
+              res->ms_pass_kmer = ctx->sort_stats.pass_ms_total;
+              res->ms_scatter_kmer = ctx->sort_stats.scatter_ms_total;
+              void *cbuf = (low == km_a) ? km_b : km_a;
+              if ((rc = fkx_collapse(ctx, low, nw, cbuf, nw, &nc, &ovf2)) != FK_OK)
+                break;
+              km_b = low; km_a = cbuf;                 // km_a holds the collapsed records
+            }
+          const int nhigh = w.kmer_bytes - nlow;
+          for (int i = 0; i < nhigh; i++)
+            bytes[i] = nhigh - 1 - i;
+          km_sorted = km_a;
+          if ((rc = fkx_lsd_sort(ctx, nc, km_a, km_b, w.kmer_stride, bytes, nhigh, &km_sorted)) != FK_OK)
             break;
           res->passes_final  = ctx->sort_stats.passes;
           res->ms_pass_final = ctx->sort_stats.pass_ms_total;
           res->ncollapsed    = nc;
-          km_a = cbuf; km_b = grouped;                 // the pair now in use
-          // first-byte census of the (collapsed) k-mers, for the .ktab part boundaries
+          if (nlow == 0)
+            { res->passes_kmer  = ctx->sort_stats.passes;
+              res->ms_pass_kmer = ctx->sort_stats.pass_ms_total;
+              res->ms_scatter_kmer = ctx->sort_stats.scatter_ms_total;
+            }
+          // first-byte census of the sorted records, for the .ktab part boundaries
           for (int x = 0; x < 256; x++)
             res->wfirst[x] = (h_roff != NULL) ? exact_census[x] : (int64_t) ctx->h_scratch[x];
         }
