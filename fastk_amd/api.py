@@ -338,3 +338,31 @@ class Context:
                 return None
         self._ck(rc)
         return hist, mi.value, nd.value, nt.value
+
+
+def write_files(kmer, table_cutoff, nthreads, hist, max_inst, table, outdir, root, wfirst=None):
+    """Write <root>.hist and, with table_cutoff > 0, <root>.ktab + hidden parts from host arrays with
+    the library's writers (host-only C code: works without a GPU).  table: (n, KMER_WORD) uint8,
+    sorted.  Part boundaries follow wfirst (first-byte census of the weighted k-mers, split.c's
+    Table_Split input) when given, else the first-byte census of the table itself."""
+    L = load_library()
+    r = CResult()
+    h = np.asarray(hist, dtype=np.int64)
+    for i in range(1, HIST_BINS):
+        r.hist[i] = int(h[i])
+    r.max_inst = int(max_inst)
+    t = np.ascontiguousarray(table, dtype=np.uint8)
+    r.ntable = t.shape[0]
+    r.table = t.ctypes.data_as(C.POINTER(C.c_uint8))
+    if wfirst is not None and int(np.sum(wfirst)) > 0:
+        census = np.asarray(wfirst, dtype=np.int64)
+    else:
+        census = np.bincount(t[:, 0], minlength=256) if t.shape[0] else np.zeros(256, dtype=np.int64)
+    for x in range(256):
+        r.wfirst[x] = int(census[x])
+    r.nweighted = int(census.sum())
+    if L.fk_write_hist(C.byref(r), kmer, os.path.join(outdir, root + ".hist").encode()) != 0:
+        raise FastKError(L.fk_last_error(None).decode())
+    if table_cutoff > 0 and L.fk_write_ktab(C.byref(r), kmer, table_cutoff, nthreads, outdir.encode(),
+                                            root.encode()) != 0:
+        raise FastKError(L.fk_last_error(None).decode())

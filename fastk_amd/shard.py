@@ -46,10 +46,30 @@ class HipEngine:
             offs.append(offs[-1] + c)
         return recs, counts, offs, ni
 
-    def count_supermers(self, recs, nsuper):
-        res = self.ctx.count_device_supermers(recs.data_ptr() if nsuper else None, nsuper)
+    def sort_table(self, recs):
+        """(n, KMER_WORD) host records -> sorted on the k-mer bytes with the device radix engine."""
+        n, kw = recs.shape
+        if n == 0:
+            return recs
+        stride = self.ctx.w.kmer_stride
+        dev = np.zeros((n, stride), dtype=np.uint8)
+        dev[:, :self.ctx.w.kmer_bytes] = recs[:, :self.ctx.w.kmer_bytes]
+        dev[:, stride - 2:] = recs[:, kw - 2:]
+        a = self.ctx.alloc(dev.nbytes).upload(dev)
+        b = self.ctx.alloc(dev.nbytes)
+        p = self.ctx.msd_sort(a.ptr, b.ptr, n, stride, self.ctx.w.kmer_bytes)
+        out = a.download(dev.nbytes, ptr=p).reshape(n, stride)
+        a.free(); b.free()
+        res = np.empty((n, kw), dtype=np.uint8)
+        res[:, :kw - 2] = out[:, :kw - 2]
+        res[:, kw - 2:] = out[:, stride - 2:]
+        return res
+
+    def count_supermers(self, recs, nsuper, fetch_table=False):
+        res = self.ctx.count_device_supermers(recs.data_ptr() if nsuper else None, nsuper,
+                                              fetch_table=fetch_table)
         return dict(hist=res.hist, max_inst=res.max_inst, nweighted=res.nweighted,
-                    ndistinct=res.ndistinct, ntable=res.ntable, result=res)
+                    ndistinct=res.ndistinct, ntable=res.ntable, wfirst=res.wfirst, result=res)
 
 
 # One all_to_all_single call moves at most this many bytes between any pair of ranks: element counts
@@ -96,13 +116,13 @@ def _exchange_records(recs, inbox, send_n, recv_n, stride, group, s_off=None):
             o += rl[d] * stride
 
 
-def count_sharded(engine, reads, group=None, verify=False):
+def count_sharded(engine, reads, group=None, verify=False, fetch_table=False):
     """Run the sharded path; every rank returns the same global totals.
 
     verify=True adds a checksum of the exchanged payload (used by bench.py's warm-up steps).
 
     Returns dict(hist int64[0x8000], max_inst, ninst, nsuper, nweighted, ndistinct, ntable,
-    local=<this rank's engine result>)."""
+    wfirst int64[256], local=<this rank's engine result>)."""
     world = dist.get_world_size(group)
     stride = engine.stride
     recs, counts, s_off, ninst = engine.split(reads)
@@ -127,13 +147,16 @@ def count_sharded(engine, reads, group=None, verify=False):
             raise RuntimeError("super-mer exchange corrupted the payload (checksums differ)")
     del recs
 
-    loc = engine.count_supermers(inbox, nrecv)
+    loc = engine.count_supermers(inbox, nrecv, fetch_table) if fetch_table \
+        else engine.count_supermers(inbox, nrecv)
 
-    tot = torch.zeros(HIST_BINS + 8, dtype=torch.int64, device=dev)
+    tot = torch.zeros(HIST_BINS + 8 + 256, dtype=torch.int64, device=dev)
     tot[:HIST_BINS] = torch.from_numpy(np.asarray(loc["hist"], dtype=np.int64)).to(dev)
     extra = [loc["max_inst"], ninst, nrecv, loc["nweighted"], loc["ndistinct"], loc["ntable"],
              sum(send_n)]
     tot[HIST_BINS:HIST_BINS + 7] = torch.tensor(extra, dtype=torch.int64, device=dev)
+    if loc.get("wfirst") is not None:       # first-byte census of the weighted k-mers (part cuts)
+        tot[HIST_BINS + 8:] = torch.from_numpy(np.asarray(loc["wfirst"], dtype=np.int64)).to(dev)
     dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=group)
     t = tot.cpu().numpy()
     if int(t[HIST_BINS + 2]) != int(t[HIST_BINS + 6]):
@@ -141,4 +164,39 @@ def count_sharded(engine, reads, group=None, verify=False):
                            % (int(t[HIST_BINS + 6]), int(t[HIST_BINS + 2])))
     return dict(hist=t[:HIST_BINS].copy(), max_inst=int(t[HIST_BINS]), ninst=int(t[HIST_BINS + 1]),
                 nsuper=int(t[HIST_BINS + 2]), nweighted=int(t[HIST_BINS + 3]),
-                ndistinct=int(t[HIST_BINS + 4]), ntable=int(t[HIST_BINS + 5]), local=loc)
+                ndistinct=int(t[HIST_BINS + 4]), ntable=int(t[HIST_BINS + 5]),
+                wfirst=t[HIST_BINS + 8:].copy(), local=loc)
+
+
+def gather_table(table, kmer_bytes, sort_fn, group=None, dst=0):
+    """Final gather (the role of Merge_Tables, table.c:346): every rank holds a sorted table of the
+    k-mers of ITS buckets ((n, KMER_WORD) uint8, disjoint between ranks); rank dst receives all of
+    them and orders the union.  sort_fn(records ndarray) -> records sorted on the first kmer_bytes
+    bytes (HipEngine.sort_table on the GPU; tests pass a CPU sorter).  Returns the merged table on
+    dst, None elsewhere."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" \
+        else torch.device("cpu")
+    kw = table.shape[1]
+    sizes = torch.zeros(world, dtype=torch.int64, device=dev)
+    sizes[rank] = table.shape[0]
+    dist.all_reduce(sizes, op=dist.ReduceOp.SUM, group=group)
+    sizes = [int(x) for x in sizes.tolist()]
+    mine = torch.from_numpy(np.ascontiguousarray(table).reshape(-1)).to(dev)
+    per = max(1, MAX_PAIR_BYTES // kw) * kw
+    if rank != dst:
+        for o in range(0, mine.numel(), per):
+            dist.send(mine[o:o + per], dst, group=group)
+        return None
+    parts = []
+    for r in range(world):
+        if r == dst:
+            parts.append(mine)
+            continue
+        buf = torch.empty(sizes[r] * kw, dtype=torch.uint8, device=dev)
+        for o in range(0, buf.numel(), per):
+            dist.recv(buf[o:o + per], r, group=group)
+        parts.append(buf)
+    merged = torch.cat(parts).cpu().numpy().reshape(-1, kw)
+    return sort_fn(merged) if world > 1 else merged

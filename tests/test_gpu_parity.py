@@ -355,6 +355,39 @@ def test_sharded_path_on_one_gpu_matches_plain_path():
         assert outs[0][key] == outs[1][key], key
 
 
+def test_sharded_final_gather_writes_reference_files(tmp_path):
+    """count_sharded(fetch_table) -> gather_table -> write_files on a one-rank RCCL group: the files
+    are the golden ones; HipEngine.sort_table (the re-ordering rank 0 does for world > 1) restores
+    a shuffled table."""
+    import hashlib, os
+    import torch
+    import torch.distributed as dist
+    from fastk_amd import shard
+    case, bases, boff = util.load_case("synth_illumina_k40_t1_T4")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29591")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        with fastk_amd.Context(kmer=case["k"], table_cutoff=case["cutoff"], nbuckets=1) as ctx:
+            eng = shard.HipEngine(ctx, torch.device("cuda", 0))
+            reads = torch.from_numpy(bases).cuda()
+            out = shard.count_sharded(eng, reads, verify=True, fetch_table=True)
+            table = out["local"]["result"].table
+            merged = shard.gather_table(table, ctx.w.kmer_bytes, eng.sort_table)
+            rng = np.random.default_rng(5)
+            again = eng.sort_table(np.ascontiguousarray(merged[rng.permutation(len(merged))]))
+            assert np.array_equal(again, merged)
+    finally:
+        dist.destroy_process_group()
+    util.check_against_golden(case, out["hist"], out["max_inst"], merged)
+    fastk_amd.write_files(case["k"], case["cutoff"], case["T"], out["hist"], out["max_inst"], merged,
+                          str(tmp_path), "x", wfirst=out["wfirst"])
+    exp = case["expected"]
+    assert hashlib.sha256(open(tmp_path / "x.hist", "rb").read()).hexdigest() == exp["hist_sha256"]
+    assert orc.read_ktab(str(tmp_path / "x"))["stream_sha256"] == exp["ktab"]["stream_sha256"]
+
+
 @pytest.mark.parametrize("name,nb", [("synth_illumina_k40_t1_T4", 4), ("edge_k40_t1_T4", 8),
                                      ("edge_k51_t1_T4", 3)])
 def test_bucketed_split_keeps_equal_kmers_together(name, nb):

@@ -64,7 +64,7 @@ class OracleEngine:
                     ndistinct=res.ndistinct, ntable=res.ntable, result=res)
 
 
-def _worker(rank, world, port, name, q):
+def _worker(rank, world, port, name, q, outdir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -76,21 +76,29 @@ def _worker(rank, world, port, name, q):
     mine = torch.from_numpy(bases[boff[lo]:boff[hi]].copy())
     eng = OracleEngine(case["k"], world, case["cutoff"])
     out = shard.count_sharded(eng, mine, verify=True)
-    tabs = [None] * world
-    dist.all_gather_object(tabs, out["local"]["result"].table)
+    P = orc.params(case["k"])
+
+    def cpu_sort(recs):
+        return recs[np.lexsort(recs[:, :P.kmer_bytes].T[::-1])]
+
+    merged = shard.gather_table(out["local"]["result"].table, P.kmer_bytes, cpu_sort)
     if rank == 0:
+        import fastk_amd
+        fastk_amd.write_files(case["k"], case["cutoff"], case["T"], out["hist"], out["max_inst"],
+                              merged, outdir, "x")
         q.put(dict(hist=out["hist"], max_inst=out["max_inst"], ninst=out["ninst"],
-                   ntable=out["ntable"], ndistinct=out["ndistinct"], tables=tabs))
+                   ntable=out["ntable"], ndistinct=out["ndistinct"], merged=merged))
     dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("name", ["synth_tiny_k40_t1_T2", "edge_k21_t2_T3"])
-def test_two_rank_shard_matches_golden(name):
+def test_two_rank_shard_matches_golden(name, tmp_path):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + (os.getpid() % 1000)
-    procs = [ctx.Process(target=_worker, args=(r, world, port, name, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, name, q, str(tmp_path)))
+             for r in range(world)]
     for p in procs:
         p.start()
     got = q.get(timeout=300)
@@ -101,7 +109,13 @@ def test_two_rank_shard_matches_golden(name):
     exp = orc.fastk(case["k"], bases, boff, cutoff=case["cutoff"])
     assert got["ninst"] == exp.ninst
     assert got["ndistinct"] == exp.ndistinct and got["ntable"] == exp.ntable
-    # ranks hold disjoint k-mer sets; their merged tables are the reference table
-    merged = np.concatenate([t for t in got["tables"] if len(t)])
-    order = np.lexsort(merged[:, :orc.params(case["k"]).kmer_bytes].T[::-1])
-    util.check_against_golden(case, got["hist"], got["max_inst"], merged[order])
+    # ranks hold disjoint k-mer sets; the gathered, re-ordered union is the reference table, and the
+    # files rank 0 wrote with the library's writers carry the reference's bytes
+    util.check_against_golden(case, got["hist"], got["max_inst"], got["merged"])
+    import hashlib
+    exp = case["expected"]
+    assert hashlib.sha256(open(tmp_path / "x.hist", "rb").read()).hexdigest() == exp["hist_sha256"]
+    t = orc.read_ktab(str(tmp_path / "x"))
+    assert t["stream_sha256"] == exp["ktab"]["stream_sha256"]
+    assert (t["nparts"], t["minval"], t["ibytes"], t["nels"]) == \
+        (case["T"], case["cutoff"], exp["ktab"]["ibytes"], exp["ktab"]["nels"])
