@@ -21,7 +21,7 @@ EXPORTS = [
     "fk_device_alloc", "fk_device_free", "fk_copy_to_device", "fk_copy_to_host",
     "fk_get_sort_stats", "fk_version", "fk_count_device_reads", "fk_count_device_supermers", "fk_debug_set", "fk_group_records",
     "fk_count_presorted_kmers", "fk_split_supermers_emit", "fk_split_plan", "fk_split_planned",
-    "fk_train_block",
+    "fk_train_block", "fk_count_unsorted_kmers", "fk_debug_get",
 ]
 
 
@@ -112,6 +112,9 @@ def load_library():
     L.fk_copy_to_host.argtypes = [vp, vp, vp, i64]
     L.fk_get_sort_stats.argtypes = [vp, C.POINTER(SortStats)]
     L.fk_debug_set.argtypes = [vp, C.c_char_p, i64]
+    L.fk_debug_get.argtypes = [vp, C.c_char_p, C.POINTER(i64)]
+    L.fk_count_unsorted_kmers.argtypes = [vp, vp, vp, i64, C.c_int, C.POINTER(i64), C.POINTER(i64),
+                                          C.POINTER(i64), C.POINTER(vp), C.POINTER(i64)]
     L.fk_version.restype = C.c_char_p
     _lib = L
     return L
@@ -323,6 +326,24 @@ class Context:
         self._ck(self.L.fk_expand_kmers(self.h, smers_ptr, nsuper, out_ptr, cap, C.byref(nw),
                                         C.byref(nd), C.byref(ov)))
         return nw.value, nd.value, ov.value
+
+    def debug_set(self, key, value):
+        self._ck(self.L.fk_debug_set(self.h, key.encode(), int(value)))
+
+    def debug_get(self, key):
+        v = C.c_int64()
+        self._ck(self.L.fk_debug_get(self.h, key.encode(), C.byref(v)))
+        return v.value
+
+    def count_unsorted(self, kmers_ptr, tmp_ptr, nweighted, cutoff):
+        """fk_count_unsorted_kmers: returns (hist, max_inst, ndistinct, ntable, table device ptr)."""
+        hist = np.zeros(HIST_BINS, dtype=np.int64)
+        mi, nd, nt = C.c_int64(0), C.c_int64(), C.c_int64()
+        tp = C.c_void_p()
+        self._ck(self.L.fk_count_unsorted_kmers(self.h, kmers_ptr, tmp_ptr, nweighted, cutoff,
+                                                hist.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(mi),
+                                                C.byref(nd), C.byref(tp), C.byref(nt)))
+        return hist, mi.value, nd.value, nt.value, tp.value
 
     def count(self, kmers_ptr, nweighted, cutoff, table_ptr=None, cap=0, sorted_bytes=None):
         hist = np.zeros(HIST_BINS, dtype=np.int64)

@@ -1,0 +1,358 @@
+// fk_aggr.hip -- count weighted k-mers that two hashed digit passes have grouped by 16 hash bits.
+//
+// Replaces, with the same results, the reference's sort-then-scan of the weighted k-mer list
+// (Weighted_Kmer_Sort MSDsort.c:536-544 -> hist_kmers MSDsort.c:491-509 -> table_write_thread
+// count.c:564-616).  Only the table has to be in k-mer order, and only k-mers with count >= the
+// cutoff are in the table, so the W weighted records are not sorted at all: fkx_group brings all
+// copies of a k-mer into one of 65,536 hash bins (two 8-bit digit passes), and here one workgroup
+// per bin sums the weights of equal k-mers in a hash table that lives in LDS, updates the 0x8000-bin
+// histogram (saturation and max_inst exactly as MSDsort.c:498-506) and appends the qualifying
+// (k-mer, count) records to the table buffer, which the caller then sorts on KMER_BYTES.
+//
+// A bin whose distinct k-mers do not fit the LDS table is processed in 2, 4, ... rounds, each
+// round taking the records whose next hash bits select it (the bin is re-read, mostly from L2).
+#include "fk_common.h"
+
+#define AG_THREADS 1024
+#define AG_WAVES   (AG_THREADS / 64)
+#define AG_HB      4096                 // LDS-private histogram bins
+#define AG_LOCK    0x80000000u          // count word: 0 empty, AG_LOCK key being written, else count
+#define AG_HIGH    (1u << 29)           // a count that reaches this is cut back by AG_CUT, the
+#define AG_CUT     (1u << 28)           //   removed instances go straight to max_inst
+#define AG_MAXR    64
+#define AG_BINS    65536
+#define AG_UNROLL  4
+
+template <int KW> struct AgCfg
+{ static constexpr int SLOTS = (KW <= 3) ? 8192 : 4096;
+  static constexpr int LIMIT = (SLOTS * 3 / 4 < SLOTS - AG_THREADS - 64) ? SLOTS * 3 / 4
+                                                                         : SLOTS - AG_THREADS - 64;
+  static constexpr size_t LDS = (size_t) SLOTS * (KW + 1) * 4 + AG_HB * 4;
+};
+
+// position of the first record of every bin: bounds[b] = lower bound of (hash16 >= b), bounds[65536] = n
+template <int KW>
+__global__ __launch_bounds__(256) void k_ag_bounds(const u32 *__restrict__ recs, int64_t n, int kbytes,
+                                                   u64 *__restrict__ bounds)
+{ const u32 b = blockIdx.x * 256 + threadIdx.x;
+  if (b > AG_BINS) return;
+  if (b == AG_BINS) { bounds[b] = (u64) n; return; }
+  int64_t lo = 0, hi = n;
+  while (lo < hi)
+    { const int64_t mid = (lo + hi) >> 1;
+      u32 r[KW];
+#pragma unroll
+      for (int w = 0; w < KW; w++)
+        r[w] = recs[mid * KW + w];
+      u32 ha, hb;
+      fk_rec_hash<KW>(r, kbytes, ha, hb);
+      if ((hb & 0xffffu) < b) lo = mid + 1;
+      else hi = mid;
+    }
+  bounds[b] = (u64) lo;
+}
+
+// exclusive scan over the 1024 threads of the block.  tmp: AG_WAVES u32 of LDS.
+__device__ __forceinline__ u32 ag_block_exscan(u32 v, u32 *tmp, u32 *total)
+{ const u32 lane = fk_lane();
+  const u32 wave = threadIdx.x >> 6;
+  u32 x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1)
+    { u32 y = __shfl_up(x, o, 64);
+      if ((int) lane >= o) x += y;
+    }
+  if (lane == 63) tmp[wave] = x;
+  __syncthreads();
+  u32 base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < AG_WAVES; w++)
+    { const u32 t = tmp[w];
+      if ((u32) w < wave) base += t;
+      tot += t;
+    }
+  __syncthreads();
+  *total = tot;
+  return (base + x - v);
+}
+
+// scal: [0] max_inst  [1] distinct k-mers  [2] table entries  [3] failure flag  [4] bin ticket
+//       [5] extra rounds taken
+template <int KW>
+__global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__ recs,
+                                                         const u64 *__restrict__ bounds, int kbytes,
+                                                         int cutoff, u64 *__restrict__ hist_g,
+                                                         u64 *__restrict__ scal, u32 *__restrict__ table,
+                                                         int LIMIT)
+{ constexpr int SLOTS = AgCfg<KW>::SLOTS;
+  extern __shared__ u32 ag_lds[];
+  u32 *key   = ag_lds;                          // [KW][SLOTS], dword-major; weight bits cleared
+  u32 *cnt   = ag_lds + (size_t) KW * SLOTS;    // [SLOTS]
+  u32 *lhist = cnt + SLOTS;                     // [AG_HB]
+  __shared__ u32 sh_bin, sh_claimed, sh_ovf, sh_tmp[AG_WAVES];
+  __shared__ u64 sh_base;
+  const int tid = threadIdx.x;
+
+  for (int i = tid; i < SLOTS; i += AG_THREADS)
+    cnt[i] = 0;
+  for (int i = tid; i < AG_HB; i += AG_THREADS)
+    lhist[i] = 0;
+  if (tid == 0) { sh_claimed = 0; sh_ovf = 0; }
+  u64 my_max = 0;
+  u32 my_distinct = 0, my_rounds = 0;
+  u32 kmask[KW];                                // key bytes of each record dword (pad and weight off)
+#pragma unroll
+  for (int w = 0; w < KW; w++)
+    kmask[w] = (4 * w + 4 <= kbytes) ? 0xffffffffu : (4 * w < kbytes) ? ((1u << (8 * (kbytes - 4 * w))) - 1u) : 0u;
+  __syncthreads();
+
+  for (;;)
+    { if (tid == 0)
+        sh_bin = (u32) atomicAdd(&scal[4], 1ull);
+      __syncthreads();
+      const u32 bin = sh_bin;
+      __syncthreads();
+      if (bin >= AG_BINS)
+        break;
+      const int64_t beg = (int64_t) bounds[bin], end = (int64_t) bounds[bin + 1];
+      if (beg >= end)
+        continue;
+
+      u32 R = 1, r = 0;
+      for (;;)
+        { // ---- insert every record of the bin that this round selects
+          u64 round_max = 0;
+          for (int64_t i0 = beg + tid; i0 < end; i0 += (int64_t) AG_THREADS * AG_UNROLL)
+            { if (*(volatile u32 *) &sh_ovf)
+                break;
+              u32 rec[AG_UNROLL][KW];
+#pragma unroll
+              for (int u = 0; u < AG_UNROLL; u++)
+                { const int64_t i = i0 + (int64_t) u * AG_THREADS;
+                  const int64_t j = (i < end) ? i : beg;
+#pragma unroll
+                  for (int w = 0; w < KW; w++)
+                    rec[u][w] = recs[j * KW + w];
+                }
+#pragma unroll
+              for (int u = 0; u < AG_UNROLL; u++)
+                { const int64_t i = i0 + (int64_t) u * AG_THREADS;
+                  if (i >= end)
+                    break;
+                  u32 ha, hb;
+                  fk_rec_hash<KW>(rec[u], kbytes, ha, hb);
+                  if (((hb >> 16) & (R - 1)) != r)
+                    continue;
+                  if (*(volatile u32 *) &sh_ovf)
+                    break;
+                  const u32 wgt = rec[u][KW - 1] >> 16;
+#pragma unroll
+                  for (int w = 0; w < KW; w++)
+                    rec[u][w] &= kmask[w];
+                  u32 slot = ha & (SLOTS - 1);
+                  for (;;)
+                    { const u32 c = atomicCAS(&cnt[slot], 0u, AG_LOCK);
+                      if (c == 0u)
+                        { // empty: the slot is ours, write the key, then publish the count
+#pragma unroll
+                          for (int w = 0; w < KW; w++)
+                            key[w * SLOTS + slot] = rec[u][w];
+                          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                          atomicExch(&cnt[slot], wgt);
+                          if (atomicAdd(&sh_claimed, 1u) >= (u32) LIMIT)
+                            sh_ovf = 1;
+                          break;
+                        }
+                      if (c == AG_LOCK)
+                        continue;                          // being written by another lane: look again
+                      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                      bool same = true;
+#pragma unroll
+                      for (int w = 0; w < KW; w++)
+                        same = same && (key[w * SLOTS + slot] == rec[u][w]);
+                      if (same)
+                        { const u32 old = atomicAdd(&cnt[slot], wgt);
+                          if (old < AG_HIGH && old + wgt >= AG_HIGH)
+                            { atomicSub(&cnt[slot], AG_CUT);   // stays far above 0x7fff: still saturated
+                              round_max += AG_CUT;
+                            }
+                          break;
+                        }
+                      slot = (slot + 1) & (SLOTS - 1);
+                    }
+                }
+            }
+          __syncthreads();
+          const bool ovf = (sh_ovf != 0);
+          __syncthreads();
+          if (ovf)
+            { // more distinct k-mers than the table takes: halve the selection and start it again
+              for (int i = tid; i < SLOTS; i += AG_THREADS)
+                cnt[i] = 0;
+              if (tid == 0) { sh_claimed = 0; sh_ovf = 0; }
+              my_rounds += (tid == 0);
+              __syncthreads();
+              if (R >= AG_MAXR)
+                { if (tid == 0)
+                    atomicAdd(&scal[3], 1ull);
+                  break;
+                }
+              R <<= 1;
+              continue;
+            }
+
+          // ---- emit: histogram, totals, table entries; the table is left empty
+          my_max += round_max;
+          u32 c[SLOTS / AG_THREADS];
+          u32 nq = 0;
+#pragma unroll
+          for (int j = 0; j < SLOTS / AG_THREADS; j++)
+            { const int slot = j * AG_THREADS + tid;
+              const u32 v = cnt[slot];
+              cnt[slot] = 0;
+              c[j] = v;
+              if (v != 0)
+                { my_distinct += 1;
+                  u32 cc = v;
+                  if (v >= 0x7fffu)
+                    { my_max += v;
+                      cc = 0x7fffu;
+                    }
+                  if (cc < AG_HB) atomicAdd(&lhist[cc], 1u);
+                  else            atomicAdd(&hist_g[cc], 1ull);
+                  c[j] = cc;
+                  if (cutoff > 0 && (int) cc >= cutoff)
+                    nq += 1;
+                  else
+                    c[j] = 0;
+                }
+            }
+          if (cutoff > 0)
+            { u32 tot;
+              const u32 off = ag_block_exscan(nq, sh_tmp, &tot);
+              if (tid == 0 && tot > 0)
+                sh_base = atomicAdd(&scal[2], (u64) tot);
+              __syncthreads();
+              if (tot > 0)
+                { u64 o = sh_base + off;
+#pragma unroll
+                  for (int j = 0; j < SLOTS / AG_THREADS; j++)
+                    if (c[j] != 0)
+                      { const int slot = j * AG_THREADS + tid;
+#pragma unroll
+                        for (int w = 0; w < KW - 1; w++)
+                          table[o * KW + w] = key[w * SLOTS + slot];
+                        table[o * KW + KW - 1] = key[(KW - 1) * SLOTS + slot] | (c[j] << 16);
+                        o += 1;
+                      }
+                }
+            }
+          if (tid == 0) sh_claimed = 0;
+          __syncthreads();
+
+          // ---- next selection: sibling, or up
+          while (R > 1 && r >= (R >> 1))
+            { r -= (R >> 1);
+              R >>= 1;
+            }
+          if (R == 1)
+            break;
+          r += (R >> 1);
+        }
+    }
+
+  // flush the private histogram and the per-thread totals
+  __syncthreads();
+  for (int i = tid; i < AG_HB; i += AG_THREADS)
+    if (lhist[i] != 0)
+      atomicAdd(&hist_g[i], (u64) lhist[i]);
+  u64 d = my_distinct, rd = my_rounds;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+    { my_max += __shfl_down(my_max, o, 64);
+      d      += __shfl_down(d, o, 64);
+      rd     += __shfl_down(rd, o, 64);
+    }
+  if (fk_lane() == 0)
+    { if (my_max) atomicAdd(&scal[0], my_max);
+      if (d)      atomicAdd(&scal[1], d);
+      if (rd)     atomicAdd(&scal[5], rd);
+    }
+}
+
+template <int KW>
+static int aggr_t(fk_ctx *ctx, const void *d_grouped, int64_t n, int cutoff, int64_t *hist,
+                  int64_t *max_inst, int64_t *ndistinct, void *d_table, int64_t cap, int64_t *ntable)
+{ hipStream_t s = ctx->stream;
+  if (ntable) *ntable = 0;
+  if (ndistinct) *ndistinct = 0;
+  if (n == 0)
+    return (FK_OK);
+  if (cutoff > 0 && (d_table == NULL || cap < n))
+    { fk_set_error(ctx, "aggregate: the table buffer must take as many records as the input (%lld)",
+                   (long long) n);
+      return (FK_EINVAL);
+    }
+  u64 *d_bounds = (u64 *) fk_slot(ctx, FK_SLOT_AG_BOUNDS, (AG_BINS + 1) * 8);
+  u64 *d_hist   = (u64 *) fk_slot(ctx, FK_SLOT_CT_HIST, (FK_HIST_BINS + 8) * 8);
+  if (d_bounds == NULL || d_hist == NULL)
+    return (FK_ENOMEM);
+  u64 *d_scal = d_hist + FK_HIST_BINS;
+  static bool attr_set[8] = { false };
+  const size_t lds = AgCfg<KW>::LDS;
+  if (!attr_set[KW])
+    { auto kern = k_ag_count<KW>;
+      FK_HIP(ctx, hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+      attr_set[KW] = true;
+    }
+  FK_HIP(ctx, hipMemsetAsync(d_hist, 0, (FK_HIST_BINS + 8) * 8, s));
+  hipLaunchKernelGGL(k_ag_bounds<KW>, dim3(AG_BINS / 256 + 1), dim3(256), 0, s, (const u32 *) d_grouped, n,
+                     ctx->wid.kmer_bytes, d_bounds);
+  const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
+  const int limit = (ctx->dbg_aggr_limit > 0 && ctx->dbg_aggr_limit < AgCfg<KW>::LIMIT) ? ctx->dbg_aggr_limit
+                                                                                        : AgCfg<KW>::LIMIT;
+  hipLaunchKernelGGL(k_ag_count<KW>, dim3((unsigned) cus), dim3(AG_THREADS), lds, s, (const u32 *) d_grouped,
+                     (const u64 *) d_bounds, ctx->wid.kmer_bytes, cutoff, d_hist, d_scal, (u32 *) d_table, limit);
+  FK_LAUNCH_CHECK(ctx);
+  u64 *h = ctx->h_scratch;                       // pinned, 64 KB + 64 KB: the histogram needs 256 KB
+  u64 *hh = (u64 *) malloc((FK_HIST_BINS + 8) * 8);
+  if (hh == NULL) return (FK_ENOMEM);
+  (void) h;
+  if (hipMemcpyAsync(hh, d_hist, (FK_HIST_BINS + 8) * 8, hipMemcpyDeviceToHost, s) != hipSuccess
+      || hipStreamSynchronize(s) != hipSuccess)
+    { free(hh);
+      fk_set_error(ctx, "aggregate: HIP failure: %s", hipGetErrorString(hipGetLastError()));
+      return (FK_EHIP);
+    }
+  if (hh[FK_HIST_BINS + 3] != 0)
+    { free(hh);
+      return (FK_ESTATE);                          // a bin did not fit even in AG_MAXR rounds
+    }
+  for (int i = 1; i < FK_HIST_BINS; i++)
+    hist[i] += (int64_t) hh[i];
+  *max_inst += (int64_t) hh[FK_HIST_BINS + 0];
+  if (ndistinct) *ndistinct = (int64_t) hh[FK_HIST_BINS + 1];
+  if (ntable) *ntable = (int64_t) hh[FK_HIST_BINS + 2];
+  ctx->aggr_extra_rounds = (int64_t) hh[FK_HIST_BINS + 5];
+  free(hh);
+  return (FK_OK);
+}
+
+/* d_grouped: n weighted k-mer records ordered by the low 16 bits of fk_rec_hash's b word (the
+   result of fkx_group(..., key_bytes = KMER_BYTES, npasses = 2)).  Adds the histogram of their
+   counts into hist[1..0x7fff] and the instances of saturated k-mers into *max_inst; with cutoff > 0
+   writes the (k-mer, count) records with count >= cutoff to d_table IN NO PARTICULAR ORDER.
+   FK_ESTATE: some bin holds more distinct k-mers than AG_MAXR rounds of the LDS table take. */
+int fkx_aggregate(fk_ctx *ctx, const void *d_grouped, int64_t n, int cutoff, int64_t *hist,
+                  int64_t *max_inst, int64_t *ndistinct, void *d_table, int64_t cap, int64_t *ntable)
+{ switch (ctx->wid.kmer_stride >> 2)
+  { case 1: return aggr_t<1>(ctx, d_grouped, n, cutoff, hist, max_inst, ndistinct, d_table, cap, ntable);
+    case 2: return aggr_t<2>(ctx, d_grouped, n, cutoff, hist, max_inst, ndistinct, d_table, cap, ntable);
+    case 3: return aggr_t<3>(ctx, d_grouped, n, cutoff, hist, max_inst, ndistinct, d_table, cap, ntable);
+    case 4: return aggr_t<4>(ctx, d_grouped, n, cutoff, hist, max_inst, ndistinct, d_table, cap, ntable);
+    case 5: return aggr_t<5>(ctx, d_grouped, n, cutoff, hist, max_inst, ndistinct, d_table, cap, ntable);
+    default:
+      fk_set_error(ctx, "k-mer stride %d not built", ctx->wid.kmer_stride);
+      return (FK_EUNSUPPORTED);
+  }
+}

@@ -145,12 +145,14 @@ extern "C" int fk_create(const fk_params *p, fk_ctx **out)
       return (FK_ENODEVICE);
     }
   { hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess
-        && strstr(prop.gcnArchName, "gfx950") == NULL)
-      { fk_set_error(NULL, "fk_create: device %d is %s; this library is built for gfx950 only",
-                     ctx->device, prop.gcnArchName);
-        free(ctx);
-        return (FK_ENODEVICE);
+    if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess)
+      { if (strstr(prop.gcnArchName, "gfx950") == NULL)
+          { fk_set_error(NULL, "fk_create: device %d is %s; this library is built for gfx950 only",
+                         ctx->device, prop.gcnArchName);
+            free(ctx);
+            return (FK_ENODEVICE);
+          }
+        ctx->num_cus = prop.multiProcessorCount;
       }
   }
 #define CK(call) do { if ((call) != hipSuccess) { fk_set_error(NULL, "fk_create: %s failed", #call); \
@@ -272,6 +274,23 @@ extern "C" int fk_debug_set(fk_ctx *ctx, const char *key, int64_t value)
     }
   if (strcmp(key, "radix_items") == 0)
     { ctx->dbg_radix_items = (int) value;
+      return (FK_OK);
+    }
+  if (strcmp(key, "aggr_limit") == 0)
+    { ctx->dbg_aggr_limit = (int) value;
+      return (FK_OK);
+    }
+  if (strcmp(key, "kmer_stage") == 0)       // 1: sort / collapse / sort instead of hash aggregation
+    { ctx->dbg_kmer_stage = (int) value;
+      return (FK_OK);
+    }
+  return (FK_EINVAL);
+}
+
+extern "C" int fk_debug_get(fk_ctx *ctx, const char *key, int64_t *value)
+{ if (ctx == NULL || key == NULL || value == NULL) return (FK_EINVAL);
+  if (strcmp(key, "aggr_extra_rounds") == 0)
+    { *value = ctx->aggr_extra_rounds;
       return (FK_OK);
     }
   return (FK_EINVAL);
@@ -438,6 +457,34 @@ extern "C" int fk_count_presorted_kmers(fk_ctx *ctx, const void *d_kmers, int64_
     sorted_bytes = ctx->wid.kmer_bytes;
   return fkx_count(ctx, d_kmers, nweighted, cutoff, sorted_bytes, hist, max_inst, ndistinct, d_table,
                    cap, ntable);
+}
+
+extern "C" int fk_count_unsorted_kmers(fk_ctx *ctx, void *d_kmers, void *d_tmp, int64_t nweighted,
+                                       int cutoff, int64_t *hist, int64_t *max_inst, int64_t *ndistinct,
+                                       void **d_table, int64_t *ntable)
+{ if (ctx == NULL || hist == NULL || max_inst == NULL || nweighted < 0) return (FK_EINVAL);
+  if (nweighted > 0 && (d_kmers == NULL || d_tmp == NULL)) return (FK_EINVAL);
+  if (cutoff > 0 && (d_table == NULL || ntable == NULL)) return (FK_EINVAL);
+  const fk_widths &w = ctx->wid;
+  void *grouped = d_kmers;
+  int rc = fkx_group(ctx, nweighted, d_kmers, d_tmp, w.kmer_stride, w.kmer_bytes, 2, &grouped);
+  if (rc != FK_OK) return (rc);
+  void *tbuf = (grouped == d_kmers) ? d_tmp : d_kmers;
+  int64_t nt = 0;
+  rc = fkx_aggregate(ctx, grouped, nweighted, cutoff, hist, max_inst, ndistinct,
+                     cutoff > 0 ? tbuf : NULL, nweighted, &nt);
+  if (rc != FK_OK) return (rc);
+  if (cutoff > 0)
+    { int bytes[64];
+      for (int i = 0; i < w.kmer_bytes; i++)
+        bytes[i] = w.kmer_bytes - 1 - i;
+      void *sorted = tbuf;
+      if (nt > 0 && (rc = fkx_lsd_sort(ctx, nt, tbuf, grouped, w.kmer_stride, bytes, w.kmer_bytes, &sorted)) != FK_OK)
+        return (rc);
+      *d_table = sorted;
+      *ntable = nt;
+    }
+  return (FK_OK);
 }
 
 // ---- streaming interface ------------------------------------------------------------------------
@@ -676,15 +723,68 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
         break;
       hipEventRecord(ev[3], s);
 
-      // weighted k-mer stage.  The reference runs all KMER_BYTES digit passes over the W weighted
-      // records (MSDsort.c:536).  Here the LSD sort is interrupted after the FK_LOW_BYTES least
+      // weighted k-mer stage.  The reference sorts the W weighted records on KMER_BYTES and scans the
+      // result (MSDsort.c:536, 491-509).  Only the table has to come out in k-mer order, so here two
+      // hashed digit passes bring all copies of a k-mer into one of 65,536 bins, one workgroup per bin
+      // sums them in an LDS hash table (fk_aggr.hip: histogram, max_inst, table candidates), and only
+      // the table records (count >= cutoff) are sorted on KMER_BYTES.  fk_debug_set("kmer_stage",1)
+      // or a bin that does not fit selects the sort / collapse / sort path below instead.
+      void *km_sorted = km_a;
+      int   sorted_bytes = w.kmer_bytes;
+      int64_t nc = nw, ovf2 = 0;
+      int64_t nt = 0, ndk = 0;
+      const int cutoff = ctx->prm.table_cutoff;
+      void *other = NULL;
+      bool  aggregated = false;
+      float ms_aggr = 0.f;
+      if (nw > 0 && (km_b = fk_slot(ctx, FK_SLOT_KM_B, nw * w.kmer_stride)) == NULL)
+        { rc = FK_ENOMEM; break; }
+      if (nw > 0 && ctx->dbg_kmer_stage != 1)
+        { void *grouped = km_a;
+          if ((rc = fkx_group(ctx, nw, km_a, km_b, w.kmer_stride, w.kmer_bytes, 2, &grouped)) != FK_OK)
+            break;
+          res->passes_kmer  = ctx->sort_stats.passes;
+          res->ms_pass_kmer = ctx->sort_stats.pass_ms_total;
+          res->ms_scatter_kmer = ctx->sort_stats.scatter_ms_total;
+          void *tbuf = (grouped == km_a) ? km_b : km_a;
+          hipEventRecord(ctx->ev0, s);
+          rc = fkx_aggregate(ctx, grouped, nw, cutoff, res->hist, &res->max_inst, &ndk,
+                             cutoff > 0 ? tbuf : NULL, nw, &nt);     // adds to hist only on success
+          hipEventRecord(ctx->ev1, s);
+          if (rc == FK_OK)
+            { aggregated = true;
+              hipEventSynchronize(ctx->ev1);
+              hipEventElapsedTime(&ms_aggr, ctx->ev0, ctx->ev1);
+              other = tbuf;
+              res->ncollapsed = nt;
+              if (cutoff > 0 && nt > 0)
+                { int bytes[64];
+                  for (int i = 0; i < w.kmer_bytes; i++)
+                    bytes[i] = w.kmer_bytes - 1 - i;
+                  void *sorted = tbuf;
+                  if ((rc = fkx_lsd_sort(ctx, nt, tbuf, grouped, w.kmer_stride, bytes, w.kmer_bytes, &sorted)) != FK_OK)
+                    break;
+                  res->passes_final  = ctx->sort_stats.passes;
+                  res->ms_pass_final = ctx->sort_stats.pass_ms_total;
+                  other = sorted;
+                  for (int x = 0; x < 256; x++)
+                    res->wfirst[x] = (h_roff != NULL) ? exact_census[x] : (int64_t) ctx->h_scratch[x];
+                }
+            }
+          else if (rc == FK_ESTATE)
+            { km_a = grouped; km_b = tbuf;               // all records are still there, in another order
+              rc = FK_OK;
+            }
+          else
+            break;
+        }
+      if (!aggregated)
+      {
+      // The LSD sort over the W weighted records is interrupted after the FK_LOW_BYTES least
       // significant key bytes: equal k-mers that are adjacent by then are collapsed into one record
       // (weights summed, clipped like count.c:455-458) -- the collapse keeps the order, so the
       // remaining passes simply continue the same LSD sort on ~3x fewer records.  k-mers that were
       // not adjacent yet meet at the end and are summed by the count kernel.
-      void *km_sorted = km_a;
-      int   sorted_bytes = w.kmer_bytes;
-      int64_t nc = nw, ovf2 = 0;
       if (nw > 0)
         { if ((km_b = fk_slot(ctx, FK_SLOT_KM_B, nw * w.kmer_stride)) == NULL)
             { rc = FK_ENOMEM; break; }
@@ -725,9 +825,8 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
       hipEventRecord(ev[4], s);
 
       // count + table: the idle half of the k-mer ping-pong pair receives the table
-      int64_t nt = 0, ndk = 0;
-      const int cutoff = ctx->prm.table_cutoff;
-      void *other = (km_sorted == km_a) ? km_b : km_a;
+      km_sorted = (km_sorted == NULL) ? km_a : km_sorted;
+      other = (km_sorted == km_a) ? km_b : km_a;
       rc = fkx_count(ctx, km_sorted, nc, cutoff, sorted_bytes, res->hist, &res->max_inst, &ndk,
                      cutoff > 0 ? other : NULL, nc, &nt);
       if (rc == FK_ESTATE)
@@ -746,6 +845,9 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
           rc = fkx_count(ctx, km_sorted, nw, cutoff, w.kmer_bytes, res->hist, &res->max_inst, &ndk,
                          cutoff > 0 ? other : NULL, nw, &nt);
         }
+      }
+      else
+        hipEventRecord(ev[4], s);
       if (rc != FK_OK)
         break;
       res->max_inst += ovf + ovf2;                           // count.c:1551
@@ -788,8 +890,8 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
       res->ms_split      = ms_between(ev[0], ev[1]);
       res->ms_sort_super = ms_between(ev[1], ev[2]);
       res->ms_expand     = ms_between(ev[2], ev[3]);
-      res->ms_sort_kmer  = ms_between(ev[3], ev[4]);
-      res->ms_count      = ms_between(ev[4], ev[5]);
+      res->ms_sort_kmer  = ms_between(ev[3], ev[4]) - ms_aggr;     // radix passes (grouping + table sort)
+      res->ms_count      = ms_between(ev[4], ev[5]) + ms_aggr;
       res->ms_total      = ms_between(ev[0], ev[5]);
     }
   while (0);

@@ -62,13 +62,17 @@ struct fk_ctx
   int        dbg_radix_variant;   // measurement aids, see fk_debug_set
   int        dbg_radix_items;
   int        dbg_radix_engine;    // 1 = look-back engine instead of the stream engine
+  int        dbg_kmer_stage;      // 1 = sort-collapse-sort k-mer stage instead of hash aggregation
+  int        dbg_aggr_limit;      // > 0: pretend the LDS table of fk_aggr.hip takes only this many k-mers
+  int64_t    aggr_extra_rounds;   // bins x rounds that had to be split in the last aggregation
+  int        num_cus;
   void      *slot_ptr[FK_NSLOTS];
   int64_t    slot_cap[FK_NSLOTS];
 };
 
 enum { FK_SLOT_SM_A = 0, FK_SLOT_SM_B, FK_SLOT_KM_A, FK_SLOT_KM_B, FK_SLOT_EX_HEADS, FK_SLOT_EX_KMERS,
        FK_SLOT_EX_KOFF, FK_SLOT_CT_ENT, FK_SLOT_CT_OFF, FK_SLOT_CT_HIST, FK_SLOT_DIG_A, FK_SLOT_DIG_B,
-       FK_SLOT_RX_TILE, FK_SLOT_RX_CHUNK, FK_SLOT_RX_SUPER, FK_SLOT_ROFF };
+       FK_SLOT_RX_TILE, FK_SLOT_RX_CHUNK, FK_SLOT_RX_SUPER, FK_SLOT_ROFF, FK_SLOT_AG_BOUNDS };
 
 // returns a device buffer of at least nbytes for the given purpose (NULL + error set on failure)
 void *fk_slot(fk_ctx *ctx, int slot, int64_t nbytes);
@@ -110,6 +114,8 @@ int fkx_count(fk_ctx *ctx, const void *d_kmers, int64_t nweighted, int cutoff, i
               void *d_table, int64_t cap, int64_t *ntable);
 int fkx_collapse(fk_ctx *ctx, const void *d_kmers, int64_t n, void *d_out, int64_t cap,
                  int64_t *nout, int64_t *overflow);
+int fkx_aggregate(fk_ctx *ctx, const void *d_grouped, int64_t n, int cutoff, int64_t *hist,
+                  int64_t *max_inst, int64_t *ndistinct, void *d_table, int64_t cap, int64_t *ntable);
 int fkx_synth(fk_ctx *ctx, uint64_t seed, uint64_t genome_len, uint32_t read_len,
               uint32_t err_ppm, uint64_t first_read, int64_t nreads, void *d_bases);
 
@@ -123,6 +129,28 @@ __device__ __forceinline__ u32 fk_lane() { return (threadIdx.x & 63u); }
 __device__ __forceinline__ u64 fk_lanemask_lt()
 { u32 l = fk_lane();
   return (l == 0 ? 0ull : (~0ull >> (64 - l)));
+}
+
+// 64-bit mix (a, b) of the first hbytes bytes of a record of RW dwords: all of a super-mer record;
+// the KMER_BYTES key of a weighted k-mer record, so that equal k-mers with different weights meet.
+// Hashed digit p of the radix engine is byte p of b (p < 4) or byte p-4 of a.
+template <int RW>
+__device__ __forceinline__ void fk_rec_hash(const u32 *r, int hbytes, u32 &a_out, u32 &b_out)
+{ const int full = hbytes >> 2;
+  const u32 last = (hbytes & 3) ? ((1u << (8 * (hbytes & 3))) - 1u) : 0u;
+  u32 a = 0x9E3779B9u, b = 0x85EBCA6Bu;
+#pragma unroll
+  for (int w = 0; w < RW; w++)
+    { const u32 x = (w < full) ? r[w] : (w == full) ? (r[w] & last) : 0u;
+      a = (a ^ x) * 0xCC9E2D51u;
+      a = (a << 15) | (a >> 17);
+      b = (b + x) * 0x1B873593u;
+      b = ((b << 13) | (b >> 19)) ^ a;
+    }
+  a ^= b >> 16; a *= 0x85EBCA6Bu;
+  b ^= a >> 13; b *= 0xC2B2AE35u;
+  a ^= b >> 15;
+  a_out = a; b_out = b;
 }
 
 // exclusive scan of one value per thread over a 256-thread block; returns exclusive prefix,

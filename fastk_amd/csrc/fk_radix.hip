@@ -37,22 +37,8 @@ __device__ __forceinline__ u64 st_pack(u32 epoch, u64 flag, u64 val)
 // byte p of the hash, so five passes make identical records adjacent whatever their width.
 template <int RW>
 __device__ __forceinline__ u32 rx_hash_digit(const u32 *r, int byte_idx, int hbytes)
-{ // only the first hbytes bytes of the record enter the hash (all of a super-mer record; the
-  // KMER_BYTES key of a weighted k-mer record, so that equal k-mers with different weights meet)
-  const int full = hbytes >> 2;
-  const u32 last = (hbytes & 3) ? ((1u << (8 * (hbytes & 3))) - 1u) : 0u;
-  u32 a = 0x9E3779B9u, b = 0x85EBCA6Bu;
-#pragma unroll
-  for (int w = 0; w < RW; w++)
-    { const u32 x = (w < full) ? r[w] : (w == full) ? (r[w] & last) : 0u;
-      a = (a ^ x) * 0xCC9E2D51u;
-      a = (a << 15) | (a >> 17);
-      b = (b + x) * 0x1B873593u;
-      b = ((b << 13) | (b >> 19)) ^ a;
-    }
-  a ^= b >> 16; a *= 0x85EBCA6Bu;
-  b ^= a >> 13; b *= 0xC2B2AE35u;
-  a ^= b >> 15;
+{ u32 a, b;
+  fk_rec_hash<RW>(r, hbytes, a, b);
   const u32 x = (byte_idx < 4) ? b : a;
   return (x >> (8 * (byte_idx & 3))) & 0xffu;
 }

@@ -211,6 +211,18 @@ int fk_count_presorted_kmers(fk_ctx *ctx, const void *d_kmers, int64_t nweighted
                              int sorted_bytes, int64_t *hist, int64_t *max_inst,
                              int64_t *ndistinct, void *d_table, int64_t cap, int64_t *ntable);
 
+/* Count UNSORTED weighted k-mers: Weighted_Kmer_Sort + hist_kmers + table_write_thread in one call
+   (MSDsort.c:536-544, 491-509, count.c:564-616) without sorting the list -- two hashed digit
+   passes bring equal k-mers into one of 65,536 bins, a workgroup per bin sums them in an LDS hash
+   table, and only the table records (count >= cutoff) are sorted on KMER_BYTES.  d_kmers and
+   d_tmp (nweighted records each) are both clobbered; *d_table (when cutoff > 0) points into one of
+   them, *ntable records in k-mer order.  hist and *max_inst are ACCUMULATED.  Returns FK_ESTATE,
+   with nothing accumulated and all records still present in d_kmers/d_tmp order-scrambled, in the
+   (never observed) case that a bin's distinct k-mers do not fit 64 rounds of the LDS table. */
+int fk_count_unsorted_kmers(fk_ctx *ctx, void *d_kmers, void *d_tmp, int64_t nweighted, int cutoff,
+                            int64_t *hist, int64_t *max_inst, int64_t *ndistinct, void **d_table,
+                            int64_t *ntable);
+
 /* ---- utilities ---------------------------------------------------------------------------*/
 
 /* Fill d_bases with synthetic reads first_read .. first_read+nreads-1 of include/fk_synth.h,
@@ -238,6 +250,8 @@ int fk_get_sort_stats(fk_ctx *ctx, fk_sort_stats *st);
 /* Measurement aid for profiles/: selects ablated kernel variants; results are
    invalid while a non-zero variant is set.  The product path never calls it. */
 int fk_debug_set(fk_ctx *ctx, const char *key, int64_t value);
+/* Reads back a counter of the last run ("aggr_extra_rounds": bin rounds that had to be split). */
+int fk_debug_get(fk_ctx *ctx, const char *key, int64_t *value);
 
 const char *fk_version(void);
 

@@ -166,6 +166,56 @@ def test_count_bit_exact(name):
     util.check_against_golden(case, hist, mi + ovf, tab)
 
 
+@pytest.mark.parametrize("small_table", [False, True])
+@pytest.mark.parametrize("name", util.golden_names())
+def test_count_unsorted_bit_exact(name, small_table):
+    """fk_count_unsorted_kmers (hash grouping + LDS aggregation + table sort) on the weighted k-mer
+    list in RANDOM order reproduces the reference's histogram and table.  small_table shrinks the
+    LDS table to eight k-mers so that bins must be split into rounds."""
+    case, bases, boff = util.load_case(name)
+    k, cutoff = case["k"], case["cutoff"]
+    P = orc.params(k)
+    smers, _ = orc.distribute(P, bases, boff)
+    kl, ovf, _ = orc.kmer_list(P, orc.msd_sort(smers, P.smer_word))
+    kl = kl[np.random.default_rng(11).permutation(len(kl))]
+    with fastk_amd.Context(kmer=k, table_cutoff=cutoff) as ctx:
+        w = ctx.w
+        dev = _pad_kmers(kl, w.kmer_bytes, w.kmer_stride)
+        a = ctx.alloc(max(dev.nbytes, 16)).upload(dev)
+        t = ctx.alloc(max(dev.nbytes, 16))
+        distinct = len(np.unique(kl[:, :P.kmer_bytes], axis=0)) if len(kl) else 0
+        limit = 8 if small_table else 0
+        ctx.debug_set("aggr_limit", limit)
+        hist, mi, nd, nt, tp = ctx.count_unsorted(a.ptr, t.ptr, len(kl), cutoff)
+        if small_table and distinct > 65536 * 6:
+            assert ctx.debug_get("aggr_extra_rounds") > 0
+        assert nd == distinct
+        tab = _unpad_kmers(a.download(nt * w.kmer_stride, ptr=tp).reshape(nt, w.kmer_stride),
+                           w.kmer_bytes)
+    assert nd == int(hist.sum())
+    util.check_against_golden(case, hist, mi + ovf, tab)
+
+
+def test_count_unsorted_exact_max_inst_for_huge_counts(ctx40):
+    """One k-mer with 100,000 records of weight 0x7fff (3.3e9 instances, beyond 32 bits) next to
+    ordinary ones: the count saturates at 0x7fff and max_inst is exact (MSDsort.c:498-506)."""
+    rng = np.random.default_rng(4)
+    n_hot, n_cold = 100000, 5000
+    recs = np.zeros((n_hot + n_cold, 12), dtype=np.uint8)
+    recs[:n_hot, :10] = 0x5a
+    recs[:n_hot, 10:] = np.frombuffer(np.uint16(0x7fff).tobytes(), dtype=np.uint8)
+    recs[n_hot:, :10] = rng.integers(0, 256, size=(n_cold, 10))
+    recs[n_hot:, 10] = 2
+    recs = recs[rng.permutation(len(recs))]
+    a = ctx40.alloc(recs.nbytes).upload(recs)
+    t = ctx40.alloc(recs.nbytes)
+    hist, mi, nd, nt, tp = ctx40.count_unsorted(a.ptr, t.ptr, len(recs), 1)
+    assert nd == n_cold + 1 and nt == nd
+    assert hist[0x7fff] == 1 and hist[2] == n_cold
+    assert mi == n_hot * 0x7fff
+    a.free(); t.free()
+
+
 # ------------------------------------------------------------------------------ whole path
 
 @pytest.mark.parametrize("name", util.golden_names())
@@ -190,6 +240,18 @@ def test_pipeline_matches_reference_golden(name, tmp_path):
     assert t["stream_sha256"] == exp["ktab"]["stream_sha256"]
     assert (t["kmer"], t["nparts"], t["minval"], t["ibytes"], t["nels"]) == \
         (k, case["T"], case["cutoff"], exp["ktab"]["ibytes"], exp["ktab"]["nels"])
+
+
+@pytest.mark.parametrize("name", ["synth_illumina_k40_t1_T4", "edge_k51_t1_T4"])
+def test_pipeline_sort_collapse_path_matches_golden(name):
+    """fk_debug_set("kmer_stage", 1): the sort / collapse / sort k-mer stage (the fallback of the
+    hash-aggregation stage) gives the same result."""
+    case, bases, boff = util.load_case(name)
+    with fastk_amd.Context(kmer=case["k"], table_cutoff=case["cutoff"], nthreads=case["T"]) as ctx:
+        ctx.debug_set("kmer_stage", 1)
+        ctx.push_block(bases, boff.astype(np.int32))
+        res = ctx.finish()
+        util.check_against_golden(case, res.hist, res.max_inst, res.table)
 
 
 def test_empty_and_degenerate_inputs():
