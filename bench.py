@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-shard", action="store_true",
                     help="run the sharded (all-to-all) path even on one GPU: exercises RCCL + shard.py")
+    ap.add_argument("--debug", action="append", default=[], metavar="KEY=VALUE",
+                    help="fk_debug_set knob for ablation runs (results may be invalid)")
     return ap.parse_args()
 
 
@@ -126,6 +128,9 @@ def main():
     ctx = fastk_amd.Context(kmer=args.kmer, table_cutoff=1, nthreads=4, device=local_rank,
                             nbuckets=world)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    for kv in args.debug:
+        key, val = kv.split("=")
+        ctx.debug_set(key, int(val))
     reads = torch.empty(nbytes + 64, dtype=torch.uint8, device=dev)
     ctx._ck(ctx.L.fk_synth_reads(ctx.h, args.seed, glen, L, args.err_ppm, first, per,
                                  reads.data_ptr()))

@@ -21,13 +21,13 @@
 #define AG_CUT     (1u << 28)           //   removed instances go straight to max_inst
 #define AG_MAXR    64
 #define AG_BINS    65536
-#define AG_UNROLL  4
+#define AG_UNROLL  8
 
 template <int KW> struct AgCfg
 { static constexpr int SLOTS = (KW <= 3) ? 8192 : 4096;
   static constexpr int LIMIT = (SLOTS * 3 / 4 < SLOTS - AG_THREADS - 64) ? SLOTS * 3 / 4
                                                                          : SLOTS - AG_THREADS - 64;
-  static constexpr size_t LDS = (size_t) SLOTS * (KW + 1) * 4 + AG_HB * 4;
+  static constexpr size_t LDS = (size_t) SLOTS * (KW > 3 ? 32 : 16) + AG_HB * 4;
 };
 
 // position of the first record of every bin: bounds[b] = lower bound of (hash16 >= b), bounds[65536] = n
@@ -78,23 +78,30 @@ __device__ __forceinline__ u32 ag_block_exscan(u32 v, u32 *tmp, u32 *total)
 
 // scal: [0] max_inst  [1] distinct k-mers  [2] table entries  [3] failure flag  [4] bin ticket
 //       [5] extra rounds taken
+//
+// LDS table: SLOTS entries of 16 bytes {key dword 0, 1, 2, count word}; records of 4 or 5 dwords keep
+// dwords 3, 4 in a second array.  A lane's aligned 16-byte LDS access is served in one piece, so a
+// single ds_read_b128 yields a consistent (key, count word) pair: count word 0 = empty, AG_LOCK =
+// key being written (its creator stores key + AG_LOCK with one b128 write, then the weight with a
+// b32 write; LDS operations of a wave execute in order), anything else = published count.
 template <int KW>
 __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__ recs,
                                                          const u64 *__restrict__ bounds, int kbytes,
                                                          int cutoff, u64 *__restrict__ hist_g,
                                                          u64 *__restrict__ scal, u32 *__restrict__ table,
-                                                         int LIMIT)
+                                                         int LIMIT, int variant)
 { constexpr int SLOTS = AgCfg<KW>::SLOTS;
-  extern __shared__ u32 ag_lds[];
-  u32 *key   = ag_lds;                          // [KW][SLOTS], dword-major; weight bits cleared
-  u32 *cnt   = ag_lds + (size_t) KW * SLOTS;    // [SLOTS]
-  u32 *lhist = cnt + SLOTS;                     // [AG_HB]
-  __shared__ u32 sh_bin, sh_claimed, sh_ovf, sh_tmp[AG_WAVES];
+  constexpr int U = AG_UNROLL;
+  extern __shared__ uint4 ag_lds[];
+  uint4 *A     = ag_lds;                                   // [SLOTS]
+  uint4 *B     = ag_lds + SLOTS;                           // [SLOTS] when KW > 3
+  u32   *lhist = (u32 *) (ag_lds + (KW > 3 ? 2 : 1) * SLOTS);   // [AG_HB]
+  __shared__ u32 sh_claimed, sh_ovf, sh_tmp[AG_WAVES];
   __shared__ u64 sh_base;
   const int tid = threadIdx.x;
 
   for (int i = tid; i < SLOTS; i += AG_THREADS)
-    cnt[i] = 0;
+    A[i] = make_uint4(0, 0, 0, 0);
   for (int i = tid; i < AG_HB; i += AG_THREADS)
     lhist[i] = 0;
   if (tid == 0) { sh_claimed = 0; sh_ovf = 0; }
@@ -106,15 +113,9 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
     kmask[w] = (4 * w + 4 <= kbytes) ? 0xffffffffu : (4 * w < kbytes) ? ((1u << (8 * (kbytes - 4 * w))) - 1u) : 0u;
   __syncthreads();
 
-  for (;;)
-    { if (tid == 0)
-        sh_bin = (u32) atomicAdd(&scal[4], 1ull);
-      __syncthreads();
-      const u32 bin = sh_bin;
-      __syncthreads();
-      if (bin >= AG_BINS)
-        break;
-      const int64_t beg = (int64_t) bounds[bin], end = (int64_t) bounds[bin + 1];
+  // bins are dealt round-robin: hashing makes them equally heavy
+  for (u32 bin = blockIdx.x; bin < AG_BINS; bin += gridDim.x)
+    { const int64_t beg = (int64_t) bounds[bin], end = (int64_t) bounds[bin + 1];
       if (beg >= end)
         continue;
 
@@ -122,63 +123,102 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
       for (;;)
         { // ---- insert every record of the bin that this round selects
           u64 round_max = 0;
-          for (int64_t i0 = beg + tid; i0 < end; i0 += (int64_t) AG_THREADS * AG_UNROLL)
+          for (int64_t i0 = beg + tid; i0 < end; i0 += (int64_t) AG_THREADS * U)
             { if (*(volatile u32 *) &sh_ovf)
                 break;
-              u32 rec[AG_UNROLL][KW];
+              u32 rec[U][KW];
 #pragma unroll
-              for (int u = 0; u < AG_UNROLL; u++)
+              for (int u = 0; u < U; u++)
                 { const int64_t i = i0 + (int64_t) u * AG_THREADS;
                   const int64_t j = (i < end) ? i : beg;
 #pragma unroll
                   for (int w = 0; w < KW; w++)
                     rec[u][w] = recs[j * KW + w];
                 }
+              u32 slot0[U];
+              u32 pend = 0;
 #pragma unroll
-              for (int u = 0; u < AG_UNROLL; u++)
+              for (int u = 0; u < U; u++)
                 { const int64_t i = i0 + (int64_t) u * AG_THREADS;
-                  if (i >= end)
-                    break;
                   u32 ha, hb;
                   fk_rec_hash<KW>(rec[u], kbytes, ha, hb);
-                  if (((hb >> 16) & (R - 1)) != r)
-                    continue;
-                  if (*(volatile u32 *) &sh_ovf)
-                    break;
-                  const u32 wgt = rec[u][KW - 1] >> 16;
+                  slot0[u] = ha & (SLOTS - 1);
+                  if (i < end && ((hb >> 16) & (R - 1)) == r)
+                    pend |= (1u << u);
+                }
+              if (variant & 1)
+                { round_max += pend + slot0[0];
+                  continue;
+                }
+
+              // every lane walks through its own records, one probe per trip: a lane whose record
+              // is done takes its next one at once instead of idling until the slowest lane of the
+              // wave is through (probe counts differ a lot between lanes)
+              u32  cur[KW], wgt = 0, slot = 0;
+              bool have = false;
+              for (;;)
+                { if (!have)
+                    { if (pend == 0 || *(volatile u32 *) &sh_ovf)
+                        break;
+                      const int u = __ffs((int) pend) - 1;
+                      pend &= pend - 1;
 #pragma unroll
-                  for (int w = 0; w < KW; w++)
-                    rec[u][w] &= kmask[w];
-                  u32 slot = ha & (SLOTS - 1);
-                  for (;;)
-                    { const u32 c = atomicCAS(&cnt[slot], 0u, AG_LOCK);
-                      if (c == 0u)
-                        { // empty: the slot is ours, write the key, then publish the count
+                      for (int x = 0; x < U; x++)
+                        if (x == u)
+                          { slot = slot0[x];
+                            wgt  = rec[x][KW - 1] >> 16;
 #pragma unroll
-                          for (int w = 0; w < KW; w++)
-                            key[w * SLOTS + slot] = rec[u][w];
+                            for (int w = 0; w < KW; w++)
+                              cur[w] = rec[x][w] & kmask[w];
+                          }
+                      have = true;
+                    }
+                  const uint4 v = A[slot];
+                  const u32   c = v.w;
+                  bool created = false;
+                  if (c == 0u)
+                    { if (atomicCAS(&A[slot].w, 0u, AG_LOCK) == 0u)
+                        { A[slot] = make_uint4(cur[0], KW > 1 ? cur[KW > 1 ? 1 : 0] : 0u,
+                                               KW > 2 ? cur[KW > 2 ? 2 : 0] : 0u, AG_LOCK);
+                          if (KW > 3)
+                            B[slot] = make_uint4(cur[KW > 3 ? 3 : 0], KW > 4 ? cur[KW > 4 ? 4 : 0] : 0u, 0u, 0u);
                           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                          atomicExch(&cnt[slot], wgt);
-                          if (atomicAdd(&sh_claimed, 1u) >= (u32) LIMIT)
-                            sh_ovf = 1;
-                          break;
+                          *(volatile u32 *) &A[slot].w = wgt;
+                          created = true;
+                          have = false;
                         }
-                      if (c == AG_LOCK)
-                        continue;                          // being written by another lane: look again
-                      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                      bool same = true;
-#pragma unroll
-                      for (int w = 0; w < KW; w++)
-                        same = same && (key[w * SLOTS + slot] == rec[u][w]);
+                      // else: another lane took the slot in between; look at it again
+                    }
+                  else if (c != AG_LOCK)
+                    { bool same = (v.x == cur[0]);
+                      if (KW > 1) same = same && (v.y == cur[KW > 1 ? 1 : 0]);
+                      if (KW > 2) same = same && (v.z == cur[KW > 2 ? 2 : 0]);
+                      if (KW > 3 && same)
+                        { const uint4 b = B[slot];
+                          same = (b.x == cur[KW > 3 ? 3 : 0]);
+                          if (KW > 4) same = same && (b.y == cur[KW > 4 ? 4 : 0]);
+                        }
                       if (same)
-                        { const u32 old = atomicAdd(&cnt[slot], wgt);
-                          if (old < AG_HIGH && old + wgt >= AG_HIGH)
-                            { atomicSub(&cnt[slot], AG_CUT);   // stays far above 0x7fff: still saturated
-                              round_max += AG_CUT;
+                        { if (c < (AG_HIGH >> 1))
+                            atomicAdd(&A[slot].w, wgt);          // no return value needed
+                          else
+                            { const u32 old = atomicAdd(&A[slot].w, wgt);
+                              if (old < AG_HIGH && old + wgt >= AG_HIGH)
+                                { atomicSub(&A[slot].w, AG_CUT);   // stays far above 0x7fff: still saturated
+                                  round_max += AG_CUT;
+                                }
                             }
-                          break;
+                          have = false;
                         }
-                      slot = (slot + 1) & (SLOTS - 1);
+                      else
+                        slot = (slot + 1) & (SLOTS - 1);
+                    }
+                  // c == AG_LOCK: the key is being written by another lane, look again
+                  const u64 cm = __ballot(created);
+                  if (cm != 0ull && fk_lane() == (u32) (__ffsll((long long) cm) - 1))
+                    { const u32 k = (u32) __popcll(cm);
+                      if (atomicAdd(&sh_claimed, k) + k > (u32) LIMIT)
+                        sh_ovf = 1;
                     }
                 }
             }
@@ -188,7 +228,7 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
           if (ovf)
             { // more distinct k-mers than the table takes: halve the selection and start it again
               for (int i = tid; i < SLOTS; i += AG_THREADS)
-                cnt[i] = 0;
+                A[i].w = 0;
               if (tid == 0) { sh_claimed = 0; sh_ovf = 0; }
               my_rounds += (tid == 0);
               __syncthreads();
@@ -208,26 +248,26 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
 #pragma unroll
           for (int j = 0; j < SLOTS / AG_THREADS; j++)
             { const int slot = j * AG_THREADS + tid;
-              const u32 v = cnt[slot];
-              cnt[slot] = 0;
-              c[j] = v;
+              const u32 v = A[slot].w;
+              c[j] = 0;
               if (v != 0)
-                { my_distinct += 1;
+                { A[slot].w = 0;
+                  my_distinct += 1;
                   u32 cc = v;
                   if (v >= 0x7fffu)
                     { my_max += v;
                       cc = 0x7fffu;
                     }
-                  if (cc < AG_HB) atomicAdd(&lhist[cc], 1u);
+                  if (variant & 2) ;
+                  else if (cc < AG_HB) atomicAdd(&lhist[cc], 1u);
                   else            atomicAdd(&hist_g[cc], 1ull);
-                  c[j] = cc;
                   if (cutoff > 0 && (int) cc >= cutoff)
-                    nq += 1;
-                  else
-                    c[j] = 0;
+                    { nq += 1;
+                      c[j] = cc;
+                    }
                 }
             }
-          if (cutoff > 0)
+          if (cutoff > 0 && !(variant & 4))
             { u32 tot;
               const u32 off = ag_block_exscan(nq, sh_tmp, &tot);
               if (tid == 0 && tot > 0)
@@ -239,10 +279,16 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
                   for (int j = 0; j < SLOTS / AG_THREADS; j++)
                     if (c[j] != 0)
                       { const int slot = j * AG_THREADS + tid;
+                        const uint4 a = A[slot];
+                        u32 kd[5] = { a.x, a.y, a.z, 0u, 0u };
+                        if (KW > 3)
+                          { const uint4 b = B[slot];
+                            kd[3] = b.x; kd[4] = b.y;
+                          }
 #pragma unroll
                         for (int w = 0; w < KW - 1; w++)
-                          table[o * KW + w] = key[w * SLOTS + slot];
-                        table[o * KW + KW - 1] = key[(KW - 1) * SLOTS + slot] | (c[j] << 16);
+                          table[o * KW + w] = kd[w];
+                        table[o * KW + KW - 1] = kd[KW - 1] | (c[j] << 16);
                         o += 1;
                       }
                 }
@@ -312,7 +358,7 @@ static int aggr_t(fk_ctx *ctx, const void *d_grouped, int64_t n, int cutoff, int
   const int limit = (ctx->dbg_aggr_limit > 0 && ctx->dbg_aggr_limit < AgCfg<KW>::LIMIT) ? ctx->dbg_aggr_limit
                                                                                         : AgCfg<KW>::LIMIT;
   hipLaunchKernelGGL(k_ag_count<KW>, dim3((unsigned) cus), dim3(AG_THREADS), lds, s, (const u32 *) d_grouped,
-                     (const u64 *) d_bounds, ctx->wid.kmer_bytes, cutoff, d_hist, d_scal, (u32 *) d_table, limit);
+                     (const u64 *) d_bounds, ctx->wid.kmer_bytes, cutoff, d_hist, d_scal, (u32 *) d_table, limit, ctx->dbg_aggr_variant);
   FK_LAUNCH_CHECK(ctx);
   u64 *h = ctx->h_scratch;                       // pinned, 64 KB + 64 KB: the histogram needs 256 KB
   u64 *hh = (u64 *) malloc((FK_HIST_BINS + 8) * 8);

@@ -276,6 +276,10 @@ extern "C" int fk_debug_set(fk_ctx *ctx, const char *key, int64_t value)
     { ctx->dbg_radix_items = (int) value;
       return (FK_OK);
     }
+  if (strcmp(key, "aggr_variant") == 0)     // bit 0: no inserts, bit 1: no histogram, bit 2: no table
+    { ctx->dbg_aggr_variant = (int) value;
+      return (FK_OK);
+    }
   if (strcmp(key, "aggr_limit") == 0)
     { ctx->dbg_aggr_limit = (int) value;
       return (FK_OK);

@@ -25,6 +25,9 @@ template <int RW> struct RxCfg
   static constexpr int ITEMS = (RW <= 2) ? 16 : (RW == 3) ? 12 : (RW == 4) ? 8 : (RW == 5) ? 8 : 4;
 };
 
+// a record as one object of RW dwords, 4-byte aligned: copies compile to dwordxN loads/stores
+template <int RW> struct __attribute__((packed, aligned(4))) rx_rec { u32 w[RW]; };
+
 #define ST_AGG  1ull
 #define ST_PFX  2ull
 #define ST_VAL  ((1ull << 54) - 1)
@@ -570,24 +573,237 @@ __global__ __launch_bounds__(RX_THREADS) void k_rx_scatter(const u32 *__restrict
     }
   __syncthreads();
 
-#pragma unroll 4
-  for (int j = tid; j < ndw; j += RX_THREADS)
-    { const int p = j / RW;
-      const int w = j - p * RW;
-      const int sr = perm[p];
-      const u32 d  = tdig[sr];
-      dst[(goff[d] + p) * RW + w] = recs[sr * RW + w];
+  // one thread per record: sorted slot p -> source record, one RW-dword store at its new position
+  // (lanes of a wave cover consecutive slots, i.e. consecutive addresses inside a bin's run), and
+  // the digit the next pass sorts on next to it
+#pragma unroll
+  for (int it = 0; it < ITEMS; it++)
+    { const int p = it * RX_THREADS + tid;
+      if (p < tn)
+        { const int     sr = perm[p];
+          const u32     d  = tdig[sr];
+          const int64_t o  = goff[d] + p;
+          rx_rec<RW> r = *(const rx_rec<RW> *) (recs + sr * RW);
+          *(rx_rec<RW> *) (dst + o * RW) = r;
+          if (next_byte >= 0)
+            { const u32 nd = HASHED ? rx_hash_digit<RW>(r.w, next_byte, hbytes)
+                                    : (u32) lbytes[sr * RW * 4 + next_byte];
+              nextdig[o] = (uint8_t) nd;
+            }
+        }
     }
+}
 
-  // the digit the next pass sorts on, stored at each record's new position
-  if (next_byte >= 0)
-    for (int p = tid; p < tn; p += RX_THREADS)
-      { const int sr = perm[p];
-        const u32 d  = tdig[sr];
-        const u32 nd = HASHED ? rx_hash_digit<RW>(recs + sr * RW, next_byte, hbytes)
-                              : (u32) lbytes[sr * RW * 4 + next_byte];
-        nextdig[goff[d] + p] = (uint8_t) nd;
+// ---------------------------------------------------------------------------------------------
+// Wide variant of k_rx_scatter: 1024 threads and a tile of 1024*ITEMS records per workgroup (one
+// workgroup per CU, ~140 KB of LDS), so a bin's run inside a tile is 2.7x longer (R = 12: 32 records
+// = 384 bytes instead of 144) and most of the scattered writes are whole 128-byte lines.  With one
+// workgroup per CU nothing else would hide the load latency, so the workgroup is persistent: it
+// walks over its tiles and fetches the NEXT tile (records, digits, bin offsets) into registers
+// before it ranks and writes the current one.  Workgroup b belongs to XCD b % 8 and takes tiles
+// (b%8)*ceil(T/8) + b/8 + k*(grid/8): the 32 workgroups of an XCD work on neighbouring tiles.
+#define RXW_THREADS 1024
+#define RXW_WAVES   16
+
+template <int RW> struct RxCfgW
+{ static constexpr int ITEMS = (RW == 1) ? 16 : (RW <= 3) ? 8 : 4; };
+
+template <int RW, int ITEMS, bool HASHED>
+__global__ __launch_bounds__(RXW_THREADS) void k_rx_scatter_w(const u32 *__restrict__ src,
+                                                              u32 *__restrict__ dst, int64_t n,
+                                                              int next_byte,
+                                                              const uint16_t *__restrict__ tilepfx,
+                                                              const u32 *__restrict__ chunkpfx,
+                                                              const u64 *__restrict__ superpfx,
+                                                              const uint8_t *__restrict__ curdig,
+                                                              uint8_t *__restrict__ nextdig,
+                                                              int64_t ntiles, int hbytes)
+{ constexpr int TILE = RXW_THREADS * ITEMS;
+  static_assert((RX_CH - 1) * TILE < 65536 || RW < 4, "u16 tile prefixes inside a chunk");
+  constexpr int NV   = ITEMS * RW / 4;
+  constexpr int ND   = ITEMS / 4;
+  static_assert((ITEMS * RW) % 4 == 0 && ITEMS % 4 == 0, "tile must split into 16-byte and 4-byte loads");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u32      *recs     = (u32 *) smem;                                   // TILE*RW, never reordered
+  int64_t  *goff     = (int64_t *) (smem + (size_t) TILE * RW * 4);    // 256
+  u32      *whist    = (u32 *) (goff + 256);                           // RXW_WAVES*256
+  u32      *binstart = whist + RXW_WAVES * 256;                        // 256
+  u32      *tmp32    = binstart + 256;                                 // 8
+  uint16_t *perm     = (uint16_t *) (tmp32 + 8);                       // TILE: sorted slot -> record
+  uint8_t  *tdig     = (uint8_t *) (perm + TILE);                      // TILE: this pass's digit per record
+
+  const int tid  = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const u64 lt   = fk_lanemask_lt();
+  const unsigned char *lbytes = (const unsigned char *) smem;
+
+  const int64_t per   = (ntiles + 7) >> 3;
+  const int64_t first = (int64_t) (blockIdx.x >> 3);
+  const int64_t step  = (int64_t) (gridDim.x >> 3);
+  const int64_t tbase = (int64_t) (blockIdx.x & 7) * per;
+
+  uint4 v[NV];
+  u32   dg[ND];
+  u64   gp = 0;
+#pragma unroll
+  for (int q = 0; q < NV; q++)
+    v[q] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+  for (int q = 0; q < ND; q++)
+    dg[q] = 0;
+#define RXW_FETCH(T)                                                                              \
+  { const int64_t t_ = (T);                                                                       \
+    if ((t_ + 1) * TILE <= n)                                                                     \
+      { const uint4 *g4 = (const uint4 *) (src + t_ * TILE * RW);                                 \
+        _Pragma("unroll")                                                                         \
+        for (int q = 0; q < NV; q++)                                                              \
+          v[q] = g4[tid + q * RXW_THREADS];                                                       \
+        const u32 *gd = (const u32 *) (curdig + t_ * TILE) + tid * ND;                            \
+        _Pragma("unroll")                                                                         \
+        for (int q = 0; q < ND; q++)                                                              \
+          dg[q] = gd[q];                                                                          \
+      }                                                                                           \
+    if (tid < 256)                                                                                \
+      gp = superpfx[(t_ / (RX_CH * RX_SC)) * 256 + tid] + (u64) chunkpfx[(t_ / RX_CH) * 256 + tid] \
+         + (u64) tilepfx[t_ * 256 + tid];                                                         \
+  }
+
+  int64_t k = first;
+  if (k < per && tbase + k < ntiles)
+    RXW_FETCH(tbase + k)
+  for (; k < per && tbase + k < ntiles; k += step)
+    { const int64_t tile   = tbase + k;
+      const int64_t tstart = tile * TILE;
+      const int     tn     = (n - tstart < TILE) ? (int) (n - tstart) : TILE;
+      const int     ndw    = tn * RW;
+
+      if (tn == TILE)
+        { uint4 *l4 = (uint4 *) recs;
+#pragma unroll
+          for (int j = 0; j < NV; j++)
+            l4[tid + j * RXW_THREADS] = v[j];
+          u32 *ld = (u32 *) tdig + tid * ND;
+#pragma unroll
+          for (int j = 0; j < ND; j++)
+            ld[j] = dg[j];
+        }
+      else
+        { const u32 *gsrc = src + tstart * RW;
+          for (int i = tid; i < ndw; i += RXW_THREADS)
+            recs[i] = gsrc[i];
+          for (int i = tid; i < tn; i += RXW_THREADS)
+            tdig[i] = curdig[tstart + i];
+        }
+      const u64 gpre = gp;
+      for (int i = tid; i < RXW_WAVES * 256; i += RXW_THREADS)
+        whist[i] = 0;
+      __syncthreads();
+
+      // the next tile travels while this one is ranked and written
+      { const int64_t kn = k + step;
+        if (kn < per && tbase + kn < ntiles)
+          RXW_FETCH(tbase + kn)
       }
+
+      const int wbase = wave * 64 * ITEMS;
+      u32 info[ITEMS];
+      u32 old[ITEMS];
+#pragma unroll
+      for (int it = 0; it < ITEMS; it++)
+        { const int  r     = wbase + it * 64 + lane;
+          const bool valid = (r < tn);
+          const u32  d     = valid ? (u32) tdig[r] : 0u;
+          u64 mask = __ballot(valid);
+#pragma unroll
+          for (int b = 0; b < 8; b++)
+            { const bool bit = (d >> b) & 1u;
+              const u64  bm  = __ballot(bit);
+              mask &= bit ? bm : ~bm;
+            }
+          const u32 below  = (u32) __popcll(mask & lt);
+          const u32 leader = valid ? (u32) (__ffsll((unsigned long long) mask) - 1) : (u32) lane;
+          info[it] = d | (below << 8) | (leader << 16);
+          old[it] = 0;
+          if (valid && below == 0)
+            old[it] = atomicAdd(&whist[wave * 256 + d], (u32) __popcll(mask));
+        }
+#pragma unroll
+      for (int it = 0; it < ITEMS; it++)
+        { const u32 e    = info[it];
+          const u32 base = (u32) __shfl((int) old[it], (int) ((e >> 16) & 0xffu), 64);
+          info[it] = (e & 0xffu) | ((base + ((e >> 8) & 0xffu)) << 8);     // d | rank-in-wave << 8
+        }
+      __syncthreads();
+
+      // bins: exclusive scan over waves, then over the 256 bins (threads 0..255 = waves 0..3)
+      u32 run = 0, incl = 0;
+      if (tid < 256)
+        {
+#pragma unroll
+          for (int w = 0; w < RXW_WAVES; w++)
+            { const u32 t = whist[w * 256 + tid];
+              whist[w * 256 + tid] = run;
+              run += t;
+            }
+          incl = run;
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1)
+            { const u32 y = __shfl_up(incl, o, 64);
+              if (lane >= o) incl += y;
+            }
+          if (lane == 63) tmp32[wave] = incl;
+        }
+      __syncthreads();
+      if (tid < 256)
+        { u32 base = 0;
+#pragma unroll
+          for (int w = 0; w < 4; w++)
+            if (w < wave) base += tmp32[w];
+          const u32 bstart = base + incl - run;
+          binstart[tid] = bstart;
+          goff[tid] = (int64_t) gpre - (int64_t) bstart;
+        }
+      __syncthreads();
+
+#pragma unroll
+      for (int it = 0; it < ITEMS; it++)
+        { const int r = wbase + it * 64 + lane;
+          if (r < tn)
+            { const u32 e   = info[it];
+              const u32 d   = e & 0xffu;
+              const u32 pos = binstart[d] + whist[wave * 256 + d] + (e >> 8);
+              perm[pos] = (uint16_t) r;
+            }
+        }
+      __syncthreads();
+
+#pragma unroll
+      for (int it = 0; it < ITEMS; it++)
+        { const int p = it * RXW_THREADS + tid;
+          if (p < tn)
+            { const int     sr = perm[p];
+              const u32     d  = tdig[sr];
+              const int64_t o  = goff[d] + p;
+              rx_rec<RW> r = *(const rx_rec<RW> *) (recs + sr * RW);
+              *(rx_rec<RW> *) (dst + o * RW) = r;
+              if (next_byte >= 0)
+                { const u32 nd = HASHED ? rx_hash_digit<RW>(r.w, next_byte, hbytes)
+                                        : (u32) lbytes[sr * RW * 4 + next_byte];
+                  nextdig[o] = (uint8_t) nd;
+                }
+            }
+        }
+      __syncthreads();
+    }
+}
+
+#undef RXW_FETCH
+
+template <int RW, int ITEMS> static size_t rx_wide_lds_bytes()
+{ return ((size_t) RXW_THREADS * ITEMS * RW * 4 + 256 * 8 + RXW_WAVES * 256 * 4 + 256 * 4 + 8 * 4
+          + (size_t) RXW_THREADS * ITEMS * 3 + 16);
 }
 
 template <int RW, int ITEMS> static size_t rx_lds_bytes(bool hashed)
@@ -703,10 +919,10 @@ static int lsd_sort_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, const in
   return (FK_OK);
 }
 
-template <int RW, int ITEMS, bool HASHED>
+template <int RW, int ITEMS, bool HASHED, int WT>
 static int lsd_sort_stream_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, const int *bytes,
                              int nbytes, void **result, int hbytes)
-{ constexpr int TILE = RX_THREADS * ITEMS;
+{ constexpr int TILE = WT * ITEMS;
   const int64_t ntiles  = (n + TILE - 1) / TILE;
   const int64_t nchunks = (ntiles + RX_CH - 1) / RX_CH;
   const int64_t nsuper  = (nchunks + RX_SC - 1) / RX_SC;
@@ -792,10 +1008,23 @@ static int lsd_sort_stream_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, c
       FK_LAUNCH_CHECK(ctx);
     }
 
-  const size_t lds_bytes = rx_stream_lds_bytes<RW, ITEMS>();
+  size_t lds_bytes;
+  if constexpr (WT == RX_THREADS) lds_bytes = rx_stream_lds_bytes<RW, ITEMS>();
+  else lds_bytes = rx_wide_lds_bytes<RW, ITEMS>();
   u32 *src = (u32 *) d_src, *trg = (u32 *) d_trg;
   uint8_t *dcur = dig_a, *dnext = dig_b;
-  const unsigned sgrid = (unsigned) (((ntiles + 7) / 8) * 8);
+  unsigned sgrid = (unsigned) (((ntiles + 7) / 8) * 8);
+  if constexpr (WT != RX_THREADS)
+    { static bool attr_set = false;
+      if (!attr_set)
+        { auto kern = k_rx_scatter_w<RW, ITEMS, HASHED>;
+          FK_HIP(ctx, hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int) lds_bytes));
+          attr_set = true;
+        }
+      const unsigned cus = (unsigned) ((ctx->num_cus > 0 ? ctx->num_cus : 256) / 8 * 8);
+      if (sgrid > cus) sgrid = cus;
+    }
   FK_HIP(ctx, hipEventRecord(ctx->ev0, s));
   for (int i = 0; i < nrun; i++)
     if (ctx->pass_ev[2 * i] == NULL)
@@ -804,7 +1033,7 @@ static int lsd_sort_stream_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, c
       }
   for (int i = 0; i < nrun; i++)
     { const int nextb = (i + 1 < nrun) ? run[i + 1] : -1;
-      hipLaunchKernelGGL(k_rx_tilehist<ITEMS>, dim3((unsigned) nchunks), dim3(RX_THREADS), 0, s,
+      hipLaunchKernelGGL(k_rx_tilehist<TILE / RX_THREADS>, dim3((unsigned) nchunks), dim3(RX_THREADS), 0, s,
                          (const uint8_t *) dcur, n, tilepfx, chunktot);
       hipLaunchKernelGGL(k_rx_chunkscan, dim3((unsigned) nsuper), dim3(RX_THREADS), 0, s,
                          (const u32 *) chunktot, nchunks, chunkpfx, supertot);
@@ -812,10 +1041,18 @@ static int lsd_sort_stream_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, c
                          (const u64 *) (ctx->d_digit_hist + (size_t) run[i] * 256),
                          (const u64 *) supertot, nsuper, superpfx);
       FK_HIP(ctx, hipEventRecord(ctx->pass_ev[2 * i], s));
-      hipLaunchKernelGGL((k_rx_scatter<RW, ITEMS, HASHED>), dim3(sgrid), dim3(RX_THREADS), lds_bytes, s,
-                         (const u32 *) src, trg, n, run[i], nextb, (const uint16_t *) tilepfx,
-                         (const u32 *) chunkpfx, (const u64 *) superpfx, (const uint8_t *) dcur, dnext, ntiles,
-                         hbytes);
+      if constexpr (WT == RX_THREADS)
+        hipLaunchKernelGGL((k_rx_scatter<RW, ITEMS, HASHED>), dim3(sgrid),
+                           dim3(RX_THREADS), lds_bytes, s,
+                           (const u32 *) src, trg, n, run[i], nextb, (const uint16_t *) tilepfx,
+                           (const u32 *) chunkpfx, (const u64 *) superpfx, (const uint8_t *) dcur, dnext, ntiles,
+                           hbytes);
+      else
+        hipLaunchKernelGGL((k_rx_scatter_w<RW, ITEMS, HASHED>), dim3(sgrid),
+                           dim3(RXW_THREADS), lds_bytes, s,
+                           (const u32 *) src, trg, n, nextb, (const uint16_t *) tilepfx,
+                           (const u32 *) chunkpfx, (const u64 *) superpfx, (const uint8_t *) dcur, dnext, ntiles,
+                           hbytes);
       FK_HIP(ctx, hipEventRecord(ctx->pass_ev[2 * i + 1], s));
       FK_LAUNCH_CHECK(ctx);
       u32 *t = src; src = trg; trg = t;
@@ -847,8 +1084,12 @@ static int sort_dispatch(fk_ctx *ctx, int64_t nelem, void *d_src, void *d_trg, i
     }
   const int it = ctx->dbg_radix_items;      // measurement aid: alternative tile sizes for R = 12, 20
   const bool lookback = (ctx->dbg_radix_engine == 1 || ctx->dbg_radix_variant != 0 || it != 0);
+  // wide (1024-thread, persistent) tiles pay off for records of 16 bytes and more; narrower records
+  // are bound by instruction issue, not by the write pattern, and do better with 4 workgroups per CU
+  const bool narrow = (ctx->dbg_radix_engine == 2) || (rsize < 16 && ctx->dbg_radix_engine != 3);
 #define RX_CASE(RW) return (lookback ? lsd_sort_t<RW, RxCfg<RW>::ITEMS, HASHED>(ctx, nelem, d_src, d_trg, bytes, nbytes, result) \
-                              : lsd_sort_stream_t<RW, RxCfg<RW>::ITEMS, HASHED>(ctx, nelem, d_src, d_trg, bytes, nbytes, result, hbytes))
+                     : narrow ? lsd_sort_stream_t<RW, RxCfg<RW>::ITEMS, HASHED, RX_THREADS>(ctx, nelem, d_src, d_trg, bytes, nbytes, result, hbytes) \
+                              : lsd_sort_stream_t<RW, RxCfgW<RW>::ITEMS, HASHED, RXW_THREADS>(ctx, nelem, d_src, d_trg, bytes, nbytes, result, hbytes))
   switch (rsize >> 2)
   { case 1: RX_CASE(1);
     case 2: RX_CASE(2);
