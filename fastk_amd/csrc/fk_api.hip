@@ -719,7 +719,7 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
       if (nw > 0)
         { if ((km_a = fk_slot(ctx, FK_SLOT_KM_A, nw * w.kmer_stride)) == NULL)
             { rc = FK_ENOMEM; break; }
-          if ((rc = fkx_expand(ctx, sm_sorted, ns, km_a, nw, &nw, &nd, &ovf)) != FK_OK) break;
+          if ((rc = fkx_expand(ctx, sm_sorted, ns, km_a, nw, &nw, &nd, &ovf, true)) != FK_OK) break;
         }
       int64_t exact_census[256];
       if (h_roff != NULL && nw > 0

@@ -67,6 +67,7 @@ struct fk_ctx
   int        dbg_aggr_limit;      // > 0: pretend the LDS table of fk_aggr.hip takes only this many k-mers
   int64_t    aggr_extra_rounds;   // bins x rounds that had to be split in the last aggregation
   int        num_cus;
+  int64_t    ex_nweighted, ex_ndistinct;   // totals of the last expand sizing call
   void      *slot_ptr[FK_NSLOTS];
   int64_t    slot_cap[FK_NSLOTS];
 };
@@ -109,7 +110,7 @@ int fkx_first_byte_census(fk_ctx *ctx, const void *d_recs, int64_t n, int rsize,
 int fkx_split_fast(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void **d_out, int64_t *nsuper,
                    int64_t *ninst);
 int fkx_expand(fk_ctx *ctx, const void *d_smers, int64_t nsuper, void *d_out, int64_t cap,
-               int64_t *nweighted, int64_t *ndistinct, int64_t *overflow);
+               int64_t *nweighted, int64_t *ndistinct, int64_t *overflow, bool reuse_counts = false);
 int fkx_count(fk_ctx *ctx, const void *d_kmers, int64_t nweighted, int cutoff, int sorted_bytes,
               int64_t *hist, int64_t *max_inst, int64_t *ndistinct,
               void *d_table, int64_t cap, int64_t *ntable);

@@ -14,6 +14,7 @@
 #define EX_THREADS 256
 #define EX_ITEMS   4
 #define EX_TILE    (EX_THREADS * EX_ITEMS)
+#define EX_G       6                     // consecutive output k-mers per thread
 
 template <int RW>
 __device__ __forceinline__ bool ex_same(const u32 *a, const u32 *b)
@@ -71,9 +72,11 @@ __device__ __forceinline__ u32 ex_bits(const u32 *rec, int bit)
 // and the offset of their first k-mer inside the tile.  Phase 2 (one thread per OUTPUT k-mer, so every
 // lane works and stores are consecutive 12-byte records): find the head by binary search over the
 // offsets, cut the 2K-bit window out of the super-mer, build its reverse complement, keep the smaller.
-template <int RW, int KN>     // KN = words holding a k-mer
+template <int OW> struct __attribute__((packed, aligned(4))) ex_out { u32 w[OW]; };
+
+template <int RW, int KN, int OW>     // KN = words holding a k-mer, OW = words of an output record
 __global__ __launch_bounds__(EX_THREADS) void k_ex_expand(const u32 *__restrict__ sm, int64_t n,
-                                                          int kmer, int len_byte, int ow,
+                                                          int kmer, int len_byte,
                                                           const u64 *__restrict__ tile_koff,
                                                           u32 *__restrict__ out,
                                                           u64 *__restrict__ overflow)
@@ -163,62 +166,89 @@ __global__ __launch_bounds__(EX_THREADS) void k_ex_expand(const u32 *__restrict_
 
   const u32 nh    = s_runh;
   const u32 ktile = s_runk;
-  const int pad   = 32 * KN - 2 * kmer;           // unused low bits of the last k-mer word
-  const u32 lastm = (pad == 0) ? 0xffffffffu : ~((1u << pad) - 1u);
-  const int cw    = (ow * 4 - 2) >> 2;            // word and shift of the uint16 weight
-  const int csh   = 8 * ((ow * 4 - 2) & 3);
-  u32 *gout = out + tile_koff[blockIdx.x] * (u64) ow;
+  if (threadIdx.x == 0)
+    hoff[nh] = ktile;                             // sentinel: end of the last head's k-mers
+  __syncthreads();
+  const int padb  = 32 * KN - 2 * kmer;           // unused low bits of the last k-mer word
+  const u32 lastm = (padb == 0) ? 0xffffffffu : ~((1u << padb) - 1u);
+  u32 *gout = out + tile_koff[blockIdx.x] * (u64) OW;
 
-  for (u32 j = threadIdx.x; j < ktile; j += EX_THREADS)
-    { // head of output k-mer j: last h with hoff[h] <= j
-      u32 lo = 0, hi = nh;
+  // every thread emits EX_G CONSECUTIVE k-mers: one binary search for the first, after that the
+  // next k-mer of the same super-mer costs a fresh forward window (ex_bits) and a two-bit roll of
+  // the reverse complement; moving on to the next head re-derives both
+  for (u32 j0 = threadIdx.x * EX_G; j0 < ktile; j0 += EX_THREADS * EX_G)
+    { u32 lo = 0, hi = nh;
       while (hi - lo > 1)
         { const u32 mid = (lo + hi) >> 1;
-          if (hoff[mid] <= j) lo = mid; else hi = mid;
+          if (hoff[mid] <= j0) lo = mid; else hi = mid;
         }
-      const u32  o   = j - hoff[lo];
+      u32        o   = j0 - hoff[lo];
+      u32        nxt = hoff[lo + 1];
       const u32 *rec = recs + (u32) hrec[lo] * RW;
-      const u32  ct  = hct[lo];
-
+      u32        ct  = hct[lo];
       u32 f[KN], r[KN];
+      bool fresh = true;
 #pragma unroll
-      for (int q = 0; q < KN; q++)
-        f[q] = ex_bits(rec, 2 * (int) o + 32 * q);
-      f[KN - 1] &= lastm;
-      { u32 t[KN];
+      for (int g = 0; g < EX_G; g++)
+        { const u32 j = j0 + g;
+          if (j >= ktile)
+            break;
+          if (g > 0)
+            { if (j == nxt)
+                { lo += 1;
+                  o = 0;
+                  nxt = hoff[lo + 1];
+                  rec = recs + (u32) hrec[lo] * RW;
+                  ct  = hct[lo];
+                  fresh = true;
+                }
+              else
+                o += 1;
+            }
 #pragma unroll
-        for (int q = 0; q < KN; q++)
-          { u32 c = ~f[KN - 1 - q];
-            if (q == 0)
-              c &= lastm;
-            const u32 y = __builtin_bitreverse32(c);
-            t[q] = ((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1);
-          }
+          for (int q = 0; q < KN; q++)
+            f[q] = ex_bits(rec, 2 * (int) o + 32 * q);
+          f[KN - 1] &= lastm;
+          if (fresh)
+            { u32 t[KN];
 #pragma unroll
-        for (int q = 0; q < KN; q++)
-          { const u32 h2 = t[q];
-            const u32 l2 = (q + 1 < KN) ? t[q + 1] : 0u;
-            r[q] = (pad == 0) ? h2 : ((h2 << pad) | (l2 >> (32 - pad)));
-          }
-      }
-      bool use_f = false, decided = false;         // count.c:484-495: forward iff strictly smaller
+              for (int q = 0; q < KN; q++)
+                { u32 c = ~f[KN - 1 - q];
+                  if (q == 0)
+                    c &= lastm;
+                  t[q] = ex_revpairs(c);
+                }
 #pragma unroll
-      for (int q = 0; q < KN; q++)
-        if (!decided && f[q] != r[q])
-          { use_f = (f[q] < r[q]);
-            decided = true;
-          }
-      u32 *dst = gout + j * (u32) ow;
-#pragma unroll 1
-      for (int q = 0; q < ow; q++)
-        { u32 x = 0;
+              for (int q = 0; q < KN; q++)
+                { const u32 h2 = t[q];
+                  const u32 l2 = (q + 1 < KN) ? t[q + 1] : 0u;
+                  r[q] = (padb == 0) ? h2 : ((h2 << padb) | (l2 >> (32 - padb)));
+                }
+              fresh = false;
+            }
+          else
+            { // the window moved one base to the right: its new last base, complemented, enters
+              // the reverse complement at the top and the old first base drops out at the bottom
+              const u32 nb = ((f[KN - 1] >> padb) & 3u) ^ 3u;
 #pragma unroll
-          for (int z = 0; z < KN; z++)
-            if (q == z)
-              x = __builtin_bswap32(use_f ? f[z] : r[z]);
-          if (q == cw)
-            x |= ct << csh;
-          dst[q] = x;
+              for (int q = KN - 1; q > 0; q--)
+                r[q] = (r[q] >> 2) | (r[q - 1] << 30);
+              r[0] = (r[0] >> 2) | (nb << 30);
+              r[KN - 1] &= lastm;
+            }
+          bool use_f = false, decided = false;         // count.c:484-495: forward iff strictly smaller
+#pragma unroll
+          for (int q = 0; q < KN; q++)
+            if (!decided && f[q] != r[q])
+              { use_f = (f[q] < r[q]);
+                decided = true;
+              }
+          ex_out<OW> x;
+#pragma unroll
+          for (int q = 0; q < OW; q++)
+            x.w[q] = (q < KN) ? __builtin_bswap32(use_f ? f[q < KN ? q : 0] : r[q < KN ? q : 0]) : 0u;
+          x.w[OW - 1] |= ct << 16;                     // uint16 weight in the record's last two bytes
+          *(ex_out<OW> *) (gout + (u64) j * OW) = x;
         }
     }
 }
@@ -226,7 +256,7 @@ __global__ __launch_bounds__(EX_THREADS) void k_ex_expand(const u32 *__restrict_
 // ---------------------------------------------------------------------------------------------
 template <int RW>
 static int expand_t(fk_ctx *ctx, const void *d_smers, int64_t n, void *d_out, int64_t cap,
-                    int64_t *nweighted, int64_t *ndistinct, int64_t *overflow)
+                    int64_t *nweighted, int64_t *ndistinct, int64_t *overflow, bool reuse_counts)
 { hipStream_t s = ctx->stream;
   const int   K = ctx->prm.kmer;
   const int   kn = (2 * K + 31) / 32;
@@ -247,7 +277,15 @@ static int expand_t(fk_ctx *ctx, const void *d_smers, int64_t n, void *d_out, in
 
   int rc = FK_OK;
   do
-    { hipLaunchKernelGGL(k_ex_count<RW>, dim3((unsigned) ntiles), dim3(EX_THREADS), 0, s,
+    { if (reuse_counts && d_out != NULL)
+        { // the sizing call just before this one left the per-tile offsets in d_koff
+          *nweighted = ctx->ex_nweighted;
+          *ndistinct = ctx->ex_ndistinct;
+          if (hipMemsetAsync(d_tot + 2, 0, 8, s) != hipSuccess) { rc = FK_EHIP; break; }
+        }
+      else
+      {
+      hipLaunchKernelGGL(k_ex_count<RW>, dim3((unsigned) ntiles), dim3(EX_THREADS), 0, s,
                          (const u32 *) d_smers, n, len_byte, d_heads, d_kmers);
       // heads total: reuse the scan with d_koff as a throw-away output
       hipLaunchKernelGGL(k_exscan_tiles, dim3(1), dim3(256), 0, s, (const u32 *) d_heads, ntiles,
@@ -261,6 +299,9 @@ static int expand_t(fk_ctx *ctx, const void *d_smers, int64_t n, void *d_out, in
         { rc = FK_EHIP; break; }
       *nweighted = (int64_t) ctx->h_scratch[0];
       *ndistinct = (int64_t) ctx->h_scratch[1];
+      ctx->ex_nweighted = *nweighted;
+      ctx->ex_ndistinct = *ndistinct;
+      }
       if (d_out == NULL)
         break;
       if (cap < *nweighted)
@@ -269,23 +310,25 @@ static int expand_t(fk_ctx *ctx, const void *d_smers, int64_t n, void *d_out, in
           rc = FK_EINVAL;
           break;
         }
+#define EX_LAUNCH(KN, OW)                                                                          \
+      hipLaunchKernelGGL((k_ex_expand<RW, KN, OW>), dim3((unsigned) ntiles), dim3(EX_THREADS), 0, s,   \
+                         (const u32 *) d_smers, n, K, len_byte, (const u64 *) d_koff, (u32 *) d_out,   \
+                         d_tot + 2)
+      if (ow != kn && ow != kn + 1)
+        { fk_set_error(ctx, "k = %d: %d k-mer words do not fit records of %d words", K, kn, ow);
+          rc = FK_EUNSUPPORTED;
+          break;
+        }
       switch (kn)
-      { case 1: hipLaunchKernelGGL((k_ex_expand<RW, 1>), dim3((unsigned) ntiles), dim3(EX_THREADS), 0, s,
-                                   (const u32 *) d_smers, n, K, len_byte, ow, (const u64 *) d_koff,
-                                   (u32 *) d_out, d_tot + 2); break;
-        case 2: hipLaunchKernelGGL((k_ex_expand<RW, 2>), dim3((unsigned) ntiles), dim3(EX_THREADS), 0, s,
-                                   (const u32 *) d_smers, n, K, len_byte, ow, (const u64 *) d_koff,
-                                   (u32 *) d_out, d_tot + 2); break;
-        case 3: hipLaunchKernelGGL((k_ex_expand<RW, 3>), dim3((unsigned) ntiles), dim3(EX_THREADS), 0, s,
-                                   (const u32 *) d_smers, n, K, len_byte, ow, (const u64 *) d_koff,
-                                   (u32 *) d_out, d_tot + 2); break;
-        case 4: hipLaunchKernelGGL((k_ex_expand<RW, 4>), dim3((unsigned) ntiles), dim3(EX_THREADS), 0, s,
-                                   (const u32 *) d_smers, n, K, len_byte, ow, (const u64 *) d_koff,
-                                   (u32 *) d_out, d_tot + 2); break;
+      { case 1: if (ow == 1) EX_LAUNCH(1, 1); else EX_LAUNCH(1, 2); break;
+        case 2: if (ow == 2) EX_LAUNCH(2, 2); else EX_LAUNCH(2, 3); break;
+        case 3: if (ow == 3) EX_LAUNCH(3, 3); else EX_LAUNCH(3, 4); break;
+        case 4: if (ow == 4) EX_LAUNCH(4, 4); else EX_LAUNCH(4, 5); break;
         default:
           fk_set_error(ctx, "k = %d needs %d k-mer words; only k <= 64 is built", K, kn);
           rc = FK_EUNSUPPORTED;
       }
+#undef EX_LAUNCH
       if (rc != FK_OK) break;
       if (hipGetLastError() != hipSuccess) { rc = FK_EHIP; break; }
       if (hipMemcpyAsync(ctx->h_scratch, d_tot + 2, 8, hipMemcpyDeviceToHost, s) != hipSuccess
@@ -300,15 +343,15 @@ static int expand_t(fk_ctx *ctx, const void *d_smers, int64_t n, void *d_out, in
 }
 
 int fkx_expand(fk_ctx *ctx, const void *d_smers, int64_t nsuper, void *d_out, int64_t cap,
-               int64_t *nweighted, int64_t *ndistinct, int64_t *overflow)
+               int64_t *nweighted, int64_t *ndistinct, int64_t *overflow, bool reuse_counts)
 { switch (ctx->wid.smer_stride >> 2)
-  { case 2: return expand_t<2>(ctx, d_smers, nsuper, d_out, cap, nweighted, ndistinct, overflow);
-    case 3: return expand_t<3>(ctx, d_smers, nsuper, d_out, cap, nweighted, ndistinct, overflow);
-    case 4: return expand_t<4>(ctx, d_smers, nsuper, d_out, cap, nweighted, ndistinct, overflow);
-    case 5: return expand_t<5>(ctx, d_smers, nsuper, d_out, cap, nweighted, ndistinct, overflow);
-    case 6: return expand_t<6>(ctx, d_smers, nsuper, d_out, cap, nweighted, ndistinct, overflow);
-    case 7: return expand_t<7>(ctx, d_smers, nsuper, d_out, cap, nweighted, ndistinct, overflow);
-    case 8: return expand_t<8>(ctx, d_smers, nsuper, d_out, cap, nweighted, ndistinct, overflow);
+  { case 2: return expand_t<2>(ctx, d_smers, nsuper, d_out, cap, nweighted, ndistinct, overflow, reuse_counts);
+    case 3: return expand_t<3>(ctx, d_smers, nsuper, d_out, cap, nweighted, ndistinct, overflow, reuse_counts);
+    case 4: return expand_t<4>(ctx, d_smers, nsuper, d_out, cap, nweighted, ndistinct, overflow, reuse_counts);
+    case 5: return expand_t<5>(ctx, d_smers, nsuper, d_out, cap, nweighted, ndistinct, overflow, reuse_counts);
+    case 6: return expand_t<6>(ctx, d_smers, nsuper, d_out, cap, nweighted, ndistinct, overflow, reuse_counts);
+    case 7: return expand_t<7>(ctx, d_smers, nsuper, d_out, cap, nweighted, ndistinct, overflow, reuse_counts);
+    case 8: return expand_t<8>(ctx, d_smers, nsuper, d_out, cap, nweighted, ndistinct, overflow, reuse_counts);
     default:
       fk_set_error(ctx, "super-mer stride %d not built", ctx->wid.smer_stride);
       return (FK_EUNSUPPORTED);
