@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-shard", action="store_true",
                     help="run the sharded (all-to-all) path even on one GPU: exercises RCCL + shard.py")
+    ap.add_argument("--stream-buckets", type=int, default=1,
+                    help="count the minimizer buckets one after the other (HBM-budgeted mode), N=1 only")
     ap.add_argument("--debug", action="append", default=[], metavar="KEY=VALUE",
                     help="fk_debug_set knob for ablation runs (results may be invalid)")
     return ap.parse_args()
@@ -126,7 +128,7 @@ def main():
     nbytes = per * (L + 1)
 
     ctx = fastk_amd.Context(kmer=args.kmer, table_cutoff=1, nthreads=4, device=local_rank,
-                            nbuckets=world)
+                            nbuckets=world if sharded else max(1, args.stream_buckets))
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     for kv in args.debug:
         key, val = kv.split("=")

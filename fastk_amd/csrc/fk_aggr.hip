@@ -89,7 +89,7 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
                                                          const u64 *__restrict__ bounds, int kbytes,
                                                          int cutoff, u64 *__restrict__ hist_g,
                                                          u64 *__restrict__ scal, u32 *__restrict__ table,
-                                                         int LIMIT, int variant)
+                                                         int LIMIT, int variant, int gshift)
 { constexpr int SLOTS = AgCfg<KW>::SLOTS;
   constexpr int U = AG_UNROLL;
   extern __shared__ uint4 ag_lds[];
@@ -113,9 +113,10 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
     kmask[w] = (4 * w + 4 <= kbytes) ? 0xffffffffu : (4 * w < kbytes) ? ((1u << (8 * (kbytes - 4 * w))) - 1u) : 0u;
   __syncthreads();
 
-  // bins are dealt round-robin: hashing makes them equally heavy
-  for (u32 bin = blockIdx.x; bin < AG_BINS; bin += gridDim.x)
-    { const int64_t beg = (int64_t) bounds[bin], end = (int64_t) bounds[bin + 1];
+  // groups of 2^gshift neighbouring bins (one bin when the input is large) are dealt round-robin:
+  // hashing makes them equally heavy
+  for (u32 bin = blockIdx.x; bin < (AG_BINS >> gshift); bin += gridDim.x)
+    { const int64_t beg = (int64_t) bounds[bin << gshift], end = (int64_t) bounds[(bin + 1) << gshift];
       if (beg >= end)
         continue;
 
@@ -355,10 +356,13 @@ static int aggr_t(fk_ctx *ctx, const void *d_grouped, int64_t n, int cutoff, int
   hipLaunchKernelGGL(k_ag_bounds<KW>, dim3(AG_BINS / 256 + 1), dim3(256), 0, s, (const u32 *) d_grouped, n,
                      ctx->wid.kmer_bytes, d_bounds);
   const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
+  int gshift = 0;                                // aim at ~6,000 records per table fill
+  while (ctx->dbg_aggr_limit <= 0 && gshift < 16 && (n >> (16 - gshift - 1)) < 6000)
+    gshift += 1;
   const int limit = (ctx->dbg_aggr_limit > 0 && ctx->dbg_aggr_limit < AgCfg<KW>::LIMIT) ? ctx->dbg_aggr_limit
                                                                                         : AgCfg<KW>::LIMIT;
   hipLaunchKernelGGL(k_ag_count<KW>, dim3((unsigned) cus), dim3(AG_THREADS), lds, s, (const u32 *) d_grouped,
-                     (const u64 *) d_bounds, ctx->wid.kmer_bytes, cutoff, d_hist, d_scal, (u32 *) d_table, limit, ctx->dbg_aggr_variant);
+                     (const u64 *) d_bounds, ctx->wid.kmer_bytes, cutoff, d_hist, d_scal, (u32 *) d_table, limit, ctx->dbg_aggr_variant, gshift);
   FK_LAUNCH_CHECK(ctx);
   u64 *h = ctx->h_scratch;                       // pinned, 64 KB + 64 KB: the histogram needs 256 KB
   u64 *hh = (u64 *) malloc((FK_HIST_BINS + 8) * 8);

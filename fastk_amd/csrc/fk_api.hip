@@ -640,25 +640,230 @@ static double ms_between(hipEvent_t a, hipEvent_t b)
   return (double) ms;
 }
 
-// d_smers_in != NULL: start from caller-owned super-mer records (sharded path, after the exchange);
-// the caller's buffer is used as one half of the sort's ping-pong pair and is clobbered.
-int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers_in,
-                 int64_t nsmers_in, fk_result *res, bool fetch_table, int64_t *h_roff = NULL,
-                 int64_t nreads = 0)
+// One bucket of super-mer records -> histogram / totals accumulated into res, table records.
+//   final = true  (single bucket): the table is sorted here, *table_out points at it (device).
+//   final = false (bucket streaming): the table records of this bucket, in no particular order, are
+//                  appended to the slot FK_SLOT_TABLE at record *ntab (grown as needed).
+// sm_in is clobbered (it is one half of the grouping's ping-pong pair).
+struct fk_stage_ms { double group_s, expand, radix_k, aggr; };
+
+static int count_bucket(fk_ctx *ctx, void *sm_in, int64_t ns, fk_result *res, bool final,
+                        void **table_out, int64_t *ntab, const int64_t *exact_roff, fk_stage_ms *tm,
+                        int64_t ns_max = 0)
 { const fk_widths &w = ctx->wid;
   hipStream_t s = ctx->stream;
-  hipEvent_t ev[6];
+  const int cutoff = ctx->prm.table_cutoff;
+  hipEvent_t ev[4];
   int rc = FK_OK;
 
-  memset(res, 0, sizeof(*res));
-  for (int i = 0; i < 6; i++)
+  if (ns <= 0)
+    return (FK_OK);
+  for (int i = 0; i < 4; i++)
     if (hipEventCreate(&ev[i]) != hipSuccess)
       { fk_set_error(ctx, "fk_finish: cannot create events");
         return (FK_EHIP);
       }
   do
-    { void *sm_a = NULL, *sm_b = NULL, *km_a = NULL, *km_b = NULL;
+    { void *sm_b = fk_slot(ctx, FK_SLOT_SM_B, ns * w.smer_stride);
+      void *km_a = NULL, *km_b = NULL;
+      if (sm_b == NULL) { rc = FK_ENOMEM; break; }
+      hipEventRecord(ev[0], s);
+
+      // super-mer "sort": only has to bring identical records together (Supermer_Sort's output is
+      // consumed by the run-length pass of count.c:421-426), so four hashed digit passes suffice
+      void *sm_sorted = sm_in;
+      if ((rc = fkx_group(ctx, ns, sm_in, sm_b, w.smer_stride, w.smer_stride, FK_GROUP_PASSES, &sm_sorted)) != FK_OK)
+        break;
+      res->passes_super      = ctx->sort_stats.passes;
+      res->ms_pass_super    += ctx->sort_stats.pass_ms_total;
+      res->ms_scatter_super += ctx->sort_stats.scatter_ms_total;
+      hipEventRecord(ev[1], s);
+
+      // weighted k-mer list
+      int64_t nw = 0, nd = 0, ovf = 0;
+      if ((rc = fkx_expand(ctx, sm_sorted, ns, NULL, 0, &nw, &nd, &ovf)) != FK_OK) break;
+      res->nweighted += nw;
+      res->ndistinct_super += nd;
+      if (nw > 0)
+        { // later buckets are about as dense as this one: size for the largest of them right away
+          int64_t want = nw;
+          if (ns_max > ns)
+            want = (int64_t) ((double) nw / (double) ns * (double) ns_max * 1.02);
+          if (want * w.kmer_stride <= ctx->slot_cap[FK_SLOT_KM_A] || want < nw)
+            want = nw;
+          if ((km_a = fk_slot(ctx, FK_SLOT_KM_A, want * w.kmer_stride)) == NULL
+              || (km_b = fk_slot(ctx, FK_SLOT_KM_B, want * w.kmer_stride)) == NULL)
+            { rc = FK_ENOMEM; break; }
+          if ((rc = fkx_expand(ctx, sm_sorted, ns, km_a, nw, &nw, &nd, &ovf, true)) != FK_OK) break;
+        }
+      int64_t exact_census[256];
+      if (exact_roff != NULL && nw > 0
+          && (rc = fkx_first_byte_census(ctx, km_a, nw, w.kmer_stride, exact_census)) != FK_OK)
+        break;
+      hipEventRecord(ev[2], s);
+
+      // weighted k-mer stage.  The reference sorts the W weighted records on KMER_BYTES and scans the
+      // result (MSDsort.c:536, 491-509).  Only the table has to come out in k-mer order, so here two
+      // hashed digit passes bring all copies of a k-mer into one of 65,536 bins, one workgroup per bin
+      // sums them in an LDS hash table (fk_aggr.hip: histogram, max_inst, table candidates), and only
+      // the table records (count >= cutoff) are sorted on KMER_BYTES.  fk_debug_set("kmer_stage",1)
+      // or a bin that does not fit selects the sort / collapse / sort path below instead.
+      int64_t nt = 0, ndk = 0, ovf2 = 0;
+      void   *tab = NULL;                       // device address of this bucket's table records
+      bool    tab_sorted = false;
+      bool    aggregated = false;
+      float   ms_aggr = 0.f;
+      if (nw > 0 && ctx->dbg_kmer_stage != 1)
+        { void *grouped = km_a;
+          if ((rc = fkx_group(ctx, nw, km_a, km_b, w.kmer_stride, w.kmer_bytes, 2, &grouped)) != FK_OK)
+            break;
+          res->passes_kmer      = ctx->sort_stats.passes;
+          res->ms_pass_kmer    += ctx->sort_stats.pass_ms_total;
+          res->ms_scatter_kmer += ctx->sort_stats.scatter_ms_total;
+          void *tbuf = (grouped == km_a) ? km_b : km_a;
+          hipEventRecord(ctx->ev0, s);
+          rc = fkx_aggregate(ctx, grouped, nw, cutoff, res->hist, &res->max_inst, &ndk,
+                             cutoff > 0 ? tbuf : NULL, nw, &nt);     // adds to hist only on success
+          hipEventRecord(ctx->ev1, s);
+          if (rc == FK_OK)
+            { aggregated = true;
+              hipEventSynchronize(ctx->ev1);
+              hipEventElapsedTime(&ms_aggr, ctx->ev0, ctx->ev1);
+              tab = tbuf;
+              km_a = tbuf; km_b = grouped;       // km_a: table records, km_b: free
+            }
+          else if (rc == FK_ESTATE)
+            { km_a = grouped; km_b = tbuf;       // all records are still there, in another order
+              rc = FK_OK;
+            }
+          else
+            break;
+        }
+      if (nw > 0 && !aggregated)
+        { // The LSD sort over the W weighted records is interrupted after the FK_LOW_BYTES least
+          // significant key bytes: equal k-mers that are adjacent by then are collapsed into one record
+          // (weights summed, clipped like count.c:455-458) -- the collapse keeps the order, so the
+          // remaining passes simply continue the same LSD sort on ~3x fewer records.  k-mers that were
+          // not adjacent yet meet at the end and are summed by the count kernel.
+          const int nlow = (w.kmer_bytes > FK_LOW_BYTES + 1) ? FK_LOW_BYTES : 0;
+          int bytes[64];
+          int64_t nc = nw;
+          void *low = km_a;
+          if (nlow > 0)
+            { for (int i = 0; i < nlow; i++)
+                bytes[i] = w.kmer_bytes - 1 - i;
+              if ((rc = fkx_lsd_sort(ctx, nw, km_a, km_b, w.kmer_stride, bytes, nlow, &low)) != FK_OK)
+                break;
+              res->passes_kmer      = ctx->sort_stats.passes;
+              res->ms_pass_kmer    += ctx->sort_stats.pass_ms_total;
+              res->ms_scatter_kmer += ctx->sort_stats.scatter_ms_total;
+              void *cbuf = (low == km_a) ? km_b : km_a;
+              if ((rc = fkx_collapse(ctx, low, nw, cbuf, nw, &nc, &ovf2)) != FK_OK)
+                break;
+              km_b = low; km_a = cbuf;                 // km_a holds the collapsed records
+            }
+          const int nhigh = w.kmer_bytes - nlow;
+          for (int i = 0; i < nhigh; i++)
+            bytes[i] = nhigh - 1 - i;
+          void *km_sorted = km_a;
+          if ((rc = fkx_lsd_sort(ctx, nc, km_a, km_b, w.kmer_stride, bytes, nhigh, &km_sorted)) != FK_OK)
+            break;
+          res->ms_pass_final += ctx->sort_stats.pass_ms_total;
+          if (nlow == 0)
+            { res->passes_kmer      = ctx->sort_stats.passes;
+              res->ms_pass_kmer    += ctx->sort_stats.pass_ms_total;
+              res->ms_scatter_kmer += ctx->sort_stats.scatter_ms_total;
+            }
+          for (int x = 0; x < 256; x++)          // first-byte census of the sorted records
+            res->wfirst[x] = (exact_roff != NULL) ? exact_census[x] : (int64_t) ctx->h_scratch[x];
+          void *other = (km_sorted == km_a) ? km_b : km_a;
+          if ((rc = fkx_count(ctx, km_sorted, nc, cutoff, w.kmer_bytes, res->hist, &res->max_inst, &ndk,
+                              cutoff > 0 ? other : NULL, nc, &nt)) != FK_OK)
+            break;
+          tab = other;
+          tab_sorted = true;
+          km_a = other; km_b = km_sorted;
+        }
+      res->max_inst  += ovf + ovf2;                           // count.c:1551
+      res->ndistinct += ndk;
+      if (cutoff > 0 && nt > 0)
+        { if (final)
+            { if (!tab_sorted)
+                { int bytes[64];
+                  for (int i = 0; i < w.kmer_bytes; i++)
+                    bytes[i] = w.kmer_bytes - 1 - i;
+                  void *sorted = tab;
+                  if ((rc = fkx_lsd_sort(ctx, nt, tab, km_b, w.kmer_stride, bytes, w.kmer_bytes, &sorted)) != FK_OK)
+                    break;
+                  res->passes_final   = ctx->sort_stats.passes;
+                  res->ms_pass_final += ctx->sort_stats.pass_ms_total;
+                  tab = sorted;
+                  for (int x = 0; x < 256; x++)
+                    res->wfirst[x] = (exact_roff != NULL) ? exact_census[x] : (int64_t) ctx->h_scratch[x];
+                }
+              *table_out = tab;
+            }
+          else
+            { // keep what earlier buckets appended while the slot grows
+              const int64_t need = (*ntab + nt) * w.kmer_stride;
+              if (ctx->slot_cap[FK_SLOT_TABLE] < need)
+                { void *nbuf = NULL;
+                  const int64_t ncap = need + need / 2 + (1 << 20);
+                  if (hipMalloc(&nbuf, (size_t) ncap) != hipSuccess) { rc = FK_ENOMEM; break; }
+                  if (*ntab > 0
+                      && hipMemcpyAsync(nbuf, ctx->slot_ptr[FK_SLOT_TABLE], (size_t) (*ntab * w.kmer_stride),
+                                        hipMemcpyDeviceToDevice, s) != hipSuccess)
+                    { hipFree(nbuf); rc = FK_EHIP; break; }
+                  hipStreamSynchronize(s);
+                  if (ctx->slot_ptr[FK_SLOT_TABLE] != NULL)
+                    hipFree(ctx->slot_ptr[FK_SLOT_TABLE]);
+                  ctx->slot_ptr[FK_SLOT_TABLE] = nbuf;
+                  ctx->slot_cap[FK_SLOT_TABLE] = ncap;
+                }
+              if (hipMemcpyAsync((char *) ctx->slot_ptr[FK_SLOT_TABLE] + *ntab * w.kmer_stride, tab,
+                                 (size_t) (nt * w.kmer_stride), hipMemcpyDeviceToDevice, s) != hipSuccess)
+                { rc = FK_EHIP; break; }
+            }
+        }
+      *ntab += (cutoff > 0) ? nt : 0;
+      hipEventRecord(ev[3], s);
+      if (hipEventSynchronize(ev[3]) != hipSuccess) { rc = FK_EHIP; break; }
+      tm->group_s += ms_between(ev[0], ev[1]);
+      tm->expand  += ms_between(ev[1], ev[2]);
+      tm->radix_k += ms_between(ev[2], ev[3]) - ms_aggr;
+      tm->aggr    += ms_aggr;
+    }
+  while (0);
+  for (int i = 0; i < 4; i++)
+    hipEventDestroy(ev[i]);
+  return (rc);
+}
+
+// d_smers_in != NULL: start from caller-owned super-mer records (sharded path, after the exchange);
+// the caller's buffer is used as one half of the sort's ping-pong pair and is clobbered.
+// With nbuckets > 1 and reads as input the buckets are processed one after the other ("bucket
+// streaming": the k-mer buffers only ever hold one bucket's weighted k-mers); equal k-mers share a
+// minimizer, hence a bucket, so histograms add up and the table is the sorted union.
+int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers_in,
+                 int64_t nsmers_in, fk_result *res, bool fetch_table, int64_t *h_roff = NULL,
+                 int64_t nreads = 0)
+{ const fk_widths &w = ctx->wid;
+  hipStream_t s = ctx->stream;
+  hipEvent_t ev[3];
+  int rc = FK_OK;
+
+  memset(res, 0, sizeof(*res));
+  for (int i = 0; i < 3; i++)
+    if (hipEventCreate(&ev[i]) != hipSuccess)
+      { fk_set_error(ctx, "fk_finish: cannot create events");
+        return (FK_EHIP);
+      }
+  do
+    { void *sm_a = NULL;
       int64_t ns = 0, ni = 0;
+      int64_t bc[256], bo[256];
+      int     nbk = 1;
+      fk_stage_ms tm = { 0., 0., 0., 0. };
 
       hipEventRecord(ev[0], s);
       void *sm_in = d_smers_in;
@@ -669,6 +874,11 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
       else
         { if (h_roff != NULL)
             { // exact_parts: the reference's own rule, so that Table_Split falls where it does there
+              if (ctx->prm.nbuckets != 1)
+                { fk_set_error(ctx, "exact_parts works on one bucket only (nbuckets = %d)", ctx->prm.nbuckets);
+                  rc = FK_EUNSUPPORTED;
+                  break;
+                }
               h_roff[nreads] = nbytes;
               int64_t train = 0, olen = 0;                 // Get_First_Block(io, 1e9), io.c:2606-2630
               const int64_t maxrds = 1000000000ll / 150, omax = 1000000000ll + maxrds;
@@ -690,216 +900,94 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
               if ((rc = fkx_split_exact(ctx, d_reads, d_roff, nreads, tran, &sm_a, &ns, &ni)) != FK_OK) break;
             }
           else
-          // split (sampled capacity + one emit pass; exact count-then-emit when sharding)
-          if ((rc = fkx_split_fast(ctx, d_reads, nbytes, &sm_a, &ns, &ni)) != FK_OK) break;
+            { // split (sampled capacity + one emit pass; exact count-then-emit with several buckets)
+              if ((rc = fkx_split_fast(ctx, d_reads, nbytes, &sm_a, &ns, &ni, bc, bo)) != FK_OK) break;
+              nbk = ctx->prm.nbuckets;
+            }
           res->nsuper = ns;
           res->ninst = ni;
           sm_in = sm_a;
         }
-      if (ns > 0 && (sm_b = fk_slot(ctx, FK_SLOT_SM_B, ns * w.smer_stride)) == NULL)
-        { rc = FK_ENOMEM; break; }
       hipEventRecord(ev[1], s);
 
-      // super-mer "sort": only has to bring identical records together (Supermer_Sort's output is
-      // consumed by the run-length pass of count.c:421-426), so five hashed digit passes suffice
-      void *sm_sorted = sm_in;
-      { if ((rc = fkx_group(ctx, ns, sm_in, sm_b, w.smer_stride, w.smer_stride, FK_GROUP_PASSES, &sm_sorted)) != FK_OK)
-          break;
-        res->passes_super  = ctx->sort_stats.passes;
-        res->ms_pass_super = ctx->sort_stats.pass_ms_total;
-        res->ms_scatter_super = ctx->sort_stats.scatter_ms_total;
-      }
-      hipEventRecord(ev[2], s);
-
-      // weighted k-mer list
-      int64_t nw = 0, nd = 0, ovf = 0;
-      if ((rc = fkx_expand(ctx, sm_sorted, ns, NULL, 0, &nw, &nd, &ovf)) != FK_OK) break;
-      res->nweighted = nw;
-      res->ndistinct_super = nd;
-      if (nw > 0)
-        { if ((km_a = fk_slot(ctx, FK_SLOT_KM_A, nw * w.kmer_stride)) == NULL)
-            { rc = FK_ENOMEM; break; }
-          if ((rc = fkx_expand(ctx, sm_sorted, ns, km_a, nw, &nw, &nd, &ovf, true)) != FK_OK) break;
-        }
-      int64_t exact_census[256];
-      if (h_roff != NULL && nw > 0
-          && (rc = fkx_first_byte_census(ctx, km_a, nw, w.kmer_stride, exact_census)) != FK_OK)
-        break;
-      hipEventRecord(ev[3], s);
-
-      // weighted k-mer stage.  The reference sorts the W weighted records on KMER_BYTES and scans the
-      // result (MSDsort.c:536, 491-509).  Only the table has to come out in k-mer order, so here two
-      // hashed digit passes bring all copies of a k-mer into one of 65,536 bins, one workgroup per bin
-      // sums them in an LDS hash table (fk_aggr.hip: histogram, max_inst, table candidates), and only
-      // the table records (count >= cutoff) are sorted on KMER_BYTES.  fk_debug_set("kmer_stage",1)
-      // or a bin that does not fit selects the sort / collapse / sort path below instead.
-      void *km_sorted = km_a;
-      int   sorted_bytes = w.kmer_bytes;
-      int64_t nc = nw, ovf2 = 0;
-      int64_t nt = 0, ndk = 0;
-      const int cutoff = ctx->prm.table_cutoff;
-      void *other = NULL;
-      bool  aggregated = false;
-      float ms_aggr = 0.f;
-      if (nw > 0 && (km_b = fk_slot(ctx, FK_SLOT_KM_B, nw * w.kmer_stride)) == NULL)
-        { rc = FK_ENOMEM; break; }
-      if (nw > 0 && ctx->dbg_kmer_stage != 1)
-        { void *grouped = km_a;
-          if ((rc = fkx_group(ctx, nw, km_a, km_b, w.kmer_stride, w.kmer_bytes, 2, &grouped)) != FK_OK)
-            break;
-          res->passes_kmer  = ctx->sort_stats.passes;
-          res->ms_pass_kmer = ctx->sort_stats.pass_ms_total;
-          res->ms_scatter_kmer = ctx->sort_stats.scatter_ms_total;
-          void *tbuf = (grouped == km_a) ? km_b : km_a;
-          hipEventRecord(ctx->ev0, s);
-          rc = fkx_aggregate(ctx, grouped, nw, cutoff, res->hist, &res->max_inst, &ndk,
-                             cutoff > 0 ? tbuf : NULL, nw, &nt);     // adds to hist only on success
-          hipEventRecord(ctx->ev1, s);
-          if (rc == FK_OK)
-            { aggregated = true;
-              hipEventSynchronize(ctx->ev1);
-              hipEventElapsedTime(&ms_aggr, ctx->ev0, ctx->ev1);
-              other = tbuf;
-              res->ncollapsed = nt;
-              if (cutoff > 0 && nt > 0)
-                { int bytes[64];
-                  for (int i = 0; i < w.kmer_bytes; i++)
-                    bytes[i] = w.kmer_bytes - 1 - i;
-                  void *sorted = tbuf;
-                  if ((rc = fkx_lsd_sort(ctx, nt, tbuf, grouped, w.kmer_stride, bytes, w.kmer_bytes, &sorted)) != FK_OK)
-                    break;
-                  res->passes_final  = ctx->sort_stats.passes;
-                  res->ms_pass_final = ctx->sort_stats.pass_ms_total;
-                  other = sorted;
-                  for (int x = 0; x < 256; x++)
-                    res->wfirst[x] = (h_roff != NULL) ? exact_census[x] : (int64_t) ctx->h_scratch[x];
-                }
-            }
-          else if (rc == FK_ESTATE)
-            { km_a = grouped; km_b = tbuf;               // all records are still there, in another order
-              rc = FK_OK;
-            }
-          else
-            break;
-        }
-      if (!aggregated)
-      {
-      // The LSD sort over the W weighted records is interrupted after the FK_LOW_BYTES least
-      // significant key bytes: equal k-mers that are adjacent by then are collapsed into one record
-      // (weights summed, clipped like count.c:455-458) -- the collapse keeps the order, so the
-      // remaining passes simply continue the same LSD sort on ~3x fewer records.  k-mers that were
-      // not adjacent yet meet at the end and are summed by the count kernel.
-      if (nw > 0)
-        { if ((km_b = fk_slot(ctx, FK_SLOT_KM_B, nw * w.kmer_stride)) == NULL)
-            { rc = FK_ENOMEM; break; }
-          const int nlow = (w.kmer_bytes > FK_LOW_BYTES + 1) ? FK_LOW_BYTES : 0;
-          int bytes[64];
-          void *low = km_a;
-          if (nlow > 0)
-            { for (int i = 0; i < nlow; i++)
-                bytes[i] = w.kmer_bytes - 1 - i;
-              if ((rc = fkx_lsd_sort(ctx, nw, km_a, km_b, w.kmer_stride, bytes, nlow, &low)) != FK_OK)
-                break;
-              res->passes_kmer  = ctx->sort_stats.passes;
-              res->ms_pass_kmer = ctx->sort_stats.pass_ms_total;
-              res->ms_scatter_kmer = ctx->sort_stats.scatter_ms_total;
-              void *cbuf = (low == km_a) ? km_b : km_a;
-              if ((rc = fkx_collapse(ctx, low, nw, cbuf, nw, &nc, &ovf2)) != FK_OK)
-                break;
-              km_b = low; km_a = cbuf;                 // km_a holds the collapsed records
-            }
-          const int nhigh = w.kmer_bytes - nlow;
-          for (int i = 0; i < nhigh; i++)
-            bytes[i] = nhigh - 1 - i;
-          km_sorted = km_a;
-          if ((rc = fkx_lsd_sort(ctx, nc, km_a, km_b, w.kmer_stride, bytes, nhigh, &km_sorted)) != FK_OK)
-            break;
-          res->passes_final  = ctx->sort_stats.passes;
-          res->ms_pass_final = ctx->sort_stats.pass_ms_total;
-          res->ncollapsed    = nc;
-          if (nlow == 0)
-            { res->passes_kmer  = ctx->sort_stats.passes;
-              res->ms_pass_kmer = ctx->sort_stats.pass_ms_total;
-              res->ms_scatter_kmer = ctx->sort_stats.scatter_ms_total;
-            }
-          // first-byte census of the sorted records, for the .ktab part boundaries
-          for (int x = 0; x < 256; x++)
-            res->wfirst[x] = (h_roff != NULL) ? exact_census[x] : (int64_t) ctx->h_scratch[x];
-        }
-      hipEventRecord(ev[4], s);
-
-      // count + table: the idle half of the k-mer ping-pong pair receives the table
-      km_sorted = (km_sorted == NULL) ? km_a : km_sorted;
-      other = (km_sorted == km_a) ? km_b : km_a;
-      rc = fkx_count(ctx, km_sorted, nc, cutoff, sorted_bytes, res->hist, &res->max_inst, &ndk,
-                     cutoff > 0 ? other : NULL, nc, &nt);
-      if (rc == FK_ESTATE)
-        { int bytes[64];
-          for (int i = 0; i < w.kmer_bytes; i++)
-            bytes[i] = w.kmer_bytes - 1 - i;
-          void *full = km_sorted;
-          if ((rc = fkx_lsd_sort(ctx, nw, km_sorted, other, w.kmer_stride, bytes, w.kmer_bytes,
-                                 &full)) != FK_OK)
-            break;
-          res->passes_kmer  += ctx->sort_stats.passes;
-          res->ms_pass_kmer += ctx->sort_stats.pass_ms_total;
-          res->ms_scatter_kmer += ctx->sort_stats.scatter_ms_total;
-          other = (full == km_sorted) ? other : km_sorted;
-          km_sorted = full;
-          rc = fkx_count(ctx, km_sorted, nw, cutoff, w.kmer_bytes, res->hist, &res->max_inst, &ndk,
-                         cutoff > 0 ? other : NULL, nw, &nt);
-        }
-      }
+      void   *table = NULL;
+      int64_t ntab = 0;
+      if (nbk == 1)
+        rc = count_bucket(ctx, sm_in, ns, res, true, &table, &ntab, h_roff, &tm);
       else
-        hipEventRecord(ev[4], s);
+        { int64_t ns_max = 0;
+          for (int b = 0; b < nbk; b++)
+            ns_max = std::max(ns_max, bc[b]);
+          for (int b = 0; b < nbk && rc == FK_OK; b++)
+            rc = count_bucket(ctx, (char *) sm_in + bo[b] * w.smer_stride, bc[b], res, false, NULL, &ntab,
+                              NULL, &tm, ns_max);
+          if (rc == FK_OK && ntab > 0)
+            { // the union of the buckets' tables, in k-mer order
+              void *tmp = fk_slot(ctx, FK_SLOT_KM_A, ntab * w.kmer_stride);
+              int bytes[64];
+              if (tmp == NULL) { rc = FK_ENOMEM; break; }
+              for (int i = 0; i < w.kmer_bytes; i++)
+                bytes[i] = w.kmer_bytes - 1 - i;
+              hipEventRecord(ctx->ev0, s);
+              table = ctx->slot_ptr[FK_SLOT_TABLE];
+              if ((rc = fkx_lsd_sort(ctx, ntab, ctx->slot_ptr[FK_SLOT_TABLE], tmp, w.kmer_stride, bytes,
+                                     w.kmer_bytes, &table)) != FK_OK)
+                break;
+              res->passes_final   = ctx->sort_stats.passes;
+              res->ms_pass_final += ctx->sort_stats.pass_ms_total;
+              for (int x = 0; x < 256; x++)
+                res->wfirst[x] = (int64_t) ctx->h_scratch[x];
+              hipEventRecord(ctx->ev1, s);
+              hipEventSynchronize(ctx->ev1);
+              tm.radix_k += ms_between(ctx->ev0, ctx->ev1);
+            }
+        }
       if (rc != FK_OK)
         break;
-      res->max_inst += ovf + ovf2;                           // count.c:1551
-      res->ndistinct = ndk;
+      const int cutoff = ctx->prm.table_cutoff;
+      const int64_t nt = ntab;
+      res->ncollapsed = nt;
       res->ntable = (cutoff > 0) ? nt : 0;
-      if (cutoff > 0 && nt > 0)
-        {
-          if (fetch_table)
-            { const int64_t bytes = nt * w.kmer_word;
-              if (ctx->h_table_cap < bytes)
-                { free(ctx->h_table);
-                  ctx->h_table = (uint8_t *) malloc((size_t) bytes);
-                  ctx->h_table_cap = bytes;
-                  if (ctx->h_table == NULL)
-                    { ctx->h_table_cap = 0; rc = FK_ENOMEM; break; }
-                }
-              if (w.kmer_word == w.kmer_stride)
-                { if (hipMemcpyAsync(ctx->h_table, other, (size_t) bytes, hipMemcpyDeviceToHost, s)
-                      != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
-                    { rc = FK_EHIP; break; }
-                }
-              else
-                { uint8_t *tmp = (uint8_t *) malloc((size_t) nt * w.kmer_stride);
-                  if (tmp == NULL) { rc = FK_ENOMEM; break; }
-                  if (hipMemcpyAsync(tmp, other, (size_t) nt * w.kmer_stride, hipMemcpyDeviceToHost,
-                                     s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
-                    { free(tmp); rc = FK_EHIP; break; }
-                  for (int64_t i = 0; i < nt; i++)
-                    { memcpy(ctx->h_table + i * w.kmer_word, tmp + i * w.kmer_stride, w.kmer_bytes);
-                      memcpy(ctx->h_table + i * w.kmer_word + w.kmer_bytes,
-                             tmp + i * w.kmer_stride + w.kmer_stride - 2, 2);
-                    }
-                  free(tmp);
-                }
-              res->table = ctx->h_table;
+      if (cutoff > 0 && nt > 0 && fetch_table)
+        { const int64_t bytes = nt * w.kmer_word;
+          if (ctx->h_table_cap < bytes)
+            { free(ctx->h_table);
+              ctx->h_table = (uint8_t *) malloc((size_t) bytes);
+              ctx->h_table_cap = bytes;
+              if (ctx->h_table == NULL)
+                { ctx->h_table_cap = 0; rc = FK_ENOMEM; break; }
             }
+          if (w.kmer_word == w.kmer_stride)
+            { if (hipMemcpyAsync(ctx->h_table, table, (size_t) bytes, hipMemcpyDeviceToHost, s)
+                  != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+                { rc = FK_EHIP; break; }
+            }
+          else
+            { uint8_t *tmp = (uint8_t *) malloc((size_t) nt * w.kmer_stride);
+              if (tmp == NULL) { rc = FK_ENOMEM; break; }
+              if (hipMemcpyAsync(tmp, table, (size_t) nt * w.kmer_stride, hipMemcpyDeviceToHost,
+                                 s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+                { free(tmp); rc = FK_EHIP; break; }
+              for (int64_t i = 0; i < nt; i++)
+                { memcpy(ctx->h_table + i * w.kmer_word, tmp + i * w.kmer_stride, w.kmer_bytes);
+                  memcpy(ctx->h_table + i * w.kmer_word + w.kmer_bytes,
+                         tmp + i * w.kmer_stride + w.kmer_stride - 2, 2);
+                }
+              free(tmp);
+            }
+          res->table = ctx->h_table;
         }
-      hipEventRecord(ev[5], s);
+      hipEventRecord(ev[2], s);
       if (hipStreamSynchronize(s) != hipSuccess) { rc = FK_EHIP; break; }
       res->ms_split      = ms_between(ev[0], ev[1]);
-      res->ms_sort_super = ms_between(ev[1], ev[2]);
-      res->ms_expand     = ms_between(ev[2], ev[3]);
-      res->ms_sort_kmer  = ms_between(ev[3], ev[4]) - ms_aggr;     // radix passes (grouping + table sort)
-      res->ms_count      = ms_between(ev[4], ev[5]) + ms_aggr;
-      res->ms_total      = ms_between(ev[0], ev[5]);
+      res->ms_sort_super = tm.group_s;
+      res->ms_expand     = tm.expand;
+      res->ms_sort_kmer  = tm.radix_k;                  // radix passes (grouping + table sort)
+      res->ms_count      = tm.aggr;
+      res->ms_total      = ms_between(ev[0], ev[2]);
     }
   while (0);
-  for (int i = 0; i < 6; i++)
+  for (int i = 0; i < 3; i++)
     hipEventDestroy(ev[i]);
   if (rc == FK_EHIP && ctx->err[0] == 0)
     fk_set_error(ctx, "fk_finish: HIP failure: %s", hipGetErrorString(hipGetLastError()));

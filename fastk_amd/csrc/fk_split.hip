@@ -412,8 +412,11 @@ int fkx_split(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int
 // once with overflow detection, and only if the estimate was too small fall back to the exact
 // count-then-emit of fkx_split.  *d_out is the arena slot that received the records.
 int fkx_split_fast(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void **d_out, int64_t *nsuper,
-                   int64_t *ninst)
-{ hipStream_t s = ctx->stream;
+                   int64_t *ninst, int64_t *bucket_counts, int64_t *bucket_offsets)
+{ int64_t bc[256];
+  for (int b = 0; b < 256; b++)
+    bucket_counts[b] = bucket_offsets[b] = 0;
+  hipStream_t s = ctx->stream;
   const int   K = ctx->prm.kmer;
   u64 *d_counts = ctx->d_scratch;
   u64 *d_cursor = ctx->d_scratch + 512;
@@ -472,12 +475,38 @@ int fkx_split_fast(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void **d_ou
                 *ninst = t;
               }
               *d_out  = out;
+              bucket_counts[0] = *nsuper;
               return (FK_OK);
             }
           // estimate too small (very uneven input): exact path below
         }
     }
-  int64_t bc[256];
+  if (ctx->prm.nbuckets > 1)
+    { // one emit pass into regions sized from a 1/32 tile sample (padded); exact pair on overflow
+      int64_t cap = 0, offs[257];
+      int rc = fkx_split_plan(ctx, d_bases, nbytes, &cap, offs);
+      if (rc != FK_OK)
+        return (rc);
+      if (cap > 0)
+        { void *out = fk_slot(ctx, FK_SLOT_SM_A, cap * stride);
+          if (out == NULL)
+            return (FK_ENOMEM);
+          rc = fkx_split_planned(ctx, d_bases, nbytes, out, cap, offs, bc, ninst);
+          if (rc == FK_OK)
+            { int64_t tot = 0;
+              for (int b = 0; b < ctx->prm.nbuckets; b++)
+                { bucket_counts[b] = bc[b];
+                  bucket_offsets[b] = offs[b];
+                  tot += bc[b];
+                }
+              *nsuper = tot;
+              *d_out = out;
+              return (FK_OK);
+            }
+          if (rc != FK_ESTATE)
+            return (rc);
+        }
+    }
   int rc = fkx_split(ctx, d_bases, nbytes, NULL, 0, nsuper, ninst, bc, false);
   if (rc != FK_OK || *nsuper == 0)
     return (rc);
@@ -485,7 +514,14 @@ int fkx_split_fast(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void **d_ou
   if (out == NULL)
     return (FK_ENOMEM);
   *d_out = out;
-  return fkx_split(ctx, d_bases, nbytes, out, *nsuper, nsuper, ninst, bc, true);
+  rc = fkx_split(ctx, d_bases, nbytes, out, *nsuper, nsuper, ninst, bc, true);
+  int64_t run = 0;
+  for (int b = 0; b < ctx->prm.nbuckets && b < 256; b++)
+    { bucket_counts[b] = bc[b];
+      bucket_offsets[b] = run;
+      run += bc[b];
+    }
+  return (rc);
 }
 
 // Sampled plan for the bucketed (sharded) split: estimated records per bucket from a 1/32 tile

@@ -254,6 +254,25 @@ def test_pipeline_sort_collapse_path_matches_golden(name):
         util.check_against_golden(case, res.hist, res.max_inst, res.table)
 
 
+@pytest.mark.parametrize("nb", [2, 5, 16])
+@pytest.mark.parametrize("name", ["synth_illumina_k40_t1_T4", "edge_k40_t4_T1", "synth_illumina_k51_t1_T4"])
+def test_bucket_streaming_matches_golden(name, nb, tmp_path):
+    """nbuckets > 1 through fk_push_block / fk_finish: the minimizer buckets are counted one after
+    the other (only one bucket's weighted k-mers are ever in HBM) and the result is the reference's."""
+    case, bases, boff = util.load_case(name)
+    with fastk_amd.Context(kmer=case["k"], table_cutoff=case["cutoff"], nthreads=case["T"],
+                           nbuckets=nb) as ctx:
+        ctx.push_block(bases, boff.astype(np.int32))
+        res = ctx.finish()
+        util.check_against_golden(case, res.hist, res.max_inst, res.table)
+        ctx.write_hist(res, str(tmp_path / "x.hist"))
+        ctx.write_ktab(res, str(tmp_path), "x")
+    import hashlib
+    exp = case["expected"]
+    assert hashlib.sha256(open(tmp_path / "x.hist", "rb").read()).hexdigest() == exp["hist_sha256"]
+    assert orc.read_ktab(str(tmp_path / "x"))["stream_sha256"] == exp["ktab"]["stream_sha256"]
+
+
 def test_empty_and_degenerate_inputs():
     with fastk_amd.Context(kmer=40, table_cutoff=1) as ctx:
         res = ctx.finish()
