@@ -169,6 +169,8 @@ extern "C" int fk_create(const fk_params *p, fk_ctx **out)
   CK(hipHostMalloc((void **) &ctx->h_scratch, 65536 + 32 * 256 * 8, hipHostMallocDefault));
   CK(hipMalloc((void **) &ctx->d_digit_hist, 32 * 256 * sizeof(u64)));
   CK(hipMalloc((void **) &ctx->d_ticket, 64 * sizeof(u32)));
+  if (ctx->prm.hbm_budget > 0 && !ctx->prm.exact_parts)
+    ctx->chunk_bytes = std::max<int64_t>(ctx->prm.hbm_budget / 32, 64ll << 20);
   { uint16_t mtab[1024];
     build_minimizer_tables(mtab, ctx->h_mbucket, ctx->prm.nbuckets);
     CK(hipMemcpy(ctx->d_mrank, mtab, sizeof(mtab), hipMemcpyHostToDevice));
@@ -205,6 +207,9 @@ extern "C" void fk_destroy(fk_ctx *ctx)
     if (ctx->pass_ev[i]) hipEventDestroy(ctx->pass_ev[i]);
   if (ctx->own_stream && ctx->stream != NULL)
     hipStreamDestroy(ctx->stream);
+  for (int i = 0; i < ctx->nchunks; i++)
+    hipFree(ctx->chunks[i].ptr);
+  free(ctx->chunks);
   free(ctx->h_table);
   free(ctx->h_roff);
   if (ctx->push_lock)
@@ -274,6 +279,10 @@ extern "C" int fk_debug_set(fk_ctx *ctx, const char *key, int64_t value)
     }
   if (strcmp(key, "radix_items") == 0)
     { ctx->dbg_radix_items = (int) value;
+      return (FK_OK);
+    }
+  if (strcmp(key, "chunk_bytes") == 0)      // split the pushed reads every so many bytes (tests)
+    { ctx->chunk_bytes = value;
       return (FK_OK);
     }
   if (strcmp(key, "aggr_variant") == 0)     // bit 0: no inserts, bit 1: no histogram, bit 2: no table
@@ -512,6 +521,49 @@ static int reserve_reads(fk_ctx *ctx, int64_t extra)
   return (FK_OK);
 }
 
+// Split the reads pushed so far into super-mers grouped by bucket, keep those (compacted) as a
+// chunk and forget the reads: with hbm_budget set, the ASCII reads never have to be resident as a
+// whole.  Called with the push lock held.
+static int flush_chunk(fk_ctx *ctx)
+{ const int stride = ctx->wid.smer_stride;
+  hipStream_t s = ctx->stream;
+  if (ctx->reads_len == 0)
+    return (FK_OK);
+  FK_HIP(ctx, hipStreamSynchronize(s));
+  void   *out = NULL;
+  int64_t ns = 0, ni = 0, bc[256], bo[256];
+  int rc = fkx_split_fast(ctx, ctx->d_reads, ctx->reads_len, &out, &ns, &ni, bc, bo);
+  if (rc != FK_OK)
+    return (rc);
+  ctx->chunk_ninst += ni;
+  ctx->reads_len = 0;
+  if (ns == 0)
+    return (FK_OK);
+  if (ctx->nchunks == ctx->chunks_cap)
+    { ctx->chunks_cap = ctx->chunks_cap * 2 + 16;
+      ctx->chunks = (fk_chunk *) realloc(ctx->chunks, sizeof(fk_chunk) * (size_t) ctx->chunks_cap);
+      if (ctx->chunks == NULL) { ctx->nchunks = ctx->chunks_cap = 0; return (FK_ENOMEM); }
+    }
+  fk_chunk *c = &ctx->chunks[ctx->nchunks];
+  memset(c, 0, sizeof(*c));
+  if (hipMalloc(&c->ptr, (size_t) (ns * stride)) != hipSuccess)
+    { fk_set_error(ctx, "out of HBM: cannot keep %lld super-mer records of a chunk", (long long) ns);
+      return (FK_ENOMEM);
+    }
+  int64_t run = 0;
+  for (int b = 0; b < ctx->prm.nbuckets; b++)
+    { c->cnt[b] = bc[b];
+      if (bc[b] > 0)
+        FK_HIP(ctx, hipMemcpyAsync((char *) c->ptr + run * stride, (char *) out + bo[b] * stride,
+                                   (size_t) (bc[b] * stride), hipMemcpyDeviceToDevice, s));
+      run += bc[b];
+    }
+  c->total = run;
+  ctx->nchunks += 1;
+  FK_HIP(ctx, hipStreamSynchronize(s));
+  return (FK_OK);
+}
+
 extern "C" int fk_push_block(fk_ctx *ctx, const char *bases, const int32_t *boff, int nreads,
                              int rem, int tid)
 { (void) rem; (void) tid;
@@ -573,6 +625,8 @@ extern "C" int fk_push_block(fk_ctx *ctx, const char *bases, const int32_t *boff
         }
       ctx->reads_len += len;
       ctx->stage_idx ^= 1;
+      if (ctx->chunk_bytes > 0 && ctx->reads_len >= ctx->chunk_bytes)
+        rc = flush_chunk(ctx);
     }
   while (0);
   pthread_mutex_unlock((pthread_mutex_t *) ctx->push_lock);
@@ -620,7 +674,10 @@ extern "C" int fk_push_device(fk_ctx *ctx, const void *d_bases, int64_t nbytes)
           rc = FK_EHIP;
         }
       else
-        ctx->reads_len += nbytes + 1;
+        { ctx->reads_len += nbytes + 1;
+          if (ctx->chunk_bytes > 0 && ctx->reads_len >= ctx->chunk_bytes)
+            rc = flush_chunk(ctx);
+        }
     }
   pthread_mutex_unlock((pthread_mutex_t *) ctx->push_lock);
   return (rc);
@@ -867,7 +924,19 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
 
       hipEventRecord(ev[0], s);
       void *sm_in = d_smers_in;
-      if (d_smers_in != NULL)
+      const bool chunked = (d_smers_in == NULL && d_reads == NULL);   // the chunks of flush_chunk
+      if (chunked)
+        { nbk = ctx->prm.nbuckets;
+          for (int b = 0; b < nbk; b++)
+            { bc[b] = 0;
+              for (int c = 0; c < ctx->nchunks; c++)
+                bc[b] += ctx->chunks[c].cnt[b];
+              ns += bc[b];
+            }
+          res->nsuper = ns;
+          res->ninst  = ctx->chunk_ninst;
+        }
+      else if (d_smers_in != NULL)
         { ns = nsmers_in;
           res->nsuper = ns;
         }
@@ -912,15 +981,44 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
 
       void   *table = NULL;
       int64_t ntab = 0;
+      int64_t ns_max = 0;
+      for (int b = 0; b < nbk; b++)
+        ns_max = std::max(ns_max, bc[b]);
+      // chunked ingest: a bucket's records are gathered from the chunks right before it is counted
+      auto gather = [&](int b, void **ptr) -> int
+        { char *g = (char *) fk_slot(ctx, FK_SLOT_SM_G, ns_max * w.smer_stride);
+          if (g == NULL)
+            return (FK_ENOMEM);
+          int64_t run = 0;
+          for (int c = 0; c < ctx->nchunks; c++)
+            { const fk_chunk *ch = &ctx->chunks[c];
+              int64_t off = 0;
+              for (int x = 0; x < b; x++)
+                off += ch->cnt[x];
+              if (ch->cnt[b] > 0
+                  && hipMemcpyAsync(g + run * w.smer_stride, (char *) ch->ptr + off * w.smer_stride,
+                                    (size_t) (ch->cnt[b] * w.smer_stride), hipMemcpyDeviceToDevice, s)
+                     != hipSuccess)
+                return (FK_EHIP);
+              run += ch->cnt[b];
+            }
+          *ptr = g;
+          return (FK_OK);
+        };
       if (nbk == 1)
-        rc = count_bucket(ctx, sm_in, ns, res, true, &table, &ntab, h_roff, &tm);
+        { if (chunked && ns > 0)
+            rc = gather(0, &sm_in);
+          if (rc == FK_OK)
+            rc = count_bucket(ctx, sm_in, ns, res, true, &table, &ntab, h_roff, &tm);
+        }
       else
-        { int64_t ns_max = 0;
-          for (int b = 0; b < nbk; b++)
-            ns_max = std::max(ns_max, bc[b]);
-          for (int b = 0; b < nbk && rc == FK_OK; b++)
-            rc = count_bucket(ctx, (char *) sm_in + bo[b] * w.smer_stride, bc[b], res, false, NULL, &ntab,
-                              NULL, &tm, ns_max);
+        { for (int b = 0; b < nbk && rc == FK_OK; b++)
+            { void *p = (char *) sm_in + bo[b] * w.smer_stride;
+              if (chunked && bc[b] > 0)
+                rc = gather(b, &p);
+              if (rc == FK_OK)
+                rc = count_bucket(ctx, p, bc[b], res, false, NULL, &ntab, NULL, &tm, ns_max);
+            }
           if (rc == FK_OK && ntab > 0)
             { // the union of the buckets' tables, in k-mer order
               void *tmp = fk_slot(ctx, FK_SLOT_KM_A, ntab * w.kmer_stride);
@@ -998,6 +1096,19 @@ extern "C" int fk_finish(fk_ctx *ctx, fk_result *res)
 { if (ctx == NULL || res == NULL) return (FK_EINVAL);
   FK_HIP(ctx, hipSetDevice(ctx->device));
   FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->nchunks > 0)
+    { // chunked ingest: the rest of the reads becomes the last chunk, then the buckets are counted
+      pthread_mutex_lock((pthread_mutex_t *) ctx->push_lock);
+      int rc = flush_chunk(ctx);
+      pthread_mutex_unlock((pthread_mutex_t *) ctx->push_lock);
+      if (rc == FK_OK)
+        rc = fkx_pipeline(ctx, NULL, 0, NULL, 0, res, true);
+      for (int i = 0; i < ctx->nchunks; i++)
+        hipFree(ctx->chunks[i].ptr);
+      ctx->nchunks = 0;
+      ctx->chunk_ninst = 0;
+      return (rc);
+    }
   if (ctx->prm.exact_parts)
     { if (ctx->h_roff == NULL && ctx->reads_len > 0)
         { fk_set_error(ctx, "exact_parts needs reads pushed with fk_push_block");

@@ -16,6 +16,12 @@ typedef unsigned int       u32;
 
 #define FK_NSLOTS 24
 
+struct fk_chunk
+{ void    *ptr;             // records of bucket 0, 1, ... back to back
+  int64_t  cnt[256];
+  int64_t  total;
+};
+
 struct fk_ctx
 { fk_params  prm;
   fk_widths  wid;
@@ -54,6 +60,12 @@ struct fk_ctx
   int64_t    nroff, roff_cap;
   int        have_tran, tran[4];   // exact_parts: ranking from fk_train_block
 
+  // chunked ingest (hbm_budget > 0): super-mers of the reads pushed so far, grouped by bucket
+  struct fk_chunk *chunks;
+  int        nchunks, chunks_cap;
+  int64_t    chunk_bytes;      // split the pushed reads whenever this many bytes have accumulated (0: never)
+  int64_t    chunk_ninst;      // k-mer instances of the chunks already split
+
   hipEvent_t ev0, ev1;
   hipEvent_t pass_ev[128];       // begin/end of each scatter launch of the current sort
 
@@ -74,7 +86,7 @@ struct fk_ctx
 
 enum { FK_SLOT_SM_A = 0, FK_SLOT_SM_B, FK_SLOT_KM_A, FK_SLOT_KM_B, FK_SLOT_EX_HEADS, FK_SLOT_EX_KMERS,
        FK_SLOT_EX_KOFF, FK_SLOT_CT_ENT, FK_SLOT_CT_OFF, FK_SLOT_CT_HIST, FK_SLOT_DIG_A, FK_SLOT_DIG_B,
-       FK_SLOT_RX_TILE, FK_SLOT_RX_CHUNK, FK_SLOT_RX_SUPER, FK_SLOT_ROFF, FK_SLOT_AG_BOUNDS, FK_SLOT_TABLE };
+       FK_SLOT_RX_TILE, FK_SLOT_RX_CHUNK, FK_SLOT_RX_SUPER, FK_SLOT_ROFF, FK_SLOT_AG_BOUNDS, FK_SLOT_TABLE, FK_SLOT_SM_G };
 
 // returns a device buffer of at least nbytes for the given purpose (NULL + error set on failure)
 void *fk_slot(fk_ctx *ctx, int slot, int64_t nbytes);

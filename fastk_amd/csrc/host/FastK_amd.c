@@ -16,8 +16,11 @@
  * rule so that the hidden .ktab parts are cut at the reference's first bytes (fk_params.exact_parts);
  * without it the table's canonical stream is identical but the part boundaries are our own.
  *
- * Accepted for compatibility and ignored: -P (no temporary files exist), -M (HBM is sized by the
- * library).  Not built yet and rejected with a message: -p (profiles), -c (homopolymer
+ * -M<int>: GB of HBM the run may use (the reference's -M is host memory for the same purpose, it
+ * fixes the number of super-mer buckets, split.c:617-766): the reads are split into super-mers chunk
+ * by chunk and the minimizer buckets are counted one after the other; the number of buckets is
+ * derived from the input size.  Without -M everything stays resident in one bucket (fastest).
+ * Accepted for compatibility and ignored: -P (no temporary files exist).  Not built yet and rejected with a message: -p (profiles), -c (homopolymer
  * compression), BAM/SAM/CRAM/Dazzler inputs.
  */
 #include <stdio.h>
@@ -33,7 +36,7 @@
 
 static char *Prog_Name = "FastK_amd";
 
-static int       KMER = 40, NTHREADS = 4, DO_TABLE = 0, BC_PREFIX = 0, VERBOSE = 0, EXACT = 0;
+static int       KMER = 40, NTHREADS = 4, DO_TABLE = 0, BC_PREFIX = 0, VERBOSE = 0, EXACT = 0, MEM_GB = 0;
 static char     *OUT_NAME = NULL;
 
 typedef struct
@@ -166,7 +169,8 @@ int main(int argc, char *argv[])
         case 'v': VERBOSE = 1; break;
         case 'x': EXACT = 1; break;
         case 'N': OUT_NAME = argv[i]+2; break;
-        case 'P': case 'M': break;
+        case 'M': MEM_GB = atoi(argv[i]+2); break;
+        case 'P': break;
         case 'p': case 'c':
           fprintf(stderr,"%s: option %s is not built in this engine yet (see DESIGN.md)\n",Prog_Name,argv[i]);
           exit (1);
@@ -187,6 +191,41 @@ int main(int argc, char *argv[])
   fk_default_params(&prm);
   prm.kmer = KMER; prm.table_cutoff = DO_TABLE; prm.nthreads = NTHREADS; prm.bc_prefix = BC_PREFIX;
   prm.exact_parts = EXACT;
+  if (MEM_GB > 0 && !EXACT)
+    { /* bases ~ file bytes (FASTA), half of them (FASTQ), x4 when gzipped; the super-mers (~1 byte
+         per base) stay resident, a bucket's working set is ~7.5 bytes per base of that bucket */
+      double bases = 0., budget = 1e9 * MEM_GB;
+      for (i = 1; i <= nfiles; i++)
+        { char *r, *d;
+          int   q = classify(argv[i],&r,&d);
+          FILE *fp = fopen(argv[i],"rb");
+          if (q >= 0 && fp != NULL)
+            { size_t l = strlen(argv[i]);
+              double sz;
+              fseek(fp,0,SEEK_END);
+              sz = (double) ftell(fp);
+              if (l > 3 && strcmp(argv[i]+l-3,".gz") == 0) sz *= 4.;
+              bases += q ? sz/2. : sz;
+            }
+          if (fp != NULL) fclose(fp);
+          if (q >= 0) { free(r); free(d); }
+        }
+      { double room = budget - 1.3*bases;
+        int    nb   = 1;
+        if (room < 0.05*budget)
+          { fprintf(stderr,"%s: -M%d is too small for ~%.1f Gbp of input (the super-mers alone need ~%.0f GB)\n",
+                    Prog_Name,MEM_GB,bases/1e9,1.3*bases/1e9);
+            exit (1);
+          }
+        while (nb < 128 && 7.5*bases/nb > room)
+          nb += 1;
+        prm.nbuckets   = nb;
+        prm.hbm_budget = (int64_t) budget;
+        if (VERBOSE)
+          fprintf(stderr,"  -M%d: ~%.2f Gbp of input, %d minimizer bucket(s), reads split in chunks\n",
+                  MEM_GB,bases/1e9,nb);
+      }
+    }
   if (fk_create(&prm,&ctx) != FK_OK)
     die(NULL,"fk_create");
 

@@ -60,8 +60,16 @@ typedef struct
     int     nthreads;      /* -T: number of .ktab parts / first-byte ranges in outputs   */
     int     bc_prefix;     /* -bc<n>: ignore this many leading bases of every read       */
     int     device;        /* HIP device ordinal for this process (one process per GPU)  */
-    int     nbuckets;      /* super-mer buckets for sharding (1 = no sharding), <= 256   */
-    int64_t hbm_budget;    /* bytes of HBM the context may use, 0 = 80% of free memory   */
+    int     nbuckets;      /* minimizer buckets, <= 256 (the role of NPARTS, split.c:617-766).  Equal
+                              k-mers share a bucket.  fk_finish / fk_count_device_reads count the
+                              buckets one after the other, so only one bucket's weighted k-mers
+                              are in HBM at a time; the sharded calls (fk_split_plan ... +
+                              fk_count_device_supermers) hand bucket b to rank b                 */
+    int64_t hbm_budget;    /* > 0: bytes of HBM the run should fit in -- fk_push_block/_device then
+                              split the reads into super-mers every hbm_budget/32 bytes and drop
+                              them, so the ASCII reads are never resident as a whole (choose
+                              nbuckets so that a bucket's working set fits).  0: everything stays
+                              resident (fastest)                                                  */
     int     exact_parts;   /* 1: replay the reference's own super-mer rule (split.c:1016-1393)
                               so that the hidden .ktab part files get the reference's first-byte
                               boundaries (Table_Split, count.c:1560-1565) -- byte-identical files

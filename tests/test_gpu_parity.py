@@ -273,6 +273,43 @@ def test_bucket_streaming_matches_golden(name, nb, tmp_path):
     assert orc.read_ktab(str(tmp_path / "x"))["stream_sha256"] == exp["ktab"]["stream_sha256"]
 
 
+@pytest.mark.parametrize("nb", [1, 4])
+@pytest.mark.parametrize("name", ["synth_illumina_k40_t1_T4", "edge_k40_t1_T4", "synth_hifi_k40_t4_T8"])
+def test_chunked_ingest_matches_golden(name, nb):
+    """HBM-budgeted ingest: the pushed reads are split into super-mers every chunk_bytes and
+    forgotten; at fk_finish every bucket is gathered from the chunks and counted."""
+    case, bases, boff = util.load_case(name)
+    with fastk_amd.Context(kmer=case["k"], table_cutoff=case["cutoff"], nthreads=case["T"],
+                           nbuckets=nb) as ctx:
+        ctx.debug_set("chunk_bytes", max(4096, len(bases) // 5))
+        nreads = len(boff) - 1
+        step = max(1, nreads // 23)
+        for s0 in range(0, nreads, step):
+            e = min(nreads, s0 + step)
+            ctx.push_block(bases[boff[s0]:boff[e]], (boff[s0:e + 1] - boff[s0]).astype(np.int32))
+        res = ctx.finish()
+        exp = orc.fastk(case["k"], bases, boff, cutoff=case["cutoff"])
+        assert res.ninst == exp.ninst
+        util.check_against_golden(case, res.hist, res.max_inst, res.table)
+
+
+def test_cli_memory_option(tmp_path):
+    """FastK_amd -M<GB> (HBM budget: bucket streaming + chunked ingest) gives the same files."""
+    import hashlib, os, subprocess
+    case, bases, boff = util.load_case("synth_illumina_k40_t1_T4")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "fastk_amd", "bin", "FastK_amd")
+    path = str(tmp_path / "reads.fastq")
+    orc.write_fastq(path, bases, boff)
+    p = subprocess.run([exe, "-k40", "-t1", "-T4", "-M1", "-v", path], cwd=str(tmp_path),
+                       capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    assert "minimizer bucket" in p.stderr
+    exp = case["expected"]
+    assert hashlib.sha256(open(tmp_path / "reads.hist", "rb").read()).hexdigest() == exp["hist_sha256"]
+    assert orc.read_ktab(str(tmp_path / "reads"))["stream_sha256"] == exp["ktab"]["stream_sha256"]
+
+
 def test_empty_and_degenerate_inputs():
     with fastk_amd.Context(kmer=40, table_cutoff=1) as ctx:
         res = ctx.finish()
