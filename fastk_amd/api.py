@@ -185,13 +185,14 @@ class Context:
     """fk_ctx wrapper: one per process / GPU."""
 
     def __init__(self, kmer=40, table_cutoff=0, nthreads=4, bc_prefix=0, device=0, nbuckets=1,
-                 exact_parts=False):
+                 exact_parts=False, hbm_budget=0):
         self.L = load_library()
         p = Params()
         self.L.fk_default_params(C.byref(p))
         p.kmer, p.table_cutoff, p.nthreads = kmer, table_cutoff, nthreads
         p.bc_prefix, p.device, p.nbuckets = bc_prefix, device, nbuckets
         p.exact_parts = 1 if exact_parts else 0
+        p.hbm_budget = int(hbm_budget)
         self.params = p
         self.h = C.c_void_p()
         rc = self.L.fk_create(C.byref(p), C.byref(self.h))

@@ -107,6 +107,7 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
   if (tid == 0) { sh_claimed = 0; sh_ovf = 0; }
   u64 my_max = 0;
   u32 my_distinct = 0, my_rounds = 0;
+  u32 R0 = 1;
   u32 kmask[KW];                                // key bytes of each record dword (pad and weight off)
 #pragma unroll
   for (int w = 0; w < KW; w++)
@@ -120,7 +121,14 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
       if (beg >= end)
         continue;
 
-      u32 R = 1, r = 0;
+      // A bin is taken in R0 selections (records whose next hash bits equal r0); R0 is what the
+      // previous bin of this workgroup needed (all bins are alike), so that a table that is too
+      // small for whole bins is not found out again bin after bin.  A selection that still does
+      // not fit is halved on the spot (depth-first), exactly once.
+      bool bin_ovf = false, failed = false;
+      u32  bin_fill = 0;
+      for (u32 r0 = 0; r0 < R0 && !failed; r0++)
+      { u32 R = R0, r = r0;
       for (;;)
         { // ---- insert every record of the bin that this round selects
           u64 round_max = 0;
@@ -225,6 +233,7 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
             }
           __syncthreads();
           const bool ovf = (sh_ovf != 0);
+          const u32  fill = sh_claimed;
           __syncthreads();
           if (ovf)
             { // more distinct k-mers than the table takes: halve the selection and start it again
@@ -232,15 +241,18 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
                 A[i].w = 0;
               if (tid == 0) { sh_claimed = 0; sh_ovf = 0; }
               my_rounds += (tid == 0);
+              bin_ovf = true;
               __syncthreads();
               if (R >= AG_MAXR)
                 { if (tid == 0)
                     atomicAdd(&scal[3], 1ull);
+                  failed = true;
                   break;
                 }
               R <<= 1;
               continue;
             }
+          bin_fill = max(bin_fill, fill);
 
           // ---- emit: histogram, totals, table entries; the table is left empty
           my_max += round_max;
@@ -297,15 +309,20 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
           if (tid == 0) sh_claimed = 0;
           __syncthreads();
 
-          // ---- next selection: sibling, or up
-          while (R > 1 && r >= (R >> 1))
+          // ---- next selection below (R0, r0): sibling, or up
+          while (R > R0 && r >= (R >> 1))
             { r -= (R >> 1);
               R >>= 1;
             }
-          if (R == 1)
+          if (R == R0)
             break;
           r += (R >> 1);
         }
+      }
+      if (bin_ovf)
+        R0 = min(R0 << 1, (u32) AG_MAXR);
+      else if (R0 > 1 && bin_fill * 9 < (u32) LIMIT * 4)
+        R0 >>= 1;
     }
 
   // flush the private histogram and the per-thread totals
