@@ -22,6 +22,7 @@
 #define AG_MAXR    64
 #define AG_BINS    65536
 #define AG_UNROLL  8
+#define AG_P       4                    // slots one probe looks at (ag_read_slots is written for 4)
 
 template <int KW> struct AgCfg
 { static constexpr int SLOTS = (KW <= 3) ? 8192 : 4096;
@@ -50,6 +51,23 @@ __global__ __launch_bounds__(256) void k_ag_bounds(const u32 *__restrict__ recs,
       else hi = mid;
     }
   bounds[b] = (u64) lo;
+}
+
+// AG_P table slots starting at `slot` as AG_P single ds_read_b128: a slot's key and count word must
+// come from ONE LDS access (see k_ag_count); plain C++ loads of a uint4 may be split by the compiler
+// into a 96-bit and a 32-bit read, which lets a reader pair a stale key with a published count.
+template <int SLOTS>
+__device__ __forceinline__ void ag_read_slots(u32 base, u32 slot, uint4 (&v)[4])
+{  const u32 a0 = base + ((slot + 0) & (SLOTS - 1)) * 16u, a1 = base + ((slot + 1) & (SLOTS - 1)) * 16u;
+  const u32 a2 = base + ((slot + 2) & (SLOTS - 1)) * 16u, a3 = base + ((slot + 3) & (SLOTS - 1)) * 16u;
+  asm volatile("ds_read_b128 %0, %4\n\t"
+               "ds_read_b128 %1, %5\n\t"
+               "ds_read_b128 %2, %6\n\t"
+               "ds_read_b128 %3, %7\n\t"
+               "s_waitcnt lgkmcnt(0)"
+               : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+               : "v"(a0), "v"(a1), "v"(a2), "v"(a3)
+               : "memory");
 }
 
 // exclusive scan over the 1024 threads of the block.  tmp: AG_WAVES u32 of LDS.
@@ -94,6 +112,8 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
   constexpr int U = AG_UNROLL;
   extern __shared__ uint4 ag_lds[];
   uint4 *A     = ag_lds;                                   // [SLOTS]
+  // LDS byte address of the table for the inline-asm reads (low half of the flat address)
+  const u32 lds_base = (u32) (uintptr_t) ag_lds;
   uint4 *B     = ag_lds + SLOTS;                           // [SLOTS] when KW > 3
   u32   *lhist = (u32 *) (ag_lds + (KW > 3 ? 2 : 1) * SLOTS);   // [AG_HB]
   __shared__ u32 sh_claimed, sh_ovf, sh_tmp[AG_WAVES];
@@ -160,74 +180,86 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
                   continue;
                 }
 
-              // every lane walks through its own records, one probe per trip: a lane whose record
-              // is done takes its next one at once instead of idling until the slowest lane of the
-              // wave is through (probe counts differ a lot between lanes)
-              u32  cur[KW], wgt = 0, slot = 0;
-              bool have = false;
-              for (;;)
-                { if (!have)
-                    { if (pend == 0 || *(volatile u32 *) &sh_ovf)
-                        break;
-                      const int u = __ffs((int) pend) - 1;
-                      pend &= pend - 1;
+              // one record per lane at a time; a probe looks at AG_P consecutive slots at once (the
+              // kernel is bound by instruction issue, not by LDS bandwidth, and most records are
+              // settled by the first look even when the table is half full)
 #pragma unroll
-                      for (int x = 0; x < U; x++)
-                        if (x == u)
-                          { slot = slot0[x];
-                            wgt  = rec[x][KW - 1] >> 16;
+              for (int u = 0; u < U; u++)
+                { if (!((pend >> u) & 1u))
+                    continue;
+                  u32 cur[KW];
 #pragma unroll
-                            for (int w = 0; w < KW; w++)
-                              cur[w] = rec[x][w] & kmask[w];
-                          }
-                      have = true;
-                    }
-                  const uint4 v = A[slot];
-                  const u32   c = v.w;
-                  bool created = false;
-                  if (c == 0u)
-                    { if (atomicCAS(&A[slot].w, 0u, AG_LOCK) == 0u)
-                        { A[slot] = make_uint4(cur[0], KW > 1 ? cur[KW > 1 ? 1 : 0] : 0u,
-                                               KW > 2 ? cur[KW > 2 ? 2 : 0] : 0u, AG_LOCK);
-                          if (KW > 3)
-                            B[slot] = make_uint4(cur[KW > 3 ? 3 : 0], KW > 4 ? cur[KW > 4 ? 4 : 0] : 0u, 0u, 0u);
-                          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                          *(volatile u32 *) &A[slot].w = wgt;
-                          created = true;
-                          have = false;
+                  for (int w = 0; w < KW; w++)
+                    cur[w] = rec[u][w] & kmask[w];
+                  const u32 wgt = rec[u][KW - 1] >> 16;
+                  u32  slot = slot0[u];
+                  bool done = (*(volatile u32 *) &sh_ovf) != 0;    // a thread claims <= 1 slot per record
+                  while (!done)
+                    { uint4 v[AG_P];
+                      ag_read_slots<SLOTS>(lds_base, slot, v);
+                      // first slot that is empty (1), being written (2) or holds this k-mer (3)
+                      int act = AG_P;
+                      u32 kind = 0, cact = 0;
+#pragma unroll
+                      for (int j = AG_P - 1; j >= 0; j--)
+                        { const u32 c = v[j].w;
+                          bool same = (v[j].x == cur[0]);
+                          if (KW > 1) same = same && (v[j].y == cur[KW > 1 ? 1 : 0]);
+                          if (KW > 2) same = same && (v[j].z == cur[KW > 2 ? 2 : 0]);
+                          const u32 k = (c == 0u) ? 1u : (c == AG_LOCK) ? 2u : same ? 3u : 0u;
+                          if (k != 0u)
+                            { act = j; kind = k; cact = c; }
                         }
-                      // else: another lane took the slot in between; look at it again
-                    }
-                  else if (c != AG_LOCK)
-                    { bool same = (v.x == cur[0]);
-                      if (KW > 1) same = same && (v.y == cur[KW > 1 ? 1 : 0]);
-                      if (KW > 2) same = same && (v.z == cur[KW > 2 ? 2 : 0]);
-                      if (KW > 3 && same)
-                        { const uint4 b = B[slot];
-                          same = (b.x == cur[KW > 3 ? 3 : 0]);
-                          if (KW > 4) same = same && (b.y == cur[KW > 4 ? 4 : 0]);
-                        }
-                      if (same)
-                        { if (c < (AG_HIGH >> 1))
-                            atomicAdd(&A[slot].w, wgt);          // no return value needed
-                          else
-                            { const u32 old = atomicAdd(&A[slot].w, wgt);
-                              if (old < AG_HIGH && old + wgt >= AG_HIGH)
-                                { atomicSub(&A[slot].w, AG_CUT);   // stays far above 0x7fff: still saturated
-                                  round_max += AG_CUT;
-                                }
-                            }
-                          have = false;
+                      const u32 s = (slot + (u32) act) & (SLOTS - 1);
+                      if (KW <= 3 && kind == 3u && cact < (AG_HIGH >> 1))
+                        { atomicAdd(&A[s].w, wgt);                   // the common case: no return value needed
+                          done = true;
                         }
                       else
-                        slot = (slot + 1) & (SLOTS - 1);
-                    }
-                  // c == AG_LOCK: the key is being written by another lane, look again
-                  const u64 cm = __ballot(created);
-                  if (cm != 0ull && fk_lane() == (u32) (__ffsll((long long) cm) - 1))
-                    { const u32 k = (u32) __popcll(cm);
-                      if (atomicAdd(&sh_claimed, k) + k > (u32) LIMIT)
-                        sh_ovf = 1;
+                        { bool created = false;
+                          if (kind == 3u)
+                            { bool same = true;
+                              if (KW > 3)
+                                { const uint4 b = B[s];
+                                  same = (b.x == cur[KW > 3 ? 3 : 0]);
+                                  if (KW > 4) same = same && (b.y == cur[KW > 4 ? 4 : 0]);
+                                }
+                              if (!same)
+                                slot = (s + 1) & (SLOTS - 1);
+                              else
+                                { const u32 old = atomicAdd(&A[s].w, wgt);
+                                  if (old < AG_HIGH && old + wgt >= AG_HIGH)
+                                    { atomicSub(&A[s].w, AG_CUT);    // stays far above 0x7fff: still saturated
+                                      round_max += AG_CUT;
+                                    }
+                                  done = true;
+                                }
+                            }
+                          else if (kind == 1u)
+                            { if (atomicCAS(&A[s].w, 0u, AG_LOCK) == 0u)
+                                { A[s] = make_uint4(cur[0], KW > 1 ? cur[KW > 1 ? 1 : 0] : 0u,
+                                                    KW > 2 ? cur[KW > 2 ? 2 : 0] : 0u, AG_LOCK);
+                                  if (KW > 3)
+                                    B[s] = make_uint4(cur[KW > 3 ? 3 : 0], KW > 4 ? cur[KW > 4 ? 4 : 0] : 0u, 0u, 0u);
+                                  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                                  atomicExch(&A[s].w, wgt);                     // publish
+                                  created = true;
+                                  done = true;
+                                }
+                              else
+                                slot = s;                            // taken in between: look at it again
+                            }
+                          else if (kind == 2u)
+                            slot = s;                                // its key is being written: look again
+                          else
+                            slot = (slot + AG_P) & (SLOTS - 1);
+                          const u64 cm = __ballot(created);
+                          if (cm != 0ull && fk_lane() == (u32) (__ffsll((long long) cm) - 1))
+                            { const u32 k = (u32) __popcll(cm);
+                              if (atomicAdd(&sh_claimed, k) + k > (u32) LIMIT)
+                                sh_ovf = 1;
+                            }
+                        }
                     }
                 }
             }

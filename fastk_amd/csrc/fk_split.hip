@@ -62,16 +62,18 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
   __shared__ uint16_t wpre[SP_WORDS];
   __shared__ u32      keys[SP_KEYS + SP_KEYS / 16 + 1];
   u32 *slist = keys;          // the keys are dead once every thread has its window minima (step 3)
-  __shared__ uint16_t mtab[1024];
+  // (canonical rank << 15) | flip of every 10-bit 5-mer code; dead after step 2, when the same
+  // 4 KB serve as bbase / bcnt2 / lastkey (LDS per workgroup decides 5 vs 4 workgroups per CU)
+  __shared__ __attribute__((aligned(8))) u32 mtab32[1024];
   __shared__ uint8_t  mbucket[1024];
-  __shared__ u32      lastkey[SP_THREADS];
   __shared__ uint16_t sbits[SP_THREADS + 16];
   __shared__ uint16_t vbits[SP_THREADS + 16];
   __shared__ u32      bcnt[256];
-  __shared__ u32      bcnt2[256];
-  __shared__ u64      bbase[256];
   __shared__ u32      tmp32[8];
 
+  u64 *bbase   = (u64 *) mtab32;          // [256]
+  u32 *bcnt2   = mtab32 + 512;            // [256]
+  u32 *lastkey = mtab32 + 768;            // [SP_THREADS]
   const int     tid = threadIdx.x;
   const int     K   = a.kmer;
   const int     W   = K - 4;                       // 5-mer starts per k-mer = MAX_SUPER
@@ -81,11 +83,11 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
   const bool    one = (a.nbuckets == 1);           // single bucket: no per-record LDS atomics
 
   for (int i = tid; i < 1024; i += SP_THREADS)
-    { mtab[i]    = a.mtab[i];
+    { const u32 m = a.mtab[i];
+      mtab32[i]  = ((m >> 1) << 15) | (m & 1u);
       mbucket[i] = a.mbucket[i];
     }
   bcnt[tid] = 0;
-  bcnt2[tid] = 0;
 
   // ---- 1. ASCII -> 2-bit codes (MSB first) + invalid masks -------------------------------
   for (int q = tid; q < SP_WORDS; q += SP_THREADS)
@@ -142,38 +144,70 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
       }
   }
   // ---- 2. canonical 5-mer keys: (rank << 14 | position) << 1 | flip ------------------------
-  //      one thread rolls a 64-bit window over the 16 positions of a packed word
-  for (int q = tid; 16 * q < SP_TILE + W; q += SP_THREADS)
-    { const u64 x = (((u64) fwd[q]) << 32) | (u64) fwd[q + 1];
+  //      one thread rolls a 64-bit window over the 16 positions of a packed word.  With W >= 16
+  //      (k >= 20) the keys never go to LDS as such: a thread keeps the suffix minima of its own 16
+  //      keys in registers and publishes their PREFIX minima (slot 15 = the block minimum), because
+  //      a window of W positions starting in block t is  suffix(t) + whole blocks + prefix of the
+  //      block it ends in  -- three operands instead of W (step 3)
+  const bool fastmin = (W >= SP_CH);
+  const int  i0 = tid * SP_CH;
+  u32 mk[SP_CH];
+  { const int q = tid;
+    const u64 x = (((u64) fwd[q]) << 32) | (u64) fwd[q + 1];
+    u32 kk[SP_CH];
+#pragma unroll
+    for (int c = 0; c < 16; c++)
+      { const u32 v = (u32) (x >> (54 - 2 * c)) & 0x3ffu;
+        kk[c] = mtab32[v] | ((u32) (16 * q + c) << 1);
+      }
+    if (fastmin)
+      { mk[SP_CH - 1] = kk[SP_CH - 1];
+#pragma unroll
+        for (int c = SP_CH - 2; c >= 0; c--)
+          mk[c] = min(kk[c], mk[c + 1]);                 // suffix minima of the own block
+#pragma unroll
+        for (int c = 1; c < SP_CH; c++)
+          kk[c] = min(kk[c], kk[c - 1]);                 // prefix minima, published
+      }
+#pragma unroll
+    for (int c = 0; c < 16; c++)
+      keys[SP_KIDX(16 * q + c)] = kk[c];
+  }
+  if (16 * (SP_THREADS + tid) < SP_TILE + W)             // the halo blocks past the tile
+    { const int q = SP_THREADS + tid;
+      const u64 x = (((u64) fwd[q]) << 32) | (u64) fwd[q + 1];
+      u32 kk[SP_CH];
 #pragma unroll
       for (int c = 0; c < 16; c++)
-        { const int j = 16 * q + c;
-          const u32 v = (u32) (x >> (54 - 2 * c)) & 0x3ffu;
-          const u32 m = mtab[v];
-          keys[SP_KIDX(j)] = (((m >> 1) << 14) | (u32) j) << 1 | (m & 1u);
+        { const u32 v = (u32) (x >> (54 - 2 * c)) & 0x3ffu;
+          kk[c] = mtab32[v] | ((u32) (16 * q + c) << 1);
         }
+      if (fastmin)
+        {
+#pragma unroll
+          for (int c = 1; c < SP_CH; c++)
+            kk[c] = min(kk[c], kk[c - 1]);
+        }
+#pragma unroll
+      for (int c = 0; c < 16; c++)
+        keys[SP_KIDX(16 * q + c)] = kk[c];
     }
   __syncthreads();
 
   // ---- 3. sliding-window minimum for the thread's 16 k-mer starts ------------------------
-  const int i0 = tid * SP_CH;
-  u32 mk[SP_CH];
-  if (W >= SP_CH)
-    { u32 core = 0xffffffffu;
-      for (int j = i0 + SP_CH - 1; j <= i0 + W - 1; j++)
-        core = min(core, keys[SP_KIDX(j)]);
-      u32 run = 0xffffffffu;
-      mk[SP_CH - 1] = core;
+  if (fastmin)
+    { // window of start c ends at offset e = c + W - 1 from the block start: block t + (e >> 4)
+      const int q0 = (W - 1) >> 4, r0 = (W - 1) & 15;
+      u32 fa = 0xffffffffu;                                // whole blocks t+1 .. t+q0-1
+      for (int j = 1; j < q0; j++)
+        fa = min(fa, keys[SP_KIDX(16 * (tid + j) + 15)]);
+      const u32 fb = (q0 >= 1) ? min(fa, keys[SP_KIDX(16 * (tid + q0) + 15)]) : fa;   // .. t+q0
+      const int pbase = 17 * (tid + q0);                   // SP_KIDX of the first slot of block t+q0
 #pragma unroll
-      for (int c = SP_CH - 2; c >= 0; c--)
-        { run = min(run, keys[SP_KIDX(i0 + c)]);
-          mk[c] = min(core, run);
-        }
-      run = 0xffffffffu;
-#pragma unroll
-      for (int c = 1; c < SP_CH; c++)
-        { run = min(run, keys[SP_KIDX(i0 + W - 1 + c)]);
-          mk[c] = min(mk[c], run);
+      for (int c = 0; c < SP_CH; c++)
+        { const int off = r0 + c;                          // uniform: 0 .. 30
+          const u32 pre = keys[pbase + off + (off >> 4)];
+          mk[c] = min(min(mk[c], (off < 16) ? fa : fb), pre);
         }
     }
   else
@@ -203,6 +237,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
       }
   }
   lastkey[tid] = mk[SP_CH - 1];
+  bcnt2[tid]   = 0;
   vbits[tid]   = (uint16_t) vmask;
   if (tid < 16)
     { vbits[SP_THREADS + tid] = 0;        // nothing is valid past the tile
