@@ -21,7 +21,8 @@ EXPORTS = [
     "fk_device_alloc", "fk_device_free", "fk_copy_to_device", "fk_copy_to_host",
     "fk_get_sort_stats", "fk_version", "fk_count_device_reads", "fk_count_device_supermers", "fk_debug_set", "fk_group_records",
     "fk_count_presorted_kmers", "fk_split_supermers_emit", "fk_split_plan", "fk_split_planned",
-    "fk_train_block", "fk_count_unsorted_kmers", "fk_debug_get",
+    "fk_train_block", "fk_count_unsorted_kmers", "fk_debug_get", "fk_push_fastq", "fk_host_alloc",
+    "fk_host_free",
 ]
 
 
@@ -113,6 +114,9 @@ def load_library():
     L.fk_get_sort_stats.argtypes = [vp, C.POINTER(SortStats)]
     L.fk_debug_set.argtypes = [vp, C.c_char_p, i64]
     L.fk_debug_get.argtypes = [vp, C.c_char_p, C.POINTER(i64)]
+    L.fk_push_fastq.argtypes = [vp, vp, i64, C.POINTER(C.c_int), C.POINTER(i64), C.POINTER(i64)]
+    L.fk_host_alloc.argtypes = [i64, C.POINTER(vp)]
+    L.fk_host_free.argtypes = [vp]
     L.fk_count_unsorted_kmers.argtypes = [vp, vp, vp, i64, C.c_int, C.POINTER(i64), C.POINTER(i64),
                                           C.POINTER(i64), C.POINTER(vp), C.POINTER(i64)]
     L.fk_version.restype = C.c_char_p
@@ -230,6 +234,15 @@ class Context:
         b = np.ascontiguousarray(bases, dtype=np.uint8)
         o = np.ascontiguousarray(boff, dtype=np.int32)
         self._ck(self.L.fk_push_block(self.h, b.ctypes.data, o.ctypes.data, len(o) - 1, rem, tid))
+
+    def push_fastq(self, raw, phase=0):
+        """raw: bytes / uint8 array holding any piece of a FASTQ file; returns (phase, reads, bases)."""
+        a = np.frombuffer(raw, dtype=np.uint8) if isinstance(raw, (bytes, bytearray)) else \
+            np.ascontiguousarray(raw, dtype=np.uint8)
+        ph, nr, nb = C.c_int(phase), C.c_int64(0), C.c_int64(0)
+        self._ck(self.L.fk_push_fastq(self.h, a.ctypes.data, a.nbytes, C.byref(ph), C.byref(nr),
+                                      C.byref(nb)))
+        return ph.value, nr.value, nb.value
 
     def push_device(self, ptr, nbytes):
         self._ck(self.L.fk_push_device(self.h, ptr, nbytes))

@@ -683,6 +683,56 @@ extern "C" int fk_push_device(fk_ctx *ctx, const void *d_bases, int64_t nbytes)
   return (rc);
 }
 
+/* FASTQ text (any piece of a file, cut anywhere) -> reads, parsed on the device (fk_parse.hip).
+   *line_phase: 0 before the first byte of a file, carried from call to call. */
+extern "C" int fk_push_fastq(fk_ctx *ctx, const char *raw, int64_t nbytes, int *line_phase,
+                             int64_t *nreads, int64_t *nbases)
+{ if (ctx == NULL || raw == NULL || nbytes < 0 || line_phase == NULL) return (FK_EINVAL);
+  if (ctx->prm.bc_prefix > 0 || ctx->prm.exact_parts)
+    { fk_set_error(ctx, "fk_push_fastq: -bc and exact_parts need read offsets; use fk_push_block");
+      return (FK_EUNSUPPORTED);
+    }
+  if (nbytes == 0)
+    return (FK_OK);
+  int rc;
+  pthread_mutex_lock((pthread_mutex_t *) ctx->push_lock);
+  do
+    { hipSetDevice(ctx->device);
+      if ((rc = reserve_reads(ctx, nbytes + 16)) != FK_OK)
+        break;
+      void *d_raw = fk_slot(ctx, FK_SLOT_RAW, nbytes + 64);
+      if (d_raw == NULL) { rc = FK_ENOMEM; break; }
+      if (hipMemcpyAsync(d_raw, raw, (size_t) nbytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+        { fk_set_error(ctx, "fk_push_fastq: host to device copy failed");
+          rc = FK_EHIP;
+          break;
+        }
+      int64_t kept = 0, nr = 0;
+      if ((rc = fkx_parse_fastq(ctx, d_raw, nbytes, line_phase, ctx->d_reads + ctx->reads_len, &kept, &nr)) != FK_OK)
+        break;
+      ctx->reads_len += kept;
+      if (nreads) *nreads += nr;
+      if (nbases) *nbases += kept - nr;
+      if (ctx->chunk_bytes > 0 && ctx->reads_len >= ctx->chunk_bytes)
+        rc = flush_chunk(ctx);
+    }
+  while (0);
+  pthread_mutex_unlock((pthread_mutex_t *) ctx->push_lock);
+  return (rc);
+}
+
+extern "C" int fk_host_alloc(int64_t nbytes, void **ptr)
+{ if (ptr == NULL || nbytes <= 0) return (FK_EINVAL);
+  if (hipHostMalloc(ptr, (size_t) nbytes, hipHostMallocDefault) != hipSuccess)
+    { fk_set_error(NULL, "fk_host_alloc: cannot pin %lld bytes", (long long) nbytes);
+      return (FK_ENOMEM);
+    }
+  return (FK_OK);
+}
+
+extern "C" int fk_host_free(void *ptr)
+{ return (hipHostFree(ptr) == hipSuccess ? FK_OK : FK_EHIP); }
+
 // ---- whole path: split -> sort -> expand -> sort -> count ----------------------------------------
 #define FK_GROUP_PASSES 4      // hashed digit passes that group super-mers
 #define FK_LOW_BYTES    4      // key bytes sorted over all W records before equal neighbours are collapsed

@@ -1,0 +1,220 @@
+// fk_parse.hip -- FASTQ text -> 0-terminated reads, on the device.
+//
+// Replaces the per-byte state machine of the reference's reader threads for FASTQ
+// (fast_output_thread, io.c:574-759; line rules io.c:678-734: records are strictly four lines --
+// header, sequence, '+' line, qualities -- and every non-newline byte of the sequence line is a
+// base).  A byte belongs to a sequence line iff the number of newlines before it is 1 (mod 4), so
+// the classification is an exclusive scan of newline counts; the kept bytes (sequence bytes, and the
+// sequence line's newline turned into the 0 terminator that DATA_BLOCK.bases uses, FastK.h:87-98)
+// are compacted with a second scan.  Quality lines may contain the letters ACGT, which is why they
+// have to be removed by position and cannot be left to the splitter's non-ACGT rule.
+//
+//   k_fq_count  per tile of 16 KB: newlines, and the number of bytes whose local newline count is
+//               0,1,2,3 (mod 4) -- the kept bytes of the tile for each phase it can start in
+//   k_fq_scan   one workgroup: phase and output offset of every tile, totals
+//   k_fq_emit   classify again, compact through LDS, write
+#include "fk_common.h"
+
+#define FQ_THREADS 256
+#define FQ_PER     64                         // bytes per thread
+#define FQ_TILE    (FQ_THREADS * FQ_PER)
+
+// per-thread pass over its 64 bytes; c0 = newlines before the thread's first byte (mod 4 suffices)
+template <bool EMIT>
+__device__ __forceinline__ void fq_walk(const uint4 (&v)[4], int nvalid, u32 c0, u32 (&cnt)[4], u32 &nl,
+                                        u32 &reads, unsigned char *stage, u32 phase, u32 &kept)
+{ const u32 *w = (const u32 *) v;
+#pragma unroll
+  for (int i = 0; i < FQ_PER; i++)
+    { if (i < nvalid)
+        { const u32 ch = (w[i >> 2] >> (8 * (i & 3))) & 0xffu;
+          const u32 r  = (c0 + nl) & 3u;
+          if (!EMIT)
+            { cnt[0] += (r == 0u); cnt[1] += (r == 1u); cnt[2] += (r == 2u); cnt[3] += (r == 3u); }
+          else if (((phase + r) & 3u) == 1u)
+            { stage[kept] = (unsigned char) (ch == '\n' ? 0 : ch);
+              kept += 1;
+              reads += (ch == '\n');
+            }
+          nl += (ch == '\n');
+        }
+    }
+}
+
+__device__ __forceinline__ void fq_load(const unsigned char *raw, int64_t n, int64_t base, uint4 (&v)[4],
+                                        int &nvalid)
+{ nvalid = (n - base >= FQ_PER) ? FQ_PER : (n > base ? (int) (n - base) : 0);
+  if (nvalid == FQ_PER && ((uintptr_t) (raw + base) & 15) == 0)
+    {
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        v[k] = *(const uint4 *) (raw + base + 16 * k);
+    }
+  else
+    { unsigned char *b = (unsigned char *) v;
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        v[k] = make_uint4(0, 0, 0, 0);
+      for (int i = 0; i < nvalid; i++)
+        b[i] = raw[base + i];
+    }
+}
+
+// tile_info[t*8 + 0..3] = bytes of the tile with local newline count r (mod 4), [4] = newlines
+__global__ __launch_bounds__(FQ_THREADS) void k_fq_count(const unsigned char *__restrict__ raw, int64_t n,
+                                                         u32 *__restrict__ tile_info)
+{ __shared__ u32 tmp[8];
+  __shared__ u32 red[5];
+  const int64_t base = (int64_t) blockIdx.x * FQ_TILE + (int64_t) threadIdx.x * FQ_PER;
+  uint4 v[4];
+  int   nvalid;
+  fq_load(raw, n, base, v, nvalid);
+  // newlines of this thread first (cheap), block scan, then the residue census with the right start
+  u32 mynl = 0;
+  { const u32 *w = (const u32 *) v;
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+      { const u32 x = w[i] ^ 0x0a0a0a0au;                                  // zero byte <=> newline
+        const u32 z = (x - 0x01010101u) & ~x & 0x80808080u;
+        mynl += __popc(z);
+      }
+    if (nvalid < FQ_PER)
+      { mynl = 0;
+        const unsigned char *b = (const unsigned char *) v;
+        for (int i = 0; i < nvalid; i++)
+          mynl += (b[i] == '\n');
+      }
+  }
+  u32 tot;
+  const u32 c0 = fk_block_exscan_256<u32>(mynl, tmp, &tot);
+  u32 cnt[4] = { 0, 0, 0, 0 }, nl = 0, reads = 0, kept = 0;
+  fq_walk<false>(v, nvalid, c0, cnt, nl, reads, NULL, 0, kept);
+  if (threadIdx.x < 5) red[threadIdx.x] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; r++)
+    { u32 x = cnt[r];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1)
+        x += __shfl_down(x, o, 64);
+      if (fk_lane() == 0 && x)
+        atomicAdd(&red[r], x);
+    }
+  __syncthreads();
+  if (threadIdx.x < 4)
+    tile_info[(int64_t) blockIdx.x * 8 + threadIdx.x] = red[threadIdx.x];
+  if (threadIdx.x == 4)
+    tile_info[(int64_t) blockIdx.x * 8 + 4] = tot;
+}
+
+// tile_phase[t] = line phase at the start of tile t, tile_off[t] = kept bytes before it;
+// out[0] = kept bytes, out[1] = newlines (the caller derives the phase after the chunk)
+__global__ __launch_bounds__(256) void k_fq_scan(const u32 *__restrict__ tile_info, int64_t ntiles, u32 phase0,
+                                                 u32 *__restrict__ tile_phase, u64 *__restrict__ tile_off,
+                                                 u64 *__restrict__ out)
+{ __shared__ u64 tmp64[8];
+  __shared__ u32 tmp32[8];
+  u64 carry_off = 0;
+  u32 carry_nl = 0;
+  for (int64_t b = 0; b < ntiles; b += 256)
+    { const int64_t t = b + threadIdx.x;
+      const u32 mynl = (t < ntiles) ? tile_info[t * 8 + 4] : 0u;
+      u32 totnl;
+      const u32 exnl = fk_block_exscan_256<u32>(mynl, tmp32, &totnl);
+      const u32 ph = (phase0 + carry_nl + exnl) & 3u;
+      const u64 mykeep = (t < ntiles) ? (u64) tile_info[t * 8 + ((1u - ph) & 3u)] : 0ull;
+      u64 totk;
+      const u64 exk = fk_block_exscan_256<u64>(mykeep, tmp64, &totk);
+      if (t < ntiles)
+        { tile_phase[t] = ph;
+          tile_off[t] = carry_off + exk;
+        }
+      carry_off += totk;
+      carry_nl = (carry_nl + totnl) & 3u;          // only the phase matters; the total is summed below
+      if (threadIdx.x == 0)
+        out[1] += totnl;
+    }
+  if (threadIdx.x == 0)
+    out[0] = carry_off;
+}
+
+__global__ __launch_bounds__(FQ_THREADS) void k_fq_emit(const unsigned char *__restrict__ raw, int64_t n,
+                                                        const u32 *__restrict__ tile_phase,
+                                                        const u64 *__restrict__ tile_off,
+                                                        unsigned char *__restrict__ dst, u64 *__restrict__ nreads)
+{ __shared__ unsigned char stage[FQ_TILE];
+  __shared__ u32 tmp[8];
+  __shared__ u32 s_reads;
+  const int64_t base = (int64_t) blockIdx.x * FQ_TILE + (int64_t) threadIdx.x * FQ_PER;
+  uint4 v[4];
+  int   nvalid;
+  fq_load(raw, n, base, v, nvalid);
+  if (threadIdx.x == 0) s_reads = 0;
+  // newline prefix as in k_fq_count
+  u32 mynl = 0;
+  { const unsigned char *b = (const unsigned char *) v;
+    if (nvalid == FQ_PER)
+      { const u32 *w = (const u32 *) v;
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+          { const u32 x = w[i] ^ 0x0a0a0a0au;
+            mynl += __popc((x - 0x01010101u) & ~x & 0x80808080u);
+          }
+      }
+    else
+      for (int i = 0; i < nvalid; i++)
+        mynl += (b[i] == '\n');
+  }
+  u32 tot;
+  const u32 c0 = fk_block_exscan_256<u32>(mynl, tmp, &tot);
+  const u32 phase = tile_phase[blockIdx.x];
+  // how many bytes this thread keeps, then where they go inside the tile's output
+  u32 cnt[4] = { 0, 0, 0, 0 }, nl = 0, reads = 0, kept = 0;
+  fq_walk<false>(v, nvalid, c0, cnt, nl, reads, NULL, 0, kept);
+  const u32 want = (1u - phase) & 3u;               // local newline count (mod 4) of the kept bytes
+  const u32 mine = (want == 0u) ? cnt[0] : (want == 1u) ? cnt[1] : (want == 2u) ? cnt[2] : cnt[3];
+  u32 tkept;
+  const u32 ex = fk_block_exscan_256<u32>(mine, tmp, &tkept);
+  nl = 0; kept = 0;
+  fq_walk<true>(v, nvalid, c0, cnt, nl, reads, stage + ex, phase, kept);
+  if (reads)
+    atomicAdd(&s_reads, reads);
+  __syncthreads();
+  unsigned char *o = dst + tile_off[blockIdx.x];
+  for (u32 i = threadIdx.x; i < tkept; i += FQ_THREADS)
+    o[i] = stage[i];
+  if (threadIdx.x == 0 && s_reads)
+    atomicAdd(nreads, (u64) s_reads);
+}
+
+/* d_raw: nbytes of FASTQ text on the device; *phase: newlines seen so far in this file (mod 4), updated.
+   The sequence lines, each ended by a 0, are written to d_dst (capacity >= nbytes); *nkept bytes. */
+int fkx_parse_fastq(fk_ctx *ctx, const void *d_raw, int64_t nbytes, int *phase, void *d_dst,
+                    int64_t *nkept, int64_t *nreads)
+{ hipStream_t s = ctx->stream;
+  *nkept = 0; *nreads = 0;
+  if (nbytes <= 0)
+    return (FK_OK);
+  const int64_t ntiles = (nbytes + FQ_TILE - 1) / FQ_TILE;
+  u32 *d_info  = (u32 *) fk_slot(ctx, FK_SLOT_FQ_INFO, ntiles * 8 * 4);
+  u32 *d_phase = (u32 *) fk_slot(ctx, FK_SLOT_FQ_PHASE, ntiles * 4);
+  u64 *d_off   = (u64 *) fk_slot(ctx, FK_SLOT_FQ_OFF, ntiles * 8);
+  if (d_info == NULL || d_phase == NULL || d_off == NULL)
+    return (FK_ENOMEM);
+  u64 *d_out = ctx->d_scratch + 2048;              // [0] kept bytes [1] newlines [2] reads
+  FK_HIP(ctx, hipMemsetAsync(d_out, 0, 3 * sizeof(u64), s));
+  hipLaunchKernelGGL(k_fq_count, dim3((unsigned) ntiles), dim3(FQ_THREADS), 0, s,
+                     (const unsigned char *) d_raw, nbytes, d_info);
+  hipLaunchKernelGGL(k_fq_scan, dim3(1), dim3(256), 0, s, (const u32 *) d_info, ntiles, (u32) (*phase & 3),
+                     d_phase, d_off, d_out);
+  hipLaunchKernelGGL(k_fq_emit, dim3((unsigned) ntiles), dim3(FQ_THREADS), 0, s,
+                     (const unsigned char *) d_raw, nbytes, (const u32 *) d_phase, (const u64 *) d_off,
+                     (unsigned char *) d_dst, d_out + 2);
+  FK_LAUNCH_CHECK(ctx);
+  FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch, d_out, 3 * sizeof(u64), hipMemcpyDeviceToHost, s));
+  FK_HIP(ctx, hipStreamSynchronize(s));
+  *nkept  = (int64_t) ctx->h_scratch[0];
+  *phase  = (int) ((*phase + ctx->h_scratch[1]) & 3);
+  *nreads = (int64_t) ctx->h_scratch[2];
+  return (FK_OK);
+}

@@ -12,6 +12,8 @@
  * them to fk_push_block -- the call that replaces Distribute_Block (FastK.h:123).  Everything
  * per-base and per-record runs on the GPU inside the library.
  *
+ * FASTQ text is parsed on the GPU (fk_push_fastq) unless -bc, -x or -H (extension: host parser) is given.
+ *
  * -x (extension, no reference counterpart): exact part files -- replays the reference's own super-mer
  * rule so that the hidden .ktab parts are cut at the reference's first bytes (fk_params.exact_parts);
  * without it the table's canonical stream is identical but the part boundaries are our own.
@@ -37,6 +39,7 @@
 static char *Prog_Name = "FastK_amd";
 
 static int       KMER = 40, NTHREADS = 4, DO_TABLE = 0, BC_PREFIX = 0, VERBOSE = 0, EXACT = 0, MEM_GB = 0;
+static int       HOST_PARSE = 0;
 static char     *OUT_NAME = NULL;
 
 typedef struct
@@ -116,6 +119,33 @@ static int classify(const char *path, char **root, char **dir)
   return (-1);
 }
 
+/* FASTQ: hand the file text to the library in large pieces; the record structure is resolved on the
+   GPU (fk_push_fastq).  Used unless -bc / -x ask for host-side read offsets. */
+#define RAW_BYTES (64 << 20)
+
+static void scan_fastq_on_device(Feeder *f, const char *path)
+{ gzFile in = gzopen(path,"rb");
+  static char *raw = NULL;
+  int     phase = 0, n;
+
+  if (in == NULL)
+    { fprintf(stderr,"%s: Cannot open %s for reading\n",Prog_Name,path);
+      exit (1);
+    }
+  if (raw == NULL && fk_host_alloc(RAW_BYTES,(void **) &raw) != FK_OK)
+    die(NULL,"pinned read buffer");
+  gzbuffer(in,1 << 20);
+  flush_block(f,0);                        /* keep the order of reads across input files */
+  while ((n = gzread(in,raw,RAW_BYTES)) > 0)
+    { int64_t nr = 0, nb = 0;
+      if (fk_push_fastq(f->ctx,raw,n,&phase,&nr,&nb) != FK_OK)
+        die(f->ctx,"fk_push_fastq");
+      f->totrds += nr;
+      f->totbps += nb;
+    }
+  gzclose(in);
+}
+
 static void scan_file(Feeder *f, const char *path, int fastq)
 { gzFile  in = gzopen(path,"rb");
   static unsigned char buf[1 << 20];
@@ -168,6 +198,7 @@ int main(int argc, char *argv[])
           break;
         case 'v': VERBOSE = 1; break;
         case 'x': EXACT = 1; break;
+        case 'H': HOST_PARSE = 1; break;       /* extension: parse FASTQ on the host as well */
         case 'N': OUT_NAME = argv[i]+2; break;
         case 'M': MEM_GB = atoi(argv[i]+2); break;
         case 'P': break;
@@ -250,7 +281,10 @@ int main(int argc, char *argv[])
         { root = r; dir = d; }            /* outputs take the first file's root, FastK.c:402-405 */
       else
         { free(r); free(d); }
-      scan_file(&feed,argv[i],q);
+      if (q == 1 && !EXACT && BC_PREFIX == 0 && !HOST_PARSE)
+        scan_fastq_on_device(&feed,argv[i]);
+      else
+        scan_file(&feed,argv[i],q);
     }
   flush_block(&feed,0);
   if (OUT_NAME != NULL)                   /* -N, FastK.c:406-409 */

@@ -293,6 +293,33 @@ def test_chunked_ingest_matches_golden(name, nb):
         util.check_against_golden(case, res.hist, res.max_inst, res.table)
 
 
+@pytest.mark.parametrize("name", ["synth_illumina_k40_t1_T4", "edge_k40_t1_T4", "synth_hifi_k40_t4_T8",
+                                  "edge_k51_t1_T4"])
+def test_fastq_parsed_on_device_matches_golden(name, tmp_path):
+    """fk_push_fastq: raw FASTQ text cut into pieces at arbitrary bytes (inside headers, sequences,
+    quality lines that contain the letters ACGT) gives the reads the host parser gives."""
+    case, bases, boff = util.load_case(name)
+    parts = []
+    qpat = b"@ACGT+acgt>#I" * 4000
+    for i in range(len(boff) - 1):
+        seq = bases[boff[i]:boff[i + 1] - 1].tobytes()
+        parts.append(b"@ACGTACGTACGTACGTACGTACGTACGTACGTACGTACGTACGTACGT r%d\n" % i + seq + b"\n+ACGT\n"
+                     + qpat[i % 7:i % 7 + len(seq)] + b"\n")
+    text = b"".join(parts)
+    rng = np.random.default_rng(9)
+    with fastk_amd.Context(kmer=case["k"], table_cutoff=case["cutoff"], nthreads=case["T"]) as ctx:
+        ph, nr, nb, pos = 0, 0, 0, 0
+        while pos < len(text):
+            n = int(rng.integers(1, 200000))
+            ph, r, b = ctx.push_fastq(text[pos:pos + n], ph)
+            nr += r; nb += b
+            pos += n
+        assert nr == len(boff) - 1
+        assert nb == len(bases) - (len(boff) - 1)
+        res = ctx.finish()
+        util.check_against_golden(case, res.hist, res.max_inst, res.table)
+
+
 def test_cli_memory_option(tmp_path):
     """FastK_amd -M<GB> (HBM budget: bucket streaming + chunked ingest) gives the same files."""
     import hashlib, os, subprocess
