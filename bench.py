@@ -177,8 +177,9 @@ def main():
     ms_step = 1e3 * dt / args.steps
     value = ninst / (dt / args.steps)
 
-    # roofline of the dominant kernel: k_rx_scatter on the W weighted k-mer records (the four
-    # least-significant key-byte passes that run before collapsing), one stable 8-bit digit pass per launch.  Algorithmic bytes per launch = 2 * n * R (records read once and written
+    # roofline of the dominant kernel: k_rx_scatter on the W weighted k-mer records (the two hashed
+    # digit passes that bring equal k-mers into one of 65,536 bins before they are summed in LDS),
+    # one stable 8-bit digit pass per launch.  Algorithmic bytes per launch = 2 * n * R (records read once and written
     # once at the reference width R = KMER_WORD); duration = HIP event pair around every scatter
     # launch on the library's stream, averaged over the launches of the last step.  pass_total adds
     # the per-pass helper kernels (digit-stream histogram + two scans) that feed it.
@@ -197,7 +198,7 @@ def main():
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
         if abs(pm["weighted_kmers"] - n_pass) <= 5e-3 * n_pass and w.kmer_word == 12:
-            cands = [v for k, v in pm["kernels"].items() if k.startswith("_Z12k_rx_scatterILi3ELi12ELb0E")]
+            cands = [v for k, v in pm["kernels"].items() if k.startswith("_Z12k_rx_scatterILi3ELi12ELb")]
             traffic = max(c["traffic_bytes"] for c in cands)       # the launches over all W records
     except Exception:
         traffic = None
@@ -211,11 +212,11 @@ def main():
                     pass_total=dict(avg_ms=round(avg_pass_ms, 4),
                                     achieved=gbs(n_pass, w.kmer_word, avg_pass_ms),
                                     note="scatter + k_rx_tilehist + k_rx_chunkscan + k_rx_superscan"),
-                    final_sort=dict(records=int(loc.ncollapsed), launches=int(loc.passes_final),
+                    table_sort=dict(records=int(loc.ncollapsed), launches=int(loc.passes_final),
                                     achieved_pass_total=gbs(loc.ncollapsed, w.kmer_word,
                                                             loc.ms_pass_final / max(loc.passes_final, 1))),
                     supermer_pass=dict(
-                        kernel="k_rx_scatter<5,8,hashed> (super-mer records, R=%d B)" % w.smer_word,
+                        kernel="k_rx_scatter_w<5,4,hashed> (super-mer records, R=%d B)" % w.smer_word,
                         records=int(loc.nsuper), launches=int(loc.passes_super),
                         avg_launch_ms=round(loc.ms_scatter_super / nps, 4),
                         achieved=gbs(loc.nsuper, w.smer_word, loc.ms_scatter_super / nps),
