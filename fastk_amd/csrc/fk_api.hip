@@ -801,7 +801,8 @@ static int count_bucket(fk_ctx *ctx, void *sm_in, int64_t ns, fk_result *res, bo
           if ((km_a = fk_slot(ctx, FK_SLOT_KM_A, want * w.kmer_stride)) == NULL
               || (km_b = fk_slot(ctx, FK_SLOT_KM_B, want * w.kmer_stride)) == NULL)
             { rc = FK_ENOMEM; break; }
-          if ((rc = fkx_expand(ctx, sm_sorted, ns, km_a, nw, &nw, &nd, &ovf, true)) != FK_OK) break;
+          if ((rc = fkx_expand(ctx, sm_sorted, ns, km_a, nw, &nw, &nd, &ovf, true,
+                               ctx->dbg_kmer_stage != 1 && exact_roff == NULL)) != FK_OK) break;
         }
       int64_t exact_census[256];
       if (exact_roff != NULL && nw > 0

@@ -79,6 +79,8 @@ struct fk_ctx
   int        dbg_aggr_limit;      // > 0: pretend the LDS table of fk_aggr.hip takes only this many k-mers
   int64_t    aggr_extra_rounds;   // bins x rounds that had to be split in the last aggregation
   int        num_cus;
+  int64_t    pre_hist_n;       // > 0: d_digit_hist (hash digits 0,1) and the DIG_A stream are valid for
+                               // this many records (written by the expansion), see lsd_sort_stream_t
   int64_t    ex_nweighted, ex_ndistinct;   // totals of the last expand sizing call
   void      *slot_ptr[FK_NSLOTS];
   int64_t    slot_cap[FK_NSLOTS];
@@ -123,7 +125,8 @@ int fkx_first_byte_census(fk_ctx *ctx, const void *d_recs, int64_t n, int rsize,
 int fkx_split_fast(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void **d_out, int64_t *nsuper,
                    int64_t *ninst, int64_t *bucket_counts, int64_t *bucket_offsets);
 int fkx_expand(fk_ctx *ctx, const void *d_smers, int64_t nsuper, void *d_out, int64_t cap,
-               int64_t *nweighted, int64_t *ndistinct, int64_t *overflow, bool reuse_counts = false);
+               int64_t *nweighted, int64_t *ndistinct, int64_t *overflow, bool reuse_counts = false,
+               bool hash_stream = false);
 int fkx_count(fk_ctx *ctx, const void *d_kmers, int64_t nweighted, int cutoff, int sorted_bytes,
               int64_t *hist, int64_t *max_inst, int64_t *ndistinct,
               void *d_table, int64_t cap, int64_t *ntable);
@@ -151,23 +154,30 @@ __device__ __forceinline__ u64 fk_lanemask_lt()
 // 64-bit mix (a, b) of the first hbytes bytes of a record of RW dwords: all of a super-mer record;
 // the KMER_BYTES key of a weighted k-mer record, so that equal k-mers with different weights meet.
 // Hashed digit p of the radix engine is byte p of b (p < 4) or byte p-4 of a.
+// Two words per 32x32->64 multiply (v_mad_u64_u32), the halves of the product carried into the next
+// one, wyhash-fashion: 3 wide multiplies for a 12-byte record.  Every hot kernel is bound by
+// instruction issue and 32-bit integer multiplies are quarter rate, so the hash is kept this short;
+// nothing depends on its quality beyond evenly filled bins (identical keys always meet).
 template <int RW>
 __device__ __forceinline__ void fk_rec_hash(const u32 *r, int hbytes, u32 &a_out, u32 &b_out)
 { const int full = hbytes >> 2;
   const u32 last = (hbytes & 3) ? ((1u << (8 * (hbytes & 3))) - 1u) : 0u;
-  u32 a = 0x9E3779B9u, b = 0x85EBCA6Bu;
+  u32 lo = 0x9E3779B9u ^ (u32) hbytes, hi = 0x85EBCA6Bu;
 #pragma unroll
-  for (int w = 0; w < RW; w++)
-    { const u32 x = (w < full) ? r[w] : (w == full) ? (r[w] & last) : 0u;
-      a = (a ^ x) * 0xCC9E2D51u;
-      a = (a << 15) | (a >> 17);
-      b = (b + x) * 0x1B873593u;
-      b = ((b << 13) | (b >> 19)) ^ a;
+  for (int w = 0; w < RW; w += 2)
+    { const u32 x0 = (w < full) ? r[w] : (w == full) ? (r[w] & last) : 0u;
+      const u32 x1 = (w + 1 >= RW) ? 0x27D4EB2Fu
+                   : (w + 1 < full) ? r[w + 1 < RW ? w + 1 : 0]
+                   : (w + 1 == full) ? (r[w + 1 < RW ? w + 1 : 0] & last) : 0u;
+      const u64 p = (u64) (x0 ^ lo ^ 0xA0761D65u) * (u64) (x1 ^ hi ^ 0xE7037ED1u);
+      lo = (u32) p;
+      hi = (u32) (p >> 32);
     }
-  a ^= b >> 16; a *= 0x85EBCA6Bu;
-  b ^= a >> 13; b *= 0xC2B2AE35u;
-  a ^= b >> 15;
-  a_out = a; b_out = b;
+  const u64 p = (u64) (lo ^ 0x8EBC6AF1u) * (u64) (hi ^ 0x589965CDu);
+  u32 a = (u32) p;
+  b_out = (u32) (p >> 32) ^ a;
+  a ^= a >> 15;
+  a_out = a ^ (u32) (p >> 47);
 }
 
 // exclusive scan of one value per thread over a 256-thread block; returns exclusive prefix,

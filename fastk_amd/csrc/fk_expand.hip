@@ -79,15 +79,26 @@ __global__ __launch_bounds__(EX_THREADS) void k_ex_expand(const u32 *__restrict_
                                                           int kmer, int len_byte,
                                                           const u64 *__restrict__ tile_koff,
                                                           u32 *__restrict__ out,
-                                                          u64 *__restrict__ overflow)
+                                                          u64 *__restrict__ overflow, int64_t ntiles,
+                                                          uint8_t *__restrict__ dig,
+                                                          u64 *__restrict__ dhist, int kbytes)
 { __shared__ __attribute__((aligned(16))) u32 recs[(EX_TILE + 1) * RW];   // big-endian value words (+1 guard)
+  __shared__ u32 lh[512];                // dig != NULL: histograms of hash digits 0 and 1 of the k-mers
   __shared__ u32 hoff[EX_TILE + 1];      // first k-mer of head h inside the tile
   __shared__ uint16_t hrec[EX_TILE];     // record index of head h
   __shared__ uint16_t hct[EX_TILE];      // its clipped multiplicity
   __shared__ u32 tmp[8];
   __shared__ u32 s_runk, s_runh;
 
-  const int64_t t0 = (int64_t) blockIdx.x * EX_TILE;
+  if (dig != NULL)
+    { lh[threadIdx.x] = 0;
+      lh[256 + threadIdx.x] = 0;
+    }
+  // persistent workgroups: the digit histograms are flushed once per workgroup, not once per tile
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
+  {
+  __syncthreads();
+  const int64_t t0 = tile * EX_TILE;
   const int     tn = (n - t0 < EX_TILE) ? (int) (n - t0) : EX_TILE;
   fk_stage16<(EX_TILE * RW + 1023) / 1024, true>(recs, sm + t0 * RW, tn * RW);
   if (threadIdx.x < RW)
@@ -171,7 +182,8 @@ __global__ __launch_bounds__(EX_THREADS) void k_ex_expand(const u32 *__restrict_
   __syncthreads();
   const int padb  = 32 * KN - 2 * kmer;           // unused low bits of the last k-mer word
   const u32 lastm = (padb == 0) ? 0xffffffffu : ~((1u << padb) - 1u);
-  u32 *gout = out + tile_koff[blockIdx.x] * (u64) OW;
+  const u64 kbase = tile_koff[tile];
+  u32 *gout = out + kbase * (u64) OW;
 
   // every thread emits EX_G CONSECUTIVE k-mers: one binary search for the first, after that the
   // next k-mer of the same super-mer costs a fresh forward window (ex_bits) and a two-bit roll of
@@ -247,16 +259,32 @@ __global__ __launch_bounds__(EX_THREADS) void k_ex_expand(const u32 *__restrict_
 #pragma unroll
           for (int q = 0; q < OW; q++)
             x.w[q] = (q < KN) ? __builtin_bswap32(use_f ? f[q < KN ? q : 0] : r[q < KN ? q : 0]) : 0u;
+          if (dig != NULL)
+            { // the k-mer stage groups these records by a hash of their key bytes next: hand it the
+              // first digit stream and the histograms of its two digits (saves a pass over W)
+              u32 ha, hb;
+              fk_rec_hash<OW>(x.w, kbytes, ha, hb);
+              atomicAdd(&lh[hb & 0xffu], 1u);
+              atomicAdd(&lh[256 + ((hb >> 8) & 0xffu)], 1u);
+              dig[kbase + j] = (uint8_t) (hb & 0xffu);
+            }
           x.w[OW - 1] |= ct << 16;                     // uint16 weight in the record's last two bytes
           *(ex_out<OW> *) (gout + (u64) j * OW) = x;
         }
+    }
+  }
+  if (dig != NULL)
+    { __syncthreads();
+      if (lh[threadIdx.x])       atomicAdd(&dhist[threadIdx.x], (u64) lh[threadIdx.x]);
+      if (lh[256 + threadIdx.x]) atomicAdd(&dhist[256 + threadIdx.x], (u64) lh[256 + threadIdx.x]);
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 template <int RW>
 static int expand_t(fk_ctx *ctx, const void *d_smers, int64_t n, void *d_out, int64_t cap,
-                    int64_t *nweighted, int64_t *ndistinct, int64_t *overflow, bool reuse_counts)
+                    int64_t *nweighted, int64_t *ndistinct, int64_t *overflow, bool reuse_counts,
+                    bool hash_stream)
 { hipStream_t s = ctx->stream;
   const int   K = ctx->prm.kmer;
   const int   kn = (2 * K + 31) / 32;
@@ -311,9 +339,18 @@ static int expand_t(fk_ctx *ctx, const void *d_smers, int64_t n, void *d_out, in
           break;
         }
 #define EX_LAUNCH(KN, OW)                                                                          \
-      hipLaunchKernelGGL((k_ex_expand<RW, KN, OW>), dim3((unsigned) ntiles), dim3(EX_THREADS), 0, s,   \
+      hipLaunchKernelGGL((k_ex_expand<RW, KN, OW>), dim3((unsigned) std::min<int64_t>(ntiles, egrid)),  \
+                         dim3(EX_THREADS), 0, s,                                                        \
                          (const u32 *) d_smers, n, K, len_byte, (const u64 *) d_koff, (u32 *) d_out,   \
-                         d_tot + 2)
+                         d_tot + 2, ntiles, d_dig, ctx->d_digit_hist, ctx->wid.kmer_bytes)
+      // hash_stream: also emit what the hashed grouping of the k-mers needs (digit stream + histograms)
+      uint8_t *d_dig = NULL;
+      const int64_t egrid = 8ll * (ctx->num_cus > 0 ? ctx->num_cus : 256);
+      if (hash_stream)
+        { d_dig = (uint8_t *) fk_slot(ctx, FK_SLOT_DIG_A, *nweighted + 64);
+          if (d_dig == NULL) { rc = FK_ENOMEM; break; }
+          if (hipMemsetAsync(ctx->d_digit_hist, 0, 32 * 256 * sizeof(u64), s) != hipSuccess) { rc = FK_EHIP; break; }
+        }
       if (ow != kn && ow != kn + 1)
         { fk_set_error(ctx, "k = %d: %d k-mer words do not fit records of %d words", K, kn, ow);
           rc = FK_EUNSUPPORTED;
@@ -335,6 +372,8 @@ static int expand_t(fk_ctx *ctx, const void *d_smers, int64_t n, void *d_out, in
           || hipStreamSynchronize(s) != hipSuccess)
         { rc = FK_EHIP; break; }
       *overflow = (int64_t) ctx->h_scratch[0];
+      if (hash_stream)
+        ctx->pre_hist_n = *nweighted;
     }
   while (0);
   if (rc == FK_EHIP)
@@ -343,15 +382,16 @@ static int expand_t(fk_ctx *ctx, const void *d_smers, int64_t n, void *d_out, in
 }
 
 int fkx_expand(fk_ctx *ctx, const void *d_smers, int64_t nsuper, void *d_out, int64_t cap,
-               int64_t *nweighted, int64_t *ndistinct, int64_t *overflow, bool reuse_counts)
+               int64_t *nweighted, int64_t *ndistinct, int64_t *overflow, bool reuse_counts,
+               bool hash_stream)
 { switch (ctx->wid.smer_stride >> 2)
-  { case 2: return expand_t<2>(ctx, d_smers, nsuper, d_out, cap, nweighted, ndistinct, overflow, reuse_counts);
-    case 3: return expand_t<3>(ctx, d_smers, nsuper, d_out, cap, nweighted, ndistinct, overflow, reuse_counts);
-    case 4: return expand_t<4>(ctx, d_smers, nsuper, d_out, cap, nweighted, ndistinct, overflow, reuse_counts);
-    case 5: return expand_t<5>(ctx, d_smers, nsuper, d_out, cap, nweighted, ndistinct, overflow, reuse_counts);
-    case 6: return expand_t<6>(ctx, d_smers, nsuper, d_out, cap, nweighted, ndistinct, overflow, reuse_counts);
-    case 7: return expand_t<7>(ctx, d_smers, nsuper, d_out, cap, nweighted, ndistinct, overflow, reuse_counts);
-    case 8: return expand_t<8>(ctx, d_smers, nsuper, d_out, cap, nweighted, ndistinct, overflow, reuse_counts);
+  { case 2: return expand_t<2>(ctx, d_smers, nsuper, d_out, cap, nweighted, ndistinct, overflow, reuse_counts, hash_stream);
+    case 3: return expand_t<3>(ctx, d_smers, nsuper, d_out, cap, nweighted, ndistinct, overflow, reuse_counts, hash_stream);
+    case 4: return expand_t<4>(ctx, d_smers, nsuper, d_out, cap, nweighted, ndistinct, overflow, reuse_counts, hash_stream);
+    case 5: return expand_t<5>(ctx, d_smers, nsuper, d_out, cap, nweighted, ndistinct, overflow, reuse_counts, hash_stream);
+    case 6: return expand_t<6>(ctx, d_smers, nsuper, d_out, cap, nweighted, ndistinct, overflow, reuse_counts, hash_stream);
+    case 7: return expand_t<7>(ctx, d_smers, nsuper, d_out, cap, nweighted, ndistinct, overflow, reuse_counts, hash_stream);
+    case 8: return expand_t<8>(ctx, d_smers, nsuper, d_out, cap, nweighted, ndistinct, overflow, reuse_counts, hash_stream);
     default:
       fk_set_error(ctx, "super-mer stride %d not built", ctx->wid.smer_stride);
       return (FK_EUNSUPPORTED);

@@ -960,8 +960,15 @@ static int lsd_sort_stream_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, c
   u32 *chunkpfx = chunktot + nchunks * 256;
   u64 *superpfx = supertot + nsuper * 256;
 
-  FK_HIP(ctx, hipMemsetAsync(ctx->d_digit_hist, 0, 32 * 256 * sizeof(u64), s));
+  // the producer of the records (k_ex_expand) may have left the histograms of hash digits 0 and 1
+  // and the stream of digit 0 behind
+  const bool pre = HASHED && ctx->pre_hist_n == n && nbytes <= 2 && bytes[0] == 0
+                   && (nbytes < 2 || bytes[1] == 1) && hbytes == ctx->wid.kmer_bytes;
+  ctx->pre_hist_n = 0;
+  if (!pre)
+    FK_HIP(ctx, hipMemsetAsync(ctx->d_digit_hist, 0, 32 * 256 * sizeof(u64), s));
   FK_HIP(ctx, hipEventRecord(ctx->ev0, s));
+  if (!pre)
   { int64_t nb = (n + RX_THREADS - 1) / RX_THREADS;
     if (nb > 2048) nb = 2048;
     // the first executed pass is not known before the histograms are: emit the stream of bytes[0]
