@@ -641,3 +641,39 @@ def test_reference_main_over_gpu_shim(name, fmt, tmp_path):
     for fname, digest in case["expected"]["file_sha256"].items():
         got = hashlib.sha256(open(tmp_path / fname, "rb").read()).hexdigest()
         assert got == digest, fname
+
+
+# ------------------------------------------------------------------------------ full size
+def test_full_size_properties_configs1():
+    """BASELINE configs[1] at full size (33.3 M reads of 150 bp, 3.7 G k-mer instances): no oracle
+    finishes this in seconds, so the run is checked through properties that do not depend on size:
+    conservation (every k-mer instance is counted exactly once: sum_c c*hist[c] + max_inst ==
+    instances), distinct k-mers == sum(hist) == table entries at cutoff 1, strictly increasing
+    table, table counts reproduce the histogram, and the bucket-streamed run (4 buckets, other code
+    path: planned split, per-bucket aggregation, union sort) gives the identical histogram and table."""
+    L, glen, k = 150, 100_000_000, 40
+    nreads = int(50 * glen / L)
+    nbytes = nreads * (L + 1)
+    inst = nreads * (L - k + 1)
+    results = []
+    for nb in (1, 4):
+        with fastk_amd.Context(kmer=k, table_cutoff=1, nbuckets=nb) as ctx:
+            buf, n = ctx.synth_reads(20251001, glen, L, 1000, 0, nreads)
+            assert n == nbytes
+            res = ctx.count_device_reads(buf.ptr, nbytes, fetch_table=True)
+            buf.free()
+        h = res.hist.astype(np.int64)
+        assert res.ninst == inst
+        assert int((h[1:0x7fff] * np.arange(1, 0x7fff)).sum()) + int(res.max_inst) == inst
+        assert res.ndistinct == int(h.sum()) == res.ntable == len(res.table)
+        results.append(res)
+    a, b = results
+    assert np.array_equal(a.hist, b.hist) and a.max_inst == b.max_inst
+    assert np.array_equal(a.table, b.table)
+    t = a.table
+    # strictly increasing keys: compare as big-endian integers, 8 + 2 bytes
+    hi = t[:, :8].copy().view(">u8").ravel()
+    lo = t[:, 8:10].copy().view(">u2").ravel()
+    assert np.all((hi[1:] > hi[:-1]) | ((hi[1:] == hi[:-1]) & (lo[1:] > lo[:-1])))
+    cnt = t[:, 10:12].copy().view("<u2").ravel()
+    assert np.array_equal(np.bincount(cnt, minlength=0x8000)[1:], a.hist[1:])
