@@ -138,6 +138,8 @@ def main():
                                  reads.data_ptr()))
     torch.cuda.synchronize()
     engine = shard.HipEngine(ctx, dev)
+    if sharded:
+        engine.train_buckets(reads[:nbytes])          # scheme set-up, like Determine_Scheme: not a step
 
     def step(verify=False):
         if not sharded:

@@ -22,7 +22,7 @@ EXPORTS = [
     "fk_get_sort_stats", "fk_version", "fk_count_device_reads", "fk_count_device_supermers", "fk_debug_set", "fk_group_records",
     "fk_count_presorted_kmers", "fk_split_supermers_emit", "fk_split_plan", "fk_split_planned",
     "fk_train_block", "fk_count_unsorted_kmers", "fk_debug_get", "fk_push_fastq", "fk_host_alloc",
-    "fk_host_free",
+    "fk_host_free", "fk_bucket_census", "fk_set_bucket_weights",
 ]
 
 
@@ -117,6 +117,8 @@ def load_library():
     L.fk_push_fastq.argtypes = [vp, vp, i64, C.POINTER(C.c_int), C.POINTER(i64), C.POINTER(i64)]
     L.fk_host_alloc.argtypes = [i64, C.POINTER(vp)]
     L.fk_host_free.argtypes = [vp]
+    L.fk_bucket_census.argtypes = [vp, vp, i64, C.POINTER(i64)]
+    L.fk_set_bucket_weights.argtypes = [vp, C.POINTER(i64)]
     L.fk_count_unsorted_kmers.argtypes = [vp, vp, vp, i64, C.c_int, C.POINTER(i64), C.POINTER(i64),
                                           C.POINTER(i64), C.POINTER(vp), C.POINTER(i64)]
     L.fk_version.restype = C.c_char_p
@@ -234,6 +236,18 @@ class Context:
         b = np.ascontiguousarray(bases, dtype=np.uint8)
         o = np.ascontiguousarray(boff, dtype=np.int32)
         self._ck(self.L.fk_push_block(self.h, b.ctypes.data, o.ctypes.data, len(o) - 1, rem, tid))
+
+    def bucket_census(self, sample):
+        """sample: uint8 array of reads (host).  Returns the int64[1024] work census per minimizer rank."""
+        a = np.ascontiguousarray(sample, dtype=np.uint8)
+        counts = np.zeros(1024, dtype=np.int64)
+        self._ck(self.L.fk_bucket_census(self.h, a.ctypes.data, a.nbytes,
+                                         counts.ctypes.data_as(C.POINTER(C.c_int64))))
+        return counts
+
+    def set_bucket_weights(self, counts):
+        c = np.ascontiguousarray(counts, dtype=np.int64)
+        self._ck(self.L.fk_set_bucket_weights(self.h, c.ctypes.data_as(C.POINTER(C.c_int64))))
 
     def push_fastq(self, raw, phase=0):
         """raw: bytes / uint8 array holding any piece of a FASTQ file; returns (phase, reads, bases)."""

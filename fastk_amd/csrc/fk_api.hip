@@ -8,6 +8,7 @@
 #include <fcntl.h>
 #include <unistd.h>
 #include <algorithm>
+#include <vector>
 
 static char g_last_error[512] = "";
 
@@ -113,6 +114,75 @@ static void build_minimizer_tables(uint16_t *mtab, uint8_t *mbucket, int nbucket
       mbucket[r] = (uint8_t) (q < nbuckets ? q : 2 * nbuckets - 1 - q);
       p += 1;
     }
+}
+
+// ---- bucket training (the role of Determine_Scheme's trie balancing, split.c:617-766) -----------
+// Host-side, on a sample of reads: how much work each canonical minimizer rank attracts.  counts[r]
+// += 4 * super-mer starts + k-mer instances whose minimizer has rank r.
+extern "C" int fk_bucket_census(fk_ctx *ctx, const char *bases, int64_t nbytes, int64_t *counts)
+{ if (ctx == NULL || bases == NULL || counts == NULL || nbytes < 0) return (FK_EINVAL);
+  const int K = ctx->prm.kmer, W = K - 4;
+  uint16_t mtab[1024];
+  uint8_t  mb[1024];
+  build_minimizer_tables(mtab, mb, 1);
+  std::vector<uint32_t> key((size_t) nbytes + 8);      // canonical key of the 5-mer starting at i
+  std::vector<int32_t>  bad((size_t) nbytes + 8);      // invalid bases in [0, i)
+  uint32_t code = 0;
+  int32_t  nbad = 0;
+  for (int64_t i = 0; i < nbytes; i++)
+    { bad[i] = nbad;
+      const unsigned char c = (unsigned char) bases[i] & 0xDF;
+      uint32_t x = 0;
+      if (c == 'A') x = 0; else if (c == 'C') x = 1; else if (c == 'G') x = 2; else if (c == 'T') x = 3;
+      else nbad += 1;
+      code = ((code << 2) | x) & 0x3ffu;
+      if (i >= 4)
+        key[i - 4] = ((uint32_t) (mtab[code] >> 1) << 20) | (uint32_t) ((i - 4) & 0xfffff);
+    }
+  bad[nbytes] = nbad;
+  uint32_t prev = 0xffffffffu;
+  bool     pv = false;
+  for (int64_t i = 0; i + K <= nbytes; i++)
+    { const bool v = (bad[i + K] == bad[i]);
+      if (v)
+        { uint32_t m = 0xffffffffu;
+          for (int j = 0; j < W; j++)
+            m = std::min(m, key[i + j]);
+          const int r = (int) (m >> 20);
+          counts[r] += 1;
+          if (!pv || m != prev)
+            counts[r] += 4;
+          prev = m;
+        }
+      pv = v;
+    }
+  return (FK_OK);
+}
+
+// Deal the minimizer ranks to the buckets by measured weight (longest processing time first) instead
+// of the default serpentine deal.  Every process of a sharded run must pass the SAME counts
+// (all-reduce them first).  Any assignment gives correct results; this one balances the buckets.
+extern "C" int fk_set_bucket_weights(fk_ctx *ctx, const int64_t *counts)
+{ if (ctx == NULL || counts == NULL) return (FK_EINVAL);
+  const int nb = ctx->prm.nbuckets;
+  std::pair<int64_t, int> order[1024];
+  for (int r = 0; r < 1024; r++)
+    order[r] = std::make_pair(-counts[r], r);
+  std::sort(order, order + 1024);
+  int64_t load[256];
+  for (int b = 0; b < nb; b++)
+    load[b] = 0;
+  for (int i = 0; i < 1024; i++)
+    { int best = 0;
+      for (int b = 1; b < nb; b++)
+        if (load[b] < load[best])
+          best = b;
+      ctx->h_mbucket[order[i].second] = (uint8_t) best;
+      load[best] += -order[i].first + 1;
+    }
+  FK_HIP(ctx, hipSetDevice(ctx->device));
+  FK_HIP(ctx, hipMemcpy(ctx->d_mbucket, ctx->h_mbucket, 1024, hipMemcpyHostToDevice));
+  return (FK_OK);
 }
 
 extern "C" int fk_create(const fk_params *p, fk_ctx **out)
@@ -279,6 +349,10 @@ extern "C" int fk_debug_set(fk_ctx *ctx, const char *key, int64_t value)
     }
   if (strcmp(key, "radix_items") == 0)
     { ctx->dbg_radix_items = (int) value;
+      return (FK_OK);
+    }
+  if (strcmp(key, "verbose") == 0)          // per-bucket sizes and times on stderr
+    { ctx->dbg_verbose = (int) value;
       return (FK_OK);
     }
   if (strcmp(key, "chunk_bytes") == 0)      // split the pushed reads every so many bytes (tests)
@@ -936,6 +1010,9 @@ static int count_bucket(fk_ctx *ctx, void *sm_in, int64_t ns, fk_result *res, bo
       *ntab += (cutoff > 0) ? nt : 0;
       hipEventRecord(ev[3], s);
       if (hipEventSynchronize(ev[3]) != hipSuccess) { rc = FK_EHIP; break; }
+      if (ctx->dbg_verbose)
+        fprintf(stderr, "  bucket: %lld super-mers, %lld weighted k-mers, %lld distinct, %.2f ms\n",
+                (long long) ns, (long long) nw, (long long) ndk, ms_between(ev[0], ev[3]));
       tm->group_s += ms_between(ev[0], ev[1]);
       tm->expand  += ms_between(ev[1], ev[2]);
       tm->radix_k += ms_between(ev[2], ev[3]) - ms_aggr;

@@ -75,6 +75,7 @@ struct fk_ctx
   int        dbg_radix_items;
   int        dbg_radix_engine;    // 1 = look-back engine instead of the stream engine
   int        dbg_kmer_stage;      // 1 = sort-collapse-sort k-mer stage instead of hash aggregation
+  int        dbg_verbose;
   int        dbg_aggr_variant;    // ablations of k_ag_count (wrong results), see fk_debug_set
   int        dbg_aggr_limit;      // > 0: pretend the LDS table of fk_aggr.hip takes only this many k-mers
   int64_t    aggr_extra_rounds;   // bins x rounds that had to be split in the last aggregation

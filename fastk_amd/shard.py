@@ -26,6 +26,16 @@ class HipEngine:
         self.device = device
         self.stride = ctx.w.smer_stride
 
+    def train_buckets(self, reads, group=None, sample_bytes=2 << 20):
+        """Balance the buckets (= ranks) on a sample of the reads: every rank takes a census of the
+        head of its stripe, the censuses are all-reduced, and every rank derives the same minimizer ->
+        bucket assignment from the sum (fk_set_bucket_weights)."""
+        sample = reads[:sample_bytes].cpu().numpy()
+        counts = torch.from_numpy(self.ctx.bucket_census(sample)).to(self.device)
+        if dist.is_initialized():
+            dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
+        self.ctx.set_bucket_weights(counts.cpu().numpy())
+
     def split(self, reads):
         """reads: uint8 tensor in HBM.  Returns (records uint8 tensor, per-bucket counts, per-bucket
         record offsets into that tensor, ninst).  One emit pass into sampled, padded regions; the

@@ -242,6 +242,15 @@ int fk_push_fastq(fk_ctx *ctx, const char *raw, int64_t nbytes, int *line_phase,
 int fk_host_alloc(int64_t nbytes, void **ptr);      /* pinned host memory */
 int fk_host_free(void *ptr);
 
+/* Bucket training, the role of the trie balancing in Determine_Scheme (split.c:617-766).
+   fk_bucket_census: host-side pass over a SAMPLE of reads (any bytes, non-ACGT separates) that adds,
+   per canonical minimizer rank, 4 x super-mer starts + k-mer instances to counts[1024].
+   fk_set_bucket_weights: deal the ranks to the nbuckets buckets by those weights (longest processing
+   time first) instead of the default serpentine deal.  In a sharded run every process must pass the
+   same counts (all-reduce the census first).  Results do not depend on the assignment. */
+int fk_bucket_census(fk_ctx *ctx, const char *bases, int64_t nbytes, int64_t *counts);
+int fk_set_bucket_weights(fk_ctx *ctx, const int64_t *counts);
+
 /* ---- utilities ---------------------------------------------------------------------------*/
 
 /* Fill d_bases with synthetic reads first_read .. first_read+nreads-1 of include/fk_synth.h,

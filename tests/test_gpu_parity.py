@@ -643,6 +643,21 @@ def test_reference_main_over_gpu_shim(name, fmt, tmp_path):
         assert got == digest, fname
 
 
+def test_trained_bucket_assignment_balances_and_keeps_results():
+    """fk_bucket_census + fk_set_bucket_weights: the buckets get within a few percent of each other
+    and the bucket-streamed result is still the reference's (any assignment is valid)."""
+    case, bases, boff = util.load_case("synth_illumina_k40_t1_T4")
+    with fastk_amd.Context(kmer=40, table_cutoff=case["cutoff"], nthreads=case["T"], nbuckets=8) as ctx:
+        ctx.set_bucket_weights(ctx.bucket_census(bases[:1 << 20]))
+        rd = ctx.alloc(len(bases) + 64).upload(bases)
+        ns, ni, counts = ctx.split(rd.ptr, len(bases))
+        c = np.array(counts, dtype=float)
+        assert c.max() / c.mean() < 1.12 and c.min() / c.mean() > 0.88   # work, not records, is balanced
+        ctx.push_block(bases, boff.astype(np.int32))
+        res = ctx.finish()
+        util.check_against_golden(case, res.hist, res.max_inst, res.table)
+
+
 # ------------------------------------------------------------------------------ full size
 def test_full_size_properties_configs1():
     """BASELINE configs[1] at full size (33.3 M reads of 150 bp, 3.7 G k-mer instances): no oracle
