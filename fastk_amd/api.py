@@ -114,7 +114,7 @@ def load_library():
     L.fk_get_sort_stats.argtypes = [vp, C.POINTER(SortStats)]
     L.fk_debug_set.argtypes = [vp, C.c_char_p, i64]
     L.fk_debug_get.argtypes = [vp, C.c_char_p, C.POINTER(i64)]
-    L.fk_push_fastq.argtypes = [vp, vp, i64, C.POINTER(C.c_int), C.POINTER(i64), C.POINTER(i64)]
+    L.fk_push_fastq.argtypes = [vp, vp, i64, C.c_int, C.POINTER(C.c_int), C.POINTER(i64), C.POINTER(i64)]
     L.fk_host_alloc.argtypes = [i64, C.POINTER(vp)]
     L.fk_host_free.argtypes = [vp]
     L.fk_bucket_census.argtypes = [vp, vp, i64, C.POINTER(i64)]
@@ -249,12 +249,12 @@ class Context:
         c = np.ascontiguousarray(counts, dtype=np.int64)
         self._ck(self.L.fk_set_bucket_weights(self.h, c.ctypes.data_as(C.POINTER(C.c_int64))))
 
-    def push_fastq(self, raw, phase=0):
+    def push_fastq(self, raw, phase=0, hoco=False):
         """raw: bytes / uint8 array holding any piece of a FASTQ file; returns (phase, reads, bases)."""
         a = np.frombuffer(raw, dtype=np.uint8) if isinstance(raw, (bytes, bytearray)) else \
             np.ascontiguousarray(raw, dtype=np.uint8)
         ph, nr, nb = C.c_int(phase), C.c_int64(0), C.c_int64(0)
-        self._ck(self.L.fk_push_fastq(self.h, a.ctypes.data, a.nbytes, C.byref(ph), C.byref(nr),
+        self._ck(self.L.fk_push_fastq(self.h, a.ctypes.data, a.nbytes, 1 if hoco else 0, C.byref(ph), C.byref(nr),
                                       C.byref(nb)))
         return ph.value, nr.value, nb.value
 

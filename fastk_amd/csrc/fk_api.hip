@@ -759,7 +759,7 @@ extern "C" int fk_push_device(fk_ctx *ctx, const void *d_bases, int64_t nbytes)
 
 /* FASTQ text (any piece of a file, cut anywhere) -> reads, parsed on the device (fk_parse.hip).
    *line_phase: 0 before the first byte of a file, carried from call to call. */
-extern "C" int fk_push_fastq(fk_ctx *ctx, const char *raw, int64_t nbytes, int *line_phase,
+extern "C" int fk_push_fastq(fk_ctx *ctx, const char *raw, int64_t nbytes, int flags, int *line_phase,
                              int64_t *nreads, int64_t *nbases)
 { if (ctx == NULL || raw == NULL || nbytes < 0 || line_phase == NULL) return (FK_EINVAL);
   if (ctx->prm.bc_prefix > 0 || ctx->prm.exact_parts)
@@ -776,14 +776,19 @@ extern "C" int fk_push_fastq(fk_ctx *ctx, const char *raw, int64_t nbytes, int *
         break;
       void *d_raw = fk_slot(ctx, FK_SLOT_RAW, nbytes + 64);
       if (d_raw == NULL) { rc = FK_ENOMEM; break; }
-      if (hipMemcpyAsync(d_raw, raw, (size_t) nbytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+      // one byte in front of the text: the last byte of the previous piece (homopolymer compression)
+      d_raw = (char *) d_raw + 16;
+      const unsigned char lastb = (unsigned char) ((*line_phase >> 8) & 0xff);
+      if (hipMemcpyAsync((char *) d_raw - 1, &lastb, 1, hipMemcpyHostToDevice, ctx->stream) != hipSuccess
+          || hipMemcpyAsync(d_raw, raw, (size_t) nbytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
         { fk_set_error(ctx, "fk_push_fastq: host to device copy failed");
           rc = FK_EHIP;
           break;
         }
       int64_t kept = 0, nr = 0;
-      if ((rc = fkx_parse_fastq(ctx, d_raw, nbytes, line_phase, ctx->d_reads + ctx->reads_len, &kept, &nr)) != FK_OK)
+      if ((rc = fkx_parse_fastq(ctx, d_raw, nbytes, flags, line_phase, ctx->d_reads + ctx->reads_len, &kept, &nr)) != FK_OK)
         break;
+      *line_phase = (*line_phase & 3) | ((int) (unsigned char) raw[nbytes - 1] << 8);
       ctx->reads_len += kept;
       if (nreads) *nreads += nr;
       if (nbases) *nbases += kept - nr;

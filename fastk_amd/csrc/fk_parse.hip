@@ -20,16 +20,23 @@
 #define FQ_TILE    (FQ_THREADS * FQ_PER)
 
 // per-thread pass over its 64 bytes; c0 = newlines before the thread's first byte (mod 4 suffices)
+// prev: the byte in front of the thread's first one; hoco: drop a base equal to the byte before it
+// (homopolymer compression, io.c:284-294; the byte before the first base of a line is a newline)
 template <bool EMIT>
 __device__ __forceinline__ void fq_walk(const uint4 (&v)[4], int nvalid, u32 c0, u32 (&cnt)[4], u32 &nl,
-                                        u32 &reads, unsigned char *stage, u32 phase, u32 &kept)
+                                        u32 &reads, unsigned char *stage, u32 phase, u32 &kept, u32 prev,
+                                        bool hoco)
 { const u32 *w = (const u32 *) v;
 #pragma unroll
   for (int i = 0; i < FQ_PER; i++)
     { if (i < nvalid)
         { const u32 ch = (w[i >> 2] >> (8 * (i & 3))) & 0xffu;
           const u32 r  = (c0 + nl) & 3u;
-          if (!EMIT)
+          const bool drop = hoco && ch == prev && ch != '\n';
+          prev = ch;
+          if (drop)
+            ;
+          else if (!EMIT)
             { cnt[0] += (r == 0u); cnt[1] += (r == 1u); cnt[2] += (r == 2u); cnt[3] += (r == 3u); }
           else if (((phase + r) & 3u) == 1u)
             { stage[kept] = (unsigned char) (ch == '\n' ? 0 : ch);
@@ -62,7 +69,7 @@ __device__ __forceinline__ void fq_load(const unsigned char *raw, int64_t n, int
 
 // tile_info[t*8 + 0..3] = bytes of the tile with local newline count r (mod 4), [4] = newlines
 __global__ __launch_bounds__(FQ_THREADS) void k_fq_count(const unsigned char *__restrict__ raw, int64_t n,
-                                                         u32 *__restrict__ tile_info)
+                                                         u32 *__restrict__ tile_info, int hoco)
 { __shared__ u32 tmp[8];
   __shared__ u32 red[5];
   const int64_t base = (int64_t) blockIdx.x * FQ_TILE + (int64_t) threadIdx.x * FQ_PER;
@@ -88,7 +95,7 @@ __global__ __launch_bounds__(FQ_THREADS) void k_fq_count(const unsigned char *__
   u32 tot;
   const u32 c0 = fk_block_exscan_256<u32>(mynl, tmp, &tot);
   u32 cnt[4] = { 0, 0, 0, 0 }, nl = 0, reads = 0, kept = 0;
-  fq_walk<false>(v, nvalid, c0, cnt, nl, reads, NULL, 0, kept);
+  fq_walk<false>(v, nvalid, c0, cnt, nl, reads, NULL, 0, kept, (nvalid > 0) ? (u32) raw[base - 1] : 0u, hoco != 0);
   if (threadIdx.x < 5) red[threadIdx.x] = 0;
   __syncthreads();
 #pragma unroll
@@ -141,7 +148,8 @@ __global__ __launch_bounds__(256) void k_fq_scan(const u32 *__restrict__ tile_in
 __global__ __launch_bounds__(FQ_THREADS) void k_fq_emit(const unsigned char *__restrict__ raw, int64_t n,
                                                         const u32 *__restrict__ tile_phase,
                                                         const u64 *__restrict__ tile_off,
-                                                        unsigned char *__restrict__ dst, u64 *__restrict__ nreads)
+                                                        unsigned char *__restrict__ dst, u64 *__restrict__ nreads,
+                                                        int hoco)
 { __shared__ unsigned char stage[FQ_TILE];
   __shared__ u32 tmp[8];
   __shared__ u32 s_reads;
@@ -170,13 +178,14 @@ __global__ __launch_bounds__(FQ_THREADS) void k_fq_emit(const unsigned char *__r
   const u32 phase = tile_phase[blockIdx.x];
   // how many bytes this thread keeps, then where they go inside the tile's output
   u32 cnt[4] = { 0, 0, 0, 0 }, nl = 0, reads = 0, kept = 0;
-  fq_walk<false>(v, nvalid, c0, cnt, nl, reads, NULL, 0, kept);
+  const u32 prev0 = (nvalid > 0) ? (u32) raw[base - 1] : 0u;
+  fq_walk<false>(v, nvalid, c0, cnt, nl, reads, NULL, 0, kept, prev0, hoco != 0);
   const u32 want = (1u - phase) & 3u;               // local newline count (mod 4) of the kept bytes
   const u32 mine = (want == 0u) ? cnt[0] : (want == 1u) ? cnt[1] : (want == 2u) ? cnt[2] : cnt[3];
   u32 tkept;
   const u32 ex = fk_block_exscan_256<u32>(mine, tmp, &tkept);
   nl = 0; kept = 0;
-  fq_walk<true>(v, nvalid, c0, cnt, nl, reads, stage + ex, phase, kept);
+  fq_walk<true>(v, nvalid, c0, cnt, nl, reads, stage + ex, phase, kept, prev0, hoco != 0);
   if (reads)
     atomicAdd(&s_reads, reads);
   __syncthreads();
@@ -187,9 +196,10 @@ __global__ __launch_bounds__(FQ_THREADS) void k_fq_emit(const unsigned char *__r
     atomicAdd(nreads, (u64) s_reads);
 }
 
-/* d_raw: nbytes of FASTQ text on the device; *phase: newlines seen so far in this file (mod 4), updated.
+/* d_raw: nbytes of FASTQ text on the device, with one readable byte in front of it (the last byte
+   of the previous piece, or 0); *phase: newlines seen so far in this file (mod 4), updated.
    The sequence lines, each ended by a 0, are written to d_dst (capacity >= nbytes); *nkept bytes. */
-int fkx_parse_fastq(fk_ctx *ctx, const void *d_raw, int64_t nbytes, int *phase, void *d_dst,
+int fkx_parse_fastq(fk_ctx *ctx, const void *d_raw, int64_t nbytes, int flags, int *phase, void *d_dst,
                     int64_t *nkept, int64_t *nreads)
 { hipStream_t s = ctx->stream;
   *nkept = 0; *nreads = 0;
@@ -204,17 +214,17 @@ int fkx_parse_fastq(fk_ctx *ctx, const void *d_raw, int64_t nbytes, int *phase, 
   u64 *d_out = ctx->d_scratch + 2048;              // [0] kept bytes [1] newlines [2] reads
   FK_HIP(ctx, hipMemsetAsync(d_out, 0, 3 * sizeof(u64), s));
   hipLaunchKernelGGL(k_fq_count, dim3((unsigned) ntiles), dim3(FQ_THREADS), 0, s,
-                     (const unsigned char *) d_raw, nbytes, d_info);
+                     (const unsigned char *) d_raw, nbytes, d_info, flags & FK_FASTQ_HOCO);
   hipLaunchKernelGGL(k_fq_scan, dim3(1), dim3(256), 0, s, (const u32 *) d_info, ntiles, (u32) (*phase & 3),
                      d_phase, d_off, d_out);
   hipLaunchKernelGGL(k_fq_emit, dim3((unsigned) ntiles), dim3(FQ_THREADS), 0, s,
                      (const unsigned char *) d_raw, nbytes, (const u32 *) d_phase, (const u64 *) d_off,
-                     (unsigned char *) d_dst, d_out + 2);
+                     (unsigned char *) d_dst, d_out + 2, flags & FK_FASTQ_HOCO);
   FK_LAUNCH_CHECK(ctx);
   FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch, d_out, 3 * sizeof(u64), hipMemcpyDeviceToHost, s));
   FK_HIP(ctx, hipStreamSynchronize(s));
   *nkept  = (int64_t) ctx->h_scratch[0];
-  *phase  = (int) ((*phase + ctx->h_scratch[1]) & 3);
+  *phase  = (*phase & ~3) | (int) (((*phase & 3) + ctx->h_scratch[1]) & 3);
   *nreads = (int64_t) ctx->h_scratch[2];
   return (FK_OK);
 }

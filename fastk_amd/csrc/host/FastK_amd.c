@@ -1,6 +1,6 @@
 /* FastK_amd.c -- host driver with FastK's command line over libfastk_amd.so.
  *
- *   FastK_amd [-k<int(40)>] [-t[<int(1)>]] [-bc<int>] [-v] [-x] [-N<path_name>] [-P<dir>] [-M<int>]
+ *   FastK_amd [-k<int(40)>] [-t[<int(1)>]] [-c] [-bc<int>] [-v] [-x] [-N<path_name>] [-P<dir>] [-M<int>]
  *             [-T<int(4)>] <source>[.fa|.fasta|.fq|.fastq][.gz] ...
  *
  * Same flags, defaults, output names and encodings as the reference driver (FastK.c:34-37,
@@ -22,8 +22,7 @@
  * fixes the number of super-mer buckets, split.c:617-766): the reads are split into super-mers chunk
  * by chunk and the minimizer buckets are counted one after the other; the number of buckets is
  * derived from the input size.  Without -M everything stays resident in one bucket (fastest).
- * Accepted for compatibility and ignored: -P (no temporary files exist).  Not built yet and rejected with a message: -p (profiles), -c (homopolymer
- * compression), BAM/SAM/CRAM/Dazzler inputs.
+ * Accepted for compatibility and ignored: -P (no temporary files exist).  Not built yet and rejected with a message: -p (profiles), BAM/SAM/CRAM/Dazzler inputs.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -39,7 +38,7 @@
 static char *Prog_Name = "FastK_amd";
 
 static int       KMER = 40, NTHREADS = 4, DO_TABLE = 0, BC_PREFIX = 0, VERBOSE = 0, EXACT = 0, MEM_GB = 0;
-static int       HOST_PARSE = 0;
+static int       HOST_PARSE = 0, COMPRESS = 0;
 static char     *OUT_NAME = NULL;
 
 typedef struct
@@ -49,6 +48,7 @@ typedef struct
     int      nreads;
     int64_t  olen;
     int64_t  totbps, totrds;
+    int      lastc;
   } Feeder;
 
 static void die(fk_ctx *ctx, const char *what)
@@ -70,7 +70,12 @@ static void flush_block(Feeder *f, int rem)
 }
 
 static inline void add_base(Feeder *f, int c)
-{ if (f->olen >= BLOCK_BYTES-2)
+{ if (COMPRESS)                           /* -c: homopolymer compression, io.c:284-294,558 */
+    { if (c == f->lastc)
+        return;
+      f->lastc = c;
+    }
+  if (f->olen >= BLOCK_BYTES-2)
     { /* the read is longer than a block: close it here, continue with a K-1 overlap */
       char keep[256];
       int  ov = KMER-1;
@@ -90,7 +95,8 @@ static inline void add_base(Feeder *f, int c)
 }
 
 static inline void end_read(Feeder *f)
-{ f->bases[f->olen++] = 0;
+{ f->lastc = 0;
+  f->bases[f->olen++] = 0;
   f->nreads += 1;
   f->totrds += 1;
   f->boff[f->nreads] = (int32_t) f->olen;
@@ -138,7 +144,7 @@ static void scan_fastq_on_device(Feeder *f, const char *path)
   flush_block(f,0);                        /* keep the order of reads across input files */
   while ((n = gzread(in,raw,RAW_BYTES)) > 0)
     { int64_t nr = 0, nb = 0;
-      if (fk_push_fastq(f->ctx,raw,n,&phase,&nr,&nb) != FK_OK)
+      if (fk_push_fastq(f->ctx,raw,n,COMPRESS ? FK_FASTQ_HOCO : 0,&phase,&nr,&nb) != FK_OK)
         die(f->ctx,"fk_push_fastq");
       f->totrds += nr;
       f->totbps += nb;
@@ -202,7 +208,8 @@ int main(int argc, char *argv[])
         case 'N': OUT_NAME = argv[i]+2; break;
         case 'M': MEM_GB = atoi(argv[i]+2); break;
         case 'P': break;
-        case 'p': case 'c':
+        case 'c': COMPRESS = 1; break;
+        case 'p':
           fprintf(stderr,"%s: option %s is not built in this engine yet (see DESIGN.md)\n",Prog_Name,argv[i]);
           exit (1);
         default:

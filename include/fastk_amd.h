@@ -234,11 +234,13 @@ int fk_count_unsorted_kmers(fk_ctx *ctx, void *d_kmers, void *d_tmp, int64_t nwe
 /* FASTQ text, any piece of a file cut anywhere (host memory; pinned memory from fk_host_alloc
    copies fastest): the record structure is resolved on the device -- replaces the FASTQ branch of
    fast_output_thread (io.c:574-759, line rules io.c:678-734: strictly four lines per record, every
-   non-newline byte of the sequence line is a base) in front of fk_push_block.  *line_phase must be 0
-   before the first piece of a file and is carried between calls; *nreads and *nbases (may be NULL)
+   non-newline byte of the sequence line is a base) in front of fk_push_block.  *line_phase (parser state:
+   line number mod 4 and the last byte of the previous piece) must be 0 before the first piece of a file
+   and is carried between calls; *nreads and *nbases (may be NULL)
    are incremented.  Not available with -bc or exact_parts (they need host-side read offsets). */
-int fk_push_fastq(fk_ctx *ctx, const char *raw, int64_t nbytes, int *line_phase, int64_t *nreads,
-                  int64_t *nbases);
+#define FK_FASTQ_HOCO 1      /* flags: homopolymer-compress the reads (-c, io.c:284-294) */
+int fk_push_fastq(fk_ctx *ctx, const char *raw, int64_t nbytes, int flags, int *line_phase,
+                  int64_t *nreads, int64_t *nbases);
 int fk_host_alloc(int64_t nbytes, void **ptr);      /* pinned host memory */
 int fk_host_free(void *ptr);
 

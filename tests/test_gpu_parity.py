@@ -320,6 +320,59 @@ def test_fastq_parsed_on_device_matches_golden(name, tmp_path):
         util.check_against_golden(case, res.hist, res.max_inst, res.table)
 
 
+def _hoco(bases, boff):
+    """homopolymer-compress every read (io.c:284-294): drop a base equal to the one before it."""
+    out, off = [], [0]
+    for i in range(len(boff) - 1):
+        r = bases[boff[i]:boff[i + 1] - 1]
+        keep = np.ones(len(r), dtype=bool)
+        keep[1:] = r[1:] != r[:-1]
+        out.append(r[keep]); out.append(np.zeros(1, dtype=np.uint8))
+        off.append(off[-1] + int(keep.sum()) + 1)
+    return np.concatenate(out), np.array(off, dtype=np.int64)
+
+
+@pytest.mark.parametrize("name", ["synth_illumina_k40_t1_T4", "edge_k40_t1_T4"])
+def test_homopolymer_compression_device_host_reference(name, tmp_path):
+    """-c: the device FASTQ parser with FK_FASTQ_HOCO, the host parser of FastK_amd -c -H and the
+    reference FastK -c agree (histogram bytes)."""
+    import hashlib, os, subprocess
+    case, bases, boff = util.load_case(name)
+    k = case["k"]
+    cb, co = _hoco(bases, boff)
+    exp = orc.fastk(k, cb, co, cutoff=case["cutoff"])
+    path = str(tmp_path / "r.fastq")
+    orc.write_fastq(path, bases, boff)
+    text = open(path, "rb").read()
+    rng = np.random.default_rng(2)
+    with fastk_amd.Context(kmer=k, table_cutoff=case["cutoff"], nthreads=case["T"]) as ctx:
+        ph, pos, nb = 0, 0, 0
+        while pos < len(text):
+            n = int(rng.integers(1, 100000))
+            ph, r, b = ctx.push_fastq(text[pos:pos + n], ph, hoco=True)
+            nb += b
+            pos += n
+        assert nb == len(cb) - (len(co) - 1)
+        res = ctx.finish()
+        assert res.ninst == exp.ninst
+        assert np.array_equal(res.hist, exp.hist) and res.max_inst == exp.max_inst
+        assert np.array_equal(res.table, exp.table)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "fastk_amd", "bin", "FastK_amd")
+    digests = []
+    for extra in ([], ["-H"]):
+        subprocess.run([exe, "-k%d" % k, "-t%d" % case["cutoff"], "-c", "-N" + str(tmp_path / "o")] + extra + [path],
+                       check=True, cwd=str(tmp_path))
+        digests.append(hashlib.sha256(open(tmp_path / "o.hist", "rb").read()).hexdigest())
+    assert digests[0] == digests[1]
+    ref = os.path.join(orc.REF_DIR, "FastK")
+    if os.path.exists(ref):
+        subprocess.run([ref, "-k%d" % k, "-t%d" % case["cutoff"], "-c", "-T2", "-P" + str(tmp_path),
+                        "-N" + str(tmp_path / "ref"), path], check=True, cwd=str(tmp_path),
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        assert hashlib.sha256(open(tmp_path / "ref.hist", "rb").read()).hexdigest() == digests[0]
+
+
 def test_cli_memory_option(tmp_path):
     """FastK_amd -M<GB> (HBM budget: bucket streaming + chunked ingest) gives the same files."""
     import hashlib, os, subprocess
