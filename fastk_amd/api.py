@@ -22,7 +22,7 @@ EXPORTS = [
     "fk_get_sort_stats", "fk_version", "fk_count_device_reads", "fk_count_device_supermers", "fk_debug_set", "fk_group_records",
     "fk_count_presorted_kmers", "fk_split_supermers_emit", "fk_split_plan", "fk_split_planned",
     "fk_train_block", "fk_count_unsorted_kmers", "fk_debug_get", "fk_push_fastq", "fk_host_alloc",
-    "fk_host_free", "fk_bucket_census", "fk_set_bucket_weights",
+    "fk_host_free", "fk_bucket_census", "fk_set_bucket_weights", "fk_push_fasta",
 ]
 
 
@@ -115,6 +115,7 @@ def load_library():
     L.fk_debug_set.argtypes = [vp, C.c_char_p, i64]
     L.fk_debug_get.argtypes = [vp, C.c_char_p, C.POINTER(i64)]
     L.fk_push_fastq.argtypes = [vp, vp, i64, C.c_int, C.POINTER(C.c_int), C.POINTER(i64), C.POINTER(i64)]
+    L.fk_push_fasta.argtypes = [vp, vp, i64, C.c_int, C.POINTER(C.c_int), C.POINTER(i64), C.POINTER(i64)]
     L.fk_host_alloc.argtypes = [i64, C.POINTER(vp)]
     L.fk_host_free.argtypes = [vp]
     L.fk_bucket_census.argtypes = [vp, vp, i64, C.POINTER(i64)]
@@ -257,6 +258,15 @@ class Context:
         self._ck(self.L.fk_push_fastq(self.h, a.ctypes.data, a.nbytes, 1 if hoco else 0, C.byref(ph), C.byref(nr),
                                       C.byref(nb)))
         return ph.value, nr.value, nb.value
+
+    def push_fasta(self, raw, state=2, last=False):
+        """raw: any piece of a FASTA file; state 2 at file start; returns (state, records, bases)."""
+        a = np.frombuffer(raw, dtype=np.uint8) if isinstance(raw, (bytes, bytearray)) else \
+            np.ascontiguousarray(raw, dtype=np.uint8)
+        st, nr, nb = C.c_int(state), C.c_int64(0), C.c_int64(0)
+        self._ck(self.L.fk_push_fasta(self.h, a.ctypes.data if a.nbytes else None, a.nbytes,
+                                      1 if last else 0, C.byref(st), C.byref(nr), C.byref(nb)))
+        return st.value, nr.value, nb.value
 
     def push_device(self, ptr, nbytes):
         self._ck(self.L.fk_push_device(self.h, ptr, nbytes))

@@ -800,6 +800,58 @@ extern "C" int fk_push_fastq(fk_ctx *ctx, const char *raw, int64_t nbytes, int f
   return (rc);
 }
 
+/* FASTA text (any piece of a file, cut anywhere) -> reads, parsed on the device (fk_parse.hip).
+   *state: 2 before the first byte of a file, carried from call to call; last != 0 with the final piece
+   of a file (ends its last record). */
+extern "C" int fk_push_fasta(fk_ctx *ctx, const char *raw, int64_t nbytes, int last, int *state,
+                             int64_t *nreads, int64_t *nbases)
+{ if (ctx == NULL || (raw == NULL && nbytes > 0) || nbytes < 0 || state == NULL) return (FK_EINVAL);
+  if (ctx->prm.bc_prefix > 0 || ctx->prm.exact_parts)
+    { fk_set_error(ctx, "fk_push_fasta: -bc and exact_parts need read offsets; use fk_push_block");
+      return (FK_EUNSUPPORTED);
+    }
+  int rc = FK_OK;
+  pthread_mutex_lock((pthread_mutex_t *) ctx->push_lock);
+  do
+    { hipSetDevice(ctx->device);
+      if ((rc = reserve_reads(ctx, nbytes + 16)) != FK_OK)
+        break;
+      int64_t kept = 0, nr = 0;
+      if (nbytes > 0)
+        { void *d_raw = fk_slot(ctx, FK_SLOT_RAW, nbytes + 64);
+          if (d_raw == NULL) { rc = FK_ENOMEM; break; }
+          if (hipMemcpyAsync(d_raw, raw, (size_t) nbytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+            { fk_set_error(ctx, "fk_push_fasta: host to device copy failed");
+              rc = FK_EHIP;
+              break;
+            }
+          if ((rc = fkx_parse_fasta(ctx, d_raw, nbytes, *state, ctx->d_reads + ctx->reads_len, &kept, &nr)) != FK_OK)
+            break;
+          // the state after this piece, from the host copy of the text
+          int64_t p = nbytes - 1;
+          while (p >= 0 && raw[p] != '\n')
+            p -= 1;
+          if (p >= 0)
+            *state = (p == nbytes - 1) ? 2 : (raw[p + 1] == '>' ? 1 : 0);
+          else if (*state & 2)
+            *state = (raw[0] == '>') ? 1 : 0;
+          ctx->reads_len += kept;
+        }
+      if (last)
+        { if (hipMemsetAsync(ctx->d_reads + ctx->reads_len, 0, 1, ctx->stream) != hipSuccess)
+            { rc = FK_EHIP; break; }
+          ctx->reads_len += 1;
+        }
+      if (nreads) *nreads += nr;
+      if (nbases) *nbases += kept - nr;
+      if (ctx->chunk_bytes > 0 && ctx->reads_len >= ctx->chunk_bytes)
+        rc = flush_chunk(ctx);
+    }
+  while (0);
+  pthread_mutex_unlock((pthread_mutex_t *) ctx->push_lock);
+  return (rc);
+}
+
 extern "C" int fk_host_alloc(int64_t nbytes, void **ptr)
 { if (ptr == NULL || nbytes <= 0) return (FK_EINVAL);
   if (hipHostMalloc(ptr, (size_t) nbytes, hipHostMallocDefault) != hipSuccess)

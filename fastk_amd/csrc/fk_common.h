@@ -137,6 +137,8 @@ int fkx_aggregate(fk_ctx *ctx, const void *d_grouped, int64_t n, int cutoff, int
                   int64_t *max_inst, int64_t *ndistinct, void *d_table, int64_t cap, int64_t *ntable);
 int fkx_parse_fastq(fk_ctx *ctx, const void *d_raw, int64_t nbytes, int flags, int *phase, void *d_dst,
                     int64_t *nkept, int64_t *nreads);
+int fkx_parse_fasta(fk_ctx *ctx, const void *d_raw, int64_t nbytes, int state, void *d_dst,
+                    int64_t *nkept, int64_t *nrecs);
 int fkx_synth(fk_ctx *ctx, uint64_t seed, uint64_t genome_len, uint32_t read_len,
               uint32_t err_ppm, uint64_t first_read, int64_t nreads, void *d_bases);
 

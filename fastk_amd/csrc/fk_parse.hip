@@ -228,3 +228,261 @@ int fkx_parse_fastq(fk_ctx *ctx, const void *d_raw, int64_t nbytes, int flags, i
   *nreads = (int64_t) ctx->h_scratch[2];
   return (FK_OK);
 }
+
+// ---------------------------------------------------------------------------------------------
+// FASTA text -> 0-terminated reads (the FASTA branch of fast_output_thread, io.c:574-759): a line
+// that starts with '>' is a header, every other line is sequence, and the sequence lines of a record
+// are one read (newlines inside a record are dropped, io.c:700-734).  A byte's line is a header iff
+// the byte after the last newline before it is '>', so the classification is an exclusive MAX-scan
+// of newline positions; every header start emits the 0 that ends the previous record.
+//
+//   k_fa_count  per tile: position of its last newline (global), bytes before its first newline, and
+//               the kept bytes after the first newline (those do not depend on other tiles)
+//   k_fa_scan   one workgroup: last newline before every tile (max-scan) -> its state, output offsets
+//   k_fa_emit   classify again, compact through LDS, write
+#define FA_NONE 0xffffffffffffffffull        // "no newline so far" in the max-scan (wraps to -1 + 1 = 0)
+
+// inclusive max-scan over the 256 threads of a block, returns the exclusive value (FA_NONE-aware:
+// positions are stored +1, 0 = none)
+__device__ __forceinline__ u64 fa_block_exmax(u64 v, u64 *tmp, u64 *total)
+{ const u32 lane = fk_lane();
+  const u32 wave = threadIdx.x >> 6;
+  u64 x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1)
+    { const u64 y = __shfl_up(x, o, 64);
+      if ((int) lane >= o) x = max(x, y);
+    }
+  if (lane == 63) tmp[wave] = x;
+  __syncthreads();
+  u64 base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 4; w++)
+    { const u64 t = tmp[w];
+      if ((u32) w < wave) base = max(base, t);
+      tot = max(tot, t);
+    }
+  __syncthreads();
+  *total = tot;
+  u64 ex = __shfl_up(x, 1, 64);
+  if (lane == 0) ex = 0;
+  return max(base, ex);
+}
+
+// walk over a thread's bytes.  fresh: the first byte starts a line; header: the line the first byte
+// belongs to is a header (ignored when fresh)
+// skip: bytes 0..skip are passed over as if they were newlines (the head of a tile, k_fa_count)
+template <bool EMIT>
+__device__ __forceinline__ void fa_walk(const uint4 (&v)[4], int nvalid, bool fresh, bool header, u32 &kept,
+                                        u32 &recs, unsigned char *stage, int skip = -1)
+{ const u32 *w = (const u32 *) v;
+#pragma unroll
+  for (int i = 0; i < FQ_PER; i++)
+    { if (i < nvalid && i > skip)
+        { const u32 ch = (w[i >> 2] >> (8 * (i & 3))) & 0xffu;
+          if (fresh)
+            { header = (ch == '>');
+              if (header)
+                { if (EMIT) stage[kept] = 0;
+                  kept += 1;
+                  recs += 1;
+                }
+            }
+          fresh = (ch == '\n');
+          if (!header && ch != '\n')
+            { if (EMIT) stage[kept] = (unsigned char) ch;
+              kept += 1;
+            }
+        }
+    }
+}
+
+// last newline of the thread's bytes as position + 1 relative to `origin` (0 = none)
+__device__ __forceinline__ u64 fa_last_nl(const uint4 (&v)[4], int nvalid, int64_t origin)
+{ const unsigned char *b = (const unsigned char *) v;
+  u64 last = 0;
+#pragma unroll
+  for (int i = 0; i < FQ_PER; i++)
+    if (i < nvalid && b[i] == '\n')
+      last = (u64) (origin + i) + 1;
+  return last;
+}
+
+// tile_info[t*4 + 0] = global position + 1 of the tile's last newline (0 = none), [1] = bytes before
+// its first newline, [2] = kept bytes after the first newline, [3] = records started after it
+__global__ __launch_bounds__(FQ_THREADS) void k_fa_count(const unsigned char *__restrict__ raw, int64_t n,
+                                                         u64 *__restrict__ tile_info)
+{ __shared__ u64 tmp[8];
+  __shared__ u32 red[2];
+  __shared__ u64 s_first;
+  const int64_t tbase = (int64_t) blockIdx.x * FQ_TILE;
+  const int64_t base  = tbase + (int64_t) threadIdx.x * FQ_PER;
+  uint4 v[4];
+  int   nvalid;
+  fq_load(raw, n, base, v, nvalid);
+  const u64 mylast = fa_last_nl(v, nvalid, base);
+  u64 tot;
+  const u64 before = fa_block_exmax(mylast, tmp, &tot);       // last newline in front of this thread
+  if (threadIdx.x == 0) { red[0] = 0; red[1] = 0; s_first = 0; }
+  __syncthreads();
+  // first newline of the tile: the thread that has one while nothing precedes it
+  if (mylast != 0 && before == 0)
+    { const unsigned char *b = (const unsigned char *) v;
+      int f = 0;
+      while (b[f] != '\n') f++;
+      s_first = (u64) (base + f) + 1;
+    }
+  __syncthreads();
+  const u64 first = s_first;
+  u32 kept = 0, recs = 0;
+  if (before != 0)                                             // everything here lies after a newline
+    { const int64_t L = (int64_t) before - 1;
+      const bool fresh = (L + 1 == base);
+      fa_walk<false>(v, nvalid, fresh, !fresh && raw[L + 1] == '>', kept, recs, NULL);
+    }
+  else if (mylast != 0)                                        // holds the tile's first newline:
+    { const int f = (int) ((int64_t) first - 1 - base);        //   what follows it starts a line
+      fa_walk<false>(v, nvalid, true, false, kept, recs, NULL, f);
+    }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+    { kept += __shfl_down(kept, o, 64);
+      recs += __shfl_down(recs, o, 64);
+    }
+  if (fk_lane() == 0)
+    { if (kept) atomicAdd(&red[0], kept);
+      if (recs) atomicAdd(&red[1], recs);
+    }
+  __syncthreads();
+  if (threadIdx.x == 0)
+    { const int64_t tend = (n - tbase < FQ_TILE) ? n : tbase + FQ_TILE;
+      tile_info[(int64_t) blockIdx.x * 4 + 0] = tot;
+      tile_info[(int64_t) blockIdx.x * 4 + 1] = (first != 0) ? (u64) ((int64_t) first - 1 - tbase) : (u64) (tend - tbase);
+      tile_info[(int64_t) blockIdx.x * 4 + 2] = red[0];
+      tile_info[(int64_t) blockIdx.x * 4 + 3] = red[1];
+    }
+}
+
+// tile_state[t] = position + 1 of the last newline before tile t (0 = none in this piece);
+// tile_off[t] = kept bytes before tile t.  carry: bit 0 = the line open at the start of the piece is
+// a header, bit 1 = the piece starts at a line start.  out[0] = kept bytes, out[1] = records
+__global__ __launch_bounds__(256) void k_fa_scan(const unsigned char *__restrict__ raw,
+                                                 const u64 *__restrict__ tile_info, int64_t ntiles, int carry,
+                                                 u64 *__restrict__ tile_state, u64 *__restrict__ tile_off,
+                                                 u64 *__restrict__ out)
+{ __shared__ u64 tmp[8];
+  u64 carry_last = 0, carry_off = 0, recs = 0;
+  for (int64_t b = 0; b < ntiles; b += 256)
+    { const int64_t t = b + threadIdx.x;
+      const u64 mylast = (t < ntiles) ? tile_info[t * 4 + 0] : 0ull;
+      u64 totlast;
+      const u64 ex = max(carry_last, fa_block_exmax(mylast, tmp, &totlast));
+      u64 mykeep = 0;
+      if (t < ntiles)
+        { const int64_t tstart = t * FQ_TILE;
+          const u64 head = tile_info[t * 4 + 1];
+          bool fresh, header;
+          if (ex != 0)
+            { fresh = ((int64_t) ex == tstart);            // (ex - 1) + 1 == tstart
+              header = !fresh && raw[ex] == '>';
+            }
+          else
+            { fresh = (carry & 2) && tstart == 0;
+              header = !fresh && (((carry & 2) ? raw[0] == '>' : (carry & 1)) != 0);
+            }
+          u64 hk;
+          if (fresh)
+            hk = (head > 0 && raw[tstart] == '>') ? 1 : head;
+          else
+            hk = header ? 0 : head;
+          if (fresh && head > 0 && raw[tstart] == '>')
+            recs += 1;
+          mykeep = hk + tile_info[t * 4 + 2];
+          recs += tile_info[t * 4 + 3];
+          tile_state[t] = ex;
+        }
+      u64 totk;
+      const u64 exk = fk_block_exscan_256<u64>(mykeep, tmp, &totk);
+      if (t < ntiles)
+        tile_off[t] = carry_off + exk;
+      carry_off += totk;
+      carry_last = max(carry_last, totlast);
+    }
+  // records: sum over threads
+  __shared__ u64 s_recs;
+  if (threadIdx.x == 0) s_recs = 0;
+  __syncthreads();
+  if (recs) atomicAdd(&s_recs, recs);
+  __syncthreads();
+  if (threadIdx.x == 0)
+    { out[0] = carry_off;
+      out[1] = s_recs;
+    }
+}
+
+__global__ __launch_bounds__(FQ_THREADS) void k_fa_emit(const unsigned char *__restrict__ raw, int64_t n,
+                                                        const u64 *__restrict__ tile_state,
+                                                        const u64 *__restrict__ tile_off, int carry,
+                                                        unsigned char *__restrict__ dst)
+{ __shared__ unsigned char stage[FQ_TILE + 256];
+  __shared__ u64 tmp[8];
+  __shared__ u32 tmp32[8];
+  const int64_t tbase = (int64_t) blockIdx.x * FQ_TILE;
+  const int64_t base  = tbase + (int64_t) threadIdx.x * FQ_PER;
+  uint4 v[4];
+  int   nvalid;
+  fq_load(raw, n, base, v, nvalid);
+  const u64 mylast = fa_last_nl(v, nvalid, base);
+  u64 tot;
+  const u64 before = max(tile_state[blockIdx.x], fa_block_exmax(mylast, tmp, &tot));
+  bool fresh, header;
+  if (before != 0)
+    { fresh = ((int64_t) before == base);
+      header = !fresh && raw[before] == '>';
+    }
+  else
+    { fresh = (carry & 2) && base == 0;
+      header = !fresh && (((carry & 2) ? raw[0] == '>' : (carry & 1)) != 0);
+    }
+  u32 kept = 0, recs = 0;
+  fa_walk<false>(v, nvalid, fresh, header, kept, recs, NULL);
+  u32 tkept;
+  const u32 ex = fk_block_exscan_256<u32>(kept, tmp32, &tkept);
+  kept = 0; recs = 0;
+  fa_walk<true>(v, nvalid, fresh, header, kept, recs, stage + ex);
+  __syncthreads();
+  unsigned char *o = dst + tile_off[blockIdx.x];
+  for (u32 i = threadIdx.x; i < tkept; i += FQ_THREADS)
+    o[i] = stage[i];
+}
+
+/* d_raw: nbytes of FASTA text on the device.  *state: bit 0 = the open line is a header, bit 1 = at a
+   line start (2 before the first byte of a file); updated by the caller from the host copy of the text.
+   Every '>' at a line start writes a 0 (the end of the previous record), sequence bytes follow. */
+int fkx_parse_fasta(fk_ctx *ctx, const void *d_raw, int64_t nbytes, int state, void *d_dst,
+                    int64_t *nkept, int64_t *nrecs)
+{ hipStream_t s = ctx->stream;
+  *nkept = 0; *nrecs = 0;
+  if (nbytes <= 0)
+    return (FK_OK);
+  const int64_t ntiles = (nbytes + FQ_TILE - 1) / FQ_TILE;
+  u64 *d_info  = (u64 *) fk_slot(ctx, FK_SLOT_FQ_INFO, ntiles * 4 * 8);
+  u64 *d_state = (u64 *) fk_slot(ctx, FK_SLOT_FQ_PHASE, ntiles * 8);
+  u64 *d_off   = (u64 *) fk_slot(ctx, FK_SLOT_FQ_OFF, ntiles * 8);
+  if (d_info == NULL || d_state == NULL || d_off == NULL)
+    return (FK_ENOMEM);
+  u64 *d_out = ctx->d_scratch + 2048;
+  hipLaunchKernelGGL(k_fa_count, dim3((unsigned) ntiles), dim3(FQ_THREADS), 0, s,
+                     (const unsigned char *) d_raw, nbytes, d_info);
+  hipLaunchKernelGGL(k_fa_scan, dim3(1), dim3(256), 0, s, (const unsigned char *) d_raw, (const u64 *) d_info,
+                     ntiles, state, d_state, d_off, d_out);
+  hipLaunchKernelGGL(k_fa_emit, dim3((unsigned) ntiles), dim3(FQ_THREADS), 0, s,
+                     (const unsigned char *) d_raw, nbytes, (const u64 *) d_state, (const u64 *) d_off, state,
+                     (unsigned char *) d_dst);
+  FK_LAUNCH_CHECK(ctx);
+  FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch, d_out, 2 * sizeof(u64), hipMemcpyDeviceToHost, s));
+  FK_HIP(ctx, hipStreamSynchronize(s));
+  *nkept = (int64_t) ctx->h_scratch[0];
+  *nrecs = (int64_t) ctx->h_scratch[1];
+  return (FK_OK);
+}

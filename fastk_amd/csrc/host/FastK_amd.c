@@ -12,7 +12,8 @@
  * them to fk_push_block -- the call that replaces Distribute_Block (FastK.h:123).  Everything
  * per-base and per-record runs on the GPU inside the library.
  *
- * FASTQ text is parsed on the GPU (fk_push_fastq) unless -bc, -x or -H (extension: host parser) is given.
+ * FASTQ and FASTA text is parsed on the GPU (fk_push_fastq / fk_push_fasta) unless -bc, -x or -H
+ * (extension: host parser) is given.
  *
  * -x (extension, no reference counterpart): exact part files -- replays the reference's own super-mer
  * rule so that the hidden .ktab parts are cut at the reference's first bytes (fk_params.exact_parts);
@@ -125,14 +126,15 @@ static int classify(const char *path, char **root, char **dir)
   return (-1);
 }
 
-/* FASTQ: hand the file text to the library in large pieces; the record structure is resolved on the
-   GPU (fk_push_fastq).  Used unless -bc / -x ask for host-side read offsets. */
+/* Hand the file text to the library in large pieces; the record structure is resolved on the GPU
+   (fk_push_fastq / fk_push_fasta).  Used unless -bc / -x ask for host-side read offsets (or -c on
+   FASTA: compression across the line breaks of a record is left to the host parser). */
 #define RAW_BYTES (64 << 20)
 
-static void scan_fastq_on_device(Feeder *f, const char *path)
+static void scan_text_on_device(Feeder *f, const char *path, int fastq)
 { gzFile in = gzopen(path,"rb");
   static char *raw = NULL;
-  int     phase = 0, n;
+  int     phase = fastq ? 0 : 2, n;
 
   if (in == NULL)
     { fprintf(stderr,"%s: Cannot open %s for reading\n",Prog_Name,path);
@@ -144,11 +146,17 @@ static void scan_fastq_on_device(Feeder *f, const char *path)
   flush_block(f,0);                        /* keep the order of reads across input files */
   while ((n = gzread(in,raw,RAW_BYTES)) > 0)
     { int64_t nr = 0, nb = 0;
-      if (fk_push_fastq(f->ctx,raw,n,COMPRESS ? FK_FASTQ_HOCO : 0,&phase,&nr,&nb) != FK_OK)
-        die(f->ctx,"fk_push_fastq");
+      if (fastq)
+        { if (fk_push_fastq(f->ctx,raw,n,COMPRESS ? FK_FASTQ_HOCO : 0,&phase,&nr,&nb) != FK_OK)
+            die(f->ctx,"fk_push_fastq");
+        }
+      else if (fk_push_fasta(f->ctx,raw,n,0,&phase,&nr,&nb) != FK_OK)
+        die(f->ctx,"fk_push_fasta");
       f->totrds += nr;
       f->totbps += nb;
     }
+  if (!fastq && fk_push_fasta(f->ctx,NULL,0,1,&phase,NULL,NULL) != FK_OK)     /* ends the last record */
+    die(f->ctx,"fk_push_fasta");
   gzclose(in);
 }
 
@@ -288,8 +296,8 @@ int main(int argc, char *argv[])
         { root = r; dir = d; }            /* outputs take the first file's root, FastK.c:402-405 */
       else
         { free(r); free(d); }
-      if (q == 1 && !EXACT && BC_PREFIX == 0 && !HOST_PARSE)
-        scan_fastq_on_device(&feed,argv[i]);
+      if (!EXACT && BC_PREFIX == 0 && !HOST_PARSE && (q == 1 || !COMPRESS))
+        scan_text_on_device(&feed,argv[i],q);
       else
         scan_file(&feed,argv[i],q);
     }

@@ -241,6 +241,11 @@ int fk_count_unsorted_kmers(fk_ctx *ctx, void *d_kmers, void *d_tmp, int64_t nwe
 #define FK_FASTQ_HOCO 1      /* flags: homopolymer-compress the reads (-c, io.c:284-294) */
 int fk_push_fastq(fk_ctx *ctx, const char *raw, int64_t nbytes, int flags, int *line_phase,
                   int64_t *nreads, int64_t *nbases);
+/* The same for FASTA text (a line starting with '>' is a header, all other lines of a record are one
+   read, io.c:700-734).  *state must be 2 before the first piece of a file; last != 0 with the final
+   piece of a file. */
+int fk_push_fasta(fk_ctx *ctx, const char *raw, int64_t nbytes, int last, int *state, int64_t *nreads,
+                  int64_t *nbases);
 int fk_host_alloc(int64_t nbytes, void **ptr);      /* pinned host memory */
 int fk_host_free(void *ptr);
 

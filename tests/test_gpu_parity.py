@@ -320,6 +320,35 @@ def test_fastq_parsed_on_device_matches_golden(name, tmp_path):
         util.check_against_golden(case, res.hist, res.max_inst, res.table)
 
 
+@pytest.mark.parametrize("width", [0, 60, 7])
+@pytest.mark.parametrize("name", ["synth_hifi_k40_t4_T8", "edge_k40_t1_T4", "synth_illumina_k40_t1_T4"])
+def test_fasta_parsed_on_device_matches_golden(name, width):
+    """fk_push_fasta: raw FASTA text (single-line and multi-line records, headers that contain ACGT and
+    '>' characters) cut into pieces at arbitrary bytes gives the reference result."""
+    case, bases, boff = util.load_case(name)
+    parts = []
+    for i in range(len(boff) - 1):
+        seq = bases[boff[i]:boff[i + 1] - 1].tobytes()
+        parts.append(b">r%d ACGT>ACGTACGTACGTACGTACGTACGTACGTACGTACGTACGTACGT\n" % i)
+        if width:
+            parts.extend(seq[j:j + width] + b"\n" for j in range(0, len(seq), width))
+        else:
+            parts.append(seq + b"\n")
+    text = b"".join(parts)
+    rng = np.random.default_rng(4)
+    with fastk_amd.Context(kmer=case["k"], table_cutoff=case["cutoff"], nthreads=case["T"]) as ctx:
+        st, nr, nb, pos = 2, 0, 0, 0
+        while pos < len(text):
+            n = int(rng.integers(1, 150000))
+            st, r, b = ctx.push_fasta(text[pos:pos + n], st, last=(pos + n >= len(text)))
+            nr += r; nb += b
+            pos += n
+        assert nr == len(boff) - 1
+        assert nb == len(bases) - (len(boff) - 1)
+        res = ctx.finish()
+        util.check_against_golden(case, res.hist, res.max_inst, res.table)
+
+
 def _hoco(bases, boff):
     """homopolymer-compress every read (io.c:284-294): drop a base equal to the one before it."""
     out, off = [], [0]
