@@ -9,6 +9,7 @@
 #include <unistd.h>
 #include <algorithm>
 #include <vector>
+#include <thread>
 
 static char g_last_error[512] = "";
 
@@ -1401,17 +1402,27 @@ extern "C" int fk_write_ktab(const fk_result *res, int kmer, int table_cutoff, i
   int64_t *idx = (int64_t *) calloc((size_t) nidx, sizeof(int64_t));
   char name[4096];
   int rc = FK_OK;
-  int64_t lo = 0;
-  for (int t = 0; t < nthreads && rc == FK_OK; t++)
-    { int64_t hi = lo;
-      while (hi < res->ntable && res->table[hi * KW] < split[t + 1])
-        hi += 1;
-      const int64_t n = hi - lo;
-      snprintf(name, sizeof(name), "%s/.%s.ktab.%d", dir, root, t + 1);
-      int fd = open(name, O_WRONLY | O_CREAT | O_TRUNC, 0644);
-      if (fd < 0) { rc = FK_EINVAL; break; }
+  // part boundaries by binary search on the first byte, then one writer thread per part: the parts
+  // are disjoint first-byte ranges, so their prefix-index entries are disjoint as well
+  std::vector<int64_t> bound((size_t) nthreads + 1, 0);
+  for (int t = 1; t <= nthreads; t++)
+    { int64_t lo = bound[t - 1], hi = res->ntable;
+      while (lo < hi)
+        { const int64_t mid = (lo + hi) >> 1;
+          if (res->table[mid * KW] < split[t]) lo = mid + 1; else hi = mid;
+        }
+      bound[t] = lo;
+    }
+  std::vector<int> prc((size_t) nthreads, FK_OK);
+  auto write_part = [&](int t)
+    { const int64_t lo = bound[t], hi = bound[t + 1], n = hi - lo;
+      char pname[4096];
+      snprintf(pname, sizeof(pname), "%s/.%s.ktab.%d", dir, root, t + 1);
+      int fd = open(pname, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+      if (fd < 0) { prc[t] = FK_EINVAL; return; }
       const int pw = KW - ib;
       uint8_t *buf = (uint8_t *) malloc((size_t) (n > 0 ? n : 1) * pw);
+      if (buf == NULL) { close(fd); prc[t] = FK_ENOMEM; return; }
       for (int64_t i = lo; i < hi; i++)
         { const uint8_t *rec = res->table + i * KW;
           int64_t pre = 0;
@@ -1421,11 +1432,22 @@ extern "C" int fk_write_ktab(const fk_result *res, int kmer, int table_cutoff, i
           memcpy(buf + (i - lo) * pw, rec + ib, pw);
         }
       if (write_all(fd, &kmer, 4) | write_all(fd, &n, 8) | write_all(fd, buf, (size_t) n * pw))
-        rc = FK_EINVAL;
+        prc[t] = FK_EINVAL;
       free(buf);
       close(fd);
-      lo = hi;
-    }
+    };
+  { std::vector<std::thread> th;
+    for (int t = 1; t < nthreads; t++)
+      th.emplace_back(write_part, t);
+    write_part(0);
+    for (auto &x : th)
+      x.join();
+  }
+  for (int t = 0; t < nthreads; t++)
+    if (prc[t] != FK_OK)
+      { rc = prc[t];
+        snprintf(name, sizeof(name), "%s/.%s.ktab.%d", dir, root, t + 1);
+      }
   if (rc == FK_OK)
     { for (int64_t i = 1; i < nidx; i++)
         idx[i] += idx[i - 1];

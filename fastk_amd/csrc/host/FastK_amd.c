@@ -30,6 +30,9 @@
 #include <string.h>
 #include <ctype.h>
 #include <zlib.h>
+#include <sys/time.h>
+#include <fcntl.h>
+#include <unistd.h>
 
 #include "../../../include/fastk_amd.h"
 
@@ -37,6 +40,12 @@
 #define BLOCK_READS 100000
 
 static char *Prog_Name = "FastK_amd";
+
+static double now(void)
+{ struct timeval tv;
+  gettimeofday(&tv,NULL);
+  return (tv.tv_sec + 1e-6*tv.tv_usec);
+}
 
 static int       KMER = 40, NTHREADS = 4, DO_TABLE = 0, BC_PREFIX = 0, VERBOSE = 0, EXACT = 0, MEM_GB = 0;
 static int       HOST_PARSE = 0, COMPRESS = 0;
@@ -132,19 +141,27 @@ static int classify(const char *path, char **root, char **dir)
 #define RAW_BYTES (64 << 20)
 
 static void scan_text_on_device(Feeder *f, const char *path, int fastq)
-{ gzFile in = gzopen(path,"rb");
+{ gzFile in = NULL;
+  int    fd = -1;
   static char *raw = NULL;
   int     phase = fastq ? 0 : 2, n;
+  size_t  pl = strlen(path);
 
-  if (in == NULL)
+  /* plain files are read straight into the pinned buffer; zlib only for .gz */
+  if (pl > 3 && strcmp(path+pl-3,".gz") == 0)
+    { in = gzopen(path,"rb");
+      if (in != NULL) gzbuffer(in,1 << 20);
+    }
+  else
+    fd = open(path,O_RDONLY);
+  if (in == NULL && fd < 0)
     { fprintf(stderr,"%s: Cannot open %s for reading\n",Prog_Name,path);
       exit (1);
     }
   if (raw == NULL && fk_host_alloc(RAW_BYTES,(void **) &raw) != FK_OK)
     die(NULL,"pinned read buffer");
-  gzbuffer(in,1 << 20);
   flush_block(f,0);                        /* keep the order of reads across input files */
-  while ((n = gzread(in,raw,RAW_BYTES)) > 0)
+  while ((n = (in != NULL) ? gzread(in,raw,RAW_BYTES) : (int) read(fd,raw,RAW_BYTES)) > 0)
     { int64_t nr = 0, nb = 0;
       if (fastq)
         { if (fk_push_fastq(f->ctx,raw,n,COMPRESS ? FK_FASTQ_HOCO : 0,&phase,&nr,&nb) != FK_OK)
@@ -157,7 +174,7 @@ static void scan_text_on_device(Feeder *f, const char *path, int fastq)
     }
   if (!fastq && fk_push_fasta(f->ctx,NULL,0,1,&phase,NULL,NULL) != FK_OK)     /* ends the last record */
     die(f->ctx,"fk_push_fasta");
-  gzclose(in);
+  if (in != NULL) gzclose(in); else close(fd);
 }
 
 static void scan_file(Feeder *f, const char *path, int fastq)
@@ -234,6 +251,8 @@ int main(int argc, char *argv[])
       exit (1);
     }
 
+  double t_start = now(), t_ingest, t_count, t_write;
+
   fk_default_params(&prm);
   prm.kmer = KMER; prm.table_cutoff = DO_TABLE; prm.nthreads = NTHREADS; prm.bc_prefix = BC_PREFIX;
   prm.exact_parts = EXACT;
@@ -309,8 +328,10 @@ int main(int argc, char *argv[])
       dir  = slash ? strndup(OUT_NAME,(size_t) (slash-OUT_NAME)) : strdup(".");
     }
 
+  t_ingest = now();
   if (fk_finish(ctx,res) != FK_OK)
     die(ctx,"fk_finish");
+  t_count = now();
 
   if (VERBOSE)
     { fprintf(stderr,"\n  There are %lld reads totalling %lld bps\n",(long long) feed.totrds,(long long) feed.totbps);
@@ -329,6 +350,10 @@ int main(int argc, char *argv[])
   if (DO_TABLE > 0 && fk_write_ktab(res,KMER,DO_TABLE,NTHREADS,dir,root) != FK_OK)
     die(ctx,"writing .ktab");
 
+  t_write = now();
+  if (VERBOSE)
+    fprintf(stderr,"  Wall s: start-up + ingest %.3f  count + table fetch %.3f  write %.3f\n",
+            t_ingest-t_start,t_count-t_ingest,t_write-t_count);
   fk_destroy(ctx);
   free(feed.bases); free(feed.boff); free(res); free(root); free(dir);
   exit (0);
