@@ -352,6 +352,10 @@ extern "C" int fk_debug_set(fk_ctx *ctx, const char *key, int64_t value)
     { ctx->dbg_radix_items = (int) value;
       return (FK_OK);
     }
+  if (strcmp(key, "table_sort") == 0)       // 1: plain full-key table sort, >= 2: prefix bytes of the short one
+    { ctx->dbg_table_sort = (int) value;
+      return (FK_OK);
+    }
   if (strcmp(key, "verbose") == 0)          // per-bucket sizes and times on stderr
     { ctx->dbg_verbose = (int) value;
       return (FK_OK);
@@ -379,6 +383,10 @@ extern "C" int fk_debug_get(fk_ctx *ctx, const char *key, int64_t *value)
 { if (ctx == NULL || key == NULL || value == NULL) return (FK_EINVAL);
   if (strcmp(key, "aggr_extra_rounds") == 0)
     { *value = ctx->aggr_extra_rounds;
+      return (FK_OK);
+    }
+  if (strcmp(key, "table_sort_ties") == 0)
+    { *value = ctx->tsort_ties;
       return (FK_OK);
     }
   return (FK_EINVAL);
@@ -563,11 +571,8 @@ extern "C" int fk_count_unsorted_kmers(fk_ctx *ctx, void *d_kmers, void *d_tmp, 
                      cutoff > 0 ? tbuf : NULL, nweighted, &nt);
   if (rc != FK_OK) return (rc);
   if (cutoff > 0)
-    { int bytes[64];
-      for (int i = 0; i < w.kmer_bytes; i++)
-        bytes[i] = w.kmer_bytes - 1 - i;
-      void *sorted = tbuf;
-      if (nt > 0 && (rc = fkx_lsd_sort(ctx, nt, tbuf, grouped, w.kmer_stride, bytes, w.kmer_bytes, &sorted)) != FK_OK)
+    { void *sorted = tbuf;
+      if (nt > 0 && (rc = fkx_sort_table(ctx, nt, tbuf, grouped, &sorted, NULL)) != FK_OK)
         return (rc);
       *d_table = sorted;
       *ntable = nt;
@@ -1029,17 +1034,15 @@ static int count_bucket(fk_ctx *ctx, void *sm_in, int64_t ns, fk_result *res, bo
       if (cutoff > 0 && nt > 0)
         { if (final)
             { if (!tab_sorted)
-                { int bytes[64];
-                  for (int i = 0; i < w.kmer_bytes; i++)
-                    bytes[i] = w.kmer_bytes - 1 - i;
-                  void *sorted = tab;
-                  if ((rc = fkx_lsd_sort(ctx, nt, tab, km_b, w.kmer_stride, bytes, w.kmer_bytes, &sorted)) != FK_OK)
+                { void *sorted = tab;
+                  int64_t census[256];
+                  if ((rc = fkx_sort_table(ctx, nt, tab, km_b, &sorted, census)) != FK_OK)
                     break;
                   res->passes_final   = ctx->sort_stats.passes;
                   res->ms_pass_final += ctx->sort_stats.pass_ms_total;
                   tab = sorted;
                   for (int x = 0; x < 256; x++)
-                    res->wfirst[x] = (exact_roff != NULL) ? exact_census[x] : (int64_t) ctx->h_scratch[x];
+                    res->wfirst[x] = (exact_roff != NULL) ? exact_census[x] : census[x];
                 }
               *table_out = tab;
             }
@@ -1208,19 +1211,16 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
           if (rc == FK_OK && ntab > 0)
             { // the union of the buckets' tables, in k-mer order
               void *tmp = fk_slot(ctx, FK_SLOT_KM_A, ntab * w.kmer_stride);
-              int bytes[64];
+              int64_t census[256];
               if (tmp == NULL) { rc = FK_ENOMEM; break; }
-              for (int i = 0; i < w.kmer_bytes; i++)
-                bytes[i] = w.kmer_bytes - 1 - i;
               hipEventRecord(ctx->ev0, s);
               table = ctx->slot_ptr[FK_SLOT_TABLE];
-              if ((rc = fkx_lsd_sort(ctx, ntab, ctx->slot_ptr[FK_SLOT_TABLE], tmp, w.kmer_stride, bytes,
-                                     w.kmer_bytes, &table)) != FK_OK)
+              if ((rc = fkx_sort_table(ctx, ntab, ctx->slot_ptr[FK_SLOT_TABLE], tmp, &table, census)) != FK_OK)
                 break;
               res->passes_final   = ctx->sort_stats.passes;
               res->ms_pass_final += ctx->sort_stats.pass_ms_total;
               for (int x = 0; x < 256; x++)
-                res->wfirst[x] = (int64_t) ctx->h_scratch[x];
+                res->wfirst[x] = census[x];
               hipEventRecord(ctx->ev1, s);
               hipEventSynchronize(ctx->ev1);
               tm.radix_k += ms_between(ctx->ev0, ctx->ev1);

@@ -1,0 +1,271 @@
+// fk_tsort.hip -- order the table records (distinct k-mers) on KMER_BYTES with fewer digit passes.
+//
+// The reference's table comes out of Weighted_Kmer_Sort fully sorted (MSDsort.c:536-544); here the
+// table records leave the aggregation in no order and must be sorted on all KMER_BYTES.  n distinct
+// keys rarely agree in their leading P = ceil(log256 n) + 1 bytes, so the table is LSD-sorted on
+// those P bytes only (P passes instead of KMER_BYTES), the few records that tie with a neighbour on
+// the P bytes are pulled out (stream compaction, in position order), sorted on the full key among
+// themselves, and written back into the slots they came from: runs of ties are contiguous and in
+// run order both before and after, so the i-th sorted tie belongs in the i-th tie slot.  The result
+// is the same total order whatever the data looks like; repetitive data only makes the repaired
+// subset larger.
+#include "fk_common.h"
+
+#define TS_THREADS 256
+#define TS_ITEMS   8
+#define TS_TILE    (TS_THREADS * TS_ITEMS)
+
+template <int KW>
+__device__ __forceinline__ bool ts_same(const u32 *a, const u32 *b, int full, u32 lastm)
+{ bool same = true;
+#pragma unroll
+  for (int w = 0; w < KW; w++)
+    { const u32 m = (w < full) ? 0xffffffffu : (w == full) ? lastm : 0u;
+      same = same && (((a[w] ^ b[w]) & m) == 0u);
+    }
+  return same;
+}
+
+// EMIT = false: tile_count[t] = records of tile t that agree with a neighbour on the first pbytes bytes
+// EMIT = true : those records go to sub[] and their positions to pos[], from offset tile_off[t]
+template <int KW, bool EMIT>
+__global__ __launch_bounds__(TS_THREADS) void k_ts_ties(const u32 *__restrict__ recs, int64_t n, int pbytes,
+                                                        u32 *__restrict__ tile_count,
+                                                        const u64 *__restrict__ tile_off,
+                                                        u32 *__restrict__ sub, u64 *__restrict__ pos)
+{ __shared__ u32 tmp[8];
+  const int  full  = pbytes >> 2;
+  const u32  lastm = (pbytes & 3) ? ((1u << (8 * (pbytes & 3))) - 1u) : 0u;
+  const int64_t t0 = (int64_t) blockIdx.x * TS_TILE + (int64_t) threadIdx.x * TS_ITEMS;
+  u32 r[TS_ITEMS + 2][KW];
+#pragma unroll
+  for (int j = 0; j < TS_ITEMS + 2; j++)
+    { const int64_t i = t0 + j - 1;
+#pragma unroll
+      for (int w = 0; w < KW; w++)
+        r[j][w] = (i >= 0 && i < n) ? recs[i * KW + w] : 0u;
+    }
+  u32 flags = 0, cnt = 0;
+#pragma unroll
+  for (int j = 1; j <= TS_ITEMS; j++)
+    { const int64_t i = t0 + j - 1;
+      if (i < n)
+        { const bool tie = (i > 0 && ts_same<KW>(r[j], r[j - 1], full, lastm))
+                        || (i + 1 < n && ts_same<KW>(r[j], r[j + 1], full, lastm));
+          if (tie)
+            { flags |= 1u << j;
+              cnt += 1;
+            }
+        }
+    }
+  u32 tot;
+  const u32 ex = fk_block_exscan_256<u32>(cnt, tmp, &tot);
+  if (!EMIT)
+    { if (threadIdx.x == 0)
+        tile_count[blockIdx.x] = tot;
+      return;
+    }
+  u64 o = tile_off[blockIdx.x] + ex;
+#pragma unroll
+  for (int j = 1; j <= TS_ITEMS; j++)
+    if ((flags >> j) & 1u)
+      {
+#pragma unroll
+        for (int w = 0; w < KW; w++)
+          sub[o * KW + w] = r[j][w];
+        pos[o] = (u64) (t0 + j - 1);
+        o += 1;
+      }
+}
+
+// records as byte strings: a < b on the first kbytes bytes
+template <int KW>
+__device__ __forceinline__ bool ts_less(const u32 *a, const u32 *b, int kfull, u32 klast)
+{
+#pragma unroll
+  for (int w = 0; w < KW; w++)
+    { const u32 m = (w < kfull) ? 0xffffffffu : (w == kfull) ? klast : 0u;
+      const u32 x = __builtin_bswap32(a[w] & m), y = __builtin_bswap32(b[w] & m);
+      if (x != y)
+        return (x < y);
+    }
+  return (false);
+}
+
+// In-place repair of short tie runs: the thread of a run's first record insertion-sorts the run on
+// the full key (runs are disjoint, so no other thread touches these records).  Read data makes such
+// runs common and short: a k-mer and its single-substitution error variants agree on every prefix
+// that does not contain the substituted base.  A run longer than `limit` raises *long_runs and is
+// left to the compaction path.
+template <int KW>
+__global__ __launch_bounds__(TS_THREADS) void k_ts_fix(u32 *__restrict__ recs, int64_t n, int pbytes,
+                                                       int kbytes, int limit, u32 *__restrict__ long_runs)
+{ const int  full  = pbytes >> 2;
+  const u32  lastm = (pbytes & 3) ? ((1u << (8 * (pbytes & 3))) - 1u) : 0u;
+  const int  kfull = kbytes >> 2;
+  const u32  klast = (kbytes & 3) ? ((1u << (8 * (kbytes & 3))) - 1u) : 0u;
+  const int64_t i = (int64_t) blockIdx.x * TS_THREADS + threadIdx.x;
+  if (i >= n)
+    return;
+  u32 me[KW], nb[KW];
+#pragma unroll
+  for (int w = 0; w < KW; w++)
+    me[w] = recs[i * KW + w];
+  if (i > 0)
+    {
+#pragma unroll
+      for (int w = 0; w < KW; w++)
+        nb[w] = recs[(i - 1) * KW + w];
+      if (ts_same<KW>(me, nb, full, lastm))
+        return;                                    // not the first record of its run
+    }
+  for (int64_t j = i + 1; j < n; j++)
+    { u32 x[KW];
+#pragma unroll
+      for (int w = 0; w < KW; w++)
+        x[w] = recs[j * KW + w];
+      if (!ts_same<KW>(me, x, full, lastm))
+        break;
+      if (j - i >= limit)
+        { *long_runs = 1;
+          return;
+        }
+      int64_t k = j - 1;                            // insert x into the sorted recs[i..j-1]
+      while (k >= i)
+        { u32 y[KW];
+#pragma unroll
+          for (int w = 0; w < KW; w++)
+            y[w] = recs[k * KW + w];
+          if (!ts_less<KW>(x, y, kfull, klast))
+            break;
+#pragma unroll
+          for (int w = 0; w < KW; w++)
+            recs[(k + 1) * KW + w] = y[w];
+          k -= 1;
+        }
+#pragma unroll
+      for (int w = 0; w < KW; w++)
+        recs[(k + 1) * KW + w] = x[w];
+    }
+}
+
+template <int KW>
+__global__ __launch_bounds__(TS_THREADS) void k_ts_putback(const u32 *__restrict__ sub,
+                                                           const u64 *__restrict__ pos, int64_t m,
+                                                           u32 *__restrict__ recs)
+{ const int64_t j = (int64_t) blockIdx.x * TS_THREADS + threadIdx.x;
+  if (j >= m)
+    return;
+  const u64 p = pos[j];
+#pragma unroll
+  for (int w = 0; w < KW; w++)
+    recs[p * KW + w] = sub[j * KW + w];
+}
+
+template <int KW>
+static int tsort_t(fk_ctx *ctx, int64_t n, void *d_tab, void *d_tmp, void **result, int64_t *wfirst)
+{ hipStream_t s = ctx->stream;
+  const int kb = ctx->wid.kmer_bytes, stride = ctx->wid.kmer_stride;
+  int bytes[64];
+  *result = d_tab;
+  if (n <= 0)
+    return (FK_OK);
+  int P = 1;
+  while (P < 8 && (n >> (8 * P)) > 0)
+    P += 1;                                         // ceil(log256 n)
+  P += 1;
+  if (ctx->dbg_table_sort >= 2 && ctx->dbg_table_sort < kb)   // tests: a short prefix makes many ties
+    P = ctx->dbg_table_sort;
+  else if (P >= kb || n < (1 << 20) || ctx->dbg_table_sort == 1)
+    P = kb;
+  if (P >= kb)
+    { for (int i = 0; i < kb; i++)
+        bytes[i] = kb - 1 - i;
+      int rc = fkx_lsd_sort(ctx, n, d_tab, d_tmp, stride, bytes, kb, result);
+      if (rc == FK_OK && wfirst != NULL)
+        for (int x = 0; x < 256; x++)
+          wfirst[x] = (int64_t) ctx->h_scratch[x];
+      return (rc);
+    }
+  for (int i = 0; i < P; i++)
+    bytes[i] = P - 1 - i;
+  void *sorted = d_tab;
+  int rc = fkx_lsd_sort(ctx, n, d_tab, d_tmp, stride, bytes, P, &sorted);
+  if (rc != FK_OK)
+    return (rc);
+  const int passes = ctx->sort_stats.passes;
+  const double pass_ms = ctx->sort_stats.pass_ms_total, scat_ms = ctx->sort_stats.scatter_ms_total;
+  if (wfirst != NULL)
+    for (int x = 0; x < 256; x++)
+      wfirst[x] = (int64_t) ctx->h_scratch[x];
+  *result = sorted;
+
+  // short tie runs are sorted where they are; only if some run is long does the compaction path run
+  u64 *d_tot = ctx->d_scratch + 3072;
+  FK_HIP(ctx, hipMemsetAsync(d_tot + 1, 0, 8, s));
+  hipLaunchKernelGGL(k_ts_fix<KW>, dim3((unsigned) ((n + TS_THREADS - 1) / TS_THREADS)), dim3(TS_THREADS), 0, s,
+                     (u32 *) sorted, n, P, kb, 48, (u32 *) (d_tot + 1));
+  FK_LAUNCH_CHECK(ctx);
+  FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch + 4096, d_tot + 1, 8, hipMemcpyDeviceToHost, s));
+  FK_HIP(ctx, hipStreamSynchronize(s));
+  ctx->tsort_ties = 0;
+  if ((ctx->h_scratch[4096] & 0xffffffffull) == 0 && ctx->dbg_table_sort < 2)
+    { ctx->sort_stats.passes = passes;
+      return (FK_OK);
+    }
+
+  const int64_t ntiles = (n + TS_TILE - 1) / TS_TILE;
+  u32 *d_cnt = (u32 *) fk_slot(ctx, FK_SLOT_CT_ENT, ntiles * 4);
+  u64 *d_off = (u64 *) fk_slot(ctx, FK_SLOT_CT_OFF, ntiles * 8);
+  if (d_cnt == NULL || d_off == NULL)
+    return (FK_ENOMEM);
+  hipLaunchKernelGGL((k_ts_ties<KW, false>), dim3((unsigned) ntiles), dim3(TS_THREADS), 0, s,
+                     (const u32 *) sorted, n, P, d_cnt, (const u64 *) NULL, (u32 *) NULL, (u64 *) NULL);
+  hipLaunchKernelGGL(k_exscan_tiles, dim3(1), dim3(256), 0, s, (const u32 *) d_cnt, ntiles, d_off, d_tot);
+  FK_LAUNCH_CHECK(ctx);
+  FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch + 4096, d_tot, 8, hipMemcpyDeviceToHost, s));
+  FK_HIP(ctx, hipStreamSynchronize(s));
+  const int64_t m = (int64_t) ctx->h_scratch[4096];
+  ctx->tsort_ties = m;
+  if (m == 0)
+    return (FK_OK);
+  u32 *d_sa = (u32 *) fk_slot(ctx, FK_SLOT_TIE_A, m * stride);
+  u32 *d_sb = (u32 *) fk_slot(ctx, FK_SLOT_TIE_B, m * stride);
+  u64 *d_ps = (u64 *) fk_slot(ctx, FK_SLOT_TIE_POS, m * 8);
+  if (d_sa == NULL || d_sb == NULL || d_ps == NULL)
+    return (FK_ENOMEM);
+  hipLaunchKernelGGL((k_ts_ties<KW, true>), dim3((unsigned) ntiles), dim3(TS_THREADS), 0, s,
+                     (const u32 *) sorted, n, P, d_cnt, (const u64 *) d_off, d_sa, d_ps);
+  FK_LAUNCH_CHECK(ctx);
+  for (int i = 0; i < kb; i++)
+    bytes[i] = kb - 1 - i;
+  void *subsorted = d_sa;
+  if ((rc = fkx_lsd_sort(ctx, m, d_sa, d_sb, stride, bytes, kb, &subsorted)) != FK_OK)
+    return (rc);
+  hipLaunchKernelGGL(k_ts_putback<KW>, dim3((unsigned) ((m + TS_THREADS - 1) / TS_THREADS)), dim3(TS_THREADS), 0, s,
+                     (const u32 *) subsorted, (const u64 *) d_ps, m, (u32 *) sorted);
+  FK_LAUNCH_CHECK(ctx);
+  FK_HIP(ctx, hipStreamSynchronize(s));
+  // report the passes over the whole table (what bench.py prices), not the small repair sort
+  ctx->sort_stats.passes = passes;
+  ctx->sort_stats.pass_ms_total = pass_ms;
+  ctx->sort_stats.scatter_ms_total = scat_ms;
+  ctx->sort_stats.nelem = n;
+  return (FK_OK);
+}
+
+/* Sort n table records (kmer_stride bytes each, distinct keys or not) on their KMER_BYTES key.
+   d_tab and d_tmp are the ping-pong pair; *result points at the sorted one.  wfirst (may be NULL)
+   receives the first-byte census of the records. */
+int fkx_sort_table(fk_ctx *ctx, int64_t n, void *d_tab, void *d_tmp, void **result, int64_t *wfirst)
+{ switch (ctx->wid.kmer_stride >> 2)
+  { case 1: return tsort_t<1>(ctx, n, d_tab, d_tmp, result, wfirst);
+    case 2: return tsort_t<2>(ctx, n, d_tab, d_tmp, result, wfirst);
+    case 3: return tsort_t<3>(ctx, n, d_tab, d_tmp, result, wfirst);
+    case 4: return tsort_t<4>(ctx, n, d_tab, d_tmp, result, wfirst);
+    case 5: return tsort_t<5>(ctx, n, d_tab, d_tmp, result, wfirst);
+    default:
+      fk_set_error(ctx, "k-mer stride %d not built", ctx->wid.kmer_stride);
+      return (FK_EUNSUPPORTED);
+  }
+}

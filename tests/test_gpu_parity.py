@@ -419,6 +419,22 @@ def test_cli_memory_option(tmp_path):
     assert orc.read_ktab(str(tmp_path / "reads"))["stream_sha256"] == exp["ktab"]["stream_sha256"]
 
 
+@pytest.mark.parametrize("prefix", [1, 2, 3, 5])
+@pytest.mark.parametrize("name", ["synth_illumina_k40_t1_T4", "edge_k40_t1_T4", "synth_illumina_k51_t1_T4"])
+def test_table_sort_by_prefix_and_tie_repair(name, prefix):
+    """fk_debug_set("table_sort", p): the table is sorted on its first p key bytes only and the
+    records that tie with a neighbour are repaired (p = 2, 3: nearly everything ties on these small
+    tables; p = 1 is the plain full-key sort); the table must come out in the reference's order."""
+    case, bases, boff = util.load_case(name)
+    with fastk_amd.Context(kmer=case["k"], table_cutoff=case["cutoff"], nthreads=case["T"]) as ctx:
+        ctx.debug_set("table_sort", prefix)
+        ctx.push_block(bases, boff.astype(np.int32))
+        res = ctx.finish()
+        if prefix in (2, 3):
+            assert ctx.debug_get("table_sort_ties") > 0
+        util.check_against_golden(case, res.hist, res.max_inst, res.table)
+
+
 def test_empty_and_degenerate_inputs():
     with fastk_amd.Context(kmer=40, table_cutoff=1) as ctx:
         res = ctx.finish()
