@@ -435,6 +435,34 @@ def test_table_sort_by_prefix_and_tie_repair(name, prefix):
         util.check_against_golden(case, res.hist, res.max_inst, res.table)
 
 
+@pytest.mark.parametrize("k", [12, 16, 19, 20, 21, 28, 31, 32, 33, 44, 47, 48, 52, 56, 60, 63, 64])
+def test_whole_path_across_k(k):
+    """Record widths change with k (KMER_BYTES 3..16, one to five dwords per k-mer record, window
+    W = k-4 below and above the 16-position block of the splitter): the whole path must agree with
+    the CPU restatement for every width class, resident and bucket-streamed."""
+    rng = np.random.default_rng(k)
+    genome = rng.integers(0, 4, size=30000)
+    reads = []
+    for _ in range(1500):
+        s0 = int(rng.integers(0, len(genome) - 200))
+        r = genome[s0:s0 + int(rng.integers(k - 2, 200))].copy()
+        if rng.random() < 0.5:
+            r = (3 - r)[::-1]
+        if rng.random() < 0.2 and len(r) > 5:
+            r[int(rng.integers(0, len(r)))] = 4                     # an N
+        reads.append("".join("acgtn"[x] for x in r))
+    reads += ["a" * 150] * 300 + ["acgt" * 40] * 50                  # repeats, low complexity
+    bases, boff = orc.block_from_reads(reads)
+    exp = orc.fastk(k, bases, boff, cutoff=2)
+    for nb in (1, 3):
+        with fastk_amd.Context(kmer=k, table_cutoff=2, nbuckets=nb) as ctx:
+            ctx.push_block(bases, boff.astype(np.int32))
+            res = ctx.finish()
+            assert res.ninst == exp.ninst
+            assert np.array_equal(res.hist, exp.hist) and res.max_inst == exp.max_inst
+            assert res.ntable == exp.ntable and np.array_equal(res.table, exp.table)
+
+
 def test_empty_and_degenerate_inputs():
     with fastk_amd.Context(kmer=40, table_cutoff=1) as ctx:
         res = ctx.finish()
