@@ -143,10 +143,83 @@ __global__ __launch_bounds__(TS_THREADS) void k_ts_fix(u32 *__restrict__ recs, i
             recs[(k + 1) * KW + w] = y[w];
           k -= 1;
         }
+      if (k + 1 != j)
+        {
 #pragma unroll
-      for (int w = 0; w < KW; w++)
-        recs[(k + 1) * KW + w] = x[w];
+          for (int w = 0; w < KW; w++)
+            recs[(k + 1) * KW + w] = x[w];
+        }
     }
+}
+
+// The same repair through LDS: a workgroup loads a tile of TS_TILE records plus TS_HALO more, sorts
+// the runs that START in its tile (they may reach into the halo) and writes back the stretch from its
+// first run start to the end of its last run -- the stretch before belongs to a run of the previous
+// tile, whose workgroup writes it.  Records read while a neighbour rewrites them may be torn, but
+// only their first pbytes bytes are looked at, and those are the same for every record of a run.
+#define TS_HALO 64
+
+template <int KW>
+__global__ __launch_bounds__(TS_THREADS) void k_ts_fix_tile(u32 *__restrict__ recs, int64_t n, int pbytes,
+                                                            int kbytes, u32 *__restrict__ long_runs)
+{ __shared__ __attribute__((aligned(16))) u32 t[(TS_TILE + TS_HALO) * KW];
+  __shared__ u32 prev[KW];                                // the record in front of the tile
+  __shared__ int s_lo, s_hi;
+  const int  full  = pbytes >> 2;
+  const u32  lastm = (pbytes & 3) ? ((1u << (8 * (pbytes & 3))) - 1u) : 0u;
+  const int  kfull = kbytes >> 2;
+  const u32  klast = (kbytes & 3) ? ((1u << (8 * (kbytes & 3))) - 1u) : 0u;
+  const int64_t t0 = (int64_t) blockIdx.x * TS_TILE;      // global index of LDS slot 0
+  const int  tn = (int) ((n - t0 < TS_TILE + TS_HALO) ? (n - t0) : (TS_TILE + TS_HALO));   // slots 0..tn-1
+  const int  own = (tn < TS_TILE) ? tn : TS_TILE;         // run starts this workgroup owns: slots 0..own-1
+  fk_stage16<((TS_TILE + TS_HALO) * KW + 1023) / 1024, false>(t, recs + t0 * KW, tn * KW);
+  if (threadIdx.x < KW)
+    prev[threadIdx.x] = (t0 > 0) ? recs[(t0 - 1) * KW + threadIdx.x] : 0u;
+  if (threadIdx.x == 0) { s_lo = TS_TILE + TS_HALO + 1; s_hi = 0; }
+  __syncthreads();
+  int lo = TS_TILE + TS_HALO + 1, hi = 0;
+  for (int q = 0; q < TS_ITEMS; q++)
+    { const int i = q * TS_THREADS + threadIdx.x;          // LDS slot
+      if (i >= own)
+        continue;
+      const bool head = (t0 + i == 0) || !ts_same<KW>(t + i * KW, (i > 0) ? t + (i - 1) * KW : prev, full, lastm);
+      if (!head)
+        continue;
+      lo = min(lo, i);
+      int j = i + 1;
+      for (; j < tn; j++)
+        { u32 x[KW];
+#pragma unroll
+          for (int w = 0; w < KW; w++)
+            x[w] = t[j * KW + w];
+          if (!ts_same<KW>(t + i * KW, x, full, lastm))
+            break;
+          int k = j - 1;
+          while (k >= i && ts_less<KW>(x, t + k * KW, kfull, klast))
+            {
+#pragma unroll
+              for (int w = 0; w < KW; w++)
+                t[(k + 1) * KW + w] = t[k * KW + w];
+              k -= 1;
+            }
+          if (k + 1 != j)
+            {
+#pragma unroll
+              for (int w = 0; w < KW; w++)
+                t[(k + 1) * KW + w] = x[w];
+            }
+        }
+      // the run may go on past what was loaded
+      if (j >= tn && t0 + tn < n)
+        *long_runs = 1;
+      hi = max(hi, j);
+    }
+  if (lo < TS_TILE + TS_HALO + 1) atomicMin(&s_lo, lo);
+  if (hi > 0) atomicMax(&s_hi, hi);
+  __syncthreads();
+  const int wlo = s_lo, whi = s_hi;                        // write back slots [wlo, whi)
+  for (int j = wlo * KW + threadIdx.x; j < whi * KW; j += TS_THREADS)
+    recs[t0 * KW + j] = t[j];
 }
 
 template <int KW>
@@ -203,8 +276,12 @@ static int tsort_t(fk_ctx *ctx, int64_t n, void *d_tab, void *d_tmp, void **resu
   // short tie runs are sorted where they are; only if some run is long does the compaction path run
   u64 *d_tot = ctx->d_scratch + 3072;
   FK_HIP(ctx, hipMemsetAsync(d_tot + 1, 0, 8, s));
-  hipLaunchKernelGGL(k_ts_fix<KW>, dim3((unsigned) ((n + TS_THREADS - 1) / TS_THREADS)), dim3(TS_THREADS), 0, s,
-                     (u32 *) sorted, n, P, kb, 48, (u32 *) (d_tot + 1));
+  if (((uintptr_t) sorted & 15) == 0)
+    hipLaunchKernelGGL(k_ts_fix_tile<KW>, dim3((unsigned) ((n + TS_TILE - 1) / TS_TILE)), dim3(TS_THREADS), 0, s,
+                       (u32 *) sorted, n, P, kb, (u32 *) (d_tot + 1));
+  else
+    hipLaunchKernelGGL(k_ts_fix<KW>, dim3((unsigned) ((n + TS_THREADS - 1) / TS_THREADS)), dim3(TS_THREADS), 0, s,
+                       (u32 *) sorted, n, P, kb, 48, (u32 *) (d_tot + 1));
   FK_LAUNCH_CHECK(ctx);
   FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch + 4096, d_tot + 1, 8, hipMemcpyDeviceToHost, s));
   FK_HIP(ctx, hipStreamSynchronize(s));
