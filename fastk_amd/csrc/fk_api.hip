@@ -1051,7 +1051,14 @@ static int count_bucket(fk_ctx *ctx, void *sm_in, int64_t ns, fk_result *res, bo
               const int64_t need = (*ntab + nt) * w.kmer_stride;
               if (ctx->slot_cap[FK_SLOT_TABLE] < need)
                 { void *nbuf = NULL;
-                  const int64_t ncap = need + need / 2 + (1 << 20);
+                  // the other buckets are about as rich as the ones seen so far: size for all of them
+                  // at once (growing by copies costs more than the counting at tens of GB)
+                  int64_t ncap = need + need / 2 + (1 << 20);
+                  if (ns_max > 0 && ns > 0 && ctx->prm.nbuckets > 1)
+                    { const double per_sm = (double) (*ntab + nt) / (double) (ctx->acc_ns + ns);
+                      const int64_t all = (int64_t) (per_sm * (double) ctx->acc_ns_total * 1.03) * w.kmer_stride;
+                      if (all > ncap) ncap = all + (1 << 20);
+                    }
                   if (hipMalloc(&nbuf, (size_t) ncap) != hipSuccess) { rc = FK_ENOMEM; break; }
                   if (*ntab > 0
                       && hipMemcpyAsync(nbuf, ctx->slot_ptr[FK_SLOT_TABLE], (size_t) (*ntab * w.kmer_stride),
@@ -1069,6 +1076,7 @@ static int count_bucket(fk_ctx *ctx, void *sm_in, int64_t ns, fk_result *res, bo
             }
         }
       *ntab += (cutoff > 0) ? nt : 0;
+      ctx->acc_ns += ns;
       hipEventRecord(ev[3], s);
       if (hipEventSynchronize(ev[3]) != hipSuccess) { rc = FK_EHIP; break; }
       if (ctx->dbg_verbose)
@@ -1173,6 +1181,8 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
       int64_t ns_max = 0;
       for (int b = 0; b < nbk; b++)
         ns_max = std::max(ns_max, bc[b]);
+      ctx->acc_ns = 0;
+      ctx->acc_ns_total = ns;
       // chunked ingest: a bucket's records are gathered from the chunks right before it is counted
       auto gather = [&](int b, void **ptr) -> int
         { char *g = (char *) fk_slot(ctx, FK_SLOT_SM_G, ns_max * w.smer_stride);
