@@ -22,7 +22,8 @@ EXPORTS = [
     "fk_get_sort_stats", "fk_version", "fk_count_device_reads", "fk_count_device_supermers", "fk_debug_set", "fk_group_records",
     "fk_count_presorted_kmers", "fk_split_supermers_emit", "fk_split_plan", "fk_split_planned",
     "fk_train_block", "fk_count_unsorted_kmers", "fk_debug_get", "fk_push_fastq", "fk_host_alloc",
-    "fk_host_free", "fk_bucket_census", "fk_set_bucket_weights", "fk_push_fasta",
+    "fk_host_free", "fk_bucket_census", "fk_set_bucket_weights", "fk_push_fasta", "fk_merge_tables",
+    "fk_write_ktab_ex",
 ]
 
 
@@ -116,6 +117,7 @@ def load_library():
     L.fk_debug_get.argtypes = [vp, C.c_char_p, C.POINTER(i64)]
     L.fk_push_fastq.argtypes = [vp, vp, i64, C.c_int, C.POINTER(C.c_int), C.POINTER(i64), C.POINTER(i64)]
     L.fk_push_fasta.argtypes = [vp, vp, i64, C.c_int, C.POINTER(C.c_int), C.POINTER(i64), C.POINTER(i64)]
+    L.fk_merge_tables.argtypes = [vp, vp, i64, i64, C.POINTER(CResult)]
     L.fk_host_alloc.argtypes = [i64, C.POINTER(vp)]
     L.fk_host_free.argtypes = [vp]
     L.fk_bucket_census.argtypes = [vp, vp, i64, C.POINTER(i64)]
@@ -267,6 +269,13 @@ class Context:
         self._ck(self.L.fk_push_fasta(self.h, a.ctypes.data if a.nbytes else None, a.nbytes,
                                       1 if last else 0, C.byref(st), C.byref(nr), C.byref(nb)))
         return st.value, nr.value, nb.value
+
+    def merge_tables(self, records, max_inst_in=0):
+        """records: (n, KMER_WORD) uint8 entries of all input tables; returns the merged Result."""
+        a = np.ascontiguousarray(records, dtype=np.uint8)
+        r = CResult()
+        self._ck(self.L.fk_merge_tables(self.h, a.ctypes.data, a.shape[0], int(max_inst_in), C.byref(r)))
+        return Result(r, self.w.kmer_word)
 
     def push_device(self, ptr, nbytes):
         self._ck(self.L.fk_push_device(self.h, ptr, nbytes))

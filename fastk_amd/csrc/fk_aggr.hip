@@ -107,7 +107,7 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
                                                          const u64 *__restrict__ bounds, int kbytes,
                                                          int cutoff, u64 *__restrict__ hist_g,
                                                          u64 *__restrict__ scal, u32 *__restrict__ table,
-                                                         int LIMIT, int variant, int gshift)
+                                                         int LIMIT, int variant, int gshift, u32 sat)
 { constexpr int SLOTS = AgCfg<KW>::SLOTS;
   constexpr int U = AG_UNROLL;
   extern __shared__ uint4 ag_lds[];
@@ -299,10 +299,10 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
                 { A[slot].w = 0;
                   my_distinct += 1;
                   u32 cc = v;
+                  if (v >= sat)                                // sat = 0x7fff, MSDsort.c:498-506
+                    my_max += v;
                   if (v >= 0x7fffu)
-                    { my_max += v;
-                      cc = 0x7fffu;
-                    }
+                    cc = 0x7fffu;
                   if (variant & 2) ;
                   else if (cc < AG_HB) atomicAdd(&lhist[cc], 1u);
                   else            atomicAdd(&hist_g[cc], 1ull);
@@ -411,7 +411,8 @@ static int aggr_t(fk_ctx *ctx, const void *d_grouped, int64_t n, int cutoff, int
   const int limit = (ctx->dbg_aggr_limit > 0 && ctx->dbg_aggr_limit < AgCfg<KW>::LIMIT) ? ctx->dbg_aggr_limit
                                                                                         : AgCfg<KW>::LIMIT;
   hipLaunchKernelGGL(k_ag_count<KW>, dim3((unsigned) cus), dim3(AG_THREADS), lds, s, (const u32 *) d_grouped,
-                     (const u64 *) d_bounds, ctx->wid.kmer_bytes, cutoff, d_hist, d_scal, (u32 *) d_table, limit, ctx->dbg_aggr_variant, gshift);
+                     (const u64 *) d_bounds, ctx->wid.kmer_bytes, cutoff, d_hist, d_scal, (u32 *) d_table, limit, ctx->dbg_aggr_variant, gshift,
+                     (u32) (ctx->aggr_sat > 0 ? ctx->aggr_sat : 0x7fff));
   FK_LAUNCH_CHECK(ctx);
   u64 *h = ctx->h_scratch;                       // pinned, 64 KB + 64 KB: the histogram needs 256 KB
   u64 *hh = (u64 *) malloc((FK_HIST_BINS + 8) * 8);

@@ -580,6 +580,78 @@ extern "C" int fk_count_unsorted_kmers(fk_ctx *ctx, void *d_kmers, void *d_tmp, 
   return (FK_OK);
 }
 
+/* Sum-merge of k-mer tables (Fastmerge.c:168-457): records = the entries of all input tables, any
+   order, KMER_WORD bytes each (host).  Equal k-mers are summed, the count saturates at 0x7fff
+   exactly as Fastmerge.c:313-329: hist[0x7fff] counts the saturated k-mers and max_inst receives, for a
+   k-mer whose sum exceeds 0x7fff, the input counts below 0x7fff (the instances behind inputs that
+   were saturated already come from the inputs' own histograms: pass their sum as max_inst_in).
+   Runs on the aggregation + table-sort kernels of the counting path. */
+extern "C" int fk_merge_tables(fk_ctx *ctx, const uint8_t *records, int64_t n, int64_t max_inst_in,
+                               fk_result *res)
+{ if (ctx == NULL || res == NULL || n < 0 || (records == NULL && n > 0)) return (FK_EINVAL);
+  const fk_widths &w = ctx->wid;
+  hipStream_t s = ctx->stream;
+  memset(res, 0, sizeof(*res));
+  res->max_inst = max_inst_in;
+  if (n == 0)
+    return (FK_OK);
+  FK_HIP(ctx, hipSetDevice(ctx->device));
+  void *d_a = fk_slot(ctx, FK_SLOT_KM_A, n * w.kmer_stride);
+  void *d_b = fk_slot(ctx, FK_SLOT_KM_B, n * w.kmer_stride);
+  if (d_a == NULL || d_b == NULL)
+    return (FK_ENOMEM);
+  // device layout (stride), and an input that is saturated already gets weight 0x8000: a sum reaches
+  // 0x8000 exactly when Fastmerge calls the k-mer saturated (sum > 0x7fff, or a saturated input)
+  std::vector<uint8_t> stage((size_t) n * w.kmer_stride, 0);
+  int64_t nsat = 0;
+  for (int64_t i = 0; i < n; i++)
+    { const uint8_t *r = records + i * w.kmer_word;
+      uint8_t *o = stage.data() + i * w.kmer_stride;
+      memcpy(o, r, w.kmer_bytes);
+      uint16_t c;
+      memcpy(&c, r + w.kmer_bytes, 2);
+      if (c >= 0x7fff) { c = 0x8000; nsat += 1; }
+      memcpy(o + w.kmer_stride - 2, &c, 2);
+    }
+  FK_HIP(ctx, hipMemcpyAsync(d_a, stage.data(), stage.size(), hipMemcpyHostToDevice, s));
+  FK_HIP(ctx, hipStreamSynchronize(s));
+  void *grouped = d_a;
+  int rc = fkx_group(ctx, n, d_a, d_b, w.kmer_stride, w.kmer_bytes, 2, &grouped);
+  if (rc != FK_OK) return (rc);
+  void *tbuf = (grouped == d_a) ? d_b : d_a;
+  int64_t nt = 0, nd = 0, mx = 0;
+  ctx->aggr_sat = 0x8000;
+  rc = fkx_aggregate(ctx, grouped, n, 1, res->hist, &mx, &nd, tbuf, n, &nt);
+  ctx->aggr_sat = 0;
+  if (rc != FK_OK) return (rc);
+  res->max_inst += mx - 0x8000ll * nsat;
+  res->ndistinct = nd;
+  res->nweighted = n;
+  res->ntable = nt;
+  void *sorted = tbuf;
+  int64_t census[256];
+  if ((rc = fkx_sort_table(ctx, nt, tbuf, grouped, &sorted, census)) != FK_OK)
+    return (rc);
+  for (int x = 0; x < 256; x++)
+    res->wfirst[x] = census[x];
+  const int64_t bytes = nt * w.kmer_word;
+  if (ctx->h_table_cap < bytes)
+    { free(ctx->h_table);
+      ctx->h_table = (uint8_t *) malloc((size_t) bytes);
+      ctx->h_table_cap = bytes;
+      if (ctx->h_table == NULL) { ctx->h_table_cap = 0; return (FK_ENOMEM); }
+    }
+  std::vector<uint8_t> back((size_t) nt * w.kmer_stride);
+  FK_HIP(ctx, hipMemcpyAsync(back.data(), sorted, back.size(), hipMemcpyDeviceToHost, s));
+  FK_HIP(ctx, hipStreamSynchronize(s));
+  for (int64_t i = 0; i < nt; i++)
+    { memcpy(ctx->h_table + i * w.kmer_word, back.data() + i * w.kmer_stride, w.kmer_bytes);
+      memcpy(ctx->h_table + i * w.kmer_word + w.kmer_bytes, back.data() + i * w.kmer_stride + w.kmer_stride - 2, 2);
+    }
+  res->table = ctx->h_table;
+  return (FK_OK);
+}
+
 // ---- streaming interface ------------------------------------------------------------------------
 static int reserve_reads(fk_ctx *ctx, int64_t extra)
 { const int64_t need = ctx->reads_len + extra + 64;
@@ -1376,8 +1448,17 @@ extern "C" int fk_write_hist(const fk_result *res, int kmer, const char *path)
 // .ktab stub + hidden parts (table.c:162-342, 485-498, README.md:965-1006).  Part t holds the
 // first-byte range [split[t], split[t+1]) chosen by the reference's rule (MSDsort.c:330-352 over
 // the weighted k-mer first-byte census, count.c:1560-1565).
+extern "C" int fk_write_ktab_ex(const fk_result *res, int kmer, int table_cutoff, int nthreads,
+                                int idx_bytes, const char *dir, const char *root);
+
 extern "C" int fk_write_ktab(const fk_result *res, int kmer, int table_cutoff, int nthreads,
                              const char *dir, const char *root)
+{ return fk_write_ktab_ex(res, kmer, table_cutoff, nthreads, 0, dir, root); }
+
+// idx_bytes 1..3 fixes the prefix-index width (Fastmerge chooses it from the number of INPUT entries,
+// Fastmerge.c:742-756); 0 = FastK's rule on the table size (count.c:1620-1626)
+extern "C" int fk_write_ktab_ex(const fk_result *res, int kmer, int table_cutoff, int nthreads,
+                                int idx_bytes, const char *dir, const char *root)
 { if (res == NULL || dir == NULL || root == NULL || nthreads < 1 || table_cutoff < 1)
     return (FK_EINVAL);
   fk_widths w;
@@ -1385,7 +1466,8 @@ extern "C" int fk_write_ktab(const fk_result *res, int kmer, int table_cutoff, i
   if (res->ntable > 0 && res->table == NULL) return (FK_EINVAL);
   const int KW = w.kmer_word;
   int ib;                                                   // count.c:1620-1626
-  if (res->ntable > 0x4000000ll && kmer >= 12) ib = 3;
+  if (idx_bytes >= 1 && idx_bytes <= 3) ib = idx_bytes;
+  else if (res->ntable > 0x4000000ll && kmer >= 12) ib = 3;
   else if (res->ntable >= 0x40000ll && kmer >= 8) ib = 2;
   else ib = 1;
 

@@ -1,0 +1,215 @@
+/* Fastmerge_amd.c -- Fastmerge's table / histogram merge over libfastk_amd.so.
+ *
+ *   Fastmerge_amd [-ht] [-T<int(4)>] <target> <source>[.ktab] ...
+ *
+ * Same options and outputs as the reference tool for tables and histograms (Fastmerge.c:26-29,
+ * 521-540): -t writes <target>.ktab + hidden parts, -h writes <target>.hist; k-mers present in
+ * several sources get the sum of their counts, saturated at 32767 with the reference's bookkeeping of
+ * the histogram's high-count field (Fastmerge.c:313-329, 985-1030).  The k-mers are summed on the GPU
+ * by the aggregation kernel of the counting path (fk_merge_tables).  The prefix-index width follows
+ * Fastmerge's rule on the number of input entries (Fastmerge.c:742-756), the cutoff field is the
+ * smallest of the sources' (Fastmerge.c:719-720); the part boundaries are our own.
+ * Not built: profile merging (-p sources), #<parts>, -P, -S.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdint.h>
+#include <fcntl.h>
+#include <unistd.h>
+
+#include "../../../include/fastk_amd.h"
+
+static char *Prog_Name = "Fastmerge_amd";
+
+static void die(fk_ctx *ctx, const char *what)
+{ fprintf(stderr,"%s: %s: %s\n",Prog_Name,what,fk_last_error(ctx));
+  exit (1);
+}
+
+static void split_path(const char *arg, const char *suffix, char **dir, char **root)
+{ const char *slash = strrchr(arg,'/');
+  const char *base  = slash ? slash+1 : arg;
+  size_t bl = strlen(base), sl = strlen(suffix);
+  if (bl > sl && strcmp(base+bl-sl,suffix) == 0)
+    bl -= sl;
+  *root = strndup(base,bl);
+  *dir  = slash ? strndup(arg,(size_t) (slash-arg)) : strdup(".");
+}
+
+static int read_all(int fd, void *p, size_t n)
+{ uint8_t *b = (uint8_t *) p;
+  while (n > 0)
+    { ssize_t r = read(fd,b,n);
+      if (r <= 0) return (-1);
+      b += r; n -= (size_t) r;
+    }
+  return (0);
+}
+
+/* appends the entries of table <dir>/<root>.ktab to *recs as KMER_WORD-byte records
+   (README.md:965-1006: stub = k, nparts, minval, ibyte, cumulative prefix index; part t = k, n,
+   n entries without their first ibyte bytes, in table order) */
+static void load_table(const char *dir, const char *root, int kmer_word, int *kmer, int *minval,
+                       uint8_t **recs, int64_t *n, int64_t *cap)
+{ char name[4096];
+  int  k, nparts, mv, ib, fd, t;
+  int64_t nidx, *idx, pre = 0, seen = 0;
+
+  snprintf(name,sizeof(name),"%s/%s.ktab",dir,root);
+  fd = open(name,O_RDONLY);
+  if (fd < 0)
+    { fprintf(stderr,"%s: Cannot open table %s\n",Prog_Name,name); exit (1); }
+  if (read_all(fd,&k,4) | read_all(fd,&nparts,4) | read_all(fd,&mv,4) | read_all(fd,&ib,4))
+    { fprintf(stderr,"%s: %s is not a k-mer table stub\n",Prog_Name,name); exit (1); }
+  nidx = 1ll << (8*ib);
+  idx  = malloc(sizeof(int64_t)*(size_t) nidx);
+  if (idx == NULL || read_all(fd,idx,sizeof(int64_t)*(size_t) nidx))
+    { fprintf(stderr,"%s: Cannot read the index of %s\n",Prog_Name,name); exit (1); }
+  close(fd);
+  if (*kmer == 0)
+    *kmer = k;
+  else if (*kmer != k)
+    { fprintf(stderr,"%s: K-mer tables do not involve the same K\n",Prog_Name); exit (1); }
+  if (mv < *minval)
+    *minval = mv;
+
+  for (t = 1; t <= nparts; t++)
+    { int     pk;
+      int64_t pn, i;
+      int     pw = kmer_word - ib;
+      uint8_t *buf;
+
+      snprintf(name,sizeof(name),"%s/.%s.ktab.%d",dir,root,t);
+      fd = open(name,O_RDONLY);
+      if (fd < 0 || read_all(fd,&pk,4) | read_all(fd,&pn,8))
+        { fprintf(stderr,"%s: Cannot read table part %s\n",Prog_Name,name); exit (1); }
+      buf = malloc((size_t) (pn > 0 ? pn : 1)*pw);
+      if (buf == NULL || (pn > 0 && read_all(fd,buf,(size_t) pn*pw)))
+        { fprintf(stderr,"%s: Cannot read table part %s\n",Prog_Name,name); exit (1); }
+      close(fd);
+      if (*n + pn > *cap)
+        { *cap  = (*n + pn)*2 + 1024;
+          *recs = realloc(*recs,(size_t) *cap*kmer_word);
+          if (*recs == NULL)
+            { fprintf(stderr,"%s: Out of memory\n",Prog_Name); exit (1); }
+        }
+      for (i = 0; i < pn; i++)
+        { uint8_t *o = *recs + (*n + i)*kmer_word;
+          int b;
+          while (pre < nidx-1 && idx[pre] <= seen)        /* prefix of entry number `seen` */
+            pre += 1;
+          for (b = 0; b < ib; b++)
+            o[b] = (uint8_t) (pre >> (8*(ib-1-b)));
+          memcpy(o+ib,buf+i*pw,pw);
+          seen += 1;
+        }
+      *n += pn;
+      free(buf);
+    }
+  free(idx);
+}
+
+/* high-count field of <dir>/<root>.hist (count.c:1893-1910: k, low, high, int64 ilowcnt, int64 ihighcnt, ...) */
+static int64_t load_high_count(const char *dir, const char *root, int *found)
+{ char name[4096];
+  int  h[3], fd;
+  int64_t v[2];
+
+  snprintf(name,sizeof(name),"%s/%s.hist",dir,root);
+  fd = open(name,O_RDONLY);
+  *found = 0;
+  if (fd < 0)
+    return (0);
+  if (read_all(fd,h,12) | read_all(fd,v,16))
+    { close(fd); return (0); }
+  close(fd);
+  *found = 1;
+  return (v[1]);
+}
+
+int main(int argc, char *argv[])
+{ int  DO_HIST = 0, DO_TABLE = 0, NTHREADS = 4;
+  int  i, j, narg, kmer = 0, minval = 0x10000, ib;
+  char *odir, *oroot, name[4096];
+  uint8_t *recs = NULL;
+  int64_t  n = 0, cap = 0, high = 0;
+  fk_widths  w;
+  fk_params  prm;
+  fk_ctx    *ctx;
+  fk_result *res;
+
+  for (i = j = 1; i < argc; i++)
+    if (argv[i][0] == '-' && argv[i][1] != '\0')
+      { char *p;
+        if (argv[i][1] == 'T')
+          { NTHREADS = atoi(argv[i]+2); continue; }
+        for (p = argv[i]+1; *p; p++)
+          if (*p == 'h') DO_HIST = 1;
+          else if (*p == 't') DO_TABLE = 1;
+          else
+            { fprintf(stderr,"%s: -%c is not built in this tool (see the header of Fastmerge_amd.c)\n",Prog_Name,*p);
+              exit (1);
+            }
+      }
+    else
+      argv[j++] = argv[i];
+  argc = j;
+  if (argc < 3 || NTHREADS < 1)
+    { fprintf(stderr,"\nUsage: %s [-ht] [-T<int(4)>] <target> <source>[.hist|.ktab] ...\n",Prog_Name);
+      exit (1);
+    }
+  if (DO_HIST + DO_TABLE == 0)
+    { fprintf(stderr,"%s: At least one of -h or -t must be set\n",Prog_Name); exit (1); }
+  split_path(argv[1],"",&odir,&oroot);
+  narg = argc-2;
+
+  /* k is in every stub: read it from the first one to size the records */
+  { char *d, *r;
+    int   fd, k;
+    split_path(argv[2],".ktab",&d,&r);
+    snprintf(name,sizeof(name),"%s/%s.ktab",d,r);
+    fd = open(name,O_RDONLY);
+    if (fd < 0 || read_all(fd,&k,4))
+      { fprintf(stderr,"%s: Cannot open table %s\n",Prog_Name,name); exit (1); }
+    close(fd);
+    if (fk_get_widths(k,&w) != FK_OK)
+      { fprintf(stderr,"%s: k = %d is not supported\n",Prog_Name,k); exit (1); }
+    free(d); free(r);
+  }
+  for (i = 0; i < narg; i++)
+    { char *d, *r;
+      int   found;
+      split_path(argv[i+2],".ktab",&d,&r);
+      { size_t l = strlen(r);                          /* a source may also be named <root>.hist */
+        if (l > 5 && strcmp(r+l-5,".hist") == 0) r[l-5] = '\0';
+      }
+      load_table(d,r,w.kmer_word,&kmer,&minval,&recs,&n,&cap);
+      high += load_high_count(d,r,&found);
+      if (!found && i == 0 && DO_HIST)
+        fprintf(stderr,"%s: Warning: no input histograms => overflow count low\n",Prog_Name);
+      free(d); free(r);
+    }
+
+  fk_default_params(&prm);
+  prm.kmer = kmer; prm.table_cutoff = 1; prm.nthreads = NTHREADS;
+  if (fk_create(&prm,&ctx) != FK_OK)
+    die(NULL,"fk_create");
+  res = malloc(sizeof(fk_result));
+  if (fk_merge_tables(ctx,recs,n,high,res) != FK_OK)
+    die(ctx,"fk_merge_tables");
+
+  if (n >= 0x8000000ll) ib = 3;                        /* Fastmerge.c:742-756, on the INPUT entries */
+  else if (n >= 0x80000ll) ib = 2;
+  else ib = 1;
+  if (DO_TABLE && fk_write_ktab_ex(res,kmer,minval,NTHREADS,ib,odir,oroot) != FK_OK)
+    die(ctx,"writing .ktab");
+  if (DO_HIST)
+    { snprintf(name,sizeof(name),"%s/%s.hist",odir,oroot);
+      if (fk_write_hist(res,kmer,name) != FK_OK)
+        die(ctx,"writing .hist");
+    }
+  fk_destroy(ctx);
+  free(recs); free(res);
+  exit (0);
+}

@@ -258,6 +258,16 @@ int fk_host_free(void *ptr);
 int fk_bucket_census(fk_ctx *ctx, const char *bases, int64_t nbytes, int64_t *counts);
 int fk_set_bucket_weights(fk_ctx *ctx, const int64_t *counts);
 
+/* Sum-merge of k-mer tables, the table/histogram part of Fastmerge (Fastmerge.c:168-457, 985-1030):
+   records = the entries of all input tables in any order, KMER_WORD bytes each (host memory);
+   max_inst_in = sum of the inputs' histogram "high count" fields (hist[0x8001], 0 if unknown).
+   res->hist / max_inst / table (sorted, counts saturated at 0x7fff) as Fastmerge computes them. */
+int fk_merge_tables(fk_ctx *ctx, const uint8_t *records, int64_t n, int64_t max_inst_in, fk_result *res);
+
+/* fk_write_ktab with an explicit prefix-index width (1..3; 0 = FastK's rule). */
+int fk_write_ktab_ex(const fk_result *res, int kmer, int table_cutoff, int nthreads, int idx_bytes,
+                     const char *dir, const char *root);
+
 /* ---- utilities ---------------------------------------------------------------------------*/
 
 /* Fill d_bases with synthetic reads first_read .. first_read+nreads-1 of include/fk_synth.h,

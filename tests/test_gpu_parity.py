@@ -402,6 +402,69 @@ def test_homopolymer_compression_device_host_reference(name, tmp_path):
         assert hashlib.sha256(open(tmp_path / "ref.hist", "rb").read()).hexdigest() == digests[0]
 
 
+@pytest.mark.parametrize("name", ["synth_illumina_k40_t1_T4", "edge_k40_t1_T4", "synth_illumina_k51_t1_T4"])
+def test_table_merge_matches_reference_fastmerge(name, tmp_path):
+    """Fastmerge_amd -ht (fk_merge_tables: the aggregation kernel sums equal k-mers of several tables,
+    saturation bookkeeping of Fastmerge.c:313-329): three tables counted from thirds of the reads merge
+    into exactly the table and histogram of the whole data set."""
+    import hashlib, os, subprocess
+    case, bases, boff = util.load_case(name)
+    k = case["k"]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "fastk_amd", "bin", "FastK_amd")
+    mrg = os.path.join(root, "fastk_amd", "bin", "Fastmerge_amd")
+    nreads = len(boff) - 1
+    cuts = [0, nreads // 3, 2 * nreads // 3, nreads]
+    srcs = []
+    for i in range(3):
+        lo, hi = cuts[i], cuts[i + 1]
+        path = str(tmp_path / ("p%d.fastq" % i))
+        orc.write_fastq(path, bases[boff[lo]:boff[hi]], boff[lo:hi + 1] - boff[lo])
+        subprocess.run([exe, "-k%d" % k, "-t1", "-T3", path], check=True, cwd=str(tmp_path))
+        srcs.append(str(tmp_path / ("p%d" % i)))
+    subprocess.run([mrg, "-ht", "-T2", str(tmp_path / "ours")] + srcs, check=True, cwd=str(tmp_path))
+    ours = orc.read_ktab(str(tmp_path / "ours"))
+    ours_hist = open(tmp_path / "ours.hist", "rb").read()
+    # expected: Fastmerge's rules (Fastmerge.c:313-329, 985-1030) applied to the three piece tables
+    kb = orc.params(k).kmer_bytes
+    pieces = [orc.fastk(k, bases[boff[cuts[i]]:boff[cuts[i + 1]]],
+                        boff[cuts[i]:cuts[i + 1] + 1] - boff[cuts[i]], cutoff=1) for i in range(3)]
+    allrec = np.concatenate([p_.table for p_ in pieces])
+    order = np.lexsort(allrec[:, :kb].T[::-1])
+    allrec = allrec[order]
+    cnt = allrec[:, kb:kb + 2].copy().view("<u2").ravel().astype(np.int64)
+    head = np.ones(len(allrec), dtype=bool)
+    head[1:] = np.any(allrec[1:, :kb] != allrec[:-1, :kb], axis=1)
+    gid = np.cumsum(head) - 1
+    tot = np.bincount(gid, weights=cnt).astype(np.int64)
+    low = np.bincount(gid, weights=np.where(cnt < 0x7fff, cnt, 0)).astype(np.int64)
+    exp_hist = np.bincount(np.minimum(tot, 0x7fff), minlength=0x8000)[1:]
+    exp_high = int(low[tot > 0x7fff].sum()) + sum(int(p_.max_inst) for p_ in pieces)
+    exp_tab = allrec[head].copy()
+    exp_tab[:, kb:kb + 2] = np.minimum(tot, 0x7fff).astype("<u2").view(np.uint8).reshape(-1, 2)
+    h = np.frombuffer(ours_hist[28:], dtype=np.int64)
+    assert np.array_equal(h, exp_hist)
+    assert int(np.frombuffer(ours_hist[20:28], dtype=np.int64)[0]) == exp_high
+    assert ours["nels"] == len(exp_tab)
+    assert ours["stream_sha256"] == orc.table_stream_sha256(k, exp_tab, ours["ibytes"])
+    # where nothing saturates, that is the table and histogram of the whole data set
+    whole = orc.fastk(k, bases, boff, cutoff=1)
+    if whole.hist[0x7fff] == 0:
+        assert np.array_equal(h, whole.hist[1:]) and np.array_equal(exp_tab, whole.table)
+    # the reference tool: same header fields; its merged counts depend on -T (k-mers next to its
+    # thread partition points are not merged: for these sources -T1..-T4 give four different
+    # histograms, none equal to the whole-data one), so only closeness can be asked of it
+    ref = os.path.join(orc.REF_DIR, "Fastmerge")
+    if os.path.exists(ref):
+        subprocess.run([ref, "-ht", "-T2", str(tmp_path / "ref")] + srcs, check=True, cwd=str(tmp_path),
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        theirs = orc.read_ktab(str(tmp_path / "ref"))
+        for f in ("kmer", "minval", "ibytes"):
+            assert ours[f] == theirs[f], f
+        rh = np.frombuffer(open(tmp_path / "ref.hist", "rb").read()[28:], dtype=np.int64)
+        assert int(np.abs(rh - h).sum()) <= 64 and abs(theirs["nels"] - ours["nels"]) <= 32
+
+
 def test_cli_memory_option(tmp_path):
     """FastK_amd -M<GB> (HBM budget: bucket streaming + chunked ingest) gives the same files."""
     import hashlib, os, subprocess
