@@ -138,41 +138,38 @@ __global__ __launch_bounds__(EX_THREADS) void k_ex_expand(const u32 *__restrict_
         { s_runk = runk + totk; s_runh = runh + toth; }
 
       if (head)
-        { // multiplicity: walk forward while the next record is identical
-          const int64_t i = t0 + l;
-          u32 mine[RW];
-#pragma unroll
-          for (int w = 0; w < RW; w++)
-            mine[w] = recs[l * RW + w];
-          int64_t ct = 1;
-          int64_t j = i + 1;
-          int     lj = l + 1;
-          bool open = true;
-          while (open && j < n && lj < tn)
-            { bool same = true;
-#pragma unroll
-              for (int w = 0; w < RW; w++)
-                same &= (recs[lj * RW + w] == mine[w]);
-              if (same) { ct += 1; j += 1; lj += 1; }
-              else open = false;
-            }
-          while (open && j < n)
-            { bool same = true;
-#pragma unroll
-              for (int w = 0; w < RW; w++)
-                same &= (__builtin_bswap32(sm[j * RW + w]) == mine[w]);
-              if (same) { ct += 1; j += 1; }
-              else open = false;
-            }
-          if (ct >= 0x8000)                          // count.c:455-458
-            { atomicAdd(overflow, (u64) (ct - 0x7fff) * (u64) nk);
-              ct = 0x7fff;
-            }
-          hoff[runh + exh] = runk + exk;
+        { hoff[runh + exh] = runk + exk;
           hrec[runh + exh] = (uint16_t) l;
-          hct[runh + exh]  = (uint16_t) ct;
         }
     }
+  __syncthreads();
+
+  // multiplicity of a head = distance to the next head (the records are grouped); only the last run
+  // of the tile may go on in the next tiles and is followed there
+  { const u32 nh1 = s_runh;
+    for (u32 h = threadIdx.x; h < nh1; h += EX_THREADS)
+      { const int l = hrec[h];
+        int64_t ct = (h + 1 < nh1) ? (int64_t) hrec[h + 1] - l : (int64_t) tn - l;
+        if (h + 1 == nh1)
+          { int64_t j = t0 + tn;
+            bool open = true;
+            while (open && j < n)
+              { bool same = true;
+#pragma unroll
+                for (int w = 0; w < RW; w++)
+                  same &= (__builtin_bswap32(sm[j * RW + w]) == recs[l * RW + w]);
+                if (same) { ct += 1; j += 1; }
+                else open = false;
+              }
+          }
+        if (ct >= 0x8000)                          // count.c:455-458
+          { const u32 nk = ((recs[l * RW + (len_byte >> 2)] >> (24 - 8 * (len_byte & 3))) & 0xffu) + 1u;
+            atomicAdd(overflow, (u64) (ct - 0x7fff) * (u64) nk);
+            ct = 0x7fff;
+          }
+        hct[h] = (uint16_t) ct;
+      }
+  }
   __syncthreads();
 
   const u32 nh    = s_runh;
