@@ -185,15 +185,60 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
               // settled by the first look even when the table is half full)
 #pragma unroll
               for (int u = 0; u < U; u++)
-                { if (!((pend >> u) & 1u))
-                    continue;
-                  u32 cur[KW];
+                { u32 cur[KW];
 #pragma unroll
                   for (int w = 0; w < KW; w++)
                     cur[w] = rec[u][w] & kmask[w];
                   const u32 wgt = rec[u][KW - 1] >> 16;
                   u32  slot = slot0[u];
-                  bool done = (*(volatile u32 *) &sh_ovf) != 0;    // a thread claims <= 1 slot per record
+                  // a thread claims <= 1 slot per record, so looking at the overflow flag once per
+                  // record keeps the table from filling up
+                  const bool todo = ((pend >> u) & 1u) && (*(volatile u32 *) &sh_ovf) == 0;
+                  bool done = !todo;
+                  // First look, straight-line for the whole wave (nested divergent branches cost more
+                  // scalar instructions here than the probes cost vector ones): most records either
+                  // hit their k-mer or claim an empty slot right away.
+                  { uint4 v[AG_P];
+                    ag_read_slots<SLOTS>(lds_base, slot, v);
+                    int act = AG_P;
+                    u32 kind = 0, cact = 0;
+#pragma unroll
+                    for (int j = AG_P - 1; j >= 0; j--)
+                      { const u32 c = v[j].w;
+                        bool same = (v[j].x == cur[0]);
+                        if (KW > 1) same = same && (v[j].y == cur[KW > 1 ? 1 : 0]);
+                        if (KW > 2) same = same && (v[j].z == cur[KW > 2 ? 2 : 0]);
+                        const u32 k = (c == 0u) ? 1u : (c == AG_LOCK) ? 2u : same ? 3u : 0u;
+                        if (k != 0u)
+                          { act = j; kind = k; cact = c; }
+                      }
+                    const u32 s = (slot + (u32) act) & (SLOTS - 1);
+                    if (KW <= 3 && todo && kind == 3u && cact < (AG_HIGH >> 1))
+                      { atomicAdd(&A[s].w, wgt);
+                        done = true;
+                      }
+                    bool created = false;
+                    if (KW <= 3 && todo && kind == 1u)
+                      { if (atomicCAS(&A[s].w, 0u, AG_LOCK) == 0u)
+                          { A[s] = make_uint4(cur[0], KW > 1 ? cur[KW > 1 ? 1 : 0] : 0u,
+                                              KW > 2 ? cur[KW > 2 ? 2 : 0] : 0u, AG_LOCK);
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                            atomicExch(&A[s].w, wgt);                       // publish
+                            created = true;
+                            done = true;
+                          }
+                      }
+                    const u64 cm = __ballot(created);
+                    if (cm != 0ull && fk_lane() == (u32) (__ffsll((long long) cm) - 1))
+                      { const u32 k = (u32) __popcll(cm);
+                        if (atomicAdd(&sh_claimed, k) + k > (u32) LIMIT)
+                          sh_ovf = 1;
+                      }
+                    // whoever is left (lost a race, met a slot being written, no hit in AG_P slots,
+                    // wide keys, very large counts) goes through the general loop below
+                    if (!done)
+                      slot = (kind == 1u || kind == 2u) ? s : (kind == 0u) ? ((slot + AG_P) & (SLOTS - 1)) : slot;
+                  }
                   while (!done)
                     { uint4 v[AG_P];
                       ag_read_slots<SLOTS>(lds_base, slot, v);
