@@ -215,6 +215,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
 #pragma unroll
       for (int c = 0; c < SP_CH; c++)
         { u32 m = 0xffffffffu;
+#pragma unroll 1
           for (int j = 0; j < W; j++)
             m = min(m, keys[SP_KIDX(i0 + c + j)]);
           mk[c] = m;
