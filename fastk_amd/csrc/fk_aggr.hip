@@ -102,7 +102,9 @@ __device__ __forceinline__ u32 ag_block_exscan(u32 v, u32 *tmp, u32 *total)
 // single ds_read_b128 yields a consistent (key, count word) pair: count word 0 = empty, AG_LOCK =
 // key being written (its creator stores key + AG_LOCK with one b128 write, then the weight with a
 // b32 write; LDS operations of a wave execute in order), anything else = published count.
-template <int KW>
+// DEDUP: the records are super-mers (whole record = key, weight 1); every distinct record comes out
+// once, followed by a dword with its multiplicity (records of KW + 1 dwords), nothing else is computed.
+template <int KW, bool DEDUP>
 __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__ recs,
                                                          const u64 *__restrict__ bounds, int kbytes,
                                                          int cutoff, u64 *__restrict__ hist_g,
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
 #pragma unroll
                   for (int w = 0; w < KW; w++)
                     cur[w] = rec[u][w] & kmask[w];
-                  const u32 wgt = rec[u][KW - 1] >> 16;
+                  const u32 wgt = DEDUP ? 1u : (rec[u][KW - 1] >> 16);
                   u32  slot = slot0[u];
                   // a thread claims <= 1 slot per record, so looking at the overflow flag once per
                   // record keeps the table from filling up
@@ -213,15 +215,29 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
                           { act = j; kind = k; cact = c; }
                       }
                     const u32 s = (slot + (u32) act) & (SLOTS - 1);
-                    if (KW <= 3 && todo && kind == 3u && cact < (AG_HIGH >> 1))
+                    bool hit = todo && kind == 3u && cact < (AG_HIGH >> 1);
+                    bool bmiss = false;
+                    if (KW > 3 && hit)
+                      { const uint4 b = B[s];
+                        bool same = (b.x == cur[KW > 3 ? 3 : 0]);
+                        if (KW > 4) same = same && (b.y == cur[KW > 4 ? 4 : 0]);
+                        if (KW > 5) same = same && (b.z == cur[KW > 5 ? 5 : 0]);
+                        if (KW > 6) same = same && (b.w == cur[KW > 6 ? 6 : 0]);
+                        bmiss = !same;
+                        hit = same;
+                      }
+                    if (hit)
                       { atomicAdd(&A[s].w, wgt);
                         done = true;
                       }
                     bool created = false;
-                    if (KW <= 3 && todo && kind == 1u)
+                    if (todo && kind == 1u)
                       { if (atomicCAS(&A[s].w, 0u, AG_LOCK) == 0u)
                           { A[s] = make_uint4(cur[0], KW > 1 ? cur[KW > 1 ? 1 : 0] : 0u,
                                               KW > 2 ? cur[KW > 2 ? 2 : 0] : 0u, AG_LOCK);
+                            if (KW > 3)
+                              B[s] = make_uint4(cur[KW > 3 ? 3 : 0], KW > 4 ? cur[KW > 4 ? 4 : 0] : 0u,
+                                                KW > 5 ? cur[KW > 5 ? 5 : 0] : 0u, KW > 6 ? cur[KW > 6 ? 6 : 0] : 0u);
                             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                             atomicExch(&A[s].w, wgt);                       // publish
                             created = true;
@@ -237,7 +253,8 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
                     // whoever is left (lost a race, met a slot being written, no hit in AG_P slots,
                     // wide keys, very large counts) goes through the general loop below
                     if (!done)
-                      slot = (kind == 1u || kind == 2u) ? s : (kind == 0u) ? ((slot + AG_P) & (SLOTS - 1)) : slot;
+                      slot = (kind == 1u || kind == 2u) ? s : (kind == 0u) ? ((slot + AG_P) & (SLOTS - 1))
+                           : bmiss ? ((s + 1) & (SLOTS - 1)) : slot;
                   }
                   while (!done)
                     { uint4 v[AG_P];
@@ -268,6 +285,8 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
                                 { const uint4 b = B[s];
                                   same = (b.x == cur[KW > 3 ? 3 : 0]);
                                   if (KW > 4) same = same && (b.y == cur[KW > 4 ? 4 : 0]);
+                                  if (KW > 5) same = same && (b.z == cur[KW > 5 ? 5 : 0]);
+                                  if (KW > 6) same = same && (b.w == cur[KW > 6 ? 6 : 0]);
                                 }
                               if (!same)
                                 slot = (s + 1) & (SLOTS - 1);
@@ -285,7 +304,8 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
                                 { A[s] = make_uint4(cur[0], KW > 1 ? cur[KW > 1 ? 1 : 0] : 0u,
                                                     KW > 2 ? cur[KW > 2 ? 2 : 0] : 0u, AG_LOCK);
                                   if (KW > 3)
-                                    B[s] = make_uint4(cur[KW > 3 ? 3 : 0], KW > 4 ? cur[KW > 4 ? 4 : 0] : 0u, 0u, 0u);
+                                    B[s] = make_uint4(cur[KW > 3 ? 3 : 0], KW > 4 ? cur[KW > 4 ? 4 : 0] : 0u,
+                                                      KW > 5 ? cur[KW > 5 ? 5 : 0] : 0u, KW > 6 ? cur[KW > 6 ? 6 : 0] : 0u);
                                   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                                   atomicExch(&A[s].w, wgt);                     // publish
                                   created = true;
@@ -344,6 +364,11 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
                 { A[slot].w = 0;
                   my_distinct += 1;
                   u32 cc = v;
+                  if (DEDUP)
+                    { nq += 1;
+                      c[j] = v;
+                      continue;
+                    }
                   if (v >= sat)                                // sat = 0x7fff, MSDsort.c:498-506
                     my_max += v;
                   if (v >= 0x7fffu)
@@ -357,7 +382,7 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
                     }
                 }
             }
-          if (cutoff > 0 && !(variant & 4))
+          if ((DEDUP || cutoff > 0) && !(variant & 4))
             { u32 tot;
               const u32 off = ag_block_exscan(nq, sh_tmp, &tot);
               if (tid == 0 && tot > 0)
@@ -370,15 +395,25 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
                     if (c[j] != 0)
                       { const int slot = j * AG_THREADS + tid;
                         const uint4 a = A[slot];
-                        u32 kd[5] = { a.x, a.y, a.z, 0u, 0u };
+                        u32 kd[7] = { a.x, a.y, a.z, 0u, 0u, 0u, 0u };
                         if (KW > 3)
                           { const uint4 b = B[slot];
-                            kd[3] = b.x; kd[4] = b.y;
+                            kd[3] = b.x; kd[4] = b.y; kd[5] = b.z; kd[6] = b.w;
                           }
+                        if (DEDUP)
+                          {
 #pragma unroll
-                        for (int w = 0; w < KW - 1; w++)
-                          table[o * KW + w] = kd[w];
-                        table[o * KW + KW - 1] = kd[KW - 1] | (c[j] << 16);
+                            for (int w = 0; w < KW; w++)
+                              table[o * (KW + 1) + w] = kd[w];
+                            table[o * (KW + 1) + KW] = c[j];
+                          }
+                        else
+                          {
+#pragma unroll
+                            for (int w = 0; w < KW - 1; w++)
+                              table[o * KW + w] = kd[w];
+                            table[o * KW + KW - 1] = kd[KW - 1] | (c[j] << 16);
+                          }
                         o += 1;
                       }
                 }
@@ -442,7 +477,7 @@ static int aggr_t(fk_ctx *ctx, const void *d_grouped, int64_t n, int cutoff, int
   static bool attr_set[8] = { false };
   const size_t lds = AgCfg<KW>::LDS;
   if (!attr_set[KW])
-    { auto kern = k_ag_count<KW>;
+    { auto kern = k_ag_count<KW, false>;
       FK_HIP(ctx, hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
       attr_set[KW] = true;
     }
@@ -455,7 +490,7 @@ static int aggr_t(fk_ctx *ctx, const void *d_grouped, int64_t n, int cutoff, int
     gshift += 1;
   const int limit = (ctx->dbg_aggr_limit > 0 && ctx->dbg_aggr_limit < AgCfg<KW>::LIMIT) ? ctx->dbg_aggr_limit
                                                                                         : AgCfg<KW>::LIMIT;
-  hipLaunchKernelGGL(k_ag_count<KW>, dim3((unsigned) cus), dim3(AG_THREADS), lds, s, (const u32 *) d_grouped,
+  hipLaunchKernelGGL((k_ag_count<KW, false>), dim3((unsigned) cus), dim3(AG_THREADS), lds, s, (const u32 *) d_grouped,
                      (const u64 *) d_bounds, ctx->wid.kmer_bytes, cutoff, d_hist, d_scal, (u32 *) d_table, limit, ctx->dbg_aggr_variant, gshift,
                      (u32) (ctx->aggr_sat > 0 ? ctx->aggr_sat : 0x7fff));
   FK_LAUNCH_CHECK(ctx);
@@ -499,5 +534,63 @@ int fkx_aggregate(fk_ctx *ctx, const void *d_grouped, int64_t n, int cutoff, int
     default:
       fk_set_error(ctx, "k-mer stride %d not built", ctx->wid.kmer_stride);
       return (FK_EUNSUPPORTED);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Super-mer de-duplication with the same kernel: n records of KW dwords, grouped by 16 hash bits of
+// the whole record -> every distinct record once, followed by its multiplicity (KW + 1 dwords each,
+// in no particular order).  Replaces two of the four grouping passes and the run detection of the
+// expansion (count.c:421-426).
+template <int KW>
+static int dedup_t(fk_ctx *ctx, const void *d_grouped, int64_t n, void *d_out, int64_t cap, int64_t *nout)
+{ hipStream_t s = ctx->stream;
+  *nout = 0;
+  if (n == 0)
+    return (FK_OK);
+  if (d_out == NULL || cap < n)
+    { fk_set_error(ctx, "dedup: the output buffer must take as many records as the input (%lld)", (long long) n);
+      return (FK_EINVAL);
+    }
+  u64 *d_bounds = (u64 *) fk_slot(ctx, FK_SLOT_AG_BOUNDS, (AG_BINS + 1) * 8);
+  u64 *d_hist   = (u64 *) fk_slot(ctx, FK_SLOT_CT_HIST, (FK_HIST_BINS + 8) * 8);
+  if (d_bounds == NULL || d_hist == NULL)
+    return (FK_ENOMEM);
+  u64 *d_scal = d_hist + FK_HIST_BINS;
+  static bool attr_set = false;
+  const size_t lds = AgCfg<KW>::LDS;
+  if (!attr_set)
+    { auto kern = k_ag_count<KW, true>;
+      FK_HIP(ctx, hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+      attr_set = true;
+    }
+  FK_HIP(ctx, hipMemsetAsync(d_scal, 0, 8 * 8, s));
+  hipLaunchKernelGGL(k_ag_bounds<KW>, dim3(AG_BINS / 256 + 1), dim3(256), 0, s, (const u32 *) d_grouped, n,
+                     KW * 4, d_bounds);
+  const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
+  int gshift = 0;
+  while (gshift < 16 && (n >> (16 - gshift - 1)) < 8000)     // a full batch of records per table fill
+    gshift += 1;
+  hipLaunchKernelGGL((k_ag_count<KW, true>), dim3((unsigned) cus), dim3(AG_THREADS), lds, s, (const u32 *) d_grouped,
+                     (const u64 *) d_bounds, KW * 4, 1, d_hist, d_scal, (u32 *) d_out, AgCfg<KW>::LIMIT, 0,
+                     gshift, 0x7fffu);
+  FK_LAUNCH_CHECK(ctx);
+  FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch + 4100, d_scal, 8 * 8, hipMemcpyDeviceToHost, s));
+  FK_HIP(ctx, hipStreamSynchronize(s));
+  if (ctx->h_scratch[4100 + 3] != 0)
+    return (FK_ESTATE);
+  *nout = (int64_t) ctx->h_scratch[4100 + 2];
+  return (FK_OK);
+}
+
+int fkx_dedup_supermers(fk_ctx *ctx, const void *d_grouped, int64_t n, void *d_out, int64_t cap, int64_t *nout)
+{ switch (ctx->wid.smer_stride >> 2)
+  { case 2: return dedup_t<2>(ctx, d_grouped, n, d_out, cap, nout);
+    case 3: return dedup_t<3>(ctx, d_grouped, n, d_out, cap, nout);
+    case 4: return dedup_t<4>(ctx, d_grouped, n, d_out, cap, nout);
+    case 5: return dedup_t<5>(ctx, d_grouped, n, d_out, cap, nout);
+    case 6: return dedup_t<6>(ctx, d_grouped, n, d_out, cap, nout);
+    case 7: return dedup_t<7>(ctx, d_grouped, n, d_out, cap, nout);
+    default: return (FK_EUNSUPPORTED);              // the caller keeps the four-pass grouping
   }
 }

@@ -352,6 +352,10 @@ extern "C" int fk_debug_set(fk_ctx *ctx, const char *key, int64_t value)
     { ctx->dbg_radix_items = (int) value;
       return (FK_OK);
     }
+  if (strcmp(key, "smer_stage") == 0)       // 1: four grouping passes + run detection instead of LDS de-duplication
+    { ctx->dbg_smer_stage = (int) value;
+      return (FK_OK);
+    }
   if (strcmp(key, "table_sort") == 0)       // 1: plain full-key table sort, >= 2: prefix bytes of the short one
     { ctx->dbg_table_sort = (int) value;
       return (FK_OK);
@@ -986,18 +990,49 @@ static int count_bucket(fk_ctx *ctx, void *sm_in, int64_t ns, fk_result *res, bo
       hipEventRecord(ev[0], s);
 
       // super-mer "sort": only has to bring identical records together (Supermer_Sort's output is
-      // consumed by the run-length pass of count.c:421-426), so four hashed digit passes suffice
+      // consumed by the run-length pass of count.c:421-426).  Two hashed digit passes put all copies
+      // of a record into one of 65,536 bins and the aggregation kernel de-duplicates every bin in an
+      // LDS hash table (distinct record + multiplicity); records too wide for that table, or
+      // fk_debug_set("smer_stage",1), take four hashed passes and the expansion finds the runs itself
       void *sm_sorted = sm_in;
-      if ((rc = fkx_group(ctx, ns, sm_in, sm_b, w.smer_stride, w.smer_stride, FK_GROUP_PASSES, &sm_sorted)) != FK_OK)
-        break;
-      res->passes_super      = ctx->sort_stats.passes;
-      res->ms_pass_super    += ctx->sort_stats.pass_ms_total;
-      res->ms_scatter_super += ctx->sort_stats.scatter_ms_total;
+      int64_t nsx = ns;                          // records handed to the expansion
+      bool    dd = false;
+      if (ctx->dbg_smer_stage != 1 && (w.smer_stride >> 2) >= 2 && (w.smer_stride >> 2) <= 7)
+        { void *grouped = sm_in;
+          if ((rc = fkx_group(ctx, ns, sm_in, sm_b, w.smer_stride, w.smer_stride, 2, &grouped)) != FK_OK)
+            break;
+          res->passes_super      = ctx->sort_stats.passes;
+          res->ms_pass_super    += ctx->sort_stats.pass_ms_total;
+          res->ms_scatter_super += ctx->sort_stats.scatter_ms_total;
+          void *dd_out = fk_slot(ctx, FK_SLOT_SM_D, ns * (w.smer_stride + 4));
+          if (dd_out == NULL) { rc = FK_ENOMEM; break; }
+          rc = fkx_dedup_supermers(ctx, grouped, ns, dd_out, ns, &nsx);
+          if (rc == FK_OK)
+            { dd = true;
+              sm_sorted = dd_out;
+            }
+          else if (rc == FK_ESTATE)
+            { void *other = (grouped == sm_in) ? sm_b : sm_in;      // a bin did not fit: group fully
+              sm_sorted = grouped;
+              nsx = ns;
+              if ((rc = fkx_group(ctx, ns, grouped, other, w.smer_stride, w.smer_stride, FK_GROUP_PASSES, &sm_sorted)) != FK_OK)
+                break;
+            }
+          else
+            break;
+        }
+      else
+        { if ((rc = fkx_group(ctx, ns, sm_in, sm_b, w.smer_stride, w.smer_stride, FK_GROUP_PASSES, &sm_sorted)) != FK_OK)
+            break;
+          res->passes_super      = ctx->sort_stats.passes;
+          res->ms_pass_super    += ctx->sort_stats.pass_ms_total;
+          res->ms_scatter_super += ctx->sort_stats.scatter_ms_total;
+        }
       hipEventRecord(ev[1], s);
 
       // weighted k-mer list
       int64_t nw = 0, nd = 0, ovf = 0;
-      if ((rc = fkx_expand(ctx, sm_sorted, ns, NULL, 0, &nw, &nd, &ovf)) != FK_OK) break;
+      if ((rc = fkx_expand(ctx, sm_sorted, nsx, NULL, 0, &nw, &nd, &ovf, false, false, dd)) != FK_OK) break;
       res->nweighted += nw;
       res->ndistinct_super += nd;
       if (nw > 0)
@@ -1010,8 +1045,8 @@ static int count_bucket(fk_ctx *ctx, void *sm_in, int64_t ns, fk_result *res, bo
           if ((km_a = fk_slot(ctx, FK_SLOT_KM_A, want * w.kmer_stride)) == NULL
               || (km_b = fk_slot(ctx, FK_SLOT_KM_B, want * w.kmer_stride)) == NULL)
             { rc = FK_ENOMEM; break; }
-          if ((rc = fkx_expand(ctx, sm_sorted, ns, km_a, nw, &nw, &nd, &ovf, true,
-                               ctx->dbg_kmer_stage != 1 && exact_roff == NULL)) != FK_OK) break;
+          if ((rc = fkx_expand(ctx, sm_sorted, nsx, km_a, nw, &nw, &nd, &ovf, true,
+                               ctx->dbg_kmer_stage != 1 && exact_roff == NULL, dd)) != FK_OK) break;
         }
       int64_t exact_census[256];
       if (exact_roff != NULL && nw > 0

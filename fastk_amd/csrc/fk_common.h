@@ -76,6 +76,7 @@ struct fk_ctx
   int        dbg_radix_engine;    // 1 = look-back engine instead of the stream engine
   int        dbg_kmer_stage;      // 1 = sort-collapse-sort k-mer stage instead of hash aggregation
   int        dbg_verbose;
+  int        dbg_smer_stage;      // 1: four hashed grouping passes for the super-mers (no LDS de-duplication)
   int        dbg_table_sort;      // 1: plain KMER_BYTES-pass table sort; >= 2: prefix length of the short sort
   int64_t    tsort_ties;          // records the last table sort had to repair
   int        dbg_aggr_variant;    // ablations of k_ag_count (wrong results), see fk_debug_set
@@ -95,7 +96,7 @@ enum { FK_SLOT_SM_A = 0, FK_SLOT_SM_B, FK_SLOT_KM_A, FK_SLOT_KM_B, FK_SLOT_EX_HE
        FK_SLOT_EX_KOFF, FK_SLOT_CT_ENT, FK_SLOT_CT_OFF, FK_SLOT_CT_HIST, FK_SLOT_DIG_A, FK_SLOT_DIG_B,
        FK_SLOT_RX_TILE, FK_SLOT_RX_CHUNK, FK_SLOT_RX_SUPER, FK_SLOT_ROFF, FK_SLOT_AG_BOUNDS, FK_SLOT_TABLE, FK_SLOT_SM_G,
        FK_SLOT_RAW, FK_SLOT_FQ_INFO, FK_SLOT_FQ_PHASE, FK_SLOT_FQ_OFF, FK_SLOT_TIE_A, FK_SLOT_TIE_B,
-       FK_SLOT_TIE_POS };
+       FK_SLOT_TIE_POS, FK_SLOT_SM_D };
 
 // returns a device buffer of at least nbytes for the given purpose (NULL + error set on failure)
 void *fk_slot(fk_ctx *ctx, int slot, int64_t nbytes);
@@ -132,7 +133,7 @@ int fkx_split_fast(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void **d_ou
                    int64_t *ninst, int64_t *bucket_counts, int64_t *bucket_offsets);
 int fkx_expand(fk_ctx *ctx, const void *d_smers, int64_t nsuper, void *d_out, int64_t cap,
                int64_t *nweighted, int64_t *ndistinct, int64_t *overflow, bool reuse_counts = false,
-               bool hash_stream = false);
+               bool hash_stream = false, bool dedup = false);
 int fkx_count(fk_ctx *ctx, const void *d_kmers, int64_t nweighted, int cutoff, int sorted_bytes,
               int64_t *hist, int64_t *max_inst, int64_t *ndistinct,
               void *d_table, int64_t cap, int64_t *ntable);
@@ -144,6 +145,7 @@ int fkx_parse_fastq(fk_ctx *ctx, const void *d_raw, int64_t nbytes, int flags, i
                     int64_t *nkept, int64_t *nreads);
 int fkx_parse_fasta(fk_ctx *ctx, const void *d_raw, int64_t nbytes, int state, void *d_dst,
                     int64_t *nkept, int64_t *nrecs);
+int fkx_dedup_supermers(fk_ctx *ctx, const void *d_grouped, int64_t n, void *d_out, int64_t cap, int64_t *nout);
 int fkx_sort_table(fk_ctx *ctx, int64_t n, void *d_tab, void *d_tmp, void **result, int64_t *wfirst);
 int fkx_synth(fk_ctx *ctx, uint64_t seed, uint64_t genome_len, uint32_t read_len,
               uint32_t err_ppm, uint64_t first_read, int64_t nreads, void *d_bases);

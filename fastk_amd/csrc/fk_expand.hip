@@ -26,19 +26,22 @@ __device__ __forceinline__ bool ex_same(const u32 *a, const u32 *b)
 }
 
 // ---- (1) per tile: heads and k-mers ----------------------------------------------------------
-template <int RW>
+// DD: the records are already de-duplicated (fkx_dedup_supermers): RW dwords + one dword with the
+// multiplicity, every record is a run of its own
+template <int RW, bool DD>
 __global__ __launch_bounds__(EX_THREADS) void k_ex_count(const u32 *__restrict__ sm, int64_t n,
                                                          int len_byte, u32 *__restrict__ tile_heads,
                                                          u32 *__restrict__ tile_kmers)
-{ __shared__ u32 tmp[8];
+{ constexpr int RS = RW + (DD ? 1 : 0);
+  __shared__ u32 tmp[8];
   const int64_t t0 = (int64_t) blockIdx.x * EX_TILE;
   u32 heads = 0, kmers = 0;
 #pragma unroll
   for (int it = 0; it < EX_ITEMS; it++)
     { const int64_t i = t0 + it * EX_THREADS + threadIdx.x;
       if (i < n)
-        { const u32 *r = sm + i * RW;
-          const bool head = (i == 0) || !ex_same<RW>(r, r - RW);
+        { const u32 *r = sm + i * RS;
+          const bool head = DD || (i == 0) || !ex_same<RW>(r, r - RS);
           if (head)
             { heads += 1;
               kmers += ((r[len_byte >> 2] >> (8 * (len_byte & 3))) & 0xffu) + 1u;
@@ -74,7 +77,7 @@ __device__ __forceinline__ u32 ex_bits(const u32 *rec, int bit)
 // offsets, cut the 2K-bit window out of the super-mer, build its reverse complement, keep the smaller.
 template <int OW> struct __attribute__((packed, aligned(4))) ex_out { u32 w[OW]; };
 
-template <int RW, int KN, int OW>     // KN = words holding a k-mer, OW = words of an output record
+template <int RW, int KN, int OW, bool DD>   // KN = words holding a k-mer, OW = words of an output record
 __global__ __launch_bounds__(EX_THREADS) void k_ex_expand(const u32 *__restrict__ sm, int64_t n,
                                                           int kmer, int len_byte,
                                                           const u64 *__restrict__ tile_koff,
@@ -82,7 +85,8 @@ __global__ __launch_bounds__(EX_THREADS) void k_ex_expand(const u32 *__restrict_
                                                           u64 *__restrict__ overflow, int64_t ntiles,
                                                           uint8_t *__restrict__ dig,
                                                           u64 *__restrict__ dhist, int kbytes)
-{ __shared__ __attribute__((aligned(16))) u32 recs[(EX_TILE + 1) * RW];   // big-endian value words (+1 guard)
+{ constexpr int RS = RW + (DD ? 1 : 0);             // dwords per input record
+  __shared__ __attribute__((aligned(16))) u32 recs[(EX_TILE + 1) * RS];   // big-endian value words (+1 guard)
   __shared__ u32 lh[512];                // dig != NULL: histograms of hash digits 0 and 1 of the k-mers
   __shared__ u32 hoff[EX_TILE + 1];      // first k-mer of head h inside the tile
   __shared__ uint16_t hrec[EX_TILE];     // record index of head h
@@ -100,9 +104,9 @@ __global__ __launch_bounds__(EX_THREADS) void k_ex_expand(const u32 *__restrict_
   __syncthreads();
   const int64_t t0 = tile * EX_TILE;
   const int     tn = (n - t0 < EX_TILE) ? (int) (n - t0) : EX_TILE;
-  fk_stage16<(EX_TILE * RW + 1023) / 1024, true>(recs, sm + t0 * RW, tn * RW);
-  if (threadIdx.x < RW)
-    recs[tn * RW + threadIdx.x] = 0;               // guard word read by ex_bits at the last record
+  fk_stage16<(EX_TILE * RS + 1023) / 1024, true>(recs, sm + t0 * RS, tn * RS);
+  if (threadIdx.x < RS)
+    recs[tn * RS + threadIdx.x] = 0;               // guard word read by ex_bits at the last record
   if (threadIdx.x == 0)
     { s_runk = 0; s_runh = 0; }
   __syncthreads();
@@ -114,20 +118,20 @@ __global__ __launch_bounds__(EX_THREADS) void k_ex_expand(const u32 *__restrict_
       u32  nk = 0;
       if (l < tn)
         { const int64_t i = t0 + l;
-          head = (i == 0);
+          head = DD || (i == 0);
           if (!head)
             { if (l > 0)
-                head = !ex_same<RW>(recs + l * RW, recs + (l - 1) * RW);
+                head = !ex_same<RW>(recs + l * RS, recs + (l - 1) * RS);
               else
                 { bool same = true;
 #pragma unroll
                   for (int w = 0; w < RW; w++)
-                    same &= (__builtin_bswap32(sm[(i - 1) * RW + w]) == recs[w]);
+                    same &= (__builtin_bswap32(sm[(i - 1) * RS + w]) == recs[w]);
                   head = !same;
                 }
             }
           if (head)
-            nk = ((recs[l * RW + (len_byte >> 2)] >> (24 - 8 * (len_byte & 3))) & 0xffu) + 1u;
+            nk = ((recs[l * RS + (len_byte >> 2)] >> (24 - 8 * (len_byte & 3))) & 0xffu) + 1u;
         }
       u32 totk, toth;
       const u32 exk = fk_block_exscan_256<u32>(nk, tmp, &totk);
@@ -150,20 +154,22 @@ __global__ __launch_bounds__(EX_THREADS) void k_ex_expand(const u32 *__restrict_
     for (u32 h = threadIdx.x; h < nh1; h += EX_THREADS)
       { const int l = hrec[h];
         int64_t ct = (h + 1 < nh1) ? (int64_t) hrec[h + 1] - l : (int64_t) tn - l;
-        if (h + 1 == nh1)
+        if (DD)
+          ct = (int64_t) __builtin_bswap32(recs[l * RS + RW]);
+        else if (h + 1 == nh1)
           { int64_t j = t0 + tn;
             bool open = true;
             while (open && j < n)
               { bool same = true;
 #pragma unroll
                 for (int w = 0; w < RW; w++)
-                  same &= (__builtin_bswap32(sm[j * RW + w]) == recs[l * RW + w]);
+                  same &= (__builtin_bswap32(sm[j * RS + w]) == recs[l * RS + w]);
                 if (same) { ct += 1; j += 1; }
                 else open = false;
               }
           }
         if (ct >= 0x8000)                          // count.c:455-458
-          { const u32 nk = ((recs[l * RW + (len_byte >> 2)] >> (24 - 8 * (len_byte & 3))) & 0xffu) + 1u;
+          { const u32 nk = ((recs[l * RS + (len_byte >> 2)] >> (24 - 8 * (len_byte & 3))) & 0xffu) + 1u;
             atomicAdd(overflow, (u64) (ct - 0x7fff) * (u64) nk);
             ct = 0x7fff;
           }
@@ -193,7 +199,7 @@ __global__ __launch_bounds__(EX_THREADS) void k_ex_expand(const u32 *__restrict_
         }
       u32        o   = j0 - hoff[lo];
       u32        nxt = hoff[lo + 1];
-      const u32 *rec = recs + (u32) hrec[lo] * RW;
+      const u32 *rec = recs + (u32) hrec[lo] * RS;
       u32        ct  = hct[lo];
       u32 f[KN], r[KN];
       bool fresh = true;
@@ -207,7 +213,7 @@ __global__ __launch_bounds__(EX_THREADS) void k_ex_expand(const u32 *__restrict_
                 { lo += 1;
                   o = 0;
                   nxt = hoff[lo + 1];
-                  rec = recs + (u32) hrec[lo] * RW;
+                  rec = recs + (u32) hrec[lo] * RS;
                   ct  = hct[lo];
                   fresh = true;
                 }
@@ -281,7 +287,7 @@ __global__ __launch_bounds__(EX_THREADS) void k_ex_expand(const u32 *__restrict_
 template <int RW>
 static int expand_t(fk_ctx *ctx, const void *d_smers, int64_t n, void *d_out, int64_t cap,
                     int64_t *nweighted, int64_t *ndistinct, int64_t *overflow, bool reuse_counts,
-                    bool hash_stream)
+                    bool hash_stream, bool dedup)
 { hipStream_t s = ctx->stream;
   const int   K = ctx->prm.kmer;
   const int   kn = (2 * K + 31) / 32;
@@ -310,8 +316,12 @@ static int expand_t(fk_ctx *ctx, const void *d_smers, int64_t n, void *d_out, in
         }
       else
       {
-      hipLaunchKernelGGL(k_ex_count<RW>, dim3((unsigned) ntiles), dim3(EX_THREADS), 0, s,
-                         (const u32 *) d_smers, n, len_byte, d_heads, d_kmers);
+      if (dedup)
+        hipLaunchKernelGGL((k_ex_count<RW, true>), dim3((unsigned) ntiles), dim3(EX_THREADS), 0, s,
+                           (const u32 *) d_smers, n, len_byte, d_heads, d_kmers);
+      else
+        hipLaunchKernelGGL((k_ex_count<RW, false>), dim3((unsigned) ntiles), dim3(EX_THREADS), 0, s,
+                           (const u32 *) d_smers, n, len_byte, d_heads, d_kmers);
       // heads total: reuse the scan with d_koff as a throw-away output
       hipLaunchKernelGGL(k_exscan_tiles, dim3(1), dim3(256), 0, s, (const u32 *) d_heads, ntiles,
                          d_koff, d_tot + 1);
@@ -336,10 +346,18 @@ static int expand_t(fk_ctx *ctx, const void *d_smers, int64_t n, void *d_out, in
           break;
         }
 #define EX_LAUNCH(KN, OW)                                                                          \
-      hipLaunchKernelGGL((k_ex_expand<RW, KN, OW>), dim3((unsigned) std::min<int64_t>(ntiles, egrid)),  \
-                         dim3(EX_THREADS), 0, s,                                                        \
-                         (const u32 *) d_smers, n, K, len_byte, (const u64 *) d_koff, (u32 *) d_out,   \
-                         d_tot + 2, ntiles, d_dig, ctx->d_digit_hist, ctx->wid.kmer_bytes)
+    do {                                                                                             \
+      if (dedup)                                                                                       \
+        hipLaunchKernelGGL((k_ex_expand<RW, KN, OW, true>), dim3((unsigned) std::min<int64_t>(ntiles, egrid)), \
+                           dim3(EX_THREADS), 0, s,                                                      \
+                           (const u32 *) d_smers, n, K, len_byte, (const u64 *) d_koff, (u32 *) d_out, \
+                           d_tot + 2, ntiles, d_dig, ctx->d_digit_hist, ctx->wid.kmer_bytes);          \
+      else                                                                                             \
+        hipLaunchKernelGGL((k_ex_expand<RW, KN, OW, false>), dim3((unsigned) std::min<int64_t>(ntiles, egrid)), \
+                           dim3(EX_THREADS), 0, s,                                                      \
+                           (const u32 *) d_smers, n, K, len_byte, (const u64 *) d_koff, (u32 *) d_out, \
+                           d_tot + 2, ntiles, d_dig, ctx->d_digit_hist, ctx->wid.kmer_bytes);          \
+    } while (0)
       // hash_stream: also emit what the hashed grouping of the k-mers needs (digit stream + histograms)
       uint8_t *d_dig = NULL;
       const int64_t egrid = 8ll * (ctx->num_cus > 0 ? ctx->num_cus : 256);
@@ -380,15 +398,15 @@ static int expand_t(fk_ctx *ctx, const void *d_smers, int64_t n, void *d_out, in
 
 int fkx_expand(fk_ctx *ctx, const void *d_smers, int64_t nsuper, void *d_out, int64_t cap,
                int64_t *nweighted, int64_t *ndistinct, int64_t *overflow, bool reuse_counts,
-               bool hash_stream)
+               bool hash_stream, bool dedup)
 { switch (ctx->wid.smer_stride >> 2)
-  { case 2: return expand_t<2>(ctx, d_smers, nsuper, d_out, cap, nweighted, ndistinct, overflow, reuse_counts, hash_stream);
-    case 3: return expand_t<3>(ctx, d_smers, nsuper, d_out, cap, nweighted, ndistinct, overflow, reuse_counts, hash_stream);
-    case 4: return expand_t<4>(ctx, d_smers, nsuper, d_out, cap, nweighted, ndistinct, overflow, reuse_counts, hash_stream);
-    case 5: return expand_t<5>(ctx, d_smers, nsuper, d_out, cap, nweighted, ndistinct, overflow, reuse_counts, hash_stream);
-    case 6: return expand_t<6>(ctx, d_smers, nsuper, d_out, cap, nweighted, ndistinct, overflow, reuse_counts, hash_stream);
-    case 7: return expand_t<7>(ctx, d_smers, nsuper, d_out, cap, nweighted, ndistinct, overflow, reuse_counts, hash_stream);
-    case 8: return expand_t<8>(ctx, d_smers, nsuper, d_out, cap, nweighted, ndistinct, overflow, reuse_counts, hash_stream);
+  { case 2: return expand_t<2>(ctx, d_smers, nsuper, d_out, cap, nweighted, ndistinct, overflow, reuse_counts, hash_stream, dedup);
+    case 3: return expand_t<3>(ctx, d_smers, nsuper, d_out, cap, nweighted, ndistinct, overflow, reuse_counts, hash_stream, dedup);
+    case 4: return expand_t<4>(ctx, d_smers, nsuper, d_out, cap, nweighted, ndistinct, overflow, reuse_counts, hash_stream, dedup);
+    case 5: return expand_t<5>(ctx, d_smers, nsuper, d_out, cap, nweighted, ndistinct, overflow, reuse_counts, hash_stream, dedup);
+    case 6: return expand_t<6>(ctx, d_smers, nsuper, d_out, cap, nweighted, ndistinct, overflow, reuse_counts, hash_stream, dedup);
+    case 7: return expand_t<7>(ctx, d_smers, nsuper, d_out, cap, nweighted, ndistinct, overflow, reuse_counts, hash_stream, dedup);
+    case 8: return expand_t<8>(ctx, d_smers, nsuper, d_out, cap, nweighted, ndistinct, overflow, reuse_counts, hash_stream, dedup);
     default:
       fk_set_error(ctx, "super-mer stride %d not built", ctx->wid.smer_stride);
       return (FK_EUNSUPPORTED);

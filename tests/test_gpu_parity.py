@@ -526,6 +526,18 @@ def test_whole_path_across_k(k):
             assert res.ntable == exp.ntable and np.array_equal(res.table, exp.table)
 
 
+@pytest.mark.parametrize("name", ["synth_illumina_k40_t1_T4", "edge_k40_t1_T4", "synth_illumina_k51_t1_T4"])
+def test_pipeline_four_pass_supermer_path_matches_golden(name):
+    """fk_debug_set("smer_stage", 1): super-mers grouped by four hashed passes and run detection in
+    the expansion (the path for very wide records and the fallback of the LDS de-duplication)."""
+    case, bases, boff = util.load_case(name)
+    with fastk_amd.Context(kmer=case["k"], table_cutoff=case["cutoff"], nthreads=case["T"]) as ctx:
+        ctx.debug_set("smer_stage", 1)
+        ctx.push_block(bases, boff.astype(np.int32))
+        res = ctx.finish()
+        util.check_against_golden(case, res.hist, res.max_inst, res.table)
+
+
 def test_empty_and_degenerate_inputs():
     with fastk_amd.Context(kmer=40, table_cutoff=1) as ctx:
         res = ctx.finish()
