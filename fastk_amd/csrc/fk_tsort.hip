@@ -162,89 +162,60 @@ __global__ __launch_bounds__(TS_THREADS) void k_ts_fix(u32 *__restrict__ recs, i
 template <int KW>
 __global__ __launch_bounds__(TS_THREADS) void k_ts_fix_tile(u32 *__restrict__ recs, int64_t n, int pbytes,
                                                             int kbytes, u32 *__restrict__ long_runs)
-{ constexpr int NS = TS_TILE + TS_HALO;                   // LDS slots
-  constexpr int NI = (NS + TS_THREADS - 1) / TS_THREADS;  // slots per thread
-  __shared__ __attribute__((aligned(16))) u32 t[NS * KW];
+{ __shared__ __attribute__((aligned(16))) u32 t[(TS_TILE + TS_HALO) * KW];
   __shared__ u32 prev[KW];                                // the record in front of the tile
-  __shared__ unsigned char hd[NS + 1];                    // 1: the slot starts a run
   __shared__ int s_lo, s_hi;
   const int  full  = pbytes >> 2;
   const u32  lastm = (pbytes & 3) ? ((1u << (8 * (pbytes & 3))) - 1u) : 0u;
   const int  kfull = kbytes >> 2;
   const u32  klast = (kbytes & 3) ? ((1u << (8 * (kbytes & 3))) - 1u) : 0u;
   const int64_t t0 = (int64_t) blockIdx.x * TS_TILE;      // global index of LDS slot 0
-  const int  tn = (int) ((n - t0 < NS) ? (n - t0) : NS);  // slots 0..tn-1 hold records
+  const int  tn = (int) ((n - t0 < TS_TILE + TS_HALO) ? (n - t0) : (TS_TILE + TS_HALO));   // slots 0..tn-1
   const int  own = (tn < TS_TILE) ? tn : TS_TILE;         // run starts this workgroup owns: slots 0..own-1
-  fk_stage16<(NS * KW + 1023) / 1024, false>(t, recs + t0 * KW, tn * KW);
+  fk_stage16<((TS_TILE + TS_HALO) * KW + 1023) / 1024, false>(t, recs + t0 * KW, tn * KW);
   if (threadIdx.x < KW)
     prev[threadIdx.x] = (t0 > 0) ? recs[(t0 - 1) * KW + threadIdx.x] : 0u;
-  if (threadIdx.x == 0) { s_lo = NS + 1; s_hi = 0; }
+  if (threadIdx.x == 0) { s_lo = TS_TILE + TS_HALO + 1; s_hi = 0; }
   __syncthreads();
-  for (int i = threadIdx.x; i <= tn; i += TS_THREADS)
-    hd[i] = (i == tn) ? 1
-          : ((t0 + i == 0) || !ts_same<KW>(t + i * KW, (i > 0) ? t + (i - 1) * KW : prev, full, lastm)) ? 1 : 0;
-  __syncthreads();
-
-  // Every record finds its run [rs, re) and its rank among the run's keys (all lanes work; the runs
-  // are short), keeps its record in registers, and after a barrier drops it at rs + rank.  Runs that
-  // start in front of the tile belong to the previous workgroup, runs that start in the halo to the
-  // next one; a run that leaves the loaded slots raises *long_runs.
-  u32 mine[NI][KW];
-  int dest[NI];
-  int lo = NS + 1, hi = 0;
-#pragma unroll
-  for (int q = 0; q < NI; q++)
-    { const int i = q * TS_THREADS + threadIdx.x;
-      dest[q] = -1;
-      if (i >= tn)
+  int lo = TS_TILE + TS_HALO + 1, hi = 0;
+  for (int q = 0; q < TS_ITEMS; q++)
+    { const int i = q * TS_THREADS + threadIdx.x;          // LDS slot
+      if (i >= own)
         continue;
-      int rs = i;
-      while (rs > 0 && !hd[rs])
-        rs -= 1;
-      if (!hd[rs] || rs >= own)                            // started before the tile / in the halo
+      const bool head = (t0 + i == 0) || !ts_same<KW>(t + i * KW, (i > 0) ? t + (i - 1) * KW : prev, full, lastm);
+      if (!head)
         continue;
-      int re = i + 1;
-      while (!hd[re])
-        re += 1;
-      if (re == tn && t0 + tn < n && re - rs > 1)          // may go on past what was loaded
-        { bool more = false;
-          if (tn == NS)
-            more = true;
-          if (more) *long_runs = 1;
-        }
-      lo = min(lo, rs);
-      hi = max(hi, re);
-      if (re - rs == 1)
-        continue;                                          // alone: stays where it is
-#pragma unroll
-      for (int w = 0; w < KW; w++)
-        mine[q][w] = t[i * KW + w];
-      int rank = 0;
-      for (int j = rs; j < re; j++)
-        rank += ts_less<KW>(t + j * KW, mine[q], kfull, klast) ? 1 : 0;
-      // equal keys keep their order (the table's keys are distinct, other callers may pass ties)
-      for (int j = rs; j < i; j++)
-        { bool eq = true;
+      lo = min(lo, i);
+      int j = i + 1;
+      for (; j < tn; j++)
+        { u32 x[KW];
 #pragma unroll
           for (int w = 0; w < KW; w++)
-            { const u32 m = (w < kfull) ? 0xffffffffu : (w == kfull) ? klast : 0u;
-              eq = eq && (((t[j * KW + w] ^ mine[q][w]) & m) == 0u);
+            x[w] = t[j * KW + w];
+          if (!ts_same<KW>(t + i * KW, x, full, lastm))
+            break;
+          int k = j - 1;
+          while (k >= i && ts_less<KW>(x, t + k * KW, kfull, klast))
+            {
+#pragma unroll
+              for (int w = 0; w < KW; w++)
+                t[(k + 1) * KW + w] = t[k * KW + w];
+              k -= 1;
             }
-          rank += eq ? 1 : 0;
+          if (k + 1 != j)
+            {
+#pragma unroll
+              for (int w = 0; w < KW; w++)
+                t[(k + 1) * KW + w] = x[w];
+            }
         }
-      dest[q] = rs + rank;
+      // the run may go on past what was loaded
+      if (j >= tn && t0 + tn < n)
+        *long_runs = 1;
+      hi = max(hi, j);
     }
-  if (lo < NS + 1) atomicMin(&s_lo, lo);
+  if (lo < TS_TILE + TS_HALO + 1) atomicMin(&s_lo, lo);
   if (hi > 0) atomicMax(&s_hi, hi);
-  __syncthreads();
-#pragma unroll
-  for (int q = 0; q < NI; q++)
-    if (dest[q] >= 0)
-      {
-#pragma unroll
-        for (int w = 0; w < KW; w++)
-          t[dest[q] * KW + w] = mine[q][w];
-      }
   __syncthreads();
   const int wlo = s_lo, whi = s_hi;                        // write back slots [wlo, whi)
   for (int j = wlo * KW + threadIdx.x; j < whi * KW; j += TS_THREADS)
