@@ -447,7 +447,7 @@ __global__ __launch_bounds__(RX_THREADS) void k_rx_scatter(const u32 *__restrict
                                                            const u64 *__restrict__ superpfx,
                                                            const uint8_t *__restrict__ curdig,
                                                            uint8_t *__restrict__ nextdig,
-                                                           int64_t ntiles, int hbytes)
+                                                           int64_t ntiles, int hbytes, int unstable)
 { constexpr int TILE = RX_THREADS * ITEMS;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -520,6 +520,21 @@ __global__ __launch_bounds__(RX_THREADS) void k_rx_scatter(const u32 *__restrict
 
   u32 info[ITEMS];
   u32 old[ITEMS];
+  // unstable (first pass of a hashed grouping: nothing depends on the order inside a bin): one LDS
+  // atomic per record instead of the 8-ballot match -- the kernel is bound by instruction issue
+  if (HASHED && unstable)
+    {
+#pragma unroll
+      for (int it = 0; it < ITEMS; it++)
+        { const int  r     = wbase + it * 64 + lane;
+          const bool valid = (r < tn);
+          const u32  d     = valid ? (u32) tdig[r] : 0u;
+          const u32  rk    = valid ? atomicAdd(&whist[wave * 256 + d], 1u) : 0u;
+          info[it] = d | (rk << 8);
+        }
+    }
+  else
+  {
 #pragma unroll
   for (int it = 0; it < ITEMS; it++)
     { const int  r     = wbase + it * 64 + lane;
@@ -545,6 +560,7 @@ __global__ __launch_bounds__(RX_THREADS) void k_rx_scatter(const u32 *__restrict
       const u32 base = (u32) __shfl((int) old[it], (int) ((e >> 16) & 0xffu), 64);
       info[it] = (e & 0xffu) | ((base + ((e >> 8) & 0xffu)) << 8);     // d | rank-in-wave << 8
     }
+  }
   __syncthreads();
 
   { u32 run = 0;
@@ -617,7 +633,7 @@ __global__ __launch_bounds__(RXW_THREADS) void k_rx_scatter_w(const u32 *__restr
                                                               const u64 *__restrict__ superpfx,
                                                               const uint8_t *__restrict__ curdig,
                                                               uint8_t *__restrict__ nextdig,
-                                                              int64_t ntiles, int hbytes)
+                                                              int64_t ntiles, int hbytes, int unstable)
 { constexpr int TILE = RXW_THREADS * ITEMS;
   static_assert((RX_CH - 1) * TILE < 65536 || RW < 4, "u16 tile prefixes inside a chunk");
   constexpr int NV   = ITEMS * RW / 4;
@@ -710,6 +726,19 @@ __global__ __launch_bounds__(RXW_THREADS) void k_rx_scatter_w(const u32 *__restr
       const int wbase = wave * 64 * ITEMS;
       u32 info[ITEMS];
       u32 old[ITEMS];
+      if (HASHED && unstable)
+        {
+#pragma unroll
+          for (int it = 0; it < ITEMS; it++)
+            { const int  r     = wbase + it * 64 + lane;
+              const bool valid = (r < tn);
+              const u32  d     = valid ? (u32) tdig[r] : 0u;
+              const u32  rk    = valid ? atomicAdd(&whist[wave * 256 + d], 1u) : 0u;
+              info[it] = d | (rk << 8);
+            }
+        }
+      else
+      {
 #pragma unroll
       for (int it = 0; it < ITEMS; it++)
         { const int  r     = wbase + it * 64 + lane;
@@ -735,6 +764,7 @@ __global__ __launch_bounds__(RXW_THREADS) void k_rx_scatter_w(const u32 *__restr
           const u32 base = (u32) __shfl((int) old[it], (int) ((e >> 16) & 0xffu), 64);
           info[it] = (e & 0xffu) | ((base + ((e >> 8) & 0xffu)) << 8);     // d | rank-in-wave << 8
         }
+      }
       __syncthreads();
 
       // bins: exclusive scan over waves, then over the 256 bins (threads 0..255 = waves 0..3)
@@ -1053,13 +1083,13 @@ static int lsd_sort_stream_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, c
                            dim3(RX_THREADS), lds_bytes, s,
                            (const u32 *) src, trg, n, run[i], nextb, (const uint16_t *) tilepfx,
                            (const u32 *) chunkpfx, (const u64 *) superpfx, (const uint8_t *) dcur, dnext, ntiles,
-                           hbytes);
+                           hbytes, (HASHED && i == 0 && ctx->dbg_radix_engine != 4) ? 1 : 0);
       else
         hipLaunchKernelGGL((k_rx_scatter_w<RW, ITEMS, HASHED>), dim3(sgrid),
                            dim3(RXW_THREADS), lds_bytes, s,
                            (const u32 *) src, trg, n, nextb, (const uint16_t *) tilepfx,
                            (const u32 *) chunkpfx, (const u64 *) superpfx, (const uint8_t *) dcur, dnext, ntiles,
-                           hbytes);
+                           hbytes, (HASHED && i == 0 && ctx->dbg_radix_engine != 4) ? 1 : 0);
       FK_HIP(ctx, hipEventRecord(ctx->pass_ev[2 * i + 1], s));
       FK_LAUNCH_CHECK(ctx);
       u32 *t = src; src = trg; trg = t;
