@@ -46,6 +46,9 @@ def parse():
                     help="run the sharded (all-to-all) path even on one GPU: exercises RCCL + shard.py")
     ap.add_argument("--stream-buckets", type=int, default=1,
                     help="count the minimizer buckets one after the other (HBM-budgeted mode), N=1 only")
+    ap.add_argument("--exchange-rounds", type=int, default=4,
+                    help="N > 1: the super-mer exchange is cut into this many pieces; piece i+1 travels "
+                         "while piece i is counted (1 = one all-to-all, then count)")
     ap.add_argument("--debug", action="append", default=[], metavar="KEY=VALUE",
                     help="fk_debug_set knob for ablation runs (results may be invalid)")
     return ap.parse_args()
@@ -128,7 +131,7 @@ def main():
     nbytes = per * (L + 1)
 
     ctx = fastk_amd.Context(kmer=args.kmer, table_cutoff=1, nthreads=4, device=local_rank,
-                            nbuckets=world if sharded else max(1, args.stream_buckets))
+                            nbuckets=world * max(1, args.exchange_rounds) if sharded else max(1, args.stream_buckets))
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     for kv in args.debug:
         key, val = kv.split("=")
@@ -144,6 +147,8 @@ def main():
     def step(verify=False):
         if not sharded:
             return ctx.count_device_reads(reads.data_ptr(), nbytes, fetch_table=False)
+        if args.exchange_rounds > 1:
+            return shard.count_sharded_rounds(engine, reads[:nbytes], args.exchange_rounds, verify=verify)
         return shard.count_sharded(engine, reads[:nbytes], verify=verify)
 
     def barrier():
@@ -233,7 +238,9 @@ def main():
                                     % (args.coverage, L, args.err_ppm, args.genome_mbp, args.kmer),
                            reads_per_gpu=per, kmer_instances=int(ninst), supermers=int(nsuper),
                            weighted_kmers=int(nweighted), distinct_kmers=int(ndistinct),
-                           parallelism="minimizer-bucket shard x%d" % world),
+                           parallelism="minimizer-bucket shard x%d" % world
+                                       + (", exchange in %d overlapped rounds" % args.exchange_rounds
+                                          if sharded and args.exchange_rounds > 1 else "")),
                roofline=roofline,
                stage_ms=dict((k, round(v, 3)) for k, v in loc.ms.items()))
     if rank == 0:

@@ -23,7 +23,7 @@ EXPORTS = [
     "fk_count_presorted_kmers", "fk_split_supermers_emit", "fk_split_plan", "fk_split_planned",
     "fk_train_block", "fk_count_unsorted_kmers", "fk_debug_get", "fk_push_fastq", "fk_host_alloc",
     "fk_host_free", "fk_bucket_census", "fk_set_bucket_weights", "fk_push_fasta", "fk_merge_tables",
-    "fk_write_ktab_ex",
+    "fk_write_ktab_ex", "fk_rounds_begin", "fk_rounds_add", "fk_rounds_finish",
 ]
 
 
@@ -118,6 +118,9 @@ def load_library():
     L.fk_push_fastq.argtypes = [vp, vp, i64, C.c_int, C.POINTER(C.c_int), C.POINTER(i64), C.POINTER(i64)]
     L.fk_push_fasta.argtypes = [vp, vp, i64, C.c_int, C.POINTER(C.c_int), C.POINTER(i64), C.POINTER(i64)]
     L.fk_merge_tables.argtypes = [vp, vp, i64, i64, C.POINTER(CResult)]
+    L.fk_rounds_begin.argtypes = [vp]
+    L.fk_rounds_add.argtypes = [vp, vp, i64]
+    L.fk_rounds_finish.argtypes = [vp, C.c_int, C.POINTER(CResult)]
     L.fk_host_alloc.argtypes = [i64, C.POINTER(vp)]
     L.fk_host_free.argtypes = [vp]
     L.fk_bucket_census.argtypes = [vp, vp, i64, C.POINTER(i64)]
@@ -269,6 +272,17 @@ class Context:
         self._ck(self.L.fk_push_fasta(self.h, a.ctypes.data if a.nbytes else None, a.nbytes,
                                       1 if last else 0, C.byref(st), C.byref(nr), C.byref(nb)))
         return st.value, nr.value, nb.value
+
+    def rounds_begin(self):
+        self._ck(self.L.fk_rounds_begin(self.h))
+
+    def rounds_add(self, ptr, nsuper):
+        self._ck(self.L.fk_rounds_add(self.h, ptr, nsuper))
+
+    def rounds_finish(self, fetch_table=False):
+        r = CResult()
+        self._ck(self.L.fk_rounds_finish(self.h, 1 if fetch_table else 0, C.byref(r)))
+        return Result(r, self.w.kmer_word)
 
     def merge_tables(self, records, max_inst_in=0):
         """records: (n, KMER_WORD) uint8 entries of all input tables; returns the merged Result."""

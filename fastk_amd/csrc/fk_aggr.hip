@@ -486,7 +486,7 @@ static int aggr_t(fk_ctx *ctx, const void *d_grouped, int64_t n, int cutoff, int
                      ctx->wid.kmer_bytes, d_bounds);
   const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
   int gshift = 0;                                // aim at ~6,000 records per table fill
-  while (ctx->dbg_aggr_limit <= 0 && gshift < 16 && (n >> (16 - gshift - 1)) < 6000)
+  while (ctx->dbg_aggr_limit <= 0 && gshift < 16 && (n >> (16 - gshift)) < 8000)   // >= one full batch per fill
     gshift += 1;
   const int limit = (ctx->dbg_aggr_limit > 0 && ctx->dbg_aggr_limit < AgCfg<KW>::LIMIT) ? ctx->dbg_aggr_limit
                                                                                         : AgCfg<KW>::LIMIT;
@@ -569,7 +569,7 @@ static int dedup_t(fk_ctx *ctx, const void *d_grouped, int64_t n, void *d_out, i
                      KW * 4, d_bounds);
   const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
   int gshift = 0;
-  while (gshift < 16 && (n >> (16 - gshift - 1)) < 8000)     // a full batch of records per table fill
+  while (gshift < 16 && (n >> (16 - gshift)) < 6000)         // most of a batch of records per table fill
     gshift += 1;
   hipLaunchKernelGGL((k_ag_count<KW, true>), dim3((unsigned) cus), dim3(AG_THREADS), lds, s, (const u32 *) d_grouped,
                      (const u64 *) d_bounds, KW * 4, 1, d_hist, d_scal, (u32 *) d_out, AgCfg<KW>::LIMIT, 0,

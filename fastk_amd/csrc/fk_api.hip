@@ -282,6 +282,7 @@ extern "C" void fk_destroy(fk_ctx *ctx)
     hipFree(ctx->chunks[i].ptr);
   free(ctx->chunks);
   free(ctx->h_table);
+  free(ctx->acc_res);
   free(ctx->h_roff);
   if (ctx->push_lock)
     { pthread_mutex_destroy((pthread_mutex_t *) ctx->push_lock);
@@ -1200,6 +1201,65 @@ static int count_bucket(fk_ctx *ctx, void *sm_in, int64_t ns, fk_result *res, bo
   return (rc);
 }
 
+// The table candidates the buckets appended to FK_SLOT_TABLE -> one table in k-mer order.
+static int sort_union_table(fk_ctx *ctx, int64_t ntab, fk_result *res, void **table, fk_stage_ms *tm)
+{ const fk_widths &w = ctx->wid;
+  hipStream_t s = ctx->stream;
+  void *tmp = fk_slot(ctx, FK_SLOT_KM_A, ntab * w.kmer_stride);
+  int64_t census[256];
+  if (tmp == NULL) return (FK_ENOMEM);
+  hipEventRecord(ctx->ev0, s);
+  *table = ctx->slot_ptr[FK_SLOT_TABLE];
+  int rc = fkx_sort_table(ctx, ntab, ctx->slot_ptr[FK_SLOT_TABLE], tmp, table, census);
+  if (rc != FK_OK) return (rc);
+  res->passes_final   = ctx->sort_stats.passes;
+  res->ms_pass_final += ctx->sort_stats.pass_ms_total;
+  for (int x = 0; x < 256; x++)
+    res->wfirst[x] = census[x];
+  hipEventRecord(ctx->ev1, s);
+  hipEventSynchronize(ctx->ev1);
+  tm->radix_k += ms_between(ctx->ev0, ctx->ev1);
+  return (FK_OK);
+}
+
+// ntable / ncollapsed and, if asked, the table itself (host copy in reference layout) into res
+static int fetch_result_table(fk_ctx *ctx, fk_result *res, void *table, int64_t nt, bool fetch_table)
+{ const fk_widths &w = ctx->wid;
+  hipStream_t s = ctx->stream;
+  const int cutoff = ctx->prm.table_cutoff;
+  res->ncollapsed = nt;
+  res->ntable = (cutoff > 0) ? nt : 0;
+  if (!(cutoff > 0 && nt > 0 && fetch_table))
+    return (FK_OK);
+  const int64_t bytes = nt * w.kmer_word;
+  if (ctx->h_table_cap < bytes)
+    { free(ctx->h_table);
+      ctx->h_table = (uint8_t *) malloc((size_t) bytes);
+      ctx->h_table_cap = bytes;
+      if (ctx->h_table == NULL)
+        { ctx->h_table_cap = 0; return (FK_ENOMEM); }
+    }
+  if (w.kmer_word == w.kmer_stride)
+    { if (hipMemcpyAsync(ctx->h_table, table, (size_t) bytes, hipMemcpyDeviceToHost, s) != hipSuccess
+          || hipStreamSynchronize(s) != hipSuccess)
+        return (FK_EHIP);
+    }
+  else
+    { uint8_t *tmp = (uint8_t *) malloc((size_t) nt * w.kmer_stride);
+      if (tmp == NULL) return (FK_ENOMEM);
+      if (hipMemcpyAsync(tmp, table, (size_t) nt * w.kmer_stride, hipMemcpyDeviceToHost, s) != hipSuccess
+          || hipStreamSynchronize(s) != hipSuccess)
+        { free(tmp); return (FK_EHIP); }
+      for (int64_t i = 0; i < nt; i++)
+        { memcpy(ctx->h_table + i * w.kmer_word, tmp + i * w.kmer_stride, w.kmer_bytes);
+          memcpy(ctx->h_table + i * w.kmer_word + w.kmer_bytes, tmp + i * w.kmer_stride + w.kmer_stride - 2, 2);
+        }
+      free(tmp);
+    }
+  res->table = ctx->h_table;
+  return (FK_OK);
+}
+
 // d_smers_in != NULL: start from caller-owned super-mer records (sharded path, after the exchange);
 // the caller's buffer is used as one half of the sort's ping-pong pair and is clobbered.
 // With nbuckets > 1 and reads as input the buckets are processed one after the other ("bucket
@@ -1325,59 +1385,13 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
               if (rc == FK_OK)
                 rc = count_bucket(ctx, p, bc[b], res, false, NULL, &ntab, NULL, &tm, ns_max);
             }
-          if (rc == FK_OK && ntab > 0)
-            { // the union of the buckets' tables, in k-mer order
-              void *tmp = fk_slot(ctx, FK_SLOT_KM_A, ntab * w.kmer_stride);
-              int64_t census[256];
-              if (tmp == NULL) { rc = FK_ENOMEM; break; }
-              hipEventRecord(ctx->ev0, s);
-              table = ctx->slot_ptr[FK_SLOT_TABLE];
-              if ((rc = fkx_sort_table(ctx, ntab, ctx->slot_ptr[FK_SLOT_TABLE], tmp, &table, census)) != FK_OK)
-                break;
-              res->passes_final   = ctx->sort_stats.passes;
-              res->ms_pass_final += ctx->sort_stats.pass_ms_total;
-              for (int x = 0; x < 256; x++)
-                res->wfirst[x] = census[x];
-              hipEventRecord(ctx->ev1, s);
-              hipEventSynchronize(ctx->ev1);
-              tm.radix_k += ms_between(ctx->ev0, ctx->ev1);
-            }
+          if (rc == FK_OK && ntab > 0 && (rc = sort_union_table(ctx, ntab, res, &table, &tm)) != FK_OK)
+            break;
         }
       if (rc != FK_OK)
         break;
-      const int cutoff = ctx->prm.table_cutoff;
-      const int64_t nt = ntab;
-      res->ncollapsed = nt;
-      res->ntable = (cutoff > 0) ? nt : 0;
-      if (cutoff > 0 && nt > 0 && fetch_table)
-        { const int64_t bytes = nt * w.kmer_word;
-          if (ctx->h_table_cap < bytes)
-            { free(ctx->h_table);
-              ctx->h_table = (uint8_t *) malloc((size_t) bytes);
-              ctx->h_table_cap = bytes;
-              if (ctx->h_table == NULL)
-                { ctx->h_table_cap = 0; rc = FK_ENOMEM; break; }
-            }
-          if (w.kmer_word == w.kmer_stride)
-            { if (hipMemcpyAsync(ctx->h_table, table, (size_t) bytes, hipMemcpyDeviceToHost, s)
-                  != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
-                { rc = FK_EHIP; break; }
-            }
-          else
-            { uint8_t *tmp = (uint8_t *) malloc((size_t) nt * w.kmer_stride);
-              if (tmp == NULL) { rc = FK_ENOMEM; break; }
-              if (hipMemcpyAsync(tmp, table, (size_t) nt * w.kmer_stride, hipMemcpyDeviceToHost,
-                                 s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
-                { free(tmp); rc = FK_EHIP; break; }
-              for (int64_t i = 0; i < nt; i++)
-                { memcpy(ctx->h_table + i * w.kmer_word, tmp + i * w.kmer_stride, w.kmer_bytes);
-                  memcpy(ctx->h_table + i * w.kmer_word + w.kmer_bytes,
-                         tmp + i * w.kmer_stride + w.kmer_stride - 2, 2);
-                }
-              free(tmp);
-            }
-          res->table = ctx->h_table;
-        }
+      if ((rc = fetch_result_table(ctx, res, table, ntab, fetch_table)) != FK_OK)
+        break;
       hipEventRecord(ev[2], s);
       if (hipStreamSynchronize(s) != hipSuccess) { rc = FK_EHIP; break; }
       res->ms_split      = ms_between(ev[0], ev[1]);
@@ -1447,6 +1461,51 @@ extern "C" int fk_count_device_supermers(fk_ctx *ctx, void *d_smers, int64_t nsu
   FK_HIP(ctx, hipSetDevice(ctx->device));
   return fkx_pipeline(ctx, NULL, 0, nsuper > 0 ? d_smers : (void *) dummy, nsuper, res,
                       fetch_table != 0);
+}
+
+/* Rounds: the records a rank owns may arrive in several pieces (one per exchange round, so that the
+   exchange of piece i+1 overlaps the counting of piece i).  Every piece must be closed under k-mer
+   identity (whole minimizer buckets).  begin -> add (once per piece; d_smers is clobbered) -> finish:
+   histogram, totals and the table over all pieces, exactly as if they had been counted together. */
+extern "C" int fk_rounds_begin(fk_ctx *ctx)
+{ if (ctx == NULL) return (FK_EINVAL);
+  if (ctx->acc_res == NULL && (ctx->acc_res = (fk_result *) malloc(sizeof(fk_result))) == NULL)
+    return (FK_ENOMEM);
+  memset(ctx->acc_res, 0, sizeof(fk_result));
+  ctx->acc_ntab = 0;
+  ctx->acc_ns = 0;
+  ctx->acc_ns_total = 0;
+  ctx->acc_tm[0] = ctx->acc_tm[1] = ctx->acc_tm[2] = ctx->acc_tm[3] = 0.;
+  return (FK_OK);
+}
+
+extern "C" int fk_rounds_add(fk_ctx *ctx, void *d_smers, int64_t nsuper)
+{ if (ctx == NULL || ctx->acc_res == NULL || nsuper < 0 || (d_smers == NULL && nsuper > 0)) return (FK_EINVAL);
+  FK_HIP(ctx, hipSetDevice(ctx->device));
+  fk_stage_ms tm = { 0., 0., 0., 0. };
+  ctx->acc_res->nsuper += nsuper;
+  int rc = count_bucket(ctx, d_smers, nsuper, ctx->acc_res, false, NULL, &ctx->acc_ntab, NULL, &tm);
+  ctx->acc_tm[0] += tm.group_s; ctx->acc_tm[1] += tm.expand; ctx->acc_tm[2] += tm.radix_k; ctx->acc_tm[3] += tm.aggr;
+  return (rc);
+}
+
+extern "C" int fk_rounds_finish(fk_ctx *ctx, int fetch_table, fk_result *res)
+{ if (ctx == NULL || ctx->acc_res == NULL || res == NULL) return (FK_EINVAL);
+  FK_HIP(ctx, hipSetDevice(ctx->device));
+  *res = *ctx->acc_res;
+  fk_stage_ms tm = { ctx->acc_tm[0], ctx->acc_tm[1], ctx->acc_tm[2], ctx->acc_tm[3] };
+  void *table = NULL;
+  int rc = FK_OK;
+  if (ctx->acc_ntab > 0 && (rc = sort_union_table(ctx, ctx->acc_ntab, res, &table, &tm)) != FK_OK)
+    return (rc);
+  if ((rc = fetch_result_table(ctx, res, table, ctx->acc_ntab, fetch_table != 0)) != FK_OK)
+    return (rc);
+  res->ms_sort_super = tm.group_s;
+  res->ms_expand     = tm.expand;
+  res->ms_sort_kmer  = tm.radix_k;
+  res->ms_count      = tm.aggr;
+  res->ms_total      = tm.group_s + tm.expand + tm.radix_k + tm.aggr;
+  return (FK_OK);
 }
 
 // ---- encodings ----------------------------------------------------------------------------------

@@ -84,6 +84,9 @@ struct fk_ctx
   int64_t    aggr_extra_rounds;   // bins x rounds that had to be split in the last aggregation
   int        num_cus;
   int        aggr_sat;            // > 0: count that makes a k-mer's instances go to max_inst (merge: 0x8000)
+  fk_result *acc_res;          // fk_rounds_*: totals over the pieces added so far
+  int64_t    acc_ntab;
+  double     acc_tm[4];
   int64_t    acc_ns, acc_ns_total;   // bucket streaming: super-mers counted so far / in all buckets
   int64_t    pre_hist_n;       // > 0: d_digit_hist (hash digits 0,1) and the DIG_A stream are valid for
                                // this many records (written by the expansion), see lsd_sort_stream_t

@@ -75,6 +75,17 @@ class HipEngine:
         res[:, kw - 2:] = out[:, stride - 2:]
         return res
 
+    def rounds_begin(self):
+        self.ctx.rounds_begin()
+
+    def rounds_add(self, recs, nsuper):
+        self.ctx.rounds_add(recs.data_ptr() if nsuper else None, nsuper)
+
+    def rounds_finish(self, fetch_table=False):
+        res = self.ctx.rounds_finish(fetch_table=fetch_table)
+        return dict(hist=res.hist, max_inst=res.max_inst, nweighted=res.nweighted,
+                    ndistinct=res.ndistinct, ntable=res.ntable, wfirst=res.wfirst, result=res)
+
     def count_supermers(self, recs, nsuper, fetch_table=False):
         res = self.ctx.count_device_supermers(recs.data_ptr() if nsuper else None, nsuper,
                                               fetch_table=fetch_table)
@@ -219,3 +230,100 @@ def gather_table(table, kmer_bytes, sort_fn, group=None, dst=0):
         parts.append(buf)
     merged = torch.cat(parts).cpu().numpy().reshape(-1, kw)
     return sort_fn(merged) if world > 1 else merged
+
+
+def _post_round(recs, inbox, send_n, recv_n, s_off, stride, group):
+    """Start the exchange of one round: own bucket copied locally, every other pair by point-to-point
+    operations handed to the backend as one batch.  Returns the work handles (wait on them before the
+    inbox is read).  A pair moves at most MAX_PAIR_BYTES per operation."""
+    world = len(send_n)
+    me = dist.get_rank(group)
+    r_off = [0] * world
+    for i in range(1, world):
+        r_off[i] = r_off[i - 1] + recv_n[i - 1]
+    if send_n[me]:
+        inbox[r_off[me] * stride:(r_off[me] + recv_n[me]) * stride].copy_(
+            recs[s_off[me] * stride:(s_off[me] + send_n[me]) * stride])
+    per = max(1, MAX_PAIR_BYTES // stride)
+    ops = []
+    for k in range(1, world):
+        to, frm = (me + k) % world, (me - k) % world
+        gto = dist.get_global_rank(group, to) if group is not None else to
+        gfrm = dist.get_global_rank(group, frm) if group is not None else frm
+        for o in range(0, send_n[to], per):
+            n = min(per, send_n[to] - o)
+            ops.append(dist.P2POp(dist.isend, recs[(s_off[to] + o) * stride:(s_off[to] + o + n) * stride],
+                                  gto, group))
+        for o in range(0, recv_n[frm], per):
+            n = min(per, recv_n[frm] - o)
+            ops.append(dist.P2POp(dist.irecv, inbox[(r_off[frm] + o) * stride:(r_off[frm] + o + n) * stride],
+                                  gfrm, group))
+    return dist.batch_isend_irecv(ops) if ops else []
+
+
+def count_sharded_rounds(engine, reads, rounds, group=None, verify=False, fetch_table=False):
+    """The sharded path with the exchange cut into `rounds` pieces: the engine's context has
+    world * rounds minimizer buckets, bucket r * world + d goes to rank d in round r, and the exchange
+    of round r + 1 runs while round r is being counted (the counting never waits for more than the
+    first piece).  Same result dictionary as count_sharded."""
+    world = dist.get_world_size(group)
+    me = dist.get_rank(group)
+    stride = engine.stride
+    recs, counts, s_off, ninst = engine.split(reads)
+    assert len(counts) == world * rounds, "context must be created with nbuckets == world size * rounds"
+    dev = recs.device
+    # counts[r * world + d]: my records for rank d in round r; every rank learns what it receives
+    send = torch.tensor(counts, dtype=torch.int64, device=dev).view(rounds, world).t().contiguous()
+    recv = torch.empty_like(send)                                   # recv[frm][r]
+    dist.all_to_all_single(recv.view(-1), send.view(-1), group=group)
+    recv = recv.cpu().tolist()
+    send_n = [[int(counts[r * world + d]) for d in range(world)] for r in range(rounds)]
+    send_o = [[int(s_off[r * world + d]) for d in range(world)] for r in range(rounds)]
+    recv_n = [[int(recv[f][r]) for f in range(world)] for r in range(rounds)]
+    most = max(sum(x) for x in recv_n)
+    inbox = [torch.empty(max(most, 1) * stride, dtype=torch.uint8, device=dev) for _ in range(min(2, rounds))]
+    engine.rounds_begin()
+    works = _post_round(recs, inbox[0], send_n[0], recv_n[0], send_o[0], stride, group)
+    nrecv = 0
+    chk_sent = torch.zeros((), dtype=torch.int64, device=dev)
+    chk_recv = torch.zeros((), dtype=torch.int64, device=dev)
+    for r in range(rounds):
+        for w in works:
+            w.wait()
+        box = inbox[r % len(inbox)]
+        n_r = sum(recv_n[r])
+        if verify:
+            chk_recv += box[:n_r * stride].sum(dtype=torch.int64)
+            for d in range(world):
+                chk_sent += recs[send_o[r][d] * stride:(send_o[r][d] + send_n[r][d]) * stride].sum(dtype=torch.int64)
+        if r + 1 < rounds:                       # the next piece travels while this one is counted
+            works = _post_round(recs, inbox[(r + 1) % len(inbox)], send_n[r + 1], recv_n[r + 1],
+                                send_o[r + 1], stride, group)
+        else:
+            works = []
+        engine.rounds_add(box[:n_r * stride], n_r)
+        nrecv += n_r
+    loc = engine.rounds_finish(fetch_table)
+    if verify:
+        chk = torch.stack([chk_sent, chk_recv])
+        dist.all_reduce(chk, op=dist.ReduceOp.SUM, group=group)
+        if int(chk[0].item()) != int(chk[1].item()):
+            raise RuntimeError("super-mer exchange corrupted the payload (checksums differ)")
+    del recs
+
+    tot = torch.zeros(HIST_BINS + 8 + 256, dtype=torch.int64, device=dev)
+    tot[:HIST_BINS] = torch.from_numpy(np.asarray(loc["hist"], dtype=np.int64)).to(dev)
+    extra = [loc["max_inst"], ninst, nrecv, loc["nweighted"], loc["ndistinct"], loc["ntable"],
+             sum(int(c) for c in counts)]
+    tot[HIST_BINS:HIST_BINS + 7] = torch.tensor(extra, dtype=torch.int64, device=dev)
+    if loc.get("wfirst") is not None:
+        tot[HIST_BINS + 8:] = torch.from_numpy(np.asarray(loc["wfirst"], dtype=np.int64)).to(dev)
+    dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=group)
+    t = tot.cpu().numpy()
+    if int(t[HIST_BINS + 2]) != int(t[HIST_BINS + 6]):
+        raise RuntimeError("super-mer exchange lost records: %d sent, %d received"
+                           % (int(t[HIST_BINS + 6]), int(t[HIST_BINS + 2])))
+    return dict(hist=t[:HIST_BINS].copy(), max_inst=int(t[HIST_BINS]), ninst=int(t[HIST_BINS + 1]),
+                nsuper=int(t[HIST_BINS + 2]), nweighted=int(t[HIST_BINS + 3]),
+                ndistinct=int(t[HIST_BINS + 4]), ntable=int(t[HIST_BINS + 5]),
+                wfirst=t[HIST_BINS + 8:].copy(), local=loc)

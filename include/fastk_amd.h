@@ -268,6 +268,14 @@ int fk_merge_tables(fk_ctx *ctx, const uint8_t *records, int64_t n, int64_t max_
 int fk_write_ktab_ex(const fk_result *res, int kmer, int table_cutoff, int nthreads, int idx_bytes,
                      const char *dir, const char *root);
 
+/* The records a rank owns, counted piece by piece (one piece per exchange round of the sharded run,
+   so that the exchange of the next piece overlaps the counting of this one).  A piece must consist of
+   whole minimizer buckets.  fk_rounds_add clobbers d_smers; fk_rounds_finish gives the result over all
+   pieces (what fk_count_device_supermers gives for their union). */
+int fk_rounds_begin(fk_ctx *ctx);
+int fk_rounds_add(fk_ctx *ctx, void *d_smers, int64_t nsuper);
+int fk_rounds_finish(fk_ctx *ctx, int fetch_table, fk_result *res);
+
 /* ---- utilities ---------------------------------------------------------------------------*/
 
 /* Fill d_bases with synthetic reads first_read .. first_read+nreads-1 of include/fk_synth.h,

@@ -17,11 +17,12 @@ class OracleEngine:
     """split / count stages on CPU tensors using the oracle; bucket = f(minimizer of the super-mer)
     so that equal canonical k-mers always land in the same bucket (FastK.h:3-7)."""
 
-    def __init__(self, kmer, world, cutoff):
+    def __init__(self, kmer, world, cutoff, rounds=1):
         self.P = orc.params(kmer)
-        self.world = world
+        self.world = world * rounds            # buckets: bucket r * world + d goes to rank d in round r
         self.cutoff = cutoff
         self.stride = self.P.smer_word
+        self.pieces = None
 
     def _bucket(self, rec):
         P = self.P
@@ -53,6 +54,33 @@ class OracleEngine:
             offs.append(offs[-1] + c)
         return out, counts, offs, ninst
 
+    # the rounds interface of the product engine: pieces are counted one by one and summed; pieces are
+    # whole buckets, so their tables are disjoint
+    def rounds_begin(self):
+        self.pieces = []
+
+    def rounds_add(self, recs, nsuper):
+        self.pieces.append(self.count_supermers(recs.clone(), nsuper) if nsuper else None)
+
+    def rounds_finish(self, fetch_table=False):
+        P = self.P
+        hist = np.zeros(0x8000, dtype=np.int64)
+        mx = nw = nd = nt = 0
+        tabs = []
+        for p in self.pieces:
+            if p is None:
+                continue
+            hist += p["hist"]; mx += p["max_inst"]; nw += p["nweighted"]; nd += p["ndistinct"]; nt += p["ntable"]
+            tabs.append(p["result"].table)
+        table = np.concatenate(tabs) if tabs else np.zeros((0, P.kmer_bytes + 2), dtype=np.uint8)
+        table = table[np.lexsort(table[:, :P.kmer_bytes].T[::-1])] if len(table) else table
+
+        class R:
+            pass
+        res = R()
+        res.table = table
+        return dict(hist=hist, max_inst=mx, nweighted=nw, ndistinct=nd, ntable=nt, result=res)
+
     def count_supermers(self, recs, nsuper):
         P = self.P
         a = recs.numpy().reshape(nsuper, P.smer_word)
@@ -64,7 +92,7 @@ class OracleEngine:
                     ndistinct=res.ndistinct, ntable=res.ntable, result=res)
 
 
-def _worker(rank, world, port, name, q, outdir):
+def _worker(rank, world, port, name, q, outdir, rounds=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -74,8 +102,11 @@ def _worker(rank, world, port, name, q, outdir):
     nreads = len(boff) - 1
     lo, hi = rank * nreads // world, (rank + 1) * nreads // world
     mine = torch.from_numpy(bases[boff[lo]:boff[hi]].copy())
-    eng = OracleEngine(case["k"], world, case["cutoff"])
-    out = shard.count_sharded(eng, mine, verify=True)
+    eng = OracleEngine(case["k"], world, case["cutoff"], rounds)
+    if rounds == 1:
+        out = shard.count_sharded(eng, mine, verify=True)
+    else:
+        out = shard.count_sharded_rounds(eng, mine, rounds, verify=True)
     P = orc.params(case["k"])
 
     def cpu_sort(recs):
@@ -91,13 +122,14 @@ def _worker(rank, world, port, name, q, outdir):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("rounds", [1, 3])
 @pytest.mark.parametrize("name", ["synth_tiny_k40_t1_T2", "edge_k21_t2_T3"])
-def test_two_rank_shard_matches_golden(name, tmp_path):
+def test_two_rank_shard_matches_golden(name, rounds, tmp_path):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + (os.getpid() % 1000)
-    procs = [ctx.Process(target=_worker, args=(r, world, port, name, q, str(tmp_path)))
+    procs = [ctx.Process(target=_worker, args=(r, world, port, name, q, str(tmp_path), rounds))
              for r in range(world)]
     for p in procs:
         p.start()
