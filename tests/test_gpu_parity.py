@@ -538,6 +538,19 @@ def test_pipeline_four_pass_supermer_path_matches_golden(name):
         util.check_against_golden(case, res.hist, res.max_inst, res.table)
 
 
+@pytest.mark.parametrize("nb", [1, 3])
+def test_histogram_only_run(nb):
+    """No -t: no table is requested, the k-mer stage ends with the aggregation (no table sort)."""
+    case, bases, boff = util.load_case("synth_illumina_k40_t1_T4")
+    exp = orc.fastk(40, bases, boff, cutoff=1)
+    with fastk_amd.Context(kmer=40, table_cutoff=0, nbuckets=nb) as ctx:
+        ctx.push_block(bases, boff.astype(np.int32))
+        res = ctx.finish()
+        assert res.ntable == 0 and len(res.table) == 0
+        assert np.array_equal(res.hist, exp.hist) and res.max_inst == exp.max_inst
+        assert res.ndistinct == exp.ndistinct and res.ninst == exp.ninst
+
+
 def test_empty_and_degenerate_inputs():
     with fastk_amd.Context(kmer=40, table_cutoff=1) as ctx:
         res = ctx.finish()
