@@ -24,6 +24,7 @@ EXPORTS = [
     "fk_train_block", "fk_count_unsorted_kmers", "fk_debug_get", "fk_push_fastq", "fk_host_alloc",
     "fk_host_free", "fk_bucket_census", "fk_set_bucket_weights", "fk_push_fasta", "fk_merge_tables",
     "fk_write_ktab_ex", "fk_rounds_begin", "fk_rounds_add", "fk_rounds_finish",
+    "fk_make_profiles", "fk_write_prof",
 ]
 
 
@@ -54,6 +55,11 @@ class CResult(C.Structure):
                 ("ms_pass_super", C.c_double), ("ms_pass_kmer", C.c_double),
                 ("ms_scatter_super", C.c_double), ("ms_scatter_kmer", C.c_double),
                 ("ncollapsed", C.c_int64), ("passes_final", C.c_int), ("ms_pass_final", C.c_double)]
+
+
+class CProfiles(C.Structure):
+    _fields_ = [("nreads", C.c_int64), ("nbytes", C.c_int64), ("data", C.POINTER(C.c_uint8)),
+                ("offsets", C.POINTER(C.c_int64))]
 
 
 class SortStats(C.Structure):
@@ -118,6 +124,8 @@ def load_library():
     L.fk_push_fastq.argtypes = [vp, vp, i64, C.c_int, C.POINTER(C.c_int), C.POINTER(i64), C.POINTER(i64)]
     L.fk_push_fasta.argtypes = [vp, vp, i64, C.c_int, C.POINTER(C.c_int), C.POINTER(i64), C.POINTER(i64)]
     L.fk_merge_tables.argtypes = [vp, vp, i64, i64, C.POINTER(CResult)]
+    L.fk_make_profiles.argtypes = [vp, vp, i64, C.POINTER(CProfiles)]
+    L.fk_write_prof.argtypes = [C.POINTER(CProfiles), ci, ci, C.c_char_p, C.c_char_p]
     L.fk_rounds_begin.argtypes = [vp]
     L.fk_rounds_add.argtypes = [vp, vp, i64]
     L.fk_rounds_finish.argtypes = [vp, C.c_int, C.POINTER(CResult)]
@@ -283,6 +291,20 @@ class Context:
         r = CResult()
         self._ck(self.L.fk_rounds_finish(self.h, 1 if fetch_table else 0, C.byref(r)))
         return Result(r, self.w.kmer_word)
+
+    def make_profiles(self, ptr=None, nbytes=0, outdir=None, root=None, nparts=1):
+        """Profiles of the reads just counted (cutoff 1, resident run): returns (data, offsets) as
+        numpy copies; with outdir/root also writes <root>.prof + hidden parts."""
+        pr = CProfiles()
+        self._ck(self.L.fk_make_profiles(self.h, ptr, nbytes, C.byref(pr)))
+        n = pr.nreads
+        offs = np.ctypeslib.as_array(pr.offsets, shape=(n + 1,)).copy() if n >= 0 and pr.offsets \
+            else np.zeros(1, dtype=np.int64)
+        data = np.ctypeslib.as_array(pr.data, shape=(pr.nbytes,)).copy() if pr.nbytes > 0 \
+            else np.zeros(0, dtype=np.uint8)
+        if outdir is not None:
+            self._ck(self.L.fk_write_prof(C.byref(pr), self.w.kmer, nparts, outdir.encode(), root.encode()))
+        return data, offs
 
     def merge_tables(self, records, max_inst_in=0):
         """records: (n, KMER_WORD) uint8 entries of all input tables; returns the merged Result."""

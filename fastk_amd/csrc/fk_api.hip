@@ -265,6 +265,8 @@ extern "C" void fk_destroy(fk_ctx *ctx)
   if (ctx->h_scratch) hipHostFree(ctx->h_scratch);
   hipFree(ctx->d_digit_hist); hipFree(ctx->d_status); hipFree(ctx->d_ticket);
   hipFree(ctx->d_reads);
+  free(ctx->h_prof);
+  free(ctx->h_prof_off);
   for (int i = 0; i < FK_NSLOTS; i++)
     if (ctx->slot_ptr[i] != NULL)
       hipFree(ctx->slot_ptr[i]);
@@ -1392,6 +1394,10 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
         break;
       if ((rc = fetch_result_table(ctx, res, table, ntab, fetch_table)) != FK_OK)
         break;
+      // fk_make_profiles looks k-mers up in this table: it has to hold every k-mer of resident reads
+      ctx->have_table = (!chunked && d_smers_in == NULL && ctx->prm.table_cutoff == 1);
+      ctx->last_table = table;
+      ctx->last_ntab  = ntab;
       hipEventRecord(ev[2], s);
       if (hipStreamSynchronize(s) != hipSuccess) { rc = FK_EHIP; break; }
       res->ms_split      = ms_between(ev[0], ev[1]);
@@ -1521,6 +1527,103 @@ static int write_all(int fd, const void *p, size_t n)
 
 // .hist: int k; int 1; int 0x7fff; int64 hist[1]; int64 max_inst; int64 hist[1..0x7fff]
 // (count.c:1893-1910, README.md:936-961)
+// ---- profiles (-p) ---------------------------------------------------------------------------
+
+extern "C" int fk_make_profiles(fk_ctx *ctx, const void *d_bases, int64_t nbytes, fk_profiles *out)
+{ if (ctx == NULL || out == NULL || nbytes < 0) return (FK_EINVAL);
+  memset(out, 0, sizeof(*out));
+  FK_HIP(ctx, hipSetDevice(ctx->device));
+  if (!ctx->have_table)
+    { fk_set_error(ctx, "fk_make_profiles: needs the table of a finished resident run with table_cutoff 1");
+      return (FK_ESTATE);
+    }
+  if (ctx->prm.bc_prefix > 0)
+    { fk_set_error(ctx, "fk_make_profiles: not available together with bc_prefix");
+      return (FK_EUNSUPPORTED);
+    }
+  if (d_bases == NULL)
+    { d_bases = ctx->d_reads;
+      nbytes  = ctx->reads_len;
+    }
+  int64_t nreads = 0, nprof = 0;
+  void *d_data = NULL;
+  uint64_t *d_offs = NULL;
+  int rc = fkx_profiles(ctx, d_bases, nbytes, ctx->last_table, ctx->last_ntab, &nreads, &nprof, &d_data, &d_offs);
+  if (rc != FK_OK)
+    return (rc);
+  if (ctx->h_prof_cap < nprof + 1)
+    { free(ctx->h_prof);
+      ctx->h_prof = (uint8_t *) malloc((size_t) nprof + 1);
+      ctx->h_prof_cap = nprof + 1;
+      if (ctx->h_prof == NULL) { ctx->h_prof_cap = 0; return (FK_ENOMEM); }
+    }
+  if (ctx->h_prof_off_cap < nreads + 1)
+    { free(ctx->h_prof_off);
+      ctx->h_prof_off = (int64_t *) malloc(sizeof(int64_t) * (size_t) (nreads + 1));
+      ctx->h_prof_off_cap = nreads + 1;
+      if (ctx->h_prof_off == NULL) { ctx->h_prof_off_cap = 0; return (FK_ENOMEM); }
+    }
+  ctx->h_prof_off[0] = 0;
+  if (nreads > 0)
+    { if (nprof > 0)
+        FK_HIP(ctx, hipMemcpyAsync(ctx->h_prof, d_data, (size_t) nprof, hipMemcpyDeviceToHost, ctx->stream));
+      FK_HIP(ctx, hipMemcpyAsync(ctx->h_prof_off, d_offs, (size_t) (nreads + 1) * 8, hipMemcpyDeviceToHost,
+                                 ctx->stream));
+      FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+  out->nreads  = nreads;
+  out->nbytes  = nprof;
+  out->data    = ctx->h_prof;
+  out->offsets = ctx->h_prof_off;
+  return (FK_OK);
+}
+
+// <root>.prof stub + hidden .<root>.pidx.N / .<root>.prof.N (README "K-mer Profile Files"); part t
+// holds reads [t nreads / nparts, (t+1) nreads / nparts)
+extern "C" int fk_write_prof(const fk_profiles *p, int kmer, int nparts, const char *dir, const char *root)
+{ if (p == NULL || dir == NULL || root == NULL || nparts < 1 || (p->nreads > 0 && p->offsets == NULL))
+    return (FK_EINVAL);
+  char path[4096];
+  snprintf(path, sizeof(path), "%s/%s.prof", dir, root);
+  int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+  if (fd < 0)
+    { fk_set_error(NULL, "Cannot open %s for writing", path);
+      return (FK_EINVAL);
+    }
+  int32_t stub[2] = { kmer, nparts };
+  int bad = write_all(fd, stub, 8);
+  close(fd);
+  for (int t = 0; t < nparts && !bad; t++)
+    { const int64_t r0 = p->nreads * t / nparts, r1 = p->nreads * (t + 1) / nparts;
+      const int64_t n = r1 - r0;
+      const int64_t b0 = (n > 0) ? p->offsets[r0] : 0;
+      snprintf(path, sizeof(path), "%s/.%s.pidx.%d", dir, root, t + 1);
+      fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+      if (fd < 0) { bad = 1; break; }
+      int32_t k32 = kmer;
+      bad |= write_all(fd, &k32, 4) | write_all(fd, &r0, 8) | write_all(fd, &n, 8);
+      int64_t buf[4096];
+      for (int64_t i = 0; i < n && !bad; i += 4096)
+        { const int64_t m = (n - i < 4096) ? n - i : 4096;
+          for (int64_t j = 0; j < m; j++)
+            buf[j] = p->offsets[r0 + i + j + 1] - b0;
+          bad |= write_all(fd, buf, (size_t) m * 8);
+        }
+      close(fd);
+      snprintf(path, sizeof(path), "%s/.%s.prof.%d", dir, root, t + 1);
+      fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+      if (fd < 0) { bad = 1; break; }
+      if (n > 0 && p->offsets[r1] > b0)
+        bad |= write_all(fd, p->data + b0, (size_t) (p->offsets[r1] - b0));
+      close(fd);
+    }
+  if (bad)
+    { fk_set_error(NULL, "Cannot write profile files %s/%s.prof.  Enough disk space?", dir, root);
+      return (FK_EINVAL);
+    }
+  return (FK_OK);
+}
+
 extern "C" int fk_write_hist(const fk_result *res, int kmer, const char *path)
 { if (res == NULL || path == NULL) return (FK_EINVAL);
   int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);

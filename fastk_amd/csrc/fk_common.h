@@ -14,7 +14,7 @@
 typedef unsigned long long u64;
 typedef unsigned int       u32;
 
-#define FK_NSLOTS 32
+#define FK_NSLOTS 40
 
 struct fk_chunk
 { void    *ptr;             // records of bucket 0, 1, ... back to back
@@ -55,6 +55,12 @@ struct fk_ctx
   hipEvent_t stage_ev[2];
   uint8_t   *h_table;      // result table (host)
   int64_t    h_table_cap;
+  void      *last_table;   // sorted table of the last resident run (HBM), for fk_make_profiles
+  int64_t    last_ntab;
+  bool       have_table;
+  uint8_t   *h_prof;       // profiles of fk_make_profiles (host)
+  int64_t   *h_prof_off;
+  int64_t    h_prof_cap, h_prof_off_cap;
   void      *push_lock;    // pthread mutex
   int64_t   *h_roff;       // exact_parts: byte offset of every pushed read (+ end), host
   int64_t    nroff, roff_cap;
@@ -99,7 +105,8 @@ enum { FK_SLOT_SM_A = 0, FK_SLOT_SM_B, FK_SLOT_KM_A, FK_SLOT_KM_B, FK_SLOT_EX_HE
        FK_SLOT_EX_KOFF, FK_SLOT_CT_ENT, FK_SLOT_CT_OFF, FK_SLOT_CT_HIST, FK_SLOT_DIG_A, FK_SLOT_DIG_B,
        FK_SLOT_RX_TILE, FK_SLOT_RX_CHUNK, FK_SLOT_RX_SUPER, FK_SLOT_ROFF, FK_SLOT_AG_BOUNDS, FK_SLOT_TABLE, FK_SLOT_SM_G,
        FK_SLOT_RAW, FK_SLOT_FQ_INFO, FK_SLOT_FQ_PHASE, FK_SLOT_FQ_OFF, FK_SLOT_TIE_A, FK_SLOT_TIE_B,
-       FK_SLOT_TIE_POS, FK_SLOT_SM_D };
+       FK_SLOT_TIE_POS, FK_SLOT_SM_D, FK_SLOT_PF_IDX, FK_SLOT_PF_CNT, FK_SLOT_PF_ZC, FK_SLOT_PF_ZO,
+       FK_SLOT_PF_ENDS, FK_SLOT_PF_LEN, FK_SLOT_PF_OFF, FK_SLOT_PF_OUT };
 
 // returns a device buffer of at least nbytes for the given purpose (NULL + error set on failure)
 void *fk_slot(fk_ctx *ctx, int slot, int64_t nbytes);
@@ -150,6 +157,8 @@ int fkx_parse_fasta(fk_ctx *ctx, const void *d_raw, int64_t nbytes, int state, v
                     int64_t *nkept, int64_t *nrecs);
 int fkx_dedup_supermers(fk_ctx *ctx, const void *d_grouped, int64_t n, void *d_out, int64_t cap, int64_t *nout);
 int fkx_sort_table(fk_ctx *ctx, int64_t n, void *d_tab, void *d_tmp, void **result, int64_t *wfirst);
+int fkx_profiles(fk_ctx *ctx, const void *d_bases, int64_t nbytes, const void *d_table, int64_t nt,
+                 int64_t *nreads_out, int64_t *nprof_out, void **d_data, uint64_t **d_offs);
 int fkx_synth(fk_ctx *ctx, uint64_t seed, uint64_t genome_len, uint32_t read_len,
               uint32_t err_ppm, uint64_t first_read, int64_t nreads, void *d_bases);
 

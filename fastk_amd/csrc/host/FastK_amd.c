@@ -48,7 +48,7 @@ static double now(void)
 }
 
 static int       KMER = 40, NTHREADS = 4, DO_TABLE = 0, BC_PREFIX = 0, VERBOSE = 0, EXACT = 0, MEM_GB = 0;
-static int       HOST_PARSE = 0, COMPRESS = 0;
+static int       HOST_PARSE = 0, COMPRESS = 0, PROFILE = 0;
 static char     *OUT_NAME = NULL;
 
 typedef struct
@@ -235,8 +235,13 @@ int main(int argc, char *argv[])
         case 'P': break;
         case 'c': COMPRESS = 1; break;
         case 'p':
-          fprintf(stderr,"%s: option %s is not built in this engine yet (see DESIGN.md)\n",Prog_Name,argv[i]);
-          exit (1);
+          if (argv[i][2] != '\0')
+            { fprintf(stderr,"%s: option %s (profiles relative to another table) is not built in this engine\n",
+                      Prog_Name,argv[i]);
+              exit (1);
+            }
+          PROFILE = 1;
+          break;
         default:
           fprintf(stderr,"\n%s: %s is not a legal optional argument\n",Prog_Name,argv[i]);
           exit (1);
@@ -245,16 +250,24 @@ int main(int argc, char *argv[])
       argv[j++] = argv[i];
   nfiles = j-1;
   if (nfiles < 1 || KMER <= 0 || NTHREADS <= 0 || DO_TABLE < 0 || BC_PREFIX < 0)
-    { fprintf(stderr,"\nUsage: %s [-k<int(40)>] [-t[<int(1)>]] [-bc<int>] [-v] [-x] [-N<path_name>]\n",Prog_Name);
+    { fprintf(stderr,"\nUsage: %s [-k<int(40)>] [-t[<int(1)>]] [-p] [-c] [-bc<int>] [-v] [-x] [-N<path_name>]\n",Prog_Name);
       fprintf(stderr,"       %*s [-P<dir>] [-M<int>] [-T<int(4)>] <source>[.fa|.fasta|.fq|.fastq][.gz] ...\n",
               (int) strlen(Prog_Name),"");
       exit (1);
     }
 
+  if (PROFILE && (MEM_GB > 0 || BC_PREFIX > 0))
+    { fprintf(stderr,"%s: -p needs the reads resident in HBM and whole: not available with -M or -bc\n",Prog_Name);
+      exit (1);
+    }
+  if (PROFILE)
+    HOST_PARSE = 1;      /* the host scanner hands over reads exactly as the reference numbers them */
+
   double t_start = now(), t_ingest, t_count, t_write;
 
   fk_default_params(&prm);
-  prm.kmer = KMER; prm.table_cutoff = DO_TABLE; prm.nthreads = NTHREADS; prm.bc_prefix = BC_PREFIX;
+  prm.kmer = KMER; prm.table_cutoff = PROFILE ? 1 : DO_TABLE;   /* -p looks every k-mer up */
+  prm.nthreads = NTHREADS; prm.bc_prefix = BC_PREFIX;
   prm.exact_parts = EXACT;
   if (MEM_GB > 0 && !EXACT)
     { /* bases ~ file bytes (FASTA), half of them (FASTQ), x4 when gzipped; the super-mers (~1 byte
@@ -332,6 +345,35 @@ int main(int argc, char *argv[])
   if (fk_finish(ctx,res) != FK_OK)
     die(ctx,"fk_finish");
   t_count = now();
+
+  if (PROFILE)
+    { fk_profiles pr;
+      double t0 = now();
+      if (fk_make_profiles(ctx,NULL,0,&pr) != FK_OK)
+        die(ctx,"fk_make_profiles");
+      if (fk_write_prof(&pr,KMER,NTHREADS,dir,root) != FK_OK)
+        die(ctx,"writing .prof");
+      if (VERBOSE)
+        fprintf(stderr,"  Profiles of %lld reads in %lld bytes (%.3f s)\n",(long long) pr.nreads,
+                (long long) pr.nbytes,now()-t0);
+      if (DO_TABLE > 1)                   /* the table was built with cutoff 1: keep count >= -t */
+        { const int kw = ((2*KMER+7)>>3) + 2;
+          const uint8_t *t = res->table;
+          uint8_t *keep;
+          int64_t  n = 0, x;
+          for (x = 0; x < res->ntable; x++)
+            if ((t[x*kw+kw-2] | (t[x*kw+kw-1] << 8)) >= DO_TABLE)
+              n += 1;
+          keep = malloc((size_t) (n > 0 ? n : 1)*kw);
+          if (keep == NULL)
+            { fprintf(stderr,"%s: Out of memory\n",Prog_Name); exit (1); }
+          for (n = x = 0; x < res->ntable; x++)
+            if ((t[x*kw+kw-2] | (t[x*kw+kw-1] << 8)) >= DO_TABLE)
+              memcpy(keep+(n++)*kw,t+x*kw,(size_t) kw);
+          res->table  = keep;             /* freed at exit */
+          res->ntable = n;
+        }
+    }
 
   if (VERBOSE)
     { fprintf(stderr,"\n  There are %lld reads totalling %lld bps\n",(long long) feed.totrds,(long long) feed.totbps);

@@ -268,6 +268,32 @@ int fk_merge_tables(fk_ctx *ctx, const uint8_t *records, int64_t n, int64_t max_
 int fk_write_ktab_ex(const fk_result *res, int kmer, int table_cutoff, int nthreads, int idx_bytes,
                      const char *dir, const char *root);
 
+/* ---- read profiles (FastK -p) --------------------------------------------------------------
+ * Replaces the profile output of the reference's counting pass (count.c:868-947, the per-super-mer
+ * fragments) and their stitching into read order (merge.c, Merge_Profiles): for every read, in input
+ * order, the counts of its k-mers (0 where the k-mer contains a non-acgt base, capped at 32767),
+ * compressed with the codec of README.md:1029-1069.  The bytes are the canonical
+ * one-byte-form-whenever-possible stream; they decode (libfastk.c:1657, Fetch_Profile) to the same
+ * counts as the reference's files, whose zero-run splits follow its internal super-mer cuts.
+ *
+ * fk_make_profiles runs after fk_finish / fk_count_device_reads of a resident run (hbm_budget 0)
+ * with table_cutoff 1 -- the table left in HBM is the dictionary.  d_bases NULL: the reads pushed
+ * into the context; otherwise the caller-owned buffer that was just counted.  Reads end at 0 bytes
+ * (a last read without one ends at nbytes); other non-acgt bytes stay inside their read.
+ * data / offsets are host memory owned by ctx, valid until the next call or fk_destroy. */
+typedef struct
+  { int64_t        nreads;
+    int64_t        nbytes;     /* total compressed bytes                                   */
+    const uint8_t *data;       /* profile of read i = data[offsets[i] .. offsets[i+1])     */
+    const int64_t *offsets;    /* nreads + 1 entries, offsets[0] = 0                       */
+  } fk_profiles;
+
+int fk_make_profiles(fk_ctx *ctx, const void *d_bases, int64_t nbytes, fk_profiles *out);
+
+/* <dir>/<root>.prof stub + hidden .<root>.pidx.N / .<root>.prof.N, N = 1..nparts (README.md:1010-1027);
+   the reads are divided evenly over the parts in input order. */
+int fk_write_prof(const fk_profiles *p, int kmer, int nparts, const char *dir, const char *root);
+
 /* The records a rank owns, counted piece by piece (one piece per exchange round of the sharded run,
    so that the exchange of the next piece overlaps the counting of this one).  A piece must consist of
    whole minimizer buckets.  fk_rounds_add clobbers d_smers; fk_rounds_finish gives the result over all

@@ -389,3 +389,139 @@ def run_ref_fastk(fastx_path, kmer, cutoff, nthreads, workdir, extra=()):
     cmd += list(extra) + [fastx_path]
     subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                    cwd=workdir)
+
+
+# --------------------------------------------------------------------------- profiles (-p)
+# Restatement of what a profile IS (README.md:1010-1069): per read, the count of every k-mer in
+# read order, 0 where the k-mer holds a non-acgt base, counts capped at 32767 -- computed here from
+# the oracle's cutoff-1 table.  The reference assembles the same numbers from per-super-mer
+# fragments (count.c:868-947) that merge.c stitches into read order; its byte stream splits zero
+# runs at those fragment boundaries (and writes d = -31 in two bytes), so parity with the
+# reference is on the DECODED counts (libfastk.c:1657 Fetch_Profile is the decoder restated below).
+
+_CODE = np.full(256, 4, dtype=np.uint8)
+for _i, _c in enumerate("acgt"):
+    _CODE[ord(_c)] = _i
+    _CODE[ord(_c.upper())] = _i
+
+
+def profile_counts(kmer, bases, boff, table):
+    """table: (n, KMER_BYTES+2) uint8 sorted, cutoff 1.  Returns a list of uint16 arrays, one per read."""
+    kb = (kmer + 3) // 4
+    keys = np.ascontiguousarray(table[:, :kb]).view("S%d" % kb).reshape(-1) if len(table) else \
+        np.zeros(0, dtype="S%d" % kb)
+    cnts = (table[:, kb].astype(np.uint16) | (table[:, kb + 1].astype(np.uint16) << 8)) if len(table) \
+        else np.zeros(0, dtype=np.uint16)
+    wts = np.array([64, 16, 4, 1], dtype=np.uint8)
+    out = []
+    for r in range(len(boff) - 1):
+        s = bases[boff[r]:boff[r + 1] - 1]
+        n = len(s) - kmer + 1
+        if n <= 0:
+            out.append(np.zeros(0, dtype=np.uint16))
+            continue
+        code = _CODE[s]
+        win = np.lib.stride_tricks.sliding_window_view(code, kmer)            # (n, k)
+        ok = (win < 4).all(axis=1)
+        f = np.zeros((n, kb * 4), dtype=np.uint8)
+        f[:, :kmer] = win & 3
+        g = np.zeros((n, kb * 4), dtype=np.uint8)
+        g[:, :kmer] = 3 - (win[:, ::-1] & 3)
+        fb = (f.reshape(n, kb, 4) * wts).sum(axis=2).astype(np.uint8)
+        gb = (g.reshape(n, kb, 4) * wts).sum(axis=2).astype(np.uint8)
+        diff = fb != gb
+        first = diff.argmax(axis=1)
+        rows = np.arange(n)
+        use_rc = diff.any(axis=1) & (gb[rows, first] < fb[rows, first])
+        canon = np.where(use_rc[:, None], gb, fb)
+        q = np.ascontiguousarray(canon).view("S%d" % kb).reshape(-1)
+        pos = np.searchsorted(keys, q)
+        pos = np.minimum(pos, max(len(keys) - 1, 0))
+        hit = (keys[pos] == q) if len(keys) else np.zeros(n, dtype=bool)
+        c = np.where(hit & ok, cnts[pos] if len(keys) else 0, 0).astype(np.uint16)
+        out.append(c)
+    return out
+
+
+def profile_encode(counts):
+    """Canonical stream of README.md:1029-1069: one-byte forms whenever possible, runs up to 63."""
+    if len(counts) == 0:
+        return b""
+    o = bytearray()
+    p = int(counts[0])
+    if p < 128:
+        o.append(p)
+    else:
+        o += bytes([0x80 | (p >> 8), p & 0xff])
+    run = 0
+    for c in counts[1:]:
+        c = int(c)
+        if c == p:
+            run += 1
+            if run == 63:
+                o.append(63)
+                run = 0
+            continue
+        if run:
+            o.append(run)
+            run = 0
+        d = c - p
+        if -32 < d < 32:
+            o.append(0x40 | (d & 0x3f))
+        else:
+            d &= 0x7fff
+            o += bytes([0x80 | (d >> 8), d & 0xff])
+        p = c
+    if run:
+        o.append(run)
+    return bytes(o)
+
+
+def profile_decode(b):
+    """Fetch_Profile, libfastk.c:1657-1780."""
+    if len(b) == 0:
+        return []
+    if b[0] & 0x80:
+        c = ((b[0] & 0x7f) << 8) | b[1]
+        i = 2
+    else:
+        c = b[0]
+        i = 1
+    res = [c]
+    while i < len(b):
+        x = b[i]
+        if x & 0x80:
+            d = ((x & 0x7f) << 8) | b[i + 1]
+            i += 2
+            c = (c + d) & 0x7fff
+            res.append(c)
+        elif x & 0x40:
+            d = x & 0x3f
+            if d & 0x20:
+                d -= 0x40
+            c = (c + d) & 0xffff
+            res.append(c)
+            i += 1
+        else:
+            res.extend([c] * x)
+            i += 1
+    return res
+
+
+def read_profiles(outdir, root):
+    """<root>.prof stub + hidden parts -> (kmer, list of per-read encoded byte strings)."""
+    kmer, nparts = struct.unpack("<ii", open(os.path.join(outdir, root + ".prof"), "rb").read(8))
+    out = []
+    for t in range(1, nparts + 1):
+        px = open(os.path.join(outdir, ".%s.pidx.%d" % (root, t)), "rb").read()
+        k2, = struct.unpack("<i", px[:4])
+        b, n = struct.unpack("<qq", px[4:20])
+        assert k2 == kmer and b == len(out)
+        offs = np.frombuffer(px[20:20 + 8 * n], dtype=np.int64)
+        data = open(os.path.join(outdir, ".%s.prof.%d" % (root, t)), "rb").read()
+        assert n == 0 or offs[-1] == len(data)
+        prev = 0
+        for o in offs:
+            out.append(data[prev:int(o)])
+            prev = int(o)
+    return kmer, out

@@ -906,3 +906,133 @@ def test_full_size_properties_configs1():
     assert np.all((hi[1:] > hi[:-1]) | ((hi[1:] == hi[:-1]) & (lo[1:] > lo[:-1])))
     cnt = t[:, 10:12].copy().view("<u2").ravel()
     assert np.array_equal(np.bincount(cnt, minlength=0x8000)[1:], a.hist[1:])
+
+
+# ------------------------------------------------------------------------------ profiles (-p)
+
+def _check_profiles(k, bases, boff, data, offs, table=None):
+    if table is None:
+        table = orc.fastk(k, bases, boff, cutoff=1).table
+    exp = orc.profile_counts(k, bases, boff, table)
+    assert len(offs) == len(exp) + 1 and offs[0] == 0 and offs[-1] == len(data)
+    raw = data.tobytes()
+    for i, x in enumerate(exp):
+        got = raw[offs[i]:offs[i + 1]]
+        assert got == orc.profile_encode(x), "read %d" % i
+    return exp
+
+
+@pytest.mark.parametrize("nb", [1, 4])
+@pytest.mark.parametrize("name", ["synth_tiny_k40_t1_T2", "edge_k40_t1_T4", "edge_k51_t1_T4",
+                                  "synth_illumina_k40_t1_T4"])
+def test_profiles_match_oracle_and_reference(name, nb, tmp_path):
+    """Profiles from the device (table lookup per position + codec) are the oracle's canonical streams,
+    decode to what the reference's own -p files decode to, and the reference's Profex lists the files
+    written by fk_write_prof exactly like its own."""
+    import os
+    import subprocess
+    case, bases, boff = util.load_case(name)
+    k = case["k"]
+    d = str(tmp_path)
+    with fastk_amd.Context(kmer=k, table_cutoff=1, nthreads=case["T"], nbuckets=nb) as ctx:
+        nreads = len(boff) - 1
+        step = max(1, nreads // 3)
+        for s in range(0, nreads, step):
+            e = min(nreads, s + step)
+            ctx.push_block(bases[boff[s]:boff[e]], (boff[s:e + 1] - boff[s]).astype(np.int32))
+        res = ctx.finish()
+        data, offs = ctx.make_profiles(outdir=d, root="x", nparts=case["T"])
+    exp = _check_profiles(k, bases, boff, data, offs, res.table)
+    if not orc.have_ref() or nb != 1:
+        return
+    rd = os.path.join(d, "ref")
+    os.mkdir(rd)
+    path = os.path.join(rd, "x.fastq")
+    orc.write_fastq(path, bases, boff)
+    orc.run_ref_fastk(path, k, 1, case["T"], rd, extra=("-p",))
+    kk, enc = orc.read_profiles(rd, "x")
+    assert kk == k and len(enc) == len(exp)
+    for e, x in zip(enc, exp):
+        assert orc.profile_decode(e) == x.tolist()
+    profex = os.path.join(orc.REF_DIR, "Profex")
+    if os.path.exists(profex):
+        a = subprocess.run([profex, os.path.join(d, "x"), "1-#"], check=True, capture_output=True).stdout
+        b = subprocess.run([profex, os.path.join(rd, "x"), "1-#"], check=True, capture_output=True).stdout
+        assert a == b and len(a) > 0
+
+
+@pytest.mark.parametrize("k", [12, 16, 17, 31, 32, 33, 48, 63, 64])
+def test_profiles_across_k(k):
+    rng = np.random.default_rng(100 + k)
+    genome = rng.integers(0, 4, size=20000)
+    reads = []
+    for _ in range(800):
+        s0 = int(rng.integers(0, len(genome) - 400))
+        r = genome[s0:s0 + int(rng.integers(max(1, k - 3), 400))].copy()
+        if rng.random() < 0.5:
+            r = (3 - r)[::-1]
+        if rng.random() < 0.3 and len(r) > 5:
+            r[int(rng.integers(0, len(r)))] = 4
+        reads.append("".join("acgtn"[x] for x in r))
+    reads += ["", "a" * 300, "acgt" * 60, "n" * 50, "ac" * 90] * 3
+    reads += ["a" * 9000]                                           # a run > 63 many times over
+    bases, boff = orc.block_from_reads(reads)
+    with fastk_amd.Context(kmer=k, table_cutoff=1) as ctx:
+        ctx.push_block(bases, boff.astype(np.int32))
+        ctx.finish()
+        data, offs = ctx.make_profiles()
+    _check_profiles(k, bases, boff, data, offs)
+
+
+def test_profiles_saturated_counts_and_call_order():
+    k = 40
+    rng = np.random.default_rng(9)
+    unit = "".join("acgt"[x] for x in rng.integers(0, 4, size=60))
+    reads = [unit] * 40000 + ["".join("acgt"[x] for x in rng.integers(0, 4, size=100)) for _ in range(50)]
+    bases, boff = orc.block_from_reads(reads)
+    with fastk_amd.Context(kmer=k, table_cutoff=1) as ctx:
+        with pytest.raises(fastk_amd.FastKError):
+            ctx.make_profiles()                                     # nothing counted yet
+        ctx.push_block(bases, boff.astype(np.int32))
+        ctx.finish()
+        data, offs = ctx.make_profiles()
+    exp = _check_profiles(k, bases, boff, data, offs)
+    assert int(exp[0][0]) == 32767                                  # capped like the table's counts
+    with fastk_amd.Context(kmer=k, table_cutoff=2) as ctx:
+        ctx.push_block(bases, boff.astype(np.int32))
+        ctx.finish()
+        with pytest.raises(fastk_amd.FastKError):
+            ctx.make_profiles()                                     # needs the cutoff-1 table
+
+
+@pytest.mark.parametrize("name,fmt", [("edge_k40_t4_T1", "fasta"), ("synth_hifi_k40_t4_T8", "fastq")])
+def test_cli_profiles_option(name, fmt, tmp_path):
+    """FastK_amd -p -t<n>: profiles decode to the reference's, the .hist and the cutoff-n table are the
+    usual ones (the engine counts with cutoff 1 for the look-ups and filters on the way out)."""
+    import hashlib, os, subprocess
+    case, bases, boff = util.load_case(name)
+    k = case["k"]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "fastk_amd", "bin", "FastK_amd")
+    path = str(tmp_path / ("reads." + fmt))
+    (orc.write_fasta if fmt == "fasta" else orc.write_fastq)(path, bases, boff)
+    subprocess.run([exe, "-k%d" % k, "-t%d" % case["cutoff"], "-T%d" % case["T"], "-p", "-v", path],
+                   check=True, cwd=str(tmp_path))
+    exp = case["expected"]
+    assert hashlib.sha256(open(tmp_path / "reads.hist", "rb").read()).hexdigest() == exp["hist_sha256"]
+    t = orc.read_ktab(str(tmp_path / "reads"))
+    assert t["stream_sha256"] == exp["ktab"]["stream_sha256"] and t["minval"] == case["cutoff"]
+    kk, enc = orc.read_profiles(str(tmp_path), "reads")
+    table = orc.fastk(k, bases, boff, cutoff=1).table
+    want = orc.profile_counts(k, bases, boff, table)
+    assert kk == k and len(enc) == len(want)
+    for e, x in zip(enc, want):
+        assert e == orc.profile_encode(x)
+    if orc.have_ref():
+        rd = tmp_path / "ref"
+        rd.mkdir()
+        rp = str(rd / ("reads." + fmt))
+        (orc.write_fasta if fmt == "fasta" else orc.write_fastq)(rp, bases, boff)
+        orc.run_ref_fastk(rp, k, case["cutoff"], case["T"], str(rd), extra=("-p",))
+        k2, renc = orc.read_profiles(str(rd), "reads")
+        assert [orc.profile_decode(e) for e in renc] == [x.tolist() for x in want]
