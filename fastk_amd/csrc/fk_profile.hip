@@ -142,9 +142,9 @@ static __global__ __launch_bounds__(256) void k_pf_counts(const uint8_t *__restr
             }
           const u32 pre = a[0] >> pshift;
           int64_t lo = (int64_t) idx[pre], hi = (int64_t) idx[pre + 1];
-          while (lo < hi)
-            { const int64_t mid = (lo + hi) >> 1;
-              const u32 *r = table + mid * sdw;
+          // -1 / 0 / +1: record m is below / equal to / above the key
+          auto probe = [&](int64_t m) -> int
+            { const u32 *r = table + m * sdw;
               int cmp = 0;
 #pragma unroll
               for (int w = 0; w < KW; w++)
@@ -154,11 +154,47 @@ static __global__ __launch_bounds__(256) void k_pf_counts(const uint8_t *__restr
                     cmp = (x < a[w]) ? -1 : 1;
                 }
               if (cmp == 0)
-                { cnt = r[sdw - 1] >> 16;
-                  break;
+                cnt = r[sdw - 1] >> 16;
+              return (cmp);
+            };
+          bool found = false;
+          if (hi - lo > 8)
+            { // the bits after the prefix are close to uniform inside a bucket: start at the interpolated
+              // rank and gallop, so that the probes stay within a cache line or two of the answer
+              const u32 nxt = (a[0] << (32 - pshift)) | ((KW > 1) ? (a[KW > 1 ? 1 : 0] >> pshift) : 0u);
+              int64_t e = lo + (int64_t) (((u64) (hi - lo) * nxt) >> 32);
+              int c = probe(e);
+              if (c == 0)
+                found = true;
+              else if (c < 0)
+                { lo = e + 1;
+                  for (int64_t step = 2; ; step <<= 1)
+                    { const int64_t m = lo + step - 1;
+                      if (m >= hi) break;
+                      c = probe(m);
+                      if (c == 0) { found = true; break; }
+                      if (c > 0) { hi = m; break; }
+                      lo = m + 1;
+                    }
                 }
-              if (cmp < 0) lo = mid + 1;
-              else         hi = mid;
+              else
+                { hi = e;
+                  for (int64_t step = 2; ; step <<= 1)
+                    { const int64_t m = hi - step;
+                      if (m < lo) break;
+                      c = probe(m);
+                      if (c == 0) { found = true; break; }
+                      if (c < 0) { lo = m + 1; break; }
+                      hi = m;
+                    }
+                }
+            }
+          while (!found && lo < hi)
+            { const int64_t mid = (lo + hi) >> 1;
+              const int c = probe(mid);
+              if (c == 0) break;
+              if (c < 0) lo = mid + 1;
+              else       hi = mid;
             }
         }
       out[p] = (uint16_t) cnt;
