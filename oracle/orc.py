@@ -526,3 +526,14 @@ def read_profiles(outdir, root):
             out.append(data[prev:int(o)])
             prev = int(o)
     return kmer, out
+
+
+def profiles_digest(count_lists):
+    """sha256 over, per read, int32 length + uint16 counts (little-endian): the golden fixtures pin the
+    reference's decoded profiles with it."""
+    h = hashlib.sha256()
+    for c in count_lists:
+        a = np.asarray(c, dtype="<u2")
+        h.update(struct.pack("<i", len(a)))
+        h.update(a.tobytes())
+    return h.hexdigest()

@@ -9,7 +9,8 @@ Each case <name> produces
     <name>.json      input description + expected results from the reference:
                      sparse .hist (nonzero bins, ilow, ihigh, sha256 of the 262,164 file bytes),
                      .ktab header fields, nels, part sizes, sha256 of the canonical stream
-                     (stub index from byte 16 + part payloads from byte 12), sha256 of every file
+                     (stub index from byte 16 + part payloads from byte 12), sha256 of every file,
+                     digest of the decoded -p profiles (orc.profiles_digest)
     <name>.fa.gz     the input reads, only for hand-built edge-case inputs (synthetic inputs are
                      regenerated from include/fk_synth.h parameters)
     <name>.table.gz  the full (k-mer bytes, count) table, only for small cases
@@ -125,6 +126,17 @@ def main():
                             for i in range(max(0, t["nels"] - 8), t["nels"])]),
             file_sha256={f: sha(open(os.path.join(d, f), "rb").read()) for f in files},
         )
+        # profiles: the reference's -p run (own directory, same input); what is pinned is the DECODED
+        # count vectors (the reference's bytes depend on its internal super-mer cuts)
+        pd = tempfile.mkdtemp(prefix="fkgoldp")
+        ppath = os.path.join(pd, "x." + case["fmt"])
+        shutil.copy(path, ppath)
+        orc.run_ref_fastk(ppath, k, case["cutoff"], case["T"], pd, extra=("-p",))
+        pk, enc = orc.read_profiles(pd, "x")
+        exp["prof"] = dict(nreads=len(enc), ref_bytes=sum(len(e) for e in enc),
+                           decoded_sha256=orc.profiles_digest([orc.profile_decode(e) for e in enc]),
+                           first_ref_hex=[e.hex() for e in enc[:4]])
+        shutil.rmtree(pd)
         meta = dict(case)
         meta["expected"] = exp
         meta["generated_by"] = "tests/golden/make_golden.py with oracle/_ref/FastK (reference build)"

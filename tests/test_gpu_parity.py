@@ -943,6 +943,9 @@ def test_profiles_match_oracle_and_reference(name, nb, tmp_path):
         res = ctx.finish()
         data, offs = ctx.make_profiles(outdir=d, root="x", nparts=case["T"])
     exp = _check_profiles(k, bases, boff, data, offs, res.table)
+    raw = data.tobytes()
+    mine = [orc.profile_decode(raw[offs[i]:offs[i + 1]]) for i in range(len(offs) - 1)]
+    assert orc.profiles_digest(mine) == case["expected"]["prof"]["decoded_sha256"]   # the reference's
     if not orc.have_ref() or nb != 1:
         return
     rd = os.path.join(d, "ref")

@@ -56,3 +56,19 @@ def test_empty_and_short_inputs():
     bases, boff = orc.block_from_reads(["acgtacgtacgtacgtacgtacgtacgtacgtacgtacgt"])
     res = orc.fastk(40, bases, boff, cutoff=1)
     assert res.ninst == 1 and res.ntable == 1 and res.hist[1] == 1
+
+
+@pytest.mark.parametrize("name", util.golden_names())
+def test_oracle_profiles_match_golden_digest(name):
+    """Decoded -p profiles captured from the reference (make_golden.py) against the oracle's per-read
+    counts, and the codec: the reference's own bytes of the first reads decode to them."""
+    case, bases, boff = util.load_case(name)
+    k = case["k"]
+    g = case["expected"]["prof"]
+    table = orc.fastk(k, bases, boff, cutoff=1).table
+    counts = orc.profile_counts(k, bases, boff, table)
+    assert len(counts) == g["nreads"]
+    assert orc.profiles_digest(counts) == g["decoded_sha256"]
+    for hx, c in zip(g["first_ref_hex"], counts):
+        assert orc.profile_decode(bytes.fromhex(hx)) == c.tolist()
+    assert sum(len(orc.profile_encode(c)) for c in counts) <= g["ref_bytes"]
