@@ -24,7 +24,7 @@ EXPORTS = [
     "fk_train_block", "fk_count_unsorted_kmers", "fk_debug_get", "fk_push_fastq", "fk_host_alloc",
     "fk_host_free", "fk_bucket_census", "fk_set_bucket_weights", "fk_push_fasta", "fk_merge_tables",
     "fk_write_ktab_ex", "fk_rounds_begin", "fk_rounds_add", "fk_rounds_finish",
-    "fk_make_profiles", "fk_write_prof",
+    "fk_make_profiles", "fk_write_prof", "fk_set_table",
 ]
 
 
@@ -125,6 +125,7 @@ def load_library():
     L.fk_push_fasta.argtypes = [vp, vp, i64, C.c_int, C.POINTER(C.c_int), C.POINTER(i64), C.POINTER(i64)]
     L.fk_merge_tables.argtypes = [vp, vp, i64, i64, C.POINTER(CResult)]
     L.fk_make_profiles.argtypes = [vp, vp, i64, C.POINTER(CProfiles)]
+    L.fk_set_table.argtypes = [vp, vp, i64]
     L.fk_write_prof.argtypes = [C.POINTER(CProfiles), ci, ci, C.c_char_p, C.c_char_p]
     L.fk_rounds_begin.argtypes = [vp]
     L.fk_rounds_add.argtypes = [vp, vp, i64]
@@ -291,6 +292,11 @@ class Context:
         r = CResult()
         self._ck(self.L.fk_rounds_finish(self.h, 1 if fetch_table else 0, C.byref(r)))
         return Result(r, self.w.kmer_word)
+
+    def set_table(self, records):
+        """(n, KMER_WORD) uint8 entries, any order: the dictionary of the next make_profiles."""
+        a = np.ascontiguousarray(records, dtype=np.uint8)
+        self._ck(self.L.fk_set_table(self.h, a.ctypes.data if a.shape[0] else None, a.shape[0]))
 
     def make_profiles(self, ptr=None, nbytes=0, outdir=None, root=None, nparts=1):
         """Profiles of the reads just counted (cutoff 1, resident run): returns (data, offsets) as

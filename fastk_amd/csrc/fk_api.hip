@@ -1529,12 +1529,49 @@ static int write_all(int fd, const void *p, size_t n)
 // (count.c:1893-1910, README.md:936-961)
 // ---- profiles (-p) ---------------------------------------------------------------------------
 
+extern "C" int fk_set_table(fk_ctx *ctx, const uint8_t *records, int64_t n)
+{ if (ctx == NULL || n < 0 || (records == NULL && n > 0)) return (FK_EINVAL);
+  const fk_widths &w = ctx->wid;
+  hipStream_t s = ctx->stream;
+  FK_HIP(ctx, hipSetDevice(ctx->device));
+  ctx->have_table = false;
+  ctx->last_table = NULL;
+  ctx->last_ntab  = 0;
+  if (n > 0)
+    { void *d_t = fk_slot(ctx, FK_SLOT_TABLE, n * w.kmer_stride);
+      void *d_x = fk_slot(ctx, FK_SLOT_KM_A, n * w.kmer_stride);
+      if (d_t == NULL || d_x == NULL)
+        return (FK_ENOMEM);
+      if (w.kmer_word == w.kmer_stride)
+        FK_HIP(ctx, hipMemcpyAsync(d_t, records, (size_t) n * w.kmer_stride, hipMemcpyHostToDevice, s));
+      else
+        { std::vector<uint8_t> stage((size_t) n * w.kmer_stride, 0);
+          for (int64_t i = 0; i < n; i++)
+            { memcpy(stage.data() + i * w.kmer_stride, records + i * w.kmer_word, w.kmer_bytes);
+              memcpy(stage.data() + i * w.kmer_stride + w.kmer_stride - 2, records + i * w.kmer_word + w.kmer_bytes, 2);
+            }
+          FK_HIP(ctx, hipMemcpyAsync(d_t, stage.data(), stage.size(), hipMemcpyHostToDevice, s));
+          FK_HIP(ctx, hipStreamSynchronize(s));
+        }
+      void *sorted = d_t;
+      int64_t census[256];
+      int rc = fkx_sort_table(ctx, n, d_t, d_x, &sorted, census);
+      if (rc != FK_OK)
+        return (rc);
+      FK_HIP(ctx, hipStreamSynchronize(s));
+      ctx->last_table = sorted;
+    }
+  ctx->last_ntab  = n;
+  ctx->have_table = true;
+  return (FK_OK);
+}
+
 extern "C" int fk_make_profiles(fk_ctx *ctx, const void *d_bases, int64_t nbytes, fk_profiles *out)
 { if (ctx == NULL || out == NULL || nbytes < 0) return (FK_EINVAL);
   memset(out, 0, sizeof(*out));
   FK_HIP(ctx, hipSetDevice(ctx->device));
   if (!ctx->have_table)
-    { fk_set_error(ctx, "fk_make_profiles: needs the table of a finished resident run with table_cutoff 1");
+    { fk_set_error(ctx, "fk_make_profiles: needs fk_set_table or the table of a finished resident run with table_cutoff 1");
       return (FK_ESTATE);
     }
   if (ctx->prm.bc_prefix > 0)

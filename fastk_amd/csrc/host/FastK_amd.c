@@ -41,6 +41,8 @@
 
 static char *Prog_Name = "FastK_amd";
 
+#include "ktab_io.h"
+
 static double now(void)
 { struct timeval tv;
   gettimeofday(&tv,NULL);
@@ -49,6 +51,7 @@ static double now(void)
 
 static int       KMER = 40, NTHREADS = 4, DO_TABLE = 0, BC_PREFIX = 0, VERBOSE = 0, EXACT = 0, MEM_GB = 0;
 static int       HOST_PARSE = 0, COMPRESS = 0, PROFILE = 0;
+static char     *PRO_NAME = NULL;
 static char     *OUT_NAME = NULL;
 
 typedef struct
@@ -235,9 +238,10 @@ int main(int argc, char *argv[])
         case 'P': break;
         case 'c': COMPRESS = 1; break;
         case 'p':
-          if (argv[i][2] != '\0')
-            { fprintf(stderr,"%s: option %s (profiles relative to another table) is not built in this engine\n",
-                      Prog_Name,argv[i]);
+          if (argv[i][2] == ':')
+            PRO_NAME = argv[i]+3;          /* profiles relative to this table, FastK.c:270-282 */
+          else if (argv[i][2] != '\0')
+            { fprintf(stderr,"\n%s: %s is not a legal optional argument\n",Prog_Name,argv[i]);
               exit (1);
             }
           PROFILE = 1;
@@ -250,7 +254,7 @@ int main(int argc, char *argv[])
       argv[j++] = argv[i];
   nfiles = j-1;
   if (nfiles < 1 || KMER <= 0 || NTHREADS <= 0 || DO_TABLE < 0 || BC_PREFIX < 0)
-    { fprintf(stderr,"\nUsage: %s [-k<int(40)>] [-t[<int(1)>]] [-p] [-c] [-bc<int>] [-v] [-x] [-N<path_name>]\n",Prog_Name);
+    { fprintf(stderr,"\nUsage: %s [-k<int(40)>] [-t[<int(1)>]] [-p[:<table>[.ktab]]] [-c] [-bc<int>] [-v] [-x] [-N<path_name>]\n",Prog_Name);
       fprintf(stderr,"       %*s [-P<dir>] [-M<int>] [-T<int(4)>] <source>[.fa|.fasta|.fq|.fastq][.gz] ...\n",
               (int) strlen(Prog_Name),"");
       exit (1);
@@ -342,6 +346,32 @@ int main(int argc, char *argv[])
     }
 
   t_ingest = now();
+  if (PRO_NAME != NULL)
+    { /* relative profiles: the counts are those of the given table; only profiles are produced
+         (README.md:112-120) */
+      char *tdir, *troot;
+      uint8_t *recs = NULL;
+      int64_t  n = 0, cap = 0;
+      int      tk = 0, mv = 0x7fff;
+      fk_profiles pr;
+      fk_widths   wd;
+      fk_get_widths(KMER,&wd);
+      split_path(PRO_NAME,".ktab",&tdir,&troot);
+      load_table(tdir,troot,wd.kmer_word,&tk,&mv,&recs,&n,&cap,KMER);
+      if (DO_TABLE > 0)
+        fprintf(stderr,"%s: Warning: -p:%s overides -t option\n",Prog_Name,PRO_NAME);
+      if (fk_set_table(ctx,recs,n) != FK_OK)
+        die(ctx,"fk_set_table");
+      if (fk_make_profiles(ctx,NULL,0,&pr) != FK_OK)
+        die(ctx,"fk_make_profiles");
+      if (fk_write_prof(&pr,KMER,NTHREADS,dir,root) != FK_OK)
+        die(ctx,"writing .prof");
+      if (VERBOSE)
+        fprintf(stderr,"  Profiles of %lld reads relative to %lld %d-mers of %s in %lld bytes\n",
+                (long long) pr.nreads,(long long) n,KMER,PRO_NAME,(long long) pr.nbytes);
+      fk_destroy(ctx);
+      exit (0);
+    }
   if (fk_finish(ctx,res) != FK_OK)
     die(ctx,"fk_finish");
   t_count = now();

@@ -75,6 +75,14 @@ class HipEngine:
         res[:, kw - 2:] = out[:, stride - 2:]
         return res
 
+    def set_table(self, records):
+        """(n, KMER_WORD) host records, any order -> dictionary of make_profiles (fk_set_table)."""
+        self.ctx.set_table(records)
+
+    def make_profiles(self, reads):
+        """reads: uint8 tensor in HBM (0-terminated reads) -> (codec bytes, nreads + 1 offsets)."""
+        return self.ctx.make_profiles(reads.data_ptr(), reads.numel())
+
     def rounds_begin(self):
         self.ctx.rounds_begin()
 
@@ -230,6 +238,46 @@ def gather_table(table, kmer_bytes, sort_fn, group=None, dst=0):
         parts.append(buf)
     merged = torch.cat(parts).cpu().numpy().reshape(-1, kw)
     return sort_fn(merged) if world > 1 else merged
+
+
+def allgather_table(table, group=None):
+    """Every rank's (n, KMER_WORD) table to every rank: the concatenation in rank order (disjoint k-mer
+    sets, so it is the whole data set's table up to order).  One broadcast per source rank, at most
+    MAX_PAIR_BYTES per operation."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" \
+        else torch.device("cpu")
+    kw = table.shape[1]
+    sizes = torch.zeros(world, dtype=torch.int64, device=dev)
+    sizes[rank] = table.shape[0]
+    dist.all_reduce(sizes, op=dist.ReduceOp.SUM, group=group)
+    sizes = [int(x) for x in sizes.tolist()]
+    out = torch.empty(sum(sizes) * kw, dtype=torch.uint8, device=dev)
+    per = max(1, MAX_PAIR_BYTES // kw) * kw
+    o = 0
+    for r in range(world):
+        seg = out[o:o + sizes[r] * kw]
+        if r == rank and sizes[r]:
+            seg.copy_(torch.from_numpy(np.ascontiguousarray(table).reshape(-1)))
+        src = dist.get_global_rank(group, r) if group is not None else r
+        for c in range(0, seg.numel(), per):
+            dist.broadcast(seg[c:c + per], src, group=group)
+        o += sizes[r] * kw
+    return out.cpu().numpy().reshape(-1, kw)
+
+
+def profiles_sharded(engine, reads, local_table, group=None):
+    """Profiles (FastK -p) of this rank's reads in a sharded run.  A read's k-mers were counted on the
+    ranks owning their minimizer buckets, so every rank first receives all tables (cutoff 1; an
+    all-gather of KMER_WORD records), installs the union as its dictionary and then looks its own reads
+    up locally -- no per-read traffic.  Returns (codec bytes, offsets) for the reads of this rank, in
+    their order; rank r's reads follow rank r-1's in the data set, so the .pidx/.prof part files can be
+    written per rank."""
+    union = allgather_table(local_table, group) if dist.is_initialized() and dist.get_world_size(group) > 1 \
+        else local_table
+    engine.set_table(union)
+    return engine.make_profiles(reads)
 
 
 def _post_round(recs, inbox, send_n, recv_n, s_off, stride, group):

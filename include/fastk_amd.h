@@ -290,6 +290,14 @@ typedef struct
 
 int fk_make_profiles(fk_ctx *ctx, const void *d_bases, int64_t nbytes, fk_profiles *out);
 
+/* Install another table as the dictionary of fk_make_profiles: relative profiles (FastK -p:<table>,
+   FastK.c:270-282 + the cmer_merge path count.c:675-815 -- counts are those of the given table, 0 for
+   k-mers it does not hold), and the sharded run, where every rank installs the union of all ranks'
+   tables.  records: n entries of kmer_word bytes ([KMER_BYTES][uint16 count]) in any order, k-mers
+   distinct; they are copied to HBM and ordered there.  No counting run is needed: push the reads,
+   call fk_set_table, then fk_make_profiles(ctx, NULL, 0, &out). */
+int fk_set_table(fk_ctx *ctx, const uint8_t *records, int64_t n);
+
 /* <dir>/<root>.prof stub + hidden .<root>.pidx.N / .<root>.prof.N, N = 1..nparts (README.md:1010-1027);
    the reads are divided evenly over the parts in input order. */
 int fk_write_prof(const fk_profiles *p, int kmer, int nparts, const char *dir, const char *root);

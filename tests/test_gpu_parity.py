@@ -737,6 +737,10 @@ def test_sharded_final_gather_writes_reference_files(tmp_path):
             rng = np.random.default_rng(5)
             again = eng.sort_table(np.ascontiguousarray(merged[rng.permutation(len(merged))]))
             assert np.array_equal(again, merged)
+            # profiles of the rank's reads against the union of all ranks' tables (here: one rank)
+            pdata, poffs = shard.profiles_sharded(eng, reads, table)
+            mine = [orc.profile_decode(pdata.tobytes()[poffs[i]:poffs[i + 1]]) for i in range(len(poffs) - 1)]
+            assert orc.profiles_digest(mine) == case["expected"]["prof"]["decoded_sha256"]
     finally:
         dist.destroy_process_group()
     util.check_against_golden(case, out["hist"], out["max_inst"], merged)
@@ -1038,4 +1042,58 @@ def test_cli_profiles_option(name, fmt, tmp_path):
         (orc.write_fasta if fmt == "fasta" else orc.write_fastq)(rp, bases, boff)
         orc.run_ref_fastk(rp, k, case["cutoff"], case["T"], str(rd), extra=("-p",))
         k2, renc = orc.read_profiles(str(rd), "reads")
+        assert [orc.profile_decode(e) for e in renc] == [x.tolist() for x in want]
+
+
+def test_relative_profiles_against_another_table(tmp_path):
+    """-p:<table> (README.md:112-120): counts come from another data set's table, 0 for k-mers it does
+    not hold; API (fk_set_table + fk_make_profiles, no counting run) and CLI against the reference."""
+    import os, subprocess
+    k, T = 40, 3
+    _, basesB, boffB = util.load_case("synth_illumina_k40_t1_T4")        # table source
+    rng = np.random.default_rng(77)
+    nB = len(boffB) - 1
+    readsA = []
+    for i in rng.integers(0, nB, size=600):                              # reads of B, some mutated
+        r = basesB[boffB[i]:boffB[i + 1] - 1].copy()
+        if rng.random() < 0.5:
+            r[int(rng.integers(0, len(r)))] = ord("acgt"[int(rng.integers(0, 4))])
+        if rng.random() < 0.1:
+            r[int(rng.integers(0, len(r)))] = ord("N")
+        readsA.append(r.tobytes().decode())
+    readsA += ["".join("acgt"[x] for x in rng.integers(0, 4, size=200)) for _ in range(50)]   # unrelated
+    readsA += ["acgt" * 5, ""]
+    basesA, boffA = orc.block_from_reads(readsA)
+    tabB = orc.fastk(k, basesB, boffB, cutoff=2).table                   # a cutoff-2 table: absent k-mers -> 0
+    want = orc.profile_counts(k, basesA, boffA, tabB)
+    assert any((w == 0).any() and (w > 0).any() for w in want)
+    rng.shuffle(tabB)                                                    # any order is accepted
+    with fastk_amd.Context(kmer=k, table_cutoff=0) as ctx:
+        ctx.push_block(basesA, boffA.astype(np.int32))
+        ctx.set_table(tabB)
+        data, offs = ctx.make_profiles()
+    raw = data.tobytes()
+    for i, x in enumerate(want):
+        assert raw[offs[i]:offs[i + 1]] == orc.profile_encode(x), i
+
+    # CLI + the reference on files
+    d = str(tmp_path)
+    pb, pa = os.path.join(d, "B.fasta"), os.path.join(d, "A.fasta")
+    orc.write_fasta(pb, basesB, boffB)
+    orc.write_fasta(pa, basesA, boffA)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "fastk_amd", "bin", "FastK_amd")
+    subprocess.run([exe, "-k%d" % k, "-t2", "-T2", pb], check=True, cwd=d)
+    subprocess.run([exe, "-k%d" % k, "-T%d" % T, "-p:B", "-v", pa], check=True, cwd=d)
+    assert not os.path.exists(os.path.join(d, "A.hist"))                 # only profiles are produced
+    kk, enc = orc.read_profiles(d, "A")
+    assert kk == k and enc == [orc.profile_encode(x) for x in want]
+    if orc.have_ref():
+        rd = os.path.join(d, "ref")
+        os.mkdir(rd)
+        for f in ("A.fasta", "B.fasta"):
+            os.link(os.path.join(d, f), os.path.join(rd, f))
+        orc.run_ref_fastk(os.path.join(rd, "B.fasta"), k, 2, 2, rd)
+        orc.run_ref_fastk(os.path.join(rd, "A.fasta"), k, 0, T, rd, extra=("-p:B",))
+        k2, renc = orc.read_profiles(rd, "A")
         assert [orc.profile_decode(e) for e in renc] == [x.tolist() for x in want]

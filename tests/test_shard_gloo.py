@@ -81,6 +81,17 @@ class OracleEngine:
         res.table = table
         return dict(hist=hist, max_inst=mx, nweighted=nw, ndistinct=nd, ntable=nt, result=res)
 
+    def set_table(self, records):
+        self.dictionary = records[np.lexsort(records[:, :self.P.kmer_bytes].T[::-1])]
+
+    def make_profiles(self, reads):
+        bases = reads.numpy()
+        ends = np.nonzero(bases == 0)[0]
+        boff = np.concatenate([[0], ends + 1]).astype(np.int64)
+        blobs = [orc.profile_encode(c) for c in orc.profile_counts(self.P.kmer, bases, boff, self.dictionary)]
+        offs = np.concatenate([[0], np.cumsum([len(b) for b in blobs])]).astype(np.int64)
+        return np.frombuffer(b"".join(blobs), dtype=np.uint8), offs
+
     def count_supermers(self, recs, nsuper):
         P = self.P
         a = recs.numpy().reshape(nsuper, P.smer_word)
@@ -151,3 +162,47 @@ def test_two_rank_shard_matches_golden(name, rounds, tmp_path):
     assert t["stream_sha256"] == exp["ktab"]["stream_sha256"]
     assert (t["nparts"], t["minval"], t["ibytes"], t["nels"]) == \
         (case["T"], case["cutoff"], exp["ktab"]["ibytes"], exp["ktab"]["nels"])
+
+
+def _prof_worker(rank, world, port, name, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from fastk_amd import shard
+    shard.MAX_PAIR_BYTES = 4096
+    case, bases, boff = util.load_case(name)
+    nreads = len(boff) - 1
+    lo, hi = rank * nreads // world, (rank + 1) * nreads // world
+    mine = torch.from_numpy(bases[boff[lo]:boff[hi]].copy())
+    eng = OracleEngine(case["k"], world, 1)
+    out = shard.count_sharded(eng, mine, verify=True)
+    data, offs = shard.profiles_sharded(eng, mine, out["local"]["result"].table)
+    q.put((rank, lo, hi, data.tobytes(), offs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_profiles_match_whole_data_oracle():
+    """Every rank's profiles (its own reads, union of all ranks' tables as dictionary) are the profiles
+    of those reads in the whole data set."""
+    name, world = "synth_tiny_k40_t1_T2", 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30500 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_prof_worker, args=(r, world, port, name, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=300) for _ in range(world)])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    case, bases, boff = util.load_case(name)
+    k = case["k"]
+    want = orc.profile_counts(k, bases, boff, orc.fastk(k, bases, boff, cutoff=1).table)
+    allc = []
+    for rank, lo, hi, raw, offs in got:
+        assert len(offs) == hi - lo + 1
+        for i in range(hi - lo):
+            assert raw[offs[i]:offs[i + 1]] == orc.profile_encode(want[lo + i])
+            allc.append(orc.profile_decode(raw[offs[i]:offs[i + 1]]))
+    assert orc.profiles_digest(allc) == case["expected"]["prof"]["decoded_sha256"]   # the reference's
