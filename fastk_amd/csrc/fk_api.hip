@@ -242,6 +242,8 @@ extern "C" int fk_create(const fk_params *p, fk_ctx **out)
   CK(hipMalloc((void **) &ctx->d_ticket, 64 * sizeof(u32)));
   if (ctx->prm.hbm_budget > 0 && !ctx->prm.exact_parts)
     ctx->chunk_bytes = std::max<int64_t>(ctx->prm.hbm_budget / 32, 64ll << 20);
+  if (ctx->prm.hbm_budget > 0)
+    ctx->spill_limit = ctx->prm.hbm_budget / 2;     // the other half is a bucket's working set
   { uint16_t mtab[1024];
     build_minimizer_tables(mtab, ctx->h_mbucket, ctx->prm.nbuckets);
     CK(hipMemcpy(ctx->d_mrank, mtab, sizeof(mtab), hipMemcpyHostToDevice));
@@ -253,6 +255,13 @@ extern "C" int fk_create(const fk_params *p, fk_ctx **out)
   ctx->push_lock = m;
   *out = ctx;
   return (FK_OK);
+}
+
+static void free_chunk(fk_chunk *c)
+{ if (c->ptr == NULL) return;
+  if (c->on_host) hipHostFree(c->ptr);
+  else            hipFree(c->ptr);
+  c->ptr = NULL;
 }
 
 extern "C" void fk_destroy(fk_ctx *ctx)
@@ -281,7 +290,7 @@ extern "C" void fk_destroy(fk_ctx *ctx)
   if (ctx->own_stream && ctx->stream != NULL)
     hipStreamDestroy(ctx->stream);
   for (int i = 0; i < ctx->nchunks; i++)
-    hipFree(ctx->chunks[i].ptr);
+    free_chunk(&ctx->chunks[i]);
   free(ctx->chunks);
   free(ctx->h_table);
   free(ctx->acc_res);
@@ -367,6 +376,10 @@ extern "C" int fk_debug_set(fk_ctx *ctx, const char *key, int64_t value)
     { ctx->dbg_verbose = (int) value;
       return (FK_OK);
     }
+  if (strcmp(key, "spill_limit") == 0)      // chunk records kept in HBM before spilling to the host (tests)
+    { ctx->spill_limit = value;
+      return (FK_OK);
+    }
   if (strcmp(key, "chunk_bytes") == 0)      // split the pushed reads every so many bytes (tests)
     { ctx->chunk_bytes = value;
       return (FK_OK);
@@ -390,6 +403,10 @@ extern "C" int fk_debug_get(fk_ctx *ctx, const char *key, int64_t *value)
 { if (ctx == NULL || key == NULL || value == NULL) return (FK_EINVAL);
   if (strcmp(key, "aggr_extra_rounds") == 0)
     { *value = ctx->aggr_extra_rounds;
+      return (FK_OK);
+    }
+  if (strcmp(key, "spilled_bytes") == 0)    // super-mer records the last chunked run moved to host memory
+    { *value = ctx->spilled_bytes;
       return (FK_OK);
     }
   if (strcmp(key, "table_sort_ties") == 0)
@@ -705,16 +722,35 @@ static int flush_chunk(fk_ctx *ctx)
     }
   fk_chunk *c = &ctx->chunks[ctx->nchunks];
   memset(c, 0, sizeof(*c));
-  if (hipMalloc(&c->ptr, (size_t) (ns * stride)) != hipSuccess)
-    { fk_set_error(ctx, "out of HBM: cannot keep %lld super-mer records of a chunk", (long long) ns);
-      return (FK_ENOMEM);
+  if (ctx->nchunks == 0)
+    ctx->spilled_bytes = 0;
+  // the chunks stay in HBM up to spill_limit; later ones go to pinned host memory and come back
+  // bucket by bucket when they are counted (inputs whose super-mers alone exceed the HBM budget)
+  const int64_t bytes = ns * stride;
+  c->on_host = (ctx->spill_limit > 0 && ctx->chunk_hbm_bytes + bytes > ctx->spill_limit);
+  if (c->on_host)
+    { if (hipHostMalloc(&c->ptr, (size_t) bytes, hipHostMallocDefault) != hipSuccess)
+        { fk_set_error(ctx, "out of host memory: cannot spill %lld super-mer records of a chunk", (long long) ns);
+          c->ptr = NULL;
+          return (FK_ENOMEM);
+        }
+      ctx->spilled_bytes += bytes;
+    }
+  else
+    { if (hipMalloc(&c->ptr, (size_t) bytes) != hipSuccess)
+        { fk_set_error(ctx, "out of HBM: cannot keep %lld super-mer records of a chunk", (long long) ns);
+          c->ptr = NULL;
+          return (FK_ENOMEM);
+        }
+      ctx->chunk_hbm_bytes += bytes;
     }
   int64_t run = 0;
   for (int b = 0; b < ctx->prm.nbuckets; b++)
     { c->cnt[b] = bc[b];
       if (bc[b] > 0)
         FK_HIP(ctx, hipMemcpyAsync((char *) c->ptr + run * stride, (char *) out + bo[b] * stride,
-                                   (size_t) (bc[b] * stride), hipMemcpyDeviceToDevice, s));
+                                   (size_t) (bc[b] * stride),
+                                   c->on_host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, s));
       run += bc[b];
     }
   c->total = run;
@@ -1190,8 +1226,10 @@ static int count_bucket(fk_ctx *ctx, void *sm_in, int64_t ns, fk_result *res, bo
       hipEventRecord(ev[3], s);
       if (hipEventSynchronize(ev[3]) != hipSuccess) { rc = FK_EHIP; break; }
       if (ctx->dbg_verbose)
-        fprintf(stderr, "  bucket: %lld super-mers, %lld weighted k-mers, %lld distinct, %.2f ms\n",
-                (long long) ns, (long long) nw, (long long) ndk, ms_between(ev[0], ev[3]));
+        fprintf(stderr, "  bucket: %lld super-mers, %lld weighted k-mers, %lld distinct, %.2f ms "
+                        "(super-mers %.2f, expand %.2f, k-mers %.2f of which aggregation %.2f)\n",
+                (long long) ns, (long long) nw, (long long) ndk, ms_between(ev[0], ev[3]),
+                ms_between(ev[0], ev[1]), ms_between(ev[1], ev[2]), ms_between(ev[2], ev[3]), ms_aggr);
       tm->group_s += ms_between(ev[0], ev[1]);
       tm->expand  += ms_between(ev[1], ev[2]);
       tm->radix_k += ms_between(ev[2], ev[3]) - ms_aggr;
@@ -1365,7 +1403,8 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
                 off += ch->cnt[x];
               if (ch->cnt[b] > 0
                   && hipMemcpyAsync(g + run * w.smer_stride, (char *) ch->ptr + off * w.smer_stride,
-                                    (size_t) (ch->cnt[b] * w.smer_stride), hipMemcpyDeviceToDevice, s)
+                                    (size_t) (ch->cnt[b] * w.smer_stride),
+                                    ch->on_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, s)
                      != hipSuccess)
                 return (FK_EHIP);
               run += ch->cnt[b];
@@ -1427,8 +1466,9 @@ extern "C" int fk_finish(fk_ctx *ctx, fk_result *res)
       if (rc == FK_OK)
         rc = fkx_pipeline(ctx, NULL, 0, NULL, 0, res, true);
       for (int i = 0; i < ctx->nchunks; i++)
-        hipFree(ctx->chunks[i].ptr);
+        free_chunk(&ctx->chunks[i]);
       ctx->nchunks = 0;
+      ctx->chunk_hbm_bytes = 0;
       ctx->chunk_ninst = 0;
       return (rc);
     }

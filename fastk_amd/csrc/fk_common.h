@@ -20,6 +20,7 @@ struct fk_chunk
 { void    *ptr;             // records of bucket 0, 1, ... back to back
   int64_t  cnt[256];
   int64_t  total;
+  int      on_host;         // records live in pinned host memory (spilled), not in HBM
 };
 
 struct fk_ctx
@@ -71,6 +72,9 @@ struct fk_ctx
   int        nchunks, chunks_cap;
   int64_t    chunk_bytes;      // split the pushed reads whenever this many bytes have accumulated (0: never)
   int64_t    chunk_ninst;      // k-mer instances of the chunks already split
+  int64_t    chunk_hbm_bytes;  // chunk records currently held in HBM
+  int64_t    spill_limit;      // > 0: chunks beyond this many HBM bytes go to pinned host memory
+  int64_t    spilled_bytes;    // statistics: bytes spilled by the current run
 
   hipEvent_t ev0, ev1;
   hipEvent_t pass_ev[128];       // begin/end of each scatter launch of the current sort

@@ -275,7 +275,8 @@ int main(int argc, char *argv[])
   prm.exact_parts = EXACT;
   if (MEM_GB > 0 && !EXACT)
     { /* bases ~ file bytes (FASTA), half of them (FASTQ), x4 when gzipped; the super-mers (~1 byte
-         per base) stay resident, a bucket's working set is ~7.5 bytes per base of that bucket */
+         per base) stay in HBM up to half the budget and spill to host memory beyond, a bucket's
+         working set is ~7.5 bytes per base of that bucket */
       double bases = 0., budget = 1e9 * MEM_GB;
       for (i = 1; i <= nfiles; i++)
         { char *r, *d;
@@ -292,14 +293,9 @@ int main(int argc, char *argv[])
           if (fp != NULL) fclose(fp);
           if (q >= 0) { free(r); free(d); }
         }
-      { double room = budget - 1.3*bases;
+      { double room = budget/2.;         /* the library keeps super-mers in the other half, the rest in host memory */
         int    nb   = 1;
-        if (room < 0.05*budget)
-          { fprintf(stderr,"%s: -M%d is too small for ~%.1f Gbp of input (the super-mers alone need ~%.0f GB)\n",
-                    Prog_Name,MEM_GB,bases/1e9,1.3*bases/1e9);
-            exit (1);
-          }
-        while (nb < 128 && 7.5*bases/nb > room)
+        while (nb < 256 && 7.5*bases/nb > room)
           nb += 1;
         prm.nbuckets   = nb;
         prm.hbm_budget = (int64_t) budget;

@@ -68,8 +68,9 @@ typedef struct
     int64_t hbm_budget;    /* > 0: bytes of HBM the run should fit in -- fk_push_block/_device then
                               split the reads into super-mers every hbm_budget/32 bytes and drop
                               them, so the ASCII reads are never resident as a whole (choose
-                              nbuckets so that a bucket's working set fits).  0: everything stays
-                              resident (fastest)                                                  */
+                              nbuckets so that a bucket's working set fits); super-mer records
+                              beyond hbm_budget/2 are kept in pinned host memory until their bucket
+                              is counted.  0: everything stays resident (fastest)                 */
     int     exact_parts;   /* 1: replay the reference's own super-mer rule (split.c:1016-1393)
                               so that the hidden .ktab part files get the reference's first-byte
                               boundaries (Table_Split, count.c:1560-1565) -- byte-identical files

@@ -293,6 +293,31 @@ def test_chunked_ingest_matches_golden(name, nb):
         util.check_against_golden(case, res.hist, res.max_inst, res.table)
 
 
+@pytest.mark.parametrize("nb", [1, 3])
+@pytest.mark.parametrize("name", ["synth_illumina_k40_t1_T4", "synth_hifi_k40_t4_T8"])
+def test_chunks_spilled_to_host_memory(name, nb):
+    """Chunks beyond the HBM allowance live in pinned host memory and come back bucket by bucket:
+    same results, and the run really spilled."""
+    case, bases, boff = util.load_case(name)
+    with fastk_amd.Context(kmer=case["k"], table_cutoff=case["cutoff"], nthreads=case["T"],
+                           nbuckets=nb) as ctx:
+        ctx.debug_set("chunk_bytes", max(4096, len(bases) // 6))
+        ctx.debug_set("spill_limit", max(4096, len(bases) // 30))    # first chunk or two stay, the rest spill
+        nreads = len(boff) - 1
+        step = max(1, nreads // 17)
+        for s0 in range(0, nreads, step):
+            e = min(nreads, s0 + step)
+            ctx.push_block(bases[boff[s0]:boff[e]], (boff[s0:e + 1] - boff[s0]).astype(np.int32))
+        res = ctx.finish()
+        assert ctx.debug_get("spilled_bytes") > 0
+        util.check_against_golden(case, res.hist, res.max_inst, res.table)
+        # the context is reusable afterwards, resident this time
+        ctx.debug_set("chunk_bytes", 0)
+        ctx.push_block(bases, boff.astype(np.int32))
+        res = ctx.finish()
+        util.check_against_golden(case, res.hist, res.max_inst, res.table)
+
+
 @pytest.mark.parametrize("name", ["synth_illumina_k40_t1_T4", "edge_k40_t1_T4", "synth_hifi_k40_t4_T8",
                                   "edge_k51_t1_T4"])
 def test_fastq_parsed_on_device_matches_golden(name, tmp_path):

@@ -26,6 +26,8 @@ def run(args, budget_gb, buckets):
     piece = max(1, int(args.piece_mb * 1e6) // (L + 1))              # reads generated per push
     with fastk_amd.Context(kmer=args.kmer, table_cutoff=args.cutoff, nthreads=4, nbuckets=buckets,
                            hbm_budget=int(budget_gb * 1e9)) as ctx:
+        if args.verbose:
+            ctx.debug_set("verbose", 1)
         buf = ctx.alloc(piece * (L + 1) + 64)
         t0 = time.perf_counter()
         t_gen = 0.0
@@ -35,13 +37,14 @@ def run(args, budget_gb, buckets):
             ctx.synth_reads(args.seed, glen, L, args.err_ppm, first, n, buf=buf)
             t_gen += time.perf_counter() - g0
             ctx.push_device(buf.ptr, n * (L + 1) - 1)                # push adds the last terminator
+        t_push = time.perf_counter() - t0
         res = ctx.finish()
         dt = time.perf_counter() - t0
         buf.free()
     inst = nreads * (L - args.kmer + 1)
     h = res.hist.astype(np.int64)
     conserved = int((h[1:0x7fff] * np.arange(1, 0x7fff)).sum()) + int(res.max_inst)
-    return dict(budget_gb=budget_gb, buckets=buckets, seconds=dt, synth_seconds=t_gen,
+    return dict(budget_gb=budget_gb, buckets=buckets, seconds=dt, synth_seconds=t_gen, push_seconds=t_push,
                 kmers_per_s=inst / (dt - t_gen), ninst=int(res.ninst), expected_inst=inst,
                 conserved=conserved, nsuper=int(res.nsuper), nweighted=int(res.nweighted),
                 ndistinct=int(res.ndistinct), ntable=int(res.ntable), device_ms=res.ms), res
@@ -59,6 +62,7 @@ def main():
     ap.add_argument("--budget-gb", type=float, default=32.0)
     ap.add_argument("--buckets", type=int, default=4)
     ap.add_argument("--piece-mb", type=float, default=512.0)
+    ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--compare", action="store_true", help="also run all-resident and compare")
     args = ap.parse_args()
     out, res = run(args, args.budget_gb, args.buckets)
