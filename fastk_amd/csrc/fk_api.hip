@@ -1434,7 +1434,7 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
       if ((rc = fetch_result_table(ctx, res, table, ntab, fetch_table)) != FK_OK)
         break;
       // fk_make_profiles looks k-mers up in this table: it has to hold every k-mer of resident reads
-      ctx->have_table = (!chunked && d_smers_in == NULL && ctx->prm.table_cutoff == 1);
+      ctx->have_table = (d_smers_in == NULL && ctx->prm.table_cutoff == 1);
       ctx->last_table = table;
       ctx->last_ntab  = ntab;
       hipEventRecord(ev[2], s);
@@ -1619,7 +1619,11 @@ extern "C" int fk_make_profiles(fk_ctx *ctx, const void *d_bases, int64_t nbytes
       return (FK_EUNSUPPORTED);
     }
   if (d_bases == NULL)
-    { d_bases = ctx->d_reads;
+    { if (ctx->chunk_bytes > 0)
+        { fk_set_error(ctx, "fk_make_profiles: the reads of a chunked run are not kept -- pass them again piece by piece");
+          return (FK_ESTATE);
+        }
+      d_bases = ctx->d_reads;
       nbytes  = ctx->reads_len;
     }
   int64_t nreads = 0, nprof = 0;

@@ -277,9 +277,11 @@ int fk_write_ktab_ex(const fk_result *res, int kmer, int table_cutoff, int nthre
  * one-byte-form-whenever-possible stream; they decode (libfastk.c:1657, Fetch_Profile) to the same
  * counts as the reference's files, whose zero-run splits follow its internal super-mer cuts.
  *
- * fk_make_profiles runs after fk_finish / fk_count_device_reads of a resident run (hbm_budget 0)
- * with table_cutoff 1 -- the table left in HBM is the dictionary.  d_bases NULL: the reads pushed
- * into the context; otherwise the caller-owned buffer that was just counted.  Reads end at 0 bytes
+ * fk_make_profiles runs after fk_finish / fk_count_device_reads with table_cutoff 1 -- the table
+ * left in HBM is the dictionary.  d_bases NULL: the reads pushed into the context (resident runs,
+ * hbm_budget 0); otherwise a caller-owned buffer of reads of the data set just counted -- after a
+ * chunked run (hbm_budget > 0), whose reads were dropped on the way, the caller passes them again
+ * piece by piece (whole reads per piece) and concatenates the results.  Reads end at 0 bytes
  * (a last read without one ends at nbytes); other non-acgt bytes stay inside their read.
  * data / offsets are host memory owned by ctx, valid until the next call or fk_destroy. */
 typedef struct

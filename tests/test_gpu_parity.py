@@ -1122,3 +1122,29 @@ def test_relative_profiles_against_another_table(tmp_path):
         orc.run_ref_fastk(os.path.join(rd, "A.fasta"), k, 0, T, rd, extra=("-p:B",))
         k2, renc = orc.read_profiles(rd, "A")
         assert [orc.profile_decode(e) for e in renc] == [x.tolist() for x in want]
+
+
+def test_profiles_after_chunked_run_piece_by_piece():
+    """A chunked (HBM-budgeted, bucketed) run drops the reads; its table still serves look-ups for
+    reads handed over again in pieces: concatenated, the profiles are the data set's."""
+    case, bases, boff = util.load_case("synth_illumina_k40_t1_T4")
+    k = case["k"]
+    with fastk_amd.Context(kmer=k, table_cutoff=1, nbuckets=3, hbm_budget=1 << 30) as ctx:
+        ctx.debug_set("chunk_bytes", len(bases) // 4)
+        ctx.push_block(bases, boff.astype(np.int32))
+        res = ctx.finish()
+        util.check_against_golden(case, res.hist, res.max_inst, res.table)
+        with pytest.raises(fastk_amd.FastKError):
+            ctx.make_profiles()
+        got = []
+        nreads = len(boff) - 1
+        for lo in range(0, nreads, 7001):
+            hi = min(nreads, lo + 7001)
+            piece = np.ascontiguousarray(bases[boff[lo]:boff[hi]])
+            buf = ctx.alloc(len(piece) + 64).upload(piece)
+            data, offs = ctx.make_profiles(buf.ptr, len(piece))
+            raw = data.tobytes()
+            got += [orc.profile_decode(raw[offs[i]:offs[i + 1]]) for i in range(len(offs) - 1)]
+            buf.free()
+    assert len(got) == nreads
+    assert orc.profiles_digest(got) == case["expected"]["prof"]["decoded_sha256"]
