@@ -59,7 +59,7 @@ class CResult(C.Structure):
 
 class CProfiles(C.Structure):
     _fields_ = [("nreads", C.c_int64), ("nbytes", C.c_int64), ("data", C.POINTER(C.c_uint8)),
-                ("offsets", C.POINTER(C.c_int64))]
+                ("offsets", C.POINTER(C.c_int64)), ("nsplit", C.c_int), ("split", C.POINTER(C.c_int64))]
 
 
 class SortStats(C.Structure):

@@ -276,6 +276,8 @@ extern "C" void fk_destroy(fk_ctx *ctx)
   hipFree(ctx->d_reads);
   free(ctx->h_prof);
   free(ctx->h_prof_off);
+  free(ctx->h_prof_split);
+  free(ctx->blocks);
   for (int i = 0; i < FK_NSLOTS; i++)
     if (ctx->slot_ptr[i] != NULL)
       hipFree(ctx->slot_ptr[i]);
@@ -761,7 +763,7 @@ static int flush_chunk(fk_ctx *ctx)
 
 extern "C" int fk_push_block(fk_ctx *ctx, const char *bases, const int32_t *boff, int nreads,
                              int rem, int tid)
-{ (void) rem; (void) tid;
+{ (void) rem;
   if (ctx == NULL || bases == NULL || boff == NULL || nreads < 0) return (FK_EINVAL);
   if (nreads == 0)
     return (FK_OK);
@@ -820,6 +822,14 @@ extern "C" int fk_push_block(fk_ctx *ctx, const char *bases, const int32_t *boff
         }
       ctx->reads_len += len;
       ctx->stage_idx ^= 1;
+      if (ctx->nblocks == ctx->blocks_cap)
+        { ctx->blocks_cap = ctx->blocks_cap * 2 + 256;
+          ctx->blocks = (fk_block *) realloc(ctx->blocks, sizeof(fk_block) * (size_t) ctx->blocks_cap);
+          if (ctx->blocks == NULL) { ctx->nblocks = ctx->blocks_cap = 0; rc = FK_ENOMEM; break; }
+        }
+      ctx->blocks[ctx->nblocks].tid = tid;
+      ctx->blocks[ctx->nblocks].nreads = nreads;
+      ctx->nblocks += 1;
       if (ctx->chunk_bytes > 0 && ctx->reads_len >= ctx->chunk_bytes)
         rc = flush_chunk(ctx);
     }
@@ -859,6 +869,7 @@ extern "C" int fk_push_device(fk_ctx *ctx, const void *d_bases, int64_t nbytes)
     { fk_set_error(ctx, "fk_push_device: -bc and exact_parts need read offsets; use fk_push_block");
       return (FK_EUNSUPPORTED);
     }
+  ctx->blocks_bad = true;
   int rc;
   pthread_mutex_lock((pthread_mutex_t *) ctx->push_lock);
   if ((rc = reserve_reads(ctx, nbytes + 1)) == FK_OK)
@@ -887,6 +898,7 @@ extern "C" int fk_push_fastq(fk_ctx *ctx, const char *raw, int64_t nbytes, int f
     { fk_set_error(ctx, "fk_push_fastq: -bc and exact_parts need read offsets; use fk_push_block");
       return (FK_EUNSUPPORTED);
     }
+  ctx->blocks_bad = true;
   if (nbytes == 0)
     return (FK_OK);
   int rc;
@@ -931,6 +943,7 @@ extern "C" int fk_push_fasta(fk_ctx *ctx, const char *raw, int64_t nbytes, int l
     { fk_set_error(ctx, "fk_push_fasta: -bc and exact_parts need read offsets; use fk_push_block");
       return (FK_EUNSUPPORTED);
     }
+  ctx->blocks_bad = true;
   int rc = FK_OK;
   pthread_mutex_lock((pthread_mutex_t *) ctx->push_lock);
   do
@@ -1618,6 +1631,7 @@ extern "C" int fk_make_profiles(fk_ctx *ctx, const void *d_bases, int64_t nbytes
     { fk_set_error(ctx, "fk_make_profiles: not available together with bc_prefix");
       return (FK_EUNSUPPORTED);
     }
+  const bool own_reads = (d_bases == NULL);
   if (d_bases == NULL)
     { if (ctx->chunk_bytes > 0)
         { fk_set_error(ctx, "fk_make_profiles: the reads of a chunked run are not kept -- pass them again piece by piece");
@@ -1652,10 +1666,66 @@ extern "C" int fk_make_profiles(fk_ctx *ctx, const void *d_bases, int64_t nbytes
                                  ctx->stream));
       FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
+  // Blocks pushed by several input threads interleave in HBM; the data set's read order is thread 0's
+  // reads, then thread 1's, ... (io.c gives every thread a contiguous range of the input), and the
+  // reference's part files are exactly those ranges.
+  ctx->h_prof_nsplit = 0;
+  if (own_reads && !ctx->blocks_bad && ctx->nblocks > 0)
+    { int64_t tot = 0;
+      int     maxtid = 0;
+      bool    sorted = true;
+      for (int64_t b = 0; b < ctx->nblocks; b++)
+        { tot += ctx->blocks[b].nreads;
+          if (ctx->blocks[b].tid > maxtid) maxtid = ctx->blocks[b].tid;
+          if (b > 0 && ctx->blocks[b].tid < ctx->blocks[b - 1].tid) sorted = false;
+          if (ctx->blocks[b].tid < 0) tot = -1 - nreads;
+        }
+      if (tot == nreads && maxtid < 4096)
+        { const int nt = maxtid + 1;
+          free(ctx->h_prof_split);
+          ctx->h_prof_split = (int64_t *) calloc((size_t) nt + 1, sizeof(int64_t));
+          if (ctx->h_prof_split == NULL) return (FK_ENOMEM);
+          for (int64_t b = 0; b < ctx->nblocks; b++)
+            ctx->h_prof_split[ctx->blocks[b].tid + 1] += ctx->blocks[b].nreads;
+          for (int t = 0; t < nt; t++)
+            ctx->h_prof_split[t + 1] += ctx->h_prof_split[t];
+          ctx->h_prof_nsplit = nt;
+          if (!sorted)
+            { uint8_t *nd = (uint8_t *) malloc((size_t) nprof + 1);
+              int64_t *no = (int64_t *) malloc(sizeof(int64_t) * (size_t) (nreads + 1));
+              std::vector<int64_t> cur(ctx->h_prof_split, ctx->h_prof_split + nt);   // next read slot per thread
+              std::vector<int64_t> len((size_t) nreads);
+              if (nd == NULL || no == NULL) { free(nd); free(no); return (FK_ENOMEM); }
+              int64_t r = 0;
+              for (int64_t b = 0; b < ctx->nblocks; b++)       // lengths into their final slots
+                for (int64_t i = 0; i < ctx->blocks[b].nreads; i++, r++)
+                  len[(size_t) cur[ctx->blocks[b].tid]++] = ctx->h_prof_off[r + 1] - ctx->h_prof_off[r];
+              no[0] = 0;
+              for (int64_t i = 0; i < nreads; i++)
+                no[i + 1] = no[i] + len[(size_t) i];
+              for (int t = 0; t < nt; t++)
+                cur[(size_t) t] = ctx->h_prof_split[t];
+              r = 0;
+              for (int64_t b = 0; b < ctx->nblocks; b++)
+                { const int64_t n = ctx->blocks[b].nreads;
+                  if (n == 0) continue;
+                  const int64_t dst = cur[(size_t) ctx->blocks[b].tid];
+                  memcpy(nd + no[dst], ctx->h_prof + ctx->h_prof_off[r],
+                         (size_t) (ctx->h_prof_off[r + n] - ctx->h_prof_off[r]));
+                  cur[(size_t) ctx->blocks[b].tid] += n;
+                  r += n;
+                }
+              free(ctx->h_prof);     ctx->h_prof = nd;      ctx->h_prof_cap = nprof + 1;
+              free(ctx->h_prof_off); ctx->h_prof_off = no;  ctx->h_prof_off_cap = nreads + 1;
+            }
+        }
+    }
   out->nreads  = nreads;
   out->nbytes  = nprof;
   out->data    = ctx->h_prof;
   out->offsets = ctx->h_prof_off;
+  out->nsplit  = ctx->h_prof_nsplit;
+  out->split   = ctx->h_prof_nsplit > 0 ? ctx->h_prof_split : NULL;
   return (FK_OK);
 }
 
@@ -1675,7 +1745,9 @@ extern "C" int fk_write_prof(const fk_profiles *p, int kmer, int nparts, const c
   int bad = write_all(fd, stub, 8);
   close(fd);
   for (int t = 0; t < nparts && !bad; t++)
-    { const int64_t r0 = p->nreads * t / nparts, r1 = p->nreads * (t + 1) / nparts;
+    { const bool by_thread = (p->nsplit == nparts && p->split != NULL);
+      const int64_t r0 = by_thread ? p->split[t] : p->nreads * t / nparts;
+      const int64_t r1 = by_thread ? p->split[t + 1] : p->nreads * (t + 1) / nparts;
       const int64_t n = r1 - r0;
       const int64_t b0 = (n > 0) ? p->offsets[r0] : 0;
       snprintf(path, sizeof(path), "%s/.%s.pidx.%d", dir, root, t + 1);

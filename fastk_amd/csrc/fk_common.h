@@ -23,6 +23,11 @@ struct fk_chunk
   int      on_host;         // records live in pinned host memory (spilled), not in HBM
 };
 
+struct fk_block       // one fk_push_block call: which input thread, how many reads
+{ int      tid;
+  int64_t  nreads;
+};
+
 struct fk_ctx
 { fk_params  prm;
   fk_widths  wid;
@@ -59,6 +64,11 @@ struct fk_ctx
   void      *last_table;   // sorted table of the last resident run (HBM), for fk_make_profiles
   int64_t    last_ntab;
   bool       have_table;
+  struct fk_block *blocks;  // push history (for the read order of the profiles)
+  int64_t    nblocks, blocks_cap;
+  bool       blocks_bad;    // reads also arrived through calls that carry no thread id
+  int64_t   *h_prof_split; // reads of input thread t start at h_prof_split[t]
+  int        h_prof_nsplit;
   uint8_t   *h_prof;       // profiles of fk_make_profiles (host)
   int64_t   *h_prof_off;
   int64_t    h_prof_cap, h_prof_off_cap;

@@ -1,5 +1,5 @@
-/* gpu_path.c -- the shim of INTEGRATION.md, compilable: it replaces split.c, count.c, table.c and
- * MSDsort.c in a build of the REFERENCE FastK (FastK.c, io.c, merge.c, LSDsort.c, libfastk.c stay
+/* gpu_path.c -- the shim of INTEGRATION.md, compilable: it replaces split.c, count.c, table.c,
+ * merge.c and MSDsort.c in a build of the REFERENCE FastK (FastK.c, io.c, LSDsort.c, libfastk.c stay
  * as they are), so that the reference's own main(), option parsing and input layer drive the GPU
  * path through the C-ABI.  Built only where the reference sources are present (target ref_gpu of
  * the test-infrastructure Makefile); tests/test_gpu_parity.py runs the result as the end-to-end
@@ -31,12 +31,13 @@ int Determine_Scheme(DATA_BLOCK *block)
   fk_widths w;
 
   (void) block;
-  if (DO_PROFILE || PRO_TABLE != NULL || COMPRESS)
-    { fprintf(stderr,"%s: -p and -c are not built on the GPU path\n",Prog_Name);
+  if (COMPRESS || (DO_PROFILE && BC_PREFIX > 0))
+    { fprintf(stderr,"%s: -c, and -p together with -bc, are not built on the GPU path\n",Prog_Name);
       Clean_Exit(1);
     }
   fk_default_params(&p);
-  p.kmer = KMER; p.table_cutoff = DO_TABLE; p.nthreads = NTHREADS; p.bc_prefix = BC_PREFIX;
+  p.kmer = KMER; p.nthreads = NTHREADS; p.bc_prefix = BC_PREFIX;
+  p.table_cutoff = DO_PROFILE ? 1 : DO_TABLE;      /* profiles look every k-mer up in the table */
   p.exact_parts = 1;
   if (fk_create(&p,&GPU) != FK_OK)
     die("fk_create");
@@ -59,28 +60,64 @@ void Distribute_Block(DATA_BLOCK *block, int tid)
     die("fk_push_block");
 }
 
+/* replaces Split_Table (split.c:1943): the relative table needs no redistribution here, it becomes
+   the dictionary of the look-ups in Sorting */
 void Split_Table(char *root)
-{ (void) root;
-  fprintf(stderr,"%s: -p:table is not built on the GPU path\n",Prog_Name);
-  Clean_Exit(1);
-}
+{ (void) root; }
 
-/* replaces Sorting (count.c:1202) */
+/* replaces Sorting (count.c:1202), including its profile half (count.c:639-1181) */
 void Sorting(char *path, char *root)
 { char *name = malloc(strlen(path)+strlen(root)+10);
 
-  if (fk_finish(GPU,&RES) != FK_OK)
-    die("fk_finish");
-  sprintf(name,"%s/%s.hist",path,root);
-  if (fk_write_hist(&RES,KMER,name) != FK_OK)
-    die("writing .hist");
+  if (PRO_TABLE == NULL)
+    { if (fk_finish(GPU,&RES) != FK_OK)
+        die("fk_finish");
+      sprintf(name,"%s/%s.hist",path,root);
+      if (fk_write_hist(&RES,KMER,name) != FK_OK)
+        die("writing .hist");
+    }
+  else
+    { /* -p:<table>: only profiles, counts from the given table (README.md:112-120) */
+      int      tb = PRO_TABLE->tbyte;
+      uint8   *recs = malloc((size_t) (PRO_TABLE->nels > 0 ? PRO_TABLE->nels : 1)*tb);
+      int64    n = 0;
+      if (recs == NULL)
+        { fprintf(stderr,"%s: Out of memory\n",Prog_Name); Clean_Exit(1); }
+      for (First_Kmer_Entry(PRO_TABLE); PRO_TABLE->csuf != NULL; Next_Kmer_Entry(PRO_TABLE))
+        Current_Entry(PRO_TABLE,recs+(n++)*tb);
+      if (fk_set_table(GPU,recs,n) != FK_OK)
+        die("fk_set_table");
+      free(recs);
+    }
+  if (DO_PROFILE)
+    { fk_profiles pr;
+      if (fk_make_profiles(GPU,NULL,0,&pr) != FK_OK)
+        die("fk_make_profiles");
+      if (fk_write_prof(&pr,KMER,NTHREADS,path,root) != FK_OK)
+        die("writing .prof");
+    }
   free(name);
 }
 
 /* replaces Merge_Tables (table.c:346) */
 void Merge_Tables(char *path, char *root)
-{ if (fk_write_ktab(&RES,KMER,DO_TABLE,NTHREADS,path,root) != FK_OK)
+{ if (DO_PROFILE && DO_TABLE > 1)       /* counted with cutoff 1 for the look-ups: keep count >= -t */
+    { int      kw = ((2*KMER+7)>>3) + 2;
+      const uint8 *t = RES.table;
+      uint8   *keep = malloc((size_t) (RES.ntable > 0 ? RES.ntable : 1)*kw);
+      int64    n = 0, x;
+      if (keep == NULL)
+        { fprintf(stderr,"%s: Out of memory\n",Prog_Name); Clean_Exit(1); }
+      for (x = 0; x < RES.ntable; x++)
+        if ((t[x*kw+kw-2] | (t[x*kw+kw-1] << 8)) >= DO_TABLE)
+          memcpy(keep+(n++)*kw,t+x*kw,(size_t) kw);
+      RES.table  = keep;
+      RES.ntable = n;
+    }
+  if (fk_write_ktab(&RES,KMER,DO_TABLE,NTHREADS,path,root) != FK_OK)
     die("writing .ktab");
-  fk_destroy(GPU);
-  GPU = NULL;
 }
+
+/* replaces Merge_Profiles (merge.c): the profiles were written in read order by Sorting */
+void Merge_Profiles(char *path, char *root)
+{ (void) path; (void) root; }

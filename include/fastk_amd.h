@@ -283,12 +283,18 @@ int fk_write_ktab_ex(const fk_result *res, int kmer, int table_cutoff, int nthre
  * chunked run (hbm_budget > 0), whose reads were dropped on the way, the caller passes them again
  * piece by piece (whole reads per piece) and concatenates the results.  Reads end at 0 bytes
  * (a last read without one ends at nbytes); other non-acgt bytes stay inside their read.
- * data / offsets are host memory owned by ctx, valid until the next call or fk_destroy. */
+ * Read order: blocks pushed with distinct tid interleave arbitrarily in time; the profiles come out
+ * in the data set's order -- all reads of tid 0 in push order, then tid 1, ... (io.c hands every
+ * input thread a contiguous range of the input, io.c:2455-2521) -- and split[] gives those ranges,
+ * which are the reference's part files when fk_write_prof is called with nparts = nsplit.
+ * data / offsets / split are host memory owned by ctx, valid until the next call or fk_destroy. */
 typedef struct
   { int64_t        nreads;
     int64_t        nbytes;     /* total compressed bytes                                   */
     const uint8_t *data;       /* profile of read i = data[offsets[i] .. offsets[i+1])     */
     const int64_t *offsets;    /* nreads + 1 entries, offsets[0] = 0                       */
+    int            nsplit;     /* input threads seen by fk_push_block (0: not applicable)  */
+    const int64_t *split;      /* reads of thread t: split[t] .. split[t+1] (nsplit + 1)   */
   } fk_profiles;
 
 int fk_make_profiles(fk_ctx *ctx, const void *d_bases, int64_t nbytes, fk_profiles *out);
@@ -302,7 +308,8 @@ int fk_make_profiles(fk_ctx *ctx, const void *d_bases, int64_t nbytes, fk_profil
 int fk_set_table(fk_ctx *ctx, const uint8_t *records, int64_t n);
 
 /* <dir>/<root>.prof stub + hidden .<root>.pidx.N / .<root>.prof.N, N = 1..nparts (README.md:1010-1027);
-   the reads are divided evenly over the parts in input order. */
+   part t holds the reads of input thread t when nparts == p->nsplit, else the reads are divided evenly
+   over the parts in input order. */
 int fk_write_prof(const fk_profiles *p, int kmer, int nparts, const char *dir, const char *root);
 
 /* The records a rank owns, counted piece by piece (one piece per exchange round of the sharded run,

@@ -886,6 +886,39 @@ def test_reference_main_over_gpu_shim(name, fmt, tmp_path):
         assert got == digest, fname
 
 
+@pytest.mark.parametrize("name", ["edge_k40_t4_T1", "synth_illumina_k40_t1_T4", "synth_hifi_k40_t4_T8"])
+def test_reference_main_with_profiles_over_gpu_shim(name, tmp_path):
+    """The reference's main() with -p on the GPU path: .hist and every .ktab file are still the
+    reference's bytes (table filtered to -t on the way out), the profiles decode to the reference's
+    (golden digest), and -p:<table> of the same reads against that table gives its counts."""
+    import hashlib, os, subprocess
+    exe = os.path.join(orc.REF_DIR, "FastK_gpu")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/FastK_gpu not built (needs the reference sources at build time)")
+    case, bases, boff = util.load_case(name)
+    k = case["k"]
+    path = str(tmp_path / "x.fasta")
+    orc.write_fasta(path, bases, boff, width=0 if case["kind"] == "edge" else 100)
+    subprocess.run([exe, "-k%d" % k, "-t%d" % case["cutoff"], "-T%d" % case["T"], "-p",
+                    "-P" + str(tmp_path), path], check=True, cwd=str(tmp_path),
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    for fname, digest in case["expected"]["file_sha256"].items():
+        assert hashlib.sha256(open(tmp_path / fname, "rb").read()).hexdigest() == digest, fname
+    kk, enc = orc.read_profiles(str(tmp_path), "x")
+    assert kk == k and len(enc) == case["expected"]["prof"]["nreads"]
+    assert orc.profiles_digest([orc.profile_decode(e) for e in enc]) == case["expected"]["prof"]["decoded_sha256"]
+    # relative to its own cutoff-t table: counts below the cutoff read as 0
+    rel = str(tmp_path / "y.fasta")
+    os.link(path, rel)
+    subprocess.run([exe, "-k%d" % k, "-T2", "-p:x", "-P" + str(tmp_path), rel], check=True, cwd=str(tmp_path),
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    assert not os.path.exists(tmp_path / "y.hist")
+    k2, renc = orc.read_profiles(str(tmp_path), "y")
+    full = [orc.profile_decode(e) for e in enc]
+    want = [[c if c >= case["cutoff"] else 0 for c in r] for r in full]
+    assert [orc.profile_decode(e) for e in renc] == want
+
+
 def test_trained_bucket_assignment_balances_and_keeps_results():
     """fk_bucket_census + fk_set_bucket_weights: the buckets get within a few percent of each other
     and the bucket-streamed result is still the reference's (any assignment is valid)."""
@@ -1148,3 +1181,31 @@ def test_profiles_after_chunked_run_piece_by_piece():
             buf.free()
     assert len(got) == nreads
     assert orc.profiles_digest(got) == case["expected"]["prof"]["decoded_sha256"]
+
+
+def test_profiles_follow_input_thread_order(tmp_path):
+    """Blocks of three input threads pushed interleaved (what io.c's threads do): profiles come out in
+    data-set order (thread 0's reads, then thread 1's, ...) and the part files are the threads' ranges."""
+    import struct
+    case, bases, boff = util.load_case("synth_illumina_k40_t1_T4")
+    k = case["k"]
+    nreads = len(boff) - 1
+    cuts = [0, nreads // 5, nreads // 2, nreads]                  # uneven thread ranges
+    cur = cuts[:3]
+    with fastk_amd.Context(kmer=k, table_cutoff=1, nthreads=3) as ctx:
+        step = 611
+        while any(cur[t] < cuts[t + 1] for t in range(3)):
+            for t in (2, 0, 1):
+                lo, hi = cur[t], min(cuts[t + 1], cur[t] + step)
+                if lo < hi:
+                    ctx.push_block(bases[boff[lo]:boff[hi]], (boff[lo:hi + 1] - boff[lo]).astype(np.int32), tid=t)
+                    cur[t] = hi
+        ctx.finish()
+        data, offs = ctx.make_profiles(outdir=str(tmp_path), root="x", nparts=3)
+    raw = data.tobytes()
+    got = [orc.profile_decode(raw[offs[i]:offs[i + 1]]) for i in range(nreads)]
+    assert orc.profiles_digest(got) == case["expected"]["prof"]["decoded_sha256"]
+    for t in range(3):
+        px = open(tmp_path / (".x.pidx.%d" % (t + 1)), "rb").read()
+        b, n = struct.unpack("<qq", px[4:20])
+        assert (b, n) == (cuts[t], cuts[t + 1] - cuts[t])
