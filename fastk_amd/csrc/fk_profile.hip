@@ -10,7 +10,7 @@
 //   k_pf_zeros   positions of the read terminators (0 bytes) -> read boundaries
 //   k_pf_encode  one thread per read: length pass, then emit pass of the codec
 // The codec output is the canonical one-byte-wherever-possible stream; it decodes to the same counts
-// as the reference's files, whose run splits follow the reference's internal super-mer cuts.
+// as the reference's files, whose run splits follow the reference's internal work panels (merge.c:65,711).
 #include "fk_common.h"
 
 #define PF_TILE  4096

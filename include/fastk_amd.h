@@ -275,7 +275,8 @@ int fk_write_ktab_ex(const fk_result *res, int kmer, int table_cutoff, int nthre
  * order, the counts of its k-mers (0 where the k-mer contains a non-acgt base, capped at 32767),
  * compressed with the codec of README.md:1029-1069.  The bytes are the canonical
  * one-byte-form-whenever-possible stream; they decode (libfastk.c:1657, Fetch_Profile) to the same
- * counts as the reference's files, whose zero-run splits follow its internal super-mer cuts.
+ * counts as the reference's files, whose zero-run splits follow its internal work panels
+ * (merge.c:65,711-716).
  *
  * fk_make_profiles runs after fk_finish / fk_count_device_reads with table_cutoff 1 -- the table
  * left in HBM is the dictionary.  d_bases NULL: the reads pushed into the context (resident runs,

@@ -395,9 +395,9 @@ def run_ref_fastk(fastx_path, kmer, cutoff, nthreads, workdir, extra=()):
 # Restatement of what a profile IS (README.md:1010-1069): per read, the count of every k-mer in
 # read order, 0 where the k-mer holds a non-acgt base, counts capped at 32767 -- computed here from
 # the oracle's cutoff-1 table.  The reference assembles the same numbers from per-super-mer
-# fragments (count.c:868-947) that merge.c stitches into read order; its byte stream splits zero
-# runs at those fragment boundaries (and writes a junction d = -31 in two bytes, merge.c:456,590),
-# so parity with the
+# fragments (count.c:868-947) that merge.c stitches into read order; its byte stream flushes the
+# pending zero run at every panel of 1024*NPARTS fragments (merge.c:65,711-716) and writes a junction
+# d = -31 in two bytes (merge.c:456,590), so parity with the
 # reference is on the DECODED counts (libfastk.c:1657 Fetch_Profile is the decoder restated below).
 
 _CODE = np.full(256, 4, dtype=np.uint8)
