@@ -6,6 +6,7 @@ missing or no MI355X is visible, calls raise FastKError.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -24,7 +25,8 @@ EXPORTS = [
     "fk_train_block", "fk_count_unsorted_kmers", "fk_debug_get", "fk_push_fastq", "fk_host_alloc",
     "fk_host_free", "fk_bucket_census", "fk_set_bucket_weights", "fk_push_fasta", "fk_merge_tables",
     "fk_write_ktab_ex", "fk_rounds_begin", "fk_rounds_add", "fk_rounds_finish",
-    "fk_make_profiles", "fk_write_prof", "fk_set_table",
+    "fk_make_profiles", "fk_write_prof", "fk_set_table", "fk_ktab_idx_bytes", "fk_ktab_split",
+    "fk_write_ktab_range", "fk_write_ktab_stub",
 ]
 
 
@@ -79,6 +81,15 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise FastKError("%s is missing: build it with `make -C fastk_amd/csrc` "
                          "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+    # PyTorch-ROCm ships its own copy of the HIP runtime.  A process that loads this library first
+    # (binding /opt/rocm's runtime) and imports torch afterwards ends up with two runtimes, and the second
+    # one finds no usable GPU ("No HIP GPUs are available").  Importing torch first makes the dynamic
+    # linker resolve both to one runtime, whatever order the caller uses later.
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(LIB_PATH)
     vp, i64, ci = C.c_void_p, C.c_int64, C.c_int
     L.fk_get_widths.argtypes = [ci, C.POINTER(Widths)]
@@ -127,6 +138,10 @@ def load_library():
     L.fk_make_profiles.argtypes = [vp, vp, i64, C.POINTER(CProfiles)]
     L.fk_set_table.argtypes = [vp, vp, i64]
     L.fk_write_prof.argtypes = [C.POINTER(CProfiles), ci, ci, C.c_char_p, C.c_char_p]
+    L.fk_ktab_idx_bytes.argtypes = [ci, i64]
+    L.fk_ktab_split.argtypes = [C.POINTER(i64), ci, ci, C.POINTER(ci)]
+    L.fk_write_ktab_range.argtypes = [vp, i64, ci, ci, C.POINTER(ci), ci, ci, C.c_char_p, C.c_char_p, vp]
+    L.fk_write_ktab_stub.argtypes = [ci, ci, ci, ci, vp, C.c_char_p, C.c_char_p]
     L.fk_rounds_begin.argtypes = [vp]
     L.fk_rounds_add.argtypes = [vp, vp, i64]
     L.fk_rounds_finish.argtypes = [vp, C.c_int, C.POINTER(CResult)]
@@ -475,4 +490,40 @@ def write_files(kmer, table_cutoff, nthreads, hist, max_inst, table, outdir, roo
         raise FastKError(L.fk_last_error(None).decode())
     if table_cutoff > 0 and L.fk_write_ktab(C.byref(r), kmer, table_cutoff, nthreads, outdir.encode(),
                                             root.encode()) != 0:
+        raise FastKError(L.fk_last_error(None).decode())
+
+
+# ---- one table written by several ranks (host-only C code behind these) ------------------------
+
+def ktab_idx_bytes(kmer, ntable):
+    return int(load_library().fk_ktab_idx_bytes(kmer, int(ntable)))
+
+
+def ktab_split(wfirst, kmer, nparts):
+    """First-byte boundaries of nparts parts (Table_Split) from the summed weighted k-mer census."""
+    w = (C.c_int64 * 256)(*[int(x) for x in wfirst])
+    out = (C.c_int * (nparts + 1))()
+    if load_library().fk_ktab_split(w, kmer, nparts, out) != 0:
+        raise FastKError("fk_ktab_split failed")
+    return list(out)
+
+
+def write_ktab_range(records, kmer, idx_bytes, split, part0, nhere, outdir, root):
+    """Writes parts part0 .. part0+nhere-1 from sorted (n, KMER_WORD) records; returns the per-prefix
+    entry counts (int64[256**idx_bytes]) of what was written."""
+    L = load_library()
+    a = np.ascontiguousarray(records, dtype=np.uint8)
+    sp = (C.c_int * len(split))(*split)
+    cnt = np.zeros(256 ** idx_bytes, dtype=np.int64)
+    if L.fk_write_ktab_range(a.ctypes.data if a.shape[0] else None, a.shape[0], kmer, idx_bytes, sp, part0,
+                             nhere, outdir.encode(), root.encode(), cnt.ctypes.data) != 0:
+        raise FastKError(L.fk_last_error(None).decode())
+    return cnt
+
+
+def write_ktab_stub(kmer, nparts, table_cutoff, idx_bytes, prefix_counts, outdir, root):
+    L = load_library()
+    c = np.ascontiguousarray(prefix_counts, dtype=np.int64)
+    if L.fk_write_ktab_stub(kmer, nparts, table_cutoff, idx_bytes, c.ctypes.data, outdir.encode(),
+                            root.encode()) != 0:
         raise FastKError(L.fk_last_error(None).decode())

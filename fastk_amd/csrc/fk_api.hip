@@ -1632,6 +1632,10 @@ extern "C" int fk_make_profiles(fk_ctx *ctx, const void *d_bases, int64_t nbytes
       return (FK_EUNSUPPORTED);
     }
   const bool own_reads = (d_bases == NULL);
+  if (((uintptr_t) d_bases & 15) != 0)
+    { fk_set_error(ctx, "fk_make_profiles: d_bases must be 16-byte aligned");
+      return (FK_EINVAL);
+    }
   if (d_bases == NULL)
     { if (ctx->chunk_bytes > 0)
         { fk_set_error(ctx, "fk_make_profiles: the reads of a chunked run are not kept -- pass them again piece by piece");
@@ -1805,108 +1809,149 @@ extern "C" int fk_write_ktab(const fk_result *res, int kmer, int table_cutoff, i
                              const char *dir, const char *root)
 { return fk_write_ktab_ex(res, kmer, table_cutoff, nthreads, 0, dir, root); }
 
+// ---- .ktab writing, in pieces so that several ranks can each write the parts they hold ------------
+
+extern "C" int fk_ktab_idx_bytes(int kmer, int64_t ntable)       // count.c:1620-1626
+{ if (ntable > 0x4000000ll && kmer >= 12) return (3);
+  if (ntable >= 0x40000ll && kmer >= 8) return (2);
+  return (1);
+}
+
+// Table_Split (count.c:1560-1565 with MSDsort.c:330-352): first-byte boundaries of nparts parts that
+// balance the weighted k-mer census; split[t] .. split[t+1] is part t's first-byte range
+extern "C" int fk_ktab_split(const int64_t *wfirst, int kmer, int nparts, int *split)
+{ fk_widths w;
+  if (wfirst == NULL || split == NULL || nparts < 1 || fk_get_widths(kmer, &w) != FK_OK)
+    return (FK_EINVAL);
+  const int KW = w.kmer_word;
+  int64_t asize = 0, sum = 0;
+  for (int x = 0; x < 256; x++)
+    asize += wfirst[x] * KW;
+  int64_t thr = asize / nparts;
+  int n = 0, beg = 0;
+  for (int x = 0; x < 256; x++)
+    { sum += wfirst[x] * KW;
+      if (sum >= thr && n < nparts)
+        { split[n++] = beg;
+          thr = (asize * (n + 1)) / nparts;
+          beg = x + 1;
+        }
+    }
+  while (n < nparts)
+    split[n++] = 256;
+  split[nparts] = 256;
+  return (FK_OK);
+}
+
+// Parts part0 .. part0+nhere-1 of a table from the sorted records that fall into their first-byte
+// ranges (records outside are ignored); prefix_counts[p] is incremented for every record written
+extern "C" int fk_write_ktab_range(const uint8_t *records, int64_t n, int kmer, int idx_bytes, const int *split,
+                                   int part0, int nhere, const char *dir, const char *root,
+                                   int64_t *prefix_counts)
+{ fk_widths w;
+  if (dir == NULL || root == NULL || split == NULL || prefix_counts == NULL || nhere < 0 || part0 < 0
+      || idx_bytes < 1 || idx_bytes > 3 || n < 0 || (n > 0 && records == NULL)
+      || fk_get_widths(kmer, &w) != FK_OK)
+    return (FK_EINVAL);
+  const int KW = w.kmer_word, ib = idx_bytes;
+  // part boundaries by binary search on the first byte, then one writer thread per part: the parts
+  // are disjoint first-byte ranges, so their prefix-index entries are disjoint as well
+  std::vector<int64_t> bound((size_t) nhere + 1, 0);
+  for (int t = 0; t <= nhere; t++)
+    { int64_t lo = (t > 0) ? bound[t - 1] : 0, hi = n;
+      while (lo < hi)
+        { const int64_t mid = (lo + hi) >> 1;
+          if (records[mid * KW] < split[part0 + t]) lo = mid + 1; else hi = mid;
+        }
+      bound[t] = lo;
+    }
+  std::vector<int> prc((size_t) (nhere > 0 ? nhere : 1), FK_OK);
+  auto write_part = [&](int t)
+    { const int64_t lo = bound[t], hi = bound[t + 1], cnt = hi - lo;
+      char pname[4096];
+      snprintf(pname, sizeof(pname), "%s/.%s.ktab.%d", dir, root, part0 + t + 1);
+      int fd = open(pname, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+      if (fd < 0) { prc[t] = FK_EINVAL; return; }
+      const int pw = KW - ib;
+      uint8_t *buf = (uint8_t *) malloc((size_t) (cnt > 0 ? cnt : 1) * pw);
+      if (buf == NULL) { close(fd); prc[t] = FK_ENOMEM; return; }
+      for (int64_t i = lo; i < hi; i++)
+        { const uint8_t *rec = records + i * KW;
+          int64_t pre = 0;
+          for (int b = 0; b < ib; b++)
+            pre = (pre << 8) | rec[b];
+          prefix_counts[pre] += 1;
+          memcpy(buf + (i - lo) * pw, rec + ib, pw);
+        }
+      if (write_all(fd, &kmer, 4) | write_all(fd, &cnt, 8) | write_all(fd, buf, (size_t) cnt * pw))
+        prc[t] = FK_EINVAL;
+      free(buf);
+      close(fd);
+    };
+  if (nhere > 0)
+    { std::vector<std::thread> th;
+      for (int t = 1; t < nhere; t++)
+        th.emplace_back(write_part, t);
+      write_part(0);
+      for (auto &x : th)
+        x.join();
+    }
+  for (int t = 0; t < nhere; t++)
+    if (prc[t] != FK_OK)
+      { fk_set_error(NULL, "Cannot write to %s/.%s.ktab.%d.  Enough disk space?", dir, root, part0 + t + 1);
+        return (prc[t]);
+      }
+  return (FK_OK);
+}
+
+// <root>.ktab: k, parts, cutoff, index width, cumulative prefix index (README.md:965-985) from the
+// per-prefix counts summed over all parts
+extern "C" int fk_write_ktab_stub(int kmer, int nparts, int table_cutoff, int idx_bytes,
+                                  const int64_t *prefix_counts, const char *dir, const char *root)
+{ if (dir == NULL || root == NULL || prefix_counts == NULL || idx_bytes < 1 || idx_bytes > 3 || nparts < 1)
+    return (FK_EINVAL);
+  const int64_t nidx = 1ll << (8 * idx_bytes);
+  int64_t *idx = (int64_t *) malloc((size_t) nidx * sizeof(int64_t));
+  if (idx == NULL) return (FK_ENOMEM);
+  int64_t run = 0;
+  for (int64_t i = 0; i < nidx; i++)
+    { run += prefix_counts[i];
+      idx[i] = run;
+    }
+  char name[4096];
+  snprintf(name, sizeof(name), "%s/%s.ktab", dir, root);
+  int rc = FK_OK;
+  int fd = open(name, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+  if (fd < 0)
+    rc = FK_EINVAL;
+  else
+    { int32_t h[4] = { kmer, nparts, table_cutoff, idx_bytes };
+      if (write_all(fd, h, 16) | write_all(fd, idx, (size_t) nidx * 8))
+        rc = FK_EINVAL;
+      close(fd);
+    }
+  free(idx);
+  if (rc != FK_OK)
+    fk_set_error(NULL, "Cannot write to %s.  Enough disk space?", name);
+  return (rc);
+}
+
 // idx_bytes 1..3 fixes the prefix-index width (Fastmerge chooses it from the number of INPUT entries,
 // Fastmerge.c:742-756); 0 = FastK's rule on the table size (count.c:1620-1626)
 extern "C" int fk_write_ktab_ex(const fk_result *res, int kmer, int table_cutoff, int nthreads,
                                 int idx_bytes, const char *dir, const char *root)
 { if (res == NULL || dir == NULL || root == NULL || nthreads < 1 || table_cutoff < 1)
     return (FK_EINVAL);
-  fk_widths w;
-  if (fk_get_widths(kmer, &w) != FK_OK) return (FK_EINVAL);
   if (res->ntable > 0 && res->table == NULL) return (FK_EINVAL);
-  const int KW = w.kmer_word;
-  int ib;                                                   // count.c:1620-1626
-  if (idx_bytes >= 1 && idx_bytes <= 3) ib = idx_bytes;
-  else if (res->ntable > 0x4000000ll && kmer >= 12) ib = 3;
-  else if (res->ntable >= 0x40000ll && kmer >= 8) ib = 2;
-  else ib = 1;
-
-  int *split = (int *) malloc(sizeof(int) * (nthreads + 1));
-  { int64_t asize = 0, sum = 0;
-    for (int x = 0; x < 256; x++)
-      asize += res->wfirst[x] * KW;
-    int64_t thr = asize / nthreads;
-    int n = 0, beg = 0;
-    for (int x = 0; x < 256; x++)
-      { sum += res->wfirst[x] * KW;
-        if (sum >= thr && n < nthreads)
-          { split[n++] = beg;
-            thr = (asize * (n + 1)) / nthreads;
-            beg = x + 1;
-          }
-      }
-    while (n < nthreads)
-      split[n++] = 256;
-    split[nthreads] = 256;
-  }
-
-  const int64_t nidx = 1ll << (8 * ib);
-  int64_t *idx = (int64_t *) calloc((size_t) nidx, sizeof(int64_t));
-  char name[4096];
-  int rc = FK_OK;
-  // part boundaries by binary search on the first byte, then one writer thread per part: the parts
-  // are disjoint first-byte ranges, so their prefix-index entries are disjoint as well
-  std::vector<int64_t> bound((size_t) nthreads + 1, 0);
-  for (int t = 1; t <= nthreads; t++)
-    { int64_t lo = bound[t - 1], hi = res->ntable;
-      while (lo < hi)
-        { const int64_t mid = (lo + hi) >> 1;
-          if (res->table[mid * KW] < split[t]) lo = mid + 1; else hi = mid;
-        }
-      bound[t] = lo;
-    }
-  std::vector<int> prc((size_t) nthreads, FK_OK);
-  auto write_part = [&](int t)
-    { const int64_t lo = bound[t], hi = bound[t + 1], n = hi - lo;
-      char pname[4096];
-      snprintf(pname, sizeof(pname), "%s/.%s.ktab.%d", dir, root, t + 1);
-      int fd = open(pname, O_WRONLY | O_CREAT | O_TRUNC, 0644);
-      if (fd < 0) { prc[t] = FK_EINVAL; return; }
-      const int pw = KW - ib;
-      uint8_t *buf = (uint8_t *) malloc((size_t) (n > 0 ? n : 1) * pw);
-      if (buf == NULL) { close(fd); prc[t] = FK_ENOMEM; return; }
-      for (int64_t i = lo; i < hi; i++)
-        { const uint8_t *rec = res->table + i * KW;
-          int64_t pre = 0;
-          for (int b = 0; b < ib; b++)
-            pre = (pre << 8) | rec[b];
-          idx[pre] += 1;
-          memcpy(buf + (i - lo) * pw, rec + ib, pw);
-        }
-      if (write_all(fd, &kmer, 4) | write_all(fd, &n, 8) | write_all(fd, buf, (size_t) n * pw))
-        prc[t] = FK_EINVAL;
-      free(buf);
-      close(fd);
-    };
-  { std::vector<std::thread> th;
-    for (int t = 1; t < nthreads; t++)
-      th.emplace_back(write_part, t);
-    write_part(0);
-    for (auto &x : th)
-      x.join();
-  }
-  for (int t = 0; t < nthreads; t++)
-    if (prc[t] != FK_OK)
-      { rc = prc[t];
-        snprintf(name, sizeof(name), "%s/.%s.ktab.%d", dir, root, t + 1);
-      }
+  const int ib = (idx_bytes >= 1 && idx_bytes <= 3) ? idx_bytes : fk_ktab_idx_bytes(kmer, res->ntable);
+  std::vector<int> split((size_t) nthreads + 1);
+  int rc = fk_ktab_split(res->wfirst, kmer, nthreads, split.data());
+  if (rc != FK_OK) return (rc);
+  int64_t *cnt = (int64_t *) calloc((size_t) 1 << (8 * ib), sizeof(int64_t));
+  if (cnt == NULL) return (FK_ENOMEM);
+  rc = fk_write_ktab_range(res->table, res->ntable, kmer, ib, split.data(), 0, nthreads, dir, root, cnt);
   if (rc == FK_OK)
-    { for (int64_t i = 1; i < nidx; i++)
-        idx[i] += idx[i - 1];
-      snprintf(name, sizeof(name), "%s/%s.ktab", dir, root);
-      int fd = open(name, O_WRONLY | O_CREAT | O_TRUNC, 0644);
-      if (fd < 0)
-        rc = FK_EINVAL;
-      else
-        { int32_t h[4] = { kmer, nthreads, table_cutoff, ib };
-          if (write_all(fd, h, 16) | write_all(fd, idx, (size_t) nidx * 8))
-            rc = FK_EINVAL;
-          close(fd);
-        }
-    }
-  if (rc != FK_OK)
-    fk_set_error(NULL, "Cannot write to %s.  Enough disk space?", name);
-  free(idx);
-  free(split);
+    rc = fk_write_ktab_stub(kmer, nthreads, table_cutoff, ib, cnt, dir, root);
+  free(cnt);
   return (rc);
 }

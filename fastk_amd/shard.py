@@ -240,6 +240,50 @@ def gather_table(table, kmer_bytes, sort_fn, group=None, dst=0):
     return sort_fn(merged) if world > 1 else merged
 
 
+def write_table_sharded(table, wfirst, ntable, kmer, cutoff, parts_per_rank, outdir, root, sort_fn,
+                        group=None):
+    """Final step without a gather (SURVEY 8e, C3 first option): a second all-to-all-v, keyed by the
+    first k-mer byte, gives rank r the k-mers of a contiguous first-byte range -- the ranges of
+    Table_Split over world x parts_per_rank parts, from the all-reduced weighted census wfirst -- and
+    every rank writes the hidden part files of its range itself; rank 0 adds the stub from the summed
+    prefix counts.  table: this rank's sorted (n, KMER_WORD) records (its buckets' k-mers); ntable: the
+    global entry count (fixes the index width).  sort_fn orders the received runs (HipEngine.sort_table).
+    The files are what fk_write_ktab writes from the merged table with nthreads = world x
+    parts_per_rank.  outdir must be shared by the ranks."""
+    from . import api
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" \
+        else torch.device("cpu")
+    kw = table.shape[1]
+    nparts = world * parts_per_rank
+    split = api.ktab_split(wfirst, kmer, nparts)
+    ib = api.ktab_idx_bytes(kmer, ntable)
+    # destination r owns first bytes [split[r*m], split[(r+1)*m])
+    first = table[:, 0] if table.shape[0] else np.zeros(0, dtype=np.uint8)
+    cuts = [int(np.searchsorted(first, min(split[r * parts_per_rank], 256), side="left")) if r else 0
+            for r in range(world)] + [table.shape[0]]
+    send_n = [cuts[r + 1] - cuts[r] for r in range(world)]
+    send = torch.tensor(send_n, dtype=torch.int64, device=dev)
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send, group=group)
+    recv_n = [int(x) for x in recv.tolist()]
+    out = torch.from_numpy(np.ascontiguousarray(table).reshape(-1)).to(dev)
+    inbox = torch.empty(max(sum(recv_n), 1) * kw, dtype=torch.uint8, device=dev)[: sum(recv_n) * kw]
+    _exchange_records(out, inbox, send_n, recv_n, kw, group)
+    mine = inbox.cpu().numpy().reshape(-1, kw)
+    if world > 1 and mine.shape[0]:
+        mine = sort_fn(mine)                       # world sorted runs -> one
+    cnt = api.write_ktab_range(mine, kmer, ib, split, rank * parts_per_rank, parts_per_rank, outdir, root)
+    tot = torch.from_numpy(cnt).to(dev)
+    dist.reduce(tot, dist.get_global_rank(group, 0) if group is not None else 0, op=dist.ReduceOp.SUM,
+                group=group)
+    if rank == 0:
+        api.write_ktab_stub(kmer, nparts, cutoff, ib, tot.cpu().numpy(), outdir, root)
+    dist.barrier(group=group)
+    return mine.shape[0]
+
+
 def allgather_table(table, group=None):
     """Every rank's (n, KMER_WORD) table to every rank: the concatenation in rank order (disjoint k-mer
     sets, so it is the whole data set's table up to order).  One broadcast per source rank, at most

@@ -280,7 +280,7 @@ int fk_write_ktab_ex(const fk_result *res, int kmer, int table_cutoff, int nthre
  *
  * fk_make_profiles runs after fk_finish / fk_count_device_reads with table_cutoff 1 -- the table
  * left in HBM is the dictionary.  d_bases NULL: the reads pushed into the context (resident runs,
- * hbm_budget 0); otherwise a caller-owned buffer of reads of the data set just counted -- after a
+ * hbm_budget 0); otherwise a caller-owned, 16-byte aligned buffer of reads of the data set just counted -- after a
  * chunked run (hbm_budget > 0), whose reads were dropped on the way, the caller passes them again
  * piece by piece (whole reads per piece) and concatenates the results.  Reads end at 0 bytes
  * (a last read without one ends at nbytes); other non-acgt bytes stay inside their read.
@@ -312,6 +312,24 @@ int fk_set_table(fk_ctx *ctx, const uint8_t *records, int64_t n);
    part t holds the reads of input thread t when nparts == p->nsplit, else the reads are divided evenly
    over the parts in input order. */
 int fk_write_prof(const fk_profiles *p, int kmer, int nparts, const char *dir, const char *root);
+
+/* ---- writing one table from several ranks ----------------------------------------------------
+ * The pieces of fk_write_ktab (Merge_Tables, table.c:346-533), for the sharded run where rank r ends
+ * up holding the k-mers of a contiguous first-byte range and writes the hidden part files of that
+ * range itself (README.md:988: parts are ordered ranges of the table):
+ *   fk_ktab_idx_bytes   prefix-index width for a table of ntable entries (count.c:1620-1626)
+ *   fk_ktab_split       Table_Split's first-byte boundaries (count.c:1560-1565, MSDsort.c:330-352)
+ *                       from the summed first-byte census of the weighted k-mers; split[nparts+1]
+ *   fk_write_ktab_range writes .<root>.ktab.<part0+1 ..> from sorted records (kmer_word bytes each)
+ *                       and adds the per-prefix entry counts to prefix_counts[256^idx_bytes]
+ *   fk_write_ktab_stub  writes <root>.ktab from the prefix counts summed over all ranks
+ * fk_write_ktab is these three in one process. */
+int fk_ktab_idx_bytes(int kmer, int64_t ntable);
+int fk_ktab_split(const int64_t *wfirst, int kmer, int nparts, int *split);
+int fk_write_ktab_range(const uint8_t *records, int64_t n, int kmer, int idx_bytes, const int *split,
+                        int part0, int nhere, const char *dir, const char *root, int64_t *prefix_counts);
+int fk_write_ktab_stub(int kmer, int nparts, int table_cutoff, int idx_bytes, const int64_t *prefix_counts,
+                       const char *dir, const char *root);
 
 /* The records a rank owns, counted piece by piece (one piece per exchange round of the sharded run,
    so that the exchange of the next piece overlaps the counting of this one).  A piece must consist of

@@ -763,6 +763,8 @@ def test_sharded_final_gather_writes_reference_files(tmp_path):
             again = eng.sort_table(np.ascontiguousarray(merged[rng.permutation(len(merged))]))
             assert np.array_equal(again, merged)
             # profiles of the rank's reads against the union of all ranks' tables (here: one rank)
+            shard.write_table_sharded(table, out["wfirst"], out["ntable"], case["k"], case["cutoff"],
+                                      case["T"], str(tmp_path), "y", eng.sort_table)
             pdata, poffs = shard.profiles_sharded(eng, reads, table)
             mine = [orc.profile_decode(pdata.tobytes()[poffs[i]:poffs[i + 1]]) for i in range(len(poffs) - 1)]
             assert orc.profiles_digest(mine) == case["expected"]["prof"]["decoded_sha256"]
@@ -774,6 +776,8 @@ def test_sharded_final_gather_writes_reference_files(tmp_path):
     exp = case["expected"]
     assert hashlib.sha256(open(tmp_path / "x.hist", "rb").read()).hexdigest() == exp["hist_sha256"]
     assert orc.read_ktab(str(tmp_path / "x"))["stream_sha256"] == exp["ktab"]["stream_sha256"]
+    for f in ["%s.ktab"] + [".%%s.ktab.%d" % (i + 1) for i in range(case["T"])]:     # written by the rank(s)
+        assert open(tmp_path / (f % "y"), "rb").read() == open(tmp_path / (f % "x"), "rb").read(), f
 
 
 @pytest.mark.parametrize("name,nb", [("synth_illumina_k40_t1_T4", 4), ("edge_k40_t1_T4", 8),

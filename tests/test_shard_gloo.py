@@ -103,6 +103,15 @@ class OracleEngine:
                     ndistinct=res.ndistinct, ntable=res.ntable, result=res)
 
 
+def _wfirst(case, bases, boff):
+    """first-byte census of the weighted k-mers of the whole data set (what the all-reduced wfirst of
+    the product run holds); the checker engine does not track it, so it is recomputed here"""
+    P = orc.params(case["k"])
+    recs, _ = orc.distribute(P, bases, boff)
+    kl, _, _ = orc.kmer_list(P, orc.msd_sort(recs, P.smer_word))
+    return np.bincount(kl[:, 0], minlength=256).astype(np.int64)
+
+
 def _worker(rank, world, port, name, q, outdir, rounds=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -124,6 +133,9 @@ def _worker(rank, world, port, name, q, outdir, rounds=1):
         return recs[np.lexsort(recs[:, :P.kmer_bytes].T[::-1])]
 
     merged = shard.gather_table(out["local"]["result"].table, P.kmer_bytes, cpu_sort)
+    # the same table written without the gather: every rank writes the parts of its first-byte range
+    shard.write_table_sharded(out["local"]["result"].table, _wfirst(case, bases, boff), out["ntable"], case["k"],
+                              case["cutoff"], 2, outdir, "y", cpu_sort)
     if rank == 0:
         import fastk_amd
         fastk_amd.write_files(case["k"], case["cutoff"], case["T"], out["hist"], out["max_inst"],
@@ -162,6 +174,15 @@ def test_two_rank_shard_matches_golden(name, rounds, tmp_path):
     assert t["stream_sha256"] == exp["ktab"]["stream_sha256"]
     assert (t["nparts"], t["minval"], t["ibytes"], t["nels"]) == \
         (case["T"], case["cutoff"], exp["ktab"]["ibytes"], exp["ktab"]["nels"])
+    # written rank by rank (2 ranks x 2 parts): the same canonical stream, and byte for byte the files
+    # the one-process writer makes for 4 parts from the merged table
+    y = orc.read_ktab(str(tmp_path / "y"))
+    assert y["stream_sha256"] == exp["ktab"]["stream_sha256"] and y["nparts"] == 4
+    import fastk_amd
+    fastk_amd.write_files(case["k"], case["cutoff"], 4, got["hist"], got["max_inst"], got["merged"],
+                          str(tmp_path), "z", wfirst=_wfirst(case, bases, boff))
+    for f in ["%s.ktab"] + [".%%s.ktab.%d" % (i + 1) for i in range(4)]:
+        assert open(tmp_path / (f % "y"), "rb").read() == open(tmp_path / (f % "z"), "rb").read(), f
 
 
 def _prof_worker(rank, world, port, name, q):
