@@ -264,8 +264,6 @@ int main(int argc, char *argv[])
     { fprintf(stderr,"%s: -p needs the reads resident in HBM and whole: not available with -M or -bc\n",Prog_Name);
       exit (1);
     }
-  if (PROFILE)
-    HOST_PARSE = 1;      /* the host scanner hands over reads exactly as the reference numbers them */
 
   double t_start = now(), t_ingest, t_count, t_write;
 
@@ -328,7 +326,9 @@ int main(int argc, char *argv[])
         { root = r; dir = d; }            /* outputs take the first file's root, FastK.c:402-405 */
       else
         { free(r); free(d); }
-      if (!EXACT && BC_PREFIX == 0 && !HOST_PARSE && (q == 1 || !COMPRESS))
+      /* profiles need the reads exactly as the reference numbers them: the device FASTQ parser keeps
+         one terminated read per record; FASTA text goes through the host scanner */
+      if (!EXACT && BC_PREFIX == 0 && !HOST_PARSE && (q == 1 || !(COMPRESS || PROFILE)))
         scan_text_on_device(&feed,argv[i],q);
       else
         scan_file(&feed,argv[i],q);

@@ -1074,7 +1074,8 @@ def test_profiles_saturated_counts_and_call_order():
             ctx.make_profiles()                                     # needs the cutoff-1 table
 
 
-@pytest.mark.parametrize("name,fmt", [("edge_k40_t4_T1", "fasta"), ("synth_hifi_k40_t4_T8", "fastq")])
+@pytest.mark.parametrize("name,fmt", [("edge_k40_t4_T1", "fasta"), ("synth_hifi_k40_t4_T8", "fastq"),
+                                      ("edge_k51_t1_T4", "fastq")])
 def test_cli_profiles_option(name, fmt, tmp_path):
     """FastK_amd -p -t<n>: profiles decode to the reference's, the .hist and the cutoff-n table are the
     usual ones (the engine counts with cutoff 1 for the look-ups and filters on the way out)."""

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--err-ppm", type=int, default=1000)
     ap.add_argument("--kmer", type=int, default=40)
     ap.add_argument("--seed", type=int, default=20251001)
+    ap.add_argument("--profiles", action="store_true", help="also time -p (profiles) against the reference")
     args = ap.parse_args()
     from oracle import orc
     glen = int(args.genome_mbp * 1e6)
@@ -73,6 +74,28 @@ def main():
             out["reference_kmers_per_s"] = inst / dt
             assert open(os.path.join(d, "ref.hist"), "rb").read() == digests["gpu_parse"]
             out["hist_equal_to_reference"] = True
+        if args.profiles:                          # the same with -p: .prof + .pidx files as well
+            best = None
+            for _ in range(2):
+                t0 = time.perf_counter()
+                subprocess.run([exe, "-k%d" % args.kmer, "-t1", "-T4", "-p", "-N" + os.path.join(d, "gp"), path],
+                               check=True)
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            out["profiles_seconds"] = best
+            if os.path.exists(ref):
+                t0 = time.perf_counter()
+                subprocess.run([ref, "-k%d" % args.kmer, "-t1", "-p", "-T%d" % cores, "-P" + d,
+                                "-N" + os.path.join(d, "rp"), path],
+                               check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=d)
+                out["reference_profiles_seconds"] = time.perf_counter() - t0
+                # spot check: the first and last 2000 reads decode identically
+                _, mine = orc.read_profiles(d, "gp")
+                _, theirs = orc.read_profiles(d, "rp")
+                assert len(mine) == len(theirs) == nreads
+                for i in list(range(2000)) + list(range(nreads - 2000, nreads)):
+                    assert orc.profile_decode(mine[i]) == orc.profile_decode(theirs[i]), i
+                out["profiles_decode_equal_to_reference"] = True
     finally:
         subprocess.run(["rm", "-rf", d])
     print(json.dumps(out))
