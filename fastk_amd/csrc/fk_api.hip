@@ -1592,8 +1592,7 @@ extern "C" int fk_set_table(fk_ctx *ctx, const uint8_t *records, int64_t n)
   ctx->last_ntab  = 0;
   if (n > 0)
     { void *d_t = fk_slot(ctx, FK_SLOT_TABLE, n * w.kmer_stride);
-      void *d_x = fk_slot(ctx, FK_SLOT_KM_A, n * w.kmer_stride);
-      if (d_t == NULL || d_x == NULL)
+      if (d_t == NULL)
         return (FK_ENOMEM);
       if (w.kmer_word == w.kmer_stride)
         FK_HIP(ctx, hipMemcpyAsync(d_t, records, (size_t) n * w.kmer_stride, hipMemcpyHostToDevice, s));
@@ -1606,13 +1605,8 @@ extern "C" int fk_set_table(fk_ctx *ctx, const uint8_t *records, int64_t n)
           FK_HIP(ctx, hipMemcpyAsync(d_t, stage.data(), stage.size(), hipMemcpyHostToDevice, s));
           FK_HIP(ctx, hipStreamSynchronize(s));
         }
-      void *sorted = d_t;
-      int64_t census[256];
-      int rc = fkx_sort_table(ctx, n, d_t, d_x, &sorted, census);
-      if (rc != FK_OK)
-        return (rc);
       FK_HIP(ctx, hipStreamSynchronize(s));
-      ctx->last_table = sorted;
+      ctx->last_table = d_t;                   // the look-ups hash the records: no order needed
     }
   ctx->last_ntab  = n;
   ctx->have_table = true;

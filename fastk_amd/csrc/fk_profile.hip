@@ -3,12 +3,13 @@
 // builds them in count.c:868-947 from its sorted super-mer lists and stitches them in merge.c).
 //
 // Here the profiles are produced from the two things the counting path leaves in HBM: the reads and
-// the sorted k-mer table with cutoff 1.
-//   k_pf_index   24-bit prefix index over the sorted table
-//   k_pf_counts  one lookup per base position: canonical k-mer from LDS-packed 2-bit codes, binary
-//                search inside the prefix bucket -> u16 count (0 where the window is not all acgt)
+// the k-mer table with cutoff 1.
+//   k_pf_hbuild  the table as an open-addressing dictionary: 64-byte lines of 4 (2) record slots
+//   k_pf_counts  one look-up per base position: canonical k-mer from LDS-packed 2-bit codes, its home
+//                line read with 16-byte loads -> u16 count (0 where the window is not all acgt)
 //   k_pf_zeros   positions of the read terminators (0 bytes) -> read boundaries
-//   k_pf_encode  one thread per read: length pass, then emit pass of the codec
+//   k_pf_encode  one thread per read, 128 reads per workgroup staged through LDS: length pass, scan,
+//                emit pass of the codec
 // The codec output is the canonical one-byte-wherever-possible stream; it decodes to the same counts
 // as the reference's files, whose run splits follow the reference's internal work panels (merge.c:65,711).
 #include "fk_common.h"
@@ -19,18 +20,56 @@
 #define PF_ZCH   16384        // bytes per workgroup of k_pf_zeros
 
 // ---------------------------------------------------------------------------------------
-// prefix index: idx[p] = first table record whose leading key bits (>> pshift of the first
-// big-endian key word) are >= p, idx[NP] = nt
+// dictionary: open-addressing hash table over the table records.  A slot holds one record in its
+// device layout (sdw dwords, padded to SD = 4 or 8 dwords); the dword with the count doubles as the
+// occupancy flag (counts are >= 1).  Slots are grouped into 64-byte lines of G = 16 / SD slots: a key's
+// home line is hash -> line, insertion takes the first free slot of the line (else the next line), a
+// look-up reads the whole line with 16-byte loads -- one HBM sector per look-up at load factor 1/2,
+// against index + binary-search probes of the sorted table.
 
-static __global__ __launch_bounds__(256) void k_pf_index(const u32 *__restrict__ table, int64_t nt, int sdw,
-                                                          int pshift, int64_t NP, u64 *__restrict__ idx)
-{ const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
-  if (i > nt)
+template <int KW>
+__device__ __forceinline__ u64 pf_hash(const u32 *d)
+{ u64 h = 0x9E3779B97F4A7C15ull;
+#pragma unroll
+  for (int w = 0; w < KW; w++)
+    { h = (h ^ d[w]) * 0xD6E8FEB86659FD93ull;
+      h ^= h >> 32;
+    }
+  return (h);
+}
+
+template <int KW, int SW>
+static __global__ __launch_bounds__(256) void k_pf_hbuild(const u32 *__restrict__ table, int64_t nt,
+                                                           u32 kmask, u32 *__restrict__ slots, u64 nlines)
+{ constexpr int SD = (SW <= 4) ? 4 : 8, G = 16 / SD, sdw = SW;
+  const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (i >= nt)
     return;
-  const int64_t pprev = (i == 0) ? -1 : (int64_t) (__builtin_bswap32(table[(i - 1) * sdw]) >> pshift);
-  const int64_t pcur  = (i == nt) ? NP : (int64_t) (__builtin_bswap32(table[i * sdw]) >> pshift);
-  for (int64_t p = pprev + 1; p <= pcur; p++)
-    idx[p] = (u64) i;
+  u32 r[SD], kd[KW];
+#pragma unroll
+  for (int w = 0; w < SD; w++)
+    r[w] = (w < sdw) ? table[i * sdw + w] : 0u;
+#pragma unroll
+  for (int w = 0; w < KW; w++)
+    kd[w] = (w == KW - 1) ? (r[w] & kmask) : r[w];
+  const u64 h = pf_hash<KW>(kd);
+  u64 line = (u64) (((unsigned __int128) h * nlines) >> 64);
+  const int st = (int) (h & (G - 1));
+  const u32 last = r[sdw - 1];
+  while (true)
+    { for (int j = 0; j < G; j++)
+        { u32 *sl = slots + (line * G + ((st + j) & (G - 1))) * SD;
+          if (atomicCAS(sl + (sdw - 1), 0u, last) == 0u)
+            {
+#pragma unroll
+              for (int w = 0; w < SD; w++)
+                if (w < sdw - 1)
+                  sl[w] = r[w];
+              return;
+            }
+        }
+      line = (line + 1 == nlines) ? 0 : line + 1;
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -41,11 +80,10 @@ __device__ __forceinline__ u32 pf_rev2(u32 x)      // reverse the order of the 1
   return (((y & 0x55555555u) << 1) | ((y >> 1) & 0x55555555u));
 }
 
-template <int KW>
+template <int KW, int SW>
 static __global__ __launch_bounds__(256) void k_pf_counts(const uint8_t *__restrict__ bases, int64_t n, int K,
-                                                           const u32 *__restrict__ table, int sdw, int kbytes,
-                                                           const u64 *__restrict__ idx, int pshift,
-                                                           uint16_t *__restrict__ out)
+                                                           const u32 *__restrict__ slots, u64 nlines,
+                                                           u32 kmask, uint16_t *__restrict__ out)
 { __shared__ u32      fw[PF_NG + KW + 2];       // 2-bit codes, 16 per word, first base in the top bits
   __shared__ __attribute__((aligned(16))) uint16_t bad[PF_NG + 16];          // bit j of bad[g]: base 16 g + j is not acgt (or past n)
   const int     tid = threadIdx.x;
@@ -89,8 +127,7 @@ static __global__ __launch_bounds__(256) void k_pf_counts(const uint8_t *__restr
   const int tb = K - 16 * (KW - 1);             // bases in the last key word
   const u32 tmask = (tb == 16) ? 0xffffffffu : ~(0xffffffffu >> (2 * tb));
   const int ps = 2 * (16 - tb);
-  const int kb_last = kbytes - 4 * (KW - 1);    // key bytes in the last record word
-  const u32 rmask = (kb_last == 4) ? 0xffffffffu : ~(0xffffffffu >> (8 * kb_last));
+  constexpr int SD = (SW <= 4) ? 4 : 8, G = 16 / SD;
   const u32 *bad32 = (const u32 *) bad;
 
 #pragma unroll 1
@@ -140,61 +177,37 @@ static __global__ __launch_bounds__(256) void k_pf_counts(const uint8_t *__restr
               for (int w = 0; w < KW; w++)
                 a[w] = b[w];
             }
-          const u32 pre = a[0] >> pshift;
-          int64_t lo = (int64_t) idx[pre], hi = (int64_t) idx[pre + 1];
-          // -1 / 0 / +1: record m is below / equal to / above the key
-          auto probe = [&](int64_t m) -> int
-            { const u32 *r = table + m * sdw;
-              int cmp = 0;
+          u32 kd[KW];                                     // the key as the record's dwords
 #pragma unroll
-              for (int w = 0; w < KW; w++)
-                { u32 x = __builtin_bswap32(r[w]);
-                  if (w == KW - 1) x &= rmask;
-                  if (cmp == 0 && x != a[w])
-                    cmp = (x < a[w]) ? -1 : 1;
+          for (int w = 0; w < KW; w++)
+            kd[w] = __builtin_bswap32(a[w]);
+          const u64 h = pf_hash<KW>(kd);
+          u64 line = (u64) (((unsigned __int128) h * nlines) >> 64);
+          while (true)
+            { const uint4 *lp = (const uint4 *) (slots + line * 16);
+              u32 v[16];
+#pragma unroll
+              for (int q = 0; q < 4; q++)
+                { const uint4 x = lp[q];
+                  v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
                 }
-              if (cmp == 0)
-                cnt = r[sdw - 1] >> 16;
-              return (cmp);
-            };
-          bool found = false;
-          if (hi - lo > 8)
-            { // the bits after the prefix are close to uniform inside a bucket: start at the interpolated
-              // rank and gallop, so that the probes stay within a cache line or two of the answer
-              const u32 nxt = (a[0] << (32 - pshift)) | ((KW > 1) ? (a[KW > 1 ? 1 : 0] >> pshift) : 0u);
-              int64_t e = lo + (int64_t) (((u64) (hi - lo) * nxt) >> 32);
-              int c = probe(e);
-              if (c == 0)
-                found = true;
-              else if (c < 0)
-                { lo = e + 1;
-                  for (int64_t step = 2; ; step <<= 1)
-                    { const int64_t m = lo + step - 1;
-                      if (m >= hi) break;
-                      c = probe(m);
-                      if (c == 0) { found = true; break; }
-                      if (c > 0) { hi = m; break; }
-                      lo = m + 1;
+              bool hit = false, room = false;
+#pragma unroll
+              for (int j = 0; j < G; j++)
+                { const u32 last = v[j * SD + SW - 1];
+                  bool eq = (last != 0u);
+#pragma unroll
+                  for (int w = 0; w < KW; w++)
+                    eq = eq && (((w == KW - 1) ? (v[j * SD + w] & kmask) : v[j * SD + w]) == kd[w]);
+                  if (eq)
+                    { cnt = last >> 16;
+                      hit = true;
                     }
+                  room = room || (last == 0u);
                 }
-              else
-                { hi = e;
-                  for (int64_t step = 2; ; step <<= 1)
-                    { const int64_t m = hi - step;
-                      if (m < lo) break;
-                      c = probe(m);
-                      if (c == 0) { found = true; break; }
-                      if (c < 0) { lo = m + 1; break; }
-                      hi = m;
-                    }
-                }
-            }
-          while (!found && lo < hi)
-            { const int64_t mid = (lo + hi) >> 1;
-              const int c = probe(mid);
-              if (c == 0) break;
-              if (c < 0) lo = mid + 1;
-              else       hi = mid;
+              if (hit || room)
+                break;
+              line = (line + 1 == nlines) ? 0 : line + 1;
             }
         }
       out[p] = (uint16_t) cnt;
@@ -246,79 +259,165 @@ static __global__ __launch_bounds__(256) void k_pf_zeros(const uint8_t *__restri
 // the codec (README: first count in 1-2 bytes, then forward differences: 00x = run of x equal
 // counts (x <= 63), 01x = 6-bit two's complement difference, 1x.y = 15-bit difference mod 2^15)
 
+#define PF_ER      128          // reads per workgroup of k_pf_encode (one thread each)
+#define PF_ECAP    20480        // staged counts per workgroup (40 KB of LDS)
+#define PF_OCAP    24576        // staged codec bytes per workgroup
+
+// A workgroup takes PF_ER consecutive reads.  Their counts are one contiguous stretch of cnts: when it
+// fits, it is staged in LDS with coalesced loads (a thread walking its own read in global memory
+// touches a different cache line than its 63 neighbours on every step) and, in the emit pass, the
+// codec bytes are collected in LDS and written out as one contiguous run.
 template <bool EMIT>
-static __global__ __launch_bounds__(64) void k_pf_encode(const uint16_t *__restrict__ cnts,
-                                                         const int64_t *__restrict__ ends, int64_t nreads,
-                                                         int64_t nbytes, int K, u32 *__restrict__ lens,
-                                                         const u64 *__restrict__ offs, uint8_t *__restrict__ out)
-{ const int64_t r = (int64_t) blockIdx.x * 64 + threadIdx.x;
-  if (r >= nreads)
-    return;
-  const int64_t s = (r == 0) ? 0 : ends[r - 1] + 1;
-  const int64_t e = ends[r] < nbytes ? ends[r] : nbytes;
-  const int64_t np = e - s - K + 1;
-  uint8_t *o = EMIT ? out + offs[r] : NULL;
+static __global__ __launch_bounds__(PF_ER) void k_pf_encode(const uint16_t *__restrict__ cnts,
+                                                            const int64_t *__restrict__ ends, int64_t nreads,
+                                                            int64_t nbytes, int K, u32 *__restrict__ lens,
+                                                            const u64 *__restrict__ offs, uint8_t *__restrict__ out)
+{ __shared__ __attribute__((aligned(16))) uint16_t lc[PF_ECAP];
+  __shared__ __attribute__((aligned(16))) uint8_t  lo[EMIT ? PF_OCAP : 16];
+  const int64_t r0 = (int64_t) blockIdx.x * PF_ER;
+  const int64_t r  = r0 + threadIdx.x;
+  const int64_t rl = (r0 + PF_ER < nreads ? r0 + PF_ER : nreads) - 1;        // last read of the group
+  const int64_t g0 = (r0 == 0) ? 0 : ends[r0 - 1] + 1;                       // first position of the group
+  const int64_t g1 = ends[rl] < nbytes ? ends[rl] : nbytes;
+  const int64_t a0 = g0 & ~(int64_t) 7;                                      // 16-byte aligned start
+  const bool    staged = (g1 - a0 <= PF_ECAP);
+  if (staged)
+    { const int n8 = (int) ((g1 - a0 + 7) >> 3);
+      const uint4 *src = (const uint4 *) (cnts + a0);      // cnts has 64 bytes of slack at the end
+      for (int i = threadIdx.x; i < n8; i += PF_ER)
+        ((uint4 *) lc)[i] = src[i];
+    }
+  u64 ob = 0;
+  bool ostaged = false;
+  if (EMIT)
+    { ob = offs[r0];
+      ostaged = (offs[rl + 1] - ob <= PF_OCAP);
+    }
+  __syncthreads();
+
   u32 len = 0;
-  if (np > 0)
-    { const uint16_t *c = cnts + s;
-      u32 prev = c[0];
-      if (prev < 128)
-        { if (EMIT) o[len] = (uint8_t) prev;
-          len += 1;
-        }
-      else
-        { if (EMIT) { o[len] = (uint8_t) (0x80u | (prev >> 8)); o[len + 1] = (uint8_t) prev; }
-          len += 2;
-        }
-      u32 run = 0;
-      for (int64_t j = 1; j < np; j++)
-        { const u32 x = c[j];
-          if (x == prev)
-            { if (++run == 63)
-                { if (EMIT) o[len] = 63;
+  if (r < nreads)
+    { const int64_t s = (r == 0) ? 0 : ends[r - 1] + 1;
+      const int64_t e = ends[r] < nbytes ? ends[r] : nbytes;
+      const int64_t np = e - s - K + 1;
+      uint8_t *o = NULL;
+      if (EMIT)
+        o = ostaged ? lo + (offs[r] - ob) : out + offs[r];
+      if (np > 0)
+        { const uint16_t *c = staged ? lc + (s - a0) : cnts + s;
+          u32 prev = c[0];
+          if (prev < 128)
+            { if (EMIT) o[len] = (uint8_t) prev;
+              len += 1;
+            }
+          else
+            { if (EMIT) { o[len] = (uint8_t) (0x80u | (prev >> 8)); o[len + 1] = (uint8_t) prev; }
+              len += 2;
+            }
+          u32 run = 0;
+          for (int64_t j = 1; j < np; j++)
+            { const u32 x = c[j];
+              if (x == prev)
+                { if (++run == 63)
+                    { if (EMIT) o[len] = 63;
+                      len += 1;
+                      run = 0;
+                    }
+                  continue;
+                }
+              if (run != 0)
+                { if (EMIT) o[len] = (uint8_t) run;
                   len += 1;
                   run = 0;
                 }
-              continue;
+              const int d = (int) x - (int) prev;
+              if (d > -32 && d < 32)
+                { if (EMIT) o[len] = (uint8_t) (0x40u | ((u32) d & 0x3fu));
+                  len += 1;
+                }
+              else
+                { const u32 dd = (u32) d & 0x7fffu;
+                  if (EMIT) { o[len] = (uint8_t) (0x80u | (dd >> 8)); o[len + 1] = (uint8_t) dd; }
+                  len += 2;
+                }
+              prev = x;
             }
           if (run != 0)
             { if (EMIT) o[len] = (uint8_t) run;
               len += 1;
-              run = 0;
             }
-          const int d = (int) x - (int) prev;
-          if (d > -32 && d < 32)
-            { if (EMIT) o[len] = (uint8_t) (0x40u | ((u32) d & 0x3fu));
-              len += 1;
-            }
-          else
-            { const u32 dd = (u32) d & 0x7fffu;
-              if (EMIT) { o[len] = (uint8_t) (0x80u | (dd >> 8)); o[len + 1] = (uint8_t) dd; }
-              len += 2;
-            }
-          prev = x;
         }
-      if (run != 0)
-        { if (EMIT) o[len] = (uint8_t) run;
-          len += 1;
-        }
+      if (!EMIT)
+        lens[r] = len;
     }
-  if (!EMIT)
-    lens[r] = len;
+  if (EMIT && ostaged)
+    { __syncthreads();
+      const int tot = (int) (offs[rl + 1] - ob);
+      uint8_t *dst = out + ob;
+      const int head = (int) ((4 - ((uintptr_t) dst & 3)) & 3);           // bytes up to dword alignment
+      if ((int) threadIdx.x < head && (int) threadIdx.x < tot)
+        dst[threadIdx.x] = lo[threadIdx.x];
+      const int nd = (tot > head) ? (tot - head) >> 2 : 0;
+      for (int i = threadIdx.x; i < nd; i += PF_ER)
+        { const uint8_t *q = lo + head + 4 * i;
+          ((u32 *) (dst + head))[i] = (u32) q[0] | ((u32) q[1] << 8) | ((u32) q[2] << 16) | ((u32) q[3] << 24);
+        }
+      for (int i = head + 4 * nd + (int) threadIdx.x; i < tot; i += PF_ER)
+        dst[i] = lo[i];
+    }
+}
+
+// exclusive scan of n u32 values into u64 offsets with many workgroups: block sums, a scan of the sums
+// (k_exscan_tiles, one workgroup), block-local scans on top of them; out[n] gets the total
+static __global__ __launch_bounds__(256) void k_pf_blocksum(const u32 *__restrict__ in, int64_t n, u32 *__restrict__ sums)
+{ __shared__ u32 tmp[8];
+  const int64_t i0 = ((int64_t) blockIdx.x * 256 + threadIdx.x) * 16;
+  u32 mine = 0;
+#pragma unroll
+  for (int k = 0; k < 16; k++)
+    mine += (i0 + k < n) ? in[i0 + k] : 0u;
+  u32 tot;
+  (void) fk_block_exscan_256<u32>(mine, tmp, &tot);
+  if (threadIdx.x == 0)
+    sums[blockIdx.x] = tot;
+}
+
+static __global__ __launch_bounds__(256) void k_pf_blockscan(const u32 *__restrict__ in, int64_t n,
+                                                             const u64 *__restrict__ base, u64 *__restrict__ out)
+{ __shared__ u64 tmp[8];
+  const int64_t i0 = ((int64_t) blockIdx.x * 256 + threadIdx.x) * 16;
+  u32 v[16];
+  u64 mine = 0;
+#pragma unroll
+  for (int k = 0; k < 16; k++)
+    { v[k] = (i0 + k < n) ? in[i0 + k] : 0u;
+      mine += v[k];
+    }
+  u64 tot;
+  u64 run = base[blockIdx.x] + fk_block_exscan_256<u64>(mine, tmp, &tot);
+#pragma unroll
+  for (int k = 0; k < 16; k++)
+    { if (i0 + k < n)
+        out[i0 + k] = run;
+      run += v[k];
+    }
 }
 
 // ---------------------------------------------------------------------------------------
 
-template <int KW>
-static void pf_launch_counts(hipStream_t s, int64_t ntiles, const uint8_t *bases, int64_t n, int K,
-                             const u32 *table, int sdw, int kbytes, const u64 *idx, int pshift, uint16_t *out)
-{ hipLaunchKernelGGL(k_pf_counts<KW>, dim3((unsigned) ntiles), dim3(256), 0, s, bases, n, K, table, sdw, kbytes,
-                     idx, pshift, out);
+template <int KW, int SW>
+static void pf_dictionary_and_counts(hipStream_t s, const u32 *table, int64_t nt, u32 kmask, u32 *slots, u64 nlines,
+                                     int64_t ntiles, const uint8_t *bases, int64_t n, int K, uint16_t *out)
+{ if (nt > 0)
+    hipLaunchKernelGGL((k_pf_hbuild<KW, SW>), dim3((unsigned) ((nt + 255) / 256)), dim3(256), 0, s, table, nt, kmask,
+                       slots, nlines);
+  hipLaunchKernelGGL((k_pf_counts<KW, SW>), dim3((unsigned) ntiles), dim3(256), 0, s, bases, n, K,
+                     (const u32 *) slots, nlines, kmask, out);
 }
 
 // Profiles of the reads in d_bases[0..nbytes) (reads end at 0 bytes; a last read without terminator
-// ends at nbytes) against the sorted table d_table (nt records of kmer_stride bytes, cutoff 1).
-// Results stay in HBM: *d_data (nprof bytes) and *d_offs (nreads + 1 offsets).
+// ends at nbytes) against the table d_table (nt records of kmer_stride bytes with distinct k-mers, any
+// order, counts >= 1).  Results stay in HBM: *d_data (nprof bytes) and *d_offs (nreads + 1 offsets).
 int fkx_profiles(fk_ctx *ctx, const void *d_bases, int64_t nbytes, const void *d_table, int64_t nt,
                  int64_t *nreads_out, int64_t *nprof_out, void **d_data, uint64_t **d_offs)
 { const fk_widths &w = ctx->wid;
@@ -326,9 +425,8 @@ int fkx_profiles(fk_ctx *ctx, const void *d_bases, int64_t nbytes, const void *d
   const int K = w.kmer;
   const int KW = (w.kmer_bytes + 3) / 4;
   const int sdw = w.kmer_stride / 4;
-  const int PB = w.kmer_bytes < 3 ? w.kmer_bytes : 3;
-  const int pshift = 32 - 8 * PB;
-  const int64_t NP = 1ll << (8 * PB);
+  const int kb_last = w.kmer_bytes - 4 * (KW - 1);          // key bytes in the last key dword
+  const u32 kmask = (kb_last == 4) ? 0xffffffffu : ((1u << (8 * kb_last)) - 1u);
   const uint8_t *bases = (const uint8_t *) d_bases;
 
   *nreads_out = 0;
@@ -342,34 +440,24 @@ int fkx_profiles(fk_ctx *ctx, const void *d_bases, int64_t nbytes, const void *d
       return (FK_EUNSUPPORTED);
     }
 
-  // 1. prefix index
-  u64 *idx = (u64 *) fk_slot(ctx, FK_SLOT_PF_IDX, (NP + 2) * 8);
-  if (idx == NULL) return (FK_ENOMEM);
-  if (nt == 0)
-    FK_HIP(ctx, hipMemsetAsync(idx, 0, (size_t) (NP + 2) * 8, s));
-  else
-    { hipLaunchKernelGGL(k_pf_index, dim3((unsigned) ((nt + 1 + 255) / 256)), dim3(256), 0, s,
-                         (const u32 *) d_table, nt, sdw, pshift, NP, idx);
-      FK_LAUNCH_CHECK(ctx);
-    }
-
-  // 2. counts per position
+  // 1. + 2. dictionary (load factor <= 1/2), then counts per position
+  const int     G = (sdw <= 4) ? 4 : 2;                       // slots per 64-byte line
+  const int64_t nlines = std::max<int64_t>(1, (2 * nt + G - 1) / G);
+  u32 *slots = (u32 *) fk_slot(ctx, FK_SLOT_PF_IDX, nlines * 64);
   uint16_t *cnts = (uint16_t *) fk_slot(ctx, FK_SLOT_PF_CNT, nbytes * 2 + 64);
-  if (cnts == NULL) return (FK_ENOMEM);
+  if (slots == NULL || cnts == NULL) return (FK_ENOMEM);
+  FK_HIP(ctx, hipMemsetAsync(slots, 0, (size_t) nlines * 64, s));
   const int64_t ntiles = (nbytes + PF_TILE - 1) / PF_TILE;
-  switch (KW)
-    { case 1: pf_launch_counts<1>(s, ntiles, bases, nbytes, K, (const u32 *) d_table, sdw, w.kmer_bytes, idx, pshift, cnts); break;
-      case 2: pf_launch_counts<2>(s, ntiles, bases, nbytes, K, (const u32 *) d_table, sdw, w.kmer_bytes, idx, pshift, cnts); break;
-      case 3: pf_launch_counts<3>(s, ntiles, bases, nbytes, K, (const u32 *) d_table, sdw, w.kmer_bytes, idx, pshift, cnts); break;
-      case 4: pf_launch_counts<4>(s, ntiles, bases, nbytes, K, (const u32 *) d_table, sdw, w.kmer_bytes, idx, pshift, cnts); break;
-      case 5: pf_launch_counts<5>(s, ntiles, bases, nbytes, K, (const u32 *) d_table, sdw, w.kmer_bytes, idx, pshift, cnts); break;
-      case 6: pf_launch_counts<6>(s, ntiles, bases, nbytes, K, (const u32 *) d_table, sdw, w.kmer_bytes, idx, pshift, cnts); break;
-      case 7: pf_launch_counts<7>(s, ntiles, bases, nbytes, K, (const u32 *) d_table, sdw, w.kmer_bytes, idx, pshift, cnts); break;
-      case 8: pf_launch_counts<8>(s, ntiles, bases, nbytes, K, (const u32 *) d_table, sdw, w.kmer_bytes, idx, pshift, cnts); break;
-      default:
-        fk_set_error(ctx, "profiles: k = %d not supported", K);
-        return (FK_EUNSUPPORTED);
+#define PF_CASE(kw, sw)                                                                                     \
+  if (KW == kw && sdw == sw)                                                                                \
+    pf_dictionary_and_counts<kw, sw>(s, (const u32 *) d_table, nt, kmask, slots, (u64) nlines, ntiles, bases, \
+                                     nbytes, K, cnts);                                                      \
+  else
+  PF_CASE(1, 1) PF_CASE(1, 2) PF_CASE(2, 2) PF_CASE(2, 3) PF_CASE(3, 3) PF_CASE(3, 4) PF_CASE(4, 4) PF_CASE(4, 5)
+    { fk_set_error(ctx, "profiles: k = %d not supported", K);
+      return (FK_EUNSUPPORTED);
     }
+#undef PF_CASE
   FK_LAUNCH_CHECK(ctx);
 
   // 3. read boundaries
@@ -403,17 +491,25 @@ int fkx_profiles(fk_ctx *ctx, const void *d_bases, int64_t nbytes, const void *d
   u32 *lens = (u32 *) fk_slot(ctx, FK_SLOT_PF_LEN, nreads * 4 + 64);
   u64 *offs = (u64 *) fk_slot(ctx, FK_SLOT_PF_OFF, (nreads + 1) * 8 + 64);
   if (lens == NULL || offs == NULL) return (FK_ENOMEM);
-  const unsigned nb = (unsigned) ((nreads + 63) / 64);
-  hipLaunchKernelGGL(k_pf_encode<false>, dim3(nb), dim3(64), 0, s, (const uint16_t *) cnts, (const int64_t *) ends,
+  const unsigned nb = (unsigned) ((nreads + PF_ER - 1) / PF_ER);
+  hipLaunchKernelGGL(k_pf_encode<false>, dim3(nb), dim3(PF_ER), 0, s, (const uint16_t *) cnts, (const int64_t *) ends,
                      nreads, nbytes, K, lens, (const u64 *) NULL, (uint8_t *) NULL);
-  hipLaunchKernelGGL(k_exscan_tiles, dim3(1), dim3(256), 0, s, (const u32 *) lens, nreads, offs, offs + nreads);
+  { const int64_t nblk = (nreads + 4095) / 4096;
+    u32 *bs = (u32 *) fk_slot(ctx, FK_SLOT_PF_ZC, nblk * 4 + 64);            // the zero counts are done with
+    u64 *bo = (u64 *) fk_slot(ctx, FK_SLOT_PF_ZO, nblk * 8 + 64);
+    if (bs == NULL || bo == NULL) return (FK_ENOMEM);
+    hipLaunchKernelGGL(k_pf_blocksum, dim3((unsigned) nblk), dim3(256), 0, s, (const u32 *) lens, nreads, bs);
+    hipLaunchKernelGGL(k_exscan_tiles, dim3(1), dim3(256), 0, s, (const u32 *) bs, nblk, bo, offs + nreads);
+    hipLaunchKernelGGL(k_pf_blockscan, dim3((unsigned) nblk), dim3(256), 0, s, (const u32 *) lens, nreads,
+                       (const u64 *) bo, offs);
+  }
   FK_LAUNCH_CHECK(ctx);
   FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch, offs + nreads, 8, hipMemcpyDeviceToHost, s));
   FK_HIP(ctx, hipStreamSynchronize(s));       // also keeps the stack variable nbytes alive for the copy above
   const int64_t nprof = (int64_t) ctx->h_scratch[0];
   uint8_t *data = (uint8_t *) fk_slot(ctx, FK_SLOT_PF_OUT, nprof + 64);
   if (data == NULL) return (FK_ENOMEM);
-  hipLaunchKernelGGL(k_pf_encode<true>, dim3(nb), dim3(64), 0, s, (const uint16_t *) cnts, (const int64_t *) ends,
+  hipLaunchKernelGGL(k_pf_encode<true>, dim3(nb), dim3(PF_ER), 0, s, (const uint16_t *) cnts, (const int64_t *) ends,
                      nreads, nbytes, K, (u32 *) NULL, (const u64 *) offs, data);
   FK_LAUNCH_CHECK(ctx);
   *nprof_out = nprof;

@@ -304,7 +304,7 @@ int fk_make_profiles(fk_ctx *ctx, const void *d_bases, int64_t nbytes, fk_profil
    FastK.c:270-282 + the cmer_merge path count.c:675-815 -- counts are those of the given table, 0 for
    k-mers it does not hold), and the sharded run, where every rank installs the union of all ranks'
    tables.  records: n entries of kmer_word bytes ([KMER_BYTES][uint16 count]) in any order, k-mers
-   distinct; they are copied to HBM and ordered there.  No counting run is needed: push the reads,
+   distinct, counts >= 1; they are copied to HBM.  No counting run is needed: push the reads,
    call fk_set_table, then fk_make_profiles(ctx, NULL, 0, &out). */
 int fk_set_table(fk_ctx *ctx, const uint8_t *records, int64_t n);
 
