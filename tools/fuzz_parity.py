@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""Randomised differential run of the whole path against the CPU oracle: random k, read mixes (both
+strands, N's, upper/lower case, reads shorter than k, duplicates, low complexity), bucket counts,
+chunked ingest with and without host spill, block sizes and input-thread ids, table cut-offs, and the
+profile stage.  Every iteration compares histogram, max_inst, instance count, table and (cut-off 1)
+profiles bit for bit.
+
+  python tools/fuzz_parity.py [iterations=100] [seed=1]
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import fastk_amd                                                     # noqa: E402
+from oracle import orc                                               # noqa: E402
+
+
+def make_reads(rng, k):
+    glen = int(rng.integers(500, 40000))
+    genome = rng.integers(0, 4, size=glen)
+    if rng.random() < 0.3:                                           # a repeat-rich genome
+        unit = genome[:int(rng.integers(20, 300))]
+        genome = np.concatenate([unit] * (glen // len(unit) + 1))[:glen]
+    reads = []
+    n = int(rng.integers(1, 1500))
+    maxlen = int(rng.choice([k + 5, 150, 400, 3000]))
+    for _ in range(n):
+        L = int(rng.integers(max(1, k - 4), maxlen + 1))
+        L = min(L, glen - 1)
+        s0 = int(rng.integers(0, glen - L))
+        r = genome[s0:s0 + L].copy()
+        if rng.random() < 0.5:
+            r = (3 - r)[::-1]
+        for _ in range(int(rng.poisson(L * 0.003))):
+            r[int(rng.integers(0, L))] = int(rng.integers(0, 4))
+        if rng.random() < 0.15:
+            a = int(rng.integers(0, L))
+            r[a:a + int(rng.integers(1, 40))] = 4
+        t = "".join("acgtn"[x] for x in r)
+        if rng.random() < 0.3:
+            t = t.upper()
+        reads.append(t)
+    if rng.random() < 0.3:
+        reads += [reads[0]] * int(rng.integers(2, 40000 if rng.random() < 0.1 else 300))
+    if rng.random() < 0.2:
+        reads += ["a" * int(rng.integers(k, 400))] * int(rng.integers(1, 50))
+    if rng.random() < 0.2:
+        reads += ["", "acg", "n" * 30]
+    order = rng.permutation(len(reads))
+    return [reads[i] for i in order]
+
+
+def main():
+    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    t0 = time.time()
+    for it in range(iters):
+        k = int(rng.choice([12, 15, 16, 17, 21, 25, 31, 32, 33, 40, 47, 48, 51, 55, 63, 64]))
+        cutoff = int(rng.choice([1, 1, 2, 3]))
+        nb = int(rng.choice([1, 1, 2, 3, 7]))
+        reads = make_reads(rng, k)
+        bases, boff = orc.block_from_reads(reads)
+        exp = orc.fastk(k, bases, boff, cutoff=cutoff)
+        chunk = int(rng.choice([0, 0, max(4096, len(bases) // 5)]))
+        spill = chunk > 0 and rng.random() < 0.5
+        desc = dict(it=it, k=k, cutoff=cutoff, nb=nb, nreads=len(reads), nbytes=len(bases), chunk=chunk, spill=bool(spill))
+        try:
+            with fastk_amd.Context(kmer=k, table_cutoff=cutoff, nbuckets=nb) as ctx:
+                if chunk:
+                    ctx.debug_set("chunk_bytes", chunk)
+                    if spill:
+                        ctx.debug_set("spill_limit", max(4096, len(bases) // 20))
+                nreads = len(boff) - 1
+                nthreads = int(rng.integers(1, 4))
+                cuts = sorted(int(x) for x in rng.integers(0, nreads + 1, size=nthreads - 1))
+                cuts = [0] + cuts + [nreads]
+                cur = cuts[:-1].copy()
+                while any(cur[t] < cuts[t + 1] for t in range(nthreads)):
+                    t = int(rng.integers(0, nthreads))
+                    if cur[t] >= cuts[t + 1]:
+                        continue
+                    hi = min(cuts[t + 1], cur[t] + int(rng.integers(1, 400)))
+                    lo = cur[t]
+                    ctx.push_block(bases[boff[lo]:boff[hi]], (boff[lo:hi + 1] - boff[lo]).astype(np.int32), tid=t)
+                    cur[t] = hi
+                res = ctx.finish()
+                assert res.ninst == exp.ninst, "ninst"
+                assert np.array_equal(res.hist, exp.hist), "hist"
+                assert res.max_inst == exp.max_inst, "max_inst"
+                assert res.ntable == exp.ntable and np.array_equal(res.table, exp.table), "table"
+                if cutoff == 1 and not chunk:
+                    data, offs = ctx.make_profiles()
+                    want = orc.profile_counts(k, bases, boff, exp.table)
+                    raw = data.tobytes()
+                    assert len(offs) == len(want) + 1, "profile count"
+                    for i, x in enumerate(want):
+                        assert raw[offs[i]:offs[i + 1]] == orc.profile_encode(x), "profile of read %d" % i
+        except Exception as e:                                      # noqa: BLE001
+            print("FAILED", desc, repr(e))
+            np.save("gpurun_out/fuzz_fail_bases.npy", bases)
+            np.save("gpurun_out/fuzz_fail_boff.npy", boff)
+            raise
+        if it % 10 == 9:
+            print("iteration %d ok (%.1f s)" % (it + 1, time.time() - t0), flush=True)
+    print("all %d iterations equal to the oracle (seed %d, %.1f s)" % (iters, seed, time.time() - t0))
+
+
+if __name__ == "__main__":
+    main()
