@@ -26,7 +26,8 @@ EXPORTS = [
     "fk_host_free", "fk_bucket_census", "fk_set_bucket_weights", "fk_push_fasta", "fk_merge_tables",
     "fk_write_ktab_ex", "fk_rounds_begin", "fk_rounds_add", "fk_rounds_finish",
     "fk_make_profiles", "fk_write_prof", "fk_set_table", "fk_ktab_idx_bytes", "fk_ktab_split",
-    "fk_write_ktab_range", "fk_write_ktab_stub",
+    "fk_write_ktab_range", "fk_write_ktab_stub", "fk_split_supermers_emit_pos", "fk_profile_lookup_supermers",
+    "fk_profile_scatter", "fk_profile_encode",
 ]
 
 
@@ -142,6 +143,10 @@ def load_library():
     L.fk_ktab_split.argtypes = [C.POINTER(i64), ci, ci, C.POINTER(ci)]
     L.fk_write_ktab_range.argtypes = [vp, i64, ci, ci, C.POINTER(ci), ci, ci, C.c_char_p, C.c_char_p, vp]
     L.fk_write_ktab_stub.argtypes = [ci, ci, ci, ci, vp, C.c_char_p, C.c_char_p]
+    L.fk_split_supermers_emit_pos.argtypes = [vp, vp, i64, vp, i64, C.POINTER(i64), vp]
+    L.fk_profile_lookup_supermers.argtypes = [vp, vp, i64, vp, i64, C.POINTER(i64)]
+    L.fk_profile_scatter.argtypes = [vp, vp, vp, i64, vp, i64, ci]
+    L.fk_profile_encode.argtypes = [vp, vp, i64, C.POINTER(CProfiles)]
     L.fk_rounds_begin.argtypes = [vp]
     L.fk_rounds_add.argtypes = [vp, vp, i64]
     L.fk_rounds_finish.argtypes = [vp, C.c_int, C.POINTER(CResult)]
@@ -307,6 +312,27 @@ class Context:
         r = CResult()
         self._ck(self.L.fk_rounds_finish(self.h, 1 if fetch_table else 0, C.byref(r)))
         return Result(r, self.w.kmer_word)
+
+    def split_emit_pos(self, reads_ptr, nbytes, out_ptr, cap, counts, pos_ptr):
+        bc = (C.c_int64 * 256)(*[int(c) for c in counts])
+        self._ck(self.L.fk_split_supermers_emit_pos(self.h, reads_ptr, nbytes, out_ptr, cap, bc, pos_ptr))
+
+    def profile_lookup_supermers(self, smers_ptr, nsuper, counts_ptr=None, cap=0):
+        ni = C.c_int64()
+        self._ck(self.L.fk_profile_lookup_supermers(self.h, smers_ptr, nsuper, counts_ptr, cap, C.byref(ni)))
+        return ni.value
+
+    def profile_scatter(self, smers_ptr, pos_ptr, nsuper, counts_ptr, nbytes, reset=True):
+        self._ck(self.L.fk_profile_scatter(self.h, smers_ptr, pos_ptr, nsuper, counts_ptr, nbytes, 1 if reset else 0))
+
+    def profile_encode(self, reads_ptr, nbytes):
+        pr = CProfiles()
+        self._ck(self.L.fk_profile_encode(self.h, reads_ptr, nbytes, C.byref(pr)))
+        n = pr.nreads
+        offs = np.ctypeslib.as_array(pr.offsets, shape=(n + 1,)).copy() if pr.offsets else np.zeros(1, dtype=np.int64)
+        data = np.ctypeslib.as_array(pr.data, shape=(pr.nbytes,)).copy() if pr.nbytes > 0 \
+            else np.zeros(0, dtype=np.uint8)
+        return data, offs
 
     def set_table(self, records):
         """(n, KMER_WORD) uint8 entries, any order: the dictionary of the next make_profiles."""

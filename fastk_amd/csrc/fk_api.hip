@@ -1448,6 +1448,7 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
         break;
       // fk_make_profiles looks k-mers up in this table: it has to hold every k-mer of resident reads
       ctx->have_table = (d_smers_in == NULL && ctx->prm.table_cutoff == 1);
+      ctx->have_part_table = (ctx->prm.table_cutoff == 1);
       ctx->last_table = table;
       ctx->last_ntab  = ntab;
       hipEventRecord(ev[2], s);
@@ -1559,6 +1560,10 @@ extern "C" int fk_rounds_finish(fk_ctx *ctx, int fetch_table, fk_result *res)
     return (rc);
   if ((rc = fetch_result_table(ctx, res, table, ctx->acc_ntab, fetch_table != 0)) != FK_OK)
     return (rc);
+  ctx->have_table = false;                       // a rank's pieces: not the whole data set
+  ctx->have_part_table = (ctx->prm.table_cutoff == 1);
+  ctx->last_table = table;
+  ctx->last_ntab  = ctx->acc_ntab;
   res->ms_sort_super = tm.group_s;
   res->ms_expand     = tm.expand;
   res->ms_sort_kmer  = tm.radix_k;
@@ -1582,68 +1587,10 @@ static int write_all(int fd, const void *p, size_t n)
 // (count.c:1893-1910, README.md:936-961)
 // ---- profiles (-p) ---------------------------------------------------------------------------
 
-extern "C" int fk_set_table(fk_ctx *ctx, const uint8_t *records, int64_t n)
-{ if (ctx == NULL || n < 0 || (records == NULL && n > 0)) return (FK_EINVAL);
-  const fk_widths &w = ctx->wid;
-  hipStream_t s = ctx->stream;
-  FK_HIP(ctx, hipSetDevice(ctx->device));
-  ctx->have_table = false;
-  ctx->last_table = NULL;
-  ctx->last_ntab  = 0;
-  if (n > 0)
-    { void *d_t = fk_slot(ctx, FK_SLOT_TABLE, n * w.kmer_stride);
-      if (d_t == NULL)
-        return (FK_ENOMEM);
-      if (w.kmer_word == w.kmer_stride)
-        FK_HIP(ctx, hipMemcpyAsync(d_t, records, (size_t) n * w.kmer_stride, hipMemcpyHostToDevice, s));
-      else
-        { std::vector<uint8_t> stage((size_t) n * w.kmer_stride, 0);
-          for (int64_t i = 0; i < n; i++)
-            { memcpy(stage.data() + i * w.kmer_stride, records + i * w.kmer_word, w.kmer_bytes);
-              memcpy(stage.data() + i * w.kmer_stride + w.kmer_stride - 2, records + i * w.kmer_word + w.kmer_bytes, 2);
-            }
-          FK_HIP(ctx, hipMemcpyAsync(d_t, stage.data(), stage.size(), hipMemcpyHostToDevice, s));
-          FK_HIP(ctx, hipStreamSynchronize(s));
-        }
-      FK_HIP(ctx, hipStreamSynchronize(s));
-      ctx->last_table = d_t;                   // the look-ups hash the records: no order needed
-    }
-  ctx->last_ntab  = n;
-  ctx->have_table = true;
-  return (FK_OK);
-}
-
-extern "C" int fk_make_profiles(fk_ctx *ctx, const void *d_bases, int64_t nbytes, fk_profiles *out)
-{ if (ctx == NULL || out == NULL || nbytes < 0) return (FK_EINVAL);
-  memset(out, 0, sizeof(*out));
-  FK_HIP(ctx, hipSetDevice(ctx->device));
-  if (!ctx->have_table)
-    { fk_set_error(ctx, "fk_make_profiles: needs fk_set_table or the table of a finished resident run with table_cutoff 1");
-      return (FK_ESTATE);
-    }
-  if (ctx->prm.bc_prefix > 0)
-    { fk_set_error(ctx, "fk_make_profiles: not available together with bc_prefix");
-      return (FK_EUNSUPPORTED);
-    }
-  const bool own_reads = (d_bases == NULL);
-  if (((uintptr_t) d_bases & 15) != 0)
-    { fk_set_error(ctx, "fk_make_profiles: d_bases must be 16-byte aligned");
-      return (FK_EINVAL);
-    }
-  if (d_bases == NULL)
-    { if (ctx->chunk_bytes > 0)
-        { fk_set_error(ctx, "fk_make_profiles: the reads of a chunked run are not kept -- pass them again piece by piece");
-          return (FK_ESTATE);
-        }
-      d_bases = ctx->d_reads;
-      nbytes  = ctx->reads_len;
-    }
-  int64_t nreads = 0, nprof = 0;
-  void *d_data = NULL;
-  uint64_t *d_offs = NULL;
-  int rc = fkx_profiles(ctx, d_bases, nbytes, ctx->last_table, ctx->last_ntab, &nreads, &nprof, &d_data, &d_offs);
-  if (rc != FK_OK)
-    return (rc);
+// compressed profiles + offsets from HBM into the context's host buffers, in the data set's read order
+static int profiles_to_host(fk_ctx *ctx, int64_t nreads, int64_t nprof, void *d_data, uint64_t *d_offs,
+                            bool own_reads)
+{
   if (ctx->h_prof_cap < nprof + 1)
     { free(ctx->h_prof);
       ctx->h_prof = (uint8_t *) malloc((size_t) nprof + 1);
@@ -1718,12 +1665,149 @@ extern "C" int fk_make_profiles(fk_ctx *ctx, const void *d_bases, int64_t nbytes
             }
         }
     }
+  return (FK_OK);
+}
+
+extern "C" int fk_set_table(fk_ctx *ctx, const uint8_t *records, int64_t n)
+{ if (ctx == NULL || n < 0 || (records == NULL && n > 0)) return (FK_EINVAL);
+  const fk_widths &w = ctx->wid;
+  hipStream_t s = ctx->stream;
+  FK_HIP(ctx, hipSetDevice(ctx->device));
+  ctx->have_table = false;
+  ctx->have_part_table = false;
+  ctx->last_table = NULL;
+  ctx->last_ntab  = 0;
+  if (n > 0)
+    { void *d_t = fk_slot(ctx, FK_SLOT_TABLE, n * w.kmer_stride);
+      if (d_t == NULL)
+        return (FK_ENOMEM);
+      if (w.kmer_word == w.kmer_stride)
+        FK_HIP(ctx, hipMemcpyAsync(d_t, records, (size_t) n * w.kmer_stride, hipMemcpyHostToDevice, s));
+      else
+        { std::vector<uint8_t> stage((size_t) n * w.kmer_stride, 0);
+          for (int64_t i = 0; i < n; i++)
+            { memcpy(stage.data() + i * w.kmer_stride, records + i * w.kmer_word, w.kmer_bytes);
+              memcpy(stage.data() + i * w.kmer_stride + w.kmer_stride - 2, records + i * w.kmer_word + w.kmer_bytes, 2);
+            }
+          FK_HIP(ctx, hipMemcpyAsync(d_t, stage.data(), stage.size(), hipMemcpyHostToDevice, s));
+          FK_HIP(ctx, hipStreamSynchronize(s));
+        }
+      FK_HIP(ctx, hipStreamSynchronize(s));
+      ctx->last_table = d_t;                   // the look-ups hash the records: no order needed
+    }
+  ctx->last_ntab  = n;
+  ctx->have_table = true;
+  return (FK_OK);
+}
+
+extern "C" int fk_make_profiles(fk_ctx *ctx, const void *d_bases, int64_t nbytes, fk_profiles *out)
+{ if (ctx == NULL || out == NULL || nbytes < 0) return (FK_EINVAL);
+  memset(out, 0, sizeof(*out));
+  FK_HIP(ctx, hipSetDevice(ctx->device));
+  if (!ctx->have_table)
+    { fk_set_error(ctx, "fk_make_profiles: needs fk_set_table or the table of a finished resident run with table_cutoff 1");
+      return (FK_ESTATE);
+    }
+  if (ctx->prm.bc_prefix > 0)
+    { fk_set_error(ctx, "fk_make_profiles: not available together with bc_prefix");
+      return (FK_EUNSUPPORTED);
+    }
+  const bool own_reads = (d_bases == NULL);
+  if (((uintptr_t) d_bases & 15) != 0)
+    { fk_set_error(ctx, "fk_make_profiles: d_bases must be 16-byte aligned");
+      return (FK_EINVAL);
+    }
+  if (d_bases == NULL)
+    { if (ctx->chunk_bytes > 0)
+        { fk_set_error(ctx, "fk_make_profiles: the reads of a chunked run are not kept -- pass them again piece by piece");
+          return (FK_ESTATE);
+        }
+      d_bases = ctx->d_reads;
+      nbytes  = ctx->reads_len;
+    }
+  int64_t nreads = 0, nprof = 0;
+  void *d_data = NULL;
+  uint64_t *d_offs = NULL;
+  int rc = fkx_profiles(ctx, d_bases, nbytes, ctx->last_table, ctx->last_ntab, &nreads, &nprof, &d_data, &d_offs);
+  if (rc != FK_OK)
+    return (rc);
+  if ((rc = profiles_to_host(ctx, nreads, nprof, d_data, d_offs, own_reads)) != FK_OK)
+    return (rc);
   out->nreads  = nreads;
   out->nbytes  = nprof;
   out->data    = ctx->h_prof;
   out->offsets = ctx->h_prof_off;
   out->nsplit  = ctx->h_prof_nsplit;
   out->split   = ctx->h_prof_nsplit > 0 ? ctx->h_prof_split : NULL;
+  return (FK_OK);
+}
+
+// ---- profiles in the sharded run: look-ups on the owning rank, counts sent back ----------------------
+
+extern "C" int fk_split_supermers_emit_pos(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out,
+                                           int64_t cap, const int64_t *bucket_counts, void *d_pos)
+{ if (ctx == NULL || d_bases == NULL || d_out == NULL || bucket_counts == NULL || d_pos == NULL || nbytes < 0)
+    return (FK_EINVAL);
+  if (((uintptr_t) d_bases & 15) != 0)
+    { fk_set_error(ctx, "fk_split_supermers_emit_pos: read buffer must be 16-byte aligned");
+      return (FK_EINVAL);
+    }
+  int64_t bc[256], ns = 0, ni = 0;
+  for (int b = 0; b < ctx->prm.nbuckets; b++)
+    { bc[b] = bucket_counts[b];
+      ns += bc[b];
+    }
+  if (cap < ns)
+    { fk_set_error(ctx, "fk_split_supermers_emit_pos: buffer holds %lld records, %lld needed",
+                   (long long) cap, (long long) ns);
+      return (FK_EINVAL);
+    }
+  if (ns == 0)
+    return (FK_OK);
+  FK_HIP(ctx, hipSetDevice(ctx->device));
+  return fkx_split(ctx, d_bases, nbytes, d_out, cap, &ns, &ni, bc, true, d_pos);
+}
+
+extern "C" int fk_profile_lookup_supermers(fk_ctx *ctx, const void *d_smers, int64_t nsuper, void *d_counts,
+                                           int64_t cap, int64_t *ninst)
+{ if (ctx == NULL || ninst == NULL || nsuper < 0 || (nsuper > 0 && d_smers == NULL)) return (FK_EINVAL);
+  FK_HIP(ctx, hipSetDevice(ctx->device));
+  if (!ctx->have_part_table && !ctx->have_table)
+    { fk_set_error(ctx, "fk_profile_lookup_supermers: needs the table of a finished run with table_cutoff 1");
+      return (FK_ESTATE);
+    }
+  return fkx_profile_lookup_supermers(ctx, d_smers, nsuper, ctx->last_table, ctx->last_ntab, d_counts, cap, ninst);
+}
+
+extern "C" int fk_profile_scatter(fk_ctx *ctx, const void *d_smers, const void *d_pos, int64_t nsuper,
+                                  const void *d_counts, int64_t nbytes, int reset)
+{ if (ctx == NULL || nsuper < 0 || nbytes < 0 || (nsuper > 0 && (d_smers == NULL || d_pos == NULL || d_counts == NULL)))
+    return (FK_EINVAL);
+  FK_HIP(ctx, hipSetDevice(ctx->device));
+  return fkx_profile_scatter(ctx, d_smers, d_pos, nsuper, d_counts, nbytes, reset != 0);
+}
+
+extern "C" int fk_profile_encode(fk_ctx *ctx, const void *d_bases, int64_t nbytes, fk_profiles *out)
+{ if (ctx == NULL || out == NULL || d_bases == NULL || nbytes < 0) return (FK_EINVAL);
+  memset(out, 0, sizeof(*out));
+  FK_HIP(ctx, hipSetDevice(ctx->device));
+  if (((uintptr_t) d_bases & 15) != 0)
+    { fk_set_error(ctx, "fk_profile_encode: d_bases must be 16-byte aligned");
+      return (FK_EINVAL);
+    }
+  int64_t nreads = 0, nprof = 0;
+  void *d_data = NULL;
+  uint64_t *d_offs = NULL;
+  int rc = fkx_profile_encode_counts(ctx, d_bases, nbytes, &nreads, &nprof, &d_data, &d_offs);
+  if (rc != FK_OK)
+    return (rc);
+  ctx->h_prof_nsplit = 0;
+  if ((rc = profiles_to_host(ctx, nreads, nprof, d_data, d_offs, false)) != FK_OK)
+    return (rc);
+  out->nreads  = nreads;
+  out->nbytes  = nprof;
+  out->data    = ctx->h_prof;
+  out->offsets = ctx->h_prof_off;
   return (FK_OK);
 }
 

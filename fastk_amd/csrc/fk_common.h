@@ -63,7 +63,8 @@ struct fk_ctx
   int64_t    h_table_cap;
   void      *last_table;   // sorted table of the last resident run (HBM), for fk_make_profiles
   int64_t    last_ntab;
-  bool       have_table;
+  bool       have_table;    // last_table holds every k-mer of the data set (or was installed by fk_set_table)
+  bool       have_part_table; // last_table holds every k-mer of the records this context counted (cutoff 1)
   struct fk_block *blocks;  // push history (for the read order of the profiles)
   int64_t    nblocks, blocks_cap;
   bool       blocks_bad;    // reads also arrived through calls that carry no thread id
@@ -144,7 +145,8 @@ int fkx_lsd_sort(fk_ctx *ctx, int64_t nelem, void *d_src, void *d_trg, int rsize
 int fkx_group(fk_ctx *ctx, int64_t nelem, void *d_src, void *d_trg, int rsize, int key_bytes,
               int npasses, void **result);
 int fkx_split(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int64_t cap,
-              int64_t *nsuper, int64_t *ninst, int64_t *bucket_counts, bool counts_known);
+              int64_t *nsuper, int64_t *ninst, int64_t *bucket_counts, bool counts_known,
+              void *d_pos = NULL);
 int fkx_split_plan(fk_ctx *ctx, const void *d_bases, int64_t nbytes, int64_t *cap, int64_t *offsets);
 int fkx_split_planned(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int64_t cap,
                       const int64_t *offsets, int64_t *counts, int64_t *ninst);
@@ -173,6 +175,12 @@ int fkx_dedup_supermers(fk_ctx *ctx, const void *d_grouped, int64_t n, void *d_o
 int fkx_sort_table(fk_ctx *ctx, int64_t n, void *d_tab, void *d_tmp, void **result, int64_t *wfirst);
 int fkx_profiles(fk_ctx *ctx, const void *d_bases, int64_t nbytes, const void *d_table, int64_t nt,
                  int64_t *nreads_out, int64_t *nprof_out, void **d_data, uint64_t **d_offs);
+int fkx_profile_lookup_supermers(fk_ctx *ctx, const void *d_smers, int64_t ns, const void *d_table, int64_t nt,
+                                 void *d_out, int64_t cap, int64_t *ninst);
+int fkx_profile_scatter(fk_ctx *ctx, const void *d_smers, const void *d_pos, int64_t ns, const void *d_in,
+                        int64_t nbytes, bool reset);
+int fkx_profile_encode_counts(fk_ctx *ctx, const void *d_bases, int64_t nbytes, int64_t *nreads_out,
+                              int64_t *nprof_out, void **d_data, uint64_t **d_offs);
 int fkx_synth(fk_ctx *ctx, uint64_t seed, uint64_t genome_len, uint32_t read_len,
               uint32_t err_ppm, uint64_t first_read, int64_t nreads, void *d_bases);
 

@@ -80,6 +80,70 @@ __device__ __forceinline__ u32 pf_rev2(u32 x)      // reverse the order of the 1
   return (((y & 0x55555555u) << 1) | ((y >> 1) & 0x55555555u));
 }
 
+// count of the k-mer whose forward strand is a[] (K bases, first base in the top bits of a[0], pad
+// bits zero): reverse complement, canonical = the smaller, home line of the dictionary
+template <int KW, int SW>
+__device__ __forceinline__ u32 pf_count_of(u32 *a, u32 tmask, int ps, const u32 *__restrict__ slots, u64 nlines,
+                                           u32 kmask)
+{ constexpr int SD = (SW <= 4) ? 4 : 8, G = 16 / SD;
+  u32 b[KW + 1];
+  u32 cnt = 0;
+#pragma unroll
+  for (int w = 0; w < KW; w++)
+    b[w] = pf_rev2(~a[KW - 1 - w]);
+  b[KW] = 0;
+#pragma unroll
+  for (int w = 0; w < KW; w++)
+    b[w] = (u32) (((((u64) b[w]) << 32) | b[w + 1]) << ps >> 32);
+  b[KW - 1] &= tmask;
+  bool rc_less = false, decided = false;
+#pragma unroll
+  for (int w = 0; w < KW; w++)
+    if (!decided && a[w] != b[w])
+      { rc_less = b[w] < a[w];
+        decided = true;
+      }
+  if (rc_less)
+    {
+#pragma unroll
+      for (int w = 0; w < KW; w++)
+        a[w] = b[w];
+    }
+  u32 kd[KW];                                     // the key as the record's dwords
+#pragma unroll
+  for (int w = 0; w < KW; w++)
+    kd[w] = __builtin_bswap32(a[w]);
+  const u64 h = pf_hash<KW>(kd);
+  u64 line = (u64) (((unsigned __int128) h * nlines) >> 64);
+  while (true)
+    { const uint4 *lp = (const uint4 *) (slots + line * 16);
+      u32 v[16];
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        { const uint4 x = lp[q];
+          v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
+        }
+      bool hit = false, room = false;
+#pragma unroll
+      for (int j = 0; j < G; j++)
+        { const u32 last = v[j * SD + SW - 1];
+          bool eq = (last != 0u);
+#pragma unroll
+          for (int w = 0; w < KW; w++)
+            eq = eq && (((w == KW - 1) ? (v[j * SD + w] & kmask) : v[j * SD + w]) == kd[w]);
+          if (eq)
+            { cnt = last >> 16;
+              hit = true;
+            }
+          room = room || (last == 0u);
+        }
+      if (hit || room)
+        break;
+      line = (line + 1 == nlines) ? 0 : line + 1;
+    }
+  return (cnt);
+}
+
 template <int KW, int SW>
 static __global__ __launch_bounds__(256) void k_pf_counts(const uint8_t *__restrict__ bases, int64_t n, int K,
                                                            const u32 *__restrict__ slots, u64 nlines,
@@ -151,67 +215,74 @@ static __global__ __launch_bounds__(256) void k_pf_counts(const uint8_t *__restr
       u32 cnt = 0;
       if (ok)
         { const int q = i >> 4, sh = (i & 15) * 2;
-          u32 a[KW], b[KW + 1];
+          u32 a[KW];
 #pragma unroll
           for (int w = 0; w < KW; w++)
             a[w] = (u32) (((((u64) fw[q + w]) << 32) | fw[q + w + 1]) << sh >> 32);
           a[KW - 1] &= tmask;
-#pragma unroll
-          for (int w = 0; w < KW; w++)
-            b[w] = pf_rev2(~a[KW - 1 - w]);
-          b[KW] = 0;
-#pragma unroll
-          for (int w = 0; w < KW; w++)
-            b[w] = (u32) (((((u64) b[w]) << 32) | b[w + 1]) << ps >> 32);
-          b[KW - 1] &= tmask;
-          bool rc_less = false, decided = false;
-#pragma unroll
-          for (int w = 0; w < KW; w++)
-            if (!decided && a[w] != b[w])
-              { rc_less = b[w] < a[w];
-                decided = true;
-              }
-          if (rc_less)
-            {
-#pragma unroll
-              for (int w = 0; w < KW; w++)
-                a[w] = b[w];
-            }
-          u32 kd[KW];                                     // the key as the record's dwords
-#pragma unroll
-          for (int w = 0; w < KW; w++)
-            kd[w] = __builtin_bswap32(a[w]);
-          const u64 h = pf_hash<KW>(kd);
-          u64 line = (u64) (((unsigned __int128) h * nlines) >> 64);
-          while (true)
-            { const uint4 *lp = (const uint4 *) (slots + line * 16);
-              u32 v[16];
-#pragma unroll
-              for (int q = 0; q < 4; q++)
-                { const uint4 x = lp[q];
-                  v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
-                }
-              bool hit = false, room = false;
-#pragma unroll
-              for (int j = 0; j < G; j++)
-                { const u32 last = v[j * SD + SW - 1];
-                  bool eq = (last != 0u);
-#pragma unroll
-                  for (int w = 0; w < KW; w++)
-                    eq = eq && (((w == KW - 1) ? (v[j * SD + w] & kmask) : v[j * SD + w]) == kd[w]);
-                  if (eq)
-                    { cnt = last >> 16;
-                      hit = true;
-                    }
-                  room = room || (last == 0u);
-                }
-              if (hit || room)
-                break;
-              line = (line + 1 == nlines) ? 0 : line + 1;
-            }
+          cnt = pf_count_of<KW, SW>(a, tmask, ps, slots, nlines, kmask);
         }
       out[p] = (uint16_t) cnt;
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// sharded run: the rank that owns a super-mer's bucket looks its k-mers up and the counts travel back
+
+// k-mers per super-mer record (its length byte + 1)
+static __global__ __launch_bounds__(256) void k_pf_smer_n(const u32 *__restrict__ smers, int64_t ns, int sww,
+                                                           int smer_bytes, u32 *__restrict__ n)
+{ const int64_t r = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (r < ns)
+    n[r] = ((smers[r * sww + (smer_bytes >> 2)] >> (8 * (smer_bytes & 3))) & 0xffu) + 1u;
+}
+
+// counts of the k-mers of every record, in record order: out[koff[r] + j] = count of its j-th k-mer
+template <int KW, int SW, int RWS>          // RWS: capacity in record dwords (4 or 8), sww the real stride
+static __global__ __launch_bounds__(256) void k_pf_smer_counts(const u32 *__restrict__ smers, int64_t ns, int sww,
+                                                                const u64 *__restrict__ koff, int K,
+                                                                const u32 *__restrict__ slots, u64 nlines,
+                                                                u32 kmask, uint16_t *__restrict__ out)
+{ const int64_t r = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (r >= ns)
+    return;
+  u32 w[RWS + KW + 1];
+#pragma unroll
+  for (int q = 0; q < RWS + KW + 1; q++)
+    w[q] = (q < RWS && q < sww) ? __builtin_bswap32(smers[r * sww + q]) : 0u;
+  const int n = (int) (koff[r + 1] - koff[r]);
+  const int tb = K - 16 * (KW - 1);
+  const u32 tmask = (tb == 16) ? 0xffffffffu : ~(0xffffffffu >> (2 * tb));
+  const int ps = 2 * (16 - tb);
+  uint16_t *o = out + koff[r];
+  for (int j = 0; j < n; j++)
+    { // bases [j, j+K) of the record: shift the whole word array left by one base per step
+      u32 a[KW];
+#pragma unroll
+      for (int q = 0; q < KW; q++)
+        a[q] = w[q];
+      a[KW - 1] &= tmask;
+      o[j] = (uint16_t) pf_count_of<KW, SW>(a, tmask, ps, slots, nlines, kmask);
+#pragma unroll
+      for (int q = 0; q < RWS + KW; q++)
+        w[q] = (w[q] << 2) | (w[q + 1] >> 30);
+      w[RWS + KW] <<= 2;
+    }
+}
+
+// the counts that came back, placed at the positions the records were cut from
+static __global__ __launch_bounds__(256) void k_pf_scatter(const u64 *__restrict__ pos, const u64 *__restrict__ koff,
+                                                            int64_t ns, const uint16_t *__restrict__ in,
+                                                            uint16_t *__restrict__ cnts)
+{ const int64_t r = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (r >= ns)
+    return;
+  const u64 p = pos[r] >> 1;
+  const bool flip = (pos[r] & 1u) != 0;
+  const int n = (int) (koff[r + 1] - koff[r]);
+  const uint16_t *c = in + koff[r];
+  for (int j = 0; j < n; j++)
+    cnts[p + (flip ? n - 1 - j : j)] = c[j];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -406,27 +477,83 @@ static __global__ __launch_bounds__(256) void k_pf_blockscan(const u32 *__restri
 // ---------------------------------------------------------------------------------------
 
 template <int KW, int SW>
-static void pf_dictionary_and_counts(hipStream_t s, const u32 *table, int64_t nt, u32 kmask, u32 *slots, u64 nlines,
-                                     int64_t ntiles, const uint8_t *bases, int64_t n, int K, uint16_t *out)
+static void pf_launch_build(hipStream_t s, const u32 *table, int64_t nt, u32 kmask, u32 *slots, u64 nlines)
 { if (nt > 0)
     hipLaunchKernelGGL((k_pf_hbuild<KW, SW>), dim3((unsigned) ((nt + 255) / 256)), dim3(256), 0, s, table, nt, kmask,
                        slots, nlines);
-  hipLaunchKernelGGL((k_pf_counts<KW, SW>), dim3((unsigned) ntiles), dim3(256), 0, s, bases, n, K,
-                     (const u32 *) slots, nlines, kmask, out);
 }
+
+template <int KW, int SW>
+static void pf_launch_counts(hipStream_t s, const u32 *slots, u64 nlines, u32 kmask, int64_t ntiles,
+                             const uint8_t *bases, int64_t n, int K, uint16_t *out)
+{ hipLaunchKernelGGL((k_pf_counts<KW, SW>), dim3((unsigned) ntiles), dim3(256), 0, s, bases, n, K, slots, nlines,
+                     kmask, out);
+}
+
+template <int KW, int SW>
+static void pf_launch_smer_counts(hipStream_t s, const u32 *smers, int64_t ns, int sww, const u64 *koff, int K,
+                                  const u32 *slots, u64 nlines, u32 kmask, uint16_t *out)
+{ const unsigned nb = (unsigned) ((ns + 255) / 256);
+  if (sww <= 4)
+    hipLaunchKernelGGL((k_pf_smer_counts<KW, SW, 4>), dim3(nb), dim3(256), 0, s, smers, ns, sww, koff, K, slots,
+                       nlines, kmask, out);
+  else
+    hipLaunchKernelGGL((k_pf_smer_counts<KW, SW, 8>), dim3(nb), dim3(256), 0, s, smers, ns, sww, koff, K, slots,
+                       nlines, kmask, out);
+}
+
+// dispatch on (key dwords, record dwords) of the k-mer records
+#define PF_DISPATCH(ctx, KW, sdw, CALL)                                                              \
+  do                                                                                                 \
+    { if      (KW == 1 && sdw == 1) { CALL(1, 1); } else if (KW == 1 && sdw == 2) { CALL(1, 2); }     \
+      else if (KW == 2 && sdw == 2) { CALL(2, 2); } else if (KW == 2 && sdw == 3) { CALL(2, 3); }     \
+      else if (KW == 3 && sdw == 3) { CALL(3, 3); } else if (KW == 3 && sdw == 4) { CALL(3, 4); }     \
+      else if (KW == 4 && sdw == 4) { CALL(4, 4); } else if (KW == 4 && sdw == 5) { CALL(4, 5); }     \
+      else                                                                                           \
+        { fk_set_error(ctx, "profiles: k = %d not supported", ctx->wid.kmer);                        \
+          return (FK_EUNSUPPORTED);                                                                  \
+        }                                                                                            \
+    }                                                                                                \
+  while (0)
+
+struct pf_dict
+{ u32 *slots;
+  u64  nlines;
+  u32  kmask;
+  int  KW, sdw;
+};
+
+// the table (nt records of kmer_stride bytes, distinct k-mers, any order, counts >= 1) as the
+// dictionary of the look-up kernels, load factor <= 1/2
+static int pf_dictionary(fk_ctx *ctx, const void *d_table, int64_t nt, pf_dict *d)
+{ const fk_widths &w = ctx->wid;
+  hipStream_t s = ctx->stream;
+  d->KW  = (w.kmer_bytes + 3) / 4;
+  d->sdw = w.kmer_stride / 4;
+  const int kb_last = w.kmer_bytes - 4 * (d->KW - 1);        // key bytes in the last key dword
+  d->kmask = (kb_last == 4) ? 0xffffffffu : ((1u << (8 * kb_last)) - 1u);
+  const int G = (d->sdw <= 4) ? 4 : 2;                       // slots per 64-byte line
+  d->nlines = (u64) std::max<int64_t>(1, (2 * nt + G - 1) / G);
+  d->slots = (u32 *) fk_slot(ctx, FK_SLOT_PF_IDX, (int64_t) d->nlines * 64);
+  if (d->slots == NULL) return (FK_ENOMEM);
+  FK_HIP(ctx, hipMemsetAsync(d->slots, 0, (size_t) d->nlines * 64, s));
+#define PF_CALL(kw, sw) pf_launch_build<kw, sw>(s, (const u32 *) d_table, nt, d->kmask, d->slots, d->nlines)
+  PF_DISPATCH(ctx, d->KW, d->sdw, PF_CALL);
+#undef PF_CALL
+  FK_LAUNCH_CHECK(ctx);
+  return (FK_OK);
+}
+
+static int fkx_profile_encode(fk_ctx *ctx, const uint8_t *bases, int64_t nbytes, const uint16_t *cnts,
+                              int64_t *nreads_out, int64_t *nprof_out, void **d_data, uint64_t **d_offs);
 
 // Profiles of the reads in d_bases[0..nbytes) (reads end at 0 bytes; a last read without terminator
 // ends at nbytes) against the table d_table (nt records of kmer_stride bytes with distinct k-mers, any
 // order, counts >= 1).  Results stay in HBM: *d_data (nprof bytes) and *d_offs (nreads + 1 offsets).
 int fkx_profiles(fk_ctx *ctx, const void *d_bases, int64_t nbytes, const void *d_table, int64_t nt,
                  int64_t *nreads_out, int64_t *nprof_out, void **d_data, uint64_t **d_offs)
-{ const fk_widths &w = ctx->wid;
-  hipStream_t s = ctx->stream;
-  const int K = w.kmer;
-  const int KW = (w.kmer_bytes + 3) / 4;
-  const int sdw = w.kmer_stride / 4;
-  const int kb_last = w.kmer_bytes - 4 * (KW - 1);          // key bytes in the last key dword
-  const u32 kmask = (kb_last == 4) ? 0xffffffffu : ((1u << (8 * kb_last)) - 1u);
+{ hipStream_t s = ctx->stream;
+  const int K = ctx->wid.kmer;
   const uint8_t *bases = (const uint8_t *) d_bases;
 
   *nreads_out = 0;
@@ -440,25 +567,117 @@ int fkx_profiles(fk_ctx *ctx, const void *d_bases, int64_t nbytes, const void *d
       return (FK_EUNSUPPORTED);
     }
 
-  // 1. + 2. dictionary (load factor <= 1/2), then counts per position
-  const int     G = (sdw <= 4) ? 4 : 2;                       // slots per 64-byte line
-  const int64_t nlines = std::max<int64_t>(1, (2 * nt + G - 1) / G);
-  u32 *slots = (u32 *) fk_slot(ctx, FK_SLOT_PF_IDX, nlines * 64);
+  // 1. + 2. dictionary, then counts per position
+  pf_dict d;
+  int rc = pf_dictionary(ctx, d_table, nt, &d);
+  if (rc != FK_OK) return (rc);
   uint16_t *cnts = (uint16_t *) fk_slot(ctx, FK_SLOT_PF_CNT, nbytes * 2 + 64);
-  if (slots == NULL || cnts == NULL) return (FK_ENOMEM);
-  FK_HIP(ctx, hipMemsetAsync(slots, 0, (size_t) nlines * 64, s));
+  if (cnts == NULL) return (FK_ENOMEM);
   const int64_t ntiles = (nbytes + PF_TILE - 1) / PF_TILE;
-#define PF_CASE(kw, sw)                                                                                     \
-  if (KW == kw && sdw == sw)                                                                                \
-    pf_dictionary_and_counts<kw, sw>(s, (const u32 *) d_table, nt, kmask, slots, (u64) nlines, ntiles, bases, \
-                                     nbytes, K, cnts);                                                      \
-  else
-  PF_CASE(1, 1) PF_CASE(1, 2) PF_CASE(2, 2) PF_CASE(2, 3) PF_CASE(3, 3) PF_CASE(3, 4) PF_CASE(4, 4) PF_CASE(4, 5)
-    { fk_set_error(ctx, "profiles: k = %d not supported", K);
+#define PF_CALL(kw, sw) pf_launch_counts<kw, sw>(s, d.slots, d.nlines, d.kmask, ntiles, bases, nbytes, K, cnts)
+  PF_DISPATCH(ctx, d.KW, d.sdw, PF_CALL);
+#undef PF_CALL
+  FK_LAUNCH_CHECK(ctx);
+  return fkx_profile_encode(ctx, bases, nbytes, cnts, nreads_out, nprof_out, d_data, d_offs);
+}
+
+// Sharded run, owner side: counts of the k-mers of ns super-mer records (device stride) from the
+// dictionary of d_table, record after record: d_out[0 .. *ninst) u16.  cap in counts.
+int fkx_profile_lookup_supermers(fk_ctx *ctx, const void *d_smers, int64_t ns, const void *d_table, int64_t nt,
+                                 void *d_out, int64_t cap, int64_t *ninst)
+{ const fk_widths &w = ctx->wid;
+  hipStream_t s = ctx->stream;
+  *ninst = 0;
+  if (ns == 0)
+    return (FK_OK);
+  pf_dict d;
+  int rc = pf_dictionary(ctx, d_table, nt, &d);
+  if (rc != FK_OK) return (rc);
+  const int sww = w.smer_stride / 4;
+  u32 *n   = (u32 *) fk_slot(ctx, FK_SLOT_PF_LEN, ns * 4 + 64);
+  u64 *off = (u64 *) fk_slot(ctx, FK_SLOT_PF_OFF, (ns + 1) * 8 + 64);
+  const int64_t nblk = (ns + 4095) / 4096;
+  u32 *bs = (u32 *) fk_slot(ctx, FK_SLOT_PF_ZC, nblk * 4 + 64);
+  u64 *bo = (u64 *) fk_slot(ctx, FK_SLOT_PF_ZO, nblk * 8 + 64);
+  if (n == NULL || off == NULL || bs == NULL || bo == NULL) return (FK_ENOMEM);
+  hipLaunchKernelGGL(k_pf_smer_n, dim3((unsigned) ((ns + 255) / 256)), dim3(256), 0, s, (const u32 *) d_smers, ns,
+                     sww, w.smer_bytes, n);
+  hipLaunchKernelGGL(k_pf_blocksum, dim3((unsigned) nblk), dim3(256), 0, s, (const u32 *) n, ns, bs);
+  hipLaunchKernelGGL(k_exscan_tiles, dim3(1), dim3(256), 0, s, (const u32 *) bs, nblk, bo, off + ns);
+  hipLaunchKernelGGL(k_pf_blockscan, dim3((unsigned) nblk), dim3(256), 0, s, (const u32 *) n, ns, (const u64 *) bo, off);
+  FK_LAUNCH_CHECK(ctx);
+  FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch, off + ns, 8, hipMemcpyDeviceToHost, s));
+  FK_HIP(ctx, hipStreamSynchronize(s));
+  *ninst = (int64_t) ctx->h_scratch[0];
+  if (d_out == NULL || cap == 0)
+    return (FK_OK);
+  if (cap < *ninst)
+    { fk_set_error(ctx, "profile look-up: buffer holds %lld counts, %lld needed", (long long) cap, (long long) *ninst);
+      return (FK_EINVAL);
+    }
+  if (sww > 8)
+    { fk_set_error(ctx, "profiles: k = %d not supported", w.kmer);
       return (FK_EUNSUPPORTED);
     }
-#undef PF_CASE
+#define PF_CALL(kw, sw) pf_launch_smer_counts<kw, sw>(s, (const u32 *) d_smers, ns, sww, (const u64 *) off, w.kmer, \
+                                                      d.slots, d.nlines, d.kmask, (uint16_t *) d_out)
+  PF_DISPATCH(ctx, d.KW, d.sdw, PF_CALL);
+#undef PF_CALL
   FK_LAUNCH_CHECK(ctx);
+  FK_HIP(ctx, hipStreamSynchronize(s));
+  return (FK_OK);
+}
+
+// Sharded run, reader side: counts that came back for the ns records this rank sent (same order),
+// placed at the positions d_pos the records were cut from; reset clears the per-position array first.
+// fkx_profile_encode_counts then turns the array into profiles.
+int fkx_profile_scatter(fk_ctx *ctx, const void *d_smers, const void *d_pos, int64_t ns, const void *d_in,
+                        int64_t nbytes, bool reset)
+{ const fk_widths &w = ctx->wid;
+  hipStream_t s = ctx->stream;
+  uint16_t *cnts = (uint16_t *) fk_slot(ctx, FK_SLOT_PF_CNT, nbytes * 2 + 64);
+  if (cnts == NULL) return (FK_ENOMEM);
+  if (reset)
+    FK_HIP(ctx, hipMemsetAsync(cnts, 0, (size_t) nbytes * 2 + 64, s));
+  if (ns == 0)
+    return (FK_OK);
+  const int sww = w.smer_stride / 4;
+  u32 *n   = (u32 *) fk_slot(ctx, FK_SLOT_PF_LEN, ns * 4 + 64);
+  u64 *off = (u64 *) fk_slot(ctx, FK_SLOT_PF_OFF, (ns + 1) * 8 + 64);
+  const int64_t nblk = (ns + 4095) / 4096;
+  u32 *bs = (u32 *) fk_slot(ctx, FK_SLOT_PF_ZC, nblk * 4 + 64);
+  u64 *bo = (u64 *) fk_slot(ctx, FK_SLOT_PF_ZO, nblk * 8 + 64);
+  if (n == NULL || off == NULL || bs == NULL || bo == NULL) return (FK_ENOMEM);
+  hipLaunchKernelGGL(k_pf_smer_n, dim3((unsigned) ((ns + 255) / 256)), dim3(256), 0, s, (const u32 *) d_smers, ns,
+                     sww, w.smer_bytes, n);
+  hipLaunchKernelGGL(k_pf_blocksum, dim3((unsigned) nblk), dim3(256), 0, s, (const u32 *) n, ns, bs);
+  hipLaunchKernelGGL(k_exscan_tiles, dim3(1), dim3(256), 0, s, (const u32 *) bs, nblk, bo, off + ns);
+  hipLaunchKernelGGL(k_pf_blockscan, dim3((unsigned) nblk), dim3(256), 0, s, (const u32 *) n, ns, (const u64 *) bo, off);
+  hipLaunchKernelGGL(k_pf_scatter, dim3((unsigned) ((ns + 255) / 256)), dim3(256), 0, s, (const u64 *) d_pos,
+                     (const u64 *) off, ns, (const uint16_t *) d_in, cnts);
+  FK_LAUNCH_CHECK(ctx);
+  FK_HIP(ctx, hipStreamSynchronize(s));
+  return (FK_OK);
+}
+
+int fkx_profile_encode_counts(fk_ctx *ctx, const void *d_bases, int64_t nbytes, int64_t *nreads_out,
+                              int64_t *nprof_out, void **d_data, uint64_t **d_offs)
+{ *nreads_out = 0;
+  *nprof_out = 0;
+  *d_data = NULL;
+  *d_offs = NULL;
+  if (nbytes <= 0)
+    return (FK_OK);
+  uint16_t *cnts = (uint16_t *) fk_slot(ctx, FK_SLOT_PF_CNT, nbytes * 2 + 64);     // what fkx_profile_scatter filled
+  if (cnts == NULL) return (FK_ENOMEM);
+  return fkx_profile_encode(ctx, (const uint8_t *) d_bases, nbytes, cnts, nreads_out, nprof_out, d_data, d_offs);
+}
+
+// read boundaries and codec over the per-position counts
+static int fkx_profile_encode(fk_ctx *ctx, const uint8_t *bases, int64_t nbytes, const uint16_t *cnts,
+                              int64_t *nreads_out, int64_t *nprof_out, void **d_data, uint64_t **d_offs)
+{ hipStream_t s = ctx->stream;
+  const int K = ctx->wid.kmer;
 
   // 3. read boundaries
   const int64_t nz = (nbytes + PF_ZCH - 1) / PF_ZCH;

@@ -44,6 +44,7 @@ struct SplitArgs
   int64_t   cap;
   u32      *overflowed;
   int       tile_stride;    // count mode: visit every tile_stride-th tile only (sampling)
+  u64      *pos;            // POS kernels only: (position of the record's first k-mer << 1) | flip per record
 };
 
 __device__ __forceinline__ u32 sp_window(const u32 *arr, int off)
@@ -54,7 +55,7 @@ __device__ __forceinline__ u32 sp_window(const u32 *arr, int off)
   return (sh == 0) ? hi : ((hi << sh) | (lo >> (32 - sh)));
 }
 
-template <bool EMIT>
+template <bool EMIT, bool POS = false>
 __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
 { __shared__ u32      fwd[SP_WORDS];
   __shared__ u32      rcw[SP_WORDS];
@@ -334,6 +335,8 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
       const u32 *arr = flip ? rcw : fwd;
       const int  st  = flip ? (R - (i + L)) : i;
       u32 *dst = a.out + slot * sww;
+      if (POS)
+        a.pos[slot] = ((u64) (t0 + i) << 1) | flip;
       for (int q = 0; q < sww; q++)
         { u32 x = 0;
           const int rem = L - 16 * q;
@@ -353,7 +356,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
 // counts_known: bucket_counts[] (and *nsuper, *ninst) hold the result of an earlier counting call
 // on the same input, so only the emit kernel runs.
 int fkx_split(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int64_t cap,
-              int64_t *nsuper, int64_t *ninst, int64_t *bucket_counts, bool counts_known)
+              int64_t *nsuper, int64_t *ninst, int64_t *bucket_counts, bool counts_known, void *d_pos)
 { hipStream_t s = ctx->stream;
   const int   K = ctx->prm.kmer;
   const int   nb = ctx->prm.nbuckets;
@@ -393,6 +396,7 @@ int fkx_split(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int
   a.overflowed = d_ovf;
   a.tile_stride = 1;
   a.limit = NULL;
+  a.pos = (u64 *) d_pos;
 
   const int64_t nstarts = nbytes - K + 1;
   const int64_t ntiles  = (nstarts + SP_TILE - 1) / SP_TILE;
@@ -433,7 +437,10 @@ int fkx_split(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int
     }
 
   FK_HIP(ctx, hipMemcpyAsync(d_cursor, base, nb * sizeof(u64), hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(k_split<true>, dim3((unsigned) ntiles), dim3(SP_THREADS), 0, s, a);
+  if (d_pos != NULL)
+    hipLaunchKernelGGL((k_split<true, true>), dim3((unsigned) ntiles), dim3(SP_THREADS), 0, s, a);
+  else
+    hipLaunchKernelGGL(k_split<true>, dim3((unsigned) ntiles), dim3(SP_THREADS), 0, s, a);
   FK_LAUNCH_CHECK(ctx);
   FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch, d_ovf, sizeof(u32), hipMemcpyDeviceToHost, s));
   FK_HIP(ctx, hipStreamSynchronize(s));
@@ -478,7 +485,7 @@ int fkx_split_fast(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void **d_ou
       a.mbucket = ctx->d_mbucket;
       a.counts = d_counts;
       a.cursor = d_cursor;
-      a.limit = NULL;
+      a.limit = NULL; a.pos = NULL;
       a.overflowed = d_ovf;
       const int64_t nstarts = nbytes - K + 1;
       const int64_t ntiles  = (nstarts + SP_TILE - 1) / SP_TILE;
@@ -592,7 +599,7 @@ int fkx_split_plan(fk_ctx *ctx, const void *d_bases, int64_t nbytes, int64_t *ca
   a.mbucket = ctx->d_mbucket;
   a.counts = ctx->d_scratch;
   a.cursor = ctx->d_scratch + 512;
-  a.limit = NULL;
+  a.limit = NULL; a.pos = NULL;
   a.out = NULL; a.cap = 0;
   a.overflowed = (u32 *) (ctx->d_scratch + 1024);
   a.tile_stride = sample;
@@ -650,6 +657,7 @@ int fkx_split_planned(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_
   a.counts = ctx->d_scratch;
   a.cursor = ctx->d_scratch + 512;
   a.limit = ctx->d_scratch + 768;
+  a.pos = NULL;
   a.out = (u32 *) d_out; a.cap = cap;
   a.overflowed = (u32 *) (ctx->d_scratch + 1024);
   a.tile_stride = 1;

@@ -83,6 +83,41 @@ class HipEngine:
         """reads: uint8 tensor in HBM (0-terminated reads) -> (codec bytes, nreads + 1 offsets)."""
         return self.ctx.make_profiles(reads.data_ptr(), reads.numel())
 
+    # ---- profiles with the look-ups on the owning rank (profiles_exchanged) ----
+    def split_with_positions(self, reads):
+        """Exact count-then-emit split that also returns, per record, (position << 1) | flip (int64
+        tensor in HBM, same order as the records).  Buckets are contiguous, no padding."""
+        n = reads.numel()
+        ns, ni, counts = self.ctx.split(reads.data_ptr(), n)
+        recs = torch.empty(max(ns, 1) * self.stride, dtype=torch.uint8, device=self.device)
+        pos = torch.empty(max(ns, 1), dtype=torch.int64, device=self.device)
+        if ns:
+            self.ctx.split_emit_pos(reads.data_ptr(), n, recs.data_ptr(), ns, counts, pos.data_ptr())
+        offs = [0]
+        for c in counts[:-1]:
+            offs.append(offs[-1] + c)
+        return recs, counts, offs, ni, pos
+
+    def kmers_per_record(self, recs, nsuper):
+        """int64 tensor: k-mers of each record (its length byte + 1)."""
+        col = recs[: nsuper * self.stride].view(nsuper, self.stride)[:, self.ctx.w.smer_bytes]
+        return col.to(torch.int64) + 1
+
+    def lookup_supermers(self, recs, nsuper):
+        """Counts (uint16, as a uint8 tensor of 2 bytes each) of the k-mers of the records, record after
+        record, from the table this context holds after counting."""
+        ninst = self.ctx.profile_lookup_supermers(recs.data_ptr() if nsuper else None, nsuper)
+        out = torch.empty(max(ninst, 1) * 2, dtype=torch.uint8, device=self.device)
+        if nsuper:
+            self.ctx.profile_lookup_supermers(recs.data_ptr(), nsuper, out.data_ptr(), ninst)
+        return out[: ninst * 2]
+
+    def scatter_and_encode(self, reads, recs, pos, nsuper, counts):
+        n = reads.numel()
+        self.ctx.profile_scatter(recs.data_ptr() if nsuper else None, pos.data_ptr() if nsuper else None, nsuper,
+                                 counts.data_ptr() if nsuper else None, n, reset=True)
+        return self.ctx.profile_encode(reads.data_ptr(), n)
+
     def rounds_begin(self):
         self.ctx.rounds_begin()
 
@@ -322,6 +357,53 @@ def profiles_sharded(engine, reads, local_table, group=None):
         else local_table
     engine.set_table(union)
     return engine.make_profiles(reads)
+
+
+def profiles_exchanged(engine, reads, group=None):
+    """Counting + profiles of this rank's reads with no table replication (scales with the data set):
+    every super-mer record goes to the rank owning its bucket as in count_sharded, the sender keeps the
+    position it was cut from; after counting, the owner looks the k-mers of every record it received up
+    in its own table and the counts travel back over the same pairs (2 bytes per k-mer instance); the
+    sender scatters them to the positions and runs the codec.  The context must have table_cutoff 1 and
+    nbuckets == world size.  Returns (count_sharded-style totals dict, codec bytes, offsets)."""
+    world = dist.get_world_size(group)
+    stride = engine.stride
+    recs, counts, s_off, ninst, pos = engine.split_with_positions(reads)
+    assert len(counts) == world, "context must be created with nbuckets == world size"
+    dev = recs.device if hasattr(recs, "device") else torch.device("cpu")
+    send_n = [int(c) for c in counts]
+    nsent = sum(send_n)
+    per_rec = engine.kmers_per_record(recs, nsent)                      # k-mers of every sent record
+    inst_to = [int(per_rec[o:o + c].sum().item()) for o, c in zip(s_off, send_n)]
+    meta = torch.tensor(send_n + inst_to, dtype=torch.int64, device=dev).view(2, world).t().contiguous().view(-1)
+    got = torch.empty_like(meta)
+    dist.all_to_all_single(got, meta, group=group)
+    got = got.view(world, 2)
+    recv_n = [int(x) for x in got[:, 0].tolist()]
+    inst_from = [int(x) for x in got[:, 1].tolist()]
+    nrecv = sum(recv_n)
+    inbox = torch.empty(max(nrecv, 1) * stride, dtype=torch.uint8, device=dev)[: nrecv * stride]
+    _exchange_records(recs, inbox, send_n, recv_n, stride, group, s_off)
+    kept = inbox.clone()                                                # counting clobbers its input
+    loc = engine.count_supermers(inbox, nrecv, True)
+    del inbox
+    back = engine.lookup_supermers(kept, nrecv)                         # uint8 view of uint16 counts
+    assert back.numel() == 2 * sum(inst_from)
+    del kept
+    mine = torch.empty(max(sum(inst_to), 1) * 2, dtype=torch.uint8, device=dev)[: sum(inst_to) * 2]
+    _exchange_records(back, mine, inst_from, inst_to, 2, group)
+    data, offs = engine.scatter_and_encode(reads, recs, pos, nsent, mine)
+
+    tot = torch.zeros(HIST_BINS + 8, dtype=torch.int64, device=dev)
+    tot[:HIST_BINS] = torch.from_numpy(np.asarray(loc["hist"], dtype=np.int64)).to(dev)
+    tot[HIST_BINS:HIST_BINS + 6] = torch.tensor([loc["max_inst"], ninst, nrecv, loc["nweighted"], loc["ndistinct"],
+                                                 loc["ntable"]], dtype=torch.int64, device=dev)
+    dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=group)
+    t = tot.cpu().numpy()
+    totals = dict(hist=t[:HIST_BINS].copy(), max_inst=int(t[HIST_BINS]), ninst=int(t[HIST_BINS + 1]),
+                  nsuper=int(t[HIST_BINS + 2]), nweighted=int(t[HIST_BINS + 3]), ndistinct=int(t[HIST_BINS + 4]),
+                  ntable=int(t[HIST_BINS + 5]), local=loc)
+    return totals, data, offs
 
 
 def _post_round(recs, inbox, send_n, recv_n, s_off, stride, group):

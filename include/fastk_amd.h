@@ -308,6 +308,30 @@ int fk_make_profiles(fk_ctx *ctx, const void *d_bases, int64_t nbytes, fk_profil
    call fk_set_table, then fk_make_profiles(ctx, NULL, 0, &out). */
 int fk_set_table(fk_ctx *ctx, const uint8_t *records, int64_t n);
 
+/* Profiles in the sharded run without replicating the table (the reference carries run ordinals
+ * through its sorts for the same purpose, count.c:639-1181): the rank that reads a stripe keeps, for
+ * every super-mer record it sends away, the position it was cut from; the owning rank looks the
+ * record's k-mers up in ITS table after counting and sends the counts back (2 bytes per k-mer
+ * instance, same order as the records came); the reader scatters them to the positions and encodes.
+ *   fk_split_supermers_emit_pos  fk_split_supermers_emit that also writes d_pos[record] =
+ *                                (byte offset of the record's first k-mer in d_bases << 1) | flip
+ *                                (flip: the record holds the reverse strand, its k-mers run backwards)
+ *   fk_profile_lookup_supermers  owner: counts of the k-mers of nsuper records (device stride, e.g. a
+ *                                copy of the inbox taken before counting clobbered it), record after
+ *                                record, into d_counts (uint16, cap entries; cap 0 only sizes);
+ *                                needs the table of a finished cutoff-1 run of this context
+ *   fk_profile_scatter           reader: counts of the records it sent (same order) to their positions
+ *                                in a per-position array of nbytes entries (reset != 0 clears it first)
+ *   fk_profile_encode            reader: read boundaries + codec over that array -> profiles of the
+ *                                reads in d_bases (as fk_make_profiles returns them) */
+int fk_split_supermers_emit_pos(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int64_t cap,
+                                const int64_t *bucket_counts, void *d_pos);
+int fk_profile_lookup_supermers(fk_ctx *ctx, const void *d_smers, int64_t nsuper, void *d_counts, int64_t cap,
+                                int64_t *ninst);
+int fk_profile_scatter(fk_ctx *ctx, const void *d_smers, const void *d_pos, int64_t nsuper, const void *d_counts,
+                       int64_t nbytes, int reset);
+int fk_profile_encode(fk_ctx *ctx, const void *d_bases, int64_t nbytes, fk_profiles *out);
+
 /* <dir>/<root>.prof stub + hidden .<root>.pidx.N / .<root>.prof.N, N = 1..nparts (README.md:1010-1027);
    part t holds the reads of input thread t when nparts == p->nsplit, else the reads are divided evenly
    over the parts in input order. */

@@ -1226,3 +1226,30 @@ def test_randomised_differential_run():
                        capture_output=True, text=True, timeout=900, cwd=root)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     assert "all 40 iterations equal to the oracle" in p.stdout
+
+
+@pytest.mark.parametrize("name", ["synth_illumina_k40_t1_T4", "edge_k40_t1_T4", "edge_k51_t1_T4"])
+def test_profiles_with_lookups_on_the_owning_rank(name):
+    """shard.profiles_exchanged on a one-rank RCCL group: split with positions -> exchange -> count ->
+    owner-side look-ups of the received records -> counts back -> scatter to positions -> codec.  Totals
+    are the golden ones and the profiles decode to the reference's."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from fastk_amd import shard
+    case, bases, boff = util.load_case(name)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29593")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        with fastk_amd.Context(kmer=case["k"], table_cutoff=1, nbuckets=1) as ctx:
+            eng = shard.HipEngine(ctx, torch.device("cuda", 0))
+            reads = torch.from_numpy(bases).cuda()
+            tot, data, offs = shard.profiles_exchanged(eng, reads)
+    finally:
+        dist.destroy_process_group()
+    util.check_against_golden(case, tot["hist"], tot["max_inst"], tot["local"]["result"].table)
+    raw = data.tobytes()
+    got = [orc.profile_decode(raw[offs[i]:offs[i + 1]]) for i in range(len(offs) - 1)]
+    assert orc.profiles_digest(got) == case["expected"]["prof"]["decoded_sha256"]

@@ -101,6 +101,7 @@ def main():
                         assert raw[offs[i]:offs[i + 1]] == orc.profile_encode(x), "profile of read %d" % i
         except Exception as e:                                      # noqa: BLE001
             print("FAILED", desc, repr(e))
+            os.makedirs("gpurun_out", exist_ok=True)
             np.save("gpurun_out/fuzz_fail_bases.npy", bases)
             np.save("gpurun_out/fuzz_fail_boff.npy", boff)
             raise
