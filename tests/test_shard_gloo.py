@@ -81,6 +81,74 @@ class OracleEngine:
         res.table = table
         return dict(hist=hist, max_inst=mx, nweighted=nw, ndistinct=nd, ntable=nt, result=res)
 
+    # ---- checker versions of the stages of shard.profiles_exchanged: one record per valid k-mer
+    #      (any cut of the reads into super-mers is a legal input of the counting stages)
+    def split_with_positions(self, reads):
+        P = self.P
+        k = P.kmer
+        bases = reads.numpy()
+        code = orc._CODE[bases]
+        recs, pos = [], []
+        n = len(bases)
+        valid_run = 0
+        for i in range(n):
+            valid_run = valid_run + 1 if code[i] < 4 else 0
+            if valid_run >= k:
+                st = i - k + 1
+                rec = np.zeros(P.smer_word, dtype=np.uint8)
+                c = code[st:st + k]
+                pad = np.zeros(P.smer_bytes * 4, dtype=np.uint8)
+                pad[:k] = c
+                rec[:P.smer_bytes] = (pad.reshape(-1, 4) * np.array([64, 16, 4, 1], dtype=np.uint8)).sum(axis=1)
+                rec[P.smer_bytes] = 0                                  # one k-mer
+                recs.append(rec)
+                pos.append(st << 1)
+        recs = np.array(recs, dtype=np.uint8).reshape(-1, P.smer_word)
+        b = np.array([self._bucket(r) for r in recs], dtype=np.int64)
+        order = np.argsort(b, kind="stable")
+        counts = np.bincount(b, minlength=self.world).tolist()
+        offs = [0]
+        for c in counts[:-1]:
+            offs.append(offs[-1] + c)
+        return (torch.from_numpy(np.ascontiguousarray(recs[order]).reshape(-1)), counts, offs, len(recs),
+                torch.from_numpy(np.array(pos, dtype=np.int64)[order]))
+
+    def kmers_per_record(self, recs, nsuper):
+        return recs[: nsuper * self.stride].view(nsuper, self.stride)[:, self.P.smer_bytes].to(torch.int64) + 1
+
+    def lookup_supermers(self, recs, nsuper):
+        P = self.P
+        kb = P.kmer_bytes
+        tab = self.last_table
+        keys = {bytes(r[:kb]): int(r[kb]) | (int(r[kb + 1]) << 8) for r in tab}
+        a = recs.numpy().reshape(nsuper, P.smer_word)
+        out = np.zeros(nsuper, dtype="<u2")
+        comp = np.array([3, 2, 1, 0], dtype=np.uint8)
+        wts = np.array([64, 16, 4, 1], dtype=np.uint8)
+        for i, r in enumerate(a):
+            codes = np.array([(int(r[j >> 2]) >> (6 - 2 * (j & 3))) & 3 for j in range(P.kmer)], dtype=np.uint8)
+            rc = comp[codes[::-1]]
+            def pack(c):
+                pad = np.zeros(kb * 4, dtype=np.uint8)
+                pad[:P.kmer] = c
+                return bytes((pad.reshape(-1, 4) * wts).sum(axis=1).astype(np.uint8))
+            out[i] = keys.get(min(pack(codes), pack(rc)), 0)
+        return torch.from_numpy(out.view(np.uint8).copy())
+
+    def scatter_and_encode(self, reads, recs, pos, nsuper, counts):
+        bases = reads.numpy()
+        c16 = np.zeros(len(bases), dtype=np.uint16)
+        got = counts.numpy().view("<u2")
+        c16[pos.numpy()[:nsuper] >> 1] = got[:nsuper]
+        ends = np.nonzero(bases == 0)[0]
+        blobs, start = [], 0
+        for e in ends:
+            npos = e - start - self.P.kmer + 1
+            blobs.append(orc.profile_encode(c16[start:start + npos]) if npos > 0 else b"")
+            start = e + 1
+        offs = np.concatenate([[0], np.cumsum([len(b) for b in blobs])]).astype(np.int64)
+        return np.frombuffer(b"".join(blobs), dtype=np.uint8), offs
+
     def set_table(self, records):
         self.dictionary = records[np.lexsort(records[:, :self.P.kmer_bytes].T[::-1])]
 
@@ -92,13 +160,14 @@ class OracleEngine:
         offs = np.concatenate([[0], np.cumsum([len(b) for b in blobs])]).astype(np.int64)
         return np.frombuffer(b"".join(blobs), dtype=np.uint8), offs
 
-    def count_supermers(self, recs, nsuper):
+    def count_supermers(self, recs, nsuper, fetch_table=False):
         P = self.P
         a = recs.numpy().reshape(nsuper, P.smer_word)
         ss = orc.msd_sort(a, P.smer_word)
         kl, ovf, nd = orc.kmer_list(P, ss)
         ks = orc.msd_sort(kl, P.kmer_bytes)
         res = orc.count_sorted(P, ks, self.cutoff)
+        self.last_table = res.table
         return dict(hist=res.hist, max_inst=res.max_inst + ovf, nweighted=len(kl),
                     ndistinct=res.ndistinct, ntable=res.ntable, result=res)
 
@@ -227,3 +296,44 @@ def test_two_rank_profiles_match_whole_data_oracle():
             assert raw[offs[i]:offs[i + 1]] == orc.profile_encode(want[lo + i])
             allc.append(orc.profile_decode(raw[offs[i]:offs[i + 1]]))
     assert orc.profiles_digest(allc) == case["expected"]["prof"]["decoded_sha256"]   # the reference's
+
+
+def _xprof_worker(rank, world, port, name, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from fastk_amd import shard
+    shard.MAX_PAIR_BYTES = 4096
+    case, bases, boff = util.load_case(name)
+    nreads = len(boff) - 1
+    lo, hi = rank * nreads // world, (rank + 1) * nreads // world
+    mine = torch.from_numpy(bases[boff[lo]:boff[hi]].copy())
+    eng = OracleEngine(case["k"], world, 1)
+    tot, data, offs = shard.profiles_exchanged(eng, mine)
+    q.put((rank, lo, hi, data.tobytes(), offs, tot["hist"], tot["max_inst"], tot["ninst"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_profiles_with_owner_side_lookups():
+    """shard.profiles_exchanged over two ranks: records to their owners, counts back to the readers.
+    Every rank's profiles are those of its reads in the whole data set; totals are the golden ones."""
+    name, world = "synth_tiny_k40_t1_T2", 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_xprof_worker, args=(r, world, port, name, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=600) for _ in range(world)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    case, bases, boff = util.load_case(name)
+    exp = orc.fastk(case["k"], bases, boff, cutoff=1)
+    allc = []
+    for rank, lo, hi, raw, offs, hist, mx, ninst in got:
+        assert len(offs) == hi - lo + 1
+        assert np.array_equal(hist, exp.hist) and mx == exp.max_inst and ninst == exp.ninst
+        allc += [orc.profile_decode(raw[offs[i]:offs[i + 1]]) for i in range(hi - lo)]
+    assert orc.profiles_digest(allc) == case["expected"]["prof"]["decoded_sha256"]
