@@ -359,13 +359,14 @@ def profiles_sharded(engine, reads, local_table, group=None):
     return engine.make_profiles(reads)
 
 
-def profiles_exchanged(engine, reads, group=None):
+def profiles_exchanged(engine, reads, group=None, fetch_table=False):
     """Counting + profiles of this rank's reads with no table replication (scales with the data set):
     every super-mer record goes to the rank owning its bucket as in count_sharded, the sender keeps the
     position it was cut from; after counting, the owner looks the k-mers of every record it received up
     in its own table and the counts travel back over the same pairs (2 bytes per k-mer instance); the
     sender scatters them to the positions and runs the codec.  The context must have table_cutoff 1 and
-    nbuckets == world size.  Returns (count_sharded-style totals dict, codec bytes, offsets)."""
+    nbuckets == world size.  Returns (count_sharded-style totals dict, codec bytes, offsets); the rank's
+    table stays in HBM unless fetch_table."""
     world = dist.get_world_size(group)
     stride = engine.stride
     recs, counts, s_off, ninst, pos = engine.split_with_positions(reads)
@@ -385,7 +386,7 @@ def profiles_exchanged(engine, reads, group=None):
     inbox = torch.empty(max(nrecv, 1) * stride, dtype=torch.uint8, device=dev)[: nrecv * stride]
     _exchange_records(recs, inbox, send_n, recv_n, stride, group, s_off)
     kept = inbox.clone()                                                # counting clobbers its input
-    loc = engine.count_supermers(inbox, nrecv, True)
+    loc = engine.count_supermers(inbox, nrecv, fetch_table)
     del inbox
     back = engine.lookup_supermers(kept, nrecv)                         # uint8 view of uint16 counts
     assert back.numel() == 2 * sum(inst_from)

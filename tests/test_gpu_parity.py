@@ -1246,7 +1246,7 @@ def test_profiles_with_lookups_on_the_owning_rank(name):
         with fastk_amd.Context(kmer=case["k"], table_cutoff=1, nbuckets=1) as ctx:
             eng = shard.HipEngine(ctx, torch.device("cuda", 0))
             reads = torch.from_numpy(bases).cuda()
-            tot, data, offs = shard.profiles_exchanged(eng, reads)
+            tot, data, offs = shard.profiles_exchanged(eng, reads, fetch_table=True)
     finally:
         dist.destroy_process_group()
     util.check_against_golden(case, tot["hist"], tot["max_inst"], tot["local"]["result"].table)
