@@ -99,6 +99,36 @@ def main():
                     assert len(offs) == len(want) + 1, "profile count"
                     for i, x in enumerate(want):
                         assert raw[offs[i]:offs[i + 1]] == orc.profile_encode(x), "profile of read %d" % i
+            if cutoff == 1 and it % 2 == 0:
+                # the sharded profile pieces on one context: split with positions, count the records,
+                # owner-side look-ups, scatter back, codec
+                with fastk_amd.Context(kmer=k, table_cutoff=1, nbuckets=1) as ctx:
+                    n = len(bases)
+                    rbuf = ctx.alloc(n + 64).upload(bases)
+                    ns, ni, counts = ctx.split(rbuf.ptr, n)
+                    w = ctx.w
+                    recs = ctx.alloc(max(ns, 1) * w.smer_stride)
+                    keep = ctx.alloc(max(ns, 1) * w.smer_stride)
+                    pos = ctx.alloc(max(ns, 1) * 8)
+                    if ns:
+                        ctx.split_emit_pos(rbuf.ptr, n, recs.ptr, ns, counts, pos.ptr)
+                        host = recs.download(ns * w.smer_stride)
+                        keep.upload(host)
+                    r2 = ctx.count_device_supermers(recs.ptr if ns else None, ns, fetch_table=True)
+                    assert np.array_equal(r2.hist, exp.hist) and np.array_equal(r2.table, exp.table), "supermer run"
+                    ninst = ctx.profile_lookup_supermers(keep.ptr if ns else None, ns)
+                    assert ninst == exp.ninst, "look-up instance count"
+                    cbuf = ctx.alloc(max(ninst, 1) * 2)
+                    if ns:
+                        ctx.profile_lookup_supermers(keep.ptr, ns, cbuf.ptr, ninst)
+                    ctx.profile_scatter(keep.ptr if ns else None, pos.ptr if ns else None, ns,
+                                        cbuf.ptr if ns else None, n, reset=True)
+                    data, offs = ctx.profile_encode(rbuf.ptr, n)
+                    want = orc.profile_counts(k, bases, boff, exp.table)
+                    raw = data.tobytes()
+                    assert len(offs) == len(want) + 1, "exchanged profile count"
+                    for i, x in enumerate(want):
+                        assert raw[offs[i]:offs[i + 1]] == orc.profile_encode(x), "exchanged profile of read %d" % i
         except Exception as e:                                      # noqa: BLE001
             print("FAILED", desc, repr(e))
             os.makedirs("gpurun_out", exist_ok=True)
