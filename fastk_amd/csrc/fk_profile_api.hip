@@ -1,0 +1,237 @@
+// fk_profile_api.hip -- C-ABI entry points of the profile stage (fk_profile.hip holds the kernels).
+#include "fk_common.h"
+#include "../../include/fk_synth.h"
+#include <pthread.h>
+#include <stdarg.h>
+#include <fcntl.h>
+#include <unistd.h>
+#include <algorithm>
+#include <vector>
+#include <thread>
+
+// ---- profiles (-p) ---------------------------------------------------------------------------
+
+// compressed profiles + offsets from HBM into the context's host buffers, in the data set's read order
+static int profiles_to_host(fk_ctx *ctx, int64_t nreads, int64_t nprof, void *d_data, uint64_t *d_offs,
+                            bool own_reads)
+{
+  if (ctx->h_prof_cap < nprof + 1)
+    { free(ctx->h_prof);
+      ctx->h_prof = (uint8_t *) malloc((size_t) nprof + 1);
+      ctx->h_prof_cap = nprof + 1;
+      if (ctx->h_prof == NULL) { ctx->h_prof_cap = 0; return (FK_ENOMEM); }
+    }
+  if (ctx->h_prof_off_cap < nreads + 1)
+    { free(ctx->h_prof_off);
+      ctx->h_prof_off = (int64_t *) malloc(sizeof(int64_t) * (size_t) (nreads + 1));
+      ctx->h_prof_off_cap = nreads + 1;
+      if (ctx->h_prof_off == NULL) { ctx->h_prof_off_cap = 0; return (FK_ENOMEM); }
+    }
+  ctx->h_prof_off[0] = 0;
+  if (nreads > 0)
+    { if (nprof > 0)
+        FK_HIP(ctx, hipMemcpyAsync(ctx->h_prof, d_data, (size_t) nprof, hipMemcpyDeviceToHost, ctx->stream));
+      FK_HIP(ctx, hipMemcpyAsync(ctx->h_prof_off, d_offs, (size_t) (nreads + 1) * 8, hipMemcpyDeviceToHost,
+                                 ctx->stream));
+      FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+  // Blocks pushed by several input threads interleave in HBM; the data set's read order is thread 0's
+  // reads, then thread 1's, ... (io.c gives every thread a contiguous range of the input), and the
+  // reference's part files are exactly those ranges.
+  ctx->h_prof_nsplit = 0;
+  if (own_reads && !ctx->blocks_bad && ctx->nblocks > 0)
+    { int64_t tot = 0;
+      int     maxtid = 0;
+      bool    sorted = true;
+      for (int64_t b = 0; b < ctx->nblocks; b++)
+        { tot += ctx->blocks[b].nreads;
+          if (ctx->blocks[b].tid > maxtid) maxtid = ctx->blocks[b].tid;
+          if (b > 0 && ctx->blocks[b].tid < ctx->blocks[b - 1].tid) sorted = false;
+          if (ctx->blocks[b].tid < 0) tot = -1 - nreads;
+        }
+      if (tot == nreads && maxtid < 4096)
+        { const int nt = maxtid + 1;
+          free(ctx->h_prof_split);
+          ctx->h_prof_split = (int64_t *) calloc((size_t) nt + 1, sizeof(int64_t));
+          if (ctx->h_prof_split == NULL) return (FK_ENOMEM);
+          for (int64_t b = 0; b < ctx->nblocks; b++)
+            ctx->h_prof_split[ctx->blocks[b].tid + 1] += ctx->blocks[b].nreads;
+          for (int t = 0; t < nt; t++)
+            ctx->h_prof_split[t + 1] += ctx->h_prof_split[t];
+          ctx->h_prof_nsplit = nt;
+          if (!sorted)
+            { uint8_t *nd = (uint8_t *) malloc((size_t) nprof + 1);
+              int64_t *no = (int64_t *) malloc(sizeof(int64_t) * (size_t) (nreads + 1));
+              std::vector<int64_t> cur(ctx->h_prof_split, ctx->h_prof_split + nt);   // next read slot per thread
+              std::vector<int64_t> len((size_t) nreads);
+              if (nd == NULL || no == NULL) { free(nd); free(no); return (FK_ENOMEM); }
+              int64_t r = 0;
+              for (int64_t b = 0; b < ctx->nblocks; b++)       // lengths into their final slots
+                for (int64_t i = 0; i < ctx->blocks[b].nreads; i++, r++)
+                  len[(size_t) cur[ctx->blocks[b].tid]++] = ctx->h_prof_off[r + 1] - ctx->h_prof_off[r];
+              no[0] = 0;
+              for (int64_t i = 0; i < nreads; i++)
+                no[i + 1] = no[i] + len[(size_t) i];
+              for (int t = 0; t < nt; t++)
+                cur[(size_t) t] = ctx->h_prof_split[t];
+              r = 0;
+              for (int64_t b = 0; b < ctx->nblocks; b++)
+                { const int64_t n = ctx->blocks[b].nreads;
+                  if (n == 0) continue;
+                  const int64_t dst = cur[(size_t) ctx->blocks[b].tid];
+                  memcpy(nd + no[dst], ctx->h_prof + ctx->h_prof_off[r],
+                         (size_t) (ctx->h_prof_off[r + n] - ctx->h_prof_off[r]));
+                  cur[(size_t) ctx->blocks[b].tid] += n;
+                  r += n;
+                }
+              free(ctx->h_prof);     ctx->h_prof = nd;      ctx->h_prof_cap = nprof + 1;
+              free(ctx->h_prof_off); ctx->h_prof_off = no;  ctx->h_prof_off_cap = nreads + 1;
+            }
+        }
+    }
+  return (FK_OK);
+}
+
+extern "C" int fk_set_table(fk_ctx *ctx, const uint8_t *records, int64_t n)
+{ if (ctx == NULL || n < 0 || (records == NULL && n > 0)) return (FK_EINVAL);
+  const fk_widths &w = ctx->wid;
+  hipStream_t s = ctx->stream;
+  FK_HIP(ctx, hipSetDevice(ctx->device));
+  ctx->have_table = false;
+  ctx->have_part_table = false;
+  ctx->last_table = NULL;
+  ctx->last_ntab  = 0;
+  if (n > 0)
+    { void *d_t = fk_slot(ctx, FK_SLOT_TABLE, n * w.kmer_stride);
+      if (d_t == NULL)
+        return (FK_ENOMEM);
+      if (w.kmer_word == w.kmer_stride)
+        FK_HIP(ctx, hipMemcpyAsync(d_t, records, (size_t) n * w.kmer_stride, hipMemcpyHostToDevice, s));
+      else
+        { std::vector<uint8_t> stage((size_t) n * w.kmer_stride, 0);
+          for (int64_t i = 0; i < n; i++)
+            { memcpy(stage.data() + i * w.kmer_stride, records + i * w.kmer_word, w.kmer_bytes);
+              memcpy(stage.data() + i * w.kmer_stride + w.kmer_stride - 2, records + i * w.kmer_word + w.kmer_bytes, 2);
+            }
+          FK_HIP(ctx, hipMemcpyAsync(d_t, stage.data(), stage.size(), hipMemcpyHostToDevice, s));
+          FK_HIP(ctx, hipStreamSynchronize(s));
+        }
+      FK_HIP(ctx, hipStreamSynchronize(s));
+      ctx->last_table = d_t;                   // the look-ups hash the records: no order needed
+    }
+  ctx->last_ntab  = n;
+  ctx->have_table = true;
+  return (FK_OK);
+}
+
+extern "C" int fk_make_profiles(fk_ctx *ctx, const void *d_bases, int64_t nbytes, fk_profiles *out)
+{ if (ctx == NULL || out == NULL || nbytes < 0) return (FK_EINVAL);
+  memset(out, 0, sizeof(*out));
+  FK_HIP(ctx, hipSetDevice(ctx->device));
+  if (!ctx->have_table)
+    { fk_set_error(ctx, "fk_make_profiles: needs fk_set_table or the table of a finished resident run with table_cutoff 1");
+      return (FK_ESTATE);
+    }
+  if (ctx->prm.bc_prefix > 0)
+    { fk_set_error(ctx, "fk_make_profiles: not available together with bc_prefix");
+      return (FK_EUNSUPPORTED);
+    }
+  const bool own_reads = (d_bases == NULL);
+  if (((uintptr_t) d_bases & 15) != 0)
+    { fk_set_error(ctx, "fk_make_profiles: d_bases must be 16-byte aligned");
+      return (FK_EINVAL);
+    }
+  if (d_bases == NULL)
+    { if (ctx->chunk_bytes > 0)
+        { fk_set_error(ctx, "fk_make_profiles: the reads of a chunked run are not kept -- pass them again piece by piece");
+          return (FK_ESTATE);
+        }
+      d_bases = ctx->d_reads;
+      nbytes  = ctx->reads_len;
+    }
+  int64_t nreads = 0, nprof = 0;
+  void *d_data = NULL;
+  uint64_t *d_offs = NULL;
+  int rc = fkx_profiles(ctx, d_bases, nbytes, ctx->last_table, ctx->last_ntab, &nreads, &nprof, &d_data, &d_offs);
+  if (rc != FK_OK)
+    return (rc);
+  if ((rc = profiles_to_host(ctx, nreads, nprof, d_data, d_offs, own_reads)) != FK_OK)
+    return (rc);
+  out->nreads  = nreads;
+  out->nbytes  = nprof;
+  out->data    = ctx->h_prof;
+  out->offsets = ctx->h_prof_off;
+  out->nsplit  = ctx->h_prof_nsplit;
+  out->split   = ctx->h_prof_nsplit > 0 ? ctx->h_prof_split : NULL;
+  return (FK_OK);
+}
+
+// ---- profiles in the sharded run: look-ups on the owning rank, counts sent back ----------------------
+
+extern "C" int fk_split_supermers_emit_pos(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out,
+                                           int64_t cap, const int64_t *bucket_counts, void *d_pos)
+{ if (ctx == NULL || d_bases == NULL || d_out == NULL || bucket_counts == NULL || d_pos == NULL || nbytes < 0)
+    return (FK_EINVAL);
+  if (((uintptr_t) d_bases & 15) != 0)
+    { fk_set_error(ctx, "fk_split_supermers_emit_pos: read buffer must be 16-byte aligned");
+      return (FK_EINVAL);
+    }
+  int64_t bc[256], ns = 0, ni = 0;
+  for (int b = 0; b < ctx->prm.nbuckets; b++)
+    { bc[b] = bucket_counts[b];
+      ns += bc[b];
+    }
+  if (cap < ns)
+    { fk_set_error(ctx, "fk_split_supermers_emit_pos: buffer holds %lld records, %lld needed",
+                   (long long) cap, (long long) ns);
+      return (FK_EINVAL);
+    }
+  if (ns == 0)
+    return (FK_OK);
+  FK_HIP(ctx, hipSetDevice(ctx->device));
+  return fkx_split(ctx, d_bases, nbytes, d_out, cap, &ns, &ni, bc, true, d_pos);
+}
+
+extern "C" int fk_profile_lookup_supermers(fk_ctx *ctx, const void *d_smers, int64_t nsuper, void *d_counts,
+                                           int64_t cap, int64_t *ninst)
+{ if (ctx == NULL || ninst == NULL || nsuper < 0 || (nsuper > 0 && d_smers == NULL)) return (FK_EINVAL);
+  FK_HIP(ctx, hipSetDevice(ctx->device));
+  if (!ctx->have_part_table && !ctx->have_table)
+    { fk_set_error(ctx, "fk_profile_lookup_supermers: needs the table of a finished run with table_cutoff 1");
+      return (FK_ESTATE);
+    }
+  return fkx_profile_lookup_supermers(ctx, d_smers, nsuper, ctx->last_table, ctx->last_ntab, d_counts, cap, ninst);
+}
+
+extern "C" int fk_profile_scatter(fk_ctx *ctx, const void *d_smers, const void *d_pos, int64_t nsuper,
+                                  const void *d_counts, int64_t nbytes, int reset)
+{ if (ctx == NULL || nsuper < 0 || nbytes < 0 || (nsuper > 0 && (d_smers == NULL || d_pos == NULL || d_counts == NULL)))
+    return (FK_EINVAL);
+  FK_HIP(ctx, hipSetDevice(ctx->device));
+  return fkx_profile_scatter(ctx, d_smers, d_pos, nsuper, d_counts, nbytes, reset != 0);
+}
+
+extern "C" int fk_profile_encode(fk_ctx *ctx, const void *d_bases, int64_t nbytes, fk_profiles *out)
+{ if (ctx == NULL || out == NULL || d_bases == NULL || nbytes < 0) return (FK_EINVAL);
+  memset(out, 0, sizeof(*out));
+  FK_HIP(ctx, hipSetDevice(ctx->device));
+  if (((uintptr_t) d_bases & 15) != 0)
+    { fk_set_error(ctx, "fk_profile_encode: d_bases must be 16-byte aligned");
+      return (FK_EINVAL);
+    }
+  int64_t nreads = 0, nprof = 0;
+  void *d_data = NULL;
+  uint64_t *d_offs = NULL;
+  int rc = fkx_profile_encode_counts(ctx, d_bases, nbytes, &nreads, &nprof, &d_data, &d_offs);
+  if (rc != FK_OK)
+    return (rc);
+  ctx->h_prof_nsplit = 0;
+  if ((rc = profiles_to_host(ctx, nreads, nprof, d_data, d_offs, false)) != FK_OK)
+    return (rc);
+  out->nreads  = nreads;
+  out->nbytes  = nprof;
+  out->data    = ctx->h_prof;
+  out->offsets = ctx->h_prof_off;
+  return (FK_OK);
+}
+
