@@ -129,6 +129,39 @@ def main():
                     assert len(offs) == len(want) + 1, "exchanged profile count"
                     for i, x in enumerate(want):
                         assert raw[offs[i]:offs[i + 1]] == orc.profile_encode(x), "exchanged profile of read %d" % i
+            if it % 3 == 0 and all(len(r) > 0 for r in reads):
+                # the device text parsers: the same reads as FASTQ / FASTA text, cut at random bytes
+                fastq = bool(rng.random() < 0.5)
+                width = int(rng.choice([0, 0, 7, 60, 100]))
+                parts = []
+                for i, r in enumerate(reads):
+                    seq = r.encode()
+                    if fastq:
+                        parts.append(b"@r%d extra+@ text\n" % i + seq + b"\n+\n" +
+                                     bytes(rng.integers(33, 75, size=len(seq), dtype=np.uint8)) + b"\n")
+                    else:
+                        parts.append(b">r%d ACGT>acgt\n" % i)
+                        if width:
+                            parts.extend(seq[j:j + width] + b"\n" for j in range(0, len(seq), width))
+                        else:
+                            parts.append(seq + b"\n")
+                text = b"".join(parts)
+                if rng.random() < 0.3 and not fastq:
+                    text = text[:-1]                                 # no newline at the end of the file
+                with fastk_amd.Context(kmer=k, table_cutoff=cutoff, nbuckets=nb) as ctx:
+                    st, nr, p0 = (0 if fastq else 2), 0, 0
+                    while p0 < len(text):
+                        n = int(rng.integers(1, max(2, len(text) // int(rng.integers(1, 12)))))
+                        if fastq:
+                            st, r_, _ = ctx.push_fastq(text[p0:p0 + n], st)
+                        else:
+                            st, r_, _ = ctx.push_fasta(text[p0:p0 + n], st, last=(p0 + n >= len(text)))
+                        nr += r_
+                        p0 += n
+                    res = ctx.finish()
+                    assert nr == len(reads), "parsed read count %d != %d" % (nr, len(reads))
+                    assert res.ninst == exp.ninst and np.array_equal(res.hist, exp.hist), "text parser: hist"
+                    assert np.array_equal(res.table, exp.table), "text parser: table"
         except Exception as e:                                      # noqa: BLE001
             print("FAILED", desc, repr(e))
             os.makedirs("gpurun_out", exist_ok=True)
