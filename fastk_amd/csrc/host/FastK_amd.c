@@ -1,10 +1,11 @@
 /* FastK_amd.c -- host driver with FastK's command line over libfastk_amd.so.
  *
- *   FastK_amd [-k<int(40)>] [-t[<int(1)>]] [-c] [-bc<int>] [-v] [-x] [-N<path_name>] [-P<dir>] [-M<int>]
- *             [-T<int(4)>] <source>[.fa|.fasta|.fq|.fastq][.gz] ...
+ *   FastK_amd [-k<int(40)>] [-t[<int(1)>]] [-p[:<table>[.ktab]]] [-c] [-bc<int>] [-v] [-x] [-N<path_name>] [-P<dir>] [-M<int>]
+ *             [-T<int(4)>] <source>[.fa|.fasta|.fq|.fastq][.gz]|.sam|.bam ...
  *
  * Same flags, defaults, output names and encodings as the reference driver (FastK.c:34-37,
- * 250-319, 361-409): <root>.hist always, <root>.ktab + hidden .<root>.ktab.<1..T> with -t.
+ * 250-319, 361-409): <root>.hist always, <root>.ktab + hidden .<root>.ktab.<1..T> with -t,
+ * <root>.prof + hidden .<root>.pidx/.prof.<1..T> with -p (only those with -p:<table>).
  * The host side is plain C: it parses FASTA/FASTQ with the reference's line rules
  * (io.c:678-734: FASTQ strictly 4-line, FASTA possibly multi-line, every non-newline byte of a
  * sequence line is a base), cuts the input into DATA_BLOCK-shaped blocks (FastK.h:87-98; a read
@@ -23,7 +24,9 @@
  * fixes the number of super-mer buckets, split.c:617-766): the reads are split into super-mers chunk
  * by chunk and the minimizer buckets are counted one after the other; the number of buckets is
  * derived from the input size.  Without -M everything stays resident in one bucket (fastest).
- * Accepted for compatibility and ignored: -P (no temporary files exist).  Not built yet and rejected with a message: -p (profiles), BAM/SAM/CRAM/Dazzler inputs.
+ * SAM and BAM input follow io.c:1314-1495 (secondary / supplementary records skipped).
+ * Accepted for compatibility and ignored: -P (no temporary files exist).  Rejected with a message:
+ * CRAM and Dazzler inputs.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -118,11 +121,11 @@ static inline void end_read(Feeder *f)
     flush_block(f,0);
 }
 
-/* returns 1 for FASTQ, 0 for FASTA, -1 unknown; sets *root (malloc'd) and *dir */
+/* returns 1 for FASTQ, 0 for FASTA, 2 for SAM, 3 for BAM, -1 unknown; sets *root (malloc'd) and *dir */
 static int classify(const char *path, char **root, char **dir)
 { static const char *suf[] = { ".fastq.gz", ".fasta.gz", ".fq.gz", ".fa.gz", ".fastq", ".fasta",
-                               ".fq", ".fa", NULL };
-  static const int   isq[] = { 1, 0, 1, 0, 1, 0, 1, 0 };
+                               ".fq", ".fa", ".sam", ".bam", NULL };
+  static const int   isq[] = { 1, 0, 1, 0, 1, 0, 1, 0, 2, 3 };
   const char *slash = strrchr(path,'/');
   const char *base  = slash ? slash+1 : path;
   size_t      bl    = strlen(base);
@@ -266,6 +269,143 @@ static void scan_file(Feeder *f, const char *path, int fastq)
   gzclose(in);
 }
 
+/* SAM text (io.c:1424-1495): one read per alignment line, SEQ is field 10; secondary and
+   supplementary records (flags & 0x900) are skipped; every SEQ character becomes one of acgt by the
+   reference's IUPAC_2_DNA rule (c, b, s, y -> c; g, k -> g; t -> t; 1, 2, 3 -> c, g, t; anything
+   else, n included, -> a), either case. */
+static int sam_base(int c)
+{ switch (c)
+  { case 'C': case 'c': case 'B': case 'b': case 'S': case 's': case 'Y': case 'y': case '1': return ('c');
+    case 'G': case 'g': case 'K': case 'k': case '2': return ('g');
+    case 'T': case 't': case '3': return ('t');
+    default: return ('a');
+  }
+}
+
+static void scan_sam(Feeder *f, const char *path)
+{ gzFile in = gzopen(path,"rb");
+  size_t cap = 1 << 20, len;
+  char  *line = malloc(cap);
+
+  if (in == NULL || line == NULL)
+    { fprintf(stderr,"%s: Cannot open %s for reading\n",Prog_Name,path);
+      exit (1);
+    }
+  gzbuffer(in,1 << 20);
+  while (gzgets(in,line,(int) cap) != NULL)
+    { char *p, *q;
+      long  flags;
+      int   i;
+
+      len = strlen(line);
+      while (len == cap-1 && line[len-1] != '\n')          /* a line longer than the buffer */
+        { cap *= 2;
+          line = realloc(line,cap);
+          if (line == NULL)
+            { fprintf(stderr,"%s: Out of memory\n",Prog_Name); exit (1); }
+          if (gzgets(in,line+len,(int) (cap-len)) == NULL)
+            break;
+          len += strlen(line+len);
+        }
+      if (line[0] == '@' || line[0] == '\n' || line[0] == '\0')
+        continue;
+      p = strchr(line,'\t');
+      if (p == NULL)
+        { fprintf(stderr,"\n%s: Too few required fields in SAM record, file corrupted?\n",Prog_Name); exit (1); }
+      flags = strtol(q = p+1,&p,0);
+      if (p == q)
+        { fprintf(stderr,"\n%s: Cannot parse flags\n",Prog_Name); exit (1); }
+      for (i = 0; i < 7; i++)
+        { p = strchr(p+1,'\t');
+          if (p == NULL)
+            { fprintf(stderr,"\n%s: Too few required fields in SAM record, file corrupted?\n",Prog_Name); exit (1); }
+        }
+      q = p+1;
+      if (*q == '*')
+        { fprintf(stderr,"\n%s: No sequence for read?\n",Prog_Name); exit (1); }
+      if ((flags & 0x900) != 0)
+        continue;
+      if (*q == '\t' || *q == '\n' || *q == '\0')
+        continue;                                             /* zero-length records are dropped, io.c:1597 */
+      for ( ; *q != '\t' && *q != '\n' && *q != '\0'; q++)
+        add_base(f,sam_base(*q));
+      end_read(f);
+    }
+  free(line);
+  gzclose(in);
+}
+
+/* BAM (io.c:1314-1392): BGZF blocks are gzip members, so zlib's gzread delivers the plain BAM stream;
+   per record the 36-byte fixed part, then name, CIGAR, 4-bit bases ("=acmgrsvtwyhkdbn": letters other
+   than acgt break k-mers like any other non-base), qualities, tags.  Records with flags & 0x900 and
+   records without bases are skipped. */
+static int bam_need(gzFile in, void *buf, int n, const char *path)
+{ int got = gzread(in,buf,(unsigned) n);
+  if (got == 0)
+    return (0);
+  if (got != n)
+    { fprintf(stderr,"\n%s: Non-sensical BAM record in %s, file corrupted?\n",Prog_Name,path); exit (1); }
+  return (1);
+}
+
+static uint32_t le32(const unsigned char *x)
+{ return ((uint32_t) x[0] | ((uint32_t) x[1] << 8) | ((uint32_t) x[2] << 16) | ((uint32_t) x[3] << 24)); }
+
+static void scan_bam(Feeder *f, const char *path)
+{ static const char code[] = "=acmgrsvtwyhkdbn";
+  gzFile in = gzopen(path,"rb");
+  unsigned char x[36], *data = NULL;
+  size_t   dmax = 0;
+  uint32_t i, n;
+
+  if (in == NULL)
+    { fprintf(stderr,"%s: Cannot open %s for reading\n",Prog_Name,path); exit (1); }
+  gzbuffer(in,1 << 20);
+  if (!bam_need(in,x,8,path) || memcmp(x,"BAM\1",4) != 0)      /* magic, l_text */
+    { fprintf(stderr,"%s: %s is not a BAM file\n",Prog_Name,path); exit (1); }
+  n = le32(x+4);
+  data = malloc(dmax = (size_t) n + 1024);
+  if (data == NULL)
+    { fprintf(stderr,"%s: Out of memory\n",Prog_Name); exit (1); }
+  if (n > 0) bam_need(in,data,(int) n,path);                  /* header text */
+  bam_need(in,x,4,path);                                      /* n_ref */
+  n = le32(x);
+  for (i = 0; i < n; i++)
+    { uint32_t l;
+      bam_need(in,x,4,path);
+      l = le32(x);
+      if (l + 4 > dmax) data = realloc(data,dmax = (size_t) l + 1024);
+      bam_need(in,data,(int) l + 4,path);                     /* name, l_ref */
+    }
+  while (bam_need(in,x,36,path))
+    { int32_t  ldata  = (int32_t) le32(x) - 32;
+      int      lname  = x[12];
+      int      lcigar = x[16] | (x[17] << 8);
+      int      flags  = x[18] | (x[19] << 8);
+      int32_t  lseq   = (int32_t) le32(x+20);
+      int      j;
+
+      if (ldata < 0 || lseq < 0 || lname < 1 || lname + ((lseq+1) >> 1) + lseq + (lcigar << 2) > ldata)
+        { fprintf(stderr,"\n%s: Non-sensical BAM record, file corrupted?\n",Prog_Name); exit (1); }
+      if ((size_t) ldata > dmax)
+        { dmax = (size_t) (1.2*ldata) + 1000;
+          data = realloc(data,dmax);
+        }
+      if (data == NULL)
+        { fprintf(stderr,"%s: Out of memory\n",Prog_Name); exit (1); }
+      if (ldata > 0) bam_need(in,data,ldata,path);
+      if ((flags & 0x900) != 0 || lseq <= 0)
+        continue;
+      { const unsigned char *t = data + lname + (lcigar << 2);
+        for (j = 0; j < lseq; j++)
+          add_base(f,code[(j & 1) ? (t[j >> 1] & 0xf) : (t[j >> 1] >> 4)]);
+      }
+      end_read(f);
+    }
+  free(data);
+  gzclose(in);
+}
+
 int main(int argc, char *argv[])
 { fk_params  prm;
   fk_ctx    *ctx;
@@ -310,7 +450,7 @@ int main(int argc, char *argv[])
   nfiles = j-1;
   if (nfiles < 1 || KMER <= 0 || NTHREADS <= 0 || DO_TABLE < 0 || BC_PREFIX < 0)
     { fprintf(stderr,"\nUsage: %s [-k<int(40)>] [-t[<int(1)>]] [-p[:<table>[.ktab]]] [-c] [-bc<int>] [-v] [-x] [-N<path_name>]\n",Prog_Name);
-      fprintf(stderr,"       %*s [-P<dir>] [-M<int>] [-T<int(4)>] <source>[.fa|.fasta|.fq|.fastq][.gz] ...\n",
+      fprintf(stderr,"       %*s [-P<dir>] [-M<int>] [-T<int(4)>] <source>[.fa|.fasta|.fq|.fastq][.gz]|.sam|.bam ...\n",
               (int) strlen(Prog_Name),"");
       exit (1);
     }
@@ -341,7 +481,7 @@ int main(int argc, char *argv[])
               fseek(fp,0,SEEK_END);
               sz = (double) ftell(fp);
               if (l > 3 && strcmp(argv[i]+l-3,".gz") == 0) sz *= 4.;
-              bases += q ? sz/2. : sz;
+              bases += (q == 3) ? 2.*sz : (q ? sz/2. : sz);
             }
           if (fp != NULL) fclose(fp);
           if (q >= 0) { free(r); free(d); }
@@ -373,7 +513,7 @@ int main(int argc, char *argv[])
     { char *r, *d;
       int   q = classify(argv[i],&r,&d);
       if (q < 0)
-        { fprintf(stderr,"%s: %s is not a .fa/.fasta/.fq/.fastq[.gz] file (other inputs are not built)\n",
+        { fprintf(stderr,"%s: %s is not a .fa/.fasta/.fq/.fastq[.gz], .sam or .bam file (other inputs are not built)\n",
                   Prog_Name,argv[i]);
           exit (1);
         }
@@ -383,7 +523,11 @@ int main(int argc, char *argv[])
         { free(r); free(d); }
       /* profiles need the reads exactly as the reference numbers them: the device FASTQ parser keeps
          one terminated read per record; FASTA text goes through the host scanner */
-      if (!EXACT && BC_PREFIX == 0 && !HOST_PARSE && (q == 1 || !(COMPRESS || PROFILE)))
+      if (q == 2)
+        scan_sam(&feed,argv[i]);
+      else if (q == 3)
+        scan_bam(&feed,argv[i]);
+      else if (!EXACT && BC_PREFIX == 0 && !HOST_PARSE && (q == 1 || !(COMPRESS || PROFILE)))
         scan_text_on_device(&feed,argv[i],q);
       else
         scan_file(&feed,argv[i],q);

@@ -537,3 +537,53 @@ def profiles_digest(count_lists):
         h.update(struct.pack("<i", len(a)))
         h.update(a.tobytes())
     return h.hexdigest()
+
+
+# --------------------------------------------------------------------------- SAM / BAM test inputs
+
+def write_sam(path, reads, flags=None):
+    """reads: list of str; flags[i] (default 4 = unmapped).  A minimal valid SAM with one aux tag per line
+    (the reference insists on one, io.c:1481)."""
+    with open(path, "wb") as f:
+        f.write(b"@HD\tVN:1.6\tSO:unknown\n@RG\tID:x\n")
+        for i, r in enumerate(reads):
+            fl = 4 if flags is None else flags[i]
+            q = "I" * len(r)
+            f.write(("r%d\t%d\t*\t0\t0\t*\t*\t0\t0\t%s\t%s\tRG:Z:x\n" % (i, fl, r, q)).encode())
+
+
+def _bgzf_block(data):
+    import zlib
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    body = c.compress(data) + c.flush()
+    bsize = 12 + 6 + len(body) + 8 - 1
+    return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", bsize) + body +
+            struct.pack("<II", zlib.crc32(data) & 0xffffffff, len(data)))
+
+
+def write_bam(path, reads, flags=None):
+    """Unaligned BAM in BGZF blocks (SAM spec 4.2) with the reads as records; letters outside
+    =ACMGRSVTWYHKDBN become N."""
+    code = {c: i for i, c in enumerate("=ACMGRSVTWYHKDBN")}
+    text = b"@HD\tVN:1.6\tSO:unknown\n"
+    out = bytearray(b"BAM\x01" + struct.pack("<i", len(text)) + text + struct.pack("<i", 0))
+    for i, r in enumerate(reads):
+        name = ("r%d" % i).encode() + b"\x00"
+        fl = 4 if flags is None else flags[i]
+        L = len(r)
+        nib = [code.get(ch.upper(), 15) for ch in r] + [0]
+        seq = bytes((nib[j] << 4) | nib[j + 1] for j in range(0, L + (L & 1), 2)) if L else b""
+        qual = b"\xff" * L
+        rec = struct.pack("<iiBBHHHiiii", -1, -1, len(name), 0, 4680, 0, fl, L, -1, -1, 0) + name + seq + qual
+        out += struct.pack("<i", len(rec)) + rec
+    with open(path, "wb") as f:
+        data = bytes(out)
+        for o in range(0, len(data), 60000):
+            f.write(_bgzf_block(data[o:o + 60000]))
+        f.write(_bgzf_block(b""))
+
+
+def sam_bases(read):
+    """What the reference makes of a SAM SEQ field (IUPAC_2_DNA, io.c:1394-1404): everything is a base."""
+    m = {"c": "c", "b": "c", "s": "c", "y": "c", "1": "c", "g": "g", "k": "g", "2": "g", "t": "t", "3": "t"}
+    return "".join(m.get(ch.lower(), "a") for ch in read)

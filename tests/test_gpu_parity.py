@@ -1253,3 +1253,43 @@ def test_profiles_with_lookups_on_the_owning_rank(name):
     raw = data.tobytes()
     got = [orc.profile_decode(raw[offs[i]:offs[i + 1]]) for i in range(len(offs) - 1)]
     assert orc.profiles_digest(got) == case["expected"]["prof"]["decoded_sha256"]
+
+
+@pytest.mark.parametrize("kind", ["sam", "bam"])
+def test_cli_reads_sam_and_bam(kind, tmp_path):
+    """FastK_amd on .sam / .bam input (io.c:1314-1495): secondary / supplementary records are skipped, SAM
+    letters go through the reference's everything-is-a-base rule, BAM's 4-bit codes keep n & co. as
+    breaks.  .hist bytes and the table stream equal the reference's on the same file; -p too."""
+    import hashlib, os, subprocess
+    case, bases, boff = util.load_case("edge_k40_t1_T4")
+    reads = [bases[boff[i]:boff[i + 1] - 1].tobytes().decode() for i in range(len(boff) - 1)]
+    reads = [r for r in reads if len(r) > 0][:6000] + ["acgtNRYKMacgt" * 8, "ac" * 70000]   # a read longer than a block piece
+    rng = np.random.default_rng(3)
+    flags = [int(rng.choice([0, 4, 16, 0x100, 0x800, 0x904])) for _ in reads]
+    flags[-1] = 0
+    k, T = 40, 3
+    d = str(tmp_path)
+    path = os.path.join(d, "x." + kind)
+    (orc.write_sam if kind == "sam" else orc.write_bam)(path, reads, flags)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "fastk_amd", "bin", "FastK_amd")
+    subprocess.run([exe, "-k%d" % k, "-t1", "-T%d" % T, "-p", "-Nmine", path], check=True, cwd=d)
+    kept = [r for r, f in zip(reads, flags) if not (f & 0x900)]
+    kept = [orc.sam_bases(r) for r in kept] if kind == "sam" else \
+        ["".join(ch if ch.upper() in "=ACMGRSVTWYHKDBN" else "N" for ch in r).lower() for r in kept]
+    b2, o2 = orc.block_from_reads(kept)
+    exp = orc.fastk(k, b2, o2, cutoff=1)
+    assert open(os.path.join(d, "mine.hist"), "rb").read() == orc.hist_file_bytes(k, exp.hist, exp.max_inst)
+    t = orc.read_ktab(os.path.join(d, "mine"))
+    assert t["stream_sha256"] == orc.table_stream_sha256(k, exp.table)
+    kk, enc = orc.read_profiles(d, "mine")
+    want = orc.profile_counts(k, b2, o2, exp.table)
+    assert len(enc) == len(want) and all(e == orc.profile_encode(x) for e, x in zip(enc, want))
+    if orc.have_ref():
+        rd = os.path.join(d, "ref")
+        os.mkdir(rd)
+        rp = os.path.join(rd, "x." + kind)
+        os.link(path, rp)
+        orc.run_ref_fastk(rp, k, 1, T, rd)
+        assert open(os.path.join(rd, "x.hist"), "rb").read() == open(os.path.join(d, "mine.hist"), "rb").read()
+        assert orc.read_ktab(os.path.join(rd, "x"))["stream_sha256"] == t["stream_sha256"]
