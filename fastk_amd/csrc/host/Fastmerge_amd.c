@@ -1,6 +1,6 @@
 /* Fastmerge_amd.c -- Fastmerge's table / histogram merge over libfastk_amd.so.
  *
- *   Fastmerge_amd [-ht] [-T<int(4)>] <target> <source>[.ktab] ...
+ *   Fastmerge_amd [-ht] [-T<int(4)>] [-#<int(1)>] [-P<dir>] <target> <source>[.hist|.ktab] ...
  *
  * Same options and outputs as the reference tool for tables and histograms (Fastmerge.c:26-29,
  * 521-540): -t writes <target>.ktab + hidden parts, -h writes <target>.hist; k-mers present in
@@ -9,7 +9,9 @@
  * by the aggregation kernel of the counting path (fk_merge_tables).  The prefix-index width follows
  * Fastmerge's rule on the number of input entries (Fastmerge.c:742-756), the cutoff field is the
  * smallest of the sources' (Fastmerge.c:719-720); the part boundaries are our own.
- * Not built: profile merging (-p sources), #<parts>, -P, -S.
+ * -#<n>: n hidden part files per thread (README.md:190); -P is accepted and ignored (no caching is
+ * needed); profiles cannot be merged by the reference either (README.md:176-179: use -p:<merged table>).
+ * Not built: -S slices.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -48,7 +50,7 @@ static int64_t load_high_count(const char *dir, const char *root, int *found)
 }
 
 int main(int argc, char *argv[])
-{ int  DO_HIST = 0, DO_TABLE = 0, NTHREADS = 4;
+{ int  DO_HIST = 0, DO_TABLE = 0, NTHREADS = 4, NPARTS = 1;
   int  i, j, narg, kmer = 0, minval = 0x10000, ib;
   char *odir, *oroot, name[4096];
   uint8_t *recs = NULL;
@@ -59,10 +61,16 @@ int main(int argc, char *argv[])
   fk_result *res;
 
   for (i = j = 1; i < argc; i++)
-    if (argv[i][0] == '-' && argv[i][1] != '\0')
+    if (argv[i][0] == '#' && argv[i][1] != '\0')      /* the usage line of the reference writes it without '-' */
+      NPARTS = atoi(argv[i]+1);
+    else if (argv[i][0] == '-' && argv[i][1] != '\0')
       { char *p;
         if (argv[i][1] == 'T')
           { NTHREADS = atoi(argv[i]+2); continue; }
+        if (argv[i][1] == '#')                         /* parts per thread, Fastmerge.c:26, README.md:190 */
+          { NPARTS = atoi(argv[i]+2); continue; }
+        if (argv[i][1] == 'P')                         /* local cache directory: nothing is cached here */
+          continue;
         for (p = argv[i]+1; *p; p++)
           if (*p == 'h') DO_HIST = 1;
           else if (*p == 't') DO_TABLE = 1;
@@ -74,8 +82,8 @@ int main(int argc, char *argv[])
     else
       argv[j++] = argv[i];
   argc = j;
-  if (argc < 3 || NTHREADS < 1)
-    { fprintf(stderr,"\nUsage: %s [-ht] [-T<int(4)>] <target> <source>[.hist|.ktab] ...\n",Prog_Name);
+  if (argc < 3 || NTHREADS < 1 || NPARTS < 1)
+    { fprintf(stderr,"\nUsage: %s [-ht] [-T<int(4)>] [-#<int(1)>] [-P<dir>] <target> <source>[.hist|.ktab] ...\n",Prog_Name);
       exit (1);
     }
   if (DO_HIST + DO_TABLE == 0)
@@ -121,7 +129,7 @@ int main(int argc, char *argv[])
   if (n >= 0x8000000ll) ib = 3;                        /* Fastmerge.c:742-756, on the INPUT entries */
   else if (n >= 0x80000ll) ib = 2;
   else ib = 1;
-  if (DO_TABLE && fk_write_ktab_ex(res,kmer,minval,NTHREADS,ib,odir,oroot) != FK_OK)
+  if (DO_TABLE && fk_write_ktab_ex(res,kmer,minval,NTHREADS*NPARTS,ib,odir,oroot) != FK_OK)
     die(ctx,"writing .ktab");
   if (DO_HIST)
     { snprintf(name,sizeof(name),"%s/%s.hist",odir,oroot);

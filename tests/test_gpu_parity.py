@@ -450,6 +450,10 @@ def test_table_merge_matches_reference_fastmerge(name, tmp_path):
     subprocess.run([mrg, "-ht", "-T2", str(tmp_path / "ours")] + srcs, check=True, cwd=str(tmp_path))
     ours = orc.read_ktab(str(tmp_path / "ours"))
     ours_hist = open(tmp_path / "ours.hist", "rb").read()
+    # -#3: three hidden parts per thread, same table
+    subprocess.run([mrg, "-t", "-T2", "-#3", "-P/tmp", str(tmp_path / "six")] + srcs, check=True, cwd=str(tmp_path))
+    six = orc.read_ktab(str(tmp_path / "six"))
+    assert six["nparts"] == 6 and six["stream_sha256"] == ours["stream_sha256"]
     # expected: Fastmerge's rules (Fastmerge.c:313-329, 985-1030) applied to the three piece tables
     kb = orc.params(k).kmer_bytes
     pieces = [orc.fastk(k, bases[boff[cuts[i]]:boff[cuts[i + 1]]],
