@@ -191,7 +191,6 @@ static __global__ __launch_bounds__(256) void k_pf_counts(const uint8_t *__restr
   const int tb = K - 16 * (KW - 1);             // bases in the last key word
   const u32 tmask = (tb == 16) ? 0xffffffffu : ~(0xffffffffu >> (2 * tb));
   const int ps = 2 * (16 - tb);
-  constexpr int SD = (SW <= 4) ? 4 : 8, G = 16 / SD;
   const u32 *bad32 = (const u32 *) bad;
 
 #pragma unroll 1
