@@ -412,7 +412,7 @@ int main(int argc, char *argv[])
   fk_result *res;
   Feeder     feed;
   char      *root = NULL, *dir = NULL, name[4096];
-  int        i, j, nfiles;
+  int        i, j, nfiles, ftype = -1;
 
   for (i = j = 1; i < argc; i++)
     if (argv[i][0] == '-')
@@ -515,6 +515,12 @@ int main(int argc, char *argv[])
       if (q < 0)
         { fprintf(stderr,"%s: %s is not a .fa/.fasta/.fq/.fastq[.gz], .sam or .bam file (other inputs are not built)\n",
                   Prog_Name,argv[i]);
+          exit (1);
+        }
+      if (i == 1)
+        ftype = q;
+      else if (q != ftype)                /* io.c: one input type per run */
+        { fprintf(stderr,"%s: All files must be of the same type\n",Prog_Name);
           exit (1);
         }
       if (i == 1)

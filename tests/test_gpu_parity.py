@@ -1297,3 +1297,51 @@ def test_cli_reads_sam_and_bam(kind, tmp_path):
         orc.run_ref_fastk(rp, k, 1, T, rd)
         assert open(os.path.join(rd, "x.hist"), "rb").read() == open(os.path.join(d, "mine.hist"), "rb").read()
         assert orc.read_ktab(os.path.join(rd, "x"))["stream_sha256"] == t["stream_sha256"]
+
+
+def test_cli_output_naming_follows_reference(tmp_path):
+    """Output names and places (FastK.c:361-409): next to the FIRST input with its root by default, -N
+    overrides both; several inputs make one data set.  Same file lists and same .hist as the reference."""
+    import hashlib, os, subprocess
+    case, bases, boff = util.load_case("synth_tiny_k40_t1_T2")
+    nreads = len(boff) - 1
+    half = nreads // 2
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "fastk_amd", "bin", "FastK_amd")
+    ref = os.path.join(orc.REF_DIR, "FastK")
+    if not os.path.exists(ref):
+        pytest.skip("reference build not available")
+
+    def layout(d):
+        os.makedirs(os.path.join(d, "in", "sub"))
+        os.makedirs(os.path.join(d, "out"))
+        orc.write_fasta(os.path.join(d, "in", "a.part.fasta"), bases[:boff[half]], boff[:half + 1])
+        orc.write_fasta(os.path.join(d, "in", "sub", "b.fa"), bases[boff[half]:], boff[half:] - boff[half], width=60)
+        orc.write_fastq(os.path.join(d, "in", "sub", "c.fq"), bases[boff[half]:], boff[half:] - boff[half])
+
+    def listing(d):
+        out = []
+        for dp, _, fs in os.walk(d):
+            out += [os.path.relpath(os.path.join(dp, f), d) for f in fs]
+        return sorted(out)
+
+    for n, extra in enumerate(([], ["-Nout/named"], ["-Nplain"])):
+        dirs = []
+        for tool in (exe, ref):
+            d = str(tmp_path / ("t%d_%d" % (n, len(dirs))))
+            os.makedirs(d)
+            layout(d)
+            cmd = [tool, "-k40", "-t1", "-T2"] + extra + ["in/a.part.fasta", "in/sub/b.fa"]
+            if tool == ref:
+                cmd.insert(1, "-P" + d)
+            subprocess.run(cmd, check=True, cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            dirs.append(d)
+        assert listing(dirs[0]) == listing(dirs[1]), extra
+        hist = [f for f in listing(dirs[0]) if f.endswith(".hist")]
+        assert len(hist) == 1
+        mine = open(os.path.join(dirs[0], hist[0]), "rb").read()
+        assert mine == open(os.path.join(dirs[1], hist[0]), "rb").read()
+        assert hashlib.sha256(mine).hexdigest() == case["expected"]["hist_sha256"]
+        for tool, d in zip((exe, ref), dirs):                       # one input type per run, both tools
+            p = subprocess.run([tool, "-k40", "-T2", "in/a.part.fasta", "in/sub/c.fq"], cwd=d, capture_output=True, text=True)
+            assert p.returncode == 1 and "All files must be of the same type" in p.stderr
