@@ -142,6 +142,38 @@ static int classify(const char *path, char **root, char **dir)
   return (-1);
 }
 
+/* The reference's name resolution (Fetch_File, io.c:136-160): the argument may omit its extension, or
+   name the uncompressed file when only the .gz exists; candidates are tried in the reference's order
+   and the first that opens wins.  Returns a malloc'd path, or exits like the reference. */
+static char *resolve_input(const char *arg)
+{ static const char *strip[] = { ".cram", ".bam", ".sam", ".db", ".dam", ".fastq", ".fasta", ".fq", ".fa",
+                                 ".fastq.gz", ".fasta.gz", ".fastq", ".fasta", ".fq.gz", ".fa.gz", ".fq", ".fa" };
+  static const char *add[]   = { ".cram", ".bam", ".sam", ".db", ".dam", ".fastq", ".fasta", ".fq", ".fa",
+                                 ".fastq.gz", ".fasta.gz", ".fastq.gz", ".fasta.gz", ".fq.gz", ".fa.gz",
+                                 ".fq.gz", ".fa.gz" };
+  size_t al = strlen(arg);
+  int    i;
+
+  for (i = 0; i < 17; i++)
+    { size_t sl = strlen(strip[i]);
+      size_t keep = (al > sl && strcmp(arg+al-sl,strip[i]) == 0) ? al-sl : al;
+      char  *path = malloc(keep+strlen(add[i])+1);
+      int    fd;
+      if (path == NULL)
+        { fprintf(stderr,"%s: Out of memory\n",Prog_Name); exit (1); }
+      memcpy(path,arg,keep);
+      strcpy(path+keep,add[i]);
+      fd = open(path,O_RDONLY);
+      if (fd >= 0)
+        { close(fd);
+          return (path);
+        }
+      free(path);
+    }
+  fprintf(stderr,"\n%s: Cannot open %s as a .cram|[bs]am|f{ast}[aq][.gz]|db|dam file\n",Prog_Name,arg);
+  exit (1);
+}
+
 /* Hand the file text to the library in large pieces; the record structure is resolved on the GPU
    (fk_push_fastq / fk_push_fasta).  Used unless -bc / -x ask for host-side read offsets (or -c on
    FASTA: compression across the line breaks of a record is left to the host parser). */
@@ -455,6 +487,9 @@ int main(int argc, char *argv[])
       exit (1);
     }
 
+  for (i = 1; i <= nfiles; i++)
+    argv[i] = resolve_input(argv[i]);
+
   if (PROFILE && (MEM_GB > 0 || BC_PREFIX > 0))
     { fprintf(stderr,"%s: -p needs the reads resident in HBM and whole: not available with -M or -bc\n",Prog_Name);
       exit (1);
@@ -513,7 +548,7 @@ int main(int argc, char *argv[])
     { char *r, *d;
       int   q = classify(argv[i],&r,&d);
       if (q < 0)
-        { fprintf(stderr,"%s: %s is not a .fa/.fasta/.fq/.fastq[.gz], .sam or .bam file (other inputs are not built)\n",
+        { fprintf(stderr,"%s: %s: CRAM and Dazzler inputs are not built in this engine\n",
                   Prog_Name,argv[i]);
           exit (1);
         }

@@ -1325,6 +1325,28 @@ def test_cli_output_naming_follows_reference(tmp_path):
             out += [os.path.relpath(os.path.join(dp, f), d) for f in fs]
         return sorted(out)
 
+    # the extension may be left out, and foo.fastq finds foo.fastq.gz (Fetch_File, io.c:136-160)
+    import gzip
+    gdirs = []
+    for tool in (exe, ref):
+        d = str(tmp_path / ("g%d" % len(gdirs)))
+        os.makedirs(d)
+        layout(d)
+        with open(os.path.join(d, "in", "sub", "c.fq"), "rb") as f, gzip.open(os.path.join(d, "in", "z.fastq.gz"), "wb") as g:
+            g.write(f.read())
+        for args in (["in/a.part"], ["in/z.fastq"], ["in/z"]):
+            cmd = [tool, "-k40", "-t1", "-T2"] + args
+            if tool == ref:
+                cmd.insert(1, "-P" + d)
+            subprocess.run(cmd, check=True, cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        p = subprocess.run([tool, "-k40", "in/nothing"], cwd=d, capture_output=True, text=True)
+        assert p.returncode == 1 and "Cannot open in/nothing as a" in p.stderr
+        gdirs.append(d)
+    assert listing(gdirs[0]) == listing(gdirs[1])
+    for f in listing(gdirs[0]):
+        if f.endswith(".hist"):
+            assert open(os.path.join(gdirs[0], f), "rb").read() == open(os.path.join(gdirs[1], f), "rb").read(), f
+
     for n, extra in enumerate(([], ["-Nout/named"], ["-Nplain"])):
         dirs = []
         for tool in (exe, ref):
