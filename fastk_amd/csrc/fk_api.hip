@@ -763,8 +763,7 @@ static int flush_chunk(fk_ctx *ctx)
 
 extern "C" int fk_push_block(fk_ctx *ctx, const char *bases, const int32_t *boff, int nreads,
                              int rem, int tid)
-{ (void) rem;
-  if (ctx == NULL || bases == NULL || boff == NULL || nreads < 0) return (FK_EINVAL);
+{ if (ctx == NULL || bases == NULL || boff == NULL || nreads < 0) return (FK_EINVAL);
   if (nreads == 0)
     return (FK_OK);
   const int64_t len = (int64_t) boff[nreads] - boff[0];
@@ -828,6 +827,7 @@ extern "C" int fk_push_block(fk_ctx *ctx, const char *bases, const int32_t *boff
           if (ctx->blocks == NULL) { ctx->nblocks = ctx->blocks_cap = 0; rc = FK_ENOMEM; break; }
         }
       ctx->blocks[ctx->nblocks].tid = tid;
+      ctx->blocks[ctx->nblocks].rem = rem;
       ctx->blocks[ctx->nblocks].nreads = nreads;
       ctx->nblocks += 1;
       if (ctx->chunk_bytes > 0 && ctx->reads_len >= ctx->chunk_bytes)

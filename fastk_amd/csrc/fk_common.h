@@ -25,6 +25,7 @@ struct fk_chunk
 
 struct fk_block       // one fk_push_block call: which input thread, how many reads
 { int      tid;
+  int      rem;      // > 0: the block's last read continues in the thread's next block
   int64_t  nreads;
 };
 

@@ -12,9 +12,63 @@
 // ---- profiles (-p) ---------------------------------------------------------------------------
 
 // compressed profiles + offsets from HBM into the context's host buffers, in the data set's read order
-static int profiles_to_host(fk_ctx *ctx, int64_t nreads, int64_t nprof, void *d_data, uint64_t *d_offs,
+// the codec on the host (README.md:1029-1069; same streams as k_pf_encode), for reads that arrived in pieces
+static void fk_profile_decode_append(const uint8_t *b, int64_t len, std::vector<uint16_t> &out)
+{ if (len <= 0) return;
+  int64_t i;
+  uint32_t c;
+  if (b[0] & 0x80) { c = ((uint32_t) (b[0] & 0x7f) << 8) | b[1]; i = 2; }
+  else             { c = b[0]; i = 1; }
+  out.push_back((uint16_t) c);
+  while (i < len)
+    { const uint32_t x = b[i];
+      if (x & 0x80)
+        { c = (c + ((((x & 0x7f) << 8) | b[i + 1]))) & 0x7fff;
+          out.push_back((uint16_t) c);
+          i += 2;
+        }
+      else if (x & 0x40)
+        { int d = (int) (x & 0x3f);
+          if (d & 0x20) d -= 0x40;
+          c = (uint32_t) ((int) c + d) & 0xffff;
+          out.push_back((uint16_t) c);
+          i += 1;
+        }
+      else
+        { out.insert(out.end(), (size_t) x, (uint16_t) c);
+          i += 1;
+        }
+    }
+}
+
+static void fk_profile_encode_append(const std::vector<uint16_t> &c, std::vector<uint8_t> &o)
+{ if (c.empty()) return;
+  uint32_t prev = c[0], run = 0;
+  if (prev < 128) o.push_back((uint8_t) prev);
+  else { o.push_back((uint8_t) (0x80 | (prev >> 8))); o.push_back((uint8_t) prev); }
+  for (size_t j = 1; j < c.size(); j++)
+    { const uint32_t x = c[j];
+      if (x == prev)
+        { if (++run == 63) { o.push_back(63); run = 0; }
+          continue;
+        }
+      if (run) { o.push_back((uint8_t) run); run = 0; }
+      const int d = (int) x - (int) prev;
+      if (d > -32 && d < 32)
+        o.push_back((uint8_t) (0x40 | (d & 0x3f)));
+      else
+        { const uint32_t dd = (uint32_t) d & 0x7fff;
+          o.push_back((uint8_t) (0x80 | (dd >> 8)));
+          o.push_back((uint8_t) dd);
+        }
+      prev = x;
+    }
+  if (run) o.push_back((uint8_t) run);
+}
+
+static int profiles_to_host(fk_ctx *ctx, int64_t *nreads_io, int64_t *nprof_io, void *d_data, uint64_t *d_offs,
                             bool own_reads)
-{
+{ const int64_t nreads = *nreads_io, nprof = *nprof_io;
   if (ctx->h_prof_cap < nprof + 1)
     { free(ctx->h_prof);
       ctx->h_prof = (uint8_t *) malloc((size_t) nprof + 1);
@@ -42,50 +96,94 @@ static int profiles_to_host(fk_ctx *ctx, int64_t nreads, int64_t nprof, void *d_
   if (own_reads && !ctx->blocks_bad && ctx->nblocks > 0)
     { int64_t tot = 0;
       int     maxtid = 0;
-      bool    sorted = true;
+      bool    sorted = true, joins = false;
       for (int64_t b = 0; b < ctx->nblocks; b++)
         { tot += ctx->blocks[b].nreads;
           if (ctx->blocks[b].tid > maxtid) maxtid = ctx->blocks[b].tid;
           if (b > 0 && ctx->blocks[b].tid < ctx->blocks[b - 1].tid) sorted = false;
           if (ctx->blocks[b].tid < 0) tot = -1 - nreads;
+          if (ctx->blocks[b].rem > 0) joins = true;
         }
       if (tot == nreads && maxtid < 4096)
         { const int nt = maxtid + 1;
           free(ctx->h_prof_split);
           ctx->h_prof_split = (int64_t *) calloc((size_t) nt + 1, sizeof(int64_t));
           if (ctx->h_prof_split == NULL) return (FK_ENOMEM);
-          for (int64_t b = 0; b < ctx->nblocks; b++)
-            ctx->h_prof_split[ctx->blocks[b].tid + 1] += ctx->blocks[b].nreads;
-          for (int t = 0; t < nt; t++)
-            ctx->h_prof_split[t + 1] += ctx->h_prof_split[t];
           ctx->h_prof_nsplit = nt;
-          if (!sorted)
-            { uint8_t *nd = (uint8_t *) malloc((size_t) nprof + 1);
-              int64_t *no = (int64_t *) malloc(sizeof(int64_t) * (size_t) (nreads + 1));
-              std::vector<int64_t> cur(ctx->h_prof_split, ctx->h_prof_split + nt);   // next read slot per thread
-              std::vector<int64_t> len((size_t) nreads);
-              if (nd == NULL || no == NULL) { free(nd); free(no); return (FK_ENOMEM); }
-              int64_t r = 0;
-              for (int64_t b = 0; b < ctx->nblocks; b++)       // lengths into their final slots
-                for (int64_t i = 0; i < ctx->blocks[b].nreads; i++, r++)
-                  len[(size_t) cur[ctx->blocks[b].tid]++] = ctx->h_prof_off[r + 1] - ctx->h_prof_off[r];
-              no[0] = 0;
-              for (int64_t i = 0; i < nreads; i++)
-                no[i + 1] = no[i] + len[(size_t) i];
+          if (sorted && !joins)
+            { for (int64_t b = 0; b < ctx->nblocks; b++)
+                ctx->h_prof_split[ctx->blocks[b].tid + 1] += ctx->blocks[b].nreads;
               for (int t = 0; t < nt; t++)
-                cur[(size_t) t] = ctx->h_prof_split[t];
-              r = 0;
-              for (int64_t b = 0; b < ctx->nblocks; b++)
-                { const int64_t n = ctx->blocks[b].nreads;
-                  if (n == 0) continue;
-                  const int64_t dst = cur[(size_t) ctx->blocks[b].tid];
-                  memcpy(nd + no[dst], ctx->h_prof + ctx->h_prof_off[r],
-                         (size_t) (ctx->h_prof_off[r + n] - ctx->h_prof_off[r]));
-                  cur[(size_t) ctx->blocks[b].tid] += n;
-                  r += n;
+                ctx->h_prof_split[t + 1] += ctx->h_prof_split[t];
+            }
+          else
+            { // blocks in data-set order: by thread, then in push order; a block pushed with rem > 0 ends
+              // in a read that goes on as the first read of the thread's next block (which repeats its
+              // last K-1 bases, io.c:557-570): the two profiles are one read's -- their counts are
+              // concatenated and encoded again
+              std::vector<int64_t> first((size_t) ctx->nblocks), order;
+              { int64_t r = 0;
+                for (int64_t b = 0; b < ctx->nblocks; b++)
+                  { first[(size_t) b] = r;
+                    r += ctx->blocks[b].nreads;
+                  }
+              }
+              for (int t = 0; t < nt; t++)
+                for (int64_t b = 0; b < ctx->nblocks; b++)
+                  if (ctx->blocks[b].tid == t && ctx->blocks[b].nreads > 0)
+                    order.push_back(b);
+              std::vector<uint8_t> nd;
+              std::vector<int64_t> no(1, 0);
+              std::vector<uint16_t> chain;
+              bool open_chain = false;
+              nd.reserve((size_t) nprof + 16);
+              no.reserve((size_t) nreads + 1);
+              for (size_t oi = 0; oi < order.size(); oi++)
+                { const int64_t b = order[oi];
+                  const int     t = ctx->blocks[b].tid;
+                  const bool goes_on = ctx->blocks[b].rem > 0 && oi + 1 < order.size()
+                                       && ctx->blocks[order[oi + 1]].tid == t;
+                  for (int64_t i = 0; i < ctx->blocks[b].nreads; i++)
+                    { const int64_t r  = first[(size_t) b] + i;
+                      const uint8_t *p = ctx->h_prof + ctx->h_prof_off[r];
+                      const int64_t  l = ctx->h_prof_off[r + 1] - ctx->h_prof_off[r];
+                      const bool last  = (i == ctx->blocks[b].nreads - 1);
+                      if (open_chain || (last && goes_on))
+                        { fk_profile_decode_append(p, l, chain);
+                          open_chain = true;
+                          if (!(last && goes_on))              // the read ends here
+                            { fk_profile_encode_append(chain, nd);
+                              no.push_back((int64_t) nd.size());
+                              chain.clear();
+                              open_chain = false;
+                              ctx->h_prof_split[t + 1] += 1;
+                            }
+                        }
+                      else
+                        { nd.insert(nd.end(), p, p + l);
+                          no.push_back((int64_t) nd.size());
+                          ctx->h_prof_split[t + 1] += 1;
+                        }
+                    }
+                  if (open_chain && !goes_on)                  // (a dangling piece: close it as it is)
+                    { fk_profile_encode_append(chain, nd);
+                      no.push_back((int64_t) nd.size());
+                      chain.clear();
+                      open_chain = false;
+                      ctx->h_prof_split[t + 1] += 1;
+                    }
                 }
-              free(ctx->h_prof);     ctx->h_prof = nd;      ctx->h_prof_cap = nprof + 1;
-              free(ctx->h_prof_off); ctx->h_prof_off = no;  ctx->h_prof_off_cap = nreads + 1;
+              for (int t = 0; t < nt; t++)
+                ctx->h_prof_split[t + 1] += ctx->h_prof_split[t];
+              *nreads_io = (int64_t) no.size() - 1;
+              *nprof_io  = (int64_t) nd.size();
+              uint8_t *bd = (uint8_t *) malloc(nd.size() + 1);
+              int64_t *bo = (int64_t *) malloc(sizeof(int64_t) * no.size());
+              if (bd == NULL || bo == NULL) { free(bd); free(bo); return (FK_ENOMEM); }
+              memcpy(bd, nd.data(), nd.size());
+              memcpy(bo, no.data(), sizeof(int64_t) * no.size());
+              free(ctx->h_prof);     ctx->h_prof = bd;      ctx->h_prof_cap = (int64_t) nd.size() + 1;
+              free(ctx->h_prof_off); ctx->h_prof_off = bo;  ctx->h_prof_off_cap = (int64_t) no.size();
             }
         }
     }
@@ -155,7 +253,7 @@ extern "C" int fk_make_profiles(fk_ctx *ctx, const void *d_bases, int64_t nbytes
   int rc = fkx_profiles(ctx, d_bases, nbytes, ctx->last_table, ctx->last_ntab, &nreads, &nprof, &d_data, &d_offs);
   if (rc != FK_OK)
     return (rc);
-  if ((rc = profiles_to_host(ctx, nreads, nprof, d_data, d_offs, own_reads)) != FK_OK)
+  if ((rc = profiles_to_host(ctx, &nreads, &nprof, d_data, d_offs, own_reads)) != FK_OK)
     return (rc);
   out->nreads  = nreads;
   out->nbytes  = nprof;
@@ -226,7 +324,7 @@ extern "C" int fk_profile_encode(fk_ctx *ctx, const void *d_bases, int64_t nbyte
   if (rc != FK_OK)
     return (rc);
   ctx->h_prof_nsplit = 0;
-  if ((rc = profiles_to_host(ctx, nreads, nprof, d_data, d_offs, false)) != FK_OK)
+  if ((rc = profiles_to_host(ctx, &nreads, &nprof, d_data, d_offs, false)) != FK_OK)
     return (rc);
   out->nreads  = nreads;
   out->nbytes  = nprof;

@@ -287,7 +287,9 @@ int fk_write_ktab_ex(const fk_result *res, int kmer, int table_cutoff, int nthre
  * Read order: blocks pushed with distinct tid interleave arbitrarily in time; the profiles come out
  * in the data set's order -- all reads of tid 0 in push order, then tid 1, ... (io.c hands every
  * input thread a contiguous range of the input, io.c:2455-2521) -- and split[] gives those ranges,
- * which are the reference's part files when fk_write_prof is called with nparts = nsplit.
+ * which are the reference's part files when fk_write_prof is called with nparts = nsplit.  A read that
+ * was pushed in pieces (blocks with rem > 0, the next block of that tid repeating K-1 bases) gets ONE
+ * profile: the pieces' counts are joined on the host and encoded again.
  * data / offsets / split are host memory owned by ctx, valid until the next call or fk_destroy. */
 typedef struct
   { int64_t        nreads;

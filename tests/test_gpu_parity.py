@@ -1367,3 +1367,68 @@ def test_cli_output_naming_follows_reference(tmp_path):
         for tool, d in zip((exe, ref), dirs):                       # one input type per run, both tools
             p = subprocess.run([tool, "-k40", "-T2", "in/a.part.fasta", "in/sub/c.fq"], cwd=d, capture_output=True, text=True)
             assert p.returncode == 1 and "All files must be of the same type" in p.stderr
+
+
+def test_profiles_of_reads_pushed_in_pieces(tmp_path):
+    """A read longer than a DATA_BLOCK arrives as pieces: every block but the last is pushed with rem = 1
+    and the next block of the same thread repeats the last K-1 bases (io.c:557-570).  Counting sees every
+    k-mer once, and the profile is the whole read's, not one per piece."""
+    import os, subprocess
+    k = 40
+    rng = np.random.default_rng(21)
+    genome = "".join("acgt"[x] for x in rng.integers(0, 4, size=30000))
+    reads = []
+    for i in range(40):
+        L = int(rng.integers(30, 6000))
+        s0 = int(rng.integers(0, len(genome) - L))
+        reads.append(genome[s0:s0 + L] if i % 7 else genome[s0:s0 + L].replace("a", "N", 1))
+    bases, boff = orc.block_from_reads(reads)
+    exp = orc.fastk(k, bases, boff, cutoff=1)
+    want = orc.profile_counts(k, bases, boff, exp.table)
+    with fastk_amd.Context(kmer=k, table_cutoff=1) as ctx:
+        owner = [int(rng.integers(0, 3)) for _ in reads]
+        for t in range(3):                                   # data-set order: thread 0's reads, then 1's, 2's
+            pass
+        order = sorted(range(len(reads)), key=lambda i: owner[i])
+        pending = {t: [i for i in order if owner[i] == t] for t in range(3)}
+        state = {t: None for t in range(3)}                  # (read index, next start) of a read in progress
+        while any(pending[t] or state[t] for t in range(3)):
+            t = int(rng.integers(0, 3))
+            if state[t] is None:
+                if not pending[t]:
+                    continue
+                state[t] = (pending[t].pop(0), 0)
+            i, st = state[t]
+            r = reads[i]
+            cut = len(r) if len(r) - st < 300 or rng.random() < 0.3 else st + int(rng.integers(k, len(r) - st))
+            piece = r[st:cut].encode() + b"\x00"
+            arr = np.frombuffer(piece, dtype=np.uint8)
+            last = (cut == len(r))
+            ctx.push_block(arr, np.array([0, len(arr)], dtype=np.int32), rem=0 if last else 1, tid=t)
+            state[t] = None if last else (i, cut - (k - 1))
+        res = ctx.finish()
+        assert res.ninst == exp.ninst and np.array_equal(res.hist, exp.hist) and np.array_equal(res.table, exp.table)
+        data, offs = ctx.make_profiles()
+    raw = data.tobytes()
+    assert len(offs) == len(reads) + 1
+    for j, i in enumerate(order):
+        assert raw[offs[j]:offs[j + 1]] == orc.profile_encode(want[i]), "read %d" % i
+
+    # the reference's main() over the shim cuts a 2.6 Mbp read into 1 MB blocks itself: same profiles as
+    # the reference's own run
+    exe = os.path.join(orc.REF_DIR, "FastK_gpu")
+    ref = os.path.join(orc.REF_DIR, "FastK")
+    if not (os.path.exists(exe) and os.path.exists(ref)):
+        return
+    big = "".join("acgt"[x] for x in rng.integers(0, 4, size=2600000))
+    b2, o2 = orc.block_from_reads([reads[0], big, reads[1], big[:1500000]])
+    outs = []
+    for tool, name in ((exe, "g"), (ref, "r")):
+        d = str(tmp_path / name)
+        os.makedirs(d)
+        orc.write_fasta(os.path.join(d, "x.fasta"), b2, o2, width=100)
+        subprocess.run([tool, "-k%d" % k, "-t1", "-T2", "-p", "-P" + d, os.path.join(d, "x.fasta")], check=True,
+                       cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        kk, enc = orc.read_profiles(d, "x")
+        outs.append([orc.profiles_digest([orc.profile_decode(e)]) for e in enc])
+    assert outs[0] == outs[1] and len(outs[0]) == 4
