@@ -1432,3 +1432,32 @@ def test_profiles_of_reads_pushed_in_pieces(tmp_path):
         kk, enc = orc.read_profiles(d, "x")
         outs.append([orc.profiles_digest([orc.profile_decode(e)]) for e in enc])
     assert outs[0] == outs[1] and len(outs[0]) == 4
+
+
+@pytest.mark.parametrize("fmt", ["fastq", "fasta"])
+def test_cli_profiles_of_homopolymer_compressed_reads(fmt, tmp_path):
+    """-c -p: the profiles are those of the compressed reads (io.c:284-294 applied first), as in the reference."""
+    import os, subprocess
+    case, bases, boff = util.load_case("synth_illumina_k40_t1_T4")
+    ref = os.path.join(orc.REF_DIR, "FastK")
+    if not os.path.exists(ref):
+        pytest.skip("reference build not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "fastk_amd", "bin", "FastK_amd")
+    outs = []
+    for tool, name in ((exe, "g"), (ref, "r")):
+        d = str(tmp_path / name)
+        os.makedirs(d)
+        path = os.path.join(d, "x." + fmt)
+        if fmt == "fastq":
+            orc.write_fastq(path, bases, boff)
+        else:
+            orc.write_fasta(path, bases, boff, width=70)
+        cmd = [tool, "-k40", "-t1", "-T3", "-c", "-p", path]
+        if tool == ref:
+            cmd.insert(1, "-P" + d)
+        subprocess.run(cmd, check=True, cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        kk, enc = orc.read_profiles(d, "x")
+        outs.append((orc.profiles_digest([orc.profile_decode(e) for e in enc]), len(enc),
+                     open(os.path.join(d, "x.hist"), "rb").read()))
+    assert outs[0] == outs[1]
