@@ -1387,9 +1387,7 @@ def test_profiles_of_reads_pushed_in_pieces(tmp_path):
     want = orc.profile_counts(k, bases, boff, exp.table)
     with fastk_amd.Context(kmer=k, table_cutoff=1) as ctx:
         owner = [int(rng.integers(0, 3)) for _ in reads]
-        for t in range(3):                                   # data-set order: thread 0's reads, then 1's, 2's
-            pass
-        order = sorted(range(len(reads)), key=lambda i: owner[i])
+        order = sorted(range(len(reads)), key=lambda i: owner[i])   # data-set order: thread 0's reads, then 1's, 2's
         pending = {t: [i for i in order if owner[i] == t] for t in range(3)}
         state = {t: None for t in range(3)}                  # (read index, next start) of a read in progress
         while any(pending[t] or state[t] for t in range(3)):
