@@ -810,7 +810,7 @@ extern "C" int fk_push_block(fk_ctx *ctx, const char *bases, const int32_t *boff
           { const int64_t o = boff[i] - boff[0];
             const int64_t e = boff[i + 1] - boff[0] - 1;
             for (int64_t j = o; j < e && j < o + ctx->prm.bc_prefix; j++)
-              st[j] = 0;
+              st[j] = 'N';                 // not a base, and not a read terminator either (profiles)
           }
       if (hipMemcpyAsync(ctx->d_reads + ctx->reads_len, st, (size_t) len, hipMemcpyHostToDevice,
                          ctx->stream) != hipSuccess

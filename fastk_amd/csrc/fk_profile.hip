@@ -340,7 +340,7 @@ static __global__ __launch_bounds__(256) void k_pf_zeros(const uint8_t *__restri
 template <bool EMIT>
 static __global__ __launch_bounds__(PF_ER) void k_pf_encode(const uint16_t *__restrict__ cnts,
                                                             const int64_t *__restrict__ ends, int64_t nreads,
-                                                            int64_t nbytes, int K, u32 *__restrict__ lens,
+                                                            int64_t nbytes, int K, int bc, u32 *__restrict__ lens,
                                                             const u64 *__restrict__ offs, uint8_t *__restrict__ out)
 { __shared__ __attribute__((aligned(16))) uint16_t lc[PF_ECAP];
   __shared__ __attribute__((aligned(16))) uint8_t  lo[EMIT ? PF_OCAP : 16];
@@ -367,8 +367,9 @@ static __global__ __launch_bounds__(PF_ER) void k_pf_encode(const uint16_t *__re
 
   u32 len = 0;
   if (r < nreads)
-    { const int64_t s = (r == 0) ? 0 : ends[r - 1] + 1;
+    { const int64_t s0 = (r == 0) ? 0 : ends[r - 1] + 1;
       const int64_t e = ends[r] < nbytes ? ends[r] : nbytes;
+      const int64_t s = (s0 + bc < e) ? s0 + bc : e;        // -bc: the profile is the trimmed read's
       const int64_t np = e - s - K + 1;
       uint8_t *o = NULL;
       if (EMIT)
@@ -711,7 +712,7 @@ static int fkx_profile_encode(fk_ctx *ctx, const uint8_t *bases, int64_t nbytes,
   if (lens == NULL || offs == NULL) return (FK_ENOMEM);
   const unsigned nb = (unsigned) ((nreads + PF_ER - 1) / PF_ER);
   hipLaunchKernelGGL(k_pf_encode<false>, dim3(nb), dim3(PF_ER), 0, s, (const uint16_t *) cnts, (const int64_t *) ends,
-                     nreads, nbytes, K, lens, (const u64 *) NULL, (uint8_t *) NULL);
+                     nreads, nbytes, K, ctx->prm.bc_prefix, lens, (const u64 *) NULL, (uint8_t *) NULL);
   { const int64_t nblk = (nreads + 4095) / 4096;
     u32 *bs = (u32 *) fk_slot(ctx, FK_SLOT_PF_ZC, nblk * 4 + 64);            // the zero counts are done with
     u64 *bo = (u64 *) fk_slot(ctx, FK_SLOT_PF_ZO, nblk * 8 + 64);
@@ -728,7 +729,7 @@ static int fkx_profile_encode(fk_ctx *ctx, const uint8_t *bases, int64_t nbytes,
   uint8_t *data = (uint8_t *) fk_slot(ctx, FK_SLOT_PF_OUT, nprof + 64);
   if (data == NULL) return (FK_ENOMEM);
   hipLaunchKernelGGL(k_pf_encode<true>, dim3(nb), dim3(PF_ER), 0, s, (const uint16_t *) cnts, (const int64_t *) ends,
-                     nreads, nbytes, K, (u32 *) NULL, (const u64 *) offs, data);
+                     nreads, nbytes, K, ctx->prm.bc_prefix, (u32 *) NULL, (const u64 *) offs, data);
   FK_LAUNCH_CHECK(ctx);
   *nprof_out = nprof;
   *d_data = data;

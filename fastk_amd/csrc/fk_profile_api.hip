@@ -230,10 +230,6 @@ extern "C" int fk_make_profiles(fk_ctx *ctx, const void *d_bases, int64_t nbytes
     { fk_set_error(ctx, "fk_make_profiles: needs fk_set_table or the table of a finished resident run with table_cutoff 1");
       return (FK_ESTATE);
     }
-  if (ctx->prm.bc_prefix > 0)
-    { fk_set_error(ctx, "fk_make_profiles: not available together with bc_prefix");
-      return (FK_EUNSUPPORTED);
-    }
   const bool own_reads = (d_bases == NULL);
   if (((uintptr_t) d_bases & 15) != 0)
     { fk_set_error(ctx, "fk_make_profiles: d_bases must be 16-byte aligned");

@@ -490,8 +490,8 @@ int main(int argc, char *argv[])
   for (i = 1; i <= nfiles; i++)
     argv[i] = resolve_input(argv[i]);
 
-  if (PROFILE && (MEM_GB > 0 || BC_PREFIX > 0))
-    { fprintf(stderr,"%s: -p needs the reads resident in HBM and whole: not available with -M or -bc\n",Prog_Name);
+  if (PROFILE && MEM_GB > 0)
+    { fprintf(stderr,"%s: -p needs the reads resident in HBM: not available with -M\n",Prog_Name);
       exit (1);
     }
 

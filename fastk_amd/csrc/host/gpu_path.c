@@ -31,10 +31,7 @@ int Determine_Scheme(DATA_BLOCK *block)
   fk_widths w;
 
   (void) block;
-  if (COMPRESS || (DO_PROFILE && BC_PREFIX > 0))
-    { fprintf(stderr,"%s: -c, and -p together with -bc, are not built on the GPU path\n",Prog_Name);
-      Clean_Exit(1);
-    }
+  /* -c: io.c compresses the homopolymer runs before it hands the blocks over (io.c:557-560) */
   fk_default_params(&p);
   p.kmer = KMER; p.nthreads = NTHREADS; p.bc_prefix = BC_PREFIX;
   p.table_cutoff = DO_PROFILE ? 1 : DO_TABLE;      /* profiles look every k-mer up in the table */

@@ -1459,3 +1459,37 @@ def test_cli_profiles_of_homopolymer_compressed_reads(fmt, tmp_path):
         outs.append((orc.profiles_digest([orc.profile_decode(e) for e in enc]), len(enc),
                      open(os.path.join(d, "x.hist"), "rb").read()))
     assert outs[0] == outs[1]
+
+
+@pytest.mark.parametrize("flags", [["-bc8", "-p"], ["-c"], ["-c", "-bc5", "-p"]])
+def test_barcode_prefix_and_compression_with_profiles(flags, tmp_path):
+    """-bc<n> with -p: the profile is the trimmed read's (reference behaviour); -c: homopolymer-compressed
+    reads.  FastK_amd and the reference's main() over the shim against the reference itself: .hist bytes,
+    table stream and decoded profiles."""
+    import os, subprocess
+    case, bases, boff = util.load_case("edge_k40_t1_T4")
+    ref = os.path.join(orc.REF_DIR, "FastK")
+    shim = os.path.join(orc.REF_DIR, "FastK_gpu")
+    if not os.path.exists(ref):
+        pytest.skip("reference build not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tools = [("r", ref), ("a", os.path.join(root, "fastk_amd", "bin", "FastK_amd"))]
+    if os.path.exists(shim):
+        tools.append(("s", shim))
+    outs = {}
+    for name, tool in tools:
+        d = str(tmp_path / name)
+        os.makedirs(d)
+        path = os.path.join(d, "x.fasta")
+        orc.write_fasta(path, bases[:boff[6000]], boff[:6001], width=80)
+        cmd = [tool, "-k40", "-t1", "-T2"] + flags + [path]
+        if name != "a":
+            cmd.insert(1, "-P" + d)
+        subprocess.run(cmd, check=True, cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        prof = None
+        if "-p" in flags:
+            kk, enc = orc.read_profiles(d, "x")
+            prof = (len(enc), orc.profiles_digest([orc.profile_decode(e) for e in enc]))
+        outs[name] = (open(os.path.join(d, "x.hist"), "rb").read(), orc.read_ktab(os.path.join(d, "x"))["stream_sha256"], prof)
+    for name in outs:
+        assert outs[name] == outs["r"], name
