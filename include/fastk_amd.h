@@ -272,7 +272,8 @@ int fk_write_ktab_ex(const fk_result *res, int kmer, int table_cutoff, int nthre
 /* ---- read profiles (FastK -p) --------------------------------------------------------------
  * Replaces the profile output of the reference's counting pass (count.c:868-947, the per-super-mer
  * fragments) and their stitching into read order (merge.c, Merge_Profiles): for every read, in input
- * order, the counts of its k-mers (0 where the k-mer contains a non-acgt base, capped at 32767),
+ * order, the counts of its k-mers (0 where the k-mer contains a non-acgt base, capped at 32767; with
+ * bc_prefix, of the read without its first bc_prefix bases, for reads pushed with fk_push_block),
  * compressed with the codec of README.md:1029-1069.  The bytes are the canonical
  * one-byte-form-whenever-possible stream; they decode (libfastk.c:1657, Fetch_Profile) to the same
  * counts as the reference's files, whose zero-run splits follow its internal work panels
