@@ -1450,6 +1450,7 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
       ctx->have_table = (d_smers_in == NULL && ctx->prm.table_cutoff == 1);
       ctx->have_part_table = (ctx->prm.table_cutoff == 1);
       ctx->last_table = table;
+      ctx->pf_dict_table = NULL;
       ctx->last_ntab  = ntab;
       hipEventRecord(ev[2], s);
       if (hipStreamSynchronize(s) != hipSuccess) { rc = FK_EHIP; break; }
@@ -1563,6 +1564,7 @@ extern "C" int fk_rounds_finish(fk_ctx *ctx, int fetch_table, fk_result *res)
   ctx->have_table = false;                       // a rank's pieces: not the whole data set
   ctx->have_part_table = (ctx->prm.table_cutoff == 1);
   ctx->last_table = table;
+  ctx->pf_dict_table = NULL;
   ctx->last_ntab  = ctx->acc_ntab;
   res->ms_sort_super = tm.group_s;
   res->ms_expand     = tm.expand;

@@ -71,6 +71,8 @@ struct fk_ctx
   bool       blocks_bad;    // reads also arrived through calls that carry no thread id
   int64_t   *h_prof_split; // reads of input thread t start at h_prof_split[t]
   int        h_prof_nsplit;
+  const void *pf_dict_table; // the table the dictionary in FK_SLOT_PF_IDX was built from (NULL: none)
+  int64_t    pf_dict_nt;
   uint8_t   *h_prof;       // profiles of fk_make_profiles (host)
   int64_t   *h_prof_off;
   int64_t    h_prof_cap, h_prof_off_cap;

@@ -534,6 +534,13 @@ static int pf_dictionary(fk_ctx *ctx, const void *d_table, int64_t nt, pf_dict *
   d->kmask = (kb_last == 4) ? 0xffffffffu : ((1u << (8 * kb_last)) - 1u);
   const int G = (d->sdw <= 4) ? 4 : 2;                       // slots per 64-byte line
   d->nlines = (u64) std::max<int64_t>(1, (2 * nt + G - 1) / G);
+  // the dictionary of an unchanged table is kept between calls (reads profiled piece by piece)
+  if (ctx->pf_dict_table == d_table && ctx->pf_dict_nt == nt && d_table != NULL
+      && ctx->slot_ptr[FK_SLOT_PF_IDX] != NULL && ctx->slot_cap[FK_SLOT_PF_IDX] >= (int64_t) d->nlines * 64)
+    { d->slots = (u32 *) ctx->slot_ptr[FK_SLOT_PF_IDX];
+      return (FK_OK);
+    }
+  ctx->pf_dict_table = NULL;
   d->slots = (u32 *) fk_slot(ctx, FK_SLOT_PF_IDX, (int64_t) d->nlines * 64);
   if (d->slots == NULL) return (FK_ENOMEM);
   FK_HIP(ctx, hipMemsetAsync(d->slots, 0, (size_t) d->nlines * 64, s));
@@ -541,6 +548,8 @@ static int pf_dictionary(fk_ctx *ctx, const void *d_table, int64_t nt, pf_dict *
   PF_DISPATCH(ctx, d->KW, d->sdw, PF_CALL);
 #undef PF_CALL
   FK_LAUNCH_CHECK(ctx);
+  ctx->pf_dict_table = d_table;
+  ctx->pf_dict_nt    = nt;
   return (FK_OK);
 }
 

@@ -198,6 +198,7 @@ extern "C" int fk_set_table(fk_ctx *ctx, const uint8_t *records, int64_t n)
   ctx->have_table = false;
   ctx->have_part_table = false;
   ctx->last_table = NULL;
+  ctx->pf_dict_table = NULL;
   ctx->last_ntab  = 0;
   if (n > 0)
     { void *d_t = fk_slot(ctx, FK_SLOT_TABLE, n * w.kmer_stride);
@@ -215,7 +216,8 @@ extern "C" int fk_set_table(fk_ctx *ctx, const uint8_t *records, int64_t n)
           FK_HIP(ctx, hipStreamSynchronize(s));
         }
       FK_HIP(ctx, hipStreamSynchronize(s));
-      ctx->last_table = d_t;                   // the look-ups hash the records: no order needed
+      ctx->last_table = d_t;
+      ctx->pf_dict_table = NULL;                   // the look-ups hash the records: no order needed
     }
   ctx->last_ntab  = n;
   ctx->have_table = true;

@@ -66,6 +66,15 @@ typedef struct
     int64_t  olen;
     int64_t  totbps, totrds;
     int      lastc;
+    int64_t  cap_bytes;      /* block capacity (bases incl. terminators) and reads */
+    int      cap_reads;
+    /* second pass of -p with -M: the blocks are not counted, their reads are looked up in the table of
+       the first pass piece by piece and the profiles collected here */
+    int      to_profiles;
+    void    *d_piece;        /* device buffer of cap_bytes */
+    uint8_t *pdata;
+    int64_t *poffs;
+    int64_t  pbytes, pbytes_cap, preads, preads_cap;
   } Feeder;
 
 static void die(fk_ctx *ctx, const char *what)
@@ -79,7 +88,41 @@ static void flush_block(Feeder *f, int rem)
 { if (f->nreads == 0)
     return;
   f->boff[f->nreads] = (int32_t) f->olen;
-  if (fk_push_block(f->ctx,f->bases,f->boff,f->nreads,rem,0) != FK_OK)
+  if (f->to_profiles)
+    { fk_profiles pr;
+      int64_t i;
+      if (rem)
+        { fprintf(stderr,"%s: -p with -M: a read is longer than %lld bases\n",Prog_Name,(long long) f->cap_bytes);
+          exit (1);
+        }
+      if (BC_PREFIX > 0)                  /* as fk_push_block does in the counting pass */
+        for (i = 0; i < f->nreads; i++)
+          { int64_t j, e = f->boff[i+1]-1;
+            for (j = f->boff[i]; j < e && j < f->boff[i]+BC_PREFIX; j++)
+              f->bases[j] = 'N';
+          }
+      if (fk_copy_to_device(f->ctx,f->d_piece,f->bases,f->olen) != FK_OK
+          || fk_make_profiles(f->ctx,f->d_piece,f->olen,&pr) != FK_OK)
+        die(f->ctx,"fk_make_profiles");
+      if (f->pbytes+pr.nbytes > f->pbytes_cap)
+        { f->pbytes_cap = (f->pbytes+pr.nbytes)*2 + (1 << 20);
+          f->pdata = realloc(f->pdata,(size_t) f->pbytes_cap);
+        }
+      if (f->preads+pr.nreads+1 > f->preads_cap)
+        { f->preads_cap = (f->preads+pr.nreads+1)*2 + 1024;
+          f->poffs = realloc(f->poffs,sizeof(int64_t)*(size_t) f->preads_cap);
+        }
+      if (f->pdata == NULL || f->poffs == NULL)
+        { fprintf(stderr,"%s: Out of memory\n",Prog_Name); exit (1); }
+      if (pr.nbytes > 0)
+        memcpy(f->pdata+f->pbytes,pr.data,(size_t) pr.nbytes);
+      f->poffs[0] = 0;
+      for (i = 0; i < pr.nreads; i++)
+        f->poffs[f->preads+i+1] = f->pbytes + pr.offsets[i+1];
+      f->pbytes += pr.nbytes;
+      f->preads += pr.nreads;
+    }
+  else if (fk_push_block(f->ctx,f->bases,f->boff,f->nreads,rem,0) != FK_OK)
     die(f->ctx,"fk_push_block");
   f->nreads  = 0;
   f->olen    = 0;
@@ -92,7 +135,7 @@ static inline void add_base(Feeder *f, int c)
         return;
       f->lastc = c;
     }
-  if (f->olen >= BLOCK_BYTES-2)
+  if (f->olen >= f->cap_bytes-2)
     { /* the read is longer than a block: close it here, continue with a K-1 overlap */
       char keep[256];
       int  ov = KMER-1;
@@ -117,7 +160,7 @@ static inline void end_read(Feeder *f)
   f->nreads += 1;
   f->totrds += 1;
   f->boff[f->nreads] = (int32_t) f->olen;
-  if (f->olen > BLOCK_BYTES - (1 << 20) || f->nreads >= BLOCK_READS)
+  if (f->olen > f->cap_bytes - (1 << 20) || f->nreads >= f->cap_reads)
     flush_block(f,0);
 }
 
@@ -490,10 +533,6 @@ int main(int argc, char *argv[])
   for (i = 1; i <= nfiles; i++)
     argv[i] = resolve_input(argv[i]);
 
-  if (PROFILE && MEM_GB > 0)
-    { fprintf(stderr,"%s: -p needs the reads resident in HBM: not available with -M\n",Prog_Name);
-      exit (1);
-    }
 
   double t_start = now(), t_ingest, t_count, t_write;
 
@@ -537,6 +576,8 @@ int main(int argc, char *argv[])
 
   memset(&feed,0,sizeof(feed));
   feed.ctx   = ctx;
+  feed.cap_bytes = BLOCK_BYTES;
+  feed.cap_reads = BLOCK_READS;
   feed.bases = malloc(BLOCK_BYTES+16);
   feed.boff  = malloc(sizeof(int32_t)*(BLOCK_READS+2));
   res        = malloc(sizeof(fk_result));
@@ -615,7 +656,34 @@ int main(int argc, char *argv[])
   if (PROFILE)
     { fk_profiles pr;
       double t0 = now();
-      if (fk_make_profiles(ctx,NULL,0,&pr) != FK_OK)
+      if (MEM_GB > 0 && !EXACT)
+        { /* the counting pass dropped the reads chunk by chunk: scan the input again and look the reads
+             up piece by piece in the table the pass left in HBM */
+          Feeder pf;
+          memset(&pf,0,sizeof(pf));
+          pf.ctx = ctx;
+          pf.to_profiles = 1;
+          pf.cap_bytes = 256 << 20;
+          pf.cap_reads = 4 << 20;
+          pf.bases = malloc((size_t) pf.cap_bytes+16);
+          pf.boff  = malloc(sizeof(int32_t)*((size_t) pf.cap_reads+2));
+          if (pf.bases == NULL || pf.boff == NULL || fk_device_alloc(ctx,pf.cap_bytes+64,&pf.d_piece) != FK_OK)
+            { fprintf(stderr,"%s: Out of memory\n",Prog_Name); exit (1); }
+          pf.boff[0] = 0;
+          for (i = 1; i <= nfiles; i++)
+            { if (ftype == 2) scan_sam(&pf,argv[i]);
+              else if (ftype == 3) scan_bam(&pf,argv[i]);
+              else scan_file(&pf,argv[i],ftype);
+            }
+          flush_block(&pf,0);
+          if (pf.poffs == NULL)
+            { pf.poffs = malloc(sizeof(int64_t)); pf.poffs[0] = 0; }
+          memset(&pr,0,sizeof(pr));
+          pr.nreads = pf.preads; pr.nbytes = pf.pbytes; pr.data = pf.pdata; pr.offsets = pf.poffs;
+          fk_device_free(ctx,pf.d_piece);
+          free(pf.bases); free(pf.boff);
+        }
+      else if (fk_make_profiles(ctx,NULL,0,&pr) != FK_OK)
         die(ctx,"fk_make_profiles");
       if (fk_write_prof(&pr,KMER,NTHREADS,dir,root) != FK_OK)
         die(ctx,"writing .prof");

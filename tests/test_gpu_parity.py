@@ -1493,3 +1493,32 @@ def test_barcode_prefix_and_compression_with_profiles(flags, tmp_path):
         outs[name] = (open(os.path.join(d, "x.hist"), "rb").read(), orc.read_ktab(os.path.join(d, "x"))["stream_sha256"], prof)
     for name in outs:
         assert outs[name] == outs["r"], name
+
+
+@pytest.mark.parametrize("fmt,extra", [("fastq", []), ("fasta", ["-bc6"]), ("bam", ["-c"])])
+def test_cli_profiles_with_memory_budget(fmt, extra, tmp_path):
+    """-p with -M: the counting pass is chunked (reads dropped on the way), a second pass over the input looks
+    the reads up piece by piece.  Every output file equals the resident run's."""
+    import os, subprocess
+    case, bases, boff = util.load_case("synth_illumina_k40_t1_T4")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "fastk_amd", "bin", "FastK_amd")
+    reads = [bases[boff[i]:boff[i + 1] - 1].tobytes().decode() for i in range(len(boff) - 1)]
+    outs = []
+    for name, mem in (("res", []), ("mem", ["-M1"])):
+        d = str(tmp_path / name)
+        os.makedirs(d)
+        path = os.path.join(d, "x." + fmt)
+        if fmt == "fastq":
+            orc.write_fastq(path, bases, boff)
+        elif fmt == "fasta":
+            orc.write_fasta(path, bases, boff, width=60)
+        else:
+            orc.write_bam(path, reads)
+        subprocess.run([exe, "-k40", "-t2", "-T3", "-p"] + extra + mem + [path], check=True, cwd=d,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        files = sorted(f for f in os.listdir(d) if f != "x." + fmt)
+        outs.append({f: open(os.path.join(d, f), "rb").read() for f in files})
+    assert sorted(outs[0]) == sorted(outs[1]) and len(outs[0]) == 1 + 4 + 1 + 6
+    for f in outs[0]:
+        assert outs[0][f] == outs[1][f], f
