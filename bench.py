@@ -113,6 +113,13 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    if os.environ.get("FK_RANKS_SHARE_GPU") == "1":
+        # test rig for boxes with one GPU (tests/test_gpu_parity.py): all ranks on device 0, RCCL told
+        # that they sit on different hosts so that it accepts them (socket transport; not a measurement)
+        local_rank = 0
+        os.environ["NCCL_HOSTID"] = "fk-rank-%d" % rank
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("NCCL_IB_DISABLE", "1")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     sharded = world > 1 or args.force_shard

@@ -743,6 +743,45 @@ def test_sharded_path_on_one_gpu_matches_plain_path():
         assert outs[0][key] == outs[1][key], key
 
 
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_ranks_on_one_gpu_match_one_context(ranks):
+    """A real exchange between processes: `ranks` RCCL ranks share device 0 (tools/ranks_on_one_gpu.py
+    gives each its own NCCL_HOSTID, so RCCL accepts them and moves the payload over its socket
+    transport).  count_sharded, count_sharded_rounds, gather_table, write_table_sharded,
+    profiles_sharded and profiles_exchanged with the HIP stages on every rank: histogram, totals,
+    merged table, the .ktab files the ranks write and every read's profile bytes equal the
+    one-context run over all reads."""
+    import importlib.util, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("ranks_on_one_gpu", os.path.join(root, "tools", "ranks_on_one_gpu.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rc, text = mod.parent(world=ranks, port=29650 + ranks)
+    assert rc == 0, text[-3000:]
+    assert text.count("equal to the one-context run") == 4 and "MISMATCH" not in text, text[-3000:]
+
+
+def test_bench_contract_with_two_ranks_on_one_gpu():
+    """The driver's N > 1 command line (torch.distributed.run ... bench.py --gpus 2) end to end, both
+    ranks on device 0: one JSON line from rank 0, n_gpus 2, twice the one-rank k-mer instances
+    (weak scaling), exchange verified by the warm-up step's checksums."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29663", os.path.join(root, "bench.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--genome-mbp", "2"]
+    env = dict(os.environ, FK_RANKS_SHARE_GPU="1")
+    p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    lines = [x for x in p.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak"
+    reads = int(50 * 2 * 2e6 / 150) // 2 * 2
+    assert out["config"]["kmer_instances"] == reads * 111
+    assert out["value"] > 0 and out["roofline"]["achieved"] > 0 and "cpu_baseline" not in out
+
+
 def test_sharded_final_gather_writes_reference_files(tmp_path):
     """count_sharded(fetch_table) -> gather_table -> write_files on a one-rank RCCL group: the files
     are the golden ones; HipEngine.sort_table (the re-ordering rank 0 does for world > 1) restores
