@@ -70,6 +70,33 @@ __device__ __forceinline__ void ag_read_slots(u32 base, u32 slot, uint4 (&v)[4])
                : "memory");
 }
 
+// The first of the AG_P slots just read that settles a probe: empty (kind 1), being written (2) or
+// holding this key's first three dwords (3); act = AG_P, kind 0 when none does.  Written without
+// control flow: a slot settles iff min(count word, key difference, count word ^ AG_LOCK) == 0, and
+// the kind follows from the count word of the chosen slot alone (neither empty nor locked => the
+// key matched).  The straightforward nested conditionals compile to ~45 exec-mask instructions per
+// slot here; this form is ~7 VALU per slot.
+template <int KW>
+__device__ __forceinline__ void ag_classify(const uint4 (&v)[AG_P], const u32 *cur, int &act, u32 &kind,
+                                            u32 &cact)
+{ u32 a = AG_P, c = 0;
+#pragma unroll
+  for (int j = AG_P - 1; j >= 0; j--)
+    { u32 e = v[j].x ^ cur[0];
+      if (KW > 1) e |= v[j].y ^ cur[KW > 1 ? 1 : 0];
+      if (KW > 2) e |= v[j].z ^ cur[KW > 2 ? 2 : 0];
+      const u32  t = min(min(v[j].w, e), v[j].w ^ AG_LOCK);
+      const bool h = (t == 0u);
+      a = h ? (u32) j : a;
+      c = h ? v[j].w : c;
+    }
+  u32 k = 3u;
+  k = (c == AG_LOCK) ? 2u : k;
+  k = (c == 0u) ? 1u : k;
+  k = (a == (u32) AG_P) ? 0u : k;
+  act = (int) a; kind = k; cact = c;
+}
+
 // exclusive scan over the 1024 threads of the block.  tmp: AG_WAVES u32 of LDS.
 __device__ __forceinline__ u32 ag_block_exscan(u32 v, u32 *tmp, u32 *total)
 { const u32 lane = fk_lane();
@@ -202,18 +229,9 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
                   // hit their k-mer or claim an empty slot right away.
                   { uint4 v[AG_P];
                     ag_read_slots<SLOTS>(lds_base, slot, v);
-                    int act = AG_P;
-                    u32 kind = 0, cact = 0;
-#pragma unroll
-                    for (int j = AG_P - 1; j >= 0; j--)
-                      { const u32 c = v[j].w;
-                        bool same = (v[j].x == cur[0]);
-                        if (KW > 1) same = same && (v[j].y == cur[KW > 1 ? 1 : 0]);
-                        if (KW > 2) same = same && (v[j].z == cur[KW > 2 ? 2 : 0]);
-                        const u32 k = (c == 0u) ? 1u : (c == AG_LOCK) ? 2u : same ? 3u : 0u;
-                        if (k != 0u)
-                          { act = j; kind = k; cact = c; }
-                      }
+                    int act;
+                    u32 kind, cact;
+                    ag_classify<KW>(v, cur, act, kind, cact);
                     const u32 s = (slot + (u32) act) & (SLOTS - 1);
                     bool hit = todo && kind == 3u && cact < (AG_HIGH >> 1);
                     bool bmiss = false;
@@ -260,18 +278,9 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
                     { uint4 v[AG_P];
                       ag_read_slots<SLOTS>(lds_base, slot, v);
                       // first slot that is empty (1), being written (2) or holds this k-mer (3)
-                      int act = AG_P;
-                      u32 kind = 0, cact = 0;
-#pragma unroll
-                      for (int j = AG_P - 1; j >= 0; j--)
-                        { const u32 c = v[j].w;
-                          bool same = (v[j].x == cur[0]);
-                          if (KW > 1) same = same && (v[j].y == cur[KW > 1 ? 1 : 0]);
-                          if (KW > 2) same = same && (v[j].z == cur[KW > 2 ? 2 : 0]);
-                          const u32 k = (c == 0u) ? 1u : (c == AG_LOCK) ? 2u : same ? 3u : 0u;
-                          if (k != 0u)
-                            { act = j; kind = k; cact = c; }
-                        }
+                      int act;
+                      u32 kind, cact;
+                      ag_classify<KW>(v, cur, act, kind, cact);
                       const u32 s = (slot + (u32) act) & (SLOTS - 1);
                       if (KW <= 3 && kind == 3u && cact < (AG_HIGH >> 1))
                         { atomicAdd(&A[s].w, wgt);                   // the common case: no return value needed
