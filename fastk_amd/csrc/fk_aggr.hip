@@ -70,6 +70,23 @@ __device__ __forceinline__ void ag_read_slots(u32 base, u32 slot, uint4 (&v)[4])
                : "memory");
 }
 
+// The same AG_P reads plus one dword (the workgroup's overflow flag) in the same batch, so that the
+// flag costs no LDS round trip of its own in front of every probe.
+template <int SLOTS>
+__device__ __forceinline__ void ag_read_slots_flag(u32 base, u32 slot, uint4 (&v)[4], u32 flag_addr, u32 &flag)
+{  const u32 a0 = base + ((slot + 0) & (SLOTS - 1)) * 16u, a1 = base + ((slot + 1) & (SLOTS - 1)) * 16u;
+  const u32 a2 = base + ((slot + 2) & (SLOTS - 1)) * 16u, a3 = base + ((slot + 3) & (SLOTS - 1)) * 16u;
+  asm volatile("ds_read_b32 %4, %9\n\t"
+               "ds_read_b128 %0, %5\n\t"
+               "ds_read_b128 %1, %6\n\t"
+               "ds_read_b128 %2, %7\n\t"
+               "ds_read_b128 %3, %8\n\t"
+               "s_waitcnt lgkmcnt(0)"
+               : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(flag)
+               : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(flag_addr)
+               : "memory");
+}
+
 // The first of the AG_P slots just read that settles a probe: empty (kind 1), being written (2) or
 // holding this key's first three dwords (3); act = AG_P, kind 0 when none does.  Written without
 // control flow: a slot settles iff min(count word, key difference, count word ^ AG_LOCK) == 0, and
@@ -146,6 +163,7 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
   uint4 *B     = ag_lds + SLOTS;                           // [SLOTS] when KW > 3
   u32   *lhist = (u32 *) (ag_lds + (KW > 3 ? 2 : 1) * SLOTS);   // [AG_HB]
   __shared__ u32 sh_claimed, sh_ovf, sh_tmp[AG_WAVES];
+  const u32 ovf_addr = (u32) (uintptr_t) &sh_ovf;
   __shared__ u64 sh_base;
   const int tid = threadIdx.x;
 
@@ -222,13 +240,16 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
                   u32  slot = slot0[u];
                   // a thread claims <= 1 slot per record, so looking at the overflow flag once per
                   // record keeps the table from filling up
-                  const bool todo = ((pend >> u) & 1u) && (*(volatile u32 *) &sh_ovf) == 0;
-                  bool done = !todo;
+                  // (the flag arrives with the slots of the first look: one LDS round trip, not two)
                   // First look, straight-line for the whole wave (nested divergent branches cost more
                   // scalar instructions here than the probes cost vector ones): most records either
                   // hit their k-mer or claim an empty slot right away.
-                  { uint4 v[AG_P];
-                    ag_read_slots<SLOTS>(lds_base, slot, v);
+                  uint4 v0[AG_P];
+                  u32   ovf_now;
+                  ag_read_slots_flag<SLOTS>(lds_base, slot, v0, ovf_addr, ovf_now);
+                  const bool todo = ((pend >> u) & 1u) && ovf_now == 0;
+                  bool done = !todo;
+                  { uint4 (&v)[AG_P] = v0;
                     int act;
                     u32 kind, cact;
                     ag_classify<KW>(v, cur, act, kind, cact);
