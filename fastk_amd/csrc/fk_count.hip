@@ -45,15 +45,12 @@ __device__ __forceinline__ bool ct_same_key(const u32 *a, const u32 *b, const Ct
 // lexicographic order of two keys (memory-order bytes): big-endian word compare under the masks
 template <int KW>
 __device__ __forceinline__ bool ct_key_less(const u32 *a, const u32 *b, const CtMask<KW> &k)
-{ bool less = false, decided = false;
+{ bool less = false;                                   // mask arithmetic, no short-circuit: no branches
 #pragma unroll
-  for (int w = 0; w < KW; w++)
+  for (int w = KW - 1; w >= 0; w--)
     { const u32 x = __builtin_bswap32(a[w] & k.m[w]);
       const u32 y = __builtin_bswap32(b[w] & k.m[w]);
-      if (!decided && x != y)
-        { less = (x < y);
-          decided = true;
-        }
+      less = (x < y) | ((x == y) & less);
     }
   return less;
 }

@@ -67,8 +67,9 @@ __device__ __forceinline__ u32 ex_revpairs(u32 x)
 __device__ __forceinline__ u32 ex_bits(const u32 *rec, int bit)
 { const u32 hi = rec[bit >> 5];
   const u32 lo = rec[(bit >> 5) + 1];
-  const int sh = bit & 31;
-  return (sh == 0) ? hi : ((hi << sh) | (lo >> (32 - sh)));
+  // one 64-bit shift: with a conditional on sh == 0 the compiler sinks the second load into a
+  // divergent branch (an exec-mask round trip and a second LDS wait per word)
+  return ((u32) (((((u64) hi) << 32) | (u64) lo) >> (32 - (bit & 31))));
 }
 
 // Phase 1 (one thread per record): run heads, their multiplicity (walk forward in LDS, count.c:421-426)
@@ -251,13 +252,10 @@ __global__ __launch_bounds__(EX_THREADS) void k_ex_expand(const u32 *__restrict_
               r[0] = (r[0] >> 2) | (nb << 30);
               r[KN - 1] &= lastm;
             }
-          bool use_f = false, decided = false;         // count.c:484-495: forward iff strictly smaller
+          bool use_f = (f[KN - 1] < r[KN - 1]);        // count.c:484-495: forward iff strictly smaller
 #pragma unroll
-          for (int q = 0; q < KN; q++)
-            if (!decided && f[q] != r[q])
-              { use_f = (f[q] < r[q]);
-                decided = true;
-              }
+          for (int q = KN - 2; q >= 0; q--)            // (no short-circuit: mask arithmetic, no branches)
+            use_f = (f[q] < r[q]) | ((f[q] == r[q]) & use_f);
           ex_out<OW> x;
 #pragma unroll
           for (int q = 0; q < OW; q++)

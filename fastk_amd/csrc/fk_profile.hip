@@ -96,13 +96,10 @@ __device__ __forceinline__ u32 pf_count_of(u32 *a, u32 tmask, int ps, const u32 
   for (int w = 0; w < KW; w++)
     b[w] = (u32) (((((u64) b[w]) << 32) | b[w + 1]) << ps >> 32);
   b[KW - 1] &= tmask;
-  bool rc_less = false, decided = false;
+  bool rc_less = (b[KW - 1] < a[KW - 1]);            // mask arithmetic, no short-circuit: no branches
 #pragma unroll
-  for (int w = 0; w < KW; w++)
-    if (!decided && a[w] != b[w])
-      { rc_less = b[w] < a[w];
-        decided = true;
-      }
+  for (int w = KW - 2; w >= 0; w--)
+    rc_less = (b[w] < a[w]) | ((b[w] == a[w]) & rc_less);
   if (rc_less)
     {
 #pragma unroll

@@ -51,8 +51,9 @@ __device__ __forceinline__ u32 sp_window(const u32 *arr, int off)
 { // 16 bases (32 bits) starting at base offset `off` of an MSB-first packed array
   const u32 hi = arr[off >> 4];
   const u32 lo = arr[(off >> 4) + 1];
-  const int sh = 2 * (off & 15);
-  return (sh == 0) ? hi : ((hi << sh) | (lo >> (32 - sh)));
+  // one 64-bit shift; a conditional on the shift being 0 makes the compiler sink the second load
+  // into a divergent branch
+  return ((u32) (((((u64) hi) << 32) | (u64) lo) >> (32 - 2 * (off & 15))));
 }
 
 template <bool EMIT, bool POS = false>
