@@ -255,8 +255,8 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
 #pragma unroll
     for (int c = 0; c < SP_CH; c++)
       { const bool v = (vmask >> c) & 1u;
-        if (v && (!pv || (mk[c] >> 1) != (pk >> 1)))
-          smask |= 1u << c;
+        const bool st = v & (!pv | ((mk[c] >> 1) != (pk >> 1)));      // no short-circuit: no branches
+        smask |= (st ? 1u : 0u) << c;
         pv = v;
         pk = mk[c];
       }

@@ -17,13 +17,13 @@
 
 template <int KW>
 __device__ __forceinline__ bool ts_same(const u32 *a, const u32 *b, int full, u32 lastm)
-{ bool same = true;
+{ u32 diff = 0;                                         // no short-circuit: straight-line code
 #pragma unroll
   for (int w = 0; w < KW; w++)
     { const u32 m = (w < full) ? 0xffffffffu : (w == full) ? lastm : 0u;
-      same = same && (((a[w] ^ b[w]) & m) == 0u);
+      diff |= (a[w] ^ b[w]) & m;
     }
-  return same;
+  return (diff == 0u);
 }
 
 // EMIT = false: tile_count[t] = records of tile t that agree with a neighbour on the first pbytes bytes
@@ -81,15 +81,14 @@ __global__ __launch_bounds__(TS_THREADS) void k_ts_ties(const u32 *__restrict__ 
 // records as byte strings: a < b on the first kbytes bytes
 template <int KW>
 __device__ __forceinline__ bool ts_less(const u32 *a, const u32 *b, int kfull, u32 klast)
-{
+{ bool less = false;                                    // from the last word up, mask arithmetic only
 #pragma unroll
-  for (int w = 0; w < KW; w++)
+  for (int w = KW - 1; w >= 0; w--)
     { const u32 m = (w < kfull) ? 0xffffffffu : (w == kfull) ? klast : 0u;
       const u32 x = __builtin_bswap32(a[w] & m), y = __builtin_bswap32(b[w] & m);
-      if (x != y)
-        return (x < y);
+      less = (x < y) | ((x == y) & less);
     }
-  return (false);
+  return (less);
 }
 
 // In-place repair of short tie runs: the thread of a run's first record insertion-sorts the run on
