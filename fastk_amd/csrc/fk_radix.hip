@@ -15,6 +15,7 @@
 // key bytes are taken by one extra read of the records (k_digit_hist) before the first pass.
 // The pass is stable, so LSD order over a byte list reproduces LSD_Sort bit for bit.
 #include "fk_common.h"
+#include <type_traits>
 
 #define RX_THREADS 256
 #define RX_WAVES   4
@@ -514,6 +515,10 @@ __global__ __launch_bounds__(RX_THREADS) void k_rx_scatter(const u32 *__restrict
                  + (u64) chunkpfx[(tile / RX_CH) * 256 + tid] + (u64) tilepfx[tile * 256 + tid];
   __syncthreads();
 
+  // Everything after the loads exists twice: for a full tile (all but the last one) every "is this
+  // slot inside the tile" predicate is a compile-time true and its exec-mask bookkeeping disappears.
+  auto pass = [&](auto full_tile)
+  { constexpr bool FULL = decltype(full_tile)::value;
   const int  wbase = wave * 64 * ITEMS;
   const u64  lt    = fk_lanemask_lt();
   const unsigned char *lbytes = (const unsigned char *) smem;
@@ -527,7 +532,7 @@ __global__ __launch_bounds__(RX_THREADS) void k_rx_scatter(const u32 *__restrict
 #pragma unroll
       for (int it = 0; it < ITEMS; it++)
         { const int  r     = wbase + it * 64 + lane;
-          const bool valid = (r < tn);
+          const bool valid = FULL || (r < tn);
           const u32  d     = valid ? (u32) tdig[r] : 0u;
           const u32  rk    = valid ? atomicAdd(&whist[wave * 256 + d], 1u) : 0u;
           info[it] = d | (rk << 8);
@@ -538,7 +543,7 @@ __global__ __launch_bounds__(RX_THREADS) void k_rx_scatter(const u32 *__restrict
 #pragma unroll
   for (int it = 0; it < ITEMS; it++)
     { const int  r     = wbase + it * 64 + lane;
-      const bool valid = (r < tn);
+      const bool valid = FULL || (r < tn);
       const u32  d     = valid ? (u32) tdig[r] : 0u;
       u64 mask = __ballot(valid);
 #pragma unroll
@@ -580,7 +585,7 @@ __global__ __launch_bounds__(RX_THREADS) void k_rx_scatter(const u32 *__restrict
 #pragma unroll
   for (int it = 0; it < ITEMS; it++)
     { const int r = wbase + it * 64 + lane;
-      if (r < tn)
+      if (FULL || r < tn)
         { const u32 e   = info[it];
           const u32 d   = e & 0xffu;
           const u32 pos = binstart[d] + whist[wave * 256 + d] + (e >> 8);
@@ -595,7 +600,7 @@ __global__ __launch_bounds__(RX_THREADS) void k_rx_scatter(const u32 *__restrict
 #pragma unroll
   for (int it = 0; it < ITEMS; it++)
     { const int p = it * RX_THREADS + tid;
-      if (p < tn)
+      if (FULL || p < tn)
         { const int     sr = perm[p];
           const u32     d  = tdig[sr];
           const int64_t o  = goff[d] + p;
@@ -608,6 +613,11 @@ __global__ __launch_bounds__(RX_THREADS) void k_rx_scatter(const u32 *__restrict
             }
         }
     }
+  };
+  if (tn == TILE)
+    pass(std::true_type{});
+  else
+    pass(std::false_type{});
 }
 
 // ---------------------------------------------------------------------------------------------
