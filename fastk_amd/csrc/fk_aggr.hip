@@ -70,6 +70,13 @@ __device__ __forceinline__ void ag_read_slots(u32 base, u32 slot, uint4 (&v)[4])
                : "memory");
 }
 
+// One slot (key + count word) with a single ds_write_b128 (see ag_read_slots).
+__device__ __forceinline__ void ag_write_slot(u32 addr, uint4 v)
+{ typedef unsigned int ag_u32x4 __attribute__((ext_vector_type(4)));
+  const ag_u32x4 x = { v.x, v.y, v.z, v.w };
+  asm volatile("ds_write_b128 %0, %1" : : "v"(addr), "v"(x) : "memory");
+}
+
 // The same AG_P reads plus one dword (the workgroup's overflow flag) in the same batch, so that the
 // flag costs no LDS round trip of its own in front of every probe.
 template <int SLOTS>
@@ -144,8 +151,9 @@ __device__ __forceinline__ u32 ag_block_exscan(u32 v, u32 *tmp, u32 *total)
 // LDS table: SLOTS entries of 16 bytes {key dword 0, 1, 2, count word}; records of 4 or 5 dwords keep
 // dwords 3, 4 in a second array.  A lane's aligned 16-byte LDS access is served in one piece, so a
 // single ds_read_b128 yields a consistent (key, count word) pair: count word 0 = empty, AG_LOCK =
-// key being written (its creator stores key + AG_LOCK with one b128 write, then the weight with a
-// b32 write; LDS operations of a wave execute in order), anything else = published count.
+// slot claimed with ds_cmpst, key not there yet (its creator then stores key + weight with ONE b128
+// write, after the key's tail for wide records; LDS operations of a wave execute in order),
+// anything else = published count.
 // DEDUP: the records are super-mers (whole record = key, weight 1); every distinct record comes out
 // once, followed by a dword with its multiplicity (records of KW + 1 dwords), nothing else is computed.
 template <int KW, bool DEDUP>
@@ -272,13 +280,16 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
                     bool created = false;
                     if (todo && kind == 1u)
                       { if (atomicCAS(&A[s].w, 0u, AG_LOCK) == 0u)
-                          { A[s] = make_uint4(cur[0], KW > 1 ? cur[KW > 1 ? 1 : 0] : 0u,
-                                              KW > 2 ? cur[KW > 2 ? 2 : 0] : 0u, AG_LOCK);
+                          { // key and weight appear together: the (wider) key's tail first, then ONE 16-byte write of
+                            // key + count word -- LDS serves a wave's operations in order and an aligned 16-byte
+                            // access in one piece, so no reader can pair this count with another key
                             if (KW > 3)
-                              B[s] = make_uint4(cur[KW > 3 ? 3 : 0], KW > 4 ? cur[KW > 4 ? 4 : 0] : 0u,
-                                                KW > 5 ? cur[KW > 5 ? 5 : 0] : 0u, KW > 6 ? cur[KW > 6 ? 6 : 0] : 0u);
-                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                            atomicExch(&A[s].w, wgt);                       // publish
+                              { B[s] = make_uint4(cur[KW > 3 ? 3 : 0], KW > 4 ? cur[KW > 4 ? 4 : 0] : 0u,
+                                                  KW > 5 ? cur[KW > 5 ? 5 : 0] : 0u, KW > 6 ? cur[KW > 6 ? 6 : 0] : 0u);
+                                asm volatile("" ::: "memory");
+                              }
+                            ag_write_slot(lds_base + s * 16u, make_uint4(cur[0], KW > 1 ? cur[KW > 1 ? 1 : 0] : 0u,
+                                                                         KW > 2 ? cur[KW > 2 ? 2 : 0] : 0u, wgt));
                             created = true;
                             done = true;
                           }
@@ -331,13 +342,16 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
                             }
                           else if (kind == 1u)
                             { if (atomicCAS(&A[s].w, 0u, AG_LOCK) == 0u)
-                                { A[s] = make_uint4(cur[0], KW > 1 ? cur[KW > 1 ? 1 : 0] : 0u,
-                                                    KW > 2 ? cur[KW > 2 ? 2 : 0] : 0u, AG_LOCK);
+                                { // key and weight appear together: the (wider) key's tail first, then ONE 16-byte write of
+                                  // key + count word -- LDS serves a wave's operations in order and an aligned 16-byte
+                                  // access in one piece, so no reader can pair this count with another key
                                   if (KW > 3)
-                                    B[s] = make_uint4(cur[KW > 3 ? 3 : 0], KW > 4 ? cur[KW > 4 ? 4 : 0] : 0u,
-                                                      KW > 5 ? cur[KW > 5 ? 5 : 0] : 0u, KW > 6 ? cur[KW > 6 ? 6 : 0] : 0u);
-                                  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                                  atomicExch(&A[s].w, wgt);                     // publish
+                                    { B[s] = make_uint4(cur[KW > 3 ? 3 : 0], KW > 4 ? cur[KW > 4 ? 4 : 0] : 0u,
+                                                        KW > 5 ? cur[KW > 5 ? 5 : 0] : 0u, KW > 6 ? cur[KW > 6 ? 6 : 0] : 0u);
+                                      asm volatile("" ::: "memory");
+                                    }
+                                  ag_write_slot(lds_base + s * 16u, make_uint4(cur[0], KW > 1 ? cur[KW > 1 ? 1 : 0] : 0u,
+                                                                               KW > 2 ? cur[KW > 2 ? 2 : 0] : 0u, wgt));
                                   created = true;
                                   done = true;
                                 }
