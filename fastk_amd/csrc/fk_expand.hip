@@ -190,8 +190,8 @@ __global__ __launch_bounds__(EX_THREADS) void k_ex_expand(const u32 *__restrict_
   u32 *gout = out + kbase * (u64) OW;
 
   // every thread emits EX_G CONSECUTIVE k-mers: one binary search for the first, after that the
-  // next k-mer of the same super-mer costs a fresh forward window (ex_bits) and a two-bit roll of
-  // the reverse complement; moving on to the next head re-derives both
+  // next k-mer costs a fresh forward window (ex_bits) and its reverse complement; moving on to the
+  // next head only changes the record the window is cut from
   for (u32 j0 = threadIdx.x * EX_G; j0 < ktile; j0 += EX_THREADS * EX_G)
     { u32 lo = 0, hi = nh;
       while (hi - lo > 1)
@@ -203,7 +203,6 @@ __global__ __launch_bounds__(EX_THREADS) void k_ex_expand(const u32 *__restrict_
       const u32 *rec = recs + (u32) hrec[lo] * RS;
       u32        ct  = hct[lo];
       u32 f[KN], r[KN];
-      bool fresh = true;
 #pragma unroll
       for (int g = 0; g < EX_G; g++)
         { const u32 j = j0 + g;
@@ -216,7 +215,6 @@ __global__ __launch_bounds__(EX_THREADS) void k_ex_expand(const u32 *__restrict_
                   nxt = hoff[lo + 1];
                   rec = recs + (u32) hrec[lo] * RS;
                   ct  = hct[lo];
-                  fresh = true;
                 }
               else
                 o += 1;
@@ -225,33 +223,24 @@ __global__ __launch_bounds__(EX_THREADS) void k_ex_expand(const u32 *__restrict_
           for (int q = 0; q < KN; q++)
             f[q] = ex_bits(rec, 2 * (int) o + 32 * q);
           f[KN - 1] &= lastm;
-          if (fresh)
-            { u32 t[KN];
+          // reverse complement straight from the forward window, every time: rolling the previous one
+          // by a base is cheaper per k-mer, but some lane of a wave enters a new super-mer at almost
+          // every step, so the wave would run both forms
+          { u32 t[KN];
 #pragma unroll
-              for (int q = 0; q < KN; q++)
-                { u32 c = ~f[KN - 1 - q];
-                  if (q == 0)
-                    c &= lastm;
-                  t[q] = ex_revpairs(c);
-                }
+            for (int q = 0; q < KN; q++)
+              { u32 c = ~f[KN - 1 - q];
+                if (q == 0)
+                  c &= lastm;
+                t[q] = ex_revpairs(c);
+              }
 #pragma unroll
-              for (int q = 0; q < KN; q++)
-                { const u32 h2 = t[q];
-                  const u32 l2 = (q + 1 < KN) ? t[q + 1] : 0u;
-                  r[q] = (padb == 0) ? h2 : ((h2 << padb) | (l2 >> (32 - padb)));
-                }
-              fresh = false;
-            }
-          else
-            { // the window moved one base to the right: its new last base, complemented, enters
-              // the reverse complement at the top and the old first base drops out at the bottom
-              const u32 nb = ((f[KN - 1] >> padb) & 3u) ^ 3u;
-#pragma unroll
-              for (int q = KN - 1; q > 0; q--)
-                r[q] = (r[q] >> 2) | (r[q - 1] << 30);
-              r[0] = (r[0] >> 2) | (nb << 30);
-              r[KN - 1] &= lastm;
-            }
+            for (int q = 0; q < KN; q++)
+              { const u32 h2 = t[q];
+                const u32 l2 = (q + 1 < KN) ? t[q + 1] : 0u;
+                r[q] = (padb == 0) ? h2 : ((h2 << padb) | (l2 >> (32 - padb)));
+              }
+          }
           bool use_f = (f[KN - 1] < r[KN - 1]);        // count.c:484-495: forward iff strictly smaller
 #pragma unroll
           for (int q = KN - 2; q >= 0; q--)            // (no short-circuit: mask arithmetic, no branches)
