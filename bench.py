@@ -5,11 +5,26 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W   (N>1 under t
 prints ONE JSON line on rank 0.  A "step" is one pass of the whole hot path over one batch of
 synthetic reads that is already resident in HBM when the timed region starts.
 
-Workload = BASELINE.json configs[1]: 50x coverage, 150 bp reads, 0.1 % substitutions, of a
-100 Mbp uniform random genome, k=40 -t1 (33.3 M reads, ~3.7 G k-mer instances) per GPU.
-At N GPUs the genome is N x 100 Mbp (weak scaling: fixed work per GPU); rank r owns read stripe
-r; super-mers are exchanged by minimizer bucket with one RCCL all-to-all-v, then each GPU sorts
-and counts its buckets; histograms are all-reduced.
+N = 1 (default --config 2) = BASELINE.json configs[2], the set the north-star target is quoted on:
+50x coverage of a 3 Gbp uniform random genome in 15 kbp reads with 0.2 % substitutions, k=40 -t4
+(10 M reads, 150 G bases, ~149.6 G k-mer instances).  The 150 GB of ASCII reads stay resident; the
+8.3 G super-mer records (166 GB) do not fit beside them, so the reads are split in `split_passes`
+passes, each keeping one group of minimizer buckets, and the buckets are counted one after the other
+(the role of FastK's NPARTS, split.c:617-766; count.c:1202 bucket loop).
+    --config 1 = BASELINE.json configs[1]: 50x of 100 Mbp in 150 bp reads, k=40 -t1, all resident.
+N > 1 runs the configs[1] workload per GPU (weak scaling): rank r owns read stripe r, super-mers are
+exchanged by minimizer bucket with RCCL, each GPU counts its buckets, histograms are all-reduced.
+
+The line also carries (N = 1):
+  roofline      dominant radix kernel (k_rx_scatter over the weighted k-mer records): algorithmic
+                2*n*R bytes per launch / launch duration by HIP events on the library's stream;
+                copy_ceiling = a device-to-device copy measured in this process
+  value_device  SURVEY 8(d) "device pipeline": first H2D of reads lying in pinned host memory ->
+                sorted table in pinned host memory (fk_push_block ... fk_finish)
+  value_e2e     SURVEY 8(d) "end to end": FASTA file -> .hist + .ktab files through bin/FastK_amd
+                (file in /dev/shm; --e2e-scale < 1 shrinks the genome, stated in the record)
+  cpu_baseline  reference FastK (oracle/_ref, built from the reference's sources) on this box's
+                host cores on a bounded sample of the same shape
 """
 import argparse
 import json
@@ -27,73 +42,242 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
+CONFIGS = {
+    1: dict(genome_mbp=100.0, coverage=50.0, read_len=150, err_ppm=1000, cutoff=1, buckets=1,
+            split_passes=1, cpu_sample_mbp=20.0,
+            label="50x coverage, 150 bp reads, err 1000 ppm, of a %g Mbp genome%s, k=%d -t1 "
+                  "(BASELINE.json configs[1])"),
+    2: dict(genome_mbp=3000.0, coverage=50.0, read_len=15000, err_ppm=2000, cutoff=4, buckets=16,
+            split_passes=4, cpu_sample_mbp=20.0,
+            label="50x coverage, 15 kbp HiFi-shaped reads, err 2000 ppm, of a %g Mbp genome%s, k=%d -t4 "
+                  "(BASELINE.json configs[2])"),
+}
+
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2],
+                    help="BASELINE.json configs[] index; 0 = 2 on one GPU, 1 on several")
     ap.add_argument("--kmer", type=int, default=40)
-    ap.add_argument("--genome-mbp", type=float, default=100.0, help="genome size per GPU (Mbp)")
-    ap.add_argument("--coverage", type=float, default=50.0)
-    ap.add_argument("--read-len", type=int, default=150)
-    ap.add_argument("--err-ppm", type=int, default=1000)
+    ap.add_argument("--genome-mbp", type=float, default=None, help="genome size per GPU (Mbp)")
+    ap.add_argument("--scale", type=float, default=1.0,
+                    help="development aid: shrink the genome by this factor (named in config.workload)")
+    ap.add_argument("--coverage", type=float, default=None)
+    ap.add_argument("--read-len", type=int, default=None)
+    ap.add_argument("--err-ppm", type=int, default=None)
+    ap.add_argument("--cutoff", type=int, default=None)
     ap.add_argument("--seed", type=int, default=20251001)
-    ap.add_argument("--cpu-sample-mbp", type=float, default=20.0,
+    ap.add_argument("--cpu-sample-mbp", type=float, default=None,
                     help="genome size of the bounded CPU-baseline sample (same coverage/shape)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-device-leg", action="store_true", help="skip value_device (pinned host -> host)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip value_e2e (file -> files)")
+    ap.add_argument("--e2e-scale", type=float, default=0.1,
+                    help="value_e2e runs on this fraction of the genome (1 = the full 150 GB FASTA)")
     ap.add_argument("--force-shard", action="store_true",
                     help="run the sharded (all-to-all) path even on one GPU: exercises RCCL + shard.py")
-    ap.add_argument("--stream-buckets", type=int, default=1,
-                    help="count the minimizer buckets one after the other (HBM-budgeted mode), N=1 only")
+    ap.add_argument("--stream-buckets", type=int, default=None,
+                    help="minimizer buckets counted one after the other, N=1 only")
+    ap.add_argument("--split-passes", type=int, default=None,
+                    help="split passes over the resident reads (each keeps 1/passes of the super-mers)")
     ap.add_argument("--exchange-rounds", type=int, default=4,
                     help="N > 1: the super-mer exchange is cut into this many pieces; piece i+1 travels "
                          "while piece i is counted (1 = one all-to-all, then count)")
     ap.add_argument("--debug", action="append", default=[], metavar="KEY=VALUE",
                     help="fk_debug_set knob for ablation runs (results may be invalid)")
+    ap.add_argument("--verbose", action="store_true")
     return ap.parse_args()
 
 
-def cpu_baseline(args):
+def log(args, *a):
+    if args.verbose:
+        print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def write_fastx(path, bases, nreads, L, fastq):
+    """reads as rows of L+1 bytes (0-terminated) -> FASTA (one line per read) or FASTQ file."""
+    rows = bases.reshape(nreads, L + 1)[:, :L]
+    if fastq:
+        mat = np.empty((nreads, 3 + L + 3 + L + 1), dtype=np.uint8)
+        mat[:, 0:3] = np.frombuffer(b"@r\n", dtype=np.uint8)
+        mat[:, 3:3 + L] = rows
+        mat[:, 3 + L:6 + L] = np.frombuffer(b"\n+\n", dtype=np.uint8)
+        mat[:, 6 + L:6 + 2 * L] = ord("I")
+        mat[:, 6 + 2 * L] = ord("\n")
+    else:
+        mat = np.empty((nreads, 3 + L + 1), dtype=np.uint8)
+        mat[:, 0:3] = np.frombuffer(b">r\n", dtype=np.uint8)
+        mat[:, 3:3 + L] = rows
+        mat[:, 3 + L] = ord("\n")
+    mat.tofile(path)
+
+
+def cpu_baseline(args, cfg):
     """Reference FastK (oracle/_ref/FastK, built from the reference sources) on this box's host
     cores, on a bounded sample of the same workload; falls back to the scalar port."""
     from oracle import orc
     cores = os.cpu_count() or 1
-    glen = int(args.cpu_sample_mbp * 1e6)
-    nreads = int(args.coverage * glen / args.read_len)
-    sample = "%gx coverage of a %g Mbp genome, %d x %d bp reads, err %d ppm, k=%d -t1" % (
-        args.coverage, args.cpu_sample_mbp, nreads, args.read_len, args.err_ppm, args.kmer)
-    bases, boff = orc.synth_block(args.seed, glen, args.read_len, args.err_ppm, 0, nreads)
-    inst = nreads * (args.read_len - args.kmer + 1)
+    L = cfg["read_len"]
+    glen = int(cfg["cpu_sample_mbp"] * 1e6)
+    nreads = int(cfg["coverage"] * glen / L)
+    sample = "%gx coverage of a %g Mbp genome, %d x %d bp reads, err %d ppm, k=%d -t%d" % (
+        cfg["coverage"], cfg["cpu_sample_mbp"], nreads, L, cfg["err_ppm"], args.kmer, cfg["cutoff"])
+    bases, boff = orc.synth_block(args.seed, glen, L, cfg["err_ppm"], 0, nreads)
+    inst = nreads * (L - args.kmer + 1)
     if orc.have_ref():
         d = tempfile.mkdtemp(prefix="fkbase")
         try:
-            L = args.read_len
-            mat = np.empty((nreads, 3 + L + 3 + L + 1), dtype=np.uint8)
-            mat[:, 0:3] = np.frombuffer(b"@r\n", dtype=np.uint8)
-            mat[:, 3:3 + L] = bases.reshape(nreads, L + 1)[:, :L]
-            mat[:, 3 + L:6 + L] = np.frombuffer(b"\n+\n", dtype=np.uint8)
-            mat[:, 6 + L:6 + 2 * L] = ord("I")
-            mat[:, 6 + 2 * L] = ord("\n")
-            path = os.path.join(d, "s.fastq")
-            mat.tofile(path)
-            del mat
-            cmd = [os.path.join(orc.REF_DIR, "FastK"), "-k%d" % args.kmer, "-t1", "-T%d" % cores,
-                   "-P" + d, path]
+            fastq = L <= 1000
+            path = os.path.join(d, "s.fastq" if fastq else "s.fasta")
+            write_fastx(path, bases, nreads, L, fastq)
+            cmd = [os.path.join(orc.REF_DIR, "FastK"), "-k%d" % args.kmer, "-t%d" % cfg["cutoff"],
+                   "-T%d" % cores, "-P" + d, path]
             t0 = time.perf_counter()
             subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                            cwd=d)
             dt = time.perf_counter() - t0
             return dict(value=inst / dt, unit="k-mers/s", cores=cores, kind="reference",
-                        sample=sample + " (FASTQ file, reference FastK -T%d, %.1f s wall)" % (cores, dt))
+                        sample=sample + " (%s file, reference FastK -T%d, %.1f s wall, parse and file "
+                                        "writes included)" % ("FASTQ" if fastq else "FASTA", cores, dt))
         finally:
             subprocess.run(["rm", "-rf", d])
     t0 = time.perf_counter()
-    res = orc.fastk(args.kmer, bases, boff, cutoff=1)
+    res = orc.fastk(args.kmer, bases, boff, cutoff=cfg["cutoff"])
     dt = time.perf_counter() - t0
     assert res.ninst == inst
     return dict(value=inst / dt, unit="k-mers/s", cores=1, kind="port",
                 sample=sample + " (scalar CPU restatement, %.1f s)" % dt)
+
+
+def copy_ceiling(torch, dev):
+    """Device-to-device copy rate on this box (read + write bytes per second), 4 GiB buffers."""
+    n = 4 << 30
+    a = torch.empty(n, dtype=torch.uint8, device=dev)
+    b = torch.empty(n, dtype=torch.uint8, device=dev)
+    a.fill_(1)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    del a, b
+    torch.cuda.empty_cache()
+    return round(2.0 * n / (best * 1e-3) / 1e9, 1)
+
+
+def device_leg(args, cfg, fastk_amd, ctx_gen, glen, nreads, L, local_rank):
+    """SURVEY 8(d) device pipeline: reads in pinned host memory -> fk_push_block (H2D) -> fk_finish ->
+    sorted table in pinned host memory.  Returns the record for the JSON line."""
+    import ctypes as C
+    lib = ctx_gen.L
+    per_block = max(1, min(nreads, (1 << 30) // (L + 1)))         # ~1 GB DATA_BLOCKs (int32 offsets)
+    nbytes = nreads * (L + 1)
+    host = C.c_void_p()
+    t0 = time.perf_counter()
+    if lib.fk_host_alloc(nbytes + 64, C.byref(host)) != 0:
+        return dict(skipped="cannot pin %d bytes of host memory" % nbytes)
+    t_pin = time.perf_counter() - t0
+    piece = ctx_gen.alloc(per_block * (L + 1) + 64)
+    for first in range(0, nreads, per_block):
+        n = min(per_block, nreads - first)
+        ctx_gen.synth_reads(args.seed, glen, L, cfg["err_ppm"], first, n, buf=piece)
+        ctx_gen._ck(lib.fk_copy_to_host(ctx_gen.h, host.value + first * (L + 1), piece.ptr, n * (L + 1)))
+    piece.free()
+    boff = (np.arange(per_block + 1, dtype=np.int64) * (L + 1)).astype(np.int32)
+    budget = int(args.device_budget_gb * 1e9)
+    out = {}
+    with fastk_amd.Context(kmer=args.kmer, table_cutoff=cfg["cutoff"], nthreads=4, device=local_rank,
+                           nbuckets=max(cfg["buckets"], 1) if budget else 1, hbm_budget=budget) as ctx:
+        if budget and cfg["buckets"] > 1:
+            sample = np.ctypeslib.as_array(C.cast(host, C.POINTER(C.c_uint8)), shape=(min(nbytes, 8 << 20),))
+            ctx.set_bucket_weights(ctx.bucket_census(sample))
+        times = []
+        for rep in range(2):                       # first run sizes the arenas and pins the table buffer
+            ctx.reset()
+            t0 = time.perf_counter()
+            for first in range(0, nreads, per_block):
+                n = min(per_block, nreads - first)
+                ctx._ck(lib.fk_push_block(ctx.h, host.value + first * (L + 1), boff.ctypes.data, n, 0, 0))
+            res = fastk_amd.api.CResult()
+            ctx._ck(lib.fk_finish(ctx.h, C.byref(res)))
+            times.append(time.perf_counter() - t0)
+        inst = int(res.ninst)
+        out = dict(value=inst / times[-1], unit="k-mers/s", seconds=round(times[-1], 3),
+                   first_run_seconds=round(times[0], 3), pin_seconds=round(t_pin, 2),
+                   h2d_bytes=int(nbytes), d2h_bytes=int(res.ntable) * ctx.w.kmer_word,
+                   table_entries=int(res.ntable), spilled_bytes=int(res.spilled_bytes),
+                   hbm_budget_gb=args.device_budget_gb,
+                   definition="first H2D of pinned host reads (fk_push_block, ~1 GB blocks) -> sorted table "
+                              "in pinned host memory (fk_finish); second of two runs")
+        h = np.ctypeslib.as_array(res.hist).astype(np.int64)
+        conserved = int((h[1:0x7fff] * np.arange(1, 0x7fff)).sum()) + int(res.max_inst)
+        assert conserved == inst == nreads * (L - args.kmer + 1), "device leg: %d k-mer instances counted, %d " \
+            "in the histogram, %d expected" % (inst, conserved, nreads * (L - args.kmer + 1))
+    lib.fk_host_free(host)
+    return out
+
+
+def e2e_leg(args, cfg, fastk_amd, ctx_gen, L):
+    """SURVEY 8(d) end to end: FASTA file (RAM disk) -> .hist + .ktab files through bin/FastK_amd."""
+    glen = int(cfg["genome_mbp"] * 1e6 * args.scale * args.e2e_scale)
+    nreads = int(cfg["coverage"] * glen / L)
+    if nreads < 1:
+        return dict(skipped="e2e sample empty")
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    d = tempfile.mkdtemp(prefix="fke2e", dir=base)
+    try:
+        fastq = L <= 1000
+        path = os.path.join(d, "reads.fastq" if fastq else "reads.fasta")
+        per = max(1, min(nreads, (2 << 30) // (L + 1)))
+        piece = ctx_gen.alloc(per * (L + 1) + 64)
+        with open(path, "wb") as f:
+            for first in range(0, nreads, per):
+                n = min(per, nreads - first)
+                ctx_gen.synth_reads(args.seed, glen, L, cfg["err_ppm"], first, n, buf=piece)
+                rows = piece.download(n * (L + 1)).reshape(n, L + 1)[:, :L]
+                if fastq:
+                    mat = np.empty((n, 3 + L + 3 + L + 1), dtype=np.uint8)
+                    mat[:, 0:3] = np.frombuffer(b"@r\n", dtype=np.uint8)
+                    mat[:, 3:3 + L] = rows
+                    mat[:, 3 + L:6 + L] = np.frombuffer(b"\n+\n", dtype=np.uint8)
+                    mat[:, 6 + L:6 + 2 * L] = ord("I")
+                    mat[:, 6 + 2 * L] = ord("\n")
+                else:
+                    mat = np.empty((n, 3 + L + 1), dtype=np.uint8)
+                    mat[:, 0:3] = np.frombuffer(b">r\n", dtype=np.uint8)
+                    mat[:, 3:3 + L] = rows
+                    mat[:, 3 + L] = ord("\n")
+                mat.tofile(f)
+        piece.free()
+        fbytes = os.path.getsize(path)
+        exe = os.path.join(ROOT, "fastk_amd", "bin", "FastK_amd")
+        cmd = [exe, "-k%d" % args.kmer, "-t%d" % cfg["cutoff"], "-T%d" % args.e2e_threads,
+               "-M%d" % args.e2e_mem_gb, "-N" + os.path.join(d, "out"), path]
+        times = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+            times.append(time.perf_counter() - t0)
+        inst = nreads * (L - args.kmer + 1)
+        out_bytes = sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d)
+                        if f.startswith("out") or f.startswith(".out"))
+        return dict(value=inst / min(times), unit="k-mers/s", seconds=round(min(times), 3),
+                    scale=args.scale * args.e2e_scale, kmer_instances=inst, input_bytes=fbytes,
+                    output_bytes=out_bytes, command=" ".join(os.path.basename(c) if c == exe else
+                                                             ("<file>" if c == path else c) for c in cmd[:-2]),
+                    definition="process start -> exit of bin/FastK_amd on a %s file in %s: read + parse, "
+                               "H2D, device pipeline, D2H, .hist + .ktab written; best of 2"
+                               % ("FASTQ" if fastq else "FASTA", base))
+    finally:
+        subprocess.run(["rm", "-rf", d])
 
 
 def main():
@@ -130,26 +314,43 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
 
-    L = args.read_len
-    glen = int(args.genome_mbp * 1e6) * world
-    total_reads = int(args.coverage * glen / L)
+    cfg_id = args.config or (1 if sharded else 2)
+    cfg = dict(CONFIGS[cfg_id])
+    for key, val in (("genome_mbp", args.genome_mbp), ("coverage", args.coverage), ("read_len", args.read_len),
+                     ("err_ppm", args.err_ppm), ("cutoff", args.cutoff), ("buckets", args.stream_buckets),
+                     ("split_passes", args.split_passes), ("cpu_sample_mbp", args.cpu_sample_mbp)):
+        if val is not None:
+            cfg[key] = val
+    custom = any(v is not None for v in (args.genome_mbp, args.coverage, args.read_len, args.err_ppm, args.cutoff))
+    args.device_budget_gb = 280.0 if cfg_id == 2 else 0.0
+    args.e2e_threads = 32 if cfg_id == 2 else 4
+    args.e2e_mem_gb = 256 if cfg_id == 2 else 64
+
+    L = cfg["read_len"]
+    glen = int(cfg["genome_mbp"] * 1e6 * args.scale) * world
+    total_reads = int(cfg["coverage"] * glen / L)
     per = total_reads // world
     first = rank * per
     nbytes = per * (L + 1)
 
-    ctx = fastk_amd.Context(kmer=args.kmer, table_cutoff=1, nthreads=4, device=local_rank,
-                            nbuckets=world * max(1, args.exchange_rounds) if sharded else max(1, args.stream_buckets))
+    nbuckets = world * max(1, args.exchange_rounds) if sharded else max(1, cfg["buckets"])
+    passes = 1 if sharded else max(1, cfg["split_passes"])
+    ctx = fastk_amd.Context(kmer=args.kmer, table_cutoff=cfg["cutoff"], nthreads=4, device=local_rank,
+                            nbuckets=nbuckets, split_passes=passes)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     for kv in args.debug:
         key, val = kv.split("=")
         ctx.debug_set(key, int(val))
+    ceiling = copy_ceiling(torch, dev) if rank == 0 else None
+    log(args, "copy ceiling", ceiling, "GB/s; generating", nbytes, "bytes of reads")
     reads = torch.empty(nbytes + 64, dtype=torch.uint8, device=dev)
-    ctx._ck(ctx.L.fk_synth_reads(ctx.h, args.seed, glen, L, args.err_ppm, first, per,
+    ctx._ck(ctx.L.fk_synth_reads(ctx.h, args.seed, glen, L, cfg["err_ppm"], first, per,
                                  reads.data_ptr()))
     torch.cuda.synchronize()
     engine = shard.HipEngine(ctx, dev)
-    if sharded:
-        engine.train_buckets(reads[:nbytes])          # scheme set-up, like Determine_Scheme: not a step
+    if sharded or nbuckets > 1:
+        engine.train_buckets(reads[:nbytes], sample_bytes=(2 << 20) if sharded else (8 << 20))
+        # (scheme set-up on a sample, like Determine_Scheme: not a step)
 
     def step(verify=False):
         if not sharded:
@@ -165,8 +366,10 @@ def main():
             torch.cuda.synchronize()
 
     last = None
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
+        t0 = time.perf_counter()
         last = step(verify=True)
+        log(args, "warm-up step %d: %.3f s" % (i, time.perf_counter() - t0))
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -181,80 +384,119 @@ def main():
     if not sharded:
         loc = last
         ninst, nsuper, nweighted, ndistinct = last.ninst, last.nsuper, last.nweighted, last.ndistinct
+        ntable = last.ntable
+        h = last.hist.astype(np.int64)
+        conserved = int((h[1:0x7fff] * np.arange(1, 0x7fff)).sum()) + int(last.max_inst)
+        assert conserved == ninst, "conservation law violated: %d != %d" % (conserved, ninst)
     else:
         loc = last["local"]["result"]
         ninst, nsuper = last["ninst"], last["nsuper"]
         nweighted, ndistinct = last["nweighted"], last["ndistinct"]
+        ntable = None
     expect = total_reads // world * world * (L - args.kmer + 1)
     assert ninst == expect, "k-mer instance count %d != %d" % (ninst, expect)
 
     ms_step = 1e3 * dt / args.steps
     value = ninst / (dt / args.steps)
+    log(args, "timed: %.3f s per step" % (dt / args.steps), loc.ms)
 
-    # roofline of the dominant kernel: k_rx_scatter on the W weighted k-mer records (the two hashed
+    # roofline of the dominant kernel: k_rx_scatter on the weighted k-mer records (the two hashed
     # digit passes that bring equal k-mers into one of 65,536 bins before they are summed in LDS),
-    # one stable 8-bit digit pass per launch.  Algorithmic bytes per launch = 2 * n * R (records read once and written
-    # once at the reference width R = KMER_WORD); duration = HIP event pair around every scatter
-    # launch on the library's stream, averaged over the launches of the last step.  pass_total adds
-    # the per-pass helper kernels (digit-stream histogram + two scans) that feed it.
+    # one stable 8-bit digit pass per launch.  Algorithmic bytes per launch = 2 * n * R (records read
+    # once and written once at the reference width R = KMER_WORD); duration = HIP event pair around
+    # every scatter launch on the library's stream.  With bucket streaming a step has 2 launches per
+    # bucket: achieved = (sum of the launches' algorithmic bytes) / (sum of their durations), and the
+    # per-launch figures are the averages.  pass_total adds the per-pass helper kernels.
     w = ctx.w
-    n_pass = loc.nweighted
-    npk = max(loc.passes_kmer, 1)
-    avg_ms = loc.ms_scatter_kmer / npk
-    avg_pass_ms = loc.ms_pass_kmer / npk
-    gbs = lambda nrec, width, ms: round((2.0 * nrec * width) / (ms * 1e-3) / 1e9, 1) if ms > 0 else 0.0
-    achieved = gbs(n_pass, w.kmer_word, avg_ms)
-    nps = max(loc.passes_super, 1)
+    n_rec = loc.nweighted
+    nl_k = max(loc.launches_kmer, 1)
+    nl_s = max(loc.launches_super, 1)
+    per_bucket = max(loc.buckets_counted, 1)
+    gbs = lambda nbytes_, ms: round(nbytes_ / (ms * 1e-3) / 1e9, 1) if ms > 0 else 0.0
+    passes_k = max(loc.passes_kmer, 1)
+    algo_k = 2.0 * n_rec * w.kmer_word * passes_k          # all scatter launches over W of one step
+    achieved = gbs(algo_k, loc.ms_scatter_kmer)
+    passes_s = max(loc.passes_super, 1)
+    algo_s = 2.0 * loc.nsuper * w.smer_word * passes_s
     # HBM traffic per launch from PMC counters cannot be collected by this process; it comes from
-    # the committed rocprofv3 passes over this same command (profiles/r01_pmc_traffic.json) and is
-    # only reported when the workload (records per launch) is the profiled one.
+    # the committed rocprofv3 passes over this same command and is only reported when the workload
+    # (records per launch) is the profiled one.
     traffic = None
-    try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        if abs(pm["weighted_kmers"] - n_pass) <= 5e-3 * n_pass and w.kmer_word == 12:
-            cands = [v for k, v in pm["kernels"].items() if k.startswith("_Z12k_rx_scatterILi3ELi12ELb")]
-            traffic = max(c["traffic_bytes"] for c in cands)       # the launches over all W records
-    except Exception:
-        traffic = None
+    traffic_src = None
+    for name in ("r02_pmc_traffic_configs%d.json" % cfg_id, "r01_pmc_traffic.json"):
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", name)))
+            per_launch = n_rec / (nl_k / passes_k)
+            if abs(pm["records_per_launch"] - per_launch) <= 2e-2 * per_launch and w.kmer_word == 12:
+                traffic = pm["scatter_traffic_bytes_per_launch"]
+                traffic_src = name
+                break
+        except Exception:
+            continue
     roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
-                    traffic_unit="bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_traffic.json)",
-                    algorithmic_bytes=2.0 * n_pass * w.kmer_word,
+                    traffic_unit="bytes per launch (FETCH_SIZE + WRITE_SIZE with the guide's gfx950 corrections, "
+                                 "profiles/%s)" % traffic_src if traffic_src else None,
+                    copy_ceiling=ceiling, frac_of_copy_ceiling=round(achieved / ceiling, 4) if ceiling else None,
+                    algorithmic_bytes=round(algo_k / nl_k, 1),
                     kernel="k_rx_scatter<3,12> (weighted k-mer records, R=%d B)" % w.kmer_word,
-                    records_per_launch=int(n_pass), launches_per_step=int(loc.passes_kmer),
-                    avg_launch_ms=round(avg_ms, 4),
-                    pass_total=dict(avg_ms=round(avg_pass_ms, 4),
-                                    achieved=gbs(n_pass, w.kmer_word, avg_pass_ms),
+                    records_per_launch=int(n_rec / (nl_k / passes_k)), launches_per_step=int(nl_k),
+                    avg_launch_ms=round(loc.ms_scatter_kmer / nl_k, 4),
+                    pass_total=dict(avg_ms=round(loc.ms_pass_kmer / nl_k, 4),
+                                    achieved=gbs(algo_k, loc.ms_pass_kmer),
                                     note="scatter + k_rx_tilehist + k_rx_chunkscan + k_rx_superscan"),
                     table_sort=dict(records=int(loc.ncollapsed), launches=int(loc.passes_final),
-                                    achieved_pass_total=gbs(loc.ncollapsed, w.kmer_word,
-                                                            loc.ms_pass_final / max(loc.passes_final, 1))),
+                                    achieved_pass_total=gbs(2.0 * loc.ncollapsed * w.kmer_word * max(loc.passes_final, 1),
+                                                            loc.ms_pass_final)),
                     supermer_pass=dict(
                         kernel="k_rx_scatter_w<5,4,hashed> (super-mer records, R=%d B)" % w.smer_word,
-                        records=int(loc.nsuper), launches=int(loc.passes_super),
-                        avg_launch_ms=round(loc.ms_scatter_super / nps, 4),
-                        achieved=gbs(loc.nsuper, w.smer_word, loc.ms_scatter_super / nps),
-                        pass_total_achieved=gbs(loc.nsuper, w.smer_word, loc.ms_pass_super / nps)))
+                        records_per_launch=int(loc.nsuper / (nl_s / passes_s)), launches=int(nl_s),
+                        avg_launch_ms=round(loc.ms_scatter_super / nl_s, 4),
+                        achieved=gbs(algo_s, loc.ms_scatter_super),
+                        pass_total_achieved=gbs(algo_s, loc.ms_pass_super)))
 
+    scale_note = "" if args.scale == 1.0 else " SCALED by %g (development run)" % args.scale
+    workload = cfg["label"] % (cfg["genome_mbp"] * args.scale, " per GPU" if sharded else "", args.kmer) + scale_note
+    if custom:
+        workload = "custom: " + workload
     out = dict(metric="canonical k-mers/sec (k=40, whole hot path, reads resident in HBM)",
                value=value, unit="k-mers/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                ms_per_step=ms_step, higher_is_better=True, scaling="weak", vs_baseline=None,
                dtype="u8", data="synthetic",
-               config=dict(workload="%gx coverage, %d bp reads, err %d ppm, of a %g Mbp genome per GPU"
-                                    ", k=%d -t1 (BASELINE.json configs[1])"
-                                    % (args.coverage, L, args.err_ppm, args.genome_mbp, args.kmer),
-                           reads_per_gpu=per, kmer_instances=int(ninst), supermers=int(nsuper),
+               config=dict(workload=workload, reads_per_gpu=per, bases_per_gpu=per * L,
+                           kmer_instances=int(ninst), supermers=int(nsuper),
                            weighted_kmers=int(nweighted), distinct_kmers=int(ndistinct),
-                           parallelism="minimizer-bucket shard x%d" % world
-                                       + (", exchange in %d overlapped rounds" % args.exchange_rounds
-                                          if sharded and args.exchange_rounds > 1 else "")),
+                           table_entries=ntable, table_cutoff=cfg["cutoff"],
+                           parallelism=("minimizer-bucket shard x%d" % world
+                                        + (", exchange in %d overlapped rounds" % args.exchange_rounds
+                                           if args.exchange_rounds > 1 else "")) if sharded else
+                                       "1 GPU, %d minimizer buckets counted one after the other, %d split pass(es) "
+                                       "over the resident reads" % (loc.buckets_counted, loc.split_passes)),
                roofline=roofline,
                stage_ms=dict((k, round(v, 3)) for k, v in loc.ms.items()))
+    if not sharded:
+        out["stage_ms"]["table_sort"] = round(loc.ms_table_sort, 3)
+    del reads
+    torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and not args.force_shard:
+        ctx.close()
+        ctx = None
+        gen = fastk_amd.Context(kmer=args.kmer, device=local_rank)
+        if not args.no_device_leg:
+            t0 = time.perf_counter()
+            out["value_device"] = device_leg(args, cfg, fastk_amd, gen, glen, per, L, local_rank)
+            log(args, "device leg %.1f s" % (time.perf_counter() - t0), out["value_device"])
+        if not args.no_e2e:
+            t0 = time.perf_counter()
+            out["value_e2e"] = e2e_leg(args, cfg, fastk_amd, gen, L)
+            log(args, "e2e leg %.1f s" % (time.perf_counter() - t0), out["value_e2e"])
+        gen.close()
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, cfg)
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out))
-    ctx.close()
+    if ctx is not None:
+        ctx.close()
     if sharded:
         dist.destroy_process_group()
 

@@ -27,7 +27,7 @@ EXPORTS = [
     "fk_write_ktab_ex", "fk_rounds_begin", "fk_rounds_add", "fk_rounds_finish",
     "fk_make_profiles", "fk_write_prof", "fk_set_table", "fk_ktab_idx_bytes", "fk_ktab_split",
     "fk_write_ktab_range", "fk_write_ktab_stub", "fk_split_supermers_emit_pos", "fk_profile_lookup_supermers",
-    "fk_profile_scatter", "fk_profile_encode",
+    "fk_profile_scatter", "fk_profile_encode", "fk_reset",
 ]
 
 
@@ -44,7 +44,7 @@ class Widths(C.Structure):
 class Params(C.Structure):
     _fields_ = [("kmer", C.c_int), ("table_cutoff", C.c_int), ("nthreads", C.c_int),
                 ("bc_prefix", C.c_int), ("device", C.c_int), ("nbuckets", C.c_int),
-                ("hbm_budget", C.c_int64), ("exact_parts", C.c_int)]
+                ("hbm_budget", C.c_int64), ("exact_parts", C.c_int), ("split_passes", C.c_int)]
 
 
 class CResult(C.Structure):
@@ -57,7 +57,9 @@ class CResult(C.Structure):
                 ("passes_super", C.c_int), ("passes_kmer", C.c_int),
                 ("ms_pass_super", C.c_double), ("ms_pass_kmer", C.c_double),
                 ("ms_scatter_super", C.c_double), ("ms_scatter_kmer", C.c_double),
-                ("ncollapsed", C.c_int64), ("passes_final", C.c_int), ("ms_pass_final", C.c_double)]
+                ("ncollapsed", C.c_int64), ("passes_final", C.c_int), ("ms_pass_final", C.c_double),
+                ("launches_super", C.c_int64), ("launches_kmer", C.c_int64), ("split_passes", C.c_int),
+                ("buckets_counted", C.c_int), ("spilled_bytes", C.c_int64), ("ms_table_sort", C.c_double)]
 
 
 class CProfiles(C.Structure):
@@ -107,6 +109,7 @@ def load_library():
     L.fk_train_block.argtypes = [vp, vp, vp, ci]
     L.fk_push_device.argtypes = [vp, vp, i64]
     L.fk_finish.argtypes = [vp, C.POINTER(CResult)]
+    L.fk_reset.argtypes = [vp]
     L.fk_count_device_reads.argtypes = [vp, vp, i64, ci, C.POINTER(CResult)]
     L.fk_count_device_supermers.argtypes = [vp, vp, i64, ci, C.POINTER(CResult)]
     L.fk_write_hist.argtypes = [C.POINTER(CResult), ci, C.c_char_p]
@@ -185,6 +188,9 @@ class Result:
         self.ms_scatter_kmer = float(cres.ms_scatter_kmer)
         self.ncollapsed = int(cres.ncollapsed)
         self.passes_final, self.ms_pass_final = int(cres.passes_final), float(cres.ms_pass_final)
+        self.launches_super, self.launches_kmer = int(cres.launches_super), int(cres.launches_kmer)
+        self.split_passes, self.buckets_counted = int(cres.split_passes), int(cres.buckets_counted)
+        self.spilled_bytes, self.ms_table_sort = int(cres.spilled_bytes), float(cres.ms_table_sort)
         if self.ntable > 0 and cres.table:
             self.table = np.ctypeslib.as_array(cres.table, shape=(self.ntable, kmer_word)).copy()
         else:
@@ -226,7 +232,7 @@ class Context:
     """fk_ctx wrapper: one per process / GPU."""
 
     def __init__(self, kmer=40, table_cutoff=0, nthreads=4, bc_prefix=0, device=0, nbuckets=1,
-                 exact_parts=False, hbm_budget=0):
+                 exact_parts=False, hbm_budget=0, split_passes=0):
         self.L = load_library()
         p = Params()
         self.L.fk_default_params(C.byref(p))
@@ -234,6 +240,7 @@ class Context:
         p.bc_prefix, p.device, p.nbuckets = bc_prefix, device, nbuckets
         p.exact_parts = 1 if exact_parts else 0
         p.hbm_budget = int(hbm_budget)
+        p.split_passes = int(split_passes)
         self.params = p
         self.h = C.c_void_p()
         rc = self.L.fk_create(C.byref(p), C.byref(self.h))
@@ -359,6 +366,9 @@ class Context:
         r = CResult()
         self._ck(self.L.fk_merge_tables(self.h, a.ctypes.data, a.shape[0], int(max_inst_in), C.byref(r)))
         return Result(r, self.w.kmer_word)
+
+    def reset(self):
+        self._ck(self.L.fk_reset(self.h))
 
     def push_device(self, ptr, nbytes):
         self._ck(self.L.fk_push_device(self.h, ptr, nbytes))

@@ -4,6 +4,7 @@
 #include "../../include/fk_synth.h"
 
 #include <pthread.h>
+#include <math.h>
 #include <stdarg.h>
 #include <fcntl.h>
 #include <unistd.h>
@@ -36,13 +37,42 @@ void *fk_slot(fk_ctx *ctx, int slot, int64_t nbytes)
   nbytes += nbytes / 32 + (1 << 20);
   void *p = NULL;
   if (hipMalloc(&p, (size_t) nbytes) != hipSuccess)
-    { fk_set_error(ctx, "out of HBM: cannot allocate %lld bytes (arena slot %d)",
-                   (long long) nbytes, slot);
+    { size_t fr = 0, tot = 0;
+      int64_t held = 0;
+      char    big[256] = "";
+      hipMemGetInfo(&fr, &tot);
+      for (int i = 0; i < FK_NSLOTS; i++)
+        { held += ctx->slot_cap[i];
+          if (ctx->slot_cap[i] >= (1ll << 30) && strlen(big) < 220)
+            snprintf(big + strlen(big), sizeof(big) - strlen(big), " %d:%.1f", i, (double) ctx->slot_cap[i] / 1e9);
+        }
+      fk_set_error(ctx, "out of HBM: cannot allocate %lld bytes (arena slot %d); %.1f GB free of %.1f, arena holds "
+                        "%.1f GB, chunks %.1f GB; slots over 1 GB [slot:GB]%s", (long long) nbytes, slot,
+                   (double) fr / 1e9, (double) tot / 1e9, (double) held / 1e9, (double) ctx->chunk_hbm_bytes / 1e9, big);
       return (NULL);
     }
   ctx->slot_ptr[slot] = p;
   ctx->slot_cap[slot] = nbytes;
   return (p);
+}
+
+// The result table's host copy lives in pinned memory (the D2H copy of a 36 GB table runs at the
+// PCIe rate only from there); grown with headroom, kept until fk_destroy.
+static int reserve_host_table(fk_ctx *ctx, int64_t bytes)
+{ if (ctx->h_table_cap >= bytes)
+    return (FK_OK);
+  if (ctx->h_table != NULL)
+    hipHostFree(ctx->h_table);
+  ctx->h_table = NULL;
+  ctx->h_table_cap = 0;
+  const int64_t want = bytes + bytes / 32 + 4096;
+  if (hipHostMalloc((void **) &ctx->h_table, (size_t) want, hipHostMallocDefault) != hipSuccess)
+    { ctx->h_table = NULL;
+      fk_set_error(ctx, "out of host memory: cannot pin %lld bytes for the result table", (long long) want);
+      return (FK_ENOMEM);
+    }
+  ctx->h_table_cap = want;
+  return (FK_OK);
 }
 
 extern "C" const char *fk_last_error(const fk_ctx *ctx)
@@ -236,6 +266,7 @@ extern "C" int fk_create(const fk_params *p, fk_ctx **out)
   CK(hipEventCreate(&ctx->stage_ev[1]));
   CK(hipMalloc((void **) &ctx->d_mrank, 1024 * sizeof(uint16_t)));
   CK(hipMalloc((void **) &ctx->d_mbucket, 1024));
+  CK(hipMalloc((void **) &ctx->d_mbucket_pass, 1024));
   CK(hipMalloc((void **) &ctx->d_scratch, 65536));
   CK(hipHostMalloc((void **) &ctx->h_scratch, 65536 + 32 * 256 * 8, hipHostMallocDefault));
   CK(hipMalloc((void **) &ctx->d_digit_hist, 32 * 256 * sizeof(u64)));
@@ -270,7 +301,7 @@ extern "C" void fk_destroy(fk_ctx *ctx)
   hipSetDevice(ctx->device);
   if (ctx->stream != NULL)
     hipStreamSynchronize(ctx->stream);
-  hipFree(ctx->d_mrank); hipFree(ctx->d_mbucket); hipFree(ctx->d_scratch);
+  hipFree(ctx->d_mrank); hipFree(ctx->d_mbucket); hipFree(ctx->d_mbucket_pass); hipFree(ctx->d_scratch);
   if (ctx->h_scratch) hipHostFree(ctx->h_scratch);
   hipFree(ctx->d_digit_hist); hipFree(ctx->d_status); hipFree(ctx->d_ticket);
   hipFree(ctx->d_reads);
@@ -294,7 +325,7 @@ extern "C" void fk_destroy(fk_ctx *ctx)
   for (int i = 0; i < ctx->nchunks; i++)
     free_chunk(&ctx->chunks[i]);
   free(ctx->chunks);
-  free(ctx->h_table);
+  if (ctx->h_table) hipHostFree(ctx->h_table);
   free(ctx->acc_res);
   free(ctx->h_roff);
   if (ctx->push_lock)
@@ -661,12 +692,8 @@ extern "C" int fk_merge_tables(fk_ctx *ctx, const uint8_t *records, int64_t n, i
   for (int x = 0; x < 256; x++)
     res->wfirst[x] = census[x];
   const int64_t bytes = nt * w.kmer_word;
-  if (ctx->h_table_cap < bytes)
-    { free(ctx->h_table);
-      ctx->h_table = (uint8_t *) malloc((size_t) bytes);
-      ctx->h_table_cap = bytes;
-      if (ctx->h_table == NULL) { ctx->h_table_cap = 0; return (FK_ENOMEM); }
-    }
+  if (reserve_host_table(ctx, bytes) != FK_OK)
+    return (FK_ENOMEM);
   std::vector<uint8_t> back((size_t) nt * w.kmer_stride);
   FK_HIP(ctx, hipMemcpyAsync(back.data(), sorted, back.size(), hipMemcpyDeviceToHost, s));
   FK_HIP(ctx, hipStreamSynchronize(s));
@@ -1036,7 +1063,11 @@ static int count_bucket(fk_ctx *ctx, void *sm_in, int64_t ns, fk_result *res, bo
         return (FK_EHIP);
       }
   do
-    { void *sm_b = fk_slot(ctx, FK_SLOT_SM_B, ns * w.smer_stride);
+    { // The buffers of the two stages are never live together: the second half of the super-mer
+      // grouping's ping-pong pair lives in the k-mer slot A and the de-duplicated records in the k-mer
+      // slot B (which is only sized for the weighted k-mers once the expansion has consumed them).
+      const bool lds_dedup = (ctx->dbg_smer_stage != 1 && (w.smer_stride >> 2) >= 2 && (w.smer_stride >> 2) <= 7);
+      void *sm_b = fk_slot(ctx, lds_dedup ? FK_SLOT_KM_A : FK_SLOT_SM_B, ns * w.smer_stride);
       void *km_a = NULL, *km_b = NULL;
       if (sm_b == NULL) { rc = FK_ENOMEM; break; }
       hipEventRecord(ev[0], s);
@@ -1049,14 +1080,15 @@ static int count_bucket(fk_ctx *ctx, void *sm_in, int64_t ns, fk_result *res, bo
       void *sm_sorted = sm_in;
       int64_t nsx = ns;                          // records handed to the expansion
       bool    dd = false;
-      if (ctx->dbg_smer_stage != 1 && (w.smer_stride >> 2) >= 2 && (w.smer_stride >> 2) <= 7)
+      if (lds_dedup)
         { void *grouped = sm_in;
           if ((rc = fkx_group(ctx, ns, sm_in, sm_b, w.smer_stride, w.smer_stride, 2, &grouped)) != FK_OK)
             break;
           res->passes_super      = ctx->sort_stats.passes;
+          res->launches_super   += ctx->sort_stats.passes;
           res->ms_pass_super    += ctx->sort_stats.pass_ms_total;
           res->ms_scatter_super += ctx->sort_stats.scatter_ms_total;
-          void *dd_out = fk_slot(ctx, FK_SLOT_SM_D, ns * (w.smer_stride + 4));
+          void *dd_out = fk_slot(ctx, FK_SLOT_KM_B, ns * (w.smer_stride + 4));
           if (dd_out == NULL) { rc = FK_ENOMEM; break; }
           rc = fkx_dedup_supermers(ctx, grouped, ns, dd_out, ns, &nsx);
           if (rc == FK_OK)
@@ -1064,7 +1096,14 @@ static int count_bucket(fk_ctx *ctx, void *sm_in, int64_t ns, fk_result *res, bo
               sm_sorted = dd_out;
             }
           else if (rc == FK_ESTATE)
-            { void *other = (grouped == sm_in) ? sm_b : sm_in;      // a bin did not fit: group fully
+            { // a bin did not fit: group fully; the pair must not touch the k-mer slots any more
+              void *other = fk_slot(ctx, FK_SLOT_SM_B, ns * w.smer_stride);
+              if (other == NULL) { rc = FK_ENOMEM; break; }
+              if (grouped != sm_in)
+                { if (hipMemcpyAsync(sm_in, grouped, (size_t) (ns * w.smer_stride), hipMemcpyDeviceToDevice, s) != hipSuccess)
+                    { rc = FK_EHIP; break; }
+                  grouped = sm_in;
+                }
               sm_sorted = grouped;
               nsx = ns;
               if ((rc = fkx_group(ctx, ns, grouped, other, w.smer_stride, w.smer_stride, FK_GROUP_PASSES, &sm_sorted)) != FK_OK)
@@ -1077,6 +1116,7 @@ static int count_bucket(fk_ctx *ctx, void *sm_in, int64_t ns, fk_result *res, bo
         { if ((rc = fkx_group(ctx, ns, sm_in, sm_b, w.smer_stride, w.smer_stride, FK_GROUP_PASSES, &sm_sorted)) != FK_OK)
             break;
           res->passes_super      = ctx->sort_stats.passes;
+          res->launches_super   += ctx->sort_stats.passes;
           res->ms_pass_super    += ctx->sort_stats.pass_ms_total;
           res->ms_scatter_super += ctx->sort_stats.scatter_ms_total;
         }
@@ -1088,17 +1128,20 @@ static int count_bucket(fk_ctx *ctx, void *sm_in, int64_t ns, fk_result *res, bo
       res->nweighted += nw;
       res->ndistinct_super += nd;
       if (nw > 0)
-        { // later buckets are about as dense as this one: size for the largest of them right away
-          int64_t want = nw;
-          if (ns_max > ns)
-            want = (int64_t) ((double) nw / (double) ns * (double) ns_max * 1.02);
-          if (want * w.kmer_stride <= ctx->slot_cap[FK_SLOT_KM_A] || want < nw)
-            want = nw;
-          if ((km_a = fk_slot(ctx, FK_SLOT_KM_A, want * w.kmer_stride)) == NULL
-              || (km_b = fk_slot(ctx, FK_SLOT_KM_B, want * w.kmer_stride)) == NULL)
+        { // (slots grow on demand: hipMalloc / hipFree of tens of GB take well under a millisecond here,
+          // and buckets balanced by work differ too much in density for a prediction to be worth it)
+          const int64_t want = nw;
+          if (ctx->dbg_verbose)
+            fprintf(stderr, "  bucket sizing: %lld records (%lld after de-duplication), largest bucket ~%lld, "
+                            "%lld weighted k-mers, buffers for %lld\n", (long long) ns, (long long) nsx,
+                    (long long) ns_max, (long long) nw, (long long) want);
+          if ((km_a = fk_slot(ctx, FK_SLOT_KM_A, want * w.kmer_stride)) == NULL)
             { rc = FK_ENOMEM; break; }
           if ((rc = fkx_expand(ctx, sm_sorted, nsx, km_a, nw, &nw, &nd, &ovf, true,
                                ctx->dbg_kmer_stage != 1 && exact_roff == NULL, dd)) != FK_OK) break;
+          // (the de-duplicated super-mers in slot B are dead from here on)
+          if ((km_b = fk_slot(ctx, FK_SLOT_KM_B, want * w.kmer_stride)) == NULL)
+            { rc = FK_ENOMEM; break; }
         }
       int64_t exact_census[256];
       if (exact_roff != NULL && nw > 0
@@ -1122,6 +1165,7 @@ static int count_bucket(fk_ctx *ctx, void *sm_in, int64_t ns, fk_result *res, bo
           if ((rc = fkx_group(ctx, nw, km_a, km_b, w.kmer_stride, w.kmer_bytes, 2, &grouped)) != FK_OK)
             break;
           res->passes_kmer      = ctx->sort_stats.passes;
+          res->launches_kmer   += ctx->sort_stats.passes;
           res->ms_pass_kmer    += ctx->sort_stats.pass_ms_total;
           res->ms_scatter_kmer += ctx->sort_stats.scatter_ms_total;
           void *tbuf = (grouped == km_a) ? km_b : km_a;
@@ -1159,6 +1203,7 @@ static int count_bucket(fk_ctx *ctx, void *sm_in, int64_t ns, fk_result *res, bo
               if ((rc = fkx_lsd_sort(ctx, nw, km_a, km_b, w.kmer_stride, bytes, nlow, &low)) != FK_OK)
                 break;
               res->passes_kmer      = ctx->sort_stats.passes;
+              res->launches_kmer   += ctx->sort_stats.passes;
               res->ms_pass_kmer    += ctx->sort_stats.pass_ms_total;
               res->ms_scatter_kmer += ctx->sort_stats.scatter_ms_total;
               void *cbuf = (low == km_a) ? km_b : km_a;
@@ -1214,11 +1259,22 @@ static int count_bucket(fk_ctx *ctx, void *sm_in, int64_t ns, fk_result *res, bo
                   // at once (growing by copies costs more than the counting at tens of GB)
                   int64_t ncap = need + need / 2 + (1 << 20);
                   if (ns_max > 0 && ns > 0 && ctx->prm.nbuckets > 1)
-                    { const double per_sm = (double) (*ntab + nt) / (double) (ctx->acc_ns + ns);
-                      const int64_t all = (int64_t) (per_sm * (double) ctx->acc_ns_total * 1.03) * w.kmer_stride;
+                    { // buckets carry about equal work (fk_set_bucket_weights) or about equal records
+                      // (default deal): the smaller of the two extrapolations (the slot grows again if
+                      // that was too little)
+                      const double by_sm = (double) (*ntab + nt) / (double) (ctx->acc_ns + ns) * (double) ctx->acc_ns_total;
+                      const double by_bk = (double) (*ntab + nt) / (double) (res->buckets_counted + 1) * (double) ctx->prm.nbuckets;
+                      const int64_t all = (int64_t) (std::min(by_sm, by_bk) * 1.10) * w.kmer_stride;
                       if (all > ncap) ncap = all + (1 << 20);
                     }
-                  if (hipMalloc(&nbuf, (size_t) ncap) != hipSuccess) { rc = FK_ENOMEM; break; }
+                  if (hipMalloc(&nbuf, (size_t) ncap) != hipSuccess)
+                    { ncap = need + (1 << 20);                // no room for the extrapolation: what is needed now
+                      if (hipMalloc(&nbuf, (size_t) ncap) != hipSuccess)
+                        { fk_set_error(ctx, "out of HBM: cannot allocate %lld bytes for the table records", (long long) ncap);
+                          rc = FK_ENOMEM;
+                          break;
+                        }
+                    }
                   if (*ntab > 0
                       && hipMemcpyAsync(nbuf, ctx->slot_ptr[FK_SLOT_TABLE], (size_t) (*ntab * w.kmer_stride),
                                         hipMemcpyDeviceToDevice, s) != hipSuccess)
@@ -1236,6 +1292,7 @@ static int count_bucket(fk_ctx *ctx, void *sm_in, int64_t ns, fk_result *res, bo
         }
       *ntab += (cutoff > 0) ? nt : 0;
       ctx->acc_ns += ns;
+      res->buckets_counted += 1;
       hipEventRecord(ev[3], s);
       if (hipEventSynchronize(ev[3]) != hipSuccess) { rc = FK_EHIP; break; }
       if (ctx->dbg_verbose)
@@ -1258,20 +1315,37 @@ static int count_bucket(fk_ctx *ctx, void *sm_in, int64_t ns, fk_result *res, bo
 static int sort_union_table(fk_ctx *ctx, int64_t ntab, fk_result *res, void **table, fk_stage_ms *tm)
 { const fk_widths &w = ctx->wid;
   hipStream_t s = ctx->stream;
-  void *tmp = fk_slot(ctx, FK_SLOT_KM_A, ntab * w.kmer_stride);
+  // second buffer of the sort: every per-bucket buffer is idle by now -- take one that is large
+  // enough as it is (after a multi-pass split the super-mer slot is) before growing one
+  void *tmp = NULL;
+  { static const int idle[5] = { FK_SLOT_SM_A, FK_SLOT_KM_A, FK_SLOT_KM_B, FK_SLOT_SM_G, FK_SLOT_SM_D };
+    for (int i = 0; i < 5 && tmp == NULL; i++)
+      if (ctx->slot_cap[idle[i]] >= ntab * w.kmer_stride)
+        tmp = ctx->slot_ptr[idle[i]];
+    if (tmp == NULL)
+      tmp = fk_slot(ctx, FK_SLOT_KM_A, ntab * w.kmer_stride);
+  }
   int64_t census[256];
   if (tmp == NULL) return (FK_ENOMEM);
-  hipEventRecord(ctx->ev0, s);
+  hipEvent_t te[2];                              // (the sort itself records ctx->ev0 / ev1)
+  if (hipEventCreate(&te[0]) != hipSuccess || hipEventCreate(&te[1]) != hipSuccess)
+    return (FK_EHIP);
+  hipEventRecord(te[0], s);
   *table = ctx->slot_ptr[FK_SLOT_TABLE];
   int rc = fkx_sort_table(ctx, ntab, ctx->slot_ptr[FK_SLOT_TABLE], tmp, table, census);
-  if (rc != FK_OK) return (rc);
+  if (rc != FK_OK)
+    { hipEventDestroy(te[0]); hipEventDestroy(te[1]);
+      return (rc);
+    }
   res->passes_final   = ctx->sort_stats.passes;
   res->ms_pass_final += ctx->sort_stats.pass_ms_total;
   for (int x = 0; x < 256; x++)
     res->wfirst[x] = census[x];
-  hipEventRecord(ctx->ev1, s);
-  hipEventSynchronize(ctx->ev1);
-  tm->radix_k += ms_between(ctx->ev0, ctx->ev1);
+  hipEventRecord(te[1], s);
+  hipEventSynchronize(te[1]);
+  tm->radix_k += ms_between(te[0], te[1]);
+  res->ms_table_sort += ms_between(te[0], te[1]);
+  hipEventDestroy(te[0]); hipEventDestroy(te[1]);
   return (FK_OK);
 }
 
@@ -1285,13 +1359,8 @@ static int fetch_result_table(fk_ctx *ctx, fk_result *res, void *table, int64_t 
   if (!(cutoff > 0 && nt > 0 && fetch_table))
     return (FK_OK);
   const int64_t bytes = nt * w.kmer_word;
-  if (ctx->h_table_cap < bytes)
-    { free(ctx->h_table);
-      ctx->h_table = (uint8_t *) malloc((size_t) bytes);
-      ctx->h_table_cap = bytes;
-      if (ctx->h_table == NULL)
-        { ctx->h_table_cap = 0; return (FK_ENOMEM); }
-    }
+  if (reserve_host_table(ctx, bytes) != FK_OK)
+    return (FK_ENOMEM);
   if (w.kmer_word == w.kmer_stride)
     { if (hipMemcpyAsync(ctx->h_table, table, (size_t) bytes, hipMemcpyDeviceToHost, s) != hipSuccess
           || hipStreamSynchronize(s) != hipSuccess)
@@ -1335,8 +1404,10 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
   do
     { void *sm_a = NULL;
       int64_t ns = 0, ni = 0;
-      int64_t bc[256], bo[256];
+      int64_t bc[256] = { 0 }, bo[256] = { 0 };
       int     nbk = 1;
+      int     ngroups = 1;                 // split passes over resident reads (fk_params.split_passes)
+      int64_t gcap_all = 0, goffs[257];
       fk_stage_ms tm = { 0., 0., 0., 0. };
 
       hipEventRecord(ev[0], s);
@@ -1386,19 +1457,34 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
               if ((rc = fkx_split_exact(ctx, d_reads, d_roff, nreads, tran, &sm_a, &ns, &ni)) != FK_OK) break;
             }
           else
-            { // split (sampled capacity + one emit pass; exact count-then-emit with several buckets)
-              if ((rc = fkx_split_fast(ctx, d_reads, nbytes, &sm_a, &ns, &ni, bc, bo)) != FK_OK) break;
-              nbk = ctx->prm.nbuckets;
+            { nbk = ctx->prm.nbuckets;
+              // several split passes over resident reads, each emitting one group of buckets?
+              if (nbk > 1 && nbk <= 255 && (ctx->prm.split_passes > 1 || (ctx->prm.split_passes == 0 && ctx->prm.hbm_budget > 0)))
+                { if ((rc = fkx_split_plan(ctx, d_reads, nbytes, &gcap_all, goffs)) != FK_OK) break;
+                  ngroups = ctx->prm.split_passes;
+                  if (ngroups <= 0)
+                    ngroups = (int) ((gcap_all * w.smer_stride + ctx->prm.hbm_budget / 2 - 1) / (ctx->prm.hbm_budget / 2));
+                  if (ngroups > nbk) ngroups = nbk;
+                  if (gcap_all == 0) ngroups = 1;
+                }
+              if (ngroups <= 1)
+                { // split (sampled capacity + one emit pass; exact count-then-emit with several buckets)
+                  ngroups = 1;
+                  if ((rc = fkx_split_fast(ctx, d_reads, nbytes, &sm_a, &ns, &ni, bc, bo)) != FK_OK) break;
+                }
             }
           res->nsuper = ns;
           res->ninst = ni;
           sm_in = sm_a;
         }
       hipEventRecord(ev[1], s);
+      double ms_split_groups = 0.;
 
       void   *table = NULL;
       int64_t ntab = 0;
       int64_t ns_max = 0;
+      if (nbk == 1)
+        bc[0] = ns;
       for (int b = 0; b < nbk; b++)
         ns_max = std::max(ns_max, bc[b]);
       ctx->acc_ns = 0;
@@ -1425,7 +1511,91 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
           *ptr = g;
           return (FK_OK);
         };
-      if (nbk == 1)
+      if (ngroups > 1)
+        { // Multi-pass split: the buckets are dealt into ngroups runs of consecutive buckets of about
+          // equal (estimated) size; every pass re-reads the reads and keeps one run's super-mers.
+          int     gb[257];
+          int64_t est[256], tot = 0, gmax = 0;
+          for (int b = 0; b < nbk; b++)
+            { est[b] = goffs[b + 1] - goffs[b];
+              ns_max = std::max(ns_max, est[b]);
+            }
+          { // runs of consecutive buckets, at most ngroups of them, with the smallest possible largest
+            // run: binary search on the run capacity, greedy fill
+            int64_t lo_c = ns_max, hi_c = gcap_all;
+            auto fill = [&](int64_t capv, int *bounds) -> int
+              { int g = 0;
+                int64_t acc = 0;
+                bounds[0] = 0;
+                for (int b = 0; b < nbk; b++)
+                  { if (acc + est[b] > capv && acc > 0)
+                      { bounds[++g] = b;
+                        acc = 0;
+                      }
+                    acc += est[b];
+                  }
+                bounds[++g] = nbk;
+                return (g);
+              };
+            while (lo_c < hi_c)
+              { const int64_t mid = lo_c + (hi_c - lo_c) / 2;
+                if (fill(mid, gb) <= ngroups) hi_c = mid; else lo_c = mid + 1;
+              }
+            ngroups = fill(lo_c, gb);
+          }
+          for (int g = 0; g < ngroups; g++)
+            { int64_t sum = 0;
+              for (int b = gb[g]; b < gb[g + 1]; b++)
+                sum += est[b];
+              gmax = std::max(gmax, sum);
+            }
+          ctx->acc_ns_total = gcap_all;
+          hipEvent_t gev[2];
+          if (hipEventCreate(&gev[0]) != hipSuccess || hipEventCreate(&gev[1]) != hipSuccess)
+            { rc = FK_EHIP; break; }
+          for (int g = 0; g < ngroups && rc == FK_OK; g++)
+            { int64_t lo[257], cnt[256], nig = 0;
+              double  grow = 1.0;
+              for (int tries = 0; ; tries++)
+                { int64_t run = 0;
+                  for (int b = 0; b < nbk; b++)
+                    { lo[b] = run;
+                      if (b >= gb[g] && b < gb[g + 1])
+                        run += (int64_t) ((double) est[b] * grow);
+                    }
+                  lo[nbk] = run;
+                  void *out = fk_slot(ctx, FK_SLOT_SM_A, std::max(run, gmax) * w.smer_stride);
+                  if (out == NULL) { rc = FK_ENOMEM; break; }
+                  sm_a = out;
+                  hipEventRecord(gev[0], s);
+                  rc = fkx_split_planned(ctx, d_reads, nbytes, out, ctx->slot_cap[FK_SLOT_SM_A] / w.smer_stride,
+                                         lo, cnt, &nig, gb[g], gb[g + 1]);
+                  hipEventRecord(gev[1], s);
+                  hipEventSynchronize(gev[1]);
+                  ms_split_groups += ms_between(gev[0], gev[1]);
+                  if (rc != FK_ESTATE || tries >= 2)
+                    break;
+                  grow *= 1.5;                // the sample under-estimated a bucket: wider regions
+                }
+              if (rc != FK_OK)
+                break;
+              if (g == 0)
+                res->ninst = nig;
+              for (int b = gb[g]; b < gb[g + 1] && rc == FK_OK; b++)
+                { tot += cnt[b];
+                  rc = count_bucket(ctx, (char *) sm_a + lo[b] * w.smer_stride, cnt[b], res, false, NULL,
+                                    &ntab, NULL, &tm, ns_max);
+                }
+            }
+          hipEventDestroy(gev[0]);
+          hipEventDestroy(gev[1]);
+          if (rc != FK_OK)
+            break;
+          res->nsuper = tot;
+          if (ntab > 0 && (rc = sort_union_table(ctx, ntab, res, &table, &tm)) != FK_OK)
+            break;
+        }
+      else if (nbk == 1)
         { if (chunked && ns > 0)
             rc = gather(0, &sm_in);
           if (rc == FK_OK)
@@ -1454,7 +1624,9 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
       ctx->last_ntab  = ntab;
       hipEventRecord(ev[2], s);
       if (hipStreamSynchronize(s) != hipSuccess) { rc = FK_EHIP; break; }
-      res->ms_split      = ms_between(ev[0], ev[1]);
+      res->ms_split      = ms_between(ev[0], ev[1]) + ms_split_groups;
+      res->split_passes  = ngroups;
+      res->spilled_bytes = chunked ? ctx->spilled_bytes : 0;
       res->ms_sort_super = tm.group_s;
       res->ms_expand     = tm.expand;
       res->ms_sort_kmer  = tm.radix_k;                  // radix passes (grouping + table sort)
@@ -1499,6 +1671,26 @@ extern "C" int fk_finish(fk_ctx *ctx, fk_result *res)
       return fkx_pipeline(ctx, ctx->d_reads, ctx->reads_len, NULL, 0, res, true, ctx->h_roff, ctx->nroff);
     }
   return fkx_pipeline(ctx, ctx->d_reads, ctx->reads_len, NULL, 0, res, true);
+}
+
+/* Forget the reads pushed so far (and any chunks split from them); arenas, staging buffers and the
+   bucket assignment stay, so the next data set starts without allocations. */
+extern "C" int fk_reset(fk_ctx *ctx)
+{ if (ctx == NULL) return (FK_EINVAL);
+  FK_HIP(ctx, hipSetDevice(ctx->device));
+  FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  pthread_mutex_lock((pthread_mutex_t *) ctx->push_lock);
+  ctx->reads_len = 0;
+  ctx->nblocks = 0;
+  ctx->blocks_bad = false;
+  ctx->nroff = 0;
+  for (int i = 0; i < ctx->nchunks; i++)
+    free_chunk(&ctx->chunks[i]);
+  ctx->nchunks = 0;
+  ctx->chunk_hbm_bytes = 0;
+  ctx->chunk_ninst = 0;
+  pthread_mutex_unlock((pthread_mutex_t *) ctx->push_lock);
+  return (FK_OK);
 }
 
 /* Same pipeline on a caller-owned device buffer, table left out unless asked (bench path). */

@@ -40,6 +40,7 @@ struct fk_ctx
   // minimizer scheme (device tables)
   uint16_t  *d_mrank;     // [1024] rank of every 5-mer under the hashed order
   uint8_t   *d_mbucket;   // [1024] bucket of a minimizer RANK
+  uint8_t   *d_mbucket_pass; // [1024] the same for one group pass of a multi-pass split (0xFF = not now)
   uint8_t    h_mbucket[1024];
 
   // small device scratch (counters, histograms)
@@ -152,7 +153,7 @@ int fkx_split(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int
               void *d_pos = NULL);
 int fkx_split_plan(fk_ctx *ctx, const void *d_bases, int64_t nbytes, int64_t *cap, int64_t *offsets);
 int fkx_split_planned(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int64_t cap,
-                      const int64_t *offsets, int64_t *counts, int64_t *ninst);
+                      const int64_t *offsets, int64_t *counts, int64_t *ninst, int b0 = 0, int b1 = -1);
 int fkx_train_tran(fk_ctx *ctx, const void *d_bases, const int64_t *h_roff, int64_t train_reads,
                    int nthreads, int *tran);
 int fkx_split_exact(fk_ctx *ctx, const void *d_bases, const int64_t *d_roff, int64_t nreads,

@@ -45,6 +45,10 @@ struct SplitArgs
   u32      *overflowed;
   int       tile_stride;    // count mode: visit every tile_stride-th tile only (sampling)
   u64      *pos;            // POS kernels only: (position of the record's first k-mer << 1) | flip per record
+  int64_t   tile0;          // first tile of this launch (a grid holds at most SP_MAXGRID workgroups)
+  u32       skipb;          // super-mers whose bucket entry equals skipb are dropped (0xFF in a group
+                            // pass of a multi-pass split, where mbucket marks the other groups' ranks;
+                            // 0x100 = nothing is dropped)
 };
 
 __device__ __forceinline__ u32 sp_window(const u32 *arr, int off)
@@ -79,7 +83,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
   const int     tid = threadIdx.x;
   const int     K   = a.kmer;
   const int     W   = K - 4;                       // 5-mer starts per k-mer = MAX_SUPER
-  const int64_t t0  = (int64_t) blockIdx.x * a.tile_stride * SP_TILE;
+  const int64_t t0  = (a.tile0 + (int64_t) blockIdx.x) * a.tile_stride * SP_TILE;
   const int     nw  = SP_TILE / 16 + (K + 14) / 16; // words that hold real bases
   const int     R   = nw * 16;                     // bases covered by the packed arrays
   const bool    one = (a.nbuckets == 1);           // single bucket: no per-record LDS atomics
@@ -296,7 +300,10 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
           const u32 key  = mk[c];
           const u32 rank = key >> 15;
           if (!one)
-            atomicAdd(&bcnt[mbucket[rank]], 1u);
+            { const u32 b = mbucket[rank];
+              if (b != a.skipb)
+                atomicAdd(&bcnt[b], 1u);
+            }
           if (EMIT)
             slist[k] = (u32) i | ((key & 1u) << 12) | ((u32) n << 13) | (rank << 20);
           k += 1;
@@ -327,6 +334,8 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
       const int n    = (e >> 13) & 0x7fu;
       const u32 rank = e >> 20;
       const u32 b    = one ? 0u : mbucket[rank];
+      if (b == a.skipb)
+        continue;
       const u64 slot = bbase[b] + (one ? s : atomicAdd(&bcnt2[b], 1u));
       if ((int64_t) slot >= a.cap || (a.limit != NULL && slot >= a.limit[b]))
         { *a.overflowed = 1;
@@ -350,6 +359,19 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
             x |= ((u32) (n - 1)) << lensh;
           dst[q] = __builtin_bswap32(x);
         }
+    }
+}
+
+// A launch covers gridDim.x * blockDim.x < 2^32 work-items: inputs of more than 2^23 tiles (32 G bases)
+// are taken in several launches (a single one silently wraps).
+#define SP_MAXGRID (1 << 23)
+
+template <bool EMIT, bool POS>
+static void sp_launch(SplitArgs a, int64_t ngrid, hipStream_t s)
+{ for (int64_t t = 0; t < ngrid; t += SP_MAXGRID)
+    { a.tile0 = t;
+      const int64_t nb = (ngrid - t < SP_MAXGRID) ? (ngrid - t) : SP_MAXGRID;
+      hipLaunchKernelGGL((k_split<EMIT, POS>), dim3((unsigned) nb), dim3(SP_THREADS), 0, s, a);
     }
 }
 
@@ -398,6 +420,7 @@ int fkx_split(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int
   a.tile_stride = 1;
   a.limit = NULL;
   a.pos = (u64 *) d_pos;
+  a.skipb = 0x100u;
 
   const int64_t nstarts = nbytes - K + 1;
   const int64_t ntiles  = (nstarts + SP_TILE - 1) / SP_TILE;
@@ -406,7 +429,7 @@ int fkx_split(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int
   int64_t tot = 0;
   u64    *base = ctx->h_scratch + 512;          // pinned, so the async upload below is safe
   if (!counts_known)
-    { hipLaunchKernelGGL(k_split<false>, dim3((unsigned) ntiles), dim3(SP_THREADS), 0, s, a);
+    { sp_launch<false, false>(a, ntiles, s);
       FK_LAUNCH_CHECK(ctx);
       FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch, d_counts, 320 * sizeof(u64), hipMemcpyDeviceToHost, s));
       FK_HIP(ctx, hipStreamSynchronize(s));
@@ -439,9 +462,9 @@ int fkx_split(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int
 
   FK_HIP(ctx, hipMemcpyAsync(d_cursor, base, nb * sizeof(u64), hipMemcpyHostToDevice, s));
   if (d_pos != NULL)
-    hipLaunchKernelGGL((k_split<true, true>), dim3((unsigned) ntiles), dim3(SP_THREADS), 0, s, a);
+    sp_launch<true, true>(a, ntiles, s);
   else
-    hipLaunchKernelGGL(k_split<true>, dim3((unsigned) ntiles), dim3(SP_THREADS), 0, s, a);
+    sp_launch<true, false>(a, ntiles, s);
   FK_LAUNCH_CHECK(ctx);
   FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch, d_ovf, sizeof(u32), hipMemcpyDeviceToHost, s));
   FK_HIP(ctx, hipStreamSynchronize(s));
@@ -486,7 +509,7 @@ int fkx_split_fast(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void **d_ou
       a.mbucket = ctx->d_mbucket;
       a.counts = d_counts;
       a.cursor = d_cursor;
-      a.limit = NULL; a.pos = NULL;
+      a.limit = NULL; a.pos = NULL; a.skipb = 0x100u;
       a.overflowed = d_ovf;
       const int64_t nstarts = nbytes - K + 1;
       const int64_t ntiles  = (nstarts + SP_TILE - 1) / SP_TILE;
@@ -494,7 +517,7 @@ int fkx_split_fast(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void **d_ou
       if (ntiles >= 64 * sample)
         { FK_HIP(ctx, hipMemsetAsync(ctx->d_scratch, 0, 1032 * sizeof(u64), s));
           a.out = NULL; a.cap = 0; a.tile_stride = sample;
-          hipLaunchKernelGGL(k_split<false>, dim3((unsigned) (ntiles / sample)), dim3(SP_THREADS), 0, s, a);
+          sp_launch<false, false>(a, ntiles / sample, s);
           FK_LAUNCH_CHECK(ctx);
           FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch, d_counts, sizeof(u64), hipMemcpyDeviceToHost, s));
           FK_HIP(ctx, hipStreamSynchronize(s));
@@ -506,7 +529,7 @@ int fkx_split_fast(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void **d_ou
           cap = ctx->slot_cap[FK_SLOT_SM_A] / stride;          // use the headroom too
           FK_HIP(ctx, hipMemsetAsync(ctx->d_scratch, 0, 1032 * sizeof(u64), s));
           a.out = (u32 *) out; a.cap = cap; a.tile_stride = 1;
-          hipLaunchKernelGGL(k_split<true>, dim3((unsigned) ntiles), dim3(SP_THREADS), 0, s, a);
+          sp_launch<true, false>(a, ntiles, s);
           FK_LAUNCH_CHECK(ctx);
           FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch, ctx->d_scratch, 1032 * sizeof(u64),
                                      hipMemcpyDeviceToHost, s));
@@ -600,12 +623,12 @@ int fkx_split_plan(fk_ctx *ctx, const void *d_bases, int64_t nbytes, int64_t *ca
   a.mbucket = ctx->d_mbucket;
   a.counts = ctx->d_scratch;
   a.cursor = ctx->d_scratch + 512;
-  a.limit = NULL; a.pos = NULL;
+  a.limit = NULL; a.pos = NULL; a.skipb = 0x100u;
   a.out = NULL; a.cap = 0;
   a.overflowed = (u32 *) (ctx->d_scratch + 1024);
   a.tile_stride = sample;
   FK_HIP(ctx, hipMemsetAsync(ctx->d_scratch, 0, 1032 * sizeof(u64), s));
-  hipLaunchKernelGGL(k_split<false>, dim3((unsigned) (ntiles / sample)), dim3(SP_THREADS), 0, s, a);
+  sp_launch<false, false>(a, ntiles / sample, s);
   FK_LAUNCH_CHECK(ctx);
   FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch, ctx->d_scratch, 256 * sizeof(u64), hipMemcpyDeviceToHost, s));
   FK_HIP(ctx, hipStreamSynchronize(s));
@@ -622,30 +645,48 @@ int fkx_split_plan(fk_ctx *ctx, const void *d_bases, int64_t nbytes, int64_t *ca
 
 // Emit into the planned regions; counts[b] receives what bucket b really holds.
 // FK_ESTATE: some region was too small (very uneven input) -- use the exact two-call path.
+// [b0, b1) a proper sub-range of the buckets: a GROUP PASS of a multi-pass split -- only the super-mers
+// of these buckets are emitted (offsets[b0..b1] are their regions in d_out), the others are dropped;
+// *ninst still counts every valid k-mer of the input.
 int fkx_split_planned(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int64_t cap,
-                      const int64_t *offsets, int64_t *counts, int64_t *ninst)
+                      const int64_t *offsets, int64_t *counts, int64_t *ninst, int b0, int b1)
 { hipStream_t s = ctx->stream;
   const int   K = ctx->prm.kmer;
   const int   nb = ctx->prm.nbuckets;
+  if (b1 < 0) b1 = nb;
+  const bool  group = (b0 > 0 || b1 < nb);
   for (int b = 0; b < nb; b++)
     counts[b] = 0;
   *ninst = 0;
   if (nbytes < K)
     return (FK_OK);
-  if (offsets[nb] > cap)
+  if (b0 < 0 || b1 > nb || b0 >= b1 || (group && nb > 255))
+    { fk_set_error(ctx, "planned split: bad bucket range [%d,%d) of %d", b0, b1, nb);
+      return (FK_EINVAL);
+    }
+  if (offsets[b1] > cap)
     { fk_set_error(ctx, "planned split needs %lld records, buffer holds %lld",
-                   (long long) offsets[nb], (long long) cap);
+                   (long long) offsets[b1], (long long) cap);
       return (FK_EINVAL);
     }
   const int64_t nstarts = nbytes - K + 1;
   const int64_t ntiles  = (nstarts + SP_TILE - 1) / SP_TILE;
   u64 *h = ctx->h_scratch + 512;                     // pinned
   for (int b = 0; b < nb; b++)
-    { h[b] = (u64) offsets[b];                       // cursors start at the region starts
-      h[256 + b] = (u64) offsets[b + 1];             // limits
+    { const bool in = (b >= b0 && b < b1);
+      h[b] = in ? (u64) offsets[b] : 0;              // cursors start at the region starts
+      h[256 + b] = in ? (u64) offsets[b + 1] : 0;    // limits
     }
   FK_HIP(ctx, hipMemsetAsync(ctx->d_scratch, 0, 1032 * sizeof(u64), s));
   FK_HIP(ctx, hipMemcpyAsync(ctx->d_scratch + 512, h, 512 * sizeof(u64), hipMemcpyHostToDevice, s));
+  if (group)
+    { uint8_t *hm = (uint8_t *) (ctx->h_scratch + 1040);          // pinned, past the counters
+      for (int r = 0; r < 1024; r++)
+        { const int b = ctx->h_mbucket[r];
+          hm[r] = (uint8_t) ((b >= b0 && b < b1) ? b : 0xFF);
+        }
+      FK_HIP(ctx, hipMemcpyAsync(ctx->d_mbucket_pass, hm, 1024, hipMemcpyHostToDevice, s));
+    }
   SplitArgs a;
   a.bases = (const unsigned char *) d_bases;
   a.nbytes = nbytes;
@@ -654,15 +695,16 @@ int fkx_split_planned(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_
   a.sww = ctx->wid.smer_stride / 4;
   a.nbuckets = nb;
   a.mtab = ctx->d_mrank;
-  a.mbucket = ctx->d_mbucket;
+  a.mbucket = group ? ctx->d_mbucket_pass : ctx->d_mbucket;
   a.counts = ctx->d_scratch;
   a.cursor = ctx->d_scratch + 512;
   a.limit = ctx->d_scratch + 768;
   a.pos = NULL;
+  a.skipb = group ? 0xFFu : 0x100u;
   a.out = (u32 *) d_out; a.cap = cap;
   a.overflowed = (u32 *) (ctx->d_scratch + 1024);
   a.tile_stride = 1;
-  hipLaunchKernelGGL(k_split<true>, dim3((unsigned) ntiles), dim3(SP_THREADS), 0, s, a);
+  sp_launch<true, false>(a, ntiles, s);
   FK_LAUNCH_CHECK(ctx);
   FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch, ctx->d_scratch, 1032 * sizeof(u64), hipMemcpyDeviceToHost, s));
   FK_HIP(ctx, hipStreamSynchronize(s));
@@ -670,7 +712,7 @@ int fkx_split_planned(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_
     { fk_set_error(ctx, "planned split: a bucket region was too small");
       return (FK_ESTATE);
     }
-  for (int b = 0; b < nb; b++)
+  for (int b = b0; b < b1; b++)
     counts[b] = (int64_t) ctx->h_scratch[512 + b] - offsets[b];
   int64_t t = 0;
   for (int x = 0; x < 64; x++)

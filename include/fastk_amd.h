@@ -76,6 +76,13 @@ typedef struct
                               boundaries (Table_Split, count.c:1560-1565) -- byte-identical files
                               whenever the reference would use one bucket (k-mers fit -M);
                               needs fk_push_block (read offsets); ~10x slower split           */
+    int     split_passes;  /* fk_count_device_reads on reads that stay resident, nbuckets > 1: split the
+                              reads this many times, each pass emitting the super-mers of one group of
+                              buckets only, so that 1/split_passes of the super-mer records are in HBM
+                              at a time (the reads are re-read instead of spilling records: the role
+                              of NPARTS when reads + records exceed memory, split.c:617-766).
+                              0 = automatic: 1, or with hbm_budget > 0 as many as it takes for one
+                              pass's records to fit hbm_budget / 2                                   */
   } fk_params;
 
 void fk_default_params(fk_params *p);
@@ -105,6 +112,9 @@ int fk_push_block(fk_ctx *ctx, const char *bases, const int32_t *boff, int nread
    file order by one thread. */
 int fk_train_block(fk_ctx *ctx, const char *bases, const int32_t *boff, int nreads);
 
+/* Drop everything pushed so far (a new data set follows); arenas and buffers are kept. */
+int fk_reset(fk_ctx *ctx);
+
 /* Same, for reads already resident in HBM (any byte that is not acgtACGT separates reads). */
 int fk_push_device(fk_ctx *ctx, const void *d_bases, int64_t nbytes);
 
@@ -126,6 +136,12 @@ typedef struct
     int64_t  ncollapsed;                  /* records left after collapsing grouped weighted k-mers     */
     int      passes_final;                /* digit passes of the final KMER_BYTES sort over ncollapsed */
     double   ms_pass_final;
+    int64_t  launches_super, launches_kmer; /* scatter launches behind ms_scatter_super / _kmer (with
+                                              bucket streaming: passes x buckets)                      */
+    int      split_passes;                /* split passes over the reads (fk_params.split_passes)      */
+    int      buckets_counted;             /* non-empty minimizer buckets counted one after the other   */
+    int64_t  spilled_bytes;               /* super-mer records that went through host memory           */
+    double   ms_table_sort;               /* device time of the table sort (all of its kernels)        */
   } fk_result;
 
 /* Replaces Sorting() + the merge of Merge_Tables() (count.c:1202, table.c:346): runs the

@@ -732,8 +732,8 @@ def test_sharded_path_on_one_gpu_matches_plain_path():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
     for extra in ([], ["--force-shard"]):
-        cmd = [sys.executable, os.path.join(root, "bench.py"), "--genome-mbp", "2", "--steps", "1",
-               "--warmup", "0", "--no-cpu-baseline"] + extra
+        cmd = [sys.executable, os.path.join(root, "bench.py"), "--config", "1", "--genome-mbp", "2", "--steps", "1",
+               "--warmup", "0", "--no-cpu-baseline", "--no-device-leg", "--no-e2e"] + extra
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
         p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
         assert p.returncode == 0, p.stderr[-2000:]
@@ -987,6 +987,43 @@ def test_trained_bucket_assignment_balances_and_keeps_results():
         assert c.max() / c.mean() < 1.12 and c.min() / c.mean() > 0.88   # work, not records, is balanced
         ctx.push_block(bases, boff.astype(np.int32))
         res = ctx.finish()
+        util.check_against_golden(case, res.hist, res.max_inst, res.table)
+
+
+@pytest.mark.parametrize("name,nb,passes", [("synth_illumina_k40_t1_T4", 8, 2), ("synth_illumina_k40_t1_T4", 5, 5),
+                                            ("synth_hifi_k40_t4_T8", 12, 3), ("edge_k40_t1_T4", 7, 2),
+                                            ("synth_illumina_k51_t1_T4", 6, 4)])
+def test_multi_pass_split_over_resident_reads(name, nb, passes):
+    """fk_params.split_passes: the reads stay resident and are split `passes` times, each pass keeping the
+    super-mers of one group of minimizer buckets only (how BASELINE configs[2] fits one GPU: 150 GB of
+    reads + 166 GB of records do not).  Histogram, totals and table must be the reference's."""
+    case, bases, boff = util.load_case(name)
+    with fastk_amd.Context(kmer=case["k"], table_cutoff=case["cutoff"], nthreads=case["T"], nbuckets=nb,
+                           split_passes=passes) as ctx:
+        rd = ctx.alloc(len(bases) + 64).upload(bases)
+        res = ctx.count_device_reads(rd.ptr, len(bases), fetch_table=True)
+        assert 1 < res.split_passes <= passes and res.buckets_counted <= nb
+        util.check_against_golden(case, res.hist, res.max_inst, res.table)
+        one = ctx.count_device_reads(rd.ptr, len(bases), fetch_table=True)      # arena re-use: same again
+        assert np.array_equal(one.hist, res.hist) and np.array_equal(one.table, res.table)
+        assert one.nsuper == res.nsuper and one.ninst == res.ninst
+    with fastk_amd.Context(kmer=case["k"], table_cutoff=case["cutoff"], nthreads=case["T"], nbuckets=nb) as ctx:
+        rd = ctx.alloc(len(bases) + 64).upload(bases)
+        ref = ctx.count_device_reads(rd.ptr, len(bases), fetch_table=False)
+        assert ref.split_passes == 1
+        assert (ref.nsuper, ref.ninst, ref.nweighted, ref.ndistinct) == (res.nsuper, res.ninst, res.nweighted,
+                                                                         res.ndistinct)
+
+
+def test_multi_pass_split_automatic_from_budget():
+    """split_passes = 0 with an hbm_budget: as many passes as it takes for one pass's records to fit
+    half the budget."""
+    case, bases, boff = util.load_case("synth_illumina_k40_t1_T4")
+    with fastk_amd.Context(kmer=40, table_cutoff=case["cutoff"], nthreads=case["T"], nbuckets=16,
+                           hbm_budget=12 << 20) as ctx:
+        rd = ctx.alloc(len(bases) + 64).upload(bases)
+        res = ctx.count_device_reads(rd.ptr, len(bases), fetch_table=True)
+        assert res.split_passes > 1
         util.check_against_golden(case, res.hist, res.max_inst, res.table)
 
 
