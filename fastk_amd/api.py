@@ -280,9 +280,9 @@ class Context:
         self._ck(self.L.fk_push_block(self.h, b.ctypes.data, o.ctypes.data, len(o) - 1, rem, tid))
 
     def bucket_census(self, sample):
-        """sample: uint8 array of reads (host).  Returns the int64[1024] work census per minimizer rank."""
+        """sample: uint8 array of reads (host).  Returns the int64[16384] work census per minimizer rank."""
         a = np.ascontiguousarray(sample, dtype=np.uint8)
-        counts = np.zeros(1024, dtype=np.int64)
+        counts = np.zeros(16384, dtype=np.int64)
         self._ck(self.L.fk_bucket_census(self.h, a.ctypes.data, a.nbytes,
                                          counts.ctypes.data_as(C.POINTER(C.c_int64))))
         return counts

@@ -87,7 +87,8 @@ extern "C" int fk_get_widths(int kmer, fk_widths *w)
     return (FK_EINVAL);
   int v, bits = 0;
   w->kmer       = kmer;
-  w->min_len    = 5;
+  w->min_len    = 5;      // the widths are those of PAD_LEN = 5; the splitter's 7-mer minimizers only make
+                          // super-mers of at most kmer - 6 k-mers, which these records hold
   w->max_super  = kmer - 4;
   for (v = w->max_super; v > 0; v >>= 1)
     bits += 1;
@@ -112,32 +113,25 @@ extern "C" void fk_default_params(fk_params *p)
   p->hbm_budget = 0;
 }
 
-// ---- minimizer order: pseudo-random ranking of the 1024 5-mers, canonical over both strands -----
-static void build_minimizer_tables(uint16_t *mtab, uint8_t *mbucket, int nbuckets)
-{ std::pair<uint64_t, int> order[1024];
-  int rank[1024];
-  for (int v = 0; v < 1024; v++)
-    order[v] = std::make_pair(fk_mix64(0x6b6d6572ull + (uint64_t) v), v);
-  std::sort(order, order + 1024);
-  for (int r = 0; r < 1024; r++)
-    rank[order[r].second] = r;
-  for (int v = 0; v < 1024; v++)
-    { int rc = 0;
-      for (int j = 0; j < 5; j++)
-        rc |= (3 - ((v >> (2 * j)) & 3)) << (2 * (4 - j));
-      const int a = rank[v], b = rank[rc];
-      mtab[v] = (uint16_t) ((std::min(a, b) << 1) | (b < a ? 1 : 0));
-    }
-  // Buckets must carry equal loads (one bucket = one GPU).  A smaller rank wins more windows, so the
-  // load of a rank falls monotonically with its value: deal the canonical ranks (the values that
-  // actually occur as a minimum of a 5-mer and its reverse complement) out in serpentine order.
-  bool used[1024];
-  for (int r = 0; r < 1024; r++)
+// ---- minimizer order: canonical 7-mers ranked by fk_mrank14 ----------------------------------------
+static uint32_t revcomp7(uint32_t v)
+{ uint32_t rc = 0;
+  for (int j = 0; j < FK_MIN_LEN; j++)
+    rc |= (3u - ((v >> (2 * j)) & 3u)) << (2 * (FK_MIN_LEN - 1 - j));
+  return (rc);
+}
+
+static void build_minimizer_tables(uint8_t *mbucket, int nbuckets)
+{ // Buckets must carry equal loads (one bucket = one GPU).  A smaller rank wins more windows, so the
+  // load of a rank falls monotonically with its value: deal the ranks that occur (the images of the
+  // canonical codes) out in serpentine order.
+  static bool used[FK_NRANKS];
+  for (int r = 0; r < FK_NRANKS; r++)
     used[r] = false;
-  for (int v = 0; v < 1024; v++)
-    used[mtab[v] >> 1] = true;
+  for (uint32_t v = 0; v < FK_NRANKS; v++)
+    used[fk_mrank14(std::min(v, revcomp7(v)))] = true;
   int p = 0;
-  for (int r = 0; r < 1024; r++)
+  for (int r = 0; r < FK_NRANKS; r++)
     { mbucket[r] = 0;
       if (!used[r])
         continue;
@@ -149,14 +143,11 @@ static void build_minimizer_tables(uint16_t *mtab, uint8_t *mbucket, int nbucket
 
 // ---- bucket training (the role of Determine_Scheme's trie balancing, split.c:617-766) -----------
 // Host-side, on a sample of reads: how much work each canonical minimizer rank attracts.  counts[r]
-// += 4 * super-mer starts + k-mer instances whose minimizer has rank r.
+// += 4 * super-mer starts + k-mer instances whose minimizer has rank r  (r < FK_NRANKS = 16384).
 extern "C" int fk_bucket_census(fk_ctx *ctx, const char *bases, int64_t nbytes, int64_t *counts)
 { if (ctx == NULL || bases == NULL || counts == NULL || nbytes < 0) return (FK_EINVAL);
-  const int K = ctx->prm.kmer, W = K - 4;
-  uint16_t mtab[1024];
-  uint8_t  mb[1024];
-  build_minimizer_tables(mtab, mb, 1);
-  std::vector<uint32_t> key((size_t) nbytes + 8);      // canonical key of the 5-mer starting at i
+  const int K = ctx->prm.kmer, W = K - (FK_MIN_LEN - 1);
+  std::vector<uint64_t> key((size_t) nbytes + 8);      // (rank, position) of the 7-mer starting at i
   std::vector<int32_t>  bad((size_t) nbytes + 8);      // invalid bases in [0, i)
   uint32_t code = 0;
   int32_t  nbad = 0;
@@ -166,20 +157,21 @@ extern "C" int fk_bucket_census(fk_ctx *ctx, const char *bases, int64_t nbytes, 
       uint32_t x = 0;
       if (c == 'A') x = 0; else if (c == 'C') x = 1; else if (c == 'G') x = 2; else if (c == 'T') x = 3;
       else nbad += 1;
-      code = ((code << 2) | x) & 0x3ffu;
-      if (i >= 4)
-        key[i - 4] = ((uint32_t) (mtab[code] >> 1) << 20) | (uint32_t) ((i - 4) & 0xfffff);
+      code = ((code << 2) | x) & 0x3fffu;
+      if (i >= FK_MIN_LEN - 1)
+        key[i - (FK_MIN_LEN - 1)] = ((uint64_t) fk_mrank14(std::min(code, revcomp7(code))) << 40)
+                                  | (uint64_t) (i - (FK_MIN_LEN - 1));
     }
   bad[nbytes] = nbad;
-  uint32_t prev = 0xffffffffu;
+  uint64_t prev = ~0ull;
   bool     pv = false;
   for (int64_t i = 0; i + K <= nbytes; i++)
     { const bool v = (bad[i + K] == bad[i]);
       if (v)
-        { uint32_t m = 0xffffffffu;
+        { uint64_t m = ~0ull;
           for (int j = 0; j < W; j++)
             m = std::min(m, key[i + j]);
-          const int r = (int) (m >> 20);
+          const int r = (int) (m >> 40);
           counts[r] += 1;
           if (!pv || m != prev)
             counts[r] += 4;
@@ -196,14 +188,14 @@ extern "C" int fk_bucket_census(fk_ctx *ctx, const char *bases, int64_t nbytes, 
 extern "C" int fk_set_bucket_weights(fk_ctx *ctx, const int64_t *counts)
 { if (ctx == NULL || counts == NULL) return (FK_EINVAL);
   const int nb = ctx->prm.nbuckets;
-  std::pair<int64_t, int> order[1024];
-  for (int r = 0; r < 1024; r++)
+  std::vector<std::pair<int64_t, int> > order(FK_NRANKS);
+  for (int r = 0; r < FK_NRANKS; r++)
     order[r] = std::make_pair(-counts[r], r);
-  std::sort(order, order + 1024);
+  std::sort(order.begin(), order.end());
   int64_t load[256];
   for (int b = 0; b < nb; b++)
     load[b] = 0;
-  for (int i = 0; i < 1024; i++)
+  for (int i = 0; i < FK_NRANKS; i++)
     { int best = 0;
       for (int b = 1; b < nb; b++)
         if (load[b] < load[best])
@@ -212,7 +204,7 @@ extern "C" int fk_set_bucket_weights(fk_ctx *ctx, const int64_t *counts)
       load[best] += -order[i].first + 1;
     }
   FK_HIP(ctx, hipSetDevice(ctx->device));
-  FK_HIP(ctx, hipMemcpy(ctx->d_mbucket, ctx->h_mbucket, 1024, hipMemcpyHostToDevice));
+  FK_HIP(ctx, hipMemcpy(ctx->d_mbucket, ctx->h_mbucket, FK_NRANKS, hipMemcpyHostToDevice));
   return (FK_OK);
 }
 
@@ -264,9 +256,9 @@ extern "C" int fk_create(const fk_params *p, fk_ctx **out)
   CK(hipEventCreate(&ctx->ev1));
   CK(hipEventCreate(&ctx->stage_ev[0]));
   CK(hipEventCreate(&ctx->stage_ev[1]));
-  CK(hipMalloc((void **) &ctx->d_mrank, 1024 * sizeof(uint16_t)));
-  CK(hipMalloc((void **) &ctx->d_mbucket, 1024));
-  CK(hipMalloc((void **) &ctx->d_mbucket_pass, 1024));
+  CK(hipMalloc((void **) &ctx->d_mbucket, FK_NRANKS));
+  CK(hipMalloc((void **) &ctx->d_mbucket_pass, FK_NRANKS));
+  CK(hipHostMalloc((void **) &ctx->h_mbucket_pass, FK_NRANKS, hipHostMallocDefault));
   CK(hipMalloc((void **) &ctx->d_scratch, 65536));
   CK(hipHostMalloc((void **) &ctx->h_scratch, 65536 + 32 * 256 * 8, hipHostMallocDefault));
   CK(hipMalloc((void **) &ctx->d_digit_hist, 32 * 256 * sizeof(u64)));
@@ -275,11 +267,8 @@ extern "C" int fk_create(const fk_params *p, fk_ctx **out)
     ctx->chunk_bytes = std::max<int64_t>(ctx->prm.hbm_budget / 32, 64ll << 20);
   if (ctx->prm.hbm_budget > 0)
     ctx->spill_limit = ctx->prm.hbm_budget / 2;     // the other half is a bucket's working set
-  { uint16_t mtab[1024];
-    build_minimizer_tables(mtab, ctx->h_mbucket, ctx->prm.nbuckets);
-    CK(hipMemcpy(ctx->d_mrank, mtab, sizeof(mtab), hipMemcpyHostToDevice));
-    CK(hipMemcpy(ctx->d_mbucket, ctx->h_mbucket, 1024, hipMemcpyHostToDevice));
-  }
+  build_minimizer_tables(ctx->h_mbucket, ctx->prm.nbuckets);
+  CK(hipMemcpy(ctx->d_mbucket, ctx->h_mbucket, FK_NRANKS, hipMemcpyHostToDevice));
 #undef CK
   pthread_mutex_t *m = (pthread_mutex_t *) malloc(sizeof(pthread_mutex_t));
   pthread_mutex_init(m, NULL);
@@ -301,7 +290,8 @@ extern "C" void fk_destroy(fk_ctx *ctx)
   hipSetDevice(ctx->device);
   if (ctx->stream != NULL)
     hipStreamSynchronize(ctx->stream);
-  hipFree(ctx->d_mrank); hipFree(ctx->d_mbucket); hipFree(ctx->d_mbucket_pass); hipFree(ctx->d_scratch);
+  hipFree(ctx->d_mbucket); hipFree(ctx->d_mbucket_pass); hipFree(ctx->d_scratch);
+  if (ctx->h_mbucket_pass) hipHostFree(ctx->h_mbucket_pass);
   if (ctx->h_scratch) hipHostFree(ctx->h_scratch);
   hipFree(ctx->d_digit_hist); hipFree(ctx->d_status); hipFree(ctx->d_ticket);
   hipFree(ctx->d_reads);

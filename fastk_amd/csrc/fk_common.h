@@ -16,6 +16,23 @@ typedef unsigned int       u32;
 
 #define FK_NSLOTS 40
 
+// Minimizers are canonical 7-mers ordered by a bijective mix of their 14-bit code (odd multiplies and
+// xor-shifts are invertible mod 2^14, so distinct 7-mers never tie): FK_NRANKS rank values, of which
+// the 8192 images of canonical codes occur.
+#define FK_MIN_LEN 7
+#define FK_NRANKS  16384
+
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+static inline uint32_t fk_mrank14(uint32_t c)
+{ c = (c * 0x2D51u) & 0x3fffu;
+  c ^= c >> 7;
+  c = (c * 0x1A6Bu) & 0x3fffu;
+  c ^= c >> 6;
+  return (c);
+}
+
 struct fk_chunk
 { void    *ptr;             // records of bucket 0, 1, ... back to back
   int64_t  cnt[256];
@@ -38,10 +55,10 @@ struct fk_ctx
   char       err[512];
 
   // minimizer scheme (device tables)
-  uint16_t  *d_mrank;     // [1024] rank of every 5-mer under the hashed order
-  uint8_t   *d_mbucket;   // [1024] bucket of a minimizer RANK
-  uint8_t   *d_mbucket_pass; // [1024] the same for one group pass of a multi-pass split (0xFF = not now)
-  uint8_t    h_mbucket[1024];
+  uint8_t   *d_mbucket;   // [FK_NRANKS] bucket of a minimizer RANK
+  uint8_t   *d_mbucket_pass; // [FK_NRANKS] the same for one group pass of a multi-pass split (0xFF = not now)
+  uint8_t    h_mbucket[FK_NRANKS];
+  uint8_t   *h_mbucket_pass; // pinned staging of d_mbucket_pass
 
   // small device scratch (counters, histograms)
   u64       *d_scratch;   // 64 KB

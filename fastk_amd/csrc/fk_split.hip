@@ -11,10 +11,16 @@
 //   * the read buffer is treated as one flat byte string; any byte that is not acgtACGT (read
 //     terminators, N, newlines) invalidates the k-mers that cover it -- exactly the k-mers the
 //     reference skips (split.c:1079, 1124-1128, 1323-1330);
-//   * minimizer of a k-mer = smallest canonical 5-mer of its K-4 5-mer starts under a fixed
-//     pseudo-random order, leftmost on ties (min over packed (rank,position) keys);
+//   * minimizer of a k-mer = smallest canonical 7-mer of its K-6 7-mer starts under a fixed
+//     pseudo-random order (a bijective mix of the 14-bit code, fk_mrank14), leftmost on ties (min
+//     over packed (rank,position) keys).  Seven bases, not the reference's initial five: the
+//     smallest 5-mer wins 6.8 % of all windows at k = 40, so no deal of 5-mer ranks can balance
+//     more than ~14 buckets -- the reference pads its heavy minimizers by two bases for the same
+//     reason (refine_tree, split.c:437-472: PAD_LEN 5 -> 7); with 7-mers the heaviest rank holds
+//     0.4 %;
 //   * a super-mer = maximal run of consecutive valid k-mers with the same minimizer POSITION, cut
-//     at tile edges; it holds at most K-4 = MAX_SUPER k-mers, so the record widths are FastK's;
+//     at tile edges; it holds at most K-6 k-mers (MAX_SUPER after one PAD refinement), which the
+//     record widths of K-4 hold;
 //   * the record is reverse-complemented when the minimizer lies on the - strand (split.c:1281),
 //     so the two strands of a locus give byte-identical records;
 //   * bucket = f(minimizer value): equal canonical k-mers always share a bucket.
@@ -35,8 +41,7 @@ struct SplitArgs
   int       smer_bytes;
   int       sww;            // record stride in dwords
   int       nbuckets;
-  const uint16_t *mtab;     // [1024] (canonical rank << 1) | flip
-  const uint8_t  *mbucket;  // [1024] bucket of a canonical rank
+  const uint8_t  *mbucket;  // [FK_NRANKS] bucket of a canonical minimizer rank (global memory: one read per super-mer)
   u64      *counts;         // [nbuckets] records per bucket (count mode)  + [256] = instances
   u64      *cursor;         // [nbuckets] running write cursors (emit mode), pre-set to bucket bases
   const u64 *limit;         // [nbuckets] end of each bucket's region (NULL: only `cap` bounds the output)
@@ -60,6 +65,16 @@ __device__ __forceinline__ u32 sp_window(const u32 *arr, int off)
   return ((u32) (((((u64) hi) << 32) | (u64) lo) >> (32 - 2 * (off & 15))));
 }
 
+// (rank << 15) | flip of a 7-mer: canonical = the smaller of the forward code and its reverse
+// complement (flip = the reverse complement is), rank = fk_mrank14(canonical).  Both arguments may
+// carry garbage above bit 13.
+__device__ __forceinline__ u32 sp_key7(u32 fw, u32 rc)
+{ fw &= 0x3fffu;
+  rc &= 0x3fffu;
+  const u32 flip = (rc < fw) ? 1u : 0u;
+  return ((fk_mrank14(min(fw, rc)) << 15) | flip);
+}
+
 template <bool EMIT, bool POS = false>
 __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
 { __shared__ u32      fwd[SP_WORDS];
@@ -68,31 +83,23 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
   __shared__ uint16_t wpre[SP_WORDS];
   __shared__ u32      keys[SP_KEYS + SP_KEYS / 16 + 1];
   u32 *slist = keys;          // the keys are dead once every thread has its window minima (step 3)
-  // (canonical rank << 15) | flip of every 10-bit 5-mer code; dead after step 2, when the same
-  // 4 KB serve as bbase / bcnt2 / lastkey (LDS per workgroup decides 5 vs 4 workgroups per CU)
-  __shared__ __attribute__((aligned(8))) u32 mtab32[1024];
-  __shared__ uint8_t  mbucket[1024];
+  __shared__ __attribute__((aligned(8))) u32 aux32[1024];     // bbase / bcnt2 / lastkey
   __shared__ uint16_t sbits[SP_THREADS + 16];
   __shared__ uint16_t vbits[SP_THREADS + 16];
   __shared__ u32      bcnt[256];
   __shared__ u32      tmp32[8];
 
-  u64 *bbase   = (u64 *) mtab32;          // [256]
-  u32 *bcnt2   = mtab32 + 512;            // [256]
-  u32 *lastkey = mtab32 + 768;            // [SP_THREADS]
+  u64 *bbase   = (u64 *) aux32;           // [256]
+  u32 *bcnt2   = aux32 + 512;             // [256]
+  u32 *lastkey = aux32 + 768;             // [SP_THREADS]
   const int     tid = threadIdx.x;
   const int     K   = a.kmer;
-  const int     W   = K - 4;                       // 5-mer starts per k-mer = MAX_SUPER
+  const int     W   = K - 6;                       // 7-mer starts per k-mer = longest super-mer
   const int64_t t0  = (a.tile0 + (int64_t) blockIdx.x) * a.tile_stride * SP_TILE;
   const int     nw  = SP_TILE / 16 + (K + 14) / 16; // words that hold real bases
   const int     R   = nw * 16;                     // bases covered by the packed arrays
   const bool    one = (a.nbuckets == 1);           // single bucket: no per-record LDS atomics
 
-  for (int i = tid; i < 1024; i += SP_THREADS)
-    { const u32 m = a.mtab[i];
-      mtab32[i]  = ((m >> 1) << 15) | (m & 1u);
-      mbucket[i] = a.mbucket[i];
-    }
   bcnt[tid] = 0;
 
   // ---- 1. ASCII -> 2-bit codes (MSB first) + invalid masks -------------------------------
@@ -160,12 +167,13 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
   u32 mk[SP_CH];
   { const int q = tid;
     const u64 x = (((u64) fwd[q]) << 32) | (u64) fwd[q + 1];
+    // the reverse complements of the 7-mers at 16q .. 16q+15 lie at rc offsets R-7-(16q+c): 22 bases
+    // from offset 10 of the two rc words nw-q-2, nw-q-1; the one of start c is bits [2c, 2c+14) of them
+    const u64 y = (((u64) rcw[nw - q - 2]) << 32) | (u64) rcw[nw - q - 1];
     u32 kk[SP_CH];
 #pragma unroll
     for (int c = 0; c < 16; c++)
-      { const u32 v = (u32) (x >> (54 - 2 * c)) & 0x3ffu;
-        kk[c] = mtab32[v] | ((u32) (16 * q + c) << 1);
-      }
+      kk[c] = sp_key7((u32) (x >> (50 - 2 * c)), (u32) (y >> (2 * c))) | ((u32) (16 * q + c) << 1);
     if (fastmin)
       { mk[SP_CH - 1] = kk[SP_CH - 1];
 #pragma unroll
@@ -182,12 +190,12 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
   if (16 * (SP_THREADS + tid) < SP_TILE + W)             // the halo blocks past the tile
     { const int q = SP_THREADS + tid;
       const u64 x = (((u64) fwd[q]) << 32) | (u64) fwd[q + 1];
+      const int qr = nw - q - 2;                            // may run off the front for the last halo words
+      const u64 y = (((u64) (qr >= 0 ? rcw[qr] : 0u)) << 32) | (u64) (qr + 1 >= 0 ? rcw[qr + 1] : 0u);
       u32 kk[SP_CH];
 #pragma unroll
       for (int c = 0; c < 16; c++)
-        { const u32 v = (u32) (x >> (54 - 2 * c)) & 0x3ffu;
-          kk[c] = mtab32[v] | ((u32) (16 * q + c) << 1);
-        }
+        kk[c] = sp_key7((u32) (x >> (50 - 2 * c)), (u32) (y >> (2 * c))) | ((u32) (16 * q + c) << 1);
       if (fastmin)
         {
 #pragma unroll
@@ -298,14 +306,14 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
               }
           }
           const u32 key  = mk[c];
-          const u32 rank = key >> 15;
+          u32 b = 0;
           if (!one)
-            { const u32 b = mbucket[rank];
+            { b = a.mbucket[key >> 15];
               if (b != a.skipb)
                 atomicAdd(&bcnt[b], 1u);
             }
           if (EMIT)
-            slist[k] = (u32) i | ((key & 1u) << 12) | ((u32) n << 13) | (rank << 20);
+            slist[k] = (u32) i | ((key & 1u) << 12) | ((u32) n << 13) | (b << 20);
           k += 1;
         }
   }
@@ -332,8 +340,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
       const int i    = e & 0xfffu;
       const u32 flip = (e >> 12) & 1u;
       const int n    = (e >> 13) & 0x7fu;
-      const u32 rank = e >> 20;
-      const u32 b    = one ? 0u : mbucket[rank];
+      const u32 b    = e >> 20;
       if (b == a.skipb)
         continue;
       const u64 slot = bbase[b] + (one ? s : atomicAdd(&bcnt2[b], 1u));
@@ -410,7 +417,6 @@ int fkx_split(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int
   a.smer_bytes = ctx->wid.smer_bytes;
   a.sww = ctx->wid.smer_stride / 4;
   a.nbuckets = nb;
-  a.mtab = ctx->d_mrank;
   a.mbucket = ctx->d_mbucket;
   a.counts = d_counts;
   a.cursor = d_cursor;
@@ -505,8 +511,7 @@ int fkx_split_fast(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void **d_ou
       a.smer_bytes = ctx->wid.smer_bytes;
       a.sww = stride / 4;
       a.nbuckets = 1;
-      a.mtab = ctx->d_mrank;
-      a.mbucket = ctx->d_mbucket;
+          a.mbucket = ctx->d_mbucket;
       a.counts = d_counts;
       a.cursor = d_cursor;
       a.limit = NULL; a.pos = NULL; a.skipb = 0x100u;
@@ -619,7 +624,6 @@ int fkx_split_plan(fk_ctx *ctx, const void *d_bases, int64_t nbytes, int64_t *ca
   a.smer_bytes = ctx->wid.smer_bytes;
   a.sww = ctx->wid.smer_stride / 4;
   a.nbuckets = nb;
-  a.mtab = ctx->d_mrank;
   a.mbucket = ctx->d_mbucket;
   a.counts = ctx->d_scratch;
   a.cursor = ctx->d_scratch + 512;
@@ -680,12 +684,12 @@ int fkx_split_planned(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_
   FK_HIP(ctx, hipMemsetAsync(ctx->d_scratch, 0, 1032 * sizeof(u64), s));
   FK_HIP(ctx, hipMemcpyAsync(ctx->d_scratch + 512, h, 512 * sizeof(u64), hipMemcpyHostToDevice, s));
   if (group)
-    { uint8_t *hm = (uint8_t *) (ctx->h_scratch + 1040);          // pinned, past the counters
-      for (int r = 0; r < 1024; r++)
+    { uint8_t *hm = ctx->h_mbucket_pass;                          // pinned (the previous pass has been waited for)
+      for (int r = 0; r < FK_NRANKS; r++)
         { const int b = ctx->h_mbucket[r];
           hm[r] = (uint8_t) ((b >= b0 && b < b1) ? b : 0xFF);
         }
-      FK_HIP(ctx, hipMemcpyAsync(ctx->d_mbucket_pass, hm, 1024, hipMemcpyHostToDevice, s));
+      FK_HIP(ctx, hipMemcpyAsync(ctx->d_mbucket_pass, hm, FK_NRANKS, hipMemcpyHostToDevice, s));
     }
   SplitArgs a;
   a.bases = (const unsigned char *) d_bases;
@@ -694,7 +698,6 @@ int fkx_split_planned(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_
   a.smer_bytes = ctx->wid.smer_bytes;
   a.sww = ctx->wid.smer_stride / 4;
   a.nbuckets = nb;
-  a.mtab = ctx->d_mrank;
   a.mbucket = group ? ctx->d_mbucket_pass : ctx->d_mbucket;
   a.counts = ctx->d_scratch;
   a.cursor = ctx->d_scratch + 512;

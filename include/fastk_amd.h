@@ -34,6 +34,7 @@ extern "C" {
 #define FK_ESTATE       -6   /* call order violated                            */
 
 #define FK_HIST_BINS  0x8000 /* count.c:1205 counts[0x8000]                    */
+#define FK_MIN_RANKS  16384  /* rank values of the 7-mer minimizers (fk_bucket_census)  */
 
 typedef struct fk_ctx fk_ctx;
 
@@ -268,7 +269,7 @@ int fk_host_free(void *ptr);
 
 /* Bucket training, the role of the trie balancing in Determine_Scheme (split.c:617-766).
    fk_bucket_census: host-side pass over a SAMPLE of reads (any bytes, non-ACGT separates) that adds,
-   per canonical minimizer rank, 4 x super-mer starts + k-mer instances to counts[1024].
+   per canonical minimizer rank, 4 x super-mer starts + k-mer instances to counts[FK_MIN_RANKS].
    fk_set_bucket_weights: deal the ranks to the nbuckets buckets by those weights (longest processing
    time first) instead of the default serpentine deal.  In a sharded run every process must pass the
    same counts (all-reduce the census first).  Results do not depend on the assignment. */
