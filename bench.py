@@ -196,6 +196,9 @@ def device_leg(args, cfg, fastk_amd, ctx_gen, glen, nreads, L, local_rank):
     out = {}
     with fastk_amd.Context(kmer=args.kmer, table_cutoff=cfg["cutoff"], nthreads=4, device=local_rank,
                            nbuckets=max(cfg["buckets"], 1) if budget else 1, hbm_budget=budget) as ctx:
+        for kv in args.debug:
+            key, val = kv.split("=")
+            ctx.debug_set(key, int(val))
         if budget and cfg["buckets"] > 1:
             sample = np.ctypeslib.as_array(C.cast(host, C.POINTER(C.c_uint8)), shape=(min(nbytes, 8 << 20),))
             ctx.set_bucket_weights(ctx.bucket_census(sample))
@@ -206,9 +209,14 @@ def device_leg(args, cfg, fastk_amd, ctx_gen, glen, nreads, L, local_rank):
             for first in range(0, nreads, per_block):
                 n = min(per_block, nreads - first)
                 ctx._ck(lib.fk_push_block(ctx.h, host.value + first * (L + 1), boff.ctypes.data, n, 0, 0))
+            t_push = time.perf_counter() - t0
             res = fastk_amd.api.CResult()
             ctx._ck(lib.fk_finish(ctx.h, C.byref(res)))
             times.append(time.perf_counter() - t0)
+            log(args, "device leg run %d: push %.3f s, finish %.3f s (device ms: split %.0f, super-mers %.0f, expand %.0f, "
+                      "k-mers %.0f, count %.0f, table sort %.0f, total %.0f)" % (
+                rep, t_push, times[-1] - t_push, res.ms_split, res.ms_sort_super, res.ms_expand, res.ms_sort_kmer,
+                res.ms_count, res.ms_table_sort, res.ms_total))
         inst = int(res.ninst)
         out = dict(value=inst / times[-1], unit="k-mers/s", seconds=round(times[-1], 3),
                    first_run_seconds=round(times[0], 3), pin_seconds=round(t_pin, 2),

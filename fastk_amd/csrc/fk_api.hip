@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <vector>
 #include <thread>
+#include <chrono>
 
 static char g_last_error[512] = "";
 
@@ -252,6 +253,8 @@ extern "C" int fk_create(const fk_params *p, fk_ctx **out)
                                                     fk_destroy(ctx); return (FK_EHIP); } } while (0)
   CK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   ctx->own_stream = true;
+  CK(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+  CK(hipEventCreateWithFlags(&ctx->reads_ev, hipEventDisableTiming));
   CK(hipEventCreate(&ctx->ev0));
   CK(hipEventCreate(&ctx->ev1));
   CK(hipEventCreate(&ctx->stage_ev[0]));
@@ -264,9 +267,11 @@ extern "C" int fk_create(const fk_params *p, fk_ctx **out)
   CK(hipMalloc((void **) &ctx->d_digit_hist, 32 * 256 * sizeof(u64)));
   CK(hipMalloc((void **) &ctx->d_ticket, 64 * sizeof(u32)));
   if (ctx->prm.hbm_budget > 0 && !ctx->prm.exact_parts)
-    ctx->chunk_bytes = std::max<int64_t>(ctx->prm.hbm_budget / 32, 64ll << 20);
+    ctx->chunk_bytes = std::min<int64_t>(std::max<int64_t>(ctx->prm.hbm_budget / 32, 64ll << 20), 2ll << 30);
   if (ctx->prm.hbm_budget > 0)
-    ctx->spill_limit = ctx->prm.hbm_budget / 2;     // the other half is a bucket's working set
+    // a quarter of the budget is left for what is alive while a bucket is counted (two read
+    // buffers, a chunk's split output, the bucket's records and weighted k-mers, the growing table)
+    ctx->spill_limit = ctx->prm.hbm_budget - std::max<int64_t>(ctx->prm.hbm_budget / 4, 256ll << 20);
   build_minimizer_tables(ctx->h_mbucket, ctx->prm.nbuckets);
   CK(hipMemcpy(ctx->d_mbucket, ctx->h_mbucket, FK_NRANKS, hipMemcpyHostToDevice));
 #undef CK
@@ -277,17 +282,17 @@ extern "C" int fk_create(const fk_params *p, fk_ctx **out)
   return (FK_OK);
 }
 
-static void free_chunk(fk_chunk *c)
-{ if (c->ptr == NULL) return;
-  if (c->on_host) hipHostFree(c->ptr);
-  else            hipFree(c->ptr);
-  c->ptr = NULL;
-}
+static void free_chunk(fk_ctx *ctx, fk_chunk *c);
+static int  flush_join(fk_ctx *ctx);
+static void rewind_slabs(fk_ctx *ctx);
 
 extern "C" void fk_destroy(fk_ctx *ctx)
 { if (ctx == NULL)
     return;
   hipSetDevice(ctx->device);
+  (void) flush_join(ctx);
+  if (ctx->copy_stream != NULL)
+    hipStreamSynchronize(ctx->copy_stream);
   if (ctx->stream != NULL)
     hipStreamSynchronize(ctx->stream);
   hipFree(ctx->d_mbucket); hipFree(ctx->d_mbucket_pass); hipFree(ctx->d_scratch);
@@ -295,6 +300,9 @@ extern "C" void fk_destroy(fk_ctx *ctx)
   if (ctx->h_scratch) hipHostFree(ctx->h_scratch);
   hipFree(ctx->d_digit_hist); hipFree(ctx->d_status); hipFree(ctx->d_ticket);
   hipFree(ctx->d_reads);
+  hipFree(ctx->d_reads_alt);
+  if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
+  if (ctx->reads_ev) hipEventDestroy(ctx->reads_ev);
   free(ctx->h_prof);
   free(ctx->h_prof_off);
   free(ctx->h_prof_split);
@@ -313,8 +321,15 @@ extern "C" void fk_destroy(fk_ctx *ctx)
   if (ctx->own_stream && ctx->stream != NULL)
     hipStreamDestroy(ctx->stream);
   for (int i = 0; i < ctx->nchunks; i++)
-    free_chunk(&ctx->chunks[i]);
+    free_chunk(ctx, &ctx->chunks[i]);
   free(ctx->chunks);
+  for (int i = 0; i < ctx->nslabs; i++)
+    hipFree(ctx->slabs[i].ptr);
+  free(ctx->slabs);
+  for (int i = 0; i < ctx->nspill; i++)
+    if (ctx->spill_buf[i].ptr != NULL)
+      hipHostFree(ctx->spill_buf[i].ptr);
+  free(ctx->spill_buf);
   if (ctx->h_table) hipHostFree(ctx->h_table);
   free(ctx->acc_res);
   free(ctx->h_roff);
@@ -696,18 +711,27 @@ extern "C" int fk_merge_tables(fk_ctx *ctx, const uint8_t *records, int64_t n, i
 }
 
 // ---- streaming interface ------------------------------------------------------------------------
+// stream that carries the copies into the read buffer: in chunked mode a stream of its own, so that
+// they overlap the split of the previous chunk (which runs on ctx->stream)
+static inline hipStream_t push_stream(fk_ctx *ctx)
+{ return (ctx->chunk_bytes > 0 ? ctx->copy_stream : ctx->stream); }
+
 static int reserve_reads(fk_ctx *ctx, int64_t extra)
 { const int64_t need = ctx->reads_len + extra + 64;
   if (need <= ctx->reads_cap)
     return (FK_OK);
+  hipStream_t ps = push_stream(ctx);
   int64_t ncap = std::max<int64_t>(need, ctx->reads_cap * 2);
   ncap = std::max<int64_t>(ncap, 64ll << 20);
+  if (ctx->chunk_bytes > 0)                      // a chunk's worth at once: no re-allocation while it fills
+    ncap = std::max<int64_t>(ncap, ctx->chunk_bytes + ctx->chunk_bytes / 8 + (64ll << 20));
   char *nbuf = NULL;
   FK_HIP(ctx, hipMalloc((void **) &nbuf, (size_t) ncap));
-  if (ctx->reads_len > 0)
-    { FK_HIP(ctx, hipMemcpyAsync(nbuf, ctx->d_reads, (size_t) ctx->reads_len,
-                                 hipMemcpyDeviceToDevice, ctx->stream));
-      FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->d_reads != NULL)
+    { FK_HIP(ctx, hipStreamSynchronize(ctx->stream));       // device-side pushes write through this one
+      if (ctx->reads_len > 0)
+        FK_HIP(ctx, hipMemcpyAsync(nbuf, ctx->d_reads, (size_t) ctx->reads_len, hipMemcpyDeviceToDevice, ps));
+      FK_HIP(ctx, hipStreamSynchronize(ps));
     }
   if (ctx->d_reads != NULL)
     FK_HIP(ctx, hipFree(ctx->d_reads));
@@ -716,22 +740,108 @@ static int reserve_reads(fk_ctx *ctx, int64_t extra)
   return (FK_OK);
 }
 
-// Split the reads pushed so far into super-mers grouped by bucket, keep those (compacted) as a
-// chunk and forget the reads: with hbm_budget set, the ASCII reads never have to be resident as a
-// whole.  Called with the push lock held.
-static int flush_chunk(fk_ctx *ctx)
+// Pinned host buffer for a spilled chunk: one per chunk, kept in the context and used again by the next
+// run (hipHostMalloc moves ~15 GB/s, slower than the spill copy itself).
+static int spill_acquire(fk_ctx *ctx, int64_t bytes, int *slot)
+{ int best = -1;
+  for (int i = 0; i < ctx->nspill; i++)
+    if (!ctx->spill_buf[i].in_use && ctx->spill_buf[i].cap >= bytes
+        && (best < 0 || ctx->spill_buf[i].cap < ctx->spill_buf[best].cap))
+      best = i;
+  if (best < 0)
+    { for (int i = 0; i < ctx->nspill && best < 0; i++)      // an idle one that is too small: replace it
+        if (!ctx->spill_buf[i].in_use)
+          { hipHostFree(ctx->spill_buf[i].ptr);
+            ctx->spill_buf[i].ptr = NULL;
+            ctx->spill_buf[i].cap = 0;
+            best = i;
+          }
+      if (best < 0)
+        { if (ctx->nspill == ctx->spill_cap)
+            { ctx->spill_cap = ctx->spill_cap * 2 + 16;
+              ctx->spill_buf = (fk_spill_buf *) realloc(ctx->spill_buf, sizeof(fk_spill_buf) * (size_t) ctx->spill_cap);
+              if (ctx->spill_buf == NULL) { ctx->nspill = ctx->spill_cap = 0; return (FK_ENOMEM); }
+            }
+          best = ctx->nspill++;
+          ctx->spill_buf[best].ptr = NULL;
+          ctx->spill_buf[best].cap = 0;
+        }
+      const int64_t want = bytes + bytes / 16 + 4096;
+      if (hipHostMalloc(&ctx->spill_buf[best].ptr, (size_t) want, hipHostMallocDefault) != hipSuccess)
+        { ctx->spill_buf[best].ptr = NULL;
+          return (FK_ENOMEM);
+        }
+      ctx->spill_buf[best].cap = want;
+    }
+  ctx->spill_buf[best].in_use = 1;
+  *slot = best;
+  return (FK_OK);
+}
+
+static void free_chunk(fk_ctx *ctx, fk_chunk *c)
+{ if (c->on_host && c->total > 0)
+    ctx->spill_buf[c->spill_slot].in_use = 0;
+  c->total = 0;                        // (HBM runs live in the slabs, which are rewound as a whole)
+}
+
+static void rewind_slabs(fk_ctx *ctx)
+{ for (int i = 0; i < ctx->nslabs; i++)
+    ctx->slabs[i].used = 0;
+  ctx->chunk_hbm_bytes = 0;
+}
+
+#define FK_SLAB_BYTES (8ll << 30)
+
+// room for `bytes` of records in the HBM store; NULL when that would exceed spill_limit (or HBM)
+static void *slab_alloc(fk_ctx *ctx, int64_t bytes)
+{ bytes = (bytes + 255) & ~255ll;
+  for (int i = 0; i < ctx->nslabs; i++)
+    if (ctx->slabs[i].cap - ctx->slabs[i].used >= bytes)
+      { void *p = ctx->slabs[i].ptr + ctx->slabs[i].used;
+        ctx->slabs[i].used += bytes;
+        ctx->chunk_hbm_bytes += bytes;
+        return (p);
+      }
+  int64_t held = 0;
+  for (int i = 0; i < ctx->nslabs; i++)
+    held += ctx->slabs[i].cap;
+  int64_t cap = std::max<int64_t>(FK_SLAB_BYTES, bytes);
+  if (ctx->spill_limit > 0 && held + cap > ctx->spill_limit)
+    cap = std::max<int64_t>(ctx->spill_limit - held, 0);        // the last slab may be smaller
+  if (cap < bytes)
+    return (NULL);
+  if (ctx->nslabs == ctx->slabs_cap)
+    { ctx->slabs_cap = ctx->slabs_cap * 2 + 16;
+      ctx->slabs = (fk_slab *) realloc(ctx->slabs, sizeof(fk_slab) * (size_t) ctx->slabs_cap);
+      if (ctx->slabs == NULL) { ctx->nslabs = ctx->slabs_cap = 0; return (NULL); }
+    }
+  char *p = NULL;
+  if (hipMalloc((void **) &p, (size_t) cap) != hipSuccess)
+    { (void) hipGetLastError();
+      return (NULL);
+    }
+  fk_slab *sl = &ctx->slabs[ctx->nslabs++];
+  sl->ptr = p; sl->cap = cap; sl->used = bytes;
+  ctx->chunk_hbm_bytes += bytes;
+  return (p);
+}
+
+// Split `len` bytes of reads at `buf` into super-mers grouped by bucket and keep those (compacted)
+// as a chunk: with hbm_budget set, the ASCII reads never have to be resident as a whole.  Runs on
+// ctx->stream; called by the flush helper thread or, with no helper running, by the pushing thread.
+static int flush_buffer(fk_ctx *ctx, const char *buf, int64_t len)
 { const int stride = ctx->wid.smer_stride;
   hipStream_t s = ctx->stream;
-  if (ctx->reads_len == 0)
+  if (len == 0)
     return (FK_OK);
-  FK_HIP(ctx, hipStreamSynchronize(s));
   void   *out = NULL;
   int64_t ns = 0, ni = 0, bc[256], bo[256];
-  int rc = fkx_split_fast(ctx, ctx->d_reads, ctx->reads_len, &out, &ns, &ni, bc, bo);
+  const auto tc0 = std::chrono::steady_clock::now();
+  int rc = fkx_split_fast(ctx, buf, len, &out, &ns, &ni, bc, bo);
   if (rc != FK_OK)
     return (rc);
+  const auto tc1 = std::chrono::steady_clock::now();
   ctx->chunk_ninst += ni;
-  ctx->reads_len = 0;
   if (ns == 0)
     return (FK_OK);
   if (ctx->nchunks == ctx->chunks_cap)
@@ -743,38 +853,110 @@ static int flush_chunk(fk_ctx *ctx)
   memset(c, 0, sizeof(*c));
   if (ctx->nchunks == 0)
     ctx->spilled_bytes = 0;
-  // the chunks stay in HBM up to spill_limit; later ones go to pinned host memory and come back
-  // bucket by bucket when they are counted (inputs whose super-mers alone exceed the HBM budget)
+  // the records stay in HBM (slab store) up to spill_limit; beyond that a chunk goes to pinned host
+  // memory as a whole and comes back bucket by bucket when its buckets are counted
   const int64_t bytes = ns * stride;
-  c->on_host = (ctx->spill_limit > 0 && ctx->chunk_hbm_bytes + bytes > ctx->spill_limit);
+  for (int b = 0; b < ctx->prm.nbuckets; b++)
+    { c->cnt[b] = bc[b];
+      c->run[b] = NULL;
+    }
+  { int b = 0;
+    for (; b < ctx->prm.nbuckets; b++)
+      if (bc[b] > 0 && (c->run[b] = slab_alloc(ctx, bc[b] * stride)) == NULL)
+        break;
+    c->on_host = (b < ctx->prm.nbuckets);
+  }
   if (c->on_host)
-    { if (hipHostMalloc(&c->ptr, (size_t) bytes, hipHostMallocDefault) != hipSuccess)
+    { if (spill_acquire(ctx, bytes, &c->spill_slot) != FK_OK)
         { fk_set_error(ctx, "out of host memory: cannot spill %lld super-mer records of a chunk", (long long) ns);
-          c->ptr = NULL;
           return (FK_ENOMEM);
+        }
+      // (slab room taken for the first buckets of this chunk before the store ran out stays unused)
+      char *h = (char *) ctx->spill_buf[c->spill_slot].ptr;
+      int64_t run = 0;
+      for (int b = 0; b < ctx->prm.nbuckets; b++)
+        { c->run[b] = h + run * stride;
+          run += bc[b];
         }
       ctx->spilled_bytes += bytes;
     }
-  else
-    { if (hipMalloc(&c->ptr, (size_t) bytes) != hipSuccess)
-        { fk_set_error(ctx, "out of HBM: cannot keep %lld super-mer records of a chunk", (long long) ns);
-          c->ptr = NULL;
-          return (FK_ENOMEM);
-        }
-      ctx->chunk_hbm_bytes += bytes;
-    }
   int64_t run = 0;
   for (int b = 0; b < ctx->prm.nbuckets; b++)
-    { c->cnt[b] = bc[b];
-      if (bc[b] > 0)
-        FK_HIP(ctx, hipMemcpyAsync((char *) c->ptr + run * stride, (char *) out + bo[b] * stride,
-                                   (size_t) (bc[b] * stride),
+    { if (bc[b] > 0)
+        FK_HIP(ctx, hipMemcpyAsync(c->run[b], (char *) out + bo[b] * stride, (size_t) (bc[b] * stride),
                                    c->on_host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, s));
       run += bc[b];
     }
   c->total = run;
   ctx->nchunks += 1;
+  const auto tc2 = std::chrono::steady_clock::now();
   FK_HIP(ctx, hipStreamSynchronize(s));
+  if (ctx->dbg_verbose)
+    { const auto tc3 = std::chrono::steady_clock::now();
+      fprintf(stderr, "  chunk %d: %lld bytes of reads -> %lld records%s; split %.1f ms, allocation + copies issued %.1f ms, "
+                      "copies done %.1f ms\n", ctx->nchunks - 1, (long long) len, (long long) ns, c->on_host ? " (host)" : "",
+              std::chrono::duration<double, std::milli>(tc1 - tc0).count(),
+              std::chrono::duration<double, std::milli>(tc2 - tc1).count(),
+              std::chrono::duration<double, std::milli>(tc3 - tc2).count());
+    }
+  return (FK_OK);
+}
+
+// Wait for the flush helper, if one is running; returns its result.
+static int flush_join(fk_ctx *ctx)
+{ if (ctx->flush_thread == NULL)
+    return (FK_OK);
+  std::thread *t = (std::thread *) ctx->flush_thread;
+  t->join();
+  delete t;
+  ctx->flush_thread = NULL;
+  if (ctx->flush_rc != FK_OK)
+    memcpy(ctx->err, ctx->flush_err, sizeof(ctx->err));
+  return (ctx->flush_rc);
+}
+
+// The reads pushed so far become a chunk.  Called with the push lock held.
+//   async: the copies into the buffer were issued on copy_stream (fk_push_block, chunked mode) --
+//          the buffer goes to a helper thread that waits for them and splits it, and the caller goes
+//          on copying into the other buffer;
+//   else:  the split runs here and now.
+static int flush_chunk(fk_ctx *ctx, bool async = false)
+{ int rc = flush_join(ctx);
+  if (rc != FK_OK || ctx->reads_len == 0)
+    return (rc);
+  char   *buf = ctx->d_reads;
+  int64_t len = ctx->reads_len;
+  if (!async)
+    { FK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+      FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      ctx->reads_len = 0;
+      return flush_buffer(ctx, buf, len);
+    }
+  FK_HIP(ctx, hipEventRecord(ctx->reads_ev, ctx->copy_stream));
+  std::swap(ctx->d_reads, ctx->d_reads_alt);
+  std::swap(ctx->reads_cap, ctx->reads_cap_alt);
+  ctx->reads_len = 0;
+  ctx->flush_rc = FK_OK;
+  ctx->flush_thread = new std::thread([ctx, buf, len]()
+    { int r = FK_EHIP;
+      if (hipSetDevice(ctx->device) == hipSuccess
+          && hipStreamWaitEvent(ctx->stream, ctx->reads_ev, 0) == hipSuccess)
+        r = flush_buffer(ctx, buf, len);
+      if (r != FK_OK)
+        memcpy(ctx->flush_err, ctx->err, sizeof(ctx->flush_err));
+      ctx->flush_rc = r;
+    });
+  return (FK_OK);
+}
+
+// fk_push_device / _fastq / _fasta write the read buffer through ctx->stream: no flush helper may be
+// running on it, and earlier host blocks must have landed.  Called with the push lock held.
+static int device_push_begin(fk_ctx *ctx)
+{ int rc = flush_join(ctx);
+  if (rc != FK_OK)
+    return (rc);
+  if (ctx->chunk_bytes > 0)
+    FK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
   return (FK_OK);
 }
 
@@ -790,8 +972,28 @@ extern "C" int fk_push_block(fk_ctx *ctx, const char *bases, const int32_t *boff
     { hipSetDevice(ctx->device);
       if ((rc = reserve_reads(ctx, len)) != FK_OK)
         break;
+      hipStream_t ps = push_stream(ctx);
+      // blocks that lie in pinned host memory are copied from where they are
+      bool direct = false;
+      if (!ctx->prm.exact_parts && ctx->prm.bc_prefix == 0)
+        { hipPointerAttribute_t at;
+          if (hipPointerGetAttributes(&at, bases) == hipSuccess)
+            direct = (at.type == hipMemoryTypeHost);
+          else
+            (void) hipGetLastError();
+        }
+      if (direct)
+        { if (hipMemcpyAsync(ctx->d_reads + ctx->reads_len, bases + boff[0], (size_t) len, hipMemcpyHostToDevice,
+                             ps) != hipSuccess)
+            { fk_set_error(ctx, "fk_push_block: host to device copy failed");
+              rc = FK_EHIP;
+              break;
+            }
+          if (hipStreamSynchronize(ps) != hipSuccess)      // the caller may reuse the block once we return
+            { rc = FK_EHIP; break; }                       // (the split of the previous chunk overlaps anyway)
+        }
       const int si = ctx->stage_idx;
-      if (ctx->stage_cap < len)
+      if (!direct && ctx->stage_cap < len)
         { for (int i = 0; i < 2; i++)
             { if (ctx->h_stage[i])
                 { hipEventSynchronize(ctx->stage_ev[i]);
@@ -809,10 +1011,11 @@ extern "C" int fk_push_block(fk_ctx *ctx, const char *bases, const int32_t *boff
           if (rc != FK_OK)
             break;
         }
-      if (hipEventSynchronize(ctx->stage_ev[si]) != hipSuccess)
+      if (!direct && hipEventSynchronize(ctx->stage_ev[si]) != hipSuccess)
         { rc = FK_EHIP; break; }
       char *st = ctx->h_stage[si];
-      memcpy(st, bases + boff[0], (size_t) len);
+      if (!direct)
+        memcpy(st, bases + boff[0], (size_t) len);
       if (ctx->prm.exact_parts)
         { if (ctx->nroff + nreads + 1 > ctx->roff_cap)
             { ctx->roff_cap = std::max<int64_t>(ctx->nroff + nreads + 1, ctx->roff_cap * 2 + 1024);
@@ -829,15 +1032,16 @@ extern "C" int fk_push_block(fk_ctx *ctx, const char *bases, const int32_t *boff
             for (int64_t j = o; j < e && j < o + ctx->prm.bc_prefix; j++)
               st[j] = 'N';                 // not a base, and not a read terminator either (profiles)
           }
-      if (hipMemcpyAsync(ctx->d_reads + ctx->reads_len, st, (size_t) len, hipMemcpyHostToDevice,
-                         ctx->stream) != hipSuccess
-          || hipEventRecord(ctx->stage_ev[si], ctx->stream) != hipSuccess)
-        { fk_set_error(ctx, "fk_push_block: host to device copy failed");
-          rc = FK_EHIP;
-          break;
+      if (!direct)
+        { if (hipMemcpyAsync(ctx->d_reads + ctx->reads_len, st, (size_t) len, hipMemcpyHostToDevice, ps) != hipSuccess
+              || hipEventRecord(ctx->stage_ev[si], ps) != hipSuccess)
+            { fk_set_error(ctx, "fk_push_block: host to device copy failed");
+              rc = FK_EHIP;
+              break;
+            }
+          ctx->stage_idx ^= 1;
         }
       ctx->reads_len += len;
-      ctx->stage_idx ^= 1;
       if (ctx->nblocks == ctx->blocks_cap)
         { ctx->blocks_cap = ctx->blocks_cap * 2 + 256;
           ctx->blocks = (fk_block *) realloc(ctx->blocks, sizeof(fk_block) * (size_t) ctx->blocks_cap);
@@ -848,7 +1052,7 @@ extern "C" int fk_push_block(fk_ctx *ctx, const char *bases, const int32_t *boff
       ctx->blocks[ctx->nblocks].nreads = nreads;
       ctx->nblocks += 1;
       if (ctx->chunk_bytes > 0 && ctx->reads_len >= ctx->chunk_bytes)
-        rc = flush_chunk(ctx);
+        rc = flush_chunk(ctx, true);
     }
   while (0);
   pthread_mutex_unlock((pthread_mutex_t *) ctx->push_lock);
@@ -889,7 +1093,7 @@ extern "C" int fk_push_device(fk_ctx *ctx, const void *d_bases, int64_t nbytes)
   ctx->blocks_bad = true;
   int rc;
   pthread_mutex_lock((pthread_mutex_t *) ctx->push_lock);
-  if ((rc = reserve_reads(ctx, nbytes + 1)) == FK_OK)
+  if ((rc = device_push_begin(ctx)) == FK_OK && (rc = reserve_reads(ctx, nbytes + 1)) == FK_OK)
     { if (hipMemcpyAsync(ctx->d_reads + ctx->reads_len, d_bases, (size_t) nbytes,
                          hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess
           || hipMemsetAsync(ctx->d_reads + ctx->reads_len + nbytes, 0, 1, ctx->stream) != hipSuccess)
@@ -922,7 +1126,7 @@ extern "C" int fk_push_fastq(fk_ctx *ctx, const char *raw, int64_t nbytes, int f
   pthread_mutex_lock((pthread_mutex_t *) ctx->push_lock);
   do
     { hipSetDevice(ctx->device);
-      if ((rc = reserve_reads(ctx, nbytes + 16)) != FK_OK)
+      if ((rc = device_push_begin(ctx)) != FK_OK || (rc = reserve_reads(ctx, nbytes + 16)) != FK_OK)
         break;
       void *d_raw = fk_slot(ctx, FK_SLOT_RAW, nbytes + 64);
       if (d_raw == NULL) { rc = FK_ENOMEM; break; }
@@ -965,7 +1169,7 @@ extern "C" int fk_push_fasta(fk_ctx *ctx, const char *raw, int64_t nbytes, int l
   pthread_mutex_lock((pthread_mutex_t *) ctx->push_lock);
   do
     { hipSetDevice(ctx->device);
-      if ((rc = reserve_reads(ctx, nbytes + 16)) != FK_OK)
+      if ((rc = device_push_begin(ctx)) != FK_OK || (rc = reserve_reads(ctx, nbytes + 16)) != FK_OK)
         break;
       int64_t kept = 0, nr = 0;
       if (nbytes > 0)
@@ -1487,11 +1691,8 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
           int64_t run = 0;
           for (int c = 0; c < ctx->nchunks; c++)
             { const fk_chunk *ch = &ctx->chunks[c];
-              int64_t off = 0;
-              for (int x = 0; x < b; x++)
-                off += ch->cnt[x];
               if (ch->cnt[b] > 0
-                  && hipMemcpyAsync(g + run * w.smer_stride, (char *) ch->ptr + off * w.smer_stride,
+                  && hipMemcpyAsync(g + run * w.smer_stride, ch->run[b],
                                     (size_t) (ch->cnt[b] * w.smer_stride),
                                     ch->on_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, s)
                      != hipSuccess)
@@ -1634,6 +1835,13 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
 extern "C" int fk_finish(fk_ctx *ctx, fk_result *res)
 { if (ctx == NULL || res == NULL) return (FK_EINVAL);
   FK_HIP(ctx, hipSetDevice(ctx->device));
+  { pthread_mutex_lock((pthread_mutex_t *) ctx->push_lock);
+    int rc = flush_join(ctx);
+    pthread_mutex_unlock((pthread_mutex_t *) ctx->push_lock);
+    if (rc != FK_OK)
+      return (rc);
+  }
+  FK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
   FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (ctx->nchunks > 0)
     { // chunked ingest: the rest of the reads becomes the last chunk, then the buckets are counted
@@ -1643,9 +1851,9 @@ extern "C" int fk_finish(fk_ctx *ctx, fk_result *res)
       if (rc == FK_OK)
         rc = fkx_pipeline(ctx, NULL, 0, NULL, 0, res, true);
       for (int i = 0; i < ctx->nchunks; i++)
-        free_chunk(&ctx->chunks[i]);
+        free_chunk(ctx, &ctx->chunks[i]);
       ctx->nchunks = 0;
-      ctx->chunk_hbm_bytes = 0;
+      rewind_slabs(ctx);
       ctx->chunk_ninst = 0;
       return (rc);
     }
@@ -1668,16 +1876,18 @@ extern "C" int fk_finish(fk_ctx *ctx, fk_result *res)
 extern "C" int fk_reset(fk_ctx *ctx)
 { if (ctx == NULL) return (FK_EINVAL);
   FK_HIP(ctx, hipSetDevice(ctx->device));
-  FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   pthread_mutex_lock((pthread_mutex_t *) ctx->push_lock);
+  (void) flush_join(ctx);
+  hipStreamSynchronize(ctx->copy_stream);
+  hipStreamSynchronize(ctx->stream);
   ctx->reads_len = 0;
   ctx->nblocks = 0;
   ctx->blocks_bad = false;
   ctx->nroff = 0;
   for (int i = 0; i < ctx->nchunks; i++)
-    free_chunk(&ctx->chunks[i]);
+    free_chunk(ctx, &ctx->chunks[i]);
   ctx->nchunks = 0;
-  ctx->chunk_hbm_bytes = 0;
+  rewind_slabs(ctx);
   ctx->chunk_ninst = 0;
   pthread_mutex_unlock((pthread_mutex_t *) ctx->push_lock);
   return (FK_OK);

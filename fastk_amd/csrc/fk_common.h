@@ -34,10 +34,25 @@ static inline uint32_t fk_mrank14(uint32_t c)
 }
 
 struct fk_chunk
-{ void    *ptr;             // records of bucket 0, 1, ... back to back
+{ void    *run[256];        // records of bucket b: cnt[b] of them at run[b] (HBM slab or pinned host buffer)
   int64_t  cnt[256];
   int64_t  total;
   int      on_host;         // records live in pinned host memory (spilled), not in HBM
+  int      spill_slot;      // on_host: index into fk_ctx.spill_buf
+};
+
+// HBM store of the chunks' records: large slabs filled by bump allocation, kept until fk_destroy and
+// filled again from the start by the next run (allocating and freeing a buffer per chunk instead
+// stalled for seconds inside hipMalloc once the address space had been through one run)
+struct fk_slab
+{ char    *ptr;
+  int64_t  cap, used;
+};
+
+struct fk_spill_buf         // pinned host buffer for one spilled chunk, kept for the next run
+{ void    *ptr;
+  int64_t  cap;
+  int      in_use;
 };
 
 struct fk_block       // one fk_push_block call: which input thread, how many reads
@@ -74,6 +89,19 @@ struct fk_ctx
   // streaming interface state
   char      *d_reads;      // pushed reads (HBM)
   int64_t    reads_len, reads_cap;
+  // chunked ingest: host-to-device copies run on copy_stream into one of two read buffers while the
+  // other one is split into super-mers by a helper thread on `stream`
+  hipStream_t copy_stream;
+  hipEvent_t  reads_ev;     // all copies into the buffer handed to the helper have been issued before it
+  char      *d_reads_alt;   // the idle read buffer (NULL until first needed)
+  int64_t    reads_cap_alt;
+  void      *flush_thread;  // std::thread * of the running flush, NULL if none
+  int        flush_rc;      // its result
+  char       flush_err[512];
+  struct fk_slab *slabs;
+  int        nslabs, slabs_cap;
+  struct fk_spill_buf *spill_buf;
+  int        nspill, spill_cap;
   char      *h_stage[2];   // pinned staging for fk_push_block
   int64_t    stage_cap;
   int        stage_idx;

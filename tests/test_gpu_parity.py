@@ -1020,7 +1020,7 @@ def test_multi_pass_split_automatic_from_budget():
     half the budget."""
     case, bases, boff = util.load_case("synth_illumina_k40_t1_T4")
     with fastk_amd.Context(kmer=40, table_cutoff=case["cutoff"], nthreads=case["T"], nbuckets=16,
-                           hbm_budget=12 << 20) as ctx:
+                           hbm_budget=6 << 20) as ctx:
         rd = ctx.alloc(len(bases) + 64).upload(bases)
         res = ctx.count_device_reads(rd.ptr, len(bases), fetch_table=True)
         assert res.split_passes > 1
