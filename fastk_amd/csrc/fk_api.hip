@@ -219,10 +219,11 @@ extern "C" int fk_create(const fk_params *p, fk_ctx **out)
   ctx->prm = *p;
   if (ctx->prm.nbuckets < 1) ctx->prm.nbuckets = 1;
   if (ctx->prm.nthreads < 1) ctx->prm.nthreads = 1;
-  if (ctx->prm.nbuckets > 256 || fk_get_widths(p->kmer, &ctx->wid) != FK_OK || p->kmer > 128
+  if (ctx->prm.nbuckets > 256 || fk_get_widths(p->kmer, &ctx->wid) != FK_OK || p->kmer > 64
       || p->kmer < 8)
-    { fk_set_error(NULL, "fk_create: unsupported parameters (k=%d nbuckets=%d)", p->kmer,
-                   p->nbuckets);
+    { fk_set_error(NULL, "fk_create: unsupported parameters (k=%d nbuckets=%d): k from 8 to 64 (the expansion "
+                         "and counting kernels are built for k-mers of up to four 32-bit words), at most 256 buckets",
+                   p->kmer, p->nbuckets);
       free(ctx);
       return (FK_EINVAL);
     }

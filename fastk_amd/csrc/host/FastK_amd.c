@@ -53,7 +53,7 @@ static double now(void)
   return (tv.tv_sec + 1e-6*tv.tv_usec);
 }
 
-static int       KMER = 40, NTHREADS = 4, DO_TABLE = 0, BC_PREFIX = 0, VERBOSE = 0, EXACT = 0, MEM_GB = 0;
+static int       KMER = 40, NTHREADS = 4, DO_TABLE = 0, BC_PREFIX = 0, VERBOSE = 0, EXACT = 0, MEM_GB = 0, NGPUS = 1;
 static int       HOST_PARSE = 0, COMPRESS = 0, PROFILE = 0;
 static char     *PRO_NAME = NULL;
 static char     *OUT_NAME = NULL;
@@ -489,40 +489,82 @@ int main(int argc, char *argv[])
   char      *root = NULL, *dir = NULL, name[4096];
   int        i, j, nfiles, ftype = -1;
 
-  for (i = j = 1; i < argc; i++)
-    if (argv[i][0] == '-')
-      switch (argv[i][1])
-      { case 'k': KMER = atoi(argv[i]+2); break;
-        case 'T': NTHREADS = atoi(argv[i]+2); break;
-        case 't': DO_TABLE = (argv[i][2] == '\0') ? 1 : atoi(argv[i]+2); break;
-        case 'b':
-          if (argv[i][2] != 'c')
-            { fprintf(stderr,"\n%s: -%s is not a legal optional argument\n",Prog_Name,argv[i]); exit (1); }
-          BC_PREFIX = atoi(argv[i]+3);
-          break;
-        case 'v': VERBOSE = 1; break;
-        case 'x': EXACT = 1; break;
-        case 'H': HOST_PARSE = 1; break;       /* extension: parse FASTQ on the host as well */
-        case 'N': OUT_NAME = argv[i]+2; break;
-        case 'M': MEM_GB = atoi(argv[i]+2); break;
-        case 'P': break;
-        case 'c': COMPRESS = 1; break;
-        case 'p':
-          if (argv[i][2] == ':')
-            PRO_NAME = argv[i]+3;          /* profiles relative to this table, FastK.c:270-282 */
-          else if (argv[i][2] != '\0')
-            { fprintf(stderr,"\n%s: %s is not a legal optional argument\n",Prog_Name,argv[i]);
-              exit (1);
+  /* Option rules of the reference (FastK.c:250-319 with ARG_FLAGS / ARG_POSITIVE / ARG_NON_NEGATIVE of
+     gene_core.h:37-70): the letters v c p t combine in one argument (-vt, -tp); -t<int>, -k, -T, -M,
+     -bc take a whole decimal number or the run ends with the reference's message.  -x and -H are this
+     driver's own flags and combine with the reference's. */
+  { int flags[128], k, g;
+    memset(flags,0,sizeof(flags));
+    for (i = j = 1; i < argc; i++)
+      if (argv[i][0] == '-')
+        { int   isflags = 0;
+          char *num = NULL, *what = NULL;
+          int  *var = NULL, nonneg = 0;
+          switch (argv[i][1])
+          { case 'k': num = argv[i]+2; var = &KMER; what = "K-mer length"; break;
+            case 'T': num = argv[i]+2; var = &NTHREADS; what = "Number of threads"; break;
+            case 'M': num = argv[i]+2; var = &MEM_GB; what = "GB of memory for sorting step"; break;
+            case 'G': num = argv[i]+2; var = &NGPUS; what = "Number of GPUs"; break;
+            case 'b':
+              if (argv[i][2] != 'c')
+                { fprintf(stderr,"\n%s: -%s is not a legal optional argument\n",Prog_Name,argv[i]); exit (1); }
+              num = argv[i]+3; var = &BC_PREFIX; what = "Bar code prefiex"; nonneg = 1;
+              break;
+            case 't':
+              if (argv[i][2] == '\0' || isalpha((unsigned char) argv[i][2]))
+                isflags = 1;
+              else
+                { num = argv[i]+2; var = &DO_TABLE; what = "Cutoff for k-mer table"; }
+              break;
+            case 'p':
+              if (argv[i][2] == ':')
+                { PRO_NAME = argv[i]+3;      /* profiles relative to this table, FastK.c:270-282 */
+                  PROFILE  = 1;
+                }
+              else
+                isflags = 1;
+              break;
+            case 'N': OUT_NAME = argv[i]+2; break;
+            case 'P': break;
+            default:  isflags = 1; break;
+          }
+          if (num != NULL)
+            { char *eptr;
+              long  v = strtol(num,&eptr,10);
+              if (*eptr != '\0' || num[0] == '\0')
+                { fprintf(stderr,"%s: -%c '%s' argument is not an integer\n",Prog_Name,argv[i][1],argv[i]+2);
+                  exit (1);
+                }
+              if (nonneg ? (v < 0) : (v <= 0))
+                { fprintf(stderr,"%s: %s must be %s (%ld)\n",Prog_Name,what,nonneg ? "non-negative" : "positive",v);
+                  exit (1);
+                }
+              *var = (int) v;
             }
-          PROFILE = 1;
-          break;
-        default:
-          fprintf(stderr,"\n%s: %s is not a legal optional argument\n",Prog_Name,argv[i]);
-          exit (1);
-      }
-    else
-      argv[j++] = argv[i];
+          if (isflags)
+            for (k = 1; argv[i][k] != '\0'; k++)
+              { if (strchr("vcptxH",argv[i][k]) == NULL)
+                  { fprintf(stderr,"%s: -%c is an illegal option\n",Prog_Name,argv[i][k]);
+                    exit (1);
+                  }
+                flags[(int) argv[i][k]] = 1;
+              }
+        }
+      else
+        argv[j++] = argv[i];
+    VERBOSE    = flags['v'];
+    COMPRESS   = flags['c'];
+    EXACT      = flags['x'];
+    HOST_PARSE = flags['H'];
+    if (flags['t']) DO_TABLE = 1;
+    if (flags['p']) PROFILE = 1;
+    (void) g;
+  }
   nfiles = j-1;
+  if (KMER > 64 || KMER < 8)         /* the device expansion is built for k-mers of up to four 32-bit words */
+    { fprintf(stderr,"%s: K-mer length must be between 8 and 64 in this engine (%d)\n",Prog_Name,KMER);
+      exit (1);
+    }
   if (nfiles < 1 || KMER <= 0 || NTHREADS <= 0 || DO_TABLE < 0 || BC_PREFIX < 0)
     { fprintf(stderr,"\nUsage: %s [-k<int(40)>] [-t[<int(1)>]] [-p[:<table>[.ktab]]] [-c] [-bc<int>] [-v] [-x] [-N<path_name>]\n",Prog_Name);
       fprintf(stderr,"       %*s [-P<dir>] [-M<int>] [-T<int(4)>] <source>[.fa|.fasta|.fq|.fastq][.gz]|.sam|.bam ...\n",

@@ -25,6 +25,16 @@ class HipEngine:
         self.ctx = ctx
         self.device = device
         self.stride = ctx.w.smer_stride
+        # The library launches on the context's stream, torch and RCCL order their work against torch's
+        # current stream: bind the two, so that an exchange (w.wait() only orders torch's current
+        # stream) is complete before a stage kernel reads the inbox, and a stage is complete before
+        # torch reuses its output.  Contract for callers: keep this device's current stream unchanged
+        # for the life of the engine, or call bind_stream() again after switching.
+        self.bind_stream()
+
+    def bind_stream(self):
+        if isinstance(self.device, torch.device) and self.device.type == "cuda":
+            self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
 
     def train_buckets(self, reads, group=None, sample_bytes=2 << 20):
         """Balance the buckets (= ranks) on a sample of the reads: every rank takes a census of the
@@ -258,9 +268,10 @@ def gather_table(table, kmer_bytes, sort_fn, group=None, dst=0):
     sizes = [int(x) for x in sizes.tolist()]
     mine = torch.from_numpy(np.ascontiguousarray(table).reshape(-1)).to(dev)
     per = max(1, MAX_PAIR_BYTES // kw) * kw
+    gdst = dist.get_global_rank(group, dst) if group is not None else dst
     if rank != dst:
         for o in range(0, mine.numel(), per):
-            dist.send(mine[o:o + per], dst, group=group)
+            dist.send(mine[o:o + per], gdst, group=group)
         return None
     parts = []
     for r in range(world):
@@ -268,8 +279,9 @@ def gather_table(table, kmer_bytes, sort_fn, group=None, dst=0):
             parts.append(mine)
             continue
         buf = torch.empty(sizes[r] * kw, dtype=torch.uint8, device=dev)
+        gsrc = dist.get_global_rank(group, r) if group is not None else r
         for o in range(0, buf.numel(), per):
-            dist.recv(buf[o:o + per], r, group=group)
+            dist.recv(buf[o:o + per], gsrc, group=group)
         parts.append(buf)
     merged = torch.cat(parts).cpu().numpy().reshape(-1, kw)
     return sort_fn(merged) if world > 1 else merged

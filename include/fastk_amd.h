@@ -56,7 +56,7 @@ int fk_get_widths(int kmer, fk_widths *w);
 
 /* Options that exist on FastK's command line (FastK.c:34-37,250-319). */
 typedef struct
-  { int     kmer;          /* -k (default 40)                                            */
+  { int     kmer;          /* -k (default 40); 8 <= kmer <= 64, fk_create rejects anything else   */
     int     table_cutoff;  /* -t<n>: 0 = no table, else keep k-mers with count >= n      */
     int     nthreads;      /* -T: number of .ktab parts / first-byte ranges in outputs   */
     int     bc_prefix;     /* -bc<n>: ignore this many leading bases of every read       */

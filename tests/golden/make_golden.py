@@ -83,14 +83,40 @@ CASES = [
 ]
 
 
+# Digest-only cases above fixture size (no table file, no profiles): BASELINE.json configs[0] exactly
+# (1 M x 150 bp reads of a 10 Mbp genome, 0.1 % errors, FASTQ, -k40 -t1 -T4) and the two bounded
+# samples bench.py times the reference on (50x of a 20 Mbp genome, Illumina- and HiFi-shaped).
+# `python tests/golden/make_golden.py --large` regenerates only these (minutes of reference time).
+LARGE_CASES = [
+    dict(name="configs0_k40_t1_T4", kind="large", k=40, cutoff=1, T=4, fmt="fastq",
+         synth=dict(seed=20251001, genome_len=10000000, read_len=150, err_ppm=1000, nreads=1000000)),
+    dict(name="illumina50x20M_k40_t1_T4", kind="large", k=40, cutoff=1, T=4, fmt="fastq",
+         synth=dict(seed=20251001, genome_len=20000000, read_len=150, err_ppm=1000, nreads=6666666)),
+    dict(name="hifi50x20M_k40_t4_T4", kind="large", k=40, cutoff=4, T=4, fmt="fasta",
+         synth=dict(seed=20251001, genome_len=20000000, read_len=15000, err_ppm=2000, nreads=66666)),
+]
+
+
 def sha(b):
     return hashlib.sha256(b).hexdigest()
+
+
+def sha_file(path):
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        while True:
+            b = f.read(1 << 24)
+            if not b:
+                break
+            h.update(b)
+    return h.hexdigest()
 
 
 def main():
     if not orc.have_ref():
         orc.build(ref=True)
-    for case in CASES:
+    cases = LARGE_CASES if "--large" in sys.argv else (CASES + LARGE_CASES if "--all" in sys.argv else CASES)
+    for case in cases:
         name = case["name"]
         k = case["k"]
         if case["kind"] == "edge":
@@ -124,8 +150,17 @@ def main():
                       first=[t["table"][i].tobytes().hex() for i in range(min(8, t["nels"]))],
                       last=[t["table"][i].tobytes().hex()
                             for i in range(max(0, t["nels"] - 8), t["nels"])]),
-            file_sha256={f: sha(open(os.path.join(d, f), "rb").read()) for f in files},
+            file_sha256={f: sha_file(os.path.join(d, f)) for f in files},
         )
+        if case["kind"] == "large":
+            meta = dict(case)
+            meta["expected"] = exp
+            meta["generated_by"] = "tests/golden/make_golden.py --large with oracle/_ref/FastK (reference build)"
+            with open(os.path.join(HERE, name + ".json"), "w") as f:
+                json.dump(meta, f, indent=1, sort_keys=True)
+            shutil.rmtree(d)
+            print(name, "nels", t["nels"], "parts", t["part_sizes"], "ihigh", h["ihigh"])
+            continue
         # profiles: the reference's -p run (own directory, same input); what is pinned is the DECODED
         # count vectors (the reference's bytes depend on its internal super-mer cuts)
         pd = tempfile.mkdtemp(prefix="fkgoldp")

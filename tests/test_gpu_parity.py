@@ -1027,6 +1027,122 @@ def test_multi_pass_split_automatic_from_budget():
         util.check_against_golden(case, res.hist, res.max_inst, res.table)
 
 
+# ------------------------------------------------------------------------------ above fixture size
+# Digest-only golden cases made by the reference (tests/golden/make_golden.py --large): BASELINE.json
+# configs[0] at its stated size and the two samples bench.py times the reference on.
+
+LARGE = ["configs0_k40_t1_T4", "hifi50x20M_k40_t4_T4", "illumina50x20M_k40_t1_T4"]
+
+
+def _push_in_pieces(ctx, bases, boff, pieces):
+    nreads = len(boff) - 1
+    step = max(1, (nreads + pieces - 1) // pieces)
+    for s0 in range(0, nreads, step):
+        e = min(nreads, s0 + step)
+        ctx.push_block(bases[boff[s0]:boff[e]], (boff[s0:e + 1] - boff[s0]).astype(np.int32))
+
+
+@pytest.mark.parametrize("name", LARGE)
+def test_reference_digests_above_fixture_size(name, tmp_path):
+    """Library path against the reference's digests at BASELINE configs[0] size and above: the default
+    pipeline (position-parallel split, hash aggregation; resident and bucket-streamed with a budget)
+    must give the reference's .hist bytes and .ktab canonical stream, and exact_parts every file."""
+    case, bases, boff = util.load_case(name)
+    k, T, cutoff = case["k"], case["T"], case["cutoff"]
+    with fastk_amd.Context(kmer=k, table_cutoff=cutoff, nthreads=T) as ctx:
+        _push_in_pieces(ctx, bases, boff, 7)
+        res = ctx.finish()
+        util.check_against_golden(case, res.hist, res.max_inst, res.table)
+    with fastk_amd.Context(kmer=k, table_cutoff=cutoff, nthreads=T, nbuckets=5, hbm_budget=2 << 30) as ctx:
+        _push_in_pieces(ctx, bases, boff, 7)
+        res2 = ctx.finish()
+        assert np.array_equal(res2.hist, res.hist) and res2.max_inst == res.max_inst
+        assert np.array_equal(res2.table, res.table)
+    del res, res2
+    with fastk_amd.Context(kmer=k, table_cutoff=cutoff, nthreads=T, exact_parts=True) as ctx:
+        _push_in_pieces(ctx, bases, boff, 3)
+        res = ctx.finish()
+        ctx.write_hist(res, str(tmp_path / "x.hist"))
+        ctx.write_ktab(res, str(tmp_path), "x")
+    for fname, digest in case["expected"]["file_sha256"].items():
+        assert util.sha_file(tmp_path / fname) == digest, fname
+
+
+@pytest.mark.parametrize("name", LARGE[:2])
+def test_drivers_against_reference_digests_above_fixture_size(name, tmp_path):
+    """The C driver (FastK_amd, text parsed on the GPU; then -x) and the reference's own main() over the
+    shim (FastK_gpu) on the same inputs as files: stream digests, then every file digest."""
+    import os, subprocess
+    case, bases, boff = util.load_case(name)
+    exp = case["expected"]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "fastk_amd", "bin", "FastK_amd")
+    path = str(tmp_path / ("x." + case["fmt"]))
+    util.write_fastx(path, bases, boff, case["fmt"] == "fastq")
+    args = ["-k%d" % case["k"], "-t%d" % case["cutoff"], "-T%d" % case["T"]]
+    subprocess.run([exe] + args + [path], check=True, cwd=str(tmp_path))
+    assert util.sha_file(tmp_path / "x.hist") == exp["hist_sha256"]
+    t = orc.read_ktab(str(tmp_path / "x"))
+    assert t["stream_sha256"] == exp["ktab"]["stream_sha256"] and t["nels"] == exp["ktab"]["nels"]
+    del t
+    for cmd in ([exe] + args + ["-x", path], [os.path.join(orc.REF_DIR, "FastK_gpu")] + args + ["-P" + str(tmp_path), path]):
+        if not os.path.exists(cmd[0]):
+            continue
+        for f in os.listdir(tmp_path):
+            if f != os.path.basename(path):
+                os.remove(tmp_path / f)
+        subprocess.run(cmd, check=True, cwd=str(tmp_path), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        for fname, digest in exp["file_sha256"].items():
+            assert util.sha_file(tmp_path / fname) == digest, (os.path.basename(cmd[0]), fname)
+
+
+@pytest.mark.parametrize("name", ["edge_k40_t1_T4", "synth_hifi_k40_t4_T8", "synth_illumina_k51_t1_T4"])
+def test_reference_readers_accept_our_files(name, tmp_path):
+    """SURVEY 8(f)-1 reader conformance: the reference-built Histex, Tabex and Logex (oracle/_ref) print
+    for OUR files (default pipeline: our own part boundaries) exactly what they print for the files of
+    the reference FastK run in place on the same input."""
+    import os, subprocess
+    tools = {t: os.path.join(orc.REF_DIR, t) for t in ("FastK", "Histex", "Tabex", "Logex")}
+    if not all(os.path.exists(p) for p in tools.values()):
+        pytest.skip("oracle/_ref tools not built (needs the reference sources at build time)")
+    case, bases, boff = util.load_case(name)
+    k, T, cutoff = case["k"], case["T"], case["cutoff"]
+    ours, theirs = tmp_path / "ours", tmp_path / "theirs"
+    ours.mkdir(); theirs.mkdir()
+    orc.write_fasta(str(theirs / "x.fasta"), bases, boff)
+    orc.run_ref_fastk(str(theirs / "x.fasta"), k, cutoff, T, str(theirs))
+    with fastk_amd.Context(kmer=k, table_cutoff=cutoff, nthreads=T) as ctx:
+        ctx.push_block(bases, boff.astype(np.int32))
+        res = ctx.finish()
+        ctx.write_hist(res, str(ours / "x.hist"))
+        ctx.write_ktab(res, str(ours), "x")
+
+    def run(tool, *args):
+        outs = []
+        for d in (ours, theirs):
+            p = subprocess.run([tools[tool]] + list(args), cwd=str(d), capture_output=True, text=True)
+            assert p.returncode == 0, (tool, args, p.stderr[-500:])
+            outs.append(p.stdout + p.stderr)
+        assert outs[0] == outs[1], (tool, args)
+        return outs[0]
+
+    assert len(run("Histex", "x")) > 0                       # the default range
+    run("Histex", "-h1:20", "x")
+    run("Histex", "-A", "-k", "-h1:32767", "x")              # k-mer instances, every count, ASCII
+    run("Histex", "-G", "x")                                 # the GeneScope form
+    assert "OK" in run("Tabex", "-C", "x")
+    assert len(run("Tabex", "-A", "-t%d" % max(cutoff, 2), "x")) > 0      # the whole table as text
+    run("Tabex", "x", "100-200")
+    # Logex: a one-table expression (k-mers with count >= 2), table and histogram output
+    for d in (ours, theirs):
+        p = subprocess.run([tools["Logex"], "-T%d" % T, "-h", "sel = A[2-]", "x"], cwd=str(d), capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr[-500:]
+    for f in ("sel.hist",):
+        assert util.sha_file(ours / f) == util.sha_file(theirs / f), f
+    a, b = orc.read_ktab(str(ours / "sel")), orc.read_ktab(str(theirs / "sel"))
+    assert a["stream_sha256"] == b["stream_sha256"] and a["nels"] == b["nels"]
+
+
 # ------------------------------------------------------------------------------ full size
 def test_full_size_properties_configs1():
     """BASELINE configs[1] at full size (33.3 M reads of 150 bp, 3.7 G k-mer instances): no oracle

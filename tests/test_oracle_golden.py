@@ -24,6 +24,18 @@ def test_oracle_matches_reference_golden(name, tmp_path):
     assert t["part_sizes"] == case["expected"]["ktab"]["part_sizes"]
 
 
+def test_oracle_matches_reference_at_configs0(tmp_path):
+    """BASELINE.json configs[0] at its stated size (1 M x 150 bp reads of a 10 Mbp genome, k=40 -t1 -T4):
+    the restatement reproduces every file digest of the reference run (make_golden.py --large)."""
+    case, bases, boff = util.load_case("configs0_k40_t1_T4")
+    assert len(boff) - 1 == 1000000
+    res = orc.fastk(case["k"], bases, boff, cutoff=case["cutoff"], nthreads=case["T"])
+    util.check_against_golden(case, res.hist, res.max_inst, res.table)
+    orc.write_outputs(res, case["cutoff"], case["T"], str(tmp_path), "x")
+    for fname, digest in case["expected"]["file_sha256"].items():
+        assert util.sha_file(os.path.join(str(tmp_path), fname)) == digest, fname
+
+
 @pytest.mark.parametrize("name", ["edge_k40_t1_T4", "edge_k21_t2_T3", "synth_tiny_k40_t1_T2"])
 def test_brute_force_definition_matches_golden(name):
     case, bases, boff = util.load_case(name)

@@ -12,10 +12,11 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def golden_names(kind=None):
+    """kind None: every fixture-sized case (the digest-only "large" cases are asked for by name or kind)."""
     out = []
     for p in sorted(glob.glob(os.path.join(GOLDEN, "*.json"))):
         c = json.load(open(p))
-        if kind is None or c["kind"] == kind:
+        if (kind is None and c["kind"] != "large") or c["kind"] == kind:
             out.append(c["name"])
     return out
 
@@ -70,3 +71,35 @@ def check_against_golden(case, hist, max_inst, table, name=None):
     gt = golden_table(name or case["name"], k)
     if gt is not None:
         assert np.array_equal(table, gt), "table entries differ from reference"
+
+
+def write_fastx(path, bases, boff, fastq):
+    """Vectorised writer for equal-length reads (the synthetic cases): one line per read."""
+    n = len(boff) - 1
+    L = int(boff[1] - boff[0]) - 1
+    rows = np.asarray(bases).reshape(n, L + 1)[:, :L]
+    if fastq:
+        mat = np.empty((n, 3 + L + 3 + L + 1), dtype=np.uint8)
+        mat[:, 0:3] = np.frombuffer(b"@r\n", dtype=np.uint8)
+        mat[:, 3:3 + L] = rows
+        mat[:, 3 + L:6 + L] = np.frombuffer(b"\n+\n", dtype=np.uint8)
+        mat[:, 6 + L:6 + 2 * L] = ord("I")
+        mat[:, 6 + 2 * L] = ord("\n")
+    else:
+        mat = np.empty((n, 3 + L + 1), dtype=np.uint8)
+        mat[:, 0:3] = np.frombuffer(b">r\n", dtype=np.uint8)
+        mat[:, 3:3 + L] = rows
+        mat[:, 3 + L] = ord("\n")
+    mat.tofile(path)
+
+
+def sha_file(path):
+    import hashlib
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        while True:
+            b = f.read(1 << 24)
+            if not b:
+                break
+            h.update(b)
+    return h.hexdigest()
