@@ -377,6 +377,32 @@ def table_stream_sha256(kmer, table, ib=None):
 
 # --------------------------------------------------------------------------- reference binary
 
+_fkref = None
+
+
+def ref_lsd_sort(recs, byte_list, nthreads=4):
+    """The REFERENCE's own LSD_Sort (LSDsort.c:115, compiled where it lies into oracle/_ref/libfkref.so)
+    on an (n, rsize) uint8 array; byte_list least significant first.  Returns the sorted copy."""
+    global _fkref
+    if _fkref is None:
+        _fkref = C.CDLL(os.path.join(REF_DIR, "libfkref.so"), mode=os.RTLD_LAZY)   # CRAM symbols stay unresolved
+        _fkref.LSD_Sort.restype = C.c_void_p
+        _fkref.LSD_Sort.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    C.c_int.in_dll(_fkref, "NTHREADS").value = nthreads
+    n, rsize = recs.shape
+    src = np.ascontiguousarray(recs).copy()
+    trg = np.empty_like(src)
+    bl = (C.c_int * (len(byte_list) + 1))(*(list(byte_list) + [-1]))
+    if n == 0:
+        return src
+    out = _fkref.LSD_Sort(n, src.ctypes.data, trg.ctypes.data, rsize, bl)
+    return (src if out == src.ctypes.data else trg).copy()
+
+
+def have_fkref():
+    return os.path.exists(os.path.join(REF_DIR, "libfkref.so"))
+
+
 def have_ref():
     return os.path.exists(os.path.join(REF_DIR, "FastK"))
 

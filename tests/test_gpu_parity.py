@@ -1027,6 +1027,24 @@ def test_multi_pass_split_automatic_from_budget():
         util.check_against_golden(case, res.hist, res.max_inst, res.table)
 
 
+@pytest.mark.parametrize("rsize,n,keys", [(12, 400003, 10), (20, 150001, 19), (12, 100000, 5), (28, 30000, 25)])
+def test_lsd_sort_equals_reference_engine(ctx40, rsize, n, keys):
+    """fk_lsd_sort_records against the REFERENCE's LSD_Sort itself (oracle/_ref/libfkref.so, LSDsort.c:115
+    compiled where it lies), not only against the restatement: same bytes, ties in input order."""
+    if not orc.have_fkref():
+        pytest.skip("oracle/_ref/libfkref.so not built (needs the reference sources at build time)")
+    rng = np.random.default_rng(n)
+    recs = rng.integers(0, 256, size=(n, rsize), dtype=np.uint8)
+    recs[:, 0] = rng.integers(0, 4, size=n)
+    order = list(range(keys - 1, -1, -1))
+    a = ctx40.alloc(recs.nbytes).upload(recs)
+    b = ctx40.alloc(recs.nbytes)
+    res = ctx40.lsd_sort(a.ptr, b.ptr, n, rsize, order)
+    got = a.download(recs.nbytes, ptr=res).reshape(n, rsize)
+    a.free(); b.free()
+    assert np.array_equal(got, orc.ref_lsd_sort(recs, order, 5))
+
+
 # ------------------------------------------------------------------------------ above fixture size
 # Digest-only golden cases made by the reference (tests/golden/make_golden.py --large): BASELINE.json
 # configs[0] at its stated size and the two samples bench.py times the reference on.
@@ -1177,6 +1195,73 @@ def test_full_size_properties_configs1():
     assert np.all((hi[1:] > hi[:-1]) | ((hi[1:] == hi[:-1]) & (lo[1:] > lo[:-1])))
     cnt = t[:, 10:12].copy().view("<u2").ravel()
     assert np.array_equal(np.bincount(cnt, minlength=0x8000)[1:], a.hist[1:])
+
+
+def test_full_size_properties_configs2():
+    """BASELINE configs[2] at full size on one GPU: 50x of a 3 Gbp genome in 15 kbp reads with 0.2 %
+    substitutions, k=40 -t4 (10 M reads, 150 G bases, 149.61 G k-mer instances, ~8.6 G super-mers,
+    ~22 G weighted k-mers, 3.0 G table entries).  The 150 GB of reads stay resident; the run takes 2
+    split passes over them and 48 minimizer buckets one after the other (bench.py's setting), then again
+    with 3 passes and 40 buckets (other group boundaries, other bucket contents).  Checked: instance
+    count, conservation (sum c*hist[c] + max_inst == instances), sum(hist) == distinct k-mers, table
+    entries == sum(hist[4:]), strictly increasing table, table counts reproduce the histogram from the
+    cutoff up, and both settings give the identical histogram and table.  A summary goes to
+    gpurun_out/full_size_configs2.json."""
+    import json, os, time
+    L, glen, k, cutoff = 15000, 3_000_000_000, 40, 4
+    nreads = int(50 * glen / L)
+    nbytes = nreads * (L + 1)
+    inst = nreads * (L - k + 1)
+    summary = dict(reads=nreads, bases=nreads * L, kmer_instances=inst, runs=[])
+    tables = []
+    with fastk_amd.Context(kmer=k) as gen:
+        buf = gen.alloc(nbytes + 64)
+        piece = 1 << 20                                    # reads per generator call
+        for first in range(0, nreads, piece):
+            n = min(piece, nreads - first)
+            gen._ck(gen.L.fk_synth_reads(gen.h, 20251001, glen, L, 2000, first, n, buf.ptr + first * (L + 1)))
+        gen._ck(gen.L.fk_synchronize(gen.h))
+        sample = buf.download(8 << 20)
+        for nb, passes in ((48, 2), (40, 3)):
+            with fastk_amd.Context(kmer=k, table_cutoff=cutoff, nbuckets=nb, split_passes=passes) as ctx:
+                ctx.set_bucket_weights(ctx.bucket_census(sample))
+                t0 = time.perf_counter()
+                res = ctx.count_device_reads(buf.ptr, nbytes, fetch_table=True)
+                dt = time.perf_counter() - t0
+            h = res.hist.astype(np.int64)
+            assert res.ninst == inst
+            assert int((h[1:0x7fff] * np.arange(1, 0x7fff)).sum()) + int(res.max_inst) == inst
+            assert res.ndistinct == int(h.sum())
+            assert res.ntable == int(h[cutoff:].sum()) == len(res.table)
+            assert res.split_passes == passes and res.buckets_counted == nb
+            summary["runs"].append(dict(buckets=nb, split_passes=passes, seconds_first_run_with_table_fetch=round(dt, 2),
+                                        supermers=res.nsuper, weighted_kmers=res.nweighted, distinct_kmers=res.ndistinct,
+                                        table_entries=res.ntable, device_ms=res.ms))
+            tables.append((res.hist, res.max_inst, res.table))
+            del res
+        buf.free()
+    (ha, ma, ta), (hb, mb, tb) = tables
+    assert np.array_equal(ha, hb) and ma == mb
+    step = 1 << 27                                         # entries per slice of the 36 GB tables
+    cnt_hist = np.zeros(0x8000, dtype=np.int64)
+    prev_hi, prev_lo = None, None
+    for o in range(0, len(ta), step):
+        a, b = ta[o:o + step], tb[o:o + step]
+        assert np.array_equal(a, b), "tables differ in entries %d.." % o
+        hi = np.ascontiguousarray(a[:, :8]).view(">u8").ravel()
+        lo = np.ascontiguousarray(a[:, 8:10]).view(">u2").ravel()
+        assert np.all((hi[1:] > hi[:-1]) | ((hi[1:] == hi[:-1]) & (lo[1:] > lo[:-1]))), "table not increasing near %d" % o
+        if prev_hi is not None:
+            assert (hi[0] > prev_hi) or (hi[0] == prev_hi and lo[0] > prev_lo)
+        prev_hi, prev_lo = hi[-1], lo[-1]
+        cnt_hist += np.bincount(np.ascontiguousarray(a[:, 10:12]).view("<u2").ravel(), minlength=0x8000)
+    assert np.array_equal(cnt_hist[cutoff:], ha[cutoff:]) and cnt_hist[:cutoff].sum() == 0
+    summary["checks"] = "instances, conservation, sum(hist) = distinct, ntable = sum(hist[4:]), table strictly increasing, " \
+                        "table counts = histogram, identical histogram and table for (48 buckets, 2 passes) and (40, 3)"
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "full_size_configs2.json"), "w") as f:
+            json.dump(summary, f, indent=1)
 
 
 # ------------------------------------------------------------------------------ profiles (-p)

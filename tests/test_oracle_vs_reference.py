@@ -60,3 +60,16 @@ def test_files_byte_identical_to_reference(k, T, cutoff, fmt, tmp_path):
     out = subprocess.run([os.path.join(orc.REF_DIR, "Tabex"), "-C", os.path.join(od, "x")],
                          capture_output=True, text=True)
     assert "Table is OK" in out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("rsize,n,nbytes,T", [(12, 50000, 10, 4), (20, 30011, 19, 3), (16, 1000, 5, 1), (12, 7, 10, 4)])
+def test_oracle_lsd_engine_equals_reference_lsd_sort(rsize, n, nbytes, T):
+    """Sort-engine unit parity against the reference's own LSD_Sort (libfkref.so = LSDsort.c compiled
+    where it lies): same records in, same bytes out, ties (partial keys) in input order."""
+    if not orc.have_fkref():
+        pytest.skip("oracle/_ref/libfkref.so not built (needs the reference sources at build time)")
+    rng = np.random.default_rng(rsize * 1000 + n)
+    recs = rng.integers(0, 256, size=(n, rsize), dtype=np.uint8)
+    recs[:, 1] = rng.integers(0, 3, size=n)
+    order = list(range(nbytes - 1, -1, -1))
+    assert np.array_equal(orc.lsd_sort(recs, order), orc.ref_lsd_sort(recs, order, T))
