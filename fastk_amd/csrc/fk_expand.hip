@@ -94,6 +94,10 @@ __global__ __launch_bounds__(EX_THREADS) void k_ex_expand(const u32 *__restrict_
   __shared__ uint16_t hct[EX_TILE];      // its clipped multiplicity
   __shared__ u32 tmp[8];
   __shared__ u32 s_runk, s_runh;
+  // digit bytes of the k-mers a wave emits in one step (64 * EX_G consecutive ones), staged so that the
+  // stream is written as whole dwords: a byte store per k-mer made every 32-byte sector of the stream
+  // go to memory EX_G times (WRITE_SIZE 1.43 x the algorithmic W * 13 bytes, profiles/r02_a)
+  __shared__ __attribute__((aligned(16))) u32 sdig[EX_THREADS / 64][(64 * EX_G) / 4 + 2];
 
   if (dig != NULL)
     { lh[threadIdx.x] = 0;
@@ -192,8 +196,13 @@ __global__ __launch_bounds__(EX_THREADS) void k_ex_expand(const u32 *__restrict_
   // every thread emits EX_G CONSECUTIVE k-mers: one binary search for the first, after that the
   // next k-mer costs a fresh forward window (ex_bits) and its reverse complement; moving on to the
   // next head only changes the record the window is cut from
-  for (u32 j0 = threadIdx.x * EX_G; j0 < ktile; j0 += EX_THREADS * EX_G)
-    { u32 lo = 0, hi = nh;
+  const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  for (u32 jw = (threadIdx.x & ~63u) * EX_G; jw < ktile; jw += EX_THREADS * EX_G)     // uniform in a wave
+    { const u32 j0 = jw + lane * EX_G;
+      u64 dgs = 0;                                  // this thread's digit bytes, first k-mer lowest
+      if (j0 < ktile)
+      {
+      u32 lo = 0, hi = nh;
       while (hi - lo > 1)
         { const u32 mid = (lo + hi) >> 1;
           if (hoff[mid] <= j0) lo = mid; else hi = mid;
@@ -256,10 +265,35 @@ __global__ __launch_bounds__(EX_THREADS) void k_ex_expand(const u32 *__restrict_
               fk_rec_hash<OW>(x.w, kbytes, ha, hb);
               atomicAdd(&lh[hb & 0xffu], 1u);
               atomicAdd(&lh[256 + ((hb >> 8) & 0xffu)], 1u);
-              dig[kbase + j] = (uint8_t) (hb & 0xffu);
+              dgs |= (u64) (hb & 0xffu) << (8 * g);
             }
           x.w[OW - 1] |= ct << 16;                     // uint16 weight in the record's last two bytes
           *(ex_out<OW> *) (gout + (u64) j * OW) = x;
+        }
+      }
+      if (dig != NULL)
+        { // the wave's digits: bytes jw .. jw + nv - 1 of the tile's stretch of the stream
+          static_assert(EX_G == 6, "three 16-bit stores per thread");
+          uint16_t *s16 = (uint16_t *) sdig[wv] + lane * (EX_G / 2);
+          s16[0] = (uint16_t) dgs; s16[1] = (uint16_t) (dgs >> 16); s16[2] = (uint16_t) (dgs >> 32);
+          __builtin_amdgcn_wave_barrier();             // (LDS operations of a wave execute in order)
+          const u32 nv = (ktile - jw < 64u * EX_G) ? (ktile - jw) : 64u * EX_G;
+          uint8_t  *gd = dig + kbase + jw;
+          const uint8_t *sb = (const uint8_t *) sdig[wv];
+          u32 head = (u32) ((4u - ((u32) (uintptr_t) gd & 3u)) & 3u);
+          if (head > nv) head = nv;
+          if (lane < head)
+            gd[lane] = sb[lane];
+          const u32 ndw = (nv - head) >> 2;
+          for (u32 t = lane; t < ndw; t += 64)
+            { const u32 x0 = sdig[wv][t + (head >> 2)], x1 = sdig[wv][t + (head >> 2) + 1];
+              const u32 sh = 8u * (head & 3u);
+              *(u32 *) (gd + head + 4 * t) = sh ? ((x0 >> sh) | (x1 << (32 - sh))) : x0;
+            }
+          const u32 done = head + 4 * ndw;
+          if (lane < nv - done)
+            gd[done + lane] = sb[done + lane];
+          __builtin_amdgcn_wave_barrier();
         }
     }
   }
