@@ -296,7 +296,7 @@ extern "C" void fk_destroy(fk_ctx *ctx)
     hipStreamSynchronize(ctx->copy_stream);
   if (ctx->stream != NULL)
     hipStreamSynchronize(ctx->stream);
-  hipFree(ctx->d_mbucket); hipFree(ctx->d_mbucket_pass); hipFree(ctx->d_scratch);
+  hipFree(ctx->d_mbucket); hipFree(ctx->d_mbucket_pass); hipFree(ctx->d_scratch); hipFree(ctx->d_cursors);
   if (ctx->h_mbucket_pass) hipHostFree(ctx->h_mbucket_pass);
   if (ctx->h_scratch) hipHostFree(ctx->h_scratch);
   hipFree(ctx->d_digit_hist); hipFree(ctx->d_status); hipFree(ctx->d_ticket);

@@ -19,6 +19,7 @@ typedef unsigned int       u32;
 // Minimizers are canonical 7-mers ordered by a bijective mix of their 14-bit code (odd multiplies and
 // xor-shifts are invertible mod 2^14, so distinct 7-mers never tie): FK_NRANKS rank values, of which
 // the 8192 images of canonical codes occur.
+#define FK_CURSOR_STRIDE 512
 #define FK_MIN_LEN 7
 #define FK_NRANKS  16384
 
@@ -74,6 +75,7 @@ struct fk_ctx
   uint8_t   *d_mbucket_pass; // [FK_NRANKS] the same for one group pass of a multi-pass split (0xFF = not now)
   uint8_t    h_mbucket[FK_NRANKS];
   uint8_t   *h_mbucket_pass; // pinned staging of d_mbucket_pass
+  u64       *d_cursors;      // [256 * FK_CURSOR_STRIDE] per-bucket write cursors of the planned split, 4 KB apart
 
   // small device scratch (counters, histograms)
   u64       *d_scratch;   // 64 KB

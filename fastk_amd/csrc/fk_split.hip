@@ -43,7 +43,9 @@ struct SplitArgs
   int       nbuckets;
   const uint8_t  *mbucket;  // [FK_NRANKS] bucket of a canonical minimizer rank (global memory: one read per super-mer)
   u64      *counts;         // [nbuckets] records per bucket (count mode)  + [256] = instances
-  u64      *cursor;         // [nbuckets] running write cursors (emit mode), pre-set to bucket bases
+  u64      *cursor;         // [nbuckets * cstride] running write cursors (emit mode), pre-set to bucket bases
+  int       cstride;        // u64 words between two buckets' cursors: every tile adds to every bucket's cursor, and
+                            // cursors that share a memory channel serialise (FK_CURSOR_STRIDE words = 4 KB apart)
   const u64 *limit;         // [nbuckets] end of each bucket's region (NULL: only `cap` bounds the output)
   u32      *out;
   int64_t   cap;
@@ -328,7 +330,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
     }
 
   if (tid < a.nbuckets && bcnt[tid] != 0)
-    bbase[tid] = atomicAdd(&a.cursor[tid], (u64) bcnt[tid]);
+    bbase[tid] = atomicAdd(&a.cursor[(size_t) tid * a.cstride], (u64) bcnt[tid]);
   __syncthreads();
 
   // ---- 7. build and write the records -----------------------------------------------------
@@ -419,7 +421,7 @@ int fkx_split(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int
   a.nbuckets = nb;
   a.mbucket = ctx->d_mbucket;
   a.counts = d_counts;
-  a.cursor = d_cursor;
+  a.cursor = d_cursor; a.cstride = 1;
   a.out = (u32 *) d_out;
   a.cap = cap;
   a.overflowed = d_ovf;
@@ -513,7 +515,7 @@ int fkx_split_fast(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void **d_ou
       a.nbuckets = 1;
           a.mbucket = ctx->d_mbucket;
       a.counts = d_counts;
-      a.cursor = d_cursor;
+      a.cursor = d_cursor; a.cstride = 1;
       a.limit = NULL; a.pos = NULL; a.skipb = 0x100u;
       a.overflowed = d_ovf;
       const int64_t nstarts = nbytes - K + 1;
@@ -626,7 +628,7 @@ int fkx_split_plan(fk_ctx *ctx, const void *d_bases, int64_t nbytes, int64_t *ca
   a.nbuckets = nb;
   a.mbucket = ctx->d_mbucket;
   a.counts = ctx->d_scratch;
-  a.cursor = ctx->d_scratch + 512;
+  a.cursor = ctx->d_scratch + 512; a.cstride = 1;
   a.limit = NULL; a.pos = NULL; a.skipb = 0x100u;
   a.out = NULL; a.cap = 0;
   a.overflowed = (u32 *) (ctx->d_scratch + 1024);
@@ -683,6 +685,10 @@ int fkx_split_planned(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_
     }
   FK_HIP(ctx, hipMemsetAsync(ctx->d_scratch, 0, 1032 * sizeof(u64), s));
   FK_HIP(ctx, hipMemcpyAsync(ctx->d_scratch + 512, h, 512 * sizeof(u64), hipMemcpyHostToDevice, s));
+  if (ctx->d_cursors == NULL)
+    FK_HIP(ctx, hipMalloc((void **) &ctx->d_cursors, 256 * FK_CURSOR_STRIDE * sizeof(u64)));
+  FK_HIP(ctx, hipMemcpy2DAsync(ctx->d_cursors, FK_CURSOR_STRIDE * sizeof(u64), h, sizeof(u64), sizeof(u64), (size_t) nb,
+                               hipMemcpyHostToDevice, s));
   if (group)
     { uint8_t *hm = ctx->h_mbucket_pass;                          // pinned (the previous pass has been waited for)
       for (int r = 0; r < FK_NRANKS; r++)
@@ -700,7 +706,7 @@ int fkx_split_planned(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_
   a.nbuckets = nb;
   a.mbucket = group ? ctx->d_mbucket_pass : ctx->d_mbucket;
   a.counts = ctx->d_scratch;
-  a.cursor = ctx->d_scratch + 512;
+  a.cursor = ctx->d_cursors; a.cstride = FK_CURSOR_STRIDE;
   a.limit = ctx->d_scratch + 768;
   a.pos = NULL;
   a.skipb = group ? 0xFFu : 0x100u;
@@ -710,6 +716,8 @@ int fkx_split_planned(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_
   sp_launch<true, false>(a, ntiles, s);
   FK_LAUNCH_CHECK(ctx);
   FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch, ctx->d_scratch, 1032 * sizeof(u64), hipMemcpyDeviceToHost, s));
+  FK_HIP(ctx, hipMemcpy2DAsync(ctx->h_scratch + 512, sizeof(u64), ctx->d_cursors, FK_CURSOR_STRIDE * sizeof(u64),
+                               sizeof(u64), (size_t) nb, hipMemcpyDeviceToHost, s));
   FK_HIP(ctx, hipStreamSynchronize(s));
   if (*(u32 *) (ctx->h_scratch + 1024) != 0)
     { fk_set_error(ctx, "planned split: a bucket region was too small");
