@@ -27,7 +27,8 @@ EXPORTS = [
     "fk_write_ktab_ex", "fk_rounds_begin", "fk_rounds_add", "fk_rounds_finish",
     "fk_make_profiles", "fk_write_prof", "fk_set_table", "fk_ktab_idx_bytes", "fk_ktab_split",
     "fk_write_ktab_range", "fk_write_ktab_stub", "fk_split_supermers_emit_pos", "fk_profile_lookup_supermers",
-    "fk_profile_scatter", "fk_profile_encode", "fk_reset",
+    "fk_profile_scatter", "fk_profile_encode", "fk_reset", "fk_shard_unique_id", "fk_shard_create",
+    "fk_shard_count", "fk_shard_write", "fk_shard_destroy",
 ]
 
 
@@ -110,6 +111,12 @@ def load_library():
     L.fk_push_device.argtypes = [vp, vp, i64]
     L.fk_finish.argtypes = [vp, C.POINTER(CResult)]
     L.fk_reset.argtypes = [vp]
+    L.fk_shard_unique_id.argtypes = [C.c_char_p]
+    L.fk_shard_create.argtypes = [vp, ci, ci, C.c_char_p, C.POINTER(vp)]
+    L.fk_shard_count.argtypes = [vp, C.POINTER(CResult)]
+    L.fk_shard_write.argtypes = [vp, C.POINTER(CResult), ci, C.c_char_p, C.c_char_p]
+    L.fk_shard_destroy.argtypes = [vp]
+    L.fk_shard_destroy.restype = None
     L.fk_count_device_reads.argtypes = [vp, vp, i64, ci, C.POINTER(CResult)]
     L.fk_count_device_supermers.argtypes = [vp, vp, i64, ci, C.POINTER(CResult)]
     L.fk_write_hist.argtypes = [C.POINTER(CResult), ci, C.c_char_p]

@@ -1,0 +1,487 @@
+// fk_shard.hip -- the sharded run from a C host: one process per GPU, RCCL called directly.
+//
+// What the reference does with files between its phases, a node's GPUs do over xGMI:
+//   C1  every rank splits the reads it was handed into super-mers grouped by minimizer bucket; bucket
+//       r*world + d goes to rank d in round r: grouped ncclSend/ncclRecv of the SMER_WORD records
+//       replaces the ".T" file shuffle (split.c:1263 <-> count.c:1347); round r+1 travels on its own
+//       stream while round r is counted;
+//   C2  the 0x8000-bin histogram, the totals and the first-byte census are all-reduced
+//       (count.c:1543-1553);
+//   C3  a second exchange keyed by the first k-mer byte gives rank r the table entries of a contiguous
+//       first-byte range -- the ranges Table_Split picks for nparts parts (count.c:1560-1565) -- and
+//       every rank writes the hidden part files of its range itself (table.c:346-533: parts are ordered
+//       ranges of the table, README.md:988); the per-prefix entry counts are reduced to rank 0, which
+//       writes the stub and the .hist file.
+// Everything that travels stays in HBM; only the sorted part payloads cross PCIe (pinned) to be written.
+//
+// RCCL is bound at run time (dlopen of librccl.so.1): the library has no link-time dependency on it, a
+// process that never shards never loads it, and inside a PyTorch process the copy torch already
+// loaded is the one that gets used.
+#include "fk_common.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+#include <vector>
+#include <algorithm>
+
+int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers_in, int64_t nsmers_in,
+                 fk_result *res, bool fetch_table, int64_t *h_roff, int64_t nreads);
+
+struct fk_rccl
+{ ncclResult_t (*GetUniqueId)(ncclUniqueId *);
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
+  ncclResult_t (*CommDestroy)(ncclComm_t);
+  ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+  ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
+  ncclResult_t (*GroupStart)();
+  ncclResult_t (*GroupEnd)();
+  const char  *(*GetErrorString)(ncclResult_t);
+};
+
+static fk_rccl g_rccl;
+static bool    g_rccl_ok = false;
+
+static int load_rccl(fk_ctx *ctx)
+{ if (g_rccl_ok)
+    return (FK_OK);
+  void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (h == NULL) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (h == NULL) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (h == NULL)
+    { fk_set_error(ctx, "sharded run: cannot load librccl.so.1 (%s)", dlerror());
+      return (FK_EUNSUPPORTED);
+    }
+#define SYM(field, name) \
+  if ((*(void **) &g_rccl.field = dlsym(h, name)) == NULL)                                   \
+    { fk_set_error(ctx, "sharded run: librccl has no %s", name); return (FK_EUNSUPPORTED); }
+  SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy")
+  SYM(Send, "ncclSend") SYM(Recv, "ncclRecv") SYM(AllReduce, "ncclAllReduce") SYM(AllGather, "ncclAllGather")
+  SYM(GroupStart, "ncclGroupStart") SYM(GroupEnd, "ncclGroupEnd") SYM(GetErrorString, "ncclGetErrorString")
+#undef SYM
+  g_rccl_ok = true;
+  return (FK_OK);
+}
+
+#define FK_NCCL(ctx, call)                                                                      \
+  do { ncclResult_t r_ = (call);                                                                 \
+       if (r_ != ncclSuccess)                                                                    \
+         { fk_set_error(ctx, "%s failed: %s (%s:%d)", #call, g_rccl.GetErrorString(r_), __FILE__, __LINE__); \
+           return (FK_EHIP);                                                                     \
+         }                                                                                       \
+     } while (0)
+
+#define FK_PAIR_BYTES (1ll << 30)      // one ncclSend/ncclRecv moves at most this much
+
+struct fk_shard
+{ fk_ctx     *ctx;
+  int         rank, world, rounds;
+  ncclComm_t  comm;
+  hipStream_t xs;                 // the exchange runs here, counting on ctx->stream
+  hipEvent_t  xev[2];
+  int64_t    *d_small, *h_small;  // counts, histogram and totals on their way through the collectives
+  int64_t     small_cap;          // in int64
+  void       *inbox[2];
+  int64_t     inbox_cap[2];
+  fk_result   local;              // this rank's own result (its table stays in HBM, in ctx)
+  int64_t     lfirst[256];        // first-byte census of this rank's table
+};
+
+extern "C" int fk_shard_unique_id(char *id128)
+{ if (id128 == NULL) return (FK_EINVAL);
+  int rc = load_rccl(NULL);
+  if (rc != FK_OK) return (rc);
+  ncclUniqueId id;
+  if (g_rccl.GetUniqueId(&id) != ncclSuccess)
+    { fk_set_error(NULL, "ncclGetUniqueId failed");
+      return (FK_EHIP);
+    }
+  static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+  memcpy(id128, &id, 128);
+  return (FK_OK);
+}
+
+extern "C" void fk_shard_destroy(fk_shard *sh)
+{ if (sh == NULL) return;
+  hipSetDevice(sh->ctx->device);
+  if (sh->xs) hipStreamSynchronize(sh->xs);
+  if (sh->comm) g_rccl.CommDestroy(sh->comm);
+  for (int i = 0; i < 2; i++)
+    { if (sh->xev[i]) hipEventDestroy(sh->xev[i]);
+      if (sh->inbox[i]) hipFree(sh->inbox[i]);
+    }
+  if (sh->xs) hipStreamDestroy(sh->xs);
+  if (sh->d_small) hipFree(sh->d_small);
+  if (sh->h_small) hipHostFree(sh->h_small);
+  free(sh);
+}
+
+extern "C" int fk_shard_create(fk_ctx *ctx, int rank, int world, const char *id128, fk_shard **out)
+{ if (ctx == NULL || out == NULL || id128 == NULL || world < 1 || rank < 0 || rank >= world) return (FK_EINVAL);
+  *out = NULL;
+  if (ctx->prm.nbuckets % world != 0 || ctx->prm.nbuckets / world < 1)
+    { fk_set_error(ctx, "fk_shard_create: the context's %d buckets are not a multiple of the %d ranks (bucket r*world+d "
+                        "goes to rank d in round r)", ctx->prm.nbuckets, world);
+      return (FK_EINVAL);
+    }
+  int rc = load_rccl(ctx);
+  if (rc != FK_OK) return (rc);
+  fk_shard *sh = (fk_shard *) calloc(1, sizeof(fk_shard));
+  if (sh == NULL) return (FK_ENOMEM);
+  sh->ctx = ctx; sh->rank = rank; sh->world = world; sh->rounds = ctx->prm.nbuckets / world;
+  FK_HIP(ctx, hipSetDevice(ctx->device));
+  ncclUniqueId id;
+  memcpy(&id, id128, 128);
+  { ncclResult_t r = g_rccl.CommInitRank(&sh->comm, world, id, rank);
+    if (r != ncclSuccess)
+      { fk_set_error(ctx, "ncclCommInitRank(rank %d of %d) failed: %s", rank, world, g_rccl.GetErrorString(r));
+        free(sh);
+        return (FK_EHIP);
+      }
+  }
+  sh->small_cap = (int64_t) world * ctx->prm.nbuckets + 2 * (FK_HIST_BINS + 1024);
+  if (hipStreamCreateWithFlags(&sh->xs, hipStreamNonBlocking) != hipSuccess
+      || hipEventCreateWithFlags(&sh->xev[0], hipEventDisableTiming) != hipSuccess
+      || hipEventCreateWithFlags(&sh->xev[1], hipEventDisableTiming) != hipSuccess
+      || hipMalloc((void **) &sh->d_small, (size_t) sh->small_cap * 8) != hipSuccess
+      || hipHostMalloc((void **) &sh->h_small, (size_t) sh->small_cap * 8, hipHostMallocDefault) != hipSuccess)
+    { fk_set_error(ctx, "fk_shard_create: cannot set up streams and buffers");
+      fk_shard_destroy(sh);
+      return (FK_EHIP);
+    }
+  *out = sh;
+  return (FK_OK);
+}
+
+// every rank contributes n int64; all[r*n .. r*n+n) = rank r's.  Host in, host out.
+static int allgather_i64(fk_shard *sh, const int64_t *mine, int n, int64_t *all)
+{ fk_ctx *ctx = sh->ctx;
+  int64_t *d_in = sh->d_small, *d_out = sh->d_small + n;
+  if ((int64_t) n * (sh->world + 1) > sh->small_cap) return (FK_EINVAL);
+  memcpy(sh->h_small, mine, (size_t) n * 8);
+  FK_HIP(ctx, hipMemcpyAsync(d_in, sh->h_small, (size_t) n * 8, hipMemcpyHostToDevice, sh->xs));
+  FK_NCCL(ctx, g_rccl.AllGather(d_in, d_out, (size_t) n, ncclInt64, sh->comm, sh->xs));
+  FK_HIP(ctx, hipMemcpyAsync(sh->h_small, d_out, (size_t) n * sh->world * 8, hipMemcpyDeviceToHost, sh->xs));
+  FK_HIP(ctx, hipStreamSynchronize(sh->xs));
+  memcpy(all, sh->h_small, (size_t) n * sh->world * 8);
+  return (FK_OK);
+}
+
+static int allreduce_i64(fk_shard *sh, int64_t *vals, int n)
+{ fk_ctx *ctx = sh->ctx;
+  if (n > sh->small_cap) return (FK_EINVAL);
+  memcpy(sh->h_small, vals, (size_t) n * 8);
+  FK_HIP(ctx, hipMemcpyAsync(sh->d_small, sh->h_small, (size_t) n * 8, hipMemcpyHostToDevice, sh->xs));
+  FK_NCCL(ctx, g_rccl.AllReduce(sh->d_small, sh->d_small, (size_t) n, ncclInt64, ncclSum, sh->comm, sh->xs));
+  FK_HIP(ctx, hipMemcpyAsync(sh->h_small, sh->d_small, (size_t) n * 8, hipMemcpyDeviceToHost, sh->xs));
+  FK_HIP(ctx, hipStreamSynchronize(sh->xs));
+  memcpy(vals, sh->h_small, (size_t) n * 8);
+  return (FK_OK);
+}
+
+// Rank `me` sends send_bytes[d] from send_ptr[d] to every rank d and receives recv_bytes[s] at recv_ptr[s]
+// from every rank s, in grouped calls of at most FK_PAIR_BYTES per pair (the local share is a device copy).
+static int exchange(fk_shard *sh, char *const *send_ptr, const int64_t *send_bytes, char *const *recv_ptr,
+                    const int64_t *recv_bytes)
+{ fk_ctx *ctx = sh->ctx;
+  const int W = sh->world, me = sh->rank;
+  if (send_bytes[me] != recv_bytes[me])
+    { fk_set_error(ctx, "exchange: rank %d keeps %lld bytes but expects %lld", me, (long long) send_bytes[me],
+                   (long long) recv_bytes[me]);
+      return (FK_EHIP);
+    }
+  if (send_bytes[me] > 0)
+    FK_HIP(ctx, hipMemcpyAsync(recv_ptr[me], send_ptr[me], (size_t) send_bytes[me], hipMemcpyDeviceToDevice, sh->xs));
+  int64_t most = 0;
+  for (int p = 0; p < W; p++)
+    if (p != me)
+      most = std::max(most, std::max(send_bytes[p], recv_bytes[p]));
+  for (int64_t o = 0; o < most; o += FK_PAIR_BYTES)
+    { FK_NCCL(ctx, g_rccl.GroupStart());
+      for (int p = 0; p < W; p++)
+        { if (p == me) continue;
+          if (o < send_bytes[p])
+            FK_NCCL(ctx, g_rccl.Send(send_ptr[p] + o, (size_t) std::min<int64_t>(FK_PAIR_BYTES, send_bytes[p] - o),
+                                     ncclUint8, p, sh->comm, sh->xs));
+          if (o < recv_bytes[p])
+            FK_NCCL(ctx, g_rccl.Recv(recv_ptr[p] + o, (size_t) std::min<int64_t>(FK_PAIR_BYTES, recv_bytes[p] - o),
+                                     ncclUint8, p, sh->comm, sh->xs));
+        }
+      FK_NCCL(ctx, g_rccl.GroupEnd());
+    }
+  return (FK_OK);
+}
+
+static int reserve_inbox(fk_shard *sh, int i, int64_t bytes)
+{ if (sh->inbox_cap[i] >= bytes)
+    return (FK_OK);
+  if (sh->inbox[i] != NULL)
+    hipFree(sh->inbox[i]);
+  sh->inbox[i] = NULL;
+  sh->inbox_cap[i] = 0;
+  const int64_t want = bytes + bytes / 16 + (1 << 20);
+  if (hipMalloc(&sh->inbox[i], (size_t) want) != hipSuccess)
+    { fk_set_error(sh->ctx, "out of HBM: cannot allocate %lld bytes for the records of an exchange round", (long long) want);
+      return (FK_ENOMEM);
+    }
+  sh->inbox_cap[i] = want;
+  return (FK_OK);
+}
+
+/* C1 + per-rank counting + C2 over the reads pushed into the context (they stay resident: hbm_budget 0).
+   res: the GLOBAL histogram, max_inst and totals (identical on every rank), wfirst = first-byte census of
+   the whole table, ntable = its entries; res->table is NULL -- every rank's share stays in HBM for
+   fk_shard_write.  Returns FK_EHIP with a message if the exchange did not conserve records or k-mers. */
+extern "C" int fk_shard_count(fk_shard *sh, fk_result *res)
+{ if (sh == NULL || res == NULL) return (FK_EINVAL);
+  fk_ctx *ctx = sh->ctx;
+  const int W = sh->world, R = sh->rounds, me = sh->rank, nb = ctx->prm.nbuckets;
+  const int stride = ctx->wid.smer_stride;
+  FK_HIP(ctx, hipSetDevice(ctx->device));
+  if (ctx->chunk_bytes > 0 || ctx->prm.exact_parts)
+    { fk_set_error(ctx, "fk_shard_count: the sharded run keeps its stripe of reads resident (hbm_budget 0, no exact_parts)");
+      return (FK_EUNSUPPORTED);
+    }
+  FK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+  FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+
+  // ---- split this rank's reads into bucketed super-mers (planned regions, exact pair on overflow)
+  int64_t cap = 0, offs[257], cnt[256], ninst = 0;
+  void   *outbox = NULL;
+  memset(cnt, 0, sizeof(cnt));
+  memset(offs, 0, sizeof(offs));
+  int rc = fkx_split_plan(ctx, ctx->d_reads, ctx->reads_len, &cap, offs);
+  if (rc != FK_OK) return (rc);
+  if (cap > 0)
+    { if ((outbox = fk_slot(ctx, FK_SLOT_SM_A, cap * stride)) == NULL) return (FK_ENOMEM);
+      rc = fkx_split_planned(ctx, ctx->d_reads, ctx->reads_len, outbox, cap, offs, cnt, &ninst);
+      if (rc == FK_ESTATE)
+        { int64_t ns = 0;
+          if ((rc = fkx_split(ctx, ctx->d_reads, ctx->reads_len, NULL, 0, &ns, &ninst, cnt, false)) != FK_OK) return (rc);
+          if ((outbox = fk_slot(ctx, FK_SLOT_SM_A, std::max<int64_t>(ns, 1) * stride)) == NULL) return (FK_ENOMEM);
+          if (ns > 0 && (rc = fkx_split(ctx, ctx->d_reads, ctx->reads_len, outbox, ns, &ns, &ninst, cnt, true)) != FK_OK)
+            return (rc);
+          int64_t run = 0;
+          for (int b = 0; b < nb; b++) { offs[b] = run; run += cnt[b]; }
+        }
+      else if (rc != FK_OK)
+        return (rc);
+    }
+
+  // ---- who sends how much to whom: all[s*nb + b] = records of bucket b at rank s
+  std::vector<int64_t> all((size_t) W * nb);
+  if ((rc = allgather_i64(sh, cnt, nb, all.data())) != FK_OK) return (rc);
+  int64_t sent = 0, expect = 0, inmax = 0;
+  for (int b = 0; b < nb; b++) sent += cnt[b];
+  for (int r = 0; r < R; r++)
+    { int64_t in = 0;
+      for (int s = 0; s < W; s++) in += all[(size_t) s * nb + r * W + me];
+      inmax = std::max(inmax, in);
+      expect += in;
+    }
+  for (int i = 0; i < (R > 1 ? 2 : 1); i++)
+    if ((rc = reserve_inbox(sh, i, std::max<int64_t>(inmax, 1) * stride)) != FK_OK) return (rc);
+
+  std::vector<int64_t> nin(R);
+  auto post = [&](int r) -> int
+    { char   *sp[256], *rp[256];
+      int64_t sb[256], rb[256], run = 0;
+      for (int p = 0; p < W; p++)
+        { const int b = r * W + p;
+          sp[p] = (char *) outbox + offs[b] * stride;
+          sb[p] = cnt[b] * stride;
+          rp[p] = (char *) sh->inbox[r & 1] + run * stride;
+          rb[p] = all[(size_t) p * nb + r * W + me] * stride;
+          run += all[(size_t) p * nb + r * W + me];
+        }
+      nin[r] = run;
+      int e = exchange(sh, sp, sb, rp, rb);
+      if (e != FK_OK) return (e);
+      FK_HIP(ctx, hipEventRecord(sh->xev[r & 1], sh->xs));
+      return (FK_OK);
+    };
+
+  // ---- rounds: piece r+1 travels while piece r is counted
+  if ((rc = fk_rounds_begin(ctx)) != FK_OK) return (rc);
+  if ((rc = post(0)) != FK_OK) return (rc);
+  for (int r = 0; r < R; r++)
+    { FK_HIP(ctx, hipEventSynchronize(sh->xev[r & 1]));
+      if (r + 1 < R && (rc = post(r + 1)) != FK_OK) return (rc);      // inbox (r+1)&1 was consumed by round r-1
+      if ((rc = fk_rounds_add(ctx, sh->inbox[r & 1], nin[r])) != FK_OK) return (rc);
+    }
+  if ((rc = fk_rounds_finish(ctx, 0, &sh->local)) != FK_OK) return (rc);
+  FK_HIP(ctx, hipStreamSynchronize(sh->xs));
+  for (int x = 0; x < 256; x++)
+    sh->lfirst[x] = sh->local.wfirst[x];
+
+  // ---- C2: histogram, totals, census
+  std::vector<int64_t> v(FK_HIST_BINS + 256 + 16, 0);
+  for (int i = 0; i < FK_HIST_BINS; i++) v[i] = sh->local.hist[i];
+  for (int x = 0; x < 256; x++) v[FK_HIST_BINS + x] = sh->local.wfirst[x];
+  int64_t *t = v.data() + FK_HIST_BINS + 256;
+  t[0] = sh->local.max_inst; t[1] = ninst; t[2] = sent; t[3] = sh->local.ndistinct_super; t[4] = sh->local.nweighted;
+  t[5] = sh->local.ndistinct; t[6] = sh->local.ntable; t[7] = expect; t[8] = sh->local.nsuper;
+  if ((rc = allreduce_i64(sh, v.data(), (int) v.size())) != FK_OK) return (rc);
+  memset(res, 0, sizeof(*res));
+  for (int i = 0; i < FK_HIST_BINS; i++) res->hist[i] = v[i];
+  for (int x = 0; x < 256; x++) res->wfirst[x] = v[FK_HIST_BINS + x];
+  res->max_inst = t[0]; res->ninst = t[1]; res->nsuper = t[2]; res->ndistinct_super = t[3]; res->nweighted = t[4];
+  res->ndistinct = t[5]; res->ntable = t[6];
+  res->ms_split = sh->local.ms_split; res->ms_sort_super = sh->local.ms_sort_super; res->ms_expand = sh->local.ms_expand;
+  res->ms_sort_kmer = sh->local.ms_sort_kmer; res->ms_count = sh->local.ms_count; res->ms_total = sh->local.ms_total;
+  res->buckets_counted = sh->local.buckets_counted;
+  // conservation: every record sent was received and counted, every k-mer instance is in the histogram
+  if (t[2] != t[7] || t[2] != t[8])
+    { fk_set_error(ctx, "sharded run: the exchange lost records (%lld sent, %lld expected, %lld counted)",
+                   (long long) t[2], (long long) t[7], (long long) t[8]);
+      return (FK_EHIP);
+    }
+  { int64_t tot = res->max_inst;
+    for (int c = 1; c < 0x7fff; c++) tot += (int64_t) c * res->hist[c];
+    if (tot != res->ninst)
+      { fk_set_error(ctx, "sharded run: %lld k-mer instances were split but the histogram holds %lld",
+                     (long long) res->ninst, (long long) tot);
+        return (FK_EHIP);
+      }
+  }
+  return (FK_OK);
+}
+
+// device stride -> reference width (k-mer bytes + uint16 count), one thread per record
+__global__ __launch_bounds__(256) void k_sh_repack(const uint8_t *__restrict__ in, int64_t n, int stride, int kbytes,
+                                                   uint8_t *__restrict__ out)
+{ const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t *r = in + i * stride;
+  uint8_t *o = out + i * (kbytes + 2);
+  for (int j = 0; j < kbytes; j++) o[j] = r[j];
+  o[kbytes] = r[stride - 2];
+  o[kbytes + 1] = r[stride - 1];
+}
+
+/* C3 + output files after fk_shard_count: <dir>/<root>.hist and the .ktab stub from rank 0, the hidden parts
+   .<root>.ktab.<rank*m+1 .. rank*m+m> from every rank (m = nparts / world; nparts must be a multiple of the
+   ranks).  With table_cutoff 0 only the histogram is written.  The files are byte for byte those
+   fk_write_hist / fk_write_ktab write in a one-GPU run with -T nparts. */
+extern "C" int fk_shard_write(fk_shard *sh, const fk_result *res, int nparts, const char *dir, const char *root)
+{ if (sh == NULL || res == NULL || dir == NULL || root == NULL) return (FK_EINVAL);
+  fk_ctx *ctx = sh->ctx;
+  const int W = sh->world, me = sh->rank;
+  const fk_widths &w = ctx->wid;
+  const int cutoff = ctx->prm.table_cutoff;
+  FK_HIP(ctx, hipSetDevice(ctx->device));
+  if (me == 0)
+    { char path[4096];
+      snprintf(path, sizeof(path), "%s/%s.hist", dir, root);
+      int rc = fk_write_hist(res, ctx->prm.kmer, path);
+      if (rc != FK_OK) return (rc);
+    }
+  if (cutoff <= 0)
+    return (FK_OK);
+  if (nparts < W || nparts % W != 0)
+    { fk_set_error(ctx, "fk_shard_write: %d parts cannot be dealt to %d ranks", nparts, W);
+      return (FK_EINVAL);
+    }
+  const int m = nparts / W;
+  std::vector<int> split(nparts + 1);
+  int rc = fk_ktab_split(res->wfirst, ctx->prm.kmer, nparts, split.data());
+  if (rc != FK_OK) return (rc);
+  const int ib = fk_ktab_idx_bytes(ctx->prm.kmer, res->ntable);
+
+  // this rank's sorted table: the entries of first-byte range d go to rank d
+  const char *tab = (const char *) ctx->last_table;
+  int64_t pre[257];
+  pre[0] = 0;
+  for (int x = 0; x < 256; x++) pre[x + 1] = pre[x] + sh->lfirst[x];
+  if (pre[256] != ctx->last_ntab)
+    { fk_set_error(ctx, "fk_shard_write: census (%lld) and table (%lld entries) disagree", (long long) pre[256],
+                   (long long) ctx->last_ntab);
+      return (FK_ESTATE);
+    }
+  std::vector<int64_t> mine(W), all((size_t) W * W);
+  for (int d = 0; d < W; d++)
+    mine[d] = pre[split[(d + 1) * m]] - pre[split[d * m]];
+  if ((rc = allgather_i64(sh, mine.data(), W, all.data())) != FK_OK) return (rc);
+  int64_t nin = 0;
+  for (int s = 0; s < W; s++) nin += all[(size_t) s * W + me];
+  const int64_t bytes = std::max<int64_t>(nin, 1) * w.kmer_stride;
+  char *a = NULL, *b = NULL;
+  if (hipMalloc((void **) &a, (size_t) bytes) != hipSuccess || hipMalloc((void **) &b, (size_t) bytes) != hipSuccess)
+    { if (a) hipFree(a);
+      fk_set_error(ctx, "out of HBM: cannot allocate 2 x %lld bytes for this rank's range of the table", (long long) bytes);
+      return (FK_ENOMEM);
+    }
+  do
+    { char   *sp[256], *rp[256];
+      int64_t sb[256], rb[256], run = 0;
+      for (int p = 0; p < W; p++)
+        { sp[p] = (char *) tab + pre[split[p * m]] * w.kmer_stride;
+          sb[p] = mine[p] * w.kmer_stride;
+          rp[p] = a + run * w.kmer_stride;
+          rb[p] = all[(size_t) p * W + me] * w.kmer_stride;
+          run += all[(size_t) p * W + me];
+        }
+      FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      if ((rc = exchange(sh, sp, sb, rp, rb)) != FK_OK) break;
+      if (hipStreamSynchronize(sh->xs) != hipSuccess) { rc = FK_EHIP; break; }
+      // W sorted runs of disjoint k-mer sets -> one sorted range
+      void *sorted = a;
+      int   bytes_list[64];
+      for (int i = 0; i < w.kmer_bytes; i++) bytes_list[i] = w.kmer_bytes - 1 - i;
+      if (W > 1 && nin > 0
+          && (rc = fkx_lsd_sort(ctx, nin, a, b, w.kmer_stride, bytes_list, w.kmer_bytes, &sorted)) != FK_OK)
+        break;
+      const int64_t hbytes = std::max<int64_t>(nin, 1) * w.kmer_word;
+      uint8_t *host = NULL;
+      if (hipHostMalloc((void **) &host, (size_t) hbytes, hipHostMallocDefault) != hipSuccess)
+        { fk_set_error(ctx, "out of host memory: cannot pin %lld bytes for this rank's table range", (long long) hbytes);
+          rc = FK_ENOMEM;
+          break;
+        }
+      const void *src = sorted;
+      if (w.kmer_word != w.kmer_stride && nin > 0)
+        { void *other = (sorted == (void *) a) ? (void *) b : (void *) a;
+          hipLaunchKernelGGL(k_sh_repack, dim3((unsigned) ((nin + 255) / 256)), dim3(256), 0, ctx->stream,
+                             (const uint8_t *) sorted, nin, w.kmer_stride, w.kmer_bytes, (uint8_t *) other);
+          src = other;
+        }
+      if (nin > 0
+          && (hipMemcpyAsync(host, src, (size_t) (nin * w.kmer_word), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess
+              || hipStreamSynchronize(ctx->stream) != hipSuccess))
+        { hipHostFree(host); rc = FK_EHIP; break; }
+      int64_t npre = 1;
+      for (int i = 0; i < ib; i++) npre *= 256;
+      std::vector<int64_t> pc((size_t) npre, 0);
+      rc = fk_write_ktab_range(host, nin, ctx->prm.kmer, ib, split.data(), me * m, m, dir, root, pc.data());
+      hipHostFree(host);
+      if (rc != FK_OK) break;
+      // per-prefix entry counts of all ranks -> rank 0 writes the stub
+      int64_t *d_pc = NULL;
+      if (hipMalloc((void **) &d_pc, (size_t) npre * 8) != hipSuccess) { rc = FK_ENOMEM; break; }
+      if (hipMemcpyAsync(d_pc, pc.data(), (size_t) npre * 8, hipMemcpyHostToDevice, sh->xs) != hipSuccess
+          || g_rccl.AllReduce(d_pc, d_pc, (size_t) npre, ncclInt64, ncclSum, sh->comm, sh->xs) != ncclSuccess
+          || hipMemcpyAsync(pc.data(), d_pc, (size_t) npre * 8, hipMemcpyDeviceToHost, sh->xs) != hipSuccess
+          || hipStreamSynchronize(sh->xs) != hipSuccess)
+        { hipFree(d_pc);
+          fk_set_error(ctx, "fk_shard_write: reducing the prefix counts failed");
+          rc = FK_EHIP;
+          break;
+        }
+      hipFree(d_pc);
+      int64_t tot = 0;
+      for (int64_t i = 0; i < npre; i++) tot += pc[(size_t) i];
+      if (tot != res->ntable)
+        { fk_set_error(ctx, "sharded run: the table exchange lost entries (%lld written, %lld counted)", (long long) tot,
+                       (long long) res->ntable);
+          rc = FK_EHIP;
+          break;
+        }
+      if (me == 0)
+        rc = fk_write_ktab_stub(ctx->prm.kmer, nparts, cutoff, ib, pc.data(), dir, root);
+    }
+  while (0);
+  hipFree(a);
+  hipFree(b);
+  return (rc);
+}

@@ -1,7 +1,7 @@
 /* FastK_amd.c -- host driver with FastK's command line over libfastk_amd.so.
  *
  *   FastK_amd [-k<int(40)>] [-t[<int(1)>]] [-p[:<table>[.ktab]]] [-c] [-bc<int>] [-v] [-x] [-N<path_name>] [-P<dir>] [-M<int>]
- *             [-T<int(4)>] <source>[.fa|.fasta|.fq|.fastq][.gz]|.sam|.bam ...
+ *             [-T<int(4)>] [-G<int(1)>] <source>[.fa|.fasta|.fq|.fastq][.gz]|.sam|.bam ...
  *
  * Same flags, defaults, output names and encodings as the reference driver (FastK.c:34-37,
  * 250-319, 361-409): <root>.hist always, <root>.ktab + hidden .<root>.ktab.<1..T> with -t,
@@ -24,6 +24,12 @@
  * fixes the number of super-mer buckets, split.c:617-766): the reads are split into super-mers chunk
  * by chunk and the minimizer buckets are counted one after the other; the number of buckets is
  * derived from the input size.  Without -M everything stays resident in one bucket (fastest).
+ * -G<int>: that many GPUs of this node, one process each (extension; the reference has threads, not devices):
+ * the program starts -G copies of itself, every copy reads its stripe of the input (plain FASTA / FASTQ: a byte
+ * range cut at record starts, io.c:2455-2521; anything else: every -G'th block of reads), the super-mers travel
+ * to the GPU that owns their minimizer bucket with RCCL (fk_shard_count), and every rank writes the hidden
+ * .ktab parts of its own first-byte range (fk_shard_write); -T is rounded up to a multiple of -G.  The files
+ * are those of the one-GPU run with that -T.
  * SAM and BAM input follow io.c:1314-1495 (secondary / supplementary records skipped).
  * Accepted for compatibility and ignored: -P (no temporary files exist).  Rejected with a message:
  * CRAM and Dazzler inputs.
@@ -37,6 +43,9 @@
 #include <fcntl.h>
 #include <unistd.h>
 #include <pthread.h>
+#include <time.h>
+#include <sys/types.h>
+#include <sys/wait.h>
 
 #include "../../../include/fastk_amd.h"
 
@@ -57,6 +66,11 @@ static int       KMER = 40, NTHREADS = 4, DO_TABLE = 0, BC_PREFIX = 0, VERBOSE =
 static int       HOST_PARSE = 0, COMPRESS = 0, PROFILE = 0;
 static char     *PRO_NAME = NULL;
 static char     *OUT_NAME = NULL;
+/* -G<n>: one process per GPU.  The parent starts n copies of itself (before it has touched any GPU) with
+   --fk-rank=<r> --fk-idfile=<path>; RANK >= 0 marks such a copy. */
+static int       RANK = -1, ROUNDS = 4;
+static char     *ID_FILE = NULL;
+static int64_t   BLOCK_NO = 0;     /* host-parsed input of a sharded run: block j belongs to rank j mod n */
 
 typedef struct
   { fk_ctx  *ctx;
@@ -122,6 +136,8 @@ static void flush_block(Feeder *f, int rem)
       f->pbytes += pr.nbytes;
       f->preads += pr.nreads;
     }
+  else if (RANK >= 0 && NGPUS > 1 && !rem && (BLOCK_NO++ % NGPUS) != RANK)
+    ;                               /* another rank's block (any division of the reads gives the same counts) */
   else if (fk_push_block(f->ctx,f->bases,f->boff,f->nreads,rem,0) != FK_OK)
     die(f->ctx,"fk_push_block");
   f->nreads  = 0;
@@ -274,6 +290,50 @@ static int parallel_read(int fd, char *dst, off_t off, size_t max)
   return (n);
 }
 
+/* First record start at or after byte `from` of a plain FASTA / FASTQ file (the file size if there is none):
+   the reference stripes its input over threads the same way (io.c:2455-2521).  FASTA: a '>' that begins a
+   line.  FASTQ: a line that begins with '@' whose next-but-one line begins with '+' (a quality line may begin
+   with '@' too, but then the next-but-one line is a sequence). */
+static off_t record_start(int fd, off_t from, off_t size, int fastq)
+{ enum { WIN = 1 << 20 };
+  static char *win = NULL;
+  off_t  pos = from;
+  off_t  cand = -1;           /* FASTQ: start of a line that begins with '@' */
+  int    lines_after = 0, atbol;
+
+  if (from <= 0) return (0);
+  if (win == NULL && (win = malloc(WIN)) == NULL)
+    { fprintf(stderr,"%s: Out of memory\n",Prog_Name); exit (1); }
+  { char c;                   /* are we at the beginning of a line? */
+    atbol = (pread(fd,&c,1,from-1) == 1 && c == '\n');
+  }
+  while (pos < size)
+    { ssize_t n = pread(fd,win,WIN,pos), i;
+      if (n <= 0) break;
+      for (i = 0; i < n; i++)
+        { char c = win[i];
+          if (atbol)
+            { if (!fastq)
+                { if (c == '>') return (pos+i); }
+              else
+                { if (cand >= 0)
+                    { lines_after += 1;
+                      if (lines_after == 2)
+                        { if (c == '+') return (cand);
+                          cand = -1;
+                        }
+                    }
+                  if (cand < 0 && c == '@')
+                    { cand = pos+i; lines_after = 0; }
+                }
+            }
+          atbol = (c == '\n');
+        }
+      pos += n;
+    }
+  return (size);
+}
+
 static void scan_text_on_device(Feeder *f, const char *path, int fastq)
 { gzFile in = NULL;
   int    fd = -1;
@@ -295,8 +355,14 @@ static void scan_text_on_device(Feeder *f, const char *path, int fastq)
   if (raw == NULL && fk_host_alloc(RAW_BYTES,(void **) &raw) != FK_OK)
     die(NULL,"pinned read buffer");
   flush_block(f,0);                        /* keep the order of reads across input files */
-  off_t foff = 0;
-  while ((n = (in != NULL) ? gzread(in,raw,RAW_BYTES) : parallel_read(fd,raw,foff,RAW_BYTES)) > 0)
+  off_t foff = 0, fend = -1;
+  if (fd >= 0 && RANK >= 0 && NGPUS > 1)   /* this rank's stripe of the file, cut at record starts */
+    { off_t size = lseek(fd,0,SEEK_END);
+      foff = record_start(fd,(off_t) ((double) size*RANK/NGPUS),size,fastq);
+      fend = (RANK+1 == NGPUS) ? size : record_start(fd,(off_t) ((double) size*(RANK+1)/NGPUS),size,fastq);
+    }
+  while ((n = (in != NULL) ? gzread(in,raw,RAW_BYTES)
+                           : parallel_read(fd,raw,foff,(fend >= 0 && fend-foff < RAW_BYTES) ? (size_t) (fend-foff) : RAW_BYTES)) > 0)
     { int64_t nr = 0, nb = 0;
       foff += n;
       if (fastq)
@@ -481,6 +547,79 @@ static void scan_bam(Feeder *f, const char *path)
   gzclose(in);
 }
 
+/* -G<n>: the parent never touches a GPU.  It starts n copies of this program, one per GPU, each told its rank
+   and the path of a file through which rank 0 hands the RCCL unique id to the others, and waits for them.
+   FK_RANKS_SHARE_GPU=1 (test rig for boxes with a single GPU): all ranks use device 0 and get a NCCL_HOSTID of
+   their own, so that RCCL accepts them and moves the payload over its socket transport. */
+static int launch_ranks(int argc, char **argv)
+{ char  idfile[256], self[4096];
+  pid_t pid[64];
+  int   r, status, rc = 0;
+  ssize_t sl = readlink("/proc/self/exe",self,sizeof(self)-1);
+
+  if (sl <= 0 || NGPUS > 64)
+    { fprintf(stderr,"%s: cannot start %d ranks\n",Prog_Name,NGPUS); exit (1); }
+  self[sl] = '\0';
+  snprintf(idfile,sizeof(idfile),"/tmp/.fastk_amd_id_%d_%ld",(int) getpid(),(long) time(NULL));
+  unlink(idfile);
+  for (r = 0; r < NGPUS; r++)
+    { pid[r] = fork();
+      if (pid[r] < 0)
+        { fprintf(stderr,"%s: fork failed\n",Prog_Name); exit (1); }
+      if (pid[r] == 0)
+        { char **av = malloc(sizeof(char *)*(argc+3));
+          char  *a1 = malloc(64), *a2 = malloc(300);
+          int    k;
+          for (k = 0; k < argc; k++) av[k] = argv[k];
+          snprintf(a1,64,"--fk-rank=%d",r);
+          snprintf(a2,300,"--fk-idfile=%s",idfile);
+          av[argc] = a1; av[argc+1] = a2; av[argc+2] = NULL;
+          if (getenv("FK_RANKS_SHARE_GPU") != NULL)
+            { char host[64];
+              snprintf(host,sizeof(host),"fk-rank-%d",r);
+              setenv("NCCL_HOSTID",host,1);
+              setenv("NCCL_SOCKET_IFNAME","lo",0);
+              setenv("NCCL_IB_DISABLE","1",0);
+            }
+          execv(self,av);
+          fprintf(stderr,"%s: cannot start rank %d\n",Prog_Name,r);
+          _exit (1);
+        }
+    }
+  for (r = 0; r < NGPUS; r++)
+    if (waitpid(pid[r],&status,0) < 0 || !WIFEXITED(status) || WEXITSTATUS(status) != 0)
+      rc = 1;
+  unlink(idfile);
+  return (rc);
+}
+
+/* rank 0 writes the 128 bytes (temporary name, then rename: readers never see a partial file) */
+static void share_unique_id(char *id)
+{ char tmp[400];
+  int  tries;
+  if (RANK == 0)
+    { FILE *f;
+      if (fk_shard_unique_id(id) != FK_OK)
+        die(NULL,"fk_shard_unique_id");
+      snprintf(tmp,sizeof(tmp),"%s.tmp",ID_FILE);
+      f = fopen(tmp,"wb");
+      if (f == NULL || fwrite(id,1,128,f) != 128 || fclose(f) != 0 || rename(tmp,ID_FILE) != 0)
+        { fprintf(stderr,"%s: cannot write %s\n",Prog_Name,ID_FILE); exit (1); }
+      return;
+    }
+  for (tries = 0; tries < 6000; tries++)         /* up to a minute */
+    { FILE *f = fopen(ID_FILE,"rb");
+      if (f != NULL)
+        { size_t n = fread(id,1,128,f);
+          fclose(f);
+          if (n == 128) return;
+        }
+      usleep(10000);
+    }
+  fprintf(stderr,"%s: rank %d never received the RCCL id\n",Prog_Name,RANK);
+  exit (1);
+}
+
 int main(int argc, char *argv[])
 { fk_params  prm;
   fk_ctx    *ctx;
@@ -489,6 +628,11 @@ int main(int argc, char *argv[])
   char      *root = NULL, *dir = NULL, name[4096];
   int        i, j, nfiles, ftype = -1;
 
+  int    argc0 = argc;
+  char **argv0 = malloc(sizeof(char *)*(argc+4));
+  for (i = 0; i < argc; i++)
+    argv0[i] = argv[i];
+
   /* Option rules of the reference (FastK.c:250-319 with ARG_FLAGS / ARG_POSITIVE / ARG_NON_NEGATIVE of
      gene_core.h:37-70): the letters v c p t combine in one argument (-vt, -tp); -t<int>, -k, -T, -M,
      -bc take a whole decimal number or the run ends with the reference's message.  -x and -H are this
@@ -496,7 +640,11 @@ int main(int argc, char *argv[])
   { int flags[128], k, g;
     memset(flags,0,sizeof(flags));
     for (i = j = 1; i < argc; i++)
-      if (argv[i][0] == '-')
+      if (strncmp(argv[i],"--fk-rank=",10) == 0)
+        RANK = atoi(argv[i]+10);
+      else if (strncmp(argv[i],"--fk-idfile=",12) == 0)
+        ID_FILE = argv[i]+12;
+      else if (argv[i][0] == '-')
         { int   isflags = 0;
           char *num = NULL, *what = NULL;
           int  *var = NULL, nonneg = 0;
@@ -576,6 +724,13 @@ int main(int argc, char *argv[])
     argv[i] = resolve_input(argv[i]);
 
 
+  if (NGPUS > 1 && (PROFILE || EXACT || PRO_NAME != NULL))
+    { fprintf(stderr,"%s: -G%d counts k-mers (.hist, .ktab); -p and -x run on one GPU\n",Prog_Name,NGPUS);
+      exit (1);
+    }
+  if (NGPUS > 1 && RANK < 0)
+    return (launch_ranks(argc0,argv0));
+
   double t_start = now(), t_ingest, t_count, t_write;
 
   fk_default_params(&prm);
@@ -613,8 +768,24 @@ int main(int argc, char *argv[])
                   MEM_GB,bases/1e9,nb);
       }
     }
+  fk_shard *shard = NULL;
+  if (RANK >= 0 && NGPUS > 1)
+    { /* one of the ranks of a -G run: its own GPU, world x ROUNDS minimizer buckets (bucket r*world+d goes to
+         rank d in exchange round r), its stripe of the reads resident */
+      prm.device     = (getenv("FK_RANKS_SHARE_GPU") != NULL) ? 0 : RANK;
+      prm.nbuckets   = NGPUS*ROUNDS;
+      prm.hbm_budget = 0;
+      if (prm.nbuckets > 256)
+        prm.nbuckets = NGPUS*(256/NGPUS);
+    }
   if (fk_create(&prm,&ctx) != FK_OK)
     die(NULL,"fk_create");
+  if (RANK >= 0 && NGPUS > 1)
+    { char id[128];
+      share_unique_id(id);
+      if (fk_shard_create(ctx,RANK,NGPUS,id,&shard) != FK_OK)
+        die(ctx,"fk_shard_create");
+    }
 
   memset(&feed,0,sizeof(feed));
   feed.ctx   = ctx;
@@ -651,7 +822,8 @@ int main(int argc, char *argv[])
         scan_sam(&feed,argv[i]);
       else if (q == 3)
         scan_bam(&feed,argv[i]);
-      else if (!EXACT && BC_PREFIX == 0 && !HOST_PARSE && (q == 1 || !(COMPRESS || PROFILE)))
+      else if (!EXACT && BC_PREFIX == 0 && !HOST_PARSE && (q == 1 || !(COMPRESS || PROFILE))
+               && !(NGPUS > 1 && strlen(argv[i]) > 3 && strcmp(argv[i]+strlen(argv[i])-3,".gz") == 0))
         scan_text_on_device(&feed,argv[i],q);
       else
         scan_file(&feed,argv[i],q);
@@ -688,6 +860,26 @@ int main(int argc, char *argv[])
       if (VERBOSE)
         fprintf(stderr,"  Profiles of %lld reads relative to %lld %d-mers of %s in %lld bytes\n",
                 (long long) pr.nreads,(long long) n,KMER,PRO_NAME,(long long) pr.nbytes);
+      fk_destroy(ctx);
+      exit (0);
+    }
+  if (shard != NULL)
+    { /* exchange + count + all-reduce, then the second exchange and this rank's share of the files */
+      int nparts = ((NTHREADS+NGPUS-1)/NGPUS)*NGPUS;
+      if (fk_shard_count(shard,res) != FK_OK)
+        die(ctx,"fk_shard_count");
+      t_count = now();
+      if (fk_shard_write(shard,res,nparts,dir,root) != FK_OK)
+        die(ctx,"fk_shard_write");
+      t_write = now();
+      if (VERBOSE && RANK == 0)
+        { fprintf(stderr,"\n  %d ranks: %lld %d-mers in %lld super-mers, %lld weighted k-mers, %lld distinct, %lld in the table (%d parts)\n",
+                  NGPUS,(long long) res->ninst,KMER,(long long) res->nsuper,(long long) res->nweighted,
+                  (long long) res->ndistinct,(long long) res->ntable,nparts);
+          fprintf(stderr,"  Wall s (rank 0): start-up + ingest %.3f  exchange + count %.3f  table exchange + write %.3f\n",
+                  t_ingest-t_start,t_count-t_ingest,t_write-t_count);
+        }
+      fk_shard_destroy(shard);
       fk_destroy(ctx);
       exit (0);
     }

@@ -383,6 +383,34 @@ int fk_rounds_begin(fk_ctx *ctx);
 int fk_rounds_add(fk_ctx *ctx, void *d_smers, int64_t nsuper);
 int fk_rounds_finish(fk_ctx *ctx, int fetch_table, fk_result *res);
 
+/* ---- the sharded run from a C host: one process per GPU, RCCL over xGMI ------------
+ * Replaces the reference's file traffic between its phases on a node with several GPUs: the ".T"
+ * super-mer shuffle (split.c:1263 <-> count.c:1347) becomes grouped ncclSend/ncclRecv of SMER_WORD
+ * records keyed by minimizer bucket, the histogram reduce (count.c:1543-1553) an all-reduce, and the
+ * merge of the per-bucket tables (table.c:346-533) a second exchange keyed by the first k-mer byte after
+ * which every rank writes the hidden .ktab parts of its own first-byte range.  Reads are striped over
+ * the ranks by the host (io.c:2455-2521 stripes them over threads).  RCCL is loaded at run time.
+ *
+ *   rank 0:      fk_shard_unique_id(id)            and hands the 128 bytes to the other ranks (file, pipe)
+ *   every rank:  fk_create(nbuckets = world * rounds, device = its GPU, hbm_budget 0)
+ *                fk_shard_create(ctx, rank, world, id, &sh)
+ *                fk_push_block / fk_push_fastq / fk_push_fasta / fk_push_device   its stripe of the reads
+ *                fk_shard_count(sh, &res)          C1: bucket r*world+d -> rank d in round r, round r+1 travels
+ *                                                  while round r is counted; C2: res = GLOBAL histogram,
+ *                                                  totals and first-byte census, identical on all ranks
+ *                                                  (res.table is NULL: each rank's share stays in HBM);
+ *                                                  fails if records or k-mer instances were not conserved
+ *                fk_shard_write(sh, &res, nparts, dir, root)   C3 + files, byte for byte those of a one-GPU
+ *                                                  run with -T nparts (nparts a multiple of world)
+ *                fk_shard_destroy(sh); fk_destroy(ctx)
+ */
+typedef struct fk_shard fk_shard;
+int  fk_shard_unique_id(char *id128);
+int  fk_shard_create(fk_ctx *ctx, int rank, int world, const char *id128, fk_shard **sh);
+int  fk_shard_count(fk_shard *sh, fk_result *res);
+int  fk_shard_write(fk_shard *sh, const fk_result *res, int nparts, const char *dir, const char *root);
+void fk_shard_destroy(fk_shard *sh);
+
 /* ---- utilities ---------------------------------------------------------------------------*/
 
 /* Fill d_bases with synthetic reads first_read .. first_read+nreads-1 of include/fk_synth.h,

@@ -748,6 +748,48 @@ _RCCL_RIG_ERRORS = ("ncclInvalidUsage", "ncclSystemError", "ncclUnhandledCudaErr
                     "unhandled system error", "invalid usage")
 
 
+@pytest.mark.parametrize("name,fmt,ranks", [("synth_illumina_k40_t1_T4", "fastq", 2), ("synth_illumina_k40_t1_T4", "fastq", 4),
+                                             ("synth_hifi_k40_t4_T8", "fasta", 2), ("edge_k40_t1_T4", "fasta", 4),
+                                             ("synth_illumina_k51_t1_T4", "fastq", 2), ("configs0_k40_t1_T4", "fastq", 4)])
+def test_c_driver_sharded_over_rccl_writes_the_one_gpu_files(name, fmt, ranks, tmp_path):
+    """FastK_amd -G<n>: the C host starts one process per rank, every rank reads its stripe of the file,
+    the super-mers travel by minimizer bucket and the table entries by first byte with RCCL called from
+    C (fk_shard_count / fk_shard_write, no Python, no host staging of the payload), and every rank writes
+    its own hidden .ktab parts.  On this one-GPU box the ranks share device 0 (FK_RANKS_SHARE_GPU=1: RCCL
+    then moves the payload over its socket transport).  Every file must be byte-identical to the one-GPU
+    run with the same -T, and .hist / the canonical stream must be the reference's."""
+    import os, subprocess
+    case, bases, boff = util.load_case(name)
+    exp = case["expected"]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "fastk_amd", "bin", "FastK_amd")
+    path = str(tmp_path / ("reads." + fmt))
+    if case["kind"] == "edge":
+        orc.write_fasta(path, bases, boff)
+    else:
+        util.write_fastx(path, bases, boff, fmt == "fastq")
+    T = 4
+    args = ["-k%d" % case["k"], "-t%d" % case["cutoff"], "-T%d" % T]
+    one, many = tmp_path / "one", tmp_path / "many"
+    one.mkdir(); many.mkdir()
+    subprocess.run([exe] + args + ["-N" + str(one / "x"), path], check=True)
+    env = dict(os.environ, FK_RANKS_SHARE_GPU="1")
+    p = subprocess.run([exe] + args + ["-v", "-G%d" % ranks, "-N" + str(many / "x"), path], env=env, capture_output=True, text=True,
+                       timeout=900)
+    if p.returncode != 0 and any(m in p.stdout + p.stderr for m in _RCCL_RIG_ERRORS):
+        if os.environ.get("FK_REQUIRE_RANKS") == "1":
+            pytest.fail("RCCL would not bring up %d ranks on one GPU: %s" % (ranks, p.stderr[-500:]))
+        pytest.skip("RCCL would not bring up several ranks on one GPU here: " + p.stderr[-300:])
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    files = sorted(os.listdir(one))
+    assert files == sorted(os.listdir(many)) and len(files) == 2 + T
+    for f in files:
+        assert util.sha_file(one / f) == util.sha_file(many / f), f
+    assert util.sha_file(many / "x.hist") == exp["hist_sha256"]
+    t = orc.read_ktab(str(many / "x"))
+    assert t["stream_sha256"] == exp["ktab"]["stream_sha256"] and t["nels"] == exp["ktab"]["nels"]
+
+
 @pytest.mark.parametrize("ranks", [2, 4])
 def test_ranks_on_one_gpu_match_one_context(ranks):
     """A real exchange between processes: `ranks` RCCL ranks share device 0 (tools/ranks_on_one_gpu.py
