@@ -322,9 +322,17 @@ def write_table_sharded(table, wfirst, ntable, kmer, cutoff, parts_per_rank, out
     if world > 1 and mine.shape[0]:
         mine = sort_fn(mine)                       # world sorted runs -> one
     cnt = api.write_ktab_range(mine, kmer, ib, split, rank * parts_per_rank, parts_per_rank, outdir, root)
+    written = int(cnt.sum())                        # (before the reduce: on CPU `tot` shares cnt's memory)
     tot = torch.from_numpy(cnt).to(dev)
     dist.reduce(tot, dist.get_global_rank(group, 0) if group is not None else 0, op=dist.ReduceOp.SUM,
                 group=group)
+    # conservation: the prefix counts of what the ranks wrote must add up to the global entry count
+    # (a collective that drops or duplicates entries must never produce a table that merely looks fine)
+    chk = torch.tensor([written, table.shape[0]], dtype=torch.int64, device=dev)
+    dist.all_reduce(chk, op=dist.ReduceOp.SUM, group=group)
+    if int(chk[0]) != int(ntable) or int(chk[1]) != int(ntable):
+        raise RuntimeError("table exchange lost entries: %d written, %d held by the ranks, %d counted"
+                           % (int(chk[0]), int(chk[1]), int(ntable)))
     if rank == 0:
         api.write_ktab_stub(kmer, nparts, cutoff, ib, tot.cpu().numpy(), outdir, root)
     dist.barrier(group=group)
@@ -355,6 +363,20 @@ def allgather_table(table, group=None):
         for c in range(0, seg.numel(), per):
             dist.broadcast(seg[c:c + per], src, group=group)
         o += sizes[r] * kw
+    # conservation: every rank must now hold the bytes every source holds (per source segment the sum of
+    # all bytes and of every third byte, compared across ranks by min/max reductions)
+    sums = torch.zeros(2 * world, dtype=torch.int64, device=dev)
+    o = 0
+    for r in range(world):
+        seg = out[o:o + sizes[r] * kw]
+        sums[2 * r] = seg.sum(dtype=torch.int64)
+        sums[2 * r + 1] = seg[::3].sum(dtype=torch.int64)
+        o += sizes[r] * kw
+    lo, hi = sums.clone(), sums.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    if not torch.equal(lo, hi):
+        raise RuntimeError("table all-gather corrupted the payload (per-source checksums differ between ranks)")
     return out.cpu().numpy().reshape(-1, kw)
 
 
@@ -412,10 +434,21 @@ def profiles_exchanged(engine, reads, group=None, fetch_table=False):
     tot[HIST_BINS:HIST_BINS + 6] = torch.tensor([loc["max_inst"], ninst, nrecv, loc["nweighted"], loc["ndistinct"],
                                                  loc["ntable"]], dtype=torch.int64, device=dev)
     dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=group)
+    tot2 = torch.tensor([nsent, nrecv, sum(inst_to), sum(inst_from)], dtype=torch.int64, device=dev)
+    dist.all_reduce(tot2, op=dist.ReduceOp.SUM, group=group)
     t = tot.cpu().numpy()
     totals = dict(hist=t[:HIST_BINS].copy(), max_inst=int(t[HIST_BINS]), ninst=int(t[HIST_BINS + 1]),
                   nsuper=int(t[HIST_BINS + 2]), nweighted=int(t[HIST_BINS + 3]), ndistinct=int(t[HIST_BINS + 4]),
                   ntable=int(t[HIST_BINS + 5]), local=loc)
+    # conservation: records and per-k-mer counts sent == received over all ranks, every k-mer instance split
+    # off the reads is in the histogram
+    if int(tot2[0]) != int(tot2[1]) or int(tot2[2]) != int(tot2[3]):
+        raise RuntimeError("profile exchange lost data: %d records sent, %d received; %d counts expected back, %d sent back"
+                           % tuple(int(x) for x in tot2.tolist()))
+    h = totals["hist"]
+    if int((h[1:0x7fff] * np.arange(1, 0x7fff)).sum()) + totals["max_inst"] != totals["ninst"]:
+        raise RuntimeError("profile exchange: the histogram does not hold the %d k-mer instances that were split"
+                           % totals["ninst"])
     return totals, data, offs
 
 

@@ -805,6 +805,8 @@ def test_ranks_on_one_gpu_match_one_context(ranks):
     spec.loader.exec_module(mod)
     rc, text = mod.parent(world=ranks, port=29650 + ranks)
     if rc != 0 and "MISMATCH" not in text and any(m in text for m in _RCCL_RIG_ERRORS):
+        if os.environ.get("FK_REQUIRE_RANKS") == "1":
+            pytest.fail("RCCL would not bring up %d ranks on one GPU (FK_REQUIRE_RANKS=1): %s" % (ranks, text[-500:]))
         pytest.skip("RCCL would not bring up several ranks on one GPU here: " + text[-300:])
     assert rc == 0, text[-3000:]
     assert text.count("equal to the one-context run") == 4 and "MISMATCH" not in text, text[-3000:]
@@ -822,6 +824,8 @@ def test_bench_contract_with_two_ranks_on_one_gpu():
     env = dict(os.environ, FK_RANKS_SHARE_GPU="1")
     p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
     if p.returncode != 0 and any(m in p.stdout + p.stderr for m in _RCCL_RIG_ERRORS):
+        if os.environ.get("FK_REQUIRE_RANKS") == "1":
+            pytest.fail("RCCL would not bring up two ranks on one GPU (FK_REQUIRE_RANKS=1): " + p.stderr[-500:])
         pytest.skip("RCCL would not bring up two ranks on one GPU here: " + p.stderr[-300:])
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
     lines = [x for x in p.stdout.splitlines() if x.startswith("{")]
