@@ -387,20 +387,29 @@ extern "C" int fk_copy_to_host(fk_ctx *ctx, void *dst, const void *d_src, int64_
   return (FK_OK);
 }
 
-/* Measurement aids for profiles/ (never used by the product path): "radix_variant" 0/1/2 selects
-   ablated radix-pass kernels whose OUTPUT IS WRONG but whose duration isolates one cost. */
+/* Test and measurement knobs (never used by the product path).  Every knob of a normal build keeps
+   results valid (alternative code paths, smaller limits); the kernels whose output is wrong on purpose
+   exist only in -DFK_ABLATION builds. */
 extern "C" int fk_debug_set(fk_ctx *ctx, const char *key, int64_t value)
 { if (ctx == NULL || key == NULL) return (FK_EINVAL);
-  if (strcmp(key, "radix_variant") == 0)
+#ifdef FK_ABLATION
+  if (strcmp(key, "radix_variant") == 0)   // ablated look-back kernels: WRONG output, isolates one cost each
     { ctx->dbg_radix_variant = (int) value;
-      return (FK_OK);
-    }
-  if (strcmp(key, "radix_engine") == 0)
-    { ctx->dbg_radix_engine = (int) value;
       return (FK_OK);
     }
   if (strcmp(key, "radix_items") == 0)
     { ctx->dbg_radix_items = (int) value;
+      return (FK_OK);
+    }
+#else
+  if (strcmp(key, "radix_variant") == 0 || strcmp(key, "radix_items") == 0 || (strcmp(key, "radix_engine") == 0 && value == 1))
+    { fk_set_error(ctx, "fk_debug_set(%s): the look-back radix engine and its ablations are only in builds made with "
+                        "-DFK_ABLATION (make -C fastk_amd/csrc ABLATION=1)", key);
+      return (FK_EUNSUPPORTED);
+    }
+#endif
+  if (strcmp(key, "radix_engine") == 0)    // 2 / 3: narrow / wide stream tiles whatever the width, 4: stable first pass
+    { ctx->dbg_radix_engine = (int) value;
       return (FK_OK);
     }
   if (strcmp(key, "smer_stage") == 0)       // 1: four grouping passes + run detection instead of LDS de-duplication
@@ -423,9 +432,15 @@ extern "C" int fk_debug_set(fk_ctx *ctx, const char *key, int64_t value)
     { ctx->chunk_bytes = value;
       return (FK_OK);
     }
-  if (strcmp(key, "aggr_variant") == 0)     // bit 0: no inserts, bit 1: no histogram, bit 2: no table
-    { ctx->dbg_aggr_variant = (int) value;
+  if (strcmp(key, "aggr_variant") == 0)     // bit 0: no inserts, bit 1: no histogram, bit 2: no table (WRONG output)
+    {
+#ifdef FK_ABLATION
+      ctx->dbg_aggr_variant = (int) value;
       return (FK_OK);
+#else
+      fk_set_error(ctx, "fk_debug_set(aggr_variant): ablations are only in -DFK_ABLATION builds");
+      return (FK_EUNSUPPORTED);
+#endif
     }
   if (strcmp(key, "aggr_limit") == 0)
     { ctx->dbg_aggr_limit = (int) value;

@@ -5,15 +5,16 @@
 //   Supermer_Sort /     MSDsort.c:458-489, 536-544 (radix_sort :129-261)
 //   Weighted_Kmer_Sort                                                -> same engine, key bytes MSB..LSB
 //
-// One digit pass = ONE kernel (k_radix_pass): every workgroup takes a tile of records by ticket,
-// stages it in LDS with 16-byte coalesced loads, ranks the 8-bit digit of its records with
-// wave64 ballots (match-any) into per-wave LDS histograms, obtains the tile's global bin offsets by
-// decoupled look-back over 8-byte {epoch,flag,count} status words (relaxed agent-scope atomics, the
-// count travels inside the word so no other fence is needed), reorders the tile by digit inside
-// LDS and writes every bin's run to HBM as consecutive dwords.  HBM traffic per pass is one read
-// and one write of the records (2*n*R bytes) plus 2 KB of status per tile.  Digit histograms for all
-// key bytes are taken by one extra read of the records (k_digit_hist) before the first pass.
-// The pass is stable, so LSD order over a byte list reproduces LSD_Sort bit for bit.
+// The product engine is the dependency-free "stream" digit pass further down (k_rx_tilehist /
+// k_rx_chunkscan / k_rx_superscan / k_rx_scatter): every pass also writes the digit the NEXT pass sorts
+// on next to each record, so a pass gets its per-tile bin offsets from an n-byte stream without touching
+// the records and without any inter-workgroup dependency.  HBM traffic per pass is one read and one write
+// of the records (2*n*R bytes) plus 2n bytes of digit stream.  Every pass is stable, so LSD order over a
+// byte list reproduces LSD_Sort bit for bit.
+//
+// The first engine -- ONE kernel per pass with decoupled look-back over status words, and seven ablated
+// VARIANTs of it whose output is wrong on purpose -- is measurement ballast: it is only compiled with
+// -DFK_ABLATION (make ABLATION=1) and is not part of the shipped library.
 #include "fk_common.h"
 #include <type_traits>
 
@@ -109,6 +110,7 @@ __global__ __launch_bounds__(RX_THREADS) void k_digit_hist(const u32 *__restrict
       atomicAdd(&out[i], (u64) h[i]);
 }
 
+#ifdef FK_ABLATION
 // ---------------------------------------------------------------------------------------------
 // one stable 8-bit digit pass
 // VARIANT is a measurement aid (fk_debug_set "radix_variant"); only 0 produces a sorted result:
@@ -328,6 +330,8 @@ __global__ __launch_bounds__(RX_THREADS) void k_radix_pass(const u32 *__restrict
       dst[g] = recs[sr * RW + w];
     }
 }
+
+#endif   // FK_ABLATION
 
 // =============================================================================================
 // Dependency-free digit pass ("stream" engine, the default).
@@ -846,16 +850,20 @@ template <int RW, int ITEMS> static size_t rx_wide_lds_bytes()
           + (size_t) RXW_THREADS * ITEMS * 3 + 16);
 }
 
+#ifdef FK_ABLATION
 template <int RW, int ITEMS> static size_t rx_lds_bytes(bool hashed)
 { return ((size_t) RX_THREADS * ITEMS * RW * 4 + 256 * 8 + 8 * 8 + RX_WAVES * 256 * 4 + 256 * 4
           + 8 * 4 + 16 + (size_t) RX_THREADS * ITEMS * (hashed ? 4 : 2) + 16);
 }
+
+#endif
 
 template <int RW, int ITEMS> static size_t rx_stream_lds_bytes()
 { return ((size_t) RX_THREADS * ITEMS * RW * 4 + 256 * 8 + 8 * 8 + RX_WAVES * 256 * 4 + 256 * 4
           + 8 * 4 + 16 + (size_t) RX_THREADS * ITEMS * 3 + 16);
 }
 
+#ifdef FK_ABLATION
 // hashed: bytes[] index the record hash (rx_hash_digit) instead of the record itself
 template <int RW, int ITEMS, bool HASHED>
 static int lsd_sort_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, const int *bytes,
@@ -959,6 +967,8 @@ static int lsd_sort_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, const in
   return (FK_OK);
 }
 
+#endif   // FK_ABLATION
+
 template <int RW, int ITEMS, bool HASHED, int WT>
 static int lsd_sort_stream_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, const int *bytes,
                              int nbytes, void **result, int hbytes)
@@ -1022,23 +1032,28 @@ static int lsd_sort_stream_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, c
     FK_LAUNCH_CHECK(ctx);
   }
   FK_HIP(ctx, hipEventRecord(ctx->ev1, s));
-  FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch, ctx->d_digit_hist, (size_t) (HASHED ? 8 : RW * 4) * 256 * 8,
-                             hipMemcpyDeviceToHost, s));
-  FK_HIP(ctx, hipStreamSynchronize(s));
-  { float ms = 0.f;
-    FK_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-    ctx->sort_stats.hist_ms = ms;
-  }
-
   int run[64], nrun = 0;                 // the passes that actually permute something
-  for (int i = 0; i < nbytes; i++)
-    { const u64 *h = ctx->h_scratch + (size_t) bytes[i] * 256;
-      bool constant = false;
-      for (int x = 0; x < 256; x++)
-        if (h[x] == (u64) n)
-          constant = true;
-      if (!constant)
+  if (HASHED)
+    { // digits of a hash are never constant on real input, and a pass over a constant digit is merely the
+      // identity: no reason to bring the histograms to the host and wait for them before the first pass
+      for (int i = 0; i < nbytes; i++)
         run[nrun++] = bytes[i];
+    }
+  else
+    { FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch, ctx->d_digit_hist, (size_t) RW * 4 * 256 * 8, hipMemcpyDeviceToHost, s));
+      FK_HIP(ctx, hipStreamSynchronize(s));
+      float ms = 0.f;
+      FK_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+      ctx->sort_stats.hist_ms = ms;
+      for (int i = 0; i < nbytes; i++)
+        { const u64 *h = ctx->h_scratch + (size_t) bytes[i] * 256;
+          bool constant = false;
+          for (int x = 0; x < 256; x++)
+            if (h[x] == (u64) n)
+              constant = true;
+          if (!constant)
+            run[nrun++] = bytes[i];
+        }
     }
   if (nrun == 0)
     return (FK_OK);
@@ -1129,24 +1144,33 @@ static int sort_dispatch(fk_ctx *ctx, int64_t nelem, void *d_src, void *d_trg, i
     { fk_set_error(ctx, "record size %d not supported (multiple of 4, <= 32)", rsize);
       return (FK_EUNSUPPORTED);
     }
-  const int it = ctx->dbg_radix_items;      // measurement aid: alternative tile sizes for R = 12, 20
-  const bool lookback = (ctx->dbg_radix_engine == 1 || ctx->dbg_radix_variant != 0 || it != 0);
   // wide (1024-thread, persistent) tiles pay off for records of 16 bytes and more; narrower records
   // are bound by instruction issue, not by the write pattern, and do better with 4 workgroups per CU
   const bool narrow = (ctx->dbg_radix_engine == 2) || (rsize < 16 && ctx->dbg_radix_engine != 3);
+#ifdef FK_ABLATION
+  const int it = ctx->dbg_radix_items;      // measurement aid: alternative tile sizes for R = 12, 20
+  const bool lookback = (ctx->dbg_radix_engine == 1 || ctx->dbg_radix_variant != 0 || it != 0);
 #define RX_CASE(RW) return (lookback ? lsd_sort_t<RW, RxCfg<RW>::ITEMS, HASHED>(ctx, nelem, d_src, d_trg, bytes, nbytes, result) \
                      : narrow ? lsd_sort_stream_t<RW, RxCfg<RW>::ITEMS, HASHED, RX_THREADS>(ctx, nelem, d_src, d_trg, bytes, nbytes, result, hbytes) \
                               : lsd_sort_stream_t<RW, RxCfgW<RW>::ITEMS, HASHED, RXW_THREADS>(ctx, nelem, d_src, d_trg, bytes, nbytes, result, hbytes))
+#else
+#define RX_CASE(RW) return (narrow ? lsd_sort_stream_t<RW, RxCfg<RW>::ITEMS, HASHED, RX_THREADS>(ctx, nelem, d_src, d_trg, bytes, nbytes, result, hbytes) \
+                                   : lsd_sort_stream_t<RW, RxCfgW<RW>::ITEMS, HASHED, RXW_THREADS>(ctx, nelem, d_src, d_trg, bytes, nbytes, result, hbytes))
+#endif
   switch (rsize >> 2)
   { case 1: RX_CASE(1);
     case 2: RX_CASE(2);
     case 3:
+#ifdef FK_ABLATION
       if (!HASHED && it == 8)  return lsd_sort_t<3, 8, HASHED>(ctx, nelem, d_src, d_trg, bytes, nbytes, result);
       if (!HASHED && it == 16) return lsd_sort_t<3, 16, HASHED>(ctx, nelem, d_src, d_trg, bytes, nbytes, result);
+#endif
       RX_CASE(3);
     case 4: RX_CASE(4);
     case 5:
+#ifdef FK_ABLATION
       if (!HASHED && it == 16) return lsd_sort_t<5, 12, HASHED>(ctx, nelem, d_src, d_trg, bytes, nbytes, result);
+#endif
       RX_CASE(5);
     case 6: RX_CASE(6);
     case 7: RX_CASE(7);
@@ -1168,11 +1192,13 @@ int fkx_group(fk_ctx *ctx, int64_t nelem, void *d_src, void *d_trg, int rsize, i
 { static const int bytes[8] = { 0, 1, 2, 3, 4, 5, 6, 7 };
   if (npasses < 1 || npasses > 8 || key_bytes < 1 || key_bytes > rsize)
     return (FK_EINVAL);
+#ifdef FK_ABLATION
   const bool lookback = (ctx->dbg_radix_engine == 1 || ctx->dbg_radix_variant != 0 || ctx->dbg_radix_items != 0);
   if (lookback && key_bytes != rsize)
     { fk_set_error(ctx, "the look-back engine hashes whole records only");
       return (FK_EUNSUPPORTED);
     }
+#endif
   return sort_dispatch<true>(ctx, nelem, d_src, d_trg, rsize, bytes, npasses, result, key_bytes);
 }
 

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Measure the radix digit pass in isolation on random records (run on the GPU box).
+"""(needs a library built with `make -C fastk_amd/csrc ABLATION=1`: the look-back engine and its variants are not in the shipped build)
+Measure the radix digit pass in isolation on random records (run on the GPU box).
 Prints achieved algorithmic GB/s (2*n*R / avg pass ms) for the real kernel and for the ablated
 variants, plus a hipMemcpy device-to-device copy ceiling of the same byte count."""
 import sys, os, time, json
