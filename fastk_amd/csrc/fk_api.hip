@@ -936,7 +936,10 @@ static int flush_join(fk_ctx *ctx)
 //          the buffer goes to a helper thread that waits for them and splits it, and the caller goes
 //          on copying into the other buffer;
 //   else:  the split runs here and now.
-static int flush_chunk(fk_ctx *ctx, bool async = false)
+//   carry: the text pushes (fk_push_fastq / _fasta) may stop in the middle of a read; the chunk is
+//          split as it is and the last K-1 bases of the unfinished read open the next chunk, so the k-mers
+//          across the cut are counted exactly once (what a block with rem > 0 does, io.c:557-570).
+static int flush_chunk(fk_ctx *ctx, bool async = false, bool carry = false)
 { int rc = flush_join(ctx);
   if (rc != FK_OK || ctx->reads_len == 0)
     return (rc);
@@ -945,8 +948,28 @@ static int flush_chunk(fk_ctx *ctx, bool async = false)
   if (!async)
     { FK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
       FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      int64_t keep = 0;
+      if (carry)
+        { const int64_t look = std::min<int64_t>(len, ctx->prm.kmer - 1);
+          char tail[256];
+          FK_HIP(ctx, hipMemcpy(tail, buf + len - look, (size_t) look, hipMemcpyDeviceToHost));
+          while (keep < look && tail[look - 1 - keep] != 0)      // bases after the last read terminator
+            keep += 1;
+        }
       ctx->reads_len = 0;
-      return flush_buffer(ctx, buf, len);
+      rc = flush_buffer(ctx, buf, len);
+      if (rc == FK_OK && keep > 0)
+        { // (source and destination cannot overlap: a chunk is far longer than 2 (K-1) bytes -- but be safe)
+          if (len >= 2 * keep)
+            FK_HIP(ctx, hipMemcpy(buf, buf + len - keep, (size_t) keep, hipMemcpyDeviceToDevice));
+          else
+            { char tmp[256];
+              FK_HIP(ctx, hipMemcpy(tmp, buf + len - keep, (size_t) keep, hipMemcpyDeviceToHost));
+              FK_HIP(ctx, hipMemcpy(buf, tmp, (size_t) keep, hipMemcpyHostToDevice));
+            }
+          ctx->reads_len = keep;
+        }
+      return (rc);
     }
   FK_HIP(ctx, hipEventRecord(ctx->reads_ev, ctx->copy_stream));
   std::swap(ctx->d_reads, ctx->d_reads_alt);
@@ -1163,7 +1186,7 @@ extern "C" int fk_push_fastq(fk_ctx *ctx, const char *raw, int64_t nbytes, int f
       if (nreads) *nreads += nr;
       if (nbases) *nbases += kept - nr;
       if (ctx->chunk_bytes > 0 && ctx->reads_len >= ctx->chunk_bytes)
-        rc = flush_chunk(ctx);
+        rc = flush_chunk(ctx, false, true);
     }
   while (0);
   pthread_mutex_unlock((pthread_mutex_t *) ctx->push_lock);
@@ -1215,8 +1238,8 @@ extern "C" int fk_push_fasta(fk_ctx *ctx, const char *raw, int64_t nbytes, int l
         }
       if (nreads) *nreads += nr;
       if (nbases) *nbases += kept - nr;
-      if (ctx->chunk_bytes > 0 && ctx->reads_len >= ctx->chunk_bytes)
-        rc = flush_chunk(ctx);
+      if (ctx->chunk_bytes > 0 && ctx->reads_len >= ctx->chunk_bytes && !last)
+        rc = flush_chunk(ctx, false, true);
     }
   while (0);
   pthread_mutex_unlock((pthread_mutex_t *) ctx->push_lock);

@@ -29,7 +29,7 @@
 #define SP_THREADS 256
 #define SP_CH      16                      // k-mer starts per thread
 #define SP_TILE    (SP_THREADS * SP_CH)    // 4096 k-mer starts per workgroup
-#define SP_MAXK    128
+#define SP_MAXK    64                       // fk_create admits k <= 64; 27.1 KB of LDS lets six workgroups share a CU
 #define SP_WORDS   (SP_TILE / 16 + SP_MAXK / 16 + 2)   // packed words incl. halo and guard
 #define SP_KEYS    (SP_TILE + SP_MAXK)
 #define SP_KIDX(i) ((i) + ((i) >> 4))     // one pad word per 16 keys: thread t's chunk starts at bank 17t

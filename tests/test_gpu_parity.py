@@ -1310,6 +1310,42 @@ def test_full_size_properties_configs2():
             json.dump(summary, f, indent=1)
 
 
+def test_configs4_scaled_slice_k51_profiles_with_spill(tmp_path):
+    """BASELINE configs[4] (100x of a 32 Gbp genome, k=51 -t1 -p, HBM-spill stress) at a STATED SCALE of
+    1/1000: 100x coverage of a 32 Mbp genome in 150 bp reads (21.3 M reads, 3.2 G bases, 2.13 G k-mer
+    instances), through the C driver on one GPU with -M2: 2 GB budget, so the reads are split chunk by chunk,
+    ~3/4 of the 28-byte super-mer records go through pinned host memory and come back bucket by bucket, and
+    the profiles take the second pass over the input.  Checked: conservation, sum(hist) = table entries at
+    -t1, and .hist / .ktab / every .prof file byte-identical to the all-resident run of the same command."""
+    import os, subprocess
+    L, glen, k = 150, 32_000_000, 51
+    nreads = int(100 * glen / L)
+    bases, boff = orc.synth_block(4051, glen, L, 1000, 0, nreads)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "fastk_amd", "bin", "FastK_amd")
+    path = str(tmp_path / "x.fastq")
+    util.write_fastx(path, bases, boff, True)
+    del bases
+    outs = {}
+    for name, mem in (("res", []), ("mem", ["-M2"])):
+        d = tmp_path / name
+        d.mkdir()
+        p = subprocess.run([exe, "-k%d" % k, "-t1", "-T4", "-p", "-v"] + mem + ["-N" + str(d / "x"), path], capture_output=True,
+                           text=True)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs[name] = {f: util.sha_file(d / f) for f in sorted(os.listdir(d))}
+        if mem:
+            assert "minimizer bucket" in p.stderr                     # the budget really chunked the run
+    assert outs["res"] == outs["mem"] and len(outs["res"]) == 2 + 4 + 1 + 8
+    h = orc.read_hist(str(tmp_path / "mem" / "x.hist"))
+    hist = np.asarray(h["hist"], dtype=np.int64)
+    cnt = np.arange(h["low"], h["low"] + len(hist))
+    inst = nreads * (L - k + 1)
+    assert int((hist[:-1] * cnt[:-1]).sum()) + int(h["ihigh"]) == inst
+    t = orc.read_ktab(str(tmp_path / "mem" / "x"))
+    assert t["nels"] == int(hist.sum())
+
+
 # ------------------------------------------------------------------------------ profiles (-p)
 
 def _check_profiles(k, bases, boff, data, offs, table=None):
