@@ -267,18 +267,20 @@ def e2e_leg(args, cfg, fastk_amd, ctx_gen, L):
         piece.free()
         fbytes = os.path.getsize(path)
         exe = os.path.join(ROOT, "fastk_amd", "bin", "FastK_amd")
-        cmd = [exe, "-k%d" % args.kmer, "-t%d" % cfg["cutoff"], "-T%d" % args.e2e_threads,
+        cmd = [exe, "-v", "-k%d" % args.kmer, "-t%d" % cfg["cutoff"], "-T%d" % args.e2e_threads,
                "-M%d" % args.e2e_mem_gb, "-N" + os.path.join(d, "out"), path]
-        times = []
+        times, phases = [], ""
         for _ in range(2):
             t0 = time.perf_counter()
-            subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+            p = subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
             times.append(time.perf_counter() - t0)
+            if times[-1] == min(times):
+                phases = " ".join(x.strip() for x in p.stderr.splitlines() if "Wall s" in x)
         inst = nreads * (L - args.kmer + 1)
         out_bytes = sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d)
                         if f.startswith("out") or f.startswith(".out"))
         return dict(value=inst / min(times), unit="k-mers/s", seconds=round(min(times), 3),
-                    scale=args.scale * args.e2e_scale, kmer_instances=inst, input_bytes=fbytes,
+                    scale=args.scale * args.e2e_scale, kmer_instances=inst, input_bytes=fbytes, phases=phases,
                     output_bytes=out_bytes, command=" ".join(os.path.basename(c) if c == exe else
                                                              ("<file>" if c == path else c) for c in cmd[:-2]),
                     definition="process start -> exit of bin/FastK_amd on a %s file in %s: read + parse, "

@@ -240,8 +240,9 @@ static char *resolve_input(const char *arg)
 
 /* A chunk of a plain file is copied out of the page cache by READERS threads at once: one thread's
    read() moves ~5 GB/s, which is what would otherwise bound the ingest of FASTQ text that the
-   device parses at several hundred GB/s. */
-#define READERS 4
+   device parses at several hundred GB/s.  The next piece is read (by a helper thread) while the
+   current one crosses PCIe and is parsed. */
+#define READERS 16
 
 typedef struct
   { int    fd;
@@ -334,10 +335,32 @@ static off_t record_start(int fd, off_t from, off_t size, int fastq)
   return (size);
 }
 
+typedef struct
+  { gzFile in;
+    int    fd;
+    char  *dst;
+    off_t  off, fend;
+    int    got;
+  } Fetch_Job;
+
+static void *fetch_job(void *arg)
+{ Fetch_Job *j = (Fetch_Job *) arg;
+  if (j->in != NULL)
+    j->got = gzread(j->in,j->dst,RAW_BYTES);
+  else
+    { size_t max = RAW_BYTES;
+      if (j->fend >= 0 && j->fend - j->off < (off_t) RAW_BYTES)
+        max = (j->fend > j->off) ? (size_t) (j->fend - j->off) : 0;
+      j->got = (max > 0) ? parallel_read(j->fd,j->dst,j->off,max) : 0;
+    }
+  if (j->got < 0) j->got = 0;
+  return (NULL);
+}
+
 static void scan_text_on_device(Feeder *f, const char *path, int fastq)
 { gzFile in = NULL;
   int    fd = -1;
-  static char *raw = NULL;
+  static char *raw = NULL, *raw2 = NULL;
   int     phase = fastq ? 0 : 2, n;
   size_t  pl = strlen(path);
 
@@ -361,19 +384,39 @@ static void scan_text_on_device(Feeder *f, const char *path, int fastq)
       foff = record_start(fd,(off_t) ((double) size*RANK/NGPUS),size,fastq);
       fend = (RANK+1 == NGPUS) ? size : record_start(fd,(off_t) ((double) size*(RANK+1)/NGPUS),size,fastq);
     }
-  while ((n = (in != NULL) ? gzread(in,raw,RAW_BYTES)
-                           : parallel_read(fd,raw,foff,(fend >= 0 && fend-foff < RAW_BYTES) ? (size_t) (fend-foff) : RAW_BYTES)) > 0)
-    { int64_t nr = 0, nb = 0;
-      foff += n;
-      if (fastq)
-        { if (fk_push_fastq(f->ctx,raw,n,COMPRESS ? FK_FASTQ_HOCO : 0,&phase,&nr,&nb) != FK_OK)
-            die(f->ctx,"fk_push_fastq");
-        }
-      else if (fk_push_fasta(f->ctx,raw,n,0,&phase,&nr,&nb) != FK_OK)
-        die(f->ctx,"fk_push_fasta");
-      f->totrds += nr;
-      f->totbps += nb;
-    }
+  if (raw2 == NULL && fk_host_alloc(RAW_BYTES,(void **) &raw2) != FK_OK)
+    die(NULL,"pinned read buffer");
+  { Fetch_Job fj;
+    pthread_t th;
+    char     *cur = raw, *nxt = raw2;
+    int       pending = 0;
+    fj.in = in; fj.fd = fd; fj.fend = fend;
+    /* piece 0 is read here; from then on piece i+1 is fetched by a helper while piece i is pushed */
+    fj.dst = cur; fj.off = foff;
+    fetch_job(&fj);
+    n = fj.got;
+    foff += n;
+    while (n > 0)
+      { int64_t nr = 0, nb = 0;
+        fj.dst = nxt; fj.off = foff;
+        pthread_create(&th,NULL,fetch_job,&fj);
+        pending = 1;
+        if (fastq)
+          { if (fk_push_fastq(f->ctx,cur,n,COMPRESS ? FK_FASTQ_HOCO : 0,&phase,&nr,&nb) != FK_OK)
+              die(f->ctx,"fk_push_fastq");
+          }
+        else if (fk_push_fasta(f->ctx,cur,n,0,&phase,&nr,&nb) != FK_OK)
+          die(f->ctx,"fk_push_fasta");
+        f->totrds += nr;
+        f->totbps += nb;
+        pthread_join(th,NULL);
+        pending = 0;
+        n = fj.got;
+        foff += n;
+        { char *t = cur; cur = nxt; nxt = t; }
+      }
+    (void) pending;
+  }
   if (!fastq && fk_push_fasta(f->ctx,NULL,0,1,&phase,NULL,NULL) != FK_OK)     /* ends the last record */
     die(f->ctx,"fk_push_fasta");
   if (in != NULL) gzclose(in); else close(fd);
