@@ -75,7 +75,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-device-leg", action="store_true", help="skip value_device (pinned host -> host)")
     ap.add_argument("--no-e2e", action="store_true", help="skip value_e2e (file -> files)")
-    ap.add_argument("--e2e-scale", type=float, default=0.1,
+    ap.add_argument("--e2e-scale", type=float, default=1.0,
                     help="value_e2e runs on this fraction of the genome (1 = the full 150 GB FASTA)")
     ap.add_argument("--force-shard", action="store_true",
                     help="run the sharded (all-to-all) path even on one GPU: exercises RCCL + shard.py")
@@ -272,7 +272,10 @@ def e2e_leg(args, cfg, fastk_amd, ctx_gen, L):
         times, phases = [], ""
         for _ in range(2):
             t0 = time.perf_counter()
-            p = subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+            p = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+            if p.returncode != 0:
+                return dict(failed="FastK_amd exit %d: %s" % (p.returncode, p.stderr[-600:]), input_bytes=fbytes,
+                            scale=args.scale * args.e2e_scale)
             times.append(time.perf_counter() - t0)
             if times[-1] == min(times):
                 phases = " ".join(x.strip() for x in p.stderr.splitlines() if "Wall s" in x)
@@ -494,15 +497,24 @@ def main():
         gen = fastk_amd.Context(kmer=args.kmer, device=local_rank)
         if not args.no_device_leg:
             t0 = time.perf_counter()
-            out["value_device"] = device_leg(args, cfg, fastk_amd, gen, glen, per, L, local_rank)
+            try:
+                out["value_device"] = device_leg(args, cfg, fastk_amd, gen, glen, per, L, local_rank)
+            except Exception as e:                               # a leg that fails must not take the line with it
+                out["value_device"] = dict(failed=repr(e)[-600:])
             log(args, "device leg %.1f s" % (time.perf_counter() - t0), out["value_device"])
         if not args.no_e2e:
             t0 = time.perf_counter()
-            out["value_e2e"] = e2e_leg(args, cfg, fastk_amd, gen, L)
+            try:
+                out["value_e2e"] = e2e_leg(args, cfg, fastk_amd, gen, L)
+            except Exception as e:
+                out["value_e2e"] = dict(failed=repr(e)[-600:])
             log(args, "e2e leg %.1f s" % (time.perf_counter() - t0), out["value_e2e"])
         gen.close()
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, cfg)
+            try:
+                out["cpu_baseline"] = cpu_baseline(args, cfg)
+            except Exception as e:
+                out["cpu_baseline"] = dict(failed=repr(e)[-600:])
     if rank == 0:
         print(json.dumps(out))
     if ctx is not None:

@@ -800,9 +800,12 @@ int main(int argc, char *argv[])
           if (fp != NULL) fclose(fp);
           if (q >= 0) { free(r); free(d); }
         }
-      { double room = budget/2.;         /* the library keeps super-mers in the other half, the rest in host memory */
+      { /* the library keeps the super-mer records (~1.1 bytes per base) in 3/4 of the budget and spills beyond;
+           a bucket's working set (its records twice, its weighted k-mers twice: ~6 bytes per base of the bucket)
+           gets a sixteenth, which leaves the rest for the table, its sort and the read buffers */
+        double room = budget/16.;
         int    nb   = 1;
-        while (nb < 256 && 7.5*bases/nb > room)
+        while (nb < 255 && 6.*bases/nb > room)
           nb += 1;
         prm.nbuckets   = nb;
         prm.hbm_budget = (int64_t) budget;
