@@ -436,7 +436,7 @@ def main():
     # (records per launch) is the profiled one.
     traffic = None
     traffic_src = None
-    for name in ("r02_pmc_traffic_configs%d.json" % cfg_id, "r01_pmc_traffic.json"):
+    for name in ("r02_c_configs%d_pmc_traffic.json" % cfg_id,):
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", name)))
             per_launch = n_rec / (nl_k / passes_k)
