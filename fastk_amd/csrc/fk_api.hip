@@ -1582,6 +1582,26 @@ static int sort_union_table(fk_ctx *ctx, int64_t ntab, fk_result *res, void **ta
   return (FK_OK);
 }
 
+// device stride -> reference width (k-mer bytes + uint16 count), one thread per record
+__global__ __launch_bounds__(256) void k_repack_table(const uint8_t *__restrict__ in, int64_t n, int stride, int kbytes,
+                                                      uint8_t *__restrict__ out)
+{ const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t *r = in + i * stride;
+  uint8_t *o = out + i * (kbytes + 2);
+  for (int j = 0; j < kbytes; j++) o[j] = r[j];
+  o[kbytes] = r[stride - 2];
+  o[kbytes + 1] = r[stride - 1];
+}
+
+int fkx_repack_table(fk_ctx *ctx, const void *d_in, int64_t n, void *d_out)
+{ if (n <= 0) return (FK_OK);
+  hipLaunchKernelGGL(k_repack_table, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                     (const uint8_t *) d_in, n, ctx->wid.kmer_stride, ctx->wid.kmer_bytes, (uint8_t *) d_out);
+  FK_LAUNCH_CHECK(ctx);
+  return (FK_OK);
+}
+
 // ntable / ncollapsed and, if asked, the table itself (host copy in reference layout) into res
 static int fetch_result_table(fk_ctx *ctx, fk_result *res, void *table, int64_t nt, bool fetch_table)
 { const fk_widths &w = ctx->wid;
@@ -1600,16 +1620,27 @@ static int fetch_result_table(fk_ctx *ctx, fk_result *res, void *table, int64_t 
         return (FK_EHIP);
     }
   else
-    { uint8_t *tmp = (uint8_t *) malloc((size_t) nt * w.kmer_stride);
-      if (tmp == NULL) return (FK_ENOMEM);
-      if (hipMemcpyAsync(tmp, table, (size_t) nt * w.kmer_stride, hipMemcpyDeviceToHost, s) != hipSuccess
-          || hipStreamSynchronize(s) != hipSuccess)
-        { free(tmp); return (FK_EHIP); }
-      for (int64_t i = 0; i < nt; i++)
-        { memcpy(ctx->h_table + i * w.kmer_word, tmp + i * w.kmer_stride, w.kmer_bytes);
-          memcpy(ctx->h_table + i * w.kmer_word + w.kmer_bytes, tmp + i * w.kmer_stride + w.kmer_stride - 2, 2);
+    { // records wider than KMER_WORD on the device (k = 41..48, 49..64 ...): packed by a kernel into an idle
+      // buffer, then one copy -- not a per-record loop on the host
+      void *pk = NULL;
+      static const int idle[4] = { FK_SLOT_SM_A, FK_SLOT_KM_B, FK_SLOT_SM_G, FK_SLOT_SM_D };
+      for (int i = 0; i < 4 && pk == NULL; i++)
+        if (ctx->slot_cap[idle[i]] >= bytes && ctx->slot_ptr[idle[i]] != table
+            && !((char *) table >= (char *) ctx->slot_ptr[idle[i]]
+                 && (char *) table < (char *) ctx->slot_ptr[idle[i]] + ctx->slot_cap[idle[i]]))
+          pk = ctx->slot_ptr[idle[i]];
+      bool own = false;
+      if (pk == NULL)
+        { if (hipMalloc(&pk, (size_t) bytes) != hipSuccess) return (FK_ENOMEM);
+          own = true;
         }
-      free(tmp);
+      int rc = fkx_repack_table(ctx, table, nt, pk);
+      if (rc == FK_OK
+          && (hipMemcpyAsync(ctx->h_table, pk, (size_t) bytes, hipMemcpyDeviceToHost, s) != hipSuccess
+              || hipStreamSynchronize(s) != hipSuccess))
+        rc = FK_EHIP;
+      if (own) hipFree(pk);
+      if (rc != FK_OK) return (rc);
     }
   res->table = ctx->h_table;
   return (FK_OK);

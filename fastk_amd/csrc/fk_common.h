@@ -87,6 +87,7 @@ struct fk_ctx
   int64_t    status_cap;   // in u64 words
   u32       *d_ticket;     // [64] tile tickets
   fk_sort_stats sort_stats;
+  u64        rx_attr_done; // wide scatter instantiations whose dynamic-LDS attribute is set on this context's device
 
   // streaming interface state
   char      *d_reads;      // pushed reads (HBM)
@@ -232,6 +233,7 @@ int fkx_profile_scatter(fk_ctx *ctx, const void *d_smers, const void *d_pos, int
                         int64_t nbytes, bool reset);
 int fkx_profile_encode_counts(fk_ctx *ctx, const void *d_bases, int64_t nbytes, int64_t *nreads_out,
                               int64_t *nprof_out, void **d_data, uint64_t **d_offs);
+int fkx_repack_table(fk_ctx *ctx, const void *d_in, int64_t n, void *d_out);   // device stride -> KMER_WORD records
 int fkx_synth(fk_ctx *ctx, uint64_t seed, uint64_t genome_len, uint32_t read_len,
               uint32_t err_ppm, uint64_t first_read, int64_t nreads, void *d_bases);
 

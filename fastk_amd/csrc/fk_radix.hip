@@ -1077,12 +1077,14 @@ static int lsd_sort_stream_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, c
   uint8_t *dcur = dig_a, *dnext = dig_b;
   unsigned sgrid = (unsigned) (((ntiles + 7) / 8) * 8);
   if constexpr (WT != RX_THREADS)
-    { static bool attr_set = false;
-      if (!attr_set)
+    { // the attribute belongs to the (function, device) pair: remembered per context (= per device), not per
+      // process -- a host that drives several devices from one process must set it on each of them
+      const u64 bit = 1ull << ((RW * 2 + (HASHED ? 1 : 0)) & 63);
+      if ((ctx->rx_attr_done & bit) == 0)
         { auto kern = k_rx_scatter_w<RW, ITEMS, HASHED>;
           FK_HIP(ctx, hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int) lds_bytes));
-          attr_set = true;
+          ctx->rx_attr_done |= bit;
         }
       const unsigned cus = (unsigned) ((ctx->num_cus > 0 ? ctx->num_cus : 256) / 8 * 8);
       if (sgrid > cus) sgrid = cus;

@@ -348,18 +348,6 @@ extern "C" int fk_shard_count(fk_shard *sh, fk_result *res)
   return (FK_OK);
 }
 
-// device stride -> reference width (k-mer bytes + uint16 count), one thread per record
-__global__ __launch_bounds__(256) void k_sh_repack(const uint8_t *__restrict__ in, int64_t n, int stride, int kbytes,
-                                                   uint8_t *__restrict__ out)
-{ const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const uint8_t *r = in + i * stride;
-  uint8_t *o = out + i * (kbytes + 2);
-  for (int j = 0; j < kbytes; j++) o[j] = r[j];
-  o[kbytes] = r[stride - 2];
-  o[kbytes + 1] = r[stride - 1];
-}
-
 /* C3 + output files after fk_shard_count: <dir>/<root>.hist and the .ktab stub from rank 0, the hidden parts
    .<root>.ktab.<rank*m+1 .. rank*m+m> from every rank (m = nparts / world; nparts must be a multiple of the
    ranks).  With table_cutoff 0 only the histogram is written.  The files are byte for byte those
@@ -442,8 +430,8 @@ extern "C" int fk_shard_write(fk_shard *sh, const fk_result *res, int nparts, co
       const void *src = sorted;
       if (w.kmer_word != w.kmer_stride && nin > 0)
         { void *other = (sorted == (void *) a) ? (void *) b : (void *) a;
-          hipLaunchKernelGGL(k_sh_repack, dim3((unsigned) ((nin + 255) / 256)), dim3(256), 0, ctx->stream,
-                             (const uint8_t *) sorted, nin, w.kmer_stride, w.kmer_bytes, (uint8_t *) other);
+          if ((rc = fkx_repack_table(ctx, sorted, nin, other)) != FK_OK)
+            { hipHostFree(host); break; }
           src = other;
         }
       if (nin > 0
