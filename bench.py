@@ -12,8 +12,12 @@ N = 1 (default --config 2) = BASELINE.json configs[2], the set the north-star ta
 passes, each keeping one group of minimizer buckets, and the buckets are counted one after the other
 (the role of FastK's NPARTS, split.c:617-766; count.c:1202 bucket loop).
     --config 1 = BASELINE.json configs[1]: 50x of 100 Mbp in 150 bp reads, k=40 -t1, all resident.
-N > 1 runs the configs[1] workload per GPU (weak scaling): rank r owns read stripe r, super-mers are
-exchanged by minimizer bucket with RCCL, each GPU counts its buckets, histograms are all-reduced.
+N > 1 (default --config 3) = BASELINE.json configs[3]: the SAME 3 Gbp HiFi-shaped set striped over the N GPUs
+(strong scaling: the N = 1 line above is its first point), counted through the C engine's sharded entry
+points: rank r owns read stripe r, super-mers travel by minimizer bucket with grouped ncclSend/ncclRecv in
+rounds that overlap the counting, histograms are all-reduced (fk_shard_count_device, fastk_amd/csrc/
+fk_shard.hip).  --config 1 with N > 1 is round 1's weak-scaling run of configs[1] per GPU through the
+torch.distributed harness (fastk_amd/shard.py).
 
 The line also carries (N = 1):
   roofline      dominant radix kernel (k_rx_scatter over the weighted k-mer records): algorithmic
@@ -51,6 +55,10 @@ CONFIGS = {
             split_passes=2, cpu_sample_mbp=20.0,
             label="50x coverage, 15 kbp HiFi-shaped reads, err 2000 ppm, of a %g Mbp genome%s, k=%d -t4 "
                   "(BASELINE.json configs[2])"),
+    3: dict(genome_mbp=3000.0, coverage=50.0, read_len=15000, err_ppm=2000, cutoff=4, buckets=1,
+            split_passes=1, cpu_sample_mbp=20.0,
+            label="50x coverage, 15 kbp HiFi-shaped reads, err 2000 ppm, of a %g Mbp genome%s, k=%d -t4, "
+                  "sharded over the GPUs by minimizer bucket (BASELINE.json configs[3])"),
 }
 
 
@@ -59,8 +67,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2],
-                    help="BASELINE.json configs[] index; 0 = 2 on one GPU, 1 on several")
+    ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3],
+                    help="BASELINE.json configs[] index; 0 = 2 on one GPU, 3 on several (the same set sharded through "
+                         "the C engine fk_shard_*, strong scaling); 1 = configs[1] (per GPU with N > 1: weak scaling)")
     ap.add_argument("--kmer", type=int, default=40)
     ap.add_argument("--genome-mbp", type=float, default=None, help="genome size per GPU (Mbp)")
     ap.add_argument("--scale", type=float, default=1.0,
@@ -293,6 +302,72 @@ def e2e_leg(args, cfg, fastk_amd, ctx_gen, L):
         subprocess.run(["rm", "-rf", d])
 
 
+def main_config3(args, cfg, torch, fastk_amd, dist, rank, local_rank, world, dev):
+    """BASELINE configs[3]: the 50x HiFi-shaped 3 Gbp set of configs[2], striped over the GPUs (rank r generates
+    reads r*n/world ..), counted through the C engine's sharded entry points (fk_shard_count_device: planned
+    split, grouped ncclSend/ncclRecv of the records in overlapped rounds, per-rank counting, ncclAllReduce).
+    Total work is fixed: strong scaling.  One process per GPU; torch.distributed only hands the RCCL id round
+    and provides the barrier of the timing contract."""
+    L = cfg["read_len"]
+    glen = int(cfg["genome_mbp"] * 1e6 * args.scale)
+    total_reads = int(cfg["coverage"] * glen / L) // world * world
+    per = total_reads // world
+    first = rank * per
+    nbytes = per * (L + 1)
+    rounds = max(4, 32 // world)
+    ctx = fastk_amd.Context(kmer=args.kmer, table_cutoff=cfg["cutoff"], nthreads=4, device=local_rank,
+                            nbuckets=min(256 // world * world, world * rounds))
+    idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+    if rank == 0:
+        idt.copy_(torch.frombuffer(bytearray(fastk_amd.Shard.unique_id()), dtype=torch.uint8))
+    if dist is not None:
+        dist.broadcast(idt, 0)
+    shard = fastk_amd.Shard(ctx, rank, world, bytes(idt.cpu().numpy().tobytes()))
+    reads = torch.empty(nbytes + 64, dtype=torch.uint8, device=dev)
+    ctx._ck(ctx.L.fk_synth_reads(ctx.h, args.seed, glen, L, cfg["err_ppm"], first, per, reads.data_ptr()))
+    ctx._ck(ctx.L.fk_synchronize(ctx.h))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    last = None
+    for _ in range(args.warmup):
+        last = shard.count(reads.data_ptr(), nbytes)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = shard.count(reads.data_ptr(), nbytes)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    expect = total_reads * (L - args.kmer + 1)
+    assert last.ninst == expect, "k-mer instance count %d != %d" % (last.ninst, expect)
+    scale_note = "" if args.scale == 1.0 else " SCALED by %g (development run)" % args.scale
+    out = dict(metric="canonical k-mers/sec (k=40, whole hot path, reads resident in HBM)",
+               value=last.ninst / (dt / args.steps), unit="k-mers/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+               ms_per_step=1e3 * dt / args.steps, higher_is_better=True, scaling="strong", vs_baseline=None,
+               dtype="u8", data="synthetic",
+               config=dict(workload=cfg["label"] % (cfg["genome_mbp"] * args.scale, "", args.kmer) + scale_note,
+                           reads_per_gpu=per, bases_per_gpu=per * L, kmer_instances=int(last.ninst),
+                           supermers=int(last.nsuper), weighted_kmers=int(last.nweighted),
+                           distinct_kmers=int(last.ndistinct), table_entries=int(last.ntable), table_cutoff=cfg["cutoff"],
+                           parallelism="minimizer-bucket shard x%d through fk_shard_* (RCCL from C), %d exchange rounds "
+                                       "overlapped with counting" % (world, ctx.params.nbuckets // world)),
+               stage_ms_rank0=dict((k, round(v, 3)) for k, v in last.ms.items()))
+    if rank == 0:
+        print(json.dumps(out))
+    shard.close()
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -327,7 +402,7 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
 
-    cfg_id = args.config or (1 if sharded else 2)
+    cfg_id = args.config or (3 if world > 1 else (1 if sharded else 2))
     cfg = dict(CONFIGS[cfg_id])
     for key, val in (("genome_mbp", args.genome_mbp), ("coverage", args.coverage), ("read_len", args.read_len),
                      ("err_ppm", args.err_ppm), ("cutoff", args.cutoff), ("buckets", args.stream_buckets),
@@ -338,6 +413,9 @@ def main():
     args.device_budget_gb = 280.0 if cfg_id == 2 else 0.0
     args.e2e_threads = 32 if cfg_id == 2 else 4
     args.e2e_mem_gb = 256 if cfg_id == 2 else 64
+
+    if cfg_id == 3:
+        return main_config3(args, cfg, torch, fastk_amd, dist if sharded else None, rank, local_rank, world, dev)
 
     L = cfg["read_len"]
     glen = int(cfg["genome_mbp"] * 1e6 * args.scale) * world

@@ -4,4 +4,4 @@ The product is the C-ABI shared library fastk_amd/lib/libfastk_amd.so (hand-writ
 include/fastk_amd.h); this package is its ctypes host mirror.
 """
 from .api import (Context, DeviceBuffer, FastKError, Result, HIST_BINS, EXPORTS, LIB_PATH,  # noqa: F401
-                  load_library, widths, write_files)
+                  load_library, widths, write_files, Shard)

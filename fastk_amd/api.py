@@ -28,7 +28,7 @@ EXPORTS = [
     "fk_make_profiles", "fk_write_prof", "fk_set_table", "fk_ktab_idx_bytes", "fk_ktab_split",
     "fk_write_ktab_range", "fk_write_ktab_stub", "fk_split_supermers_emit_pos", "fk_profile_lookup_supermers",
     "fk_profile_scatter", "fk_profile_encode", "fk_reset", "fk_shard_unique_id", "fk_shard_create",
-    "fk_shard_count", "fk_shard_write", "fk_shard_destroy",
+    "fk_shard_count", "fk_shard_write", "fk_shard_destroy", "fk_shard_count_device",
 ]
 
 
@@ -114,6 +114,7 @@ def load_library():
     L.fk_shard_unique_id.argtypes = [C.c_char_p]
     L.fk_shard_create.argtypes = [vp, ci, ci, C.c_char_p, C.POINTER(vp)]
     L.fk_shard_count.argtypes = [vp, C.POINTER(CResult)]
+    L.fk_shard_count_device.argtypes = [vp, vp, i64, C.POINTER(CResult)]
     L.fk_shard_write.argtypes = [vp, C.POINTER(CResult), ci, C.c_char_p, C.c_char_p]
     L.fk_shard_destroy.argtypes = [vp]
     L.fk_shard_destroy.restype = None
@@ -506,6 +507,42 @@ class Context:
                 return None
         self._ck(rc)
         return hist, mi.value, nd.value, nt.value
+
+
+class Shard:
+    """fk_shard wrapper: this process is one rank of a sharded run (include/fastk_amd.h).  The context must have
+    been created with nbuckets = world * rounds."""
+
+    def __init__(self, ctx, rank, world, unique_id):
+        self.ctx, self.rank, self.world = ctx, rank, world
+        self.h = C.c_void_p()
+        ctx._ck(ctx.L.fk_shard_create(ctx.h, rank, world, bytes(unique_id), C.byref(self.h)))
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        L = load_library()
+        if L.fk_shard_unique_id(buf) != 0:
+            raise FastKError("fk_shard_unique_id failed: %s" % L.fk_last_error(None).decode())
+        return buf.raw
+
+    def count(self, ptr=None, nbytes=0):
+        """Exchange + count + all-reduce over the pushed reads, or over resident reads at ptr.  Returns the
+        GLOBAL Result (table stays sharded in HBM)."""
+        r = CResult()
+        if ptr is None:
+            self.ctx._ck(self.ctx.L.fk_shard_count(self.h, C.byref(r)))
+        else:
+            self.ctx._ck(self.ctx.L.fk_shard_count_device(self.h, ptr, nbytes, C.byref(r)))
+        return Result(r, self.ctx.w.kmer_word)
+
+    def write(self, res, nparts, outdir, root):
+        self.ctx._ck(self.ctx.L.fk_shard_write(self.h, C.byref(res._c), nparts, outdir.encode(), root.encode()))
+
+    def close(self):
+        if self.h:
+            self.ctx.L.fk_shard_destroy(self.h)
+            self.h = None
 
 
 def write_files(kmer, table_cutoff, nthreads, hist, max_inst, table, outdir, root, wfirst=None):

@@ -233,11 +233,11 @@ static int reserve_inbox(fk_shard *sh, int i, int64_t bytes)
    res: the GLOBAL histogram, max_inst and totals (identical on every rank), wfirst = first-byte census of
    the whole table, ntable = its entries; res->table is NULL -- every rank's share stays in HBM for
    fk_shard_write.  Returns FK_EHIP with a message if the exchange did not conserve records or k-mers. */
+static int shard_count(fk_shard *sh, const void *d_reads, int64_t reads_len, fk_result *res);
+
 extern "C" int fk_shard_count(fk_shard *sh, fk_result *res)
 { if (sh == NULL || res == NULL) return (FK_EINVAL);
   fk_ctx *ctx = sh->ctx;
-  const int W = sh->world, R = sh->rounds, me = sh->rank, nb = ctx->prm.nbuckets;
-  const int stride = ctx->wid.smer_stride;
   FK_HIP(ctx, hipSetDevice(ctx->device));
   if (ctx->chunk_bytes > 0 || ctx->prm.exact_parts)
     { fk_set_error(ctx, "fk_shard_count: the sharded run keeps its stripe of reads resident (hbm_budget 0, no exact_parts)");
@@ -245,22 +245,43 @@ extern "C" int fk_shard_count(fk_shard *sh, fk_result *res)
     }
   FK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
   FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return shard_count(sh, ctx->d_reads, ctx->reads_len, res);
+}
+
+/* The same over reads that are already resident in HBM and stay owned by the caller (16-byte aligned; any
+   byte that is not acgtACGT separates reads), like fk_count_device_reads. */
+extern "C" int fk_shard_count_device(fk_shard *sh, const void *d_bases, int64_t nbytes, fk_result *res)
+{ if (sh == NULL || res == NULL || nbytes < 0 || (d_bases == NULL && nbytes > 0)) return (FK_EINVAL);
+  fk_ctx *ctx = sh->ctx;
+  if (((uintptr_t) d_bases & 15) != 0)
+    { fk_set_error(ctx, "fk_shard_count_device: read buffer must be 16-byte aligned");
+      return (FK_EINVAL);
+    }
+  FK_HIP(ctx, hipSetDevice(ctx->device));
+  FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return shard_count(sh, d_bases, nbytes, res);
+}
+
+static int shard_count(fk_shard *sh, const void *d_reads, int64_t reads_len, fk_result *res)
+{ fk_ctx *ctx = sh->ctx;
+  const int W = sh->world, R = sh->rounds, me = sh->rank, nb = ctx->prm.nbuckets;
+  const int stride = ctx->wid.smer_stride;
 
   // ---- split this rank's reads into bucketed super-mers (planned regions, exact pair on overflow)
   int64_t cap = 0, offs[257], cnt[256], ninst = 0;
   void   *outbox = NULL;
   memset(cnt, 0, sizeof(cnt));
   memset(offs, 0, sizeof(offs));
-  int rc = fkx_split_plan(ctx, ctx->d_reads, ctx->reads_len, &cap, offs);
+  int rc = fkx_split_plan(ctx, d_reads, reads_len, &cap, offs);
   if (rc != FK_OK) return (rc);
   if (cap > 0)
     { if ((outbox = fk_slot(ctx, FK_SLOT_SM_A, cap * stride)) == NULL) return (FK_ENOMEM);
-      rc = fkx_split_planned(ctx, ctx->d_reads, ctx->reads_len, outbox, cap, offs, cnt, &ninst);
+      rc = fkx_split_planned(ctx, d_reads, reads_len, outbox, cap, offs, cnt, &ninst);
       if (rc == FK_ESTATE)
         { int64_t ns = 0;
-          if ((rc = fkx_split(ctx, ctx->d_reads, ctx->reads_len, NULL, 0, &ns, &ninst, cnt, false)) != FK_OK) return (rc);
+          if ((rc = fkx_split(ctx, d_reads, reads_len, NULL, 0, &ns, &ninst, cnt, false)) != FK_OK) return (rc);
           if ((outbox = fk_slot(ctx, FK_SLOT_SM_A, std::max<int64_t>(ns, 1) * stride)) == NULL) return (FK_ENOMEM);
-          if (ns > 0 && (rc = fkx_split(ctx, ctx->d_reads, ctx->reads_len, outbox, ns, &ns, &ninst, cnt, true)) != FK_OK)
+          if (ns > 0 && (rc = fkx_split(ctx, d_reads, reads_len, outbox, ns, &ns, &ninst, cnt, true)) != FK_OK)
             return (rc);
           int64_t run = 0;
           for (int b = 0; b < nb; b++) { offs[b] = run; run += cnt[b]; }

@@ -820,7 +820,7 @@ def test_bench_contract_with_two_ranks_on_one_gpu():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", "29663", os.path.join(root, "bench.py"),
-           "--gpus", "2", "--steps", "2", "--warmup", "1", "--genome-mbp", "2"]
+           "--gpus", "2", "--config", "1", "--steps", "2", "--warmup", "1", "--genome-mbp", "2"]
     env = dict(os.environ, FK_RANKS_SHARE_GPU="1")
     p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
     if p.returncode != 0 and any(m in p.stdout + p.stderr for m in _RCCL_RIG_ERRORS):
@@ -835,6 +835,42 @@ def test_bench_contract_with_two_ranks_on_one_gpu():
     reads = int(50 * 2 * 2e6 / 150) // 2 * 2
     assert out["config"]["kmer_instances"] == reads * 111
     assert out["value"] > 0 and out["roofline"]["achieved"] > 0 and "cpu_baseline" not in out
+
+
+@pytest.mark.parametrize("ranks", [1, 2])
+def test_bench_config3_through_the_c_shard_engine(ranks):
+    """bench.py --config 3 (BASELINE configs[3]: the HiFi-shaped set striped over the GPUs, strong scaling) drives
+    fk_shard_count_device -- RCCL called from C -- under the driver's torch.distributed.run command line; at 1/1000
+    scale, two ranks on the one GPU.  Totals must equal a plain one-context count of the same reads."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tail = [os.path.join(root, "bench.py"), "--gpus", str(ranks), "--scale", "0.001", "--steps", "2", "--warmup", "1"]
+    if ranks == 1:
+        tail += ["--config", "3"]                 # (with several ranks configs[3] is the default)
+    if ranks == 1:
+        cmd, env = [sys.executable] + tail, dict(os.environ)
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
+               "--master-addr", "127.0.0.1", "--master-port", "29671"] + tail
+        env = dict(os.environ, FK_RANKS_SHARE_GPU="1")
+    p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    if p.returncode != 0 and any(m in p.stdout + p.stderr for m in _RCCL_RIG_ERRORS):
+        if os.environ.get("FK_REQUIRE_RANKS") == "1":
+            pytest.fail("RCCL would not bring up %d ranks on one GPU: %s" % (ranks, p.stderr[-500:]))
+        pytest.skip("RCCL would not bring up several ranks on one GPU here: " + p.stderr[-300:])
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    lines = [x for x in p.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == ranks and out["scaling"] == "strong" and "configs[3]" in out["config"]["workload"]
+    L, glen, k = 15000, 3_000_000, 40
+    nreads = int(50 * glen / L) // ranks * ranks
+    assert out["config"]["kmer_instances"] == nreads * (L - k + 1)
+    with fastk_amd.Context(kmer=k, table_cutoff=4) as ctx:
+        buf, n = ctx.synth_reads(20251001, glen, L, 2000, 0, nreads)
+        ref = ctx.count_device_reads(buf.ptr, n, fetch_table=False)
+        buf.free()
+    assert (out["config"]["distinct_kmers"], out["config"]["table_entries"]) == (ref.ndistinct, ref.ntable)
 
 
 def test_sharded_final_gather_writes_reference_files(tmp_path):
