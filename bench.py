@@ -349,6 +349,19 @@ def main_config3(args, cfg, torch, fastk_amd, dist, rank, local_rank, world, dev
     expect = total_reads * (L - args.kmer + 1)
     assert last.ninst == expect, "k-mer instance count %d != %d" % (last.ninst, expect)
     scale_note = "" if args.scale == 1.0 else " SCALED by %g (development run)" % args.scale
+    # roofline of the graded kernel on rank 0's share: k_rx_scatter<3,12> over the weighted k-mers of the pieces
+    # this rank counted (2 launches per piece), same accounting as at N = 1
+    loc = shard.local_result()
+    w = ctx.w
+    nl = max(loc.launches_kmer, 1)
+    passes_k = max(loc.passes_kmer, 1)
+    algo = 2.0 * loc.nweighted * w.kmer_word * passes_k
+    ach = round(algo / (loc.ms_scatter_kmer * 1e-3) / 1e9, 1) if loc.ms_scatter_kmer > 0 else 0.0
+    roofline = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
+                    traffic=None, algorithmic_bytes=round(algo / nl, 1),
+                    kernel="k_rx_scatter<3,12> (weighted k-mer records, R=%d B), rank 0's share" % w.kmer_word,
+                    records_per_launch=int(loc.nweighted / (nl / passes_k)), launches_per_step=int(nl),
+                    avg_launch_ms=round(loc.ms_scatter_kmer / nl, 4))
     out = dict(metric="canonical k-mers/sec (k=40, whole hot path, reads resident in HBM)",
                value=last.ninst / (dt / args.steps), unit="k-mers/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                ms_per_step=1e3 * dt / args.steps, higher_is_better=True, scaling="strong", vs_baseline=None,
@@ -359,6 +372,7 @@ def main_config3(args, cfg, torch, fastk_amd, dist, rank, local_rank, world, dev
                            distinct_kmers=int(last.ndistinct), table_entries=int(last.ntable), table_cutoff=cfg["cutoff"],
                            parallelism="minimizer-bucket shard x%d through fk_shard_* (RCCL from C), %d exchange rounds "
                                        "overlapped with counting" % (world, ctx.params.nbuckets // world)),
+               roofline=roofline,
                stage_ms_rank0=dict((k, round(v, 3)) for k, v in last.ms.items()))
     if rank == 0:
         print(json.dumps(out))

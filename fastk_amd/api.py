@@ -28,7 +28,7 @@ EXPORTS = [
     "fk_make_profiles", "fk_write_prof", "fk_set_table", "fk_ktab_idx_bytes", "fk_ktab_split",
     "fk_write_ktab_range", "fk_write_ktab_stub", "fk_split_supermers_emit_pos", "fk_profile_lookup_supermers",
     "fk_profile_scatter", "fk_profile_encode", "fk_reset", "fk_shard_unique_id", "fk_shard_create",
-    "fk_shard_count", "fk_shard_write", "fk_shard_destroy", "fk_shard_count_device",
+    "fk_shard_count", "fk_shard_write", "fk_shard_destroy", "fk_shard_count_device", "fk_shard_local_result",
 ]
 
 
@@ -115,6 +115,7 @@ def load_library():
     L.fk_shard_create.argtypes = [vp, ci, ci, C.c_char_p, C.POINTER(vp)]
     L.fk_shard_count.argtypes = [vp, C.POINTER(CResult)]
     L.fk_shard_count_device.argtypes = [vp, vp, i64, C.POINTER(CResult)]
+    L.fk_shard_local_result.argtypes = [vp, C.POINTER(CResult)]
     L.fk_shard_write.argtypes = [vp, C.POINTER(CResult), ci, C.c_char_p, C.c_char_p]
     L.fk_shard_destroy.argtypes = [vp]
     L.fk_shard_destroy.restype = None
@@ -534,6 +535,11 @@ class Shard:
             self.ctx._ck(self.ctx.L.fk_shard_count(self.h, C.byref(r)))
         else:
             self.ctx._ck(self.ctx.L.fk_shard_count_device(self.h, ptr, nbytes, C.byref(r)))
+        return Result(r, self.ctx.w.kmer_word)
+
+    def local_result(self):
+        r = CResult()
+        self.ctx._ck(self.ctx.L.fk_shard_local_result(self.h, C.byref(r)))
         return Result(r, self.ctx.w.kmer_word)
 
     def write(self, res, nparts, outdir, root):

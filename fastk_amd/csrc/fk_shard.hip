@@ -248,6 +248,15 @@ extern "C" int fk_shard_count(fk_shard *sh, fk_result *res)
   return shard_count(sh, ctx->d_reads, ctx->reads_len, res);
 }
 
+/* This rank's own share of the last fk_shard_count: its record / k-mer counts and the per-kernel timings
+   (ms_scatter_kmer, launches_kmer ...) that the roofline accounting needs; table is NULL. */
+extern "C" int fk_shard_local_result(fk_shard *sh, fk_result *res)
+{ if (sh == NULL || res == NULL) return (FK_EINVAL);
+  *res = sh->local;
+  res->table = NULL;
+  return (FK_OK);
+}
+
 /* The same over reads that are already resident in HBM and stay owned by the caller (16-byte aligned; any
    byte that is not acgtACGT separates reads), like fk_count_device_reads. */
 extern "C" int fk_shard_count_device(fk_shard *sh, const void *d_bases, int64_t nbytes, fk_result *res)

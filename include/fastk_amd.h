@@ -411,6 +411,8 @@ int  fk_shard_count(fk_shard *sh, fk_result *res);
 /* fk_shard_count over a stripe that is already resident in HBM and stays owned by the caller (16-byte aligned;
    any byte that is not acgtACGT separates reads), the sharded twin of fk_count_device_reads */
 int  fk_shard_count_device(fk_shard *sh, const void *d_bases, int64_t nbytes, fk_result *res);
+/* this rank's own share of the last fk_shard_count (counts and per-kernel device times; table NULL) */
+int  fk_shard_local_result(fk_shard *sh, fk_result *res);
 int  fk_shard_write(fk_shard *sh, const fk_result *res, int nparts, const char *dir, const char *root);
 void fk_shard_destroy(fk_shard *sh);
 
