@@ -52,7 +52,7 @@ CONFIGS = {
             label="50x coverage, 150 bp reads, err 1000 ppm, of a %g Mbp genome%s, k=%d -t1 "
                   "(BASELINE.json configs[1])"),
     2: dict(genome_mbp=3000.0, coverage=50.0, read_len=15000, err_ppm=2000, cutoff=4, buckets=48,
-            split_passes=2, cpu_sample_mbp=20.0,
+            split_passes=3, cpu_sample_mbp=20.0,
             label="50x coverage, 15 kbp HiFi-shaped reads, err 2000 ppm, of a %g Mbp genome%s, k=%d -t4 "
                   "(BASELINE.json configs[2])"),
     3: dict(genome_mbp=3000.0, coverage=50.0, read_len=15000, err_ppm=2000, cutoff=4, buckets=1,

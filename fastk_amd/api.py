@@ -60,7 +60,7 @@ class CResult(C.Structure):
                 ("ms_scatter_super", C.c_double), ("ms_scatter_kmer", C.c_double),
                 ("ncollapsed", C.c_int64), ("passes_final", C.c_int), ("ms_pass_final", C.c_double),
                 ("launches_super", C.c_int64), ("launches_kmer", C.c_int64), ("split_passes", C.c_int),
-                ("buckets_counted", C.c_int), ("spilled_bytes", C.c_int64), ("ms_table_sort", C.c_double)]
+                ("replay_passes", C.c_int), ("buckets_counted", C.c_int), ("spilled_bytes", C.c_int64), ("ms_table_sort", C.c_double)]
 
 
 class CProfiles(C.Structure):
@@ -199,6 +199,7 @@ class Result:
         self.passes_final, self.ms_pass_final = int(cres.passes_final), float(cres.ms_pass_final)
         self.launches_super, self.launches_kmer = int(cres.launches_super), int(cres.launches_kmer)
         self.split_passes, self.buckets_counted = int(cres.split_passes), int(cres.buckets_counted)
+        self.replay_passes = int(cres.replay_passes)
         self.spilled_bytes, self.ms_table_sort = int(cres.spilled_bytes), float(cres.ms_table_sort)
         if self.ntable > 0 and cres.table:
             self.table = np.ctypeslib.as_array(cres.table, shape=(self.ntable, kmer_word)).copy()

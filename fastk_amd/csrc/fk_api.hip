@@ -446,6 +446,10 @@ extern "C" int fk_debug_set(fk_ctx *ctx, const char *key, int64_t value)
     { ctx->dbg_aggr_limit = (int) value;
       return (FK_OK);
     }
+  if (strcmp(key, "split_replay") == 0)     // 0: every pass of a multi-pass split recomputes the minimizers
+    { ctx->dbg_no_replay = (value == 0) ? 1 : 0;
+      return (FK_OK);
+    }
   if (strcmp(key, "kmer_stage") == 0)       // 1: sort / collapse / sort instead of hash aggregation
     { ctx->dbg_kmer_stage = (int) value;
       return (FK_OK);
@@ -1811,6 +1815,25 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
               gmax = std::max(gmax, sum);
             }
           ctx->acc_ns_total = gcap_all;
+          // Entry replay: the first pass also records the 4-byte entries (start, flip, length, bucket) of the
+          // super-mers it does not emit; the later passes rebuild their records from those and the reads and
+          // skip the minimizer computation (72 % of a pass).  Falls back to full passes when the entries do
+          // not fit or cannot be allocated.
+          bool replay = (ctx->dbg_no_replay == 0);
+          if (replay)
+            { int64_t first = 0;
+              for (int b = gb[0]; b < gb[1]; b++)
+                first += est[b];
+              const int64_t ntiles = (nbytes - ctx->prm.kmer + 1 + 4095) / 4096;
+              ctx->ent_cap = ((gcap_all - first) + (gcap_all - first) / 16 + 64 * 8192) / 64 * 64;
+              const int64_t nchunks = (ntiles + 15) / 16;
+              if (fk_slot(ctx, FK_SLOT_ENT, ctx->ent_cap * 4) == NULL || fk_slot(ctx, FK_SLOT_TENT, ntiles * 8) == NULL
+                  || fk_slot(ctx, FK_SLOT_TCNT, ntiles * nbk * 2) == NULL
+                  || fk_slot(ctx, FK_SLOT_CBASE, nchunks * nbk * 12) == NULL)
+                { replay = false;
+                  ctx->err[0] = 0;
+                }
+            }
           hipEvent_t gev[2];
           if (hipEventCreate(&gev[0]) != hipSuccess || hipEventCreate(&gev[1]) != hipSuccess)
             { rc = FK_EHIP; break; }
@@ -1822,7 +1845,8 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
                   for (int b = 0; b < nbk; b++)
                     { lo[b] = run;
                       if (b >= gb[g] && b < gb[g + 1])
-                        run += (int64_t) ((double) est[b] * grow);
+                        run += (replay && g > 0) ? ctx->ent_totals[b]            // exact: the recording pass counted them
+                                                 : (int64_t) ((double) est[b] * grow);
                     }
                   lo[nbk] = run;
                   void *out = fk_slot(ctx, FK_SLOT_SM_A, std::max(run, gmax) * w.smer_stride);
@@ -1830,7 +1854,9 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
                   sm_a = out;
                   hipEventRecord(gev[0], s);
                   rc = fkx_split_planned(ctx, d_reads, nbytes, out, ctx->slot_cap[FK_SLOT_SM_A] / w.smer_stride,
-                                         lo, cnt, &nig, gb[g], gb[g + 1]);
+                                         lo, cnt, &nig, gb[g], gb[g + 1], replay ? (g == 0 ? 1 : 2) : 0);
+                  if (replay && g == 0 && rc == FK_OK && !ctx->ent_valid)
+                    replay = false;                 // the entries did not fit: full passes for the other groups
                   hipEventRecord(gev[1], s);
                   hipEventSynchronize(gev[1]);
                   ms_split_groups += ms_between(gev[0], gev[1]);
@@ -1842,6 +1868,7 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
                 break;
               if (g == 0)
                 res->ninst = nig;
+              res->replay_passes += (replay && g > 0) ? 1 : 0;
               for (int b = gb[g]; b < gb[g + 1] && rc == FK_OK; b++)
                 { tot += cnt[b];
                   rc = count_bucket(ctx, (char *) sm_a + lo[b] * w.smer_stride, cnt[b], res, false, NULL,

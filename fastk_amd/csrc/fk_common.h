@@ -14,7 +14,7 @@
 typedef unsigned long long u64;
 typedef unsigned int       u32;
 
-#define FK_NSLOTS 40
+#define FK_NSLOTS 48
 
 // Minimizers are canonical 7-mers ordered by a bijective mix of their 14-bit code (odd multiplies and
 // xor-shifts are invertible mod 2^14, so distinct 7-mers never tie): FK_NRANKS rank values, of which
@@ -75,7 +75,12 @@ struct fk_ctx
   uint8_t   *d_mbucket_pass; // [FK_NRANKS] the same for one group pass of a multi-pass split (0xFF = not now)
   uint8_t    h_mbucket[FK_NRANKS];
   uint8_t   *h_mbucket_pass; // pinned staging of d_mbucket_pass
-  u64       *d_cursors;      // [256 * FK_CURSOR_STRIDE] per-bucket write cursors of the planned split, 4 KB apart
+  u64       *d_cursors;      // [(256 + 64) * FK_CURSOR_STRIDE] per-bucket write cursors of the planned split, 4 KB apart,
+                             // then the 64 cursors of the entry sub-regions
+  int64_t    ent_cap;        // multi-pass split with replay: room (entries) in FK_SLOT_ENT
+  int64_t    ent_ntiles;     // tiles the recorded entries belong to
+  bool       ent_valid;      // the last recording pass fitted
+  int64_t    ent_totals[256];// exact super-mers per bucket, from the recording pass's count table
 
   // small device scratch (counters, histograms)
   u64       *d_scratch;   // 64 KB
@@ -149,6 +154,7 @@ struct fk_ctx
   int        dbg_radix_engine;    // 1 = look-back engine instead of the stream engine
   int        dbg_kmer_stage;      // 1 = sort-collapse-sort k-mer stage instead of hash aggregation
   int        dbg_verbose;
+  int        dbg_no_replay;       // 1: multi-pass split without entry replay
   int        dbg_smer_stage;      // 1: four hashed grouping passes for the super-mers (no LDS de-duplication)
   int        dbg_table_sort;      // 1: plain KMER_BYTES-pass table sort; >= 2: prefix length of the short sort
   int64_t    tsort_ties;          // records the last table sort had to repair
@@ -173,7 +179,7 @@ enum { FK_SLOT_SM_A = 0, FK_SLOT_SM_B, FK_SLOT_KM_A, FK_SLOT_KM_B, FK_SLOT_EX_HE
        FK_SLOT_RX_TILE, FK_SLOT_RX_CHUNK, FK_SLOT_RX_SUPER, FK_SLOT_ROFF, FK_SLOT_AG_BOUNDS, FK_SLOT_TABLE, FK_SLOT_SM_G,
        FK_SLOT_RAW, FK_SLOT_FQ_INFO, FK_SLOT_FQ_PHASE, FK_SLOT_FQ_OFF, FK_SLOT_TIE_A, FK_SLOT_TIE_B,
        FK_SLOT_TIE_POS, FK_SLOT_SM_D, FK_SLOT_PF_IDX, FK_SLOT_PF_CNT, FK_SLOT_PF_ZC, FK_SLOT_PF_ZO,
-       FK_SLOT_PF_ENDS, FK_SLOT_PF_LEN, FK_SLOT_PF_OFF, FK_SLOT_PF_OUT };
+       FK_SLOT_PF_ENDS, FK_SLOT_PF_LEN, FK_SLOT_PF_OFF, FK_SLOT_PF_OUT, FK_SLOT_ENT, FK_SLOT_TENT, FK_SLOT_TCNT, FK_SLOT_CBASE };
 
 // returns a device buffer of at least nbytes for the given purpose (NULL + error set on failure)
 void *fk_slot(fk_ctx *ctx, int slot, int64_t nbytes);
@@ -201,7 +207,7 @@ int fkx_split(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int
               void *d_pos = NULL);
 int fkx_split_plan(fk_ctx *ctx, const void *d_bases, int64_t nbytes, int64_t *cap, int64_t *offsets);
 int fkx_split_planned(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int64_t cap,
-                      const int64_t *offsets, int64_t *counts, int64_t *ninst, int b0 = 0, int b1 = -1);
+                      const int64_t *offsets, int64_t *counts, int64_t *ninst, int b0 = 0, int b1 = -1, int mode = 0);
 int fkx_train_tran(fk_ctx *ctx, const void *d_bases, const int64_t *h_roff, int64_t train_reads,
                    int nthreads, int *tran);
 int fkx_split_exact(fk_ctx *ctx, const void *d_bases, const int64_t *d_roff, int64_t nreads,

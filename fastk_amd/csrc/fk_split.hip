@@ -32,7 +32,8 @@
 #define SP_MAXK    64                       // fk_create admits k <= 64; 27.1 KB of LDS lets six workgroups share a CU
 #define SP_WORDS   (SP_TILE / 16 + SP_MAXK / 16 + 2)   // packed words incl. halo and guard
 #define SP_KEYS    (SP_TILE + SP_MAXK)
-#define SP_KIDX(i) ((i) + ((i) >> 4))     // one pad word per 16 keys: thread t's chunk starts at bank 17t
+#define SP_KIDX(i) ((i) + ((i) >> 4))
+#define SP_RCH     16                      // tiles per chunk of the replay offsets (in-chunk prefixes fit 16 bits)     // one pad word per 16 keys: thread t's chunk starts at bank 17t
 
 struct SplitArgs
 { const unsigned char *bases;
@@ -53,6 +54,19 @@ struct SplitArgs
   int       tile_stride;    // count mode: visit every tile_stride-th tile only (sampling)
   u64      *pos;            // POS kernels only: (position of the record's first k-mer << 1) | flip per record
   int64_t   tile0;          // first tile of this launch (a grid holds at most SP_MAXGRID workgroups)
+  // multi-pass split with entry replay: the first pass emits the records of buckets [gb0, gb1) and leaves, per
+  // tile, the 4-byte entries (start, flip, length, bucket) of all OTHER super-mers behind; the later passes
+  // rebuild their records from the entries and the reads (k_split_replay) without recomputing any minimizer
+  u32      *ent;            // entries, 64 sub-regions of ent_cap / 64 each (NULL: not recording)
+  u64      *ent_cursor;     // [64 * cstride] write cursors of the sub-regions
+  u64      *tile_ent;       // [tiles] (absolute first entry << 13) | entries of the tile
+  int64_t   ent_cap;
+  int       gb0, gb1;
+  // the recording pass also leaves, per tile and bucket, the number of super-mers (u16 [tiles][nbuckets]); two
+  // small scans turn them into in-chunk prefixes (in place) and chunk bases, so a replay pass knows where each of
+  // its records goes without a single global atomic (24 cursor round trips per tile were 3/4 of a replay pass)
+  uint16_t *tile_cnt;       // [tiles * nbuckets]: counts, after the scan exclusive prefixes inside a chunk of SP_RCH tiles
+  const u64 *chunk_base;    // [chunks * nbuckets] records of the bucket in all earlier chunks
   u32       skipb;          // super-mers whose bucket entry equals skipb are dropped (0xFF in a group
                             // pass of a multi-pass split, where mbucket marks the other groups' ranks;
                             // 0x100 = nothing is dropped)
@@ -120,6 +134,9 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
   __shared__ uint16_t vbits[SP_THREADS + 16];
   __shared__ u32      bcnt[256];
   __shared__ u32      tmp32[8];
+  __shared__ u32      nother, nother2;
+  __shared__ u64      ebase;
+  const bool rec = (a.ent != NULL);
 
   u64 *bbase   = (u64 *) aux32;           // [256]
   u32 *bcnt2   = aux32 + 512;             // [256]
@@ -133,6 +150,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
   const bool    one = (a.nbuckets == 1);           // single bucket: no per-record LDS atomics
 
   bcnt[tid] = 0;
+  if (tid == 0) { nother = 0; nother2 = 0; }
 
   // ---- 1. ASCII -> 2-bit codes (MSB first) + invalid masks -------------------------------
   for (int q = tid; q < SP_WORDS; q += SP_THREADS)
@@ -332,8 +350,10 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
           u32 b = 0;
           if (!one)
             { b = a.mbucket[key >> 15];
-              if (b != a.skipb)
-                atomicAdd(&bcnt[b], 1u);
+              if (rec || b != a.skipb)
+                atomicAdd(&bcnt[b], 1u);                  // (recording: every bucket is counted, the row goes to tile_cnt)
+              if (rec && !(b >= (u32) a.gb0 && b < (u32) a.gb1))
+                atomicAdd(&nother, 1u);
             }
           if (EMIT)
             slist[k] = (u32) i | ((key & 1u) << 12) | ((u32) n << 13) | (b << 20);
@@ -343,6 +363,22 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
   if (one && tid == 0)
     bcnt[0] = nstart_total;
   __syncthreads();
+  if (EMIT && rec && tid == SP_THREADS - 1)
+    { // room for this tile's other entries in sub-region (tile mod 64)
+      const u32 lane64 = blockIdx.x & 63u;
+      const u64 sub = (u64) (a.ent_cap / 64);
+      u64 at = 0;
+      if (nother != 0)
+        { at = atomicAdd(&a.ent_cursor[(size_t) lane64 * a.cstride], (u64) nother);
+          if (at + nother > sub)
+            { *a.overflowed = 2;
+              at = 0;
+              nother = 0;
+            }
+        }
+      ebase = (u64) lane64 * sub + at;
+      a.tile_ent[a.tile0 + blockIdx.x] = (ebase << 13) | (u64) nother;
+    }
 
   if (!EMIT)
     { if (tid < a.nbuckets && bcnt[tid] != 0)
@@ -350,7 +386,9 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
       return;
     }
 
-  if (tid < a.nbuckets && bcnt[tid] != 0)
+  if (rec && tid < a.nbuckets)
+    a.tile_cnt[(size_t) (a.tile0 + blockIdx.x) * a.nbuckets + tid] = (uint16_t) bcnt[tid];
+  if (tid < a.nbuckets && bcnt[tid] != 0 && (!rec || (tid >= a.gb0 && tid < a.gb1)))
     bbase[tid] = atomicAdd(&a.cursor[(size_t) tid * a.cstride], (u64) bcnt[tid]);
   __syncthreads();
 
@@ -364,7 +402,14 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
       const u32 flip = (e >> 12) & 1u;
       const int n    = (e >> 13) & 0x7fu;
       const u32 b    = e >> 20;
-      if (b == a.skipb)
+      if (rec)
+        { if (!(b >= (u32) a.gb0 && b < (u32) a.gb1))
+            { if (nother != 0)
+                a.ent[ebase + atomicAdd(&nother2, 1u)] = e;
+              continue;
+            }
+        }
+      else if (b == a.skipb)
         continue;
       const u64 slot = bbase[b] + (one ? s : atomicAdd(&bcnt2[b], 1u));
       if ((int64_t) slot >= a.cap || (a.limit != NULL && slot >= a.limit[b]))
@@ -377,6 +422,139 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
       u32 *dst = a.out + slot * sww;
       if (POS)
         a.pos[slot] = ((u64) (t0 + i) << 1) | flip;
+      for (int q = 0; q < sww; q++)
+        { u32 x = 0;
+          const int rem = L - 16 * q;
+          if (rem > 0)
+            { x = sp_window(arr, st + 16 * q);
+              if (rem < 16)
+                x &= ~(0xffffffffu >> (2 * rem));
+            }
+          if (q == lenw)
+            x |= ((u32) (n - 1)) << lensh;
+          dst[q] = __builtin_bswap32(x);
+        }
+    }
+}
+
+// tile_cnt rows of SP_RCH consecutive tiles -> exclusive prefixes inside the chunk (in place) + the chunk's totals
+__global__ __launch_bounds__(256) void k_split_chunk(uint16_t *__restrict__ tile_cnt, int64_t ntiles, int nb,
+                                                     u32 *__restrict__ chunk_tot)
+{ const int64_t ch = (int64_t) blockIdx.x * (256 / 64) + (threadIdx.x >> 6);     // one wave per chunk, lane = bucket (+64, ...)
+  const int64_t t0 = ch * SP_RCH;
+  if (t0 >= ntiles) return;
+  for (int b = threadIdx.x & 63; b < nb; b += 64)
+    { u32 run = 0;
+      for (int t = 0; t < SP_RCH && t0 + t < ntiles; t++)
+        { const size_t at = (size_t) (t0 + t) * nb + b;
+          const u32 c = tile_cnt[at];
+          tile_cnt[at] = (uint16_t) run;
+          run += c;
+        }
+      chunk_tot[(size_t) ch * nb + b] = run;
+    }
+}
+
+// per bucket (one workgroup each): exclusive scan of its chunk totals over all chunks; total[b] = all its records
+__global__ __launch_bounds__(256) void k_split_chunkscan(const u32 *__restrict__ chunk_tot, int64_t nchunks, int nb,
+                                                         u64 *__restrict__ chunk_base, u64 *__restrict__ total)
+{ __shared__ u64 tmp[8];
+  const int b = blockIdx.x;
+  const int64_t per = (nchunks + 255) / 256;
+  const int64_t lo = (int64_t) threadIdx.x * per, hi = (lo + per < nchunks) ? lo + per : nchunks;
+  u64 mine = 0;
+  for (int64_t c = lo; c < hi; c++)
+    mine += chunk_tot[(size_t) c * nb + b];
+  u64 tot;
+  u64 run = fk_block_exscan_256<u64>(mine, tmp, &tot);
+  for (int64_t c = lo; c < hi; c++)
+    { chunk_base[(size_t) c * nb + b] = run;
+      run += chunk_tot[(size_t) c * nb + b];
+    }
+  if (threadIdx.x == 0)
+    total[b] = tot;
+}
+
+// A later pass of the multi-pass split: the tile's entries of the first pass (position, flip, length, bucket of
+// every super-mer that pass did not emit) + the reads -> the records of buckets [gb0, gb1).  Steps 1 and 7 of
+// k_split only: no keys, no minima, no validity, no start masks.
+__global__ __launch_bounds__(SP_THREADS) void k_split_replay(SplitArgs a)
+{ __shared__ u32 fwd[SP_WORDS];
+  __shared__ u32 rcw[SP_WORDS];
+  __shared__ u32 slist[SP_TILE];
+  __shared__ __attribute__((aligned(8))) u64 bbase[256];
+  __shared__ u32 bcnt2[256];
+
+  const int     tid = threadIdx.x;
+  const int     K   = a.kmer;
+  const int64_t tile = a.tile0 + blockIdx.x;
+  const u64     te  = a.tile_ent[tile];
+  const u32     cnt = (u32) (te & 0x1fffu);
+  if (cnt == 0)
+    return;
+  const u64     eb  = te >> 13;
+  const int64_t t0  = tile * SP_TILE;
+  const int     nw  = SP_TILE / 16 + (K + 14) / 16;
+  const int     R   = nw * 16;
+
+  bcnt2[tid] = 0;
+  for (u32 s = tid; s < cnt; s += SP_THREADS)
+    slist[s] = a.ent[eb + s];
+  for (int q = tid; q < SP_WORDS; q += SP_THREADS)
+    { u32 word = 0, bad = 0;
+      if (q < nw)
+        { const int64_t g = t0 + (int64_t) q * 16;
+          __attribute__((aligned(16))) unsigned char c[16];
+          if (g + 16 <= a.nbytes)
+            { const uint4 v = *(const uint4 *) (a.bases + g);
+              *(uint4 *) c = v;
+            }
+          else
+            {
+#pragma unroll
+              for (int j = 0; j < 16; j++)
+                c[j] = (g + j < a.nbytes) ? a.bases[g + j] : 0;
+            }
+          sp_pack16(*(const uint4 *) c, word, bad);
+        }
+      fwd[q] = word;
+    }
+  __syncthreads();
+  for (int q = tid; q < SP_WORDS; q += SP_THREADS)
+    { u32 x = 0;
+      if (q < nw)
+        { const u32 y = __builtin_bitreverse32(fwd[nw - 1 - q]);
+          x = ~(((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1));
+        }
+      rcw[q] = x;
+    }
+  // where this tile's records of bucket b go: region start (cursor[b], constant during a replay pass) + the bucket's
+  // records in earlier chunks + in the earlier tiles of this chunk -- exact, no reservation needed
+  if (tid >= a.gb0 && tid < a.gb1)
+    bbase[tid] = a.cursor[(size_t) tid * a.cstride] + a.chunk_base[(size_t) (tile / SP_RCH) * a.nbuckets + tid]
+               + (u64) a.tile_cnt[(size_t) tile * a.nbuckets + tid];
+  __syncthreads();
+
+  const int sww = a.sww;
+  const int lenw = a.smer_bytes >> 2;
+  const int lensh = 24 - 8 * (a.smer_bytes & 3);
+  for (u32 s = tid; s < cnt; s += SP_THREADS)
+    { const u32 e    = slist[s];
+      const int i    = e & 0xfffu;
+      const u32 flip = (e >> 12) & 1u;
+      const int n    = (e >> 13) & 0x7fu;
+      const u32 b    = e >> 20;
+      if (!(b >= (u32) a.gb0 && b < (u32) a.gb1))
+        continue;
+      const u64 slot = bbase[b] + atomicAdd(&bcnt2[b], 1u);
+      if ((int64_t) slot >= a.cap || (a.limit != NULL && slot >= a.limit[b]))
+        { *a.overflowed = 1;
+          continue;
+        }
+      const int  L   = n - 1 + K;
+      const u32 *arr = flip ? rcw : fwd;
+      const int  st  = flip ? (R - (i + L)) : i;
+      u32 *dst = a.out + slot * sww;
       for (int q = 0; q < sww; q++)
         { u32 x = 0;
           const int rem = L - 16 * q;
@@ -449,7 +627,7 @@ int fkx_split(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int
   a.tile_stride = 1;
   a.limit = NULL;
   a.pos = (u64 *) d_pos;
-  a.skipb = 0x100u;
+  a.skipb = 0x100u; a.ent = NULL;
 
   const int64_t nstarts = nbytes - K + 1;
   const int64_t ntiles  = (nstarts + SP_TILE - 1) / SP_TILE;
@@ -537,7 +715,7 @@ int fkx_split_fast(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void **d_ou
           a.mbucket = ctx->d_mbucket;
       a.counts = d_counts;
       a.cursor = d_cursor; a.cstride = 1;
-      a.limit = NULL; a.pos = NULL; a.skipb = 0x100u;
+      a.limit = NULL; a.pos = NULL; a.skipb = 0x100u; a.ent = NULL;
       a.overflowed = d_ovf;
       const int64_t nstarts = nbytes - K + 1;
       const int64_t ntiles  = (nstarts + SP_TILE - 1) / SP_TILE;
@@ -650,7 +828,7 @@ int fkx_split_plan(fk_ctx *ctx, const void *d_bases, int64_t nbytes, int64_t *ca
   a.mbucket = ctx->d_mbucket;
   a.counts = ctx->d_scratch;
   a.cursor = ctx->d_scratch + 512; a.cstride = 1;
-  a.limit = NULL; a.pos = NULL; a.skipb = 0x100u;
+  a.limit = NULL; a.pos = NULL; a.skipb = 0x100u; a.ent = NULL;
   a.out = NULL; a.cap = 0;
   a.overflowed = (u32 *) (ctx->d_scratch + 1024);
   a.tile_stride = sample;
@@ -673,10 +851,13 @@ int fkx_split_plan(fk_ctx *ctx, const void *d_bases, int64_t nbytes, int64_t *ca
 // Emit into the planned regions; counts[b] receives what bucket b really holds.
 // FK_ESTATE: some region was too small (very uneven input) -- use the exact two-call path.
 // [b0, b1) a proper sub-range of the buckets: a GROUP PASS of a multi-pass split -- only the super-mers
-// of these buckets are emitted (offsets[b0..b1] are their regions in d_out), the others are dropped;
-// *ninst still counts every valid k-mer of the input.
+// of these buckets are emitted (offsets[b0..b1] are their regions in d_out); *ninst still counts every
+// valid k-mer of the input.  mode 0: the others are dropped (every pass recomputes all minimizers);
+// mode 1: the others' 4-byte entries are recorded per tile (ctx->ent_cap entries of room; ctx->ent_valid
+// tells whether they all fitted); mode 2: no minimizers at all -- the records of [b0, b1) are rebuilt from
+// the entries a mode-1 pass over the same reads left behind (k_split_replay).
 int fkx_split_planned(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int64_t cap,
-                      const int64_t *offsets, int64_t *counts, int64_t *ninst, int b0, int b1)
+                      const int64_t *offsets, int64_t *counts, int64_t *ninst, int b0, int b1, int mode)
 { hipStream_t s = ctx->stream;
   const int   K = ctx->prm.kmer;
   const int   nb = ctx->prm.nbuckets;
@@ -687,8 +868,8 @@ int fkx_split_planned(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_
   *ninst = 0;
   if (nbytes < K)
     return (FK_OK);
-  if (b0 < 0 || b1 > nb || b0 >= b1 || (group && nb > 255))
-    { fk_set_error(ctx, "planned split: bad bucket range [%d,%d) of %d", b0, b1, nb);
+  if (b0 < 0 || b1 > nb || b0 >= b1 || (group && nb > 255) || (mode != 0 && !group))
+    { fk_set_error(ctx, "planned split: bad bucket range [%d,%d) of %d (mode %d)", b0, b1, nb, mode);
       return (FK_EINVAL);
     }
   if (offsets[b1] > cap)
@@ -707,10 +888,10 @@ int fkx_split_planned(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_
   FK_HIP(ctx, hipMemsetAsync(ctx->d_scratch, 0, 1032 * sizeof(u64), s));
   FK_HIP(ctx, hipMemcpyAsync(ctx->d_scratch + 512, h, 512 * sizeof(u64), hipMemcpyHostToDevice, s));
   if (ctx->d_cursors == NULL)
-    FK_HIP(ctx, hipMalloc((void **) &ctx->d_cursors, 256 * FK_CURSOR_STRIDE * sizeof(u64)));
+    FK_HIP(ctx, hipMalloc((void **) &ctx->d_cursors, (256 + 64) * FK_CURSOR_STRIDE * sizeof(u64)));
   FK_HIP(ctx, hipMemcpy2DAsync(ctx->d_cursors, FK_CURSOR_STRIDE * sizeof(u64), h, sizeof(u64), sizeof(u64), (size_t) nb,
                                hipMemcpyHostToDevice, s));
-  if (group)
+  if (group && mode == 0)
     { uint8_t *hm = ctx->h_mbucket_pass;                          // pinned (the previous pass has been waited for)
       for (int r = 0; r < FK_NRANKS; r++)
         { const int b = ctx->h_mbucket[r];
@@ -725,25 +906,84 @@ int fkx_split_planned(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_
   a.smer_bytes = ctx->wid.smer_bytes;
   a.sww = ctx->wid.smer_stride / 4;
   a.nbuckets = nb;
-  a.mbucket = group ? ctx->d_mbucket_pass : ctx->d_mbucket;
+  a.mbucket = (group && mode == 0) ? ctx->d_mbucket_pass : ctx->d_mbucket;
   a.counts = ctx->d_scratch;
   a.cursor = ctx->d_cursors; a.cstride = FK_CURSOR_STRIDE;
   a.limit = ctx->d_scratch + 768;
   a.pos = NULL;
-  a.skipb = group ? 0xFFu : 0x100u;
+  a.skipb = (group && mode == 0) ? 0xFFu : 0x100u;
   a.out = (u32 *) d_out; a.cap = cap;
   a.overflowed = (u32 *) (ctx->d_scratch + 1024);
   a.tile_stride = 1;
-  sp_launch<true, false>(a, ntiles, s);
+  a.ent = NULL; a.ent_cursor = ctx->d_cursors + 256 * FK_CURSOR_STRIDE; a.tile_ent = NULL; a.ent_cap = 0;
+  a.gb0 = b0; a.gb1 = b1;
+  const int64_t nchunks = (ntiles + SP_RCH - 1) / SP_RCH;
+  a.tile_cnt = NULL; a.chunk_base = NULL;
+  if (mode != 0)
+    { a.ent = (u32 *) ctx->slot_ptr[FK_SLOT_ENT];
+      a.tile_ent = (u64 *) ctx->slot_ptr[FK_SLOT_TENT];
+      a.tile_cnt = (uint16_t *) ctx->slot_ptr[FK_SLOT_TCNT];
+      a.chunk_base = (const u64 *) ctx->slot_ptr[FK_SLOT_CBASE];
+      a.ent_cap = ctx->ent_cap;
+      if (a.ent == NULL || a.tile_ent == NULL || a.tile_cnt == NULL || a.chunk_base == NULL
+          || ctx->slot_cap[FK_SLOT_TENT] < ntiles * 8 || ctx->slot_cap[FK_SLOT_TCNT] < ntiles * nb * 2
+          || ctx->slot_cap[FK_SLOT_CBASE] < nchunks * nb * 12
+          || (mode == 2 && (!ctx->ent_valid || ctx->ent_ntiles != ntiles)))
+        { fk_set_error(ctx, "planned split: no entries to record into / replay from");
+          return (FK_ESTATE);
+        }
+      if (mode == 2)
+        for (int b = b0; b < b1; b++)
+          if (ctx->ent_totals[b] > offsets[b + 1] - offsets[b])
+            { fk_set_error(ctx, "planned split: a bucket region was too small");
+              return (FK_ESTATE);
+            }
+    }
+  if (mode == 1)
+    { FK_HIP(ctx, hipMemsetAsync(a.ent_cursor, 0, 64 * FK_CURSOR_STRIDE * sizeof(u64), s));
+      ctx->ent_valid = false;
+    }
+  if (mode == 2)
+    { for (int64_t t = 0; t < ntiles; t += SP_MAXGRID)
+        { a.tile0 = t;
+          const int64_t nbk = (ntiles - t < SP_MAXGRID) ? (ntiles - t) : SP_MAXGRID;
+          hipLaunchKernelGGL(k_split_replay, dim3((unsigned) nbk), dim3(SP_THREADS), 0, s, a);
+        }
+    }
+  else
+    sp_launch<true, false>(a, ntiles, s);
   FK_LAUNCH_CHECK(ctx);
   FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch, ctx->d_scratch, 1032 * sizeof(u64), hipMemcpyDeviceToHost, s));
   FK_HIP(ctx, hipMemcpy2DAsync(ctx->h_scratch + 512, sizeof(u64), ctx->d_cursors, FK_CURSOR_STRIDE * sizeof(u64),
                                sizeof(u64), (size_t) nb, hipMemcpyDeviceToHost, s));
   FK_HIP(ctx, hipStreamSynchronize(s));
-  if (*(u32 *) (ctx->h_scratch + 1024) != 0)
+  const u32 ovf = *(u32 *) (ctx->h_scratch + 1024);
+  if (ovf == 1)
     { fk_set_error(ctx, "planned split: a bucket region was too small");
       return (FK_ESTATE);
     }
+  if (mode == 1)
+    { ctx->ent_valid = (ovf == 0);                   // 2: the entries did not fit -- the records emitted are fine
+      ctx->ent_ntiles = ntiles;
+      if (ctx->ent_valid)
+        { // counts -> in-chunk prefixes + chunk bases + exact totals of every bucket
+          u32 *ctot = (u32 *) ((u64 *) ctx->slot_ptr[FK_SLOT_CBASE] + (size_t) nchunks * nb);
+          u64 *dtot = ctx->d_scratch + 2048;
+          hipLaunchKernelGGL(k_split_chunk, dim3((unsigned) ((nchunks + 3) / 4)), dim3(256), 0, s,
+                             (uint16_t *) ctx->slot_ptr[FK_SLOT_TCNT], ntiles, nb, ctot);
+          hipLaunchKernelGGL(k_split_chunkscan, dim3((unsigned) nb), dim3(256), 0, s, (const u32 *) ctot, nchunks, nb,
+                             (u64 *) ctx->slot_ptr[FK_SLOT_CBASE], dtot);
+          FK_LAUNCH_CHECK(ctx);
+          FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch + 2048, dtot, (size_t) nb * 8, hipMemcpyDeviceToHost, s));
+          FK_HIP(ctx, hipStreamSynchronize(s));
+          for (int b = 0; b < nb; b++)
+            ctx->ent_totals[b] = (int64_t) ctx->h_scratch[2048 + b];
+        }
+    }
+  if (mode == 2)
+    for (int b = b0; b < b1; b++)
+      counts[b] = ctx->ent_totals[b];
+  else
   for (int b = b0; b < b1; b++)
     counts[b] = (int64_t) ctx->h_scratch[512 + b] - offsets[b];
   int64_t t = 0;

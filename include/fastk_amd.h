@@ -140,6 +140,8 @@ typedef struct
     int64_t  launches_super, launches_kmer; /* scatter launches behind ms_scatter_super / _kmer (with
                                               bucket streaming: passes x buckets)                      */
     int      split_passes;                /* split passes over the reads (fk_params.split_passes)      */
+    int      replay_passes;               /* of those, passes that rebuilt records from recorded entries
+                                             instead of recomputing the minimizers                     */
     int      buckets_counted;             /* non-empty minimizer buckets counted one after the other   */
     int64_t  spilled_bytes;               /* super-mer records that went through host memory           */
     double   ms_table_sort;               /* device time of the table sort (all of its kernels)        */

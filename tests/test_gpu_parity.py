@@ -1085,7 +1085,13 @@ def test_multi_pass_split_over_resident_reads(name, nb, passes):
         rd = ctx.alloc(len(bases) + 64).upload(bases)
         res = ctx.count_device_reads(rd.ptr, len(bases), fetch_table=True)
         assert 1 < res.split_passes <= passes and res.buckets_counted <= nb
+        assert res.replay_passes == res.split_passes - 1       # later passes rebuild records from recorded entries
         util.check_against_golden(case, res.hist, res.max_inst, res.table)
+        ctx.debug_set("split_replay", 0)                        # every pass recomputes the minimizers: same result
+        full = ctx.count_device_reads(rd.ptr, len(bases), fetch_table=True)
+        assert full.replay_passes == 0 and full.split_passes == res.split_passes
+        assert np.array_equal(full.hist, res.hist) and np.array_equal(full.table, res.table) and full.nsuper == res.nsuper
+        ctx.debug_set("split_replay", 1)
         one = ctx.count_device_reads(rd.ptr, len(bases), fetch_table=True)      # arena re-use: same again
         assert np.array_equal(one.hist, res.hist) and np.array_equal(one.table, res.table)
         assert one.nsuper == res.nsuper and one.ninst == res.ninst
@@ -1282,9 +1288,10 @@ def test_full_size_properties_configs1():
 def test_full_size_properties_configs2():
     """BASELINE configs[2] at full size on one GPU: 50x of a 3 Gbp genome in 15 kbp reads with 0.2 %
     substitutions, k=40 -t4 (10 M reads, 150 G bases, 149.61 G k-mer instances, ~8.6 G super-mers,
-    ~22 G weighted k-mers, 3.0 G table entries).  The 150 GB of reads stay resident; the run takes 2
-    split passes over them and 48 minimizer buckets one after the other (bench.py's setting), then again
-    with 3 passes and 40 buckets (other group boundaries, other bucket contents).  Checked: instance
+    ~22 G weighted k-mers, 3.0 G table entries).  The 150 GB of reads stay resident; the run takes 3
+    split passes over them (one that computes the minimizers and records the other groups' entries, two that
+    replay them) and 48 minimizer buckets one after the other (bench.py's setting), then again with 40 buckets
+    and three full passes (other group boundaries, other bucket contents, no replay).  Checked: instance
     count, conservation (sum c*hist[c] + max_inst == instances), sum(hist) == distinct k-mers, table
     entries == sum(hist[4:]), strictly increasing table, table counts reproduce the histogram from the
     cutoff up, and both settings give the identical histogram and table.  A summary goes to
@@ -1304,9 +1311,11 @@ def test_full_size_properties_configs2():
             gen._ck(gen.L.fk_synth_reads(gen.h, 20251001, glen, L, 2000, first, n, buf.ptr + first * (L + 1)))
         gen._ck(gen.L.fk_synchronize(gen.h))
         sample = buf.download(8 << 20)
-        for nb, passes in ((48, 2), (40, 3)):
+        for nb, passes in ((48, 3), (40, 3)):
             with fastk_amd.Context(kmer=k, table_cutoff=cutoff, nbuckets=nb, split_passes=passes) as ctx:
                 ctx.set_bucket_weights(ctx.bucket_census(sample))
+                if nb == 40:
+                    ctx.debug_set("split_replay", 0)          # this run recomputes the minimizers in every pass
                 t0 = time.perf_counter()
                 res = ctx.count_device_reads(buf.ptr, nbytes, fetch_table=True)
                 dt = time.perf_counter() - t0
@@ -1316,6 +1325,7 @@ def test_full_size_properties_configs2():
             assert res.ndistinct == int(h.sum())
             assert res.ntable == int(h[cutoff:].sum()) == len(res.table)
             assert res.split_passes == passes and res.buckets_counted == nb
+            assert res.replay_passes == (passes - 1 if nb == 48 else 0)
             summary["runs"].append(dict(buckets=nb, split_passes=passes, seconds_first_run_with_table_fetch=round(dt, 2),
                                         supermers=res.nsuper, weighted_kmers=res.nweighted, distinct_kmers=res.ndistinct,
                                         table_entries=res.ntable, device_ms=res.ms))
@@ -1339,7 +1349,7 @@ def test_full_size_properties_configs2():
         cnt_hist += np.bincount(np.ascontiguousarray(a[:, 10:12]).view("<u2").ravel(), minlength=0x8000)
     assert np.array_equal(cnt_hist[cutoff:], ha[cutoff:]) and cnt_hist[:cutoff].sum() == 0
     summary["checks"] = "instances, conservation, sum(hist) = distinct, ntable = sum(hist[4:]), table strictly increasing, " \
-                        "table counts = histogram, identical histogram and table for (48 buckets, 2 passes) and (40, 3)"
+                        "table counts = histogram, identical histogram and table for (48 buckets, 3 passes with entry replay) and (40 buckets, 3 full passes)"
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(out):
         with open(os.path.join(out, "full_size_configs2.json"), "w") as f:
