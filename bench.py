@@ -8,9 +8,10 @@ synthetic reads that is already resident in HBM when the timed region starts.
 N = 1 (default --config 2) = BASELINE.json configs[2], the set the north-star target is quoted on:
 50x coverage of a 3 Gbp uniform random genome in 15 kbp reads with 0.2 % substitutions, k=40 -t4
 (10 M reads, 150 G bases, ~149.6 G k-mer instances).  The 150 GB of ASCII reads stay resident; the
-8.3 G super-mer records (166 GB) do not fit beside them, so the reads are split in `split_passes`
-passes, each keeping one group of minimizer buckets, and the buckets are counted one after the other
-(the role of FastK's NPARTS, split.c:617-766; count.c:1202 bucket loop).
+8.6 G super-mer records (172 GB) do not fit beside them, so the reads are split in `split_passes`
+passes, each keeping one group of minimizer buckets (the first pass finds the minimizers and records
+4-byte entries for the rest, the later passes replay them), and the buckets are counted one after the
+other (the role of FastK's NPARTS, split.c:617-766; count.c:1202 bucket loop).
     --config 1 = BASELINE.json configs[1]: 50x of 100 Mbp in 150 bp reads, k=40 -t1, all resident.
 N > 1 (default --config 3) = BASELINE.json configs[3]: the SAME 3 Gbp HiFi-shaped set striped over the N GPUs
 (strong scaling: the N = 1 line above is its first point), counted through the C engine's sharded entry
@@ -528,7 +529,7 @@ def main():
     # (records per launch) is the profiled one.
     traffic = None
     traffic_src = None
-    for name in ("r02_c_configs%d_pmc_traffic.json" % cfg_id,):
+    for name in ("r02_d_configs%d_pmc_traffic.json" % cfg_id, "r02_c_configs%d_pmc_traffic.json" % cfg_id):
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", name)))
             per_launch = n_rec / (nl_k / passes_k)

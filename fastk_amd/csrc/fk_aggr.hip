@@ -23,6 +23,12 @@
 #define AG_BINS    65536
 #define AG_UNROLL  8
 #define AG_P       4                    // slots one probe looks at (ag_read_slots is written for 4)
+#define AG_NSCAL   16                   // scalars behind the histogram (8 results + 8 phase timers of ablation builds)
+#ifdef FK_ABLATION
+#define AG_T(k) do { if (tid == 0) { const u64 now_ = __builtin_readcyclecounter(); ph[k] += now_ - tlast; tlast = now_; } } while (0)
+#else
+#define AG_T(k) do { } while (0)
+#endif
 
 template <int KW> struct AgCfg
 { static constexpr int SLOTS = (KW <= 3) ? 8192 : 4096;
@@ -183,6 +189,9 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
   u64 my_max = 0;
   u32 my_distinct = 0, my_rounds = 0;
   u32 R0 = 1;
+#ifdef FK_ABLATION
+  u64 ph[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tlast = __builtin_readcyclecounter();
+#endif
   u32 kmask[KW];                                // key bytes of each record dword (pad and weight off)
 #pragma unroll
   for (int w = 0; w < KW; w++)
@@ -195,6 +204,7 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
     { const int64_t beg = (int64_t) bounds[bin << gshift], end = (int64_t) bounds[(bin + 1) << gshift];
       if (beg >= end)
         continue;
+      AG_T(0);
 
       // A bin is taken in R0 selections (records whose next hash bits equal r0); R0 is what the
       // previous bin of this workgroup needed (all bins are alike), so that a table that is too
@@ -234,6 +244,9 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
                 { round_max += pend + slot0[0];
                   continue;
                 }
+#ifdef FK_ABLATION
+              if (tid == 0 && slot0[0] != 0xffffffffu) AG_T(1);
+#endif
 
               // one record per lane at a time; a probe looks at AG_P consecutive slots at once (the
               // kernel is bound by instruction issue, not by LDS bandwidth, and most records are
@@ -372,7 +385,9 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
                     }
                 }
             }
+          AG_T(2);
           __syncthreads();
+          AG_T(3);
           const bool ovf = (sh_ovf != 0);
           const u32  fill = sh_claimed;
           __syncthreads();
@@ -426,12 +441,15 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
                     }
                 }
             }
+          AG_T(4);
           if ((DEDUP || cutoff > 0) && !(variant & 4))
             { u32 tot;
               const u32 off = ag_block_exscan(nq, sh_tmp, &tot);
+              AG_T(5);
               if (tid == 0 && tot > 0)
                 sh_base = atomicAdd(&scal[2], (u64) tot);
               __syncthreads();
+              AG_T(6);
               if (tot > 0)
                 { u64 o = sh_base + off;
 #pragma unroll
@@ -464,6 +482,7 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
             }
           if (tid == 0) sh_claimed = 0;
           __syncthreads();
+          AG_T(7);
 
           // ---- next selection below (R0, r0): sibling, or up
           while (R > R0 && r >= (R >> 1))
@@ -498,6 +517,11 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
       if (d)      atomicAdd(&scal[1], d);
       if (rd)     atomicAdd(&scal[5], rd);
     }
+#ifdef FK_ABLATION
+  if (tid == 0)
+    for (int k = 0; k < 8; k++)
+      atomicAdd(&scal[8 + k], ph[k]);
+#endif
 }
 
 template <int KW>
@@ -514,7 +538,7 @@ static int aggr_t(fk_ctx *ctx, const void *d_grouped, int64_t n, int cutoff, int
       return (FK_EINVAL);
     }
   u64 *d_bounds = (u64 *) fk_slot(ctx, FK_SLOT_AG_BOUNDS, (AG_BINS + 1) * 8);
-  u64 *d_hist   = (u64 *) fk_slot(ctx, FK_SLOT_CT_HIST, (FK_HIST_BINS + 8) * 8);
+  u64 *d_hist   = (u64 *) fk_slot(ctx, FK_SLOT_CT_HIST, (FK_HIST_BINS + AG_NSCAL) * 8);
   if (d_bounds == NULL || d_hist == NULL)
     return (FK_ENOMEM);
   u64 *d_scal = d_hist + FK_HIST_BINS;
@@ -525,7 +549,7 @@ static int aggr_t(fk_ctx *ctx, const void *d_grouped, int64_t n, int cutoff, int
       FK_HIP(ctx, hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
       attr_set[KW] = true;
     }
-  FK_HIP(ctx, hipMemsetAsync(d_hist, 0, (FK_HIST_BINS + 8) * 8, s));
+  FK_HIP(ctx, hipMemsetAsync(d_hist, 0, (FK_HIST_BINS + AG_NSCAL) * 8, s));
   hipLaunchKernelGGL(k_ag_bounds<KW>, dim3(AG_BINS / 256 + 1), dim3(256), 0, s, (const u32 *) d_grouped, n,
                      ctx->wid.kmer_bytes, d_bounds);
   const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
@@ -539,10 +563,10 @@ static int aggr_t(fk_ctx *ctx, const void *d_grouped, int64_t n, int cutoff, int
                      (u32) (ctx->aggr_sat > 0 ? ctx->aggr_sat : 0x7fff));
   FK_LAUNCH_CHECK(ctx);
   u64 *h = ctx->h_scratch;                       // pinned, 64 KB + 64 KB: the histogram needs 256 KB
-  u64 *hh = (u64 *) malloc((FK_HIST_BINS + 8) * 8);
+  u64 *hh = (u64 *) malloc((FK_HIST_BINS + AG_NSCAL) * 8);
   if (hh == NULL) return (FK_ENOMEM);
   (void) h;
-  if (hipMemcpyAsync(hh, d_hist, (FK_HIST_BINS + 8) * 8, hipMemcpyDeviceToHost, s) != hipSuccess
+  if (hipMemcpyAsync(hh, d_hist, (FK_HIST_BINS + AG_NSCAL) * 8, hipMemcpyDeviceToHost, s) != hipSuccess
       || hipStreamSynchronize(s) != hipSuccess)
     { free(hh);
       fk_set_error(ctx, "aggregate: HIP failure: %s", hipGetErrorString(hipGetLastError()));
@@ -558,6 +582,14 @@ static int aggr_t(fk_ctx *ctx, const void *d_grouped, int64_t n, int cutoff, int
   if (ndistinct) *ndistinct = (int64_t) hh[FK_HIST_BINS + 1];
   if (ntable) *ntable = (int64_t) hh[FK_HIST_BINS + 2];
   ctx->aggr_extra_rounds = (int64_t) hh[FK_HIST_BINS + 5];
+#ifdef FK_ABLATION
+  if (getenv("FK_AG_TIMING") != NULL)
+    { fprintf(stderr, "ag phases (cycles of thread 0, all workgroups) n=%lld:", (long long) n);
+      for (int k = 0; k < 8; k++)
+        fprintf(stderr, " %llu", (unsigned long long) hh[FK_HIST_BINS + 8 + k]);
+      fprintf(stderr, "\n");
+    }
+#endif
   free(hh);
   return (FK_OK);
 }
@@ -597,7 +629,7 @@ static int dedup_t(fk_ctx *ctx, const void *d_grouped, int64_t n, void *d_out, i
       return (FK_EINVAL);
     }
   u64 *d_bounds = (u64 *) fk_slot(ctx, FK_SLOT_AG_BOUNDS, (AG_BINS + 1) * 8);
-  u64 *d_hist   = (u64 *) fk_slot(ctx, FK_SLOT_CT_HIST, (FK_HIST_BINS + 8) * 8);
+  u64 *d_hist   = (u64 *) fk_slot(ctx, FK_SLOT_CT_HIST, (FK_HIST_BINS + AG_NSCAL) * 8);
   if (d_bounds == NULL || d_hist == NULL)
     return (FK_ENOMEM);
   u64 *d_scal = d_hist + FK_HIST_BINS;
