@@ -75,7 +75,7 @@ struct fk_ctx
   uint8_t   *d_mbucket_pass; // [FK_NRANKS] the same for one group pass of a multi-pass split (0xFF = not now)
   uint8_t    h_mbucket[FK_NRANKS];
   uint8_t   *h_mbucket_pass; // pinned staging of d_mbucket_pass
-  u64       *d_cursors;      // [(256 + 64) * FK_CURSOR_STRIDE] per-bucket write cursors of the planned split, 4 KB apart,
+  u64       *d_cursors;      // [(256 * 8 streams + 64) * FK_CURSOR_STRIDE] write cursors of the streamed split emit, 4 KB apart,
                              // then the 64 cursors of the entry sub-regions
   int64_t    ent_cap;        // multi-pass split with replay: room (entries) in FK_SLOT_ENT
   int64_t    ent_ntiles;     // tiles the recorded entries belong to

@@ -33,6 +33,9 @@
 #define SP_WORDS   (SP_TILE / 16 + SP_MAXK / 16 + 2)   // packed words incl. halo and guard
 #define SP_KEYS    (SP_TILE + SP_MAXK)
 #define SP_KIDX(i) ((i) + ((i) >> 4))
+#define SP_LB      10                      // log2 of the records per chunk of a stream (see SplitArgs.lstreams)
+#define SP_LSTREAMS 3                      // 8 streams per bucket
+#define SP_PL      1024                    // super-mer starts the position list of a tile takes at a time
 #define SP_RCH     16                      // tiles per chunk of the replay offsets (in-chunk prefixes fit 16 bits)     // one pad word per 16 keys: thread t's chunk starts at bank 17t
 
 struct SplitArgs
@@ -44,7 +47,7 @@ struct SplitArgs
   int       nbuckets;
   const uint8_t  *mbucket;  // [FK_NRANKS] bucket of a canonical minimizer rank (global memory: one read per super-mer)
   u64      *counts;         // [nbuckets] records per bucket (count mode)  + [256] = instances
-  u64      *cursor;         // [nbuckets * cstride] running write cursors (emit mode), pre-set to bucket bases
+  u64      *cursor;         // [(nbuckets << lstreams) * cstride] running write cursors (emit mode), from 0
   int       cstride;        // u64 words between two buckets' cursors: every tile adds to every bucket's cursor, and
                             // cursors that share a memory channel serialise (FK_CURSOR_STRIDE words = 4 KB apart)
   const u64 *limit;         // [nbuckets] end of each bucket's region (NULL: only `cap` bounds the output)
@@ -67,6 +70,13 @@ struct SplitArgs
   // its records goes without a single global atomic (24 cursor round trips per tile were 3/4 of a replay pass)
   uint16_t *tile_cnt;       // [tiles * nbuckets]: counts, after the scan exclusive prefixes inside a chunk of SP_RCH tiles
   const u64 *chunk_base;    // [chunks * nbuckets] records of the bucket in all earlier chunks
+  // Every tile reserves room with one returning atomicAdd per bucket, and the memory side serves ~80 M of them per
+  // second and ADDRESS (measured: 1.23 M tiles on one cursor = 15.0 ms however little else the kernel does, 8.4 ms
+  // on four).  So a bucket has 2^lstreams cursors, tile t uses cursor t mod 2^lstreams, and stream c owns
+  // the chunks c, c + C, c + 2C, ... (SP_LB records each) of the bucket's region: the region fills evenly from the
+  // front, k_split_compact closes the ragged end (a few chunks per bucket) afterwards.
+  int       lstreams;
+  const u64 *rbase;         // [nbuckets] first record of each bucket's region (the cursors count from 0)
   u32       skipb;          // super-mers whose bucket entry equals skipb are dropped (0xFF in a group
                             // pass of a multi-pass split, where mbucket marks the other groups' ranks;
                             // 0x100 = nothing is dropped)
@@ -126,12 +136,11 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
 { __shared__ u32      fwd[SP_WORDS];
   __shared__ u32      rcw[SP_WORDS];
   __shared__ uint16_t inv16[SP_WORDS];
-  __shared__ uint16_t wpre[SP_WORDS];
-  __shared__ u32      keys[SP_KEYS + SP_KEYS / 16 + 1];
-  u32 *slist = keys;          // the keys are dead once every thread has its window minima (step 3)
+  __shared__ __attribute__((aligned(16))) u32 keys[SP_KEYS + SP_KEYS / 16 + 1];   // prefix minima (step 2), then the window minima by position
+  __shared__ uint16_t pos16[SP_PL];                      // positions of the tile's super-mer starts
   __shared__ __attribute__((aligned(8))) u32 aux32[1024];     // bbase / bcnt2 / lastkey
-  __shared__ uint16_t sbits[SP_THREADS + 16];
-  __shared__ uint16_t vbits[SP_THREADS + 16];
+  __shared__ uint16_t sbits[SP_THREADS + 16];            // boundary bits: start | invalid
+  __shared__ uint16_t vbits[SP_THREADS];
   __shared__ u32      bcnt[256];
   __shared__ u32      tmp32[8];
   __shared__ u32      nother, nother2;
@@ -148,6 +157,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
   const int     nw  = SP_TILE / 16 + (K + 14) / 16; // words that hold real bases
   const int     R   = nw * 16;                     // bases covered by the packed arrays
   const bool    one = (a.nbuckets == 1);           // single bucket: no per-record LDS atomics
+  const u32     strm = (u32) (a.tile0 + blockIdx.x) & ((1u << a.lstreams) - 1u);   // round robin: equal tile counts
 
   bcnt[tid] = 0;
   if (tid == 0) { nother = 0; nother2 = 0; }
@@ -184,19 +194,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
         }
       rcw[q] = x;
     }
-  // exclusive count of invalid bases before each packed word
-  { u32 tot;
-    const u32 mine = __popc((u32) inv16[tid]);
-    const u32 ex   = fk_block_exscan_256<u32>(mine, tmp32, &tot);
-    wpre[tid] = (uint16_t) ex;
-    if (tid == 0)
-      { u32 run = tot;
-        for (int q = SP_THREADS; q < SP_WORDS; q++)
-          { wpre[q] = (uint16_t) run;
-            run += __popc((u32) inv16[q]);
-          }
-      }
-  }
+  __syncthreads();
   // ---- 2. canonical 5-mer keys: (rank << 14 | position) << 1 | flip ------------------------
   //      one thread rolls a 64-bit window over the 16 positions of a packed word.  With W >= 16
   //      (k >= 20) the keys never go to LDS as such: a thread keeps the suffix minima of its own 16
@@ -278,47 +276,59 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
     }
 
   // ---- 4. validity of each k-mer: no invalid base in [i, i+K) ------------------------------
-  //      prefix counts of invalid bases; the 16 window ends of a thread touch two packed words
+  //      K >= 16: the window of start c (in word t) is the rest of word t from bit c, the whole words
+  //      t+1 .. t+kq-1 and the first c+kr bits of the word pair (t+kq, t+kq+1), K = 16 kq + kr -- so the
+  //      valid starts of a thread are one interval [fls(m0), ctz(E) - kr], a dozen instructions per
+  //      THREAD (the prefix counts this replaces cost 14 per base)
   u32 vmask = 0;
-  { const u32 w0 = wpre[tid], m0 = inv16[tid];
-    const int qe = tid + (K >> 4);
-    const u32 we0 = wpre[qe], me0 = inv16[qe], we1 = wpre[qe + 1], me1 = inv16[qe + 1];
+  if (K >= 16)
+    { const int kq = K >> 4, kr = K & 15;
+      const u32 m0 = inv16[tid];
+      u32 mid = 0;
+      for (int j = 1; j < kq; j++)
+        mid |= inv16[tid + j];
+      const u32 E     = (u32) inv16[tid + kq] | ((u32) inv16[tid + kq + 1] << 16);
+      const int lowc  = 32 - __clz((int) m0);                       // first start past the last invalid base of word t
+      const int highc = (E != 0 ? __ffs((int) E) - 1 : 32) - kr;    // last start whose window ends before the next one
+      const u32 up    = (highc >= 15) ? 0xffffu : (highc < 0 ? 0u : ((2u << highc) - 1u));
+      vmask = (mid != 0) ? 0u : (up & ~((1u << lowc) - 1u) & 0xffffu);
+    }
+  else
+    { const u32 M = (u32) inv16[tid] | ((u32) inv16[tid + 1] << 16);
+      const u32 km = (1u << K) - 1u;
 #pragma unroll
-    for (int c = 0; c < SP_CH; c++)
-      { const int  eo  = c + (K & 15);                     // offset of the window end from word qe
-        const u32  ci  = w0 + __popc(m0 & ((1u << c) - 1u));
-        const bool hi  = (eo >= 16);
-        const u32  ce  = (hi ? we1 : we0) + __popc((hi ? me1 : me0) & ((1u << (eo & 15)) - 1u));
-        vmask |= (ci == ce ? 1u : 0u) << c;
-      }
-  }
+      for (int c = 0; c < SP_CH; c++)
+        vmask |= (((M >> c) & km) == 0u ? 1u : 0u) << c;
+    }
   lastkey[tid] = mk[SP_CH - 1];
   bcnt2[tid]   = 0;
   vbits[tid]   = (uint16_t) vmask;
   if (tid < 16)
-    { vbits[SP_THREADS + tid] = 0;        // nothing is valid past the tile
-      sbits[SP_THREADS + tid] = 0;
-    }
+    sbits[SP_THREADS + tid] = 0xffffu;      // past the tile everything is a boundary
   __syncthreads();
 
   // ---- 5. super-mer starts: valid and (first of tile | previous invalid | new minimizer) ---
-  u32 smask = 0;
-  { u32  pk = (tid > 0) ? lastkey[tid - 1] : 0xffffffffu;
-    bool pv = (tid > 0) ? ((vbits[tid - 1] >> (SP_CH - 1)) & 1u) : false;
+  u32 smask;
+  { u32 pk = (tid > 0) ? lastkey[tid - 1] : 0xffffffffu;
+    const u32 pv = (tid > 0) ? (((u32) vbits[tid - 1] >> (SP_CH - 1)) & 1u) : 0u;
+    u32 kc = 0;
 #pragma unroll
     for (int c = 0; c < SP_CH; c++)
-      { const bool v = (vmask >> c) & 1u;
-        const bool st = v & (!pv | ((mk[c] >> 1) != (pk >> 1)));      // no short-circuit: no branches
-        smask |= (st ? 1u : 0u) << c;
-        pv = v;
+      { kc |= (((mk[c] ^ pk) > 1u) ? 1u : 0u) << c;       // key without the flip bit differs
         pk = mk[c];
       }
+    smask = vmask & (~((vmask << 1) | pv) | kc) & 0xffffu;
   }
-  sbits[tid] = (uint16_t) smask;
+  // boundaries (a start, or an invalid k-mer) for the length search of step 6; the window minima go to LDS
+  // (the prefix minima in `keys` are dead: every thread passed the barrier above), position-indexed
+  sbits[tid] = (uint16_t) (smask | (~vmask & 0xffffu));
+#pragma unroll
+  for (int j = 0; j < SP_CH / 4; j++)
+    *(uint4 *) &keys[i0 + 4 * j] = make_uint4(mk[4 * j], mk[4 * j + 1], mk[4 * j + 2], mk[4 * j + 3]);
 
   u32 nstart_total;
   const u32 sidx0 = fk_block_exscan_256<u32>(__popc(smask), tmp32, &nstart_total);
-  // (the scan's barriers also publish sbits)
+  // (the scan's barriers also publish sbits and the minima)
 
   { // instances = valid k-mers in the tile, spread over 64 counters (summed by the host)
     u32 tot;
@@ -327,41 +337,42 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
       atomicAdd(&a.counts[256 + (blockIdx.x & 63)], (u64) tot);
   }
 
-  // ---- 6. one entry per super-mer: position, length, flip, rank ---------------------------
-  { u32 k = sidx0;
-#pragma unroll
-    for (int c = 0; c < SP_CH; c++)
-      if ((smask >> c) & 1u)
-        { const int i = i0 + c;
-          // next boundary (start or invalid) after i; bit SP_TILE is a sentinel (all invalid)
-          int n = 0;
-          { int p = i + 1;
-            while (true)
-              { const int q = p >> 4;
-                u32 bnd = ((u32) sbits[q] | (~(u32) vbits[q] & 0xffffu)) >> (p & 15);
-                if (bnd != 0)
-                  { n = p + (__ffs(bnd) - 1) - i;
-                    break;
-                  }
-                p = (q + 1) << 4;
-              }
-          }
-          const u32 key  = mk[c];
-          u32 b = 0;
-          if (!one)
-            { b = a.mbucket[key >> 15];
-              if (rec || b != a.skipb)
-                atomicAdd(&bcnt[b], 1u);                  // (recording: every bucket is counted, the row goes to tile_cnt)
-              if (rec && !(b >= (u32) a.gb0 && b < (u32) a.gb1))
-                atomicAdd(&nother, 1u);
-            }
-          if (EMIT)
-            slist[k] = (u32) i | ((key & 1u) << 12) | ((u32) n << 13) | (b << 20);
-          k += 1;
-        }
+  // ---- 6. the super-mers of the tile, one per thread -----------------------------------------
+  //      A thread lists the positions of its own starts (a loop over the set bits of smask: ~4 rounds per
+  //      wave); after that thread s owns super-mer s: position from the list, minimizer from LDS, length
+  //      from the boundary bits.  (Walking the 16 positions of a thread with a branch per position kept 6 %
+  //      of the lanes busy and was a third of the kernel's instructions.)  The list takes SP_PL starts; a
+  //      tile with more (never seen on reads: a start every four bases) is taken in several rounds.
+#define SP_LIST(base)                                                          \
+  { u32 sm_ = smask, k_ = sidx0 - (base);                                      \
+    while (sm_ != 0)                                                           \
+      { const int c_ = __ffs((int) sm_) - 1;                                   \
+        sm_ &= sm_ - 1;                                                        \
+        if (k_ < (u32) SP_PL) pos16[k_] = (uint16_t) (i0 + c_);                \
+        k_ += 1;                                                               \
+      }                                                                        \
   }
-  if (one && tid == 0)
-    bcnt[0] = nstart_total;
+  SP_LIST(0u);
+  __syncthreads();
+  if (one)
+    { if (tid == 0) bcnt[0] = nstart_total; }
+  else
+    for (u32 base = 0; base < nstart_total; base += SP_PL)
+      { if (base != 0)
+          { __syncthreads();
+            SP_LIST(base);
+            __syncthreads();
+          }
+        const u32 lim = min(nstart_total, base + (u32) SP_PL);
+        for (u32 s = base + tid; s < lim; s += SP_THREADS)
+          { const u32 key = keys[pos16[s - base]];
+            const u32 b   = a.mbucket[key >> 15];
+            if (rec || b != a.skipb)
+              atomicAdd(&bcnt[b], 1u);                  // (recording: every bucket is counted, the row goes to tile_cnt)
+            if (rec && !(b >= (u32) a.gb0 && b < (u32) a.gb1))
+              atomicAdd(&nother, 1u);
+          }
+      }
   __syncthreads();
   if (EMIT && rec && tid == SP_THREADS - 1)
     { // room for this tile's other entries in sub-region (tile mod 64)
@@ -389,52 +400,69 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
   if (rec && tid < a.nbuckets)
     a.tile_cnt[(size_t) (a.tile0 + blockIdx.x) * a.nbuckets + tid] = (uint16_t) bcnt[tid];
   if (tid < a.nbuckets && bcnt[tid] != 0 && (!rec || (tid >= a.gb0 && tid < a.gb1)))
-    bbase[tid] = atomicAdd(&a.cursor[(size_t) tid * a.cstride], (u64) bcnt[tid]);
+    bbase[tid] = atomicAdd(&a.cursor[(((size_t) tid << a.lstreams) + strm) * a.cstride], (u64) bcnt[tid]);
   __syncthreads();
 
   // ---- 7. build and write the records -----------------------------------------------------
   const int sww = a.sww;
   const int lenw = a.smer_bytes >> 2;
   const int lensh = 24 - 8 * (a.smer_bytes & 3);
-  for (u32 s = tid; s < nstart_total; s += SP_THREADS)
-    { const u32 e    = slist[s];
-      const int i    = e & 0xfffu;
-      const u32 flip = (e >> 12) & 1u;
-      const int n    = (e >> 13) & 0x7fu;
-      const u32 b    = e >> 20;
-      if (rec)
-        { if (!(b >= (u32) a.gb0 && b < (u32) a.gb1))
-            { if (nother != 0)
-                a.ent[ebase + atomicAdd(&nother2, 1u)] = e;
+  for (u32 base = 0; base < nstart_total; base += SP_PL)
+    { if (nstart_total > (u32) SP_PL)
+        { __syncthreads();
+          SP_LIST(base);
+          __syncthreads();
+        }
+      const u32 lim = min(nstart_total, base + (u32) SP_PL);
+      for (u32 s = base + tid; s < lim; s += SP_THREADS)
+        { const int i    = pos16[s - base];
+          const u32 key  = keys[i];
+          const u32 flip = key & 1u;
+          const u32 b    = one ? 0u : (u32) a.mbucket[key >> 15];
+          // length: distance to the next boundary, at most W <= 58 positions on; 64 (80 for k > 53)
+          // boundary bits from the word of i
+          const int qi = i >> 4, ci = i & 15;
+          u64 ab = ((u64) sbits[qi] | ((u64) sbits[qi + 1] << 16) | ((u64) sbits[qi + 2] << 32)
+                    | ((u64) sbits[qi + 3] << 48)) >> (ci + 1);
+          if (W > 47)
+            ab |= (u64) sbits[qi + 4] << (63 - ci);
+          const int n = __ffsll((long long) ab);
+          if (rec)
+            { if (!(b >= (u32) a.gb0 && b < (u32) a.gb1))
+                { if (nother != 0)
+                    a.ent[ebase + atomicAdd(&nother2, 1u)] = (u32) i | (flip << 12) | ((u32) n << 13) | (b << 20);
+                  continue;
+                }
+            }
+          else if (b == a.skipb)
+            continue;
+          const u64 lp   = bbase[b] + (one ? s : atomicAdd(&bcnt2[b], 1u));     // position in the tile's stream
+          const u64 slot = a.rbase[b] + (((((lp >> SP_LB) << a.lstreams) + strm) << SP_LB) | (lp & ((1u << SP_LB) - 1u)));
+          if ((int64_t) slot >= a.cap || (a.limit != NULL && slot >= a.limit[b]))
+            { *a.overflowed = 1;
               continue;
             }
-        }
-      else if (b == a.skipb)
-        continue;
-      const u64 slot = bbase[b] + (one ? s : atomicAdd(&bcnt2[b], 1u));
-      if ((int64_t) slot >= a.cap || (a.limit != NULL && slot >= a.limit[b]))
-        { *a.overflowed = 1;
-          continue;
-        }
-      const int  L   = n - 1 + K;
-      const u32 *arr = flip ? rcw : fwd;
-      const int  st  = flip ? (R - (i + L)) : i;
-      u32 *dst = a.out + slot * sww;
-      if (POS)
-        a.pos[slot] = ((u64) (t0 + i) << 1) | flip;
-      for (int q = 0; q < sww; q++)
-        { u32 x = 0;
-          const int rem = L - 16 * q;
-          if (rem > 0)
-            { x = sp_window(arr, st + 16 * q);
-              if (rem < 16)
-                x &= ~(0xffffffffu >> (2 * rem));
+          const int  L   = n - 1 + K;
+          const u32 *arr = flip ? rcw : fwd;
+          const int  st  = flip ? (R - (i + L)) : i;
+          u32 *dst = a.out + slot * sww;
+          if (POS)
+            a.pos[slot] = ((u64) (t0 + i) << 1) | flip;
+          for (int q = 0; q < sww; q++)
+            { u32 x = 0;
+              const int rem = L - 16 * q;
+              if (rem > 0)
+                { x = sp_window(arr, st + 16 * q);
+                  if (rem < 16)
+                    x &= ~(0xffffffffu >> (2 * rem));
+                }
+              if (q == lenw)
+                x |= ((u32) (n - 1)) << lensh;
+              dst[q] = __builtin_bswap32(x);
             }
-          if (q == lenw)
-            x |= ((u32) (n - 1)) << lensh;
-          dst[q] = __builtin_bswap32(x);
         }
     }
+#undef SP_LIST
 }
 
 // tile_cnt rows of SP_RCH consecutive tiles -> exclusive prefixes inside the chunk (in place) + the chunk's totals
@@ -528,10 +556,10 @@ __global__ __launch_bounds__(SP_THREADS) void k_split_replay(SplitArgs a)
         }
       rcw[q] = x;
     }
-  // where this tile's records of bucket b go: region start (cursor[b], constant during a replay pass) + the bucket's
+  // where this tile's records of bucket b go: region start + the bucket's
   // records in earlier chunks + in the earlier tiles of this chunk -- exact, no reservation needed
   if (tid >= a.gb0 && tid < a.gb1)
-    bbase[tid] = a.cursor[(size_t) tid * a.cstride] + a.chunk_base[(size_t) (tile / SP_RCH) * a.nbuckets + tid]
+    bbase[tid] = a.rbase[tid] + a.chunk_base[(size_t) (tile / SP_RCH) * a.nbuckets + tid]
                + (u64) a.tile_cnt[(size_t) tile * a.nbuckets + tid];
   __syncthreads();
 
@@ -568,6 +596,88 @@ __global__ __launch_bounds__(SP_THREADS) void k_split_replay(SplitArgs a)
           dst[q] = __builtin_bswap32(x);
         }
     }
+}
+
+// Closes the ragged end of the chunk-interleaved streams (SplitArgs.lstreams): afterwards the records of bucket b
+// are rbase[b] .. rbase[b] + sum of its cursors, contiguous.  One workgroup per bucket: the chunks of the rows that
+// are not full in every stream move down in (row, stream) order; a record never moves up and never past an unread
+// one, so batches of "all read, barrier, all write" in that order are a memmove.  A few chunks per bucket.
+#define SP_CT 1024
+__global__ __launch_bounds__(SP_CT) void k_split_compact(u32 *__restrict__ out, int sww, const u64 *__restrict__ cursor,
+                                                         int cstride, int lstreams, const u64 *__restrict__ rbase, int b0,
+                                                         const u32 *__restrict__ overflowed)
+{ const int b = b0 + blockIdx.x, C = 1 << lstreams, tid = threadIdx.x;
+  __shared__ u64 L[1 << SP_LSTREAMS];
+  if (*overflowed == 1u)                 // a region was too small: records were dropped, the caller starts over
+    return;
+  if (tid < C)
+    L[tid] = cursor[(((size_t) b << lstreams) + tid) * cstride];
+  __syncthreads();
+  u64 rmin = ~0ull, rmax = 0;
+  for (int c = 0; c < C; c++)
+    { rmin = min(rmin, L[c] >> SP_LB);
+      rmax = max(rmax, (L[c] + ((1u << SP_LB) - 1u)) >> SP_LB);
+    }
+  const u64 r0 = rbase[b];
+  u64 dst = (r0 + ((rmin << lstreams) << SP_LB)) * (u64) sww;
+  for (u64 r = rmin; r < rmax; r++)
+    for (int c = 0; c < C; c++)
+      { const int64_t have = (int64_t) L[c] - (int64_t) (r << SP_LB);
+        if (have <= 0)
+          continue;
+        const u64 n   = (u64) (have < (1 << SP_LB) ? have : (1 << SP_LB)) * (u64) sww;
+        const u64 src = (r0 + (((r << lstreams) + (u64) c) << SP_LB)) * (u64) sww;
+        if (src != dst)
+          for (u64 off = 0; off < n; off += 4 * SP_CT)
+            { u32 v[4];
+#pragma unroll
+              for (int u = 0; u < 4; u++)
+                { const u64 i = off + (u64) u * SP_CT + tid;
+                  v[u] = (i < n) ? out[src + i] : 0u;
+                }
+              __syncthreads();
+#pragma unroll
+              for (int u = 0; u < 4; u++)
+                { const u64 i = off + (u64) u * SP_CT + tid;
+                  if (i < n)
+                    out[dst + i] = v[u];
+                }
+              __threadfence_block();
+              __syncthreads();
+            }
+        dst += n;
+      }
+}
+
+// the cursors of the streamed emit: (256 buckets x 2^SP_LSTREAMS streams + 64 entry sub-regions), 4 KB apart
+static u64 *sp_cursors(fk_ctx *ctx)
+{ if (ctx->d_cursors == NULL
+      && hipMalloc((void **) &ctx->d_cursors, ((size_t) (256 << SP_LSTREAMS) + 64) * FK_CURSOR_STRIDE * sizeof(u64)) != hipSuccess)
+    { ctx->d_cursors = NULL;
+      fk_set_error(ctx, "split: no memory for the cursors");
+    }
+  return (ctx->d_cursors);
+}
+
+// after the emit over buckets [b0, b1): close the stream ends, then bring the cursors to the host; totals[b - b0]
+// = records of bucket b.  Synchronises the stream.
+static int sp_finish_streams(fk_ctx *ctx, const SplitArgs &a, int b0, int b1, int64_t *totals)
+{ hipStream_t s = ctx->stream;
+  const int C = 1 << a.lstreams;
+  hipLaunchKernelGGL(k_split_compact, dim3((unsigned) (b1 - b0)), dim3(SP_CT), 0, s, a.out, a.sww, (const u64 *) a.cursor,
+                     a.cstride, a.lstreams, a.rbase, b0, (const u32 *) a.overflowed);
+  FK_LAUNCH_CHECK(ctx);
+  u64 *h = ctx->h_scratch + 8192;                  // pinned; (b1 - b0) * C <= 2048 words
+  FK_HIP(ctx, hipMemcpy2DAsync(h, sizeof(u64), a.cursor + ((size_t) b0 << a.lstreams) * a.cstride, (size_t) a.cstride * sizeof(u64),
+                               sizeof(u64), (size_t) (b1 - b0) * C, hipMemcpyDeviceToHost, s));
+  FK_HIP(ctx, hipStreamSynchronize(s));
+  for (int b = b0; b < b1; b++)
+    { int64_t t = 0;
+      for (int c = 0; c < C; c++)
+        t += (int64_t) h[(size_t) (b - b0) * C + c];
+      totals[b - b0] = t;
+    }
+  return (FK_OK);
 }
 
 // A launch covers gridDim.x * blockDim.x < 2^32 work-items: inputs of more than 2^23 tiles (32 G bases)
@@ -611,7 +721,7 @@ int fkx_split(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int
   if (nbytes < K)
     return (FK_OK);
 
-  SplitArgs a;
+  SplitArgs a = SplitArgs();
   a.bases = (const unsigned char *) d_bases;
   a.nbytes = nbytes;
   a.kmer = K;
@@ -667,7 +777,9 @@ int fkx_split(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int
       return (FK_EINVAL);
     }
 
-  FK_HIP(ctx, hipMemcpyAsync(d_cursor, base, nb * sizeof(u64), hipMemcpyHostToDevice, s));
+  // exact regions: one stream per bucket (the cursors, zeroed above, count from the region starts)
+  FK_HIP(ctx, hipMemcpyAsync(ctx->d_scratch + 768, base, nb * sizeof(u64), hipMemcpyHostToDevice, s));
+  a.rbase = ctx->d_scratch + 768; a.lstreams = 0;
   if (d_pos != NULL)
     sp_launch<true, true>(a, ntiles, s);
   else
@@ -705,7 +817,7 @@ int fkx_split_fast(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void **d_ou
   if (nbytes < K)
     return (FK_OK);
   if (ctx->prm.nbuckets == 1)
-    { SplitArgs a;
+    { SplitArgs a = SplitArgs();
       a.bases = (const unsigned char *) d_bases;
       a.nbytes = nbytes;
       a.kmer = K;
@@ -735,13 +847,21 @@ int fkx_split_fast(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void **d_ou
           cap = ctx->slot_cap[FK_SLOT_SM_A] / stride;          // use the headroom too
           FK_HIP(ctx, hipMemsetAsync(ctx->d_scratch, 0, 1032 * sizeof(u64), s));
           a.out = (u32 *) out; a.cap = cap; a.tile_stride = 1;
+          if (sp_cursors(ctx) == NULL)
+            return (FK_ENOMEM);
+          a.cursor = ctx->d_cursors; a.cstride = FK_CURSOR_STRIDE; a.lstreams = SP_LSTREAMS;
+          a.rbase = ctx->d_scratch + 768;                        // zero: the region starts at record 0
+          FK_HIP(ctx, hipMemsetAsync(ctx->d_cursors, 0, ((size_t) 1 << SP_LSTREAMS) * FK_CURSOR_STRIDE * sizeof(u64), s));
           sp_launch<true, false>(a, ntiles, s);
           FK_LAUNCH_CHECK(ctx);
           FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch, ctx->d_scratch, 1032 * sizeof(u64),
                                      hipMemcpyDeviceToHost, s));
-          FK_HIP(ctx, hipStreamSynchronize(s));
+          int64_t tot1 = 0;
+          const int rcs = sp_finish_streams(ctx, a, 0, 1, &tot1);
+          if (rcs != FK_OK)
+            return (rcs);
           if (*(u32 *) (ctx->h_scratch + 1024) == 0)
-            { *nsuper = (int64_t) ctx->h_scratch[512];           // the cursor = records written
+            { *nsuper = tot1;
               { int64_t t = 0;
                 for (int x = 0; x < 64; x++)
                   t += (int64_t) ctx->h_scratch[256 + x];
@@ -751,6 +871,7 @@ int fkx_split_fast(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void **d_ou
               bucket_counts[0] = *nsuper;
               return (FK_OK);
             }
+          a.cursor = d_cursor; a.cstride = 1; a.lstreams = 0;
           // estimate too small (very uneven input): exact path below
         }
     }
@@ -818,7 +939,7 @@ int fkx_split_plan(fk_ctx *ctx, const void *d_bases, int64_t nbytes, int64_t *ca
   int sample = 32;
   while (sample > 1 && ntiles / sample < 64)
     sample >>= 1;
-  SplitArgs a;
+  SplitArgs a = SplitArgs();
   a.bases = (const unsigned char *) d_bases;
   a.nbytes = nbytes;
   a.kmer = K;
@@ -841,7 +962,7 @@ int fkx_split_plan(fk_ctx *ctx, const void *d_bases, int64_t nbytes, int64_t *ca
   int64_t tot = 0;
   for (int b = 0; b < nb; b++)
     { offsets[b] = tot;
-      tot += (int64_t) ((double) ctx->h_scratch[b] * scale * 1.05) + 8192;
+      tot += (int64_t) ((double) ctx->h_scratch[b] * scale * 1.05) + 8192 + (2 << (SP_LB + SP_LSTREAMS));   // + ragged stream ends
     }
   offsets[nb] = tot;
   *cap = tot;
@@ -882,15 +1003,15 @@ int fkx_split_planned(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_
   u64 *h = ctx->h_scratch + 512;                     // pinned
   for (int b = 0; b < nb; b++)
     { const bool in = (b >= b0 && b < b1);
-      h[b] = in ? (u64) offsets[b] : 0;              // cursors start at the region starts
+      h[b] = in ? (u64) offsets[b] : 0;              // region starts
       h[256 + b] = in ? (u64) offsets[b + 1] : 0;    // limits
     }
   FK_HIP(ctx, hipMemsetAsync(ctx->d_scratch, 0, 1032 * sizeof(u64), s));
   FK_HIP(ctx, hipMemcpyAsync(ctx->d_scratch + 512, h, 512 * sizeof(u64), hipMemcpyHostToDevice, s));
-  if (ctx->d_cursors == NULL)
-    FK_HIP(ctx, hipMalloc((void **) &ctx->d_cursors, (256 + 64) * FK_CURSOR_STRIDE * sizeof(u64)));
-  FK_HIP(ctx, hipMemcpy2DAsync(ctx->d_cursors, FK_CURSOR_STRIDE * sizeof(u64), h, sizeof(u64), sizeof(u64), (size_t) nb,
-                               hipMemcpyHostToDevice, s));
+  if (sp_cursors(ctx) == NULL)
+    return (FK_ENOMEM);
+  if (mode != 2)
+    FK_HIP(ctx, hipMemsetAsync(ctx->d_cursors, 0, ((size_t) nb << SP_LSTREAMS) * FK_CURSOR_STRIDE * sizeof(u64), s));
   if (group && mode == 0)
     { uint8_t *hm = ctx->h_mbucket_pass;                          // pinned (the previous pass has been waited for)
       for (int r = 0; r < FK_NRANKS; r++)
@@ -899,7 +1020,7 @@ int fkx_split_planned(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_
         }
       FK_HIP(ctx, hipMemcpyAsync(ctx->d_mbucket_pass, hm, FK_NRANKS, hipMemcpyHostToDevice, s));
     }
-  SplitArgs a;
+  SplitArgs a = SplitArgs();
   a.bases = (const unsigned char *) d_bases;
   a.nbytes = nbytes;
   a.kmer = K;
@@ -908,14 +1029,15 @@ int fkx_split_planned(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_
   a.nbuckets = nb;
   a.mbucket = (group && mode == 0) ? ctx->d_mbucket_pass : ctx->d_mbucket;
   a.counts = ctx->d_scratch;
-  a.cursor = ctx->d_cursors; a.cstride = FK_CURSOR_STRIDE;
+  a.cursor = ctx->d_cursors; a.cstride = FK_CURSOR_STRIDE; a.lstreams = SP_LSTREAMS;
+  a.rbase = ctx->d_scratch + 512;
   a.limit = ctx->d_scratch + 768;
   a.pos = NULL;
   a.skipb = (group && mode == 0) ? 0xFFu : 0x100u;
   a.out = (u32 *) d_out; a.cap = cap;
   a.overflowed = (u32 *) (ctx->d_scratch + 1024);
   a.tile_stride = 1;
-  a.ent = NULL; a.ent_cursor = ctx->d_cursors + 256 * FK_CURSOR_STRIDE; a.tile_ent = NULL; a.ent_cap = 0;
+  a.ent = NULL; a.ent_cursor = ctx->d_cursors + ((size_t) 256 << SP_LSTREAMS) * FK_CURSOR_STRIDE; a.tile_ent = NULL; a.ent_cap = 0;
   a.gb0 = b0; a.gb1 = b1;
   const int64_t nchunks = (ntiles + SP_RCH - 1) / SP_RCH;
   a.tile_cnt = NULL; a.chunk_base = NULL;
@@ -954,9 +1076,14 @@ int fkx_split_planned(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_
     sp_launch<true, false>(a, ntiles, s);
   FK_LAUNCH_CHECK(ctx);
   FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch, ctx->d_scratch, 1032 * sizeof(u64), hipMemcpyDeviceToHost, s));
-  FK_HIP(ctx, hipMemcpy2DAsync(ctx->h_scratch + 512, sizeof(u64), ctx->d_cursors, FK_CURSOR_STRIDE * sizeof(u64),
-                               sizeof(u64), (size_t) nb, hipMemcpyDeviceToHost, s));
-  FK_HIP(ctx, hipStreamSynchronize(s));
+  int64_t totals[256];
+  if (mode != 2)
+    { const int rcs = sp_finish_streams(ctx, a, b0, b1, totals);
+      if (rcs != FK_OK)
+        return (rcs);
+    }
+  else
+    FK_HIP(ctx, hipStreamSynchronize(s));
   const u32 ovf = *(u32 *) (ctx->h_scratch + 1024);
   if (ovf == 1)
     { fk_set_error(ctx, "planned split: a bucket region was too small");
@@ -985,7 +1112,7 @@ int fkx_split_planned(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_
       counts[b] = ctx->ent_totals[b];
   else
   for (int b = b0; b < b1; b++)
-    counts[b] = (int64_t) ctx->h_scratch[512 + b] - offsets[b];
+    counts[b] = totals[b - b0];
   int64_t t = 0;
   for (int x = 0; x < 64; x++)
     t += (int64_t) ctx->h_scratch[256 + x];
