@@ -12,7 +12,7 @@
 //     terminators, N, newlines) invalidates the k-mers that cover it -- exactly the k-mers the
 //     reference skips (split.c:1079, 1124-1128, 1323-1330);
 //   * minimizer of a k-mer = smallest canonical 7-mer of its K-6 7-mer starts under a fixed
-//     pseudo-random order (a bijective mix of the 14-bit code, fk_mrank14), leftmost on ties (min
+//     pseudo-random order (a multiplicative hash of the 14-bit code, fk_mrank14), leftmost on ties (min
 //     over packed (rank,position) keys).  Seven bases, not the reference's initial five: the
 //     smallest 5-mer wins 6.8 % of all windows at k = 40, so no deal of 5-mer ranks can balance
 //     more than ~14 buckets -- the reference pads its heavy minimizers by two bases for the same
@@ -251,9 +251,9 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
   if (fastmin)
     { // window of start c ends at offset e = c + W - 1 from the block start: block t + (e >> 4)
       const int q0 = (W - 1) >> 4, r0 = (W - 1) & 15;
-      u32 fa = 0xffffffffu;                                // whole blocks t+1 .. t+q0-1
-      for (int j = 1; j < q0; j++)
-        fa = min(fa, keys[SP_KIDX(16 * (tid + j) + 15)]);
+      u32 fa = 0xffffffffu;                                // whole blocks t+1 .. t+q0-1 (q0 <= 3: W <= 58)
+      if (q0 > 1) fa = keys[SP_KIDX(16 * (tid + 1) + 15)];
+      if (q0 > 2) fa = min(fa, keys[SP_KIDX(16 * (tid + 2) + 15)]);
       const u32 fb = (q0 >= 1) ? min(fa, keys[SP_KIDX(16 * (tid + q0) + 15)]) : fa;   // .. t+q0
       const int pbase = 17 * (tid + q0);                   // SP_KIDX of the first slot of block t+q0
 #pragma unroll
@@ -323,8 +323,8 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
   // (the prefix minima in `keys` are dead: every thread passed the barrier above), position-indexed
   sbits[tid] = (uint16_t) (smask | (~vmask & 0xffffu));
 #pragma unroll
-  for (int j = 0; j < SP_CH / 4; j++)
-    *(uint4 *) &keys[i0 + 4 * j] = make_uint4(mk[4 * j], mk[4 * j + 1], mk[4 * j + 2], mk[4 * j + 3]);
+  for (int c = 0; c < SP_CH; c++)
+    keys[SP_KIDX(i0 + c)] = mk[c];                         // 17 tid + c: conflict-free dword stores, no address arithmetic
 
   u32 nstart_total;
   const u32 sidx0 = fk_block_exscan_256<u32>(__popc(smask), tmp32, &nstart_total);
@@ -365,7 +365,8 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
           }
         const u32 lim = min(nstart_total, base + (u32) SP_PL);
         for (u32 s = base + tid; s < lim; s += SP_THREADS)
-          { const u32 key = keys[pos16[s - base]];
+          { const int ip = pos16[s - base];
+            const u32 key = keys[SP_KIDX(ip)];
             const u32 b   = a.mbucket[key >> 15];
             if (rec || b != a.skipb)
               atomicAdd(&bcnt[b], 1u);                  // (recording: every bucket is counted, the row goes to tile_cnt)
@@ -416,7 +417,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
       const u32 lim = min(nstart_total, base + (u32) SP_PL);
       for (u32 s = base + tid; s < lim; s += SP_THREADS)
         { const int i    = pos16[s - base];
-          const u32 key  = keys[i];
+          const u32 key  = keys[SP_KIDX(i)];
           const u32 flip = key & 1u;
           const u32 b    = one ? 0u : (u32) a.mbucket[key >> 15];
           // length: distance to the next boundary, at most W <= 58 positions on; 64 (80 for k > 53)
