@@ -121,14 +121,13 @@ __device__ __forceinline__ void sp_pack16(const uint4 v, u32 &word, u32 &bad)
   bad  = bd;
 }
 
-// (rank << 15) | flip of a 7-mer: canonical = the smaller of the forward code and its reverse
-// complement (flip = the reverse complement is), rank = fk_mrank14(canonical).  Both arguments may
-// carry garbage above bit 13.
+// rank << 15 of a 7-mer: canonical = the smaller of the forward code and its reverse complement, rank =
+// fk_mrank14(canonical).  Both arguments may carry garbage above bit 13.  (Which strand the canonical form
+// is on only matters for the one minimizer a super-mer ends up with: step 7 looks it up again.)
 __device__ __forceinline__ u32 sp_key7(u32 fw, u32 rc)
 { fw &= 0x3fffu;
   rc &= 0x3fffu;
-  const u32 flip = (rc < fw) ? 1u : 0u;
-  return ((fk_mrank14(min(fw, rc)) << 15) | flip);
+  return (fk_mrank14(min(fw, rc)) << 15);
 }
 
 template <bool EMIT, bool POS = false>
@@ -167,18 +166,17 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
     { u32 word = 0, bad = 0xffffu;
       if (q < nw)
         { const int64_t g = t0 + (int64_t) q * 16;
-          __attribute__((aligned(16))) unsigned char c[16];
+          uint4 v;
           if (g + 16 <= a.nbytes)
-            { const uint4 v = *(const uint4 *) (a.bases + g);
-              *(uint4 *) c = v;
-            }
+            v = *(const uint4 *) (a.bases + g);
           else
-            {
-#pragma unroll
+            { u32 d[4] = { 0u, 0u, 0u, 0u };                   // the last bytes of the input, one by one
               for (int j = 0; j < 16; j++)
-                c[j] = (g + j < a.nbytes) ? a.bases[g + j] : 0;
+                if (g + j < a.nbytes)
+                  d[j >> 2] |= (u32) a.bases[g + j] << (8 * (j & 3));
+              v = make_uint4(d[0], d[1], d[2], d[3]);
             }
-          sp_pack16(*(const uint4 *) c, word, bad);
+          sp_pack16(v, word, bad);
         }
       fwd[q]   = word;
       inv16[q] = (uint16_t) bad;
@@ -195,7 +193,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
       rcw[q] = x;
     }
   __syncthreads();
-  // ---- 2. canonical 5-mer keys: (rank << 14 | position) << 1 | flip ------------------------
+  // ---- 2. canonical 7-mer keys: (rank << 14 | position) << 1 ----------------------------------
   //      one thread rolls a 64-bit window over the 16 positions of a packed word.  With W >= 16
   //      (k >= 20) the keys never go to LDS as such: a thread keeps the suffix minima of its own 16
   //      keys in registers and publishes their PREFIX minima (slot 15 = the block minimum), because
@@ -314,7 +312,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
     u32 kc = 0;
 #pragma unroll
     for (int c = 0; c < SP_CH; c++)
-      { kc |= (((mk[c] ^ pk) > 1u) ? 1u : 0u) << c;       // key without the flip bit differs
+      { kc |= ((mk[c] != pk) ? 1u : 0u) << c;
         pk = mk[c];
       }
     smask = vmask & (~((vmask << 1) | pv) | kc) & 0xffffu;
@@ -324,18 +322,19 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
   sbits[tid] = (uint16_t) (smask | (~vmask & 0xffffu));
 #pragma unroll
   for (int c = 0; c < SP_CH; c++)
-    keys[SP_KIDX(i0 + c)] = mk[c];                         // 17 tid + c: conflict-free dword stores, no address arithmetic
+    keys[17 * tid + c] = mk[c];                            // = SP_KIDX(i0 + c): conflict-free dword stores, one address
 
+  // one scan for both: super-mer starts before this thread (low half) and the tile's valid k-mers (total, high half)
   u32 nstart_total;
-  const u32 sidx0 = fk_block_exscan_256<u32>(__popc(smask), tmp32, &nstart_total);
-  // (the scan's barriers also publish sbits and the minima)
-
-  { // instances = valid k-mers in the tile, spread over 64 counters (summed by the host)
-    u32 tot;
-    (void) fk_block_exscan_256<u32>(__popc(vmask), tmp32, &tot);
-    if (tid == 0 && tot != 0)
-      atomicAdd(&a.counts[256 + (blockIdx.x & 63)], (u64) tot);
+  u32 sidx0;
+  { u32 tot;
+    sidx0 = fk_block_exscan_256<u32>((u32) __popc(smask) | ((u32) __popc(vmask) << 16), tmp32, &tot) & 0xffffu;
+    nstart_total = tot & 0xffffu;
+    // instances = valid k-mers in the tile, spread over 64 counters (summed by the host)
+    if (tid == 0 && (tot >> 16) != 0)
+      atomicAdd(&a.counts[256 + (blockIdx.x & 63)], (u64) (tot >> 16));
   }
+  // (the scan's barriers also publish sbits and the minima)
 
   // ---- 6. the super-mers of the tile, one per thread -----------------------------------------
   //      A thread lists the positions of its own starts (a loop over the set bits of smask: ~4 rounds per
@@ -418,7 +417,9 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
       for (u32 s = base + tid; s < lim; s += SP_THREADS)
         { const int i    = pos16[s - base];
           const u32 key  = keys[SP_KIDX(i)];
-          const u32 flip = key & 1u;
+          // strand of the minimizer: its 7-mer against the reverse complement, both from the packed words
+          const int pm   = (int) ((key >> 1) & 0x3fffu);
+          const u32 flip = ((sp_window(rcw, R - 7 - pm) >> 18) < (sp_window(fwd, pm) >> 18)) ? 1u : 0u;
           const u32 b    = one ? 0u : (u32) a.mbucket[key >> 15];
           // length: distance to the next boundary, at most W <= 58 positions on; 64 (80 for k > 53)
           // boundary bits from the word of i
@@ -533,18 +534,17 @@ __global__ __launch_bounds__(SP_THREADS) void k_split_replay(SplitArgs a)
     { u32 word = 0, bad = 0;
       if (q < nw)
         { const int64_t g = t0 + (int64_t) q * 16;
-          __attribute__((aligned(16))) unsigned char c[16];
+          uint4 v;
           if (g + 16 <= a.nbytes)
-            { const uint4 v = *(const uint4 *) (a.bases + g);
-              *(uint4 *) c = v;
-            }
+            v = *(const uint4 *) (a.bases + g);
           else
-            {
-#pragma unroll
+            { u32 d[4] = { 0u, 0u, 0u, 0u };                   // the last bytes of the input, one by one
               for (int j = 0; j < 16; j++)
-                c[j] = (g + j < a.nbytes) ? a.bases[g + j] : 0;
+                if (g + j < a.nbytes)
+                  d[j >> 2] |= (u32) a.bases[g + j] << (8 * (j & 3));
+              v = make_uint4(d[0], d[1], d[2], d[3]);
             }
-          sp_pack16(*(const uint4 *) c, word, bad);
+          sp_pack16(v, word, bad);
         }
       fwd[q] = word;
     }
