@@ -1829,7 +1829,7 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
               const int64_t nchunks = (ntiles + 15) / 16;
               if (fk_slot(ctx, FK_SLOT_ENT, ctx->ent_cap * 4) == NULL || fk_slot(ctx, FK_SLOT_TENT, ntiles * 8) == NULL
                   || fk_slot(ctx, FK_SLOT_TCNT, ntiles * nbk * 2) == NULL
-                  || fk_slot(ctx, FK_SLOT_CBASE, nchunks * nbk * 12) == NULL)
+                  || fk_slot(ctx, FK_SLOT_CBASE, nchunks * nbk * 12 + FK_CBASE_EXTRA) == NULL)
                 { replay = false;
                   ctx->err[0] = 0;
                 }

@@ -19,6 +19,7 @@ typedef unsigned int       u32;
 // Minimizers are canonical 7-mers ordered by a bijective mix of their 14-bit code (odd multiplies and
 // xor-shifts are invertible mod 2^14, so distinct 7-mers never tie): FK_NRANKS rank values, of which
 // the 8192 images of canonical codes occur.
+#define FK_CBASE_EXTRA ((2 << 20) + 64)      // partition sums of the chunk scan behind the chunk bases (fk_split.hip)
 #define FK_CURSOR_STRIDE 512
 #define FK_MIN_LEN 7
 #define FK_NRANKS  16384

@@ -485,24 +485,54 @@ __global__ __launch_bounds__(256) void k_split_chunk(uint16_t *__restrict__ tile
     }
 }
 
-// per bucket (one workgroup each): exclusive scan of its chunk totals over all chunks; total[b] = all its records
-__global__ __launch_bounds__(256) void k_split_chunkscan(const u32 *__restrict__ chunk_tot, int64_t nchunks, int nb,
-                                                         u64 *__restrict__ chunk_base, u64 *__restrict__ total)
+// Exclusive scan of every bucket's chunk totals over all chunks, in three steps: the chunks are cut into np
+// partitions of `len` rows; (1) a thread (r, b) of workgroup p adds up bucket b over partition p * R + r (R = 256 /
+// nb partitions per workgroup: the lanes of a row read consecutive words), (2) one workgroup per bucket scans the
+// np partition sums, (3) the threads of (1) write the running bases of their rows.  (One workgroup per bucket
+// walking all 2.3 M rows of configs[2] with a stride of nb words took 11 ms.)
+#define SP_CSP 1024                       // workgroups of steps 1 and 3
+__global__ __launch_bounds__(256) void k_split_chunksum(const u32 *__restrict__ chunk_tot, int64_t nchunks, int nb, int64_t len,
+                                                        u64 *__restrict__ part)
+{ const int R = 256 / nb, r = threadIdx.x / nb, b = threadIdx.x % nb;
+  if (r >= R) return;
+  const int64_t pr = (int64_t) blockIdx.x * R + r;
+  const int64_t lo = pr * len, hi = (lo + len < nchunks) ? lo + len : nchunks;
+  u64 sum = 0;
+  for (int64_t c = lo; c < hi; c++)
+    sum += chunk_tot[(size_t) c * nb + b];
+  part[(size_t) pr * nb + b] = sum;
+}
+
+__global__ __launch_bounds__(256) void k_split_chunkscan(u64 *__restrict__ part, int64_t np, int nb, u64 *__restrict__ total)
 { __shared__ u64 tmp[8];
   const int b = blockIdx.x;
-  const int64_t per = (nchunks + 255) / 256;
-  const int64_t lo = (int64_t) threadIdx.x * per, hi = (lo + per < nchunks) ? lo + per : nchunks;
+  const int64_t per = (np + 255) / 256;
+  const int64_t lo = (int64_t) threadIdx.x * per, hi = (lo + per < np) ? lo + per : np;
   u64 mine = 0;
   for (int64_t c = lo; c < hi; c++)
-    mine += chunk_tot[(size_t) c * nb + b];
+    mine += part[(size_t) c * nb + b];
   u64 tot;
   u64 run = fk_block_exscan_256<u64>(mine, tmp, &tot);
+  for (int64_t c = lo; c < hi; c++)
+    { const u64 v = part[(size_t) c * nb + b];
+      part[(size_t) c * nb + b] = run;
+      run += v;
+    }
+  if (threadIdx.x == 0)
+    total[b] = tot;
+}
+
+__global__ __launch_bounds__(256) void k_split_chunkbase(const u32 *__restrict__ chunk_tot, int64_t nchunks, int nb, int64_t len,
+                                                         const u64 *__restrict__ part, u64 *__restrict__ chunk_base)
+{ const int R = 256 / nb, r = threadIdx.x / nb, b = threadIdx.x % nb;
+  if (r >= R) return;
+  const int64_t pr = (int64_t) blockIdx.x * R + r;
+  const int64_t lo = pr * len, hi = (lo + len < nchunks) ? lo + len : nchunks;
+  u64 run = part[(size_t) pr * nb + b];
   for (int64_t c = lo; c < hi; c++)
     { chunk_base[(size_t) c * nb + b] = run;
       run += chunk_tot[(size_t) c * nb + b];
     }
-  if (threadIdx.x == 0)
-    total[b] = tot;
 }
 
 // A later pass of the multi-pass split: the tile's entries of the first pass (position, flip, length, bucket of
@@ -518,26 +548,39 @@ __global__ __launch_bounds__(SP_THREADS) void k_split_replay(SplitArgs a)
   const int     tid = threadIdx.x;
   const int     K   = a.kmer;
   const int64_t tile = a.tile0 + blockIdx.x;
+  const int64_t t0  = tile * SP_TILE;
+  const int     nw  = SP_TILE / 16 + (K + 14) / 16;
+  const int     R   = nw * 16;
+  // Every load that does not depend on another is issued up front: the tile's entry descriptor, its bases and the
+  // three terms of the bucket offsets; only the entries themselves have to wait for the descriptor.  (One after
+  // the other these were three memory round trips per tile, and the kernel does little else.)
   const u64     te  = a.tile_ent[tile];
+  uint4 v0 = make_uint4(0u, 0u, 0u, 0u), v1 = make_uint4(0u, 0u, 0u, 0u);
+  const int64_t g0 = t0 + (int64_t) tid * 16, g1 = t0 + (int64_t) (tid + SP_THREADS) * 16;
+  const bool    in0 = (g0 + 16 <= a.nbytes), in1 = (tid + SP_THREADS < nw && g1 + 16 <= a.nbytes);
+  if (in0) v0 = *(const uint4 *) (a.bases + g0);
+  if (in1) v1 = *(const uint4 *) (a.bases + g1);
+  u64 bb = 0;
+  if (tid >= a.gb0 && tid < a.gb1)
+    bb = a.rbase[tid] + a.chunk_base[(size_t) (tile / SP_RCH) * a.nbuckets + tid]
+       + (u64) a.tile_cnt[(size_t) tile * a.nbuckets + tid];
   const u32     cnt = (u32) (te & 0x1fffu);
   if (cnt == 0)
     return;
   const u64     eb  = te >> 13;
-  const int64_t t0  = tile * SP_TILE;
-  const int     nw  = SP_TILE / 16 + (K + 14) / 16;
-  const int     R   = nw * 16;
 
   bcnt2[tid] = 0;
   for (u32 s = tid; s < cnt; s += SP_THREADS)
     slist[s] = a.ent[eb + s];
+  // where this tile's records of bucket b go: region start + the bucket's records in earlier chunks + in the
+  // earlier tiles of this chunk -- exact, no reservation needed
+  bbase[tid] = bb;
   for (int q = tid; q < SP_WORDS; q += SP_THREADS)
     { u32 word = 0, bad = 0;
       if (q < nw)
         { const int64_t g = t0 + (int64_t) q * 16;
-          uint4 v;
-          if (g + 16 <= a.nbytes)
-            v = *(const uint4 *) (a.bases + g);
-          else
+          uint4 v = (q == tid) ? v0 : v1;
+          if (!(g + 16 <= a.nbytes))
             { u32 d[4] = { 0u, 0u, 0u, 0u };                   // the last bytes of the input, one by one
               for (int j = 0; j < 16; j++)
                 if (g + j < a.nbytes)
@@ -557,11 +600,6 @@ __global__ __launch_bounds__(SP_THREADS) void k_split_replay(SplitArgs a)
         }
       rcw[q] = x;
     }
-  // where this tile's records of bucket b go: region start + the bucket's
-  // records in earlier chunks + in the earlier tiles of this chunk -- exact, no reservation needed
-  if (tid >= a.gb0 && tid < a.gb1)
-    bbase[tid] = a.rbase[tid] + a.chunk_base[(size_t) (tile / SP_RCH) * a.nbuckets + tid]
-               + (u64) a.tile_cnt[(size_t) tile * a.nbuckets + tid];
   __syncthreads();
 
   const int sww = a.sww;
@@ -1050,7 +1088,7 @@ int fkx_split_planned(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_
       a.ent_cap = ctx->ent_cap;
       if (a.ent == NULL || a.tile_ent == NULL || a.tile_cnt == NULL || a.chunk_base == NULL
           || ctx->slot_cap[FK_SLOT_TENT] < ntiles * 8 || ctx->slot_cap[FK_SLOT_TCNT] < ntiles * nb * 2
-          || ctx->slot_cap[FK_SLOT_CBASE] < nchunks * nb * 12
+          || ctx->slot_cap[FK_SLOT_CBASE] < nchunks * nb * 12 + FK_CBASE_EXTRA
           || (mode == 2 && (!ctx->ent_valid || ctx->ent_ntiles != ntiles)))
         { fk_set_error(ctx, "planned split: no entries to record into / replay from");
           return (FK_ESTATE);
@@ -1099,8 +1137,14 @@ int fkx_split_planned(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_
           u64 *dtot = ctx->d_scratch + 2048;
           hipLaunchKernelGGL(k_split_chunk, dim3((unsigned) ((nchunks + 3) / 4)), dim3(256), 0, s,
                              (uint16_t *) ctx->slot_ptr[FK_SLOT_TCNT], ntiles, nb, ctot);
-          hipLaunchKernelGGL(k_split_chunkscan, dim3((unsigned) nb), dim3(256), 0, s, (const u32 *) ctot, nchunks, nb,
-                             (u64 *) ctx->slot_ptr[FK_SLOT_CBASE], dtot);
+          { const int64_t npart = (int64_t) SP_CSP * (256 / nb);
+            const int64_t len = (nchunks + npart - 1) / npart;
+            u64 *part = (u64 *) ((char *) ctx->slot_ptr[FK_SLOT_CBASE] + (((size_t) nchunks * nb * 12 + 7) & ~(size_t) 7));
+            hipLaunchKernelGGL(k_split_chunksum, dim3(SP_CSP), dim3(256), 0, s, (const u32 *) ctot, nchunks, nb, len, part);
+            hipLaunchKernelGGL(k_split_chunkscan, dim3((unsigned) nb), dim3(256), 0, s, part, npart, nb, dtot);
+            hipLaunchKernelGGL(k_split_chunkbase, dim3(SP_CSP), dim3(256), 0, s, (const u32 *) ctot, nchunks, nb, len,
+                               (const u64 *) part, (u64 *) ctx->slot_ptr[FK_SLOT_CBASE]);
+          }
           FK_LAUNCH_CHECK(ctx);
           FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch + 2048, dtot, (size_t) nb * 8, hipMemcpyDeviceToHost, s));
           FK_HIP(ctx, hipStreamSynchronize(s));
