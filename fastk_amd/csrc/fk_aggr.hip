@@ -21,7 +21,8 @@
 #define AG_CUT     (1u << 28)           //   removed instances go straight to max_inst
 #define AG_MAXR    64
 #define AG_BINS    65536
-#define AG_UNROLL  8
+#define AG_UNROLL  8                    // records per thread in a full table fill (the bin merging rule aims at 1024 x 8)
+#define AG_BATCH   2                    // records per lane in a batch a wave takes at a time
 #define AG_P       4                    // slots one probe looks at (ag_read_slots is written for 4)
 #define AG_NSCAL   16                   // scalars behind the histogram (8 results + 8 phase timers of ablation builds)
 #ifdef FK_ABLATION
@@ -169,14 +170,14 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
                                                          u64 *__restrict__ scal, u32 *__restrict__ table,
                                                          int LIMIT, int variant, int gshift, u32 sat)
 { constexpr int SLOTS = AgCfg<KW>::SLOTS;
-  constexpr int U = AG_UNROLL;
+  constexpr int U = AG_BATCH;
   extern __shared__ uint4 ag_lds[];
   uint4 *A     = ag_lds;                                   // [SLOTS]
   // LDS byte address of the table for the inline-asm reads (low half of the flat address)
   const u32 lds_base = (u32) (uintptr_t) ag_lds;
   uint4 *B     = ag_lds + SLOTS;                           // [SLOTS] when KW > 3
   u32   *lhist = (u32 *) (ag_lds + (KW > 3 ? 2 : 1) * SLOTS);   // [AG_HB]
-  __shared__ u32 sh_claimed, sh_ovf, sh_tmp[AG_WAVES];
+  __shared__ u32 sh_claimed, sh_ovf, sh_next, sh_tmp[AG_WAVES];
   const u32 ovf_addr = (u32) (uintptr_t) &sh_ovf;
   __shared__ u64 sh_base;
   const int tid = threadIdx.x;
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
     A[i] = make_uint4(0, 0, 0, 0);
   for (int i = tid; i < AG_HB; i += AG_THREADS)
     lhist[i] = 0;
-  if (tid == 0) { sh_claimed = 0; sh_ovf = 0; }
+  if (tid == 0) { sh_claimed = 0; sh_ovf = 0; sh_next = 0; }
   u64 my_max = 0;
   u32 my_distinct = 0, my_rounds = 0;
   u32 R0 = 1;
@@ -217,32 +218,62 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
       for (;;)
         { // ---- insert every record of the bin that this round selects
           u64 round_max = 0;
-          for (int64_t i0 = beg + tid; i0 < end; i0 += (int64_t) AG_THREADS * U)
+          // The waves take batches of 64 x U records from a counter in LDS instead of fixed shares: the time a
+          // batch takes varies (probe chains, lost races), and with fixed shares the workgroup waited at the barrier
+          // below for its slowest wave 44 % of the time.  The next batch is loaded while this one is inserted.
+          const u32 lane = fk_lane();
+          u32 rec[U][KW], nrec[U][KW];
+          int64_t base, nbase;
+          { u32 g = 0;
+            if (lane == 0) g = atomicAdd(&sh_next, 1u);
+            g = (u32) __builtin_amdgcn_readfirstlane((int) g);
+            base = beg + (int64_t) g * (64 * U);
+            if (base < end)
+              {
+#pragma unroll
+                for (int u = 0; u < U; u++)
+                  { const int64_t i = base + u * 64 + lane;
+                    const int64_t j = (i < end) ? i : beg;
+#pragma unroll
+                    for (int w = 0; w < KW; w++)
+                      rec[u][w] = recs[j * KW + w];
+                  }
+              }
+          }
+          while (base < end)
             { if (*(volatile u32 *) &sh_ovf)
                 break;
-              u32 rec[U][KW];
+              { u32 g = 0;
+                if (lane == 0) g = atomicAdd(&sh_next, 1u);
+                g = (u32) __builtin_amdgcn_readfirstlane((int) g);
+                nbase = beg + (int64_t) g * (64 * U);
+                if (nbase < end)
+                  {
 #pragma unroll
-              for (int u = 0; u < U; u++)
-                { const int64_t i = i0 + (int64_t) u * AG_THREADS;
-                  const int64_t j = (i < end) ? i : beg;
+                    for (int u = 0; u < U; u++)
+                      { const int64_t i = nbase + u * 64 + lane;
+                        const int64_t j = (i < end) ? i : beg;
 #pragma unroll
-                  for (int w = 0; w < KW; w++)
-                    rec[u][w] = recs[j * KW + w];
-                }
+                        for (int w = 0; w < KW; w++)
+                          nrec[u][w] = recs[j * KW + w];
+                      }
+                  }
+              }
               u32 slot0[U];
               u32 pend = 0;
 #pragma unroll
               for (int u = 0; u < U; u++)
-                { const int64_t i = i0 + (int64_t) u * AG_THREADS;
+                { const int64_t i = base + u * 64 + lane;
                   u32 ha, hb;
                   fk_rec_hash<KW>(rec[u], kbytes, ha, hb);
                   slot0[u] = ha & (SLOTS - 1);
                   if (i < end && ((hb >> 16) & (R - 1)) == r)
                     pend |= (1u << u);
                 }
-              if (variant & 1)
+              const bool skip_insert = (variant & 1) != 0;
+              if (skip_insert)
                 { round_max += pend + slot0[0];
-                  continue;
+                  pend = 0;
                 }
 #ifdef FK_ABLATION
               if (tid == 0 && slot0[0] != 0xffffffffu) AG_T(1);
@@ -384,6 +415,13 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
                         }
                     }
                 }
+              // the batch loaded meanwhile becomes the current one
+              base = nbase;
+#pragma unroll
+              for (int u = 0; u < U; u++)
+#pragma unroll
+                for (int w = 0; w < KW; w++)
+                  rec[u][w] = nrec[u][w];
             }
           AG_T(2);
           __syncthreads();
@@ -395,7 +433,7 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
             { // more distinct k-mers than the table takes: halve the selection and start it again
               for (int i = tid; i < SLOTS; i += AG_THREADS)
                 A[i].w = 0;
-              if (tid == 0) { sh_claimed = 0; sh_ovf = 0; }
+              if (tid == 0) { sh_claimed = 0; sh_ovf = 0; sh_next = 0; }
               my_rounds += (tid == 0);
               bin_ovf = true;
               __syncthreads();
@@ -480,7 +518,7 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
                       }
                 }
             }
-          if (tid == 0) sh_claimed = 0;
+          if (tid == 0) { sh_claimed = 0; sh_next = 0; }
           __syncthreads();
           AG_T(7);
 
@@ -553,9 +591,16 @@ static int aggr_t(fk_ctx *ctx, const void *d_grouped, int64_t n, int cutoff, int
   hipLaunchKernelGGL(k_ag_bounds<KW>, dim3(AG_BINS / 256 + 1), dim3(256), 0, s, (const u32 *) d_grouped, n,
                      ctx->wid.kmer_bytes, d_bounds);
   const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
-  int gshift = 0;                                // aim at ~6,000 records per table fill
-  while (ctx->dbg_aggr_limit <= 0 && gshift < 16 && (n >> (16 - gshift)) < 8000)   // >= one full batch per fill
+  // Neighbouring bins are merged while a table fill stays within one batch of 1024 x 8 records: small inputs
+  // get full batches, and a fill never holds more records than that by choice -- a fill whose distinct k-mers
+  // pass LIMIT is done over in two selections (measured at configs[2], 7,080 records and 4,570 distinct k-mers
+  // per bin: one bin per fill 323 ms per step, two bins per fill -> two selections each 459 ms, one bin in two
+  // selections 402 ms).
+  int gshift = 0;
+  while (ctx->dbg_aggr_limit <= 0 && gshift < 16 && ((n >> (16 - gshift)) << 1) <= AG_THREADS * AG_UNROLL)
     gshift += 1;
+  if (ctx->dbg_aggr_gshift > 0)
+    gshift = ctx->dbg_aggr_gshift - 1;
   const int limit = (ctx->dbg_aggr_limit > 0 && ctx->dbg_aggr_limit < AgCfg<KW>::LIMIT) ? ctx->dbg_aggr_limit
                                                                                         : AgCfg<KW>::LIMIT;
   hipLaunchKernelGGL((k_ag_count<KW, false>), dim3((unsigned) cus), dim3(AG_THREADS), lds, s, (const u32 *) d_grouped,
