@@ -22,7 +22,7 @@
 #define AG_MAXR    64
 #define AG_BINS    65536
 #define AG_UNROLL  8                    // records per thread in a full table fill (the bin merging rule aims at 1024 x 8)
-#define AG_BATCH   2                    // records per lane in a batch a wave takes at a time
+#define AG_BATCH   1                    // records per lane in a batch a wave takes at a time (1 or 2)
 #define AG_P       4                    // slots one probe looks at (ag_read_slots is written for 4)
 #define AG_NSCAL   16                   // scalars behind the histogram (8 results + 8 phase timers of ablation builds)
 #ifdef FK_ABLATION
@@ -33,8 +33,10 @@
 
 template <int KW> struct AgCfg
 { static constexpr int SLOTS = (KW <= 3) ? 8192 : 4096;
-  static constexpr int LIMIT = (SLOTS * 3 / 4 < SLOTS - AG_THREADS - 64) ? SLOTS * 3 / 4
-                                                                         : SLOTS - AG_THREADS - 64;
+  // fill limit: once it is passed every thread may still claim AG_BATCH slots (it looks at the overflow flag once
+  // per batch), and the table must never fill up
+  static constexpr int LIMIT = (SLOTS * 3 / 4 < SLOTS - AG_THREADS * AG_BATCH - 64) ? SLOTS * 3 / 4
+                                                                                    : SLOTS - AG_THREADS * AG_BATCH - 64;
   static constexpr size_t LDS = (size_t) SLOTS * (KW > 3 ? 32 : 16) + AG_HB * 4;
 };
 
@@ -98,6 +100,30 @@ __device__ __forceinline__ void ag_read_slots_flag(u32 base, u32 slot, uint4 (&v
                "s_waitcnt lgkmcnt(0)"
                : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(flag)
                : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(flag_addr)
+               : "memory");
+}
+
+// The first look of two records: 2 x AG_P slots and the overflow flag in one batch of reads.
+template <int SLOTS>
+__device__ __forceinline__ void ag_read_slots2_flag(u32 base, u32 slota, u32 slotb, uint4 (&va)[4], uint4 (&vb)[4],
+                                                    u32 flag_addr, u32 &flag)
+{ const u32 a0 = base + ((slota + 0) & (SLOTS - 1)) * 16u, a1 = base + ((slota + 1) & (SLOTS - 1)) * 16u;
+  const u32 a2 = base + ((slota + 2) & (SLOTS - 1)) * 16u, a3 = base + ((slota + 3) & (SLOTS - 1)) * 16u;
+  const u32 b0 = base + ((slotb + 0) & (SLOTS - 1)) * 16u, b1 = base + ((slotb + 1) & (SLOTS - 1)) * 16u;
+  const u32 b2 = base + ((slotb + 2) & (SLOTS - 1)) * 16u, b3 = base + ((slotb + 3) & (SLOTS - 1)) * 16u;
+  asm volatile("ds_read_b32 %8, %17\n\t"
+               "ds_read_b128 %0, %9\n\t"
+               "ds_read_b128 %1, %10\n\t"
+               "ds_read_b128 %2, %11\n\t"
+               "ds_read_b128 %3, %12\n\t"
+               "ds_read_b128 %4, %13\n\t"
+               "ds_read_b128 %5, %14\n\t"
+               "ds_read_b128 %6, %15\n\t"
+               "ds_read_b128 %7, %16\n\t"
+               "s_waitcnt lgkmcnt(0)"
+               : "=&v"(va[0]), "=&v"(va[1]), "=&v"(va[2]), "=&v"(va[3]), "=&v"(vb[0]), "=&v"(vb[1]), "=&v"(vb[2]), "=&v"(vb[3]),
+                 "=&v"(flag)
+               : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b0), "v"(b1), "v"(b2), "v"(b3), "v"(flag_addr)
                : "memory");
 }
 
@@ -192,6 +218,7 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
   u32 R0 = 1;
 #ifdef FK_ABLATION
   u64 ph[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tlast = __builtin_readcyclecounter();
+  u32 n_first = 0, n_loop = 0;          // wave-level: first looks (pairs), iterations of the general loop
 #endif
   u32 kmask[KW];                                // key bytes of each record dword (pad and weight off)
 #pragma unroll
@@ -279,79 +306,123 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
               if (tid == 0 && slot0[0] != 0xffffffffu) AG_T(1);
 #endif
 
-              // one record per lane at a time; a probe looks at AG_P consecutive slots at once (the
-              // kernel is bound by instruction issue, not by LDS bandwidth, and most records are
-              // settled by the first look even when the table is half full)
+              // First look for the two records of the batch TOGETHER: the reads of both probes in one LDS round
+              // trip, then both claims in flight at once (a wave's LDS operations complete in order, so when the
+              // two records of a lane want the same empty slot the second claim sees the first one's lock and
+              // goes to the general loop).  Four waves per SIMD cannot hide three dependent LDS round trips per
+              // record; two records per lane halve them.  A probe looks at AG_P consecutive slots at once;
+              // straight-line for the whole wave (nested divergent branches cost more scalar instructions here
+              // than the probes cost vector ones): most records hit their k-mer or claim an empty slot right away.
+              u32  cu_[U][KW], wg_[U], sl_[U], sx[U], kind[U];
+              bool dn_[U], todo[U], bmiss[U], created[U];
 #pragma unroll
               for (int u = 0; u < U; u++)
-                { u32 cur[KW];
+                {
 #pragma unroll
                   for (int w = 0; w < KW; w++)
-                    cur[w] = rec[u][w] & kmask[w];
-                  const u32 wgt = DEDUP ? 1u : (rec[u][KW - 1] >> 16);
-                  u32  slot = slot0[u];
-                  // a thread claims <= 1 slot per record, so looking at the overflow flag once per
-                  // record keeps the table from filling up
-                  // (the flag arrives with the slots of the first look: one LDS round trip, not two)
-                  // First look, straight-line for the whole wave (nested divergent branches cost more
-                  // scalar instructions here than the probes cost vector ones): most records either
-                  // hit their k-mer or claim an empty slot right away.
-                  uint4 v0[AG_P];
-                  u32   ovf_now;
-                  ag_read_slots_flag<SLOTS>(lds_base, slot, v0, ovf_addr, ovf_now);
-                  const bool todo = ((pend >> u) & 1u) && ovf_now == 0;
-                  bool done = !todo;
-                  { uint4 (&v)[AG_P] = v0;
-                    int act;
-                    u32 kind, cact;
-                    ag_classify<KW>(v, cur, act, kind, cact);
-                    const u32 s = (slot + (u32) act) & (SLOTS - 1);
-                    bool hit = todo && kind == 3u && cact < (AG_HIGH >> 1);
-                    bool bmiss = false;
-                    if (KW > 3 && hit)
-                      { const uint4 b = B[s];
-                        bool same = (b.x == cur[KW > 3 ? 3 : 0]);
-                        if (KW > 4) same = same && (b.y == cur[KW > 4 ? 4 : 0]);
-                        if (KW > 5) same = same && (b.z == cur[KW > 5 ? 5 : 0]);
-                        if (KW > 6) same = same && (b.w == cur[KW > 6 ? 6 : 0]);
-                        bmiss = !same;
-                        hit = same;
-                      }
-                    if (hit)
-                      { atomicAdd(&A[s].w, wgt);
-                        done = true;
-                      }
-                    bool created = false;
-                    if (todo && kind == 1u)
-                      { if (atomicCAS(&A[s].w, 0u, AG_LOCK) == 0u)
-                          { // key and weight appear together: the (wider) key's tail first, then ONE 16-byte write of
-                            // key + count word -- LDS serves a wave's operations in order and an aligned 16-byte
-                            // access in one piece, so no reader can pair this count with another key
-                            if (KW > 3)
-                              { B[s] = make_uint4(cur[KW > 3 ? 3 : 0], KW > 4 ? cur[KW > 4 ? 4 : 0] : 0u,
-                                                  KW > 5 ? cur[KW > 5 ? 5 : 0] : 0u, KW > 6 ? cur[KW > 6 ? 6 : 0] : 0u);
-                                asm volatile("" ::: "memory");
-                              }
-                            ag_write_slot(lds_base + s * 16u, make_uint4(cur[0], KW > 1 ? cur[KW > 1 ? 1 : 0] : 0u,
-                                                                         KW > 2 ? cur[KW > 2 ? 2 : 0] : 0u, wgt));
-                            created = true;
-                            done = true;
-                          }
-                      }
-                    const u64 cm = __ballot(created);
-                    if (cm != 0ull && fk_lane() == (u32) (__ffsll((long long) cm) - 1))
-                      { const u32 k = (u32) __popcll(cm);
-                        if (atomicAdd(&sh_claimed, k) + k > (u32) LIMIT)
-                          sh_ovf = 1;
-                      }
-                    // whoever is left (lost a race, met a slot being written, no hit in AG_P slots,
-                    // wide keys, very large counts) goes through the general loop below
-                    if (!done)
-                      slot = (kind == 1u || kind == 2u) ? s : (kind == 0u) ? ((slot + AG_P) & (SLOTS - 1))
-                           : bmiss ? ((s + 1) & (SLOTS - 1)) : slot;
+                    cu_[u][w] = rec[u][w] & kmask[w];
+                  wg_[u]  = DEDUP ? 1u : (rec[u][KW - 1] >> 16);
+                  sl_[u] = slot0[u];
+                }
+#ifdef FK_ABLATION
+              if (fk_lane() == 0) n_first += 1;
+#endif
+              { // a thread claims <= U slots per look at the overflow flag (it arrives with the slots: one LDS
+                // round trip), which LIMIT leaves room for
+                uint4 v0[U][AG_P];
+                u32   ovf_now;
+                if (U == 2)
+                  ag_read_slots2_flag<SLOTS>(lds_base, sl_[0], sl_[U - 1], v0[0], v0[U - 1], ovf_addr, ovf_now);
+                else
+                  ag_read_slots_flag<SLOTS>(lds_base, sl_[0], v0[0], ovf_addr, ovf_now);
+                bool hit[U];
+#pragma unroll
+                for (int u = 0; u < U; u++)
+                  { int act;
+                    u32 cact;
+                    ag_classify<KW>(v0[u], cu_[u], act, kind[u], cact);
+                    sx[u]   = (sl_[u] + (u32) act) & (SLOTS - 1);
+                    todo[u] = ((pend >> u) & 1u) && ovf_now == 0;
+                    dn_[u] = !todo[u];
+                    hit[u]  = todo[u] && kind[u] == 3u && cact < (AG_HIGH >> 1);
+                    bmiss[u] = false;
+                    created[u] = false;
                   }
+                if (KW > 3)
+                  {
+#pragma unroll
+                    for (int u = 0; u < U; u++)
+                      if (hit[u])
+                        { const uint4 b = B[sx[u]];
+                          bool same = (b.x == cu_[u][KW > 3 ? 3 : 0]);
+                          if (KW > 4) same = same && (b.y == cu_[u][KW > 4 ? 4 : 0]);
+                          if (KW > 5) same = same && (b.z == cu_[u][KW > 5 ? 5 : 0]);
+                          if (KW > 6) same = same && (b.w == cu_[u][KW > 6 ? 6 : 0]);
+                          bmiss[u] = !same;
+                          hit[u] = same;
+                        }
+                  }
+#pragma unroll
+                for (int u = 0; u < U; u++)
+                  if (hit[u])
+                    { atomicAdd(&A[sx[u]].w, wg_[u]);
+                      dn_[u] = true;
+                    }
+                u32 got[U];
+#pragma unroll
+                for (int u = 0; u < U; u++)
+                  { got[u] = 1u;
+                    if (todo[u] && kind[u] == 1u)
+                      got[u] = atomicCAS(&A[sx[u]].w, 0u, AG_LOCK);
+                  }
+#pragma unroll
+                for (int u = 0; u < U; u++)
+                  if (got[u] == 0u)
+                    { // key and weight appear together: the (wider) key's tail first, then ONE 16-byte write of
+                      // key + count word -- LDS serves a wave's operations in order and an aligned 16-byte
+                      // access in one piece, so no reader can pair this count with another key
+                      if (KW > 3)
+                        { B[sx[u]] = make_uint4(cu_[u][KW > 3 ? 3 : 0], KW > 4 ? cu_[u][KW > 4 ? 4 : 0] : 0u,
+                                                KW > 5 ? cu_[u][KW > 5 ? 5 : 0] : 0u, KW > 6 ? cu_[u][KW > 6 ? 6 : 0] : 0u);
+                          asm volatile("" ::: "memory");
+                        }
+                      ag_write_slot(lds_base + sx[u] * 16u, make_uint4(cu_[u][0], KW > 1 ? cu_[u][KW > 1 ? 1 : 0] : 0u,
+                                                                        KW > 2 ? cu_[u][KW > 2 ? 2 : 0] : 0u, wg_[u]));
+                      created[u] = true;
+                      dn_[u] = true;
+                    }
+                u32 kcl = 0;
+                u64 cany = 0;
+#pragma unroll
+                for (int u = 0; u < U; u++)
+                  { const u64 cm = __ballot(created[u]);
+                    kcl  += (u32) __popcll(cm);
+                    cany |= cm;
+                  }
+                if (cany != 0ull && fk_lane() == (u32) (__ffsll((long long) cany) - 1))
+                  { if (atomicAdd(&sh_claimed, kcl) + kcl > (u32) LIMIT)
+                      sh_ovf = 1;
+                  }
+                // whoever is left (lost a race, met a slot being written, no hit in AG_P slots,
+                // wide keys, very large counts) goes through the general loop below
+#pragma unroll
+                for (int u = 0; u < U; u++)
+                  if (!dn_[u])
+                    sl_[u] = (kind[u] == 1u || kind[u] == 2u) ? sx[u] : (kind[u] == 0u) ? ((sl_[u] + AG_P) & (SLOTS - 1))
+                            : bmiss[u] ? ((sx[u] + 1) & (SLOTS - 1)) : sl_[u];
+              }
+#pragma unroll
+              for (int u = 0; u < U; u++)
+                { bool done = dn_[u];
+                  u32  slot = sl_[u];
+                  u32 (&cur)[KW] = cu_[u];
+                  const u32 wgt = wg_[u];
                   while (!done)
-                    { uint4 v[AG_P];
+                    {
+#ifdef FK_ABLATION
+                      if (fk_lane() == (u32) (__ffsll((long long) __ballot(1)) - 1)) n_loop += 1;
+#endif
+                      uint4 v[AG_P];
                       ag_read_slots<SLOTS>(lds_base, slot, v);
                       // first slot that is empty (1), being written (2) or holds this k-mer (3)
                       int act;
@@ -450,13 +521,23 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
 
           // ---- emit: histogram, totals, table entries; the table is left empty
           my_max += round_max;
-          u32 c[SLOTS / AG_THREADS];
-          u32 nq = 0;
+          // (all count words first: eight independent LDS reads instead of eight round trips; the k-mers seen once
+          // or twice -- four out of five on read sets with sequencing errors -- are counted per wave with a ballot:
+          // one LDS atomic per lane on the same two histogram bins serialised the whole sweep)
+          u32 c[SLOTS / AG_THREADS], vv[SLOTS / AG_THREADS];
+          u32 nq = 0, n1 = 0, n2 = 0;
+#pragma unroll
+          for (int j = 0; j < SLOTS / AG_THREADS; j++)
+            vv[j] = A[j * AG_THREADS + tid].w;
 #pragma unroll
           for (int j = 0; j < SLOTS / AG_THREADS; j++)
             { const int slot = j * AG_THREADS + tid;
-              const u32 v = A[slot].w;
+              const u32 v = vv[j];
               c[j] = 0;
+              if (!DEDUP)
+                { n1 += (u32) __popcll(__ballot(v == 1u));
+                  n2 += (u32) __popcll(__ballot(v == 2u));
+                }
               if (v != 0)
                 { A[slot].w = 0;
                   my_distinct += 1;
@@ -470,7 +551,7 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
                     my_max += v;
                   if (v >= 0x7fffu)
                     cc = 0x7fffu;
-                  if (variant & 2) ;
+                  if ((variant & 2) || cc <= 2u) ;
                   else if (cc < AG_HB) atomicAdd(&lhist[cc], 1u);
                   else            atomicAdd(&hist_g[cc], 1ull);
                   if (cutoff > 0 && (int) cc >= cutoff)
@@ -478,6 +559,10 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
                       c[j] = cc;
                     }
                 }
+            }
+          if (!DEDUP && !(variant & 2) && fk_lane() == 0)
+            { if (n1 != 0) atomicAdd(&lhist[1], n1);
+              if (n2 != 0) atomicAdd(&lhist[2], n2);
             }
           AG_T(4);
           if ((DEDUP || cutoff > 0) && !(variant & 4))
@@ -557,8 +642,19 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
     }
 #ifdef FK_ABLATION
   if (tid == 0)
-    for (int k = 0; k < 8; k++)
+    for (int k = 0; k < 6; k++)
       atomicAdd(&scal[8 + k], ph[k]);
+  if (tid == 0)
+    atomicAdd(&scal[8 + 6], ph[6] + ph[7]);
+  { u64 nl = n_loop, nf = n_first;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+      { nl += __shfl_down(nl, o, 64);
+        nf += __shfl_down(nf, o, 64);
+      }
+    if (fk_lane() == 0)
+      atomicAdd(&scal[8 + 7], (nf << 32) | nl);
+  }
 #endif
 }
 
@@ -632,7 +728,8 @@ static int aggr_t(fk_ctx *ctx, const void *d_grouped, int64_t n, int cutoff, int
     { fprintf(stderr, "ag phases (cycles of thread 0, all workgroups) n=%lld:", (long long) n);
       for (int k = 0; k < 8; k++)
         fprintf(stderr, " %llu", (unsigned long long) hh[FK_HIST_BINS + 8 + k]);
-      fprintf(stderr, "\n");
+      fprintf(stderr, "  first looks %llu loop iterations %llu\n", (unsigned long long) (hh[FK_HIST_BINS + 15] >> 32),
+              (unsigned long long) (hh[FK_HIST_BINS + 15] & 0xffffffffull));
     }
 #endif
   free(hh);
