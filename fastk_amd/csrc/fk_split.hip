@@ -537,11 +537,12 @@ __global__ __launch_bounds__(256) void k_split_chunkbase(const u32 *__restrict__
 
 // A later pass of the multi-pass split: the tile's entries of the first pass (position, flip, length, bucket of
 // every super-mer that pass did not emit) + the reads -> the records of buckets [gb0, gb1).  Steps 1 and 7 of
-// k_split only: no keys, no minima, no validity, no start masks.
+// k_split only: no keys, no minima, no validity, no start masks.  (Persistent workgroups that keep the loads of the
+// next tile and the descriptor of the one after in flight were tried: 473 instead of 459 ms of split time per
+// configs[2] step -- the kernel is not waiting for its two dependent round trips either.)
 __global__ __launch_bounds__(SP_THREADS) void k_split_replay(SplitArgs a)
 { __shared__ u32 fwd[SP_WORDS];
   __shared__ u32 rcw[SP_WORDS];
-  __shared__ u32 slist[SP_TILE];
   __shared__ __attribute__((aligned(8))) u64 bbase[256];
   __shared__ u32 bcnt2[256];
 
@@ -570,8 +571,11 @@ __global__ __launch_bounds__(SP_THREADS) void k_split_replay(SplitArgs a)
   const u64     eb  = te >> 13;
 
   bcnt2[tid] = 0;
-  for (u32 s = tid; s < cnt; s += SP_THREADS)
-    slist[s] = a.ent[eb + s];
+  // a thread builds the records of the entries tid, tid + 256, ...: the first one is fetched now and used after
+  // the bases are converted (no staging in LDS: 5.3 KB per workgroup, the CU's wave limit decides the occupancy)
+  u32 e0 = 0;
+  if ((u32) tid < cnt)
+    e0 = a.ent[eb + tid];
   // where this tile's records of bucket b go: region start + the bucket's records in earlier chunks + in the
   // earlier tiles of this chunk -- exact, no reservation needed
   bbase[tid] = bb;
@@ -606,7 +610,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_split_replay(SplitArgs a)
   const int lenw = a.smer_bytes >> 2;
   const int lensh = 24 - 8 * (a.smer_bytes & 3);
   for (u32 s = tid; s < cnt; s += SP_THREADS)
-    { const u32 e    = slist[s];
+    { const u32 e    = (s == (u32) tid) ? e0 : a.ent[eb + s];
       const int i    = e & 0xfffu;
       const u32 flip = (e >> 12) & 1u;
       const int n    = (e >> 13) & 0x7fu;
