@@ -179,7 +179,7 @@ __device__ __forceinline__ u32 ag_block_exscan(u32 v, u32 *tmp, u32 *total)
 }
 
 // scal: [0] max_inst  [1] distinct k-mers  [2] table entries  [3] failure flag  [4] bin ticket
-//       [5] extra rounds taken
+//       [5] extra rounds taken  [6] table buffer too small (tcap records)
 //
 // LDS table: SLOTS entries of 16 bytes {key dword 0, 1, 2, count word}; records of 4 or 5 dwords keep
 // dwords 3, 4 in a second array.  A lane's aligned 16-byte LDS access is served in one piece, so a
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
                                                          const u64 *__restrict__ bounds, int kbytes,
                                                          int cutoff, u64 *__restrict__ hist_g,
                                                          u64 *__restrict__ scal, u32 *__restrict__ table,
-                                                         int LIMIT, int variant, int gshift, u32 sat)
+                                                         int LIMIT, int variant, int gshift, u32 sat, u64 tcap)
 { constexpr int SLOTS = AgCfg<KW>::SLOTS;
   constexpr int U = AG_BATCH;
   extern __shared__ uint4 ag_lds[];
@@ -573,7 +573,11 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
                 sh_base = atomicAdd(&scal[2], (u64) tot);
               __syncthreads();
               AG_T(6);
-              if (tot > 0)
+              if (tot > 0 && sh_base + tot > tcap)
+                { if (tid == 0)                       // the table buffer is full (direct append to a union buffer)
+                    atomicAdd(&scal[6], 1ull);
+                }
+              else if (tot > 0)
                 { u64 o = sh_base + off;
 #pragma unroll
                   for (int j = 0; j < SLOTS / AG_THREADS; j++)
@@ -666,9 +670,8 @@ static int aggr_t(fk_ctx *ctx, const void *d_grouped, int64_t n, int cutoff, int
   if (ndistinct) *ndistinct = 0;
   if (n == 0)
     return (FK_OK);
-  if (cutoff > 0 && (d_table == NULL || cap < n))
-    { fk_set_error(ctx, "aggregate: the table buffer must take as many records as the input (%lld)",
-                   (long long) n);
+  if (cutoff > 0 && (d_table == NULL || cap <= 0))
+    { fk_set_error(ctx, "aggregate: no table buffer");
       return (FK_EINVAL);
     }
   u64 *d_bounds = (u64 *) fk_slot(ctx, FK_SLOT_AG_BOUNDS, (AG_BINS + 1) * 8);
@@ -701,7 +704,7 @@ static int aggr_t(fk_ctx *ctx, const void *d_grouped, int64_t n, int cutoff, int
                                                                                         : AgCfg<KW>::LIMIT;
   hipLaunchKernelGGL((k_ag_count<KW, false>), dim3((unsigned) cus), dim3(AG_THREADS), lds, s, (const u32 *) d_grouped,
                      (const u64 *) d_bounds, ctx->wid.kmer_bytes, cutoff, d_hist, d_scal, (u32 *) d_table, limit, ctx->dbg_aggr_variant, gshift,
-                     (u32) (ctx->aggr_sat > 0 ? ctx->aggr_sat : 0x7fff));
+                     (u32) (ctx->aggr_sat > 0 ? ctx->aggr_sat : 0x7fff), (u64) cap);
   FK_LAUNCH_CHECK(ctx);
   u64 *h = ctx->h_scratch;                       // pinned, 64 KB + 64 KB: the histogram needs 256 KB
   u64 *hh = (u64 *) malloc((FK_HIST_BINS + AG_NSCAL) * 8);
@@ -716,6 +719,10 @@ static int aggr_t(fk_ctx *ctx, const void *d_grouped, int64_t n, int cutoff, int
   if (hh[FK_HIST_BINS + 3] != 0)
     { free(hh);
       return (FK_ESTATE);                          // a bin did not fit even in AG_MAXR rounds
+    }
+  if (hh[FK_HIST_BINS + 6] != 0)
+    { free(hh);
+      return (FKX_TABLE_FULL);                     // fewer than `cap` records of room: nothing was accumulated
     }
   for (int i = 1; i < FK_HIST_BINS; i++)
     hist[i] += (int64_t) hh[i];
@@ -791,7 +798,7 @@ static int dedup_t(fk_ctx *ctx, const void *d_grouped, int64_t n, void *d_out, i
     gshift += 1;
   hipLaunchKernelGGL((k_ag_count<KW, true>), dim3((unsigned) cus), dim3(AG_THREADS), lds, s, (const u32 *) d_grouped,
                      (const u64 *) d_bounds, KW * 4, 1, d_hist, d_scal, (u32 *) d_out, AgCfg<KW>::LIMIT, 0,
-                     gshift, 0x7fffu);
+                     gshift, 0x7fffu, (u64) cap);
   FK_LAUNCH_CHECK(ctx);
   FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch + 4100, d_scal, 8 * 8, hipMemcpyDeviceToHost, s));
   FK_HIP(ctx, hipStreamSynchronize(s));

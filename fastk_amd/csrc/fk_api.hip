@@ -296,7 +296,7 @@ extern "C" void fk_destroy(fk_ctx *ctx)
     hipStreamSynchronize(ctx->copy_stream);
   if (ctx->stream != NULL)
     hipStreamSynchronize(ctx->stream);
-  hipFree(ctx->d_mbucket); hipFree(ctx->d_mbucket_pass); hipFree(ctx->d_scratch); hipFree(ctx->d_cursors);
+  hipFree(ctx->d_mbucket); hipFree(ctx->d_mbucket_pass); hipFree(ctx->d_scratch); hipFree(ctx->d_cursors); hipFree(ctx->d_plan);
   if (ctx->h_mbucket_pass) hipHostFree(ctx->h_mbucket_pass);
   if (ctx->h_scratch) hipHostFree(ctx->h_scratch);
   hipFree(ctx->d_digit_hist); hipFree(ctx->d_status); hipFree(ctx->d_ticket);
@@ -1400,6 +1400,7 @@ static int count_bucket(fk_ctx *ctx, void *sm_in, int64_t ns, fk_result *res, bo
       void   *tab = NULL;                       // device address of this bucket's table records
       bool    tab_sorted = false;
       bool    aggregated = false;
+      bool    direct = false;                   // the table records are already in the union buffer
       float   ms_aggr = 0.f;
       if (nw > 0 && ctx->dbg_kmer_stage != 1)
         { void *grouped = km_a;
@@ -1410,9 +1411,28 @@ static int count_bucket(fk_ctx *ctx, void *sm_in, int64_t ns, fk_result *res, bo
           res->ms_pass_kmer    += ctx->sort_stats.pass_ms_total;
           res->ms_scatter_kmer += ctx->sort_stats.scatter_ms_total;
           void *tbuf = (grouped == km_a) ? km_b : km_a;
+          // Bucket streaming: the table candidates go straight behind those of the earlier buckets when the union
+          // buffer has clearly enough room left (1.5 x what a bucket has brought so far); the kernel checks the
+          // bound, and a bucket that does not fit after all is aggregated again into its own buffer.
+          int64_t room = 0;
+          if (!final && cutoff > 0 && ctx->slot_ptr[FK_SLOT_TABLE] != NULL && res->buckets_counted > 0 && ntab != NULL)
+            { room = ctx->slot_cap[FK_SLOT_TABLE] / w.kmer_stride - *ntab;
+              const int64_t expect = *ntab / res->buckets_counted;
+              if (room < expect + expect / 2 + 4096)
+                room = 0;
+            }
           hipEventRecord(ctx->ev0, s);
-          rc = fkx_aggregate(ctx, grouped, nw, cutoff, res->hist, &res->max_inst, &ndk,
-                             cutoff > 0 ? tbuf : NULL, nw, &nt);     // adds to hist only on success
+          if (room > 0)
+            { rc = fkx_aggregate(ctx, grouped, nw, cutoff, res->hist, &res->max_inst, &ndk,
+                                 (char *) ctx->slot_ptr[FK_SLOT_TABLE] + *ntab * w.kmer_stride, room, &nt);
+              if (rc == FKX_TABLE_FULL)
+                room = 0;
+              else if (rc == FK_OK)
+                direct = true;
+            }
+          if (room == 0)
+            rc = fkx_aggregate(ctx, grouped, nw, cutoff, res->hist, &res->max_inst, &ndk,
+                               cutoff > 0 ? tbuf : NULL, nw, &nt);     // adds to hist only on success
           hipEventRecord(ctx->ev1, s);
           if (rc == FK_OK)
             { aggregated = true;
@@ -1491,7 +1511,7 @@ static int count_bucket(fk_ctx *ctx, void *sm_in, int64_t ns, fk_result *res, bo
                 }
               *table_out = tab;
             }
-          else
+          else if (!direct)
             { // keep what earlier buckets appended while the slot grows
               const int64_t need = (*ntab + nt) * w.kmer_stride;
               if (ctx->slot_cap[FK_SLOT_TABLE] < need)

@@ -19,6 +19,7 @@ typedef unsigned int       u32;
 // Minimizers are canonical 7-mers ordered by a bijective mix of their 14-bit code (odd multiplies and
 // xor-shifts are invertible mod 2^14, so distinct 7-mers never tie): FK_NRANKS rank values, of which
 // the 8192 images of canonical codes occur.
+#define FKX_TABLE_FULL 100                   // fkx_aggregate: the table buffer took fewer records than qualified (internal)
 #define FK_CBASE_EXTRA ((2 << 20) + 64)      // partition sums of the chunk scan behind the chunk bases (fk_split.hip)
 #define FK_CURSOR_STRIDE 512
 #define FK_MIN_LEN 7
@@ -77,6 +78,7 @@ struct fk_ctx
   uint8_t   *d_mbucket_pass; // [FK_NRANKS] the same for one group pass of a multi-pass split (0xFF = not now)
   uint8_t    h_mbucket[FK_NRANKS];
   uint8_t   *h_mbucket_pass; // pinned staging of d_mbucket_pass
+  u64       *d_plan;         // [32][256] spread bucket counters of the sampled split plan
   u64       *d_cursors;      // [(256 * 8 streams + 64) * FK_CURSOR_STRIDE] write cursors of the streamed split emit, 4 KB apart,
                              // then the 64 cursors of the entry sub-regions
   int64_t    ent_cap;        // multi-pass split with replay: room (entries) in FK_SLOT_ENT

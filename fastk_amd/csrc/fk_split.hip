@@ -75,6 +75,7 @@ struct SplitArgs
   // on four).  So a bucket has 2^lstreams cursors, tile t uses cursor t mod 2^lstreams, and stream c owns
   // the chunks c, c + C, c + 2C, ... (SP_LB records each) of the bucket's region: the region fills evenly from the
   // front, k_split_compact closes the ragged end (a few chunks per bucket) afterwards.
+  u64      *plan;           // count mode: [32][256] spread bucket counters (NULL: counts[])
   int       lstreams;
   const u64 *rbase;         // [nbuckets] first record of each bucket's region (the cursors count from 0)
   u32       skipb;          // super-mers whose bucket entry equals skipb are dropped (0xFF in a group
@@ -393,7 +394,11 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
 
   if (!EMIT)
     { if (tid < a.nbuckets && bcnt[tid] != 0)
-        atomicAdd(&a.counts[tid], (u64) bcnt[tid]);
+        { // a sampled plan spreads the bucket counters over 32 copies 2 KB apart: every tile adds to every
+          // bucket's counter, and one address takes ~80 M atomics per second (the plan of configs[2] took 24.6 ms)
+          if (a.plan != NULL) atomicAdd(&a.plan[((blockIdx.x & 31u) << 8) + tid], (u64) bcnt[tid]);
+          else                atomicAdd(&a.counts[tid], (u64) bcnt[tid]);
+        }
       return;
     }
 
@@ -997,10 +1002,21 @@ int fkx_split_plan(fk_ctx *ctx, const void *d_bases, int64_t nbytes, int64_t *ca
   a.overflowed = (u32 *) (ctx->d_scratch + 1024);
   a.tile_stride = sample;
   FK_HIP(ctx, hipMemsetAsync(ctx->d_scratch, 0, 1032 * sizeof(u64), s));
+  if (ctx->d_plan == NULL)
+    FK_HIP(ctx, hipMalloc((void **) &ctx->d_plan, 32 * 256 * sizeof(u64)));
+  FK_HIP(ctx, hipMemsetAsync(ctx->d_plan, 0, 32 * 256 * sizeof(u64), s));
+  a.plan = ctx->d_plan;
   sp_launch<false, false>(a, ntiles / sample, s);
   FK_LAUNCH_CHECK(ctx);
-  FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch, ctx->d_scratch, 256 * sizeof(u64), hipMemcpyDeviceToHost, s));
+  u64 *hp = ctx->h_scratch + 8192;                 // pinned, 32 x 256 words
+  FK_HIP(ctx, hipMemcpyAsync(hp, ctx->d_plan, 32 * 256 * sizeof(u64), hipMemcpyDeviceToHost, s));
   FK_HIP(ctx, hipStreamSynchronize(s));
+  for (int b = 0; b < nb; b++)
+    { u64 t = 0;
+      for (int c = 0; c < 32; c++)
+        t += hp[c * 256 + b];
+      ctx->h_scratch[b] = t;
+    }
   const double scale = (double) ntiles / (double) (ntiles / sample);
   int64_t tot = 0;
   for (int b = 0; b < nb; b++)
