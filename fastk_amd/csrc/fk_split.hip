@@ -225,24 +225,24 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
     for (int c = 0; c < 16; c++)
       keys[SP_KIDX(16 * q + c)] = kk[c];
   }
-  if (16 * (SP_THREADS + tid) < SP_TILE + W)             // the halo blocks past the tile
-    { const int q = SP_THREADS + tid;
+  if (tid < SP_MAXK)                                     // the halo past the tile: one position per lane of wave 0
+    { // (a thread per 16-position block, as above, made wave 0 run the whole key code a second time for three
+      //  or four of its lanes: a twelfth of the kernel's instructions)
+      const int p = SP_TILE + tid, q = p >> 4, c = p & 15;
       const u64 x = (((u64) fwd[q]) << 32) | (u64) fwd[q + 1];
       const int qr = nw - q - 2;                            // may run off the front for the last halo words
       const u64 y = (((u64) (qr >= 0 ? rcw[qr] : 0u)) << 32) | (u64) (qr + 1 >= 0 ? rcw[qr + 1] : 0u);
-      u32 kk[SP_CH];
-#pragma unroll
-      for (int c = 0; c < 16; c++)
-        kk[c] = sp_key7((u32) (x >> (50 - 2 * c)), (u32) (y >> (2 * c))) | ((u32) (16 * q + c) << 1);
+      u32 kk = sp_key7((u32) (x >> (50 - 2 * c)), (u32) (y >> (2 * c))) | ((u32) p << 1);
       if (fastmin)
         {
 #pragma unroll
-          for (int c = 1; c < SP_CH; c++)
-            kk[c] = min(kk[c], kk[c - 1]);
+          for (int o = 1; o < 16; o <<= 1)                  // prefix minima inside the block of 16 lanes
+            { const u32 t = __shfl_up(kk, o, 16);
+              if (c >= o) kk = min(kk, t);
+            }
         }
-#pragma unroll
-      for (int c = 0; c < 16; c++)
-        keys[SP_KIDX(16 * q + c)] = kk[c];
+      if (p < SP_TILE + ((W + 15) & ~15))
+        keys[SP_KIDX(p)] = kk;
     }
   __syncthreads();
 
