@@ -289,6 +289,9 @@ def e2e_leg(args, cfg, fastk_amd, ctx_gen, L):
             times.append(time.perf_counter() - t0)
             if times[-1] == min(times):
                 phases = " ".join(x.strip() for x in p.stderr.splitlines() if "Wall s" in x)
+            if os.environ.get("FK_E2E_LOG"):
+                with open(os.environ["FK_E2E_LOG"], "a") as lf:
+                    lf.write("---- run: %.3f s\n%s\n" % (times[-1], p.stderr))
         inst = nreads * (L - args.kmer + 1)
         out_bytes = sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d)
                         if f.startswith("out") or f.startswith(".out"))

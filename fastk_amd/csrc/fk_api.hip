@@ -8,6 +8,7 @@
 #include <stdarg.h>
 #include <fcntl.h>
 #include <unistd.h>
+#include <sys/mman.h>
 #include <algorithm>
 #include <vector>
 #include <thread>
@@ -59,15 +60,76 @@ void *fk_slot(fk_ctx *ctx, int slot, int64_t nbytes)
 
 // The result table's host copy lives in pinned memory (the D2H copy of a 36 GB table runs at the
 // PCIe rate only from there); grown with headroom, kept until fk_destroy.
+// ---- large pinned host buffers --------------------------------------------------------------------
+// hipHostMalloc allocates, zeroes and pins at ~8 GB/s (17 GB: 2.1 s; the 36 GB result table of configs[2]: 5-6 s,
+// more than the whole device pipeline).  Ordinary huge-page memory touched by a few threads and then registered
+// is ready in 0.13 s per 17 GB and copies at the same 57 GB/s (tools/probe/pin_probe.cpp).  Buffers below
+// FK_PIN_FAST come from hipHostMalloc as before.
+#define FK_PIN_FAST ((int64_t) 64 << 20)
+static pthread_mutex_t         g_pin_lock = PTHREAD_MUTEX_INITIALIZER;
+static std::vector<void *>     g_pin_reg;             // buffers that were registered, not hipHostMalloc'ed
+
+int fkx_pinned_alloc(void **out, int64_t bytes)
+{ *out = NULL;
+  if (bytes < FK_PIN_FAST)
+    return (hipHostMalloc(out, (size_t) (bytes > 0 ? bytes : 1), hipHostMallocDefault) == hipSuccess ? FK_OK : FK_ENOMEM);
+  const size_t n = ((size_t) bytes + ((size_t) 2 << 20) - 1) & ~(((size_t) 2 << 20) - 1);
+  char *p = (char *) aligned_alloc((size_t) 2 << 20, n);
+  if (p == NULL)
+    return (FK_ENOMEM);
+  madvise(p, n, MADV_HUGEPAGE);
+  { const int T = 8;
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; t++)
+      th.emplace_back([=]()
+        { const size_t lo = n / T * t, hi = (t == T - 1) ? n : n / T * (t + 1);
+          for (size_t i = lo; i < hi; i += 4096)
+            p[i] = 0;
+        });
+    for (auto &x : th)
+      x.join();
+  }
+  if (hipHostRegister(p, n, hipHostRegisterDefault) != hipSuccess)
+    { (void) hipGetLastError();
+      free(p);
+      return (hipHostMalloc(out, (size_t) bytes, hipHostMallocDefault) == hipSuccess ? FK_OK : FK_ENOMEM);
+    }
+  pthread_mutex_lock(&g_pin_lock);
+  g_pin_reg.push_back(p);
+  pthread_mutex_unlock(&g_pin_lock);
+  *out = p;
+  return (FK_OK);
+}
+
+int fkx_pinned_free(void *p)
+{ if (p == NULL)
+    return (FK_OK);
+  bool mine = false;
+  pthread_mutex_lock(&g_pin_lock);
+  for (size_t i = 0; i < g_pin_reg.size(); i++)
+    if (g_pin_reg[i] == p)
+      { g_pin_reg[i] = g_pin_reg.back();
+        g_pin_reg.pop_back();
+        mine = true;
+        break;
+      }
+  pthread_mutex_unlock(&g_pin_lock);
+  if (!mine)
+    return (hipHostFree(p) == hipSuccess ? FK_OK : FK_EHIP);
+  (void) hipHostUnregister(p);
+  free(p);
+  return (FK_OK);
+}
+
 static int reserve_host_table(fk_ctx *ctx, int64_t bytes)
 { if (ctx->h_table_cap >= bytes)
     return (FK_OK);
   if (ctx->h_table != NULL)
-    hipHostFree(ctx->h_table);
+    fkx_pinned_free(ctx->h_table);
   ctx->h_table = NULL;
   ctx->h_table_cap = 0;
   const int64_t want = bytes + bytes / 32 + 4096;
-  if (hipHostMalloc((void **) &ctx->h_table, (size_t) want, hipHostMallocDefault) != hipSuccess)
+  if (fkx_pinned_alloc((void **) &ctx->h_table, want) != FK_OK)
     { ctx->h_table = NULL;
       fk_set_error(ctx, "out of host memory: cannot pin %lld bytes for the result table", (long long) want);
       return (FK_ENOMEM);
@@ -312,7 +374,7 @@ extern "C" void fk_destroy(fk_ctx *ctx)
     if (ctx->slot_ptr[i] != NULL)
       hipFree(ctx->slot_ptr[i]);
   for (int i = 0; i < 2; i++)
-    { if (ctx->h_stage[i]) hipHostFree(ctx->h_stage[i]);
+    { if (ctx->h_stage[i]) fkx_pinned_free(ctx->h_stage[i]);
       if (ctx->stage_ev[i]) hipEventDestroy(ctx->stage_ev[i]);
     }
   if (ctx->ev0) hipEventDestroy(ctx->ev0);
@@ -329,9 +391,9 @@ extern "C" void fk_destroy(fk_ctx *ctx)
   free(ctx->slabs);
   for (int i = 0; i < ctx->nspill; i++)
     if (ctx->spill_buf[i].ptr != NULL)
-      hipHostFree(ctx->spill_buf[i].ptr);
+      fkx_pinned_free(ctx->spill_buf[i].ptr);
   free(ctx->spill_buf);
-  if (ctx->h_table) hipHostFree(ctx->h_table);
+  if (ctx->h_table) fkx_pinned_free(ctx->h_table);
   free(ctx->acc_res);
   free(ctx->h_roff);
   if (ctx->push_lock)
@@ -779,7 +841,7 @@ static int spill_acquire(fk_ctx *ctx, int64_t bytes, int *slot)
   if (best < 0)
     { for (int i = 0; i < ctx->nspill && best < 0; i++)      // an idle one that is too small: replace it
         if (!ctx->spill_buf[i].in_use)
-          { hipHostFree(ctx->spill_buf[i].ptr);
+          { fkx_pinned_free(ctx->spill_buf[i].ptr);
             ctx->spill_buf[i].ptr = NULL;
             ctx->spill_buf[i].cap = 0;
             best = i;
@@ -795,7 +857,7 @@ static int spill_acquire(fk_ctx *ctx, int64_t bytes, int *slot)
           ctx->spill_buf[best].cap = 0;
         }
       const int64_t want = bytes + bytes / 16 + 4096;
-      if (hipHostMalloc(&ctx->spill_buf[best].ptr, (size_t) want, hipHostMallocDefault) != hipSuccess)
+      if (fkx_pinned_alloc(&ctx->spill_buf[best].ptr, want) != FK_OK)
         { ctx->spill_buf[best].ptr = NULL;
           return (FK_ENOMEM);
         }
@@ -1048,14 +1110,13 @@ extern "C" int fk_push_block(fk_ctx *ctx, const char *bases, const int32_t *boff
         { for (int i = 0; i < 2; i++)
             { if (ctx->h_stage[i])
                 { hipEventSynchronize(ctx->stage_ev[i]);
-                  hipHostFree(ctx->h_stage[i]);
+                  fkx_pinned_free(ctx->h_stage[i]);
                   ctx->h_stage[i] = NULL;
                 }
             }
           ctx->stage_cap = std::max<int64_t>(len, 4ll << 20);
           for (int i = 0; i < 2; i++)
-            if (hipHostMalloc((void **) &ctx->h_stage[i], (size_t) ctx->stage_cap,
-                              hipHostMallocDefault) != hipSuccess)
+            if (fkx_pinned_alloc((void **) &ctx->h_stage[i], ctx->stage_cap) != FK_OK)
               { fk_set_error(ctx, "fk_push_block: cannot allocate pinned staging");
                 rc = FK_ENOMEM;
               }
@@ -1260,7 +1321,7 @@ extern "C" int fk_push_fasta(fk_ctx *ctx, const char *raw, int64_t nbytes, int l
 
 extern "C" int fk_host_alloc(int64_t nbytes, void **ptr)
 { if (ptr == NULL || nbytes <= 0) return (FK_EINVAL);
-  if (hipHostMalloc(ptr, (size_t) nbytes, hipHostMallocDefault) != hipSuccess)
+  if (fkx_pinned_alloc(ptr, nbytes) != FK_OK)
     { fk_set_error(NULL, "fk_host_alloc: cannot pin %lld bytes", (long long) nbytes);
       return (FK_ENOMEM);
     }
@@ -1268,7 +1329,7 @@ extern "C" int fk_host_alloc(int64_t nbytes, void **ptr)
 }
 
 extern "C" int fk_host_free(void *ptr)
-{ return (hipHostFree(ptr) == hipSuccess ? FK_OK : FK_EHIP); }
+{ return (fkx_pinned_free(ptr)); }
 
 // ---- whole path: split -> sort -> expand -> sort -> count ----------------------------------------
 #define FK_GROUP_PASSES 4      // hashed digit passes that group super-mers
@@ -1277,6 +1338,12 @@ extern "C" int fk_host_free(void *ptr)
 // FK_PREFIX_BYTES 64 = disabled: sort every key byte.  A shorter prefix (fk_count_presorted_kmers) does not pay on
 // read data: one-substitution error k-mers share long prefixes with their true k-mer, so about half
 // of all prefix runs are heterogeneous and would need a local sort (measured).
+
+static double fk_wall(void)
+{ struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ((double) ts.tv_sec + 1e-9 * (double) ts.tv_nsec);
+}
 
 static double ms_between(hipEvent_t a, hipEvent_t b)
 { float ms = 0.f;
@@ -1918,20 +1985,35 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
             rc = count_bucket(ctx, sm_in, ns, res, true, &table, &ntab, h_roff, &tm);
         }
       else
-        { for (int b = 0; b < nbk && rc == FK_OK; b++)
+        { const bool tim = (getenv("FK_FINISH_TIMING") != NULL);
+          double t_g = 0., t_c = 0., t_s = 0.;
+          for (int b = 0; b < nbk && rc == FK_OK; b++)
             { void *p = (char *) sm_in + bo[b] * w.smer_stride;
+              const double w0 = tim ? fk_wall() : 0.;
               if (chunked && bc[b] > 0)
                 rc = gather(b, &p);
+              if (tim) { hipStreamSynchronize(s); t_g += fk_wall() - w0; }
+              const double w1 = tim ? fk_wall() : 0.;
               if (rc == FK_OK)
                 rc = count_bucket(ctx, p, bc[b], res, false, NULL, &ntab, NULL, &tm, ns_max);
+              if (tim) t_c += fk_wall() - w1;
             }
+          const double w2 = tim ? fk_wall() : 0.;
           if (rc == FK_OK && ntab > 0 && (rc = sort_union_table(ctx, ntab, res, &table, &tm)) != FK_OK)
             break;
+          if (tim)
+            { t_s = fk_wall() - w2;
+              fprintf(stderr, "  finish timing: gather %.3f s, count %.3f s, table sort %.3f s\n", t_g, t_c, t_s);
+            }
         }
       if (rc != FK_OK)
         break;
-      if ((rc = fetch_result_table(ctx, res, table, ntab, fetch_table)) != FK_OK)
-        break;
+      { const double w3 = fk_wall();
+        if ((rc = fetch_result_table(ctx, res, table, ntab, fetch_table)) != FK_OK)
+          break;
+        if (getenv("FK_FINISH_TIMING") != NULL)
+          fprintf(stderr, "  finish timing: table fetch %.3f s\n", fk_wall() - w3);
+      }
       // fk_make_profiles looks k-mers up in this table: it has to hold every k-mer of resident reads
       ctx->have_table = (d_smers_in == NULL && ctx->prm.table_cutoff == 1);
       ctx->have_part_table = (ctx->prm.table_cutoff == 1);
@@ -1971,8 +2053,11 @@ extern "C" int fk_finish(fk_ctx *ctx, fk_result *res)
   if (ctx->nchunks > 0)
     { // chunked ingest: the rest of the reads becomes the last chunk, then the buckets are counted
       pthread_mutex_lock((pthread_mutex_t *) ctx->push_lock);
+      const double w0 = fk_wall();
       int rc = flush_chunk(ctx);
       pthread_mutex_unlock((pthread_mutex_t *) ctx->push_lock);
+      if (getenv("FK_FINISH_TIMING") != NULL)
+        fprintf(stderr, "  finish timing: last flush %.3f s\n", fk_wall() - w0);
       if (rc == FK_OK)
         rc = fkx_pipeline(ctx, NULL, 0, NULL, 0, res, true);
       for (int i = 0; i < ctx->nchunks; i++)

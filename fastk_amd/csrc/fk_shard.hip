@@ -452,7 +452,7 @@ extern "C" int fk_shard_write(fk_shard *sh, const fk_result *res, int nparts, co
         break;
       const int64_t hbytes = std::max<int64_t>(nin, 1) * w.kmer_word;
       uint8_t *host = NULL;
-      if (hipHostMalloc((void **) &host, (size_t) hbytes, hipHostMallocDefault) != hipSuccess)
+      if (fkx_pinned_alloc((void **) &host, hbytes) != FK_OK)
         { fk_set_error(ctx, "out of host memory: cannot pin %lld bytes for this rank's table range", (long long) hbytes);
           rc = FK_ENOMEM;
           break;
@@ -461,18 +461,18 @@ extern "C" int fk_shard_write(fk_shard *sh, const fk_result *res, int nparts, co
       if (w.kmer_word != w.kmer_stride && nin > 0)
         { void *other = (sorted == (void *) a) ? (void *) b : (void *) a;
           if ((rc = fkx_repack_table(ctx, sorted, nin, other)) != FK_OK)
-            { hipHostFree(host); break; }
+            { fkx_pinned_free(host); break; }
           src = other;
         }
       if (nin > 0
           && (hipMemcpyAsync(host, src, (size_t) (nin * w.kmer_word), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess
               || hipStreamSynchronize(ctx->stream) != hipSuccess))
-        { hipHostFree(host); rc = FK_EHIP; break; }
+        { fkx_pinned_free(host); rc = FK_EHIP; break; }
       int64_t npre = 1;
       for (int i = 0; i < ib; i++) npre *= 256;
       std::vector<int64_t> pc((size_t) npre, 0);
       rc = fk_write_ktab_range(host, nin, ctx->prm.kmer, ib, split.data(), me * m, m, dir, root, pc.data());
-      hipHostFree(host);
+      fkx_pinned_free(host);
       if (rc != FK_OK) break;
       // per-prefix entry counts of all ranks -> rank 0 writes the stub
       int64_t *d_pc = NULL;
