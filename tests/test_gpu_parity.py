@@ -978,6 +978,25 @@ def test_planned_bucketed_split_matches_exact_counts():
         lo += c
 
 
+def test_planned_split_reports_a_region_that_is_too_small():
+    """The streamed emit (eight interleaved cursors per bucket, ragged ends closed afterwards) must notice a
+    region that cannot hold its bucket -- FK_ESTATE, the caller then takes the exact two-call path -- and must
+    not write outside the buffer while doing so (the next call on the same context still gives exact results)."""
+    case, bases, boff = util.load_case("synth_hifi_k40_t4_T8")
+    with fastk_amd.Context(kmer=40, nbuckets=6) as ctx:
+        w = ctx.w
+        rd = ctx.alloc(len(bases) + 64).upload(bases)
+        ns, ni, counts = ctx.split(rd.ptr, len(bases))
+        cap, offs = ctx.split_plan(rd.ptr, len(bases))
+        tight = [0]
+        for c in counts:                       # half of what each bucket needs
+            tight.append(tight[-1] + max(c // 2, 1))
+        buf = ctx.alloc(cap * w.smer_stride)
+        assert ctx.split_planned(rd.ptr, len(bases), buf.ptr, tight[-1], tight) is None
+        got = ctx.split_planned(rd.ptr, len(bases), buf.ptr, cap, offs)
+        assert got is not None and got[0] == counts and got[1] == ni
+
+
 # ------------------------------------------------------------------------------ exact part files
 
 @pytest.mark.parametrize("name", util.golden_names())
