@@ -774,7 +774,7 @@ int main(int argc, char *argv[])
   if (NGPUS > 1 && RANK < 0)
     return (launch_ranks(argc0,argv0));
 
-  double t_start = now(), t_ingest, t_count, t_write;
+  double t_start = now(), t_create = 0., t_created = 0., t_ingest, t_count, t_write;
 
   fk_default_params(&prm);
   prm.kmer = KMER; prm.table_cutoff = PROFILE ? 1 : DO_TABLE;   /* -p looks every k-mer up */
@@ -824,8 +824,10 @@ int main(int argc, char *argv[])
       if (prm.nbuckets > 256)
         prm.nbuckets = NGPUS*(256/NGPUS);
     }
+  t_create = now();
   if (fk_create(&prm,&ctx) != FK_OK)
     die(NULL,"fk_create");
+  t_created = now();
   if (RANK >= 0 && NGPUS > 1)
     { char id[128];
       share_unique_id(id);
@@ -1012,5 +1014,8 @@ int main(int argc, char *argv[])
             t_ingest-t_start,t_count-t_ingest,t_write-t_count);
   fk_destroy(ctx);
   free(feed.bases); free(feed.boff); free(res); free(root); free(dir);
+  if (VERBOSE)
+    fprintf(stderr,"  Wall s: fk_create %.3f (began %.3f after start)  clean-up %.3f  (process start to here %.3f)\n",
+            t_created-t_create,t_create-t_start,now()-t_write,now()-t_start);
   exit (0);
 }
