@@ -89,7 +89,7 @@ __global__ __launch_bounds__(EX_THREADS) void k_ex_expand(const u32 *__restrict_
 { constexpr int RS = RW + (DD ? 1 : 0);             // dwords per input record
   __shared__ __attribute__((aligned(16))) u32 recs[(EX_TILE + 1) * RS];   // big-endian value words (+1 guard)
   __shared__ u32 lh[512];                // dig != NULL: histograms of hash digits 0 and 1 of the k-mers
-  __shared__ u32 hoff[EX_TILE + 1];      // first k-mer of head h inside the tile
+  __shared__ uint16_t hoff[EX_TILE + 2]; // first k-mer of head h inside the tile (a tile holds < 2^16 k-mers: 1024 x (k - 6))
   __shared__ uint16_t hrec[EX_TILE];     // record index of head h
   __shared__ uint16_t hct[EX_TILE];      // its clipped multiplicity
   __shared__ u32 tmp[8];
@@ -98,6 +98,10 @@ __global__ __launch_bounds__(EX_THREADS) void k_ex_expand(const u32 *__restrict_
   // stream is written as whole dwords: a byte store per k-mer made every 32-byte sector of the stream
   // go to memory EX_G times (WRITE_SIZE 1.43 x the algorithmic W * 13 bytes, profiles/r02_a)
   __shared__ __attribute__((aligned(16))) u32 sdig[EX_THREADS / 64][(64 * EX_G) / 4 + 2];
+  // the records of one step of a wave, staged so that they are written as whole lines (records of up to 12 bytes:
+  // wider ones would not leave room for two workgroups per CU)
+  constexpr bool STAGE = (OW <= 3);
+  __shared__ u32 sout[STAGE ? EX_THREADS / 64 : 1][STAGE ? 64 * EX_G * OW : 1];
 
   if (dig != NULL)
     { lh[threadIdx.x] = 0;
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(EX_THREADS) void k_ex_expand(const u32 *__restrict_
         { s_runk = runk + totk; s_runh = runh + toth; }
 
       if (head)
-        { hoff[runh + exh] = runk + exk;
+        { hoff[runh + exh] = (uint16_t) (runk + exk);
           hrec[runh + exh] = (uint16_t) l;
         }
     }
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(EX_THREADS) void k_ex_expand(const u32 *__restrict_
   const u32 nh    = s_runh;
   const u32 ktile = s_runk;
   if (threadIdx.x == 0)
-    hoff[nh] = ktile;                             // sentinel: end of the last head's k-mers
+    hoff[nh] = (uint16_t) ktile;                  // sentinel: end of the last head's k-mers
   __syncthreads();
   const int padb  = 32 * KN - 2 * kmer;           // unused low bits of the last k-mer word
   const u32 lastm = (padb == 0) ? 0xffffffffu : ~((1u << padb) - 1u);
@@ -205,7 +209,7 @@ __global__ __launch_bounds__(EX_THREADS) void k_ex_expand(const u32 *__restrict_
       u32 lo = 0, hi = nh;
       while (hi - lo > 1)
         { const u32 mid = (lo + hi) >> 1;
-          if (hoff[mid] <= j0) lo = mid; else hi = mid;
+          if ((u32) hoff[mid] <= j0) lo = mid; else hi = mid;
         }
       u32        o   = j0 - hoff[lo];
       u32        nxt = hoff[lo + 1];
@@ -268,9 +272,32 @@ __global__ __launch_bounds__(EX_THREADS) void k_ex_expand(const u32 *__restrict_
               dgs |= (u64) (hb & 0xffu) << (8 * g);
             }
           x.w[OW - 1] |= ct << 16;                     // uint16 weight in the record's last two bytes
-          *(ex_out<OW> *) (gout + (u64) j * OW) = x;
+          if (STAGE)
+            {
+#pragma unroll
+              for (int q = 0; q < OW; q++)
+                sout[wv][lane * (EX_G * OW) + g * OW + q] = x.w[q];
+            }
+          else
+            *(ex_out<OW> *) (gout + (u64) j * OW) = x;
         }
       }
+      if (STAGE)
+        { // the wave's 64 * EX_G records leave as whole lines: lane l stores dwords l, l + 64, ... of the wave's
+          // stretch.  (A 12-byte store per record and lane, 72 bytes apart, is 64 separate write requests per
+          // instruction: the kernel ran 281 us per launch at 1/10 of configs[2] and 197 us with the same bytes sent
+          // to coalesced addresses.)
+          __builtin_amdgcn_wave_barrier();             // (LDS operations of a wave execute in order)
+          const u32 nvd = ((ktile - jw < 64u * EX_G) ? (ktile - jw) : 64u * EX_G) * OW;
+          u32 *gw = gout + (u64) jw * OW;
+#pragma unroll
+          for (int t = 0; t < EX_G * OW; t++)
+            { const u32 idx = (u32) t * 64u + lane;
+              if (idx < nvd)
+                gw[idx] = sout[wv][idx];
+            }
+          __builtin_amdgcn_wave_barrier();
+        }
       if (dig != NULL)
         { // the wave's digits: bytes jw .. jw + nv - 1 of the tile's stretch of the stream
           static_assert(EX_G == 6, "three 16-bit stores per thread");
