@@ -122,6 +122,32 @@ __device__ __forceinline__ void sp_pack16(const uint4 v, u32 &word, u32 &bad)
   bad  = bd;
 }
 
+// A 20-byte super-mer record (k = 37 .. 40) in one piece: six packed words in (independent LDS reads), five words
+// out, stored as dwordx4 + dword.  Five separate dword stores per lane, each lane at an unrelated address, are five
+// write requests per record: the replay passes spent a quarter of their time on them.  Other record widths take the
+// generic loop.
+struct __attribute__((packed, aligned(4))) sp_rec5 { u32 w[5]; };
+__device__ __forceinline__ void sp_put_record5(const u32 *arr, int st, int L, u32 lenbits, int lenw, u32 *dst)
+{ const int wi = st >> 4;
+  const u32 sh = 32u - 2u * (u32) (st & 15);                  // 2 .. 32
+  u32 w[6];
+#pragma unroll
+  for (int q = 0; q < 6; q++)
+    w[q] = arr[wi + q];                                       // wi + 5 < SP_WORDS for every start inside a tile
+  sp_rec5 r;
+#pragma unroll
+  for (int q = 0; q < 5; q++)
+    { u32 x = (u32) (((((u64) w[q]) << 32) | (u64) w[q + 1]) >> sh);
+      int r2 = 2 * (L - 16 * q);                              // bits of this word that hold bases
+      r2 = r2 < 0 ? 0 : (r2 > 32 ? 32 : r2);
+      x &= ~(u32) ((0xffffffffffffffffull >> r2) >> 32);
+      if (q == lenw)
+        x |= lenbits;
+      r.w[q] = __builtin_bswap32(x);
+    }
+  *(sp_rec5 *) dst = r;
+}
+
 // rank << 15 of a 7-mer: canonical = the smaller of the forward code and its reverse complement, rank =
 // fk_mrank14(canonical).  Both arguments may carry garbage above bit 13.  (Which strand the canonical form
 // is on only matters for the one minimizer a super-mer ends up with: step 7 looks it up again.)
@@ -455,6 +481,9 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
           u32 *dst = a.out + slot * sww;
           if (POS)
             a.pos[slot] = ((u64) (t0 + i) << 1) | flip;
+          if (sww == 5)
+            sp_put_record5(arr, st, L, ((u32) (n - 1)) << lensh, lenw, dst);
+          else
           for (int q = 0; q < sww; q++)
             { u32 x = 0;
               const int rem = L - 16 * q;
@@ -631,6 +660,9 @@ __global__ __launch_bounds__(SP_THREADS) void k_split_replay(SplitArgs a)
       const u32 *arr = flip ? rcw : fwd;
       const int  st  = flip ? (R - (i + L)) : i;
       u32 *dst = a.out + slot * sww;
+      if (sww == 5)
+        sp_put_record5(arr, st, L, ((u32) (n - 1)) << lensh, lenw, dst);
+      else
       for (int q = 0; q < sww; q++)
         { u32 x = 0;
           const int rem = L - 16 * q;
