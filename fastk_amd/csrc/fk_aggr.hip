@@ -31,6 +31,10 @@
 #define AG_T(k) do { } while (0)
 #endif
 
+// a record as one memory operation: three dword loads / stores per lane at a 12-byte stride are three requests per
+// record where one (dwordx3) does (a quarter of the replay passes' time was this)
+template <int N> struct __attribute__((packed, aligned(4))) ag_rec { u32 w[N]; };
+
 template <int KW> struct AgCfg
 { static constexpr int SLOTS = (KW <= 3) ? 8192 : 4096;
   // fill limit: once it is passed every thread may still claim AG_BATCH slots (it looks at the overflow flag once
@@ -261,9 +265,10 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
                 for (int u = 0; u < U; u++)
                   { const int64_t i = base + u * 64 + lane;
                     const int64_t j = (i < end) ? i : beg;
+                    const ag_rec<KW> rr = *(const ag_rec<KW> *) (recs + j * KW);
 #pragma unroll
                     for (int w = 0; w < KW; w++)
-                      rec[u][w] = recs[j * KW + w];
+                      rec[u][w] = rr.w[w];
                   }
               }
           }
@@ -280,9 +285,10 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
                     for (int u = 0; u < U; u++)
                       { const int64_t i = nbase + u * 64 + lane;
                         const int64_t j = (i < end) ? i : beg;
+                        const ag_rec<KW> rr = *(const ag_rec<KW> *) (recs + j * KW);
 #pragma unroll
                         for (int w = 0; w < KW; w++)
-                          nrec[u][w] = recs[j * KW + w];
+                          nrec[u][w] = rr.w[w];
                       }
                   }
               }
@@ -590,18 +596,20 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
                             kd[3] = b.x; kd[4] = b.y; kd[5] = b.z; kd[6] = b.w;
                           }
                         if (DEDUP)
-                          {
+                          { ag_rec<KW + 1> ro;
 #pragma unroll
                             for (int w = 0; w < KW; w++)
-                              table[o * (KW + 1) + w] = kd[w];
-                            table[o * (KW + 1) + KW] = c[j];
+                              ro.w[w] = kd[w];
+                            ro.w[KW] = c[j];
+                            *(ag_rec<KW + 1> *) (table + o * (KW + 1)) = ro;
                           }
                         else
-                          {
+                          { ag_rec<KW> ro;
 #pragma unroll
                             for (int w = 0; w < KW - 1; w++)
-                              table[o * KW + w] = kd[w];
-                            table[o * KW + KW - 1] = kd[KW - 1] | (c[j] << 16);
+                              ro.w[w] = kd[w];
+                            ro.w[KW - 1] = kd[KW - 1] | (c[j] << 16);
+                            *(ag_rec<KW> *) (table + o * KW) = ro;
                           }
                         o += 1;
                       }

@@ -60,9 +60,11 @@ __global__ __launch_bounds__(RX_THREADS) void k_hash_hist(const u32 *__restrict_
   for (int64_t i = (int64_t) blockIdx.x * RX_THREADS + threadIdx.x; i < n;
        i += (int64_t) gridDim.x * RX_THREADS)
     { u32 r[RW];
+      { const rx_rec<RW> rr = *(const rx_rec<RW> *) (src + i * RW);      // one load per record, not RW
 #pragma unroll
-      for (int w = 0; w < RW; w++)
-        r[w] = src[i * RW + w];
+        for (int w = 0; w < RW; w++)
+          r[w] = rr.w[w];
+      }
       for (int b = 0; b < nbytes; b++)
         atomicAdd(&h[b * 256 + rx_hash_digit<RW>(r, b, hbytes)], 1u);
       if (dig != NULL)
@@ -87,9 +89,11 @@ __global__ __launch_bounds__(RX_THREADS) void k_digit_hist(const u32 *__restrict
   for (int64_t i = (int64_t) blockIdx.x * RX_THREADS + threadIdx.x; i < n;
        i += (int64_t) gridDim.x * RX_THREADS)
     { u32 r[RW];
+      { const rx_rec<RW> rr = *(const rx_rec<RW> *) (src + i * RW);
 #pragma unroll
-      for (int w = 0; w < RW; w++)
-        r[w] = src[i * RW + w];
+        for (int w = 0; w < RW; w++)
+          r[w] = rr.w[w];
+      }
 #pragma unroll
       for (int w = 0; w < RW; w++)
 #pragma unroll
