@@ -12,7 +12,7 @@
 #include "fk_common.h"
 
 #define EX_THREADS 256
-#define EX_ITEMS   4
+#define EX_ITEMS   2
 #define EX_TILE    (EX_THREADS * EX_ITEMS)
 #define EX_G       6                     // consecutive output k-mers per thread
 
