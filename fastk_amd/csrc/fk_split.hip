@@ -35,7 +35,7 @@
 #define SP_KIDX(i) ((i) + ((i) >> 4))
 #define SP_LB      10                      // log2 of the records per chunk of a stream (see SplitArgs.lstreams)
 #define SP_LSTREAMS 3                      // 8 streams per bucket
-#define SP_PL      1024                    // super-mer starts the position list of a tile takes at a time
+#define SP_PL      512                     // super-mer starts the position list of a tile takes at a time
 #define SP_RCH     16                      // tiles per chunk of the replay offsets (in-chunk prefixes fit 16 bits)     // one pad word per 16 keys: thread t's chunk starts at bank 17t
 
 struct SplitArgs
@@ -163,7 +163,6 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
   __shared__ u32      rcw[SP_WORDS];
   __shared__ uint16_t inv16[SP_WORDS];
   __shared__ __attribute__((aligned(16))) u32 keys[SP_KEYS + SP_KEYS / 16 + 1];   // prefix minima (step 2), then the window minima by position
-  __shared__ uint16_t pos16[SP_PL];                      // positions of the tile's super-mer starts
   __shared__ __attribute__((aligned(8))) u32 aux32[1024];     // bbase / bcnt2 / lastkey
   __shared__ uint16_t sbits[SP_THREADS + 16];            // boundary bits: start | invalid
   __shared__ uint16_t vbits[SP_THREADS];
@@ -176,6 +175,8 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
   u64 *bbase   = (u64 *) aux32;           // [256]
   u32 *bcnt2   = aux32 + 512;             // [256]
   u32 *lastkey = aux32 + 768;             // [SP_THREADS]
+  uint16_t *pos16 = (uint16_t *) (aux32 + 768);   // [SP_PL] positions of the tile's super-mer starts: over lastkey,
+                                                  // which is dead once the start masks are made (step 5)
   const int     tid = threadIdx.x;
   const int     K   = a.kmer;
   const int     W   = K - 6;                       // 7-mer starts per k-mer = longest super-mer
