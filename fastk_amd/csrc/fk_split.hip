@@ -163,20 +163,23 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
   __shared__ u32      rcw[SP_WORDS];
   __shared__ uint16_t inv16[SP_WORDS];
   __shared__ __attribute__((aligned(16))) u32 keys[SP_KEYS + SP_KEYS / 16 + 1];   // prefix minima (step 2), then the window minima by position
-  __shared__ __attribute__((aligned(8))) u32 aux32[1024];     // bbase / bcnt2 / lastkey
+  __shared__ u32      lastkey[SP_THREADS];                // last window minimum of every thread (step 5); then pos16
   __shared__ uint16_t sbits[SP_THREADS + 16];            // boundary bits: start | invalid
-  __shared__ uint16_t vbits[SP_THREADS];
-  __shared__ u32      bcnt[256];
+  __shared__ uint8_t  vlast[SP_THREADS];                 // is the thread's last k-mer start valid? (step 5 of the next thread)
+  // per bucket: stream position of the tile's records (u64), records counted (u32), records placed (u32) -- sized
+  // by the launch for the context's bucket count: with the 4 KB that 256 buckets take a CU holds six workgroups,
+  // with the 768 bytes of 48 buckets seven
+  extern __shared__ __attribute__((aligned(8))) unsigned char sp_dyn[];
   __shared__ u32      tmp32[8];
   __shared__ u32      nother, nother2;
   __shared__ u64      ebase;
   const bool rec = (a.ent != NULL);
 
-  u64 *bbase   = (u64 *) aux32;           // [256]
-  u32 *bcnt2   = aux32 + 512;             // [256]
-  u32 *lastkey = aux32 + 768;             // [SP_THREADS]
-  uint16_t *pos16 = (uint16_t *) (aux32 + 768);   // [SP_PL] positions of the tile's super-mer starts: over lastkey,
-                                                  // which is dead once the start masks are made (step 5)
+  u64 *bbase   = (u64 *) sp_dyn;                    // [nbuckets]
+  u32 *bcnt    = (u32 *) (bbase + a.nbuckets);      // [nbuckets]
+  u32 *bcnt2   = bcnt + a.nbuckets;                 // [nbuckets]
+  uint16_t *pos16 = (uint16_t *) lastkey;           // [SP_PL] positions of the tile's super-mer starts: over lastkey,
+                                                    // which is dead once the start masks are made (step 5)
   const int     tid = threadIdx.x;
   const int     K   = a.kmer;
   const int     W   = K - 6;                       // 7-mer starts per k-mer = longest super-mer
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
   const bool    one = (a.nbuckets == 1);           // single bucket: no per-record LDS atomics
   const u32     strm = (u32) (a.tile0 + blockIdx.x) & ((1u << a.lstreams) - 1u);   // round robin: equal tile counts
 
-  bcnt[tid] = 0;
+  if (tid < a.nbuckets) bcnt[tid] = 0;
   if (tid == 0) { nother = 0; nother2 = 0; }
 
   // ---- 1. ASCII -> 2-bit codes (MSB first) + invalid masks -------------------------------
@@ -327,8 +330,8 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
         vmask |= (((M >> c) & km) == 0u ? 1u : 0u) << c;
     }
   lastkey[tid] = mk[SP_CH - 1];
-  bcnt2[tid]   = 0;
-  vbits[tid]   = (uint16_t) vmask;
+  if (tid < a.nbuckets) bcnt2[tid] = 0;
+  vlast[tid]   = (uint8_t) ((vmask >> (SP_CH - 1)) & 1u);
   if (tid < 16)
     sbits[SP_THREADS + tid] = 0xffffu;      // past the tile everything is a boundary
   __syncthreads();
@@ -336,7 +339,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
   // ---- 5. super-mer starts: valid and (first of tile | previous invalid | new minimizer) ---
   u32 smask;
   { u32 pk = (tid > 0) ? lastkey[tid - 1] : 0xffffffffu;
-    const u32 pv = (tid > 0) ? (((u32) vbits[tid - 1] >> (SP_CH - 1)) & 1u) : 0u;
+    const u32 pv = (tid > 0) ? (u32) vlast[tid - 1] : 0u;
     u32 kc = 0;
 #pragma unroll
     for (int c = 0; c < SP_CH; c++)
@@ -770,7 +773,7 @@ static void sp_launch(SplitArgs a, int64_t ngrid, hipStream_t s)
 { for (int64_t t = 0; t < ngrid; t += SP_MAXGRID)
     { a.tile0 = t;
       const int64_t nb = (ngrid - t < SP_MAXGRID) ? (ngrid - t) : SP_MAXGRID;
-      hipLaunchKernelGGL((k_split<EMIT, POS>), dim3((unsigned) nb), dim3(SP_THREADS), 0, s, a);
+      hipLaunchKernelGGL((k_split<EMIT, POS>), dim3((unsigned) nb), dim3(SP_THREADS), (size_t) a.nbuckets * 16, s, a);
     }
 }
 
