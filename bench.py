@@ -532,7 +532,7 @@ def main():
     # (records per launch) is the profiled one.
     traffic = None
     traffic_src = None
-    for name in ("r02_g_configs%d_pmc_traffic.json" % cfg_id, "r02_f_configs%d_pmc_traffic.json" % cfg_id):
+    for name in ("r02_h_configs%d_pmc_traffic.json" % cfg_id, "r02_g_configs%d_pmc_traffic.json" % cfg_id):
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", name)))
             per_launch = n_rec / (nl_k / passes_k)
