@@ -16,14 +16,10 @@
 #define AG_THREADS 1024
 #define AG_WAVES   (AG_THREADS / 64)
 #define AG_HB      4096                 // LDS-private histogram bins
-#define AG_LOCK    0x80000000u          // count word: 0 empty, AG_LOCK key being written, else count
-#define AG_HIGH    (1u << 29)           // a count that reaches this is cut back by AG_CUT, the
+#define AG_HIGH    (1u << 29)           // a carried count that reaches this is cut back by AG_CUT, the
 #define AG_CUT     (1u << 28)           //   removed instances go straight to max_inst
 #define AG_MAXR    64
 #define AG_BINS    65536
-#define AG_UNROLL  8                    // records per thread in a full table fill (the bin merging rule aims at 1024 x 8)
-#define AG_BATCH   1                    // records per lane in a batch a wave takes at a time (1 or 2)
-#define AG_P       4                    // slots one probe looks at (ag_read_slots is written for 4)
 #define AG_NSCAL   16                   // scalars behind the histogram (8 results + 8 phase timers of ablation builds)
 #ifdef FK_ABLATION
 #define AG_T(k) do { if (tid == 0) { const u64 now_ = __builtin_readcyclecounter(); ph[k] += now_ - tlast; tlast = now_; } } while (0)
@@ -36,12 +32,9 @@
 template <int N> struct __attribute__((packed, aligned(4))) ag_rec { u32 w[N]; };
 
 template <int KW> struct AgCfg
-{ static constexpr int SLOTS = (KW <= 3) ? 8192 : 4096;
-  // fill limit: once it is passed every thread may still claim AG_BATCH slots (it looks at the overflow flag once
-  // per batch), and the table must never fill up
-  static constexpr int LIMIT = (SLOTS * 3 / 4 < SLOTS - AG_THREADS * AG_BATCH - 64) ? SLOTS * 3 / 4
-                                                                                    : SLOTS - AG_THREADS * AG_BATCH - 64;
-  static constexpr size_t LDS = (size_t) SLOTS * (KW > 3 ? 32 : 16) + AG_HB * 4;
+{ static constexpr int CAP = (KW <= 3) ? 8192 : 4096;   // records one fill takes = cells of the counting sort
+  static constexpr int NS  = CAP / AG_THREADS;          // records a thread holds in registers during a fill
+  static constexpr size_t LDS = (size_t) CAP * 4 * (KW + 1) + AG_HB * 4 + 256;
 };
 
 // position of the first record of every bin: bounds[b] = lower bound of (hash16 >= b), bounds[65536] = n
@@ -64,98 +57,6 @@ __global__ __launch_bounds__(256) void k_ag_bounds(const u32 *__restrict__ recs,
       else hi = mid;
     }
   bounds[b] = (u64) lo;
-}
-
-// AG_P table slots starting at `slot` as AG_P single ds_read_b128: a slot's key and count word must
-// come from ONE LDS access (see k_ag_count); plain C++ loads of a uint4 may be split by the compiler
-// into a 96-bit and a 32-bit read, which lets a reader pair a stale key with a published count.
-template <int SLOTS>
-__device__ __forceinline__ void ag_read_slots(u32 base, u32 slot, uint4 (&v)[4])
-{  const u32 a0 = base + ((slot + 0) & (SLOTS - 1)) * 16u, a1 = base + ((slot + 1) & (SLOTS - 1)) * 16u;
-  const u32 a2 = base + ((slot + 2) & (SLOTS - 1)) * 16u, a3 = base + ((slot + 3) & (SLOTS - 1)) * 16u;
-  asm volatile("ds_read_b128 %0, %4\n\t"
-               "ds_read_b128 %1, %5\n\t"
-               "ds_read_b128 %2, %6\n\t"
-               "ds_read_b128 %3, %7\n\t"
-               "s_waitcnt lgkmcnt(0)"
-               : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
-               : "v"(a0), "v"(a1), "v"(a2), "v"(a3)
-               : "memory");
-}
-
-// One slot (key + count word) with a single ds_write_b128 (see ag_read_slots).
-__device__ __forceinline__ void ag_write_slot(u32 addr, uint4 v)
-{ typedef unsigned int ag_u32x4 __attribute__((ext_vector_type(4)));
-  const ag_u32x4 x = { v.x, v.y, v.z, v.w };
-  asm volatile("ds_write_b128 %0, %1" : : "v"(addr), "v"(x) : "memory");
-}
-
-// The same AG_P reads plus one dword (the workgroup's overflow flag) in the same batch, so that the
-// flag costs no LDS round trip of its own in front of every probe.
-template <int SLOTS>
-__device__ __forceinline__ void ag_read_slots_flag(u32 base, u32 slot, uint4 (&v)[4], u32 flag_addr, u32 &flag)
-{  const u32 a0 = base + ((slot + 0) & (SLOTS - 1)) * 16u, a1 = base + ((slot + 1) & (SLOTS - 1)) * 16u;
-  const u32 a2 = base + ((slot + 2) & (SLOTS - 1)) * 16u, a3 = base + ((slot + 3) & (SLOTS - 1)) * 16u;
-  asm volatile("ds_read_b32 %4, %9\n\t"
-               "ds_read_b128 %0, %5\n\t"
-               "ds_read_b128 %1, %6\n\t"
-               "ds_read_b128 %2, %7\n\t"
-               "ds_read_b128 %3, %8\n\t"
-               "s_waitcnt lgkmcnt(0)"
-               : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(flag)
-               : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(flag_addr)
-               : "memory");
-}
-
-// The first look of two records: 2 x AG_P slots and the overflow flag in one batch of reads.
-template <int SLOTS>
-__device__ __forceinline__ void ag_read_slots2_flag(u32 base, u32 slota, u32 slotb, uint4 (&va)[4], uint4 (&vb)[4],
-                                                    u32 flag_addr, u32 &flag)
-{ const u32 a0 = base + ((slota + 0) & (SLOTS - 1)) * 16u, a1 = base + ((slota + 1) & (SLOTS - 1)) * 16u;
-  const u32 a2 = base + ((slota + 2) & (SLOTS - 1)) * 16u, a3 = base + ((slota + 3) & (SLOTS - 1)) * 16u;
-  const u32 b0 = base + ((slotb + 0) & (SLOTS - 1)) * 16u, b1 = base + ((slotb + 1) & (SLOTS - 1)) * 16u;
-  const u32 b2 = base + ((slotb + 2) & (SLOTS - 1)) * 16u, b3 = base + ((slotb + 3) & (SLOTS - 1)) * 16u;
-  asm volatile("ds_read_b32 %8, %17\n\t"
-               "ds_read_b128 %0, %9\n\t"
-               "ds_read_b128 %1, %10\n\t"
-               "ds_read_b128 %2, %11\n\t"
-               "ds_read_b128 %3, %12\n\t"
-               "ds_read_b128 %4, %13\n\t"
-               "ds_read_b128 %5, %14\n\t"
-               "ds_read_b128 %6, %15\n\t"
-               "ds_read_b128 %7, %16\n\t"
-               "s_waitcnt lgkmcnt(0)"
-               : "=&v"(va[0]), "=&v"(va[1]), "=&v"(va[2]), "=&v"(va[3]), "=&v"(vb[0]), "=&v"(vb[1]), "=&v"(vb[2]), "=&v"(vb[3]),
-                 "=&v"(flag)
-               : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b0), "v"(b1), "v"(b2), "v"(b3), "v"(flag_addr)
-               : "memory");
-}
-
-// The first of the AG_P slots just read that settles a probe: empty (kind 1), being written (2) or
-// holding this key's first three dwords (3); act = AG_P, kind 0 when none does.  Written without
-// control flow: a slot settles iff min(count word, key difference, count word ^ AG_LOCK) == 0, and
-// the kind follows from the count word of the chosen slot alone (neither empty nor locked => the
-// key matched).  The straightforward nested conditionals compile to ~45 exec-mask instructions per
-// slot here; this form is ~7 VALU per slot.
-template <int KW>
-__device__ __forceinline__ void ag_classify(const uint4 (&v)[AG_P], const u32 *cur, int &act, u32 &kind,
-                                            u32 &cact)
-{ u32 a = AG_P, c = 0;
-#pragma unroll
-  for (int j = AG_P - 1; j >= 0; j--)
-    { u32 e = v[j].x ^ cur[0];
-      if (KW > 1) e |= v[j].y ^ cur[KW > 1 ? 1 : 0];
-      if (KW > 2) e |= v[j].z ^ cur[KW > 2 ? 2 : 0];
-      const u32  t = min(min(v[j].w, e), v[j].w ^ AG_LOCK);
-      const bool h = (t == 0u);
-      a = h ? (u32) j : a;
-      c = h ? v[j].w : c;
-    }
-  u32 k = 3u;
-  k = (c == AG_LOCK) ? 2u : k;
-  k = (c == 0u) ? 1u : k;
-  k = (a == (u32) AG_P) ? 0u : k;
-  act = (int) a; kind = k; cact = c;
 }
 
 // exclusive scan over the 1024 threads of the block.  tmp: AG_WAVES u32 of LDS.
@@ -182,15 +83,65 @@ __device__ __forceinline__ u32 ag_block_exscan(u32 v, u32 *tmp, u32 *total)
   return (base + x - v);
 }
 
+// In-place exclusive scan of cell[0 .. NS * 1024): thread t owns cells NS*t .. NS*t + NS - 1.  Returns the total.
+// The caller puts a barrier behind it before anybody reads a cell.  tmp: AG_WAVES u32 of LDS.
+template <int NS>
+__device__ __forceinline__ u32 ag_scan_cells(u32 *cell, u32 *tmp)
+{ const u32 lane = fk_lane();
+  const u32 wave = threadIdx.x >> 6;
+  uint4 *c4 = (uint4 *) cell + threadIdx.x * (NS / 4);
+  u32 c[NS];
+#pragma unroll
+  for (int i = 0; i < NS / 4; i++)
+    { const uint4 q = c4[i];
+      c[4 * i] = q.x; c[4 * i + 1] = q.y; c[4 * i + 2] = q.z; c[4 * i + 3] = q.w;
+    }
+  u32 s = 0;
+#pragma unroll
+  for (int i = 0; i < NS; i++)
+    { const u32 t = c[i];
+      c[i] = s;
+      s += t;
+    }
+  u32 x = s;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1)
+    { u32 y = __shfl_up(x, o, 64);
+      if ((int) lane >= o) x += y;
+    }
+  if (lane == 63) tmp[wave] = x;
+  __syncthreads();
+  // the 16 wave totals scanned by every group of 16 lanes
+  u32 y = tmp[lane & (AG_WAVES - 1)];
+#pragma unroll
+  for (int o = 1; o < AG_WAVES; o <<= 1)
+    { u32 z = __shfl_up(y, o, AG_WAVES);
+      if ((int) (lane & (AG_WAVES - 1)) >= o) y += z;
+    }
+  const u32 total = __shfl(y, AG_WAVES - 1, 64);
+  const u32 prev  = __shfl(y, (int) ((wave + AG_WAVES - 1) & (AG_WAVES - 1)), 64);
+  const u32 base  = ((wave == 0) ? 0u : prev) + x - s;
+#pragma unroll
+  for (int i = 0; i < NS / 4; i++)
+    c4[i] = make_uint4(c[4 * i] + base, c[4 * i + 1] + base, c[4 * i + 2] + base, c[4 * i + 3] + base);
+  return (total);
+}
+
 // scal: [0] max_inst  [1] distinct k-mers  [2] table entries  [3] failure flag  [4] bin ticket
 //       [5] extra rounds taken  [6] table buffer too small (tcap records)
 //
-// LDS table: SLOTS entries of 16 bytes {key dword 0, 1, 2, count word}; records of 4 or 5 dwords keep
-// dwords 3, 4 in a second array.  A lane's aligned 16-byte LDS access is served in one piece, so a
-// single ds_read_b128 yields a consistent (key, count word) pair: count word 0 = empty, AG_LOCK =
-// slot claimed with ds_cmpst, key not there yet (its creator then stores key + weight with ONE b128
-// write, after the key's tail for wide records; LDS operations of a wave execute in order),
-// anything else = published count.
+// One persistent workgroup per CU takes hash bins in turn.  A bin (<= CAP records, all copies of a k-mer among
+// them) is summed by a COUNTING SORT IN LDS on 13 further hash bits followed by a leader search -- no hash-table
+// protocol (compare-and-swap claims, locked slots, retries of lanes that lost a race):
+//   A   every thread holds NS records in registers; cell = hash & (CAP - 1); rank = atomic counter of the cell
+//   S   exclusive scan of the CAP cell counters in place
+//   B   position p = scanned counter + rank; key -> K[.][p], weight -> cell[p] (the counters are dead by then)
+//   C   a record with rank > 0 compares itself with the records in front of it in its cell (1.3 on average): the
+//       first equal one is the k-mer's LEADER and takes the weight (one LDS add), the record's own count becomes 0
+//   H   position p with a count != 0 is a distinct k-mer: histogram, max_inst, table candidate
+// A bin of more than CAP records is taken in chunks: the leaders found so far stay in the fill as records that
+// carry their count (heavy k-mers of any multiplicity cost LDS space once); if the distinct k-mers alone pass
+// `limit` the bin is taken in 2, 4, ... selections by further hash bits, each re-reading the bin.
 // DEDUP: the records are super-mers (whole record = key, weight 1); every distinct record comes out
 // once, followed by a dword with its multiplicity (records of KW + 1 dwords), nothing else is computed.
 template <int KW, bool DEDUP>
@@ -198,31 +149,26 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
                                                          const u64 *__restrict__ bounds, int kbytes,
                                                          int cutoff, u64 *__restrict__ hist_g,
                                                          u64 *__restrict__ scal, u32 *__restrict__ table,
-                                                         int LIMIT, int variant, int gshift, u32 sat, u64 tcap)
-{ constexpr int SLOTS = AgCfg<KW>::SLOTS;
-  constexpr int U = AG_BATCH;
+                                                         int cap_eff, int limit, int variant, int gshift, u32 sat, u64 tcap)
+{ constexpr int CAP = AgCfg<KW>::CAP;
+  constexpr int NS  = AgCfg<KW>::NS;
   extern __shared__ uint4 ag_lds[];
-  uint4 *A     = ag_lds;                                   // [SLOTS]
-  // LDS byte address of the table for the inline-asm reads (low half of the flat address)
-  const u32 lds_base = (u32) (uintptr_t) ag_lds;
-  uint4 *B     = ag_lds + SLOTS;                           // [SLOTS] when KW > 3
-  u32   *lhist = (u32 *) (ag_lds + (KW > 3 ? 2 : 1) * SLOTS);   // [AG_HB]
-  __shared__ u32 sh_claimed, sh_ovf, sh_next, sh_tmp[AG_WAVES];
-  const u32 ovf_addr = (u32) (uintptr_t) &sh_ovf;
-  __shared__ u64 sh_base;
+  u32 *cell   = (u32 *) ag_lds;                            // [CAP] counters -> offsets -> counts by position
+  u32 *K      = cell + CAP;                                // [KW][CAP] keys by position
+  u32 *lhist  = K + KW * CAP;                              // [AG_HB]
+  u32 *sh_tmp = lhist + AG_HB;                             // [AG_WAVES]
+  u64 *sh_base = (u64 *) (sh_tmp + AG_WAVES);
   const int tid = threadIdx.x;
 
-  for (int i = tid; i < SLOTS; i += AG_THREADS)
-    A[i] = make_uint4(0, 0, 0, 0);
+  for (int i = tid; i < CAP; i += AG_THREADS)
+    cell[i] = 0;
   for (int i = tid; i < AG_HB; i += AG_THREADS)
     lhist[i] = 0;
-  if (tid == 0) { sh_claimed = 0; sh_ovf = 0; sh_next = 0; }
   u64 my_max = 0;
   u32 my_distinct = 0, my_rounds = 0;
   u32 R0 = 1;
 #ifdef FK_ABLATION
   u64 ph[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tlast = __builtin_readcyclecounter();
-  u32 n_first = 0, n_loop = 0;          // wave-level: first looks (pairs), iterations of the general loop
 #endif
   u32 kmask[KW];                                // key bytes of each record dword (pad and weight off)
 #pragma unroll
@@ -230,16 +176,25 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
     kmask[w] = (4 * w + 4 <= kbytes) ? 0xffffffffu : (4 * w < kbytes) ? ((1u << (8 * (kbytes - 4 * w))) - 1u) : 0u;
   __syncthreads();
 
+  // records fetched ahead for the first chunk of the next bin (or selection) while this one is swept
+  u32     key[NS][KW], wgt[NS];          // a new record sits in key[] as loaded until step A takes its weight off
+  int64_t raw_beg = -1;
+
   // groups of 2^gshift neighbouring bins (one bin when the input is large) are dealt round-robin:
   // hashing makes them equally heavy
-  for (u32 bin = blockIdx.x; bin < (AG_BINS >> gshift); bin += gridDim.x)
+  const u32 nbins = (u32) (AG_BINS >> gshift);
+  for (u32 bin = blockIdx.x; bin < nbins; bin += gridDim.x)
     { const int64_t beg = (int64_t) bounds[bin << gshift], end = (int64_t) bounds[(bin + 1) << gshift];
       if (beg >= end)
         continue;
-      AG_T(0);
+      int64_t nx_beg = -1, nx_end = -1;         // the bin this workgroup takes next
+      if (bin + gridDim.x < nbins)
+        { nx_beg = (int64_t) bounds[(bin + gridDim.x) << gshift];
+          nx_end = (int64_t) bounds[(bin + gridDim.x + 1) << gshift];
+        }
 
       // A bin is taken in R0 selections (records whose next hash bits equal r0); R0 is what the
-      // previous bin of this workgroup needed (all bins are alike), so that a table that is too
+      // previous bin of this workgroup needed (all bins are alike), so that a fill that is too
       // small for whole bins is not found out again bin after bin.  A selection that still does
       // not fit is halved on the spot (depth-first), exactly once.
       bool bin_ovf = false, failed = false;
@@ -247,270 +202,181 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
       for (u32 r0 = 0; r0 < R0 && !failed; r0++)
       { u32 R = R0, r = r0;
       for (;;)
-        { // ---- insert every record of the bin that this round selects
-          u64 round_max = 0;
-          // The waves take batches of 64 x U records from a counter in LDS instead of fixed shares: the time a
-          // batch takes varies (probe chains, lost races), and with fixed shares the workgroup waited at the barrier
-          // below for its slowest wave 44 % of the time.  The next batch is loaded while this one is inserted.
-          const u32 lane = fk_lane();
-          u32 rec[U][KW], nrec[U][KW];
-          int64_t base, nbase;
-          { u32 g = 0;
-            if (lane == 0) g = atomicAdd(&sh_next, 1u);
-            g = (u32) __builtin_amdgcn_readfirstlane((int) g);
-            base = beg + (int64_t) g * (64 * U);
-            if (base < end)
-              {
+        { u64     round_max = 0;
+          int64_t pos = beg;
+          u32     carried = 0, vmask = 0, ntot = 0;
+          bool    ovf = false;
+          u32     v[NS];
+          for (;;)
+            { // ---- fill the register slots: slot j of thread tid is "lane position" j * 1024 + tid
+              u32 isnew = 0;
+              if (carried == 0)
+                { const int64_t room = end - pos;
+                  const u32 nnew = (room < (int64_t) cap_eff) ? (u32) room : (u32) cap_eff;
+                  if (raw_beg != pos)
+                    {
 #pragma unroll
-                for (int u = 0; u < U; u++)
-                  { const int64_t i = base + u * 64 + lane;
-                    const int64_t j = (i < end) ? i : beg;
-                    const ag_rec<KW> rr = *(const ag_rec<KW> *) (recs + j * KW);
+                      for (int j = 0; j < NS; j++)
+                        { const u32 L = (u32) (j * AG_THREADS + tid);
+                          if (L < nnew)
+                            { const ag_rec<KW> rr = *(const ag_rec<KW> *) (recs + (pos + L) * KW);
 #pragma unroll
-                    for (int w = 0; w < KW; w++)
-                      rec[u][w] = rr.w[w];
-                  }
-              }
-          }
-          while (base < end)
-            { if (*(volatile u32 *) &sh_ovf)
-                break;
-              { u32 g = 0;
-                if (lane == 0) g = atomicAdd(&sh_next, 1u);
-                g = (u32) __builtin_amdgcn_readfirstlane((int) g);
-                nbase = beg + (int64_t) g * (64 * U);
-                if (nbase < end)
-                  {
+                              for (int w = 0; w < KW; w++)
+                                key[j][w] = rr.w[w];
+                            }
+                        }
+                    }
 #pragma unroll
-                    for (int u = 0; u < U; u++)
-                      { const int64_t i = nbase + u * 64 + lane;
-                        const int64_t j = (i < end) ? i : beg;
-                        const ag_rec<KW> rr = *(const ag_rec<KW> *) (recs + j * KW);
+                  for (int j = 0; j < NS; j++)
+                    if ((u32) (j * AG_THREADS + tid) < nnew)
+                      isnew |= (1u << j);
+                  pos += nnew;
+                }
+              else
+                { // the leaders carried over keep their slots; the free slots take the next records of the bin
+                  u32 fr = 0;
+#pragma unroll
+                  for (int j = 0; j < NS; j++)
+                    if ((u32) (j * AG_THREADS + tid) < (u32) cap_eff && !((vmask >> j) & 1u))
+                      fr |= (1u << j);
+                  u32 totfree;
+                  u32 k = ag_block_exscan((u32) __popc(fr), sh_tmp, &totfree);
+                  const int64_t room = end - pos;
+                  const u32 nnew = (room < (int64_t) totfree) ? (u32) room : totfree;
+#pragma unroll
+                  for (int j = 0; j < NS; j++)
+                    if ((fr >> j) & 1u)
+                      { if (k < nnew)
+                          { const ag_rec<KW> rr = *(const ag_rec<KW> *) (recs + (pos + k) * KW);
+#pragma unroll
+                            for (int w = 0; w < KW; w++)
+                              key[j][w] = rr.w[w];
+                            isnew |= (1u << j);
+                          }
+                        k += 1;
+                      }
+                  pos += nnew;
+                }
+              raw_beg = -1;
+              AG_T(0);
+
+              // ---- A: cell and rank of every record of the fill
+              u32 sub[NS], rank[NS];
+#pragma unroll
+              for (int j = 0; j < NS; j++)
+                { if ((isnew >> j) & 1u)
+                    { wgt[j] = DEDUP ? 1u : (key[j][KW - 1] >> 16);
+#pragma unroll
+                      for (int w = 0; w < KW; w++)
+                        key[j][w] &= kmask[w];
+                    }
+                  sub[j] = 0; rank[j] = 0;
+                  if (((isnew | vmask) >> j) & 1u)
+                    { u32 ha, hb;
+                      fk_rec_hash<KW>(key[j], kbytes, ha, hb);
+                      if (((isnew >> j) & 1u) && ((hb >> 16) & (R - 1)) != r)
+                        continue;                              // not in this selection
+                      vmask |= (1u << j);
+                      sub[j]  = ha & (CAP - 1);
+                      rank[j] = atomicAdd(&cell[sub[j]], 1u);
+                    }
+                }
+              __syncthreads();
+              AG_T(1);
+              ntot = ag_scan_cells<NS>(cell, sh_tmp);
+              __syncthreads();
+              AG_T(2);
+
+              // ---- B: positions; then keys and weights to their positions (the counters become the counts)
+              u32 p[NS], off[NS];
+#pragma unroll
+              for (int j = 0; j < NS; j++)
+                { off[j] = 0;
+                  if ((vmask >> j) & 1u)
+                    off[j] = cell[sub[j]];
+                  p[j] = off[j] + rank[j];
+                }
+              __syncthreads();
+#pragma unroll
+              for (int j = 0; j < NS; j++)
+                { if ((vmask >> j) & 1u)
+                    {
+#pragma unroll
+                      for (int w = 0; w < KW; w++)
+                        K[w * CAP + p[j]] = key[j][w];
+                      cell[p[j]] = wgt[j];
+                    }
+                  const u32 L = (u32) (j * AG_THREADS + tid);
+                  if (L >= ntot)
+                    cell[L] = 0;
+                }
+              __syncthreads();
+              AG_T(3);
+
+              // ---- C: a record that is not the first of its cell looks for its k-mer in front of it
+#pragma unroll
+              for (int j = 0; j < NS; j++)
+                if (((vmask >> j) & 1u) && rank[j] != 0)
+                  { u32 q = off[j];
+                    bool found = false;
+                    while (q < p[j])
+                      { u32 e = 0;
 #pragma unroll
                         for (int w = 0; w < KW; w++)
-                          nrec[u][w] = rr.w[w];
+                          e |= K[w * CAP + q] ^ key[j][w];
+                        if (e == 0) { found = true; break; }
+                        q += 1;
+                      }
+                    if (found)
+                      { atomicAdd(&cell[q], wgt[j]);
+                        cell[p[j]] = 0;
                       }
                   }
-              }
-              u32 slot0[U];
-              u32 pend = 0;
-#pragma unroll
-              for (int u = 0; u < U; u++)
-                { const int64_t i = base + u * 64 + lane;
-                  u32 ha, hb;
-                  fk_rec_hash<KW>(rec[u], kbytes, ha, hb);
-                  slot0[u] = ha & (SLOTS - 1);
-                  if (i < end && ((hb >> 16) & (R - 1)) == r)
-                    pend |= (1u << u);
-                }
-              const bool skip_insert = (variant & 1) != 0;
-              if (skip_insert)
-                { round_max += pend + slot0[0];
-                  pend = 0;
-                }
-#ifdef FK_ABLATION
-              if (tid == 0 && slot0[0] != 0xffffffffu) AG_T(1);
-#endif
+              __syncthreads();
+              AG_T(4);
 
-              // First look for the two records of the batch TOGETHER: the reads of both probes in one LDS round
-              // trip, then both claims in flight at once (a wave's LDS operations complete in order, so when the
-              // two records of a lane want the same empty slot the second claim sees the first one's lock and
-              // goes to the general loop).  Four waves per SIMD cannot hide three dependent LDS round trips per
-              // record; two records per lane halve them.  A probe looks at AG_P consecutive slots at once;
-              // straight-line for the whole wave (nested divergent branches cost more scalar instructions here
-              // than the probes cost vector ones): most records hit their k-mer or claim an empty slot right away.
-              u32  cu_[U][KW], wg_[U], sl_[U], sx[U], kind[U];
-              bool dn_[U], todo[U], bmiss[U], created[U];
+              // ---- harvest: counts by position; the cells are left zero for the next fill
 #pragma unroll
-              for (int u = 0; u < U; u++)
-                {
-#pragma unroll
-                  for (int w = 0; w < KW; w++)
-                    cu_[u][w] = rec[u][w] & kmask[w];
-                  wg_[u]  = DEDUP ? 1u : (rec[u][KW - 1] >> 16);
-                  sl_[u] = slot0[u];
-                }
-#ifdef FK_ABLATION
-              if (fk_lane() == 0) n_first += 1;
-#endif
-              { // a thread claims <= U slots per look at the overflow flag (it arrives with the slots: one LDS
-                // round trip), which LIMIT leaves room for
-                uint4 v0[U][AG_P];
-                u32   ovf_now;
-                if (U == 2)
-                  ag_read_slots2_flag<SLOTS>(lds_base, sl_[0], sl_[U - 1], v0[0], v0[U - 1], ovf_addr, ovf_now);
-                else
-                  ag_read_slots_flag<SLOTS>(lds_base, sl_[0], v0[0], ovf_addr, ovf_now);
-                bool hit[U];
-#pragma unroll
-                for (int u = 0; u < U; u++)
-                  { int act;
-                    u32 cact;
-                    ag_classify<KW>(v0[u], cu_[u], act, kind[u], cact);
-                    sx[u]   = (sl_[u] + (u32) act) & (SLOTS - 1);
-                    todo[u] = ((pend >> u) & 1u) && ovf_now == 0;
-                    dn_[u] = !todo[u];
-                    hit[u]  = todo[u] && kind[u] == 3u && cact < (AG_HIGH >> 1);
-                    bmiss[u] = false;
-                    created[u] = false;
-                  }
-                if (KW > 3)
-                  {
-#pragma unroll
-                    for (int u = 0; u < U; u++)
-                      if (hit[u])
-                        { const uint4 b = B[sx[u]];
-                          bool same = (b.x == cu_[u][KW > 3 ? 3 : 0]);
-                          if (KW > 4) same = same && (b.y == cu_[u][KW > 4 ? 4 : 0]);
-                          if (KW > 5) same = same && (b.z == cu_[u][KW > 5 ? 5 : 0]);
-                          if (KW > 6) same = same && (b.w == cu_[u][KW > 6 ? 6 : 0]);
-                          bmiss[u] = !same;
-                          hit[u] = same;
-                        }
-                  }
-#pragma unroll
-                for (int u = 0; u < U; u++)
-                  if (hit[u])
-                    { atomicAdd(&A[sx[u]].w, wg_[u]);
-                      dn_[u] = true;
-                    }
-                u32 got[U];
-#pragma unroll
-                for (int u = 0; u < U; u++)
-                  { got[u] = 1u;
-                    if (todo[u] && kind[u] == 1u)
-                      got[u] = atomicCAS(&A[sx[u]].w, 0u, AG_LOCK);
-                  }
-#pragma unroll
-                for (int u = 0; u < U; u++)
-                  if (got[u] == 0u)
-                    { // key and weight appear together: the (wider) key's tail first, then ONE 16-byte write of
-                      // key + count word -- LDS serves a wave's operations in order and an aligned 16-byte
-                      // access in one piece, so no reader can pair this count with another key
-                      if (KW > 3)
-                        { B[sx[u]] = make_uint4(cu_[u][KW > 3 ? 3 : 0], KW > 4 ? cu_[u][KW > 4 ? 4 : 0] : 0u,
-                                                KW > 5 ? cu_[u][KW > 5 ? 5 : 0] : 0u, KW > 6 ? cu_[u][KW > 6 ? 6 : 0] : 0u);
-                          asm volatile("" ::: "memory");
-                        }
-                      ag_write_slot(lds_base + sx[u] * 16u, make_uint4(cu_[u][0], KW > 1 ? cu_[u][KW > 1 ? 1 : 0] : 0u,
-                                                                        KW > 2 ? cu_[u][KW > 2 ? 2 : 0] : 0u, wg_[u]));
-                      created[u] = true;
-                      dn_[u] = true;
-                    }
-                u32 kcl = 0;
-                u64 cany = 0;
-#pragma unroll
-                for (int u = 0; u < U; u++)
-                  { const u64 cm = __ballot(created[u]);
-                    kcl  += (u32) __popcll(cm);
-                    cany |= cm;
-                  }
-                if (cany != 0ull && fk_lane() == (u32) (__ffsll((long long) cany) - 1))
-                  { if (atomicAdd(&sh_claimed, kcl) + kcl > (u32) LIMIT)
-                      sh_ovf = 1;
-                  }
-                // whoever is left (lost a race, met a slot being written, no hit in AG_P slots,
-                // wide keys, very large counts) goes through the general loop below
-#pragma unroll
-                for (int u = 0; u < U; u++)
-                  if (!dn_[u])
-                    sl_[u] = (kind[u] == 1u || kind[u] == 2u) ? sx[u] : (kind[u] == 0u) ? ((sl_[u] + AG_P) & (SLOTS - 1))
-                            : bmiss[u] ? ((sx[u] + 1) & (SLOTS - 1)) : sl_[u];
-              }
-#pragma unroll
-              for (int u = 0; u < U; u++)
-                { bool done = dn_[u];
-                  u32  slot = sl_[u];
-                  u32 (&cur)[KW] = cu_[u];
-                  const u32 wgt = wg_[u];
-                  while (!done)
-                    {
-#ifdef FK_ABLATION
-                      if (fk_lane() == (u32) (__ffsll((long long) __ballot(1)) - 1)) n_loop += 1;
-#endif
-                      uint4 v[AG_P];
-                      ag_read_slots<SLOTS>(lds_base, slot, v);
-                      // first slot that is empty (1), being written (2) or holds this k-mer (3)
-                      int act;
-                      u32 kind, cact;
-                      ag_classify<KW>(v, cur, act, kind, cact);
-                      const u32 s = (slot + (u32) act) & (SLOTS - 1);
-                      if (KW <= 3 && kind == 3u && cact < (AG_HIGH >> 1))
-                        { atomicAdd(&A[s].w, wgt);                   // the common case: no return value needed
-                          done = true;
-                        }
-                      else
-                        { bool created = false;
-                          if (kind == 3u)
-                            { bool same = true;
-                              if (KW > 3)
-                                { const uint4 b = B[s];
-                                  same = (b.x == cur[KW > 3 ? 3 : 0]);
-                                  if (KW > 4) same = same && (b.y == cur[KW > 4 ? 4 : 0]);
-                                  if (KW > 5) same = same && (b.z == cur[KW > 5 ? 5 : 0]);
-                                  if (KW > 6) same = same && (b.w == cur[KW > 6 ? 6 : 0]);
-                                }
-                              if (!same)
-                                slot = (s + 1) & (SLOTS - 1);
-                              else
-                                { const u32 old = atomicAdd(&A[s].w, wgt);
-                                  if (old < AG_HIGH && old + wgt >= AG_HIGH)
-                                    { atomicSub(&A[s].w, AG_CUT);    // stays far above 0x7fff: still saturated
-                                      round_max += AG_CUT;
-                                    }
-                                  done = true;
-                                }
-                            }
-                          else if (kind == 1u)
-                            { if (atomicCAS(&A[s].w, 0u, AG_LOCK) == 0u)
-                                { // key and weight appear together: the (wider) key's tail first, then ONE 16-byte write of
-                                  // key + count word -- LDS serves a wave's operations in order and an aligned 16-byte
-                                  // access in one piece, so no reader can pair this count with another key
-                                  if (KW > 3)
-                                    { B[s] = make_uint4(cur[KW > 3 ? 3 : 0], KW > 4 ? cur[KW > 4 ? 4 : 0] : 0u,
-                                                        KW > 5 ? cur[KW > 5 ? 5 : 0] : 0u, KW > 6 ? cur[KW > 6 ? 6 : 0] : 0u);
-                                      asm volatile("" ::: "memory");
-                                    }
-                                  ag_write_slot(lds_base + s * 16u, make_uint4(cur[0], KW > 1 ? cur[KW > 1 ? 1 : 0] : 0u,
-                                                                               KW > 2 ? cur[KW > 2 ? 2 : 0] : 0u, wgt));
-                                  created = true;
-                                  done = true;
-                                }
-                              else
-                                slot = s;                            // taken in between: look at it again
-                            }
-                          else if (kind == 2u)
-                            slot = s;                                // its key is being written: look again
-                          else
-                            slot = (slot + AG_P) & (SLOTS - 1);
-                          const u64 cm = __ballot(created);
-                          if (cm != 0ull && fk_lane() == (u32) (__ffsll((long long) cm) - 1))
-                            { const u32 k = (u32) __popcll(cm);
-                              if (atomicAdd(&sh_claimed, k) + k > (u32) LIMIT)
-                                sh_ovf = 1;
-                            }
-                        }
+              for (int j = 0; j < NS; j++)
+                { const u32 L = (u32) (j * AG_THREADS + tid);
+                  v[j] = 0;
+                  if (L < ntot)
+                    { v[j] = cell[L];
+                      if (v[j] != 0) cell[L] = 0;
                     }
                 }
-              // the batch loaded meanwhile becomes the current one
-              base = nbase;
+              if (pos >= end)
+                break;
+              // more of the bin to come: the leaders stay, as records that carry their counts
+              u32 nl = 0, D;
 #pragma unroll
-              for (int u = 0; u < U; u++)
+              for (int j = 0; j < NS; j++)
+                nl += (v[j] != 0);
+              ag_block_exscan(nl, sh_tmp, &D);
+              if (D > (u32) limit)
+                { ovf = true;
+                  break;
+                }
+              vmask = 0;
 #pragma unroll
-                for (int w = 0; w < KW; w++)
-                  rec[u][w] = nrec[u][w];
+              for (int j = 0; j < NS; j++)
+                if (v[j] != 0)
+                  { const u32 L = (u32) (j * AG_THREADS + tid);
+                    vmask |= (1u << j);
+#pragma unroll
+                    for (int w = 0; w < KW; w++)
+                      key[j][w] = K[w * CAP + L];
+                    if (v[j] >= AG_HIGH)                       // stays far above 0x7fff: still saturated
+                      { v[j] -= AG_CUT;
+                        round_max += AG_CUT;
+                      }
+                    wgt[j] = v[j];
+                  }
+              carried = D;
+              my_rounds += (tid == 0);
             }
-          AG_T(2);
-          __syncthreads();
-          AG_T(3);
-          const bool ovf = (sh_ovf != 0);
-          const u32  fill = sh_claimed;
-          __syncthreads();
           if (ovf)
-            { // more distinct k-mers than the table takes: halve the selection and start it again
-              for (int i = tid; i < SLOTS; i += AG_THREADS)
-                A[i].w = 0;
-              if (tid == 0) { sh_claimed = 0; sh_ovf = 0; sh_next = 0; }
+            { // more distinct k-mers than the fill takes: halve the selection and start it again
               my_rounds += (tid == 0);
               bin_ovf = true;
               __syncthreads();
@@ -523,39 +389,58 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
               R <<= 1;
               continue;
             }
-          bin_fill = max(bin_fill, fill);
 
-          // ---- emit: histogram, totals, table entries; the table is left empty
+          // ---- what comes next: another selection of this bin, or the workgroup's next bin -- fetch its first
+          // chunk now, the sweep below needs no registers of the fill
+          { u32 Rn = R, rn = r;
+            while (Rn > R0 && rn >= (Rn >> 1))
+              { rn -= (Rn >> 1);
+                Rn >>= 1;
+              }
+            const bool last = (Rn == R0) && (r0 + 1 >= R0);
+            const int64_t fb = last ? nx_beg : beg, fe = last ? nx_end : end;
+            if (fb >= 0 && fb < fe)
+              { const int64_t room = fe - fb;
+                const u32 nnew = (room < (int64_t) cap_eff) ? (u32) room : (u32) cap_eff;
+#pragma unroll
+                for (int j = 0; j < NS; j++)
+                  { const u32 L = (u32) (j * AG_THREADS + tid);
+                    if (L < nnew)
+                      { const ag_rec<KW> rr = *(const ag_rec<KW> *) (recs + (fb + L) * KW);
+#pragma unroll
+                        for (int w = 0; w < KW; w++)
+                          key[j][w] = rr.w[w];
+                      }
+                  }
+                raw_beg = fb;
+              }
+          }
+
+          // ---- emit: histogram, totals, table entries
           my_max += round_max;
-          // (all count words first: eight independent LDS reads instead of eight round trips; the k-mers seen once
-          // or twice -- four out of five on read sets with sequencing errors -- are counted per wave with a ballot:
-          // one LDS atomic per lane on the same two histogram bins serialised the whole sweep)
-          u32 c[SLOTS / AG_THREADS], vv[SLOTS / AG_THREADS];
-          u32 nq = 0, n1 = 0, n2 = 0;
+          // (the k-mers seen once or twice -- four out of five on read sets with sequencing errors -- are counted
+          // per wave with a ballot: one LDS atomic per lane on the same two histogram bins serialised the sweep)
+          u32 c[NS];
+          u32 nq = 0, n1 = 0, n2 = 0, nlead = 0;
 #pragma unroll
-          for (int j = 0; j < SLOTS / AG_THREADS; j++)
-            vv[j] = A[j * AG_THREADS + tid].w;
-#pragma unroll
-          for (int j = 0; j < SLOTS / AG_THREADS; j++)
-            { const int slot = j * AG_THREADS + tid;
-              const u32 v = vv[j];
+          for (int j = 0; j < NS; j++)
+            { const u32 vv = v[j];
               c[j] = 0;
               if (!DEDUP)
-                { n1 += (u32) __popcll(__ballot(v == 1u));
-                  n2 += (u32) __popcll(__ballot(v == 2u));
+                { n1 += (u32) __popcll(__ballot(vv == 1u));
+                  n2 += (u32) __popcll(__ballot(vv == 2u));
                 }
-              if (v != 0)
-                { A[slot].w = 0;
-                  my_distinct += 1;
-                  u32 cc = v;
+              if (vv != 0)
+                { nlead += 1;
+                  u32 cc = vv;
                   if (DEDUP)
                     { nq += 1;
-                      c[j] = v;
+                      c[j] = vv;
                       continue;
                     }
-                  if (v >= sat)                                // sat = 0x7fff, MSDsort.c:498-506
-                    my_max += v;
-                  if (v >= 0x7fffu)
+                  if (vv >= sat)                               // sat = 0x7fff, MSDsort.c:498-506
+                    my_max += vv;
+                  if (vv >= 0x7fffu)
                     cc = 0x7fffu;
                   if ((variant & 2) || cc <= 2u) ;
                   else if (cc < AG_HB) atomicAdd(&lhist[cc], 1u);
@@ -566,35 +451,36 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
                     }
                 }
             }
+          my_distinct += nlead;
           if (!DEDUP && !(variant & 2) && fk_lane() == 0)
             { if (n1 != 0) atomicAdd(&lhist[1], n1);
               if (n2 != 0) atomicAdd(&lhist[2], n2);
             }
-          AG_T(4);
+          if (R0 > 1)
+            { u32 D;
+              ag_block_exscan(nlead, sh_tmp, &D);
+              bin_fill = max(bin_fill, D);
+            }
           if ((DEDUP || cutoff > 0) && !(variant & 4))
             { u32 tot;
               const u32 off = ag_block_exscan(nq, sh_tmp, &tot);
-              AG_T(5);
               if (tid == 0 && tot > 0)
-                sh_base = atomicAdd(&scal[2], (u64) tot);
+                *sh_base = atomicAdd(&scal[2], (u64) tot);
               __syncthreads();
-              AG_T(6);
-              if (tot > 0 && sh_base + tot > tcap)
+              if (tot > 0 && *sh_base + tot > tcap)
                 { if (tid == 0)                       // the table buffer is full (direct append to a union buffer)
                     atomicAdd(&scal[6], 1ull);
                 }
               else if (tot > 0)
-                { u64 o = sh_base + off;
+                { u64 o = *sh_base + off;
 #pragma unroll
-                  for (int j = 0; j < SLOTS / AG_THREADS; j++)
+                  for (int j = 0; j < NS; j++)
                     if (c[j] != 0)
-                      { const int slot = j * AG_THREADS + tid;
-                        const uint4 a = A[slot];
-                        u32 kd[7] = { a.x, a.y, a.z, 0u, 0u, 0u, 0u };
-                        if (KW > 3)
-                          { const uint4 b = B[slot];
-                            kd[3] = b.x; kd[4] = b.y; kd[5] = b.z; kd[6] = b.w;
-                          }
+                      { const u32 L = (u32) (j * AG_THREADS + tid);
+                        u32 kd[KW];
+#pragma unroll
+                        for (int w = 0; w < KW; w++)
+                          kd[w] = K[w * CAP + L];
                         if (DEDUP)
                           { ag_rec<KW + 1> ro;
 #pragma unroll
@@ -615,9 +501,8 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
                       }
                 }
             }
-          if (tid == 0) { sh_claimed = 0; sh_next = 0; }
           __syncthreads();
-          AG_T(7);
+          AG_T(5);
 
           // ---- next selection below (R0, r0): sibling, or up
           while (R > R0 && r >= (R >> 1))
@@ -631,7 +516,7 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
       }
       if (bin_ovf)
         R0 = min(R0 << 1, (u32) AG_MAXR);
-      else if (R0 > 1 && bin_fill * 9 < (u32) LIMIT * 4)
+      else if (R0 > 1 && bin_fill * 9 < (u32) limit * 4)
         R0 >>= 1;
     }
 
@@ -654,20 +539,18 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
     }
 #ifdef FK_ABLATION
   if (tid == 0)
-    for (int k = 0; k < 6; k++)
+    for (int k = 0; k < 8; k++)
       atomicAdd(&scal[8 + k], ph[k]);
-  if (tid == 0)
-    atomicAdd(&scal[8 + 6], ph[6] + ph[7]);
-  { u64 nl = n_loop, nf = n_first;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-      { nl += __shfl_down(nl, o, 64);
-        nf += __shfl_down(nf, o, 64);
-      }
-    if (fk_lane() == 0)
-      atomicAdd(&scal[8 + 7], (nf << 32) | nl);
-  }
 #endif
+}
+
+// bins merged per fill: 2^gshift, the largest group whose expected size stays within 7/16 of a fill when doubled
+template <int KW>
+static int ag_gshift(int64_t n)
+{ int gshift = 0;
+  while (gshift < 16 && ((n >> (16 - gshift)) << 1) <= AgCfg<KW>::CAP * 7 / 8)
+    gshift += 1;
+  return (gshift);
 }
 
 template <int KW>
@@ -698,20 +581,20 @@ static int aggr_t(fk_ctx *ctx, const void *d_grouped, int64_t n, int cutoff, int
   hipLaunchKernelGGL(k_ag_bounds<KW>, dim3(AG_BINS / 256 + 1), dim3(256), 0, s, (const u32 *) d_grouped, n,
                      ctx->wid.kmer_bytes, d_bounds);
   const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
-  // Neighbouring bins are merged while a table fill stays within one batch of 1024 x 8 records: small inputs
-  // get full batches, and a fill never holds more records than that by choice -- a fill whose distinct k-mers
-  // pass LIMIT is done over in two selections (measured at configs[2], 7,080 records and 4,570 distinct k-mers
-  // per bin: one bin per fill 323 ms per step, two bins per fill -> two selections each 459 ms, one bin in two
-  // selections 402 ms).
-  int gshift = 0;
-  while (ctx->dbg_aggr_limit <= 0 && gshift < 16 && ((n >> (16 - gshift)) << 1) <= AG_THREADS * AG_UNROLL)
-    gshift += 1;
+  // Neighbouring bins are merged while two of them still fit one fill with room to spare: small inputs get full
+  // fills, and a fill is never expected to hold more records than it takes -- a bin beyond CAP costs a second
+  // chunk with the first one's distinct k-mers carried along.
+  int gshift = ag_gshift<KW>(n);
+  if (ctx->dbg_aggr_limit > 0)
+    gshift = 0;
   if (ctx->dbg_aggr_gshift > 0)
     gshift = ctx->dbg_aggr_gshift - 1;
-  const int limit = (ctx->dbg_aggr_limit > 0 && ctx->dbg_aggr_limit < AgCfg<KW>::LIMIT) ? ctx->dbg_aggr_limit
-                                                                                        : AgCfg<KW>::LIMIT;
+  int cap_eff = AgCfg<KW>::CAP;                       // fk_debug_set("aggr_limit"): a fill takes only this many records
+  if (ctx->dbg_aggr_limit > 0 && ctx->dbg_aggr_limit < cap_eff)
+    cap_eff = ctx->dbg_aggr_limit < 4 ? 4 : ctx->dbg_aggr_limit;
+  const int limit = cap_eff * 3 / 4;
   hipLaunchKernelGGL((k_ag_count<KW, false>), dim3((unsigned) cus), dim3(AG_THREADS), lds, s, (const u32 *) d_grouped,
-                     (const u64 *) d_bounds, ctx->wid.kmer_bytes, cutoff, d_hist, d_scal, (u32 *) d_table, limit, ctx->dbg_aggr_variant, gshift,
+                     (const u64 *) d_bounds, ctx->wid.kmer_bytes, cutoff, d_hist, d_scal, (u32 *) d_table, cap_eff, limit, ctx->dbg_aggr_variant, gshift,
                      (u32) (ctx->aggr_sat > 0 ? ctx->aggr_sat : 0x7fff), (u64) cap);
   FK_LAUNCH_CHECK(ctx);
   u64 *h = ctx->h_scratch;                       // pinned, 64 KB + 64 KB: the histogram needs 256 KB
@@ -743,8 +626,7 @@ static int aggr_t(fk_ctx *ctx, const void *d_grouped, int64_t n, int cutoff, int
     { fprintf(stderr, "ag phases (cycles of thread 0, all workgroups) n=%lld:", (long long) n);
       for (int k = 0; k < 8; k++)
         fprintf(stderr, " %llu", (unsigned long long) hh[FK_HIST_BINS + 8 + k]);
-      fprintf(stderr, "  first looks %llu loop iterations %llu\n", (unsigned long long) (hh[FK_HIST_BINS + 15] >> 32),
-              (unsigned long long) (hh[FK_HIST_BINS + 15] & 0xffffffffull));
+      fprintf(stderr, "  (load, A, scan, B, C, harvest+emit)\n");
     }
 #endif
   free(hh);
@@ -801,11 +683,9 @@ static int dedup_t(fk_ctx *ctx, const void *d_grouped, int64_t n, void *d_out, i
   hipLaunchKernelGGL(k_ag_bounds<KW>, dim3(AG_BINS / 256 + 1), dim3(256), 0, s, (const u32 *) d_grouped, n,
                      KW * 4, d_bounds);
   const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
-  int gshift = 0;
-  while (gshift < 16 && (n >> (16 - gshift)) < 6000)         // most of a batch of records per table fill
-    gshift += 1;
+  const int gshift = ag_gshift<KW>(n);
   hipLaunchKernelGGL((k_ag_count<KW, true>), dim3((unsigned) cus), dim3(AG_THREADS), lds, s, (const u32 *) d_grouped,
-                     (const u64 *) d_bounds, KW * 4, 1, d_hist, d_scal, (u32 *) d_out, AgCfg<KW>::LIMIT, 0,
+                     (const u64 *) d_bounds, KW * 4, 1, d_hist, d_scal, (u32 *) d_out, AgCfg<KW>::CAP, AgCfg<KW>::CAP * 3 / 4, 0,
                      gshift, 0x7fffu, (u64) cap);
   FK_LAUNCH_CHECK(ctx);
   FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch + 4100, d_scal, 8 * 8, hipMemcpyDeviceToHost, s));

@@ -96,6 +96,15 @@ LARGE_CASES = [
          synth=dict(seed=20251001, genome_len=20000000, read_len=15000, err_ppm=2000, nreads=66666)),
 ]
 
+# Above 4 GiB (`--huge`, ~15 min of reference time, 10 GB input file): 50x of a 200 Mbp genome in
+# 15 kbp reads -- 10 G bases, every device buffer of the bench's configuration beyond 2^32 bytes.
+# The input is streamed to disk in pieces; the reads are regenerated on the device by
+# fk_synth_reads, so only the digests travel.
+HUGE_CASES = [
+    dict(name="hifi50x200M_k40_t4_T8", kind="huge", k=40, cutoff=4, T=8, fmt="fasta",
+         synth=dict(seed=20251001, genome_len=200000000, read_len=15000, err_ppm=2000, nreads=666666)),
+]
+
 
 def sha(b):
     return hashlib.sha256(b).hexdigest()
@@ -116,6 +125,8 @@ def main():
     if not orc.have_ref():
         orc.build(ref=True)
     cases = LARGE_CASES if "--large" in sys.argv else (CASES + LARGE_CASES if "--all" in sys.argv else CASES)
+    if "--huge" in sys.argv:
+        cases = HUGE_CASES
     for case in cases:
         name = case["name"]
         k = case["k"]
@@ -125,13 +136,28 @@ def main():
             with gzip.GzipFile(os.path.join(HERE, name + ".fa.gz"), "wb", mtime=0) as f:
                 for i, r in enumerate(reads):
                     f.write(b">r%d\n%s\n" % (i, r.encode()))
+        elif case["kind"] == "huge":
+            bases = boff = None
         else:
             s = case["synth"]
             bases, boff = orc.synth_block(s["seed"], s["genome_len"], s["read_len"], s["err_ppm"],
                                           0, s["nreads"])
-        d = tempfile.mkdtemp(prefix="fkgold")
+        d = tempfile.mkdtemp(prefix="fkgold", dir=os.environ.get("FK_GOLDEN_TMP"))
         path = os.path.join(d, "x." + case["fmt"])
-        if case["fmt"] == "fasta":
+        if case["kind"] == "huge":
+            s = case["synth"]
+            with open(path, "wb") as f:
+                for r0 in range(0, s["nreads"], 20000):
+                    nr = min(20000, s["nreads"] - r0)
+                    b, _ = orc.synth_block(s["seed"], s["genome_len"], s["read_len"], s["err_ppm"],
+                                           r0, nr)
+                    L = s["read_len"]
+                    mat = np.empty((nr, 3 + L + 1), dtype=np.uint8)
+                    mat[:, 0:3] = np.frombuffer(b">r\n", dtype=np.uint8)
+                    mat[:, 3:3 + L] = b.reshape(nr, L + 1)[:, :L]
+                    mat[:, 3 + L] = ord("\n")
+                    mat.tofile(f)
+        elif case["fmt"] == "fasta":
             orc.write_fasta(path, bases, boff, width=0 if case["kind"] == "edge" else 100)
         else:
             orc.write_fastq(path, bases, boff)
@@ -152,7 +178,7 @@ def main():
                             for i in range(max(0, t["nels"] - 8), t["nels"])]),
             file_sha256={f: sha_file(os.path.join(d, f)) for f in files},
         )
-        if case["kind"] == "large":
+        if case["kind"] in ("large", "huge"):
             meta = dict(case)
             meta["expected"] = exp
             meta["generated_by"] = "tests/golden/make_golden.py --large with oracle/_ref/FastK (reference build)"
