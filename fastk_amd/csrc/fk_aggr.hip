@@ -15,7 +15,7 @@
 
 #define AG_THREADS 1024
 #define AG_WAVES   (AG_THREADS / 64)
-#define AG_HB      4096                 // LDS-private histogram bins
+#define AG_HB      3072                 // LDS-private histogram bins
 #define AG_HIGH    (1u << 29)           // a carried count that reaches this is cut back by AG_CUT, the
 #define AG_CUT     (1u << 28)           //   removed instances go straight to max_inst
 #define AG_MAXR    64
@@ -34,7 +34,8 @@ template <int N> struct __attribute__((packed, aligned(4))) ag_rec { u32 w[N]; }
 template <int KW> struct AgCfg
 { static constexpr int CAP = (KW <= 3) ? 8192 : 4096;   // records one fill takes = cells of the counting sort
   static constexpr int NS  = CAP / AG_THREADS;          // records a thread holds in registers during a fill
-  static constexpr size_t LDS = (size_t) CAP * 4 * (KW + 1) + AG_HB * 4 + 256;
+  static constexpr int SDW = (KW <= 3) ? 4 : 8;         // dwords of a slot: key, zero padding, count in the last one
+  static constexpr size_t LDS = (size_t) CAP * SDW * 4 + CAP * 2 + AG_HB * 4 + 256;
 };
 
 // position of the first record of every bin: bounds[b] = lower bound of (hash16 >= b), bounds[65536] = n
@@ -59,71 +60,91 @@ __global__ __launch_bounds__(256) void k_ag_bounds(const u32 *__restrict__ recs,
   bounds[b] = (u64) lo;
 }
 
-// exclusive scan over the 1024 threads of the block.  tmp: AG_WAVES u32 of LDS.
-__device__ __forceinline__ u32 ag_block_exscan(u32 v, u32 *tmp, u32 *total)
-{ const u32 lane = fk_lane();
-  const u32 wave = threadIdx.x >> 6;
-  u32 x = v;
+// a value the optimiser cannot see through (keeps it from hoisting address arithmetic out of the bin loop and
+// spilling the results)
+__device__ __forceinline__ u32 ag_opaque(u32 x) { asm volatile("" : "+v"(x)); return (x); }
+
+// Cell of the counting sort (low 13 bits) and 12 further bits for step C2: a hash of the key made of full-rate 24-bit
+// multiplies (fk_rec_hash's 64-bit products are a quarter of the kernel's arithmetic).  It only spreads the k-mers of
+// one bin over the cells -- a poor spread costs time, never correctness -- and is independent of the bin's own bits.
+template <int KW>
+__device__ __forceinline__ u32 ag_cellhash(const u32 (&key)[KW])
+{ u32 h = 0x9E3779B9u;
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1)
-    { u32 y = __shfl_up(x, o, 64);
-      if ((int) lane >= o) x += y;
+  for (int w = 0; w < KW; w++)
+    { const u32 x = key[w] ^ h;
+      h = __umul24(x, 0x5bd1e9u + 0x22a3c4u * (u32) w) + __umul24(x >> 8, 0x3c6ef3u + 0x1b56c2u * (u32) w);
+      h ^= h >> 15;
     }
-  if (lane == 63) tmp[wave] = x;
-  __syncthreads();
-  u32 base = 0, tot = 0;
-#pragma unroll
-  for (int w = 0; w < AG_WAVES; w++)
-    { const u32 t = tmp[w];
-      if ((u32) w < wave) base += t;
-      tot += t;
-    }
-  __syncthreads();
-  *total = tot;
-  return (base + x - v);
+  h = __umul24(h, 0x2f0b4fu) ^ __umul24(h >> 8, 0x68e31du);
+  return (h ^ (h >> 13));
 }
 
-// In-place exclusive scan of cell[0 .. NS * 1024): thread t owns cells NS*t .. NS*t + NS - 1.  Returns the total.
-// The caller puts a barrier behind it before anybody reads a cell.  tmp: AG_WAVES u32 of LDS.
+// inclusive scan over the 64 lanes of a wave with data-parallel-primitive adds (no LDS crossbar round trips):
+// row_shr 1, 2, 4, 8 inside rows of 16 lanes, then lane 15 of rows 0 / 2 into rows 1 / 3, then lane 31 into rows 2, 3
+__device__ __forceinline__ u32 ag_wave_scan(u32 x)
+{ x += (u32) __builtin_amdgcn_update_dpp(0, (int) x, 0x111, 0xf, 0xf, false);
+  x += (u32) __builtin_amdgcn_update_dpp(0, (int) x, 0x112, 0xf, 0xf, false);
+  x += (u32) __builtin_amdgcn_update_dpp(0, (int) x, 0x114, 0xf, 0xf, false);
+  x += (u32) __builtin_amdgcn_update_dpp(0, (int) x, 0x118, 0xf, 0xf, false);
+  x += (u32) __builtin_amdgcn_update_dpp(0, (int) x, 0x142, 0xa, 0xf, false);
+  x += (u32) __builtin_amdgcn_update_dpp(0, (int) x, 0x143, 0xc, 0xf, false);
+  return (x);
+}
+
+// the 16 wave totals in tmp[] -> (sum of the waves in front of this one, sum of all); every row of 16 lanes scans them
+__device__ __forceinline__ u32 ag_wave_bases(const u32 *tmp, u32 *total)
+{ const u32 wave = threadIdx.x >> 6;
+  u32 y = tmp[fk_lane() & (AG_WAVES - 1)];
+  y += (u32) __builtin_amdgcn_update_dpp(0, (int) y, 0x111, 0xf, 0xf, false);
+  y += (u32) __builtin_amdgcn_update_dpp(0, (int) y, 0x112, 0xf, 0xf, false);
+  y += (u32) __builtin_amdgcn_update_dpp(0, (int) y, 0x114, 0xf, 0xf, false);
+  y += (u32) __builtin_amdgcn_update_dpp(0, (int) y, 0x118, 0xf, 0xf, false);
+  *total = (u32) __builtin_amdgcn_readlane((int) y, AG_WAVES - 1);
+  const u32 prev = (u32) __builtin_amdgcn_readlane((int) y, (int) ((wave + AG_WAVES - 1) & (AG_WAVES - 1)));
+  return ((wave == 0) ? 0u : prev);
+}
+
+// exclusive scan over the 1024 threads of the block with ONE barrier.  tmp: AG_WAVES u32 of LDS that nobody has
+// touched since the barrier before last (the callers alternate between two arrays).
+__device__ __forceinline__ u32 ag_block_exscan(u32 v, u32 *tmp, u32 *total)
+{ const u32 x = ag_wave_scan(v);
+  if (fk_lane() == 63) tmp[threadIdx.x >> 6] = x;
+  __syncthreads();
+  return (ag_wave_bases(tmp, total) + x - v);
+}
+
+// In-place exclusive scan of the CAP = NS * 1024 cell counters (16 bits each, two to a dword): thread t owns cells
+// NS*t .. NS*t + NS - 1.  Returns the total.  One barrier inside; the caller puts one behind it before a cell is read.
 template <int NS>
 __device__ __forceinline__ u32 ag_scan_cells(u32 *cell, u32 *tmp)
-{ const u32 lane = fk_lane();
-  const u32 wave = threadIdx.x >> 6;
-  uint4 *c4 = (uint4 *) cell + threadIdx.x * (NS / 4);
-  u32 c[NS];
-#pragma unroll
-  for (int i = 0; i < NS / 4; i++)
-    { const uint4 q = c4[i];
-      c[4 * i] = q.x; c[4 * i + 1] = q.y; c[4 * i + 2] = q.z; c[4 * i + 3] = q.w;
+{ u32 *mine = cell + threadIdx.x * (NS / 2);
+  u32 c[NS / 2];
+  if (NS == 8)
+    { const uint4 q = *(const uint4 *) mine;
+      c[0] = q.x; c[1] = q.y; c[NS / 2 - 2] = q.z; c[NS / 2 - 1] = q.w;
+    }
+  else
+    { const uint2 q = *(const uint2 *) mine;
+      c[0] = q.x; c[1] = q.y;
     }
   u32 s = 0;
 #pragma unroll
-  for (int i = 0; i < NS; i++)
-    { const u32 t = c[i];
-      c[i] = s;
-      s += t;
+  for (int i = 0; i < NS / 2; i++)
+    { const u32 lo = c[i] & 0xffffu, hi = c[i] >> 16;
+      c[i] = s | ((s + lo) << 16);                       // exclusive prefixes of the pair, relative to the thread
+      s += lo + hi;
     }
-  u32 x = s;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1)
-    { u32 y = __shfl_up(x, o, 64);
-      if ((int) lane >= o) x += y;
-    }
-  if (lane == 63) tmp[wave] = x;
+  const u32 x = ag_wave_scan(s);
+  if (fk_lane() == 63) tmp[threadIdx.x >> 6] = x;
   __syncthreads();
-  // the 16 wave totals scanned by every group of 16 lanes
-  u32 y = tmp[lane & (AG_WAVES - 1)];
-#pragma unroll
-  for (int o = 1; o < AG_WAVES; o <<= 1)
-    { u32 z = __shfl_up(y, o, AG_WAVES);
-      if ((int) (lane & (AG_WAVES - 1)) >= o) y += z;
-    }
-  const u32 total = __shfl(y, AG_WAVES - 1, 64);
-  const u32 prev  = __shfl(y, (int) ((wave + AG_WAVES - 1) & (AG_WAVES - 1)), 64);
-  const u32 base  = ((wave == 0) ? 0u : prev) + x - s;
-#pragma unroll
-  for (int i = 0; i < NS / 4; i++)
-    c4[i] = make_uint4(c[4 * i] + base, c[4 * i + 1] + base, c[4 * i + 2] + base, c[4 * i + 3] + base);
+  u32 total;
+  const u32 base = ag_wave_bases(tmp, &total) + x - s;
+  const u32 b2 = base * 0x10001u;                        // offsets stay below 2^16: no carry between the halves
+  if (NS == 8)
+    *(uint4 *) mine = make_uint4(c[0] + b2, c[1] + b2, c[NS / 2 - 2] + b2, c[NS / 2 - 1] + b2);
+  else
+    *(uint2 *) mine = make_uint2(c[0] + b2, c[1] + b2);
   return (total);
 }
 
@@ -132,13 +153,13 @@ __device__ __forceinline__ u32 ag_scan_cells(u32 *cell, u32 *tmp)
 //
 // One persistent workgroup per CU takes hash bins in turn.  A bin (<= CAP records, all copies of a k-mer among
 // them) is summed by a COUNTING SORT IN LDS on 13 further hash bits followed by a leader search -- no hash-table
-// protocol (compare-and-swap claims, locked slots, retries of lanes that lost a race):
+// protocol (compare-and-swap claims, locked slots, retries of the lanes that lost a race):
 //   A   every thread holds NS records in registers; cell = hash & (CAP - 1); rank = atomic counter of the cell
 //   S   exclusive scan of the CAP cell counters in place
-//   B   position p = scanned counter + rank; key -> K[.][p], weight -> cell[p] (the counters are dead by then)
+//   B   position p = scanned counter + rank; slot[p] = (key, weight) with one 16-byte LDS write
 //   C   a record with rank > 0 compares itself with the records in front of it in its cell (1.3 on average): the
 //       first equal one is the k-mer's LEADER and takes the weight (one LDS add), the record's own count becomes 0
-//   H   position p with a count != 0 is a distinct k-mer: histogram, max_inst, table candidate
+//   H   a slot with a count != 0 is a distinct k-mer: histogram, max_inst, table candidate
 // A bin of more than CAP records is taken in chunks: the leaders found so far stay in the fill as records that
 // carry their count (heavy k-mers of any multiplicity cost LDS space once); if the distinct k-mers alone pass
 // `limit` the bin is taken in 2, 4, ... selections by further hash bits, each re-reading the bin.
@@ -152,21 +173,26 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
                                                          int cap_eff, int limit, int variant, int gshift, u32 sat, u64 tcap)
 { constexpr int CAP = AgCfg<KW>::CAP;
   constexpr int NS  = AgCfg<KW>::NS;
+  constexpr int SDW = AgCfg<KW>::SDW;
   extern __shared__ uint4 ag_lds[];
-  u32 *cell   = (u32 *) ag_lds;                            // [CAP] counters -> offsets -> counts by position
-  u32 *K      = cell + CAP;                                // [KW][CAP] keys by position
-  u32 *lhist  = K + KW * CAP;                              // [AG_HB]
-  u32 *sh_tmp = lhist + AG_HB;                             // [AG_WAVES]
-  u64 *sh_base = (u64 *) (sh_tmp + AG_WAVES);
+  u32 *slot    = (u32 *) ag_lds;                           // [CAP][SDW] key + count, by sorted position
+  u32 *cell    = slot + CAP * SDW;                         // [CAP / 2] cell counters -> offsets, 16 bits each
+  u32 *lhist   = cell + CAP / 2;                           // [AG_HB]
+  u32 *sh_tmp  = lhist + AG_HB;                            // [2][AG_WAVES]
+  u64 *sh_base = (u64 *) (sh_tmp + 2 * AG_WAVES);
   const int tid = threadIdx.x;
+  const u32 lane = fk_lane();
+  // thread index that the optimiser cannot see through: used where a phase derives per-record addresses from it,
+  // so that the 8 x 3 address registers are computed where they are used instead of being kept (spilled) all along
+#define AG_TID(t) u32 t = (u32) tid; asm volatile("" : "+v"(t))
 
-  for (int i = tid; i < CAP; i += AG_THREADS)
+  for (int i = tid; i < CAP / 2; i += AG_THREADS)
     cell[i] = 0;
   for (int i = tid; i < AG_HB; i += AG_THREADS)
     lhist[i] = 0;
   u64 my_max = 0;
   u32 my_distinct = 0, my_rounds = 0;
-  u32 R0 = 1;
+  u32 R0 = 1, flip = 0;
 #ifdef FK_ABLATION
   u64 ph[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tlast = __builtin_readcyclecounter();
 #endif
@@ -176,23 +202,37 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
     kmask[w] = (4 * w + 4 <= kbytes) ? 0xffffffffu : (4 * w < kbytes) ? ((1u << (8 * (kbytes - 4 * w))) - 1u) : 0u;
   __syncthreads();
 
-  // records fetched ahead for the first chunk of the next bin (or selection) while this one is swept
-  u32     key[NS][KW], wgt[NS];          // a new record sits in key[] as loaded until step A takes its weight off
-  int64_t raw_beg = -1;
+  // The next bin is brought into L2 while the current one is swept: one dword per 128-byte line and thread, into
+  // a register that is looked at when the bin's own loads have arrived.  (Fetching the records themselves ahead, into
+  // registers, did not survive the register allocator: 24 more live registers per thread ended in scratch, and a
+  // reload from scratch waits for every load in flight.)
+  u32 touch = 0;
 
-  // groups of 2^gshift neighbouring bins (one bin when the input is large) are dealt round-robin:
-  // hashing makes them equally heavy
+  // Groups of 2^gshift neighbouring bins (one bin when the input is large) are dealt round-robin: hashing makes
+  // them equally heavy.  The bounds of a group are fetched two groups ahead with a VECTOR load (lane 0: first
+  // record, lane 1: end): a scalar load shares its counter with LDS, so the first LDS wait behind it would sit
+  // out a trip to memory.
   const u32 nbins = (u32) (AG_BINS >> gshift);
-  for (u32 bin = blockIdx.x; bin < nbins; bin += gridDim.x)
-    { const int64_t beg = (int64_t) bounds[bin << gshift], end = (int64_t) bounds[(bin + 1) << gshift];
-      if (beg >= end)
-        continue;
-      int64_t nx_beg = -1, nx_end = -1;         // the bin this workgroup takes next
-      if (bin + gridDim.x < nbins)
-        { nx_beg = (int64_t) bounds[(bin + gridDim.x) << gshift];
-          nx_end = (int64_t) bounds[(bin + gridDim.x + 1) << gshift];
-        }
-
+#define AG_BOUNDS_OF(b) bounds[(size_t) min((b) + ag_opaque(lane & 1u), nbins) << gshift]
+  u32 bin = blockIdx.x;
+  int64_t beg = 0, end = 0;
+  u64 nxv = 0;                                  // bounds of the next group: loaded a whole group ahead, made scalars when used
+#define AG_SCALAR64(x, l) ((int64_t) (((u64) (u32) __builtin_amdgcn_readlane((int) ((x) >> 32), l) << 32) \
+                                       | (u32) __builtin_amdgcn_readlane((int) (x), l)))
+  { const u64 b0 = (bin < nbins) ? AG_BOUNDS_OF(bin) : 0ull;
+    nxv = (bin + gridDim.x < nbins) ? AG_BOUNDS_OF(bin + gridDim.x) : 0ull;
+    beg = AG_SCALAR64(b0, 0);
+    end = AG_SCALAR64(b0, 1);
+  }
+  for (; bin < nbins; bin += gridDim.x)
+    { // (the bounds of the next group become scalars -- which waits for every memory operation in flight -- in
+      // the sweep, before the table entries are stored, not here behind the stores of the previous group)
+      int64_t nx_beg = 0, nx_end = 0;
+      bool    have_nx = false;
+#define AG_ADVANCE() do { if (!have_nx) { nx_beg = AG_SCALAR64(nxv, 0); nx_end = AG_SCALAR64(nxv, 1); have_nx = true; \
+                                           nxv = (bin + 2 * gridDim.x < nbins) ? AG_BOUNDS_OF(bin + 2 * gridDim.x) : 0ull; } } while (0)
+      if (beg < end)
+      {
       // A bin is taken in R0 selections (records whose next hash bits equal r0); R0 is what the
       // previous bin of this workgroup needed (all bins are alike), so that a fill that is too
       // small for whole bins is not found out again bin after bin.  A selection that still does
@@ -206,24 +246,22 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
           int64_t pos = beg;
           u32     carried = 0, vmask = 0, ntot = 0;
           bool    ovf = false;
-          u32     v[NS];
+          u32     v[NS], key[NS][KW], wgt[NS];
           for (;;)
             { // ---- fill the register slots: slot j of thread tid is "lane position" j * 1024 + tid
               u32 isnew = 0;
               if (carried == 0)
                 { const int64_t room = end - pos;
                   const u32 nnew = (room < (int64_t) cap_eff) ? (u32) room : (u32) cap_eff;
-                  if (raw_beg != pos)
-                    {
+                  { const u32 *bp = recs + pos * KW;
+                      AG_TID(t);
 #pragma unroll
                       for (int j = 0; j < NS; j++)
-                        { const u32 L = (u32) (j * AG_THREADS + tid);
-                          if (L < nnew)
-                            { const ag_rec<KW> rr = *(const ag_rec<KW> *) (recs + (pos + L) * KW);
+                        { const u32 L = min((u32) (j * AG_THREADS) + t, nnew - 1);    // (a slot beyond nnew is not used)
+                          const ag_rec<KW> rr = *(const ag_rec<KW> *) (bp + L * KW);
 #pragma unroll
-                              for (int w = 0; w < KW; w++)
-                                key[j][w] = rr.w[w];
-                            }
+                          for (int w = 0; w < KW; w++)
+                            key[j][w] = rr.w[w];
                         }
                     }
 #pragma unroll
@@ -240,7 +278,7 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
                     if ((u32) (j * AG_THREADS + tid) < (u32) cap_eff && !((vmask >> j) & 1u))
                       fr |= (1u << j);
                   u32 totfree;
-                  u32 k = ag_block_exscan((u32) __popc(fr), sh_tmp, &totfree);
+                  u32 k = ag_block_exscan((u32) __popc(fr), sh_tmp + (flip ^= AG_WAVES), &totfree);
                   const int64_t room = end - pos;
                   const u32 nnew = (room < (int64_t) totfree) ? (u32) room : totfree;
 #pragma unroll
@@ -257,7 +295,9 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
                       }
                   pos += nnew;
                 }
-              raw_beg = -1;
+#ifdef FK_ABLATION
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // (timers: the loads' latency apart from step A)
+#endif
               AG_T(0);
 
               // ---- A: cell and rank of every record of the fill
@@ -272,79 +312,148 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
                     }
                   sub[j] = 0; rank[j] = 0;
                   if (((isnew | vmask) >> j) & 1u)
-                    { u32 ha, hb;
-                      fk_rec_hash<KW>(key[j], kbytes, ha, hb);
-                      if (((isnew >> j) & 1u) && ((hb >> 16) & (R - 1)) != r)
-                        continue;                              // not in this selection
+                    { if (R > 1 && ((isnew >> j) & 1u))
+                        { u32 ha, hb;                          // the selections of a bin go by the bits above the bin's
+                          fk_rec_hash<KW>(key[j], kbytes, ha, hb);
+                          if (((hb >> 16) & (R - 1)) != r)
+                            continue;                          // not in this selection
+                        }
                       vmask |= (1u << j);
-                      sub[j]  = ha & (CAP - 1);
-                      rank[j] = atomicAdd(&cell[sub[j]], 1u);
+                      const u32 hc = ag_cellhash<KW>(key[j]);
+                      sub[j]  = (hc & (CAP - 1)) | ((hc >> 13) << 16);    // cell, and 12 more bits for step C
+                      const u32 sh = (sub[j] & 1u) << 4;
+                      rank[j] = (atomicAdd(&cell[(sub[j] & 0xffffu) >> 1], 1u << sh) >> sh) & 0xffffu;
                     }
                 }
               __syncthreads();
               AG_T(1);
-              ntot = ag_scan_cells<NS>(cell, sh_tmp);
+              ntot = ag_scan_cells<NS>(cell, sh_tmp + (flip ^= AG_WAVES));
               __syncthreads();
               AG_T(2);
 
-              // ---- B: positions; then keys and weights to their positions (the counters become the counts)
-              u32 p[NS], off[NS];
+              // ---- B: positions; key and weight to their slot
+              u32 p[NS], q[NS];
 #pragma unroll
               for (int j = 0; j < NS; j++)
-                { off[j] = 0;
+                { q[j] = 0;
                   if ((vmask >> j) & 1u)
-                    off[j] = cell[sub[j]];
-                  p[j] = off[j] + rank[j];
+                    q[j] = (cell[(sub[j] & 0xffffu) >> 1] >> ((sub[j] & 1u) << 4)) & 0xffffu;
                 }
-              __syncthreads();
 #pragma unroll
               for (int j = 0; j < NS; j++)
-                { if ((vmask >> j) & 1u)
-                    {
-#pragma unroll
-                      for (int w = 0; w < KW; w++)
-                        K[w * CAP + p[j]] = key[j][w];
-                      cell[p[j]] = wgt[j];
+                { p[j] = q[j] + rank[j];
+                  if ((vmask >> j) & 1u)
+                    { u32 *sp = slot + p[j] * SDW;
+                      if (SDW == 4)
+                        *(uint4 *) sp = make_uint4(key[j][0], KW > 1 ? key[j][KW > 1 ? 1 : 0] : 0u,
+                                                   KW > 2 ? key[j][KW > 2 ? 2 : 0] : 0u, wgt[j]);
+                      else
+                        { *(uint4 *) sp = make_uint4(key[j][0], key[j][1], key[j][2], key[j][KW > 3 ? 3 : 0]);
+                          *(uint4 *) (sp + 4) = make_uint4(KW > 4 ? key[j][KW > 4 ? 4 : 0] : 0u, KW > 5 ? key[j][KW > 5 ? 5 : 0] : 0u,
+                                                           KW > 6 ? key[j][KW > 6 ? 6 : 0] : 0u, wgt[j]);
+                        }
                     }
-                  const u32 L = (u32) (j * AG_THREADS + tid);
-                  if (L >= ntot)
-                    cell[L] = 0;
                 }
               __syncthreads();
               AG_T(3);
 
-              // ---- C: a record that is not the first of its cell looks for its k-mer in front of it
+              // ---- C: every k-mer of the fill gets a LEADER, the record that collects its count.
+              // C1: a record that is not the first of its cell compares itself with the first: four out of five are
+              //     the same k-mer.  (The cell counters are dead: they become the table of C2, all ones.)
+              // C2: the others are records of a k-mer that shares its cell with another: the one at the lowest position
+              //     per 12 further hash bits (atomic min) is the leader of all that are equal to it.
+              // C3: what is left (two such k-mers with the same 12 bits) looks through its cell from the front.
+              // A search through the cell alone takes as many steps as the longest wait of a new k-mer behind the
+              // copies of another -- a dozen for every wave on 50x data.
+              constexpr int T2 = CAP / 2;
+              if (NS == 8) *(uint4 *) (cell + tid * (NS / 2)) = make_uint4(~0u, ~0u, ~0u, ~0u);
+              else         *(uint2 *) (cell + tid * (NS / 2)) = make_uint2(~0u, ~0u);
+              u32 need = 0;
+#pragma unroll
+              for (int g = 0; g < NS; g += 4)                   // four records at a time: their reads travel together
+                { uint4 s0[4], s1[4];
+#pragma unroll
+                  for (int i = 0; i < 4; i++)
+                    { s0[i] = *(const uint4 *) (slot + q[g + i] * SDW);
+                      if (SDW == 8) s1[i] = *(const uint4 *) (slot + q[g + i] * SDW + 4);
+                    }
+#pragma unroll
+                  for (int i = 0; i < 4; i++)
+                    { const int j = g + i;
+                      u32 e = s0[i].x ^ key[j][0];
+                      if (KW > 1) e |= s0[i].y ^ key[j][KW > 1 ? 1 : 0];
+                      if (KW > 2) e |= s0[i].z ^ key[j][KW > 2 ? 2 : 0];
+                      if (KW > 3) e |= s0[i].w ^ key[j][KW > 3 ? 3 : 0];
+                      if (KW > 4) e |= s1[i].x ^ key[j][KW > 4 ? 4 : 0];
+                      if (KW > 5) e |= s1[i].y ^ key[j][KW > 5 ? 5 : 0];
+                      if (KW > 6) e |= s1[i].z ^ key[j][KW > 6 ? 6 : 0];
+                      if (((vmask >> j) & 1u) && p[j] != q[j])
+                        { if (e == 0)
+                            { atomicAdd(slot + q[j] * SDW + (SDW - 1), wgt[j]);
+                              slot[p[j] * SDW + (SDW - 1)] = 0;
+                            }
+                          else
+                            need |= (1u << j);
+                        }
+                    }
+                }
+              __syncthreads();
 #pragma unroll
               for (int j = 0; j < NS; j++)
-                if (((vmask >> j) & 1u) && rank[j] != 0)
-                  { u32 q = off[j];
-                    bool found = false;
-                    while (q < p[j])
-                      { u32 e = 0;
+                if ((need >> j) & 1u)
+                  atomicMin(&cell[(sub[j] >> 16) & (T2 - 1)], p[j]);
+              __syncthreads();
+#pragma unroll
+              for (int j = 0; j < NS; j++)
+                if ((need >> j) & 1u)
+                  { const u32 m = cell[(sub[j] >> 16) & (T2 - 1)];
+                    if (m == p[j])
+                      need &= ~(1u << j);                       // the leader
+                    else
+                      { const u32 *sp = slot + m * SDW;
+                        u32 e = 0;
 #pragma unroll
                         for (int w = 0; w < KW; w++)
-                          e |= K[w * CAP + q] ^ key[j][w];
+                          e |= sp[w] ^ key[j][w];
+                        if (e == 0)
+                          { atomicAdd(slot + m * SDW + (SDW - 1), wgt[j]);
+                            slot[p[j] * SDW + (SDW - 1)] = 0;
+                            need &= ~(1u << j);
+                          }
+                      }
+                  }
+#pragma unroll
+              for (int j = 0; j < NS; j++)
+                if ((need >> j) & 1u)
+                  { u32 qq = q[j] + 1;                            // (the first of the cell is another k-mer)
+                    bool found = false;
+                    while (qq < p[j])
+                      { const u32 *sp = slot + qq * SDW;
+                        u32 e = 0;
+#pragma unroll
+                        for (int w = 0; w < KW; w++)
+                          e |= sp[w] ^ key[j][w];
                         if (e == 0) { found = true; break; }
-                        q += 1;
+                        qq += 1;
                       }
                     if (found)
-                      { atomicAdd(&cell[q], wgt[j]);
-                        cell[p[j]] = 0;
+                      { atomicAdd(slot + qq * SDW + (SDW - 1), wgt[j]);
+                        slot[p[j] * SDW + (SDW - 1)] = 0;
                       }
                   }
               __syncthreads();
               AG_T(4);
 
-              // ---- harvest: counts by position; the cells are left zero for the next fill
+              // ---- harvest: counts by position; the cell counters are zeroed for the next fill
+              if (NS == 8) *(uint4 *) (cell + tid * (NS / 2)) = make_uint4(0, 0, 0, 0);
+              else         *(uint2 *) (cell + tid * (NS / 2)) = make_uint2(0, 0);
+              { AG_TID(t);
 #pragma unroll
-              for (int j = 0; j < NS; j++)
-                { const u32 L = (u32) (j * AG_THREADS + tid);
-                  v[j] = 0;
-                  if (L < ntot)
-                    { v[j] = cell[L];
-                      if (v[j] != 0) cell[L] = 0;
-                    }
-                }
+                for (int j = 0; j < NS; j++)
+                  { const u32 L = (u32) (j * AG_THREADS) + t;
+                    v[j] = (L < ntot) ? slot[L * SDW + (SDW - 1)] : 0u;
+                  }
+              }
               if (pos >= end)
                 break;
               // more of the bin to come: the leaders stay, as records that carry their counts
@@ -352,20 +461,21 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
 #pragma unroll
               for (int j = 0; j < NS; j++)
                 nl += (v[j] != 0);
-              ag_block_exscan(nl, sh_tmp, &D);
+              ag_block_exscan(nl, sh_tmp + (flip ^= AG_WAVES), &D);
               if (D > (u32) limit)
                 { ovf = true;
                   break;
                 }
               vmask = 0;
+              AG_TID(tc);
 #pragma unroll
               for (int j = 0; j < NS; j++)
                 if (v[j] != 0)
-                  { const u32 L = (u32) (j * AG_THREADS + tid);
+                  { const u32 *sp = slot + ((u32) (j * AG_THREADS) + tc) * SDW;
                     vmask |= (1u << j);
 #pragma unroll
                     for (int w = 0; w < KW; w++)
-                      key[j][w] = K[w * CAP + L];
+                      key[j][w] = sp[w];
                     if (v[j] >= AG_HIGH)                       // stays far above 0x7fff: still saturated
                       { v[j] -= AG_CUT;
                         round_max += AG_CUT;
@@ -374,6 +484,7 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
                   }
               carried = D;
               my_rounds += (tid == 0);
+              __syncthreads();                                 // the slots are read: the next fill may write them
             }
           if (ovf)
             { // more distinct k-mers than the fill takes: halve the selection and start it again
@@ -390,103 +501,98 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
               continue;
             }
 
-          // ---- what comes next: another selection of this bin, or the workgroup's next bin -- fetch its first
-          // chunk now, the sweep below needs no registers of the fill
+          // ---- what comes next: another selection of this bin (in L2 already), or the workgroup's next bin -- one dword
+          // per line of it is asked for now
           { u32 Rn = R, rn = r;
             while (Rn > R0 && rn >= (Rn >> 1))
               { rn -= (Rn >> 1);
                 Rn >>= 1;
               }
-            const bool last = (Rn == R0) && (r0 + 1 >= R0);
-            const int64_t fb = last ? nx_beg : beg, fe = last ? nx_end : end;
-            if (fb >= 0 && fb < fe)
-              { const int64_t room = fe - fb;
-                const u32 nnew = (room < (int64_t) cap_eff) ? (u32) room : (u32) cap_eff;
-#pragma unroll
-                for (int j = 0; j < NS; j++)
-                  { const u32 L = (u32) (j * AG_THREADS + tid);
-                    if (L < nnew)
-                      { const ag_rec<KW> rr = *(const ag_rec<KW> *) (recs + (fb + L) * KW);
-#pragma unroll
-                        for (int w = 0; w < KW; w++)
-                          key[j][w] = rr.w[w];
-                      }
-                  }
-                raw_beg = fb;
+            AG_ADVANCE();
+            if ((Rn == R0) && (r0 + 1 >= R0) && nx_beg < nx_end)
+              { const int64_t room = (nx_end - nx_beg) * KW;                   // dwords
+                const u32 nd = (room < (int64_t) cap_eff * KW) ? (u32) room : (u32) cap_eff * KW;
+                const u32 d = min(ag_opaque((u32) tid) * 32u, nd - 1);
+                asm volatile("" :: "v"(touch));                                // (the previous one has long arrived)
+                touch = *(const volatile u32 *) (recs + nx_beg * KW + d);
               }
           }
 
-          // ---- emit: histogram, totals, table entries
+          // ---- emit.  First the number of table entries: their place in the table buffer comes from a global atomic,
+          // a trip to memory that the histogram work below covers.
           my_max += round_max;
-          // (the k-mers seen once or twice -- four out of five on read sets with sequencing errors -- are counted
-          // per wave with a ballot: one LDS atomic per lane on the same two histogram bins serialised the sweep)
-          u32 c[NS];
-          u32 nq = 0, n1 = 0, n2 = 0, nlead = 0;
+          u32 nq = 0, nlead = 0;
 #pragma unroll
           for (int j = 0; j < NS; j++)
             { const u32 vv = v[j];
-              c[j] = 0;
-              if (!DEDUP)
-                { n1 += (u32) __popcll(__ballot(vv == 1u));
-                  n2 += (u32) __popcll(__ballot(vv == 2u));
-                }
-              if (vv != 0)
-                { nlead += 1;
-                  u32 cc = vv;
-                  if (DEDUP)
-                    { nq += 1;
-                      c[j] = vv;
-                      continue;
-                    }
-                  if (vv >= sat)                               // sat = 0x7fff, MSDsort.c:498-506
-                    my_max += vv;
-                  if (vv >= 0x7fffu)
-                    cc = 0x7fffu;
-                  if ((variant & 2) || cc <= 2u) ;
-                  else if (cc < AG_HB) atomicAdd(&lhist[cc], 1u);
-                  else            atomicAdd(&hist_g[cc], 1ull);
-                  if (cutoff > 0 && (int) cc >= cutoff)
-                    { nq += 1;
-                      c[j] = cc;
-                    }
-                }
+              nlead += (vv != 0);
+              nq    += DEDUP ? (vv != 0) : (cutoff > 0 && vv >= (u32) cutoff);
             }
+          const bool tab = (DEDUP || cutoff > 0) && !(variant & 4);
+          u32 tot = 0, toff = 0;
+          u64 tbase = 0;
+          if (tab)
+            { toff = ag_block_exscan(nq, sh_tmp + (flip ^= AG_WAVES), &tot);
+              if (tid == 0 && tot > 0)
+                tbase = atomicAdd(&scal[2], (u64) tot);
+            }
+
+          // histogram and totals (the k-mers seen once or twice -- four out of five on read sets with sequencing
+          // errors -- are counted per wave with a ballot: one LDS atomic per lane on the same two histogram bins
+          // serialised the sweep)
           my_distinct += nlead;
-          if (!DEDUP && !(variant & 2) && fk_lane() == 0)
-            { if (n1 != 0) atomicAdd(&lhist[1], n1);
-              if (n2 != 0) atomicAdd(&lhist[2], n2);
+          if (!DEDUP)
+            { u32 n1 = 0, n2 = 0;
+#pragma unroll
+              for (int j = 0; j < NS; j++)
+                { const u32 vv = v[j];
+                  n1 += (u32) __popcll(__ballot(vv == 1u));
+                  n2 += (u32) __popcll(__ballot(vv == 2u));
+                  if (vv > 2u && !(variant & 2))
+                    { if (vv >= sat)                           // sat = 0x7fff, MSDsort.c:498-506
+                        my_max += vv;
+                      const u32 cc = min(vv, 0x7fffu);
+                      if (cc < AG_HB) atomicAdd(&lhist[cc], 1u);
+                      else            atomicAdd(&hist_g[cc], 1ull);
+                    }
+                }
+              if (!(variant & 2) && lane == 0)
+                { if (n1 != 0) atomicAdd(&lhist[1], n1);
+                  if (n2 != 0) atomicAdd(&lhist[2], n2);
+                }
             }
           if (R0 > 1)
             { u32 D;
-              ag_block_exscan(nlead, sh_tmp, &D);
+              ag_block_exscan(nlead, sh_tmp + (flip ^= AG_WAVES), &D);
               bin_fill = max(bin_fill, D);
             }
-          if ((DEDUP || cutoff > 0) && !(variant & 4))
-            { u32 tot;
-              const u32 off = ag_block_exscan(nq, sh_tmp, &tot);
-              if (tid == 0 && tot > 0)
-                *sh_base = atomicAdd(&scal[2], (u64) tot);
+          AG_T(5);
+          if (tab)
+            { if (tid == 0)
+                *sh_base = tbase;
               __syncthreads();
+              AG_T(6);
               if (tot > 0 && *sh_base + tot > tcap)
                 { if (tid == 0)                       // the table buffer is full (direct append to a union buffer)
                     atomicAdd(&scal[6], 1ull);
                 }
               else if (tot > 0)
-                { u64 o = *sh_base + off;
+                { u64 o = *sh_base + toff;
+                  AG_TID(t);
 #pragma unroll
                   for (int j = 0; j < NS; j++)
-                    if (c[j] != 0)
-                      { const u32 L = (u32) (j * AG_THREADS + tid);
+                    if (DEDUP ? (v[j] != 0) : (v[j] >= (u32) cutoff))
+                      { const u32 *sp = slot + ((u32) (j * AG_THREADS) + t) * SDW;
                         u32 kd[KW];
 #pragma unroll
                         for (int w = 0; w < KW; w++)
-                          kd[w] = K[w * CAP + L];
+                          kd[w] = sp[w];
                         if (DEDUP)
                           { ag_rec<KW + 1> ro;
 #pragma unroll
                             for (int w = 0; w < KW; w++)
                               ro.w[w] = kd[w];
-                            ro.w[KW] = c[j];
+                            ro.w[KW] = v[j];
                             *(ag_rec<KW + 1> *) (table + o * (KW + 1)) = ro;
                           }
                         else
@@ -494,15 +600,16 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
 #pragma unroll
                             for (int w = 0; w < KW - 1; w++)
                               ro.w[w] = kd[w];
-                            ro.w[KW - 1] = kd[KW - 1] | (c[j] << 16);
+                            ro.w[KW - 1] = kd[KW - 1] | (min(v[j], 0x7fffu) << 16);
                             *(ag_rec<KW> *) (table + o * KW) = ro;
                           }
                         o += 1;
                       }
                 }
             }
-          __syncthreads();
-          AG_T(5);
+          if (!tab)
+            __syncthreads();                      // (the cells zeroed above meet the next fill's counters)
+          AG_T(7);                                // (otherwise no barrier: the next fill meets two before it writes a slot)
 
           // ---- next selection below (R0, r0): sibling, or up
           while (R > R0 && r >= (R >> 1))
@@ -518,7 +625,15 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
         R0 = min(R0 << 1, (u32) AG_MAXR);
       else if (R0 > 1 && bin_fill * 9 < (u32) limit * 4)
         R0 >>= 1;
+      }
+      AG_ADVANCE();
+      beg = nx_beg; end = nx_end;
     }
+#undef AG_ADVANCE
+  asm volatile("" :: "v"(touch));
+#undef AG_SCALAR64
+#undef AG_BOUNDS_OF
+#undef AG_TID
 
   // flush the private histogram and the per-thread totals
   __syncthreads();
@@ -532,7 +647,7 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
       d      += __shfl_down(d, o, 64);
       rd     += __shfl_down(rd, o, 64);
     }
-  if (fk_lane() == 0)
+  if (lane == 0)
     { if (my_max) atomicAdd(&scal[0], my_max);
       if (d)      atomicAdd(&scal[1], d);
       if (rd)     atomicAdd(&scal[5], rd);
@@ -626,7 +741,7 @@ static int aggr_t(fk_ctx *ctx, const void *d_grouped, int64_t n, int cutoff, int
     { fprintf(stderr, "ag phases (cycles of thread 0, all workgroups) n=%lld:", (long long) n);
       for (int k = 0; k < 8; k++)
         fprintf(stderr, " %llu", (unsigned long long) hh[FK_HIST_BINS + 8 + k]);
-      fprintf(stderr, "  (load, A, scan, B, C, harvest+emit)\n");
+      fprintf(stderr, "  (load, A, scan, B, C, harvest+hist, table reserve, table write)\n");
     }
 #endif
   free(hh);
