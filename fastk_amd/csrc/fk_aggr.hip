@@ -766,59 +766,3 @@ int fkx_aggregate(fk_ctx *ctx, const void *d_grouped, int64_t n, int cutoff, int
       return (FK_EUNSUPPORTED);
   }
 }
-
-// ---------------------------------------------------------------------------------------------
-// Super-mer de-duplication with the same kernel: n records of KW dwords, grouped by 16 hash bits of
-// the whole record -> every distinct record once, followed by its multiplicity (KW + 1 dwords each,
-// in no particular order).  Replaces two of the four grouping passes and the run detection of the
-// expansion (count.c:421-426).
-template <int KW>
-static int dedup_t(fk_ctx *ctx, const void *d_grouped, int64_t n, void *d_out, int64_t cap, int64_t *nout)
-{ hipStream_t s = ctx->stream;
-  *nout = 0;
-  if (n == 0)
-    return (FK_OK);
-  if (d_out == NULL || cap < n)
-    { fk_set_error(ctx, "dedup: the output buffer must take as many records as the input (%lld)", (long long) n);
-      return (FK_EINVAL);
-    }
-  u64 *d_bounds = (u64 *) fk_slot(ctx, FK_SLOT_AG_BOUNDS, (AG_BINS + 1) * 8);
-  u64 *d_hist   = (u64 *) fk_slot(ctx, FK_SLOT_CT_HIST, (FK_HIST_BINS + AG_NSCAL) * 8);
-  if (d_bounds == NULL || d_hist == NULL)
-    return (FK_ENOMEM);
-  u64 *d_scal = d_hist + FK_HIST_BINS;
-  static bool attr_set = false;
-  const size_t lds = AgCfg<KW>::LDS;
-  if (!attr_set)
-    { auto kern = k_ag_count<KW, true>;
-      FK_HIP(ctx, hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-      attr_set = true;
-    }
-  FK_HIP(ctx, hipMemsetAsync(d_scal, 0, 8 * 8, s));
-  hipLaunchKernelGGL(k_ag_bounds<KW>, dim3(AG_BINS / 256 + 1), dim3(256), 0, s, (const u32 *) d_grouped, n,
-                     KW * 4, d_bounds);
-  const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
-  const int gshift = ag_gshift<KW>(n);
-  hipLaunchKernelGGL((k_ag_count<KW, true>), dim3((unsigned) cus), dim3(AG_THREADS), lds, s, (const u32 *) d_grouped,
-                     (const u64 *) d_bounds, KW * 4, 1, d_hist, d_scal, (u32 *) d_out, AgCfg<KW>::CAP, AgCfg<KW>::CAP * 3 / 4, 0,
-                     gshift, 0x7fffu, (u64) cap);
-  FK_LAUNCH_CHECK(ctx);
-  FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch + 4100, d_scal, 8 * 8, hipMemcpyDeviceToHost, s));
-  FK_HIP(ctx, hipStreamSynchronize(s));
-  if (ctx->h_scratch[4100 + 3] != 0)
-    return (FK_ESTATE);
-  *nout = (int64_t) ctx->h_scratch[4100 + 2];
-  return (FK_OK);
-}
-
-int fkx_dedup_supermers(fk_ctx *ctx, const void *d_grouped, int64_t n, void *d_out, int64_t cap, int64_t *nout)
-{ switch (ctx->wid.smer_stride >> 2)
-  { case 2: return dedup_t<2>(ctx, d_grouped, n, d_out, cap, nout);
-    case 3: return dedup_t<3>(ctx, d_grouped, n, d_out, cap, nout);
-    case 4: return dedup_t<4>(ctx, d_grouped, n, d_out, cap, nout);
-    case 5: return dedup_t<5>(ctx, d_grouped, n, d_out, cap, nout);
-    case 6: return dedup_t<6>(ctx, d_grouped, n, d_out, cap, nout);
-    case 7: return dedup_t<7>(ctx, d_grouped, n, d_out, cap, nout);
-    default: return (FK_EUNSUPPORTED);              // the caller keeps the four-pass grouping
-  }
-}
