@@ -1221,6 +1221,97 @@ def test_drivers_against_reference_digests_above_fixture_size(name, tmp_path):
             assert util.sha_file(tmp_path / fname) == digest, (os.path.basename(cmd[0]), fname)
 
 
+def test_reference_digests_above_4GiB(tmp_path):
+    """hifi50x200M_k40_t4_T8 (tests/golden/make_golden.py --huge): 50x of a 200 Mbp genome in 15 kbp reads with
+    0.2 % substitutions -- 666,666 reads, 10.0 G bases, 9.97 G k-mer instances, 11.6 GB of super-mer records,
+    18 GB of weighted k-mers, 200.0 M table entries -- counted by the REFERENCE FastK in the build container; only
+    its digests travel, the reads are regenerated by fk_synth_reads.  Every buffer of the resident path lies
+    beyond 2^32 bytes here.  Against the reference's .hist bytes, .ktab canonical stream, entry count and stub:
+      (a) the setting bench.py times: reads resident, 48 minimizer buckets, 3 split passes with entry replay;
+      (b) the same without replay (every pass recomputes the minimizers);
+      (c) 4 buckets in one pass: 2.9 GB of super-mers and 4.5 GB of weighted k-mers per bucket;
+      (d) value_device's route: reads in host memory pushed in 1 GB blocks with a budget that spills;
+      (e) the C driver on the FASTA file, on one GPU and as two RCCL ranks (-G2)."""
+    import ctypes as C, json, os, subprocess
+    case = json.load(open(os.path.join(util.GOLDEN, "hifi50x200M_k40_t4_T8.json")))
+    s, exp = case["synth"], case["expected"]
+    k, cutoff, T, L, nreads = case["k"], case["cutoff"], case["T"], s["read_len"], s["nreads"]
+    nbytes = nreads * (L + 1)
+    assert nbytes > (1 << 32)
+
+    def check(res, what):
+        assert res.ninst == nreads * (L - k + 1), what
+        util.check_against_golden(case, res.hist, res.max_inst, res.table)
+
+    with fastk_amd.Context(kmer=k) as gen:
+        buf = gen.alloc(nbytes + 64)
+        piece = 1 << 16
+        for first in range(0, nreads, piece):
+            n = min(piece, nreads - first)
+            gen._ck(gen.L.fk_synth_reads(gen.h, s["seed"], s["genome_len"], L, s["err_ppm"], first, n, buf.ptr + first * (L + 1)))
+        gen._ck(gen.L.fk_synchronize(gen.h))
+        sample = buf.download(8 << 20)
+        for what, nb, passes, replay in (("a", 48, 3, 1), ("b", 48, 3, 0), ("c", 4, 1, 1)):
+            with fastk_amd.Context(kmer=k, table_cutoff=cutoff, nthreads=T, nbuckets=nb, split_passes=passes) as ctx:
+                ctx.set_bucket_weights(ctx.bucket_census(sample))
+                ctx.debug_set("split_replay", replay)
+                res = ctx.count_device_reads(buf.ptr, nbytes, fetch_table=True)
+                assert res.split_passes == passes and res.buckets_counted == nb, what
+                assert res.replay_passes == ((passes - 1) if replay else 0), what
+                check(res, what)
+                del res
+        # (d) the reads go to pinned host memory and come back block by block
+        lib = gen.L
+        host = C.c_void_p()
+        gen._ck(lib.fk_host_alloc(nbytes + 64, C.byref(host)))
+        gen._ck(lib.fk_copy_to_host(gen.h, host.value, buf.ptr, nbytes))
+        buf.free()
+    try:
+        with fastk_amd.Context(kmer=k, table_cutoff=cutoff, nthreads=T, nbuckets=16, hbm_budget=8 << 30) as ctx:
+            ctx.set_bucket_weights(ctx.bucket_census(sample))
+            per = 65536                                         # reads per block: 1 GB
+            boff = (np.arange(per + 1, dtype=np.int64) * (L + 1)).astype(np.int32)
+            for first in range(0, nreads, per):
+                n = min(per, nreads - first)
+                ctx._ck(lib.fk_push_block(ctx.h, host.value + first * (L + 1), boff.ctypes.data, n, 0, 0))
+            res = ctx.finish()
+            assert ctx.debug_get("spilled_bytes") > (1 << 30)
+            check(res, "d")
+            del res
+        # (e) the same reads as a FASTA file, one line per read, through the C driver
+        path = str(tmp_path / "x.fasta")
+        view = np.ctypeslib.as_array(C.cast(host.value, C.POINTER(C.c_uint8)), shape=(nbytes,))
+        with open(path, "wb") as f:
+            for first in range(0, nreads, 20000):
+                n = min(20000, nreads - first)
+                mat = np.empty((n, 3 + L + 1), dtype=np.uint8)
+                mat[:, 0:3] = np.frombuffer(b">r\n", dtype=np.uint8)
+                mat[:, 3:3 + L] = view[first * (L + 1):(first + n) * (L + 1)].reshape(n, L + 1)[:, :L]
+                mat[:, 3 + L] = ord("\n")
+                mat.tofile(f)
+        del view
+    finally:
+        lib.fk_host_free(host)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "fastk_amd", "bin", "FastK_amd")
+    args = ["-k%d" % k, "-t%d" % cutoff, "-T%d" % T]
+    for what, extra, env in (("one GPU", ["-M64"], None), ("-G2", ["-G2"], dict(os.environ, FK_RANKS_SHARE_GPU="1"))):
+        d = tmp_path / what.strip("-").replace(" ", "")
+        d.mkdir()
+        p = subprocess.run([exe] + args + extra + ["-N" + str(d / "x"), path], env=env, capture_output=True, text=True, timeout=1500)
+        if p.returncode != 0 and env is not None and any(m in p.stdout + p.stderr for m in _RCCL_RIG_ERRORS) \
+                and os.environ.get("FK_REQUIRE_RANKS") != "1":
+            pytest.skip("RCCL would not bring up two ranks on one GPU here: " + p.stderr[-300:])
+        assert p.returncode == 0, (what, (p.stdout + p.stderr)[-3000:])
+        assert util.sha_file(d / "x.hist") == exp["hist_sha256"], what
+        t = orc.read_ktab(str(d / "x"))
+        assert (t["kmer"], t["nparts"], t["minval"], t["ibytes"], t["nels"]) == (k, T, cutoff, exp["ktab"]["ibytes"], exp["ktab"]["nels"]), what
+        assert t["stream_sha256"] == exp["ktab"]["stream_sha256"], what
+        del t
+        for f in os.listdir(d):
+            os.remove(d / f)
+
+
 @pytest.mark.parametrize("name", ["edge_k40_t1_T4", "synth_hifi_k40_t4_T8", "synth_illumina_k51_t1_T4"])
 def test_reference_readers_accept_our_files(name, tmp_path):
     """SURVEY 8(f)-1 reader conformance: the reference-built Histex, Tabex and Logex (oracle/_ref) print
