@@ -53,11 +53,11 @@ CONFIGS = {
             label="50x coverage, 150 bp reads, err 1000 ppm, of a %g Mbp genome%s, k=%d -t1 "
                   "(BASELINE.json configs[1])"),
     2: dict(genome_mbp=3000.0, coverage=50.0, read_len=15000, err_ppm=2000, cutoff=4, buckets=48,
-            split_passes=3, cpu_sample_mbp=20.0,
+            split_passes=3, cpu_sample_mbp=200.0,
             label="50x coverage, 15 kbp HiFi-shaped reads, err 2000 ppm, of a %g Mbp genome%s, k=%d -t4 "
                   "(BASELINE.json configs[2])"),
     3: dict(genome_mbp=3000.0, coverage=50.0, read_len=15000, err_ppm=2000, cutoff=4, buckets=1,
-            split_passes=1, cpu_sample_mbp=20.0,
+            split_passes=1, cpu_sample_mbp=200.0,
             label="50x coverage, 15 kbp HiFi-shaped reads, err 2000 ppm, of a %g Mbp genome%s, k=%d -t4, "
                   "sharded over the GPUs by minimizer bucket (BASELINE.json configs[3])"),
 }
@@ -125,41 +125,105 @@ def write_fastx(path, bases, nreads, L, fastq):
     mat.tofile(path)
 
 
+def _write_sample(path, orc, seed, glen, L, err_ppm, nreads, fastq):
+    """the synthetic reads of a sample as a FASTA / FASTQ file, 20,000 reads at a time"""
+    with open(path, "wb") as f:
+        for r0 in range(0, nreads, 20000):
+            n = min(20000, nreads - r0)
+            b, _ = orc.synth_block(seed, glen, L, err_ppm, r0, n)
+            rows = b.reshape(n, L + 1)[:, :L]
+            if fastq:
+                mat = np.empty((n, 3 + L + 3 + L + 1), dtype=np.uint8)
+                mat[:, 0:3] = np.frombuffer(b"@r\n", dtype=np.uint8)
+                mat[:, 3:3 + L] = rows
+                mat[:, 3 + L:6 + L] = np.frombuffer(b"\n+\n", dtype=np.uint8)
+                mat[:, 6 + L:6 + 2 * L] = ord("I")
+                mat[:, 6 + 2 * L] = ord("\n")
+            else:
+                mat = np.empty((n, 3 + L + 1), dtype=np.uint8)
+                mat[:, 0:3] = np.frombuffer(b">r\n", dtype=np.uint8)
+                mat[:, 3:3 + L] = rows
+                mat[:, 3 + L] = ord("\n")
+            mat.tofile(f)
+
+
 def cpu_baseline(args, cfg):
-    """Reference FastK (oracle/_ref/FastK, built from the reference sources) on this box's host
-    cores, on a bounded sample of the same workload; falls back to the scalar port."""
+    """Reference FastK (oracle/_ref/FastK, built from the reference sources) on this box's host cores, on a
+    bounded sample of the same workload: the thread count is chosen by one run each of -T32/64/128/256 on a
+    small sample (the reference is fastest at 32-64 threads on a 256-thread box; -T<all cores> is 1.4x slower),
+    then the sample proper runs twice with the best one.  Falls back to the scalar port without the reference."""
     from oracle import orc
     cores = os.cpu_count() or 1
     L = cfg["read_len"]
-    glen = int(cfg["cpu_sample_mbp"] * 1e6)
-    nreads = int(cfg["coverage"] * glen / L)
-    sample = "%gx coverage of a %g Mbp genome, %d x %d bp reads, err %d ppm, k=%d -t%d" % (
-        cfg["coverage"], cfg["cpu_sample_mbp"], nreads, L, cfg["err_ppm"], args.kmer, cfg["cutoff"])
-    bases, boff = orc.synth_block(args.seed, glen, L, cfg["err_ppm"], 0, nreads)
-    inst = nreads * (L - args.kmer + 1)
-    if orc.have_ref():
-        d = tempfile.mkdtemp(prefix="fkbase")
-        try:
-            fastq = L <= 1000
-            path = os.path.join(d, "s.fastq" if fastq else "s.fasta")
-            write_fastx(path, bases, nreads, L, fastq)
-            cmd = [os.path.join(orc.REF_DIR, "FastK"), "-k%d" % args.kmer, "-t%d" % cfg["cutoff"],
-                   "-T%d" % cores, "-P" + d, path]
-            t0 = time.perf_counter()
-            subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
-                           cwd=d)
-            dt = time.perf_counter() - t0
-            return dict(value=inst / dt, unit="k-mers/s", cores=cores, kind="reference",
-                        sample=sample + " (%s file, reference FastK -T%d, %.1f s wall, parse and file "
-                                        "writes included)" % ("FASTQ" if fastq else "FASTA", cores, dt))
-        finally:
-            subprocess.run(["rm", "-rf", d])
-    t0 = time.perf_counter()
-    res = orc.fastk(args.kmer, bases, boff, cutoff=cfg["cutoff"])
-    dt = time.perf_counter() - t0
-    assert res.ninst == inst
-    return dict(value=inst / dt, unit="k-mers/s", cores=1, kind="port",
-                sample=sample + " (scalar CPU restatement, %.1f s)" % dt)
+    fastq = L <= 1000
+
+    def sample_of(mbp):
+        glen = int(mbp * 1e6)
+        nreads = int(cfg["coverage"] * glen / L)
+        return glen, nreads, nreads * (L - args.kmer + 1)
+
+    def text(mbp, nreads):
+        return "%gx coverage of a %g Mbp genome, %d x %d bp reads, err %d ppm, k=%d -t%d" % (
+            cfg["coverage"], mbp, nreads, L, cfg["err_ppm"], args.kmer, cfg["cutoff"])
+
+    if not orc.have_ref():
+        glen, nreads, inst = sample_of(min(cfg["cpu_sample_mbp"], 20.0))
+        bases, boff = orc.synth_block(args.seed, glen, L, cfg["err_ppm"], 0, nreads)
+        t0 = time.perf_counter()
+        res = orc.fastk(args.kmer, bases, boff, cutoff=cfg["cutoff"])
+        dt = time.perf_counter() - t0
+        assert res.ninst == inst
+        return dict(value=inst / dt, unit="k-mers/s", cores=1, kind="port",
+                    sample=text(min(cfg["cpu_sample_mbp"], 20.0), nreads) + " (scalar CPU restatement, %.1f s)" % dt)
+
+    def run(path, d, T):
+        cmd = [os.path.join(orc.REF_DIR, "FastK"), "-k%d" % args.kmer, "-t%d" % cfg["cutoff"], "-T%d" % T, "-P" + d, path]
+        t0 = time.perf_counter()
+        subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=d)
+        return time.perf_counter() - t0
+
+    d = tempfile.mkdtemp(prefix="fkbase")
+    try:
+        # thread count: one run each on a small sample
+        small_mbp = min(20.0, cfg["cpu_sample_mbp"])
+        glen, nreads, inst = sample_of(small_mbp)
+        small = os.path.join(d, "t.fastq" if fastq else "t.fasta")
+        _write_sample(small, orc, args.seed, glen, L, cfg["err_ppm"], nreads, fastq)
+        sweep = {}
+        for T in (32, 64, 128, 256):
+            if T <= cores:
+                sweep[T] = round(inst / run(small, d, T) / 1e9, 4)
+        if not sweep:
+            sweep[cores] = round(inst / run(small, d, cores) / 1e9, 4)
+        best_T = max(sweep, key=lambda t: sweep[t])
+        os.remove(small)
+        # the sample proper, twice
+        mbp = cfg["cpu_sample_mbp"]
+        glen, nreads, inst = sample_of(mbp)
+        path = os.path.join(d, "s.fastq" if fastq else "s.fasta")
+        _write_sample(path, orc, args.seed, glen, L, cfg["err_ppm"], nreads, fastq)
+        times = [run(path, d, best_T) for _ in range(2)]
+        dt = min(times)
+        out = dict(value=inst / dt, unit="k-mers/s", cores=best_T, kind="reference", host_threads=cores,
+                   thread_sweep_gkmers_per_s={"-T%d" % t: v for t, v in sweep.items()},
+                   thread_sweep_sample=text(small_mbp, sample_of(small_mbp)[1]),
+                   seconds=[round(t, 2) for t in times],
+                   sample=text(mbp, nreads) + " (%s file, reference FastK -T%d = the fastest of the sweep, best of two "
+                                              "runs %.1f s wall, parse and file writes included)"
+                                              % ("FASTQ" if fastq else "FASTA", best_T, dt))
+        # the run is also a parity anchor: this sample is the golden case hifi50x200M_k40_t4_T8
+        g = os.path.join(ROOT, "tests", "golden", "hifi50x200M_k40_t4_T8.json")
+        if os.path.exists(g):
+            case = json.load(open(g))
+            sy = case["synth"]
+            if (sy["seed"], sy["genome_len"], sy["read_len"], sy["err_ppm"], sy["nreads"], case["k"], case["cutoff"]) == \
+                    (args.seed, glen, L, cfg["err_ppm"], nreads, args.kmer, cfg["cutoff"]):
+                import hashlib
+                h = hashlib.sha256(open(os.path.join(d, "s.hist"), "rb").read()).hexdigest()
+                out["hist_sha256_equals_golden"] = (h == case["expected"]["hist_sha256"])
+        return out
+    finally:
+        subprocess.run(["rm", "-rf", d])
 
 
 def copy_ceiling(torch, dev):

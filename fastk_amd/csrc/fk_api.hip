@@ -334,7 +334,10 @@ extern "C" int fk_create(const fk_params *p, fk_ctx **out)
   if (ctx->prm.hbm_budget > 0)
     // a quarter of the budget is left for what is alive while a bucket is counted (two read
     // buffers, a chunk's split output, the bucket's records and weighted k-mers, the growing table)
-    ctx->spill_limit = ctx->prm.hbm_budget - std::max<int64_t>(ctx->prm.hbm_budget / 4, 256ll << 20);
+    // (never below half the budget: a budget under 512 MB used to make this negative, which slab_alloc reads as
+    // "no limit" -- and then the first slab alone was 8 GB)
+    ctx->spill_limit = std::max<int64_t>(ctx->prm.hbm_budget - std::max<int64_t>(ctx->prm.hbm_budget / 4, 256ll << 20),
+                                         std::max<int64_t>(ctx->prm.hbm_budget / 2, 1));
   build_minimizer_tables(ctx->h_mbucket, ctx->prm.nbuckets);
   CK(hipMemcpy(ctx->d_mbucket, ctx->h_mbucket, FK_NRANKS, hipMemcpyHostToDevice));
 #undef CK
@@ -1826,7 +1829,9 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
                 { if ((rc = fkx_split_plan(ctx, d_reads, nbytes, &gcap_all, goffs)) != FK_OK) break;
                   ngroups = ctx->prm.split_passes;
                   if (ngroups <= 0)
-                    ngroups = (int) ((gcap_all * w.smer_stride + ctx->prm.hbm_budget / 2 - 1) / (ctx->prm.hbm_budget / 2));
+                    { const int64_t half = std::max<int64_t>(ctx->prm.hbm_budget / 2, 1);
+                      ngroups = (int) std::min<int64_t>((gcap_all * w.smer_stride + half - 1) / half, 255);
+                    }
                   if (ngroups > nbk) ngroups = nbk;
                   if (gcap_all == 0) ngroups = 1;
                 }
@@ -1955,9 +1960,19 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
                   hipEventRecord(gev[1], s);
                   hipEventSynchronize(gev[1]);
                   ms_split_groups += ms_between(gev[0], gev[1]);
-                  if (rc != FK_ESTATE || tries >= 2)
+                  if (rc != FK_ESTATE || tries >= 3)
                     break;
-                  grow *= 1.5;                // the sample under-estimated a bucket: wider regions
+                  if (tries < 2)
+                    grow *= 1.5;              // the sample under-estimated a bucket: wider regions
+                  else
+                    { // very uneven input: count the buckets exactly (one more pass over the reads) instead of failing
+                      int64_t ns_x = 0, ni_x = 0, bcx[256];
+                      if ((rc = fkx_split(ctx, d_reads, nbytes, NULL, 0, &ns_x, &ni_x, bcx, false, NULL)) != FK_OK)
+                        break;
+                      for (int b = 0; b < nbk; b++)
+                        est[b] = bcx[b] + FK_REGION_SLACK;
+                      grow = 1.0;
+                    }
                 }
               if (rc != FK_OK)
                 break;

@@ -19,6 +19,7 @@ typedef unsigned int       u32;
 // Minimizers are canonical 7-mers ordered by a bijective mix of their 14-bit code (odd multiplies and
 // xor-shifts are invertible mod 2^14, so distinct 7-mers never tie): FK_NRANKS rank values, of which
 // the 8192 images of canonical codes occur.
+#define FK_REGION_SLACK 32768              // records of room a streamed bucket region needs beyond its exact count (ragged stream ends)
 #define FKX_TABLE_FULL 100                   // fkx_aggregate: the table buffer took fewer records than qualified (internal)
 #define FK_CBASE_EXTRA ((2 << 20) + 64)      // partition sums of the chunk scan behind the chunk bases (fk_split.hip)
 #define FK_CURSOR_STRIDE 512

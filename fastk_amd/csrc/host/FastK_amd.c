@@ -46,6 +46,7 @@
 #include <time.h>
 #include <sys/types.h>
 #include <sys/wait.h>
+#include <signal.h>
 
 #include "../../../include/fastk_amd.h"
 
@@ -136,8 +137,10 @@ static void flush_block(Feeder *f, int rem)
       f->pbytes += pr.nbytes;
       f->preads += pr.nreads;
     }
-  else if (RANK >= 0 && NGPUS > 1 && !rem && (BLOCK_NO++ % NGPUS) != RANK)
-    ;                               /* another rank's block (any division of the reads gives the same counts) */
+  else if (RANK >= 0 && NGPUS > 1 && (BLOCK_NO++ % NGPUS) != RANK)
+    ;                               /* another rank's block (any division of the reads gives the same counts; a piece
+                                       of a read cut at a block edge carries its K-1 overlap, so it is dealt like any
+                                       other block -- every rank pushing it would count its k-mers NGPUS times) */
   else if (fk_push_block(f->ctx,f->bases,f->boff,f->nreads,rem,0) != FK_OK)
     die(f->ctx,"fk_push_block");
   f->nreads  = 0;
@@ -595,20 +598,27 @@ static void scan_bam(Feeder *f, const char *path)
    FK_RANKS_SHARE_GPU=1 (test rig for boxes with a single GPU): all ranks use device 0 and get a NCCL_HOSTID of
    their own, so that RCCL accepts them and moves the payload over its socket transport. */
 static int launch_ranks(int argc, char **argv)
-{ char  idfile[256], self[4096];
+{ char  iddir[64], idfile[128], self[4096];
   pid_t pid[64];
-  int   r, status, rc = 0;
+  int   r, left, status, rc = 0;
   ssize_t sl = readlink("/proc/self/exe",self,sizeof(self)-1);
 
   if (sl <= 0 || NGPUS > 64)
     { fprintf(stderr,"%s: cannot start %d ranks\n",Prog_Name,NGPUS); exit (1); }
   self[sl] = '\0';
-  snprintf(idfile,sizeof(idfile),"/tmp/.fastk_amd_id_%d_%ld",(int) getpid(),(long) time(NULL));
-  unlink(idfile);
+  /* the id travels through a file in a directory of our own (mode 0700): nobody else can plant or follow it */
+  snprintf(iddir,sizeof(iddir),"/tmp/fastk_amd_XXXXXX");
+  if (mkdtemp(iddir) == NULL)
+    { fprintf(stderr,"%s: cannot create a directory in /tmp\n",Prog_Name); exit (1); }
+  snprintf(idfile,sizeof(idfile),"%s/id",iddir);
   for (r = 0; r < NGPUS; r++)
     { pid[r] = fork();
       if (pid[r] < 0)
-        { fprintf(stderr,"%s: fork failed\n",Prog_Name); exit (1); }
+        { fprintf(stderr,"%s: fork failed\n",Prog_Name);
+          for (left = 0; left < r; left++)
+            kill(pid[left],SIGKILL);
+          exit (1);
+        }
       if (pid[r] == 0)
         { char **av = malloc(sizeof(char *)*(argc+3));
           char  *a1 = malloc(64), *a2 = malloc(300);
@@ -629,10 +639,33 @@ static int launch_ranks(int argc, char **argv)
           _exit (1);
         }
     }
-  for (r = 0; r < NGPUS; r++)
-    if (waitpid(pid[r],&status,0) < 0 || !WIFEXITED(status) || WEXITSTATUS(status) != 0)
-      rc = 1;
+  /* whichever rank ends first is looked at first: when one fails its peers sit in a collective that will never
+     complete, so they are ended instead of waited for */
+  for (left = NGPUS; left > 0; left--)
+    { pid_t w = waitpid(-1,&status,0);
+      if (w < 0)
+        { rc = 1; break; }
+      for (r = 0; r < NGPUS; r++)
+        if (pid[r] == w)
+          pid[r] = -1;
+      if (!WIFEXITED(status) || WEXITSTATUS(status) != 0)
+        { if (rc == 0)
+            { fprintf(stderr,"%s: a rank failed; ending the others\n",Prog_Name);
+              for (r = 0; r < NGPUS; r++)
+                if (pid[r] > 0)
+                  kill(pid[r],SIGTERM);
+              usleep(200000);
+              for (r = 0; r < NGPUS; r++)
+                if (pid[r] > 0)
+                  kill(pid[r],SIGKILL);
+            }
+          rc = 1;
+        }
+    }
   unlink(idfile);
+  snprintf(self,sizeof(self),"%s.tmp",idfile);
+  unlink(self);
+  rmdir(iddir);
   return (rc);
 }
 
@@ -758,8 +791,10 @@ int main(int argc, char *argv[])
     }
   if (nfiles < 1 || KMER <= 0 || NTHREADS <= 0 || DO_TABLE < 0 || BC_PREFIX < 0)
     { fprintf(stderr,"\nUsage: %s [-k<int(40)>] [-t[<int(1)>]] [-p[:<table>[.ktab]]] [-c] [-bc<int>] [-v] [-x] [-N<path_name>]\n",Prog_Name);
-      fprintf(stderr,"       %*s [-P<dir>] [-M<int>] [-T<int(4)>] <source>[.fa|.fasta|.fq|.fastq][.gz]|.sam|.bam ...\n",
+      fprintf(stderr,"       %*s [-P<dir>] [-M<int>] [-T<int(4)>] [-G<int(1)>] <source>[.fa|.fasta|.fq|.fastq][.gz]|.sam|.bam ...\n",
               (int) strlen(Prog_Name),"");
+      fprintf(stderr,"\n      -G: number of GPUs (one process per GPU, minimizer buckets exchanged over RCCL; k-mer counting only)\n");
+      fprintf(stderr,"      -x: reproduce the reference's super-mer cuts, hence its hidden .ktab part boundaries (slower)\n");
       exit (1);
     }
 
@@ -771,6 +806,9 @@ int main(int argc, char *argv[])
     { fprintf(stderr,"%s: -G%d counts k-mers (.hist, .ktab); -p and -x run on one GPU\n",Prog_Name,NGPUS);
       exit (1);
     }
+  if (NGPUS > 1 && MEM_GB > 0 && RANK < 0)
+    fprintf(stderr,"%s: warning: -M%d is ignored with -G%d (every rank keeps its stripe of the reads resident)\n",
+            Prog_Name,MEM_GB,NGPUS);
   if (NGPUS > 1 && RANK < 0)
     return (launch_ranks(argc0,argv0));
 

@@ -790,6 +790,52 @@ def test_c_driver_sharded_over_rccl_writes_the_one_gpu_files(name, fmt, ranks, t
     assert t["stream_sha256"] == exp["ktab"]["stream_sha256"] and t["nels"] == exp["ktab"]["nels"]
 
 
+@pytest.mark.parametrize("how", ["gz", "hoco"])
+def test_c_driver_sharded_deals_pieces_of_long_reads(how, tmp_path):
+    """-G2 with input the HOST parses (gzipped FASTA; -c on plain FASTA) holding a read of 20 Mbp: the driver cuts it
+    into 8 MB blocks with a K-1 overlap (rem > 0, io.c:557-570) and deals the pieces to the ranks like any other
+    block.  (Round 2 pushed every cut piece on EVERY rank: the k-mers of long reads were counted once per rank and
+    the conservation checks could not see it.)  Every file must equal the one-GPU run's, and the histogram must
+    count every k-mer instance once."""
+    import gzip, os, subprocess
+    rng = np.random.default_rng(77)
+    acgt = np.frombuffer(b"acgt", dtype=np.uint8)
+    reads = [acgt[rng.integers(0, 4, size=n)] for n in (20_000_000, 3000, 9_000_000, 150, 40)]
+    if how == "hoco":                            # no homopolymer runs: -c keeps every base, the counts stay checkable
+        for r in reads:
+            same = np.nonzero(r[1:] == r[:-1])[0] + 1
+            while len(same):
+                r[same] = acgt[(np.searchsorted(acgt, r[same]) + 1 + (same & 1)) % 4]
+                same = np.nonzero(r[1:] == r[:-1])[0] + 1
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "fastk_amd", "bin", "FastK_amd")
+    path = str(tmp_path / ("long.fa.gz" if how == "gz" else "long.fa"))
+    with (gzip.open(path, "wb", compresslevel=1) if how == "gz" else open(path, "wb")) as f:
+        for i, r in enumerate(reads):
+            f.write(b">r%d\n" % i)
+            f.write(r.tobytes())
+            f.write(b"\n")
+    k, T = 40, 4
+    args = ["-k%d" % k, "-t1", "-T%d" % T] + (["-c"] if how == "hoco" else [])
+    one, many = tmp_path / "one", tmp_path / "many"
+    one.mkdir(); many.mkdir()
+    subprocess.run([exe] + args + ["-N" + str(one / "x"), path], check=True)
+    p = subprocess.run([exe] + args + ["-G2", "-N" + str(many / "x"), path], env=dict(os.environ, FK_RANKS_SHARE_GPU="1"),
+                       capture_output=True, text=True, timeout=900)
+    if p.returncode != 0 and any(m in p.stdout + p.stderr for m in _RCCL_RIG_ERRORS) and os.environ.get("FK_REQUIRE_RANKS") != "1":
+        pytest.skip("RCCL would not bring up several ranks on one GPU here: " + p.stderr[-300:])
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    files = sorted(os.listdir(one))
+    assert files == sorted(os.listdir(many)) and len(files) == 2 + T
+    for f in files:
+        assert util.sha_file(one / f) == util.sha_file(many / f), f
+    h = orc.read_hist(str(many / "x.hist"))
+    hist = np.asarray(h["hist"], dtype=np.int64)
+    cnt = np.arange(h["low"], h["low"] + len(hist))
+    inst = sum(len(r) - k + 1 for r in reads)
+    assert int((hist[:-1] * cnt[:-1]).sum()) + int(h["ihigh"]) == inst
+
+
 @pytest.mark.parametrize("ranks", [2, 4])
 def test_ranks_on_one_gpu_match_one_context(ranks):
     """A real exchange between processes: `ranks` RCCL ranks share device 0 (tools/ranks_on_one_gpu.py
