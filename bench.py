@@ -370,6 +370,46 @@ def e2e_leg(args, cfg, fastk_amd, ctx_gen, L):
         subprocess.run(["rm", "-rf", d])
 
 
+def shim_leg(args, cfg):
+    """The reference's own main() over the C-ABI shim (oracle/_ref/FastK_gpu) on the small sample
+    the CPU reference's thread sweep runs on: fast (default) and FASTK_AMD_EXACT=1, process start to exit."""
+    from oracle import orc
+    exe = os.path.join(orc.REF_DIR, "FastK_gpu")
+    if not os.path.exists(exe):
+        return dict(skipped="oracle/_ref/FastK_gpu not built")
+    L = cfg["read_len"]
+    glen = int(20e6)
+    nreads = int(cfg["coverage"] * glen / L)
+    inst = nreads * (L - args.kmer + 1)
+    fastq = L <= 1000
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    d = tempfile.mkdtemp(prefix="fkshim", dir=base)
+    try:
+        path = os.path.join(d, "s.fastq" if fastq else "s.fasta")
+        _write_sample(path, orc, args.seed, glen, L, cfg["err_ppm"], nreads, fastq)
+        out = dict(sample="%gx coverage of a 20 Mbp genome, %d x %d bp reads" % (cfg["coverage"], nreads, L),
+                   definition="process start -> exit of the reference's main() linked against libfastk_amd.so "
+                              "(-T8, io.c's reader threads feed fk_push_block); best of 2")
+        for mode in ("fast", "exact"):
+            env = dict(os.environ)
+            env.pop("FASTK_AMD_EXACT", None)
+            if mode == "exact":
+                env["FASTK_AMD_EXACT"] = "1"
+            best = None
+            for _ in range(2):
+                t0 = time.perf_counter()
+                p = subprocess.run([exe, "-k%d" % args.kmer, "-t%d" % cfg["cutoff"], "-T8", "-P" + d, path], cwd=d, env=env,
+                                   stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+                if p.returncode != 0:
+                    return dict(failed="FastK_gpu (%s) exit %d: %s" % (mode, p.returncode, p.stderr[-400:]))
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            out[mode] = dict(seconds=round(best, 3), value=inst / best, unit="k-mers/s")
+        return out
+    finally:
+        subprocess.run(["rm", "-rf", d])
+
+
 def main_config3(args, cfg, torch, fastk_amd, dist, rank, local_rank, world, dev):
     """BASELINE configs[3]: the 50x HiFi-shaped 3 Gbp set of configs[2], striped over the GPUs (rank r generates
     reads r*n/world ..), counted through the C engine's sharded entry points (fk_shard_count_device: planned
@@ -670,6 +710,11 @@ def main():
                 out["value_e2e"] = dict(failed=repr(e)[-600:])
             log(args, "e2e leg %.1f s" % (time.perf_counter() - t0), out["value_e2e"])
         gen.close()
+        if not args.no_e2e:
+            try:
+                out["value_e2e_reference_main"] = shim_leg(args, cfg)
+            except Exception as e:
+                out["value_e2e_reference_main"] = dict(failed=repr(e)[-600:])
         if not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args, cfg)

@@ -35,7 +35,17 @@ int Determine_Scheme(DATA_BLOCK *block)
   fk_default_params(&p);
   p.kmer = KMER; p.nthreads = NTHREADS; p.bc_prefix = BC_PREFIX;
   p.table_cutoff = DO_PROFILE ? 1 : DO_TABLE;      /* profiles look every k-mer up in the table */
+  /* Fast by default: the position-parallel splitter; .hist, the .ktab stub and the concatenated part payloads are
+     the reference's byte for byte, only the hidden part files are cut at other first bytes.  FASTK_AMD_EXACT=1 in
+     the environment (or -DFASTK_AMD_EXACT at build time) replays the reference's own super-mer cuts instead: every
+     file byte-identical, the split ~10x slower. */
+#ifdef FASTK_AMD_EXACT
   p.exact_parts = 1;
+#else
+  { const char *e = getenv("FASTK_AMD_EXACT");
+    p.exact_parts = (e != NULL && e[0] != '\0' && e[0] != '0');
+  }
+#endif
   if (fk_create(&p,&GPU) != FK_OK)
     die("fk_create");
   if (fk_train_block(GPU,block->bases,block->boff,block->nreads) != FK_OK)   /* split.c:529-575 */

@@ -1073,20 +1073,34 @@ def test_exact_parts_mode_reproduces_reference_files(name, tmp_path):
 def test_reference_main_over_gpu_shim(name, fmt, tmp_path):
     """oracle/_ref/FastK_gpu = the REFERENCE's own main(), option parser and multi-threaded input layer
     (FastK.c, io.c compiled where they lie) linked against libfastk_amd.so through the INTEGRATION.md
-    shim.  Its output files must be the reference's, byte for byte."""
+    shim.  By default it takes the fast splitter: .hist bytes, the .ktab stub fields and the canonical stream are
+    the reference's.  With FASTK_AMD_EXACT=1 every output file is the reference's, byte for byte."""
     import hashlib, os, subprocess
     exe = os.path.join(orc.REF_DIR, "FastK_gpu")
     if not os.path.exists(exe):
         pytest.skip("oracle/_ref/FastK_gpu not built (needs the reference sources at build time)")
     case, bases, boff = util.load_case(name)
-    path = str(tmp_path / ("x." + fmt))
-    orc.write_fasta(path, bases, boff, width=0 if case["kind"] == "edge" else 100)
-    subprocess.run([exe, "-k%d" % case["k"], "-t%d" % case["cutoff"], "-T%d" % case["T"],
-                    "-P" + str(tmp_path), path], check=True, cwd=str(tmp_path),
-                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    for fname, digest in case["expected"]["file_sha256"].items():
-        got = hashlib.sha256(open(tmp_path / fname, "rb").read()).hexdigest()
-        assert got == digest, fname
+    exp = case["expected"]
+    for mode in ("fast", "exact"):
+        d = tmp_path / mode
+        d.mkdir()
+        path = str(d / ("x." + fmt))
+        orc.write_fasta(path, bases, boff, width=0 if case["kind"] == "edge" else 100)
+        env = dict(os.environ)
+        env.pop("FASTK_AMD_EXACT", None)
+        if mode == "exact":
+            env["FASTK_AMD_EXACT"] = "1"
+        subprocess.run([exe, "-k%d" % case["k"], "-t%d" % case["cutoff"], "-T%d" % case["T"],
+                        "-P" + str(d), path], check=True, cwd=str(d), env=env,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        assert util.sha_file(d / "x.hist") == exp["hist_sha256"], mode
+        t = orc.read_ktab(str(d / "x"))
+        assert t["stream_sha256"] == exp["ktab"]["stream_sha256"], mode
+        assert (t["kmer"], t["nparts"], t["minval"], t["ibytes"], t["nels"]) == \
+            (case["k"], case["T"], case["cutoff"], exp["ktab"]["ibytes"], exp["ktab"]["nels"]), mode
+        if mode == "exact":
+            for fname, digest in exp["file_sha256"].items():
+                assert util.sha_file(d / fname) == digest, fname
 
 
 @pytest.mark.parametrize("name", ["edge_k40_t4_T1", "synth_illumina_k40_t1_T4", "synth_hifi_k40_t4_T8"])
@@ -1103,7 +1117,7 @@ def test_reference_main_with_profiles_over_gpu_shim(name, tmp_path):
     path = str(tmp_path / "x.fasta")
     orc.write_fasta(path, bases, boff, width=0 if case["kind"] == "edge" else 100)
     subprocess.run([exe, "-k%d" % k, "-t%d" % case["cutoff"], "-T%d" % case["T"], "-p",
-                    "-P" + str(tmp_path), path], check=True, cwd=str(tmp_path),
+                    "-P" + str(tmp_path), path], check=True, cwd=str(tmp_path), env=dict(os.environ, FASTK_AMD_EXACT="1"),
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     for fname, digest in case["expected"]["file_sha256"].items():
         assert hashlib.sha256(open(tmp_path / fname, "rb").read()).hexdigest() == digest, fname
@@ -1262,7 +1276,8 @@ def test_drivers_against_reference_digests_above_fixture_size(name, tmp_path):
         for f in os.listdir(tmp_path):
             if f != os.path.basename(path):
                 os.remove(tmp_path / f)
-        subprocess.run(cmd, check=True, cwd=str(tmp_path), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        subprocess.run(cmd, check=True, cwd=str(tmp_path), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                       env=dict(os.environ, FASTK_AMD_EXACT="1"))
         for fname, digest in exp["file_sha256"].items():
             assert util.sha_file(tmp_path / fname) == digest, (os.path.basename(cmd[0]), fname)
 
