@@ -28,7 +28,7 @@ EXPORTS = [
     "fk_make_profiles", "fk_write_prof", "fk_set_table", "fk_ktab_idx_bytes", "fk_ktab_split",
     "fk_write_ktab_range", "fk_write_ktab_stub", "fk_split_supermers_emit_pos", "fk_profile_lookup_supermers",
     "fk_profile_scatter", "fk_profile_encode", "fk_reset", "fk_shard_unique_id", "fk_shard_create",
-    "fk_shard_count", "fk_shard_write", "fk_shard_destroy", "fk_shard_count_device", "fk_shard_local_result",
+    "fk_shard_count", "fk_shard_gather", "fk_shard_write", "fk_shard_destroy", "fk_shard_count_device", "fk_shard_local_result",
 ]
 
 
@@ -117,6 +117,7 @@ def load_library():
     L.fk_shard_count_device.argtypes = [vp, vp, i64, C.POINTER(CResult)]
     L.fk_shard_local_result.argtypes = [vp, C.POINTER(CResult)]
     L.fk_shard_write.argtypes = [vp, C.POINTER(CResult), ci, C.c_char_p, C.c_char_p]
+    L.fk_shard_gather.argtypes = [vp, C.POINTER(CResult), ci, C.POINTER(vp), C.POINTER(i64)]
     L.fk_shard_destroy.argtypes = [vp]
     L.fk_shard_destroy.restype = None
     L.fk_count_device_reads.argtypes = [vp, vp, i64, ci, C.POINTER(CResult)]
@@ -542,6 +543,19 @@ class Shard:
         r = CResult()
         self.ctx._ck(self.ctx.L.fk_shard_local_result(self.h, C.byref(r)))
         return Result(r, self.ctx.w.kmer_word)
+
+    def gather(self, res, nparts, copy=False):
+        """C3 alone: this rank's first-byte range of the whole table (parts rank*m+1 .. rank*m+m of an nparts-part
+        .ktab), ordered, in pinned host memory owned by the shard.  Returns the entry count, or with copy=True the
+        entries as an (n, KMER_BYTES + 2) uint8 array."""
+        p, n = C.c_void_p(), C.c_int64()
+        self.ctx._ck(self.ctx.L.fk_shard_gather(self.h, C.byref(res._c), nparts, C.byref(p), C.byref(n)))
+        if not copy:
+            return n.value
+        kw = self.ctx.w.kmer_word
+        if n.value == 0:
+            return np.zeros((0, kw), dtype=np.uint8)
+        return np.ctypeslib.as_array(C.cast(p.value, C.POINTER(C.c_uint8)), shape=(n.value * kw,)).reshape(n.value, kw).copy()
 
     def write(self, res, nparts, outdir, root):
         self.ctx._ck(self.ctx.L.fk_shard_write(self.h, C.byref(res._c), nparts, outdir.encode(), root.encode()))

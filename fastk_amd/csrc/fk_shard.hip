@@ -86,6 +86,14 @@ struct fk_shard
   int64_t     inbox_cap[2];
   fk_result   local;              // this rank's own result (its table stays in HBM, in ctx)
   int64_t     lfirst[256];        // first-byte census of this rank's table
+  // C3 (fk_shard_gather): this rank's range of the whole table, ordered, in pinned host memory; kept for the next run
+  char       *g_dev[2];
+  int64_t     g_dev_cap;          // bytes each
+  uint8_t    *g_host;
+  int64_t     g_host_cap;
+  int64_t     g_n;                // entries gathered (-1: none)
+  int         g_nparts, g_ib;
+  int         g_split[257];
 };
 
 extern "C" int fk_shard_unique_id(char *id128)
@@ -114,6 +122,9 @@ extern "C" void fk_shard_destroy(fk_shard *sh)
   if (sh->xs) hipStreamDestroy(sh->xs);
   if (sh->d_small) hipFree(sh->d_small);
   if (sh->h_small) hipHostFree(sh->h_small);
+  for (int i = 0; i < 2; i++)
+    if (sh->g_dev[i]) hipFree(sh->g_dev[i]);
+  if (sh->g_host) fkx_pinned_free(sh->g_host);
   free(sh);
 }
 
@@ -378,34 +389,33 @@ static int shard_count(fk_shard *sh, const void *d_reads, int64_t reads_len, fk_
   return (FK_OK);
 }
 
-/* C3 + output files after fk_shard_count: <dir>/<root>.hist and the .ktab stub from rank 0, the hidden parts
-   .<root>.ktab.<rank*m+1 .. rank*m+m> from every rank (m = nparts / world; nparts must be a multiple of the
-   ranks).  With table_cutoff 0 only the histogram is written.  The files are byte for byte those
-   fk_write_hist / fk_write_ktab write in a one-GPU run with -T nparts. */
-extern "C" int fk_shard_write(fk_shard *sh, const fk_result *res, int nparts, const char *dir, const char *root)
-{ if (sh == NULL || res == NULL || dir == NULL || root == NULL) return (FK_EINVAL);
+/* C3, the final gather after fk_shard_count: rank d receives the entries of the first-byte ranges of parts
+   d*m .. d*m+m-1 (m = nparts / world; the boundaries are Table_Split's, count.c:1560-1565, over the all-reduced
+   census) from every rank's sorted table -- a second exchange over RCCL --, orders its `world` runs of disjoint
+   k-mers with the radix engine and brings the range to pinned host memory.  Replaces the heap merge of the bucket
+   tables (table.c:346-533).  *table stays valid until the next gather or fk_shard_destroy; device and host buffers
+   are kept for the next run. */
+extern "C" int fk_shard_gather(fk_shard *sh, const fk_result *res, int nparts, const uint8_t **table, int64_t *nentries)
+{ if (sh == NULL || res == NULL) return (FK_EINVAL);
   fk_ctx *ctx = sh->ctx;
   const int W = sh->world, me = sh->rank;
   const fk_widths &w = ctx->wid;
-  const int cutoff = ctx->prm.table_cutoff;
+  if (table) *table = NULL;
+  if (nentries) *nentries = 0;
+  sh->g_n = -1;
   FK_HIP(ctx, hipSetDevice(ctx->device));
-  if (me == 0)
-    { char path[4096];
-      snprintf(path, sizeof(path), "%s/%s.hist", dir, root);
-      int rc = fk_write_hist(res, ctx->prm.kmer, path);
-      if (rc != FK_OK) return (rc);
+  if (ctx->prm.table_cutoff <= 0)
+    { fk_set_error(ctx, "fk_shard_gather: no table was asked for (table_cutoff 0)");
+      return (FK_EINVAL);
     }
-  if (cutoff <= 0)
-    return (FK_OK);
-  if (nparts < W || nparts % W != 0)
-    { fk_set_error(ctx, "fk_shard_write: %d parts cannot be dealt to %d ranks", nparts, W);
+  if (nparts < W || nparts % W != 0 || nparts > 256)
+    { fk_set_error(ctx, "fk_shard_gather: %d parts cannot be dealt to %d ranks", nparts, W);
       return (FK_EINVAL);
     }
   const int m = nparts / W;
-  std::vector<int> split(nparts + 1);
-  int rc = fk_ktab_split(res->wfirst, ctx->prm.kmer, nparts, split.data());
+  int *split = sh->g_split;
+  int rc = fk_ktab_split(res->wfirst, ctx->prm.kmer, nparts, split);
   if (rc != FK_OK) return (rc);
-  const int ib = fk_ktab_idx_bytes(ctx->prm.kmer, res->ntable);
 
   // this rank's sorted table: the entries of first-byte range d go to rank d
   const char *tab = (const char *) ctx->last_table;
@@ -413,7 +423,7 @@ extern "C" int fk_shard_write(fk_shard *sh, const fk_result *res, int nparts, co
   pre[0] = 0;
   for (int x = 0; x < 256; x++) pre[x + 1] = pre[x] + sh->lfirst[x];
   if (pre[256] != ctx->last_ntab)
-    { fk_set_error(ctx, "fk_shard_write: census (%lld) and table (%lld entries) disagree", (long long) pre[256],
+    { fk_set_error(ctx, "fk_shard_gather: census (%lld) and table (%lld entries) disagree", (long long) pre[256],
                    (long long) ctx->last_ntab);
       return (FK_ESTATE);
     }
@@ -424,82 +434,119 @@ extern "C" int fk_shard_write(fk_shard *sh, const fk_result *res, int nparts, co
   int64_t nin = 0;
   for (int s = 0; s < W; s++) nin += all[(size_t) s * W + me];
   const int64_t bytes = std::max<int64_t>(nin, 1) * w.kmer_stride;
-  char *a = NULL, *b = NULL;
-  if (hipMalloc((void **) &a, (size_t) bytes) != hipSuccess || hipMalloc((void **) &b, (size_t) bytes) != hipSuccess)
-    { if (a) hipFree(a);
-      fk_set_error(ctx, "out of HBM: cannot allocate 2 x %lld bytes for this rank's range of the table", (long long) bytes);
-      return (FK_ENOMEM);
-    }
-  do
-    { char   *sp[256], *rp[256];
-      int64_t sb[256], rb[256], run = 0;
-      for (int p = 0; p < W; p++)
-        { sp[p] = (char *) tab + pre[split[p * m]] * w.kmer_stride;
-          sb[p] = mine[p] * w.kmer_stride;
-          rp[p] = a + run * w.kmer_stride;
-          rb[p] = all[(size_t) p * W + me] * w.kmer_stride;
-          run += all[(size_t) p * W + me];
+  if (bytes > sh->g_dev_cap)
+    { for (int i = 0; i < 2; i++)
+        { if (sh->g_dev[i]) hipFree(sh->g_dev[i]);
+          sh->g_dev[i] = NULL;
         }
+      sh->g_dev_cap = 0;
+      const int64_t want = bytes + bytes / 16;
+      if (hipMalloc((void **) &sh->g_dev[0], (size_t) want) != hipSuccess
+          || hipMalloc((void **) &sh->g_dev[1], (size_t) want) != hipSuccess)
+        { fk_set_error(ctx, "out of HBM: cannot allocate 2 x %lld bytes for this rank's range of the table", (long long) want);
+          return (FK_ENOMEM);
+        }
+      sh->g_dev_cap = want;
+    }
+  const int64_t hbytes = std::max<int64_t>(nin, 1) * w.kmer_word;
+  if (hbytes > sh->g_host_cap)
+    { if (sh->g_host) fkx_pinned_free(sh->g_host);
+      sh->g_host = NULL;
+      sh->g_host_cap = 0;
+      const int64_t want = hbytes + hbytes / 16;
+      if (fkx_pinned_alloc((void **) &sh->g_host, want) != FK_OK)
+        { fk_set_error(ctx, "out of host memory: cannot pin %lld bytes for this rank's table range", (long long) want);
+          return (FK_ENOMEM);
+        }
+      sh->g_host_cap = want;
+    }
+  char *a = sh->g_dev[0], *b = sh->g_dev[1];
+  char   *sp[256], *rp[256];
+  int64_t sb[256], rb[256], run = 0;
+  for (int p = 0; p < W; p++)
+    { sp[p] = (char *) tab + pre[split[p * m]] * w.kmer_stride;
+      sb[p] = mine[p] * w.kmer_stride;
+      rp[p] = a + run * w.kmer_stride;
+      rb[p] = all[(size_t) p * W + me] * w.kmer_stride;
+      run += all[(size_t) p * W + me];
+    }
+  FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if ((rc = exchange(sh, sp, sb, rp, rb)) != FK_OK) return (rc);
+  FK_HIP(ctx, hipStreamSynchronize(sh->xs));
+  // W sorted runs of disjoint k-mer sets -> one sorted range
+  void *sorted = a;
+  int   bytes_list[64];
+  for (int i = 0; i < w.kmer_bytes; i++) bytes_list[i] = w.kmer_bytes - 1 - i;
+  if (W > 1 && nin > 0
+      && (rc = fkx_lsd_sort(ctx, nin, a, b, w.kmer_stride, bytes_list, w.kmer_bytes, &sorted)) != FK_OK)
+    return (rc);
+  const void *src = sorted;
+  if (w.kmer_word != w.kmer_stride && nin > 0)
+    { void *other = (sorted == (void *) a) ? (void *) b : (void *) a;
+      if ((rc = fkx_repack_table(ctx, sorted, nin, other)) != FK_OK)
+        return (rc);
+      src = other;
+    }
+  if (nin > 0)
+    { FK_HIP(ctx, hipMemcpyAsync(sh->g_host, src, (size_t) (nin * w.kmer_word), hipMemcpyDeviceToHost, ctx->stream));
       FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-      if ((rc = exchange(sh, sp, sb, rp, rb)) != FK_OK) break;
-      if (hipStreamSynchronize(sh->xs) != hipSuccess) { rc = FK_EHIP; break; }
-      // W sorted runs of disjoint k-mer sets -> one sorted range
-      void *sorted = a;
-      int   bytes_list[64];
-      for (int i = 0; i < w.kmer_bytes; i++) bytes_list[i] = w.kmer_bytes - 1 - i;
-      if (W > 1 && nin > 0
-          && (rc = fkx_lsd_sort(ctx, nin, a, b, w.kmer_stride, bytes_list, w.kmer_bytes, &sorted)) != FK_OK)
-        break;
-      const int64_t hbytes = std::max<int64_t>(nin, 1) * w.kmer_word;
-      uint8_t *host = NULL;
-      if (fkx_pinned_alloc((void **) &host, hbytes) != FK_OK)
-        { fk_set_error(ctx, "out of host memory: cannot pin %lld bytes for this rank's table range", (long long) hbytes);
-          rc = FK_ENOMEM;
-          break;
-        }
-      const void *src = sorted;
-      if (w.kmer_word != w.kmer_stride && nin > 0)
-        { void *other = (sorted == (void *) a) ? (void *) b : (void *) a;
-          if ((rc = fkx_repack_table(ctx, sorted, nin, other)) != FK_OK)
-            { fkx_pinned_free(host); break; }
-          src = other;
-        }
-      if (nin > 0
-          && (hipMemcpyAsync(host, src, (size_t) (nin * w.kmer_word), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess
-              || hipStreamSynchronize(ctx->stream) != hipSuccess))
-        { fkx_pinned_free(host); rc = FK_EHIP; break; }
-      int64_t npre = 1;
-      for (int i = 0; i < ib; i++) npre *= 256;
-      std::vector<int64_t> pc((size_t) npre, 0);
-      rc = fk_write_ktab_range(host, nin, ctx->prm.kmer, ib, split.data(), me * m, m, dir, root, pc.data());
-      fkx_pinned_free(host);
-      if (rc != FK_OK) break;
-      // per-prefix entry counts of all ranks -> rank 0 writes the stub
-      int64_t *d_pc = NULL;
-      if (hipMalloc((void **) &d_pc, (size_t) npre * 8) != hipSuccess) { rc = FK_ENOMEM; break; }
-      if (hipMemcpyAsync(d_pc, pc.data(), (size_t) npre * 8, hipMemcpyHostToDevice, sh->xs) != hipSuccess
-          || g_rccl.AllReduce(d_pc, d_pc, (size_t) npre, ncclInt64, ncclSum, sh->comm, sh->xs) != ncclSuccess
-          || hipMemcpyAsync(pc.data(), d_pc, (size_t) npre * 8, hipMemcpyDeviceToHost, sh->xs) != hipSuccess
-          || hipStreamSynchronize(sh->xs) != hipSuccess)
-        { hipFree(d_pc);
-          fk_set_error(ctx, "fk_shard_write: reducing the prefix counts failed");
-          rc = FK_EHIP;
-          break;
-        }
-      hipFree(d_pc);
-      int64_t tot = 0;
-      for (int64_t i = 0; i < npre; i++) tot += pc[(size_t) i];
-      if (tot != res->ntable)
-        { fk_set_error(ctx, "sharded run: the table exchange lost entries (%lld written, %lld counted)", (long long) tot,
-                       (long long) res->ntable);
-          rc = FK_EHIP;
-          break;
-        }
-      if (me == 0)
-        rc = fk_write_ktab_stub(ctx->prm.kmer, nparts, cutoff, ib, pc.data(), dir, root);
     }
-  while (0);
-  hipFree(a);
-  hipFree(b);
+  sh->g_n = nin;
+  sh->g_nparts = nparts;
+  sh->g_ib = fk_ktab_idx_bytes(ctx->prm.kmer, res->ntable);
+  if (table) *table = sh->g_host;
+  if (nentries) *nentries = nin;
+  return (FK_OK);
+}
+
+/* Output files after fk_shard_count: <dir>/<root>.hist and the .ktab stub from rank 0, the hidden parts
+   .<root>.ktab.<rank*m+1 .. rank*m+m> from every rank (m = nparts / world; nparts must be a multiple of the
+   ranks), from the range fk_shard_gather brings in (called here).  With table_cutoff 0 only the histogram is
+   written.  The files are byte for byte those fk_write_hist / fk_write_ktab write in a one-GPU run with -T nparts. */
+extern "C" int fk_shard_write(fk_shard *sh, const fk_result *res, int nparts, const char *dir, const char *root)
+{ if (sh == NULL || res == NULL || dir == NULL || root == NULL) return (FK_EINVAL);
+  fk_ctx *ctx = sh->ctx;
+  const int W = sh->world, me = sh->rank;
+  const int cutoff = ctx->prm.table_cutoff;
+  FK_HIP(ctx, hipSetDevice(ctx->device));
+  if (me == 0)
+    { char path[4096];
+      snprintf(path, sizeof(path), "%s/%s.hist", dir, root);
+      int rc = fk_write_hist(res, ctx->prm.kmer, path);
+      if (rc != FK_OK) return (rc);
+    }
+  if (cutoff <= 0)
+    return (FK_OK);
+  const uint8_t *host = NULL;
+  int64_t nin = 0;
+  int rc = fk_shard_gather(sh, res, nparts, &host, &nin);
+  if (rc != FK_OK) return (rc);
+  const int m = nparts / W, ib = sh->g_ib;
+  int64_t npre = 1;
+  for (int i = 0; i < ib; i++) npre *= 256;
+  std::vector<int64_t> pc((size_t) npre, 0);
+  rc = fk_write_ktab_range(host, nin, ctx->prm.kmer, ib, sh->g_split, me * m, m, dir, root, pc.data());
+  if (rc != FK_OK) return (rc);
+  // per-prefix entry counts of all ranks -> rank 0 writes the stub
+  int64_t *d_pc = NULL;
+  if (hipMalloc((void **) &d_pc, (size_t) npre * 8) != hipSuccess) return (FK_ENOMEM);
+  if (hipMemcpyAsync(d_pc, pc.data(), (size_t) npre * 8, hipMemcpyHostToDevice, sh->xs) != hipSuccess
+      || g_rccl.AllReduce(d_pc, d_pc, (size_t) npre, ncclInt64, ncclSum, sh->comm, sh->xs) != ncclSuccess
+      || hipMemcpyAsync(pc.data(), d_pc, (size_t) npre * 8, hipMemcpyDeviceToHost, sh->xs) != hipSuccess
+      || hipStreamSynchronize(sh->xs) != hipSuccess)
+    { hipFree(d_pc);
+      fk_set_error(ctx, "fk_shard_write: reducing the prefix counts failed");
+      return (FK_EHIP);
+    }
+  hipFree(d_pc);
+  int64_t tot = 0;
+  for (int64_t i = 0; i < npre; i++) tot += pc[(size_t) i];
+  if (tot != res->ntable)
+    { fk_set_error(ctx, "sharded run: the table exchange lost entries (%lld written, %lld counted)", (long long) tot,
+                   (long long) res->ntable);
+      return (FK_EHIP);
+    }
+  if (me == 0)
+    rc = fk_write_ktab_stub(ctx->prm.kmer, nparts, cutoff, ib, pc.data(), dir, root);
   return (rc);
 }

@@ -402,6 +402,7 @@ int fk_rounds_finish(fk_ctx *ctx, int fetch_table, fk_result *res);
  *                                                  totals and first-byte census, identical on all ranks
  *                                                  (res.table is NULL: each rank's share stays in HBM);
  *                                                  fails if records or k-mer instances were not conserved
+ *                fk_shard_gather(sh, &res, nparts, &tab, &n)   C3 alone: this rank's range of the table, host memory
  *                fk_shard_write(sh, &res, nparts, dir, root)   C3 + files, byte for byte those of a one-GPU
  *                                                  run with -T nparts (nparts a multiple of world)
  *                fk_shard_destroy(sh); fk_destroy(ctx)
@@ -415,6 +416,11 @@ int  fk_shard_count(fk_shard *sh, fk_result *res);
 int  fk_shard_count_device(fk_shard *sh, const void *d_bases, int64_t nbytes, fk_result *res);
 /* this rank's own share of the last fk_shard_count (counts and per-kernel device times; table NULL) */
 int  fk_shard_local_result(fk_shard *sh, fk_result *res);
+/* C3 alone, the final gather of the north-star ("... per-GPU sort+count, then a final gather"; the reference's
+   counterpart is the heap merge of table.c:346-533): this rank's first-byte range of the whole table -- the parts
+   rank*m+1 .. rank*m+m of an nparts-part .ktab, m = nparts / world -- exchanged over RCCL, ordered, in pinned host
+   memory (KMER_BYTES + 2 bytes per entry; valid until the next gather / fk_shard_destroy). */
+int  fk_shard_gather(fk_shard *sh, const fk_result *res, int nparts, const uint8_t **table, int64_t *nentries);
 int  fk_shard_write(fk_shard *sh, const fk_result *res, int nparts, const char *dir, const char *root);
 void fk_shard_destroy(fk_shard *sh);
 

@@ -886,11 +886,12 @@ def test_bench_contract_with_two_ranks_on_one_gpu():
 @pytest.mark.parametrize("ranks", [1, 2])
 def test_bench_config3_through_the_c_shard_engine(ranks):
     """bench.py --config 3 (BASELINE configs[3]: the HiFi-shaped set striped over the GPUs, strong scaling) drives
-    fk_shard_count_device -- RCCL called from C -- under the driver's torch.distributed.run command line; at 1/1000
-    scale, two ranks on the one GPU.  Totals must equal a plain one-context count of the same reads."""
+    fk_shard_count_device and fk_shard_gather -- RCCL called from C -- under the driver's torch.distributed.run command
+    line; at 1/100 scale, two ranks on the one GPU.  Totals must equal a plain one-context count of the same reads, the
+    timed step includes the final gather (C3) and the ranks together hold every table entry."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    tail = [os.path.join(root, "bench.py"), "--gpus", str(ranks), "--scale", "0.001", "--steps", "2", "--warmup", "1"]
+    tail = [os.path.join(root, "bench.py"), "--gpus", str(ranks), "--scale", "0.01", "--steps", "2", "--warmup", "1"]
     if ranks == 1:
         tail += ["--config", "3"]                 # (with several ranks configs[3] is the default)
     if ranks == 1:
@@ -909,9 +910,11 @@ def test_bench_config3_through_the_c_shard_engine(ranks):
     assert len(lines) == 1, lines
     out = json.loads(lines[0])
     assert out["n_gpus"] == ranks and out["scaling"] == "strong" and "configs[3]" in out["config"]["workload"]
-    L, glen, k = 15000, 3_000_000, 40
+    L, glen, k = 15000, 30_000_000, 40
     nreads = int(50 * glen / L) // ranks * ranks
     assert out["config"]["kmer_instances"] == nreads * (L - k + 1)
+    assert out["gather_ms"] > 0 and out["count_ms"] > 0 and abs(out["gather_ms"] + out["count_ms"] - out["ms_per_step"]) < 1.0
+    assert out["config"]["gathered_entries"] == out["config"]["table_entries"] and "final gather" in out["metric"]
     with fastk_amd.Context(kmer=k, table_cutoff=4) as ctx:
         buf, n = ctx.synth_reads(20251001, glen, L, 2000, 0, nreads)
         ref = ctx.count_device_reads(buf.ptr, n, fetch_table=False)
