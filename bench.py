@@ -249,23 +249,30 @@ def copy_ceiling(torch, dev):
 
 def device_leg(args, cfg, fastk_amd, ctx_gen, glen, nreads, L, local_rank):
     """SURVEY 8(d) device pipeline: reads in pinned host memory -> fk_push_block (H2D) -> fk_finish ->
-    sorted table in pinned host memory.  Returns the record for the JSON line."""
+    sorted table in pinned host memory; then the same with the reads in two bits per base (fk_push_packed: a quarter of
+    the bytes over PCIe).  Returns the record for the JSON line."""
     import ctypes as C
     lib = ctx_gen.L
-    per_block = max(1, min(nreads, (1 << 30) // (L + 1)))         # ~1 GB DATA_BLOCKs (int32 offsets)
+    per_block = max(4, min(nreads, (1 << 30) // (L + 1)) // 4 * 4)  # ~1 GB DATA_BLOCKs (int32 offsets); whole code bytes
     nbytes = nreads * (L + 1)
-    host = C.c_void_p()
+    cbytes = (nreads * L + 3) // 4
+    host, hcodes = C.c_void_p(), C.c_void_p()
     t0 = time.perf_counter()
-    if lib.fk_host_alloc(nbytes + 64, C.byref(host)) != 0:
-        return dict(skipped="cannot pin %d bytes of host memory" % nbytes)
+    if lib.fk_host_alloc(nbytes + 64, C.byref(host)) != 0 or lib.fk_host_alloc(cbytes + 64, C.byref(hcodes)) != 0:
+        return dict(skipped="cannot pin %d bytes of host memory" % (nbytes + cbytes))
     t_pin = time.perf_counter() - t0
     piece = ctx_gen.alloc(per_block * (L + 1) + 64)
+    cpiece = ctx_gen.alloc(per_block * L // 4 + 64)
     for first in range(0, nreads, per_block):
         n = min(per_block, nreads - first)
         ctx_gen.synth_reads(args.seed, glen, L, cfg["err_ppm"], first, n, buf=piece)
         ctx_gen._ck(lib.fk_copy_to_host(ctx_gen.h, host.value + first * (L + 1), piece.ptr, n * (L + 1)))
+        ctx_gen._ck(lib.fk_pack_fixed_reads(ctx_gen.h, piece.ptr, n, L, cpiece.ptr))
+        ctx_gen._ck(lib.fk_copy_to_host(ctx_gen.h, hcodes.value + first * L // 4, cpiece.ptr, (n * L + 3) // 4))
     piece.free()
+    cpiece.free()
     boff = (np.arange(per_block + 1, dtype=np.int64) * (L + 1)).astype(np.int32)
+    rlen = np.full(per_block, L, dtype=np.int32)
     budget = int(args.device_budget_gb * 1e9)
     out = {}
     with fastk_amd.Context(kmer=args.kmer, table_cutoff=cfg["cutoff"], nthreads=4, device=local_rank,
@@ -276,34 +283,45 @@ def device_leg(args, cfg, fastk_amd, ctx_gen, glen, nreads, L, local_rank):
         if budget and cfg["buckets"] > 1:
             sample = np.ctypeslib.as_array(C.cast(host, C.POINTER(C.c_uint8)), shape=(min(nbytes, 8 << 20),))
             ctx.set_bucket_weights(ctx.bucket_census(sample))
-        times = []
-        for rep in range(2):                       # first run sizes the arenas and pins the table buffer
+        times, ref = {}, None
+        for rep, form in enumerate(("ascii", "ascii", "packed", "packed")):   # a form's first run sizes its buffers
             ctx.reset()
             t0 = time.perf_counter()
             for first in range(0, nreads, per_block):
                 n = min(per_block, nreads - first)
-                ctx._ck(lib.fk_push_block(ctx.h, host.value + first * (L + 1), boff.ctypes.data, n, 0, 0))
+                if form == "ascii":
+                    ctx._ck(lib.fk_push_block(ctx.h, host.value + first * (L + 1), boff.ctypes.data, n, 0, 0))
+                else:
+                    ctx._ck(lib.fk_push_packed(ctx.h, hcodes.value + first * L // 4, n * L, rlen.ctypes.data, n, None, 0, 0, 0))
             t_push = time.perf_counter() - t0
             res = fastk_amd.api.CResult()
             ctx._ck(lib.fk_finish(ctx.h, C.byref(res)))
-            times.append(time.perf_counter() - t0)
-            log(args, "device leg run %d: push %.3f s, finish %.3f s (device ms: split %.0f, super-mers %.0f, expand %.0f, "
+            times.setdefault(form, []).append(time.perf_counter() - t0)
+            log(args, "device leg run %d (%s): push %.3f s, finish %.3f s (device ms: split %.0f, super-mers %.0f, expand %.0f, "
                       "k-mers %.0f, count %.0f, table sort %.0f, total %.0f)" % (
-                rep, t_push, times[-1] - t_push, res.ms_split, res.ms_sort_super, res.ms_expand, res.ms_sort_kmer,
+                rep, form, t_push, times[form][-1] - t_push, res.ms_split, res.ms_sort_super, res.ms_expand, res.ms_sort_kmer,
                 res.ms_count, res.ms_table_sort, res.ms_total))
-        inst = int(res.ninst)
-        out = dict(value=inst / times[-1], unit="k-mers/s", seconds=round(times[-1], 3),
-                   first_run_seconds=round(times[0], 3), pin_seconds=round(t_pin, 2),
+            inst = int(res.ninst)
+            h = np.ctypeslib.as_array(res.hist).astype(np.int64)
+            conserved = int((h[1:0x7fff] * np.arange(1, 0x7fff)).sum()) + int(res.max_inst)
+            assert conserved == inst == nreads * (L - args.kmer + 1), "device leg (%s): %d k-mer instances counted, %d " \
+                "in the histogram, %d expected" % (form, inst, conserved, nreads * (L - args.kmer + 1))
+            sig = (h.tobytes(), int(res.max_inst), int(res.ntable))
+            assert ref is None or sig == ref, "device leg: the packed form gives another histogram"
+            ref = sig
+        out = dict(value=inst / times["ascii"][-1], unit="k-mers/s", seconds=round(times["ascii"][-1], 3),
+                   first_run_seconds=round(times["ascii"][0], 3), pin_seconds=round(t_pin, 2),
                    h2d_bytes=int(nbytes), d2h_bytes=int(res.ntable) * ctx.w.kmer_word,
                    table_entries=int(res.ntable), spilled_bytes=int(res.spilled_bytes),
                    hbm_budget_gb=args.device_budget_gb,
-                   definition="first H2D of pinned host reads (fk_push_block, ~1 GB blocks) -> sorted table "
-                              "in pinned host memory (fk_finish); second of two runs")
-        h = np.ctypeslib.as_array(res.hist).astype(np.int64)
-        conserved = int((h[1:0x7fff] * np.arange(1, 0x7fff)).sum()) + int(res.max_inst)
-        assert conserved == inst == nreads * (L - args.kmer + 1), "device leg: %d k-mer instances counted, %d " \
-            "in the histogram, %d expected" % (inst, conserved, nreads * (L - args.kmer + 1))
+                   definition="first H2D of pinned host reads (fk_push_block, ~1 GB blocks of ASCII) -> sorted table "
+                              "in pinned host memory (fk_finish); second of two runs",
+                   packed=dict(value=inst / times["packed"][-1], unit="k-mers/s", seconds=round(times["packed"][-1], 3),
+                               first_run_seconds=round(times["packed"][0], 3), h2d_bytes=int(cbytes + 4 * nreads),
+                               definition="the same with the reads in two bits per base in pinned host memory "
+                                          "(fk_push_packed: codes + read lengths; the device restores the ASCII reads in HBM)"))
     lib.fk_host_free(host)
+    lib.fk_host_free(hcodes)
     return out
 
 

@@ -28,7 +28,7 @@ EXPORTS = [
     "fk_make_profiles", "fk_write_prof", "fk_set_table", "fk_ktab_idx_bytes", "fk_ktab_split",
     "fk_write_ktab_range", "fk_write_ktab_stub", "fk_split_supermers_emit_pos", "fk_profile_lookup_supermers",
     "fk_profile_scatter", "fk_profile_encode", "fk_reset", "fk_shard_unique_id", "fk_shard_create",
-    "fk_shard_count", "fk_shard_gather", "fk_shard_write", "fk_shard_destroy", "fk_shard_count_device", "fk_shard_local_result",
+    "fk_release_device", "fk_push_packed", "fk_pack_fixed_reads", "fk_shard_count", "fk_shard_gather", "fk_shard_write", "fk_shard_destroy", "fk_shard_count_device", "fk_shard_local_result",
 ]
 
 
@@ -107,6 +107,8 @@ def load_library():
     L.fk_set_stream.argtypes = [vp, vp]
     L.fk_synchronize.argtypes = [vp]
     L.fk_push_block.argtypes = [vp, vp, vp, ci, ci, ci]
+    L.fk_push_packed.argtypes = [vp, vp, i64, vp, ci, vp, ci, ci, ci]
+    L.fk_pack_fixed_reads.argtypes = [vp, vp, i64, C.c_uint32, vp]
     L.fk_train_block.argtypes = [vp, vp, vp, ci]
     L.fk_push_device.argtypes = [vp, vp, i64]
     L.fk_finish.argtypes = [vp, C.POINTER(CResult)]
@@ -289,6 +291,15 @@ class Context:
         b = np.ascontiguousarray(bases, dtype=np.uint8)
         o = np.ascontiguousarray(boff, dtype=np.int32)
         self._ck(self.L.fk_push_block(self.h, b.ctypes.data, o.ctypes.data, len(o) - 1, rem, tid))
+
+    def push_packed(self, codes, nbases, rlen, inv=None, rem=0, tid=0):
+        """codes: uint8 array, 4 bases per byte (first base in the high bits), reads back to back; rlen: int32 lengths;
+        inv: int64 (n, 2) array of (first base, length) stretches without acgt."""
+        c = np.ascontiguousarray(codes, dtype=np.uint8)
+        r = np.ascontiguousarray(rlen, dtype=np.int32)
+        v = np.ascontiguousarray(inv if inv is not None else np.zeros((0, 2)), dtype=np.int64).reshape(-1, 2)
+        self._ck(self.L.fk_push_packed(self.h, c.ctypes.data, int(nbases), r.ctypes.data, len(r),
+                                       v.ctypes.data if len(v) else None, len(v), rem, tid))
 
     def bucket_census(self, sample):
         """sample: uint8 array of reads (host).  Returns the int64[16384] work census per minimizer rank."""

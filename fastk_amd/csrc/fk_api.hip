@@ -367,6 +367,8 @@ extern "C" void fk_destroy(fk_ctx *ctx)
   hipFree(ctx->d_digit_hist); hipFree(ctx->d_status); hipFree(ctx->d_ticket);
   hipFree(ctx->d_reads);
   hipFree(ctx->d_reads_alt);
+  hipFree(ctx->d_pk);
+  if (ctx->h_pk) hipHostFree(ctx->h_pk);
   if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
   if (ctx->reads_ev) hipEventDestroy(ctx->reads_ev);
   free(ctx->h_prof);
@@ -404,6 +406,55 @@ extern "C" void fk_destroy(fk_ctx *ctx)
       free(ctx->push_lock);
     }
   free(ctx);
+}
+
+/* Returns the context's device buffers (arena, slab store, read buffers) and its pinned staging and spill buffers
+   while the caller still works on the results of the last fk_finish, which stay valid (the table in host memory,
+   histogram, profiles).  May run in a thread of its own beside the file writers: returning 280 GB of HBM takes the
+   driver seconds, as long as writing a 36 GB table does.  The context can be used again afterwards (the buffers come
+   back on demand), but the device copy of the last table is gone. */
+extern "C" int fk_release_device(fk_ctx *ctx)
+{ if (ctx == NULL) return (FK_EINVAL);
+  FK_HIP(ctx, hipSetDevice(ctx->device));
+  (void) flush_join(ctx);
+  if (ctx->copy_stream != NULL)
+    FK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+  if (ctx->stream != NULL)
+    FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < ctx->nchunks; i++)
+    free_chunk(ctx, &ctx->chunks[i]);
+  ctx->nchunks = 0;
+  for (int i = 0; i < ctx->nslabs; i++)
+    hipFree(ctx->slabs[i].ptr);
+  ctx->nslabs = 0;
+  ctx->chunk_hbm_bytes = 0;
+  for (int i = 0; i < FK_NSLOTS; i++)
+    if (ctx->slot_ptr[i] != NULL)
+      { hipFree(ctx->slot_ptr[i]);
+        ctx->slot_ptr[i] = NULL;
+        ctx->slot_cap[i] = 0;
+      }
+  hipFree(ctx->d_reads);     ctx->d_reads = NULL;     ctx->reads_cap = 0; ctx->reads_len = 0;
+  hipFree(ctx->d_reads_alt); ctx->d_reads_alt = NULL; ctx->reads_cap_alt = 0;
+  hipFree(ctx->d_pk); ctx->d_pk = NULL; ctx->pk_cap = 0;
+  if (ctx->h_pk) { hipHostFree(ctx->h_pk); ctx->h_pk = NULL; }
+  for (int i = 0; i < ctx->nspill; i++)
+    if (ctx->spill_buf[i].ptr != NULL && !ctx->spill_buf[i].in_use)
+      { fkx_pinned_free(ctx->spill_buf[i].ptr);
+        ctx->spill_buf[i].ptr = NULL;
+        ctx->spill_buf[i].cap = 0;
+      }
+  for (int i = 0; i < 2; i++)
+    if (ctx->h_stage[i])
+      { fkx_pinned_free(ctx->h_stage[i]);
+        ctx->h_stage[i] = NULL;
+      }
+  ctx->stage_cap = 0;
+  ctx->have_table = ctx->have_part_table = false;
+  ctx->last_table = NULL;
+  ctx->last_ntab = 0;
+  ctx->pf_dict_table = NULL;
+  return (FK_OK);
 }
 
 extern "C" int fk_set_stream(fk_ctx *ctx, void *hip_stream)
@@ -596,6 +647,11 @@ extern "C" int fk_synth_reads(fk_ctx *ctx, uint64_t seed, uint64_t genome_len, u
                               uint32_t err_ppm, uint64_t first_read, int64_t nreads, void *d_bases)
 { if (ctx == NULL || d_bases == NULL || nreads < 0) return (FK_EINVAL);
   return fkx_synth(ctx, seed, genome_len, read_len, err_ppm, first_read, nreads, d_bases);
+}
+
+extern "C" int fk_pack_fixed_reads(fk_ctx *ctx, const void *d_bases, int64_t nreads, uint32_t read_len, void *d_codes)
+{ if (ctx == NULL || d_bases == NULL || d_codes == NULL || nreads < 0 || read_len == 0) return (FK_EINVAL);
+  return fkx_pack_fixed(ctx, d_bases, nreads, read_len, d_codes);
 }
 
 // ---- stage interface ----------------------------------------------------------------------------
@@ -1155,6 +1211,101 @@ extern "C" int fk_push_block(fk_ctx *ctx, const char *bases, const int32_t *boff
               break;
             }
           ctx->stage_idx ^= 1;
+        }
+      ctx->reads_len += len;
+      if (ctx->nblocks == ctx->blocks_cap)
+        { ctx->blocks_cap = ctx->blocks_cap * 2 + 256;
+          ctx->blocks = (fk_block *) realloc(ctx->blocks, sizeof(fk_block) * (size_t) ctx->blocks_cap);
+          if (ctx->blocks == NULL) { ctx->nblocks = ctx->blocks_cap = 0; rc = FK_ENOMEM; break; }
+        }
+      ctx->blocks[ctx->nblocks].tid = tid;
+      ctx->blocks[ctx->nblocks].rem = rem;
+      ctx->blocks[ctx->nblocks].nreads = nreads;
+      ctx->nblocks += 1;
+      if (ctx->chunk_bytes > 0 && ctx->reads_len >= ctx->chunk_bytes)
+        rc = flush_chunk(ctx, true);
+    }
+  while (0);
+  pthread_mutex_unlock((pthread_mutex_t *) ctx->push_lock);
+  return (rc);
+}
+
+/* The reads of a DATA_BLOCK in two bits per base (see include/fastk_amd.h): unpacked on the device into the read
+   buffer fk_push_block fills, a quarter of the bytes over PCIe. */
+extern "C" int fk_push_packed(fk_ctx *ctx, const uint8_t *codes, int64_t nbases, const int32_t *rlen, int nreads,
+                              const int64_t *inv, int ninv, int rem, int tid)
+{ if (ctx == NULL || nreads < 0 || nbases < 0 || ninv < 0 || (nbases > 0 && codes == NULL) || (nreads > 0 && rlen == NULL)
+      || (ninv > 0 && inv == NULL))
+    return (FK_EINVAL);
+  if (nreads == 0)
+    return (FK_OK);
+  if (ctx->prm.bc_prefix > 0)
+    { fk_set_error(ctx, "fk_push_packed: -bc needs the ASCII form (fk_push_block)");
+      return (FK_EUNSUPPORTED);
+    }
+  const int64_t len = nbases + nreads;                   // bases + terminators
+  const int64_t cbytes = ((nbases + 3) / 4 + 3) & ~3ll;  // the kernel reads whole dwords
+  int rc = FK_OK;
+  pthread_mutex_lock((pthread_mutex_t *) ctx->push_lock);
+  do
+    { hipSetDevice(ctx->device);
+      if ((rc = reserve_reads(ctx, len)) != FK_OK)
+        break;
+      hipStream_t ps = push_stream(ctx);
+      // staging on the device: codes | read offsets | invalid stretches (stream-ordered: the previous block's
+      // kernels are done with it before this block's copies land)
+      const int64_t off_roff = (cbytes + 15) & ~15ll, off_inv = off_roff + ((int64_t) nreads + 1) * 8;
+      const int64_t need = off_inv + (int64_t) ninv * 16 + 16;
+      if (ctx->pk_cap < need)
+        { if (hipStreamSynchronize(ps) != hipSuccess) { rc = FK_EHIP; break; }
+          if (ctx->d_pk) hipFree(ctx->d_pk);
+          if (ctx->h_pk) hipHostFree(ctx->h_pk);
+          ctx->d_pk = NULL; ctx->h_pk = NULL; ctx->pk_cap = 0;
+          const int64_t cap = need + need / 4;
+          if (hipMalloc((void **) &ctx->d_pk, (size_t) cap) != hipSuccess
+              || hipHostMalloc((void **) &ctx->h_pk, (size_t) (cap - off_roff + 64), hipHostMallocDefault) != hipSuccess)
+            { fk_set_error(ctx, "fk_push_packed: out of memory for %lld bytes of staging", (long long) cap);
+              rc = FK_ENOMEM;
+              break;
+            }
+          ctx->pk_cap = cap;
+        }
+      if (hipStreamSynchronize(ps) != hipSuccess) { rc = FK_EHIP; break; }    // h_pk is free again
+      int64_t *hro = (int64_t *) ctx->h_pk;
+      int64_t  run = 0;
+      for (int i = 0; i < nreads; i++)
+        { if (rlen[i] < 0) { rc = FK_EINVAL; break; }
+          hro[i] = run;
+          run += rlen[i];
+        }
+      hro[nreads] = run;
+      if (rc != FK_OK || run != nbases)
+        { fk_set_error(ctx, "fk_push_packed: the read lengths add up to %lld, not to %lld bases", (long long) run, (long long) nbases);
+          rc = FK_EINVAL;
+          break;
+        }
+      if (ninv > 0)
+        memcpy(hro + nreads + 1, inv, (size_t) ninv * 16);
+      if ((nbases > 0 && hipMemcpyAsync(ctx->d_pk, codes, (size_t) ((nbases + 3) / 4), hipMemcpyHostToDevice, ps) != hipSuccess)
+          || hipMemcpyAsync(ctx->d_pk + off_roff, hro, (size_t) (((int64_t) nreads + 1) * 8 + (int64_t) ninv * 16),
+                            hipMemcpyHostToDevice, ps) != hipSuccess)
+        { fk_set_error(ctx, "fk_push_packed: host to device copy failed");
+          rc = FK_EHIP;
+          break;
+        }
+      if ((rc = fkx_unpack_reads(ctx, ps, ctx->d_pk, nbases, (const int64_t *) (ctx->d_pk + off_roff), nreads,
+                                 (const int64_t *) (ctx->d_pk + off_inv), ninv, ctx->d_reads + ctx->reads_len)) != FK_OK)
+        break;
+      if (hipStreamSynchronize(ps) != hipSuccess)          // the caller may reuse its buffers once we return
+        { rc = FK_EHIP; break; }
+      if (ctx->prm.exact_parts)
+        { if (ctx->nroff + nreads + 1 > ctx->roff_cap)
+            { ctx->roff_cap = std::max<int64_t>(ctx->nroff + nreads + 1, ctx->roff_cap * 2 + 1024);
+              ctx->h_roff = (int64_t *) realloc(ctx->h_roff, sizeof(int64_t) * (size_t) ctx->roff_cap);
+              if (ctx->h_roff == NULL) { rc = FK_ENOMEM; break; }
+            }
+          for (int i = 0; i < nreads; i++)
+            ctx->h_roff[ctx->nroff++] = ctx->reads_len + hro[i] + i;
         }
       ctx->reads_len += len;
       if (ctx->nblocks == ctx->blocks_cap)

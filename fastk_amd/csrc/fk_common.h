@@ -106,6 +106,8 @@ struct fk_ctx
   // other one is split into super-mers by a helper thread on `stream`
   hipStream_t copy_stream;
   hipEvent_t  reads_ev;     // all copies into the buffer handed to the helper have been issued before it
+  char      *d_pk, *h_pk;   // fk_push_packed: staging for codes, read offsets and invalid stretches (device / pinned)
+  int64_t    pk_cap;
   char      *d_reads_alt;   // the idle read buffer (NULL until first needed)
   int64_t    reads_cap_alt;
   void      *flush_thread;  // std::thread * of the running flush, NULL if none
@@ -236,6 +238,9 @@ int fkx_aggregate(fk_ctx *ctx, const void *d_grouped, int64_t n, int cutoff, int
                   int64_t *max_inst, int64_t *ndistinct, void *d_table, int64_t cap, int64_t *ntable);
 int fkx_parse_fastq(fk_ctx *ctx, const void *d_raw, int64_t nbytes, int flags, int *phase, void *d_dst,
                     int64_t *nkept, int64_t *nreads);
+int fkx_unpack_reads(fk_ctx *ctx, hipStream_t s, const void *d_codes, int64_t nbases, const int64_t *d_roff, int64_t nreads,
+                     const int64_t *d_inv, int64_t ninv, void *d_dst);
+int fkx_pack_fixed(fk_ctx *ctx, const void *d_bases, int64_t nreads, u32 read_len, void *d_codes);
 int fkx_parse_fasta(fk_ctx *ctx, const void *d_raw, int64_t nbytes, int state, void *d_dst,
                     int64_t *nkept, int64_t *nrecs);
 int fkx_dedup_supermers(fk_ctx *ctx, const void *d_grouped, int64_t n, void *d_out, int64_t cap, int64_t *nout);

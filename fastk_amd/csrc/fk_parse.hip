@@ -486,3 +486,148 @@ int fkx_parse_fasta(fk_ctx *ctx, const void *d_raw, int64_t nbytes, int state, v
   *nrecs = (int64_t) ctx->h_scratch[1];
   return (FK_OK);
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// Reads in two bits per base -> the 0-terminated ASCII reads the splitter takes (fk_push_packed).
+// codes: the bases of the reads back to back, four to a byte, first base in the two high bits (a c g t = 0 1 2 3, the
+// .ktab encoding, README.md:977-984); roff[r] = first base of read r in that concatenation, roff[nreads] = all bases;
+// read r's bases land at dst[roff[r] + r ...], its terminator behind them.  What a FASTA / FASTQ scanner does on
+// the way in (io.c:678-734) minus the text: the host sends a quarter of the bytes over PCIe.
+#define UP_THREADS 256
+#define UP_BASES   16                      // bases per thread: one dword of codes
+
+__device__ __forceinline__ int64_t up_read_of(const int64_t *__restrict__ roff, int64_t lo, int64_t hi, int64_t pos)
+{ // largest r in [lo, hi] with roff[r] <= pos
+  while (lo < hi)
+    { const int64_t mid = (lo + hi + 1) >> 1;
+      if (roff[mid] <= pos) lo = mid; else hi = mid - 1;
+    }
+  return (lo);
+}
+
+__global__ __launch_bounds__(UP_THREADS) void k_up_bases(const unsigned char *__restrict__ codes, int64_t nbases,
+                                                         const int64_t *__restrict__ roff, int64_t nreads,
+                                                         unsigned char *__restrict__ dst)
+{ __shared__ int64_t sh_r[2];
+  const int64_t b0 = (int64_t) blockIdx.x * (UP_THREADS * UP_BASES);
+  if (threadIdx.x < 2)
+    { const int64_t pos = (threadIdx.x == 0) ? b0 : min(b0 + UP_THREADS * UP_BASES, nbases) - 1;
+      sh_r[threadIdx.x] = up_read_of(roff, 0, nreads - 1, pos);
+    }
+  __syncthreads();
+  const int64_t pos = b0 + (int64_t) threadIdx.x * UP_BASES;
+  if (pos >= nbases)
+    return;
+  const u32 c4 = *(const u32 *) (codes + (pos >> 2));            // codes is padded to a dword multiple
+  int64_t r = up_read_of(roff, sh_r[0], sh_r[1], pos);
+  const int64_t last = min(pos + UP_BASES, nbases);
+  if (roff[r + 1] >= last)
+    { // the whole group lies in one read: four dwords, wherever the read's shift puts them
+      unsigned char *o = dst + pos + r;
+      const int n = (int) (last - pos);
+      u32 w[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        { const u32 byte = (c4 >> (8 * q)) & 0xffu;
+          u32 x = 0;
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            { const u32 code = (byte >> (6 - 2 * i)) & 3u;
+              x |= ((0x74676361u >> (8 * code)) & 0xffu) << (8 * i);      // "acgt"
+            }
+          w[q] = x;
+        }
+      if (n == UP_BASES)
+        {
+#pragma unroll
+          for (int q = 0; q < 4; q++)
+            __builtin_memcpy(o + 4 * q, &w[q], 4);
+        }
+      else
+        for (int i = 0; i < n; i++)
+          o[i] = (unsigned char) (w[i >> 2] >> (8 * (i & 3)));
+      return;
+    }
+  for (int64_t i = pos; i < last; i++)
+    { while (roff[r + 1] <= i)
+        r += 1;
+      const u32 byte = (c4 >> (8 * ((i - pos) >> 2))) & 0xffu;
+      const u32 code = (byte >> (6 - 2 * ((i - pos) & 3))) & 3u;
+      dst[i + r] = (unsigned char) ((0x74676361u >> (8 * code)) & 0xffu);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_up_ends(const int64_t *__restrict__ roff, int64_t nreads,
+                                                 unsigned char *__restrict__ dst)
+{ const int64_t r = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (r < nreads)
+    dst[roff[r + 1] + r] = 0;
+}
+
+// inv: pairs (first base, length) of stretches that hold no acgt: 'n' there (one workgroup per stretch)
+__global__ __launch_bounds__(256) void k_up_invalid(const int64_t *__restrict__ inv, const int64_t *__restrict__ roff,
+                                                    int64_t nreads, int64_t nbases, unsigned char *__restrict__ dst)
+{ const int64_t s = inv[2 * (int64_t) blockIdx.x], n = inv[2 * (int64_t) blockIdx.x + 1];
+  for (int64_t i = s + threadIdx.x; i < s + n && i < nbases; i += 256)
+    if (i >= 0)
+      dst[i + up_read_of(roff, 0, nreads - 1, i)] = 'n';
+}
+
+/* d_codes (padded to a multiple of 4 bytes), d_roff[nreads + 1], d_inv[2 ninv] on the device; writes nbases + nreads
+   bytes at d_dst on stream s. */
+int fkx_unpack_reads(fk_ctx *ctx, hipStream_t s, const void *d_codes, int64_t nbases, const int64_t *d_roff, int64_t nreads,
+                     const int64_t *d_inv, int64_t ninv, void *d_dst)
+{ if (nreads <= 0)
+    return (FK_OK);
+  if (nbases > 0)
+    { const int64_t nb = (nbases + UP_THREADS * UP_BASES - 1) / (UP_THREADS * UP_BASES);
+      if (nb > 0x7fffffffll)
+        { fk_set_error(ctx, "fk_push_packed: block too large");
+          return (FK_EINVAL);
+        }
+      hipLaunchKernelGGL(k_up_bases, dim3((unsigned) nb), dim3(UP_THREADS), 0, s, (const unsigned char *) d_codes, nbases,
+                         d_roff, nreads, (unsigned char *) d_dst);
+    }
+  hipLaunchKernelGGL(k_up_ends, dim3((unsigned) ((nreads + 255) / 256)), dim3(256), 0, s, d_roff, nreads,
+                     (unsigned char *) d_dst);
+  if (ninv > 0)
+    hipLaunchKernelGGL(k_up_invalid, dim3((unsigned) ninv), dim3(256), 0, s, d_inv, d_roff, nreads, nbases,
+                       (unsigned char *) d_dst);
+  FK_LAUNCH_CHECK(ctx);
+  return (FK_OK);
+}
+
+
+// The inverse for reads of one length (measurement helper beside fk_synth_reads): rows of read_len + 1 bytes -> codes.
+__global__ __launch_bounds__(256) void k_pack_fixed(const unsigned char *__restrict__ src, int64_t nbases, u32 read_len,
+                                                    unsigned char *__restrict__ codes)
+{ const int64_t o = (int64_t) blockIdx.x * 256 + threadIdx.x;          // output byte
+  if (o * 4 >= nbases)
+    return;
+  u32 b = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+    { const int64_t pos = o * 4 + i;
+      u32 code = 0;
+      if (pos < nbases)
+        { const unsigned char c = src[pos + pos / read_len] | 0x20;
+          code = (c == 'c') ? 1u : (c == 'g') ? 2u : (c == 't') ? 3u : 0u;
+        }
+      b |= code << (6 - 2 * i);
+    }
+  codes[o] = (unsigned char) b;
+}
+
+int fkx_pack_fixed(fk_ctx *ctx, const void *d_bases, int64_t nreads, u32 read_len, void *d_codes)
+{ const int64_t nbases = nreads * (int64_t) read_len;
+  if (nbases <= 0)
+    return (FK_OK);
+  const int64_t nb = ((nbases + 3) / 4 + 255) / 256;
+  if (nb > 0x7fffffffll)
+    return (FK_EINVAL);
+  hipLaunchKernelGGL(k_pack_fixed, dim3((unsigned) nb), dim3(256), 0, ctx->stream, (const unsigned char *) d_bases, nbases,
+                     read_len, (unsigned char *) d_codes);
+  FK_LAUNCH_CHECK(ctx);
+  return (FK_OK);
+}

@@ -92,6 +92,10 @@ void fk_default_params(fk_params *p);
    Replaces the globals of FastK.h:34-83 plus the SORT_PATH temp files (split.c:1454). */
 int         fk_create(const fk_params *p, fk_ctx **ctx);
 void        fk_destroy(fk_ctx *ctx);
+/* Returns the context's device memory and pinned staging buffers while the results of the last fk_finish (host
+   memory) stay valid; thread-safe against readers of those results, so a driver can run it beside its file
+   writers.  The reference has no counterpart: its buffers go back with free() at once (count.c:1870-1890). */
+int         fk_release_device(fk_ctx *ctx);
 const char *fk_last_error(const fk_ctx *ctx);   /* ctx may be NULL: last global error */
 
 /* Use an externally owned HIP stream (e.g. torch's current stream) for all launches. */
@@ -250,6 +254,16 @@ int fk_count_presorted_kmers(fk_ctx *ctx, const void *d_kmers, int64_t nweighted
 int fk_count_unsorted_kmers(fk_ctx *ctx, void *d_kmers, void *d_tmp, int64_t nweighted, int cutoff,
                             int64_t *hist, int64_t *max_inst, int64_t *ndistinct, void **d_table,
                             int64_t *ntable);
+
+/* The reads of a DATA_BLOCK in TWO BITS PER BASE -- the north-star's first verb done by the reader threads, so that a
+   quarter of the bytes cross PCIe: codes = the bases of the block's reads back to back (no terminators), four to a
+   byte, first base in the two high bits (a c g t = 0 1 2 3: the .ktab encoding, README.md:977-984); rlen[i] = bases of
+   read i (they add up to nbases); inv = ninv pairs (first base, length), in the same concatenated coordinates, of
+   stretches that hold no acgt (N, IUPAC codes: their code bits are ignored); rem, tid as in fk_push_block.  Host
+   memory (pinned or not).  Equivalent to fk_push_block of the ASCII block: the device restores the 0-terminated
+   ASCII reads in HBM and the path continues unchanged.  Not with -bc. */
+int fk_push_packed(fk_ctx *ctx, const uint8_t *codes, int64_t nbases, const int32_t *rlen, int nreads,
+                   const int64_t *inv, int ninv, int rem, int tid);
 
 /* FASTQ text, any piece of a file cut anywhere (host memory; pinned memory from fk_host_alloc
    copies fastest): the record structure is resolved on the device -- replaces the FASTQ branch of
@@ -430,6 +444,10 @@ void fk_shard_destroy(fk_shard *sh);
    each followed by a 0 byte (DATA_BLOCK layout): nreads*(read_len+1) bytes. */
 int fk_synth_reads(fk_ctx *ctx, uint64_t seed, uint64_t genome_len, uint32_t read_len,
                    uint32_t err_ppm, uint64_t first_read, int64_t nreads, void *d_bases);
+
+/* The two-bit form fk_push_packed takes, made on the device from nreads rows of read_len bases + terminator (acgt in
+   either case; anything else becomes code 0): (nreads * read_len + 3) / 4 bytes at d_codes.  A measurement helper. */
+int fk_pack_fixed_reads(fk_ctx *ctx, const void *d_bases, int64_t nreads, uint32_t read_len, void *d_codes);
 
 int   fk_device_alloc(fk_ctx *ctx, int64_t nbytes, void **d_ptr);
 int   fk_device_free(fk_ctx *ctx, void *d_ptr);

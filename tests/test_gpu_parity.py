@@ -242,6 +242,51 @@ def test_pipeline_matches_reference_golden(name, tmp_path):
         (k, case["T"], case["cutoff"], exp["ktab"]["ibytes"], exp["ktab"]["nels"])
 
 
+def _pack_reads(bases, boff):
+    """the 2-bit form fk_push_packed takes, from a DATA_BLOCK: (codes, nbases, rlen, inv)"""
+    code = np.full(256, 255, dtype=np.uint8)
+    for i, c in enumerate(b"acgt"):
+        code[c] = i
+        code[c - 32] = i
+    n = len(boff) - 1
+    rlen = (np.diff(boff) - 1).astype(np.int32)
+    keep = np.ones(len(bases), dtype=bool)
+    keep[boff[1:] - 1] = False                                   # the terminators
+    flat = code[np.asarray(bases)[keep]]
+    bad = np.nonzero(flat == 255)[0]
+    inv = np.zeros((0, 2), dtype=np.int64)
+    if len(bad):
+        cut = np.nonzero(np.diff(bad) != 1)[0]
+        first = bad[np.concatenate([[0], cut + 1])]
+        last = bad[np.concatenate([cut, [len(bad) - 1]])]
+        inv = np.stack([first, last - first + 1], axis=1).astype(np.int64)
+    flat = np.where(flat == 255, 3, flat).astype(np.uint8)       # (what stands under an invalid base does not matter)
+    nb = len(flat)
+    pad = np.zeros((nb + 3) // 4 * 4, dtype=np.uint8)
+    pad[:nb] = flat
+    q = pad.reshape(-1, 4)
+    codes = (q[:, 0] << 6) | (q[:, 1] << 4) | (q[:, 2] << 2) | q[:, 3]
+    return codes.astype(np.uint8), nb, rlen, inv
+
+
+@pytest.mark.parametrize("name", util.golden_names())
+def test_packed_push_matches_reference_golden(name):
+    """fk_push_packed: the reads in two bits per base (+ read lengths + the stretches without acgt), in several
+    pieces; resident and chunked with a budget.  Same histogram and table as the reference."""
+    case, bases, boff = util.load_case(name)
+    k = case["k"]
+    nreads = len(boff) - 1
+    for kw in (dict(), dict(nbuckets=3, hbm_budget=64 << 20)):
+        with fastk_amd.Context(kmer=k, table_cutoff=case["cutoff"], nthreads=case["T"], **kw) as ctx:
+            step = max(1, nreads // 5)
+            for s0 in range(0, nreads, step):
+                e = min(nreads, s0 + step)
+                codes, nb, rlen, inv = _pack_reads(bases[boff[s0]:boff[e]], boff[s0:e + 1] - boff[s0])
+                ctx.push_packed(codes, nb, rlen, inv)
+            res = ctx.finish()
+            util.check_against_golden(case, res.hist, res.max_inst, res.table)
+
+
 @pytest.mark.parametrize("name", ["synth_illumina_k40_t1_T4", "edge_k51_t1_T4"])
 def test_pipeline_sort_collapse_path_matches_golden(name):
     """fk_debug_set("kmer_stage", 1): the sort / collapse / sort k-mer stage (the fallback of the
