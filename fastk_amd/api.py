@@ -28,7 +28,7 @@ EXPORTS = [
     "fk_make_profiles", "fk_write_prof", "fk_set_table", "fk_ktab_idx_bytes", "fk_ktab_split",
     "fk_write_ktab_range", "fk_write_ktab_stub", "fk_split_supermers_emit_pos", "fk_profile_lookup_supermers",
     "fk_profile_scatter", "fk_profile_encode", "fk_reset", "fk_shard_unique_id", "fk_shard_create",
-    "fk_release_device", "fk_push_packed", "fk_pack_fixed_reads", "fk_shard_count", "fk_shard_gather", "fk_shard_write", "fk_shard_destroy", "fk_shard_count_device", "fk_shard_local_result",
+    "fk_release_device", "fk_finish_device", "fk_write_ktab_device", "fk_push_packed", "fk_pack_fixed_reads", "fk_shard_count", "fk_shard_gather", "fk_shard_write", "fk_shard_destroy", "fk_shard_count_device", "fk_shard_local_result",
 ]
 
 
@@ -411,6 +411,16 @@ class Context:
         self._ck(self.L.fk_count_device_supermers(self.h, ptr, nsuper, 1 if fetch_table else 0,
                                                   C.byref(r)))
         return Result(r, self.w.kmer_word)
+
+    def finish_device(self):
+        """fk_finish without the host copy of the table (Result.table is None)."""
+        r = CResult()
+        self._ck(self.L.fk_finish_device(self.h, C.byref(r)))
+        return Result(r, self.w.kmer_word)
+
+    def write_ktab_device(self, res, outdir, root, nthreads=None):
+        self._ck(self.L.fk_write_ktab_device(self.h, C.byref(res._c), nthreads or self.params.nthreads,
+                                             outdir.encode(), root.encode()))
 
     def write_hist(self, res, path):
         self._ck(self.L.fk_write_hist(C.byref(res._c), self.kmer, path.encode()))

@@ -410,10 +410,10 @@ extern "C" void fk_destroy(fk_ctx *ctx)
 
 /* Returns the context's device buffers (arena, slab store, read buffers) and its pinned staging and spill buffers
    while the caller still works on the results of the last fk_finish, which stay valid (the table in host memory,
-   histogram, profiles).  May run in a thread of its own beside the file writers: returning 280 GB of HBM takes the
+   histogram, profiles; with keep_table also the sorted table in HBM, for fk_write_ktab_device).  May run in a thread of its own beside the file writers: returning 280 GB of HBM takes the
    driver seconds, as long as writing a 36 GB table does.  The context can be used again afterwards (the buffers come
    back on demand), but the device copy of the last table is gone. */
-extern "C" int fk_release_device(fk_ctx *ctx)
+extern "C" int fk_release_device(fk_ctx *ctx, int keep_table)
 { if (ctx == NULL) return (FK_EINVAL);
   FK_HIP(ctx, hipSetDevice(ctx->device));
   (void) flush_join(ctx);
@@ -430,7 +430,10 @@ extern "C" int fk_release_device(fk_ctx *ctx)
   ctx->chunk_hbm_bytes = 0;
   for (int i = 0; i < FK_NSLOTS; i++)
     if (ctx->slot_ptr[i] != NULL)
-      { hipFree(ctx->slot_ptr[i]);
+      { if (keep_table && ctx->last_table != NULL && (char *) ctx->last_table >= (char *) ctx->slot_ptr[i]
+            && (char *) ctx->last_table < (char *) ctx->slot_ptr[i] + ctx->slot_cap[i])
+          continue;                              // the sorted table lives here
+        hipFree(ctx->slot_ptr[i]);
         ctx->slot_ptr[i] = NULL;
         ctx->slot_cap[i] = 0;
       }
@@ -450,11 +453,147 @@ extern "C" int fk_release_device(fk_ctx *ctx)
         ctx->h_stage[i] = NULL;
       }
   ctx->stage_cap = 0;
-  ctx->have_table = ctx->have_part_table = false;
-  ctx->last_table = NULL;
-  ctx->last_ntab = 0;
   ctx->pf_dict_table = NULL;
+  if (!keep_table)
+    { ctx->have_table = ctx->have_part_table = false;
+      ctx->last_table = NULL;
+      ctx->last_ntab = 0;
+    }
   return (FK_OK);
+}
+
+// lower bounds of the first key byte in a sorted device table: bounds[b] = first record whose byte 0 is >= b
+__global__ __launch_bounds__(256) void k_first_byte_bounds(const unsigned char *__restrict__ t, int64_t n, int stride,
+                                                           int64_t *__restrict__ bounds)
+{ const int b = threadIdx.x;
+  int64_t lo = 0, hi = n;
+  while (lo < hi)
+    { const int64_t mid = (lo + hi) >> 1;
+      if (t[mid * stride] < b) lo = mid + 1; else hi = mid;
+    }
+  bounds[b] = lo;
+  if (b == 0) bounds[256] = n;
+}
+
+/* <root>.ktab + hidden parts straight from the sorted table fk_finish_device left in HBM: every part has its own
+   writer thread, which fetches its range piece by piece through two small pinned buffers (the next piece crosses
+   PCIe while this one is stripped of its prefix bytes and written), so the 36 GB table of a human-size run never
+   exists in host memory: no 36 GB to pin before and to unpin after, and the fetch hides behind the writing.
+   The files are those of fk_write_ktab (table.c:162-342,485-498). */
+extern "C" int fk_write_ktab_device(fk_ctx *ctx, const fk_result *res, int nthreads, const char *dir, const char *root)
+{ if (ctx == NULL || res == NULL || dir == NULL || root == NULL || nthreads < 1 || nthreads > 256) return (FK_EINVAL);
+  const fk_widths &w = ctx->wid;
+  const int cutoff = ctx->prm.table_cutoff, kmer = ctx->prm.kmer;
+  if (cutoff < 1)
+    { fk_set_error(ctx, "fk_write_ktab_device: no table was asked for (table_cutoff 0)");
+      return (FK_EINVAL);
+    }
+  const int64_t n = res->ntable;
+  if (n > 0 && (ctx->last_table == NULL || ctx->last_ntab != n))
+    { fk_set_error(ctx, "fk_write_ktab_device: the table of this result is not in HBM any more");
+      return (FK_ESTATE);
+    }
+  FK_HIP(ctx, hipSetDevice(ctx->device));
+  std::vector<int> split((size_t) nthreads + 1);
+  int rc = fk_ktab_split(res->wfirst, kmer, nthreads, split.data());
+  if (rc != FK_OK) return (rc);
+  const int ib = fk_ktab_idx_bytes(kmer, n);
+  const int KW = w.kmer_word, ST = w.kmer_stride, pw = KW - ib;
+  int64_t npre = 1;
+  for (int i = 0; i < ib; i++) npre *= 256;
+  std::vector<int64_t> pc((size_t) npre, 0);
+  int64_t hb[257];
+  for (int b = 0; b <= 256; b++) hb[b] = 0;
+  if (n > 0)
+    { int64_t *d_b = (int64_t *) ctx->d_scratch;
+      hipLaunchKernelGGL(k_first_byte_bounds, dim3(1), dim3(256), 0, ctx->stream, (const unsigned char *) ctx->last_table, n, ST, d_b);
+      FK_LAUNCH_CHECK(ctx);
+      FK_HIP(ctx, hipMemcpyAsync(hb, d_b, 257 * 8, hipMemcpyDeviceToHost, ctx->stream));
+      FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+  const int64_t piece = std::max<int64_t>((16ll << 20) / ST, 1);          // records per piece
+  std::vector<int> prc((size_t) nthreads, FK_OK);
+  auto write_part = [&](int t)
+    { const int64_t lo = hb[split[t]], hi = hb[split[t + 1]], cnt = hi - lo;
+      char pname[4096];
+      snprintf(pname, sizeof(pname), "%s/.%s.ktab.%d", dir, root, t + 1);
+      int fd = open(pname, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+      if (fd < 0) { prc[t] = FK_EINVAL; return; }
+      uint8_t    *pin[2] = { NULL, NULL };
+      hipStream_t st = NULL;
+      uint8_t    *out = (uint8_t *) malloc((size_t) piece * pw);
+      bool ok = (hipSetDevice(ctx->device) == hipSuccess && out != NULL
+                 && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess
+                 && hipHostMalloc((void **) &pin[0], (size_t) (piece * ST), hipHostMallocDefault) == hipSuccess
+                 && hipHostMalloc((void **) &pin[1], (size_t) (piece * ST), hipHostMallocDefault) == hipSuccess);
+      hipEvent_t ev[2] = { NULL, NULL };
+      ok = ok && hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) == hipSuccess
+              && hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) == hipSuccess;
+      if (ok && (write(fd, &kmer, 4) != 4 || write(fd, &cnt, 8) != 8))
+        ok = false;
+      auto fetch = [&](int64_t x, int which) -> bool
+        { const int64_t e = std::min(hi, x + piece);
+          return (hipMemcpyAsync(pin[which], (const char *) ctx->last_table + x * ST, (size_t) ((e - x) * ST),
+                                 hipMemcpyDeviceToHost, st) == hipSuccess
+                  && hipEventRecord(ev[which], st) == hipSuccess);
+        };
+      int64_t run_pre = -1, run_n = 0;
+      int which = 0;
+      if (ok && lo < hi)
+        ok = fetch(lo, 0);
+      for (int64_t x = lo; ok && x < hi; x += piece, which ^= 1)
+        { const int64_t e = std::min(hi, x + piece);
+          if (e < hi)
+            ok = fetch(e, which ^ 1);                       // the next piece travels while this one is written
+          if (!ok || hipEventSynchronize(ev[which]) != hipSuccess) { ok = false; break; }
+          const uint8_t *src = pin[which];
+          for (int64_t i = 0; i < e - x; i++)
+            { const uint8_t *rec = src + i * ST;
+              int64_t pre = 0;
+              for (int b = 0; b < ib; b++)
+                pre = (pre << 8) | rec[b];
+              if (pre != run_pre)
+                { if (run_n > 0) pc[(size_t) run_pre] += run_n;
+                  run_pre = pre;
+                  run_n = 0;
+                }
+              run_n += 1;
+              uint8_t *o = out + i * pw;
+              memcpy(o, rec + ib, (size_t) (w.kmer_bytes - ib));               // the k-mer's suffix
+              memcpy(o + w.kmer_bytes - ib, rec + ST - 2, 2);                  // the count
+            }
+          const uint8_t *q = out;
+          size_t left = (size_t) (e - x) * pw;
+          while (left > 0)
+            { const ssize_t wr = write(fd, q, left);
+              if (wr <= 0) { ok = false; break; }
+              q += wr; left -= (size_t) wr;
+            }
+        }
+      if (run_n > 0) pc[(size_t) run_pre] += run_n;
+      if (st) hipStreamSynchronize(st);
+      for (int i = 0; i < 2; i++)
+        { if (pin[i]) hipHostFree(pin[i]);
+          if (ev[i]) hipEventDestroy(ev[i]);
+        }
+      if (st) hipStreamDestroy(st);
+      free(out);
+      if (close(fd) != 0) ok = false;
+      if (!ok) prc[t] = FK_EINVAL;
+    };
+  { std::vector<std::thread> th;
+    for (int t = 1; t < nthreads; t++)
+      th.emplace_back(write_part, t);
+    write_part(0);
+    for (auto &x : th)
+      x.join();
+  }
+  for (int t = 0; t < nthreads; t++)
+    if (prc[t] != FK_OK)
+      { fk_set_error(ctx, "Cannot write to %s/.%s.ktab.%d.  Enough disk space?", dir, root, t + 1);
+        return (prc[t]);
+      }
+  return fk_write_ktab_stub(kmer, nthreads, cutoff, ib, pc.data(), dir, root);
 }
 
 extern "C" int fk_set_stream(fk_ctx *ctx, void *hip_stream)
@@ -2205,7 +2344,7 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
   return (rc);
 }
 
-extern "C" int fk_finish(fk_ctx *ctx, fk_result *res)
+static int finish_impl(fk_ctx *ctx, fk_result *res, bool fetch)
 { if (ctx == NULL || res == NULL) return (FK_EINVAL);
   FK_HIP(ctx, hipSetDevice(ctx->device));
   { pthread_mutex_lock((pthread_mutex_t *) ctx->push_lock);
@@ -2225,7 +2364,7 @@ extern "C" int fk_finish(fk_ctx *ctx, fk_result *res)
       if (getenv("FK_FINISH_TIMING") != NULL)
         fprintf(stderr, "  finish timing: last flush %.3f s\n", fk_wall() - w0);
       if (rc == FK_OK)
-        rc = fkx_pipeline(ctx, NULL, 0, NULL, 0, res, true);
+        rc = fkx_pipeline(ctx, NULL, 0, NULL, 0, res, fetch);
       for (int i = 0; i < ctx->nchunks; i++)
         free_chunk(ctx, &ctx->chunks[i]);
       ctx->nchunks = 0;
@@ -2242,10 +2381,18 @@ extern "C" int fk_finish(fk_ctx *ctx, fk_result *res)
         { ctx->h_roff = (int64_t *) malloc(sizeof(int64_t) * 4);
           ctx->roff_cap = 4;
         }
-      return fkx_pipeline(ctx, ctx->d_reads, ctx->reads_len, NULL, 0, res, true, ctx->h_roff, ctx->nroff);
+      return fkx_pipeline(ctx, ctx->d_reads, ctx->reads_len, NULL, 0, res, fetch, ctx->h_roff, ctx->nroff);
     }
-  return fkx_pipeline(ctx, ctx->d_reads, ctx->reads_len, NULL, 0, res, true);
+  return fkx_pipeline(ctx, ctx->d_reads, ctx->reads_len, NULL, 0, res, fetch);
 }
+
+extern "C" int fk_finish(fk_ctx *ctx, fk_result *res)
+{ return finish_impl(ctx, res, true); }
+
+/* fk_finish without the host copy of the table (res->table NULL, res->ntable set): the sorted table stays in HBM for
+   fk_write_ktab_device / fk_make_profiles. */
+extern "C" int fk_finish_device(fk_ctx *ctx, fk_result *res)
+{ return finish_impl(ctx, res, false); }
 
 /* Forget the reads pushed so far (and any chunks split from them); arenas, staging buffers and the
    bucket assignment stay, so the next data set starts without allocations. */

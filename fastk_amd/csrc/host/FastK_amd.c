@@ -148,8 +148,10 @@ static void flush_block(Feeder *f, int rem)
   f->boff[0] = 0;
 }
 
+static int KEEP_TABLE = 0;
+
 static void *release_thread(void *arg)
-{ fk_release_device((fk_ctx *) arg);
+{ fk_release_device((fk_ctx *) arg,KEEP_TABLE);
   return (NULL);
 }
 
@@ -974,7 +976,9 @@ int main(int argc, char *argv[])
       fk_destroy(ctx);
       exit (0);
     }
-  if (fk_finish(ctx,res) != FK_OK)
+  /* without profiles the table is only written: it stays in HBM and the part writers fetch it piece by piece */
+  KEEP_TABLE = (!PROFILE && DO_TABLE > 0);
+  if ((KEEP_TABLE ? fk_finish_device(ctx,res) : fk_finish(ctx,res)) != FK_OK)
     die(ctx,"fk_finish");
   t_count = now();
 
@@ -1053,11 +1057,15 @@ int main(int argc, char *argv[])
     snprintf(name,sizeof(name),"%s/%s.hist",dir,root);
     if (fk_write_hist(res,KMER,name) != FK_OK)
       die(ctx,"writing .hist");
-    if (DO_TABLE > 0 && fk_write_ktab(res,KMER,DO_TABLE,NTHREADS,dir,root) != FK_OK)
+    if (DO_TABLE > 0 && (KEEP_TABLE ? fk_write_ktab_device(ctx,res,NTHREADS,dir,root)
+                                    : fk_write_ktab(res,KMER,DO_TABLE,NTHREADS,dir,root)) != FK_OK)
       die(ctx,"writing .ktab");
     t_write = now();
     if (relt)
       pthread_join(rel,NULL);
+    if (KEEP_TABLE)
+      fk_release_device(ctx,0);              /* the table's own buffer: left to _exit it would be freed behind the
+                                                next process's back, whose ingest then takes 2 s longer */
   }
   if (VERBOSE)
     { fprintf(stderr,"  Wall s: start-up + ingest %.3f  count + table fetch %.3f  write %.3f\n",

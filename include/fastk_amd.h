@@ -93,9 +93,9 @@ void fk_default_params(fk_params *p);
 int         fk_create(const fk_params *p, fk_ctx **ctx);
 void        fk_destroy(fk_ctx *ctx);
 /* Returns the context's device memory and pinned staging buffers while the results of the last fk_finish (host
-   memory) stay valid; thread-safe against readers of those results, so a driver can run it beside its file
+   memory; with keep_table != 0 also the sorted table in HBM that fk_write_ktab_device reads) stay valid; thread-safe against readers of those results, so a driver can run it beside its file
    writers.  The reference has no counterpart: its buffers go back with free() at once (count.c:1870-1890). */
-int         fk_release_device(fk_ctx *ctx);
+int         fk_release_device(fk_ctx *ctx, int keep_table);
 const char *fk_last_error(const fk_ctx *ctx);   /* ctx may be NULL: last global error */
 
 /* Use an externally owned HIP stream (e.g. torch's current stream) for all launches. */
@@ -155,6 +155,10 @@ typedef struct
    device pipeline over everything pushed so far.  table memory stays valid until
    fk_destroy or the next fk_finish. */
 int fk_finish(fk_ctx *ctx, fk_result *res);
+/* fk_finish without the host copy of the table: res->table is NULL, res->ntable set, the sorted table stays in HBM for
+   fk_write_ktab_device (and fk_make_profiles).  What a driver that only writes files wants: the table (36 GB for a
+   50x human-size read set) then never exists in host memory. */
+int fk_finish_device(fk_ctx *ctx, fk_result *res);
 
 /* The same pipeline on reads that are already resident in HBM and stay owned by the caller
    (16-byte aligned; any byte that is not acgtACGT separates reads).  fetch_table = 0 leaves
@@ -173,6 +177,10 @@ int fk_count_device_supermers(fk_ctx *ctx, void *d_smers, int64_t nsuper, int fe
 int fk_write_hist(const fk_result *res, int kmer, const char *path);
 int fk_write_ktab(const fk_result *res, int kmer, int table_cutoff, int nthreads,
                   const char *dir, const char *root);
+/* The same files straight from the table fk_finish_device left in HBM (Merge_Tables' output, table.c:346-533): one
+   writer thread per part fetches its first-byte range in 16 MB pieces through two pinned buffers -- the next piece
+   crosses PCIe while this one is stripped of its prefix bytes and written. */
+int fk_write_ktab_device(fk_ctx *ctx, const fk_result *res, int nthreads, const char *dir, const char *root);
 
 /* ---- stage interface on device buffers ---------------------------------------------------*/
 

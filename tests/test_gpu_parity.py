@@ -242,6 +242,33 @@ def test_pipeline_matches_reference_golden(name, tmp_path):
         (k, case["T"], case["cutoff"], exp["ktab"]["ibytes"], exp["ktab"]["nels"])
 
 
+@pytest.mark.parametrize("name", ["synth_illumina_k40_t1_T4", "edge_k51_t1_T4", "synth_hifi_k40_t4_T8", "edge_k21_t2_T3"])
+def test_ktab_written_from_the_device_table(name, tmp_path):
+    """fk_finish_device + fk_write_ktab_device: the table never comes to host memory as a whole, every part writer
+    fetches its first-byte range piece by piece.  The files are fk_write_ktab's, byte for byte, and the stream is the
+    reference's; the device buffers but the table may be released meanwhile (fk_release_device(keep_table))."""
+    case, bases, boff = util.load_case(name)
+    k, T = case["k"], case["T"]
+    a, b = tmp_path / "a", tmp_path / "b"
+    a.mkdir(); b.mkdir()
+    with fastk_amd.Context(kmer=k, table_cutoff=case["cutoff"], nthreads=T) as ctx:
+        ctx.push_block(bases, boff.astype(np.int32))
+        res = ctx.finish()
+        ctx.write_ktab(res, str(a), "x")
+    with fastk_amd.Context(kmer=k, table_cutoff=case["cutoff"], nthreads=T) as ctx:
+        ctx.push_block(bases, boff.astype(np.int32))
+        res = ctx.finish_device()
+        assert res.ntable == case["expected"]["ktab"]["nels"] and len(res.table) == 0
+        ctx._ck(ctx.L.fk_release_device(ctx.h, 1))
+        ctx.write_ktab_device(res, str(b), "x")
+    import os
+    files = sorted(os.listdir(a))
+    assert files == sorted(os.listdir(b)) and len(files) == 1 + T
+    for f in files:
+        assert util.sha_file(a / f) == util.sha_file(b / f), f
+    assert orc.read_ktab(str(b / "x"))["stream_sha256"] == case["expected"]["ktab"]["stream_sha256"]
+
+
 def _pack_reads(bases, boff):
     """the 2-bit form fk_push_packed takes, from a DATA_BLOCK: (codes, nbases, rlen, inv)"""
     code = np.full(256, 255, dtype=np.uint8)
