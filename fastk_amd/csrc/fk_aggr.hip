@@ -513,8 +513,10 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
               { const int64_t room = (nx_end - nx_beg) * KW;                   // dwords
                 const u32 nd = (room < (int64_t) cap_eff * KW) ? (u32) room : (u32) cap_eff * KW;
                 const u32 d = min(ag_opaque((u32) tid) * 32u, nd - 1);
+                // (a plain load that the empty asm below keeps alive -- a volatile one becomes a FLAT load with
+                // system scope, and a flat load counts as an LDS operation too: LDS waits behind it sit out its trip)
                 asm volatile("" :: "v"(touch));                                // (the previous one has long arrived)
-                touch = *(const volatile u32 *) (recs + nx_beg * KW + d);
+                touch = recs[nx_beg * KW + d];
               }
           }
 
