@@ -28,7 +28,7 @@ EXPORTS = [
     "fk_make_profiles", "fk_write_prof", "fk_set_table", "fk_ktab_idx_bytes", "fk_ktab_split",
     "fk_write_ktab_range", "fk_write_ktab_stub", "fk_split_supermers_emit_pos", "fk_profile_lookup_supermers",
     "fk_profile_scatter", "fk_profile_encode", "fk_reset", "fk_shard_unique_id", "fk_shard_create",
-    "fk_release_device", "fk_finish_device", "fk_write_ktab_device", "fk_push_packed", "fk_pack_fixed_reads", "fk_shard_count", "fk_shard_gather", "fk_shard_write", "fk_shard_destroy", "fk_shard_count_device", "fk_shard_local_result",
+    "fk_release_device", "fk_set_sort_memory", "fk_finish_device", "fk_write_ktab_device", "fk_push_packed", "fk_pack_fixed_reads", "fk_shard_count", "fk_shard_gather", "fk_shard_write", "fk_shard_destroy", "fk_shard_count_device", "fk_shard_local_result",
 ]
 
 
@@ -108,6 +108,7 @@ def load_library():
     L.fk_synchronize.argtypes = [vp]
     L.fk_push_block.argtypes = [vp, vp, vp, ci, ci, ci]
     L.fk_push_packed.argtypes = [vp, vp, i64, vp, ci, vp, ci, ci, ci]
+    L.fk_set_sort_memory.argtypes = [vp, i64, C.c_double]
     L.fk_pack_fixed_reads.argtypes = [vp, vp, i64, C.c_uint32, vp]
     L.fk_train_block.argtypes = [vp, vp, vp, ci]
     L.fk_push_device.argtypes = [vp, vp, i64]

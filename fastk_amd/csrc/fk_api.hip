@@ -369,6 +369,8 @@ extern "C" void fk_destroy(fk_ctx *ctx)
   hipFree(ctx->d_reads_alt);
   hipFree(ctx->d_pk);
   if (ctx->h_pk) hipHostFree(ctx->h_pk);
+  hipFree(ctx->d_min_part);
+  free(ctx->min_part);
   if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
   if (ctx->reads_ev) hipEventDestroy(ctx->reads_ev);
   free(ctx->h_prof);
@@ -596,6 +598,17 @@ extern "C" int fk_write_ktab_device(fk_ctx *ctx, const fk_result *res, int nthre
   return fk_write_ktab_stub(kmer, nthreads, cutoff, ib, pc.data(), dir, root);
 }
 
+/* exact_parts only: the reference's -M in bytes (FastK.c:235,291: 12e9 by default, <int> x 1e9) and, when the caller
+   knows it, the ratio "whole input / first block" in file bytes (io.c:528,749) -- with both an exact_parts run cuts
+   the input into the reference's NPARTS buckets under the reference's scheme (fk_scheme.hip), which is what decides
+   where the hidden .ktab part files are cut.  sort_memory 0 (the default): one bucket. */
+extern "C" int fk_set_sort_memory(fk_ctx *ctx, int64_t sort_memory, double input_ratio)
+{ if (ctx == NULL || sort_memory < 0 || input_ratio < 0.) return (FK_EINVAL);
+  ctx->sort_memory = sort_memory;
+  ctx->input_ratio = input_ratio;
+  return (FK_OK);
+}
+
 extern "C" int fk_set_stream(fk_ctx *ctx, void *hip_stream)
 { if (ctx == NULL) return (FK_EINVAL);
   if (ctx->own_stream && ctx->stream != NULL)
@@ -724,6 +737,10 @@ extern "C" int fk_debug_get(fk_ctx *ctx, const char *key, int64_t *value)
 { if (ctx == NULL || key == NULL || value == NULL) return (FK_EINVAL);
   if (strcmp(key, "aggr_extra_rounds") == 0)
     { *value = ctx->aggr_extra_rounds;
+      return (FK_OK);
+    }
+  if (strcmp(key, "scheme_nparts") == 0)    // buckets of the last exact_parts run (1: the unpadded one-bucket case)
+    { *value = ctx->scheme_nparts;
       return (FK_OK);
     }
   if (strcmp(key, "spilled_bytes") == 0)    // super-mer records the last chunked run moved to host memory
@@ -1749,9 +1766,15 @@ static int count_bucket(fk_ctx *ctx, void *sm_in, int64_t ns, fk_result *res, bo
             { rc = FK_ENOMEM; break; }
         }
       int64_t exact_census[256];
+      if (exact_roff != NULL)
+        for (int x = 0; x < 256; x++)
+          ctx->exact_wfirst[x] = 0;
       if (exact_roff != NULL && nw > 0
           && (rc = fkx_first_byte_census(ctx, km_a, nw, w.kmer_stride, exact_census)) != FK_OK)
         break;
+      if (exact_roff != NULL && nw > 0)
+        for (int x = 0; x < 256; x++)
+          ctx->exact_wfirst[x] = exact_census[x];
       hipEventRecord(ev[2], s);
 
       // weighted k-mer stage.  The reference sorts the W weighted records on KMER_BYTES and scans the
@@ -2087,11 +2110,6 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
       else
         { if (h_roff != NULL)
             { // exact_parts: the reference's own rule, so that Table_Split falls where it does there
-              if (ctx->prm.nbuckets != 1)
-                { fk_set_error(ctx, "exact_parts works on one bucket only (nbuckets = %d)", ctx->prm.nbuckets);
-                  rc = FK_EUNSUPPORTED;
-                  break;
-                }
               h_roff[nreads] = nbytes;
               int64_t train = 0, olen = 0;                 // Get_First_Block(io, 1e9), io.c:2606-2630
               const int64_t maxrds = 1000000000ll / 150, omax = 1000000000ll + maxrds;
@@ -2110,7 +2128,29 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
               if (d_roff == NULL) { rc = FK_ENOMEM; break; }
               if (hipMemcpyAsync(d_roff, h_roff, (size_t) (nreads + 1) * 8, hipMemcpyHostToDevice, s) != hipSuccess)
                 { rc = FK_EHIP; break; }
-              if ((rc = fkx_split_exact(ctx, d_reads, d_roff, nreads, tran, &sm_a, &ns, &ni)) != FK_OK) break;
+              // how many buckets the reference would use (FastK.c:417-429: the k-mer records of the whole input,
+              // extrapolated from the training block, over the sort memory) and, with more than one, its scheme
+              ctx->scheme_nparts = 1;
+              if (ctx->sort_memory > 0 && train > 0)
+                { const int64_t totlen = (h_roff[train] - h_roff[0]) - train;          // bases of the block
+                  const int64_t all = nbytes - nreads;
+                  const double ratio = (ctx->input_ratio > 0.) ? ctx->input_ratio
+                                     : (train >= nreads ? 1.0 : (double) (all + nreads) / (double) (totlen + train));
+                  int64_t gsize = totlen - (int64_t) ctx->prm.kmer * train;
+                  gsize = (int64_t) ((double) gsize * ratio * (double) w.kmer_word);
+                  const int64_t np = (gsize - 1) / ctx->sort_memory + 1;
+                  if (np > 1)
+                    { if (np > FK_EXACT_MAXPARTS)
+                        { fk_set_error(ctx, "exact_parts: the reference would cut this input into %lld buckets; this engine "
+                                            "follows its scheme up to %d", (long long) np, FK_EXACT_MAXPARTS);
+                          rc = FK_EUNSUPPORTED;
+                          break;
+                        }
+                      if ((rc = fkx_train_scheme(ctx, d_reads, d_roff, train, tran, (int) np)) != FK_OK) break;
+                    }
+                }
+              if ((rc = fkx_split_exact(ctx, d_reads, d_roff, nreads, tran, &sm_a, &ns, &ni, bc, bo)) != FK_OK) break;
+              nbk = (ctx->scheme_nparts > 1) ? ctx->scheme_nparts : 1;
             }
           else
             { nbk = ctx->prm.nbuckets;
@@ -2300,12 +2340,16 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
               if (tim) { hipStreamSynchronize(s); t_g += fk_wall() - w0; }
               const double w1 = tim ? fk_wall() : 0.;
               if (rc == FK_OK)
-                rc = count_bucket(ctx, p, bc[b], res, false, NULL, &ntab, NULL, &tm, ns_max);
+                rc = count_bucket(ctx, p, bc[b], res, false, NULL, &ntab, (h_roff != NULL && b == 0) ? h_roff : NULL, &tm,
+                                  ns_max);
               if (tim) t_c += fk_wall() - w1;
             }
           const double w2 = tim ? fk_wall() : 0.;
           if (rc == FK_OK && ntab > 0 && (rc = sort_union_table(ctx, ntab, res, &table, &tm)) != FK_OK)
             break;
+          if (h_roff != NULL)                  // exact_parts: Table_Split goes by BUCKET 0's weighted k-mers (count.c:1560-1565)
+            for (int x = 0; x < 256; x++)
+              res->wfirst[x] = ctx->exact_wfirst[x];
           if (tim)
             { t_s = fk_wall() - w2;
               fprintf(stderr, "  finish timing: gather %.3f s, count %.3f s, table sort %.3f s\n", t_g, t_c, t_s);

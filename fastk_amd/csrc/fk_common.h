@@ -19,6 +19,7 @@ typedef unsigned int       u32;
 // Minimizers are canonical 7-mers ordered by a bijective mix of their 14-bit code (odd multiplies and
 // xor-shifts are invertible mod 2^14, so distinct 7-mers never tie): FK_NRANKS rank values, of which
 // the 8192 images of canonical codes occur.
+#define FK_EXACT_MAXPARTS 32                // buckets an exact_parts run follows the reference's scheme to (fk_scheme.hip)
 #define FK_REGION_SLACK 32768              // records of room a streamed bucket region needs beyond its exact count (ragged stream ends)
 #define FKX_TABLE_FULL 100                   // fkx_aggregate: the table buffer took fewer records than qualified (internal)
 #define FK_CBASE_EXTRA ((2 << 20) + 64)      // partition sums of the chunk scan behind the chunk bases (fk_split.hip)
@@ -106,6 +107,12 @@ struct fk_ctx
   // other one is split into super-mers by a helper thread on `stream`
   hipStream_t copy_stream;
   hipEvent_t  reads_ev;     // all copies into the buffer handed to the helper have been issued before it
+  // exact_parts with several buckets: the reference's scheme (fk_scheme.hip)
+  int64_t    sort_memory;   // -M in bytes as the reference counts them (0: one bucket)
+  double     input_ratio;   // whole input / training block, in the reference's file bytes (0: by bases)
+  int       *min_part, *d_min_part;   // Min_Part: the prefix trie with bucket numbers at its leaves
+  int        scheme_pad, scheme_states, scheme_nparts;
+  int64_t    exact_wfirst[256];       // first-byte census of bucket 0's weighted k-mers (Table_Split's input)
   char      *d_pk, *h_pk;   // fk_push_packed: staging for codes, read offsets and invalid stretches (device / pinned)
   int64_t    pk_cap;
   char      *d_reads_alt;   // the idle read buffer (NULL until first needed)
@@ -219,8 +226,11 @@ int fkx_split_planned(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_
                       const int64_t *offsets, int64_t *counts, int64_t *ninst, int b0 = 0, int b1 = -1, int mode = 0);
 int fkx_train_tran(fk_ctx *ctx, const void *d_bases, const int64_t *h_roff, int64_t train_reads,
                    int nthreads, int *tran);
+int fkx_train_scheme(fk_ctx *ctx, const void *d_bases, const int64_t *d_roff, int64_t train, const int *tran,
+                     int nparts_req);
 int fkx_split_exact(fk_ctx *ctx, const void *d_bases, const int64_t *d_roff, int64_t nreads,
-                    const int *tran, void **d_out, int64_t *nsuper, int64_t *ninst);
+                    const int *tran, void **d_out, int64_t *nsuper, int64_t *ninst, int64_t *bucket_counts,
+                    int64_t *bucket_offs);
 int fkx_first_byte_census(fk_ctx *ctx, const void *d_recs, int64_t n, int rsize, int64_t *census);
 int fkx_split_fast(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void **d_out, int64_t *nsuper,
                    int64_t *ninst, int64_t *bucket_counts, int64_t *bucket_offsets);

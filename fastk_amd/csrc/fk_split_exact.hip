@@ -9,13 +9,14 @@
 // base order (Tran/Cran, split.c:529-575, 630-639), strict < on arrival, <= on the forced rescan
 // after MAX_SUPER k-mers, the clipping around non-ACGT bases (split.c:1167-1232) and the
 // end-of-read flush (split.c:1342-1347) -- sequentially per read, as the reference must, with
-// reads spread over threads.  Valid for the case the reference handles with one bucket and the
-// unpadded trie (NPARTS = 1, PAD = 0: every input whose k-mers fit -M), and for blocks cut like
-// io.c cuts them.  A compatibility mode: ~10x slower than the default splitter.
+// reads spread over threads.  With the scheme of fk_scheme.hip (padded minimizers, prefix trie, leaves dealt to
+// NPARTS buckets) also for inputs the reference cuts into several buckets: the super-mers come out grouped by bucket.
+// For blocks cut like io.c cuts them.  A compatibility mode: ~10x slower than the default splitter.
 #include "fk_common.h"
 
 #define XS_THREADS 128
 #define XS_RING    256          // >= 2 * nextpow2(K) for K <= 128 (MOD_LEN, FastK.c:446-450)
+#define XS_MAXPARTS FK_EXACT_MAXPARTS
 
 struct ExactArgs
 { const unsigned char *bases;
@@ -26,10 +27,14 @@ struct ExactArgs
   int       tran[4];            // rank of a,c,g,t
   int       smer_bytes;
   int       sww;
-  u32      *cnt;                // [nreads] super-mers of each read (count pass)
-  const u64 *off;               // [nreads] first record of each read (emit pass)
+  u32      *cnt;                // [nparts][nreads] super-mers of each read per bucket (count pass)
+  const u64 *off;               // [nparts][nreads] first record of each read in each bucket (emit pass)
   u32      *out;
   u64      *inst;               // [64] valid k-mer instances, spread
+  int       pad_len;            // minimizer length MIN_LEN + PAD (5 without a scheme)
+  int       pad2;               // 2 * PAD
+  const int *trie;              // Min_Part: < 0 children at -trie[x] + base, else bucket; NULL: one bucket
+  int       nparts;
 };
 
 __device__ __forceinline__ int xs_code(unsigned ch)
@@ -46,34 +51,50 @@ __global__ __launch_bounds__(XS_THREADS) void k_split_exact(ExactArgs a)
     return;
   const int K   = a.kmer;
   const int KM1 = K - 1;
-  const int MS  = K - 4;                                  // MAX_SUPER at PAD = 0
+  const int PL1 = a.pad_len - 1;
+  const int MS  = K - PL1;                                // MAX_SUPER, split.c:628
+  const u32 vmsk = (1u << (2 * a.pad_len)) - 1u;          // PAD_MSK (pad_len <= 15)
   const unsigned char *s = a.bases + a.roff[r] + a.bc_prefix;
   const int q = (int) (a.roff[r + 1] - a.roff[r]) - 1 - a.bc_prefix;     // split.c:1077-1079
   if (q < K)
-    { if (!EMIT) a.cnt[r] = 0;
+    { if (!EMIT)
+        for (int b = 0; b < a.nparts; b++)
+          a.cnt[(int64_t) b * a.nreads + r] = 0;
       return;
     }
   int rmsk = 1;
   while (rmsk < K) rmsk <<= 1;
   rmsk = 2 * rmsk - 1;
 
-  unsigned short ring[XS_RING];           // (min(c,u) << 1) | (u < c)
+  u32 ring[XS_RING];                      // (min(c,u) << 1) | (u < c)
   const int t0 = a.tran[0], t1 = a.tran[1], t2 = a.tran[2], t3 = a.tran[3];
   auto fwv = [&](int code) -> unsigned { return (unsigned) (code == 1 ? t1 : code == 2 ? t2 : code == 3 ? t3 : t0); };
-  auto rcv = [&](int code) -> unsigned { return (unsigned) (code == 1 ? t2 : code == 2 ? t1 : code == 3 ? t0 : t3) << 8; };
+  auto rcv = [&](int code) -> unsigned { return (unsigned) (code == 1 ? t2 : code == 2 ? t1 : code == 3 ? t0 : t3) << (2 * PL1); };
 
-  u32 nrec = 0;
+  u32 nrec[XS_MAXPARTS];                  // records of this read so far, per bucket
+  for (int b = 0; b < a.nparts; b++)
+    nrec[b] = 0;
   u64 ninst = 0;
-  const u64 obase = EMIT ? a.off[r] : 0ull;
   const int lenw  = a.smer_bytes >> 2;
   const int lensh = 24 - 8 * (a.smer_bytes & 3);
 
-  auto emit = [&](int first_end, int n, int flip)
-    { // k-mers ending at first_end .. first_end+n-1: bases s[first_end-KM1 .. first_end+n-1]
+  auto emit = [&](int first_end, int n, int flip, u32 mval)
+    { // k-mers ending at first_end .. first_end+n-1: bases s[first_end-KM1 .. first_end+n-1]; mval: their minimizer
+      int bk = 0;
+      if (a.trie != NULL)                                    // split.c:1149-1157
+        { int o = (int) (mval >> a.pad2);
+          bk = a.trie[o];
+          int y = a.pad2 - 2;
+          while (bk < 0)
+            { o = (int) ((mval >> y) & 3u) - bk;
+              bk = a.trie[o];
+              y -= 2;
+            }
+        }
       if (EMIT)
         { const unsigned char *b = s + (first_end - KM1);
           const int L = n - 1 + K;
-          u32 *dst = a.out + (obase + nrec) * (u64) a.sww;
+          u32 *dst = a.out + (a.off[(int64_t) bk * a.nreads + r] + nrec[bk]) * (u64) a.sww;
           for (int w = 0; w < a.sww; w++)
             { u32 x = 0;
               for (int j = 0; j < 16; j++)
@@ -88,21 +109,21 @@ __global__ __launch_bounds__(XS_THREADS) void k_split_exact(ExactArgs a)
               dst[w] = __builtin_bswap32(x);
             }
         }
-      nrec += 1;
+      nrec[bk] += 1;
       ninst += (u64) n;
     };
 
-  unsigned c = 0, u = 0, mp = 0, mc = 1024;
+  unsigned c = 0, u = 0, mp = 0, mc = vmsk + 1u;
   int m = 0, p;
   int ilo = -1, ihi = -1, phi = -1;
   for (p = 0; p < K; p++)                                   // split.c:1096-1134
     { const int code = xs_code(s[p]);
-      c = ((c << 2) | fwv(code)) & 1023u;
+      c = ((c << 2) | fwv(code)) & vmsk;
       u = (u >> 2) | rcv(code);
-      if (p >= 4)
+      if (p >= PL1)
         { const unsigned fl = (u < c);
           mp = fl ? u : c;
-          ring[p & rmsk] = (unsigned short) ((mp << 1) | fl);
+          ring[p & rmsk] = (mp << 1) | fl;
           if (mp < mc)
             { m = p; mc = mp; }
         }
@@ -120,11 +141,11 @@ __global__ __launch_bounds__(XS_THREADS) void k_split_exact(ExactArgs a)
       bool closing, force;
       if (p < q)
         { code = xs_code(s[p]);
-          c = ((c << 2) | fwv(code)) & 1023u;
+          c = ((c << 2) | fwv(code)) & vmsk;
           u = (u >> 2) | rcv(code);
           const unsigned fl = (u < c);
           mp = fl ? u : c;
-          ring[p & rmsk] = (unsigned short) ((mp << 1) | fl);
+          ring[p & rmsk] = (mp << 1) | fl;
           force   = (p - m >= MS);
           closing = force || (mp < mc);
         }
@@ -149,7 +170,7 @@ __global__ __launch_bounds__(XS_THREADS) void k_split_exact(ExactArgs a)
           else
             n = p - last;
           if (n > 0)
-            emit(last, n, ring[m & rmsk] & 1);
+            emit(last, n, ring[m & rmsk] & 1, mc);
           if (done)
             break;
           if (force)                                         // split.c:1304-1320
@@ -173,7 +194,8 @@ __global__ __launch_bounds__(XS_THREADS) void k_split_exact(ExactArgs a)
     }
 
   if (!EMIT)
-    a.cnt[r] = nrec;
+    for (int b = 0; b < a.nparts; b++)
+      a.cnt[(int64_t) b * a.nreads + r] = nrec[b];
   if (ninst != 0)
     atomicAdd(&a.inst[r & 63], ninst);
 }
@@ -223,16 +245,22 @@ int fkx_train_tran(fk_ctx *ctx, const void *d_bases, const int64_t *h_roff, int6
   return (FK_OK);
 }
 
+/* bucket_counts / bucket_offs (records): the super-mers come out grouped by bucket when the context holds a scheme
+   (ctx->scheme_nparts > 1, fkx_train_scheme); one bucket otherwise. */
 int fkx_split_exact(fk_ctx *ctx, const void *d_bases, const int64_t *d_roff, int64_t nreads,
-                    const int *tran, void **d_out, int64_t *nsuper, int64_t *ninst)
+                    const int *tran, void **d_out, int64_t *nsuper, int64_t *ninst, int64_t *bucket_counts,
+                    int64_t *bucket_offs)
 { hipStream_t s = ctx->stream;
   *nsuper = 0; *ninst = 0; *d_out = NULL;
+  const int nparts = (ctx->scheme_nparts > 1) ? ctx->scheme_nparts : 1;
+  for (int b = 0; b < nparts; b++)
+    bucket_counts[b] = bucket_offs[b] = 0;
   if (nreads == 0)
     return (FK_OK);
-  if (ctx->prm.kmer > 128 || ctx->prm.kmer < 8)
+  if (ctx->prm.kmer > 128 || ctx->prm.kmer < 8 || nparts > XS_MAXPARTS)
     return (FK_EUNSUPPORTED);
-  u32 *d_cnt = (u32 *) fk_slot(ctx, FK_SLOT_EX_HEADS, nreads * 4);
-  u64 *d_off = (u64 *) fk_slot(ctx, FK_SLOT_EX_KOFF, nreads * 8);
+  u32 *d_cnt = (u32 *) fk_slot(ctx, FK_SLOT_EX_HEADS, nreads * nparts * 4);
+  u64 *d_off = (u64 *) fk_slot(ctx, FK_SLOT_EX_KOFF, (nreads * nparts + 1) * 8);
   if (d_cnt == NULL || d_off == NULL)
     return (FK_ENOMEM);
   u64 *d_inst = ctx->d_scratch + 2048;          // [64] instances, [64] = total records
@@ -250,13 +278,19 @@ int fkx_split_exact(fk_ctx *ctx, const void *d_bases, const int64_t *d_roff, int
   a.off = d_off;
   a.out = NULL;
   a.inst = d_inst;
+  a.nparts = nparts;
+  a.pad_len = 5 + ((nparts > 1) ? ctx->scheme_pad : 0);
+  a.pad2 = (nparts > 1) ? 2 * ctx->scheme_pad : 0;
+  a.trie = (nparts > 1) ? ctx->d_min_part : NULL;
   const unsigned grid = (unsigned) ((nreads + XS_THREADS - 1) / XS_THREADS);
   FK_HIP(ctx, hipMemsetAsync(d_inst, 0, 72 * sizeof(u64), s));
   hipLaunchKernelGGL(k_split_exact<false>, dim3(grid), dim3(XS_THREADS), 0, s, a);
-  hipLaunchKernelGGL(k_exscan_tiles, dim3(1), dim3(256), 0, s, (const u32 *) d_cnt, nreads, d_off,
+  hipLaunchKernelGGL(k_exscan_tiles, dim3(1), dim3(256), 0, s, (const u32 *) d_cnt, nreads * nparts, d_off,
                      d_inst + 64);
   FK_LAUNCH_CHECK(ctx);
   FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch, d_inst, 72 * sizeof(u64), hipMemcpyDeviceToHost, s));
+  for (int b = 1; b < nparts; b++)                       // where bucket b starts: the scan at its first read
+    FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch + 128 + b, d_off + (int64_t) b * nreads, 8, hipMemcpyDeviceToHost, s));
   FK_HIP(ctx, hipStreamSynchronize(s));
   const int64_t ns = (int64_t) ctx->h_scratch[64];
   int64_t ni = 0;
@@ -264,6 +298,11 @@ int fkx_split_exact(fk_ctx *ctx, const void *d_bases, const int64_t *d_roff, int
     ni += (int64_t) ctx->h_scratch[x];
   *nsuper = ns;
   *ninst = ni;
+  for (int b = 0; b < nparts; b++)
+    { bucket_offs[b] = (b == 0) ? 0 : (int64_t) ctx->h_scratch[128 + b];
+      if (b > 0) bucket_counts[b - 1] = bucket_offs[b] - bucket_offs[b - 1];
+    }
+  bucket_counts[nparts - 1] = ns - bucket_offs[nparts - 1];
   if (ns == 0)
     return (FK_OK);
   void *out = fk_slot(ctx, FK_SLOT_SM_A, ns * ctx->wid.smer_stride);

@@ -873,6 +873,8 @@ int main(int argc, char *argv[])
   if (fk_create(&prm,&ctx) != FK_OK)
     die(NULL,"fk_create");
   t_created = now();
+  if (EXACT)          /* -x -M<int>: the reference's sort memory (12 GB unless given, FastK.c:235,291), hence its buckets */
+    fk_set_sort_memory(ctx,(int64_t) (MEM_GB > 0 ? MEM_GB : 12)*1000000000ll,0.);
   if (RANK >= 0 && NGPUS > 1)
     { char id[128];
       share_unique_id(id);

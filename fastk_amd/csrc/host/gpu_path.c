@@ -48,6 +48,8 @@ int Determine_Scheme(DATA_BLOCK *block)
 #endif
   if (fk_create(&p,&GPU) != FK_OK)
     die("fk_create");
+  if (p.exact_parts)                /* the reference's buckets (NPARTS of FastK.c:417-429) under its own scheme */
+    fk_set_sort_memory(GPU,SORT_MEMORY,block->ratio);
   if (fk_train_block(GPU,block->bases,block->boff,block->nreads) != FK_OK)   /* split.c:529-575 */
     die("fk_train_block");
   fk_get_widths(KMER,&w);

@@ -92,6 +92,13 @@ void fk_default_params(fk_params *p);
    Replaces the globals of FastK.h:34-83 plus the SORT_PATH temp files (split.c:1454). */
 int         fk_create(const fk_params *p, fk_ctx **ctx);
 void        fk_destroy(fk_ctx *ctx);
+/* exact_parts runs only.  sort_memory: the reference's -M in bytes (12e9 by default there, -M<int> x 1e9,
+   FastK.c:235,291); input_ratio: whole input over first block in file bytes where the caller knows it (io.c:528,749;
+   0: by bases).  The run then cuts the input into the NPARTS buckets the reference would use (FastK.c:417-429) under
+   the reference's own scheme -- the padded-minimizer trie of Determine_Scheme and the drand48 deal of assign_pieces
+   (split.c:289-381,437-472,617-766) -- so that every hidden .ktab part file is cut where the reference cuts it also
+   when NPARTS > 1.  Up to 32 buckets and 15-base minimizers.  Not called: one bucket. */
+int         fk_set_sort_memory(fk_ctx *ctx, int64_t sort_memory, double input_ratio);
 /* Returns the context's device memory and pinned staging buffers while the results of the last fk_finish (host
    memory; with keep_table != 0 also the sorted table in HBM that fk_write_ktab_device reads) stay valid; thread-safe against readers of those results, so a driver can run it beside its file
    writers.  The reference has no counterpart: its buffers go back with free() at once (count.c:1870-1890). */

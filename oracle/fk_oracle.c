@@ -136,6 +136,10 @@ static void emit_supermer(Emitter *E, const char *s, int n, int flip)
   E->kmers += n;
 }
 
+static const orc_scheme *Dist_Scheme;   /* set by orc_fastk_parts around its distribute call */
+static uint8_t **Dist_Bucket;           /* bucket of every record emitted (parallel to *out), realloc'd */
+static int64_t  *Dist_Bcap;
+
 int64_t orc_distribute_block(const orc_params *P, const char *bases, const int64_t *boff,
                              int64_t nreads, int bc_prefix,
                              uint8_t **out, int64_t *nout, int64_t *cap)
@@ -248,7 +252,22 @@ int64_t orc_distribute_block(const orc_params *P, const char *bases, const int64
                 n = p-last;
 
               if (n > 0)                                     /* split.c:1234-1302 */
-                emit_supermer(&E,s+(last-(K-1)),n,rflp[m&rmsk]);
+                { if (Dist_Scheme != NULL)                   /* the bucket of its minimizer, split.c:1149-1157 */
+                    { const orc_scheme *S = Dist_Scheme;
+                      int o = (int) (mc >> (2*S->pad)), b = S->part[o], y = 2*S->pad-2;
+                      while (b < 0)
+                        { o = (int) ((mc >> y) & 3) - b;
+                          b = S->part[o];
+                          y -= 2;
+                        }
+                      if (*nout >= *Dist_Bcap)
+                        { *Dist_Bcap = (*nout)*2 + 1024;
+                          *Dist_Bucket = realloc(*Dist_Bucket,(size_t) *Dist_Bcap);
+                        }
+                      (*Dist_Bucket)[*nout] = (uint8_t) b;
+                    }
+                  emit_supermer(&E,s+(last-(K-1)),n,rflp[m&rmsk]);
+                }
 
               if (done)
                 break;
@@ -520,6 +539,272 @@ int orc_fastk(const orc_params *P, const char *bases, const int64_t *boff, int64
   return (0);
 }
 
+/* ---------------------------------------------------------------------------------------
+ * the bucket scheme                   Determine_Scheme split.c:617-766 (loop), 116-270 (census),
+ *                                     437-472 (refine_tree), 289-381 (assign_pieces)
+ * Trained on the first block (Get_First_Block, io.c:2606-2630: the caller passes its reads).  The
+ * trainer's super-mer rule is not Distribute_Block's: every byte that is not acgt counts as 'a',
+ * the rescan after a forced cut takes the FIRST smallest value (strict <), a read's last super-mer
+ * is not counted.  Leaves are dealt with drand48, which the reference never seeds: in glibc that is
+ * X' = 0x5DEECE66D X + 0xB mod 2^48 from X = 0 (the library's state starts zeroed), value X'/2^48.
+ */
+static void scheme_census(const orc_params *P0, int pad, const char *bases, const int64_t *boff, int64_t nreads,
+                          int bc_prefix, const int64_t *trie, int64_t *cnt)
+{ const int K = P0->kmer, PL = 5+pad, PL1 = PL-1, MS = K-PL1;
+  const uint64_t ptot = 1ull << (2*PL), pmsk = ptot-1;
+  uint64_t fw[256], rc[256], *ring;
+  int      rlen, rmsk, x;
+  int64_t  r;
+
+  for (x = 0; x < 256; x++)
+    { fw[x] = (uint64_t) P0->tran[0];
+      rc[x] = ((uint64_t) P0->tran[3]) << (2*PL1);
+    }
+  fw['c'] = fw['C'] = P0->tran[1];  rc['c'] = rc['C'] = ((uint64_t) P0->tran[2]) << (2*PL1);
+  fw['g'] = fw['G'] = P0->tran[2];  rc['g'] = rc['G'] = ((uint64_t) P0->tran[1]) << (2*PL1);
+  fw['t'] = fw['T'] = P0->tran[3];  rc['t'] = rc['T'] = ((uint64_t) P0->tran[0]) << (2*PL1);
+  rlen = 1;
+  while (rlen < K) rlen <<= 1;
+  rlen <<= 1;
+  rmsk = rlen-1;
+  ring = malloc(sizeof(uint64_t)*rlen);
+  for (r = 0; r < nreads; r++)
+    { const char *s = bases + boff[r] + bc_prefix;
+      int  q = (int) (boff[r+1] - boff[r]) - 1 - bc_prefix;
+      uint64_t c = 0, u = 0, mp, mc = ptot;
+      int  m = 0, p, last, n;
+
+      if (q < K)
+        continue;
+      for (p = 0; p < K; p++)
+        { x = (uint8_t) s[p];
+          c = ((c << 2) | fw[x]) & pmsk;
+          u = (u >> 2) | rc[x];
+          if (p >= PL1)
+            { mp = (u < c) ? u : c;
+              ring[p&rmsk] = mp;
+              if (mp < mc)
+                { m = p; mc = mp; }
+            }
+        }
+      last = K-1;
+      for (p = K; p < q; p++)
+        { int force;
+          x = (uint8_t) s[p];
+          c = ((c << 2) | fw[x]) & pmsk;
+          u = (u >> 2) | rc[x];
+          mp = (u < c) ? u : c;
+          ring[p&rmsk] = mp;
+          force = (p-m >= MS);
+          if (force || mp < mc)
+            { int64_t o = (int64_t) (mc >> (2*pad)), v = trie[o];
+              int b = 2*pad-2;
+              while (v < 0)
+                { o = (int64_t) ((mc >> b) & 3) - v;
+                  v = trie[o];
+                  b -= 2;
+                }
+              cnt[o] += p-last;
+              if (force)
+                { m += 1;
+                  mc = ring[m&rmsk];
+                  for (n = m+1; n <= p; n++)
+                    if (ring[n&rmsk] < mc)
+                      { m = n; mc = ring[n&rmsk]; }
+                }
+              else
+                { m = p; mc = mp; }
+              last = p;
+            }
+        }
+    }
+  free(ring);
+}
+
+static void scheme_refine(int lev, int64_t i, int64_t kthresh, int64_t *count, int *states, int *pad)
+{ lev += 1;
+  if (count[i] >= 0)
+    { if (count[i] > kthresh)
+        { int a;
+          count[i] = -(*states);
+          for (a = 0; a < 4; a++)
+            count[(*states)++] = 0;
+          if (lev > *pad)
+            *pad += 2;
+        }
+      else
+        count[i] = 0;
+    }
+  else
+    { int64_t j = -count[i];
+      int a;
+      for (a = 0; a < 4; a++)
+        scheme_refine(lev,j+a,kthresh,count,states,pad);
+    }
+}
+
+static const int64_t *Sort_Count;
+static int by_count_desc(const void *l, const void *r)     /* ties keep their order: a merge sort, like glibc's qsort */
+{ int x = *((const int *) l), y = *((const int *) r);
+  if (Sort_Count[x] != Sort_Count[y])
+    return (Sort_Count[x] > Sort_Count[y] ? -1 : 1);
+  return (x < y ? -1 : (x > y));
+}
+
+int orc_scheme_train(const orc_params *P, const char *bases, const int64_t *boff, int64_t nreads,
+                     int bc_prefix, int nparts, orc_scheme *S)
+{ int      states = 1024, pad = 0, npieces = 2*nparts, i, o;
+  int64_t *count = calloc(1024,sizeof(int64_t)), *trie, ktot = 0, kthresh, max_count, last_max = 0;
+  uint64_t rnd = 0;       /* glibc's unseeded state: X = 0 (its static drand48 data is zeroed), not POSIX's 0x1234ABCD330E */
+
+  for (;;)
+    { trie = malloc(sizeof(int64_t)*states);
+      for (i = 0; i < states; i++)
+        { trie[i] = count[i] < 0 ? count[i] : 0;
+          if (count[i] >= 0) count[i] = 0;
+        }
+      scheme_census(P,pad,bases,boff,nreads,bc_prefix,trie,count);
+      free(trie);
+      ktot = 0;
+      for (i = 0; i < states; i++)
+        if (count[i] >= 0)
+          ktot += count[i];
+      kthresh = ktot/npieces;
+      max_count = 0;
+      o = states;
+      for (i = 0; i < states; i++)
+        if (count[i] >= 0)
+          { if (count[i] > kthresh) o += 4;
+            if (count[i] > max_count) max_count = count[i];
+          }
+      if (o == states)
+        break;
+      if (pad > 0 && last_max < 1.02*max_count)
+        { npieces = (int) (ktot/max_count+1);
+          nparts  = npieces/2;
+          break;
+        }
+      if (5+pad >= P->kmer-1)
+        break;
+      count = realloc(count,sizeof(int64_t)*o);
+      for (i = states; i < o; i++)
+        count[i] = 0;
+      { int st = states;
+        for (i = 0; i < 1024; i++)
+          scheme_refine(0,i,kthresh,count,&st,&pad);
+      }
+      states = o;
+      last_max = max_count;
+    }
+  if (nparts < 1) nparts = 1;
+  { int64_t  pmer = ktot/nparts, *buck = calloc(nparts,sizeof(int64_t)), p, v, t;
+    int     *perm = malloc(sizeof(int)*states), j, n, x;
+    for (i = 0; i < states; i++) perm[i] = i;
+    Sort_Count = count;
+    qsort(perm,states,sizeof(int),by_count_desc);
+    for (i = 0; i < states; i++)
+      { x = perm[i];
+        p = count[x];
+        if (p < 0) continue;
+        if (p == 0) { count[x] = nparts-1; continue; }
+        v = 0;
+        for (j = 0; j < nparts; j++)
+          if (buck[j]+p <= pmer)
+            v += pmer-buck[j];
+        if (v == 0)
+          { n = 0;
+            for (j = 1; j < nparts; j++)
+              if (buck[j] < buck[n]) n = j;
+            buck[n] += p;
+            count[x] = n;
+          }
+        else
+          { rnd = (rnd*0x5DEECE66Dull + 0xBull) & ((1ull << 48)-1);
+            t = (int64_t) ((double) v * ((double) rnd / 281474976710656.0));
+            v = 0;
+            for (j = 0; j < nparts; j++)
+              if (buck[j]+p <= pmer)
+                { v += pmer-buck[j];
+                  if (v >= t)
+                    { buck[j] += p;
+                      count[x] = j;
+                      break;
+                    }
+                }
+          }
+      }
+    free(perm);
+    free(buck);
+  }
+  S->pad = pad; S->states = states; S->nparts = nparts;
+  S->part = malloc(sizeof(int)*states);
+  for (i = 0; i < states; i++)
+    S->part[i] = (int) count[i];
+  free(count);
+  return (0);
+}
+
+/* the whole path with the reference's buckets (count.c:1202 bucket loop): every bucket is sorted and counted on
+   its own, histograms add, tables are disjoint and merged by key; wfirst is BUCKET 0's census -- Table_Split's
+   input (count.c:1560-1565) */
+static int Cmp_KB;
+static int by_key(const void *l, const void *r) { return memcmp(l,r,Cmp_KB); }
+
+int orc_fastk_parts(const orc_params *P, const orc_scheme *S, const char *bases, const int64_t *boff,
+                    int64_t nreads, int bc_prefix, int cutoff, orc_result *R)
+{ orc_params PP = *P;
+  uint8_t *smers = NULL, *bucket = NULL, *part;
+  int64_t  ns = 0, cap = 0, bcap = 0, i;
+  int      b;
+
+  orc_params_init(&PP,P->kmer,S->pad);                  /* PAD_LEN-base minimizers; the record widths stay P's */
+  memcpy(PP.tran,P->tran,sizeof(PP.tran));
+  PP.smer = P->smer; PP.slen_bits = P->slen_bits; PP.slen_bytes = P->slen_bytes;
+  PP.smer_bytes = P->smer_bytes; PP.smer_word = P->smer_word;
+  memset(R,0,sizeof(*R));
+  Dist_Scheme = S; Dist_Bucket = &bucket; Dist_Bcap = &bcap;
+  R->ninst = orc_distribute_block(&PP,bases,boff,nreads,bc_prefix,&smers,&ns,&cap);
+  Dist_Scheme = NULL;
+  R->nsuper = ns;
+  part = malloc((size_t) (ns > 0 ? ns : 1)*P->smer_word);
+  for (b = 0; b < S->nparts; b++)
+    { orc_result Rb;
+      uint8_t   *kl = NULL;
+      int64_t    nb = 0, nw, ovf, nd;
+      for (i = 0; i < ns; i++)
+        if (bucket[i] == b)
+          memcpy(part+(nb++)*P->smer_word,smers+i*P->smer_word,P->smer_word);
+      memset(&Rb,0,sizeof(Rb));
+      orc_msd_sort(part,nb,P->smer_word,P->smer_word);
+      nw = orc_kmer_list(P,part,nb,&kl,&ovf,&nd);
+      if (b == 0)
+        for (i = 0; i < nw; i++)
+          R->wfirst[kl[i*P->kmer_word]] += 1;
+      orc_msd_sort(kl,nw,P->kmer_word,P->kmer_bytes);
+      orc_count_sorted(P,kl,nw,cutoff,&Rb);
+      R->ndistinct_super += nd;
+      R->nweighted += nw;
+      R->ndistinct += Rb.ndistinct;
+      R->max_inst += Rb.max_inst + ovf;
+      for (i = 1; i < 0x8000; i++)
+        R->hist[i] += Rb.hist[i];
+      if (Rb.ntable > 0)
+        { R->table = realloc(R->table,(size_t) (R->ntable+Rb.ntable)*P->kmer_word);
+          memcpy(R->table+R->ntable*P->kmer_word,Rb.table,(size_t) Rb.ntable*P->kmer_word);
+          R->ntable += Rb.ntable;
+        }
+      free(Rb.table);
+      free(kl);
+    }
+  Cmp_KB = P->kmer_bytes;
+  if (R->ntable > 0)
+    qsort(R->table,(size_t) R->ntable,(size_t) P->kmer_word,by_key);
+  free(part);
+  free(bucket);
+  free(smers);
+  return (0);
+}
+
 /* brute force: every valid window's canonical k-mer, sorted, run-length counted */
 int orc_brute(int kmer, const char *bases, const int64_t *boff, int64_t nreads,
               int bc_prefix, int cutoff, orc_result *R)
@@ -591,7 +876,9 @@ void orc_table_split(const orc_params *P, const orc_result *R, int nthreads, int
 { int64_t asize, sum, thr;
   int     x, n, beg;
 
-  asize = R->nweighted * P->kmer_word;
+  asize = 0;                         /* the array msd_sort partitions is bucket 0's weighted k-mer list (count.c:1560) */
+  for (x = 0; x < 256; x++)
+    asize += R->wfirst[x] * P->kmer_word;
   thr   = asize / nthreads;
   n = 0; sum = 0; beg = 0;
   for (x = 0; x < 256; x++)

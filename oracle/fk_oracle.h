@@ -46,6 +46,13 @@ typedef struct
     int64_t  wfirst[256];    /* weighted k-mers per canonical first byte (Kparts/KMER_WORD) */
   } orc_result;
 
+/* the bucket scheme of Determine_Scheme (split.c:617-766): part[] = Min_Part, the prefix trie over the
+   (5+pad)-base minimizers: part[x] < 0 => children at -part[x]+base, else the bucket of the leaf */
+typedef struct
+  { int  pad, states, nparts;
+    int *part;
+  } orc_scheme;
+
 /* widths for k with PAD extra minimizer bases (FastK.c:417,446-468; split.c:617-628) */
 void orc_params_init(orc_params *P, int kmer, int pad);
 
@@ -83,6 +90,16 @@ void orc_count_sorted(const orc_params *P, const uint8_t *kmers, int64_t nk, int
 /* Whole path on one block set: distribute -> sort -> expand -> sort -> count. */
 int orc_fastk(const orc_params *P, const char *bases, const int64_t *boff, int64_t nreads,
               int bc_prefix, int cutoff, orc_result *R);
+
+/* Determine_Scheme on the reads of the first block (P->tran trained): census by the trainer's own super-mer rule
+   (split.c:116-270), refine_tree (split.c:437-472), assign_pieces with drand48 from its default seed
+   (split.c:289-381).  nparts: the buckets asked for (FastK.c:429); S->nparts what the scheme settles on. */
+int orc_scheme_train(const orc_params *P, const char *bases, const int64_t *boff, int64_t nreads,
+                     int bc_prefix, int nparts, orc_scheme *S);
+
+/* orc_fastk bucket by bucket under a scheme (count.c:1202): same histogram and table, wfirst = bucket 0's census */
+int orc_fastk_parts(const orc_params *P, const orc_scheme *S, const char *bases, const int64_t *boff,
+                    int64_t nreads, int bc_prefix, int cutoff, orc_result *R);
 
 /* Independent brute-force definition: sort every canonical k-mer instance directly. */
 int orc_brute(int kmer, const char *bases, const int64_t *boff, int64_t nreads,

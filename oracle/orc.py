@@ -68,6 +68,10 @@ def lib():
                                 C.c_int, C.POINTER(OrcResult)]
         L.orc_brute.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                 C.POINTER(OrcResult)]
+        L.orc_scheme_train.argtypes = [C.POINTER(OrcParams), C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
+                                       C.POINTER(OrcScheme)]
+        L.orc_fastk_parts.argtypes = [C.POINTER(OrcParams), C.POINTER(OrcScheme), C.c_void_p, C.c_void_p, C.c_int64,
+                                      C.c_int, C.c_int, C.POINTER(OrcResult)]
         L.orc_result_free.argtypes = [C.POINTER(OrcResult)]
         L.orc_hist_bytes.restype = C.c_int64
         L.orc_hist_bytes.argtypes = [C.c_int, C.POINTER(OrcResult), C.c_void_p]
@@ -86,6 +90,10 @@ def lib():
         L.free.argtypes = [C.c_void_p]
         _lib = L
     return _lib
+
+
+class OrcScheme(C.Structure):
+    _fields_ = [("pad", C.c_int), ("states", C.c_int), ("nparts", C.c_int), ("part", C.POINTER(C.c_int))]
 
 
 def params(kmer, pad=0):
@@ -183,6 +191,58 @@ def hist_file_bytes(kmer, hist, max_inst):
     h = np.asarray(hist, dtype=np.int64)
     return (struct.pack("<iii", kmer, 1, 0x7fff) + struct.pack("<qq", int(h[1]), int(max_inst))
             + h[1:0x8000].tobytes())
+
+
+def first_block_reads(boff):
+    """reads Get_First_Block(io, 1e9) hands to Determine_Scheme (io.c:2606-2630, END_SEQ io.c:547-556): up to 1e9/150
+    reads, cut once the block is within DT_MINIM = 100,000 bytes of 1e9 + that many terminators"""
+    nreads = len(boff) - 1
+    maxrds = 1000000000 // 150
+    omax = 1000000000 + maxrds
+    ends = np.asarray(boff[1:], dtype=np.int64) - int(boff[0])
+    over = np.nonzero(ends > omax - 100000)[0]
+    train = nreads if len(over) == 0 else int(over[0]) + 1
+    return min(train, maxrds, nreads)
+
+
+def scheme(kmer, bases, boff, nparts, nthreads=4, bc_prefix=0):
+    """Determine_Scheme restated: (pad, nparts, Min_Part as a list) for the training block of these reads"""
+    L = lib()
+    P = params(kmer)
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    boff = np.ascontiguousarray(boff, dtype=np.int64)
+    train = first_block_reads(boff)
+    L.orc_train_tran(C.byref(P), bases.ctypes.data, boff.ctypes.data, train, nthreads)
+    S = OrcScheme()
+    L.orc_scheme_train(C.byref(P), bases.ctypes.data, boff.ctypes.data, train, bc_prefix, nparts, C.byref(S))
+    part = [S.part[i] for i in range(S.states)]
+    return P, S, part
+
+
+def fastk_parts(kmer, bases, boff, sort_memory, cutoff=1, bc_prefix=0, nthreads=4):
+    """The whole path with the reference's buckets for a sort memory of `sort_memory` bytes (FastK.c:417-429):
+    same histogram and table as fastk(); wfirst -- hence the part boundaries -- from bucket 0 alone."""
+    L = lib()
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    boff = np.ascontiguousarray(boff, dtype=np.int64)
+    nreads = len(boff) - 1
+    train = first_block_reads(boff)
+    totlen = int(boff[train] - boff[0]) - train
+    ratio = 1.0 if train >= nreads else float(int(boff[nreads] - boff[0])) / float(totlen + train)
+    kw = ((2 * kmer + 7) >> 3) + 2
+    gsize = int(float(totlen - kmer * train) * ratio * kw)
+    nparts = (gsize - 1) // sort_memory + 1
+    if nparts <= 1:
+        return fastk(kmer, bases, boff, cutoff=cutoff, bc_prefix=bc_prefix, nthreads=nthreads)
+    P, S, _ = scheme(kmer, bases, boff, nparts, nthreads, bc_prefix)
+    R = OrcResult()
+    L.orc_fastk_parts(C.byref(P), C.byref(S), bases.ctypes.data, boff.ctypes.data, nreads, bc_prefix, cutoff,
+                      C.byref(R))
+    out = Result(kmer, R, P.kmer_word)
+    out.params = P
+    out.nparts = S.nparts
+    L.orc_result_free(C.byref(R))
+    return out
 
 
 def fastk(kmer, bases, boff, cutoff=1, bc_prefix=0, train=True, pad=0, nthreads=4):

@@ -94,6 +94,18 @@ LARGE_CASES = [
          synth=dict(seed=20251001, genome_len=20000000, read_len=150, err_ppm=1000, nreads=6666666)),
     dict(name="hifi50x20M_k40_t4_T4", kind="large", k=40, cutoff=4, T=4, fmt="fasta",
          synth=dict(seed=20251001, genome_len=20000000, read_len=15000, err_ppm=2000, nreads=66666)),
+    # the reference with a small sort memory: NPARTS = 2 (unpadded trie, drand48 deal), 3, and 9 (the trie is padded)
+    # buckets -- what the hidden part files then look like depends on its scheme (split.c:289-381,437-472,617-766)
+    dict(name="configs0_k40_t1_T4_M1", kind="large", k=40, cutoff=1, T=4, fmt="fastq", ref_extra=["-M1"],
+         synth=dict(seed=20251001, genome_len=10000000, read_len=150, err_ppm=1000, nreads=1000000)),
+    dict(name="illumina50x20M_k40_t1_T4_M3", kind="large", k=40, cutoff=1, T=4, fmt="fastq", ref_extra=["-M3"],
+         synth=dict(seed=20251001, genome_len=20000000, read_len=150, err_ppm=1000, nreads=6666666)),
+    dict(name="illumina50x20M_k40_t1_T4_M1", kind="large", k=40, cutoff=1, T=4, fmt="fastq", ref_extra=["-M1"],
+         synth=dict(seed=20251001, genome_len=20000000, read_len=150, err_ppm=1000, nreads=6666666)),
+    # 10 M reads: the first block is two thirds of the input (ratio 1.5, io.c:528), 14 buckets, and seven heavy
+    # minimizers are padded to 7 bases (PAD = 2, 1052 trie states)
+    dict(name="illumina50x30M_k40_t1_T4_M1", kind="large", k=40, cutoff=1, T=4, fmt="fastq", ref_extra=["-M1"],
+         synth=dict(seed=20251001, genome_len=30000000, read_len=150, err_ppm=1000, nreads=10000000)),
 ]
 
 # Above 4 GiB (`--huge`, ~15 min of reference time, 10 GB input file): 50x of a 200 Mbp genome in
@@ -127,6 +139,9 @@ def main():
     cases = LARGE_CASES if "--large" in sys.argv else (CASES + LARGE_CASES if "--all" in sys.argv else CASES)
     if "--huge" in sys.argv:
         cases = HUGE_CASES
+    only = [a[7:] for a in sys.argv if a.startswith("--only=")]
+    if only:
+        cases = [c for c in CASES + LARGE_CASES + HUGE_CASES if c["name"] in only]
     for case in cases:
         name = case["name"]
         k = case["k"]
@@ -161,7 +176,7 @@ def main():
             orc.write_fasta(path, bases, boff, width=0 if case["kind"] == "edge" else 100)
         else:
             orc.write_fastq(path, bases, boff)
-        orc.run_ref_fastk(path, k, case["cutoff"], case["T"], d)
+        orc.run_ref_fastk(path, k, case["cutoff"], case["T"], d, extra=tuple(case.get("ref_extra", ())))
         h = orc.read_hist(os.path.join(d, "x.hist"))
         t = orc.read_ktab(os.path.join(d, "x"))
         nz = np.nonzero(h["hist"])[0]

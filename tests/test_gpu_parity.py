@@ -1328,6 +1328,51 @@ def test_reference_digests_above_fixture_size(name, tmp_path):
         assert util.sha_file(tmp_path / fname) == digest, fname
 
 
+@pytest.mark.parametrize("name", ["configs0_k40_t1_T4_M1", "illumina50x20M_k40_t1_T4_M3", "illumina50x20M_k40_t1_T4_M1",
+                                  "illumina50x30M_k40_t1_T4_M1"])
+def test_exact_parts_follows_the_reference_scheme_to_several_buckets(name, tmp_path):
+    """with a small sort memory the reference cuts its input into NPARTS > 1 buckets -- 2 at
+    BASELINE configs[0] with -M1 (unpadded trie, leaves dealt by assign_pieces' drand48 draws), 3 and 9 at the 6.7 M-read
+    sample with -M3 / -M1, 14 at a 10 M-read sample with -M1 (first block = two thirds of the input, and Determine_Scheme
+    pads seven heavy minimizers to 7 bases) -- and cuts the hidden .ktab part files by the threads that sort BUCKET 0's
+    weighted k-mers.  exact_parts with the same sort memory retrains that
+    scheme (fk_scheme.hip) and writes every file of the reference byte for byte: through the library, FastK_amd -x -M
+    and the reference's own main() over the shim (FASTK_AMD_EXACT=1)."""
+    import os, subprocess
+    case, bases, boff = util.load_case(name)
+    exp = case["expected"]
+    k, T, cutoff = case["k"], case["T"], case["cutoff"]
+    mem = int(case["ref_extra"][0][2:])
+    lib_dir = tmp_path / "lib"
+    lib_dir.mkdir()
+    with fastk_amd.Context(kmer=k, table_cutoff=cutoff, nthreads=T, exact_parts=True) as ctx:
+        ctx._ck(ctx.L.fk_set_sort_memory(ctx.h, mem * 1000000000, 0.0))
+        _push_in_pieces(ctx, bases, boff, 3)
+        res = ctx.finish()
+        assert ctx.debug_get("scheme_nparts") > 1
+        util.check_against_golden(case, res.hist, res.max_inst, res.table)
+        ctx.write_hist(res, str(lib_dir / "x.hist"))
+        ctx.write_ktab(res, str(lib_dir), "x")
+        del res
+    for fname, digest in exp["file_sha256"].items():
+        assert util.sha_file(lib_dir / fname) == digest, ("library", fname)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = str(tmp_path / ("x." + case["fmt"]))
+    util.write_fastx(path, bases, boff, case["fmt"] == "fastq")
+    args = ["-k%d" % k, "-t%d" % cutoff, "-T%d" % T, "-M%d" % mem]
+    for cmd in ([os.path.join(root, "fastk_amd", "bin", "FastK_amd")] + args + ["-x", path],
+                [os.path.join(orc.REF_DIR, "FastK_gpu")] + args + ["-P" + str(tmp_path), path]):
+        if not os.path.exists(cmd[0]):
+            continue
+        for f in os.listdir(tmp_path):
+            if f not in (os.path.basename(path), "lib"):
+                os.remove(tmp_path / f)
+        subprocess.run(cmd, check=True, cwd=str(tmp_path), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                       env=dict(os.environ, FASTK_AMD_EXACT="1"))
+        for fname, digest in exp["file_sha256"].items():
+            assert util.sha_file(tmp_path / fname) == digest, (os.path.basename(cmd[0]), fname)
+
+
 @pytest.mark.parametrize("name", LARGE[:2])
 def test_drivers_against_reference_digests_above_fixture_size(name, tmp_path):
     """The C driver (FastK_amd, text parsed on the GPU; then -x) and the reference's own main() over the

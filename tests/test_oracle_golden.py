@@ -36,6 +36,20 @@ def test_oracle_matches_reference_at_configs0(tmp_path):
         assert util.sha_file(os.path.join(str(tmp_path), fname)) == digest, fname
 
 
+def test_oracle_follows_the_reference_scheme_at_configs0_with_small_sort_memory(tmp_path):
+    """SURVEY 8(a) D3 / D4.  BASELINE configs[0] with -M1: the reference cuts the input into two buckets (Determine_Scheme,
+    assign_pieces with its unseeded drand48) and the hidden part files by bucket 0's weighted k-mers.  The restated
+    scheme + bucket loop reproduce every file digest of that run (make_golden.py --only=configs0_k40_t1_T4_M1)."""
+    case, bases, boff = util.load_case("configs0_k40_t1_T4_M1")
+    res = orc.fastk_parts(case["k"], bases, boff, int(case["ref_extra"][0][2:]) * 1000000000, cutoff=case["cutoff"],
+                          nthreads=case["T"])
+    assert res.nparts == 2
+    util.check_against_golden(case, res.hist, res.max_inst, res.table)
+    orc.write_outputs(res, case["cutoff"], case["T"], str(tmp_path), "x")
+    for fname, digest in case["expected"]["file_sha256"].items():
+        assert util.sha_file(os.path.join(str(tmp_path), fname)) == digest, fname
+
+
 @pytest.mark.parametrize("name", ["edge_k40_t1_T4", "edge_k21_t2_T3", "synth_tiny_k40_t1_T2"])
 def test_brute_force_definition_matches_golden(name):
     case, bases, boff = util.load_case(name)

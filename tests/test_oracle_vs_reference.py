@@ -73,3 +73,35 @@ def test_oracle_lsd_engine_equals_reference_lsd_sort(rsize, n, nbytes, T):
     recs[:, 1] = rng.integers(0, 3, size=n)
     order = list(range(nbytes - 1, -1, -1))
     assert np.array_equal(orc.lsd_sort(recs, order), orc.ref_lsd_sort(recs, order, T))
+
+
+def test_scheme_equals_the_reference_trainer(tmp_path):
+    """Determine_Scheme restated (orc.scheme: trainer census, refine_tree, assign_pieces with glibc's unseeded
+    drand48) against the reference's own DEBUG_SCHEME print-out (oracle/_ref/FastK_scheme: split.c compiled with that
+    macro on): the prefix trie and the bucket of every leaf, for BASELINE configs[0] with -M1 (two buckets)."""
+    import subprocess
+    from tests import util
+    exe = os.path.join(orc.REF_DIR, "FastK_scheme")
+    if not os.path.exists(exe):
+        import subprocess as sp
+        sp.run(["make", "-s", "-C", os.path.dirname(orc.REF_DIR), "ref_scheme"], check=False)
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/FastK_scheme not built (needs the reference sources)")
+    bases, boff = orc.synth_block(20251001, 10000000, 150, 1000, 0, 1000000)
+    path = os.path.join(str(tmp_path), "x.fastq")
+    util.write_fastx(path, bases, boff, True)
+    out = subprocess.run([exe, "-k40", "-t1", "-T4", "-M1", "-v", "-P" + str(tmp_path), path], capture_output=True, text=True,
+                         cwd=str(tmp_path))
+    assert out.returncode == 0 and "Dividing data into 2 blocks" in out.stderr
+    P, S, part = orc.scheme(40, bases, boff, 2)
+    inv = {P.tran[0]: "a", P.tran[1]: "c", P.tran[2]: "g", P.tran[3]: "t"}
+
+    def show(lev, i):                                     # print_ass of split.c:420-434
+        if part[i] >= 0:
+            return " %d\n" % part[i]
+        return "\n" + "".join("%*s -> %c:" % (2 * lev, "", inv[a]) + show(lev + 1, -part[i] + a) for a in range(4))
+
+    mine = "".join(" %5d:" % i + show(0, i) for i in range(1024))
+    ref = out.stdout[out.stdout.index("Padded Assignments"):].split("\n", 1)[1]
+    assert S.nparts == 2 and S.pad == 0
+    assert ref.strip() == mine.strip()
