@@ -33,6 +33,7 @@
 #define SP_WORDS   (SP_TILE / 16 + SP_MAXK / 16 + 2)   // packed words incl. halo and guard
 #define SP_KEYS    (SP_TILE + SP_MAXK)
 #define SP_KIDX(i) ((i) + ((i) >> 4))
+#define SP_RTW     8                       // tiles a replay workgroup takes
 #define SP_LB      10                      // log2 of the records per chunk of a stream (see SplitArgs.lstreams)
 #define SP_LSTREAMS 3                      // 8 streams per bucket
 #define SP_PL      512                     // super-mer starts the position list of a tile takes at a time
@@ -57,6 +58,7 @@ struct SplitArgs
   int       tile_stride;    // count mode: visit every tile_stride-th tile only (sampling)
   u64      *pos;            // POS kernels only: (position of the record's first k-mer << 1) | flip per record
   int64_t   tile0;          // first tile of this launch (a grid holds at most SP_MAXGRID workgroups)
+  int64_t   tile_end;       // replay: tiles of the input (a workgroup takes SP_RTW of them)
   // multi-pass split with entry replay: the first pass emits the records of buckets [gb0, gb1) and leaves, per
   // tile, the 4-byte entries (start, flip, length, bucket) of all OTHER super-mers behind; the later passes
   // rebuild their records from the entries and the reads (k_split_replay) without recomputing any minimizer
@@ -78,6 +80,7 @@ struct SplitArgs
   u64      *plan;           // count mode: [32][256] spread bucket counters (NULL: counts[])
   int       lstreams;
   const u64 *rbase;         // [nbuckets] first record of each bucket's region (the cursors count from 0)
+  int       abl;            // -DFK_ABLATION builds: FK_REPLAY_ABL bits -- 1 no record stores, 2 no base loads, 4 no entries
   u32       skipb;          // super-mers whose bucket entry equals skipb are dropped (0xFF in a group
                             // pass of a multi-pass split, where mbucket marks the other groups' ranks;
                             // 0x100 = nothing is dropped)
@@ -586,26 +589,50 @@ __global__ __launch_bounds__(SP_THREADS) void k_split_replay(SplitArgs a)
 
   const int     tid = threadIdx.x;
   const int     K   = a.kmer;
-  const int64_t tile = a.tile0 + blockIdx.x;
-  const int64_t t0  = tile * SP_TILE;
   const int     nw  = SP_TILE / 16 + (K + 14) / 16;
   const int     R   = nw * 16;
-  // Every load that does not depend on another is issued up front: the tile's entry descriptor, its bases and the
-  // three terms of the bucket offsets; only the entries themselves have to wait for the descriptor.  (One after
-  // the other these were three memory round trips per tile, and the kernel does little else.)
-  const u64     te  = a.tile_ent[tile];
-  uint4 v0 = make_uint4(0u, 0u, 0u, 0u), v1 = make_uint4(0u, 0u, 0u, 0u);
-  const int64_t g0 = t0 + (int64_t) tid * 16, g1 = t0 + (int64_t) (tid + SP_THREADS) * 16;
-  const bool    in0 = (g0 + 16 <= a.nbytes), in1 = (tid + SP_THREADS < nw && g1 + 16 <= a.nbytes);
-  if (in0) v0 = *(const uint4 *) (a.bases + g0);
-  if (in1) v1 = *(const uint4 *) (a.bases + g1);
-  u64 bb = 0;
-  if (tid >= a.gb0 && tid < a.gb1)
-    bb = a.rbase[tid] + a.chunk_base[(size_t) (tile / SP_RCH) * a.nbuckets + tid]
-       + (u64) a.tile_cnt[(size_t) tile * a.nbuckets + tid];
+  // A workgroup takes SP_RTW consecutive tiles: one tile per workgroup was 36 M workgroups of ~30 instructions per
+  // thread at configs[2], and the rate at which the dispatcher starts workgroups bounded the kernel (a pass that
+  // only loaded and converted the bases took 60 % of the time of the whole kernel).
+  // ... and the loads of the next tile -- its entry descriptor, its bases, the three terms of its bucket offsets, none
+  // of which depends on another -- are in flight while the current one is worked on: with eight workgroups of 4 KB
+  // per CU and a trip to memory per tile, the bytes in flight bounded the pass at half the copy rate.
+  u64   te_n = 0, bb_n = 0;
+  uint4 v0_n = make_uint4(0u, 0u, 0u, 0u), v1_n = v0_n;
+  auto fetch = [&](int64_t tile)
+    { const int64_t t0 = tile * SP_TILE;
+      te_n = a.tile_ent[tile];
+      const int64_t g0 = t0 + (int64_t) tid * 16, g1 = t0 + (int64_t) (tid + SP_THREADS) * 16;
+      v0_n = make_uint4(0u, 0u, 0u, 0u); v1_n = v0_n;
+#ifdef FK_ABLATION
+      if (a.abl & 2) { v0_n = make_uint4(0x61636774u + tid, 0x74676361u, 0x61616161u, 0x63636363u); v1_n = v0_n; }
+      else
+#endif
+      { if (g0 + 16 <= a.nbytes) v0_n = *(const uint4 *) (a.bases + g0);
+        if (tid + SP_THREADS < nw && g1 + 16 <= a.nbytes) v1_n = *(const uint4 *) (a.bases + g1);
+      }
+      bb_n = 0;
+      if (tid >= a.gb0 && tid < a.gb1)
+        bb_n = a.rbase[tid] + a.chunk_base[(size_t) (tile / SP_RCH) * a.nbuckets + tid]
+             + (u64) a.tile_cnt[(size_t) tile * a.nbuckets + tid];
+    };
+  const int64_t tile_first = a.tile0 + (int64_t) blockIdx.x * SP_RTW;
+  if (tile_first < a.tile_end)
+    fetch(tile_first);
+  for (int rt = 0; rt < SP_RTW; rt++)
+  { const int64_t tile = tile_first + rt;
+    if (tile >= a.tile_end)
+      break;
+    if (rt > 0)
+      __syncthreads();                                       // the previous tile's arrays are free
+  const int64_t t0  = tile * SP_TILE;
+  const u64     te  = te_n, bb = bb_n;
+  const uint4   v0  = v0_n, v1 = v1_n;
+  if (rt + 1 < SP_RTW && tile + 1 < a.tile_end)
+    fetch(tile + 1);
   const u32     cnt = (u32) (te & 0x1fffu);
   if (cnt == 0)
-    return;
+    continue;
   const u64     eb  = te >> 13;
 
   bcnt2[tid] = 0;
@@ -647,6 +674,12 @@ __global__ __launch_bounds__(SP_THREADS) void k_split_replay(SplitArgs a)
   const int sww = a.sww;
   const int lenw = a.smer_bytes >> 2;
   const int lensh = 24 - 8 * (a.smer_bytes & 3);
+#ifdef FK_ABLATION
+  if (a.abl & 4)
+    { if (fwd[tid] == 0x12345u && rcw[tid] == 0x54321u) *a.overflowed = 2;
+      continue;
+    }
+#endif
   for (u32 s = tid; s < cnt; s += SP_THREADS)
     { const u32 e    = (s == (u32) tid) ? e0 : a.ent[eb + s];
       const int i    = e & 0xfffu;
@@ -664,6 +697,13 @@ __global__ __launch_bounds__(SP_THREADS) void k_split_replay(SplitArgs a)
       const u32 *arr = flip ? rcw : fwd;
       const int  st  = flip ? (R - (i + L)) : i;
       u32 *dst = a.out + slot * sww;
+#ifdef FK_ABLATION
+      if (a.abl & 1)
+        { u32 x = sp_window(arr, st) ^ sp_window(arr, st + 16) ^ sp_window(arr, st + 32) ^ sp_window(arr, st + 48);
+          if (x == 0x13572468u) dst[0] = x;
+          continue;
+        }
+#endif
       if (sww == 5)
         sp_put_record5(arr, st, L, ((u32) (n - 1)) << lensh, lenw, dst);
       else
@@ -680,6 +720,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_split_replay(SplitArgs a)
           dst[q] = __builtin_bswap32(x);
         }
     }
+  }
 }
 
 // Closes the ragged end of the chunk-interleaved streams (SplitArgs.lstreams): afterwards the records of bucket b
@@ -1161,9 +1202,14 @@ int fkx_split_planned(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_
       ctx->ent_valid = false;
     }
   if (mode == 2)
-    { for (int64_t t = 0; t < ntiles; t += SP_MAXGRID)
+    { a.tile_end = ntiles;
+      for (int64_t t = 0; t < ntiles; t += (int64_t) SP_MAXGRID * SP_RTW)
         { a.tile0 = t;
-          const int64_t nbk = (ntiles - t < SP_MAXGRID) ? (ntiles - t) : SP_MAXGRID;
+          const int64_t left = (ntiles - t + SP_RTW - 1) / SP_RTW;
+          const int64_t nbk = (left < SP_MAXGRID) ? left : SP_MAXGRID;
+#ifdef FK_ABLATION
+          a.abl = getenv("FK_REPLAY_ABL") ? atoi(getenv("FK_REPLAY_ABL")) : 0;
+#endif
           hipLaunchKernelGGL(k_split_replay, dim3((unsigned) nbk), dim3(SP_THREADS), 0, s, a);
         }
     }
