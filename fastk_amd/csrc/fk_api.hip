@@ -2124,6 +2124,9 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
                 for (int x = 0; x < 4; x++)
                   tran[x] = ctx->tran[x];
               else if ((rc = fkx_train_tran(ctx, d_reads, h_roff, train, ctx->prm.nthreads, tran)) != FK_OK) break;
+              for (int x = 0; x < 4; x++)
+                ctx->exact_tran[x] = tran[x];
+              ctx->exact_tran_set = true;
               int64_t *d_roff = (int64_t *) fk_slot(ctx, FK_SLOT_ROFF, (nreads + 1) * 8);
               if (d_roff == NULL) { rc = FK_ENOMEM; break; }
               if (hipMemcpyAsync(d_roff, h_roff, (size_t) (nreads + 1) * 8, hipMemcpyHostToDevice, s) != hipSuccess)

@@ -14,7 +14,7 @@
 typedef unsigned long long u64;
 typedef unsigned int       u32;
 
-#define FK_NSLOTS 48
+#define FK_NSLOTS 49
 
 // Minimizers are canonical 7-mers ordered by a bijective mix of their 14-bit code (odd multiplies and
 // xor-shifts are invertible mod 2^14, so distinct 7-mers never tie): FK_NRANKS rank values, of which
@@ -112,6 +112,9 @@ struct fk_ctx
   double     input_ratio;   // whole input / training block, in the reference's file bytes (0: by bases)
   int       *min_part, *d_min_part;   // Min_Part: the prefix trie with bucket numbers at its leaves
   int        scheme_pad, scheme_states, scheme_nparts;
+  int        exact_tran[4];           // the base ranking the last exact_parts split used (the profile stitcher needs it)
+  bool       exact_tran_set;
+  bool       pf_own_reads;            // fk_make_profiles is encoding the pushed reads themselves
   int64_t    exact_wfirst[256];       // first-byte census of bucket 0's weighted k-mers (Table_Split's input)
   char      *d_pk, *h_pk;   // fk_push_packed: staging for codes, read offsets and invalid stretches (device / pinned)
   int64_t    pk_cap;
@@ -195,7 +198,7 @@ enum { FK_SLOT_SM_A = 0, FK_SLOT_SM_B, FK_SLOT_KM_A, FK_SLOT_KM_B, FK_SLOT_EX_HE
        FK_SLOT_RX_TILE, FK_SLOT_RX_CHUNK, FK_SLOT_RX_SUPER, FK_SLOT_ROFF, FK_SLOT_AG_BOUNDS, FK_SLOT_TABLE, FK_SLOT_SM_G,
        FK_SLOT_RAW, FK_SLOT_FQ_INFO, FK_SLOT_FQ_PHASE, FK_SLOT_FQ_OFF, FK_SLOT_TIE_A, FK_SLOT_TIE_B,
        FK_SLOT_TIE_POS, FK_SLOT_SM_D, FK_SLOT_PF_IDX, FK_SLOT_PF_CNT, FK_SLOT_PF_ZC, FK_SLOT_PF_ZO,
-       FK_SLOT_PF_ENDS, FK_SLOT_PF_LEN, FK_SLOT_PF_OFF, FK_SLOT_PF_OUT, FK_SLOT_ENT, FK_SLOT_TENT, FK_SLOT_TCNT, FK_SLOT_CBASE };
+       FK_SLOT_PF_ENDS, FK_SLOT_PF_LEN, FK_SLOT_PF_OFF, FK_SLOT_PF_OUT, FK_SLOT_ENT, FK_SLOT_TENT, FK_SLOT_TCNT, FK_SLOT_CBASE, FK_SLOT_PF_RID };
 
 // returns a device buffer of at least nbytes for the given purpose (NULL + error set on failure)
 void *fk_slot(fk_ctx *ctx, int slot, int64_t nbytes);

@@ -13,6 +13,7 @@
 // The codec output is the canonical one-byte-wherever-possible stream; it decodes to the same counts
 // as the reference's files, whose run splits follow the reference's internal work panels (merge.c:65,711).
 #include "fk_common.h"
+#include <vector>
 
 #define PF_TILE  4096
 #define PF_HALO  128          // >= kmer - 1, multiple of 16
@@ -435,6 +436,297 @@ static __global__ __launch_bounds__(PF_ER) void k_pf_encode(const uint16_t *__re
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// The reference's OWN bytes (exact_parts runs).  Its .prof stream is not a function of the counts alone: the profile
+// of a read is stitched from the profiles of its super-mers (count.c:868-947 encodes every super-mer's counts on its
+// own: first count, differences -- one byte for |d| < 32 --, runs of equal counts in bytes of up to 63, last count),
+// and Merge_Profiles (merge.c:263-716) joins them: the difference across a junction takes ONE byte only for
+// -30 <= d <= 31 (merge.c:456,590), a run of equal counts may continue across junctions, stretches of invalid k-mers
+// arrive as packets of at most MAX_NRUN zeros with run numbers of their own (split.c:1167-1232), and -- the part that
+// depends on nothing in the data -- a pending run is written out whenever the run number passes a multiple of
+// PAN_SIZE = 1024 NPARTS (merge.c:263-267,706-716), counted per input thread.  So the kernel below walks every read
+// through Distribute_Block's super-mer rule (the state machine of fk_split_exact.hip) and feeds the events -- super-mer
+// of n k-mers, packet of n invalid k-mers, end of read -- to that stitching, byte for byte.
+//   MODE 0: run numbers a read consumes;  MODE 1: bytes of its profile;  MODE 2: the bytes.
+#define PX_THREADS 64
+#define PX_RING    256
+
+struct ExactProfArgs
+{ const unsigned char *bases;
+  const int64_t *ends;          // [nreads] position of each read's terminator
+  int64_t   nreads, nbytes;
+  int       kmer, bc_prefix;
+  int       tran[4];
+  int       pad_len;            // minimizer length 5 + PAD
+  const uint16_t *cnts;         // count of the k-mer starting at every position
+  const u64 *rid0;              // [nreads] first run number of the read, counted from its input thread's first read
+  u32       pan;                // PAN_SIZE
+  u32      *nrun;               // MODE 0 out
+  u32      *lens;               // MODE 1 out
+  const u64 *offs;              // MODE 2 in
+  uint8_t  *out;
+};
+
+template <int MODE>
+static __global__ __launch_bounds__(PX_THREADS) void k_pf_exact(ExactProfArgs a)
+{ const int64_t r = (int64_t) blockIdx.x * PX_THREADS + threadIdx.x;
+  if (r >= a.nreads)
+    return;
+  const int K = a.kmer, KM1 = K - 1;
+  const int PL1 = a.pad_len - 1;
+  const int MS  = K - PL1;
+  const int MAX_NRUN = 1 + 63 * 2 * MS;                     // split.c:77
+  const u32 vmsk = (1u << (2 * a.pad_len)) - 1u;
+  const int64_t s0 = (r == 0) ? 0 : a.ends[r - 1] + 1;
+  const int64_t e0 = a.ends[r] < a.nbytes ? a.ends[r] : a.nbytes;
+  const int64_t sb = (s0 + a.bc_prefix < e0) ? s0 + a.bc_prefix : e0;
+  const unsigned char *s = a.bases + sb;
+  const uint16_t *cn = a.cnts + sb;                          // cn[j]: the k-mer that starts at base j of the read
+  const int q = (int) (e0 - sb);
+
+  // ---- the stitcher (merge.c:395-716)
+  u64  rid = (MODE == 0) ? 0 : a.rid0[r];
+  u32  nev = 0, len = 0;
+  bool wlast = true;
+  u32  lcont = 0, lz = 0;
+  uint8_t *o = (MODE == 2) ? a.out + a.offs[r] : NULL;
+  auto put = [&](u32 b) { if (MODE == 2) o[len] = (uint8_t) b; len += 1; };
+  auto next_run = [&]()
+    { // a new run number: at a multiple of PAN_SIZE the previous panel has ended, its pending run was written
+      if (MODE != 0 && rid % a.pan == 0 && lz != 0)
+        { put(lz); lz = 0; }
+      rid += 1;
+      nev += 1;
+    };
+  auto junction = [&](u32 d)                                 // d = difference as 16 bits
+    { if (d == 0)
+        { lz += 1;
+          if (lz >= 63) { put(63); lz = 0; }
+        }
+      else
+        { if (lz) { put(lz); lz = 0; }
+          if (d > 0xffe1u || d < 32u)
+            put(0x40u | (d & 0x3fu));
+          else
+            { put(0x80u | ((d >> 8) & 0xffu)); put(d & 0xffu); }
+        }
+    };
+  auto ev_zeros = [&](int n, bool last)                      // a packet of n invalid k-mers
+    { next_run();
+      if (MODE == 0) return;
+      if (wlast)
+        { put(0); lz = 0; }
+      else
+        junction((0u - lcont) & 0xffffu);
+      if (n > 1)
+        { int t = n + (int) lz - 1;
+          for ( ; t >= 63; t -= 63)
+            put(63);
+          lz = (u32) t;
+        }
+      lcont = 0;
+      if (last)
+        { if (lz) { put(lz); lz = 0; }
+          wlast = true;
+        }
+      else
+        wlast = false;
+    };
+  auto ev_interval = [&](int lo, int hi, bool last)          // invalid k-mers [lo, hi): packets of at most MAX_NRUN
+    { int f = lo;
+      for (int l = hi - MAX_NRUN; f < l; f += MAX_NRUN)
+        ev_zeros(MAX_NRUN, false);
+      ev_zeros(hi - f, last);
+    };
+  auto ev_super = [&](int first_end, int n, bool last)       // the k-mers ending at first_end .. first_end + n - 1
+    { next_run();
+      if (MODE == 0) return;
+      const uint16_t *c = cn + (first_end - KM1);
+      uint8_t tok[160];                                        // count.c:868-947: at most 2 bytes per difference
+      int nt = 0;
+      u32 p0 = c[0], pv = p0, run = 0;
+      for (int j = 1; j < n; j++)
+        { const u32 x = c[j];
+          if (x == pv)
+            { if (run > 0)
+                { if (run >= 63) { tok[nt++] = (uint8_t) run; run = 1; }
+                  else run += 1;
+                }
+              else
+                run = 1;
+            }
+          else
+            { if (run > 0) { tok[nt++] = (uint8_t) run; run = 0; }
+              const int d = (int) x - (int) pv;
+              if (d > -32 && d < 32)
+                tok[nt++] = (uint8_t) (0x40u | ((u32) d & 0x3fu));
+              else
+                { tok[nt++] = (uint8_t) (0x80u | (((u32) d >> 8) & 0xffu));
+                  tok[nt++] = (uint8_t) ((u32) d & 0xffu);
+                }
+            }
+          pv = x;
+        }
+      if (run > 0) tok[nt++] = (uint8_t) run;
+      // merge.c:541-700
+      if (wlast)
+        { if (p0 < 128) put(p0);
+          else { put(0x80u | (p0 >> 8)); put(p0 & 0xffu); }
+          lz = 0;
+        }
+      else
+        junction((p0 - lcont) & 0xffffu);
+      lcont = p0;
+      if (n > 1)
+        { lcont = pv;
+          int i0 = 0;
+          if (lz)
+            while (i0 < nt && tok[i0] < 64)
+              { lz += tok[i0];
+                if (lz >= 63) { put(63); lz -= 63; }
+                i0 += 1;
+              }
+          if (i0 < nt)
+            { if (lz) { put(lz); lz = 0; }
+              bool one = true;
+              for (int u = i0; u < nt; u++)
+                if (tok[u] & 0x80) { one = false; u += 1; }
+                else one = true;
+              int stop = nt;
+              if (one)
+                { lz = tok[nt - 1];
+                  if (lz < 63) stop = nt - 1;
+                  else lz = 0;
+                }
+              for (int u = i0; u < stop; u++)
+                put(tok[u]);
+            }
+        }
+      wlast = last;
+      if (last && lz) { put(lz); lz = 0; }
+    };
+
+  if (q < K)                                                 // split.c:1079-1086: a run number, no profile
+    { next_run();
+      if (MODE == 0) a.nrun[r] = nev;
+      if (MODE == 1) a.lens[r] = 0;
+      return;
+    }
+
+  // ---- Distribute_Block's walk (split.c:1096-1393), events instead of records.  A super-mer is handed over when
+  // the next event (or the end of the read) is known: only then is it known whether it ends the read.
+  int rmsk = 1;
+  while (rmsk < K) rmsk <<= 1;
+  rmsk = 2 * rmsk - 1;
+  u32 ring[PX_RING];
+  const int t0 = a.tran[0], t1 = a.tran[1], t2 = a.tran[2], t3 = a.tran[3];
+  auto code_of = [&](unsigned ch) -> int
+    { const unsigned u = ch & 0xDFu;
+      return (u == 0x41u) ? 0 : (u == 0x43u) ? 1 : (u == 0x47u) ? 2 : (u == 0x54u) ? 3 : 4;
+    };
+  auto fwv = [&](int code) -> u32 { return (u32) (code == 1 ? t1 : code == 2 ? t2 : code == 3 ? t3 : t0); };
+  auto rcv = [&](int code) -> u32 { return (u32) (code == 1 ? t2 : code == 2 ? t1 : code == 3 ? t0 : t3) << (2 * PL1); };
+  int  pend_e = -1, pend_n = 0;                              // a super-mer waiting for its "ends the read" flag
+  auto flush_pending = [&](bool last)
+    { if (pend_n > 0) ev_super(pend_e, pend_n, last);
+      pend_n = 0;
+    };
+
+  u32 c = 0, u = 0, mp = 0, mc = vmsk + 1u;
+  int m = 0, p;
+  int ilo = -1, ihi = -1, plo = 0, phi = -1;                 // nfst, nlst, pfst, plst
+  for (p = 0; p < K; p++)
+    { const int code = code_of(s[p]);
+      c = ((c << 2) | fwv(code)) & vmsk;
+      u = (u >> 2) | rcv(code);
+      if (p >= PL1)
+        { mp = (u < c) ? u : c;
+          ring[p & rmsk] = mp;
+          if (mp < mc) { m = p; mc = mp; }
+        }
+      if (code >= 4)
+        { if (p > ihi)
+            ilo = KM1;
+          ihi = p + K;
+        }
+    }
+  int  last = KM1;
+  bool done = false;
+  for (p = K; !done; p++)
+    { int  code = 0;
+      bool closing, force;
+      if (p < q)
+        { code = code_of(s[p]);
+          c = ((c << 2) | fwv(code)) & vmsk;
+          u = (u >> 2) | rcv(code);
+          mp = (u < c) ? u : c;
+          ring[p & rmsk] = mp;
+          force   = (p - m >= MS);
+          closing = force || (mp < mc);
+        }
+      else
+        { if (ihi == q)                                      // split.c:1342: no forced closing then
+            break;
+          mp = mc;
+          force = closing = true;
+          done = true;
+        }
+      if (closing)
+        { int n;
+          if (ihi >= last)
+            { if (ihi <= p)
+                { last = ihi;
+                  flush_pending(false);
+                  ev_interval(ilo, ihi, false);
+                  ihi = -1;
+                  n = p - last;
+                }
+              else
+                { if (phi > last)
+                    { last = phi;
+                      flush_pending(false);
+                      ev_interval(plo, phi, false);
+                      phi = -1;
+                    }
+                  n = ilo - last;
+                }
+            }
+          else
+            n = p - last;
+          if (n > 0)
+            { flush_pending(false);
+              pend_e = last; pend_n = n;
+            }
+          if (done)
+            break;
+          if (force)
+            { m += 1;
+              mc = ring[m & rmsk];
+              for (int j = m + 1; j <= p; j++)
+                { const u32 v = ring[j & rmsk];
+                  if (v <= mc) { m = j; mc = v; }
+                }
+            }
+          else
+            { m = p; mc = mp; }
+          last = p;
+        }
+      if (code >= 4)
+        { if (p > ihi)
+            { plo = ilo; phi = ihi; ilo = p; }
+          ihi = p + K;
+        }
+    }
+  if (ihi >= q)                                              // split.c:1349-1377: invalid k-mers up to the end
+    { flush_pending(false);
+      ev_interval(ilo, q, true);
+    }
+  else
+    flush_pending(true);
+  if (MODE == 0) a.nrun[r] = nev;
+  if (MODE == 1) a.lens[r] = len;
+}
+
 // exclusive scan of n u32 values into u64 offsets with many workgroups: block sums, a scan of the sums
 // (k_exscan_tiles, one workgroup), block-local scans on top of them; out[n] gets the total
 static __global__ __launch_bounds__(256) void k_pf_blocksum(const u32 *__restrict__ in, int64_t n, u32 *__restrict__ sums)
@@ -717,6 +1009,52 @@ static int fkx_profile_encode(fk_ctx *ctx, const uint8_t *bases, int64_t nbytes,
   u64 *offs = (u64 *) fk_slot(ctx, FK_SLOT_PF_OFF, (nreads + 1) * 8 + 64);
   if (lens == NULL || offs == NULL) return (FK_ENOMEM);
   const unsigned nb = (unsigned) ((nreads + PF_ER - 1) / PF_ER);
+  // exact_parts: the reference's own bytes, when the reads are the pushed ones, whole (no read cut by a block edge)
+  // and their input threads are known; else the canonical stream
+  bool exact = ctx->prm.exact_parts && ctx->exact_tran_set && ctx->pf_own_reads && !ctx->blocks_bad && ctx->nblocks > 0
+               && ctx->wid.kmer <= 128;
+  if (exact)
+    { int64_t tot = 0;
+      for (int64_t b = 0; b < ctx->nblocks; b++)
+        { tot += ctx->blocks[b].nreads;
+          if (ctx->blocks[b].rem > 0 || ctx->blocks[b].tid < 0 || ctx->blocks[b].tid >= 4096) exact = false;
+        }
+      if (tot != nreads) exact = false;
+    }
+  ExactProfArgs xa;
+  const unsigned xnb = (unsigned) ((nreads + PX_THREADS - 1) / PX_THREADS);
+  if (exact)
+    { xa.bases = bases; xa.ends = ends; xa.nreads = nreads; xa.nbytes = nbytes;
+      xa.kmer = K; xa.bc_prefix = ctx->prm.bc_prefix;
+      for (int i = 0; i < 4; i++) xa.tran[i] = ctx->exact_tran[i];
+      xa.pad_len = 5 + (ctx->scheme_nparts > 1 ? ctx->scheme_pad : 0);
+      xa.cnts = cnts;
+      xa.pan = 1024u * (u32) (ctx->scheme_nparts > 1 ? ctx->scheme_nparts : 1);
+      xa.nrun = lens; xa.lens = lens; xa.offs = NULL; xa.out = NULL; xa.rid0 = NULL;
+      // run numbers: per read on the device, their running sums per input thread on the host (blocks of several
+      // threads interleave in HBM in push order)
+      hipLaunchKernelGGL(k_pf_exact<0>, dim3(xnb), dim3(PX_THREADS), 0, s, xa);
+      FK_LAUNCH_CHECK(ctx);
+      std::vector<u32> nrun((size_t) nreads);
+      std::vector<u64> rid0((size_t) nreads);
+      FK_HIP(ctx, hipMemcpyAsync(nrun.data(), lens, (size_t) nreads * 4, hipMemcpyDeviceToHost, s));
+      FK_HIP(ctx, hipStreamSynchronize(s));
+      { std::vector<u64> run_of_tid(4096, 0);
+        int64_t r = 0;
+        for (int64_t b = 0; b < ctx->nblocks; b++)
+          for (int64_t i = 0; i < ctx->blocks[b].nreads; i++, r++)
+            { rid0[(size_t) r] = run_of_tid[(size_t) ctx->blocks[b].tid];
+              run_of_tid[(size_t) ctx->blocks[b].tid] += nrun[(size_t) r];
+            }
+      }
+      u64 *d_rid0 = (u64 *) fk_slot(ctx, FK_SLOT_PF_RID, nreads * 8 + 64);
+      if (d_rid0 == NULL) return (FK_ENOMEM);
+      FK_HIP(ctx, hipMemcpyAsync(d_rid0, rid0.data(), (size_t) nreads * 8, hipMemcpyHostToDevice, s));
+      FK_HIP(ctx, hipStreamSynchronize(s));
+      xa.rid0 = d_rid0;
+      hipLaunchKernelGGL(k_pf_exact<1>, dim3(xnb), dim3(PX_THREADS), 0, s, xa);
+    }
+  else
   hipLaunchKernelGGL(k_pf_encode<false>, dim3(nb), dim3(PF_ER), 0, s, (const uint16_t *) cnts, (const int64_t *) ends,
                      nreads, nbytes, K, ctx->prm.bc_prefix, lens, (const u64 *) NULL, (uint8_t *) NULL);
   { const int64_t nblk = (nreads + 4095) / 4096;
@@ -734,6 +1072,11 @@ static int fkx_profile_encode(fk_ctx *ctx, const uint8_t *bases, int64_t nbytes,
   const int64_t nprof = (int64_t) ctx->h_scratch[0];
   uint8_t *data = (uint8_t *) fk_slot(ctx, FK_SLOT_PF_OUT, nprof + 64);
   if (data == NULL) return (FK_ENOMEM);
+  if (exact)
+    { xa.offs = offs; xa.out = data;
+      hipLaunchKernelGGL(k_pf_exact<2>, dim3(xnb), dim3(PX_THREADS), 0, s, xa);
+    }
+  else
   hipLaunchKernelGGL(k_pf_encode<true>, dim3(nb), dim3(PF_ER), 0, s, (const uint16_t *) cnts, (const int64_t *) ends,
                      nreads, nbytes, K, ctx->prm.bc_prefix, (u32 *) NULL, (const u64 *) offs, data);
   FK_LAUNCH_CHECK(ctx);

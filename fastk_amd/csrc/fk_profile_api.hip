@@ -248,7 +248,9 @@ extern "C" int fk_make_profiles(fk_ctx *ctx, const void *d_bases, int64_t nbytes
   int64_t nreads = 0, nprof = 0;
   void *d_data = NULL;
   uint64_t *d_offs = NULL;
+  ctx->pf_own_reads = own_reads;
   int rc = fkx_profiles(ctx, d_bases, nbytes, ctx->last_table, ctx->last_ntab, &nreads, &nprof, &d_data, &d_offs);
+  ctx->pf_own_reads = false;
   if (rc != FK_OK)
     return (rc);
   if ((rc = profiles_to_host(ctx, &nreads, &nprof, d_data, d_offs, own_reads)) != FK_OK)

@@ -102,7 +102,8 @@ void Sorting(char *path, char *root)
     { fk_profiles pr;
       if (fk_make_profiles(GPU,NULL,0,&pr) != FK_OK)
         die("fk_make_profiles");
-      if (fk_write_prof(&pr,KMER,NTHREADS,path,root) != FK_OK)
+      if (fk_write_prof(&pr,KMER,ITHREADS,path,root) != FK_OK)     /* one part per INPUT thread (merge.c:880-930): fewer than
+                                                                      -T for a small input */
         die("writing .prof");
     }
   free(name);

@@ -209,9 +209,11 @@ def main():
         shutil.copy(path, ppath)
         orc.run_ref_fastk(ppath, k, case["cutoff"], case["T"], pd, extra=("-p",))
         pk, enc = orc.read_profiles(pd, "x")
+        pfiles = sorted(f for f in os.listdir(pd) if f == "x.prof" or f.startswith(".x.prof.") or f.startswith(".x.pidx."))
         exp["prof"] = dict(nreads=len(enc), ref_bytes=sum(len(e) for e in enc),
                            decoded_sha256=orc.profiles_digest([orc.profile_decode(e) for e in enc]),
-                           first_ref_hex=[e.hex() for e in enc[:4]])
+                           first_ref_hex=[e.hex() for e in enc[:4]],
+                           file_sha256={f: sha_file(os.path.join(pd, f)) for f in pfiles})
         shutil.rmtree(pd)
         meta = dict(case)
         meta["expected"] = exp

@@ -1178,7 +1178,7 @@ def test_reference_main_over_gpu_shim(name, fmt, tmp_path):
                 assert util.sha_file(d / fname) == digest, fname
 
 
-@pytest.mark.parametrize("name", ["edge_k40_t4_T1", "synth_illumina_k40_t1_T4", "synth_hifi_k40_t4_T8"])
+@pytest.mark.parametrize("name", util.golden_names())
 def test_reference_main_with_profiles_over_gpu_shim(name, tmp_path):
     """The reference's main() with -p on the GPU path: .hist and every .ktab file are still the
     reference's bytes (table filtered to -t on the way out), the profiles decode to the reference's
@@ -1189,18 +1189,26 @@ def test_reference_main_with_profiles_over_gpu_shim(name, tmp_path):
         pytest.skip("oracle/_ref/FastK_gpu not built (needs the reference sources at build time)")
     case, bases, boff = util.load_case(name)
     k = case["k"]
-    path = str(tmp_path / "x.fasta")
-    orc.write_fasta(path, bases, boff, width=0 if case["kind"] == "edge" else 100)
+    path = str(tmp_path / ("x." + case["fmt"]))          # the golden's own file layout: io.c deals the reads to its
+    if case["fmt"] == "fasta":                            # threads by file bytes, and the profile parts follow
+        orc.write_fasta(path, bases, boff, width=0 if case["kind"] == "edge" else 100)
+    else:
+        orc.write_fastq(path, bases, boff)
     subprocess.run([exe, "-k%d" % k, "-t%d" % case["cutoff"], "-T%d" % case["T"], "-p",
                     "-P" + str(tmp_path), path], check=True, cwd=str(tmp_path), env=dict(os.environ, FASTK_AMD_EXACT="1"),
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     for fname, digest in case["expected"]["file_sha256"].items():
         assert hashlib.sha256(open(tmp_path / fname, "rb").read()).hexdigest() == digest, fname
+    # in exact mode the .prof files are the reference's too, byte for byte: its super-mer junctions (a difference of -31
+    # takes two bytes there, merge.c:456,590) and its panel flushes (a pending run is written out every 1024 NPARTS
+    # runs per input thread, merge.c:263-267,706-716) are replayed by k_pf_exact
+    for fname, digest in case["expected"]["prof"]["file_sha256"].items():
+        assert util.sha_file(tmp_path / fname) == digest, fname
     kk, enc = orc.read_profiles(str(tmp_path), "x")
     assert kk == k and len(enc) == case["expected"]["prof"]["nreads"]
     assert orc.profiles_digest([orc.profile_decode(e) for e in enc]) == case["expected"]["prof"]["decoded_sha256"]
     # relative to its own cutoff-t table: counts below the cutoff read as 0
-    rel = str(tmp_path / "y.fasta")
+    rel = str(tmp_path / ("y." + case["fmt"]))
     os.link(path, rel)
     subprocess.run([exe, "-k%d" % k, "-T2", "-p:x", "-P" + str(tmp_path), rel], check=True, cwd=str(tmp_path),
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
