@@ -680,7 +680,10 @@ def main():
     # (records per launch) is the profiled one.
     traffic = None
     traffic_src = None
-    for name in ("r02_h_configs%d_pmc_traffic.json" % cfg_id, "r02_g_configs%d_pmc_traffic.json" % cfg_id):
+    import glob
+    names = sorted((os.path.basename(f) for f in glob.glob(os.path.join(ROOT, "profiles", "r0*_configs%d_pmc_traffic.json" % cfg_id))),
+                   reverse=True)                              # the newest round's first
+    for name in names:
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", name)))
             per_launch = n_rec / (nl_k / passes_k)
