@@ -477,10 +477,48 @@ __global__ __launch_bounds__(256) void k_first_byte_bounds(const unsigned char *
   if (b == 0) bounds[256] = n;
 }
 
-/* <root>.ktab + hidden parts straight from the sorted table fk_finish_device left in HBM: every part has its own
-   writer thread, which fetches its range piece by piece through two small pinned buffers (the next piece crosses
-   PCIe while this one is stripped of its prefix bytes and written), so the 36 GB table of a human-size run never
-   exists in host memory: no 36 GB to pin before and to unpin after, and the fetch hides behind the writing.
+// ends[p] = 1 + the index of the last record whose first ib key bytes spell p (ends zeroed before: 0 = no such record)
+__global__ __launch_bounds__(256) void k_prefix_ends(const unsigned char *__restrict__ t, int64_t n, int stride, int ib,
+                                                     int64_t *__restrict__ ends)
+{ const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (i >= n)
+    return;
+  u32 a = 0, b = 0;
+  for (int j = 0; j < ib; j++)
+    { a = (a << 8) | t[i * stride + j];
+      if (i + 1 < n) b = (b << 8) | t[(i + 1) * stride + j];
+    }
+  if (i + 1 == n || a != b)
+    ends[a] = i + 1;
+}
+
+// cnt table records -> the bytes they take in a .ktab part file (table.c:162-342): the k-mer without its first ib bytes,
+// then the count; pw = kb - ib + 2 bytes each, four output bytes a thread
+__global__ __launch_bounds__(256) void k_ktab_strip(const unsigned char *__restrict__ t, int64_t cnt, int stride, int ib, int kb,
+                                                    unsigned char *__restrict__ out)
+{ const int pw = kb - ib + 2;
+  const int64_t o = ((int64_t) blockIdx.x * 256 + threadIdx.x) * 4, total = cnt * pw;
+  if (o >= total)
+    return;
+  int64_t i = o / pw;
+  int     j = (int) (o - i * pw);
+  u32 v = 0;
+#pragma unroll
+  for (int q = 0; q < 4; q++)
+    { if (o + q < total)
+        { const unsigned char c = (j < kb - ib) ? t[i * stride + ib + j] : t[i * stride + stride - 2 + (j - (kb - ib))];
+          v |= (u32) c << (8 * q);
+        }
+      if (++j == pw) { j = 0; i += 1; }
+    }
+  *(u32 *) (out + o) = v;
+}
+
+/* <root>.ktab + hidden parts straight from the sorted table fk_finish_device left in HBM.  The device makes the file
+   bytes: one pass finds where every ib-byte prefix ends (the index of the stub file), and every part has a writer
+   thread with a stream of its own that strips its range piece by piece (k_ktab_strip, which stores into one of two
+   pinned host buffers) and hands the piece to write() as it is -- the next piece is made and crosses PCIe meanwhile.  The 36 GB
+   table of a human-size run never exists in host memory and no host core touches an entry.
    The files are those of fk_write_ktab (table.c:162-342,485-498). */
 extern "C" int fk_write_ktab_device(fk_ctx *ctx, const fk_result *res, int nthreads, const char *dir, const char *root)
 { if (ctx == NULL || res == NULL || dir == NULL || root == NULL || nthreads < 1 || nthreads > 256) return (FK_EINVAL);
@@ -506,14 +544,41 @@ extern "C" int fk_write_ktab_device(fk_ctx *ctx, const fk_result *res, int nthre
   std::vector<int64_t> pc((size_t) npre, 0);
   int64_t hb[257];
   for (int b = 0; b <= 256; b++) hb[b] = 0;
+  const unsigned char *table = (const unsigned char *) ctx->last_table;
+  const int64_t piece = std::max<int64_t>((16ll << 20) / ST, 1);          // records per piece
+  const int64_t pbytes = (piece * pw + 255) & ~255ll;                     // bytes of a stripped piece (a multiple of 4)
+  // No device memory is taken here: fk_release_device may be returning the rest of the context's HBM in another thread,
+  // and a hipMalloc that follows a large hipFree waits until the driver has wiped what was freed (seconds;
+  // tools/probe/malloc_probe.cpp).  The kernels store into pinned host memory instead.
+  unsigned char *h_stage = NULL;
+  int64_t       *h_ends = NULL;
+  auto cleanup = [&]()
+    { if (h_stage) hipHostFree(h_stage);
+    };
   if (n > 0)
     { int64_t *d_b = (int64_t *) ctx->d_scratch;
-      hipLaunchKernelGGL(k_first_byte_bounds, dim3(1), dim3(256), 0, ctx->stream, (const unsigned char *) ctx->last_table, n, ST, d_b);
-      FK_LAUNCH_CHECK(ctx);
-      FK_HIP(ctx, hipMemcpyAsync(hb, d_b, 257 * 8, hipMemcpyDeviceToHost, ctx->stream));
-      FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      if (hipHostMalloc((void **) &h_stage, (size_t) (pbytes * 2 * nthreads + npre * 8), hipHostMallocDefault) != hipSuccess)
+        { fk_set_error(ctx, "fk_write_ktab_device: out of host memory for the staging of %d writers", nthreads);
+          return (FK_ENOMEM);
+        }
+      h_ends = (int64_t *) (h_stage + pbytes * 2 * nthreads);
+      memset(h_ends, 0, (size_t) npre * 8);
+      hipLaunchKernelGGL(k_first_byte_bounds, dim3(1), dim3(256), 0, ctx->stream, table, n, ST, d_b);
+      hipLaunchKernelGGL(k_prefix_ends, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, ctx->stream, table, n, ST, ib, h_ends);
+      if (hipGetLastError() != hipSuccess
+          || hipMemcpyAsync(hb, d_b, 257 * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess
+          || hipStreamSynchronize(ctx->stream) != hipSuccess)
+        { cleanup();
+          fk_set_error(ctx, "fk_write_ktab_device: the prefix pass failed");
+          return (FK_EHIP);
+        }
+      int64_t last = 0;                                                   // ends -> entries per prefix
+      for (int64_t p = 0; p < npre; p++)
+        if (h_ends[p] > 0)
+          { pc[(size_t) p] = h_ends[p] - last;
+            last = h_ends[p];
+          }
     }
-  const int64_t piece = std::max<int64_t>((16ll << 20) / ST, 1);          // records per piece
   std::vector<int> prc((size_t) nthreads, FK_OK);
   auto write_part = [&](int t)
     { const int64_t lo = hb[split[t]], hi = hb[split[t + 1]], cnt = hi - lo;
@@ -521,50 +586,31 @@ extern "C" int fk_write_ktab_device(fk_ctx *ctx, const fk_result *res, int nthre
       snprintf(pname, sizeof(pname), "%s/.%s.ktab.%d", dir, root, t + 1);
       int fd = open(pname, O_WRONLY | O_CREAT | O_TRUNC, 0644);
       if (fd < 0) { prc[t] = FK_EINVAL; return; }
-      uint8_t    *pin[2] = { NULL, NULL };
       hipStream_t st = NULL;
-      uint8_t    *out = (uint8_t *) malloc((size_t) piece * pw);
-      bool ok = (hipSetDevice(ctx->device) == hipSuccess && out != NULL
-                 && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess
-                 && hipHostMalloc((void **) &pin[0], (size_t) (piece * ST), hipHostMallocDefault) == hipSuccess
-                 && hipHostMalloc((void **) &pin[1], (size_t) (piece * ST), hipHostMallocDefault) == hipSuccess);
-      hipEvent_t ev[2] = { NULL, NULL };
-      ok = ok && hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) == hipSuccess
-              && hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) == hipSuccess;
-      if (ok && (write(fd, &kmer, 4) != 4 || write(fd, &cnt, 8) != 8))
-        ok = false;
+      hipEvent_t  ev[2] = { NULL, NULL };
+      bool ok = (write(fd, &kmer, 4) == 4 && write(fd, &cnt, 8) == 8);
+      if (ok && cnt > 0)
+        ok = (hipSetDevice(ctx->device) == hipSuccess
+              && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess
+              && hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) == hipSuccess
+              && hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) == hipSuccess);
+      unsigned char *pin[2] = { h_stage + pbytes * (2 * t), h_stage + pbytes * (2 * t + 1) };
       auto fetch = [&](int64_t x, int which) -> bool
-        { const int64_t e = std::min(hi, x + piece);
-          return (hipMemcpyAsync(pin[which], (const char *) ctx->last_table + x * ST, (size_t) ((e - x) * ST),
-                                 hipMemcpyDeviceToHost, st) == hipSuccess
-                  && hipEventRecord(ev[which], st) == hipSuccess);
+        { const int64_t m = std::min(hi, x + piece) - x;
+          const int64_t words = (m * pw + 3) / 4;
+          hipLaunchKernelGGL(k_ktab_strip, dim3((unsigned) ((words + 255) / 256)), dim3(256), 0, st, table + x * ST, m, ST, ib,
+                             (int) w.kmer_bytes, pin[which]);                // stored across PCIe as it is made
+          return (hipGetLastError() == hipSuccess && hipEventRecord(ev[which], st) == hipSuccess);
         };
-      int64_t run_pre = -1, run_n = 0;
       int which = 0;
       if (ok && lo < hi)
         ok = fetch(lo, 0);
       for (int64_t x = lo; ok && x < hi; x += piece, which ^= 1)
         { const int64_t e = std::min(hi, x + piece);
           if (e < hi)
-            ok = fetch(e, which ^ 1);                       // the next piece travels while this one is written
+            ok = fetch(e, which ^ 1);                       // the next piece is made and travels while this one is written
           if (!ok || hipEventSynchronize(ev[which]) != hipSuccess) { ok = false; break; }
-          const uint8_t *src = pin[which];
-          for (int64_t i = 0; i < e - x; i++)
-            { const uint8_t *rec = src + i * ST;
-              int64_t pre = 0;
-              for (int b = 0; b < ib; b++)
-                pre = (pre << 8) | rec[b];
-              if (pre != run_pre)
-                { if (run_n > 0) pc[(size_t) run_pre] += run_n;
-                  run_pre = pre;
-                  run_n = 0;
-                }
-              run_n += 1;
-              uint8_t *o = out + i * pw;
-              memcpy(o, rec + ib, (size_t) (w.kmer_bytes - ib));               // the k-mer's suffix
-              memcpy(o + w.kmer_bytes - ib, rec + ST - 2, 2);                  // the count
-            }
-          const uint8_t *q = out;
+          const unsigned char *q = pin[which];
           size_t left = (size_t) (e - x) * pw;
           while (left > 0)
             { const ssize_t wr = write(fd, q, left);
@@ -572,14 +618,10 @@ extern "C" int fk_write_ktab_device(fk_ctx *ctx, const fk_result *res, int nthre
               q += wr; left -= (size_t) wr;
             }
         }
-      if (run_n > 0) pc[(size_t) run_pre] += run_n;
       if (st) hipStreamSynchronize(st);
       for (int i = 0; i < 2; i++)
-        { if (pin[i]) hipHostFree(pin[i]);
-          if (ev[i]) hipEventDestroy(ev[i]);
-        }
+        if (ev[i]) hipEventDestroy(ev[i]);
       if (st) hipStreamDestroy(st);
-      free(out);
       if (close(fd) != 0) ok = false;
       if (!ok) prc[t] = FK_EINVAL;
     };
@@ -590,6 +632,7 @@ extern "C" int fk_write_ktab_device(fk_ctx *ctx, const fk_result *res, int nthre
     for (auto &x : th)
       x.join();
   }
+  cleanup();
   for (int t = 0; t < nthreads; t++)
     if (prc[t] != FK_OK)
       { fk_set_error(ctx, "Cannot write to %s/.%s.ktab.%d.  Enough disk space?", dir, root, t + 1);

@@ -46,6 +46,7 @@
 #include <time.h>
 #include <sys/types.h>
 #include <sys/wait.h>
+#include <sys/mman.h>
 #include <signal.h>
 
 #include "../../../include/fastk_amd.h"
@@ -65,6 +66,7 @@ static double now(void)
 
 static int       KMER = 40, NTHREADS = 4, DO_TABLE = 0, BC_PREFIX = 0, VERBOSE = 0, EXACT = 0, MEM_GB = 0, NGPUS = 1;
 static int       HOST_PARSE = 0, COMPRESS = 0, PROFILE = 0;
+static int       DEVICE_TEXT = 0;   /* FASTK_AMD_DEVICE_TEXT=1: the file text is parsed on the device even where the readers could pack it */
 static char     *PRO_NAME = NULL;
 static char     *OUT_NAME = NULL;
 /* -G<n>: one process per GPU.  The parent starts n copies of itself (before it has touched any GPU) with
@@ -319,7 +321,7 @@ static off_t record_start(int fd, off_t from, off_t size, int fastq)
     atbol = (pread(fd,&c,1,from-1) == 1 && c == '\n');
   }
   while (pos < size)
-    { ssize_t n = pread(fd,win,WIN,pos), i;
+    { ssize_t n = pread(fd,win,(pos == from) ? 65536 : WIN,pos), i;       /* mostly found within the first lines */
       if (n <= 0) break;
       for (i = 0; i < n; i++)
         { char c = win[i];
@@ -430,6 +432,414 @@ static void scan_text_on_device(Feeder *f, const char *path, int fastq)
   if (!fastq && fk_push_fasta(f->ctx,NULL,0,1,&phase,NULL,NULL) != FK_OK)     /* ends the last record */
     die(f->ctx,"fk_push_fasta");
   if (in != NULL) gzclose(in); else close(fd);
+}
+
+/* Plain FASTA / FASTQ text, packed by the reader threads.  The file is cut at record starts into pieces of PK_PIECE
+   bytes; the workers (one per core, 64 at most) each take the next piece, resolve its lines and pack the bases two
+   bits each (plus the stretches that hold no acgt), and hand the piece to fk_push_packed: a quarter of the bytes
+   cross PCIe, none of the header / quality text does, and the line scan runs on all host cores at once instead of on
+   one copy stream.  The line rules are those of the device parsers (io.c:678-734: four lines per FASTQ record, every
+   byte of a sequence line is a base; a FASTA record runs to the next line that begins with '>').  The order in
+   which the pieces arrive is not that of the file: used for the runs whose outputs do not depend on it (no -p, -x, -bc, -c). */
+static off_t PK_PIECE = (off_t) 64 << 20;     /* FASTK_AMD_PIECE=<bytes> overrides (tests cut small files into many pieces) */
+
+static uint8_t PK_PAIR[65536];     /* two bases -> 4 bits (first base high), 0x80 if either is not acgtACGT */
+static int8_t  PK_ONE[256];
+static int     PK_AVX2 = 0;       /* the host has AVX2: 32 bases a step */
+
+typedef struct
+  { Feeder         *f;
+    int             fd, fastq;
+    const off_t    *cut;          /* ncut+1 piece boundaries, all at record starts */
+    int             ncut;
+    int             next;         /* next piece to take (under lock) */
+    int64_t         totrds, totbps;
+    double          t_read, t_pack, t_push, t_hold;   /* summed over the workers (-v) */
+    const char     *map;          /* the whole file mapped, or NULL (FASTK_AMD_MMAP=0, mmap failed): pieces are pread */
+    pthread_mutex_t push;
+    uint8_t        *pinned;       /* one pinned region for all workers (64 hipHostMalloc calls at once take >1 s) */
+    size_t          slice;
+    int             nslices, taken;
+    double          t_setup;
+    int             failed;
+    pthread_mutex_t lock;
+  } Pk_Job;
+
+typedef struct
+  { char    *text;  size_t text_cap;
+    uint8_t *codes; size_t codes_cap;        /* pinned: a slice of the job's region, or its own if a piece is larger */
+    int      codes_own;
+    int32_t *rlen;  size_t rlen_cap;
+    int64_t *inv;   size_t inv_cap;          /* pairs */
+    int64_t  nb;
+    int      nreads, ninv;
+  } Pk_Buf;
+
+static void pk_tables(void)
+{ static int done = 0;
+  int a, b;
+  if (done) return;
+  memset(PK_ONE,-1,sizeof(PK_ONE));
+  PK_ONE['a'] = PK_ONE['A'] = 0; PK_ONE['c'] = PK_ONE['C'] = 1;
+  PK_ONE['g'] = PK_ONE['G'] = 2; PK_ONE['t'] = PK_ONE['T'] = 3;
+  for (a = 0; a < 256; a++)
+    for (b = 0; b < 256; b++)
+      PK_PAIR[a | (b << 8)] = (PK_ONE[a] < 0 || PK_ONE[b] < 0) ? 0x80 : (uint8_t) ((PK_ONE[a] << 2) | PK_ONE[b]);
+#if defined(__x86_64__)
+  PK_AVX2 = __builtin_cpu_supports("avx2") && !(getenv("FASTK_AMD_SCALAR") != NULL);
+#endif
+  done = 1;
+}
+
+static void pk_oom(void)
+{ fprintf(stderr,"%s: Out of memory\n",Prog_Name); exit (1); }
+
+static inline void pk_invalid(Pk_Buf *b, int64_t pos)
+{ if (b->ninv > 0 && b->inv[2*(b->ninv-1)] + b->inv[2*(b->ninv-1)+1] == pos)
+    { b->inv[2*(b->ninv-1)+1] += 1; return; }
+  if ((size_t) b->ninv+1 > b->inv_cap)
+    { b->inv_cap = b->inv_cap*2 + 1024;
+      if ((b->inv = realloc(b->inv,sizeof(int64_t)*2*b->inv_cap)) == NULL) pk_oom();
+    }
+  b->inv[2*b->ninv] = pos; b->inv[2*b->ninv+1] = 1;
+  b->ninv += 1;
+}
+
+#if defined(__x86_64__)
+#include <immintrin.h>
+
+/* 32 bases -> 8 bytes, first base in the two high bits of the first byte; returns 0 (nothing stored) if one of
+   them is not acgtACGT */
+__attribute__((target("avx2")))
+static inline int pk_pack32(const unsigned char *s, uint64_t *out)
+{ const __m256i v  = _mm256_loadu_si256((const __m256i *) s);
+  const __m256i u  = _mm256_and_si256(v,_mm256_set1_epi8((char) 0xDF));
+  const __m256i ok = _mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(u,_mm256_set1_epi8('A')),
+                                                     _mm256_cmpeq_epi8(u,_mm256_set1_epi8('C'))),
+                                     _mm256_or_si256(_mm256_cmpeq_epi8(u,_mm256_set1_epi8('G')),
+                                                     _mm256_cmpeq_epi8(u,_mm256_set1_epi8('T'))));
+  if (_mm256_movemask_epi8(ok) != -1)
+    return (0);
+  { /* (c >> 1) & 3 = a 0  c 1  t 2  g 3;  x ^ (x >> 1) = a 0  c 1  g 2  t 3 */
+    const __m256i x  = _mm256_and_si256(_mm256_srli_epi16(v,1),_mm256_set1_epi8(3));
+    const __m256i c  = _mm256_xor_si256(x,_mm256_and_si256(_mm256_srli_epi16(x,1),_mm256_set1_epi8(1)));
+    const __m256i p2 = _mm256_maddubs_epi16(c,_mm256_set1_epi16(0x0104));        /* b0*4 + b1 per 16-bit lane */
+    const __m256i p4 = _mm256_madd_epi16(p2,_mm256_set1_epi32(0x00010010));      /* *16 + next per 32-bit lane */
+    const __m256i sh = _mm256_shuffle_epi8(p4,_mm256_setr_epi8(0,4,8,12,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,
+                                                               0,4,8,12,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1,-1));
+    const __m256i pm = _mm256_permutevar8x32_epi32(sh,_mm256_setr_epi32(0,4,1,1,1,1,1,1));
+    *out = (uint64_t) _mm_cvtsi128_si64(_mm256_castsi256_si128(pm));
+  }
+  return (1);
+}
+
+/* the whole 32-base groups of s[0..n) appended at bit offset sh of *o; returns the bases consumed (stops early at a
+   group that holds a byte that is no base) */
+__attribute__((target("avx2")))
+static int64_t pk_bases_avx2(const unsigned char *s, int64_t n, uint8_t **op, int sh, unsigned *carryp)
+{ int64_t  i = 0;
+  uint8_t *o = *op;
+  uint64_t w;
+  if (sh == 0)
+    { for (; i+32 <= n; i += 32)
+        { if (!pk_pack32(s+i,&w)) break;
+          memcpy(o,&w,8);
+          o += 8;
+        }
+    }
+  else
+    { uint64_t carry = *carryp;                                  /* the taken high bits of the current byte */
+      for (; i+32 <= n; i += 32)
+        { uint64_t be, st;
+          if (!pk_pack32(s+i,&w)) break;
+          be = __builtin_bswap64(w);                             /* first base most significant */
+          st = __builtin_bswap64((be >> sh) | (carry << 56));
+          memcpy(o,&st,8);
+          o += 8;
+          carry = (be << (8-sh)) & 0xff;
+        }
+      *carryp = (unsigned) carry;
+    }
+  *op = o;
+  return (i);
+}
+#endif
+
+/* append the n bases at s to the packed block (codes has room: it is sized from the piece) */
+static void pk_bases(Pk_Buf *b, const unsigned char *s, int64_t n)
+{ int64_t  i = 0, nb = b->nb;
+  uint8_t *o = b->codes + (nb >> 2);
+  const int sh = (int) (nb & 3)*2;          /* bits of *o already taken */
+  unsigned carry = sh ? *o : 0;
+
+#if defined(__x86_64__)
+  if (PK_AVX2)
+    while (i+32 <= n)
+      { int64_t j;
+        i += pk_bases_avx2(s+i,n-i,&o,sh,&carry);
+        if (i+32 > n) break;
+        for (j = 0; j < 32; j += 4)         /* a group with a non-base: its eight bytes the slow way */
+          { unsigned g = 0;
+            int      q;
+            for (q = 0; q < 4; q++)
+              { int v = PK_ONE[s[i+j+q]];
+                if (v < 0) { pk_invalid(b,nb+i+j+q); v = 0; }
+                g = (g << 2) | (unsigned) v;
+              }
+            *o++  = (uint8_t) (carry | (g >> sh));
+            carry = (g << (8-sh)) & 0xff;
+          }
+        i += 32;
+      }
+#endif
+  for (; i+4 <= n; i += 4)
+    { unsigned g, hi = PK_PAIR[s[i] | (s[i+1] << 8)], lo = PK_PAIR[s[i+2] | (s[i+3] << 8)];
+      if ((hi | lo) & 0x80)
+        { int j;
+          g = 0;
+          for (j = 0; j < 4; j++)
+            { int v = PK_ONE[s[i+j]];
+              if (v < 0) { pk_invalid(b,nb+i+j); v = 0; }
+              g = (g << 2) | (unsigned) v;
+            }
+        }
+      else
+        g = (hi << 4) | lo;
+      *o++  = (uint8_t) (carry | (g >> sh));
+      carry = (g << (8-sh)) & 0xff;
+    }
+  { int used = sh;                           /* the tail, base by base */
+    for (; i < n; i++)
+      { int v = PK_ONE[s[i]];
+        if (v < 0) { pk_invalid(b,nb+i); v = 0; }
+        carry |= (unsigned) v << (6-used);
+        used += 2;
+        if (used == 8)
+          { *o++ = (uint8_t) carry; carry = 0; used = 0; }
+      }
+    if (used > 0)
+      *o = (uint8_t) carry;
+  }
+  b->nb = nb+n;
+}
+
+static inline void pk_end_read(Pk_Buf *b, int64_t start)
+{ if ((size_t) b->nreads+1 > b->rlen_cap)
+    { b->rlen_cap = b->rlen_cap*2 + 4096;
+      if ((b->rlen = realloc(b->rlen,sizeof(int32_t)*b->rlen_cap)) == NULL) pk_oom();
+    }
+  b->rlen[b->nreads++] = (int32_t) (b->nb-start);
+}
+
+static void *pk_worker(void *arg)
+{ Pk_Job *job = (Pk_Job *) arg;
+  Pk_Buf  b;
+  memset(&b,0,sizeof(b));
+  for (;;)
+    { int    k;
+      off_t  beg, end;
+      size_t len, done = 0;
+      const unsigned char *p, *e;
+
+      pthread_mutex_lock(&job->lock);
+      k = (job->failed || job->next >= job->ncut) ? -1 : job->next++;
+      pthread_mutex_unlock(&job->lock);
+      if (k < 0) break;
+      beg = job->cut[k]; end = job->cut[k+1];
+      len = (size_t) (end-beg);
+      if (len == 0) continue;
+      if (job->map == NULL && len+8 > b.text_cap)
+        { free(b.text);
+          b.text_cap = len + len/8 + 64;
+          if ((b.text = malloc(b.text_cap)) == NULL) pk_oom();
+        }
+      if (b.codes == NULL)
+        { pthread_mutex_lock(&job->lock);
+          if (job->taken < job->nslices)
+            { b.codes = job->pinned + job->slice*(size_t) job->taken++;
+              b.codes_cap = job->slice;
+            }
+          pthread_mutex_unlock(&job->lock);
+        }
+      if (len/4+64 > b.codes_cap)
+        { if (b.codes_own) fk_host_free(b.codes);
+          b.codes_cap = len/4 + len/32 + 64;
+          b.codes_own = 1;
+          if (fk_host_alloc((int64_t) b.codes_cap,(void **) &b.codes) != FK_OK) pk_oom();
+        }
+      double t0 = now(), t1, t2, t3;
+      if (job->map != NULL)
+        { off_t lo = beg & ~(off_t) 4095;
+#ifndef MADV_POPULATE_READ
+#define MADV_POPULATE_READ 22
+#endif
+          madvise((void *) (job->map+lo),(size_t) (end-lo),MADV_POPULATE_READ);     /* one fault for the piece */
+          p = (const unsigned char *) job->map+beg;
+        }
+      else
+        { while (done < len)
+            { ssize_t r = pread(job->fd,b.text+done,len-done,beg+(off_t) done);
+              if (r <= 0) break;
+              done += (size_t) r;
+            }
+          if (done < len)
+            { fprintf(stderr,"%s: short read of the input\n",Prog_Name); exit (1); }
+          p = (const unsigned char *) b.text;
+        }
+      t1 = now();
+      b.nb = 0; b.nreads = 0; b.ninv = 0;
+      e = p+len;
+      if (job->fastq)
+        while (p < e)
+          { const unsigned char *nl;
+            int64_t start = b.nb;
+            nl = memchr(p,'\n',(size_t) (e-p));                 /* header */
+            if (nl == NULL) break;
+            p = nl+1;
+            nl = memchr(p,'\n',(size_t) (e-p));                 /* sequence */
+            if (nl == NULL) nl = e;
+            pk_bases(&b,p,nl-p);
+            pk_end_read(&b,start);
+            p = (nl < e) ? nl+1 : e;
+            if (p < e)
+              { nl = memchr(p,'\n',(size_t) (e-p));             /* + */
+                p  = (nl == NULL) ? e : nl+1;
+              }
+            if (p < e)
+              { nl = memchr(p,'\n',(size_t) (e-p));             /* quality */
+                p  = (nl == NULL) ? e : nl+1;
+              }
+          }
+      else
+        { int     open = 0;
+          int64_t start = 0;
+          int     first = 1;
+          while (p < e)
+            { const unsigned char *nl = memchr(p,'\n',(size_t) (e-p));
+              if (nl == NULL) nl = e;
+              if (*p == '>' || first)
+                { if (open) pk_end_read(&b,start);
+                  open = 1; start = b.nb; first = 0;
+                }
+              else
+                pk_bases(&b,p,nl-p);
+              p = (nl < e) ? nl+1 : e;
+            }
+          if (open) pk_end_read(&b,start);
+        }
+      if (job->map != NULL)                      /* drop the piece's page-table entries here, in parallel: one munmap */
+        { off_t lo = (beg+4095) & ~(off_t) 4095, hi = end & ~(off_t) 4095;     /* of 150 GB at the end takes over a second */
+          if (hi > lo)
+            madvise((void *) (job->map+lo),(size_t) (hi-lo),MADV_DONTNEED);
+        }
+      t2 = now();
+      { int rc = FK_OK;
+        double th;
+        pthread_mutex_lock(&job->push);
+        th = now();
+        if (b.nreads > 0)
+          rc = fk_push_packed(job->f->ctx,b.codes,b.nb,b.rlen,b.nreads,b.inv,b.ninv,0,k % NTHREADS);
+        th = now()-th;
+        pthread_mutex_unlock(&job->push);
+        if (rc != FK_OK)
+          { pthread_mutex_lock(&job->lock);
+            job->failed = 1;
+            pthread_mutex_unlock(&job->lock);
+            break;
+          }
+        t3 = now();
+        pthread_mutex_lock(&job->lock);
+        job->t_hold += th;
+        pthread_mutex_unlock(&job->lock);
+      }
+      pthread_mutex_lock(&job->lock);
+      job->t_read += t1-t0; job->t_pack += t2-t1; job->t_push += t3-t2;
+      job->totrds += b.nreads;
+      job->totbps += b.nb;
+      pthread_mutex_unlock(&job->lock);
+    }
+  free(b.text); free(b.rlen); free(b.inv);
+  if (b.codes_own) fk_host_free(b.codes);
+  return (NULL);
+}
+
+static void scan_text_packed(Feeder *f, const char *path, int fastq)
+{ int     fd = open(path,O_RDONLY);
+  off_t   size, foff, fend, *cut;
+  int     ncut = 0, nthr, t;
+  long    ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+  Pk_Job  job;
+  pthread_t th[64];
+
+  if (fd < 0)
+    { fprintf(stderr,"%s: Cannot open %s for reading\n",Prog_Name,path);
+      exit (1);
+    }
+  pk_tables();
+  if (getenv("FASTK_AMD_PIECE") != NULL && atoll(getenv("FASTK_AMD_PIECE")) > 0)
+    PK_PIECE = (off_t) atoll(getenv("FASTK_AMD_PIECE"));
+  flush_block(f,0);
+  size = lseek(fd,0,SEEK_END);
+  foff = 0; fend = size;
+  if (RANK >= 0 && NGPUS > 1)              /* this rank's stripe of the file, cut at record starts */
+    { foff = record_start(fd,(off_t) ((double) size*RANK/NGPUS),size,fastq);
+      fend = (RANK+1 == NGPUS) ? size : record_start(fd,(off_t) ((double) size*(RANK+1)/NGPUS),size,fastq);
+    }
+  double t_begin = now(), t_cut = now();
+  cut = malloc(sizeof(off_t)*(size_t) ((fend-foff)/PK_PIECE+3));
+  if (cut == NULL) pk_oom();
+  cut[0] = foff;
+  while (cut[ncut] < fend)
+    { off_t nx = cut[ncut]+PK_PIECE;
+      nx = (nx >= fend) ? fend : record_start(fd,nx,size,fastq);
+      if (nx > fend) nx = fend;
+      cut[++ncut] = nx;
+    }
+  t_cut = now()-t_cut;
+  memset(&job,0,sizeof(job));
+  job.f = f; job.fd = fd; job.fastq = fastq; job.cut = cut; job.ncut = ncut;
+  pthread_mutex_init(&job.lock,NULL);
+  pthread_mutex_init(&job.push,NULL);
+  /* the pieces are packed straight out of the page cache (the file mapped, a piece populated by one madvise): a
+     pread into a private buffer first moves every byte twice more and costs 10x the thread time (tools/ingest_probe.py;
+     FASTK_AMD_MMAP=0 goes back to it) */
+  if (!(getenv("FASTK_AMD_MMAP") != NULL && atoi(getenv("FASTK_AMD_MMAP")) == 0) && size > 0)
+    { void *m = mmap(NULL,(size_t) size,PROT_READ,MAP_SHARED,fd,0);
+      if (m != MAP_FAILED) job.map = (const char *) m;
+    }
+  nthr = (ncpu > 64) ? 64 : (int) ncpu;
+  if (RANK >= 0 && NGPUS > 1) nthr /= NGPUS;
+  if (getenv("FASTK_AMD_READERS") != NULL && atoi(getenv("FASTK_AMD_READERS")) > 0)
+    nthr = atoi(getenv("FASTK_AMD_READERS"));
+  if (nthr > 64) nthr = 64;
+  if (nthr > ncut) nthr = ncut;
+  if (nthr < 1) nthr = 1;
+  job.t_setup = now();
+  job.slice   = (size_t) (PK_PIECE/4 + PK_PIECE/16 + 65536) & ~(size_t) 4095;
+  job.nslices = nthr;
+  if (fk_host_alloc((int64_t) (job.slice*(size_t) nthr),(void **) &job.pinned) != FK_OK)
+    { job.pinned = NULL; job.nslices = 0; }
+  job.t_setup = now()-job.t_setup;
+  for (t = 1; t < nthr; t++)
+    pthread_create(th+t,NULL,pk_worker,&job);
+  pk_worker(&job);
+  for (t = 1; t < nthr; t++)
+    pthread_join(th[t],NULL);
+  pthread_mutex_destroy(&job.lock);
+  if (job.failed)
+    die(f->ctx,"fk_push_packed");
+  f->totrds += job.totrds;
+  f->totbps += job.totbps;
+  if (VERBOSE)
+    fprintf(stderr,"  %s: %d pieces packed by %d reader threads; thread seconds: read %.2f  pack %.2f  push %.2f of which inside fk_push_packed %.2f; cutting %.2f s, pinned buffers %.2f s, wall %.2f s\n",
+            path,ncut,nthr,job.t_read,job.t_pack,job.t_push,job.t_hold,t_cut,job.t_setup,now()-t_begin);
+  if (job.pinned != NULL)
+    fk_host_free(job.pinned);
+  if (job.map != NULL)
+    munmap((void *) job.map,(size_t) size);
+  pthread_mutex_destroy(&job.push);
+  free(cut);
+  close(fd);
 }
 
 static void scan_file(Feeder *f, const char *path, int fastq)
@@ -787,6 +1197,7 @@ int main(int argc, char *argv[])
     COMPRESS   = flags['c'];
     EXACT      = flags['x'];
     HOST_PARSE = flags['H'];
+    DEVICE_TEXT = (getenv("FASTK_AMD_DEVICE_TEXT") != NULL && atoi(getenv("FASTK_AMD_DEVICE_TEXT")) > 0);
     if (flags['t']) DO_TABLE = 1;
     if (flags['p']) PROFILE = 1;
     (void) g;
@@ -873,6 +1284,8 @@ int main(int argc, char *argv[])
   if (fk_create(&prm,&ctx) != FK_OK)
     die(NULL,"fk_create");
   t_created = now();
+  if (getenv("FASTK_AMD_DEBUG") != NULL && atoi(getenv("FASTK_AMD_DEBUG")) > 0)     /* per-chunk / per-bucket lines on stderr */
+    fk_debug_set(ctx,"verbose",atoi(getenv("FASTK_AMD_DEBUG")));
   if (EXACT)          /* -x -M<int>: the reference's sort memory (12 GB unless given, FastK.c:235,291), hence its buckets */
     fk_set_sort_memory(ctx,(int64_t) (MEM_GB > 0 ? MEM_GB : 12)*1000000000ll,0.);
   if (RANK >= 0 && NGPUS > 1)
@@ -917,6 +1330,9 @@ int main(int argc, char *argv[])
         scan_sam(&feed,argv[i]);
       else if (q == 3)
         scan_bam(&feed,argv[i]);
+      else if (!EXACT && BC_PREFIX == 0 && !HOST_PARSE && !COMPRESS && !PROFILE && !DEVICE_TEXT
+               && !(strlen(argv[i]) > 3 && strcmp(argv[i]+strlen(argv[i])-3,".gz") == 0))
+        scan_text_packed(&feed,argv[i],q);
       else if (!EXACT && BC_PREFIX == 0 && !HOST_PARSE && (q == 1 || !(COMPRESS || PROFILE))
                && !(NGPUS > 1 && strlen(argv[i]) > 3 && strcmp(argv[i]+strlen(argv[i])-3,".gz") == 0))
         scan_text_on_device(&feed,argv[i],q);

@@ -728,6 +728,39 @@ def test_cli_outputs_match_reference(name, fmt, gz, tmp_path):
         assert hashlib.sha256(open(tmp_path / mine, "rb").read()).hexdigest() == digest, fname
 
 
+@pytest.mark.parametrize("name,fmt,width,piece", [("edge_k40_t1_T4", "fasta", 0, 0), ("edge_k40_t1_T4", "fastq", 0, 700),
+                                                  ("synth_illumina_k51_t1_T4", "fastq", 0, 100000),
+                                                  ("synth_hifi_k40_t4_T8", "fasta", 80, 300000),
+                                                  ("synth_hifi_k40_t4_T8", "fasta", 0, 50000)])
+def test_cli_reader_threads_pack_the_text(name, fmt, width, piece, tmp_path):
+    """Plain FASTA / FASTQ files reach the GPU two bits per base: the reader threads of FastK_amd cut the file at record
+    starts, resolve the lines and pack the bases (scan_text_packed -> fk_push_packed).  Same .hist bytes and .ktab
+    stream as the reference, whatever the piece size; FASTK_AMD_DEVICE_TEXT=1 (text parsed on the device) agrees."""
+    import hashlib, os, subprocess
+    case, bases, boff = util.load_case(name)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "fastk_amd", "bin", "FastK_amd")
+    path = str(tmp_path / ("reads." + fmt))
+    if fmt == "fasta":
+        orc.write_fasta(path, bases, boff, **({"width": width} if width else {}))
+    else:
+        orc.write_fastq(path, bases, boff)
+    exp = case["expected"]
+    for env_extra in ({"FASTK_AMD_PIECE": str(piece)} if piece else {}, {"FASTK_AMD_DEVICE_TEXT": "1"}):
+        out = subprocess.run([exe, "-k%d" % case["k"], "-t%d" % case["cutoff"], "-T%d" % case["T"], "-v", path],
+                             check=True, cwd=str(tmp_path), env=dict(os.environ, **env_extra),
+                             capture_output=True, text=True)
+        hist = open(tmp_path / "reads.hist", "rb").read()
+        assert hashlib.sha256(hist).hexdigest() == exp["hist_sha256"], env_extra
+        t = orc.read_ktab(str(tmp_path / "reads"))
+        assert t["stream_sha256"] == exp["ktab"]["stream_sha256"], env_extra
+        assert ("There are %d reads totalling %d bps" % (len(boff) - 1, int(boff[-1]) - (len(boff) - 1))) \
+            in out.stdout + out.stderr, out.stderr
+        for f in os.listdir(tmp_path):
+            if f != "reads." + fmt:
+                os.remove(tmp_path / f)
+
+
 def test_group_records_brings_duplicates_together(ctx40):
     """fk_group_records: a permutation of the input in which equal records are adjacent."""
     rng = np.random.default_rng(21)
