@@ -403,6 +403,10 @@ extern "C" void fk_destroy(fk_ctx *ctx)
   if (ctx->h_table) fkx_pinned_free(ctx->h_table);
   free(ctx->acc_res);
   free(ctx->h_roff);
+  free(ctx->ktab_ends);
+  if (ctx->h_wstage) hipHostFree(ctx->h_wstage);
+  for (int i = 0; i < 4; i++)
+    if (ctx->wstream[i]) hipStreamDestroy(ctx->wstream[i]);
   if (ctx->push_lock)
     { pthread_mutex_destroy((pthread_mutex_t *) ctx->push_lock);
       free(ctx->push_lock);
@@ -477,6 +481,12 @@ __global__ __launch_bounds__(256) void k_first_byte_bounds(const unsigned char *
   if (b == 0) bounds[256] = n;
 }
 
+static double fk_wall(void)
+{ struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ((double) ts.tv_sec + 1e-9 * (double) ts.tv_nsec);
+}
+
 // ends[p] = 1 + the index of the last record whose first ib key bytes spell p (ends zeroed before: 0 = no such record)
 __global__ __launch_bounds__(256) void k_prefix_ends(const unsigned char *__restrict__ t, int64_t n, int stride, int ib,
                                                      int64_t *__restrict__ ends)
@@ -514,6 +524,89 @@ __global__ __launch_bounds__(256) void k_ktab_strip(const unsigned char *__restr
   *(u32 *) (out + o) = v;
 }
 
+#define KTAB_PIECE_BYTES (16ll << 20)       // of table records per piece of a part writer
+
+static int64_t ktab_piece_bytes(const fk_ctx *ctx, int ib)      // bytes of a stripped piece, rounded
+{ const int64_t piece = std::max<int64_t>(KTAB_PIECE_BYTES / ctx->wid.kmer_stride, 1);
+  return ((piece * (ctx->wid.kmer_word - ib) + 255) & ~255ll);
+}
+
+static int ktab_staging(fk_ctx *ctx, int nthreads, int ib)
+{ const int64_t need = ktab_piece_bytes(ctx, ib) * 2 * nthreads;
+  for (int i = 0; i < 4; i++)
+    if (ctx->wstream[i] == NULL)
+      FK_HIP(ctx, hipStreamCreateWithFlags(&ctx->wstream[i], hipStreamNonBlocking));
+  if (ctx->wstage_cap >= need)
+    return (FK_OK);
+  if (ctx->h_wstage) hipHostFree(ctx->h_wstage);
+  ctx->h_wstage = NULL;
+  ctx->wstage_cap = 0;
+  if (hipHostMalloc((void **) &ctx->h_wstage, (size_t) need, hipHostMallocDefault) != hipSuccess)
+    { (void) hipGetLastError();
+      fk_set_error(ctx, "fk_write_ktab_device: out of host memory for the staging of %d writers", nthreads);
+      return (FK_ENOMEM);
+    }
+  ctx->wstage_cap = need;
+  return (FK_OK);
+}
+
+// The prefix index of the table in HBM (n entries): ctx->ktab_ends[p] = entries whose first ib key bytes spell p.
+// The pass needs npre * 8 bytes of device scratch: the read buffer when it is large enough (its reads are counted),
+// else a buffer of its own.
+static int ktab_prefix_index(fk_ctx *ctx, int64_t n, int ib)
+{ int64_t npre = 1;
+  for (int i = 0; i < ib; i++) npre *= 256;
+  free(ctx->ktab_ends);
+  ctx->ktab_ends = (int64_t *) calloc((size_t) npre, 8);
+  ctx->ktab_ends_ntab = -1;
+  if (ctx->ktab_ends == NULL)
+    return (FK_ENOMEM);
+  for (int b = 0; b <= 256; b++)
+    ctx->ktab_first[b] = 0;
+  if (n > 0)
+    { int64_t *d_ends = NULL;
+      bool own = false;
+      if (ctx->d_reads != NULL && ctx->reads_cap >= npre * 8 && ctx->reads_len == 0 && ctx->flush_thread == NULL)
+        d_ends = (int64_t *) ctx->d_reads;
+      else
+        { FK_HIP(ctx, hipMalloc((void **) &d_ends, (size_t) npre * 8));
+          own = true;
+        }
+      hipError_t e = hipMemsetAsync(d_ends, 0, (size_t) npre * 8, ctx->stream);
+      if (e == hipSuccess)
+        { int64_t *d_b = (int64_t *) ctx->d_scratch;
+          hipLaunchKernelGGL(k_first_byte_bounds, dim3(1), dim3(256), 0, ctx->stream, (const unsigned char *) ctx->last_table, n,
+                             ctx->wid.kmer_stride, d_b);
+          e = hipMemcpyAsync(ctx->ktab_first, d_b, 257 * 8, hipMemcpyDeviceToHost, ctx->stream);
+        }
+      if (e == hipSuccess)
+        { hipLaunchKernelGGL(k_prefix_ends, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                             (const unsigned char *) ctx->last_table, n, ctx->wid.kmer_stride, ib, d_ends);
+          e = hipGetLastError();
+        }
+      if (e == hipSuccess)
+        e = hipMemcpyAsync(ctx->ktab_ends, d_ends, (size_t) npre * 8, hipMemcpyDeviceToHost, ctx->stream);
+      if (e == hipSuccess)
+        e = hipStreamSynchronize(ctx->stream);
+      if (own)
+        hipFree(d_ends);
+      if (e != hipSuccess)
+        { fk_set_error(ctx, "the prefix pass over the table failed: %s", hipGetErrorString(e));
+          return (FK_EHIP);
+        }
+      int64_t last = 0;                                                   // ends -> entries per prefix
+      for (int64_t p = 0; p < npre; p++)
+        if (ctx->ktab_ends[p] > 0)
+          { const int64_t end = ctx->ktab_ends[p];
+            ctx->ktab_ends[p] = end - last;
+            last = end;
+          }
+    }
+  ctx->ktab_ends_ntab = n;
+  ctx->ktab_ends_ib = ib;
+  return (FK_OK);
+}
+
 /* <root>.ktab + hidden parts straight from the sorted table fk_finish_device left in HBM.  The device makes the file
    bytes: one pass finds where every ib-byte prefix ends (the index of the stub file), and every part has a writer
    thread with a stream of its own that strips its range piece by piece (k_ktab_strip, which stores into one of two
@@ -534,6 +627,7 @@ extern "C" int fk_write_ktab_device(fk_ctx *ctx, const fk_result *res, int nthre
       return (FK_ESTATE);
     }
   FK_HIP(ctx, hipSetDevice(ctx->device));
+  const double tw0 = fk_wall();
   std::vector<int> split((size_t) nthreads + 1);
   int rc = fk_ktab_split(res->wfirst, kmer, nthreads, split.data());
   if (rc != FK_OK) return (rc);
@@ -543,42 +637,24 @@ extern "C" int fk_write_ktab_device(fk_ctx *ctx, const fk_result *res, int nthre
   for (int i = 0; i < ib; i++) npre *= 256;
   std::vector<int64_t> pc((size_t) npre, 0);
   int64_t hb[257];
-  for (int b = 0; b <= 256; b++) hb[b] = 0;
   const unsigned char *table = (const unsigned char *) ctx->last_table;
-  const int64_t piece = std::max<int64_t>((16ll << 20) / ST, 1);          // records per piece
-  const int64_t pbytes = (piece * pw + 255) & ~255ll;                     // bytes of a stripped piece (a multiple of 4)
-  // No device memory is taken here: fk_release_device may be returning the rest of the context's HBM in another thread,
-  // and a hipMalloc that follows a large hipFree waits until the driver has wiped what was freed (seconds;
-  // tools/probe/malloc_probe.cpp).  The kernels store into pinned host memory instead.
-  unsigned char *h_stage = NULL;
-  int64_t       *h_ends = NULL;
-  auto cleanup = [&]()
-    { if (h_stage) hipHostFree(h_stage);
-    };
-  if (n > 0)
-    { int64_t *d_b = (int64_t *) ctx->d_scratch;
-      if (hipHostMalloc((void **) &h_stage, (size_t) (pbytes * 2 * nthreads + npre * 8), hipHostMallocDefault) != hipSuccess)
-        { fk_set_error(ctx, "fk_write_ktab_device: out of host memory for the staging of %d writers", nthreads);
-          return (FK_ENOMEM);
-        }
-      h_ends = (int64_t *) (h_stage + pbytes * 2 * nthreads);
-      memset(h_ends, 0, (size_t) npre * 8);
-      hipLaunchKernelGGL(k_first_byte_bounds, dim3(1), dim3(256), 0, ctx->stream, table, n, ST, d_b);
-      hipLaunchKernelGGL(k_prefix_ends, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, ctx->stream, table, n, ST, ib, h_ends);
-      if (hipGetLastError() != hipSuccess
-          || hipMemcpyAsync(hb, d_b, 257 * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess
-          || hipStreamSynchronize(ctx->stream) != hipSuccess)
-        { cleanup();
-          fk_set_error(ctx, "fk_write_ktab_device: the prefix pass failed");
-          return (FK_EHIP);
-        }
-      int64_t last = 0;                                                   // ends -> entries per prefix
-      for (int64_t p = 0; p < npre; p++)
-        if (h_ends[p] > 0)
-          { pc[(size_t) p] = h_ends[p] - last;
-            last = h_ends[p];
-          }
+  const int64_t piece = std::max<int64_t>(KTAB_PIECE_BYTES / ST, 1);      // records per piece
+  const int64_t pbytes = ktab_piece_bytes(ctx, ib);                       // bytes of a stripped piece (a multiple of 4)
+  // Nothing is allocated or asked of the device here when fk_finish_device ran before (prefix index, first-byte
+  // bounds, pinned staging): fk_release_device may be returning the rest of the context's HBM in another thread, every
+  // hipFree of which holds up the other HIP calls of the process, and a hipMalloc that follows a large hipFree waits
+  // until the driver has wiped what was freed (seconds; tools/probe/malloc_probe.cpp).  The strip kernels store into
+  // pinned host memory.
+  if (ctx->ktab_ends == NULL || ctx->ktab_ends_ntab != n || ctx->ktab_ends_ib != ib)
+    { if ((rc = ktab_prefix_index(ctx, n, ib)) != FK_OK)
+        return (rc);
     }
+  memcpy(pc.data(), ctx->ktab_ends, (size_t) npre * 8);
+  memcpy(hb, ctx->ktab_first, sizeof(hb));
+  if (n > 0 && (rc = ktab_staging(ctx, nthreads, ib)) != FK_OK)
+    return (rc);
+  unsigned char *h_stage = ctx->h_wstage;
+  const double tw1 = fk_wall();
   std::vector<int> prc((size_t) nthreads, FK_OK);
   auto write_part = [&](int t)
     { const int64_t lo = hb[split[t]], hi = hb[split[t + 1]], cnt = hi - lo;
@@ -586,12 +662,11 @@ extern "C" int fk_write_ktab_device(fk_ctx *ctx, const fk_result *res, int nthre
       snprintf(pname, sizeof(pname), "%s/.%s.ktab.%d", dir, root, t + 1);
       int fd = open(pname, O_WRONLY | O_CREAT | O_TRUNC, 0644);
       if (fd < 0) { prc[t] = FK_EINVAL; return; }
-      hipStream_t st = NULL;
+      hipStream_t st = ctx->wstream[t % 4];
       hipEvent_t  ev[2] = { NULL, NULL };
       bool ok = (write(fd, &kmer, 4) == 4 && write(fd, &cnt, 8) == 8);
       if (ok && cnt > 0)
         ok = (hipSetDevice(ctx->device) == hipSuccess
-              && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess
               && hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) == hipSuccess
               && hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) == hipSuccess);
       unsigned char *pin[2] = { h_stage + pbytes * (2 * t), h_stage + pbytes * (2 * t + 1) };
@@ -603,13 +678,17 @@ extern "C" int fk_write_ktab_device(fk_ctx *ctx, const fk_result *res, int nthre
           return (hipGetLastError() == hipSuccess && hipEventRecord(ev[which], st) == hipSuccess);
         };
       int which = 0;
+      double t_wait = 0., t_write = 0.;
       if (ok && lo < hi)
         ok = fetch(lo, 0);
       for (int64_t x = lo; ok && x < hi; x += piece, which ^= 1)
         { const int64_t e = std::min(hi, x + piece);
           if (e < hi)
             ok = fetch(e, which ^ 1);                       // the next piece is made and travels while this one is written
+          const auto w0 = std::chrono::steady_clock::now();
           if (!ok || hipEventSynchronize(ev[which]) != hipSuccess) { ok = false; break; }
+          const auto w1 = std::chrono::steady_clock::now();
+          t_wait += std::chrono::duration<double>(w1 - w0).count();
           const unsigned char *q = pin[which];
           size_t left = (size_t) (e - x) * pw;
           while (left > 0)
@@ -617,11 +696,13 @@ extern "C" int fk_write_ktab_device(fk_ctx *ctx, const fk_result *res, int nthre
               if (wr <= 0) { ok = false; break; }
               q += wr; left -= (size_t) wr;
             }
+          t_write += std::chrono::duration<double>(std::chrono::steady_clock::now() - w1).count();
         }
-      if (st) hipStreamSynchronize(st);
+      if (ctx->dbg_verbose)
+        fprintf(stderr, "  .ktab part %d: %lld entries; waited %.3f s for the device, %.3f s in write()\n", t + 1, (long long) cnt,
+                t_wait, t_write);
       for (int i = 0; i < 2; i++)
         if (ev[i]) hipEventDestroy(ev[i]);
-      if (st) hipStreamDestroy(st);
       if (close(fd) != 0) ok = false;
       if (!ok) prc[t] = FK_EINVAL;
     };
@@ -632,13 +713,17 @@ extern "C" int fk_write_ktab_device(fk_ctx *ctx, const fk_result *res, int nthre
     for (auto &x : th)
       x.join();
   }
-  cleanup();
+  const double tw2 = fk_wall();
   for (int t = 0; t < nthreads; t++)
     if (prc[t] != FK_OK)
       { fk_set_error(ctx, "Cannot write to %s/.%s.ktab.%d.  Enough disk space?", dir, root, t + 1);
         return (prc[t]);
       }
-  return fk_write_ktab_stub(kmer, nthreads, cutoff, ib, pc.data(), dir, root);
+  rc = fk_write_ktab_stub(kmer, nthreads, cutoff, ib, pc.data(), dir, root);
+  if (ctx->dbg_verbose)
+    fprintf(stderr, "  fk_write_ktab_device: set-up %.3f s, part writers %.3f s, stub %.3f s\n", tw1 - tw0, tw2 - tw1,
+            fk_wall() - tw2);
+  return (rc);
 }
 
 /* exact_parts only: the reference's -M in bytes (FastK.c:235,291: 12e9 by default, <int> x 1e9) and, when the caller
@@ -1692,11 +1777,6 @@ extern "C" int fk_host_free(void *ptr)
 // read data: one-substitution error k-mers share long prefixes with their true k-mer, so about half
 // of all prefix runs are heterogeneous and would need a local sort (measured).
 
-static double fk_wall(void)
-{ struct timespec ts;
-  clock_gettime(CLOCK_MONOTONIC, &ts);
-  return ((double) ts.tv_sec + 1e-9 * (double) ts.tv_nsec);
-}
 
 static double ms_between(hipEvent_t a, hipEvent_t b)
 { float ms = 0.f;
@@ -2482,7 +2562,15 @@ extern "C" int fk_finish(fk_ctx *ctx, fk_result *res)
 /* fk_finish without the host copy of the table (res->table NULL, res->ntable set): the sorted table stays in HBM for
    fk_write_ktab_device / fk_make_profiles. */
 extern "C" int fk_finish_device(fk_ctx *ctx, fk_result *res)
-{ return finish_impl(ctx, res, false); }
+{ int rc = finish_impl(ctx, res, false);
+  if (rc == FK_OK && ctx->prm.table_cutoff > 0 && ctx->last_table != NULL && ctx->last_ntab == res->ntable)
+    { const int ib = fk_ktab_idx_bytes(ctx->prm.kmer, res->ntable);
+      rc = ktab_prefix_index(ctx, res->ntable, ib);                       // what the .ktab stub holds
+      if (rc == FK_OK && res->ntable > 0)
+        rc = ktab_staging(ctx, ctx->prm.nthreads, ib);
+    }
+  return (rc);
+}
 
 /* Forget the reads pushed so far (and any chunks split from them); arenas, staging buffers and the
    bucket assignment stay, so the next data set starts without allocations. */

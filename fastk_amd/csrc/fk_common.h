@@ -118,6 +118,15 @@ struct fk_ctx
   int64_t    exact_wfirst[256];       // first-byte census of bucket 0's weighted k-mers (Table_Split's input)
   char      *d_pk, *h_pk;   // fk_push_packed: staging for codes, read offsets and invalid stretches (device / pinned)
   int64_t    pk_cap;
+  // fk_finish_device: where every ib-byte prefix of the sorted table ends (the index of the .ktab stub), for
+  // fk_write_ktab_device; valid for a table of ktab_ends_ntab entries
+  int64_t   *ktab_ends;
+  int64_t    ktab_first[257];   // ... and where every first key byte begins
+  unsigned char *h_wstage;      // pinned staging of the part writers (two pieces each), made before the release starts
+  int64_t    wstage_cap;
+  hipStream_t wstream[4];       // ... and their streams (writer t uses wstream[t % 4]; creating one per writer takes longer than the writing)
+  int64_t    ktab_ends_ntab;
+  int        ktab_ends_ib;
   char      *d_reads_alt;   // the idle read buffer (NULL until first needed)
   int64_t    reads_cap_alt;
   void      *flush_thread;  // std::thread * of the running flush, NULL if none

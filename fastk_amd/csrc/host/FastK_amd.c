@@ -153,7 +153,10 @@ static void flush_block(Feeder *f, int rem)
 static int KEEP_TABLE = 0;
 
 static void *release_thread(void *arg)
-{ fk_release_device((fk_ctx *) arg,KEEP_TABLE);
+{ double t0 = now();
+  fk_release_device((fk_ctx *) arg,KEEP_TABLE);
+  if (VERBOSE)
+    fprintf(stderr,"  device memory released in %.3f s (beside the file writers)\n",now()-t0);
   return (NULL);
 }
 
@@ -1481,6 +1484,8 @@ int main(int argc, char *argv[])
     t_write = now();
     if (relt)
       pthread_join(rel,NULL);
+    else
+      release_thread(ctx);
     if (KEEP_TABLE)
       fk_release_device(ctx,0);              /* the table's own buffer: left to _exit it would be freed behind the
                                                 next process's back, whose ingest then takes 2 s longer */

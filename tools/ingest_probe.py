@@ -60,7 +60,7 @@ def main():
                 lines = best[1].splitlines()
                 lines = [x for x in lines if "so far" not in x] + [x for x in lines if "so far" in x][-1:]
                 for line in lines:
-                    if any(w in line for w in ("reader threads", "Wall s", "so far", "Device ms", "  chunk ")):
+                    if any(w in line for w in ("reader threads", "Wall s", "so far", "Device ms", "  chunk ", ".ktab part", "fk_write_ktab_device", "release")):
                         print("   " + line.strip())
             sys.stdout.flush()
     finally:
