@@ -308,7 +308,8 @@ static int parallel_read(int fd, char *dst, off_t off, size_t max)
 
 /* First record start at or after byte `from` of a plain FASTA / FASTQ file (the file size if there is none):
    the reference stripes its input over threads the same way (io.c:2455-2521).  FASTA: a '>' that begins a
-   line.  FASTQ: a line that begins with '@' whose next-but-one line begins with '+' (a quality line may begin
+   line which follows a line that does not begin with '>' (the line after a header is sequence to the reference
+   whatever it begins with, io.c:689-734: a record without bases swallows the header of the next one).  FASTQ: a line that begins with '@' whose next-but-one line begins with '+' (a quality line may begin
    with '@' too, but then the next-but-one line is a sequence). */
 static off_t record_start(int fd, off_t from, off_t size, int fastq)
 { enum { WIN = 1 << 20 };
@@ -316,6 +317,7 @@ static off_t record_start(int fd, off_t from, off_t size, int fastq)
   off_t  pos = from;
   off_t  cand = -1;           /* FASTQ: start of a line that begins with '@' */
   int    lines_after = 0, atbol;
+  int    prev_gt = -1, cur_gt = -1;   /* FASTA: does the previous / this line begin with '>' (-1: not seen) */
 
   if (from <= 0) return (0);
   if (win == NULL && (win = malloc(WIN)) == NULL)
@@ -330,7 +332,9 @@ static off_t record_start(int fd, off_t from, off_t size, int fastq)
         { char c = win[i];
           if (atbol)
             { if (!fastq)
-                { if (c == '>') return (pos+i); }
+                { if (c == '>' && prev_gt == 0) return (pos+i);
+                  cur_gt = (c == '>');
+                }
               else
                 { if (cand >= 0)
                     { lines_after += 1;
@@ -344,6 +348,8 @@ static off_t record_start(int fd, off_t from, off_t size, int fastq)
                 }
             }
           atbol = (c == '\n');
+          if (atbol)
+            { prev_gt = cur_gt; cur_gt = -1; }
         }
       pos += n;
     }
@@ -700,7 +706,8 @@ static void *pk_worker(void *arg)
             if (nl == NULL) break;
             p = nl+1;
             nl = memchr(p,'\n',(size_t) (e-p));                 /* sequence */
-            if (nl == NULL) nl = e;
+            if (nl == NULL)                                     /* the file ends inside it: the reference never ends */
+              break;                                            /* this read (io.c:698-705,738) */
             pk_bases(&b,p,nl-p);
             pk_end_read(&b,start);
             p = (nl < e) ? nl+1 : e;
@@ -716,17 +723,32 @@ static void *pk_worker(void *arg)
       else
         { int     open = 0;
           int64_t start = 0;
-          int     first = 1;
+          int     first = 1, after_header = 0, cut = 0;
           while (p < e)
             { const unsigned char *nl = memchr(p,'\n',(size_t) (e-p));
-              if (nl == NULL) nl = e;
-              if (*p == '>' || first)
+              if (nl == NULL) { nl = e; cut = 1; }
+              /* the reference's machine (io.c:685-734): the line after a header is sequence whatever it begins with */
+              if (first || (*p == '>' && !after_header))
                 { if (open) pk_end_read(&b,start);
-                  open = 1; start = b.nb; first = 0;
+                  open = 1; start = b.nb; first = 0; after_header = 1;
                 }
               else
-                pk_bases(&b,p,nl-p);
+                { pk_bases(&b,p,nl-p);
+                  after_header = 0;
+                }
               p = (nl < e) ? nl+1 : e;
+            }
+          /* a file that does not end in a newline: the reference ends a read at the '>' or the end of file that follows
+             a newline (io.c:717-738), so the bases of the last record are dropped */
+          if (open && after_header)                  /* ... and a header at the very end opens no read */
+            open = 0;
+          if (open && cut)
+            { b.nb = start;
+              while (b.ninv > 0 && b.inv[2*(b.ninv-1)] >= start)
+                b.ninv -= 1;
+              if (b.ninv > 0 && b.inv[2*(b.ninv-1)]+b.inv[2*(b.ninv-1)+1] > start)
+                b.inv[2*(b.ninv-1)+1] = start-b.inv[2*(b.ninv-1)];
+              open = 0;
             }
           if (open) pk_end_read(&b,start);
         }
@@ -873,6 +895,11 @@ static void scan_file(Feeder *f, const char *path, int fastq)
       }
   if (state == 6)
     end_read(f);
+  else if (state == 5 || state == 2)     /* the file ends inside a sequence line: the reference ends a read only at the */
+    { int64_t start = f->boff[f->nreads];     /* newline (FASTQ) or at the '>' / end of file behind one (FASTA), */
+      f->totbps -= f->olen-start;             /* io.c:698-738 -- these bases belong to no read */
+      f->olen = start;
+    }
   gzclose(in);
 }
 
@@ -1473,7 +1500,7 @@ int main(int argc, char *argv[])
   /* the device memory (280 GB at the size of a human genome) goes back while the files are written: the driver
      takes seconds over it, about as long as the writers take over a 36 GB table */
   { pthread_t rel;
-    int       relt = (pthread_create(&rel,NULL,release_thread,ctx) == 0);
+    int       relt = (getenv("FASTK_AMD_NO_RELEASE") == NULL && pthread_create(&rel,NULL,release_thread,ctx) == 0);
 
     snprintf(name,sizeof(name),"%s/%s.hist",dir,root);
     if (fk_write_hist(res,KMER,name) != FK_OK)
@@ -1486,7 +1513,7 @@ int main(int argc, char *argv[])
       pthread_join(rel,NULL);
     else
       release_thread(ctx);
-    if (KEEP_TABLE)
+    if (KEEP_TABLE && getenv("FASTK_AMD_TABLE_RELEASE") != NULL)
       fk_release_device(ctx,0);              /* the table's own buffer: left to _exit it would be freed behind the
                                                 next process's back, whose ingest then takes 2 s longer */
   }

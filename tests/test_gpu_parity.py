@@ -761,6 +761,85 @@ def test_cli_reader_threads_pack_the_text(name, fmt, width, piece, tmp_path):
                 os.remove(tmp_path / f)
 
 
+def _odd_text(kind, quirks):
+    """FASTA / FASTQ text with what real files hold beside acgt: upper and lower case, N runs, IUPAC codes, lines of
+    several widths, a quality line that begins with '@'; with quirks also records without bases and no newline at
+    the very end -- where the reference's scanner (io.c:685-738) does what no FASTA reader would: the line after a
+    header is sequence whatever it begins with (a record without bases swallows the next header, whose letters then
+    meet the bases behind it), and a last read that no newline ends is dropped."""
+    import random
+    rnd = random.Random(20251002 + len(kind))
+    out = []
+    def seq(n):
+        s = []
+        while len(s) < n:
+            x = rnd.random()
+            if x < 0.01:
+                s.extend("N" * rnd.randint(1, 45))
+            elif x < 0.013:
+                s.append(rnd.choice("RYKMSWnryk"))
+            else:
+                s.append(rnd.choice("acgtACGT"))
+        return "".join(s[:n])
+    nrec = 400
+    for r in range(nrec):
+        n = rnd.choice(((0,) if quirks else ()) + (1, 39, 40, 41, 97, 150, 1500, 9000)) if r % 7 == 0 else rnd.randint(60, 3000)
+        if r == nrec - 1:
+            n = 2500                                  # the read the reference drops when no newline ends it
+        b = seq(n)
+        if kind == "fasta":
+            out.append(">read%d some text > with marks @ in it\n" % r)
+            w = rnd.choice((60, 80, 7, 100000))
+            for i in range(0, len(b), w):
+                out.append(b[i:i + w] + "\n")
+        else:
+            out.append("@read%d/1 +\n%s\n+\n%s\n" % (r, b, ("@" if r % 3 == 0 else "I") + "I" * max(len(b) - 1, 0)
+                       if len(b) > 0 else ""))
+    text = "".join(out)
+    return text[:-1] if quirks else text              # quirks: the last line has no newline
+
+
+@pytest.mark.parametrize("kind,quirks", [("fasta", False), ("fastq", False), ("fasta", True), ("fastq", True)])
+def test_cli_text_parsers_agree_on_odd_files(kind, quirks, tmp_path):
+    """The ways FastK_amd reads a plain text file -- packed by the reader threads (default), scanned by the host state
+    machine (-H), parsed on the device (FASTK_AMD_DEVICE_TEXT=1) -- and the reference FastK itself give the same .hist
+    bytes and table on a file with N runs, IUPAC codes, both cases and ragged lines; the packed path also when the file
+    is cut into pieces of a few hundred bytes.  With quirks (records without bases, no final newline) the reader threads
+    and the host scanner still follow the reference; the device parser reads FASTA as FASTA and is left out."""
+    import hashlib, os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "fastk_amd", "bin", "FastK_amd")
+    path = str(tmp_path / ("odd." + kind))
+    with open(path, "w") as f:
+        f.write(_odd_text(kind, quirks))
+    seen = {}
+    runs = [("packed", [], {}), ("packed, small pieces", [], {"FASTK_AMD_PIECE": "900"}),
+            ("packed, scalar", [], {"FASTK_AMD_SCALAR": "1", "FASTK_AMD_PIECE": "5000"}),
+            ("pread pieces", [], {"FASTK_AMD_MMAP": "0", "FASTK_AMD_PIECE": "3000"}),
+            ("host scanner", ["-H"], {})]
+    if not quirks:
+        runs.append(("device text", [], {"FASTK_AMD_DEVICE_TEXT": "1"}))
+    for tag, extra, env in runs:
+        out = subprocess.run([exe, "-k40", "-t1", "-T4", "-v", "-N" + str(tmp_path / "out")] + extra + [path], check=True,
+                             cwd=str(tmp_path), env=dict(os.environ, **env), capture_output=True, text=True)
+        hist = hashlib.sha256(open(tmp_path / "out.hist", "rb").read()).hexdigest()
+        t = orc.read_ktab(str(tmp_path / "out"))
+        line = [x.strip() for x in (out.stdout + out.stderr).splitlines() if "reads totalling" in x]
+        seen[tag] = (hist, t["stream_sha256"], t["nels"], line[0] if line else "")
+        for f in os.listdir(tmp_path):
+            if f.startswith("out") or f.startswith(".out"):
+                os.remove(tmp_path / f)
+    first = seen["packed"]
+    assert first[2] > 1000
+    for tag, v in seen.items():
+        assert v == first, (tag, v, first)
+    if orc.have_ref():
+        orc.run_ref_fastk(path, 40, 1, 4, str(tmp_path))
+        assert hashlib.sha256(open(tmp_path / ("odd.hist"), "rb").read()).hexdigest() == first[0]
+        t = orc.read_ktab(str(tmp_path / "odd"))
+        assert (t["stream_sha256"], t["nels"]) == first[1:3]
+
+
 def test_group_records_brings_duplicates_together(ctx40):
     """fk_group_records: a permutation of the input in which equal records are adjacent."""
     rng = np.random.default_rng(21)
