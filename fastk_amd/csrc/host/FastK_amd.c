@@ -1500,7 +1500,7 @@ int main(int argc, char *argv[])
   /* the device memory (280 GB at the size of a human genome) goes back while the files are written: the driver
      takes seconds over it, about as long as the writers take over a 36 GB table */
   { pthread_t rel;
-    int       relt = (getenv("FASTK_AMD_NO_RELEASE") == NULL && pthread_create(&rel,NULL,release_thread,ctx) == 0);
+    int       relt = (pthread_create(&rel,NULL,release_thread,ctx) == 0);
 
     snprintf(name,sizeof(name),"%s/%s.hist",dir,root);
     if (fk_write_hist(res,KMER,name) != FK_OK)
@@ -1511,11 +1511,8 @@ int main(int argc, char *argv[])
     t_write = now();
     if (relt)
       pthread_join(rel,NULL);
-    else
-      release_thread(ctx);
-    if (KEEP_TABLE && getenv("FASTK_AMD_TABLE_RELEASE") != NULL)
-      fk_release_device(ctx,0);              /* the table's own buffer: left to _exit it would be freed behind the
-                                                next process's back, whose ingest then takes 2 s longer */
+    /* the table's own buffer (36 GB at the size of a human genome) goes with the process: hipFree takes 0.6 s over
+       it, the kernel at exit next to nothing (three runs each: 4.5 s against 3.9-4.1 s in all) */
   }
   if (VERBOSE)
     { fprintf(stderr,"  Wall s: start-up + ingest %.3f  count + table fetch %.3f  write %.3f\n",
@@ -1523,11 +1520,8 @@ int main(int argc, char *argv[])
       fprintf(stderr,"  Wall s: fk_create %.3f (began %.3f after start)  clean-up %.3f  (process start to here %.3f)\n",
               t_created-t_create,t_create-t_start,now()-t_write,now()-t_start);
     }
-  /* every output file is closed and the device memory is back; what is left (the pinned table, the context) goes
-     with the process.  (Measured at configs[2], three runs each on one box: fk_destroy before exit 16.2 s in all, of
-     which 3.3 s in fk_destroy; _exit straight after the files 12.0 s -- but the driver then frees 280 GB behind the
-     process's back and the NEXT process pays for it: fk_create 2.0 s instead of 0.1 s, ingest 6.6 s instead of 4.8 s;
-     release beside the writers 12.1 s and the next process starts clean.) */
+  /* every output file is closed and all device memory but the table's buffer is back; what is left (that buffer, the
+     context, pinned staging) goes with the process.  fk_destroy here would take seconds (3.3 s measured at configs[2]). */
   fflush(stdout);
   fflush(stderr);
   _exit (0);
