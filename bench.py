@@ -23,7 +23,8 @@ torch.distributed harness (fastk_amd/shard.py).
 The line also carries (N = 1):
   roofline      dominant radix kernel (k_rx_scatter over the weighted k-mer records): algorithmic
                 2*n*R bytes per launch / launch duration by HIP events on the library's stream;
-                copy_ceiling = a device-to-device copy measured in this process
+                copy_ceiling = a device-to-device hipMemcpy measured in this process; copy_kernel_ceiling = the
+                library's own uint4 copy kernel (fk_copy_rate) on the same buffers, 10 % above it
   value_device  SURVEY 8(d) "device pipeline": first H2D of reads lying in pinned host memory ->
                 sorted table in pinned host memory (fk_push_block ... fk_finish)
   value_e2e     SURVEY 8(d) "end to end": FASTA file -> .hist + .ktab files through bin/FastK_amd
@@ -228,8 +229,9 @@ def cpu_baseline(args, cfg):
         subprocess.run(["rm", "-rf", d])
 
 
-def copy_ceiling(torch, dev):
-    """Device-to-device copy rate on this box (read + write bytes per second), 4 GiB buffers."""
+def copy_ceiling(torch, dev, ctx=None):
+    """Device-to-device copy rate on this box (read + write bytes per second), 4 GiB buffers: hipMemcpy (what
+    torch's copy_ issues) and, with a context, the library's own copy kernel."""
     n = 4 << 30
     a = torch.empty(n, dtype=torch.uint8, device=dev)
     b = torch.empty(n, dtype=torch.uint8, device=dev)
@@ -244,9 +246,13 @@ def copy_ceiling(torch, dev):
         e1.record()
         torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1))
+    kern = None
+    if ctx is not None:                  # ... and of a hand-written uint4 copy kernel (fk_copy_rate): the truer ceiling
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        kern = round(ctx.copy_rate(b.data_ptr(), a.data_ptr(), n), 1)
     del a, b
     torch.cuda.empty_cache()
-    return round(2.0 * n / (best * 1e-3) / 1e9, 1)
+    return round(2.0 * n / (best * 1e-3) / 1e9, 1), kern
 
 
 def device_leg(args, cfg, fastk_amd, ctx_gen, glen, nreads, L, local_rank):
@@ -618,8 +624,8 @@ def main():
     for kv in args.debug:
         key, val = kv.split("=")
         ctx.debug_set(key, int(val))
-    ceiling = copy_ceiling(torch, dev) if rank == 0 else None
-    log(args, "copy ceiling", ceiling, "GB/s; generating", nbytes, "bytes of reads")
+    ceiling, ceiling_kernel = copy_ceiling(torch, dev, ctx) if rank == 0 else (None, None)
+    log(args, "copy ceiling", ceiling, "GB/s (hipMemcpy),", ceiling_kernel, "GB/s (copy kernel); generating", nbytes, "bytes of reads")
     reads = torch.empty(nbytes + 64, dtype=torch.uint8, device=dev)
     ctx._ck(ctx.L.fk_synth_reads(ctx.h, args.seed, glen, L, cfg["err_ppm"], first, per,
                                  reads.data_ptr()))
@@ -718,6 +724,8 @@ def main():
                     traffic_unit="bytes per launch (FETCH_SIZE + WRITE_SIZE with the guide's gfx950 corrections, "
                                  "profiles/%s)" % traffic_src if traffic_src else None,
                     copy_ceiling=ceiling, frac_of_copy_ceiling=round(achieved / ceiling, 4) if ceiling else None,
+                    copy_kernel_ceiling=ceiling_kernel,
+                    frac_of_copy_kernel_ceiling=round(achieved / ceiling_kernel, 4) if ceiling_kernel else None,
                     algorithmic_bytes=round(algo_k / nl_k, 1),
                     kernel="k_rx_scatter<3,12> (weighted k-mer records, R=%d B)" % w.kmer_word,
                     records_per_launch=int(n_rec / (nl_k / passes_k)), launches_per_step=int(nl_k),

@@ -28,7 +28,7 @@ EXPORTS = [
     "fk_make_profiles", "fk_write_prof", "fk_set_table", "fk_ktab_idx_bytes", "fk_ktab_split",
     "fk_write_ktab_range", "fk_write_ktab_stub", "fk_split_supermers_emit_pos", "fk_profile_lookup_supermers",
     "fk_profile_scatter", "fk_profile_encode", "fk_reset", "fk_shard_unique_id", "fk_shard_create",
-    "fk_release_device", "fk_set_sort_memory", "fk_finish_device", "fk_write_ktab_device", "fk_push_packed", "fk_pack_fixed_reads", "fk_shard_count", "fk_shard_gather", "fk_shard_write", "fk_shard_destroy", "fk_shard_count_device", "fk_shard_local_result",
+    "fk_release_device", "fk_set_sort_memory", "fk_finish_device", "fk_write_ktab_device", "fk_push_packed", "fk_pack_fixed_reads", "fk_copy_rate", "fk_shard_count", "fk_shard_gather", "fk_shard_write", "fk_shard_destroy", "fk_shard_count_device", "fk_shard_local_result",
 ]
 
 
@@ -110,6 +110,7 @@ def load_library():
     L.fk_push_packed.argtypes = [vp, vp, i64, vp, ci, vp, ci, ci, ci]
     L.fk_set_sort_memory.argtypes = [vp, i64, C.c_double]
     L.fk_pack_fixed_reads.argtypes = [vp, vp, i64, C.c_uint32, vp]
+    L.fk_copy_rate.argtypes = [vp, vp, vp, i64, C.c_int, C.POINTER(C.c_double)]
     L.fk_train_block.argtypes = [vp, vp, vp, ci]
     L.fk_push_device.argtypes = [vp, vp, i64]
     L.fk_finish.argtypes = [vp, C.POINTER(CResult)]
@@ -440,6 +441,12 @@ class Context:
                                        nreads, buf.ptr))
         self._ck(self.L.fk_synchronize(self.h))
         return buf, n
+
+    def copy_rate(self, dst_ptr, src_ptr, nbytes, reps=5):
+        """(read + write) GB/s of a plain uint4 copy kernel between two device buffers (measurement helper)."""
+        g = C.c_double()
+        self._ck(self.L.fk_copy_rate(self.h, dst_ptr, src_ptr, nbytes, reps, C.byref(g)))
+        return g.value
 
     def split(self, reads_ptr, nbytes, out_ptr=None, cap=0):
         ns, ni = C.c_int64(), C.c_int64()

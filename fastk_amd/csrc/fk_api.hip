@@ -933,6 +933,43 @@ extern "C" int fk_synth_reads(fk_ctx *ctx, uint64_t seed, uint64_t genome_len, u
   return fkx_synth(ctx, seed, genome_len, read_len, err_ppm, first_read, nreads, d_bases);
 }
 
+__global__ __launch_bounds__(256) void k_copy_tile(const uint4 *__restrict__ a, uint4 *__restrict__ b, int64_t n)
+{ const int64_t base = (int64_t) blockIdx.x * 1024 + threadIdx.x;
+  uint4 v[4];
+#pragma unroll
+  for (int u = 0; u < 4; u++)
+    if (base + u * 256 < n) v[u] = a[base + u * 256];
+#pragma unroll
+  for (int u = 0; u < 4; u++)
+    if (base + u * 256 < n) b[base + u * 256] = v[u];
+}
+
+extern "C" int fk_copy_rate(fk_ctx *ctx, void *d_dst, const void *d_src, int64_t nbytes, int reps, double *gbps)
+{ if (ctx == NULL || d_dst == NULL || d_src == NULL || nbytes < 16 || reps < 1 || gbps == NULL
+      || (((uintptr_t) d_dst | (uintptr_t) d_src) & 15) != 0)
+    return (FK_EINVAL);
+  FK_HIP(ctx, hipSetDevice(ctx->device));
+  const int64_t n = nbytes / 16;
+  if ((n + 1023) / 1024 > 0x7fffffffll) return (FK_EINVAL);
+  hipEvent_t e0, e1;
+  FK_HIP(ctx, hipEventCreate(&e0));
+  FK_HIP(ctx, hipEventCreate(&e1));
+  float best = 0.f;
+  for (int r = 0; r <= reps; r++)                         // the first run is not timed
+    { hipEventRecord(e0, ctx->stream);
+      hipLaunchKernelGGL(k_copy_tile, dim3((unsigned) ((n + 1023) / 1024)), dim3(256), 0, ctx->stream, (const uint4 *) d_src,
+                         (uint4 *) d_dst, n);
+      hipEventRecord(e1, ctx->stream);
+      if (hipEventSynchronize(e1) != hipSuccess) { hipEventDestroy(e0); hipEventDestroy(e1); return (FK_EHIP); }
+      float ms = 0.f;
+      hipEventElapsedTime(&ms, e0, e1);
+      if (r > 0 && (best == 0.f || ms < best)) best = ms;
+    }
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  *gbps = 2.0 * (double) (n * 16) / ((double) best * 1e-3) / 1e9;
+  return (FK_OK);
+}
+
 extern "C" int fk_pack_fixed_reads(fk_ctx *ctx, const void *d_bases, int64_t nreads, uint32_t read_len, void *d_codes)
 { if (ctx == NULL || d_bases == NULL || d_codes == NULL || nreads < 0 || read_len == 0) return (FK_EINVAL);
   return fkx_pack_fixed(ctx, d_bases, nreads, read_len, d_codes);

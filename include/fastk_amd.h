@@ -464,6 +464,12 @@ int fk_synth_reads(fk_ctx *ctx, uint64_t seed, uint64_t genome_len, uint32_t rea
    either case; anything else becomes code 0): (nreads * read_len + 3) / 4 bytes at d_codes.  A measurement helper. */
 int fk_pack_fixed_reads(fk_ctx *ctx, const void *d_bases, int64_t nreads, uint32_t read_len, void *d_codes);
 
+/* What a plain streaming copy reaches on this device: d_src -> d_dst (nbytes each, 16-byte aligned) with a uint4 copy
+   kernel (a tile per workgroup, four loads in flight per thread), best of reps runs; *gbps = (read + write) bytes per
+   second / 1e9.  The ceiling the scatter passes are priced against beside the 8 TB/s peak: hipMemcpy device-to-device
+   is 10 % below it on this stack.  A measurement helper. */
+int fk_copy_rate(fk_ctx *ctx, void *d_dst, const void *d_src, int64_t nbytes, int reps, double *gbps);
+
 int   fk_device_alloc(fk_ctx *ctx, int64_t nbytes, void **d_ptr);
 int   fk_device_free(fk_ctx *ctx, void *d_ptr);
 int   fk_copy_to_device(fk_ctx *ctx, void *d_dst, const void *src, int64_t nbytes);

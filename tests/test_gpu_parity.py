@@ -667,6 +667,18 @@ def test_empty_and_degenerate_inputs():
         assert np.array_equal(res.table, exp.table)
 
 
+def test_copy_rate_helper_copies(ctx40):
+    """fk_copy_rate (the copy-kernel ceiling bench.py reports) moves the bytes and returns a rate."""
+    n = 64 << 20
+    a, b = ctx40.alloc(n), ctx40.alloc(n)
+    src = np.arange(n, dtype=np.uint8)
+    a.upload(src)
+    rate = ctx40.copy_rate(b.ptr, a.ptr, n, reps=2)
+    assert rate > 100.0
+    assert np.array_equal(b.download(n), src)
+    a.free(); b.free()
+
+
 def test_device_synth_matches_host_generator(ctx40):
     buf, n = ctx40.synth_reads(99, 50000, 150, 3000, 17, 500)
     got = buf.download(n)
