@@ -459,6 +459,45 @@ def ref_lsd_sort(recs, byte_list, nthreads=4):
     return (src if out == src.ctypes.data else trg).copy()
 
 
+class _RefRange(C.Structure):                  # FastK.h:135-143
+    _fields_ = [("beg", C.c_int), ("end", C.c_int), ("off", C.c_int64), ("khist", C.c_int64 * 256),
+                ("count", C.c_int64 * 0x8000), ("max_inst", C.c_int64), ("byte1", C.c_int)]
+
+
+def ref_weighted_kmer_sort(recs, kmer, nthreads=4):
+    """The REFERENCE's own Weighted_Kmer_Sort (MSDsort.c:536-544 -> msd_sort :308-390 -> radix_sort / shell_sort, with
+    hist_kmers :491-509 called on every run of equal k-mers) on an (n, KMER_BYTES + 2) uint8 array of weighted k-mers.
+    The engine wants its input dealt on the first key byte already (count.c:1520-1539 builds the list that way), so the
+    records are first brought into first-byte order (stable).  Returns (sorted array, histogram int64[0x8000],
+    max_inst): byte 0 of a run's first record comes back as the flag 1 and that record's count as the run's sum
+    (capped at 0x7fff), exactly as the engine leaves them."""
+    global _fkref
+    if _fkref is None:
+        ref_lsd_sort(np.zeros((0, 4), dtype=np.uint8), [0])          # loads the library
+    L = _fkref
+    n, rsize = recs.shape
+    kb = (kmer + 3) // 4
+    assert rsize == kb + 2
+    L.Weighted_Kmer_Sort.restype = None
+    L.Weighted_Kmer_Sort.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.c_int,
+                                     C.POINTER(_RefRange)]
+    for name, val in (("KMER", kmer), ("KMER_BYTES", kb), ("KMER_WORD", rsize), ("DO_PROFILE", 0), ("NTHREADS", nthreads)):
+        C.c_int.in_dll(L, name).value = val
+    order = np.argsort(recs[:, 0], kind="stable")
+    arr = np.zeros((n + 4, rsize), dtype=np.uint8)                  # (slack behind the list)
+    arr[:n] = recs[order]
+    part = (C.c_int64 * 256)(*[int(c) * rsize for c in np.bincount(recs[:, 0], minlength=256)])
+    panels = (_RefRange * nthreads)()
+    if n > 0:
+        L.Weighted_Kmer_Sort(arr.ctypes.data, n, rsize, kb, part, nthreads, panels)
+    hist = np.zeros(0x8000, dtype=np.int64)
+    max_inst = 0
+    for t in range(nthreads):
+        hist += np.ctypeslib.as_array(panels[t].count)
+        max_inst += int(panels[t].max_inst)
+    return arr[:n].copy(), hist, max_inst
+
+
 def have_fkref():
     return os.path.exists(os.path.join(REF_DIR, "libfkref.so"))
 

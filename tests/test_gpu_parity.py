@@ -95,6 +95,30 @@ def test_msd_sort_matches_oracle_msd(ctx40):
     a.free(); b.free()
 
 
+def test_msd_sort_key_order_equals_reference_engine(ctx40):
+    """fk_msd_sort_records against the reference's own Weighted_Kmer_Sort (MSDsort.c:536-544, libfkref.so) on 1.5 M
+    weighted 40-mers with heavy duplication: the same key order (the engine leaves a flag in byte 0 of every run head
+    and the run's sum in its count field, so the comparison is on the key bytes, first byte restored)."""
+    if not orc.have_fkref():
+        pytest.skip("oracle/_ref/libfkref.so not built")
+    rng = np.random.default_rng(99)
+    n, kb = 1500000, 10
+    keys = rng.integers(0, 256, size=(n // 5, kb), dtype=np.uint8)
+    recs = np.zeros((n, kb + 2), dtype=np.uint8)
+    recs[:, :kb] = keys[rng.integers(0, n // 5, size=n)]
+    recs[:, kb] = rng.integers(1, 4, size=n)
+    a = ctx40.alloc(recs.nbytes).upload(recs)
+    b = ctx40.alloc(recs.nbytes)
+    res = ctx40.msd_sort(a.ptr, b.ptr, n, kb + 2, kb)
+    got = a.download(recs.nbytes, ptr=res).reshape(n, kb + 2)
+    ref, hist, _ = orc.ref_weighted_kmer_sort(recs, 40, 8)
+    ref_keys = ref[:, :kb].copy()
+    ref_keys[:, 0] = np.sort(recs[:, 0], kind="stable")
+    assert np.array_equal(got[:, :kb], ref_keys)
+    assert int(hist.sum()) == len(np.unique(recs[:, :kb], axis=0))
+    a.free(); b.free()
+
+
 # ------------------------------------------------------------------------------ stages
 
 @pytest.mark.parametrize("name", ["edge_k40_t1_T4", "synth_illumina_k40_t1_T4",

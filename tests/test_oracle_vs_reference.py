@@ -75,6 +75,51 @@ def test_oracle_lsd_engine_equals_reference_lsd_sort(rsize, n, nbytes, T):
     assert np.array_equal(orc.lsd_sort(recs, order), orc.ref_lsd_sort(recs, order, T))
 
 
+@pytest.mark.parametrize("kmer,n,distinct,T,heavy", [(40, 200000, 50000, 4, False), (40, 30011, 30011, 3, False),
+                                                     (25, 60000, 900, 1, True), (51, 5000, 4000, 4, True), (40, 3, 2, 4, False)])
+def test_oracle_msd_engine_and_counting_equal_reference_weighted_kmer_sort(kmer, n, distinct, T, heavy):
+    """The MSD engine and the counting it drives, unit level: the reference's own Weighted_Kmer_Sort (MSDsort.c:536-544:
+    msd_sort -> radix_sort / shell_sort, hist_kmers on every run of equal k-mers; libfkref.so = MSDsort.c compiled where
+    it lies) against the oracle's restatement (orc_msd_sort + orc_count_sorted) on the same weighted k-mers: same key
+    order, the same summed count in every run's first record, the same histogram and max_inst -- also with runs whose
+    sum passes 0x7fff."""
+    if not orc.have_fkref():
+        pytest.skip("oracle/_ref/libfkref.so not built (needs the reference sources at build time)")
+    rng = np.random.default_rng(kmer * 100000 + n)
+    kb = (kmer + 3) // 4
+    keys = rng.integers(0, 256, size=(distinct, kb), dtype=np.uint8)
+    keys[:, 0] = rng.integers(0, 7, size=distinct) * 37                 # few first bytes: long partitions
+    if kmer & 3:
+        keys[:, kb - 1] &= (0xff << (2 * (4 - (kmer & 3)))) & 0xff       # unused low bits are zero in a real list
+    recs = np.zeros((n, kb + 2), dtype=np.uint8)
+    pick = rng.integers(0, distinct, size=n)
+    if heavy:
+        pick[: n // 2] = pick[0]                                         # one k-mer in half of the records
+    recs[:, :kb] = keys[pick]
+    w = rng.integers(1, 40 if heavy else 5, size=n)
+    recs[:, kb] = w & 0xff
+    recs[:, kb + 1] = w >> 8
+    out, hist, max_inst = orc.ref_weighted_kmer_sort(recs, kmer, T)
+    P = orc.params(kmer)
+    mine = orc.msd_sort(recs, kb)
+    res = orc.count_sorted(P, mine, 1)
+    ref_keys = out[:, :kb].copy()
+    ref_keys[:, 0] = np.sort(recs[:, 0], kind="stable")                  # the engine flags run heads in byte 0
+    assert np.array_equal(ref_keys, mine[:, :kb])
+    heads = np.ones(n, dtype=bool)
+    heads[1:] = (mine[1:, :kb] != mine[:-1, :kb]).any(axis=1)
+    assert (out[heads, 0] == 1).all()
+    ref_counts = out[heads, kb].astype(np.int64) | (out[heads, kb + 1].astype(np.int64) << 8)
+    table = np.asarray(res.table)
+    assert table.shape[0] == int(heads.sum())
+    assert np.array_equal(table[:, :kb], mine[heads, :kb])
+    assert np.array_equal(table[:, kb].astype(np.int64) | (table[:, kb + 1].astype(np.int64) << 8), ref_counts)
+    assert np.array_equal(hist[1:], np.asarray(res.hist, dtype=np.int64)[1:0x8000])
+    assert max_inst == int(res.max_inst)
+    if heavy:
+        assert max_inst > 0
+
+
 def test_scheme_equals_the_reference_trainer(tmp_path):
     """Determine_Scheme restated (orc.scheme: trainer census, refine_tree, assign_pieces with glibc's unseeded
     drand48) against the reference's own DEBUG_SCHEME print-out (oracle/_ref/FastK_scheme: split.c compiled with that
