@@ -959,8 +959,13 @@ extern "C" int fk_copy_rate(fk_ctx *ctx, void *d_dst, const void *d_src, int64_t
     { hipEventRecord(e0, ctx->stream);
       hipLaunchKernelGGL(k_copy_tile, dim3((unsigned) ((n + 1023) / 1024)), dim3(256), 0, ctx->stream, (const uint4 *) d_src,
                          (uint4 *) d_dst, n);
+      const hipError_t le = hipGetLastError();
       hipEventRecord(e1, ctx->stream);
-      if (hipEventSynchronize(e1) != hipSuccess) { hipEventDestroy(e0); hipEventDestroy(e1); return (FK_EHIP); }
+      if (le != hipSuccess || hipEventSynchronize(e1) != hipSuccess)
+        { hipEventDestroy(e0); hipEventDestroy(e1);
+          fk_set_error(ctx, "fk_copy_rate: the copy kernel failed: %s", hipGetErrorString(le));
+          return (FK_EHIP);
+        }
       float ms = 0.f;
       hipEventElapsedTime(&ms, e0, e1);
       if (r > 0 && (best == 0.f || ms < best)) best = ms;
