@@ -419,13 +419,15 @@ __global__ __launch_bounds__(RX_THREADS) void k_rx_chunkscan(const u32 *__restri
 { const int     tid = threadIdx.x;
   const int64_t c0  = (int64_t) blockIdx.x * RX_SC;
   u32 run = 0;
-  for (int j = 0; j < RX_SC; j += 8)
-    { u32 v[8];
+  // 32 loads in flight per thread: the kernel is a chain of round trips to memory (37 workgroups at configs[2]), and
+  // with 8 per round it took 53 us, 196 times a step
+  for (int j = 0; j < RX_SC; j += 32)
+    { u32 v[32];
 #pragma unroll
-      for (int k = 0; k < 8; k++)
+      for (int k = 0; k < 32; k++)
         v[k] = (c0 + j + k < nchunks) ? chunktot[(c0 + j + k) * 256 + tid] : 0u;
 #pragma unroll
-      for (int k = 0; k < 8; k++)
+      for (int k = 0; k < 32; k++)
         if (c0 + j + k < nchunks)
           { chunkpfx[(c0 + j + k) * 256 + tid] = run;
             run += v[k];
