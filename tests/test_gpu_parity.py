@@ -797,6 +797,38 @@ def test_cli_reader_threads_pack_the_text(name, fmt, width, piece, tmp_path):
                 os.remove(tmp_path / f)
 
 
+@pytest.mark.parametrize("name", ["synth_hifi_k40_t4_T8", "edge_k40_t1_T4"])
+def test_cli_several_input_files(name, tmp_path):
+    """FastK_amd a.fasta b.fasta.gz c.fasta (one type per run, io.c; outputs named after the first file, FastK.c:402-405):
+    the reads of a golden case dealt over three files -- two plain ones, which the reader threads pack, around a gzipped
+    one, whose text is parsed on the device -- give the golden's .hist bytes and table."""
+    import gzip, hashlib, os, subprocess
+    case, bases, boff = util.load_case(name)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "fastk_amd", "bin", "FastK_amd")
+    raw = bytes(bases)
+    reads = [raw[boff[i]:boff[i + 1] - 1] for i in range(len(boff) - 1)]
+    cuts = [0, len(reads) // 3, len(reads) // 3 + len(reads) // 5, len(reads)]
+    paths = []
+    for f in range(3):
+        b, o = orc.block_from_reads(reads[cuts[f]:cuts[f + 1]])
+        path = str(tmp_path / ("part%d.fasta" % f))
+        orc.write_fasta(path, b, o, width=70 if f == 2 else 0)
+        if f == 1:
+            with open(path, "rb") as fi, gzip.open(path + ".gz", "wb") as fo:
+                fo.write(fi.read())
+            os.remove(path)
+            path += ".gz"
+        paths.append(path)
+    out = subprocess.run([exe, "-k%d" % case["k"], "-t%d" % case["cutoff"], "-T%d" % case["T"], "-v"] + paths, check=True,
+                         cwd=str(tmp_path), capture_output=True, text=True)
+    exp = case["expected"]
+    assert hashlib.sha256(open(tmp_path / "part0.hist", "rb").read()).hexdigest() == exp["hist_sha256"]
+    t = orc.read_ktab(str(tmp_path / "part0"))
+    assert t["stream_sha256"] == exp["ktab"]["stream_sha256"] and t["nels"] == exp["ktab"]["nels"]
+    assert ("There are %d reads" % len(reads)) in out.stdout + out.stderr
+
+
 def _odd_text(kind, quirks):
     """FASTA / FASTQ text with what real files hold beside acgt: upper and lower case, N runs, IUPAC codes, lines of
     several widths, a quality line that begins with '@'; with quirks also records without bases and no newline at
