@@ -829,6 +829,44 @@ def test_cli_several_input_files(name, tmp_path):
     assert ("There are %d reads" % len(reads)) in out.stdout + out.stderr
 
 
+def test_cli_one_long_record(tmp_path):
+    """A FASTA file that is ONE record of 12 Mbp in 60-base lines (a chromosome, not a read): the reader threads cannot
+    cut it (a piece ends at a record start), the host scanner (-H) cuts it into blocks with K-1 bases of overlap
+    (io.c:557-570), the device parser takes it as text -- same .hist bytes and table, and every 40-mer counted once."""
+    import hashlib, os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "fastk_amd", "bin", "FastK_amd")
+    rng = np.random.default_rng(7)
+    L = 12_000_000
+    seq = np.frombuffer(b"acgt", dtype=np.uint8)[rng.integers(0, 4, size=L)].copy()
+    for at in (1_000_000, 7_777_777):
+        seq[at:at + 500] = ord("N")
+    rows = seq.reshape(-1, 60)
+    text = np.empty((rows.shape[0], 61), dtype=np.uint8)
+    text[:, :60] = rows
+    text[:, 60] = ord("\n")
+    path = str(tmp_path / "chr.fasta")
+    with open(path, "wb") as f:
+        f.write(b">chr1 one record\n")
+        text.tofile(f)
+    seen = {}
+    for tag, extra, env in (("packed", [], {"FASTK_AMD_PIECE": "1048576"}), ("host scanner", ["-H"], {}),
+                            ("device text", [], {"FASTK_AMD_DEVICE_TEXT": "1"})):
+        subprocess.run([exe, "-k40", "-t1", "-T4", "-N" + str(tmp_path / "out")] + extra + [path], check=True,
+                       cwd=str(tmp_path), env=dict(os.environ, **env), capture_output=True, text=True)
+        hist = open(tmp_path / "out.hist", "rb").read()
+        t = orc.read_ktab(str(tmp_path / "out"))
+        seen[tag] = (hashlib.sha256(hist).hexdigest(), t["stream_sha256"], t["nels"])
+        h = orc.read_hist(str(tmp_path / "out.hist"))
+        for f in os.listdir(tmp_path):
+            if f.startswith("out") or f.startswith(".out"):
+                os.remove(tmp_path / f)
+    assert seen["packed"] == seen["host scanner"] == seen["device text"], seen
+    inst = (1_000_000 - 39) + (7_777_777 - 1_000_500 - 39) + (L - 7_778_277 - 39)
+    counts = np.asarray(h["hist"], dtype=np.int64)                 # counts[i] = k-mers that occur low + i times
+    assert int((counts * (h["low"] + np.arange(len(counts)))).sum()) == inst
+
+
 def _odd_text(kind, quirks):
     """FASTA / FASTQ text with what real files hold beside acgt: upper and lower case, N runs, IUPAC codes, lines of
     several widths, a quality line that begins with '@'; with quirks also records without bases and no newline at
