@@ -42,6 +42,23 @@ __global__ __launch_bounds__(256) void k_copy_tile_nt(const uint4 *__restrict__ 
       }
 }
 
+__global__ __launch_bounds__(256) void k_fill_tile(uint4 *__restrict__ b, size_t n, unsigned x)
+{ const size_t base = (size_t) blockIdx.x * 1024 + threadIdx.x;
+  const uint4 v = make_uint4(x, x + 1, x + 2, x + 3);
+#pragma unroll
+  for (int u = 0; u < 4; u++)
+    if (base + (size_t) u * 256 < n) b[base + (size_t) u * 256] = v;
+}
+
+__global__ __launch_bounds__(256) void k_read_tile(const uint4 *__restrict__ a, size_t n, unsigned *sink)
+{ const size_t base = (size_t) blockIdx.x * 1024 + threadIdx.x;
+  unsigned acc = 0;
+#pragma unroll
+  for (int u = 0; u < 4; u++)
+    if (base + (size_t) u * 256 < n) { const uint4 v = a[base + (size_t) u * 256]; acc ^= v.x ^ v.y ^ v.z ^ v.w; }
+  if (acc == 0x12345678u) *sink = acc;
+}
+
 template <typename F> static void timeit(const char *what, size_t bytes, F f)
 { hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
@@ -70,5 +87,9 @@ int main()
   timeit("one tile per workgroup, 8 x uint4 per thread", bytes, [&]() { hipLaunchKernelGGL(k_copy_tile<8>, dim3((unsigned) ((n + 2047) / 2048)), dim3(256), 0, 0, a, b, n); });
   timeit("the same, non-temporal, 4 x", bytes, [&]() { hipLaunchKernelGGL(k_copy_tile_nt<4>, dim3((unsigned) ((n + 1023) / 1024)), dim3(256), 0, 0, a, b, n); });
   timeit("the same, non-temporal, 8 x", bytes, [&]() { hipLaunchKernelGGL(k_copy_tile_nt<8>, dim3((unsigned) ((n + 2047) / 2048)), dim3(256), 0, 0, a, b, n); });
+  // one direction only (the rate printed counts 2 x bytes: halve it)
+  timeit("write only (fill), x2 convention", bytes, [&]() { hipLaunchKernelGGL(k_fill_tile, dim3((unsigned) ((n + 1023) / 1024)), dim3(256), 0, 0, b, n, 7u); });
+  unsigned *sink; hipMalloc((void **) &sink, 4);
+  timeit("read only, x2 convention", bytes, [&]() { hipLaunchKernelGGL(k_read_tile, dim3((unsigned) ((n + 1023) / 1024)), dim3(256), 0, 0, a, n, sink); });
   return 0;
 }
