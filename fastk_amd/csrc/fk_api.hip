@@ -334,7 +334,7 @@ extern "C" int fk_create(const fk_params *p, fk_ctx **out)
   if (ctx->prm.hbm_budget > 0)
     // a quarter of the budget is left for what is alive while a bucket is counted (two read
     // buffers, a chunk's split output, the bucket's records and weighted k-mers, the growing table)
-    // (never below half the budget: a budget under 512 MB used to make this negative, which slab_alloc reads as
+    // (never below half the budget: a budget under 512 MB used to make this negative, which fkx_slab_alloc reads as
     // "no limit" -- and then the first slab alone was 8 GB)
     ctx->spill_limit = std::max<int64_t>(ctx->prm.hbm_budget - std::max<int64_t>(ctx->prm.hbm_budget / 4, 256ll << 20),
                                          std::max<int64_t>(ctx->prm.hbm_budget / 2, 1));
@@ -348,15 +348,11 @@ extern "C" int fk_create(const fk_params *p, fk_ctx **out)
   return (FK_OK);
 }
 
-static void free_chunk(fk_ctx *ctx, fk_chunk *c);
-static int  flush_join(fk_ctx *ctx);
-static void rewind_slabs(fk_ctx *ctx);
-
 extern "C" void fk_destroy(fk_ctx *ctx)
 { if (ctx == NULL)
     return;
   hipSetDevice(ctx->device);
-  (void) flush_join(ctx);
+  (void) fkx_flush_join(ctx);
   if (ctx->copy_stream != NULL)
     hipStreamSynchronize(ctx->copy_stream);
   if (ctx->stream != NULL)
@@ -391,7 +387,7 @@ extern "C" void fk_destroy(fk_ctx *ctx)
   if (ctx->own_stream && ctx->stream != NULL)
     hipStreamDestroy(ctx->stream);
   for (int i = 0; i < ctx->nchunks; i++)
-    free_chunk(ctx, &ctx->chunks[i]);
+    fkx_free_chunk(ctx, &ctx->chunks[i]);
   free(ctx->chunks);
   for (int i = 0; i < ctx->nslabs; i++)
     hipFree(ctx->slabs[i].ptr);
@@ -422,13 +418,13 @@ extern "C" void fk_destroy(fk_ctx *ctx)
 extern "C" int fk_release_device(fk_ctx *ctx, int keep_table)
 { if (ctx == NULL) return (FK_EINVAL);
   FK_HIP(ctx, hipSetDevice(ctx->device));
-  (void) flush_join(ctx);
+  (void) fkx_flush_join(ctx);
   if (ctx->copy_stream != NULL)
     FK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
   if (ctx->stream != NULL)
     FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   for (int i = 0; i < ctx->nchunks; i++)
-    free_chunk(ctx, &ctx->chunks[i]);
+    fkx_free_chunk(ctx, &ctx->chunks[i]);
   ctx->nchunks = 0;
   for (int i = 0; i < ctx->nslabs; i++)
     hipFree(ctx->slabs[i].ptr);
@@ -466,264 +462,6 @@ extern "C" int fk_release_device(fk_ctx *ctx, int keep_table)
       ctx->last_ntab = 0;
     }
   return (FK_OK);
-}
-
-// lower bounds of the first key byte in a sorted device table: bounds[b] = first record whose byte 0 is >= b
-__global__ __launch_bounds__(256) void k_first_byte_bounds(const unsigned char *__restrict__ t, int64_t n, int stride,
-                                                           int64_t *__restrict__ bounds)
-{ const int b = threadIdx.x;
-  int64_t lo = 0, hi = n;
-  while (lo < hi)
-    { const int64_t mid = (lo + hi) >> 1;
-      if (t[mid * stride] < b) lo = mid + 1; else hi = mid;
-    }
-  bounds[b] = lo;
-  if (b == 0) bounds[256] = n;
-}
-
-static double fk_wall(void)
-{ struct timespec ts;
-  clock_gettime(CLOCK_MONOTONIC, &ts);
-  return ((double) ts.tv_sec + 1e-9 * (double) ts.tv_nsec);
-}
-
-// ends[p] = 1 + the index of the last record whose first ib key bytes spell p (ends zeroed before: 0 = no such record)
-__global__ __launch_bounds__(256) void k_prefix_ends(const unsigned char *__restrict__ t, int64_t n, int stride, int ib,
-                                                     int64_t *__restrict__ ends)
-{ const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
-  if (i >= n)
-    return;
-  u32 a = 0, b = 0;
-  for (int j = 0; j < ib; j++)
-    { a = (a << 8) | t[i * stride + j];
-      if (i + 1 < n) b = (b << 8) | t[(i + 1) * stride + j];
-    }
-  if (i + 1 == n || a != b)
-    ends[a] = i + 1;
-}
-
-// cnt table records -> the bytes they take in a .ktab part file (table.c:162-342): the k-mer without its first ib bytes,
-// then the count; pw = kb - ib + 2 bytes each, four output bytes a thread
-__global__ __launch_bounds__(256) void k_ktab_strip(const unsigned char *__restrict__ t, int64_t cnt, int stride, int ib, int kb,
-                                                    unsigned char *__restrict__ out)
-{ const int pw = kb - ib + 2;
-  const int64_t o = ((int64_t) blockIdx.x * 256 + threadIdx.x) * 4, total = cnt * pw;
-  if (o >= total)
-    return;
-  int64_t i = o / pw;
-  int     j = (int) (o - i * pw);
-  u32 v = 0;
-#pragma unroll
-  for (int q = 0; q < 4; q++)
-    { if (o + q < total)
-        { const unsigned char c = (j < kb - ib) ? t[i * stride + ib + j] : t[i * stride + stride - 2 + (j - (kb - ib))];
-          v |= (u32) c << (8 * q);
-        }
-      if (++j == pw) { j = 0; i += 1; }
-    }
-  *(u32 *) (out + o) = v;
-}
-
-#define KTAB_PIECE_BYTES (16ll << 20)       // of table records per piece of a part writer
-
-static int64_t ktab_piece_bytes(const fk_ctx *ctx, int ib)      // bytes of a stripped piece, rounded
-{ const int64_t piece = std::max<int64_t>(KTAB_PIECE_BYTES / ctx->wid.kmer_stride, 1);
-  return ((piece * (ctx->wid.kmer_word - ib) + 255) & ~255ll);
-}
-
-static int ktab_staging(fk_ctx *ctx, int nthreads, int ib)
-{ const int64_t need = ktab_piece_bytes(ctx, ib) * 2 * nthreads;
-  for (int i = 0; i < 4; i++)
-    if (ctx->wstream[i] == NULL)
-      FK_HIP(ctx, hipStreamCreateWithFlags(&ctx->wstream[i], hipStreamNonBlocking));
-  if (ctx->wstage_cap >= need)
-    return (FK_OK);
-  if (ctx->h_wstage) hipHostFree(ctx->h_wstage);
-  ctx->h_wstage = NULL;
-  ctx->wstage_cap = 0;
-  if (hipHostMalloc((void **) &ctx->h_wstage, (size_t) need, hipHostMallocDefault) != hipSuccess)
-    { (void) hipGetLastError();
-      fk_set_error(ctx, "fk_write_ktab_device: out of host memory for the staging of %d writers", nthreads);
-      return (FK_ENOMEM);
-    }
-  ctx->wstage_cap = need;
-  return (FK_OK);
-}
-
-// The prefix index of the table in HBM (n entries): ctx->ktab_ends[p] = entries whose first ib key bytes spell p.
-// The pass needs npre * 8 bytes of device scratch: the read buffer when it is large enough (its reads are counted),
-// else a buffer of its own.
-static int ktab_prefix_index(fk_ctx *ctx, int64_t n, int ib)
-{ int64_t npre = 1;
-  for (int i = 0; i < ib; i++) npre *= 256;
-  free(ctx->ktab_ends);
-  ctx->ktab_ends = (int64_t *) calloc((size_t) npre, 8);
-  ctx->ktab_ends_ntab = -1;
-  if (ctx->ktab_ends == NULL)
-    return (FK_ENOMEM);
-  for (int b = 0; b <= 256; b++)
-    ctx->ktab_first[b] = 0;
-  if (n > 0)
-    { int64_t *d_ends = NULL;
-      bool own = false;
-      if (ctx->d_reads != NULL && ctx->reads_cap >= npre * 8 && ctx->reads_len == 0 && ctx->flush_thread == NULL)
-        d_ends = (int64_t *) ctx->d_reads;
-      else
-        { FK_HIP(ctx, hipMalloc((void **) &d_ends, (size_t) npre * 8));
-          own = true;
-        }
-      hipError_t e = hipMemsetAsync(d_ends, 0, (size_t) npre * 8, ctx->stream);
-      if (e == hipSuccess)
-        { int64_t *d_b = (int64_t *) ctx->d_scratch;
-          hipLaunchKernelGGL(k_first_byte_bounds, dim3(1), dim3(256), 0, ctx->stream, (const unsigned char *) ctx->last_table, n,
-                             ctx->wid.kmer_stride, d_b);
-          e = hipMemcpyAsync(ctx->ktab_first, d_b, 257 * 8, hipMemcpyDeviceToHost, ctx->stream);
-        }
-      if (e == hipSuccess)
-        { hipLaunchKernelGGL(k_prefix_ends, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                             (const unsigned char *) ctx->last_table, n, ctx->wid.kmer_stride, ib, d_ends);
-          e = hipGetLastError();
-        }
-      if (e == hipSuccess)
-        e = hipMemcpyAsync(ctx->ktab_ends, d_ends, (size_t) npre * 8, hipMemcpyDeviceToHost, ctx->stream);
-      if (e == hipSuccess)
-        e = hipStreamSynchronize(ctx->stream);
-      if (own)
-        hipFree(d_ends);
-      if (e != hipSuccess)
-        { fk_set_error(ctx, "the prefix pass over the table failed: %s", hipGetErrorString(e));
-          return (FK_EHIP);
-        }
-      int64_t last = 0;                                                   // ends -> entries per prefix
-      for (int64_t p = 0; p < npre; p++)
-        if (ctx->ktab_ends[p] > 0)
-          { const int64_t end = ctx->ktab_ends[p];
-            ctx->ktab_ends[p] = end - last;
-            last = end;
-          }
-    }
-  ctx->ktab_ends_ntab = n;
-  ctx->ktab_ends_ib = ib;
-  return (FK_OK);
-}
-
-/* <root>.ktab + hidden parts straight from the sorted table fk_finish_device left in HBM.  The device makes the file
-   bytes: one pass finds where every ib-byte prefix ends (the index of the stub file), and every part has a writer
-   thread with a stream of its own that strips its range piece by piece (k_ktab_strip, which stores into one of two
-   pinned host buffers) and hands the piece to write() as it is -- the next piece is made and crosses PCIe meanwhile.  The 36 GB
-   table of a human-size run never exists in host memory and no host core touches an entry.
-   The files are those of fk_write_ktab (table.c:162-342,485-498). */
-extern "C" int fk_write_ktab_device(fk_ctx *ctx, const fk_result *res, int nthreads, const char *dir, const char *root)
-{ if (ctx == NULL || res == NULL || dir == NULL || root == NULL || nthreads < 1 || nthreads > 256) return (FK_EINVAL);
-  const fk_widths &w = ctx->wid;
-  const int cutoff = ctx->prm.table_cutoff, kmer = ctx->prm.kmer;
-  if (cutoff < 1)
-    { fk_set_error(ctx, "fk_write_ktab_device: no table was asked for (table_cutoff 0)");
-      return (FK_EINVAL);
-    }
-  const int64_t n = res->ntable;
-  if (n > 0 && (ctx->last_table == NULL || ctx->last_ntab != n))
-    { fk_set_error(ctx, "fk_write_ktab_device: the table of this result is not in HBM any more");
-      return (FK_ESTATE);
-    }
-  FK_HIP(ctx, hipSetDevice(ctx->device));
-  const double tw0 = fk_wall();
-  std::vector<int> split((size_t) nthreads + 1);
-  int rc = fk_ktab_split(res->wfirst, kmer, nthreads, split.data());
-  if (rc != FK_OK) return (rc);
-  const int ib = fk_ktab_idx_bytes(kmer, n);
-  const int KW = w.kmer_word, ST = w.kmer_stride, pw = KW - ib;
-  int64_t npre = 1;
-  for (int i = 0; i < ib; i++) npre *= 256;
-  std::vector<int64_t> pc((size_t) npre, 0);
-  int64_t hb[257];
-  const unsigned char *table = (const unsigned char *) ctx->last_table;
-  const int64_t piece = std::max<int64_t>(KTAB_PIECE_BYTES / ST, 1);      // records per piece
-  const int64_t pbytes = ktab_piece_bytes(ctx, ib);                       // bytes of a stripped piece (a multiple of 4)
-  // Nothing is allocated or asked of the device here when fk_finish_device ran before (prefix index, first-byte
-  // bounds, pinned staging): fk_release_device may be returning the rest of the context's HBM in another thread, every
-  // hipFree of which holds up the other HIP calls of the process, and a hipMalloc that follows a large hipFree waits
-  // until the driver has wiped what was freed (seconds; tools/probe/malloc_probe.cpp).  The strip kernels store into
-  // pinned host memory.
-  if (ctx->ktab_ends == NULL || ctx->ktab_ends_ntab != n || ctx->ktab_ends_ib != ib)
-    { if ((rc = ktab_prefix_index(ctx, n, ib)) != FK_OK)
-        return (rc);
-    }
-  memcpy(pc.data(), ctx->ktab_ends, (size_t) npre * 8);
-  memcpy(hb, ctx->ktab_first, sizeof(hb));
-  if (n > 0 && (rc = ktab_staging(ctx, nthreads, ib)) != FK_OK)
-    return (rc);
-  unsigned char *h_stage = ctx->h_wstage;
-  const double tw1 = fk_wall();
-  std::vector<int> prc((size_t) nthreads, FK_OK);
-  auto write_part = [&](int t)
-    { const int64_t lo = hb[split[t]], hi = hb[split[t + 1]], cnt = hi - lo;
-      char pname[4096];
-      snprintf(pname, sizeof(pname), "%s/.%s.ktab.%d", dir, root, t + 1);
-      int fd = open(pname, O_WRONLY | O_CREAT | O_TRUNC, 0644);
-      if (fd < 0) { prc[t] = FK_EINVAL; return; }
-      hipStream_t st = ctx->wstream[t % 4];
-      hipEvent_t  ev[2] = { NULL, NULL };
-      bool ok = (write(fd, &kmer, 4) == 4 && write(fd, &cnt, 8) == 8);
-      if (ok && cnt > 0)
-        ok = (hipSetDevice(ctx->device) == hipSuccess
-              && hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) == hipSuccess
-              && hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) == hipSuccess);
-      unsigned char *pin[2] = { h_stage + pbytes * (2 * t), h_stage + pbytes * (2 * t + 1) };
-      auto fetch = [&](int64_t x, int which) -> bool
-        { const int64_t m = std::min(hi, x + piece) - x;
-          const int64_t words = (m * pw + 3) / 4;
-          hipLaunchKernelGGL(k_ktab_strip, dim3((unsigned) ((words + 255) / 256)), dim3(256), 0, st, table + x * ST, m, ST, ib,
-                             (int) w.kmer_bytes, pin[which]);                // stored across PCIe as it is made
-          return (hipGetLastError() == hipSuccess && hipEventRecord(ev[which], st) == hipSuccess);
-        };
-      int which = 0;
-      double t_wait = 0., t_write = 0.;
-      if (ok && lo < hi)
-        ok = fetch(lo, 0);
-      for (int64_t x = lo; ok && x < hi; x += piece, which ^= 1)
-        { const int64_t e = std::min(hi, x + piece);
-          if (e < hi)
-            ok = fetch(e, which ^ 1);                       // the next piece is made and travels while this one is written
-          const auto w0 = std::chrono::steady_clock::now();
-          if (!ok || hipEventSynchronize(ev[which]) != hipSuccess) { ok = false; break; }
-          const auto w1 = std::chrono::steady_clock::now();
-          t_wait += std::chrono::duration<double>(w1 - w0).count();
-          const unsigned char *q = pin[which];
-          size_t left = (size_t) (e - x) * pw;
-          while (left > 0)
-            { const ssize_t wr = write(fd, q, left);
-              if (wr <= 0) { ok = false; break; }
-              q += wr; left -= (size_t) wr;
-            }
-          t_write += std::chrono::duration<double>(std::chrono::steady_clock::now() - w1).count();
-        }
-      if (ctx->dbg_verbose)
-        fprintf(stderr, "  .ktab part %d: %lld entries; waited %.3f s for the device, %.3f s in write()\n", t + 1, (long long) cnt,
-                t_wait, t_write);
-      for (int i = 0; i < 2; i++)
-        if (ev[i]) hipEventDestroy(ev[i]);
-      if (close(fd) != 0) ok = false;
-      if (!ok) prc[t] = FK_EINVAL;
-    };
-  { std::vector<std::thread> th;
-    for (int t = 1; t < nthreads; t++)
-      th.emplace_back(write_part, t);
-    write_part(0);
-    for (auto &x : th)
-      x.join();
-  }
-  const double tw2 = fk_wall();
-  for (int t = 0; t < nthreads; t++)
-    if (prc[t] != FK_OK)
-      { fk_set_error(ctx, "Cannot write to %s/.%s.ktab.%d.  Enough disk space?", dir, root, t + 1);
-        return (prc[t]);
-      }
-  rc = fk_write_ktab_stub(kmer, nthreads, cutoff, ib, pc.data(), dir, root);
-  if (ctx->dbg_verbose)
-    fprintf(stderr, "  fk_write_ktab_device: set-up %.3f s, part writers %.3f s, stub %.3f s\n", tw1 - tw0, tw2 - tw1,
-            fk_wall() - tw2);
-  return (rc);
 }
 
 /* exact_parts only: the reference's -M in bytes (FastK.c:235,291: 12e9 by default, <int> x 1e9) and, when the caller
@@ -931,48 +669,6 @@ extern "C" int fk_synth_reads(fk_ctx *ctx, uint64_t seed, uint64_t genome_len, u
                               uint32_t err_ppm, uint64_t first_read, int64_t nreads, void *d_bases)
 { if (ctx == NULL || d_bases == NULL || nreads < 0) return (FK_EINVAL);
   return fkx_synth(ctx, seed, genome_len, read_len, err_ppm, first_read, nreads, d_bases);
-}
-
-__global__ __launch_bounds__(256) void k_copy_tile(const uint4 *__restrict__ a, uint4 *__restrict__ b, int64_t n)
-{ const int64_t base = (int64_t) blockIdx.x * 1024 + threadIdx.x;
-  uint4 v[4];
-#pragma unroll
-  for (int u = 0; u < 4; u++)
-    if (base + u * 256 < n) v[u] = a[base + u * 256];
-#pragma unroll
-  for (int u = 0; u < 4; u++)
-    if (base + u * 256 < n) b[base + u * 256] = v[u];
-}
-
-extern "C" int fk_copy_rate(fk_ctx *ctx, void *d_dst, const void *d_src, int64_t nbytes, int reps, double *gbps)
-{ if (ctx == NULL || d_dst == NULL || d_src == NULL || nbytes < 16 || reps < 1 || gbps == NULL
-      || (((uintptr_t) d_dst | (uintptr_t) d_src) & 15) != 0)
-    return (FK_EINVAL);
-  FK_HIP(ctx, hipSetDevice(ctx->device));
-  const int64_t n = nbytes / 16;
-  if ((n + 1023) / 1024 > 0x7fffffffll) return (FK_EINVAL);
-  hipEvent_t e0, e1;
-  FK_HIP(ctx, hipEventCreate(&e0));
-  FK_HIP(ctx, hipEventCreate(&e1));
-  float best = 0.f;
-  for (int r = 0; r <= reps; r++)                         // the first run is not timed
-    { hipEventRecord(e0, ctx->stream);
-      hipLaunchKernelGGL(k_copy_tile, dim3((unsigned) ((n + 1023) / 1024)), dim3(256), 0, ctx->stream, (const uint4 *) d_src,
-                         (uint4 *) d_dst, n);
-      const hipError_t le = hipGetLastError();
-      hipEventRecord(e1, ctx->stream);
-      if (le != hipSuccess || hipEventSynchronize(e1) != hipSuccess)
-        { hipEventDestroy(e0); hipEventDestroy(e1);
-          fk_set_error(ctx, "fk_copy_rate: the copy kernel failed: %s", hipGetErrorString(le));
-          return (FK_EHIP);
-        }
-      float ms = 0.f;
-      hipEventElapsedTime(&ms, e0, e1);
-      if (r > 0 && (best == 0.f || ms < best)) best = ms;
-    }
-  hipEventDestroy(e0); hipEventDestroy(e1);
-  *gbps = 2.0 * (double) (n * 16) / ((double) best * 1e-3) / 1e9;
-  return (FK_OK);
 }
 
 extern "C" int fk_pack_fixed_reads(fk_ctx *ctx, const void *d_bases, int64_t nreads, uint32_t read_len, void *d_codes)
@@ -1184,632 +880,6 @@ extern "C" int fk_merge_tables(fk_ctx *ctx, const uint8_t *records, int64_t n, i
   res->table = ctx->h_table;
   return (FK_OK);
 }
-
-// ---- streaming interface ------------------------------------------------------------------------
-// stream that carries the copies into the read buffer: in chunked mode a stream of its own, so that
-// they overlap the split of the previous chunk (which runs on ctx->stream)
-static inline hipStream_t push_stream(fk_ctx *ctx)
-{ return (ctx->chunk_bytes > 0 ? ctx->copy_stream : ctx->stream); }
-
-static int reserve_reads(fk_ctx *ctx, int64_t extra)
-{ const int64_t need = ctx->reads_len + extra + 64;
-  if (need <= ctx->reads_cap)
-    return (FK_OK);
-  hipStream_t ps = push_stream(ctx);
-  int64_t ncap = std::max<int64_t>(need, ctx->reads_cap * 2);
-  ncap = std::max<int64_t>(ncap, 64ll << 20);
-  if (ctx->chunk_bytes > 0)                      // a chunk's worth at once: no re-allocation while it fills
-    ncap = std::max<int64_t>(ncap, ctx->chunk_bytes + ctx->chunk_bytes / 8 + (64ll << 20));
-  char *nbuf = NULL;
-  FK_HIP(ctx, hipMalloc((void **) &nbuf, (size_t) ncap));
-  if (ctx->d_reads != NULL)
-    { FK_HIP(ctx, hipStreamSynchronize(ctx->stream));       // device-side pushes write through this one
-      if (ctx->reads_len > 0)
-        FK_HIP(ctx, hipMemcpyAsync(nbuf, ctx->d_reads, (size_t) ctx->reads_len, hipMemcpyDeviceToDevice, ps));
-      FK_HIP(ctx, hipStreamSynchronize(ps));
-    }
-  if (ctx->d_reads != NULL)
-    FK_HIP(ctx, hipFree(ctx->d_reads));
-  ctx->d_reads = nbuf;
-  ctx->reads_cap = ncap;
-  return (FK_OK);
-}
-
-// Pinned host buffer for a spilled chunk: one per chunk, kept in the context and used again by the next
-// run (hipHostMalloc moves ~15 GB/s, slower than the spill copy itself).
-static int spill_acquire(fk_ctx *ctx, int64_t bytes, int *slot)
-{ int best = -1;
-  for (int i = 0; i < ctx->nspill; i++)
-    if (!ctx->spill_buf[i].in_use && ctx->spill_buf[i].cap >= bytes
-        && (best < 0 || ctx->spill_buf[i].cap < ctx->spill_buf[best].cap))
-      best = i;
-  if (best < 0)
-    { for (int i = 0; i < ctx->nspill && best < 0; i++)      // an idle one that is too small: replace it
-        if (!ctx->spill_buf[i].in_use)
-          { fkx_pinned_free(ctx->spill_buf[i].ptr);
-            ctx->spill_buf[i].ptr = NULL;
-            ctx->spill_buf[i].cap = 0;
-            best = i;
-          }
-      if (best < 0)
-        { if (ctx->nspill == ctx->spill_cap)
-            { ctx->spill_cap = ctx->spill_cap * 2 + 16;
-              ctx->spill_buf = (fk_spill_buf *) realloc(ctx->spill_buf, sizeof(fk_spill_buf) * (size_t) ctx->spill_cap);
-              if (ctx->spill_buf == NULL) { ctx->nspill = ctx->spill_cap = 0; return (FK_ENOMEM); }
-            }
-          best = ctx->nspill++;
-          ctx->spill_buf[best].ptr = NULL;
-          ctx->spill_buf[best].cap = 0;
-        }
-      const int64_t want = bytes + bytes / 16 + 4096;
-      if (fkx_pinned_alloc(&ctx->spill_buf[best].ptr, want) != FK_OK)
-        { ctx->spill_buf[best].ptr = NULL;
-          return (FK_ENOMEM);
-        }
-      ctx->spill_buf[best].cap = want;
-    }
-  ctx->spill_buf[best].in_use = 1;
-  *slot = best;
-  return (FK_OK);
-}
-
-static void free_chunk(fk_ctx *ctx, fk_chunk *c)
-{ if (c->on_host && c->total > 0)
-    ctx->spill_buf[c->spill_slot].in_use = 0;
-  c->total = 0;                        // (HBM runs live in the slabs, which are rewound as a whole)
-}
-
-static void rewind_slabs(fk_ctx *ctx)
-{ for (int i = 0; i < ctx->nslabs; i++)
-    ctx->slabs[i].used = 0;
-  ctx->chunk_hbm_bytes = 0;
-}
-
-#define FK_SLAB_BYTES (8ll << 30)
-
-// room for `bytes` of records in the HBM store; NULL when that would exceed spill_limit (or HBM)
-static void *slab_alloc(fk_ctx *ctx, int64_t bytes)
-{ bytes = (bytes + 255) & ~255ll;
-  for (int i = 0; i < ctx->nslabs; i++)
-    if (ctx->slabs[i].cap - ctx->slabs[i].used >= bytes)
-      { void *p = ctx->slabs[i].ptr + ctx->slabs[i].used;
-        ctx->slabs[i].used += bytes;
-        ctx->chunk_hbm_bytes += bytes;
-        return (p);
-      }
-  int64_t held = 0;
-  for (int i = 0; i < ctx->nslabs; i++)
-    held += ctx->slabs[i].cap;
-  int64_t cap = std::max<int64_t>(FK_SLAB_BYTES, bytes);
-  if (ctx->spill_limit > 0 && held + cap > ctx->spill_limit)
-    cap = std::max<int64_t>(ctx->spill_limit - held, 0);        // the last slab may be smaller
-  if (cap < bytes)
-    return (NULL);
-  if (ctx->nslabs == ctx->slabs_cap)
-    { ctx->slabs_cap = ctx->slabs_cap * 2 + 16;
-      ctx->slabs = (fk_slab *) realloc(ctx->slabs, sizeof(fk_slab) * (size_t) ctx->slabs_cap);
-      if (ctx->slabs == NULL) { ctx->nslabs = ctx->slabs_cap = 0; return (NULL); }
-    }
-  char *p = NULL;
-  if (hipMalloc((void **) &p, (size_t) cap) != hipSuccess)
-    { (void) hipGetLastError();
-      return (NULL);
-    }
-  fk_slab *sl = &ctx->slabs[ctx->nslabs++];
-  sl->ptr = p; sl->cap = cap; sl->used = bytes;
-  ctx->chunk_hbm_bytes += bytes;
-  return (p);
-}
-
-// Split `len` bytes of reads at `buf` into super-mers grouped by bucket and keep those (compacted)
-// as a chunk: with hbm_budget set, the ASCII reads never have to be resident as a whole.  Runs on
-// ctx->stream; called by the flush helper thread or, with no helper running, by the pushing thread.
-static int flush_buffer(fk_ctx *ctx, const char *buf, int64_t len)
-{ const int stride = ctx->wid.smer_stride;
-  hipStream_t s = ctx->stream;
-  if (len == 0)
-    return (FK_OK);
-  void   *out = NULL;
-  int64_t ns = 0, ni = 0, bc[256], bo[256];
-  const auto tc0 = std::chrono::steady_clock::now();
-  int rc = fkx_split_fast(ctx, buf, len, &out, &ns, &ni, bc, bo);
-  if (rc != FK_OK)
-    return (rc);
-  const auto tc1 = std::chrono::steady_clock::now();
-  ctx->chunk_ninst += ni;
-  if (ns == 0)
-    return (FK_OK);
-  if (ctx->nchunks == ctx->chunks_cap)
-    { ctx->chunks_cap = ctx->chunks_cap * 2 + 16;
-      ctx->chunks = (fk_chunk *) realloc(ctx->chunks, sizeof(fk_chunk) * (size_t) ctx->chunks_cap);
-      if (ctx->chunks == NULL) { ctx->nchunks = ctx->chunks_cap = 0; return (FK_ENOMEM); }
-    }
-  fk_chunk *c = &ctx->chunks[ctx->nchunks];
-  memset(c, 0, sizeof(*c));
-  if (ctx->nchunks == 0)
-    ctx->spilled_bytes = 0;
-  // the records stay in HBM (slab store) up to spill_limit; beyond that a chunk goes to pinned host
-  // memory as a whole and comes back bucket by bucket when its buckets are counted
-  const int64_t bytes = ns * stride;
-  for (int b = 0; b < ctx->prm.nbuckets; b++)
-    { c->cnt[b] = bc[b];
-      c->run[b] = NULL;
-    }
-  { int b = 0;
-    for (; b < ctx->prm.nbuckets; b++)
-      if (bc[b] > 0 && (c->run[b] = slab_alloc(ctx, bc[b] * stride)) == NULL)
-        break;
-    c->on_host = (b < ctx->prm.nbuckets);
-  }
-  if (c->on_host)
-    { if (spill_acquire(ctx, bytes, &c->spill_slot) != FK_OK)
-        { fk_set_error(ctx, "out of host memory: cannot spill %lld super-mer records of a chunk", (long long) ns);
-          return (FK_ENOMEM);
-        }
-      // (slab room taken for the first buckets of this chunk before the store ran out stays unused)
-      char *h = (char *) ctx->spill_buf[c->spill_slot].ptr;
-      int64_t run = 0;
-      for (int b = 0; b < ctx->prm.nbuckets; b++)
-        { c->run[b] = h + run * stride;
-          run += bc[b];
-        }
-      ctx->spilled_bytes += bytes;
-    }
-  int64_t run = 0;
-  for (int b = 0; b < ctx->prm.nbuckets; b++)
-    { if (bc[b] > 0)
-        FK_HIP(ctx, hipMemcpyAsync(c->run[b], (char *) out + bo[b] * stride, (size_t) (bc[b] * stride),
-                                   c->on_host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, s));
-      run += bc[b];
-    }
-  c->total = run;
-  ctx->nchunks += 1;
-  const auto tc2 = std::chrono::steady_clock::now();
-  FK_HIP(ctx, hipStreamSynchronize(s));
-  if (ctx->dbg_verbose)
-    { const auto tc3 = std::chrono::steady_clock::now();
-      fprintf(stderr, "  chunk %d: %lld bytes of reads -> %lld records%s; split %.1f ms, allocation + copies issued %.1f ms, "
-                      "copies done %.1f ms\n", ctx->nchunks - 1, (long long) len, (long long) ns, c->on_host ? " (host)" : "",
-              std::chrono::duration<double, std::milli>(tc1 - tc0).count(),
-              std::chrono::duration<double, std::milli>(tc2 - tc1).count(),
-              std::chrono::duration<double, std::milli>(tc3 - tc2).count());
-    }
-  return (FK_OK);
-}
-
-// Wait for the flush helper, if one is running; returns its result.
-static int flush_join(fk_ctx *ctx)
-{ if (ctx->flush_thread == NULL)
-    return (FK_OK);
-  std::thread *t = (std::thread *) ctx->flush_thread;
-  t->join();
-  delete t;
-  ctx->flush_thread = NULL;
-  if (ctx->flush_rc != FK_OK)
-    memcpy(ctx->err, ctx->flush_err, sizeof(ctx->err));
-  return (ctx->flush_rc);
-}
-
-// The reads pushed so far become a chunk.  Called with the push lock held.
-//   async: the copies into the buffer were issued on copy_stream (fk_push_block, chunked mode) --
-//          the buffer goes to a helper thread that waits for them and splits it, and the caller goes
-//          on copying into the other buffer;
-//   else:  the split runs here and now.
-//   carry: the text pushes (fk_push_fastq / _fasta) may stop in the middle of a read; the chunk is
-//          split as it is and the last K-1 bases of the unfinished read open the next chunk, so the k-mers
-//          across the cut are counted exactly once (what a block with rem > 0 does, io.c:557-570).
-static int flush_chunk(fk_ctx *ctx, bool async = false, bool carry = false)
-{ int rc = flush_join(ctx);
-  if (rc != FK_OK || ctx->reads_len == 0)
-    return (rc);
-  char   *buf = ctx->d_reads;
-  int64_t len = ctx->reads_len;
-  if (!async)
-    { FK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
-      FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-      int64_t keep = 0;
-      if (carry)
-        { const int64_t look = std::min<int64_t>(len, ctx->prm.kmer - 1);
-          char tail[256];
-          FK_HIP(ctx, hipMemcpy(tail, buf + len - look, (size_t) look, hipMemcpyDeviceToHost));
-          while (keep < look && tail[look - 1 - keep] != 0)      // bases after the last read terminator
-            keep += 1;
-        }
-      ctx->reads_len = 0;
-      rc = flush_buffer(ctx, buf, len);
-      if (rc == FK_OK && keep > 0)
-        { // (source and destination cannot overlap: a chunk is far longer than 2 (K-1) bytes -- but be safe)
-          if (len >= 2 * keep)
-            FK_HIP(ctx, hipMemcpy(buf, buf + len - keep, (size_t) keep, hipMemcpyDeviceToDevice));
-          else
-            { char tmp[256];
-              FK_HIP(ctx, hipMemcpy(tmp, buf + len - keep, (size_t) keep, hipMemcpyDeviceToHost));
-              FK_HIP(ctx, hipMemcpy(buf, tmp, (size_t) keep, hipMemcpyHostToDevice));
-            }
-          ctx->reads_len = keep;
-        }
-      return (rc);
-    }
-  FK_HIP(ctx, hipEventRecord(ctx->reads_ev, ctx->copy_stream));
-  std::swap(ctx->d_reads, ctx->d_reads_alt);
-  std::swap(ctx->reads_cap, ctx->reads_cap_alt);
-  ctx->reads_len = 0;
-  ctx->flush_rc = FK_OK;
-  ctx->flush_thread = new std::thread([ctx, buf, len]()
-    { int r = FK_EHIP;
-      if (hipSetDevice(ctx->device) == hipSuccess
-          && hipStreamWaitEvent(ctx->stream, ctx->reads_ev, 0) == hipSuccess)
-        r = flush_buffer(ctx, buf, len);
-      if (r != FK_OK)
-        memcpy(ctx->flush_err, ctx->err, sizeof(ctx->flush_err));
-      ctx->flush_rc = r;
-    });
-  return (FK_OK);
-}
-
-// fk_push_device / _fastq / _fasta write the read buffer through ctx->stream: no flush helper may be
-// running on it, and earlier host blocks must have landed.  Called with the push lock held.
-static int device_push_begin(fk_ctx *ctx)
-{ int rc = flush_join(ctx);
-  if (rc != FK_OK)
-    return (rc);
-  if (ctx->chunk_bytes > 0)
-    FK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
-  return (FK_OK);
-}
-
-extern "C" int fk_push_block(fk_ctx *ctx, const char *bases, const int32_t *boff, int nreads,
-                             int rem, int tid)
-{ if (ctx == NULL || bases == NULL || boff == NULL || nreads < 0) return (FK_EINVAL);
-  if (nreads == 0)
-    return (FK_OK);
-  const int64_t len = (int64_t) boff[nreads] - boff[0];
-  int rc = FK_OK;
-  pthread_mutex_lock((pthread_mutex_t *) ctx->push_lock);
-  do
-    { hipSetDevice(ctx->device);
-      if ((rc = reserve_reads(ctx, len)) != FK_OK)
-        break;
-      hipStream_t ps = push_stream(ctx);
-      // blocks that lie in pinned host memory are copied from where they are
-      bool direct = false;
-      if (!ctx->prm.exact_parts && ctx->prm.bc_prefix == 0)
-        { hipPointerAttribute_t at;
-          if (hipPointerGetAttributes(&at, bases) == hipSuccess)
-            direct = (at.type == hipMemoryTypeHost);
-          else
-            (void) hipGetLastError();
-        }
-      if (direct)
-        { if (hipMemcpyAsync(ctx->d_reads + ctx->reads_len, bases + boff[0], (size_t) len, hipMemcpyHostToDevice,
-                             ps) != hipSuccess)
-            { fk_set_error(ctx, "fk_push_block: host to device copy failed");
-              rc = FK_EHIP;
-              break;
-            }
-          if (hipStreamSynchronize(ps) != hipSuccess)      // the caller may reuse the block once we return
-            { rc = FK_EHIP; break; }                       // (the split of the previous chunk overlaps anyway)
-        }
-      const int si = ctx->stage_idx;
-      if (!direct && ctx->stage_cap < len)
-        { for (int i = 0; i < 2; i++)
-            { if (ctx->h_stage[i])
-                { hipEventSynchronize(ctx->stage_ev[i]);
-                  fkx_pinned_free(ctx->h_stage[i]);
-                  ctx->h_stage[i] = NULL;
-                }
-            }
-          ctx->stage_cap = std::max<int64_t>(len, 4ll << 20);
-          for (int i = 0; i < 2; i++)
-            if (fkx_pinned_alloc((void **) &ctx->h_stage[i], ctx->stage_cap) != FK_OK)
-              { fk_set_error(ctx, "fk_push_block: cannot allocate pinned staging");
-                rc = FK_ENOMEM;
-              }
-          if (rc != FK_OK)
-            break;
-        }
-      if (!direct && hipEventSynchronize(ctx->stage_ev[si]) != hipSuccess)
-        { rc = FK_EHIP; break; }
-      char *st = ctx->h_stage[si];
-      if (!direct)
-        memcpy(st, bases + boff[0], (size_t) len);
-      if (ctx->prm.exact_parts)
-        { if (ctx->nroff + nreads + 1 > ctx->roff_cap)
-            { ctx->roff_cap = std::max<int64_t>(ctx->nroff + nreads + 1, ctx->roff_cap * 2 + 1024);
-              ctx->h_roff = (int64_t *) realloc(ctx->h_roff, sizeof(int64_t) * (size_t) ctx->roff_cap);
-              if (ctx->h_roff == NULL) { rc = FK_ENOMEM; break; }
-            }
-          for (int i = 0; i < nreads; i++)
-            ctx->h_roff[ctx->nroff++] = ctx->reads_len + (boff[i] - boff[0]);
-        }
-      else if (ctx->prm.bc_prefix > 0)      // -bc: the skipped prefix can never be inside a k-mer
-        for (int i = 0; i < nreads; i++)
-          { const int64_t o = boff[i] - boff[0];
-            const int64_t e = boff[i + 1] - boff[0] - 1;
-            for (int64_t j = o; j < e && j < o + ctx->prm.bc_prefix; j++)
-              st[j] = 'N';                 // not a base, and not a read terminator either (profiles)
-          }
-      if (!direct)
-        { if (hipMemcpyAsync(ctx->d_reads + ctx->reads_len, st, (size_t) len, hipMemcpyHostToDevice, ps) != hipSuccess
-              || hipEventRecord(ctx->stage_ev[si], ps) != hipSuccess)
-            { fk_set_error(ctx, "fk_push_block: host to device copy failed");
-              rc = FK_EHIP;
-              break;
-            }
-          ctx->stage_idx ^= 1;
-        }
-      ctx->reads_len += len;
-      if (ctx->nblocks == ctx->blocks_cap)
-        { ctx->blocks_cap = ctx->blocks_cap * 2 + 256;
-          ctx->blocks = (fk_block *) realloc(ctx->blocks, sizeof(fk_block) * (size_t) ctx->blocks_cap);
-          if (ctx->blocks == NULL) { ctx->nblocks = ctx->blocks_cap = 0; rc = FK_ENOMEM; break; }
-        }
-      ctx->blocks[ctx->nblocks].tid = tid;
-      ctx->blocks[ctx->nblocks].rem = rem;
-      ctx->blocks[ctx->nblocks].nreads = nreads;
-      ctx->nblocks += 1;
-      if (ctx->chunk_bytes > 0 && ctx->reads_len >= ctx->chunk_bytes)
-        rc = flush_chunk(ctx, true);
-    }
-  while (0);
-  pthread_mutex_unlock((pthread_mutex_t *) ctx->push_lock);
-  return (rc);
-}
-
-/* The reads of a DATA_BLOCK in two bits per base (see include/fastk_amd.h): unpacked on the device into the read
-   buffer fk_push_block fills, a quarter of the bytes over PCIe. */
-extern "C" int fk_push_packed(fk_ctx *ctx, const uint8_t *codes, int64_t nbases, const int32_t *rlen, int nreads,
-                              const int64_t *inv, int ninv, int rem, int tid)
-{ if (ctx == NULL || nreads < 0 || nbases < 0 || ninv < 0 || (nbases > 0 && codes == NULL) || (nreads > 0 && rlen == NULL)
-      || (ninv > 0 && inv == NULL))
-    return (FK_EINVAL);
-  if (nreads == 0)
-    return (FK_OK);
-  if (ctx->prm.bc_prefix > 0)
-    { fk_set_error(ctx, "fk_push_packed: -bc needs the ASCII form (fk_push_block)");
-      return (FK_EUNSUPPORTED);
-    }
-  const int64_t len = nbases + nreads;                   // bases + terminators
-  const int64_t cbytes = ((nbases + 3) / 4 + 3) & ~3ll;  // the kernel reads whole dwords
-  int rc = FK_OK;
-  pthread_mutex_lock((pthread_mutex_t *) ctx->push_lock);
-  do
-    { hipSetDevice(ctx->device);
-      if ((rc = reserve_reads(ctx, len)) != FK_OK)
-        break;
-      hipStream_t ps = push_stream(ctx);
-      // staging on the device: codes | read offsets | invalid stretches (stream-ordered: the previous block's
-      // kernels are done with it before this block's copies land)
-      const int64_t off_roff = (cbytes + 15) & ~15ll, off_inv = off_roff + ((int64_t) nreads + 1) * 8;
-      const int64_t need = off_inv + (int64_t) ninv * 16 + 16;
-      if (ctx->pk_cap < need)
-        { if (hipStreamSynchronize(ps) != hipSuccess) { rc = FK_EHIP; break; }
-          if (ctx->d_pk) hipFree(ctx->d_pk);
-          if (ctx->h_pk) hipHostFree(ctx->h_pk);
-          ctx->d_pk = NULL; ctx->h_pk = NULL; ctx->pk_cap = 0;
-          const int64_t cap = need + need / 4;
-          if (hipMalloc((void **) &ctx->d_pk, (size_t) cap) != hipSuccess
-              || hipHostMalloc((void **) &ctx->h_pk, (size_t) (cap - off_roff + 64), hipHostMallocDefault) != hipSuccess)
-            { fk_set_error(ctx, "fk_push_packed: out of memory for %lld bytes of staging", (long long) cap);
-              rc = FK_ENOMEM;
-              break;
-            }
-          ctx->pk_cap = cap;
-        }
-      if (hipStreamSynchronize(ps) != hipSuccess) { rc = FK_EHIP; break; }    // h_pk is free again
-      int64_t *hro = (int64_t *) ctx->h_pk;
-      int64_t  run = 0;
-      for (int i = 0; i < nreads; i++)
-        { if (rlen[i] < 0) { rc = FK_EINVAL; break; }
-          hro[i] = run;
-          run += rlen[i];
-        }
-      hro[nreads] = run;
-      if (rc != FK_OK || run != nbases)
-        { fk_set_error(ctx, "fk_push_packed: the read lengths add up to %lld, not to %lld bases", (long long) run, (long long) nbases);
-          rc = FK_EINVAL;
-          break;
-        }
-      if (ninv > 0)
-        memcpy(hro + nreads + 1, inv, (size_t) ninv * 16);
-      if ((nbases > 0 && hipMemcpyAsync(ctx->d_pk, codes, (size_t) ((nbases + 3) / 4), hipMemcpyHostToDevice, ps) != hipSuccess)
-          || hipMemcpyAsync(ctx->d_pk + off_roff, hro, (size_t) (((int64_t) nreads + 1) * 8 + (int64_t) ninv * 16),
-                            hipMemcpyHostToDevice, ps) != hipSuccess)
-        { fk_set_error(ctx, "fk_push_packed: host to device copy failed");
-          rc = FK_EHIP;
-          break;
-        }
-      if ((rc = fkx_unpack_reads(ctx, ps, ctx->d_pk, nbases, (const int64_t *) (ctx->d_pk + off_roff), nreads,
-                                 (const int64_t *) (ctx->d_pk + off_inv), ninv, ctx->d_reads + ctx->reads_len)) != FK_OK)
-        break;
-      if (hipStreamSynchronize(ps) != hipSuccess)          // the caller may reuse its buffers once we return
-        { rc = FK_EHIP; break; }
-      if (ctx->prm.exact_parts)
-        { if (ctx->nroff + nreads + 1 > ctx->roff_cap)
-            { ctx->roff_cap = std::max<int64_t>(ctx->nroff + nreads + 1, ctx->roff_cap * 2 + 1024);
-              ctx->h_roff = (int64_t *) realloc(ctx->h_roff, sizeof(int64_t) * (size_t) ctx->roff_cap);
-              if (ctx->h_roff == NULL) { rc = FK_ENOMEM; break; }
-            }
-          for (int i = 0; i < nreads; i++)
-            ctx->h_roff[ctx->nroff++] = ctx->reads_len + hro[i] + i;
-        }
-      ctx->reads_len += len;
-      if (ctx->nblocks == ctx->blocks_cap)
-        { ctx->blocks_cap = ctx->blocks_cap * 2 + 256;
-          ctx->blocks = (fk_block *) realloc(ctx->blocks, sizeof(fk_block) * (size_t) ctx->blocks_cap);
-          if (ctx->blocks == NULL) { ctx->nblocks = ctx->blocks_cap = 0; rc = FK_ENOMEM; break; }
-        }
-      ctx->blocks[ctx->nblocks].tid = tid;
-      ctx->blocks[ctx->nblocks].rem = rem;
-      ctx->blocks[ctx->nblocks].nreads = nreads;
-      ctx->nblocks += 1;
-      if (ctx->chunk_bytes > 0 && ctx->reads_len >= ctx->chunk_bytes)
-        rc = flush_chunk(ctx, true);
-    }
-  while (0);
-  pthread_mutex_unlock((pthread_mutex_t *) ctx->push_lock);
-  return (rc);
-}
-
-extern "C" int fk_train_block(fk_ctx *ctx, const char *bases, const int32_t *boff, int nreads)
-{ if (ctx == NULL || bases == NULL || boff == NULL || nreads < 0) return (FK_EINVAL);
-  // frequency_thread x NTHREADS summed into thread 0's vector from j = 0 (split.c:95-112,536-539):
-  // every byte once, read stripe 0 twice
-  int64_t freq[256];
-  memset(freq, 0, sizeof(freq));
-  const int T = ctx->prm.nthreads;
-  const int64_t stripe0 = (T > 1) ? ((int64_t) nreads * 1) / T : nreads;
-  for (int64_t i = boff[0]; i < boff[nreads]; i++)
-    freq[(unsigned char) bases[i]] += 1;
-  for (int64_t i = boff[0]; i < boff[stripe0]; i++)
-    freq[(unsigned char) bases[i]] += 1;
-  const int64_t f4[4] = { freq['a'] + freq['A'], freq['c'] + freq['C'], freq['g'] + freq['G'],
-                          freq['t'] + freq['T'] };
-  for (int a = 0; a < 4; a++)
-    { int rank = 0;
-      for (int b = 0; b < 4; b++)
-        if (f4[b] < f4[a] || (f4[b] == f4[a] && b < a))
-          rank += 1;
-      ctx->tran[a] = rank;
-    }
-  ctx->have_tran = 1;
-  return (FK_OK);
-}
-
-extern "C" int fk_push_device(fk_ctx *ctx, const void *d_bases, int64_t nbytes)
-{ if (ctx == NULL || d_bases == NULL || nbytes < 0) return (FK_EINVAL);
-  if (ctx->prm.bc_prefix > 0 || ctx->prm.exact_parts)
-    { fk_set_error(ctx, "fk_push_device: -bc and exact_parts need read offsets; use fk_push_block");
-      return (FK_EUNSUPPORTED);
-    }
-  ctx->blocks_bad = true;
-  int rc;
-  pthread_mutex_lock((pthread_mutex_t *) ctx->push_lock);
-  if ((rc = device_push_begin(ctx)) == FK_OK && (rc = reserve_reads(ctx, nbytes + 1)) == FK_OK)
-    { if (hipMemcpyAsync(ctx->d_reads + ctx->reads_len, d_bases, (size_t) nbytes,
-                         hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess
-          || hipMemsetAsync(ctx->d_reads + ctx->reads_len + nbytes, 0, 1, ctx->stream) != hipSuccess)
-        { fk_set_error(ctx, "fk_push_device: device copy failed");
-          rc = FK_EHIP;
-        }
-      else
-        { ctx->reads_len += nbytes + 1;
-          if (ctx->chunk_bytes > 0 && ctx->reads_len >= ctx->chunk_bytes)
-            rc = flush_chunk(ctx);
-        }
-    }
-  pthread_mutex_unlock((pthread_mutex_t *) ctx->push_lock);
-  return (rc);
-}
-
-/* FASTQ text (any piece of a file, cut anywhere) -> reads, parsed on the device (fk_parse.hip).
-   *line_phase: 0 before the first byte of a file, carried from call to call. */
-extern "C" int fk_push_fastq(fk_ctx *ctx, const char *raw, int64_t nbytes, int flags, int *line_phase,
-                             int64_t *nreads, int64_t *nbases)
-{ if (ctx == NULL || raw == NULL || nbytes < 0 || line_phase == NULL) return (FK_EINVAL);
-  if (ctx->prm.bc_prefix > 0 || ctx->prm.exact_parts)
-    { fk_set_error(ctx, "fk_push_fastq: -bc and exact_parts need read offsets; use fk_push_block");
-      return (FK_EUNSUPPORTED);
-    }
-  ctx->blocks_bad = true;
-  if (nbytes == 0)
-    return (FK_OK);
-  int rc;
-  pthread_mutex_lock((pthread_mutex_t *) ctx->push_lock);
-  do
-    { hipSetDevice(ctx->device);
-      if ((rc = device_push_begin(ctx)) != FK_OK || (rc = reserve_reads(ctx, nbytes + 16)) != FK_OK)
-        break;
-      void *d_raw = fk_slot(ctx, FK_SLOT_RAW, nbytes + 64);
-      if (d_raw == NULL) { rc = FK_ENOMEM; break; }
-      // one byte in front of the text: the last byte of the previous piece (homopolymer compression)
-      d_raw = (char *) d_raw + 16;
-      const unsigned char lastb = (unsigned char) ((*line_phase >> 8) & 0xff);
-      if (hipMemcpyAsync((char *) d_raw - 1, &lastb, 1, hipMemcpyHostToDevice, ctx->stream) != hipSuccess
-          || hipMemcpyAsync(d_raw, raw, (size_t) nbytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
-        { fk_set_error(ctx, "fk_push_fastq: host to device copy failed");
-          rc = FK_EHIP;
-          break;
-        }
-      int64_t kept = 0, nr = 0;
-      if ((rc = fkx_parse_fastq(ctx, d_raw, nbytes, flags, line_phase, ctx->d_reads + ctx->reads_len, &kept, &nr)) != FK_OK)
-        break;
-      *line_phase = (*line_phase & 3) | ((int) (unsigned char) raw[nbytes - 1] << 8);
-      ctx->reads_len += kept;
-      if (nreads) *nreads += nr;
-      if (nbases) *nbases += kept - nr;
-      if (ctx->chunk_bytes > 0 && ctx->reads_len >= ctx->chunk_bytes)
-        rc = flush_chunk(ctx, false, true);
-    }
-  while (0);
-  pthread_mutex_unlock((pthread_mutex_t *) ctx->push_lock);
-  return (rc);
-}
-
-/* FASTA text (any piece of a file, cut anywhere) -> reads, parsed on the device (fk_parse.hip).
-   *state: 2 before the first byte of a file, carried from call to call; last != 0 with the final piece
-   of a file (ends its last record). */
-extern "C" int fk_push_fasta(fk_ctx *ctx, const char *raw, int64_t nbytes, int last, int *state,
-                             int64_t *nreads, int64_t *nbases)
-{ if (ctx == NULL || (raw == NULL && nbytes > 0) || nbytes < 0 || state == NULL) return (FK_EINVAL);
-  if (ctx->prm.bc_prefix > 0 || ctx->prm.exact_parts)
-    { fk_set_error(ctx, "fk_push_fasta: -bc and exact_parts need read offsets; use fk_push_block");
-      return (FK_EUNSUPPORTED);
-    }
-  ctx->blocks_bad = true;
-  int rc = FK_OK;
-  pthread_mutex_lock((pthread_mutex_t *) ctx->push_lock);
-  do
-    { hipSetDevice(ctx->device);
-      if ((rc = device_push_begin(ctx)) != FK_OK || (rc = reserve_reads(ctx, nbytes + 16)) != FK_OK)
-        break;
-      int64_t kept = 0, nr = 0;
-      if (nbytes > 0)
-        { void *d_raw = fk_slot(ctx, FK_SLOT_RAW, nbytes + 64);
-          if (d_raw == NULL) { rc = FK_ENOMEM; break; }
-          if (hipMemcpyAsync(d_raw, raw, (size_t) nbytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
-            { fk_set_error(ctx, "fk_push_fasta: host to device copy failed");
-              rc = FK_EHIP;
-              break;
-            }
-          if ((rc = fkx_parse_fasta(ctx, d_raw, nbytes, *state, ctx->d_reads + ctx->reads_len, &kept, &nr)) != FK_OK)
-            break;
-          // the state after this piece, from the host copy of the text
-          int64_t p = nbytes - 1;
-          while (p >= 0 && raw[p] != '\n')
-            p -= 1;
-          if (p >= 0)
-            *state = (p == nbytes - 1) ? 2 : (raw[p + 1] == '>' ? 1 : 0);
-          else if (*state & 2)
-            *state = (raw[0] == '>') ? 1 : 0;
-          ctx->reads_len += kept;
-        }
-      if (last)
-        { if (hipMemsetAsync(ctx->d_reads + ctx->reads_len, 0, 1, ctx->stream) != hipSuccess)
-            { rc = FK_EHIP; break; }
-          ctx->reads_len += 1;
-        }
-      if (nreads) *nreads += nr;
-      if (nbases) *nbases += kept - nr;
-      if (ctx->chunk_bytes > 0 && ctx->reads_len >= ctx->chunk_bytes && !last)
-        rc = flush_chunk(ctx, false, true);
-    }
-  while (0);
-  pthread_mutex_unlock((pthread_mutex_t *) ctx->push_lock);
-  return (rc);
-}
-
-extern "C" int fk_host_alloc(int64_t nbytes, void **ptr)
-{ if (ptr == NULL || nbytes <= 0) return (FK_EINVAL);
-  if (fkx_pinned_alloc(ptr, nbytes) != FK_OK)
-    { fk_set_error(NULL, "fk_host_alloc: cannot pin %lld bytes", (long long) nbytes);
-      return (FK_ENOMEM);
-    }
-  return (FK_OK);
-}
-
-extern "C" int fk_host_free(void *ptr)
-{ return (fkx_pinned_free(ptr)); }
 
 // ---- whole path: split -> sort -> expand -> sort -> count ----------------------------------------
 #define FK_GROUP_PASSES 4      // hashed digit passes that group super-mers
@@ -2256,7 +1326,7 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
 
       hipEventRecord(ev[0], s);
       void *sm_in = d_smers_in;
-      const bool chunked = (d_smers_in == NULL && d_reads == NULL);   // the chunks of flush_chunk
+      const bool chunked = (d_smers_in == NULL && d_reads == NULL);   // the chunks of fkx_flush_chunk
       if (chunked)
         { nbk = ctx->prm.nbuckets;
           for (int b = 0; b < nbk; b++)
@@ -2560,7 +1630,7 @@ static int finish_impl(fk_ctx *ctx, fk_result *res, bool fetch)
 { if (ctx == NULL || res == NULL) return (FK_EINVAL);
   FK_HIP(ctx, hipSetDevice(ctx->device));
   { pthread_mutex_lock((pthread_mutex_t *) ctx->push_lock);
-    int rc = flush_join(ctx);
+    int rc = fkx_flush_join(ctx);
     pthread_mutex_unlock((pthread_mutex_t *) ctx->push_lock);
     if (rc != FK_OK)
       return (rc);
@@ -2571,16 +1641,16 @@ static int finish_impl(fk_ctx *ctx, fk_result *res, bool fetch)
     { // chunked ingest: the rest of the reads becomes the last chunk, then the buckets are counted
       pthread_mutex_lock((pthread_mutex_t *) ctx->push_lock);
       const double w0 = fk_wall();
-      int rc = flush_chunk(ctx);
+      int rc = fkx_flush_chunk(ctx);
       pthread_mutex_unlock((pthread_mutex_t *) ctx->push_lock);
       if (getenv("FK_FINISH_TIMING") != NULL)
         fprintf(stderr, "  finish timing: last flush %.3f s\n", fk_wall() - w0);
       if (rc == FK_OK)
         rc = fkx_pipeline(ctx, NULL, 0, NULL, 0, res, fetch);
       for (int i = 0; i < ctx->nchunks; i++)
-        free_chunk(ctx, &ctx->chunks[i]);
+        fkx_free_chunk(ctx, &ctx->chunks[i]);
       ctx->nchunks = 0;
-      rewind_slabs(ctx);
+      fkx_rewind_slabs(ctx);
       ctx->chunk_ninst = 0;
       return (rc);
     }
@@ -2606,11 +1676,7 @@ extern "C" int fk_finish(fk_ctx *ctx, fk_result *res)
 extern "C" int fk_finish_device(fk_ctx *ctx, fk_result *res)
 { int rc = finish_impl(ctx, res, false);
   if (rc == FK_OK && ctx->prm.table_cutoff > 0 && ctx->last_table != NULL && ctx->last_ntab == res->ntable)
-    { const int ib = fk_ktab_idx_bytes(ctx->prm.kmer, res->ntable);
-      rc = ktab_prefix_index(ctx, res->ntable, ib);                       // what the .ktab stub holds
-      if (rc == FK_OK && res->ntable > 0)
-        rc = ktab_staging(ctx, ctx->prm.nthreads, ib);
-    }
+    rc = fkx_ktab_prepare(ctx, res->ntable);           // what the part writers need, made before any memory goes back
   return (rc);
 }
 
@@ -2620,7 +1686,7 @@ extern "C" int fk_reset(fk_ctx *ctx)
 { if (ctx == NULL) return (FK_EINVAL);
   FK_HIP(ctx, hipSetDevice(ctx->device));
   pthread_mutex_lock((pthread_mutex_t *) ctx->push_lock);
-  (void) flush_join(ctx);
+  (void) fkx_flush_join(ctx);
   hipStreamSynchronize(ctx->copy_stream);
   hipStreamSynchronize(ctx->stream);
   ctx->reads_len = 0;
@@ -2628,9 +1694,9 @@ extern "C" int fk_reset(fk_ctx *ctx)
   ctx->blocks_bad = false;
   ctx->nroff = 0;
   for (int i = 0; i < ctx->nchunks; i++)
-    free_chunk(ctx, &ctx->chunks[i]);
+    fkx_free_chunk(ctx, &ctx->chunks[i]);
   ctx->nchunks = 0;
-  rewind_slabs(ctx);
+  fkx_rewind_slabs(ctx);
   ctx->chunk_ninst = 0;
   pthread_mutex_unlock((pthread_mutex_t *) ctx->push_lock);
   return (FK_OK);

@@ -234,6 +234,21 @@ int fkx_split(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int
               int64_t *nsuper, int64_t *ninst, int64_t *bucket_counts, bool counts_known,
               void *d_pos = NULL);
 int fkx_split_plan(fk_ctx *ctx, const void *d_bases, int64_t nbytes, int64_t *cap, int64_t *offsets);
+// wall clock in seconds (phase timers of verbose runs)
+static inline double fk_wall(void)
+{ struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ((double) ts.tv_sec + 1e-9 * (double) ts.tv_nsec);
+}
+
+// fk_ingest.hip: the chunk store (called with the push lock held where they touch the read buffers)
+void  fkx_free_chunk(fk_ctx *ctx, fk_chunk *c);
+void  fkx_rewind_slabs(fk_ctx *ctx);
+void *fkx_slab_alloc(fk_ctx *ctx, int64_t bytes);
+int   fkx_flush_join(fk_ctx *ctx);
+int   fkx_flush_chunk(fk_ctx *ctx, bool async = false, bool carry = false);
+int fkx_ktab_prepare(fk_ctx *ctx, int64_t ntable);          // fk_ktab_device.hip
+
 int fkx_split_planned(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int64_t cap,
                       const int64_t *offsets, int64_t *counts, int64_t *ninst, int b0 = 0, int b1 = -1, int mode = 0);
 int fkx_train_tran(fk_ctx *ctx, const void *d_bases, const int64_t *h_roff, int64_t train_reads,
