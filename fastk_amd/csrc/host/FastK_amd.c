@@ -640,6 +640,67 @@ static inline void pk_end_read(Pk_Buf *b, int64_t start)
   b->rlen[b->nreads++] = (int32_t) (b->nb-start);
 }
 
+/* One piece of text -- whole records: it begins at a record start and ends where the next piece begins or the file
+   ends -- into b: the packed bases, the read lengths, the stretches without acgt.  The reference's line rules
+   (io.c:678-738), its oddities included: see the comments inside. */
+static void pk_parse_piece(Pk_Buf *b, const unsigned char *p, const unsigned char *e, int fastq)
+{ b->nb = 0; b->nreads = 0; b->ninv = 0;
+  if (fastq)
+    while (p < e)
+      { const unsigned char *nl;
+        int64_t start = b->nb;
+        nl = memchr(p,'\n',(size_t) (e-p));                 /* header */
+        if (nl == NULL) break;
+        p = nl+1;
+        nl = memchr(p,'\n',(size_t) (e-p));                 /* sequence */
+        if (nl == NULL)                                     /* the file ends inside it: the reference never ends */
+          break;                                            /* this read (io.c:698-705,738) */
+        pk_bases(b,p,nl-p);
+        pk_end_read(b,start);
+        p = (nl < e) ? nl+1 : e;
+        if (p < e)
+          { nl = memchr(p,'\n',(size_t) (e-p));             /* + */
+            p  = (nl == NULL) ? e : nl+1;
+          }
+        if (p < e)
+          { nl = memchr(p,'\n',(size_t) (e-p));             /* quality */
+            p  = (nl == NULL) ? e : nl+1;
+          }
+      }
+  else
+    { int     open = 0;
+      int64_t start = 0;
+      int     first = 1, after_header = 0, cut = 0;
+      while (p < e)
+        { const unsigned char *nl = memchr(p,'\n',(size_t) (e-p));
+          if (nl == NULL) { nl = e; cut = 1; }
+          /* the reference's machine (io.c:685-734): the line after a header is sequence whatever it begins with */
+          if (first || (*p == '>' && !after_header))
+            { if (open) pk_end_read(b,start);
+              open = 1; start = b->nb; first = 0; after_header = 1;
+            }
+          else
+            { pk_bases(b,p,nl-p);
+              after_header = 0;
+            }
+          p = (nl < e) ? nl+1 : e;
+        }
+      /* a file that does not end in a newline: the reference ends a read at the '>' or the end of file that follows
+         a newline (io.c:717-738), so the bases of the last record are dropped */
+      if (open && after_header)                  /* ... and a header at the very end opens no read */
+        open = 0;
+      if (open && cut)
+        { b->nb = start;
+          while (b->ninv > 0 && b->inv[2*(b->ninv-1)] >= start)
+            b->ninv -= 1;
+          if (b->ninv > 0 && b->inv[2*(b->ninv-1)]+b->inv[2*(b->ninv-1)+1] > start)
+            b->inv[2*(b->ninv-1)+1] = start-b->inv[2*(b->ninv-1)];
+          open = 0;
+        }
+      if (open) pk_end_read(b,start);
+    }
+}
+
 static void *pk_worker(void *arg)
 { Pk_Job *job = (Pk_Job *) arg;
   Pk_Buf  b;
@@ -648,7 +709,7 @@ static void *pk_worker(void *arg)
     { int    k;
       off_t  beg, end;
       size_t len, done = 0;
-      const unsigned char *p, *e;
+      const unsigned char *p;
 
       pthread_mutex_lock(&job->lock);
       k = (job->failed || job->next >= job->ncut) ? -1 : job->next++;
@@ -696,62 +757,7 @@ static void *pk_worker(void *arg)
           p = (const unsigned char *) b.text;
         }
       t1 = now();
-      b.nb = 0; b.nreads = 0; b.ninv = 0;
-      e = p+len;
-      if (job->fastq)
-        while (p < e)
-          { const unsigned char *nl;
-            int64_t start = b.nb;
-            nl = memchr(p,'\n',(size_t) (e-p));                 /* header */
-            if (nl == NULL) break;
-            p = nl+1;
-            nl = memchr(p,'\n',(size_t) (e-p));                 /* sequence */
-            if (nl == NULL)                                     /* the file ends inside it: the reference never ends */
-              break;                                            /* this read (io.c:698-705,738) */
-            pk_bases(&b,p,nl-p);
-            pk_end_read(&b,start);
-            p = (nl < e) ? nl+1 : e;
-            if (p < e)
-              { nl = memchr(p,'\n',(size_t) (e-p));             /* + */
-                p  = (nl == NULL) ? e : nl+1;
-              }
-            if (p < e)
-              { nl = memchr(p,'\n',(size_t) (e-p));             /* quality */
-                p  = (nl == NULL) ? e : nl+1;
-              }
-          }
-      else
-        { int     open = 0;
-          int64_t start = 0;
-          int     first = 1, after_header = 0, cut = 0;
-          while (p < e)
-            { const unsigned char *nl = memchr(p,'\n',(size_t) (e-p));
-              if (nl == NULL) { nl = e; cut = 1; }
-              /* the reference's machine (io.c:685-734): the line after a header is sequence whatever it begins with */
-              if (first || (*p == '>' && !after_header))
-                { if (open) pk_end_read(&b,start);
-                  open = 1; start = b.nb; first = 0; after_header = 1;
-                }
-              else
-                { pk_bases(&b,p,nl-p);
-                  after_header = 0;
-                }
-              p = (nl < e) ? nl+1 : e;
-            }
-          /* a file that does not end in a newline: the reference ends a read at the '>' or the end of file that follows
-             a newline (io.c:717-738), so the bases of the last record are dropped */
-          if (open && after_header)                  /* ... and a header at the very end opens no read */
-            open = 0;
-          if (open && cut)
-            { b.nb = start;
-              while (b.ninv > 0 && b.inv[2*(b.ninv-1)] >= start)
-                b.ninv -= 1;
-              if (b.ninv > 0 && b.inv[2*(b.ninv-1)]+b.inv[2*(b.ninv-1)+1] > start)
-                b.inv[2*(b.ninv-1)+1] = start-b.inv[2*(b.ninv-1)];
-              open = 0;
-            }
-          if (open) pk_end_read(&b,start);
-        }
+      pk_parse_piece(&b,p,p+len,job->fastq);
       if (job->map != NULL)                      /* drop the piece's page-table entries here, in parallel: one munmap */
         { off_t lo = (beg+4095) & ~(off_t) 4095, hi = end & ~(off_t) 4095;     /* of 150 GB at the end takes over a second */
           if (hi > lo)

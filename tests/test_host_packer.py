@@ -1,7 +1,9 @@
 """The two-bit packer of FastK_amd's reader threads (scan_text_packed in fastk_amd/csrc/host/FastK_amd.c: the bases of
 a FASTA / FASTQ piece four to a byte, stretches of non-bases listed beside them -- what fk_push_packed takes) against a
 base-by-base restatement: tests/csrc/host_packer_check.c includes the driver's source and drives pk_bases on random
-reads at every bit offset, through the AVX2 path and the table path.  No GPU needed."""
+reads at every bit offset, through the AVX2 path and the table path; and the piece parser (pk_parse_piece) against the
+reference's scanner (io.c:685-738) restated one byte at a time, on random FASTA / FASTQ texts with records without bases,
+empty lines, '>' and '@' where they mislead, a missing final newline and truncated ends.  No GPU needed."""
 import os
 import subprocess
 
