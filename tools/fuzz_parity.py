@@ -53,6 +53,31 @@ def make_reads(rng, k):
     return [reads[i] for i in order]
 
 
+def pack_reads(bases, boff):
+    """the 2-bit form fk_push_packed takes, from a DATA_BLOCK: (codes, nbases, rlen, inv)"""
+    code = np.full(256, 255, dtype=np.uint8)
+    for i, c in enumerate(b"acgt"):
+        code[c] = i
+        code[c - 32] = i
+    rlen = (np.diff(boff) - 1).astype(np.int32)
+    keep = np.ones(len(bases), dtype=bool)
+    keep[boff[1:] - 1] = False                                   # the terminators
+    flat = code[np.asarray(bases)[keep]]
+    bad = np.nonzero(flat == 255)[0]
+    inv = np.zeros((0, 2), dtype=np.int64)
+    if len(bad):
+        cut = np.nonzero(np.diff(bad) != 1)[0]
+        first = bad[np.concatenate([[0], cut + 1])]
+        last = bad[np.concatenate([cut, [len(bad) - 1]])]
+        inv = np.stack([first, last - first + 1], axis=1).astype(np.int64)
+    flat = np.where(flat == 255, 2, flat).astype(np.uint8)       # (what stands under an invalid base does not matter)
+    nb = len(flat)
+    pad = np.zeros((nb + 3) // 4 * 4, dtype=np.uint8)
+    pad[:nb] = flat
+    q = pad.reshape(-1, 4)
+    return ((q[:, 0] << 6) | (q[:, 1] << 4) | (q[:, 2] << 2) | q[:, 3]).astype(np.uint8), nb, rlen, inv
+
+
 def main():
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -99,6 +124,22 @@ def main():
                     assert len(offs) == len(want) + 1, "profile count"
                     for i, x in enumerate(want):
                         assert raw[offs[i]:offs[i + 1]] == orc.profile_encode(x), "profile of read %d" % i
+            if it % 2 == 1:
+                # the same reads in two bits per base (fk_push_packed), in random pieces, chunked or not
+                with fastk_amd.Context(kmer=k, table_cutoff=cutoff, nbuckets=nb) as ctx:
+                    if chunk:
+                        ctx.debug_set("chunk_bytes", chunk)
+                    nreads = len(boff) - 1
+                    lo = 0
+                    while lo < nreads:
+                        hi = min(nreads, lo + int(rng.integers(1, 600)))
+                        codes, nbp, rlen, inv = pack_reads(bases[boff[lo]:boff[hi]], boff[lo:hi + 1] - boff[lo])
+                        ctx.push_packed(codes, nbp, rlen, inv)
+                        lo = hi
+                    res = ctx.finish()
+                    assert res.ninst == exp.ninst and np.array_equal(res.hist, exp.hist) and res.max_inst == exp.max_inst, \
+                        "packed push: histogram"
+                    assert res.ntable == exp.ntable and np.array_equal(res.table, exp.table), "packed push: table"
             if cutoff == 1 and it % 2 == 0:
                 # the sharded profile pieces on one context: split with positions, count the records,
                 # owner-side look-ups, scatter back, codec
