@@ -5,7 +5,7 @@ chunked ingest with and without host spill, block sizes and input-thread ids, ta
 profile stage.  Every iteration compares histogram, max_inst, instance count, table and (cut-off 1)
 profiles bit for bit.
 
-  python tools/fuzz_parity.py [iterations=100] [seed=1]
+  python tests/fuzz_parity.py [iterations=100] [seed=1]
 """
 import os
 import sys
