@@ -2152,12 +2152,12 @@ def test_profiles_follow_input_thread_order(tmp_path):
 
 
 def test_randomised_differential_run():
-    """tools/fuzz_parity.py: random k, read mixes, buckets, chunking / host spill, block sizes, thread
+    """tests/fuzz_parity.py: random k, read mixes, buckets, chunking / host spill, block sizes, thread
     ids, cut-offs and profiles against the oracle (1,650 configurations were run when it was written;
     a short slice stays in the suite)."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    p = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "40", "7"],
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_parity.py"), "40", "7"],
                        capture_output=True, text=True, timeout=900, cwd=root)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     assert "all 40 iterations equal to the oracle" in p.stdout
