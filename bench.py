@@ -86,6 +86,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-device-leg", action="store_true", help="skip value_device (pinned host -> host)")
     ap.add_argument("--no-e2e", action="store_true", help="skip value_e2e (file -> files)")
+    ap.add_argument("--no-packed-leg", action="store_true", help="skip value_packed_resident (reads resident in two bits per base)")
     ap.add_argument("--e2e-pause", type=float, default=12.0,
                     help="seconds between the runs of the e2e leg (the driver wipes released device memory in the background)")
     ap.add_argument("--e2e-scale", type=float, default=1.0,
@@ -560,6 +561,137 @@ def main_config3(args, cfg, torch, fastk_amd, dist, rank, local_rank, world, dev
         dist.destroy_process_group()
 
 
+def roofline_record(loc, w, cfg_id, ceiling, ceiling_kernel):
+    """roofline object of one resident step (loc = its fk_result): the dominant kernel is k_rx_scatter on the weighted
+    k-mer records (the two hashed digit passes that bring equal k-mers into one of 65,536 bins before they are summed
+    in LDS), one stable 8-bit digit pass per launch.  Algorithmic bytes per launch = 2 * n * R (records read once and
+    written once at the reference width R = KMER_WORD); duration = HIP event pair around every scatter launch on the
+    library's stream.  With bucket streaming a step has 2 launches per bucket: achieved = (sum of the launches'
+    algorithmic bytes) / (sum of their durations), and the per-launch figures are the averages.  pass_total adds the
+    per-pass helper kernels."""
+    n_rec = loc.nweighted
+    nl_k = max(loc.launches_kmer, 1)
+    nl_s = max(loc.launches_super, 1)
+    gbs = lambda nbytes_, ms: round(nbytes_ / (ms * 1e-3) / 1e9, 1) if ms > 0 else 0.0
+    passes_k = max(loc.passes_kmer, 1)
+    algo_k = 2.0 * n_rec * w.kmer_word * passes_k          # all scatter launches over W of one step
+    achieved = gbs(algo_k, loc.ms_scatter_kmer)
+    passes_s = max(loc.passes_super, 1)
+    algo_s = 2.0 * loc.nsuper * w.smer_word * passes_s
+    # HBM traffic per launch from PMC counters cannot be collected by this process; it comes from the committed
+    # rocprofv3 passes over this same command and is only reported when (a) the workload (records per launch) is the
+    # profiled one and (b) the kernel source has not changed since the profile was taken (the JSON carries the
+    # sha256 of fastk_amd/csrc/fk_radix.hip it was collected with) -- otherwise null.
+    traffic = None
+    traffic_src = None
+    import glob
+    import hashlib
+    names = sorted((os.path.basename(f) for f in glob.glob(os.path.join(ROOT, "profiles", "r0*_configs%d_pmc_traffic.json" % cfg_id))),
+                   reverse=True)                              # the newest round's first
+    try:
+        radix_sha = hashlib.sha256(open(os.path.join(ROOT, "fastk_amd", "csrc", "fk_radix.hip"), "rb").read()).hexdigest()
+    except OSError:
+        radix_sha = None
+    for name in names[:1]:                                    # only the newest profile counts
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", name)))
+            per_launch = n_rec / (nl_k / passes_k)
+            if abs(pm["records_per_launch"] - per_launch) <= 2e-2 * per_launch and w.kmer_word == 12 \
+                    and pm.get("kernel_source_sha256") == radix_sha:
+                traffic = pm["scatter_traffic_bytes_per_launch"]
+                traffic_src = name
+        except Exception:
+            continue
+    return dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+                frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
+                traffic_unit="bytes per launch (FETCH_SIZE + WRITE_SIZE with the guide's gfx950 corrections, "
+                             "profiles/%s)" % traffic_src if traffic_src else None,
+                copy_ceiling=ceiling, frac_of_copy_ceiling=round(achieved / ceiling, 4) if ceiling else None,
+                copy_kernel_ceiling=ceiling_kernel,
+                frac_of_copy_kernel_ceiling=round(achieved / ceiling_kernel, 4) if ceiling_kernel else None,
+                algorithmic_bytes=round(algo_k / nl_k, 1),
+                kernel="k_rx_scatter<3,12> (weighted k-mer records, R=%d B)" % w.kmer_word,
+                records_per_launch=int(n_rec / (nl_k / passes_k)), launches_per_step=int(nl_k),
+                avg_launch_ms=round(loc.ms_scatter_kmer / nl_k, 4),
+                pass_total=dict(avg_ms=round(loc.ms_pass_kmer / nl_k, 4),
+                                achieved=gbs(algo_k, loc.ms_pass_kmer),
+                                note="scatter + k_rx_tilehist + k_rx_chunkscan + k_rx_superscan"),
+                table_sort=dict(records=int(loc.ncollapsed), launches=int(loc.passes_final),
+                                achieved_pass_total=gbs(2.0 * loc.ncollapsed * w.kmer_word * max(loc.passes_final, 1),
+                                                        loc.ms_pass_final)),
+                supermer_pass=dict(
+                    kernel="k_rx_scatter_w<5,4,hashed> (super-mer records, R=%d B)" % w.smer_word,
+                    records_per_launch=int(loc.nsuper / (nl_s / passes_s)), launches=int(nl_s),
+                    avg_launch_ms=round(loc.ms_scatter_super / nl_s, 4),
+                    achieved=gbs(algo_s, loc.ms_scatter_super),
+                    pass_total_achieved=gbs(algo_s, loc.ms_pass_super)))
+
+
+def packed_resident_leg(args, cfg, fastk_amd, torch, dev, local_rank, reads, nbytes, per, L, ceiling, ceiling_kernel):
+    """The same step with the reads resident in TWO BITS PER BASE (fk_count_device_packed): 37.5 GB instead of 150 GB,
+    so that every super-mer record fits beside them -- one split pass, no replay -- and the splitter's tile loader
+    converts nothing.  The caller's ASCII reads are packed on the device first (not timed: the form is the leg's
+    input) and released; returns the record for the JSON line."""
+    import hashlib
+    from fastk_amd import shard
+    nbases = per * L
+    ctx = fastk_amd.Context(kmer=args.kmer, table_cutoff=cfg["cutoff"], nthreads=4, device=local_rank,
+                            nbuckets=max(1, cfg["buckets"]), split_passes=1)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    for kv in args.debug:
+        key, val = kv.split("=")
+        ctx.debug_set(key, int(val))
+    try:
+        return _packed_resident_leg(args, cfg, ctx, torch, dev, reads, nbytes, per, L, ceiling, ceiling_kernel)
+    finally:
+        ctx.close()
+        torch.cuda.empty_cache()
+
+
+def _packed_resident_leg(args, cfg, ctx, torch, dev, reads, nbytes, per, L, ceiling, ceiling_kernel):
+    import hashlib
+    from fastk_amd import shard
+    nbases = per * L
+    if cfg["buckets"] > 1:
+        shard.HipEngine(ctx, dev).train_buckets(reads[:nbytes], sample_bytes=8 << 20)
+    codes = torch.empty((nbases + 3) // 4 + 64, dtype=torch.uint8, device=dev)
+    ctx._ck(ctx.L.fk_pack_fixed_reads(ctx.h, reads.data_ptr(), per, L, codes.data_ptr()))
+    roff = torch.arange(per + 1, dtype=torch.int64, device=dev) * L
+    torch.cuda.synchronize()
+    reads.set_(torch.empty(0, dtype=torch.uint8, device=dev).untyped_storage())    # the ASCII form goes
+    torch.cuda.empty_cache()
+
+    def step():
+        return ctx.count_device_packed(codes.data_ptr(), nbases, roff.data_ptr(), per, None, 0, fetch_table=False)
+
+    last = None
+    for i in range(args.warmup):
+        t0 = time.perf_counter()
+        last = step()
+        log(args, "packed-resident warm-up step %d: %.3f s" % (i, time.perf_counter() - t0))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    h = last.hist.astype(np.int64)
+    conserved = int((h[1:0x7fff] * np.arange(1, 0x7fff)).sum()) + int(last.max_inst)
+    assert conserved == last.ninst == per * (L - args.kmer + 1), \
+        "packed-resident leg: %d instances, %d in the histogram, %d expected" % (last.ninst, conserved, per * (L - args.kmer + 1))
+    log(args, "packed-resident: %.3f s per step" % dt, last.ms)
+    out = dict(metric="canonical k-mers/sec (k=%d, whole hot path, reads resident in HBM in two bits per base)" % args.kmer,
+               value=last.ninst / dt, unit="k-mers/s", ms_per_step=1e3 * dt, steps=args.steps,
+               resident_bytes=int(codes.numel() + roff.numel() * 8),
+               split_passes=int(last.split_passes), replay_passes=int(last.replay_passes),
+               buckets=int(last.buckets_counted), supermers=int(last.nsuper), weighted_kmers=int(last.nweighted),
+               table_entries=int(last.ntable), histogram_sha256=hashlib.sha256(h.tobytes()).hexdigest(),
+               stage_ms=dict((k, round(v, 3)) for k, v in last.ms.items()),
+               roofline=roofline_record(last, ctx.w, 2 if cfg["buckets"] > 1 else 1, ceiling, ceiling_kernel))
+    out["stage_ms"]["table_sort"] = round(last.ms_table_sort, 3)
+    return out
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -683,71 +815,14 @@ def main():
     value = ninst / (dt / args.steps)
     log(args, "timed: %.3f s per step" % (dt / args.steps), loc.ms)
 
-    # roofline of the dominant kernel: k_rx_scatter on the weighted k-mer records (the two hashed
-    # digit passes that bring equal k-mers into one of 65,536 bins before they are summed in LDS),
-    # one stable 8-bit digit pass per launch.  Algorithmic bytes per launch = 2 * n * R (records read
-    # once and written once at the reference width R = KMER_WORD); duration = HIP event pair around
-    # every scatter launch on the library's stream.  With bucket streaming a step has 2 launches per
-    # bucket: achieved = (sum of the launches' algorithmic bytes) / (sum of their durations), and the
-    # per-launch figures are the averages.  pass_total adds the per-pass helper kernels.
     w = ctx.w
-    n_rec = loc.nweighted
-    nl_k = max(loc.launches_kmer, 1)
-    nl_s = max(loc.launches_super, 1)
-    per_bucket = max(loc.buckets_counted, 1)
-    gbs = lambda nbytes_, ms: round(nbytes_ / (ms * 1e-3) / 1e9, 1) if ms > 0 else 0.0
-    passes_k = max(loc.passes_kmer, 1)
-    algo_k = 2.0 * n_rec * w.kmer_word * passes_k          # all scatter launches over W of one step
-    achieved = gbs(algo_k, loc.ms_scatter_kmer)
-    passes_s = max(loc.passes_super, 1)
-    algo_s = 2.0 * loc.nsuper * w.smer_word * passes_s
-    # HBM traffic per launch from PMC counters cannot be collected by this process; it comes from
-    # the committed rocprofv3 passes over this same command and is only reported when the workload
-    # (records per launch) is the profiled one.
-    traffic = None
-    traffic_src = None
-    import glob
-    names = sorted((os.path.basename(f) for f in glob.glob(os.path.join(ROOT, "profiles", "r0*_configs%d_pmc_traffic.json" % cfg_id))),
-                   reverse=True)                              # the newest round's first
-    for name in names:
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", name)))
-            per_launch = n_rec / (nl_k / passes_k)
-            if abs(pm["records_per_launch"] - per_launch) <= 2e-2 * per_launch and w.kmer_word == 12:
-                traffic = pm["scatter_traffic_bytes_per_launch"]
-                traffic_src = name
-                break
-        except Exception:
-            continue
-    roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
-                    traffic_unit="bytes per launch (FETCH_SIZE + WRITE_SIZE with the guide's gfx950 corrections, "
-                                 "profiles/%s)" % traffic_src if traffic_src else None,
-                    copy_ceiling=ceiling, frac_of_copy_ceiling=round(achieved / ceiling, 4) if ceiling else None,
-                    copy_kernel_ceiling=ceiling_kernel,
-                    frac_of_copy_kernel_ceiling=round(achieved / ceiling_kernel, 4) if ceiling_kernel else None,
-                    algorithmic_bytes=round(algo_k / nl_k, 1),
-                    kernel="k_rx_scatter<3,12> (weighted k-mer records, R=%d B)" % w.kmer_word,
-                    records_per_launch=int(n_rec / (nl_k / passes_k)), launches_per_step=int(nl_k),
-                    avg_launch_ms=round(loc.ms_scatter_kmer / nl_k, 4),
-                    pass_total=dict(avg_ms=round(loc.ms_pass_kmer / nl_k, 4),
-                                    achieved=gbs(algo_k, loc.ms_pass_kmer),
-                                    note="scatter + k_rx_tilehist + k_rx_chunkscan + k_rx_superscan"),
-                    table_sort=dict(records=int(loc.ncollapsed), launches=int(loc.passes_final),
-                                    achieved_pass_total=gbs(2.0 * loc.ncollapsed * w.kmer_word * max(loc.passes_final, 1),
-                                                            loc.ms_pass_final)),
-                    supermer_pass=dict(
-                        kernel="k_rx_scatter_w<5,4,hashed> (super-mer records, R=%d B)" % w.smer_word,
-                        records_per_launch=int(loc.nsuper / (nl_s / passes_s)), launches=int(nl_s),
-                        avg_launch_ms=round(loc.ms_scatter_super / nl_s, 4),
-                        achieved=gbs(algo_s, loc.ms_scatter_super),
-                        pass_total_achieved=gbs(algo_s, loc.ms_pass_super)))
+    roofline = roofline_record(loc, w, cfg_id, ceiling, ceiling_kernel)
 
     scale_note = "" if args.scale == 1.0 else " SCALED by %g (development run)" % args.scale
     workload = cfg["label"] % (cfg["genome_mbp"] * args.scale, " per GPU" if sharded else "", args.kmer) + scale_note
     if custom:
         workload = "custom: " + workload
-    out = dict(metric="canonical k-mers/sec (k=40, whole hot path, reads resident in HBM)",
+    out = dict(metric="canonical k-mers/sec (k=%d, whole hot path, reads resident in HBM as 0-terminated ASCII)" % args.kmer,
                value=value, unit="k-mers/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                ms_per_step=ms_step, higher_is_better=True, scaling="weak", vs_baseline=None,
                dtype="u8", data="synthetic",
@@ -764,10 +839,23 @@ def main():
                stage_ms=dict((k, round(v, 3)) for k, v in loc.ms.items()))
     if not sharded:
         out["stage_ms"]["table_sort"] = round(loc.ms_table_sort, 3)
+        out["histogram_sha256"] = __import__("hashlib").sha256(h.tobytes()).hexdigest()
+    if rank == 0 and world == 1 and not args.force_shard and not args.no_packed_leg:
+        ctx.close()
+        ctx = None
+        try:
+            out["value_packed_resident"] = packed_resident_leg(args, cfg, fastk_amd, torch, dev, local_rank, reads, nbytes,
+                                                               per, L, ceiling, ceiling_kernel)
+            assert out["value_packed_resident"]["histogram_sha256"] == out["histogram_sha256"], \
+                "the packed-resident step gives another histogram than the ASCII-resident one"
+        except Exception as e:
+            out["value_packed_resident"] = dict(failed=repr(e)[-600:])
+        log(args, "packed-resident leg", out["value_packed_resident"])
     del reads
     torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.force_shard:
-        ctx.close()
+        if ctx is not None:
+            ctx.close()
         ctx = None
         gen = fastk_amd.Context(kmer=args.kmer, device=local_rank)
         if not args.no_device_leg:

@@ -29,6 +29,7 @@ EXPORTS = [
     "fk_write_ktab_range", "fk_write_ktab_stub", "fk_split_supermers_emit_pos", "fk_profile_lookup_supermers",
     "fk_profile_scatter", "fk_profile_encode", "fk_reset", "fk_shard_unique_id", "fk_shard_create",
     "fk_release_device", "fk_set_sort_memory", "fk_finish_device", "fk_write_ktab_device", "fk_push_packed", "fk_pack_fixed_reads", "fk_copy_rate", "fk_shard_count", "fk_shard_gather", "fk_shard_write", "fk_shard_destroy", "fk_shard_count_device", "fk_shard_local_result",
+    "fk_count_device_packed",
 ]
 
 
@@ -125,6 +126,7 @@ def load_library():
     L.fk_shard_destroy.argtypes = [vp]
     L.fk_shard_destroy.restype = None
     L.fk_count_device_reads.argtypes = [vp, vp, i64, ci, C.POINTER(CResult)]
+    L.fk_count_device_packed.argtypes = [vp, vp, i64, vp, i64, vp, i64, ci, C.POINTER(CResult)]
     L.fk_count_device_supermers.argtypes = [vp, vp, i64, ci, C.POINTER(CResult)]
     L.fk_write_hist.argtypes = [C.POINTER(CResult), ci, C.c_char_p]
     L.fk_write_ktab.argtypes = [C.POINTER(CResult), ci, ci, ci, C.c_char_p, C.c_char_p]
@@ -406,6 +408,13 @@ class Context:
         r = CResult()
         self._ck(self.L.fk_count_device_reads(self.h, ptr, nbytes, 1 if fetch_table else 0,
                                               C.byref(r)))
+        return Result(r, self.w.kmer_word)
+
+    def count_device_packed(self, codes_ptr, nbases, roff_ptr, nreads, inv_ptr=None, ninv=0, fetch_table=False):
+        """reads resident in two bits per base (device pointers: codes, int64 roff[nreads + 1], int64 inv pairs)"""
+        r = CResult()
+        self._ck(self.L.fk_count_device_packed(self.h, codes_ptr, nbases, roff_ptr, nreads, inv_ptr, ninv,
+                                               1 if fetch_table else 0, C.byref(r)))
         return Result(r, self.w.kmer_word)
 
     def count_device_supermers(self, ptr, nsuper, fetch_table=False):

@@ -363,7 +363,8 @@ extern "C" void fk_destroy(fk_ctx *ctx)
   hipFree(ctx->d_digit_hist); hipFree(ctx->d_status); hipFree(ctx->d_ticket);
   hipFree(ctx->d_reads);
   hipFree(ctx->d_reads_alt);
-  hipFree(ctx->d_pk);
+  for (int i = 0; i < 2; i++)
+    { hipFree(ctx->pk[i].roff); hipFree(ctx->pk[i].inv); }
   if (ctx->h_pk) hipHostFree(ctx->h_pk);
   hipFree(ctx->d_min_part);
   free(ctx->min_part);
@@ -441,8 +442,12 @@ extern "C" int fk_release_device(fk_ctx *ctx, int keep_table)
       }
   hipFree(ctx->d_reads);     ctx->d_reads = NULL;     ctx->reads_cap = 0; ctx->reads_len = 0;
   hipFree(ctx->d_reads_alt); ctx->d_reads_alt = NULL; ctx->reads_cap_alt = 0;
-  hipFree(ctx->d_pk); ctx->d_pk = NULL; ctx->pk_cap = 0;
-  if (ctx->h_pk) { hipHostFree(ctx->h_pk); ctx->h_pk = NULL; }
+  for (int i = 0; i < 2; i++)
+    { hipFree(ctx->pk[i].roff); hipFree(ctx->pk[i].inv);
+      memset(&ctx->pk[i], 0, sizeof(ctx->pk[i]));
+    }
+  if (ctx->h_pk) { hipHostFree(ctx->h_pk); ctx->h_pk = NULL; ctx->h_pk_cap = 0; }
+  ctx->push_form = 0; ctx->pk_ascii_len = 0;
   for (int i = 0; i < ctx->nspill; i++)
     if (ctx->spill_buf[i].ptr != NULL && !ctx->spill_buf[i].in_use)
       { fkx_pinned_free(ctx->spill_buf[i].ptr);
@@ -1301,9 +1306,10 @@ static int fetch_result_table(fk_ctx *ctx, fk_result *res, void *table, int64_t 
 // With nbuckets > 1 and reads as input the buckets are processed one after the other ("bucket
 // streaming": the k-mer buffers only ever hold one bucket's weighted k-mers); equal k-mers share a
 // minimizer, hence a bucket, so histograms add up and the table is the sorted union.
+// pk != NULL: d_reads holds the reads in two bits per base, nbytes = their positions (fk_pkview).
 int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers_in,
                  int64_t nsmers_in, fk_result *res, bool fetch_table, int64_t *h_roff = NULL,
-                 int64_t nreads = 0)
+                 int64_t nreads = 0, const fk_pkview *pk = NULL)
 { const fk_widths &w = ctx->wid;
   hipStream_t s = ctx->stream;
   hipEvent_t ev[3];
@@ -1394,7 +1400,7 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
             { nbk = ctx->prm.nbuckets;
               // several split passes over resident reads, each emitting one group of buckets?
               if (nbk > 1 && nbk <= 255 && (ctx->prm.split_passes > 1 || (ctx->prm.split_passes == 0 && ctx->prm.hbm_budget > 0)))
-                { if ((rc = fkx_split_plan(ctx, d_reads, nbytes, &gcap_all, goffs)) != FK_OK) break;
+                { if ((rc = fkx_split_plan(ctx, d_reads, nbytes, &gcap_all, goffs, pk)) != FK_OK) break;
                   ngroups = ctx->prm.split_passes;
                   if (ngroups <= 0)
                     { const int64_t half = std::max<int64_t>(ctx->prm.hbm_budget / 2, 1);
@@ -1406,7 +1412,7 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
               if (ngroups <= 1)
                 { // split (sampled capacity + one emit pass; exact count-then-emit with several buckets)
                   ngroups = 1;
-                  if ((rc = fkx_split_fast(ctx, d_reads, nbytes, &sm_a, &ns, &ni, bc, bo)) != FK_OK) break;
+                  if ((rc = fkx_split_fast(ctx, d_reads, nbytes, &sm_a, &ns, &ni, bc, bo, pk)) != FK_OK) break;
                 }
             }
           res->nsuper = ns;
@@ -1492,7 +1498,7 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
             { int64_t first = 0;
               for (int b = gb[0]; b < gb[1]; b++)
                 first += est[b];
-              const int64_t ntiles = (nbytes - ctx->prm.kmer + 1 + 4095) / 4096;
+              const int64_t ntiles = (nbytes - ctx->prm.kmer + 1 + 4095) / 4096;      // (packed or not: nbytes = positions)
               ctx->ent_cap = ((gcap_all - first) + (gcap_all - first) / 16 + 64 * 8192) / 64 * 64;
               const int64_t nchunks = (ntiles + 15) / 16;
               if (fk_slot(ctx, FK_SLOT_ENT, ctx->ent_cap * 4) == NULL || fk_slot(ctx, FK_SLOT_TENT, ntiles * 8) == NULL
@@ -1522,7 +1528,7 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
                   sm_a = out;
                   hipEventRecord(gev[0], s);
                   rc = fkx_split_planned(ctx, d_reads, nbytes, out, ctx->slot_cap[FK_SLOT_SM_A] / w.smer_stride,
-                                         lo, cnt, &nig, gb[g], gb[g + 1], replay ? (g == 0 ? 1 : 2) : 0);
+                                         lo, cnt, &nig, gb[g], gb[g + 1], replay ? (g == 0 ? 1 : 2) : 0, pk);
                   if (replay && g == 0 && rc == FK_OK && !ctx->ent_valid)
                     replay = false;                 // the entries did not fit: full passes for the other groups
                   hipEventRecord(gev[1], s);
@@ -1535,7 +1541,7 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
                   else
                     { // very uneven input: count the buckets exactly (one more pass over the reads) instead of failing
                       int64_t ns_x = 0, ni_x = 0, bcx[256];
-                      if ((rc = fkx_split(ctx, d_reads, nbytes, NULL, 0, &ns_x, &ni_x, bcx, false, NULL)) != FK_OK)
+                      if ((rc = fkx_split(ctx, d_reads, nbytes, NULL, 0, &ns_x, &ni_x, bcx, false, NULL, pk)) != FK_OK)
                         break;
                       for (int b = 0; b < nbk; b++)
                         est[b] = bcx[b] + FK_REGION_SLACK;
@@ -1663,7 +1669,24 @@ static int finish_impl(fk_ctx *ctx, fk_result *res, bool fetch)
         { ctx->h_roff = (int64_t *) malloc(sizeof(int64_t) * 4);
           ctx->roff_cap = 4;
         }
-      return fkx_pipeline(ctx, ctx->d_reads, ctx->reads_len, NULL, 0, res, fetch, ctx->h_roff, ctx->nroff);
+      const void *rd = ctx->d_reads;
+      int64_t     len = ctx->reads_len;
+      if (ctx->push_form == 2)                 // the reference's rule walks reads byte by byte: restore the ASCII
+        { void *asc = NULL;
+          const int rc = fkx_unpack_store(ctx, &asc, &len);
+          if (rc != FK_OK)
+            return (rc);
+          rd = asc;
+        }
+      return fkx_pipeline(ctx, rd, len, NULL, 0, res, fetch, ctx->h_roff, ctx->nroff);
+    }
+  if (ctx->push_form == 2)
+    { const fk_pkstore *st = &ctx->pk[ctx->pk_cur];
+      fk_pkview pv;
+      pv.roff = st->roff; pv.nreads = st->nreads; pv.inv = st->inv; pv.ninv = st->ninv;
+      if (st->nreads == 0)
+        return fkx_pipeline(ctx, ctx->d_reads, 0, NULL, 0, res, fetch);
+      return fkx_pipeline(ctx, ctx->d_reads, st->npos, NULL, 0, res, fetch, NULL, 0, &pv);
     }
   return fkx_pipeline(ctx, ctx->d_reads, ctx->reads_len, NULL, 0, res, fetch);
 }
@@ -1693,6 +1716,10 @@ extern "C" int fk_reset(fk_ctx *ctx)
   ctx->nblocks = 0;
   ctx->blocks_bad = false;
   ctx->nroff = 0;
+  ctx->push_form = 0;
+  ctx->pk_ascii_len = 0;
+  for (int i = 0; i < 2; i++)
+    ctx->pk[i].nreads = ctx->pk[i].ninv = ctx->pk[i].npos = 0;
   for (int i = 0; i < ctx->nchunks; i++)
     fkx_free_chunk(ctx, &ctx->chunks[i]);
   ctx->nchunks = 0;
@@ -1712,6 +1739,27 @@ extern "C" int fk_count_device_reads(fk_ctx *ctx, const void *d_bases, int64_t n
     }
   FK_HIP(ctx, hipSetDevice(ctx->device));
   return fkx_pipeline(ctx, d_bases, nbytes, NULL, 0, res, fetch_table != 0);
+}
+
+/* fk_count_device_reads for reads that are resident in TWO BITS PER BASE and stay owned by the caller (see
+   include/fastk_amd.h): nothing is unpacked, the splitter's tile loader reads the codes. */
+extern "C" int fk_count_device_packed(fk_ctx *ctx, const void *d_codes, int64_t nbases, const int64_t *d_roff, int64_t nreads,
+                                      const int64_t *d_inv, int64_t ninv, int fetch_table, fk_result *res)
+{ if (ctx == NULL || res == NULL || d_codes == NULL || d_roff == NULL || nreads <= 0 || nbases < 0 || ninv < 0
+      || (ninv > 0 && d_inv == NULL))
+    return (FK_EINVAL);
+  if (((uintptr_t) d_codes & 3) != 0)
+    { fk_set_error(ctx, "fk_count_device_packed: the codes must be 4-byte aligned");
+      return (FK_EINVAL);
+    }
+  if (ctx->prm.exact_parts)
+    { fk_set_error(ctx, "fk_count_device_packed: exact_parts needs reads pushed with fk_push_block / fk_push_packed");
+      return (FK_EUNSUPPORTED);
+    }
+  FK_HIP(ctx, hipSetDevice(ctx->device));
+  fk_pkview pv;
+  pv.roff = d_roff; pv.nreads = nreads; pv.inv = d_inv; pv.ninv = ninv;
+  return fkx_pipeline(ctx, d_codes, nbases, NULL, 0, res, fetch_table != 0, NULL, 0, &pv);
 }
 
 /* Sort + expand + sort + count over super-mer records that are already in HBM (the records a

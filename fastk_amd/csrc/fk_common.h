@@ -14,7 +14,31 @@
 typedef unsigned long long u64;
 typedef unsigned int       u32;
 
-#define FK_NSLOTS 49
+#define FK_NSLOTS 52
+
+// Reads in two bits per base (fk_push_packed, fk_count_device_packed): the splitter's tile loader reads this form
+// directly.  codes = 16 bases per little-endian dword, the first base in the two high bits of the first byte (a c g t =
+// 0 1 2 3, the .ktab encoding) -- no terminators: read r is the positions roff[r] .. roff[r+1]-1, and a k-mer is valid
+// when it lies inside one read and touches none of the stretches inv[2j] .. inv[2j] + inv[2j+1] - 1 (sorted, disjoint:
+// N runs, the padding behind a pushed block).  Passed beside (d_bases = codes, nbytes = positions) to the fkx_split*
+// entry points; NULL there means 0-terminated ASCII reads.
+struct fk_pkview
+{ const int64_t *roff;      // [nreads + 1], device
+  int64_t        nreads;
+  const int64_t *inv;       // [2 * ninv] (first position, length), device
+  int64_t        ninv;
+};
+
+// the packed reads a context was pushed (one store per read buffer: a chunk fills while the previous one is split)
+struct fk_pkstore
+{ int64_t *roff;            // device
+  int64_t  roff_cap;        // entries
+  int64_t  nreads;
+  int64_t *inv;             // device, pairs
+  int64_t  inv_cap;         // pairs
+  int64_t  ninv;
+  int64_t  npos;            // positions used in the read buffer (a multiple of 16 after every push)
+};
 
 // Minimizers are canonical 7-mers ordered by a bijective mix of their 14-bit code (odd multiplies and
 // xor-shifts are invertible mod 2^14, so distinct 7-mers never tie): FK_NRANKS rank values, of which
@@ -65,6 +89,8 @@ struct fk_block       // one fk_push_block call: which input thread, how many re
 { int      tid;
   int      rem;      // > 0: the block's last read continues in the thread's next block
   int64_t  nreads;
+  int64_t  pk_pos, pk_nbases, pk_read0, pk_inv0, pk_ninv;   // fk_push_packed: first position, bases, first read, first stretch
+                                                            // and stretches of the block in the store
 };
 
 struct fk_ctx
@@ -116,8 +142,15 @@ struct fk_ctx
   bool       exact_tran_set;
   bool       pf_own_reads;            // fk_make_profiles is encoding the pushed reads themselves
   int64_t    exact_wfirst[256];       // first-byte census of bucket 0's weighted k-mers (Table_Split's input)
-  char      *d_pk, *h_pk;   // fk_push_packed: staging for codes, read offsets and invalid stretches (device / pinned)
-  int64_t    pk_cap;
+  // fk_push_packed: the reads stay in two bits per base -- the codes in d_reads (reads_len counts its bytes), read
+  // offsets and invalid stretches in pk[pk_cur] (pk[pk_cur ^ 1] belongs to the chunk the flush helper is splitting)
+  bool       pk_mode;       // the reads pushed so far are packed (a run takes its reads in ONE form)
+  int        pk_cur;
+  struct fk_pkstore pk[2];
+  int64_t   *h_pk;          // pinned staging of a push's offsets + stretches
+  int64_t    h_pk_cap;      // bytes
+  int64_t    pk_ascii_len;  // bytes the reads pushed so far take as 0-terminated ASCII (what fkx_unpack_store restores)
+  int        push_form;     // 0: nothing pushed yet, 1: ASCII / text pushes, 2: fk_push_packed (until fk_reset)
   // fk_finish_device: where every ib-byte prefix of the sorted table ends (the index of the .ktab stub), for
   // fk_write_ktab_device; valid for a table of ktab_ends_ntab entries
   int64_t   *ktab_ends;
@@ -207,7 +240,8 @@ enum { FK_SLOT_SM_A = 0, FK_SLOT_SM_B, FK_SLOT_KM_A, FK_SLOT_KM_B, FK_SLOT_EX_HE
        FK_SLOT_RX_TILE, FK_SLOT_RX_CHUNK, FK_SLOT_RX_SUPER, FK_SLOT_ROFF, FK_SLOT_AG_BOUNDS, FK_SLOT_TABLE, FK_SLOT_SM_G,
        FK_SLOT_RAW, FK_SLOT_FQ_INFO, FK_SLOT_FQ_PHASE, FK_SLOT_FQ_OFF, FK_SLOT_TIE_A, FK_SLOT_TIE_B,
        FK_SLOT_TIE_POS, FK_SLOT_SM_D, FK_SLOT_PF_IDX, FK_SLOT_PF_CNT, FK_SLOT_PF_ZC, FK_SLOT_PF_ZO,
-       FK_SLOT_PF_ENDS, FK_SLOT_PF_LEN, FK_SLOT_PF_OFF, FK_SLOT_PF_OUT, FK_SLOT_ENT, FK_SLOT_TENT, FK_SLOT_TCNT, FK_SLOT_CBASE, FK_SLOT_PF_RID };
+       FK_SLOT_PF_ENDS, FK_SLOT_PF_LEN, FK_SLOT_PF_OFF, FK_SLOT_PF_OUT, FK_SLOT_ENT, FK_SLOT_TENT, FK_SLOT_TCNT, FK_SLOT_CBASE, FK_SLOT_PF_RID,
+       FK_SLOT_PK_TIDX, FK_SLOT_PK_ASCII };
 
 // returns a device buffer of at least nbytes for the given purpose (NULL + error set on failure)
 void *fk_slot(fk_ctx *ctx, int slot, int64_t nbytes);
@@ -232,8 +266,9 @@ int fkx_group(fk_ctx *ctx, int64_t nelem, void *d_src, void *d_trg, int rsize, i
               int npasses, void **result);
 int fkx_split(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int64_t cap,
               int64_t *nsuper, int64_t *ninst, int64_t *bucket_counts, bool counts_known,
-              void *d_pos = NULL);
-int fkx_split_plan(fk_ctx *ctx, const void *d_bases, int64_t nbytes, int64_t *cap, int64_t *offsets);
+              void *d_pos = NULL, const fk_pkview *pk = NULL);
+int fkx_split_plan(fk_ctx *ctx, const void *d_bases, int64_t nbytes, int64_t *cap, int64_t *offsets,
+                   const fk_pkview *pk = NULL);
 // wall clock in seconds (phase timers of verbose runs)
 static inline double fk_wall(void)
 { struct timespec ts;
@@ -250,7 +285,8 @@ int   fkx_flush_chunk(fk_ctx *ctx, bool async = false, bool carry = false);
 int fkx_ktab_prepare(fk_ctx *ctx, int64_t ntable);          // fk_ktab_device.hip
 
 int fkx_split_planned(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int64_t cap,
-                      const int64_t *offsets, int64_t *counts, int64_t *ninst, int b0 = 0, int b1 = -1, int mode = 0);
+                      const int64_t *offsets, int64_t *counts, int64_t *ninst, int b0 = 0, int b1 = -1, int mode = 0,
+                      const fk_pkview *pk = NULL);
 int fkx_train_tran(fk_ctx *ctx, const void *d_bases, const int64_t *h_roff, int64_t train_reads,
                    int nthreads, int *tran);
 int fkx_train_scheme(fk_ctx *ctx, const void *d_bases, const int64_t *d_roff, int64_t train, const int *tran,
@@ -260,7 +296,7 @@ int fkx_split_exact(fk_ctx *ctx, const void *d_bases, const int64_t *d_roff, int
                     int64_t *bucket_offs);
 int fkx_first_byte_census(fk_ctx *ctx, const void *d_recs, int64_t n, int rsize, int64_t *census);
 int fkx_split_fast(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void **d_out, int64_t *nsuper,
-                   int64_t *ninst, int64_t *bucket_counts, int64_t *bucket_offsets);
+                   int64_t *ninst, int64_t *bucket_counts, int64_t *bucket_offsets, const fk_pkview *pk = NULL);
 int fkx_expand(fk_ctx *ctx, const void *d_smers, int64_t nsuper, void *d_out, int64_t cap,
                int64_t *nweighted, int64_t *ndistinct, int64_t *overflow, bool reuse_counts = false,
                bool hash_stream = false, bool dedup = false);
@@ -275,8 +311,9 @@ int fkx_aggregate(fk_ctx *ctx, const void *d_grouped, int64_t n, int cutoff, int
                   int64_t *max_inst, int64_t *ndistinct, void *d_table, int64_t cap, int64_t *ntable);
 int fkx_parse_fastq(fk_ctx *ctx, const void *d_raw, int64_t nbytes, int flags, int *phase, void *d_dst,
                     int64_t *nkept, int64_t *nreads);
-int fkx_unpack_reads(fk_ctx *ctx, hipStream_t s, const void *d_codes, int64_t nbases, const int64_t *d_roff, int64_t nreads,
-                     const int64_t *d_inv, int64_t ninv, void *d_dst);
+int fkx_unpack_reads(fk_ctx *ctx, hipStream_t s, const void *d_codes, int64_t pos0, int64_t nbases, const int64_t *d_roff,
+                     int64_t nreads, const int64_t *d_inv, int64_t ninv, void *d_dst);
+int fkx_unpack_store(fk_ctx *ctx, void **d_ascii, int64_t *nbytes);     // fk_ingest.hip: the packed reads of a resident run as ASCII
 int fkx_pack_fixed(fk_ctx *ctx, const void *d_bases, int64_t nreads, u32 read_len, void *d_codes);
 int fkx_parse_fasta(fk_ctx *ctx, const void *d_raw, int64_t nbytes, int state, void *d_dst,
                     int64_t *nkept, int64_t *nrecs);

@@ -13,6 +13,16 @@
 static inline hipStream_t push_stream(fk_ctx *ctx)
 { return (ctx->chunk_bytes > 0 ? ctx->copy_stream : ctx->stream); }
 
+// A run takes its reads in one form: 0-terminated ASCII / text (1) or two bits per base (2), until fk_reset.
+static int push_form(fk_ctx *ctx, int form)
+{ if (ctx->push_form != 0 && ctx->push_form != form)
+    { fk_set_error(ctx, "the reads of a run come in one form: fk_push_packed and the ASCII / text pushes do not mix (fk_reset starts a new run)");
+      return (FK_ESTATE);
+    }
+  ctx->push_form = form;
+  return (FK_OK);
+}
+
 static int reserve_reads(fk_ctx *ctx, int64_t extra)
 { const int64_t need = ctx->reads_len + extra + 64;
   if (need <= ctx->reads_cap)
@@ -126,7 +136,7 @@ void *fkx_slab_alloc(fk_ctx *ctx, int64_t bytes)
 // Split `len` bytes of reads at `buf` into super-mers grouped by bucket and keep those (compacted)
 // as a chunk: with hbm_budget set, the ASCII reads never have to be resident as a whole.  Runs on
 // ctx->stream; called by the flush helper thread or, with no helper running, by the pushing thread.
-static int flush_buffer(fk_ctx *ctx, const char *buf, int64_t len)
+static int flush_buffer(fk_ctx *ctx, const char *buf, int64_t len, const fk_pkstore *st = NULL)
 { const int stride = ctx->wid.smer_stride;
   hipStream_t s = ctx->stream;
   if (len == 0)
@@ -134,7 +144,10 @@ static int flush_buffer(fk_ctx *ctx, const char *buf, int64_t len)
   void   *out = NULL;
   int64_t ns = 0, ni = 0, bc[256], bo[256];
   const auto tc0 = std::chrono::steady_clock::now();
-  int rc = fkx_split_fast(ctx, buf, len, &out, &ns, &ni, bc, bo);
+  fk_pkview pv;                                  // packed reads: len counts positions
+  if (st != NULL)
+    { pv.roff = st->roff; pv.nreads = st->nreads; pv.inv = st->inv; pv.ninv = st->ninv; }
+  int rc = fkx_split_fast(ctx, buf, len, &out, &ns, &ni, bc, bo, (st != NULL) ? &pv : NULL);
   if (rc != FK_OK)
     return (rc);
   const auto tc1 = std::chrono::steady_clock::now();
@@ -226,6 +239,36 @@ int fkx_flush_chunk(fk_ctx *ctx, bool async, bool carry)
     return (rc);
   char   *buf = ctx->d_reads;
   int64_t len = ctx->reads_len;
+  fk_pkstore *st = (ctx->push_form == 2) ? &ctx->pk[ctx->pk_cur] : NULL;
+  if (st != NULL)
+    { // packed reads: the chunk is the store of the current buffer; the other store takes the next chunk's reads
+      len = st->npos;
+      if (!async)
+        { FK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+          FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+          ctx->reads_len = 0;
+          rc = flush_buffer(ctx, buf, len, st);
+          st->nreads = st->ninv = st->npos = 0;
+          return (rc);
+        }
+      FK_HIP(ctx, hipEventRecord(ctx->reads_ev, ctx->copy_stream));
+      std::swap(ctx->d_reads, ctx->d_reads_alt);
+      std::swap(ctx->reads_cap, ctx->reads_cap_alt);
+      ctx->reads_len = 0;
+      ctx->pk_cur ^= 1;
+      ctx->pk[ctx->pk_cur].nreads = ctx->pk[ctx->pk_cur].ninv = ctx->pk[ctx->pk_cur].npos = 0;
+      ctx->flush_rc = FK_OK;
+      ctx->flush_thread = new std::thread([ctx, buf, len, st]()
+        { int r = FK_EHIP;
+          if (hipSetDevice(ctx->device) == hipSuccess
+              && hipStreamWaitEvent(ctx->stream, ctx->reads_ev, 0) == hipSuccess)
+            r = flush_buffer(ctx, buf, len, st);
+          if (r != FK_OK)
+            memcpy(ctx->flush_err, ctx->err, sizeof(ctx->flush_err));
+          ctx->flush_rc = r;
+        });
+      return (FK_OK);
+    }
   if (!async)
     { FK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
       FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -290,7 +333,7 @@ extern "C" int fk_push_block(fk_ctx *ctx, const char *bases, const int32_t *boff
   pthread_mutex_lock((pthread_mutex_t *) ctx->push_lock);
   do
     { hipSetDevice(ctx->device);
-      if ((rc = reserve_reads(ctx, len)) != FK_OK)
+      if ((rc = push_form(ctx, 1)) != FK_OK || (rc = reserve_reads(ctx, len)) != FK_OK)
         break;
       hipStream_t ps = push_stream(ctx);
       // blocks that lie in pinned host memory are copied from where they are
@@ -378,8 +421,40 @@ extern "C" int fk_push_block(fk_ctx *ctx, const char *bases, const int32_t *boff
   return (rc);
 }
 
-/* The reads of a DATA_BLOCK in two bits per base (see include/fastk_amd.h): unpacked on the device into the read
-   buffer fk_push_block fills, a quarter of the bytes over PCIe. */
+// room for `nreads` more reads and `ninv` more stretches in a packed store (contents kept)
+static int pk_reserve(fk_ctx *ctx, fk_pkstore *st, int64_t nreads, int64_t ninv, hipStream_t ps)
+{ if (st->nreads + nreads + 1 > st->roff_cap)
+    { const int64_t ncap = std::max<int64_t>(st->nreads + nreads + 1, st->roff_cap * 2 + (1 << 16));
+      int64_t *n = NULL;
+      FK_HIP(ctx, hipStreamSynchronize(ps));
+      FK_HIP(ctx, hipMalloc((void **) &n, (size_t) ncap * 8));
+      if (st->roff != NULL)
+        { if (st->nreads > 0)
+            FK_HIP(ctx, hipMemcpy(n, st->roff, (size_t) (st->nreads + 1) * 8, hipMemcpyDeviceToDevice));
+          FK_HIP(ctx, hipFree(st->roff));
+        }
+      st->roff = n; st->roff_cap = ncap;
+    }
+  if (st->ninv + ninv > st->inv_cap)
+    { const int64_t ncap = std::max<int64_t>(st->ninv + ninv, st->inv_cap * 2 + (1 << 12));
+      int64_t *n = NULL;
+      FK_HIP(ctx, hipStreamSynchronize(ps));
+      FK_HIP(ctx, hipMalloc((void **) &n, (size_t) ncap * 16));
+      if (st->inv != NULL)
+        { if (st->ninv > 0)
+            FK_HIP(ctx, hipMemcpy(n, st->inv, (size_t) st->ninv * 16, hipMemcpyDeviceToDevice));
+          FK_HIP(ctx, hipFree(st->inv));
+        }
+      st->inv = n; st->inv_cap = ncap;
+    }
+  return (FK_OK);
+}
+
+/* The reads of a DATA_BLOCK in two bits per base (see include/fastk_amd.h).  They STAY packed: the codes are copied
+   behind those of the earlier blocks (every block starts on a dword: up to 15 positions of padding behind a block,
+   listed as one more stretch without acgt), the read offsets and the stretches go to the store's two sorted lists,
+   and the splitter's tile loader reads that form (fk_split.hip, PACKED kernels).  Nothing is unpacked on the counting
+   path; exact_parts runs and fk_make_profiles restore the ASCII reads on demand (fkx_unpack_store). */
 extern "C" int fk_push_packed(fk_ctx *ctx, const uint8_t *codes, int64_t nbases, const int32_t *rlen, int nreads,
                               const int64_t *inv, int ninv, int rem, int tid)
 { if (ctx == NULL || nreads < 0 || nbases < 0 || ninv < 0 || (nbases > 0 && codes == NULL) || (nreads > 0 && rlen == NULL)
@@ -391,59 +466,74 @@ extern "C" int fk_push_packed(fk_ctx *ctx, const uint8_t *codes, int64_t nbases,
     { fk_set_error(ctx, "fk_push_packed: -bc needs the ASCII form (fk_push_block)");
       return (FK_EUNSUPPORTED);
     }
-  const int64_t len = nbases + nreads;                   // bases + terminators
-  const int64_t cbytes = ((nbases + 3) / 4 + 3) & ~3ll;  // the kernel reads whole dwords
+  const int64_t npos   = (nbases + 15) & ~15ll;          // positions the block takes
+  const int64_t cbytes = (nbases + 3) / 4;
   int rc = FK_OK;
   pthread_mutex_lock((pthread_mutex_t *) ctx->push_lock);
   do
     { hipSetDevice(ctx->device);
-      if ((rc = reserve_reads(ctx, len)) != FK_OK)
+      if ((rc = push_form(ctx, 2)) != FK_OK || (rc = reserve_reads(ctx, npos / 4)) != FK_OK)
         break;
       hipStream_t ps = push_stream(ctx);
-      // staging on the device: codes | read offsets | invalid stretches (stream-ordered: the previous block's
-      // kernels are done with it before this block's copies land)
-      const int64_t off_roff = (cbytes + 15) & ~15ll, off_inv = off_roff + ((int64_t) nreads + 1) * 8;
-      const int64_t need = off_inv + (int64_t) ninv * 16 + 16;
-      if (ctx->pk_cap < need)
+      fk_pkstore *st = &ctx->pk[ctx->pk_cur];
+      const int pad = (npos > nbases) ? 1 : 0;
+      if ((rc = pk_reserve(ctx, st, nreads, (int64_t) ninv + pad, ps)) != FK_OK)
+        break;
+      // pinned staging for the two lists, sized on its own (a later block may bring fewer bases and more reads)
+      const int64_t hneed = ((int64_t) nreads + 1) * 8 + ((int64_t) ninv + 1) * 16;
+      if (ctx->h_pk_cap < hneed)
         { if (hipStreamSynchronize(ps) != hipSuccess) { rc = FK_EHIP; break; }
-          if (ctx->d_pk) hipFree(ctx->d_pk);
           if (ctx->h_pk) hipHostFree(ctx->h_pk);
-          ctx->d_pk = NULL; ctx->h_pk = NULL; ctx->pk_cap = 0;
-          const int64_t cap = need + need / 4;
-          if (hipMalloc((void **) &ctx->d_pk, (size_t) cap) != hipSuccess
-              || hipHostMalloc((void **) &ctx->h_pk, (size_t) (cap - off_roff + 64), hipHostMallocDefault) != hipSuccess)
-            { fk_set_error(ctx, "fk_push_packed: out of memory for %lld bytes of staging", (long long) cap);
+          ctx->h_pk = NULL; ctx->h_pk_cap = 0;
+          const int64_t cap = hneed + hneed / 2 + 4096;
+          if (hipHostMalloc((void **) &ctx->h_pk, (size_t) cap, hipHostMallocDefault) != hipSuccess)
+            { fk_set_error(ctx, "fk_push_packed: out of memory for %lld bytes of pinned staging", (long long) cap);
               rc = FK_ENOMEM;
               break;
             }
-          ctx->pk_cap = cap;
+          ctx->h_pk_cap = cap;
         }
-      if (hipStreamSynchronize(ps) != hipSuccess) { rc = FK_EHIP; break; }    // h_pk is free again
-      int64_t *hro = (int64_t *) ctx->h_pk;
+      const int64_t base = st->npos;
+      int64_t *hro = ctx->h_pk, *hinv = ctx->h_pk + nreads + 1;
       int64_t  run = 0;
       for (int i = 0; i < nreads; i++)
         { if (rlen[i] < 0) { rc = FK_EINVAL; break; }
-          hro[i] = run;
+          hro[i] = base + run;
           run += rlen[i];
         }
-      hro[nreads] = run;
+      hro[nreads] = base + npos;                         // the next block's first read (the padding lies in front of it)
       if (rc != FK_OK || run != nbases)
         { fk_set_error(ctx, "fk_push_packed: the read lengths add up to %lld, not to %lld bases", (long long) run, (long long) nbases);
           rc = FK_EINVAL;
           break;
         }
-      if (ninv > 0)
-        memcpy(hro + nreads + 1, inv, (size_t) ninv * 16);
-      if ((nbases > 0 && hipMemcpyAsync(ctx->d_pk, codes, (size_t) ((nbases + 3) / 4), hipMemcpyHostToDevice, ps) != hipSuccess)
-          || hipMemcpyAsync(ctx->d_pk + off_roff, hro, (size_t) (((int64_t) nreads + 1) * 8 + (int64_t) ninv * 16),
-                            hipMemcpyHostToDevice, ps) != hipSuccess)
+      { int64_t prev = 0;                                // sorted, disjoint, inside the block
+        for (int j = 0; j < ninv && rc == FK_OK; j++)
+          { const int64_t s0 = inv[2 * j], n0 = inv[2 * j + 1];
+            if (s0 < prev || n0 <= 0 || s0 + n0 > nbases)
+              { fk_set_error(ctx, "fk_push_packed: stretch %d (%lld, %lld) is out of order or outside the block's %lld bases",
+                             j, (long long) s0, (long long) n0, (long long) nbases);
+                rc = FK_EINVAL;
+              }
+            hinv[2 * j] = base + s0;
+            hinv[2 * j + 1] = n0;
+            prev = s0 + n0;
+          }
+        if (rc != FK_OK)
+          break;
+        if (pad)
+          { hinv[2 * ninv] = base + nbases;
+            hinv[2 * ninv + 1] = npos - nbases;
+          }
+      }
+      if ((cbytes > 0 && hipMemcpyAsync(ctx->d_reads + ctx->reads_len, codes, (size_t) cbytes, hipMemcpyHostToDevice, ps) != hipSuccess)
+          || hipMemcpyAsync(st->roff + st->nreads, hro, (size_t) (nreads + 1) * 8, hipMemcpyHostToDevice, ps) != hipSuccess
+          || (ninv + pad > 0
+              && hipMemcpyAsync(st->inv + 2 * st->ninv, hinv, (size_t) (ninv + pad) * 16, hipMemcpyHostToDevice, ps) != hipSuccess))
         { fk_set_error(ctx, "fk_push_packed: host to device copy failed");
           rc = FK_EHIP;
           break;
         }
-      if ((rc = fkx_unpack_reads(ctx, ps, ctx->d_pk, nbases, (const int64_t *) (ctx->d_pk + off_roff), nreads,
-                                 (const int64_t *) (ctx->d_pk + off_inv), ninv, ctx->d_reads + ctx->reads_len)) != FK_OK)
-        break;
       if (hipStreamSynchronize(ps) != hipSuccess)          // the caller may reuse its buffers once we return
         { rc = FK_EHIP; break; }
       if (ctx->prm.exact_parts)
@@ -452,25 +542,60 @@ extern "C" int fk_push_packed(fk_ctx *ctx, const uint8_t *codes, int64_t nbases,
               ctx->h_roff = (int64_t *) realloc(ctx->h_roff, sizeof(int64_t) * (size_t) ctx->roff_cap);
               if (ctx->h_roff == NULL) { rc = FK_ENOMEM; break; }
             }
-          for (int i = 0; i < nreads; i++)
-            ctx->h_roff[ctx->nroff++] = ctx->reads_len + hro[i] + i;
+          for (int i = 0; i < nreads; i++)                 // where the read starts in the restored ASCII
+            ctx->h_roff[ctx->nroff++] = ctx->pk_ascii_len + (hro[i] - base) + i;
         }
-      ctx->reads_len += len;
       if (ctx->nblocks == ctx->blocks_cap)
         { ctx->blocks_cap = ctx->blocks_cap * 2 + 256;
           ctx->blocks = (fk_block *) realloc(ctx->blocks, sizeof(fk_block) * (size_t) ctx->blocks_cap);
           if (ctx->blocks == NULL) { ctx->nblocks = ctx->blocks_cap = 0; rc = FK_ENOMEM; break; }
         }
-      ctx->blocks[ctx->nblocks].tid = tid;
-      ctx->blocks[ctx->nblocks].rem = rem;
-      ctx->blocks[ctx->nblocks].nreads = nreads;
+      fk_block *bl = &ctx->blocks[ctx->nblocks];
+      bl->tid = tid; bl->rem = rem; bl->nreads = nreads;
+      bl->pk_pos = base; bl->pk_nbases = nbases; bl->pk_read0 = st->nreads; bl->pk_inv0 = st->ninv; bl->pk_ninv = ninv;
       ctx->nblocks += 1;
-      if (ctx->chunk_bytes > 0 && ctx->reads_len >= ctx->chunk_bytes)
+      ctx->reads_len += npos / 4;
+      ctx->pk_ascii_len += nbases + nreads;
+      st->nreads += nreads;
+      st->ninv   += ninv + pad;
+      st->npos   += npos;
+      if (ctx->chunk_bytes > 0 && st->npos >= ctx->chunk_bytes)
         rc = fkx_flush_chunk(ctx, true);
     }
   while (0);
   pthread_mutex_unlock((pthread_mutex_t *) ctx->push_lock);
   return (rc);
+}
+
+/* The packed reads of a resident run (no chunk was flushed) as 0-terminated ASCII in an arena slot, block by block:
+   for the consumers that walk reads byte by byte (exact_parts, fk_make_profiles). */
+int fkx_unpack_store(fk_ctx *ctx, void **d_ascii, int64_t *nbytes)
+{ *d_ascii = NULL; *nbytes = 0;
+  if (ctx->push_form != 2)
+    return (FK_ESTATE);
+  const fk_pkstore *st = &ctx->pk[ctx->pk_cur];
+  const int64_t len = ctx->pk_ascii_len;
+  char *dst = (char *) fk_slot(ctx, FK_SLOT_PK_ASCII, len + 64);
+  if (dst == NULL)
+    return (FK_ENOMEM);
+  hipStream_t s = ctx->stream;
+  FK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+  int64_t at = 0;
+  for (int64_t b = 0; b < ctx->nblocks; b++)
+    { const fk_block *bl = &ctx->blocks[b];
+      const int rc = fkx_unpack_reads(ctx, s, ctx->d_reads, bl->pk_pos, bl->pk_nbases, st->roff + bl->pk_read0, bl->nreads,
+                                      st->inv + 2 * bl->pk_inv0, bl->pk_ninv, dst + at);
+      if (rc != FK_OK)
+        return (rc);
+      at += bl->pk_nbases + bl->nreads;
+    }
+  if (at != len)
+    { fk_set_error(ctx, "internal: %lld bytes of reads restored, %lld expected", (long long) at, (long long) len);
+      return (FK_EHIP);
+    }
+  *d_ascii = dst;
+  *nbytes = len;
+  return (FK_OK);
 }
 
 extern "C" int fk_train_block(fk_ctx *ctx, const char *bases, const int32_t *boff, int nreads)
@@ -507,7 +632,7 @@ extern "C" int fk_push_device(fk_ctx *ctx, const void *d_bases, int64_t nbytes)
   ctx->blocks_bad = true;
   int rc;
   pthread_mutex_lock((pthread_mutex_t *) ctx->push_lock);
-  if ((rc = device_push_begin(ctx)) == FK_OK && (rc = reserve_reads(ctx, nbytes + 1)) == FK_OK)
+  if ((rc = push_form(ctx, 1)) == FK_OK && (rc = device_push_begin(ctx)) == FK_OK && (rc = reserve_reads(ctx, nbytes + 1)) == FK_OK)
     { if (hipMemcpyAsync(ctx->d_reads + ctx->reads_len, d_bases, (size_t) nbytes,
                          hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess
           || hipMemsetAsync(ctx->d_reads + ctx->reads_len + nbytes, 0, 1, ctx->stream) != hipSuccess)
@@ -540,7 +665,7 @@ extern "C" int fk_push_fastq(fk_ctx *ctx, const char *raw, int64_t nbytes, int f
   pthread_mutex_lock((pthread_mutex_t *) ctx->push_lock);
   do
     { hipSetDevice(ctx->device);
-      if ((rc = device_push_begin(ctx)) != FK_OK || (rc = reserve_reads(ctx, nbytes + 16)) != FK_OK)
+      if ((rc = push_form(ctx, 1)) != FK_OK || (rc = device_push_begin(ctx)) != FK_OK || (rc = reserve_reads(ctx, nbytes + 16)) != FK_OK)
         break;
       void *d_raw = fk_slot(ctx, FK_SLOT_RAW, nbytes + 64);
       if (d_raw == NULL) { rc = FK_ENOMEM; break; }
@@ -583,7 +708,7 @@ extern "C" int fk_push_fasta(fk_ctx *ctx, const char *raw, int64_t nbytes, int l
   pthread_mutex_lock((pthread_mutex_t *) ctx->push_lock);
   do
     { hipSetDevice(ctx->device);
-      if ((rc = device_push_begin(ctx)) != FK_OK || (rc = reserve_reads(ctx, nbytes + 16)) != FK_OK)
+      if ((rc = push_form(ctx, 1)) != FK_OK || (rc = device_push_begin(ctx)) != FK_OK || (rc = reserve_reads(ctx, nbytes + 16)) != FK_OK)
         break;
       int64_t kept = 0, nr = 0;
       if (nbytes > 0)

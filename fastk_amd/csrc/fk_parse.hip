@@ -14,6 +14,7 @@
 //   k_fq_scan   one workgroup: phase and output offset of every tile, totals
 //   k_fq_emit   classify again, compact through LDS, write
 #include "fk_common.h"
+#include <algorithm>
 
 #define FQ_THREADS 256
 #define FQ_PER     64                         // bytes per thread
@@ -489,11 +490,13 @@ int fkx_parse_fasta(fk_ctx *ctx, const void *d_raw, int64_t nbytes, int state, v
 
 
 // ---------------------------------------------------------------------------------------------
-// Reads in two bits per base -> the 0-terminated ASCII reads the splitter takes (fk_push_packed).
-// codes: the bases of the reads back to back, four to a byte, first base in the two high bits (a c g t = 0 1 2 3, the
-// .ktab encoding, README.md:977-984); roff[r] = first base of read r in that concatenation, roff[nreads] = all bases;
-// read r's bases land at dst[roff[r] + r ...], its terminator behind them.  What a FASTA / FASTQ scanner does on
-// the way in (io.c:678-734) minus the text: the host sends a quarter of the bytes over PCIe.
+// Reads in two bits per base -> 0-terminated ASCII reads, for the consumers that walk reads byte by byte (exact_parts,
+// profiles) after the reads came through fk_push_packed -- the counting path splits the packed form directly
+// (fk_split.hip).  One pushed block at a time: codes = the packed read buffer, the block's bases are the positions
+// pos0 .. pos0 + nbases - 1 (four to a byte, first base in the two high bits; a c g t = 0 1 2 3, the .ktab encoding,
+// README.md:977-984; pos0 a multiple of 16); roff[r] = first position of the block's read r, roff[nreads] >= pos0 +
+// nbases (it includes the padding behind the block); read r's bases land at dst[(roff[r] - pos0) + r ...], its
+// terminator behind them.
 #define UP_THREADS 256
 #define UP_BASES   16                      // bases per thread: one dword of codes
 
@@ -506,25 +509,26 @@ __device__ __forceinline__ int64_t up_read_of(const int64_t *__restrict__ roff, 
   return (lo);
 }
 
-__global__ __launch_bounds__(UP_THREADS) void k_up_bases(const unsigned char *__restrict__ codes, int64_t nbases,
+__global__ __launch_bounds__(UP_THREADS) void k_up_bases(const unsigned char *__restrict__ codes, int64_t pos0, int64_t nbases,
                                                          const int64_t *__restrict__ roff, int64_t nreads,
                                                          unsigned char *__restrict__ dst)
 { __shared__ int64_t sh_r[2];
-  const int64_t b0 = (int64_t) blockIdx.x * (UP_THREADS * UP_BASES);
+  const int64_t end = pos0 + nbases;
+  const int64_t b0 = pos0 + (int64_t) blockIdx.x * (UP_THREADS * UP_BASES);
   if (threadIdx.x < 2)
-    { const int64_t pos = (threadIdx.x == 0) ? b0 : min(b0 + UP_THREADS * UP_BASES, nbases) - 1;
+    { const int64_t pos = (threadIdx.x == 0) ? b0 : min(b0 + UP_THREADS * UP_BASES, end) - 1;
       sh_r[threadIdx.x] = up_read_of(roff, 0, nreads - 1, pos);
     }
   __syncthreads();
   const int64_t pos = b0 + (int64_t) threadIdx.x * UP_BASES;
-  if (pos >= nbases)
+  if (pos >= end)
     return;
-  const u32 c4 = *(const u32 *) (codes + (pos >> 2));            // codes is padded to a dword multiple
+  const u32 c4 = *(const u32 *) (codes + (pos >> 2));            // the buffer is padded to a dword multiple
   int64_t r = up_read_of(roff, sh_r[0], sh_r[1], pos);
-  const int64_t last = min(pos + UP_BASES, nbases);
+  const int64_t last = min(pos + UP_BASES, end);
   if (roff[r + 1] >= last)
     { // the whole group lies in one read: four dwords, wherever the read's shift puts them
-      unsigned char *o = dst + pos + r;
+      unsigned char *o = dst + (pos - pos0) + r;
       const int n = (int) (last - pos);
       u32 w[4];
 #pragma unroll
@@ -554,30 +558,31 @@ __global__ __launch_bounds__(UP_THREADS) void k_up_bases(const unsigned char *__
         r += 1;
       const u32 byte = (c4 >> (8 * ((i - pos) >> 2))) & 0xffu;
       const u32 code = (byte >> (6 - 2 * ((i - pos) & 3))) & 3u;
-      dst[i + r] = (unsigned char) ((0x74676361u >> (8 * code)) & 0xffu);
+      dst[(i - pos0) + r] = (unsigned char) ((0x74676361u >> (8 * code)) & 0xffu);
     }
 }
 
-__global__ __launch_bounds__(256) void k_up_ends(const int64_t *__restrict__ roff, int64_t nreads,
+__global__ __launch_bounds__(256) void k_up_ends(const int64_t *__restrict__ roff, int64_t nreads, int64_t pos0, int64_t nbases,
                                                  unsigned char *__restrict__ dst)
 { const int64_t r = (int64_t) blockIdx.x * 256 + threadIdx.x;
   if (r < nreads)
-    dst[roff[r + 1] + r] = 0;
+    dst[min(roff[r + 1] - pos0, nbases) + r] = 0;               // (the last read's entry lies behind the block's padding)
 }
 
-// inv: pairs (first base, length) of stretches that hold no acgt: 'n' there (one workgroup per stretch)
+// inv: pairs (first position, length) of stretches that hold no acgt: 'n' there (one workgroup per stretch); the pairs
+// outside [pos0, pos0 + nbases) -- other blocks', the padding -- do nothing
 __global__ __launch_bounds__(256) void k_up_invalid(const int64_t *__restrict__ inv, const int64_t *__restrict__ roff,
-                                                    int64_t nreads, int64_t nbases, unsigned char *__restrict__ dst)
+                                                    int64_t nreads, int64_t pos0, int64_t nbases, unsigned char *__restrict__ dst)
 { const int64_t s = inv[2 * (int64_t) blockIdx.x], n = inv[2 * (int64_t) blockIdx.x + 1];
-  for (int64_t i = s + threadIdx.x; i < s + n && i < nbases; i += 256)
-    if (i >= 0)
-      dst[i + up_read_of(roff, 0, nreads - 1, i)] = 'n';
+  for (int64_t i = s + threadIdx.x; i < s + n && i < pos0 + nbases; i += 256)
+    if (i >= pos0)
+      dst[(i - pos0) + up_read_of(roff, 0, nreads - 1, i)] = 'n';
 }
 
-/* d_codes (padded to a multiple of 4 bytes), d_roff[nreads + 1], d_inv[2 ninv] on the device; writes nbases + nreads
-   bytes at d_dst on stream s. */
-int fkx_unpack_reads(fk_ctx *ctx, hipStream_t s, const void *d_codes, int64_t nbases, const int64_t *d_roff, int64_t nreads,
-                     const int64_t *d_inv, int64_t ninv, void *d_dst)
+/* One pushed block of the packed read buffer d_codes -> nbases + nreads bytes of ASCII at d_dst, on stream s; d_roff
+   [nreads + 1] and d_inv [2 ninv] on the device (d_inv may hold any superset of the block's stretches). */
+int fkx_unpack_reads(fk_ctx *ctx, hipStream_t s, const void *d_codes, int64_t pos0, int64_t nbases, const int64_t *d_roff,
+                     int64_t nreads, const int64_t *d_inv, int64_t ninv, void *d_dst)
 { if (nreads <= 0)
     return (FK_OK);
   if (nbases > 0)
@@ -586,13 +591,13 @@ int fkx_unpack_reads(fk_ctx *ctx, hipStream_t s, const void *d_codes, int64_t nb
         { fk_set_error(ctx, "fk_push_packed: block too large");
           return (FK_EINVAL);
         }
-      hipLaunchKernelGGL(k_up_bases, dim3((unsigned) nb), dim3(UP_THREADS), 0, s, (const unsigned char *) d_codes, nbases,
+      hipLaunchKernelGGL(k_up_bases, dim3((unsigned) nb), dim3(UP_THREADS), 0, s, (const unsigned char *) d_codes, pos0, nbases,
                          d_roff, nreads, (unsigned char *) d_dst);
     }
-  hipLaunchKernelGGL(k_up_ends, dim3((unsigned) ((nreads + 255) / 256)), dim3(256), 0, s, d_roff, nreads,
+  hipLaunchKernelGGL(k_up_ends, dim3((unsigned) ((nreads + 255) / 256)), dim3(256), 0, s, d_roff, nreads, pos0, nbases,
                      (unsigned char *) d_dst);
   if (ninv > 0)
-    hipLaunchKernelGGL(k_up_invalid, dim3((unsigned) ninv), dim3(256), 0, s, d_inv, d_roff, nreads, nbases,
+    hipLaunchKernelGGL(k_up_invalid, dim3((unsigned) ninv), dim3(256), 0, s, d_inv, d_roff, nreads, pos0, nbases,
                        (unsigned char *) d_dst);
   FK_LAUNCH_CHECK(ctx);
   return (FK_OK);
@@ -601,8 +606,8 @@ int fkx_unpack_reads(fk_ctx *ctx, hipStream_t s, const void *d_codes, int64_t nb
 
 // The inverse for reads of one length (measurement helper beside fk_synth_reads): rows of read_len + 1 bytes -> codes.
 __global__ __launch_bounds__(256) void k_pack_fixed(const unsigned char *__restrict__ src, int64_t nbases, u32 read_len,
-                                                    unsigned char *__restrict__ codes)
-{ const int64_t o = (int64_t) blockIdx.x * 256 + threadIdx.x;          // output byte
+                                                    unsigned char *__restrict__ codes, int64_t block0)
+{ const int64_t o = (block0 + (int64_t) blockIdx.x) * 256 + threadIdx.x;          // output byte
   if (o * 4 >= nbases)
     return;
   u32 b = 0;
@@ -624,10 +629,9 @@ int fkx_pack_fixed(fk_ctx *ctx, const void *d_bases, int64_t nreads, u32 read_le
   if (nbases <= 0)
     return (FK_OK);
   const int64_t nb = ((nbases + 3) / 4 + 255) / 256;
-  if (nb > 0x7fffffffll)
-    return (FK_EINVAL);
-  hipLaunchKernelGGL(k_pack_fixed, dim3((unsigned) nb), dim3(256), 0, ctx->stream, (const unsigned char *) d_bases, nbases,
-                     read_len, (unsigned char *) d_codes);
+  for (int64_t b0 = 0; b0 < nb; b0 += (1 << 23))        // a launch holds fewer than 2^32 work-items (a larger grid wraps silently)
+    hipLaunchKernelGGL(k_pack_fixed, dim3((unsigned) std::min<int64_t>(nb - b0, 1 << 23)), dim3(256), 0, ctx->stream,
+                       (const unsigned char *) d_bases, nbases, read_len, (unsigned char *) d_codes, b0);
   FK_LAUNCH_CHECK(ctx);
   return (FK_OK);
 }

@@ -244,6 +244,13 @@ extern "C" int fk_make_profiles(fk_ctx *ctx, const void *d_bases, int64_t nbytes
         }
       d_bases = ctx->d_reads;
       nbytes  = ctx->reads_len;
+      if (ctx->push_form == 2)                  // pushed in two bits per base: the look-up kernels walk ASCII reads
+        { void *asc = NULL;
+          const int rcu = fkx_unpack_store(ctx, &asc, &nbytes);
+          if (rcu != FK_OK)
+            return (rcu);
+          d_bases = asc;
+        }
     }
   int64_t nreads = 0, nprof = 0;
   void *d_data = NULL;

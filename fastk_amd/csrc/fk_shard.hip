@@ -24,9 +24,6 @@
 #include <vector>
 #include <algorithm>
 
-int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers_in, int64_t nsmers_in,
-                 fk_result *res, bool fetch_table, int64_t *h_roff, int64_t nreads);
-
 struct fk_rccl
 { ncclResult_t (*GetUniqueId)(ncclUniqueId *);
   ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
@@ -244,7 +241,7 @@ static int reserve_inbox(fk_shard *sh, int i, int64_t bytes)
    res: the GLOBAL histogram, max_inst and totals (identical on every rank), wfirst = first-byte census of
    the whole table, ntable = its entries; res->table is NULL -- every rank's share stays in HBM for
    fk_shard_write.  Returns FK_EHIP with a message if the exchange did not conserve records or k-mers. */
-static int shard_count(fk_shard *sh, const void *d_reads, int64_t reads_len, fk_result *res);
+static int shard_count(fk_shard *sh, const void *d_reads, int64_t reads_len, fk_result *res, const fk_pkview *pk = NULL);
 
 extern "C" int fk_shard_count(fk_shard *sh, fk_result *res)
 { if (sh == NULL || res == NULL) return (FK_EINVAL);
@@ -256,6 +253,14 @@ extern "C" int fk_shard_count(fk_shard *sh, fk_result *res)
     }
   FK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
   FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->push_form == 2)                         // the stripe came through fk_push_packed: split as it is
+    { const fk_pkstore *st = &ctx->pk[ctx->pk_cur];
+      fk_pkview pv;
+      pv.roff = st->roff; pv.nreads = st->nreads; pv.inv = st->inv; pv.ninv = st->ninv;
+      if (st->nreads > 0)
+        return shard_count(sh, ctx->d_reads, st->npos, res, &pv);
+      return shard_count(sh, ctx->d_reads, 0, res);
+    }
   return shard_count(sh, ctx->d_reads, ctx->reads_len, res);
 }
 
@@ -282,7 +287,7 @@ extern "C" int fk_shard_count_device(fk_shard *sh, const void *d_bases, int64_t 
   return shard_count(sh, d_bases, nbytes, res);
 }
 
-static int shard_count(fk_shard *sh, const void *d_reads, int64_t reads_len, fk_result *res)
+static int shard_count(fk_shard *sh, const void *d_reads, int64_t reads_len, fk_result *res, const fk_pkview *pk)
 { fk_ctx *ctx = sh->ctx;
   const int W = sh->world, R = sh->rounds, me = sh->rank, nb = ctx->prm.nbuckets;
   const int stride = ctx->wid.smer_stride;
@@ -292,16 +297,16 @@ static int shard_count(fk_shard *sh, const void *d_reads, int64_t reads_len, fk_
   void   *outbox = NULL;
   memset(cnt, 0, sizeof(cnt));
   memset(offs, 0, sizeof(offs));
-  int rc = fkx_split_plan(ctx, d_reads, reads_len, &cap, offs);
+  int rc = fkx_split_plan(ctx, d_reads, reads_len, &cap, offs, pk);
   if (rc != FK_OK) return (rc);
   if (cap > 0)
     { if ((outbox = fk_slot(ctx, FK_SLOT_SM_A, cap * stride)) == NULL) return (FK_ENOMEM);
-      rc = fkx_split_planned(ctx, d_reads, reads_len, outbox, cap, offs, cnt, &ninst);
+      rc = fkx_split_planned(ctx, d_reads, reads_len, outbox, cap, offs, cnt, &ninst, 0, -1, 0, pk);
       if (rc == FK_ESTATE)
         { int64_t ns = 0;
-          if ((rc = fkx_split(ctx, d_reads, reads_len, NULL, 0, &ns, &ninst, cnt, false)) != FK_OK) return (rc);
+          if ((rc = fkx_split(ctx, d_reads, reads_len, NULL, 0, &ns, &ninst, cnt, false, NULL, pk)) != FK_OK) return (rc);
           if ((outbox = fk_slot(ctx, FK_SLOT_SM_A, std::max<int64_t>(ns, 1) * stride)) == NULL) return (FK_ENOMEM);
-          if (ns > 0 && (rc = fkx_split(ctx, d_reads, reads_len, outbox, ns, &ns, &ninst, cnt, true)) != FK_OK)
+          if (ns > 0 && (rc = fkx_split(ctx, d_reads, reads_len, outbox, ns, &ns, &ninst, cnt, true, NULL, pk)) != FK_OK)
             return (rc);
           int64_t run = 0;
           for (int b = 0; b < nb; b++) { offs[b] = run; run += cnt[b]; }

@@ -84,6 +84,12 @@ struct SplitArgs
   u32       skipb;          // super-mers whose bucket entry equals skipb are dropped (0xFF in a group
                             // pass of a multi-pass split, where mbucket marks the other groups' ranks;
                             // 0x100 = nothing is dropped)
+  // PACKED kernels: `bases` holds two bits per base, 16 bases per dword (fk_pkview in fk_common.h), nbytes = positions
+  const int64_t *roff;      // [nreads + 1] first position of every read
+  int64_t   nreads;
+  const int64_t *inv;       // [2 ninv] (first position, length) of the stretches that hold no acgt
+  int64_t   ninv;
+  const u32 *tidx;          // [tiles][2] first read that ends at or behind the tile's first position, first stretch that does
 };
 
 __device__ __forceinline__ u32 sp_window(const u32 *arr, int off)
@@ -160,11 +166,111 @@ __device__ __forceinline__ u32 sp_key7(u32 fw, u32 rc)
   return (fk_mrank14(min(fw, rc)) << 15);
 }
 
-template <bool EMIT, bool POS = false>
+// valid k-mer starts among the 16 of a thread: no marked position in [i, i + Kw) -- m16[q] bit c marks position 16 q + c
+__device__ __forceinline__ u32 sp_clear_starts(const uint16_t *m16, int tid, int Kw)
+{ if (Kw >= 16)
+    { // the window of start c (in word t) is the rest of word t from bit c, the whole words t+1 .. t+kq-1 and the
+      // first c+kr bits of the word pair (t+kq, t+kq+1), Kw = 16 kq + kr -- so the valid starts of a thread are one
+      // interval [fls(m0), ctz(E) - kr], a dozen instructions per THREAD (the prefix counts this replaces cost 14 per base)
+      const int kq = Kw >> 4, kr = Kw & 15;
+      const u32 m0 = m16[tid];
+      u32 mid = 0;
+      for (int j = 1; j < kq; j++)
+        mid |= m16[tid + j];
+      const u32 E     = (u32) m16[tid + kq] | ((u32) m16[tid + kq + 1] << 16);
+      const int lowc  = 32 - __clz((int) m0);                       // first start past the last marked position of word t
+      const int highc = (E != 0 ? __ffs((int) E) - 1 : 32) - kr;    // last start whose window ends before the next one
+      const u32 up    = (highc >= 15) ? 0xffffu : (highc < 0 ? 0u : ((2u << highc) - 1u));
+      return ((mid != 0) ? 0u : (up & ~((1u << lowc) - 1u) & 0xffffu));
+    }
+  const u32 M = (u32) m16[tid] | ((u32) m16[tid + 1] << 16);
+  const u32 km = (1u << Kw) - 1u;
+  u32 v = 0;
+#pragma unroll
+  for (int c = 0; c < SP_CH; c++)
+    v |= (((M >> c) & km) == 0u ? 1u : 0u) << c;
+  return (v);
+}
+
+// PACKED: tile loader for reads in two bits per base -- the 16 bases of a dword are one byte swap away from the packed
+// word, no base conversion (a sixth of the ASCII kernel's instructions); which positions are unusable comes from two
+// short sorted lists instead of the bytes themselves: the reads' ends (a k-mer must not run across one: the
+// concatenation has no terminators) and the stretches without acgt (their code bits are arbitrary).
+template <bool PACKED>
+__device__ __forceinline__ void sp_load_tile(const SplitArgs &a, int64_t t0, int nw, u32 *fwd, uint16_t *inv16, uint16_t *bnd16)
+{ const int tid = threadIdx.x;
+  if (PACKED)
+    { const u32 *codes = (const u32 *) a.bases;
+      for (int q = tid; q < SP_WORDS; q += SP_THREADS)
+        { u32 word = 0, bad = 0xffffu;
+          if (q < nw)
+            { const int64_t g = t0 + (int64_t) q * 16;
+              if (g < a.nbytes)
+                { word = __builtin_bswap32(codes[g >> 4]);
+                  const int64_t left = a.nbytes - g;
+                  bad = (left >= 16) ? 0u : ((0xffffu << (int) left) & 0xffffu);
+                }
+            }
+          fwd[q]   = word;
+          inv16[q] = (uint16_t) bad;
+          bnd16[q] = 0;
+        }
+      return;
+    }
+  for (int q = tid; q < SP_WORDS; q += SP_THREADS)
+    { u32 word = 0, bad = 0xffffu;
+      if (q < nw)
+        { const int64_t g = t0 + (int64_t) q * 16;
+          uint4 v;
+          if (g + 16 <= a.nbytes)
+            v = *(const uint4 *) (a.bases + g);
+          else
+            { u32 d[4] = { 0u, 0u, 0u, 0u };                   // the last bytes of the input, one by one
+              for (int j = 0; j < 16; j++)
+                if (g + j < a.nbytes)
+                  d[j >> 2] |= (u32) a.bases[g + j] << (8 * (j & 3));
+              v = make_uint4(d[0], d[1], d[2], d[3]);
+            }
+          sp_pack16(v, word, bad);
+        }
+      fwd[q]   = word;
+      inv16[q] = (uint16_t) bad;
+    }
+}
+
+// PACKED, after the barrier behind sp_load_tile: the read ends and invalid stretches that fall into positions
+// [t0, t0 + R) become bits of the two masks (LDS atomics on the u16 arrays viewed as one bitmap; little-endian)
+__device__ __forceinline__ void sp_mark_tile(const SplitArgs &a, int64_t tile, int64_t t0, int R, uint16_t *inv16, uint16_t *bnd16)
+{ const int     tid  = threadIdx.x;
+  const int64_t tend = t0 + R;
+  const u32     r0   = a.tidx[2 * tile], s0 = a.tidx[2 * tile + 1];
+  u32 *bb = (u32 *) bnd16, *ib = (u32 *) inv16;
+  for (int64_t j = (int64_t) r0 + tid; j < a.nreads; j += SP_THREADS)
+    { const int64_t e = a.roff[j + 1] - 1;                      // last position of read j
+      if (e >= tend) break;
+      if (e >= t0)
+        { const int o = (int) (e - t0);
+          atomicOr(&bb[o >> 5], 1u << (o & 31));
+        }
+    }
+  for (int64_t j = (int64_t) s0 + tid; j < a.ninv; j += SP_THREADS)
+    { const int64_t s = a.inv[2 * j], n = a.inv[2 * j + 1];
+      if (s >= tend) break;
+      const int lo = (int) ((s > t0 ? s : t0) - t0), hi = (int) ((s + n < tend ? s + n : tend) - t0);
+      for (int w = lo >> 5; hi > lo && w <= ((hi - 1) >> 5); w++)
+        { const int b0 = (w << 5) > lo ? 0 : lo - (w << 5);
+          const int b1 = ((w + 1) << 5) < hi ? 32 : hi - (w << 5);
+          atomicOr(&ib[w], (u32) ((0xffffffffull >> (32 - (b1 - b0))) << b0));
+        }
+    }
+}
+
+template <bool EMIT, bool POS = false, bool PACKED = false>
 __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
 { __shared__ u32      fwd[SP_WORDS];
   __shared__ u32      rcw[SP_WORDS];
-  __shared__ uint16_t inv16[SP_WORDS];
+  __shared__ __attribute__((aligned(4))) uint16_t inv16[SP_WORDS];
+  __shared__ __attribute__((aligned(4))) uint16_t bnd16[PACKED ? SP_WORDS : 2];   // PACKED: last positions of the reads
   __shared__ __attribute__((aligned(16))) u32 keys[SP_KEYS + SP_KEYS / 16 + 1];   // prefix minima (step 2), then the window minima by position
   __shared__ u32      lastkey[SP_THREADS];                // last window minimum of every thread (step 5); then pos16
   __shared__ uint16_t sbits[SP_THREADS + 16];            // boundary bits: start | invalid
@@ -195,27 +301,11 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
   if (tid < a.nbuckets) bcnt[tid] = 0;
   if (tid == 0) { nother = 0; nother2 = 0; }
 
-  // ---- 1. ASCII -> 2-bit codes (MSB first) + invalid masks -------------------------------
-  for (int q = tid; q < SP_WORDS; q += SP_THREADS)
-    { u32 word = 0, bad = 0xffffu;
-      if (q < nw)
-        { const int64_t g = t0 + (int64_t) q * 16;
-          uint4 v;
-          if (g + 16 <= a.nbytes)
-            v = *(const uint4 *) (a.bases + g);
-          else
-            { u32 d[4] = { 0u, 0u, 0u, 0u };                   // the last bytes of the input, one by one
-              for (int j = 0; j < 16; j++)
-                if (g + j < a.nbytes)
-                  d[j >> 2] |= (u32) a.bases[g + j] << (8 * (j & 3));
-              v = make_uint4(d[0], d[1], d[2], d[3]);
-            }
-          sp_pack16(v, word, bad);
-        }
-      fwd[q]   = word;
-      inv16[q] = (uint16_t) bad;
-    }
+  // ---- 1. ASCII -> 2-bit codes (MSB first) + invalid masks; PACKED: the codes as they are ----
+  sp_load_tile<PACKED>(a, t0, nw, fwd, inv16, bnd16);
   __syncthreads();
+  if (PACKED)
+    sp_mark_tile(a, (a.tile0 + (int64_t) blockIdx.x) * a.tile_stride, t0, R, inv16, bnd16);   // read before step 4: two barriers on
 
   // reverse-complement strand, same packing: rc base p' = R-1-p
   for (int q = tid; q < SP_WORDS; q += SP_THREADS)
@@ -312,26 +402,9 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
   //      t+1 .. t+kq-1 and the first c+kr bits of the word pair (t+kq, t+kq+1), K = 16 kq + kr -- so the
   //      valid starts of a thread are one interval [fls(m0), ctz(E) - kr], a dozen instructions per
   //      THREAD (the prefix counts this replaces cost 14 per base)
-  u32 vmask = 0;
-  if (K >= 16)
-    { const int kq = K >> 4, kr = K & 15;
-      const u32 m0 = inv16[tid];
-      u32 mid = 0;
-      for (int j = 1; j < kq; j++)
-        mid |= inv16[tid + j];
-      const u32 E     = (u32) inv16[tid + kq] | ((u32) inv16[tid + kq + 1] << 16);
-      const int lowc  = 32 - __clz((int) m0);                       // first start past the last invalid base of word t
-      const int highc = (E != 0 ? __ffs((int) E) - 1 : 32) - kr;    // last start whose window ends before the next one
-      const u32 up    = (highc >= 15) ? 0xffffu : (highc < 0 ? 0u : ((2u << highc) - 1u));
-      vmask = (mid != 0) ? 0u : (up & ~((1u << lowc) - 1u) & 0xffffu);
-    }
-  else
-    { const u32 M = (u32) inv16[tid] | ((u32) inv16[tid + 1] << 16);
-      const u32 km = (1u << K) - 1u;
-#pragma unroll
-      for (int c = 0; c < SP_CH; c++)
-        vmask |= (((M >> c) & km) == 0u ? 1u : 0u) << c;
-    }
+  u32 vmask = sp_clear_starts(inv16, tid, K);
+  if (PACKED)                                            // ... and no read end in [i, i + K - 1)
+    vmask &= sp_clear_starts(bnd16, tid, K - 1);
   lastkey[tid] = mk[SP_CH - 1];
   if (tid < a.nbuckets) bcnt2[tid] = 0;
   vlast[tid]   = (uint8_t) ((vmask >> (SP_CH - 1)) & 1u);
@@ -581,6 +654,7 @@ __global__ __launch_bounds__(256) void k_split_chunkbase(const u32 *__restrict__
 // k_split only: no keys, no minima, no validity, no start masks.  (Persistent workgroups that keep the loads of the
 // next tile and the descriptor of the one after in flight were tried: 473 instead of 459 ms of split time per
 // configs[2] step -- the kernel is not waiting for its two dependent round trips either.)
+template <bool PACKED>
 __global__ __launch_bounds__(SP_THREADS) void k_split_replay(SplitArgs a)
 { __shared__ u32 fwd[SP_WORDS];
   __shared__ u32 rcw[SP_WORDS];
@@ -608,6 +682,11 @@ __global__ __launch_bounds__(SP_THREADS) void k_split_replay(SplitArgs a)
       if (a.abl & 2) { v0_n = make_uint4(0x61636774u + tid, 0x74676361u, 0x61616161u, 0x63636363u); v1_n = v0_n; }
       else
 #endif
+      if (PACKED)                                            // one dword of codes per 16 positions (.x of the pair)
+        { if (g0 < a.nbytes) v0_n.x = ((const u32 *) a.bases)[g0 >> 4];
+          if (tid + SP_THREADS < nw && g1 < a.nbytes) v1_n.x = ((const u32 *) a.bases)[g1 >> 4];
+        }
+      else
       { if (g0 + 16 <= a.nbytes) v0_n = *(const uint4 *) (a.bases + g0);
         if (tid + SP_THREADS < nw && g1 + 16 <= a.nbytes) v1_n = *(const uint4 *) (a.bases + g1);
       }
@@ -649,6 +728,10 @@ __global__ __launch_bounds__(SP_THREADS) void k_split_replay(SplitArgs a)
       if (q < nw)
         { const int64_t g = t0 + (int64_t) q * 16;
           uint4 v = (q == tid) ? v0 : v1;
+          if (PACKED)
+            word = __builtin_bswap32(v.x);
+          else
+          {
           if (!(g + 16 <= a.nbytes))
             { u32 d[4] = { 0u, 0u, 0u, 0u };                   // the last bytes of the input, one by one
               for (int j = 0; j < 16; j++)
@@ -657,6 +740,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_split_replay(SplitArgs a)
               v = make_uint4(d[0], d[1], d[2], d[3]);
             }
           sp_pack16(v, word, bad);
+          }
         }
       fwd[q] = word;
     }
@@ -814,15 +898,62 @@ static void sp_launch(SplitArgs a, int64_t ngrid, hipStream_t s)
 { for (int64_t t = 0; t < ngrid; t += SP_MAXGRID)
     { a.tile0 = t;
       const int64_t nb = (ngrid - t < SP_MAXGRID) ? (ngrid - t) : SP_MAXGRID;
-      hipLaunchKernelGGL((k_split<EMIT, POS>), dim3((unsigned) nb), dim3(SP_THREADS), (size_t) a.nbuckets * 16, s, a);
+      if (a.roff != NULL)                              // packed reads (sp_packed_args)
+        hipLaunchKernelGGL((k_split<EMIT, false, true>), dim3((unsigned) nb), dim3(SP_THREADS), (size_t) a.nbuckets * 16, s, a);
+      else
+        hipLaunchKernelGGL((k_split<EMIT, POS, false>), dim3((unsigned) nb), dim3(SP_THREADS), (size_t) a.nbuckets * 16, s, a);
     }
+}
+
+// For every tile, where its walk through the two sorted lists of a packed read set begins: the first read whose last
+// position is not in front of the tile, the first invalid stretch that does not end in front of it.  One thread per
+// list element writes the tiles that begin inside it (a 15 kbp read: four) -- entries left at 0xffffffff: nothing.
+__global__ __launch_bounds__(256) void k_pk_tidx(const int64_t *__restrict__ roff, int64_t nreads, const int64_t *__restrict__ inv,
+                                                 int64_t ninv, int64_t ntiles, int64_t tile_len, u32 *__restrict__ tidx)
+{ const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (i < nreads)
+    { const int64_t p = (i == 0) ? -1 : roff[i] - 1, e = roff[i + 1] - 1;       // last positions of reads i-1 and i
+      const int64_t tf = (p < 0) ? 0 : p / tile_len + 1;
+      for (int64_t t = tf; t < ntiles && t * tile_len <= e; t++)
+        tidx[2 * t] = (u32) i;
+    }
+  if (i < ninv)
+    { const int64_t p = (i == 0) ? -1 : inv[2 * i - 2] + inv[2 * i - 1] - 1, e = inv[2 * i] + inv[2 * i + 1] - 1;
+      const int64_t tf = (p < 0) ? 0 : p / tile_len + 1;
+      for (int64_t t = tf; t < ntiles && t * tile_len <= e; t++)
+        tidx[2 * t + 1] = (u32) i;
+    }
+}
+
+// pk != NULL: the split kernels of `a` take packed reads; builds the tile index in its arena slot
+static int sp_packed_args(fk_ctx *ctx, SplitArgs &a, const fk_pkview *pk, int64_t ntiles)
+{ a.roff = NULL; a.nreads = 0; a.inv = NULL; a.ninv = 0; a.tidx = NULL;
+  if (pk == NULL)
+    return (FK_OK);
+  if (pk->roff == NULL || pk->nreads <= 0 || pk->ninv < 0 || (pk->ninv > 0 && pk->inv == NULL)
+      || pk->nreads >= 0xffffffffll || pk->ninv >= 0xffffffffll)
+    { fk_set_error(ctx, "packed reads: %lld reads, %lld invalid stretches -- between 1 and 2^32 - 2 reads, at most 2^32 - 2 stretches",
+                   (long long) pk->nreads, (long long) pk->ninv);
+      return (FK_EINVAL);
+    }
+  u32 *tidx = (u32 *) fk_slot(ctx, FK_SLOT_PK_TIDX, ntiles * 8);
+  if (tidx == NULL)
+    return (FK_ENOMEM);
+  hipStream_t s = ctx->stream;
+  FK_HIP(ctx, hipMemsetAsync(tidx, 0xff, (size_t) ntiles * 8, s));
+  const int64_t n = (pk->nreads > pk->ninv) ? pk->nreads : pk->ninv;
+  hipLaunchKernelGGL(k_pk_tidx, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, pk->roff, pk->nreads, pk->inv, pk->ninv,
+                     ntiles, (int64_t) SP_TILE, tidx);
+  FK_LAUNCH_CHECK(ctx);
+  a.roff = pk->roff; a.nreads = pk->nreads; a.inv = pk->inv; a.ninv = pk->ninv; a.tidx = tidx;
+  return (FK_OK);
 }
 
 // ---------------------------------------------------------------------------------------------
 // counts_known: bucket_counts[] (and *nsuper, *ninst) hold the result of an earlier counting call
 // on the same input, so only the emit kernel runs.
 int fkx_split(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int64_t cap,
-              int64_t *nsuper, int64_t *ninst, int64_t *bucket_counts, bool counts_known, void *d_pos)
+              int64_t *nsuper, int64_t *ninst, int64_t *bucket_counts, bool counts_known, void *d_pos, const fk_pkview *pk)
 { hipStream_t s = ctx->stream;
   const int   K = ctx->prm.kmer;
   const int   nb = ctx->prm.nbuckets;
@@ -866,6 +997,13 @@ int fkx_split(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int
 
   const int64_t nstarts = nbytes - K + 1;
   const int64_t ntiles  = (nstarts + SP_TILE - 1) / SP_TILE;
+  if (pk != NULL && d_pos != NULL)
+    { fk_set_error(ctx, "split: record positions are not available for packed reads");
+      return (FK_EUNSUPPORTED);
+    }
+  { const int rcp = sp_packed_args(ctx, a, pk, ntiles);
+    if (rcp != FK_OK) return (rcp);
+  }
 
   FK_HIP(ctx, hipMemsetAsync(ctx->d_scratch, 0, 1032 * sizeof(u64), s));
   int64_t tot = 0;
@@ -923,7 +1061,7 @@ int fkx_split(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int
 // once with overflow detection, and only if the estimate was too small fall back to the exact
 // count-then-emit of fkx_split.  *d_out is the arena slot that received the records.
 int fkx_split_fast(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void **d_out, int64_t *nsuper,
-                   int64_t *ninst, int64_t *bucket_counts, int64_t *bucket_offsets)
+                   int64_t *ninst, int64_t *bucket_counts, int64_t *bucket_offsets, const fk_pkview *pk)
 { int64_t bc[256];
   for (int b = 0; b < 256; b++)
     bucket_counts[b] = bucket_offsets[b] = 0;
@@ -957,6 +1095,9 @@ int fkx_split_fast(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void **d_ou
       const int64_t nstarts = nbytes - K + 1;
       const int64_t ntiles  = (nstarts + SP_TILE - 1) / SP_TILE;
       const int     sample  = 32;
+      { const int rcp = sp_packed_args(ctx, a, pk, ntiles);
+        if (rcp != FK_OK) return (rcp);
+      }
       if (ntiles >= 64 * sample)
         { FK_HIP(ctx, hipMemsetAsync(ctx->d_scratch, 0, 1032 * sizeof(u64), s));
           a.out = NULL; a.cap = 0; a.tile_stride = sample;
@@ -1003,14 +1144,14 @@ int fkx_split_fast(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void **d_ou
   if (ctx->prm.nbuckets > 1)
     { // one emit pass into regions sized from a 1/32 tile sample (padded); exact pair on overflow
       int64_t cap = 0, offs[257];
-      int rc = fkx_split_plan(ctx, d_bases, nbytes, &cap, offs);
+      int rc = fkx_split_plan(ctx, d_bases, nbytes, &cap, offs, pk);
       if (rc != FK_OK)
         return (rc);
       if (cap > 0)
         { void *out = fk_slot(ctx, FK_SLOT_SM_A, cap * stride);
           if (out == NULL)
             return (FK_ENOMEM);
-          rc = fkx_split_planned(ctx, d_bases, nbytes, out, cap, offs, bc, ninst);
+          rc = fkx_split_planned(ctx, d_bases, nbytes, out, cap, offs, bc, ninst, 0, -1, 0, pk);
           if (rc == FK_OK)
             { int64_t tot = 0;
               for (int b = 0; b < ctx->prm.nbuckets; b++)
@@ -1026,14 +1167,14 @@ int fkx_split_fast(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void **d_ou
             return (rc);
         }
     }
-  int rc = fkx_split(ctx, d_bases, nbytes, NULL, 0, nsuper, ninst, bc, false);
+  int rc = fkx_split(ctx, d_bases, nbytes, NULL, 0, nsuper, ninst, bc, false, NULL, pk);
   if (rc != FK_OK || *nsuper == 0)
     return (rc);
   void *out = fk_slot(ctx, FK_SLOT_SM_A, *nsuper * stride);
   if (out == NULL)
     return (FK_ENOMEM);
   *d_out = out;
-  rc = fkx_split(ctx, d_bases, nbytes, out, *nsuper, nsuper, ninst, bc, true);
+  rc = fkx_split(ctx, d_bases, nbytes, out, *nsuper, nsuper, ninst, bc, true, NULL, pk);
   int64_t run = 0;
   for (int b = 0; b < ctx->prm.nbuckets && b < 256; b++)
     { bucket_counts[b] = bc[b];
@@ -1046,7 +1187,7 @@ int fkx_split_fast(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void **d_ou
 // Sampled plan for the bucketed (sharded) split: estimated records per bucket from a 1/32 tile
 // sample, padded by 5 %; region b starts at offsets[b].  Returns the total capacity needed.
 int fkx_split_plan(fk_ctx *ctx, const void *d_bases, int64_t nbytes, int64_t *cap,
-                   int64_t *offsets)
+                   int64_t *offsets, const fk_pkview *pk)
 { hipStream_t s = ctx->stream;
   const int   K = ctx->prm.kmer;
   const int   nb = ctx->prm.nbuckets;
@@ -1078,6 +1219,9 @@ int fkx_split_plan(fk_ctx *ctx, const void *d_bases, int64_t nbytes, int64_t *ca
   a.out = NULL; a.cap = 0;
   a.overflowed = (u32 *) (ctx->d_scratch + 1024);
   a.tile_stride = sample;
+  { const int rcp = sp_packed_args(ctx, a, pk, ntiles);
+    if (rcp != FK_OK) return (rcp);
+  }
   FK_HIP(ctx, hipMemsetAsync(ctx->d_scratch, 0, 1032 * sizeof(u64), s));
   if (ctx->d_plan == NULL)
     FK_HIP(ctx, hipMalloc((void **) &ctx->d_plan, 32 * 256 * sizeof(u64)));
@@ -1114,7 +1258,8 @@ int fkx_split_plan(fk_ctx *ctx, const void *d_bases, int64_t nbytes, int64_t *ca
 // tells whether they all fitted); mode 2: no minimizers at all -- the records of [b0, b1) are rebuilt from
 // the entries a mode-1 pass over the same reads left behind (k_split_replay).
 int fkx_split_planned(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int64_t cap,
-                      const int64_t *offsets, int64_t *counts, int64_t *ninst, int b0, int b1, int mode)
+                      const int64_t *offsets, int64_t *counts, int64_t *ninst, int b0, int b1, int mode,
+                      const fk_pkview *pk)
 { hipStream_t s = ctx->stream;
   const int   K = ctx->prm.kmer;
   const int   nb = ctx->prm.nbuckets;
@@ -1175,6 +1320,9 @@ int fkx_split_planned(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_
   a.tile_stride = 1;
   a.ent = NULL; a.ent_cursor = ctx->d_cursors + ((size_t) 256 << SP_LSTREAMS) * FK_CURSOR_STRIDE; a.tile_ent = NULL; a.ent_cap = 0;
   a.gb0 = b0; a.gb1 = b1;
+  { const int rcp = sp_packed_args(ctx, a, (mode == 2 && pk != NULL) ? NULL : pk, ntiles);   // (a replay pass needs no tile index)
+    if (rcp != FK_OK) return (rcp);
+  }
   const int64_t nchunks = (ntiles + SP_RCH - 1) / SP_RCH;
   a.tile_cnt = NULL; a.chunk_base = NULL;
   if (mode != 0)
@@ -1210,7 +1358,10 @@ int fkx_split_planned(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_
 #ifdef FK_ABLATION
           a.abl = getenv("FK_REPLAY_ABL") ? atoi(getenv("FK_REPLAY_ABL")) : 0;
 #endif
-          hipLaunchKernelGGL(k_split_replay, dim3((unsigned) nbk), dim3(SP_THREADS), 0, s, a);
+          if (pk != NULL)
+            hipLaunchKernelGGL(k_split_replay<true>, dim3((unsigned) nbk), dim3(SP_THREADS), 0, s, a);
+          else
+            hipLaunchKernelGGL(k_split_replay<false>, dim3((unsigned) nbk), dim3(SP_THREADS), 0, s, a);
         }
     }
   else

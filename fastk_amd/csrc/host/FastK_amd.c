@@ -1155,7 +1155,7 @@ int main(int argc, char *argv[])
   fk_result *res;
   Feeder     feed;
   char      *root = NULL, *dir = NULL, name[4096];
-  int        i, j, nfiles, ftype = -1;
+  int        i, j, nfiles, ftype = -1, all_plain = 1;
 
   int    argc0 = argc;
   char **argv0 = malloc(sizeof(char *)*(argc+4));
@@ -1342,6 +1342,18 @@ int main(int argc, char *argv[])
     { fprintf(stderr,"%s: Out of memory\n",Prog_Name); exit (1); }
   feed.boff[0] = 0;
 
+  /* a run takes its reads in one form (fk_push_packed keeps them in two bits per base): the reader threads pack
+     the text only when every input is a plain FASTA / FASTQ file */
+  all_plain = 1;
+  for (i = 1; i <= nfiles; i++)
+    { char *r, *d;
+      int   q = classify(argv[i],&r,&d);
+      if (q < 0 || q > 1 || (strlen(argv[i]) > 3 && strcmp(argv[i]+strlen(argv[i])-3,".gz") == 0))
+        all_plain = 0;
+      if (q >= 0)
+        { free(r); free(d); }
+    }
+
   for (i = 1; i <= nfiles; i++)
     { char *r, *d;
       int   q = classify(argv[i],&r,&d);
@@ -1366,8 +1378,7 @@ int main(int argc, char *argv[])
         scan_sam(&feed,argv[i]);
       else if (q == 3)
         scan_bam(&feed,argv[i]);
-      else if (!EXACT && BC_PREFIX == 0 && !HOST_PARSE && !COMPRESS && !PROFILE && !DEVICE_TEXT
-               && !(strlen(argv[i]) > 3 && strcmp(argv[i]+strlen(argv[i])-3,".gz") == 0))
+      else if (all_plain && !EXACT && BC_PREFIX == 0 && !HOST_PARSE && !COMPRESS && !PROFILE && !DEVICE_TEXT)
         scan_text_packed(&feed,argv[i],q);
       else if (!EXACT && BC_PREFIX == 0 && !HOST_PARSE && (q == 1 || !(COMPRESS || PROFILE))
                && !(NGPUS > 1 && strlen(argv[i]) > 3 && strcmp(argv[i]+strlen(argv[i])-3,".gz") == 0))

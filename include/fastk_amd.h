@@ -173,6 +173,15 @@ int fk_finish_device(fk_ctx *ctx, fk_result *res);
 int fk_count_device_reads(fk_ctx *ctx, const void *d_bases, int64_t nbytes, int fetch_table,
                           fk_result *res);
 
+/* fk_count_device_reads for reads that are resident in two bits per base and stay owned by the caller: d_codes =
+   nbases positions, 16 per little-endian dword in the byte order of fk_push_packed (4-byte aligned, readable up to
+   the dword that holds the last position); read r = positions d_roff[r] .. d_roff[r+1]-1 (d_roff[0] = 0,
+   d_roff[nreads] = nbases, no terminators); d_inv = ninv pairs (first position, length), sorted and disjoint, of
+   positions that belong to no k-mer (N stretches, padding).  All device memory.  With 37.5 GB instead of 150 GB of
+   reads all super-mers of a 50x human-size set fit beside them: one split pass, no replay. */
+int fk_count_device_packed(fk_ctx *ctx, const void *d_codes, int64_t nbases, const int64_t *d_roff, int64_t nreads,
+                           const int64_t *d_inv, int64_t ninv, int fetch_table, fk_result *res);
+
 /* Sort + expand + sort + count over super-mer records already in HBM: what a rank runs on the
    records it owns after the bucket exchange (the .T file shuffle of split.c:1263 <-> count.c:1347).
    d_smers (nsuper records of smer_stride bytes) is clobbered. */
@@ -272,11 +281,13 @@ int fk_count_unsorted_kmers(fk_ctx *ctx, void *d_kmers, void *d_tmp, int64_t nwe
 
 /* The reads of a DATA_BLOCK in TWO BITS PER BASE -- the north-star's first verb done by the reader threads, so that a
    quarter of the bytes cross PCIe: codes = the bases of the block's reads back to back (no terminators), four to a
-   byte, first base in the two high bits (a c g t = 0 1 2 3: the .ktab encoding, README.md:977-984); rlen[i] = bases of
-   read i (they add up to nbases); inv = ninv pairs (first base, length), in the same concatenated coordinates, of
-   stretches that hold no acgt (N, IUPAC codes: their code bits are ignored); rem, tid as in fk_push_block.  Host
-   memory (pinned or not).  Equivalent to fk_push_block of the ASCII block: the device restores the 0-terminated
-   ASCII reads in HBM and the path continues unchanged.  Not with -bc. */
+   byte, first base in the two high bits (a c g t = 0 1 2 3: the .ktab encoding, README.md:977-984; what Stuff_Seq
+   makes of a super-mer, split.c:864-989); rlen[i] = bases of read i (they add up to nbases); inv = ninv pairs (first
+   base, length), in the same concatenated coordinates, sorted and disjoint, of stretches that hold no acgt (N, IUPAC
+   codes: their code bits are ignored); rem, tid as in fk_push_block.  Host memory (pinned or not).  Equivalent to
+   fk_push_block of the ASCII block, but the reads STAY packed in HBM (a quarter of the memory) and the splitter reads
+   them in that form -- nothing is converted back; only exact_parts runs and fk_make_profiles restore ASCII reads on
+   the device.  A run takes its reads in one form: mixing with the ASCII / text pushes returns FK_ESTATE.  Not with -bc. */
 int fk_push_packed(fk_ctx *ctx, const uint8_t *codes, int64_t nbases, const int32_t *rlen, int nreads,
                    const int64_t *inv, int ninv, int rem, int tid);
 

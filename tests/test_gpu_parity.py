@@ -338,6 +338,128 @@ def test_packed_push_matches_reference_golden(name):
             util.check_against_golden(case, res.hist, res.max_inst, res.table)
 
 
+def _packed_on_device(ctx, bases, boff):
+    """the whole DATA_BLOCK as the caller-owned resident form of fk_count_device_packed: (buffers, args)"""
+    codes, nb, rlen, inv = _pack_reads(bases, boff)
+    roff = np.concatenate([[0], np.cumsum(rlen.astype(np.int64))]).astype(np.int64)
+    cpad = np.zeros((len(codes) + 3) // 4 * 4 + 4, dtype=np.uint8)
+    cpad[:len(codes)] = codes
+    d_codes = ctx.alloc(len(cpad)).upload(cpad)
+    d_roff = ctx.alloc(roff.nbytes).upload(roff)
+    d_inv = ctx.alloc(max(inv.nbytes, 16)).upload(inv) if len(inv) else None
+    return (d_codes, d_roff, d_inv), (d_codes.ptr, nb, d_roff.ptr, len(rlen), d_inv.ptr if d_inv else None, len(inv))
+
+
+@pytest.mark.parametrize("name", util.golden_names())
+def test_count_device_packed_matches_reference_golden(name):
+    """fk_count_device_packed: caller-owned reads resident in two bits per base, split by the PACKED tile loader
+    (no ASCII anywhere) -- one bucket; 5 buckets in one pass; 7 buckets in 3 split passes with entry replay and
+    without.  Same histogram and table as the reference."""
+    case, bases, boff = util.load_case(name)
+    for kw, dbg in ((dict(), {}), (dict(nbuckets=5), {}), (dict(nbuckets=7, split_passes=3), {}),
+                    (dict(nbuckets=7, split_passes=3), {"split_replay": 0})):
+        with fastk_amd.Context(kmer=case["k"], table_cutoff=case["cutoff"], nthreads=case["T"], **kw) as ctx:
+            for key, val in dbg.items():
+                ctx.debug_set(key, val)
+            bufs, args = _packed_on_device(ctx, bases, boff)
+            res = ctx.count_device_packed(*args, fetch_table=True)
+            util.check_against_golden(case, res.hist, res.max_inst, res.table)
+            for b in bufs:
+                if b is not None:
+                    b.free()
+
+
+def test_packed_and_ascii_splitters_agree_on_ragged_reads():
+    """Reads of every length around k and around the 16-position words of the tile loader, N runs at read starts, read
+    ends and across tile edges, empty reads: the PACKED splitter counts exactly the k-mer instances the ASCII splitter
+    counts and the two pipelines give the same histogram and table (which the oracle confirms)."""
+    rng = np.random.default_rng(4242)
+    k = 40
+    reads = []
+    for L in list(range(0, 130)) + [4095, 4096, 4097, 8191, 8233, 20000]:
+        r = rng.integers(0, 4, size=L)
+        s = np.frombuffer(b"acgt", dtype=np.uint8)[r].copy()
+        if L > 60 and L % 3 == 0:
+            s[0:L % 7 + 1] = ord("N")
+        if L > 60 and L % 5 == 0:
+            s[L - (L % 11) - 1:] = ord("n")
+        if L > 5000:
+            s[4090:4101] = ord("N")
+            s[4500] = ord("R")
+        reads.append(s.tobytes())
+    reads += reads[50:90]                                     # repeats: counts above 1
+    bases, boff = orc.block_from_reads(reads)
+    exp = orc.fastk(k, bases, boff, cutoff=1)
+    with fastk_amd.Context(kmer=k, table_cutoff=1, nthreads=4) as ctx:
+        ctx.push_block(bases, boff.astype(np.int32))
+        a = ctx.finish()
+    with fastk_amd.Context(kmer=k, table_cutoff=1, nthreads=4) as ctx:
+        bufs, args = _packed_on_device(ctx, bases, boff)
+        b = ctx.count_device_packed(*args, fetch_table=True)
+    assert a.ninst == b.ninst == exp.ninst
+    assert np.array_equal(a.hist, b.hist) and np.array_equal(b.hist[1:], exp.hist[1:])
+    assert np.array_equal(a.table, b.table) and np.array_equal(b.table, exp.table)
+
+
+def test_packed_pushes_of_changing_shape():
+    """a block of one long read followed by a block of many short reads (more read offsets than the first
+    block's staging held), then a block with many N stretches -- and the forms of a run do not mix."""
+    rng = np.random.default_rng(99)
+    k = 40
+    acgt = np.frombuffer(b"acgt", dtype=np.uint8)
+    long_read = acgt[rng.integers(0, 4, size=3_000_000)].tobytes()
+    short = [acgt[rng.integers(0, 4, size=45)].tobytes() for _ in range(60_000)]
+    holes = []
+    for _ in range(3000):
+        s = acgt[rng.integers(0, 4, size=100)].copy()
+        s[rng.integers(0, 100, size=8)] = ord("N")
+        holes.append(s.tobytes())
+    blocks = [orc.block_from_reads(x) for x in ([long_read], short, holes)]
+    allb, allo = orc.block_from_reads([long_read] + short + holes)
+    exp = orc.fastk(k, allb, allo, cutoff=2)
+    for kw in (dict(), dict(nbuckets=3, hbm_budget=64 << 20)):
+        with fastk_amd.Context(kmer=k, table_cutoff=2, nthreads=4, **kw) as ctx:
+            for bs, bo in blocks:
+                ctx.push_packed(*_pack_reads(bs, bo))
+            res = ctx.finish()
+            assert res.ninst == exp.ninst and np.array_equal(res.hist[1:], exp.hist[1:])
+            assert np.array_equal(res.table, exp.table)
+            with pytest.raises(fastk_amd.FastKError):
+                ctx.push_block(*[blocks[1][0], blocks[1][1].astype(np.int32)])
+            ctx.reset()
+            ctx.push_block(blocks[1][0], blocks[1][1].astype(np.int32))     # a new run may take the other form
+            with pytest.raises(fastk_amd.FastKError):
+                ctx.push_packed(*_pack_reads(*blocks[2]))
+
+
+@pytest.mark.parametrize("name", ["edge_k40_t1_T4", "synth_illumina_k40_t1_T4"])
+def test_packed_push_then_profiles_and_exact_parts(name):
+    """The two consumers that walk reads byte by byte restore the ASCII reads from the packed store on the device:
+    fk_make_profiles after packed pushes gives the profiles of the ASCII run, and an exact_parts run fed in two bits
+    per base gives the first-byte census (hence the part boundaries) of the one fed in ASCII."""
+    case, bases, boff = util.load_case(name)
+    k, nreads = case["k"], len(boff) - 1
+    step = max(1, nreads // 3)
+    prof, wf = [], []
+    for form in ("ascii", "packed"):
+        for exact in (False, True):
+            with fastk_amd.Context(kmer=k, table_cutoff=1, nthreads=case["T"], exact_parts=exact) as ctx:
+                for s0 in range(0, nreads, step):
+                    e = min(nreads, s0 + step)
+                    bs, bo = bases[boff[s0]:boff[e]], boff[s0:e + 1] - boff[s0]
+                    if form == "ascii":
+                        ctx.push_block(bs, bo.astype(np.int32))
+                    else:
+                        ctx.push_packed(*_pack_reads(bs, bo))
+                res = ctx.finish()
+                if exact:
+                    wf.append(np.array(res.wfirst))
+                else:
+                    prof.append(ctx.make_profiles())
+    assert np.array_equal(wf[0], wf[1])
+    assert np.array_equal(prof[0][0], prof[1][0]) and np.array_equal(prof[0][1], prof[1][1])
+
+
 @pytest.mark.parametrize("name", ["synth_illumina_k40_t1_T4", "edge_k51_t1_T4"])
 def test_pipeline_sort_collapse_path_matches_golden(name):
     """fk_debug_set("kmer_stage", 1): the sort / collapse / sort k-mer stage (the fallback of the
