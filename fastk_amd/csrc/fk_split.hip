@@ -89,7 +89,8 @@ struct SplitArgs
   int64_t   nreads;
   const int64_t *inv;       // [2 ninv] (first position, length) of the stretches that hold no acgt
   int64_t   ninv;
-  const u32 *tidx;          // [tiles][2] first read that ends at or behind the tile's first position, first stretch that does
+  const u32 *tidx;          // [tiles + 2][2] first read that ends at or behind the tile's first position, first stretch that
+                            // does (0xffffffff: none)
 };
 
 __device__ __forceinline__ u32 sp_window(const u32 *arr, int off)
@@ -238,24 +239,47 @@ __device__ __forceinline__ void sp_load_tile(const SplitArgs &a, int64_t t0, int
     }
 }
 
-// PACKED, after the barrier behind sp_load_tile: the read ends and invalid stretches that fall into positions
-// [t0, t0 + R) become bits of the two masks (LDS atomics on the u16 arrays viewed as one bitmap; little-endian)
-__device__ __forceinline__ void sp_mark_tile(const SplitArgs &a, int64_t tile, int64_t t0, int R, uint16_t *inv16, uint16_t *bnd16)
+// PACKED: the read ends and invalid stretches that fall into positions [t0, t0 + R) become bits of the two masks
+// (LDS atomics on the u16 arrays viewed as one bitmap; little-endian).  In two halves so that the trip to the lists
+// overlaps the trip to the codes: sp_fetch_marks, before the tile's codes are waited for, loads the list elements
+// a thread may have to look at -- the tile index brackets them: everything that can fall into this tile and its halo
+// lies in front of the first element of tile + 2, so a HiFi tile issues a load or two, not 256 -- and sp_mark_tile,
+// behind the barrier that published the zeroed masks, sets the bits.
+struct sp_marks { int64_t e, s, n; u32 r_lo, r_hi, s_lo, s_hi; };
+
+__device__ __forceinline__ void sp_fetch_marks(const SplitArgs &a, int64_t tile, sp_marks &m)
+{ const int tid = threadIdx.x;
+  m.r_lo = a.tidx[2 * tile];     m.s_lo = a.tidx[2 * tile + 1];
+  m.r_hi = a.tidx[2 * tile + 4]; m.s_hi = a.tidx[2 * tile + 5];
+  if ((int64_t) m.r_hi > a.nreads) m.r_hi = (u32) a.nreads;
+  // (the first stretch that ENDS behind the next tile may begin in this one: it is looked at as well)
+  m.s_hi = ((int64_t) m.s_hi + 1 > a.ninv) ? (u32) a.ninv : m.s_hi + 1;
+  m.e = -1; m.s = 0; m.n = 0;
+  if ((int64_t) m.r_lo + tid < (int64_t) m.r_hi)
+    m.e = a.roff[(int64_t) m.r_lo + tid + 1] - 1;              // last position of read r_lo + tid
+  if ((int64_t) m.s_lo + tid < (int64_t) m.s_hi)
+    { m.s = a.inv[2 * ((int64_t) m.s_lo + tid)];
+      m.n = a.inv[2 * ((int64_t) m.s_lo + tid) + 1];
+    }
+}
+
+__device__ __forceinline__ void sp_mark_tile(const SplitArgs &a, int64_t t0, int R, const sp_marks &m, uint16_t *inv16, uint16_t *bnd16)
 { const int     tid  = threadIdx.x;
   const int64_t tend = t0 + R;
-  const u32     r0   = a.tidx[2 * tile], s0 = a.tidx[2 * tile + 1];
   u32 *bb = (u32 *) bnd16, *ib = (u32 *) inv16;
-  for (int64_t j = (int64_t) r0 + tid; j < a.nreads; j += SP_THREADS)
-    { const int64_t e = a.roff[j + 1] - 1;                      // last position of read j
-      if (e >= tend) break;
-      if (e >= t0)
+  int64_t e = m.e;
+  for (int64_t j = (int64_t) m.r_lo + tid; j < (int64_t) m.r_hi; j += SP_THREADS)
+    { if (j != (int64_t) m.r_lo + tid)
+        e = a.roff[j + 1] - 1;
+      if (e >= t0 && e < tend)
         { const int o = (int) (e - t0);
           atomicOr(&bb[o >> 5], 1u << (o & 31));
         }
     }
-  for (int64_t j = (int64_t) s0 + tid; j < a.ninv; j += SP_THREADS)
-    { const int64_t s = a.inv[2 * j], n = a.inv[2 * j + 1];
-      if (s >= tend) break;
+  int64_t s = m.s, n = m.n;
+  for (int64_t j = (int64_t) m.s_lo + tid; j < (int64_t) m.s_hi; j += SP_THREADS)
+    { if (j != (int64_t) m.s_lo + tid)
+        { s = a.inv[2 * j]; n = a.inv[2 * j + 1]; }
       const int lo = (int) ((s > t0 ? s : t0) - t0), hi = (int) ((s + n < tend ? s + n : tend) - t0);
       for (int w = lo >> 5; hi > lo && w <= ((hi - 1) >> 5); w++)
         { const int b0 = (w << 5) > lo ? 0 : lo - (w << 5);
@@ -270,10 +294,13 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
 { __shared__ u32      fwd[SP_WORDS];
   __shared__ u32      rcw[SP_WORDS];
   __shared__ __attribute__((aligned(4))) uint16_t inv16[SP_WORDS];
-  __shared__ __attribute__((aligned(4))) uint16_t bnd16[PACKED ? SP_WORDS : 2];   // PACKED: last positions of the reads
+
   __shared__ __attribute__((aligned(16))) u32 keys[SP_KEYS + SP_KEYS / 16 + 1];   // prefix minima (step 2), then the window minima by position
   __shared__ u32      lastkey[SP_THREADS];                // last window minimum of every thread (step 5); then pos16
-  __shared__ uint16_t sbits[SP_THREADS + 16];            // boundary bits: start | invalid
+  __shared__ __attribute__((aligned(4))) uint16_t sbits[SP_THREADS + 16];            // boundary bits: start | invalid
+  uint16_t *bnd16 = sbits;      // PACKED: the reads' last positions, steps 1 to 4 -- dead before sbits is written (a
+                                // separate 524-byte array cost the seventh workgroup per CU)
+  static_assert(SP_THREADS + 16 >= SP_WORDS, "bnd16 lives in sbits");
   __shared__ uint8_t  vlast[SP_THREADS];                 // is the thread's last k-mer start valid? (step 5 of the next thread)
   // per bucket: stream position of the tile's records (u64), records counted (u32), records placed (u32) -- sized
   // by the launch for the context's bucket count: with the 4 KB that 256 buckets take a CU holds six workgroups,
@@ -302,10 +329,13 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
   if (tid == 0) { nother = 0; nother2 = 0; }
 
   // ---- 1. ASCII -> 2-bit codes (MSB first) + invalid masks; PACKED: the codes as they are ----
+  sp_marks marks;
+  if (PACKED)
+    sp_fetch_marks(a, (a.tile0 + (int64_t) blockIdx.x) * a.tile_stride, marks);
   sp_load_tile<PACKED>(a, t0, nw, fwd, inv16, bnd16);
   __syncthreads();
   if (PACKED)
-    sp_mark_tile(a, (a.tile0 + (int64_t) blockIdx.x) * a.tile_stride, t0, R, inv16, bnd16);   // read before step 4: two barriers on
+    sp_mark_tile(a, t0, R, marks, inv16, bnd16);           // read in step 4: two barriers on
 
   // reverse-complement strand, same packing: rc base p' = R-1-p
   for (int q = tid; q < SP_WORDS; q += SP_THREADS)
@@ -408,9 +438,9 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
   lastkey[tid] = mk[SP_CH - 1];
   if (tid < a.nbuckets) bcnt2[tid] = 0;
   vlast[tid]   = (uint8_t) ((vmask >> (SP_CH - 1)) & 1u);
-  if (tid < 16)
-    sbits[SP_THREADS + tid] = 0xffffu;      // past the tile everything is a boundary
   __syncthreads();
+  if (tid < 16)
+    sbits[SP_THREADS + tid] = 0xffffu;      // past the tile everything is a boundary (published by the scan's barriers)
 
   // ---- 5. super-mer starts: valid and (first of tile | previous invalid | new minimizer) ---
   u32 smask;
@@ -460,8 +490,13 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
   }
   SP_LIST(0u);
   __syncthreads();
+  // bucket and rank inside its bucket of the thread's starts tid and tid + 256 of the first round (the returning LDS
+  // atomic that counts the bucket hands out the rank: no second atomic when the records are placed)
+  u32 bsave = 0, rank0 = 0, rank1 = 0;
   if (one)
-    { if (tid == 0) bcnt[0] = nstart_total; }
+    { if (tid == 0) bcnt[0] = nstart_total;
+      rank0 = tid; rank1 = tid + SP_THREADS;
+    }
   else
     for (u32 base = 0; base < nstart_total; base += SP_PL)
       { if (base != 0)
@@ -474,10 +509,13 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
           { const int ip = pos16[s - base];
             const u32 key = keys[SP_KIDX(ip)];
             const u32 b   = a.mbucket[key >> 15];
+            u32 rk = 0;
             if (rec || b != a.skipb)
-              atomicAdd(&bcnt[b], 1u);                  // (recording: every bucket is counted, the row goes to tile_cnt)
+              rk = atomicAdd(&bcnt[b], 1u);             // (recording: every bucket is counted, the row goes to tile_cnt)
             if (rec && !(b >= (u32) a.gb0 && b < (u32) a.gb1))
               atomicAdd(&nother, 1u);
+            if (s == (u32) tid) { bsave |= b; rank0 = rk; }
+            else if (s == (u32) tid + SP_THREADS) { bsave |= b << 16; rank1 = rk; }
           }
       }
   __syncthreads();
@@ -508,38 +546,156 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
       return;
     }
 
-  if (rec && tid < a.nbuckets)
-    a.tile_cnt[(size_t) (a.tile0 + blockIdx.x) * a.nbuckets + tid] = (uint16_t) bcnt[tid];
-  if (tid < a.nbuckets && bcnt[tid] != 0 && (!rec || (tid >= a.gb0 && tid < a.gb1)))
-    bbase[tid] = atomicAdd(&a.cursor[(((size_t) tid << a.lstreams) + strm) * a.cstride], (u64) bcnt[tid]);
-  __syncthreads();
-
-  // ---- 7. build and write the records -----------------------------------------------------
+  // ---- 7. reserve room, build and write the records ------------------------------------------
+  //      One returning global atomic per bucket and tile reserves the tile's run in the bucket's stream: a trip to
+  //      the memory side.  It is issued first and its answer is needed last: the records of the thread's (up to two)
+  //      super-mers are built in registers meanwhile -- nothing on that stretch waits for a global load (the bucket and
+  //      rank of a start were kept from step 6; region start and limit of a bucket were read before the atomic) --
+  //      and only the store waits for the reservation, behind the barrier that publishes it.
   const int sww = a.sww;
   const int lenw = a.smer_bytes >> 2;
   const int lensh = 24 - 8 * (a.smer_bytes & 3);
-  for (u32 base = 0; base < nstart_total; base += SP_PL)
-    { if (nstart_total > (u32) SP_PL)
-        { __syncthreads();
-          SP_LIST(base);
-          __syncthreads();
+  const u32 lbm = (1u << SP_LB) - 1u;
+  const bool mine = (tid < a.nbuckets && bcnt[tid] != 0 && (!rec || (tid >= a.gb0 && tid < a.gb1)));
+  u64 rb = 0, lm = ~0ull, res = 0;
+  u32 mycnt = 0;
+  if (mine)
+    { rb = a.rbase[tid];
+      if (a.limit != NULL) lm = a.limit[tid];
+      mycnt = bcnt[tid];
+    }
+  if (rec && tid < a.nbuckets)
+    a.tile_cnt[(size_t) (a.tile0 + blockIdx.x) * a.nbuckets + tid] = (uint16_t) bcnt[tid];
+  if (mine)
+    res = atomicAdd(&a.cursor[(((size_t) tid << a.lstreams) + strm) * a.cstride], (u64) mycnt);
+
+  // (i, flip, n) of the super-mer that starts at list entry sl; its minimizer's key
+  auto describe = [&](u32 sl, int &i, u32 &flip, int &n, u32 &key)
+    { i   = pos16[sl];
+      key = keys[SP_KIDX(i)];
+      // strand of the minimizer: its 7-mer against the reverse complement, both from the packed words
+      const int pm = (int) ((key >> 1) & 0x3fffu);
+      flip = ((sp_window(rcw, R - 7 - pm) >> 18) < (sp_window(fwd, pm) >> 18)) ? 1u : 0u;
+      // length: distance to the next boundary, at most W <= 58 positions on; 64 (80 for k > 53) boundary bits
+      // from the word of i
+      const int qi = i >> 4, ci = i & 15;
+      u64 ab = ((u64) sbits[qi] | ((u64) sbits[qi + 1] << 16) | ((u64) sbits[qi + 2] << 32)
+                | ((u64) sbits[qi + 3] << 48)) >> (ci + 1);
+      if (W > 47)
+        ab |= (u64) sbits[qi + 4] << (63 - ci);
+      n = __ffsll((long long) ab);
+    };
+  // where record `rank` of bucket b goes (bbase: start of the chunk the tile's run begins in; bcnt: offset in it)
+  auto slot_of = [&](u32 b, u32 rank, u64 &slot) -> bool
+    { const u64 A = bbase[b];
+      const u32 t = bcnt[b] + rank;
+      slot = A + ((u64) (t >> SP_LB) << (SP_LB + a.lstreams)) + (u64) (t & lbm);
+      return (A != ~0ull);
+    };
+  auto put_generic = [&](int i, u32 flip, int n, u32 *dst)
+    { const int  L   = n - 1 + K;
+      const u32 *arr = flip ? rcw : fwd;
+      const int  st  = flip ? (R - (i + L)) : i;
+      if (sww == 5)
+        sp_put_record5(arr, st, L, ((u32) (n - 1)) << lensh, lenw, dst);
+      else
+        for (int q = 0; q < sww; q++)
+          { u32 x = 0;
+            const int rem = L - 16 * q;
+            if (rem > 0)
+              { x = sp_window(arr, st + 16 * q);
+                if (rem < 16)
+                  x &= ~(0xffffffffu >> (2 * rem));
+              }
+            if (q == lenw)
+              x |= ((u32) (n - 1)) << lensh;
+            dst[q] = __builtin_bswap32(x);
+          }
+    };
+
+  const bool piped = (nstart_total <= (u32) SP_PL);       // all starts are in the list: two per thread at most
+  sp_rec5 r0, r1;
+  u32 m0 = 0, m1 = 0;                                     // i | flip << 12 | n << 13 | b << 20; bit 31: a record to place, bit 30: an entry to record
+  if (piped)
+    {
+#pragma unroll
+      for (int h = 0; h < 2; h++)
+        { const u32 sl = (u32) tid + (u32) h * SP_THREADS;
+          if (sl < nstart_total)
+            { int i, n; u32 flip, key;
+              describe(sl, i, flip, n, key);
+              const u32 b = one ? 0u : ((bsave >> (16 * h)) & 0xffffu);
+              const u32 m = (u32) i | (flip << 12) | ((u32) n << 13) | (b << 20);
+              bool place = true;
+              if (rec)
+                { if (!(b >= (u32) a.gb0 && b < (u32) a.gb1))
+                    { if (h == 0) m0 = m | 0x40000000u; else m1 = m | 0x40000000u;   // an entry: written behind the barrier
+                      place = false;                                                 // (ebase is published there)
+                    }
+                }
+              else if (b == a.skipb)
+                place = false;
+              if (place)
+                { if (h == 0) m0 = m | 0x80000000u; else m1 = m | 0x80000000u;
+                  if (sww == 5)
+                    { const int  L   = n - 1 + K;
+                      const u32 *arr = flip ? rcw : fwd;
+                      const int  st  = flip ? (R - (i + L)) : i;
+                      sp_put_record5(arr, st, L, ((u32) (n - 1)) << lensh, lenw, (h == 0) ? r0.w : r1.w);
+                    }
+                }
+            }
         }
+    }
+  if (mine)
+    { u64 A = rb + ((((res >> SP_LB) << a.lstreams) + strm) << SP_LB);
+      const u32 off = (u32) res & lbm;
+      const u32 tl  = off + mycnt - 1;                      // the run's last record: the highest slot
+      const u64 last = A + ((u64) (tl >> SP_LB) << (SP_LB + a.lstreams)) + (u64) (tl & lbm);
+      if ((int64_t) last >= a.cap || last >= lm)
+        { *a.overflowed = 1;                                // the caller starts over with wider regions
+          A = ~0ull;
+        }
+      bbase[tid] = A;
+      bcnt[tid]  = off;
+    }
+  __syncthreads();
+
+  if (piped)
+    {
+#pragma unroll
+      for (int h = 0; h < 2; h++)
+        { const u32 m = (h == 0) ? m0 : m1;
+          if ((m & 0x40000000u) && nother != 0)
+            a.ent[ebase + atomicAdd(&nother2, 1u)] = m & 0x0fffffffu;
+          if (m & 0x80000000u)
+            { const u32 b = (m >> 20) & 0x7ffu;
+              u64 slot;
+              if (!slot_of(b, (h == 0) ? rank0 : rank1, slot))
+                continue;
+              u32 *dst = a.out + slot * sww;
+              const int i = (int) (m & 0xfffu);
+              const u32 flip = (m >> 12) & 1u;
+              if (POS)
+                a.pos[slot] = ((u64) (t0 + i) << 1) | flip;
+              if (sww == 5)
+                *(sp_rec5 *) dst = (h == 0) ? r0 : r1;
+              else
+                put_generic(i, flip, (int) ((m >> 13) & 0x7fu), dst);
+            }
+        }
+      return;
+    }
+  // a tile with more starts than the list takes (never seen on reads): round by round, ranks from a second counter
+  for (u32 base = 0; base < nstart_total; base += SP_PL)
+    { __syncthreads();
+      SP_LIST(base);
+      __syncthreads();
       const u32 lim = min(nstart_total, base + (u32) SP_PL);
       for (u32 s = base + tid; s < lim; s += SP_THREADS)
-        { const int i    = pos16[s - base];
-          const u32 key  = keys[SP_KIDX(i)];
-          // strand of the minimizer: its 7-mer against the reverse complement, both from the packed words
-          const int pm   = (int) ((key >> 1) & 0x3fffu);
-          const u32 flip = ((sp_window(rcw, R - 7 - pm) >> 18) < (sp_window(fwd, pm) >> 18)) ? 1u : 0u;
-          const u32 b    = one ? 0u : (u32) a.mbucket[key >> 15];
-          // length: distance to the next boundary, at most W <= 58 positions on; 64 (80 for k > 53)
-          // boundary bits from the word of i
-          const int qi = i >> 4, ci = i & 15;
-          u64 ab = ((u64) sbits[qi] | ((u64) sbits[qi + 1] << 16) | ((u64) sbits[qi + 2] << 32)
-                    | ((u64) sbits[qi + 3] << 48)) >> (ci + 1);
-          if (W > 47)
-            ab |= (u64) sbits[qi + 4] << (63 - ci);
-          const int n = __ffsll((long long) ab);
+        { int i, n; u32 flip, key;
+          describe(s - base, i, flip, n, key);
+          const u32 b = one ? 0u : (u32) a.mbucket[key >> 15];
           if (rec)
             { if (!(b >= (u32) a.gb0 && b < (u32) a.gb1))
                 { if (nother != 0)
@@ -549,33 +705,12 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
             }
           else if (b == a.skipb)
             continue;
-          const u64 lp   = bbase[b] + (one ? s : atomicAdd(&bcnt2[b], 1u));     // position in the tile's stream
-          const u64 slot = a.rbase[b] + (((((lp >> SP_LB) << a.lstreams) + strm) << SP_LB) | (lp & ((1u << SP_LB) - 1u)));
-          if ((int64_t) slot >= a.cap || (a.limit != NULL && slot >= a.limit[b]))
-            { *a.overflowed = 1;
-              continue;
-            }
-          const int  L   = n - 1 + K;
-          const u32 *arr = flip ? rcw : fwd;
-          const int  st  = flip ? (R - (i + L)) : i;
-          u32 *dst = a.out + slot * sww;
+          u64 slot;
+          if (!slot_of(b, one ? s : atomicAdd(&bcnt2[b], 1u), slot))
+            continue;
           if (POS)
             a.pos[slot] = ((u64) (t0 + i) << 1) | flip;
-          if (sww == 5)
-            sp_put_record5(arr, st, L, ((u32) (n - 1)) << lensh, lenw, dst);
-          else
-          for (int q = 0; q < sww; q++)
-            { u32 x = 0;
-              const int rem = L - 16 * q;
-              if (rem > 0)
-                { x = sp_window(arr, st + 16 * q);
-                  if (rem < 16)
-                    x &= ~(0xffffffffu >> (2 * rem));
-                }
-              if (q == lenw)
-                x |= ((u32) (n - 1)) << lensh;
-              dst[q] = __builtin_bswap32(x);
-            }
+          put_generic(i, flip, n, a.out + slot * sww);
         }
     }
 #undef SP_LIST
@@ -936,11 +1071,11 @@ static int sp_packed_args(fk_ctx *ctx, SplitArgs &a, const fk_pkview *pk, int64_
                    (long long) pk->nreads, (long long) pk->ninv);
       return (FK_EINVAL);
     }
-  u32 *tidx = (u32 *) fk_slot(ctx, FK_SLOT_PK_TIDX, ntiles * 8);
+  u32 *tidx = (u32 *) fk_slot(ctx, FK_SLOT_PK_TIDX, (ntiles + 2) * 8);      // a tile also looks at the entries of tile + 2
   if (tidx == NULL)
     return (FK_ENOMEM);
   hipStream_t s = ctx->stream;
-  FK_HIP(ctx, hipMemsetAsync(tidx, 0xff, (size_t) ntiles * 8, s));
+  FK_HIP(ctx, hipMemsetAsync(tidx, 0xff, (size_t) (ntiles + 2) * 8, s));
   const int64_t n = (pk->nreads > pk->ninv) ? pk->nreads : pk->ninv;
   hipLaunchKernelGGL(k_pk_tidx, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, pk->roff, pk->nreads, pk->inv, pk->ninv,
                      ntiles, (int64_t) SP_TILE, tidx);

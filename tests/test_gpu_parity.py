@@ -387,6 +387,10 @@ def test_packed_and_ascii_splitters_agree_on_ragged_reads():
             s[4090:4101] = ord("N")
             s[4500] = ord("R")
         reads.append(s.tobytes())
+    for lo, hi in ((3000, 15000), (100, 4096 * 3 + 7), (4096, 8192)):          # N runs longer than a tile
+        s = np.frombuffer(b"acgt", dtype=np.uint8)[rng.integers(0, 4, size=30000)].copy()
+        s[lo:hi] = ord("N")
+        reads.append(s.tobytes())
     reads += reads[50:90]                                     # repeats: counts above 1
     bases, boff = orc.block_from_reads(reads)
     exp = orc.fastk(k, bases, boff, cutoff=1)
