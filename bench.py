@@ -65,6 +65,8 @@ CONFIGS = {
 
 
 def parse():
+    if any(a == "--debug" or a.startswith("--debug=") for a in sys.argv[1:]):
+        os.environ["FASTK_AMD_TEST_KNOBS"] = "1"          # (fk_debug_set takes its knobs from measurement processes only)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -102,8 +104,21 @@ def parse():
                          "while piece i is counted (1 = one all-to-all, then count)")
     ap.add_argument("--debug", action="append", default=[], metavar="KEY=VALUE",
                     help="fk_debug_set knob for ablation runs (results may be invalid)")
+    ap.add_argument("--dump-table", default=None, metavar="DIR",
+                    help="N > 1 / --config 3: every rank writes its gathered range of the table to DIR/table.<rank> (tests)")
     ap.add_argument("--verbose", action="store_true")
     return ap.parse_args()
+
+
+def hist_file_sha256(kmer, hist, max_inst):
+    """sha256 of the bytes of <root>.hist for this histogram (count.c:1893-1910: int k, int 1, int 0x7fff, int64
+    counts[1], int64 max_inst, int64 counts[1..0x7fff]; 262,164 bytes) -- what the golden cases pin"""
+    import hashlib
+    h = np.asarray(hist, dtype=np.int64)
+    raw = np.array([kmer, 1, 0x7fff], dtype=np.int32).tobytes() + np.array([h[1], max_inst], dtype=np.int64).tobytes() \
+        + h[1:0x8000].astype(np.int64).tobytes()
+    assert len(raw) == 262164
+    return hashlib.sha256(raw).hexdigest()
 
 
 def log(args, *a):
@@ -524,6 +539,8 @@ def main_config3(args, cfg, torch, fastk_amd, dist, rank, local_rank, world, dev
         dist.all_reduce(t)
         gathered = int(t.item())
     assert gathered == last.ntable, "the final gather holds %d of %d table entries" % (gathered, last.ntable)
+    if args.dump_table:
+        shard.gather(last, nparts, copy=True).tofile(os.path.join(args.dump_table, "table.%d" % rank))
     scale_note = "" if args.scale == 1.0 else " SCALED by %g (development run)" % args.scale
     # roofline of the graded kernel on rank 0's share: k_rx_scatter<3,12> over the weighted k-mers of the pieces
     # this rank counted (2 launches per piece), same accounting as at N = 1
@@ -538,11 +555,28 @@ def main_config3(args, cfg, torch, fastk_amd, dist, rank, local_rank, world, dev
                     kernel="k_rx_scatter<3,12> (weighted k-mer records, R=%d B), rank 0's share" % w.kmer_word,
                     records_per_launch=int(loc.nweighted / (nl / passes_k)), launches_per_step=int(nl),
                     avg_launch_ms=round(loc.ms_scatter_kmer / nl, 4))
-    out = dict(metric="canonical k-mers/sec (k=40, whole hot path incl. the final gather of the table to host memory, reads resident in HBM)",
+    # what the exchanges moved, rank by rank (fk_shard_get_stats): how many ranks RCCL's communicator really holds,
+    # the super-mer bytes every rank sent / received / kept in C1, the device time of its sends and receives (they
+    # overlap the counting), and C3 by phase
+    mine = shard.stats()
+    keys = ("comm_ranks", "rounds", "sent_bytes", "recv_bytes", "kept_bytes", "exchange_ms", "gather_sent_bytes",
+            "gather_exchange_ms", "gather_sort_ms", "gather_d2h_ms")
+    row = torch.tensor([float(mine[k]) for k in keys], dtype=torch.float64, device=dev)
+    rows = [torch.zeros_like(row) for _ in range(world)]
+    if dist is not None:
+        dist.all_gather(rows, row)
+    else:
+        rows = [row]
+    per_rank = [dict((k, (int(v) if k.endswith("bytes") or k in ("comm_ranks", "rounds") else round(float(v), 3)))
+                     for k, v in zip(keys, r.tolist())) for r in rows]
+    out = dict(metric="canonical k-mers/sec (k=%d, whole hot path incl. the final gather of the table to host memory, reads resident "
+                      "in HBM as 0-terminated ASCII)" % args.kmer,
                value=last.ninst / (dt / args.steps), unit="k-mers/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                ms_per_step=1e3 * dt / args.steps, higher_is_better=True, scaling="strong", vs_baseline=None,
                dtype="u8", data="synthetic",
                gather_ms=round(1e3 * gather_s / args.steps, 3), count_ms=round(1e3 * (dt - gather_s) / args.steps, 3),
+               rccl_ranks=per_rank[0]["comm_ranks"], exchange=per_rank,
+               hist_file_sha256=hist_file_sha256(args.kmer, last.hist, last.max_inst),
                value_without_gather=last.ninst / max((dt - gather_s) / args.steps, 1e-9),
                config=dict(workload=cfg["label"] % (cfg["genome_mbp"] * args.scale, "", args.kmer) + scale_note,
                            reads_per_gpu=per, bases_per_gpu=per * L, kmer_instances=int(last.ninst),
@@ -814,6 +848,22 @@ def main():
     ms_step = 1e3 * dt / args.steps
     value = ninst / (dt / args.steps)
     log(args, "timed: %.3f s per step" % (dt / args.steps), loc.ms)
+    # the N > 1 lines end with the sorted table in pinned host memory (the final gather): the same boundary at N = 1
+    # is the step + the D2H of its table -- one warm-up call (it pins the host buffer), then one timed
+    on_host = None
+    if not sharded and cfg["cutoff"] > 0:
+        ctx.count_device_reads(reads.data_ptr(), nbytes, fetch_table=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r_h = ctx.count_device_reads(reads.data_ptr(), nbytes, fetch_table=True)
+        torch.cuda.synchronize()
+        dt_h = time.perf_counter() - t0
+        assert r_h.ntable == last.ntable and len(r_h.table) == r_h.ntable
+        on_host = dict(value=ninst / dt_h, unit="k-mers/s", ms_per_step=round(1e3 * dt_h, 3),
+                       d2h_bytes=int(r_h.ntable) * ctx.w.kmer_word,
+                       definition="the step + its sorted table brought to pinned host memory: the boundary of the N > 1 "
+                                  "lines (their final gather), for a scaling curve computed against this N = 1 point")
+        del r_h
 
     w = ctx.w
     roofline = roofline_record(loc, w, cfg_id, ceiling, ceiling_kernel)
@@ -824,7 +874,10 @@ def main():
         workload = "custom: " + workload
     out = dict(metric="canonical k-mers/sec (k=%d, whole hot path, reads resident in HBM as 0-terminated ASCII)" % args.kmer,
                value=value, unit="k-mers/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
-               ms_per_step=ms_step, higher_is_better=True, scaling="weak", vs_baseline=None,
+               ms_per_step=ms_step, higher_is_better=True,
+               # N = 1 is the first point of the curve whose N > 1 points stripe the SAME read set over the GPUs
+               # (configs[3]): total work fixed.  (--config 1 with N > 1 is a per-GPU workload: weak.)
+               scaling="weak" if (sharded and cfg_id == 1) else "strong", vs_baseline=None,
                dtype="u8", data="synthetic",
                config=dict(workload=workload, reads_per_gpu=per, bases_per_gpu=per * L,
                            kmer_instances=int(ninst), supermers=int(nsuper),
@@ -837,6 +890,8 @@ def main():
                                        "over the resident reads" % (loc.buckets_counted, loc.split_passes)),
                roofline=roofline,
                stage_ms=dict((k, round(v, 3)) for k, v in loc.ms.items()))
+    if on_host is not None:
+        out["value_with_table_on_host"] = on_host
     if not sharded:
         out["stage_ms"]["table_sort"] = round(loc.ms_table_sort, 3)
         out["histogram_sha256"] = __import__("hashlib").sha256(h.tobytes()).hexdigest()

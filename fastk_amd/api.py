@@ -29,7 +29,7 @@ EXPORTS = [
     "fk_write_ktab_range", "fk_write_ktab_stub", "fk_split_supermers_emit_pos", "fk_profile_lookup_supermers",
     "fk_profile_scatter", "fk_profile_encode", "fk_reset", "fk_shard_unique_id", "fk_shard_create",
     "fk_release_device", "fk_set_sort_memory", "fk_finish_device", "fk_write_ktab_device", "fk_push_packed", "fk_pack_fixed_reads", "fk_copy_rate", "fk_shard_count", "fk_shard_gather", "fk_shard_write", "fk_shard_destroy", "fk_shard_count_device", "fk_shard_local_result",
-    "fk_count_device_packed",
+    "fk_count_device_packed", "fk_shard_get_stats", "fk_shard_profiles", "fk_shard_write_prof", "fk_write_prof_range", "fk_shard_sum_i64",
 ]
 
 
@@ -67,6 +67,12 @@ class CResult(C.Structure):
 class CProfiles(C.Structure):
     _fields_ = [("nreads", C.c_int64), ("nbytes", C.c_int64), ("data", C.POINTER(C.c_uint8)),
                 ("offsets", C.POINTER(C.c_int64)), ("nsplit", C.c_int), ("split", C.POINTER(C.c_int64))]
+
+
+class ShardStats(C.Structure):
+    _fields_ = [("comm_ranks", C.c_int), ("rounds", C.c_int), ("sent_bytes", C.c_int64), ("recv_bytes", C.c_int64),
+                ("kept_bytes", C.c_int64), ("exchange_ms", C.c_double), ("gather_sent_bytes", C.c_int64),
+                ("gather_exchange_ms", C.c_double), ("gather_sort_ms", C.c_double), ("gather_d2h_ms", C.c_double)]
 
 
 class SortStats(C.Structure):
@@ -123,6 +129,7 @@ def load_library():
     L.fk_shard_local_result.argtypes = [vp, C.POINTER(CResult)]
     L.fk_shard_write.argtypes = [vp, C.POINTER(CResult), ci, C.c_char_p, C.c_char_p]
     L.fk_shard_gather.argtypes = [vp, C.POINTER(CResult), ci, C.POINTER(vp), C.POINTER(i64)]
+    L.fk_shard_get_stats.argtypes = [vp, C.POINTER(ShardStats)]
     L.fk_shard_destroy.argtypes = [vp]
     L.fk_shard_destroy.restype = None
     L.fk_count_device_reads.argtypes = [vp, vp, i64, ci, C.POINTER(CResult)]
@@ -597,6 +604,12 @@ class Shard:
 
     def write(self, res, nparts, outdir, root):
         self.ctx._ck(self.ctx.L.fk_shard_write(self.h, C.byref(res._c), nparts, outdir.encode(), root.encode()))
+
+    def stats(self):
+        """what this rank's last count (C1) and gather (C3) moved, over how many RCCL ranks"""
+        st = ShardStats()
+        self.ctx._ck(self.ctx.L.fk_shard_get_stats(self.h, C.byref(st)))
+        return dict((n, getattr(st, n)) for n, _ in ShardStats._fields_)
 
     def close(self):
         if self.h:

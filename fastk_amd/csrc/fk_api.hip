@@ -531,6 +531,17 @@ extern "C" int fk_copy_to_host(fk_ctx *ctx, void *dst, const void *d_src, int64_
    exist only in -DFK_ABLATION builds. */
 extern "C" int fk_debug_set(fk_ctx *ctx, const char *key, int64_t value)
 { if (ctx == NULL || key == NULL) return (FK_EINVAL);
+  // Only "verbose" is for users.  Everything else selects another (valid, slower or smaller) code path and exists for
+  // the parity tests and measurement scripts: the library takes those knobs only from a process that says it is
+  // one (FASTK_AMD_TEST_KNOBS=1: tests/conftest.py and bench.py --debug set it), so that no product caller can
+  // switch the path it runs by accident.
+  if (strcmp(key, "verbose") != 0)
+    { const char *e = getenv("FASTK_AMD_TEST_KNOBS");
+      if (e == NULL || strcmp(e, "1") != 0)
+        { fk_set_error(ctx, "fk_debug_set(%s): test and measurement knobs need FASTK_AMD_TEST_KNOBS=1 in the environment", key);
+          return (FK_EUNSUPPORTED);
+        }
+    }
 #ifdef FK_ABLATION
   if (strcmp(key, "radix_variant") == 0)   // ablated look-back kernels: WRONG output, isolates one cost each
     { ctx->dbg_radix_variant = (int) value;
@@ -753,10 +764,8 @@ extern "C" int fk_msd_sort_records(fk_ctx *ctx, void *d_array, void *d_tmp, int6
                                    int ksize, void **result)
 { if (ctx == NULL || result == NULL || nelem < 0 || ksize < 0 || ksize > rsize || ksize > 60)
     return (FK_EINVAL);
-  int bytes[64];
-  for (int i = 0; i < ksize; i++)
-    bytes[i] = ksize - 1 - i;      // least significant key byte first
-  return fkx_lsd_sort(ctx, nelem, d_array, d_tmp, rsize, bytes, ksize, result);
+  // the MSD engine (fk_tsort.hip): ceil(log256 n) levels whatever ksize is, small parts finished in LDS
+  return fkx_msd_sort(ctx, nelem, d_array, d_tmp, rsize, ksize, result);
 }
 
 extern "C" int fk_group_records(fk_ctx *ctx, int64_t nelem, void *d_src, void *d_trg, int rsize,

@@ -125,6 +125,7 @@ struct fk_ctx
   u32       *d_ticket;     // [64] tile tickets
   fk_sort_stats sort_stats;
   u64        rx_attr_done; // wide scatter instantiations whose dynamic-LDS attribute is set on this context's device
+  int        rx_top_pbytes;// fkx_lsd_sort_top: leading bytes the records are in order on afterwards
 
   // streaming interface state
   char      *d_reads;      // pushed reads (HBM)
@@ -319,6 +320,7 @@ int fkx_parse_fasta(fk_ctx *ctx, const void *d_raw, int64_t nbytes, int state, v
                     int64_t *nkept, int64_t *nrecs);
 int fkx_dedup_supermers(fk_ctx *ctx, const void *d_grouped, int64_t n, void *d_out, int64_t cap, int64_t *nout);
 int fkx_sort_table(fk_ctx *ctx, int64_t n, void *d_tab, void *d_tmp, void **result, int64_t *wfirst);
+int fkx_msd_sort(fk_ctx *ctx, int64_t n, void *d_a, void *d_b, int rsize, int ksize, void **result);
 int fkx_profiles(fk_ctx *ctx, const void *d_bases, int64_t nbytes, const void *d_table, int64_t nt,
                  int64_t *nreads_out, int64_t *nprof_out, void **d_data, uint64_t **d_offs);
 int fkx_profile_lookup_supermers(fk_ctx *ctx, const void *d_smers, int64_t ns, const void *d_table, int64_t nt,

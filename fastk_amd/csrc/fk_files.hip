@@ -25,30 +25,37 @@ static int write_all(int fd, const void *p, size_t n)
 // (count.c:1893-1910, README.md:936-961)
 // <root>.prof stub + hidden .<root>.pidx.N / .<root>.prof.N (README "K-mer Profile Files"); part t
 // holds reads [t nreads / nparts, (t+1) nreads / nparts)
-extern "C" int fk_write_prof(const fk_profiles *p, int kmer, int nparts, const char *dir, const char *root)
-{ if (p == NULL || dir == NULL || root == NULL || nparts < 1 || (p->nreads > 0 && p->offsets == NULL))
+// parts part0 .. part0 + nhere - 1 of an nparts-part profile set from the reads of p, whose first read is read
+// `read_base` of the data set; the stub with stub != 0
+extern "C" int fk_write_prof_range(const fk_profiles *p, int kmer, int nparts, int part0, int nhere, int64_t read_base,
+                                   int stub, const char *dir, const char *root)
+{ if (p == NULL || dir == NULL || root == NULL || nparts < 1 || part0 < 0 || nhere < 1 || part0 + nhere > nparts
+      || (p->nreads > 0 && p->offsets == NULL))
     return (FK_EINVAL);
   char path[4096];
-  snprintf(path, sizeof(path), "%s/%s.prof", dir, root);
-  int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
-  if (fd < 0)
-    { fk_set_error(NULL, "Cannot open %s for writing", path);
-      return (FK_EINVAL);
+  int  bad = 0, fd;
+  if (stub)
+    { snprintf(path, sizeof(path), "%s/%s.prof", dir, root);
+      fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+      if (fd < 0)
+        { fk_set_error(NULL, "Cannot open %s for writing", path);
+          return (FK_EINVAL);
+        }
+      int32_t st[2] = { kmer, nparts };
+      bad = write_all(fd, st, 8);
+      close(fd);
     }
-  int32_t stub[2] = { kmer, nparts };
-  int bad = write_all(fd, stub, 8);
-  close(fd);
-  for (int t = 0; t < nparts && !bad; t++)
-    { const bool by_thread = (p->nsplit == nparts && p->split != NULL);
-      const int64_t r0 = by_thread ? p->split[t] : p->nreads * t / nparts;
-      const int64_t r1 = by_thread ? p->split[t + 1] : p->nreads * (t + 1) / nparts;
-      const int64_t n = r1 - r0;
+  for (int t = 0; t < nhere && !bad; t++)
+    { const bool by_thread = (p->nsplit == nhere && p->split != NULL && nhere == nparts);
+      const int64_t r0 = by_thread ? p->split[t] : p->nreads * t / nhere;
+      const int64_t r1 = by_thread ? p->split[t + 1] : p->nreads * (t + 1) / nhere;
+      const int64_t n = r1 - r0, g0 = read_base + r0;
       const int64_t b0 = (n > 0) ? p->offsets[r0] : 0;
-      snprintf(path, sizeof(path), "%s/.%s.pidx.%d", dir, root, t + 1);
+      snprintf(path, sizeof(path), "%s/.%s.pidx.%d", dir, root, part0 + t + 1);
       fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
       if (fd < 0) { bad = 1; break; }
       int32_t k32 = kmer;
-      bad |= write_all(fd, &k32, 4) | write_all(fd, &r0, 8) | write_all(fd, &n, 8);
+      bad |= write_all(fd, &k32, 4) | write_all(fd, &g0, 8) | write_all(fd, &n, 8);
       int64_t buf[4096];
       for (int64_t i = 0; i < n && !bad; i += 4096)
         { const int64_t m = (n - i < 4096) ? n - i : 4096;
@@ -57,7 +64,7 @@ extern "C" int fk_write_prof(const fk_profiles *p, int kmer, int nparts, const c
           bad |= write_all(fd, buf, (size_t) m * 8);
         }
       close(fd);
-      snprintf(path, sizeof(path), "%s/.%s.prof.%d", dir, root, t + 1);
+      snprintf(path, sizeof(path), "%s/.%s.prof.%d", dir, root, part0 + t + 1);
       fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
       if (fd < 0) { bad = 1; break; }
       if (n > 0 && p->offsets[r1] > b0)
@@ -70,6 +77,9 @@ extern "C" int fk_write_prof(const fk_profiles *p, int kmer, int nparts, const c
     }
   return (FK_OK);
 }
+
+extern "C" int fk_write_prof(const fk_profiles *p, int kmer, int nparts, const char *dir, const char *root)
+{ return fk_write_prof_range(p, kmer, nparts, 0, nparts, 0, 1, dir, root); }
 
 extern "C" int fk_write_hist(const fk_result *res, int kmer, const char *path)
 { if (res == NULL || path == NULL) return (FK_EINVAL);

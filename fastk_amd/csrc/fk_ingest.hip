@@ -526,6 +526,9 @@ extern "C" int fk_push_packed(fk_ctx *ctx, const uint8_t *codes, int64_t nbases,
             hinv[2 * ninv + 1] = npos - nbases;
           }
       }
+      // (a copy KERNEL reading the pinned block across PCIe instead of hipMemcpyAsync was tried in round 4: 1.40 s
+      //  instead of 1.15 s inside the 2,236 pushes of configs[2] -- the ~32 GB/s of these 17 MB blocks is not the
+      //  copy engine's set-up)
       if ((cbytes > 0 && hipMemcpyAsync(ctx->d_reads + ctx->reads_len, codes, (size_t) cbytes, hipMemcpyHostToDevice, ps) != hipSuccess)
           || hipMemcpyAsync(st->roff + st->nreads, hro, (size_t) (nreads + 1) * 8, hipMemcpyHostToDevice, ps) != hipSuccess
           || (ninv + pad > 0

@@ -197,8 +197,16 @@ extern "C" int fk_write_ktab_device(fk_ctx *ctx, const fk_result *res, int nthre
     }
   memcpy(pc.data(), ctx->ktab_ends, (size_t) npre * 8);
   memcpy(hb, ctx->ktab_first, sizeof(hb));
-  if (n > 0 && (rc = ktab_staging(ctx, nthreads, ib)) != FK_OK)
-    return (rc);
+  // The pinned staging fk_finish_device made serves ctx->prm.nthreads writers.  More parts than that do not get more
+  // staging here -- hipHostFree / hipHostMalloc beside a running fk_release_device is the stall the prepare step
+  // exists to avoid -- they take turns at what exists: `lanes` writers run at a time.
+  if (n > 0 && ctx->wstage_cap < 2 * pbytes && (rc = ktab_staging(ctx, nthreads, ib)) != FK_OK)
+    return (rc);                                       // (no fk_finish_device before: nothing is being released either)
+  if (n > 0)
+    for (int i = 0; i < 4; i++)
+      if (ctx->wstream[i] == NULL)
+        FK_HIP(ctx, hipStreamCreateWithFlags(&ctx->wstream[i], hipStreamNonBlocking));
+  const int lanes = (n > 0) ? (int) std::min<int64_t>(nthreads, std::max<int64_t>(ctx->wstage_cap / (2 * pbytes), 1)) : nthreads;
   unsigned char *h_stage = ctx->h_wstage;
   const double tw1 = fk_wall();
   std::vector<int> prc((size_t) nthreads, FK_OK);
@@ -215,7 +223,8 @@ extern "C" int fk_write_ktab_device(fk_ctx *ctx, const fk_result *res, int nthre
         ok = (hipSetDevice(ctx->device) == hipSuccess
               && hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) == hipSuccess
               && hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) == hipSuccess);
-      unsigned char *pin[2] = { h_stage + pbytes * (2 * t), h_stage + pbytes * (2 * t + 1) };
+      const int ln = t % lanes;                           // (parts t, t + lanes, ... are written one after the other)
+      unsigned char *pin[2] = { h_stage + pbytes * (2 * ln), h_stage + pbytes * (2 * ln + 1) };
       auto fetch = [&](int64_t x, int which) -> bool
         { const int64_t m = std::min(hi, x + piece) - x;
           const int64_t words = (m * pw + 3) / 4;
@@ -252,10 +261,11 @@ extern "C" int fk_write_ktab_device(fk_ctx *ctx, const fk_result *res, int nthre
       if (close(fd) != 0) ok = false;
       if (!ok) prc[t] = FK_EINVAL;
     };
-  { std::vector<std::thread> th;
-    for (int t = 1; t < nthreads; t++)
-      th.emplace_back(write_part, t);
-    write_part(0);
+  { auto lane = [&](int l) { for (int t = l; t < nthreads; t += lanes) write_part(t); };
+    std::vector<std::thread> th;
+    for (int l = 1; l < lanes; l++)
+      th.emplace_back(lane, l);
+    lane(0);
     for (auto &x : th)
       x.join();
   }

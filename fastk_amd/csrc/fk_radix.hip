@@ -975,9 +975,11 @@ static int lsd_sort_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, const in
 
 #endif   // FK_ABLATION
 
+// top > 0 (the MSD engine, fk_tsort.hip): of the non-constant digits only the `top` most significant -- the last
+// `top` of bytes[] -- are passes; ctx->rx_top_pbytes = bytes the records are then in order on.
 template <int RW, int ITEMS, bool HASHED, int WT>
 static int lsd_sort_stream_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, const int *bytes,
-                             int nbytes, void **result, int hbytes)
+                             int nbytes, void **result, int hbytes, int top = 0)
 { constexpr int TILE = WT * ITEMS;
   const int64_t ntiles  = (n + TILE - 1) / TILE;
   const int64_t nchunks = (ntiles + RX_CH - 1) / RX_CH;
@@ -1059,6 +1061,18 @@ static int lsd_sort_stream_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, c
               constant = true;
           if (!constant)
             run[nrun++] = bytes[i];
+        }
+    }
+  if (top > 0)
+    { // bytes[] holds the leading key bytes, least significant first: of the non-constant ones the `top` most
+      // significant are levels (every byte in front of the last level that is not a level is constant); with no
+      // more non-constant bytes than levels the records come out in order on all the bytes given
+      ctx->rx_top_pbytes = bytes[0] + 1;
+      if (nrun > top)
+        { for (int i = 0; i < top; i++)
+            run[i] = run[nrun - top + i];
+          nrun = top;
+          ctx->rx_top_pbytes = run[0] + 1;
         }
     }
   if (nrun == 0)
@@ -1147,7 +1161,7 @@ static int lsd_sort_stream_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, c
 
 template <bool HASHED>
 static int sort_dispatch(fk_ctx *ctx, int64_t nelem, void *d_src, void *d_trg, int rsize,
-                         const int *bytes, int nbytes, void **result, int hbytes)
+                         const int *bytes, int nbytes, void **result, int hbytes, int top = 0)
 { if (rsize <= 0 || (rsize & 3) != 0 || rsize > 32)
     { fk_set_error(ctx, "record size %d not supported (multiple of 4, <= 32)", rsize);
       return (FK_EUNSUPPORTED);
@@ -1159,11 +1173,11 @@ static int sort_dispatch(fk_ctx *ctx, int64_t nelem, void *d_src, void *d_trg, i
   const int it = ctx->dbg_radix_items;      // measurement aid: alternative tile sizes for R = 12, 20
   const bool lookback = (ctx->dbg_radix_engine == 1 || ctx->dbg_radix_variant != 0 || it != 0);
 #define RX_CASE(RW) return (lookback ? lsd_sort_t<RW, RxCfg<RW>::ITEMS, HASHED>(ctx, nelem, d_src, d_trg, bytes, nbytes, result) \
-                     : narrow ? lsd_sort_stream_t<RW, RxCfg<RW>::ITEMS, HASHED, RX_THREADS>(ctx, nelem, d_src, d_trg, bytes, nbytes, result, hbytes) \
-                              : lsd_sort_stream_t<RW, RxCfgW<RW>::ITEMS, HASHED, RXW_THREADS>(ctx, nelem, d_src, d_trg, bytes, nbytes, result, hbytes))
+                     : narrow ? lsd_sort_stream_t<RW, RxCfg<RW>::ITEMS, HASHED, RX_THREADS>(ctx, nelem, d_src, d_trg, bytes, nbytes, result, hbytes, top) \
+                              : lsd_sort_stream_t<RW, RxCfgW<RW>::ITEMS, HASHED, RXW_THREADS>(ctx, nelem, d_src, d_trg, bytes, nbytes, result, hbytes, top))
 #else
-#define RX_CASE(RW) return (narrow ? lsd_sort_stream_t<RW, RxCfg<RW>::ITEMS, HASHED, RX_THREADS>(ctx, nelem, d_src, d_trg, bytes, nbytes, result, hbytes) \
-                                   : lsd_sort_stream_t<RW, RxCfgW<RW>::ITEMS, HASHED, RXW_THREADS>(ctx, nelem, d_src, d_trg, bytes, nbytes, result, hbytes))
+#define RX_CASE(RW) return (narrow ? lsd_sort_stream_t<RW, RxCfg<RW>::ITEMS, HASHED, RX_THREADS>(ctx, nelem, d_src, d_trg, bytes, nbytes, result, hbytes, top) \
+                                   : lsd_sort_stream_t<RW, RxCfgW<RW>::ITEMS, HASHED, RXW_THREADS>(ctx, nelem, d_src, d_trg, bytes, nbytes, result, hbytes, top))
 #endif
   switch (rsize >> 2)
   { case 1: RX_CASE(1);
@@ -1190,6 +1204,14 @@ static int sort_dispatch(fk_ctx *ctx, int64_t nelem, void *d_src, void *d_trg, i
 int fkx_lsd_sort(fk_ctx *ctx, int64_t nelem, void *d_src, void *d_trg, int rsize,
                  const int *bytes, int nbytes, void **result)
 { return sort_dispatch<false>(ctx, nelem, d_src, d_trg, rsize, bytes, nbytes, result, rsize); }
+
+// the levels of the MSD engine (fk_tsort.hip): bytes[] = the leading key bytes, least significant first; of the
+// non-constant ones the `top` most significant become passes
+int fkx_lsd_sort_top(fk_ctx *ctx, int64_t nelem, void *d_src, void *d_trg, int rsize, const int *bytes, int nbytes,
+                     int top, void **result)
+{ ctx->rx_top_pbytes = (nbytes > 0) ? bytes[0] + 1 : 0;
+  return sort_dispatch<false>(ctx, nelem, d_src, d_trg, rsize, bytes, nbytes, result, rsize, top);
+}
 
 // Make records with identical first key_bytes adjacent: npasses stable digit passes over a hash of them.
 // This is all the super-mer "sort" has to achieve (count.c:421-426 only run-length encodes

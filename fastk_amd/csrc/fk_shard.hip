@@ -34,6 +34,7 @@ struct fk_rccl
   ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
   ncclResult_t (*GroupStart)();
   ncclResult_t (*GroupEnd)();
+  ncclResult_t (*CommCount)(const ncclComm_t, int *);
   const char  *(*GetErrorString)(ncclResult_t);
 };
 
@@ -56,6 +57,7 @@ static int load_rccl(fk_ctx *ctx)
   SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy")
   SYM(Send, "ncclSend") SYM(Recv, "ncclRecv") SYM(AllReduce, "ncclAllReduce") SYM(AllGather, "ncclAllGather")
   SYM(GroupStart, "ncclGroupStart") SYM(GroupEnd, "ncclGroupEnd") SYM(GetErrorString, "ncclGetErrorString")
+  SYM(CommCount, "ncclCommCount")
 #undef SYM
   g_rccl_ok = true;
   return (FK_OK);
@@ -91,7 +93,28 @@ struct fk_shard
   int64_t     g_n;                // entries gathered (-1: none)
   int         g_nparts, g_ib;
   int         g_split[257];
+  // fk_shard_profiles: records + positions of the piece, counts made for the others, counts that came back
+  void       *pf_buf[4];
+  int64_t     pf_cap[4];
+  // what the last fk_shard_count / fk_shard_gather moved (fk_shard_get_stats)
+  fk_shard_stats st;
+  hipEvent_t  tev[2 * 256];       // begin / end of every exchange round on xs (timing events, made on first use)
 };
+
+// all ranks learn whether any of them failed: every rank passes its own rc and gets the first failure (its own,
+// or FK_EHIP for a peer's) -- so that a rank that ran out of memory does not leave the others in a collective
+static int allreduce_i64(fk_shard *sh, int64_t *vals, int n);
+static int agree(fk_shard *sh, int rc)
+{ int64_t bad = (rc != FK_OK) ? 1 : 0;
+  const int rc2 = allreduce_i64(sh, &bad, 1);
+  if (rc != FK_OK) return (rc);
+  if (rc2 != FK_OK) return (rc2);
+  if (bad != 0)
+    { fk_set_error(sh->ctx, "sharded run: another rank failed (rank %d stops with it)", sh->rank);
+      return (FK_EHIP);
+    }
+  return (FK_OK);
+}
 
 extern "C" int fk_shard_unique_id(char *id128)
 { if (id128 == NULL) return (FK_EINVAL);
@@ -122,7 +145,28 @@ extern "C" void fk_shard_destroy(fk_shard *sh)
   for (int i = 0; i < 2; i++)
     if (sh->g_dev[i]) hipFree(sh->g_dev[i]);
   if (sh->g_host) fkx_pinned_free(sh->g_host);
+  for (int i = 0; i < 2 * 256; i++)
+    if (sh->tev[i]) hipEventDestroy(sh->tev[i]);
+  for (int i = 0; i < 4; i++)
+    if (sh->pf_buf[i]) hipFree(sh->pf_buf[i]);
   free(sh);
+}
+
+/* element-wise sum of n int64 over all ranks, in place (host memory): what a C host needs to agree on totals */
+extern "C" int fk_shard_sum_i64(fk_shard *sh, int64_t *vals, int n)
+{ if (sh == NULL || vals == NULL || n < 1) return (FK_EINVAL);
+  FK_HIP(sh->ctx, hipSetDevice(sh->ctx->device));
+  return allreduce_i64(sh, vals, n);
+}
+
+extern "C" int fk_shard_get_stats(fk_shard *sh, fk_shard_stats *st)
+{ if (sh == NULL || st == NULL) return (FK_EINVAL);
+  *st = sh->st;
+  st->rounds = sh->rounds;
+  int n = 0;
+  if (sh->comm != NULL && g_rccl.CommCount(sh->comm, &n) == ncclSuccess)
+    st->comm_ranks = n;
+  return (FK_OK);
 }
 
 extern "C" int fk_shard_create(fk_ctx *ctx, int rank, int world, const char *id128, fk_shard **out)
@@ -241,15 +285,36 @@ static int reserve_inbox(fk_shard *sh, int i, int64_t bytes)
    res: the GLOBAL histogram, max_inst and totals (identical on every rank), wfirst = first-byte census of
    the whole table, ntable = its entries; res->table is NULL -- every rank's share stays in HBM for
    fk_shard_write.  Returns FK_EHIP with a message if the exchange did not conserve records or k-mers. */
-static int shard_count(fk_shard *sh, const void *d_reads, int64_t reads_len, fk_result *res, const fk_pkview *pk = NULL);
+static int shard_count(fk_shard *sh, const void *d_reads, int64_t reads_len, fk_result *res, const fk_pkview *pk = NULL,
+                       bool chunked = false);
 
 extern "C" int fk_shard_count(fk_shard *sh, fk_result *res)
 { if (sh == NULL || res == NULL) return (FK_EINVAL);
   fk_ctx *ctx = sh->ctx;
   FK_HIP(ctx, hipSetDevice(ctx->device));
-  if (ctx->chunk_bytes > 0 || ctx->prm.exact_parts)
-    { fk_set_error(ctx, "fk_shard_count: the sharded run keeps its stripe of reads resident (hbm_budget 0, no exact_parts)");
+  if (ctx->prm.exact_parts)
+    { fk_set_error(ctx, "fk_shard_count: exact_parts runs on one GPU");
       return (FK_EUNSUPPORTED);
+    }
+  if (ctx->chunk_bytes > 0)
+    { // hbm_budget > 0 (FastK_amd -G<n> -M<GB>): the stripe was split chunk by chunk as it was pushed and its
+      // records wait in the slab store / in pinned host memory; the rest of the reads becomes the last chunk
+      pthread_mutex_lock((pthread_mutex_t *) ctx->push_lock);
+      int rc = fkx_flush_join(ctx);
+      if (rc == FK_OK)
+        rc = fkx_flush_chunk(ctx);
+      pthread_mutex_unlock((pthread_mutex_t *) ctx->push_lock);
+      if (rc != FK_OK)
+        return (rc);
+      FK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+      FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      rc = shard_count(sh, NULL, 0, res, NULL, true);
+      for (int i = 0; i < ctx->nchunks; i++)
+        fkx_free_chunk(ctx, &ctx->chunks[i]);
+      ctx->nchunks = 0;
+      fkx_rewind_slabs(ctx);
+      ctx->chunk_ninst = 0;
+      return (rc);
     }
   FK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
   FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -287,7 +352,10 @@ extern "C" int fk_shard_count_device(fk_shard *sh, const void *d_bases, int64_t 
   return shard_count(sh, d_bases, nbytes, res);
 }
 
-static int shard_count(fk_shard *sh, const void *d_reads, int64_t reads_len, fk_result *res, const fk_pkview *pk)
+// chunked: the records are the chunks of the budgeted ingest (fk_ingest.hip) -- per bucket one run per chunk, in the
+// slab store or spilled to pinned host memory; a round's buckets are gathered into one of two round buffers right
+// before they travel (the role of the gather in front of a bucket's count in the one-GPU budgeted run).
+static int shard_count(fk_shard *sh, const void *d_reads, int64_t reads_len, fk_result *res, const fk_pkview *pk, bool chunked)
 { fk_ctx *ctx = sh->ctx;
   const int W = sh->world, R = sh->rounds, me = sh->rank, nb = ctx->prm.nbuckets;
   const int stride = ctx->wid.smer_stride;
@@ -295,9 +363,33 @@ static int shard_count(fk_shard *sh, const void *d_reads, int64_t reads_len, fk_
   // ---- split this rank's reads into bucketed super-mers (planned regions, exact pair on overflow)
   int64_t cap = 0, offs[257], cnt[256], ninst = 0;
   void   *outbox = NULL;
+  char   *rbox[2] = { NULL, NULL };              // chunked: the round buffers
   memset(cnt, 0, sizeof(cnt));
   memset(offs, 0, sizeof(offs));
-  int rc = fkx_split_plan(ctx, d_reads, reads_len, &cap, offs, pk);
+  int rc = FK_OK;
+  if (chunked)
+    { int64_t rmax = 1;
+      for (int b = 0; b < nb; b++)
+        for (int c = 0; c < ctx->nchunks; c++)
+          cnt[b] += ctx->chunks[c].cnt[b];
+      ninst = ctx->chunk_ninst;
+      for (int r = 0; r < R; r++)
+        { int64_t sum = 0;
+          for (int p = 0; p < W; p++) sum += cnt[r * W + p];
+          rmax = std::max(rmax, sum);
+        }
+      if ((rbox[0] = (char *) fk_slot(ctx, FK_SLOT_SM_A, rmax * stride)) == NULL
+          || (R > 1 && (rbox[1] = (char *) fk_slot(ctx, FK_SLOT_SM_G, rmax * stride)) == NULL))
+        return (FK_ENOMEM);
+      // (offs[] are relative to the round buffer of the bucket's round)
+      for (int r = 0; r < R; r++)
+        { int64_t run = 0;
+          for (int p = 0; p < W; p++) { offs[r * W + p] = run; run += cnt[r * W + p]; }
+        }
+    }
+  else
+  {
+  rc = fkx_split_plan(ctx, d_reads, reads_len, &cap, offs, pk);
   if (rc != FK_OK) return (rc);
   if (cap > 0)
     { if ((outbox = fk_slot(ctx, FK_SLOT_SM_A, cap * stride)) == NULL) return (FK_ENOMEM);
@@ -314,6 +406,7 @@ static int shard_count(fk_shard *sh, const void *d_reads, int64_t reads_len, fk_
       else if (rc != FK_OK)
         return (rc);
     }
+  }
 
   // ---- who sends how much to whom: all[s*nb + b] = records of bucket b at rank s
   std::vector<int64_t> all((size_t) W * nb);
@@ -333,6 +426,22 @@ static int shard_count(fk_shard *sh, const void *d_reads, int64_t reads_len, fk_
   auto post = [&](int r) -> int
     { char   *sp[256], *rp[256];
       int64_t sb[256], rb[256], run = 0;
+      if (chunked)
+        { // the round's buckets out of the chunk store, on the exchange stream in front of the sends (round buffer
+          // r & 1 was last read by the sends of round r - 2, which round r - 1's count waited for)
+          outbox = rbox[r & 1];
+          for (int p = 0; p < W; p++)
+            { const int b = r * W + p;
+              int64_t at = offs[b];
+              for (int c = 0; c < ctx->nchunks; c++)
+                { const fk_chunk *ch = &ctx->chunks[c];
+                  if (ch->cnt[b] > 0)
+                    FK_HIP(ctx, hipMemcpyAsync((char *) outbox + at * stride, ch->run[b], (size_t) (ch->cnt[b] * stride),
+                                               ch->on_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, sh->xs));
+                  at += ch->cnt[b];
+                }
+            }
+        }
       for (int p = 0; p < W; p++)
         { const int b = r * W + p;
           sp[p] = (char *) outbox + offs[b] * stride;
@@ -342,11 +451,22 @@ static int shard_count(fk_shard *sh, const void *d_reads, int64_t reads_len, fk_
           run += all[(size_t) p * nb + r * W + me];
         }
       nin[r] = run;
+      for (int p = 0; p < W; p++)
+        { if (p == me) sh->st.kept_bytes += sb[p];
+          else         { sh->st.sent_bytes += sb[p]; sh->st.recv_bytes += rb[p]; }
+        }
+      for (int i = 0; i < 2; i++)
+        if (sh->tev[2 * r + i] == NULL)
+          FK_HIP(ctx, hipEventCreate(&sh->tev[2 * r + i]));
+      FK_HIP(ctx, hipEventRecord(sh->tev[2 * r], sh->xs));
       int e = exchange(sh, sp, sb, rp, rb);
       if (e != FK_OK) return (e);
+      FK_HIP(ctx, hipEventRecord(sh->tev[2 * r + 1], sh->xs));
       FK_HIP(ctx, hipEventRecord(sh->xev[r & 1], sh->xs));
       return (FK_OK);
     };
+  sh->st.sent_bytes = sh->st.recv_bytes = sh->st.kept_bytes = 0;
+  sh->st.exchange_ms = 0.;
 
   // ---- rounds: piece r+1 travels while piece r is counted
   if ((rc = fk_rounds_begin(ctx)) != FK_OK) return (rc);
@@ -358,6 +478,11 @@ static int shard_count(fk_shard *sh, const void *d_reads, int64_t reads_len, fk_
     }
   if ((rc = fk_rounds_finish(ctx, 0, &sh->local)) != FK_OK) return (rc);
   FK_HIP(ctx, hipStreamSynchronize(sh->xs));
+  for (int r = 0; r < R; r++)
+    { float ms = 0.f;
+      if (hipEventElapsedTime(&ms, sh->tev[2 * r], sh->tev[2 * r + 1]) == hipSuccess)
+        sh->st.exchange_ms += ms;
+    }
   for (int x = 0; x < 256; x++)
     sh->lfirst[x] = sh->local.wfirst[x];
 
@@ -439,6 +564,7 @@ extern "C" int fk_shard_gather(fk_shard *sh, const fk_result *res, int nparts, c
   int64_t nin = 0;
   for (int s = 0; s < W; s++) nin += all[(size_t) s * W + me];
   const int64_t bytes = std::max<int64_t>(nin, 1) * w.kmer_stride;
+  int arc = FK_OK;
   if (bytes > sh->g_dev_cap)
     { for (int i = 0; i < 2; i++)
         { if (sh->g_dev[i]) hipFree(sh->g_dev[i]);
@@ -449,22 +575,27 @@ extern "C" int fk_shard_gather(fk_shard *sh, const fk_result *res, int nparts, c
       if (hipMalloc((void **) &sh->g_dev[0], (size_t) want) != hipSuccess
           || hipMalloc((void **) &sh->g_dev[1], (size_t) want) != hipSuccess)
         { fk_set_error(ctx, "out of HBM: cannot allocate 2 x %lld bytes for this rank's range of the table", (long long) want);
-          return (FK_ENOMEM);
+          (void) hipGetLastError();
+          arc = FK_ENOMEM;
         }
-      sh->g_dev_cap = want;
+      else
+        sh->g_dev_cap = want;
     }
   const int64_t hbytes = std::max<int64_t>(nin, 1) * w.kmer_word;
-  if (hbytes > sh->g_host_cap)
+  if (arc == FK_OK && hbytes > sh->g_host_cap)
     { if (sh->g_host) fkx_pinned_free(sh->g_host);
       sh->g_host = NULL;
       sh->g_host_cap = 0;
       const int64_t want = hbytes + hbytes / 16;
       if (fkx_pinned_alloc((void **) &sh->g_host, want) != FK_OK)
         { fk_set_error(ctx, "out of host memory: cannot pin %lld bytes for this rank's table range", (long long) want);
-          return (FK_ENOMEM);
+          arc = FK_ENOMEM;
         }
-      sh->g_host_cap = want;
+      else
+        sh->g_host_cap = want;
     }
+  if ((rc = agree(sh, arc)) != FK_OK)              // (a rank without memory must not leave the others in the exchange)
+    return (rc);
   char *a = sh->g_dev[0], *b = sh->g_dev[1];
   char   *sp[256], *rp[256];
   int64_t sb[256], rb[256], run = 0;
@@ -476,15 +607,21 @@ extern "C" int fk_shard_gather(fk_shard *sh, const fk_result *res, int nparts, c
       run += all[(size_t) p * W + me];
     }
   FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  sh->st.gather_sent_bytes = 0;
+  for (int p = 0; p < W; p++)
+    if (p != me) sh->st.gather_sent_bytes += sb[p];
+  const double g0 = fk_wall();
   if ((rc = exchange(sh, sp, sb, rp, rb)) != FK_OK) return (rc);
   FK_HIP(ctx, hipStreamSynchronize(sh->xs));
-  // W sorted runs of disjoint k-mer sets -> one sorted range
+  const double g1 = fk_wall();
+  // W sorted runs of disjoint k-mer sets -> one sorted range: the MSD engine (ceil(log256 n) levels + the LDS finish;
+  // ten LSD passes over KMER_BYTES until round 3)
   void *sorted = a;
-  int   bytes_list[64];
-  for (int i = 0; i < w.kmer_bytes; i++) bytes_list[i] = w.kmer_bytes - 1 - i;
   if (W > 1 && nin > 0
-      && (rc = fkx_lsd_sort(ctx, nin, a, b, w.kmer_stride, bytes_list, w.kmer_bytes, &sorted)) != FK_OK)
+      && (rc = fkx_msd_sort(ctx, nin, a, b, w.kmer_stride, w.kmer_bytes, &sorted)) != FK_OK)
     return (rc);
+  FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const double g2 = fk_wall();
   const void *src = sorted;
   if (w.kmer_word != w.kmer_stride && nin > 0)
     { void *other = (sorted == (void *) a) ? (void *) b : (void *) a;
@@ -496,12 +633,179 @@ extern "C" int fk_shard_gather(fk_shard *sh, const fk_result *res, int nparts, c
     { FK_HIP(ctx, hipMemcpyAsync(sh->g_host, src, (size_t) (nin * w.kmer_word), hipMemcpyDeviceToHost, ctx->stream));
       FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
+  sh->st.gather_exchange_ms = 1e3 * (g1 - g0);
+  sh->st.gather_sort_ms     = 1e3 * (g2 - g1);
+  sh->st.gather_d2h_ms      = 1e3 * (fk_wall() - g2);
   sh->g_n = nin;
   sh->g_nparts = nparts;
   sh->g_ib = fk_ktab_idx_bytes(ctx->prm.kmer, res->ntable);
   if (table) *table = sh->g_host;
   if (nentries) *nentries = nin;
   return (FK_OK);
+}
+
+// a device buffer of the shard itself (not an arena slot of the context: after the count those may hold the table)
+static void *pf_reserve(fk_shard *sh, int i, int64_t bytes)
+{ if (sh->pf_cap[i] >= bytes && sh->pf_buf[i] != NULL)
+    return (sh->pf_buf[i]);
+  if (sh->pf_buf[i]) hipFree(sh->pf_buf[i]);
+  sh->pf_buf[i] = NULL; sh->pf_cap[i] = 0;
+  const int64_t want = bytes + bytes / 8 + 4096;
+  if (hipMalloc(&sh->pf_buf[i], (size_t) want) != hipSuccess)
+    { (void) hipGetLastError();
+      fk_set_error(sh->ctx, "out of HBM: cannot allocate %lld bytes for the profile exchange", (long long) want);
+      sh->pf_buf[i] = NULL;
+      return (NULL);
+    }
+  sh->pf_cap[i] = want;
+  return (sh->pf_buf[i]);
+}
+
+/* Profiles in the sharded run from C (the reference carries run ordinals through both of its sorts for this,
+   count.c:639-1181, and stitches per-bucket fragments, merge.c:761-1006): after fk_shard_count with table_cutoff 1 every
+   rank holds the counts of the k-mers of ITS minimizer buckets.  A piece of reads (d_bases: 0-terminated ASCII, 16-byte
+   aligned, device memory; whole reads) is cut into super-mers that remember where they were cut from; the records
+   travel to the ranks that own their buckets (the C1 exchange again, round by round), the owner looks their k-mers up in
+   its table, the counts travel back in record order (2 bytes per k-mer instance), land at the positions, and the piece
+   is encoded (README.md:1029-1069).  out: as fk_make_profiles (host memory of the context, valid until the next call).
+   COLLECTIVE: all ranks call it the same number of times; a rank that has run out of reads passes nbytes = 0 until
+   *active_ranks -- the ranks that passed reads in this call -- comes back 0 (then nothing was exchanged). */
+extern "C" int fk_shard_profiles(fk_shard *sh, const void *d_bases, int64_t nbytes, fk_profiles *out, int *active_ranks)
+{ if (sh == NULL || out == NULL || nbytes < 0 || (nbytes > 0 && d_bases == NULL)) return (FK_EINVAL);
+  fk_ctx *ctx = sh->ctx;
+  const int W = sh->world, R = sh->rounds, me = sh->rank, nb = ctx->prm.nbuckets;
+  const int stride = ctx->wid.smer_stride;
+  memset(out, 0, sizeof(*out));
+  FK_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = FK_OK;
+  if (!ctx->have_part_table)
+    { fk_set_error(ctx, "fk_shard_profiles: needs fk_shard_count with table_cutoff 1 first");
+      rc = FK_ESTATE;
+    }
+  { int64_t v[2] = { (nbytes > 0) ? 1 : 0, (rc != FK_OK) ? 1 : 0 };
+    const int rc2 = allreduce_i64(sh, v, 2);
+    if (rc != FK_OK) return (rc);
+    if (rc2 != FK_OK) return (rc2);
+    if (v[1] != 0)
+      { fk_set_error(ctx, "fk_shard_profiles: another rank failed");
+        return (FK_EHIP);
+      }
+    if (active_ranks) *active_ranks = (int) v[0];
+    if (v[0] == 0)
+      return (FK_OK);
+  }
+
+  // ---- this rank's piece: super-mers by bucket, with the positions they were cut from
+  int64_t bc[256], off[257], ns = 0, ni = 0;
+  memset(bc, 0, sizeof(bc));
+  if (nbytes > 0)
+    rc = fk_split_supermers(ctx, d_bases, nbytes, NULL, 0, &ns, &ni, bc);
+  char *outbox = NULL;
+  u64  *pos = NULL;
+  if (rc == FK_OK && ns > 0)
+    { outbox = (char *) pf_reserve(sh, 0, ns * stride);
+      pos    = (u64 *) pf_reserve(sh, 1, ns * 8);
+      if (outbox == NULL || pos == NULL) rc = FK_ENOMEM;
+      else rc = fk_split_supermers_emit_pos(ctx, d_bases, nbytes, outbox, ns, bc, pos);
+    }
+  if ((rc = agree(sh, rc)) != FK_OK) return (rc);
+  off[0] = 0;
+  for (int b = 0; b < nb; b++) off[b + 1] = off[b] + bc[b];
+  std::vector<int64_t> all((size_t) W * nb);
+  if ((rc = allgather_i64(sh, bc, nb, all.data())) != FK_OK) return (rc);
+
+  bool first = true;
+  for (int r = 0; r < R; r++)
+    { // ---- records of the round's buckets to their owners
+      char   *sp[256], *rp[256];
+      int64_t sb[256], rb[256], nin = 0, seg[257];
+      seg[0] = 0;
+      for (int p = 0; p < W; p++)
+        { seg[p + 1] = seg[p] + all[(size_t) p * nb + r * W + me];
+          nin = seg[p + 1];
+        }
+      int lrc = reserve_inbox(sh, 0, std::max<int64_t>(nin, 1) * stride);
+      if ((rc = agree(sh, lrc)) != FK_OK) return (rc);
+      for (int p = 0; p < W; p++)
+        { const int b = r * W + p;
+          sp[p] = outbox + off[b] * stride;
+          sb[p] = bc[b] * stride;
+          rp[p] = (char *) sh->inbox[0] + seg[p] * stride;
+          rb[p] = (seg[p + 1] - seg[p]) * stride;
+        }
+      FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      if ((rc = exchange(sh, sp, sb, rp, rb)) != FK_OK) return (rc);
+      FK_HIP(ctx, hipStreamSynchronize(sh->xs));
+
+      // ---- the owner looks them up, source by source (the counts of a source stay together)
+      std::vector<int64_t> nis(W, 0), allni((size_t) W * W);
+      lrc = FK_OK;
+      for (int p = 0; p < W && lrc == FK_OK; p++)
+        lrc = fk_profile_lookup_supermers(ctx, (char *) sh->inbox[0] + seg[p] * stride, seg[p + 1] - seg[p], NULL, 0, &nis[p]);
+      int64_t ctot = 0, coff[257];
+      coff[0] = 0;
+      for (int p = 0; p < W; p++) { coff[p + 1] = coff[p] + nis[p]; ctot = coff[p + 1]; }
+      uint16_t *cout = NULL;
+      if (lrc == FK_OK && (cout = (uint16_t *) pf_reserve(sh, 2, std::max<int64_t>(ctot, 1) * 2)) == NULL)
+        lrc = FK_ENOMEM;
+      for (int p = 0; p < W && lrc == FK_OK; p++)
+        if (nis[p] > 0)
+          lrc = fk_profile_lookup_supermers(ctx, (char *) sh->inbox[0] + seg[p] * stride, seg[p + 1] - seg[p], cout + coff[p],
+                                            nis[p], &nis[p]);
+      if ((rc = agree(sh, lrc)) != FK_OK) return (rc);
+      if ((rc = allgather_i64(sh, nis.data(), W, allni.data())) != FK_OK) return (rc);
+
+      // ---- the counts back to where the records came from
+      int64_t back[257];
+      back[0] = 0;
+      for (int o = 0; o < W; o++) back[o + 1] = back[o] + allni[(size_t) o * W + me];
+      uint16_t *cin = (uint16_t *) pf_reserve(sh, 3, std::max<int64_t>(back[W], 1) * 2);
+      if ((rc = agree(sh, cin == NULL ? FK_ENOMEM : FK_OK)) != FK_OK) return (rc);
+      for (int p = 0; p < W; p++)
+        { sp[p] = (char *) (cout + coff[p]);
+          sb[p] = nis[p] * 2;
+          rp[p] = (char *) (cin + back[p]);
+          rb[p] = (back[p + 1] - back[p]) * 2;
+        }
+      FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      if ((rc = exchange(sh, sp, sb, rp, rb)) != FK_OK) return (rc);
+      FK_HIP(ctx, hipStreamSynchronize(sh->xs));
+      for (int o = 0; o < W && nbytes > 0; o++)
+        { const int b = r * W + o;
+          if (bc[b] == 0 && !first)
+            continue;
+          if ((rc = fk_profile_scatter(ctx, outbox + off[b] * stride, pos + off[b], bc[b], cin + back[o], nbytes, first ? 1 : 0))
+              != FK_OK)
+            return (rc);                        // (every rank is past the round's collectives: no peer waits for this one)
+          first = false;
+        }
+    }
+  if (nbytes == 0)
+    return (FK_OK);
+  return fk_profile_encode(ctx, d_bases, nbytes, out);
+}
+
+/* The .prof files of a sharded run: every rank holds the profiles of a contiguous range of the data set's reads (in file
+   order, ranks in order) and writes the hidden parts .<root>.pidx.N / .<root>.prof.N of its own range -- nparts / world
+   each, its reads divided evenly over them (README.md:1010-1027: a part names the index of its first read, which is the
+   number of reads of all ranks in front) -- and rank 0 the <root>.prof stub. */
+extern "C" int fk_shard_write_prof(fk_shard *sh, const fk_profiles *p, int kmer, int nparts, const char *dir, const char *root)
+{ if (sh == NULL || p == NULL || dir == NULL || root == NULL) return (FK_EINVAL);
+  fk_ctx *ctx = sh->ctx;
+  const int W = sh->world, me = sh->rank;
+  if (nparts < W || nparts % W != 0)
+    { fk_set_error(ctx, "fk_shard_write_prof: %d parts cannot be dealt to %d ranks", nparts, W);
+      return (FK_EINVAL);
+    }
+  std::vector<int64_t> all(W);
+  int64_t mine = p->nreads;
+  int rc = allgather_i64(sh, &mine, 1, all.data());
+  if (rc != FK_OK) return (rc);
+  int64_t base = 0;
+  for (int r = 0; r < me; r++) base += all[r];
+  const int m = nparts / W;
+  rc = fk_write_prof_range(p, kmer, nparts, me * m, m, base, me == 0, dir, root);
+  return (agree(sh, rc));
 }
 
 /* Output files after fk_shard_count: <dir>/<root>.hist and the .ktab stub from rank 0, the hidden parts
@@ -529,12 +833,22 @@ extern "C" int fk_shard_write(fk_shard *sh, const fk_result *res, int nparts, co
   const int m = nparts / W, ib = sh->g_ib;
   int64_t npre = 1;
   for (int i = 0; i < ib; i++) npre *= 256;
+  // every rank says whether its part files were written and its buffer for the reduce exists before any of them
+  // enters the reduce: a rank whose disk is full must not leave the others in a collective
   std::vector<int64_t> pc((size_t) npre, 0);
-  rc = fk_write_ktab_range(host, nin, ctx->prm.kmer, ib, sh->g_split, me * m, m, dir, root, pc.data());
-  if (rc != FK_OK) return (rc);
-  // per-prefix entry counts of all ranks -> rank 0 writes the stub
+  int wrc = fk_write_ktab_range(host, nin, ctx->prm.kmer, ib, sh->g_split, me * m, m, dir, root, pc.data());
   int64_t *d_pc = NULL;
-  if (hipMalloc((void **) &d_pc, (size_t) npre * 8) != hipSuccess) return (FK_ENOMEM);
+  if (wrc == FK_OK && hipMalloc((void **) &d_pc, (size_t) npre * 8) != hipSuccess)
+    { (void) hipGetLastError();
+      d_pc = NULL;
+      fk_set_error(ctx, "fk_shard_write: out of HBM for the prefix counts");
+      wrc = FK_ENOMEM;
+    }
+  if ((rc = agree(sh, wrc)) != FK_OK)
+    { if (d_pc) hipFree(d_pc);
+      return (rc);
+    }
+  // per-prefix entry counts of all ranks -> rank 0 writes the stub
   if (hipMemcpyAsync(d_pc, pc.data(), (size_t) npre * 8, hipMemcpyHostToDevice, sh->xs) != hipSuccess
       || g_rccl.AllReduce(d_pc, d_pc, (size_t) npre, ncclInt64, ncclSum, sh->comm, sh->xs) != ncclSuccess
       || hipMemcpyAsync(pc.data(), d_pc, (size_t) npre * 8, hipMemcpyDeviceToHost, sh->xs) != hipSuccess

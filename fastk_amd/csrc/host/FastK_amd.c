@@ -47,6 +47,7 @@
 #include <sys/types.h>
 #include <sys/wait.h>
 #include <sys/mman.h>
+#include <sys/stat.h>
 #include <signal.h>
 
 #include "../../../include/fastk_amd.h"
@@ -75,7 +76,9 @@ static int       RANK = -1, ROUNDS = 4;
 static char     *ID_FILE = NULL;
 static int64_t   BLOCK_NO = 0;     /* host-parsed input of a sharded run: block j belongs to rank j mod n */
 
-typedef struct
+#include "input_formats.h"
+
+struct Feeder
   { fk_ctx  *ctx;
     char    *bases;
     int32_t *boff;
@@ -87,12 +90,15 @@ typedef struct
     int      cap_reads;
     /* second pass of -p with -M: the blocks are not counted, their reads are looked up in the table of
        the first pass piece by piece and the profiles collected here */
-    int      to_profiles;
+    int      to_profiles;    /* 1: fk_make_profiles per block; 2: fk_shard_profiles (a rank of a -G run) */
+    void    *shard;          /* to_profiles == 2: the rank's fk_shard */
+    int64_t  rd_lo, rd_hi, rd_seen;   /* rd_hi > 0: only reads rd_lo .. rd_hi-1 of the data set (in file order) are
+                                         kept -- the contiguous range a rank of a sharded run makes profiles of */
     void    *d_piece;        /* device buffer of cap_bytes */
     uint8_t *pdata;
     int64_t *poffs;
     int64_t  pbytes, pbytes_cap, preads, preads_cap;
-  } Feeder;
+  };
 
 static void die(fk_ctx *ctx, const char *what)
 { fprintf(stderr,"%s: %s: %s\n",Prog_Name,what,fk_last_error(ctx));
@@ -118,8 +124,14 @@ static void flush_block(Feeder *f, int rem)
             for (j = f->boff[i]; j < e && j < f->boff[i]+BC_PREFIX; j++)
               f->bases[j] = 'N';
           }
-      if (fk_copy_to_device(f->ctx,f->d_piece,f->bases,f->olen) != FK_OK
-          || fk_make_profiles(f->ctx,f->d_piece,f->olen,&pr) != FK_OK)
+      if (fk_copy_to_device(f->ctx,f->d_piece,f->bases,f->olen) != FK_OK)
+        die(f->ctx,"fk_copy_to_device");
+      if (f->to_profiles == 2)
+        { int active = 0;                 /* collective: the other ranks are in this call with a block of theirs (or 0 bytes) */
+          if (fk_shard_profiles((fk_shard *) f->shard,f->d_piece,f->olen,&pr,&active) != FK_OK)
+            die(f->ctx,"fk_shard_profiles");
+        }
+      else if (fk_make_profiles(f->ctx,f->d_piece,f->olen,&pr) != FK_OK)
         die(f->ctx,"fk_make_profiles");
       if (f->pbytes+pr.nbytes > f->pbytes_cap)
         { f->pbytes_cap = (f->pbytes+pr.nbytes)*2 + (1 << 20);
@@ -187,6 +199,14 @@ static inline void add_base(Feeder *f, int c)
 
 static inline void end_read(Feeder *f)
 { f->lastc = 0;
+  if (f->rd_hi > 0)                       /* a range of the data set's reads only: the others are parsed and dropped */
+    { const int64_t idx = f->rd_seen++;
+      if (idx < f->rd_lo || idx >= f->rd_hi)
+        { f->totbps -= f->olen - f->boff[f->nreads];
+          f->olen = f->boff[f->nreads];
+          return;
+        }
+    }
   f->bases[f->olen++] = 0;
   f->nreads += 1;
   f->totrds += 1;
@@ -811,6 +831,10 @@ static void scan_text_packed(Feeder *f, const char *path, int fastq)
     PK_PIECE = (off_t) atoll(getenv("FASTK_AMD_PIECE"));
   flush_block(f,0);
   size = lseek(fd,0,SEEK_END);
+  if (size < 0)                            /* (main sends only regular files here) */
+    { fprintf(stderr,"%s: %s is not a seekable file\n",Prog_Name,path);
+      exit (1);
+    }
   foff = 0; fend = size;
   if (RANK >= 0 && NGPUS > 1)              /* this rank's stripe of the file, cut at record starts */
     { foff = record_start(fd,(off_t) ((double) size*RANK/NGPUS),size,fastq);
@@ -851,11 +875,18 @@ static void scan_text_packed(Feeder *f, const char *path, int fastq)
   if (fk_host_alloc((int64_t) (job.slice*(size_t) nthr),(void **) &job.pinned) != FK_OK)
     { job.pinned = NULL; job.nslices = 0; }
   job.t_setup = now()-job.t_setup;
-  for (t = 1; t < nthr; t++)
-    pthread_create(th+t,NULL,pk_worker,&job);
-  pk_worker(&job);
-  for (t = 1; t < nthr; t++)
-    pthread_join(th[t],NULL);
+  { int made = 1;                          /* threads that really started (the pieces are handed out by a counter: fewer
+                                              threads only take longer) */
+    for (t = 1; t < nthr; t++)
+      { if (pthread_create(th+made,NULL,pk_worker,&job) != 0)
+          break;
+        made += 1;
+      }
+    pk_worker(&job);
+    for (t = 1; t < made; t++)
+      pthread_join(th[t],NULL);
+    nthr = made;
+  }
   pthread_mutex_destroy(&job.lock);
   if (job.failed)
     die(f->ctx,"fk_push_packed");
@@ -909,142 +940,12 @@ static void scan_file(Feeder *f, const char *path, int fastq)
   gzclose(in);
 }
 
-/* SAM text (io.c:1424-1495): one read per alignment line, SEQ is field 10; secondary and
-   supplementary records (flags & 0x900) are skipped; every SEQ character becomes one of acgt by the
-   reference's IUPAC_2_DNA rule (c, b, s, y -> c; g, k -> g; t -> t; 1, 2, 3 -> c, g, t; anything
-   else, n included, -> a), either case. */
-static int sam_base(int c)
-{ switch (c)
-  { case 'C': case 'c': case 'B': case 'b': case 'S': case 's': case 'Y': case 'y': case '1': return ('c');
-    case 'G': case 'g': case 'K': case 'k': case '2': return ('g');
-    case 'T': case 't': case '3': return ('t');
-    default: return ('a');
-  }
-}
-
-static void scan_sam(Feeder *f, const char *path)
-{ gzFile in = gzopen(path,"rb");
-  size_t cap = 1 << 20, len;
-  char  *line = malloc(cap);
-
-  if (in == NULL || line == NULL)
-    { fprintf(stderr,"%s: Cannot open %s for reading\n",Prog_Name,path);
-      exit (1);
-    }
-  gzbuffer(in,1 << 20);
-  while (gzgets(in,line,(int) cap) != NULL)
-    { char *p, *q;
-      long  flags;
-      int   i;
-
-      len = strlen(line);
-      while (len == cap-1 && line[len-1] != '\n')          /* a line longer than the buffer */
-        { cap *= 2;
-          line = realloc(line,cap);
-          if (line == NULL)
-            { fprintf(stderr,"%s: Out of memory\n",Prog_Name); exit (1); }
-          if (gzgets(in,line+len,(int) (cap-len)) == NULL)
-            break;
-          len += strlen(line+len);
-        }
-      if (line[0] == '@' || line[0] == '\n' || line[0] == '\0')
-        continue;
-      p = strchr(line,'\t');
-      if (p == NULL)
-        { fprintf(stderr,"\n%s: Too few required fields in SAM record, file corrupted?\n",Prog_Name); exit (1); }
-      flags = strtol(q = p+1,&p,0);
-      if (p == q)
-        { fprintf(stderr,"\n%s: Cannot parse flags\n",Prog_Name); exit (1); }
-      for (i = 0; i < 7; i++)
-        { p = strchr(p+1,'\t');
-          if (p == NULL)
-            { fprintf(stderr,"\n%s: Too few required fields in SAM record, file corrupted?\n",Prog_Name); exit (1); }
-        }
-      q = p+1;
-      if (*q == '*')
-        { fprintf(stderr,"\n%s: No sequence for read?\n",Prog_Name); exit (1); }
-      if ((flags & 0x900) != 0)
-        continue;
-      if (*q == '\t' || *q == '\n' || *q == '\0')
-        continue;                                             /* zero-length records are dropped, io.c:1597 */
-      for ( ; *q != '\t' && *q != '\n' && *q != '\0'; q++)
-        add_base(f,sam_base(*q));
-      end_read(f);
-    }
-  free(line);
-  gzclose(in);
-}
-
-/* BAM (io.c:1314-1392): BGZF blocks are gzip members, so zlib's gzread delivers the plain BAM stream;
-   per record the 36-byte fixed part, then name, CIGAR, 4-bit bases ("=acmgrsvtwyhkdbn": letters other
-   than acgt break k-mers like any other non-base), qualities, tags.  Records with flags & 0x900 and
-   records without bases are skipped. */
-static int bam_need(gzFile in, void *buf, int n, const char *path)
-{ int got = gzread(in,buf,(unsigned) n);
-  if (got == 0)
-    return (0);
-  if (got != n)
-    { fprintf(stderr,"\n%s: Non-sensical BAM record in %s, file corrupted?\n",Prog_Name,path); exit (1); }
-  return (1);
-}
-
-static uint32_t le32(const unsigned char *x)
-{ return ((uint32_t) x[0] | ((uint32_t) x[1] << 8) | ((uint32_t) x[2] << 16) | ((uint32_t) x[3] << 24)); }
-
-static void scan_bam(Feeder *f, const char *path)
-{ static const char code[] = "=acmgrsvtwyhkdbn";
-  gzFile in = gzopen(path,"rb");
-  unsigned char x[36], *data = NULL;
-  size_t   dmax = 0;
-  uint32_t i, n;
-
-  if (in == NULL)
-    { fprintf(stderr,"%s: Cannot open %s for reading\n",Prog_Name,path); exit (1); }
-  gzbuffer(in,1 << 20);
-  if (!bam_need(in,x,8,path) || memcmp(x,"BAM\1",4) != 0)      /* magic, l_text */
-    { fprintf(stderr,"%s: %s is not a BAM file\n",Prog_Name,path); exit (1); }
-  n = le32(x+4);
-  data = malloc(dmax = (size_t) n + 1024);
-  if (data == NULL)
-    { fprintf(stderr,"%s: Out of memory\n",Prog_Name); exit (1); }
-  if (n > 0) bam_need(in,data,(int) n,path);                  /* header text */
-  bam_need(in,x,4,path);                                      /* n_ref */
-  n = le32(x);
-  for (i = 0; i < n; i++)
-    { uint32_t l;
-      bam_need(in,x,4,path);
-      l = le32(x);
-      if (l + 4 > dmax) data = realloc(data,dmax = (size_t) l + 1024);
-      bam_need(in,data,(int) l + 4,path);                     /* name, l_ref */
-    }
-  while (bam_need(in,x,36,path))
-    { int32_t  ldata  = (int32_t) le32(x) - 32;
-      int      lname  = x[12];
-      int      lcigar = x[16] | (x[17] << 8);
-      int      flags  = x[18] | (x[19] << 8);
-      int32_t  lseq   = (int32_t) le32(x+20);
-      int      j;
-
-      if (ldata < 0 || lseq < 0 || lname < 1 || lname + ((lseq+1) >> 1) + lseq + (lcigar << 2) > ldata)
-        { fprintf(stderr,"\n%s: Non-sensical BAM record, file corrupted?\n",Prog_Name); exit (1); }
-      if ((size_t) ldata > dmax)
-        { dmax = (size_t) (1.2*ldata) + 1000;
-          data = realloc(data,dmax);
-        }
-      if (data == NULL)
-        { fprintf(stderr,"%s: Out of memory\n",Prog_Name); exit (1); }
-      if (ldata > 0) bam_need(in,data,ldata,path);
-      if ((flags & 0x900) != 0 || lseq <= 0)
-        continue;
-      { const unsigned char *t = data + lname + (lcigar << 2);
-        for (j = 0; j < lseq; j++)
-          add_base(f,code[(j & 1) ? (t[j >> 1] & 0xf) : (t[j >> 1] >> 4)]);
-      }
-      end_read(f);
-    }
-  free(data);
-  gzclose(in);
-}
+/* SAM and BAM input lives in input_formats.c (SURVEY section 2 row 14 keeps only the FASTA / FASTQ feed in scope: those
+   two readers are complete as they are and are not extended); they hand bases and read ends to the block feeder
+   through these two calls. */
+void feeder_base(Feeder *f, int c)   { add_base(f,c); }
+void feeder_end_read(Feeder *f)      { end_read(f); }
+const char *feeder_prog_name(void)   { return (Prog_Name); }
 
 /* -G<n>: the parent never touches a GPU.  It starts n copies of this program, one per GPU, each told its rank
    and the path of a file through which rank 0 hands the RCCL unique id to the others, and waits for them.
@@ -1256,13 +1157,14 @@ int main(int argc, char *argv[])
     argv[i] = resolve_input(argv[i]);
 
 
-  if (NGPUS > 1 && (PROFILE || EXACT || PRO_NAME != NULL))
-    { fprintf(stderr,"%s: -G%d counts k-mers (.hist, .ktab); -p and -x run on one GPU\n",Prog_Name,NGPUS);
+  if (NGPUS > 1 && (EXACT || PRO_NAME != NULL))
+    { fprintf(stderr,"%s: -x and -p:<table> run on one GPU (-G%d takes -t, -p and -M)\n",Prog_Name,NGPUS);
       exit (1);
     }
-  if (NGPUS > 1 && MEM_GB > 0 && RANK < 0)
-    fprintf(stderr,"%s: warning: -M%d is ignored with -G%d (every rank keeps its stripe of the reads resident)\n",
-            Prog_Name,MEM_GB,NGPUS);
+  if (NGPUS > 1 && PROFILE && DO_TABLE > 1)
+    { fprintf(stderr,"%s: -G%d -p keeps every k-mer (the profiles look them up): -t1 or no table with it\n",Prog_Name,NGPUS);
+      exit (1);
+    }
   if (NGPUS > 1 && RANK < 0)
     return (launch_ranks(argc0,argv0));
 
@@ -1311,8 +1213,14 @@ int main(int argc, char *argv[])
     { /* one of the ranks of a -G run: its own GPU, world x ROUNDS minimizer buckets (bucket r*world+d goes to
          rank d in exchange round r), its stripe of the reads resident */
       prm.device     = (getenv("FK_RANKS_SHARE_GPU") != NULL) ? 0 : RANK;
-      prm.nbuckets   = NGPUS*ROUNDS;
-      prm.hbm_budget = 0;
+      { /* -M<GB> is the budget of every rank: its stripe is then split chunk by chunk as it is read (records beyond
+           the budget spill to pinned host memory) and the exchange rounds are as many as it takes for a round's
+           records and working set to stay within a sixteenth of it -- the buckets the one-GPU run would use */
+        int rounds = ROUNDS;
+        if (prm.hbm_budget > 0 && prm.nbuckets > NGPUS*rounds)
+          rounds = (prm.nbuckets+NGPUS-1)/NGPUS;
+        prm.nbuckets = NGPUS*rounds;
+      }
       if (prm.nbuckets > 256)
         prm.nbuckets = NGPUS*(256/NGPUS);
     }
@@ -1350,6 +1258,11 @@ int main(int argc, char *argv[])
       int   q = classify(argv[i],&r,&d);
       if (q < 0 || q > 1 || (strlen(argv[i]) > 3 && strcmp(argv[i]+strlen(argv[i])-3,".gz") == 0))
         all_plain = 0;
+      { struct stat sb;                   /* the reader threads map the file and cut it by offset: regular files only
+                                             (a pipe or FIFO goes through the sequential scanner) */
+        if (stat(argv[i],&sb) != 0 || !S_ISREG(sb.st_mode))
+          all_plain = 0;
+      }
       if (q >= 0)
         { free(r); free(d); }
     }
@@ -1427,9 +1340,70 @@ int main(int argc, char *argv[])
       if (fk_shard_count(shard,res) != FK_OK)
         die(ctx,"fk_shard_count");
       t_count = now();
-      if (fk_shard_write(shard,res,nparts,dir,root) != FK_OK)
-        die(ctx,"fk_shard_write");
+      if (DO_TABLE > 0)
+        { if (fk_shard_write(shard,res,nparts,dir,root) != FK_OK)
+            die(ctx,"fk_shard_write");
+        }
+      else if (RANK == 0)                 /* -p without -t: the histogram only (the table stays sharded in HBM) */
+        { snprintf(name,sizeof(name),"%s/%s.hist",dir,root);
+          if (fk_write_hist(res,KMER,name) != FK_OK)
+            die(ctx,"writing .hist");
+        }
       t_write = now();
+      if (PROFILE)
+        { /* The profile pass (count.c:639-1181 + merge.c in the reference): every rank takes a contiguous range of the
+             data set's reads -- read n r / G .. n (r+1) / G, in file order, whatever the stripes of the counting pass
+             were -- scans the input for them (the others are parsed and dropped) and hands them block by block to
+             fk_shard_profiles: their k-mers are looked up on the ranks that own them.  The calls are collective:
+             a rank that has run out of blocks keeps answering with empty ones until every rank has. */
+          Feeder pf;
+          fk_profiles pr;
+          int64_t tot = feed.totrds;
+          int     active = 1;
+          double  t0 = now();
+          if (fk_shard_sum_i64(shard,&tot,1) != FK_OK)
+            die(ctx,"fk_shard_sum_i64");
+          memset(&pf,0,sizeof(pf));
+          pf.ctx = ctx;
+          pf.to_profiles = 2;
+          pf.shard = shard;
+          pf.rd_lo = tot*RANK/NGPUS;
+          pf.rd_hi = tot*(RANK+1)/NGPUS;
+          if (pf.rd_hi == 0) pf.rd_hi = -1;  /* (no reads at all: rd_hi > 0 switches the filter on) */
+          pf.cap_bytes = 256 << 20;
+          pf.cap_reads = 4 << 20;
+          pf.bases = malloc((size_t) pf.cap_bytes+16);
+          pf.boff  = malloc(sizeof(int32_t)*((size_t) pf.cap_reads+2));
+          if (pf.bases == NULL || pf.boff == NULL || fk_device_alloc(ctx,pf.cap_bytes+64,&pf.d_piece) != FK_OK)
+            { fprintf(stderr,"%s: Out of memory\n",Prog_Name); exit (1); }
+          pf.boff[0] = 0;
+          if (pf.rd_hi > pf.rd_lo)
+            for (i = 1; i <= nfiles; i++)
+              { if (ftype == 2) scan_sam(&pf,argv[i]);
+                else if (ftype == 3) scan_bam(&pf,argv[i]);
+                else scan_file(&pf,argv[i],ftype);
+              }
+          flush_block(&pf,0);
+          while (active > 0)              /* this rank is through: empty blocks until all are */
+            if (fk_shard_profiles(shard,NULL,0,&pr,&active) != FK_OK)
+              die(ctx,"fk_shard_profiles");
+          if (pf.poffs == NULL)
+            { pf.poffs = malloc(sizeof(int64_t)); pf.poffs[0] = 0; }
+          memset(&pr,0,sizeof(pr));
+          pr.nreads = pf.preads; pr.nbytes = pf.pbytes; pr.data = pf.pdata; pr.offsets = pf.poffs;
+          if (pr.nreads != ((pf.rd_hi > 0) ? pf.rd_hi-pf.rd_lo : 0))
+            { fprintf(stderr,"%s: rank %d made %lld profiles for its %lld reads\n",Prog_Name,RANK,(long long) pr.nreads,
+                      (long long) (pf.rd_hi-pf.rd_lo));
+              exit (1);
+            }
+          if (fk_shard_write_prof(shard,&pr,KMER,nparts,dir,root) != FK_OK)
+            die(ctx,"fk_shard_write_prof");
+          if (VERBOSE)
+            fprintf(stderr,"  rank %d: profiles of reads %lld .. %lld in %lld bytes (%.3f s)\n",RANK,(long long) pf.rd_lo,
+                    (long long) pf.rd_hi-1,(long long) pr.nbytes,now()-t0);
+          fk_device_free(ctx,pf.d_piece);
+          free(pf.bases); free(pf.boff);
+        }
       if (VERBOSE && RANK == 0)
         { fprintf(stderr,"\n  %d ranks: %lld %d-mers in %lld super-mers, %lld weighted k-mers, %lld distinct, %lld in the table (%d parts)\n",
                   NGPUS,(long long) res->ninst,KMER,(long long) res->nsuper,(long long) res->nweighted,
@@ -1519,12 +1493,17 @@ int main(int argc, char *argv[])
   { pthread_t rel;
     int       relt = (pthread_create(&rel,NULL,release_thread,ctx) == 0);
 
+    /* (a writer that fails -- a full disk -- must not tear the context down under the release thread: join first) */
     snprintf(name,sizeof(name),"%s/%s.hist",dir,root);
     if (fk_write_hist(res,KMER,name) != FK_OK)
-      die(ctx,"writing .hist");
+      { if (relt) pthread_join(rel,NULL);
+        die(ctx,"writing .hist");
+      }
     if (DO_TABLE > 0 && (KEEP_TABLE ? fk_write_ktab_device(ctx,res,NTHREADS,dir,root)
                                     : fk_write_ktab(res,KMER,DO_TABLE,NTHREADS,dir,root)) != FK_OK)
-      die(ctx,"writing .ktab");
+      { if (relt) pthread_join(rel,NULL);
+        die(ctx,"writing .ktab");
+      }
     t_write = now();
     if (relt)
       pthread_join(rel,NULL);

@@ -398,6 +398,11 @@ int fk_profile_encode(fk_ctx *ctx, const void *d_bases, int64_t nbytes, fk_profi
    part t holds the reads of input thread t when nparts == p->nsplit, else the reads are divided evenly
    over the parts in input order. */
 int fk_write_prof(const fk_profiles *p, int kmer, int nparts, const char *dir, const char *root);
+/* The same for the hidden parts part0+1 .. part0+nhere of an nparts-part set only, from reads whose first one is read
+   read_base of the whole data set (the .pidx files name it); the <root>.prof stub with stub != 0.  What a rank of a
+   sharded run writes (fk_shard_write_prof). */
+int fk_write_prof_range(const fk_profiles *p, int kmer, int nparts, int part0, int nhere, int64_t read_base, int stub,
+                        const char *dir, const char *root);
 
 /* ---- writing one table from several ranks ----------------------------------------------------
  * The pieces of fk_write_ktab (Merge_Tables, table.c:346-533), for the sharded run where rank r ends
@@ -462,6 +467,30 @@ int  fk_shard_local_result(fk_shard *sh, fk_result *res);
    memory (KMER_BYTES + 2 bytes per entry; valid until the next gather / fk_shard_destroy). */
 int  fk_shard_gather(fk_shard *sh, const fk_result *res, int nparts, const uint8_t **table, int64_t *nentries);
 int  fk_shard_write(fk_shard *sh, const fk_result *res, int nparts, const char *dir, const char *root);
+/* Profiles of a sharded run (FastK -p on several GPUs; count.c:639-1181 + merge.c:761-1006 in the reference): after
+   fk_shard_count with table_cutoff 1, a piece of this rank's reads (d_bases: 0-terminated ASCII in HBM, 16-byte aligned)
+   is cut into super-mers that remember their positions, these travel to the ranks that own their minimizer buckets,
+   the owners look the k-mers up in their share of the table and send the counts back, and the piece is encoded; out as
+   fk_make_profiles.  COLLECTIVE: every rank calls it the same number of times -- a rank that has run out of reads
+   passes nbytes 0 until *active_ranks (ranks that passed reads in this call) comes back 0.
+   fk_shard_write_prof: every rank's profiles are those of a contiguous range of the data set's reads, ranks in file
+   order; it writes the hidden parts of its range (nparts / world each) and rank 0 the stub. */
+int  fk_shard_profiles(fk_shard *sh, const void *d_bases, int64_t nbytes, fk_profiles *out, int *active_ranks);
+int  fk_shard_write_prof(fk_shard *sh, const fk_profiles *p, int kmer, int nparts, const char *dir, const char *root);
+/* What the last fk_shard_count (C1) and fk_shard_gather (C3) of this rank moved, and over how many ranks. */
+typedef struct
+  { int     comm_ranks;          /* ncclCommCount of the communicator the exchanges run on              */
+    int     rounds;              /* exchange rounds of C1 (nbuckets / world)                             */
+    int64_t sent_bytes;          /* C1: super-mer records sent to other ranks                            */
+    int64_t recv_bytes;          /*     ... received from them                                           */
+    int64_t kept_bytes;          /*     ... kept (a device copy)                                         */
+    double  exchange_ms;         /*     device time of the sends / receives (they overlap the counting)  */
+    int64_t gather_sent_bytes;   /* C3: table entries sent to other ranks                                */
+    double  gather_exchange_ms, gather_sort_ms, gather_d2h_ms;   /* C3 by phase, wall clock             */
+  } fk_shard_stats;
+int  fk_shard_get_stats(fk_shard *sh, fk_shard_stats *st);
+/* vals[0..n) summed element-wise over all ranks, in place (host memory). */
+int  fk_shard_sum_i64(fk_shard *sh, int64_t *vals, int n);
 void fk_shard_destroy(fk_shard *sh);
 
 /* ---- utilities ---------------------------------------------------------------------------*/

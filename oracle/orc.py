@@ -498,6 +498,42 @@ def ref_weighted_kmer_sort(recs, kmer, nthreads=4):
     return arr[:n].copy(), hist, max_inst
 
 
+def ref_supermer_sort(recs, kmer, nthreads=4):
+    """The REFERENCE's own Supermer_Sort (MSDsort.c:458-489 -> msd_sort :306-376 -> radix_sort / shell_sort, count_smers
+    :381-456 on every run of equal super-mers) on an (n, SMER_WORD) uint8 array of super-mer records
+    [SMER_BYTES 2-bit bases][SLEN_BYTES n-1] -- called as count.c:1458 calls it: key = the whole record, the list dealt
+    on its first byte already (count.c:226-251 builds it that way; stable here).  Returns the sorted array; byte 0 of a
+    run's first record comes back as the engine leaves it (its first-byte value), so callers compare bytes 1.. and
+    restore byte 0 from the first-byte order."""
+    global _fkref
+    if _fkref is None:
+        ref_lsd_sort(np.zeros((0, 4), dtype=np.uint8), [0])          # loads the library
+    L = _fkref
+    n, rsize = recs.shape
+    min_len = 5
+    max_super = kmer - min_len + 1                                   # FastK.c:456-468 with PAD_LEN = 5
+    smer = max_super + kmer - 1
+    smer_bytes = (smer + 3) // 4
+    slen_bits = max(1, int(max_super - 1).bit_length())
+    slen_bytes = (slen_bits + 7) // 8
+    assert rsize == smer_bytes + slen_bytes, (rsize, smer_bytes, slen_bytes)
+    L.Supermer_Sort.restype = None
+    L.Supermer_Sort.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.c_int,
+                                C.POINTER(_RefRange)]
+    for name, val in (("KMER", kmer), ("KMER_BYTES", (kmer + 3) // 4), ("SMER_BYTES", smer_bytes), ("SLEN_BYTES", slen_bytes),
+                      ("SMER_WORD", rsize), ("MAX_SUPER", max_super), ("DO_PROFILE", 0), ("NTHREADS", nthreads)):
+        C.c_int.in_dll(L, name).value = val
+    order = np.argsort(recs[:, 0], kind="stable")
+    buf = np.zeros((n + 8, rsize), dtype=np.uint8)                  # array[-1] = 0 and slack behind (count.c:1333, MSDsort.c:375)
+    arr = buf[4:4 + n]
+    arr[:] = recs[order]
+    part = (C.c_int64 * 256)(*[int(c) * rsize for c in np.bincount(recs[:, 0], minlength=256)])
+    panels = (_RefRange * nthreads)()
+    if n > 0:
+        L.Supermer_Sort(arr.ctypes.data, n, rsize, rsize, part, nthreads, panels)
+    return arr.copy()
+
+
 def have_fkref():
     return os.path.exists(os.path.join(REF_DIR, "libfkref.so"))
 

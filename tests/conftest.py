@@ -11,6 +11,12 @@ if ROOT not in sys.path:
 # The several-ranks-on-one-GPU tests fail (instead of skipping) when RCCL refuses the rig: a skipped exchange test
 # is an untested exchange.  FK_REQUIRE_RANKS=0 in the environment gives the skip back.
 os.environ.setdefault("FK_REQUIRE_RANKS", "1")
+# fk_debug_set's alternative code paths (fall-backs the parity tests force) are only open to test processes
+os.environ.setdefault("FASTK_AMD_TEST_KNOBS", "1")
+# ... and so do the tests that check against the reference itself (oracle/_ref: FastK, Tabex, libfkref.so built from
+# /root/reference by oracle/Makefile; the binaries travel to the GPU box with the snapshot): a clone without them
+# must not pass by skipping.  FK_REQUIRE_REF=0 gives the skip back (a box that never had the reference sources).
+os.environ.setdefault("FK_REQUIRE_REF", "1")
 
 
 def pytest_configure(config):

@@ -100,7 +100,7 @@ def test_msd_sort_key_order_equals_reference_engine(ctx40):
     weighted 40-mers with heavy duplication: the same key order (the engine leaves a flag in byte 0 of every run head
     and the run's sum in its count field, so the comparison is on the key bytes, first byte restored)."""
     if not orc.have_fkref():
-        pytest.skip("oracle/_ref/libfkref.so not built")
+        util.no_reference("oracle/_ref/libfkref.so not built")
     rng = np.random.default_rng(99)
     n, kb = 1500000, 10
     keys = rng.integers(0, 256, size=(n // 5, kb), dtype=np.uint8)
@@ -117,6 +117,57 @@ def test_msd_sort_key_order_equals_reference_engine(ctx40):
     assert np.array_equal(got[:, :kb], ref_keys)
     assert int(hist.sum()) == len(np.unique(recs[:, :kb], axis=0))
     a.free(); b.free()
+
+
+@pytest.mark.parametrize("kmer,what", [(40, "kmers"), (51, "kmers"), (40, "supermers"), (51, "supermers")])
+def test_msd_engine_against_both_reference_sorts(kmer, what):
+    """fk_msd_sort_records -- ceil(log256 n) radix levels + the LDS finish of the small parts (fk_tsort.hip) -- against
+    the reference's own engines (libfkref.so): Weighted_Kmer_Sort on R = 12 / 15-byte weighted k-mers (MSDsort.c:536-544)
+    and Supermer_Sort on R = 20 / 26-byte super-mer records (:458-489), 3 M records each: heavy duplication, a cluster
+    of keys that agree on their first nine bytes (a part too long for a tile's halo: the compaction route) and a
+    constant key byte.  Same key order; and the whole sort takes at most six passes over the array."""
+    if not orc.have_fkref():
+        pytest.fail("oracle/_ref/libfkref.so is not built (make -C oracle ref needs /root/reference)")
+    rng = np.random.default_rng(kmer * 7 + len(what))
+    n = 3_000_000
+    with fastk_amd.Context(kmer=kmer) as ctx:
+        w = ctx.w
+        if what == "kmers":
+            kb, rs, stride = w.kmer_bytes, w.kmer_word, w.kmer_stride
+            keys = rng.integers(0, 256, size=(n // 4, kb), dtype=np.uint8)
+            keys[:5000, :9] = keys[0, :9]                        # one long part
+            keys[:, 4] = 0x5a                                    # a constant digit
+            keys[:, kb - 1] &= (0xff << (2 * (4 * kb - kmer))) & 0xff
+            ref_in = np.zeros((n, rs), dtype=np.uint8)
+            ref_in[:, :kb] = keys[rng.integers(0, n // 4, size=n)]
+            ref_in[:, kb] = rng.integers(1, 4, size=n)
+            ksize = kb
+            ref, _, _ = orc.ref_weighted_kmer_sort(ref_in, kmer, 8)
+        else:
+            rs, stride = w.smer_word, w.smer_stride
+            sb = w.smer_bytes
+            keys = rng.integers(0, 256, size=(n // 4, rs), dtype=np.uint8)
+            keys[:5000, :9] = keys[0, :9]
+            keys[:, 6] = 0x33
+            keys[:, sb:] = 0
+            keys[:, rs - 1] = rng.integers(0, kmer - 8, size=n // 4)     # n - 1 of a super-mer
+            ref_in = keys[rng.integers(0, n // 4, size=n)]
+            ksize = rs
+            ref = orc.ref_supermer_sort(ref_in, kmer, 8)
+        dev_in = np.zeros((n, stride), dtype=np.uint8)
+        dev_in[:, :ksize] = ref_in[:, :ksize]
+        if what == "kmers":
+            dev_in[:, stride - 2:] = ref_in[:, rs - 2:]
+        a = ctx.alloc(dev_in.nbytes).upload(dev_in)
+        b = ctx.alloc(dev_in.nbytes)
+        res = ctx.msd_sort(a.ptr, b.ptr, n, stride, ksize)
+        got = a.download(dev_in.nbytes, ptr=res).reshape(n, stride)
+        st = ctx.sort_stats()
+        ref_keys = ref[:, :ksize].copy()
+        ref_keys[:, 0] = np.sort(ref_in[:, 0], kind="stable")    # (the engine keeps a flag in byte 0 of a run's head)
+        assert np.array_equal(got[:, :ksize], ref_keys)
+        assert st["passes"] <= 4, st                             # 1 histogram read + <= 4 levels + the LDS finish <= 6
+        a.free(); b.free()
 
 
 # ------------------------------------------------------------------------------ stages
@@ -1300,14 +1351,19 @@ def test_bench_contract_with_two_ranks_on_one_gpu():
 
 
 @pytest.mark.parametrize("ranks", [1, 2])
-def test_bench_config3_through_the_c_shard_engine(ranks):
+def test_bench_config3_through_the_c_shard_engine(ranks, tmp_path):
     """bench.py --config 3 (BASELINE configs[3]: the HiFi-shaped set striped over the GPUs, strong scaling) drives
     fk_shard_count_device and fk_shard_gather -- RCCL called from C -- under the driver's torch.distributed.run command
-    line; at 1/100 scale, two ranks on the one GPU.  Totals must equal a plain one-context count of the same reads, the
-    timed step includes the final gather (C3) and the ranks together hold every table entry."""
+    line, two ranks on the one GPU.  The workload is the golden case hifi50x20M (50x of a 20 Mbp genome in 15 kbp reads,
+    reference FastK's files): the line's .hist digest and the canonical stream of the ranks' gathered table ranges,
+    taken in rank order, must be the REFERENCE's; the timed step includes the final gather (C3), and the line says how
+    many ranks RCCL's communicator held and what every rank sent."""
     import json, os, subprocess, sys
+    case = json.load(open(os.path.join(util.GOLDEN, "hifi50x20M_k40_t4_T4.json")))
+    sy, exp = case["synth"], case["expected"]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    tail = [os.path.join(root, "bench.py"), "--gpus", str(ranks), "--scale", "0.01", "--steps", "2", "--warmup", "1"]
+    tail = [os.path.join(root, "bench.py"), "--gpus", str(ranks), "--genome-mbp", str(sy["genome_len"] / 1e6), "--seed", str(sy["seed"]),
+            "--steps", "2", "--warmup", "1", "--dump-table", str(tmp_path)]
     if ranks == 1:
         tail += ["--config", "3"]                 # (with several ranks configs[3] is the default)
     if ranks == 1:
@@ -1326,16 +1382,22 @@ def test_bench_config3_through_the_c_shard_engine(ranks):
     assert len(lines) == 1, lines
     out = json.loads(lines[0])
     assert out["n_gpus"] == ranks and out["scaling"] == "strong" and "configs[3]" in out["config"]["workload"]
-    L, glen, k = 15000, 30_000_000, 40
-    nreads = int(50 * glen / L) // ranks * ranks
-    assert out["config"]["kmer_instances"] == nreads * (L - k + 1)
+    L, k = sy["read_len"], case["k"]
+    assert sy["nreads"] % ranks == 0
+    assert out["config"]["kmer_instances"] == sy["nreads"] * (L - k + 1)
     assert out["gather_ms"] > 0 and out["count_ms"] > 0 and abs(out["gather_ms"] + out["count_ms"] - out["ms_per_step"]) < 1.0
-    assert out["config"]["gathered_entries"] == out["config"]["table_entries"] and "final gather" in out["metric"]
-    with fastk_amd.Context(kmer=k, table_cutoff=4) as ctx:
-        buf, n = ctx.synth_reads(20251001, glen, L, 2000, 0, nreads)
-        ref = ctx.count_device_reads(buf.ptr, n, fetch_table=False)
-        buf.free()
-    assert (out["config"]["distinct_kmers"], out["config"]["table_entries"]) == (ref.ndistinct, ref.ntable)
+    assert out["config"]["gathered_entries"] == out["config"]["table_entries"] == exp["ktab"]["nels"] and "final gather" in out["metric"]
+    assert out["hist_file_sha256"] == exp["hist_sha256"], "the sharded run's .hist is not the reference's"
+    assert out["rccl_ranks"] == ranks and len(out["exchange"]) == ranks
+    for r, ex in enumerate(out["exchange"]):
+        assert ex["comm_ranks"] == ranks and ex["rounds"] >= 4 and ex["kept_bytes"] > 0
+        assert (ex["sent_bytes"] > 0) == (ranks > 1) and ex["sent_bytes"] % 20 == 0 and ex["exchange_ms"] > 0
+    assert sum(ex["sent_bytes"] for ex in out["exchange"]) == sum(ex["recv_bytes"] for ex in out["exchange"])
+    kw = (2 * k + 7) // 8 + 2
+    table = np.concatenate([np.fromfile(os.path.join(str(tmp_path), "table.%d" % r), dtype=np.uint8).reshape(-1, kw)
+                            for r in range(ranks)])
+    assert table.shape[0] == exp["ktab"]["nels"]
+    assert orc.table_stream_sha256(k, table) == exp["ktab"]["stream_sha256"], "the gathered table is not the reference's"
 
 
 def test_sharded_final_gather_writes_reference_files(tmp_path):
@@ -1497,7 +1559,7 @@ def test_reference_main_over_gpu_shim(name, fmt, tmp_path):
     import hashlib, os, subprocess
     exe = os.path.join(orc.REF_DIR, "FastK_gpu")
     if not os.path.exists(exe):
-        pytest.skip("oracle/_ref/FastK_gpu not built (needs the reference sources at build time)")
+        util.no_reference("oracle/_ref/FastK_gpu not built (needs the reference sources at build time)")
     case, bases, boff = util.load_case(name)
     exp = case["expected"]
     for mode in ("fast", "exact"):
@@ -1530,7 +1592,7 @@ def test_reference_main_with_profiles_over_gpu_shim(name, tmp_path):
     import hashlib, os, subprocess
     exe = os.path.join(orc.REF_DIR, "FastK_gpu")
     if not os.path.exists(exe):
-        pytest.skip("oracle/_ref/FastK_gpu not built (needs the reference sources at build time)")
+        util.no_reference("oracle/_ref/FastK_gpu not built (needs the reference sources at build time)")
     case, bases, boff = util.load_case(name)
     k = case["k"]
     path = str(tmp_path / ("x." + case["fmt"]))          # the golden's own file layout: io.c deals the reads to its
@@ -1626,7 +1688,7 @@ def test_lsd_sort_equals_reference_engine(ctx40, rsize, n, keys):
     """fk_lsd_sort_records against the REFERENCE's LSD_Sort itself (oracle/_ref/libfkref.so, LSDsort.c:115
     compiled where it lies), not only against the restatement: same bytes, ties in input order."""
     if not orc.have_fkref():
-        pytest.skip("oracle/_ref/libfkref.so not built (needs the reference sources at build time)")
+        util.no_reference("oracle/_ref/libfkref.so not built (needs the reference sources at build time)")
     rng = np.random.default_rng(n)
     recs = rng.integers(0, 256, size=(n, rsize), dtype=np.uint8)
     recs[:, 0] = rng.integers(0, 4, size=n)
@@ -1853,7 +1915,7 @@ def test_reference_readers_accept_our_files(name, tmp_path):
     import os, subprocess
     tools = {t: os.path.join(orc.REF_DIR, t) for t in ("FastK", "Histex", "Tabex", "Logex")}
     if not all(os.path.exists(p) for p in tools.values()):
-        pytest.skip("oracle/_ref tools not built (needs the reference sources at build time)")
+        util.no_reference("oracle/_ref tools not built (needs the reference sources at build time)")
     case, bases, boff = util.load_case(name)
     k, T, cutoff = case["k"], case["T"], case["cutoff"]
     ours, theirs = tmp_path / "ours", tmp_path / "theirs"
@@ -2367,7 +2429,7 @@ def test_cli_output_naming_follows_reference(tmp_path):
     exe = os.path.join(root, "fastk_amd", "bin", "FastK_amd")
     ref = os.path.join(orc.REF_DIR, "FastK")
     if not os.path.exists(ref):
-        pytest.skip("reference build not available")
+        util.no_reference("reference build not available")
 
     def layout(d):
         os.makedirs(os.path.join(d, "in", "sub"))
@@ -2496,7 +2558,7 @@ def test_cli_profiles_of_homopolymer_compressed_reads(fmt, tmp_path):
     case, bases, boff = util.load_case("synth_illumina_k40_t1_T4")
     ref = os.path.join(orc.REF_DIR, "FastK")
     if not os.path.exists(ref):
-        pytest.skip("reference build not available")
+        util.no_reference("reference build not available")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(root, "fastk_amd", "bin", "FastK_amd")
     outs = []
@@ -2528,7 +2590,7 @@ def test_barcode_prefix_and_compression_with_profiles(flags, tmp_path):
     ref = os.path.join(orc.REF_DIR, "FastK")
     shim = os.path.join(orc.REF_DIR, "FastK_gpu")
     if not os.path.exists(ref):
-        pytest.skip("reference build not available")
+        util.no_reference("reference build not available")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     tools = [("r", ref), ("a", os.path.join(root, "fastk_amd", "bin", "FastK_amd"))]
     if os.path.exists(shim):

@@ -1,6 +1,6 @@
 """Pin the oracle against the REFERENCE itself, run here: oracle/_ref/FastK (built by
-oracle/Makefile from /root/reference).  Skipped where the reference build is absent (e.g. when
-neither /root/reference nor a prebuilt oracle/_ref exists)."""
+oracle/Makefile from /root/reference).  The module is skipped only where neither /root/reference nor a
+prebuilt oracle/_ref exists; a missing piece of the reference build fails (tests/util.py, no_reference)."""
 import os
 import random
 
@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 from oracle import orc
+from tests import util
 
 pytestmark = pytest.mark.skipif(not orc.have_ref() and not os.path.isdir(orc.REFERENCE_SRC),
                                 reason="reference build not available")
@@ -67,7 +68,7 @@ def test_oracle_lsd_engine_equals_reference_lsd_sort(rsize, n, nbytes, T):
     """Sort-engine unit parity against the reference's own LSD_Sort (libfkref.so = LSDsort.c compiled
     where it lies): same records in, same bytes out, ties (partial keys) in input order."""
     if not orc.have_fkref():
-        pytest.skip("oracle/_ref/libfkref.so not built (needs the reference sources at build time)")
+        util.no_reference("oracle/_ref/libfkref.so not built (needs the reference sources at build time)")
     rng = np.random.default_rng(rsize * 1000 + n)
     recs = rng.integers(0, 256, size=(n, rsize), dtype=np.uint8)
     recs[:, 1] = rng.integers(0, 3, size=n)
@@ -84,7 +85,7 @@ def test_oracle_msd_engine_and_counting_equal_reference_weighted_kmer_sort(kmer,
     order, the same summed count in every run's first record, the same histogram and max_inst -- also with runs whose
     sum passes 0x7fff."""
     if not orc.have_fkref():
-        pytest.skip("oracle/_ref/libfkref.so not built (needs the reference sources at build time)")
+        util.no_reference("oracle/_ref/libfkref.so not built (needs the reference sources at build time)")
     rng = np.random.default_rng(kmer * 100000 + n)
     kb = (kmer + 3) // 4
     keys = rng.integers(0, 256, size=(distinct, kb), dtype=np.uint8)
@@ -131,7 +132,7 @@ def test_scheme_equals_the_reference_trainer(tmp_path):
         import subprocess as sp
         sp.run(["make", "-s", "-C", os.path.dirname(orc.REF_DIR), "ref_scheme"], check=False)
     if not os.path.exists(exe):
-        pytest.skip("oracle/_ref/FastK_scheme not built (needs the reference sources)")
+        util.no_reference("oracle/_ref/FastK_scheme not built (needs the reference sources)")
     bases, boff = orc.synth_block(20251001, 10000000, 150, 1000, 0, 1000000)
     path = os.path.join(str(tmp_path), "x.fastq")
     util.write_fastx(path, bases, boff, True)

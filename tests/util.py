@@ -11,6 +11,17 @@ from oracle import orc
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
+def no_reference(what):
+    """A test that checks against the reference itself found no reference build (oracle/_ref): that is a FAILURE
+    wherever the builds are expected -- in this repository's container (they are made from /root/reference by
+    oracle/Makefile) and on the GPU box (they travel with the snapshot) -- because a skipped reference test is an
+    untested claim.  FK_REQUIRE_REF=0 turns it back into a skip (a clone on a box that never had the sources)."""
+    import pytest
+    if os.environ.get("FK_REQUIRE_REF", "1") == "1":
+        pytest.fail(what + " -- build it with `make -C oracle ref` where /root/reference is mounted, or set FK_REQUIRE_REF=0")
+    pytest.skip(what)
+
+
 def golden_names(kind=None):
     """kind None: every fixture-sized case (the digest-only "large" cases are asked for by name or kind)."""
     out = []
