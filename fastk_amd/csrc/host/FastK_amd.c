@@ -85,6 +85,8 @@ struct Feeder
     int      nreads;
     int64_t  olen;
     int64_t  totbps, totrds;
+    int64_t  striped_rds;    /* of totrds: reads of this rank's STRIPE of a file (a rank of a -G run reads a byte range of
+                                a plain file; a file the host parser walks is seen whole by every rank) */
     int      lastc;
     int64_t  cap_bytes;      /* block capacity (bases incl. terminators) and reads */
     int      cap_reads;
@@ -450,6 +452,7 @@ static void scan_text_on_device(Feeder *f, const char *path, int fastq)
           die(f->ctx,"fk_push_fasta");
         f->totrds += nr;
         f->totbps += nb;
+        if (fend >= 0) f->striped_rds += nr;
         pthread_join(th,NULL);
         pending = 0;
         n = fj.got;
@@ -892,6 +895,7 @@ static void scan_text_packed(Feeder *f, const char *path, int fastq)
     die(f->ctx,"fk_push_packed");
   f->totrds += job.totrds;
   f->totbps += job.totbps;
+  if (RANK >= 0 && NGPUS > 1) f->striped_rds += job.totrds;
   if (VERBOSE)
     fprintf(stderr,"  %s: %d pieces packed by %d reader threads; thread seconds: read %.2f  pack %.2f  push %.2f of which inside fk_push_packed %.2f; cutting %.2f s, pinned buffers %.2f s, wall %.2f s\n",
             path,ncut,nthr,job.t_read,job.t_pack,job.t_push,job.t_hold,t_cut,job.t_setup,now()-t_begin);
@@ -1230,6 +1234,12 @@ int main(int argc, char *argv[])
   t_created = now();
   if (getenv("FASTK_AMD_DEBUG") != NULL && atoi(getenv("FASTK_AMD_DEBUG")) > 0)     /* per-chunk / per-bucket lines on stderr */
     fk_debug_set(ctx,"verbose",atoi(getenv("FASTK_AMD_DEBUG")));
+  /* tests only (the library takes these knobs from processes that set FASTK_AMD_TEST_KNOBS=1): chunk the ingest and
+     spill at sizes a fixture reaches */
+  if (getenv("FASTK_AMD_CHUNK_BYTES") != NULL && fk_debug_set(ctx,"chunk_bytes",atoll(getenv("FASTK_AMD_CHUNK_BYTES"))) != FK_OK)
+    die(ctx,"FASTK_AMD_CHUNK_BYTES");
+  if (getenv("FASTK_AMD_SPILL_LIMIT") != NULL && fk_debug_set(ctx,"spill_limit",atoll(getenv("FASTK_AMD_SPILL_LIMIT"))) != FK_OK)
+    die(ctx,"FASTK_AMD_SPILL_LIMIT");
   if (EXACT)          /* -x -M<int>: the reference's sort memory (12 GB unless given, FastK.c:235,291), hence its buckets */
     fk_set_sort_memory(ctx,(int64_t) (MEM_GB > 0 ? MEM_GB : 12)*1000000000ll,0.);
   if (RANK >= 0 && NGPUS > 1)
@@ -1358,11 +1368,13 @@ int main(int argc, char *argv[])
              a rank that has run out of blocks keeps answering with empty ones until every rank has. */
           Feeder pf;
           fk_profiles pr;
-          int64_t tot = feed.totrds;
+          int64_t tot = feed.striped_rds;   /* reads of the data set: the stripes add up; what the host parser walked
+                                               (gzipped files, -c) every rank saw whole */
           int     active = 1;
           double  t0 = now();
           if (fk_shard_sum_i64(shard,&tot,1) != FK_OK)
             die(ctx,"fk_shard_sum_i64");
+          tot += feed.totrds-feed.striped_rds;
           memset(&pf,0,sizeof(pf));
           pf.ctx = ctx;
           pf.to_profiles = 2;

@@ -1257,6 +1257,60 @@ def test_c_driver_sharded_over_rccl_writes_the_one_gpu_files(name, fmt, ranks, t
     assert t["stream_sha256"] == exp["ktab"]["stream_sha256"] and t["nels"] == exp["ktab"]["nels"]
 
 
+def _prof_stream(d, root):
+    """the profile set of <d>/<root>.prof as (per-read byte strings in file order): parts concatenated"""
+    kk, enc = orc.read_profiles(str(d), root)
+    return kk, enc
+
+
+@pytest.mark.parametrize("name,fmt,ranks,budget", [("synth_illumina_k51_t1_T4", "fastq", 2, True), ("synth_illumina_k40_t1_T4", "fastq", 4, True),
+                                                    ("edge_k40_t1_T4", "fasta", 2, False), ("edge_k51_t1_T4", "fasta", 2, True)])
+def test_c_driver_sharded_with_profiles_and_budget(name, fmt, ranks, budget, tmp_path):
+    """FastK_amd -G<n> -t1 -p [-M1]: BASELINE configs[4]'s options through the C host on several ranks (the one-GPU rig).
+    The counting pass of every rank splits its stripe chunk by chunk (the test shrinks the chunks and the HBM share
+    of the records so that a fixture is cut into several chunks, most of them spilled to pinned host memory) and the
+    chunk store feeds the exchange rounds; the profile pass looks every k-mer up on the rank that owns its minimizer
+    bucket (fk_shard_profiles) and every rank writes the .prof parts of its own range of the reads.  .hist, the
+    canonical .ktab stream and the DECODED profiles must be the REFERENCE's (golden digests); the profile bytes must be
+    those of the one-GPU run."""
+    import os, subprocess
+    case, bases, boff = util.load_case(name)
+    exp = case["expected"]
+    assert case["cutoff"] == 1 and "prof" in exp
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "fastk_amd", "bin", "FastK_amd")
+    path = str(tmp_path / ("reads." + fmt))
+    if case["kind"] == "edge":
+        orc.write_fasta(path, bases, boff)
+    else:
+        util.write_fastx(path, bases, boff, fmt == "fastq")
+    T = 4
+    args = ["-k%d" % case["k"], "-t1", "-p", "-T%d" % T]
+    one, many = tmp_path / "one", tmp_path / "many"
+    one.mkdir(); many.mkdir()
+    subprocess.run([exe] + args + ["-N" + str(one / "x"), path], check=True)
+    env = dict(os.environ, FK_RANKS_SHARE_GPU="1")
+    extra = []
+    if budget:
+        extra = ["-M1"]
+        env.update(FASTK_AMD_CHUNK_BYTES=str(max(len(bases) // 7, 4096)), FASTK_AMD_SPILL_LIMIT=str(max(len(bases) // 6, 4096)))
+    p = subprocess.run([exe] + args + extra + ["-v", "-G%d" % ranks, "-N" + str(many / "x"), path], env=env, capture_output=True,
+                       text=True, timeout=900)
+    if p.returncode != 0 and any(m in p.stdout + p.stderr for m in _RCCL_RIG_ERRORS):
+        if os.environ.get("FK_REQUIRE_RANKS") == "1":
+            pytest.fail("RCCL would not bring up %d ranks on one GPU: %s" % (ranks, p.stderr[-500:]))
+        pytest.skip("RCCL would not bring up several ranks on one GPU here: " + p.stderr[-300:])
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    assert util.sha_file(many / "x.hist") == exp["hist_sha256"]
+    t = orc.read_ktab(str(many / "x"))
+    assert t["stream_sha256"] == exp["ktab"]["stream_sha256"] and t["nels"] == exp["ktab"]["nels"]
+    k1, enc1 = _prof_stream(one, "x")
+    kn, encn = _prof_stream(many, "x")
+    assert k1 == kn == case["k"] and len(encn) == exp["prof"]["nreads"]
+    assert encn == enc1, "the ranks' profiles are not the one-GPU run's"
+    assert orc.profiles_digest([orc.profile_decode(e) for e in encn]) == exp["prof"]["decoded_sha256"]
+
+
 @pytest.mark.parametrize("how", ["gz", "hoco"])
 def test_c_driver_sharded_deals_pieces_of_long_reads(how, tmp_path):
     """-G2 with input the HOST parses (gzipped FASTA; -c on plain FASTA) holding a read of 20 Mbp: the driver cuts it
@@ -2088,6 +2142,38 @@ def test_configs4_scaled_slice_k51_profiles_with_spill(tmp_path):
         if mem:
             assert "minimizer bucket" in p.stderr                     # the budget really chunked the run
     assert outs["res"] == outs["mem"] and len(outs["res"]) == 2 + 4 + 1 + 8
+    # ... and as BASELINE states it, on several GPUs: -G2 -p -M2 on the one-GPU rig (two ranks share the device, each
+    # with a 2 GB budget for its stripe).  The ranks cut their parts elsewhere, so the comparison is on contents:
+    # .hist bytes, the canonical .ktab stream, and every read's profile bytes in file order.
+    d = tmp_path / "g2"
+    d.mkdir()
+    p = subprocess.run([exe, "-k%d" % k, "-t1", "-T4", "-p", "-v", "-M2", "-G2", "-N" + str(d / "x"), path], capture_output=True, text=True,
+                       env=dict(os.environ, FK_RANKS_SHARE_GPU="1"), timeout=1800)
+    if p.returncode != 0 and any(m in p.stdout + p.stderr for m in _RCCL_RIG_ERRORS):
+        if os.environ.get("FK_REQUIRE_RANKS") == "1":
+            pytest.fail("RCCL would not bring up 2 ranks on one GPU: %s" % p.stderr[-500:])
+    else:
+        assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+        assert util.sha_file(d / "x.hist") == outs["mem"]["x.hist"]
+        assert orc.read_ktab(str(d / "x"))["stream_sha256"] == orc.read_ktab(str(tmp_path / "mem" / "x"))["stream_sha256"]
+
+        def prof_bytes(dd):                       # (offsets per read, data) of the whole set, parts in order
+            import struct
+            offs, data, base = [np.zeros(1, dtype=np.int64)], [], 0
+            nparts = struct.unpack("<ii", open(dd / "x.prof", "rb").read(8))[1]
+            for tt in range(1, nparts + 1):
+                px = open(dd / (".x.pidx.%d" % tt), "rb").read()
+                first, n = struct.unpack("<qq", px[4:20])
+                assert first == sum(len(o) for o in offs) - 1
+                o = np.frombuffer(px[20:20 + 8 * n], dtype=np.int64)
+                offs.append(o + base)
+                dat = np.fromfile(dd / (".x.prof.%d" % tt), dtype=np.uint8)
+                base += len(dat)
+                data.append(dat)
+            return np.concatenate(offs), np.concatenate(data)
+        oa, da = prof_bytes(tmp_path / "mem")
+        ob, db = prof_bytes(d)
+        assert len(oa) == nreads + 1 and np.array_equal(oa, ob) and np.array_equal(da, db), "the ranks' profiles differ from the one-GPU run's"
     h = orc.read_hist(str(tmp_path / "mem" / "x.hist"))
     hist = np.asarray(h["hist"], dtype=np.int64)
     cnt = np.arange(h["low"], h["low"] + len(hist))
