@@ -336,11 +336,24 @@ def test_ktab_written_from_the_device_table(name, tmp_path):
         assert res.ntable == case["expected"]["ktab"]["nels"] and len(res.table) == 0
         ctx._ck(ctx.L.fk_release_device(ctx.h, 1))
         ctx.write_ktab_device(res, str(b), "x")
+        # more parts than the context was made for (its pinned staging serves T writers): the writers take turns at
+        # the staging that exists -- nothing is allocated beside the release -- and the files are the same
+        c, d = tmp_path / "c", tmp_path / "d"
+        c.mkdir(); d.mkdir()
+        ctx.write_ktab_device(res, str(d), "x", nthreads=3 * T + 1)
+    with fastk_amd.Context(kmer=k, table_cutoff=case["cutoff"], nthreads=T) as ctx:
+        ctx.push_block(bases, boff.astype(np.int32))
+        res = ctx.finish()
+        ctx.write_ktab(res, str(c), "x", nthreads=3 * T + 1)
     import os
     files = sorted(os.listdir(a))
     assert files == sorted(os.listdir(b)) and len(files) == 1 + T
     for f in files:
         assert util.sha_file(a / f) == util.sha_file(b / f), f
+    files = sorted(os.listdir(c))
+    assert files == sorted(os.listdir(d)) and len(files) == 1 + 3 * T + 1
+    for f in files:
+        assert util.sha_file(c / f) == util.sha_file(d / f), f
     assert orc.read_ktab(str(b / "x"))["stream_sha256"] == case["expected"]["ktab"]["stream_sha256"]
 
 
