@@ -13,8 +13,9 @@
 // round taking the records whose next hash bits select it (the bin is re-read, mostly from L2).
 #include "fk_common.h"
 
-#define AG_HB1024  3072                 // LDS-private histogram bins of the 1024-thread kernel (one workgroup per CU)
-#define AG_HB512   1536                 // ... of the 512-thread kernel (two per CU: 80,128 bytes each)
+#define AG_THREADS 1024
+#define AG_WAVES   (AG_THREADS / 64)
+#define AG_HB      3072                 // LDS-private histogram bins
 #define AG_HIGH    (1u << 29)           // a carried count that reaches this is cut back by AG_CUT, the
 #define AG_CUT     (1u << 28)           //   removed instances go straight to max_inst
 #define AG_MAXR    64
@@ -30,15 +31,11 @@
 // record where one (dwordx3) does (a quarter of the replay passes' time was this)
 template <int N> struct __attribute__((packed, aligned(4))) ag_rec { u32 w[N]; };
 
-// NT threads per workgroup: 1024 (one workgroup per CU, a fill of 8192 twelve-byte records) or 512 (two per CU with
-// fills of 4096: the phases of one workgroup -- ten barriers per fill, every wave in the same phase -- overlap the
-// other's; for bins of at most ~3.7 K records, i.e. inputs of up to ~240 M records per launch)
-template <int KW, int NT> struct AgCfg
-{ static constexpr int NS  = (KW <= 3) ? 8 : 4;         // records a thread holds in registers during a fill
-  static constexpr int CAP = NS * NT;                   // records one fill takes = cells of the counting sort
+template <int KW> struct AgCfg
+{ static constexpr int CAP = (KW <= 3) ? 8192 : 4096;   // records one fill takes = cells of the counting sort
+  static constexpr int NS  = CAP / AG_THREADS;          // records a thread holds in registers during a fill
   static constexpr int SDW = (KW <= 3) ? 4 : 8;         // dwords of a slot: key, zero padding, count in the last one
-  static constexpr int HB  = (NT == 1024) ? AG_HB1024 : AG_HB512;
-  static constexpr size_t LDS = (size_t) CAP * SDW * 4 + CAP * 2 + HB * 4 + 256;
+  static constexpr size_t LDS = (size_t) CAP * SDW * 4 + CAP * 2 + AG_HB * 4 + 256;
 };
 
 // position of the first record of every bin: bounds[b] = lower bound of (hash16 >= b), bounds[65536] = n
@@ -96,10 +93,8 @@ __device__ __forceinline__ u32 ag_wave_scan(u32 x)
 }
 
 // the 16 wave totals in tmp[] -> (sum of the waves in front of this one, sum of all); every row of 16 lanes scans them
-template <int NT>
 __device__ __forceinline__ u32 ag_wave_bases(const u32 *tmp, u32 *total)
-{ constexpr int AG_WAVES = NT / 64;                    // 8 or 16: every row of 16 lanes holds (copies of) all of them
-  const u32 wave = threadIdx.x >> 6;
+{ const u32 wave = threadIdx.x >> 6;
   u32 y = tmp[fk_lane() & (AG_WAVES - 1)];
   y += (u32) __builtin_amdgcn_update_dpp(0, (int) y, 0x111, 0xf, 0xf, false);
   y += (u32) __builtin_amdgcn_update_dpp(0, (int) y, 0x112, 0xf, 0xf, false);
@@ -110,19 +105,18 @@ __device__ __forceinline__ u32 ag_wave_bases(const u32 *tmp, u32 *total)
   return ((wave == 0) ? 0u : prev);
 }
 
-// exclusive scan over the NT threads of the block with ONE barrier.  tmp: NT / 64 u32 of LDS that nobody has
+// exclusive scan over the 1024 threads of the block with ONE barrier.  tmp: AG_WAVES u32 of LDS that nobody has
 // touched since the barrier before last (the callers alternate between two arrays).
-template <int NT>
 __device__ __forceinline__ u32 ag_block_exscan(u32 v, u32 *tmp, u32 *total)
 { const u32 x = ag_wave_scan(v);
   if (fk_lane() == 63) tmp[threadIdx.x >> 6] = x;
   __syncthreads();
-  return (ag_wave_bases<NT>(tmp, total) + x - v);
+  return (ag_wave_bases(tmp, total) + x - v);
 }
 
 // In-place exclusive scan of the CAP = NS * 1024 cell counters (16 bits each, two to a dword): thread t owns cells
 // NS*t .. NS*t + NS - 1.  Returns the total.  One barrier inside; the caller puts one behind it before a cell is read.
-template <int NS, int NT>
+template <int NS>
 __device__ __forceinline__ u32 ag_scan_cells(u32 *cell, u32 *tmp)
 { u32 *mine = cell + threadIdx.x * (NS / 2);
   u32 c[NS / 2];
@@ -145,7 +139,7 @@ __device__ __forceinline__ u32 ag_scan_cells(u32 *cell, u32 *tmp)
   if (fk_lane() == 63) tmp[threadIdx.x >> 6] = x;
   __syncthreads();
   u32 total;
-  const u32 base = ag_wave_bases<NT>(tmp, &total) + x - s;
+  const u32 base = ag_wave_bases(tmp, &total) + x - s;
   const u32 b2 = base * 0x10001u;                        // offsets stay below 2^16: no carry between the halves
   if (NS == 8)
     *(uint4 *) mine = make_uint4(c[0] + b2, c[1] + b2, c[NS / 2 - 2] + b2, c[NS / 2 - 1] + b2);
@@ -171,16 +165,15 @@ __device__ __forceinline__ u32 ag_scan_cells(u32 *cell, u32 *tmp)
 // `limit` the bin is taken in 2, 4, ... selections by further hash bits, each re-reading the bin.
 // DEDUP: the records are super-mers (whole record = key, weight 1); every distinct record comes out
 // once, followed by a dword with its multiplicity (records of KW + 1 dwords), nothing else is computed.
-template <int KW, bool DEDUP, int NT>
-__global__ __launch_bounds__(NT) void k_ag_count(const u32 *__restrict__ recs,
+template <int KW, bool DEDUP>
+__global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__ recs,
                                                          const u64 *__restrict__ bounds, int kbytes,
                                                          int cutoff, u64 *__restrict__ hist_g,
                                                          u64 *__restrict__ scal, u32 *__restrict__ table,
                                                          int cap_eff, int limit, int variant, int gshift, u32 sat, u64 tcap)
-{ constexpr int CAP = AgCfg<KW, NT>::CAP;
-  constexpr int NS  = AgCfg<KW, NT>::NS;
-  constexpr int SDW = AgCfg<KW, NT>::SDW;
-  constexpr int AG_THREADS = NT, AG_WAVES = NT / 64, AG_HB = AgCfg<KW, NT>::HB;
+{ constexpr int CAP = AgCfg<KW>::CAP;
+  constexpr int NS  = AgCfg<KW>::NS;
+  constexpr int SDW = AgCfg<KW>::SDW;
   extern __shared__ uint4 ag_lds[];
   u32 *slot    = (u32 *) ag_lds;                           // [CAP][SDW] key + count, by sorted position
   u32 *cell    = slot + CAP * SDW;                         // [CAP / 2] cell counters -> offsets, 16 bits each
@@ -285,7 +278,7 @@ __global__ __launch_bounds__(NT) void k_ag_count(const u32 *__restrict__ recs,
                     if ((u32) (j * AG_THREADS + tid) < (u32) cap_eff && !((vmask >> j) & 1u))
                       fr |= (1u << j);
                   u32 totfree;
-                  u32 k = ag_block_exscan<NT>((u32) __popc(fr), sh_tmp + (flip ^= AG_WAVES), &totfree);
+                  u32 k = ag_block_exscan((u32) __popc(fr), sh_tmp + (flip ^= AG_WAVES), &totfree);
                   const int64_t room = end - pos;
                   const u32 nnew = (room < (int64_t) totfree) ? (u32) room : totfree;
 #pragma unroll
@@ -334,7 +327,7 @@ __global__ __launch_bounds__(NT) void k_ag_count(const u32 *__restrict__ recs,
                 }
               __syncthreads();
               AG_T(1);
-              ntot = ag_scan_cells<NS, NT>(cell, sh_tmp + (flip ^= AG_WAVES));
+              ntot = ag_scan_cells<NS>(cell, sh_tmp + (flip ^= AG_WAVES));
               __syncthreads();
               AG_T(2);
 
@@ -468,7 +461,7 @@ __global__ __launch_bounds__(NT) void k_ag_count(const u32 *__restrict__ recs,
 #pragma unroll
               for (int j = 0; j < NS; j++)
                 nl += (v[j] != 0);
-              ag_block_exscan<NT>(nl, sh_tmp + (flip ^= AG_WAVES), &D);
+              ag_block_exscan(nl, sh_tmp + (flip ^= AG_WAVES), &D);
               if (D > (u32) limit)
                 { ovf = true;
                   break;
@@ -541,7 +534,7 @@ __global__ __launch_bounds__(NT) void k_ag_count(const u32 *__restrict__ recs,
           u32 tot = 0, toff = 0;
           u64 tbase = 0;
           if (tab)
-            { toff = ag_block_exscan<NT>(nq, sh_tmp + (flip ^= AG_WAVES), &tot);
+            { toff = ag_block_exscan(nq, sh_tmp + (flip ^= AG_WAVES), &tot);
               if (tid == 0 && tot > 0)
                 tbase = atomicAdd(&scal[2], (u64) tot);
             }
@@ -572,7 +565,7 @@ __global__ __launch_bounds__(NT) void k_ag_count(const u32 *__restrict__ recs,
             }
           if (R0 > 1)
             { u32 D;
-              ag_block_exscan<NT>(nlead, sh_tmp + (flip ^= AG_WAVES), &D);
+              ag_block_exscan(nlead, sh_tmp + (flip ^= AG_WAVES), &D);
               bin_fill = max(bin_fill, D);
             }
           AG_T(5);
@@ -669,16 +662,16 @@ __global__ __launch_bounds__(NT) void k_ag_count(const u32 *__restrict__ recs,
 }
 
 // bins merged per fill: 2^gshift, the largest group whose expected size stays within 7/16 of a fill when doubled
-template <int KW, int NT>
+template <int KW>
 static int ag_gshift(int64_t n)
 { int gshift = 0;
-  while (gshift < 16 && ((n >> (16 - gshift)) << 1) <= AgCfg<KW, NT>::CAP * 7 / 8)
+  while (gshift < 16 && ((n >> (16 - gshift)) << 1) <= AgCfg<KW>::CAP * 7 / 8)
     gshift += 1;
   return (gshift);
 }
 
-template <int KW, int NT>
-static int aggr_nt(fk_ctx *ctx, const void *d_grouped, int64_t n, int cutoff, int64_t *hist,
+template <int KW>
+static int aggr_t(fk_ctx *ctx, const void *d_grouped, int64_t n, int cutoff, int64_t *hist,
                   int64_t *max_inst, int64_t *ndistinct, void *d_table, int64_t cap, int64_t *ntable)
 { hipStream_t s = ctx->stream;
   if (ntable) *ntable = 0;
@@ -695,9 +688,9 @@ static int aggr_nt(fk_ctx *ctx, const void *d_grouped, int64_t n, int cutoff, in
     return (FK_ENOMEM);
   u64 *d_scal = d_hist + FK_HIST_BINS;
   static bool attr_set[8] = { false };
-  const size_t lds = AgCfg<KW, NT>::LDS;
+  const size_t lds = AgCfg<KW>::LDS;
   if (!attr_set[KW])
-    { auto kern = k_ag_count<KW, false, NT>;
+    { auto kern = k_ag_count<KW, false>;
       FK_HIP(ctx, hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
       attr_set[KW] = true;
     }
@@ -708,16 +701,16 @@ static int aggr_nt(fk_ctx *ctx, const void *d_grouped, int64_t n, int cutoff, in
   // Neighbouring bins are merged while two of them still fit one fill with room to spare: small inputs get full
   // fills, and a fill is never expected to hold more records than it takes -- a bin beyond CAP costs a second
   // chunk with the first one's distinct k-mers carried along.
-  int gshift = ag_gshift<KW, NT>(n);
+  int gshift = ag_gshift<KW>(n);
   if (ctx->dbg_aggr_limit > 0)
     gshift = 0;
   if (ctx->dbg_aggr_gshift > 0)
     gshift = ctx->dbg_aggr_gshift - 1;
-  int cap_eff = AgCfg<KW, NT>::CAP;                       // fk_debug_set("aggr_limit"): a fill takes only this many records
+  int cap_eff = AgCfg<KW>::CAP;                       // fk_debug_set("aggr_limit"): a fill takes only this many records
   if (ctx->dbg_aggr_limit > 0 && ctx->dbg_aggr_limit < cap_eff)
     cap_eff = ctx->dbg_aggr_limit < 4 ? 4 : ctx->dbg_aggr_limit;
   const int limit = cap_eff * 3 / 4;
-  hipLaunchKernelGGL((k_ag_count<KW, false, NT>), dim3((unsigned) (cus * (1024 / NT))), dim3(NT), lds, s, (const u32 *) d_grouped,
+  hipLaunchKernelGGL((k_ag_count<KW, false>), dim3((unsigned) cus), dim3(AG_THREADS), lds, s, (const u32 *) d_grouped,
                      (const u64 *) d_bounds, ctx->wid.kmer_bytes, cutoff, d_hist, d_scal, (u32 *) d_table, cap_eff, limit, ctx->dbg_aggr_variant, gshift,
                      (u32) (ctx->aggr_sat > 0 ? ctx->aggr_sat : 0x7fff), (u64) cap);
   FK_LAUNCH_CHECK(ctx);
@@ -755,18 +748,6 @@ static int aggr_nt(fk_ctx *ctx, const void *d_grouped, int64_t n, int cutoff, in
 #endif
   free(hh);
   return (FK_OK);
-}
-
-template <int KW>
-static int aggr_t(fk_ctx *ctx, const void *d_grouped, int64_t n, int cutoff, int64_t *hist,
-                  int64_t *max_inst, int64_t *ndistinct, void *d_table, int64_t cap, int64_t *ntable)
-{ // Two 512-thread workgroups per CU where a bin fits a fill of 4096 with room to spare (<= 3.4 K records on average:
-  // the bins of a launch differ by a few per cent); one of 1024 threads above that.  fk_debug_set("aggr_threads"):
-  // 512 / 1024 force one of them.
-  const bool small = (n >> 16) <= (int64_t) (AgCfg<KW, 512>::CAP * 27 / 32);
-  if (ctx->dbg_aggr_threads == 512 || (ctx->dbg_aggr_threads != 1024 && small))
-    return aggr_nt<KW, 512>(ctx, d_grouped, n, cutoff, hist, max_inst, ndistinct, d_table, cap, ntable);
-  return aggr_nt<KW, 1024>(ctx, d_grouped, n, cutoff, hist, max_inst, ndistinct, d_table, cap, ntable);
 }
 
 /* d_grouped: n weighted k-mer records ordered by the low 16 bits of fk_rec_hash's b word (the

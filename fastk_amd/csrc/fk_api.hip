@@ -600,10 +600,6 @@ extern "C" int fk_debug_set(fk_ctx *ctx, const char *key, int64_t value)
     { ctx->dbg_table_prefix = (int) value;
       return (FK_OK);
     }
-  if (strcmp(key, "aggr_threads") == 0)     // 512: two 512-thread aggregation workgroups per CU, 1024: one; 0: by bin size
-    { ctx->dbg_aggr_threads = (int) value;
-      return (FK_OK);
-    }
   if (strcmp(key, "aggr_gshift") == 0)      // bins merged per table fill = 2^(value - 1); 0 = automatic
     { ctx->dbg_aggr_gshift = (int) value;
       return (FK_OK);

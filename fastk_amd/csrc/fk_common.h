@@ -220,7 +220,6 @@ struct fk_ctx
   int64_t    tsort_ties;          // records the last table sort had to repair
   int        dbg_aggr_variant;    // ablations of k_ag_count (wrong results), see fk_debug_set
   int        dbg_table_prefix;    // >= 2: bytes the table sort's LSD passes cover before the tie repair
-  int        dbg_aggr_threads;    // 512 / 1024: threads of an aggregation workgroup (0: by bin size)
   int        dbg_aggr_gshift;     // > 0: merge 2^(this - 1) bins per table fill instead of the automatic choice
   int        dbg_aggr_limit;      // > 0: pretend the LDS table of fk_aggr.hip takes only this many k-mers
   int64_t    aggr_extra_rounds;   // bins x rounds that had to be split in the last aggregation
