@@ -240,6 +240,14 @@ def cpu_baseline(args, cfg):
                 import hashlib
                 h = hashlib.sha256(open(os.path.join(d, "s.hist"), "rb").read()).hexdigest()
                 out["hist_sha256_equals_golden"] = (h == case["expected"]["hist_sha256"])
+        # the reference on the timed configuration itself was run once (tools/cpu_baseline_full.py, ~6 min of host time:
+        # not something the default run repeats): its record, when committed, rides along
+        full = os.path.join(ROOT, "profiles", "r04_cpu_baseline_configs2_full.json")
+        if os.path.exists(full):
+            try:
+                out["full_size_run"] = json.load(open(full))
+            except Exception:
+                pass
         return out
     finally:
         subprocess.run(["rm", "-rf", d])
@@ -852,18 +860,19 @@ def main():
     # is the step + the D2H of its table -- one warm-up call (it pins the host buffer), then one timed
     on_host = None
     if not sharded and cfg["cutoff"] > 0:
-        ctx.count_device_reads(reads.data_ptr(), nbytes, fetch_table=True)
+        import ctypes as C
+        r_h = fastk_amd.api.CResult()          # (the C call itself: the Python wrapper would copy the 36 GB table once more)
+        ctx._ck(ctx.L.fk_count_device_reads(ctx.h, reads.data_ptr(), nbytes, 1, C.byref(r_h)))
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        r_h = ctx.count_device_reads(reads.data_ptr(), nbytes, fetch_table=True)
+        ctx._ck(ctx.L.fk_count_device_reads(ctx.h, reads.data_ptr(), nbytes, 1, C.byref(r_h)))
         torch.cuda.synchronize()
         dt_h = time.perf_counter() - t0
-        assert r_h.ntable == last.ntable and len(r_h.table) == r_h.ntable
+        assert r_h.ntable == last.ntable and bool(r_h.table)
         on_host = dict(value=ninst / dt_h, unit="k-mers/s", ms_per_step=round(1e3 * dt_h, 3),
                        d2h_bytes=int(r_h.ntable) * ctx.w.kmer_word,
                        definition="the step + its sorted table brought to pinned host memory: the boundary of the N > 1 "
                                   "lines (their final gather), for a scaling curve computed against this N = 1 point")
-        del r_h
 
     w = ctx.w
     roofline = roofline_record(loc, w, cfg_id, ceiling, ceiling_kernel)
@@ -895,6 +904,7 @@ def main():
     if not sharded:
         out["stage_ms"]["table_sort"] = round(loc.ms_table_sort, 3)
         out["histogram_sha256"] = __import__("hashlib").sha256(h.tobytes()).hexdigest()
+        out["hist_file_sha256"] = hist_file_sha256(args.kmer, last.hist, last.max_inst)    # what <root>.hist would hold
     if rank == 0 and world == 1 and not args.force_shard and not args.no_packed_leg:
         ctx.close()
         ctx = None

@@ -917,9 +917,10 @@ static double ms_between(hipEvent_t a, hipEvent_t b)
 // sm_in is clobbered (it is one half of the grouping's ping-pong pair).
 struct fk_stage_ms { double group_s, expand, radix_k, aggr; };
 
+// dig != NULL: the stream of hash digit 0 of the ns records, written by the splitter beside them.
 static int count_bucket(fk_ctx *ctx, void *sm_in, int64_t ns, fk_result *res, bool final,
                         void **table_out, int64_t *ntab, const int64_t *exact_roff, fk_stage_ms *tm,
-                        int64_t ns_max = 0)
+                        int64_t ns_max = 0, const uint8_t *dig = NULL)
 { const fk_widths &w = ctx->wid;
   hipStream_t s = ctx->stream;
   const int cutoff = ctx->prm.table_cutoff;
@@ -953,6 +954,7 @@ static int count_bucket(fk_ctx *ctx, void *sm_in, int64_t ns, fk_result *res, bo
       bool    dd = false;
       if (lds_dedup)
         { void *grouped = sm_in;
+          ctx->pre_dig = dig; ctx->pre_dig_n = ns;
           if ((rc = fkx_group(ctx, ns, sm_in, sm_b, w.smer_stride, w.smer_stride, 2, &grouped)) != FK_OK)
             break;
           res->passes_super      = ctx->sort_stats.passes;
@@ -1332,6 +1334,7 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
       }
   do
     { void *sm_a = NULL;
+      uint8_t *sm_dig = NULL;            // first digit stream of the super-mer grouping, from a one-pass split
       int64_t ns = 0, ni = 0;
       int64_t bc[256] = { 0 }, bo[256] = { 0 };
       int     nbk = 1;
@@ -1421,7 +1424,7 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
               if (ngroups <= 1)
                 { // split (sampled capacity + one emit pass; exact count-then-emit with several buckets)
                   ngroups = 1;
-                  if ((rc = fkx_split_fast(ctx, d_reads, nbytes, &sm_a, &ns, &ni, bc, bo, pk)) != FK_OK) break;
+                  if ((rc = fkx_split_fast(ctx, d_reads, nbytes, &sm_a, &ns, &ni, bc, bo, pk, &sm_dig)) != FK_OK) break;
                 }
             }
           res->nsuper = ns;
@@ -1580,7 +1583,7 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
         { if (chunked && ns > 0)
             rc = gather(0, &sm_in);
           if (rc == FK_OK)
-            rc = count_bucket(ctx, sm_in, ns, res, true, &table, &ntab, h_roff, &tm);
+            rc = count_bucket(ctx, sm_in, ns, res, true, &table, &ntab, h_roff, &tm, 0, chunked ? NULL : sm_dig);
         }
       else
         { const bool tim = (getenv("FK_FINISH_TIMING") != NULL);
@@ -1594,7 +1597,7 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
               const double w1 = tim ? fk_wall() : 0.;
               if (rc == FK_OK)
                 rc = count_bucket(ctx, p, bc[b], res, false, NULL, &ntab, (h_roff != NULL && b == 0) ? h_roff : NULL, &tm,
-                                  ns_max);
+                                  ns_max, (chunked || sm_dig == NULL) ? NULL : sm_dig + bo[b]);
               if (tim) t_c += fk_wall() - w1;
             }
           const double w2 = tim ? fk_wall() : 0.;

@@ -231,6 +231,8 @@ struct fk_ctx
   int64_t    acc_ns, acc_ns_total;   // bucket streaming: super-mers counted so far / in all buckets
   int64_t    pre_hist_n;       // > 0: d_digit_hist (hash digits 0,1) and the DIG_A stream are valid for
                                // this many records (written by the expansion), see lsd_sort_stream_t
+  const uint8_t *pre_dig;      // != NULL: the stream of hash digit 0 of the pre_dig_n super-mer records the next grouping
+  int64_t    pre_dig_n;        // sorts, written by the splitter beside the records (fk_split.hip)
   int64_t    ex_nweighted, ex_ndistinct;   // totals of the last expand sizing call
   void      *slot_ptr[FK_NSLOTS];
   int64_t    slot_cap[FK_NSLOTS];
@@ -242,7 +244,7 @@ enum { FK_SLOT_SM_A = 0, FK_SLOT_SM_B, FK_SLOT_KM_A, FK_SLOT_KM_B, FK_SLOT_EX_HE
        FK_SLOT_RAW, FK_SLOT_FQ_INFO, FK_SLOT_FQ_PHASE, FK_SLOT_FQ_OFF, FK_SLOT_TIE_A, FK_SLOT_TIE_B,
        FK_SLOT_TIE_POS, FK_SLOT_SM_D, FK_SLOT_PF_IDX, FK_SLOT_PF_CNT, FK_SLOT_PF_ZC, FK_SLOT_PF_ZO,
        FK_SLOT_PF_ENDS, FK_SLOT_PF_LEN, FK_SLOT_PF_OFF, FK_SLOT_PF_OUT, FK_SLOT_ENT, FK_SLOT_TENT, FK_SLOT_TCNT, FK_SLOT_CBASE, FK_SLOT_PF_RID,
-       FK_SLOT_PK_TIDX, FK_SLOT_PK_ASCII };
+       FK_SLOT_PK_TIDX, FK_SLOT_PK_ASCII, FK_SLOT_SM_DIG };
 
 // returns a device buffer of at least nbytes for the given purpose (NULL + error set on failure)
 void *fk_slot(fk_ctx *ctx, int slot, int64_t nbytes);
@@ -287,7 +289,7 @@ int fkx_ktab_prepare(fk_ctx *ctx, int64_t ntable);          // fk_ktab_device.hi
 
 int fkx_split_planned(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int64_t cap,
                       const int64_t *offsets, int64_t *counts, int64_t *ninst, int b0 = 0, int b1 = -1, int mode = 0,
-                      const fk_pkview *pk = NULL);
+                      const fk_pkview *pk = NULL, uint8_t *d_dig = NULL);
 int fkx_train_tran(fk_ctx *ctx, const void *d_bases, const int64_t *h_roff, int64_t train_reads,
                    int nthreads, int *tran);
 int fkx_train_scheme(fk_ctx *ctx, const void *d_bases, const int64_t *d_roff, int64_t train, const int *tran,
@@ -297,7 +299,8 @@ int fkx_split_exact(fk_ctx *ctx, const void *d_bases, const int64_t *d_roff, int
                     int64_t *bucket_offs);
 int fkx_first_byte_census(fk_ctx *ctx, const void *d_recs, int64_t n, int rsize, int64_t *census);
 int fkx_split_fast(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void **d_out, int64_t *nsuper,
-                   int64_t *ninst, int64_t *bucket_counts, int64_t *bucket_offsets, const fk_pkview *pk = NULL);
+                   int64_t *ninst, int64_t *bucket_counts, int64_t *bucket_offsets, const fk_pkview *pk = NULL,
+                   uint8_t **d_dig = NULL);
 int fkx_expand(fk_ctx *ctx, const void *d_smers, int64_t nsuper, void *d_out, int64_t cap,
                int64_t *nweighted, int64_t *ndistinct, int64_t *overflow, bool reuse_counts = false,
                bool hash_stream = false, bool dedup = false);

@@ -441,8 +441,15 @@ __global__ __launch_bounds__(RX_THREADS) void k_rx_superscan(const u64 *__restri
                                                              int64_t nsuper, u64 *__restrict__ superpfx)
 { __shared__ u64 tmp[8];
   const int tid = threadIdx.x;
+  // the digit's totals are the sums of the super-chunk totals (a few dozen rows): no histogram of the digit has to
+  // exist beside its stream -- which is what lets a producer of the records (the splitter, the expansion) hand over
+  // nothing but the stream
+  (void) ghist;
+  u64 tot = 0;
+  for (int64_t sc = 0; sc < nsuper; sc++)
+    tot += supertot[sc * 256 + tid];
   u64 gsum;
-  u64 run = fk_block_exscan_256<u64>(ghist[tid], tmp, &gsum);
+  u64 run = fk_block_exscan_256<u64>(tot, tmp, &gsum);
   for (int64_t sc = 0; sc < nsuper; sc++)
     { superpfx[sc * 256 + tid] = run;
       run += supertot[sc * 256 + tid];
@@ -1020,8 +1027,14 @@ static int lsd_sort_stream_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, c
 
   // the producer of the records (k_ex_expand) may have left the histograms of hash digits 0 and 1
   // and the stream of digit 0 behind
-  const bool pre = HASHED && ctx->pre_hist_n == n && nbytes <= 2 && bytes[0] == 0
-                   && (nbytes < 2 || bytes[1] == 1) && hbytes == ctx->wid.kmer_bytes;
+  // ... or the splitter the stream of hash digit 0 of whole super-mer records, beside the records (no histograms:
+  // k_rx_superscan sums the digit totals from the tile histograms)
+  const uint8_t *pre_dig = (HASHED && ctx->pre_dig != NULL && ctx->pre_dig_n == n && bytes[0] == 0 && hbytes == RW * 4)
+                           ? ctx->pre_dig : NULL;
+  ctx->pre_dig = NULL;
+  const bool pre = (pre_dig != NULL)
+                   || (HASHED && ctx->pre_hist_n == n && nbytes <= 2 && bytes[0] == 0
+                       && (nbytes < 2 || bytes[1] == 1) && hbytes == ctx->wid.kmer_bytes);
   ctx->pre_hist_n = 0;
   if (!pre)
     FK_HIP(ctx, hipMemsetAsync(ctx->d_digit_hist, 0, 32 * 256 * sizeof(u64), s));
@@ -1094,7 +1107,7 @@ static int lsd_sort_stream_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, c
   if constexpr (WT == RX_THREADS) lds_bytes = rx_stream_lds_bytes<RW, ITEMS>();
   else lds_bytes = rx_wide_lds_bytes<RW, ITEMS>();
   u32 *src = (u32 *) d_src, *trg = (u32 *) d_trg;
-  uint8_t *dcur = dig_a, *dnext = dig_b;
+  uint8_t *dcur = (pre_dig != NULL) ? (uint8_t *) pre_dig : dig_a, *dnext = dig_b;      // (a producer's stream is only read)
   unsigned sgrid = (unsigned) (((ntiles + 7) / 8) * 8);
   if constexpr (WT != RX_THREADS)
     { // the attribute belongs to the (function, device) pair: remembered per context (= per device), not per
@@ -1140,7 +1153,7 @@ static int lsd_sort_stream_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, c
       FK_HIP(ctx, hipEventRecord(ctx->pass_ev[2 * i + 1], s));
       FK_LAUNCH_CHECK(ctx);
       u32 *t = src; src = trg; trg = t;
-      uint8_t *d = dcur; dcur = dnext; dnext = d;
+      uint8_t *d = (dcur == pre_dig) ? dig_a : dcur; dcur = dnext; dnext = d;
     }
   FK_HIP(ctx, hipEventRecord(ctx->ev1, s));
   FK_HIP(ctx, hipStreamSynchronize(s));

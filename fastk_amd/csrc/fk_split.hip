@@ -91,6 +91,9 @@ struct SplitArgs
   int64_t   ninv;
   const u32 *tidx;          // [tiles + 2][2] first read that ends at or behind the tile's first position, first stretch that
                             // does (0xffffffff: none)
+  uint8_t  *dig;            // != NULL (20-byte records, one-pass emit): byte 0 of the hash of every record, at the record's
+                            // slot -- the first digit stream of the grouping sort that follows (fk_radix.hip), made
+                            // while the record is in registers instead of by a pass of its own over all records
 };
 
 __device__ __forceinline__ u32 sp_window(const u32 *arr, int off)
@@ -615,6 +618,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
 
   const bool piped = (nstart_total <= (u32) SP_PL);       // all starts are in the list: two per thread at most
   sp_rec5 r0, r1;
+  u32 d0 = 0, d1 = 0;                                     // hash digit 0 of the two records (a.dig)
   u32 m0 = 0, m1 = 0;                                     // i | flip << 12 | n << 13 | b << 20; bit 31: a record to place, bit 30: an entry to record
   if (piped)
     {
@@ -642,6 +646,11 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
                       const u32 *arr = flip ? rcw : fwd;
                       const int  st  = flip ? (R - (i + L)) : i;
                       sp_put_record5(arr, st, L, ((u32) (n - 1)) << lensh, lenw, (h == 0) ? r0.w : r1.w);
+                      if (a.dig != NULL)
+                        { u32 ha, hb;
+                          fk_rec_hash<5>((h == 0) ? r0.w : r1.w, 20, ha, hb);
+                          if (h == 0) d0 = hb & 0xffu; else d1 = hb & 0xffu;
+                        }
                     }
                 }
             }
@@ -679,7 +688,10 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
               if (POS)
                 a.pos[slot] = ((u64) (t0 + i) << 1) | flip;
               if (sww == 5)
-                *(sp_rec5 *) dst = (h == 0) ? r0 : r1;
+                { *(sp_rec5 *) dst = (h == 0) ? r0 : r1;
+                  if (a.dig != NULL)
+                    a.dig[slot] = (uint8_t) ((h == 0) ? d0 : d1);
+                }
               else
                 put_generic(i, flip, (int) ((m >> 13) & 0x7fu), dst);
             }
@@ -711,6 +723,14 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
           if (POS)
             a.pos[slot] = ((u64) (t0 + i) << 1) | flip;
           put_generic(i, flip, n, a.out + slot * sww);
+          if (a.dig != NULL && sww == 5)
+            { sp_rec5 rr;
+              const int  L   = n - 1 + K;
+              sp_put_record5(flip ? rcw : fwd, flip ? (R - (i + L)) : i, L, ((u32) (n - 1)) << lensh, lenw, rr.w);
+              u32 ha, hb;
+              fk_rec_hash<5>(rr.w, 20, ha, hb);
+              a.dig[slot] = (uint8_t) (hb & 0xffu);
+            }
         }
     }
 #undef SP_LIST
@@ -949,7 +969,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_split_replay(SplitArgs a)
 #define SP_CT 1024
 __global__ __launch_bounds__(SP_CT) void k_split_compact(u32 *__restrict__ out, int sww, const u64 *__restrict__ cursor,
                                                          int cstride, int lstreams, const u64 *__restrict__ rbase, int b0,
-                                                         const u32 *__restrict__ overflowed)
+                                                         const u32 *__restrict__ overflowed, uint8_t *__restrict__ dig)
 { const int b = b0 + blockIdx.x, C = 1 << lstreams, tid = threadIdx.x;
   __shared__ u64 L[1 << SP_LSTREAMS];
   if (*overflowed == 1u)                 // a region was too small: records were dropped, the caller starts over
@@ -971,6 +991,15 @@ __global__ __launch_bounds__(SP_CT) void k_split_compact(u32 *__restrict__ out, 
           continue;
         const u64 n   = (u64) (have < (1 << SP_LB) ? have : (1 << SP_LB)) * (u64) sww;
         const u64 src = (r0 + (((r << lstreams) + (u64) c) << SP_LB)) * (u64) sww;
+        if (src != dst && dig != NULL)                  // the records' digit bytes move with them (a chunk: <= 1024 of them)
+          { const u64 nr = n / (u64) sww, sr = src / (u64) sww, dr = dst / (u64) sww;
+            const uint8_t v = ((u64) tid < nr) ? dig[sr + tid] : (uint8_t) 0;
+            __syncthreads();
+            if ((u64) tid < nr)
+              dig[dr + tid] = v;
+            __threadfence_block();
+            __syncthreads();
+          }
         if (src != dst)
           for (u64 off = 0; off < n; off += 4 * SP_CT)
             { u32 v[4];
@@ -1009,7 +1038,7 @@ static int sp_finish_streams(fk_ctx *ctx, const SplitArgs &a, int b0, int b1, in
 { hipStream_t s = ctx->stream;
   const int C = 1 << a.lstreams;
   hipLaunchKernelGGL(k_split_compact, dim3((unsigned) (b1 - b0)), dim3(SP_CT), 0, s, a.out, a.sww, (const u64 *) a.cursor,
-                     a.cstride, a.lstreams, a.rbase, b0, (const u32 *) a.overflowed);
+                     a.cstride, a.lstreams, a.rbase, b0, (const u32 *) a.overflowed, a.dig);
   FK_LAUNCH_CHECK(ctx);
   u64 *h = ctx->h_scratch + 8192;                  // pinned; (b1 - b0) * C <= 2048 words
   FK_HIP(ctx, hipMemcpy2DAsync(h, sizeof(u64), a.cursor + ((size_t) b0 << a.lstreams) * a.cstride, (size_t) a.cstride * sizeof(u64),
@@ -1196,8 +1225,11 @@ int fkx_split(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int
 // once with overflow detection, and only if the estimate was too small fall back to the exact
 // count-then-emit of fkx_split.  *d_out is the arena slot that received the records.
 int fkx_split_fast(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void **d_out, int64_t *nsuper,
-                   int64_t *ninst, int64_t *bucket_counts, int64_t *bucket_offsets, const fk_pkview *pk)
+                   int64_t *ninst, int64_t *bucket_counts, int64_t *bucket_offsets, const fk_pkview *pk, uint8_t **d_dig)
 { int64_t bc[256];
+  if (d_dig != NULL)
+    *d_dig = NULL;
+  const bool want_dig = (d_dig != NULL && ctx->wid.smer_stride == 20);
   for (int b = 0; b < 256; b++)
     bucket_counts[b] = bucket_offsets[b] = 0;
   hipStream_t s = ctx->stream;
@@ -1246,6 +1278,9 @@ int fkx_split_fast(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void **d_ou
           if (out == NULL)
             return (FK_ENOMEM);
           cap = ctx->slot_cap[FK_SLOT_SM_A] / stride;          // use the headroom too
+          a.dig = want_dig ? (uint8_t *) fk_slot(ctx, FK_SLOT_SM_DIG, cap + 64) : NULL;
+          if (want_dig && a.dig == NULL)
+            return (FK_ENOMEM);
           FK_HIP(ctx, hipMemsetAsync(ctx->d_scratch, 0, 1032 * sizeof(u64), s));
           a.out = (u32 *) out; a.cap = cap; a.tile_stride = 1;
           if (sp_cursors(ctx) == NULL)
@@ -1269,9 +1304,11 @@ int fkx_split_fast(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void **d_ou
                 *ninst = t;
               }
               *d_out  = out;
+              if (d_dig != NULL) *d_dig = a.dig;
               bucket_counts[0] = *nsuper;
               return (FK_OK);
             }
+          a.dig = NULL;
           a.cursor = d_cursor; a.cstride = 1; a.lstreams = 0;
           // estimate too small (very uneven input): exact path below
         }
@@ -1286,7 +1323,12 @@ int fkx_split_fast(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void **d_ou
         { void *out = fk_slot(ctx, FK_SLOT_SM_A, cap * stride);
           if (out == NULL)
             return (FK_ENOMEM);
-          rc = fkx_split_planned(ctx, d_bases, nbytes, out, cap, offs, bc, ninst, 0, -1, 0, pk);
+          uint8_t *dg = want_dig ? (uint8_t *) fk_slot(ctx, FK_SLOT_SM_DIG, cap + 64) : NULL;
+          if (want_dig && dg == NULL)
+            return (FK_ENOMEM);
+          rc = fkx_split_planned(ctx, d_bases, nbytes, out, cap, offs, bc, ninst, 0, -1, 0, pk, dg);
+          if (rc == FK_OK && d_dig != NULL)
+            *d_dig = dg;
           if (rc == FK_OK)
             { int64_t tot = 0;
               for (int b = 0; b < ctx->prm.nbuckets; b++)
@@ -1394,7 +1436,7 @@ int fkx_split_plan(fk_ctx *ctx, const void *d_bases, int64_t nbytes, int64_t *ca
 // the entries a mode-1 pass over the same reads left behind (k_split_replay).
 int fkx_split_planned(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_out, int64_t cap,
                       const int64_t *offsets, int64_t *counts, int64_t *ninst, int b0, int b1, int mode,
-                      const fk_pkview *pk)
+                      const fk_pkview *pk, uint8_t *d_dig)
 { hipStream_t s = ctx->stream;
   const int   K = ctx->prm.kmer;
   const int   nb = ctx->prm.nbuckets;
@@ -1455,6 +1497,7 @@ int fkx_split_planned(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_
   a.tile_stride = 1;
   a.ent = NULL; a.ent_cursor = ctx->d_cursors + ((size_t) 256 << SP_LSTREAMS) * FK_CURSOR_STRIDE; a.tile_ent = NULL; a.ent_cap = 0;
   a.gb0 = b0; a.gb1 = b1;
+  a.dig = (mode == 0 && !group && ctx->wid.smer_stride == 20) ? d_dig : NULL;
   { const int rcp = sp_packed_args(ctx, a, (mode == 2 && pk != NULL) ? NULL : pk, ntiles);   // (a replay pass needs no tile index)
     if (rcp != FK_OK) return (rcp);
   }

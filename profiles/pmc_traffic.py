@@ -9,7 +9,9 @@ of the bytes of a wide coalesced streaming read, so reads = 2 x FETCH_SIZE x 102
 different record counts); per group: launches, mean read / write / total bytes per launch.  For the
 graded scatter kernel the per-launch traffic is also put next to the algorithmic 2*n*R of the bench
 line (records_per_launch = the bucket average)."""
+import hashlib
 import json
+import os
 import sqlite3
 import sys
 
@@ -59,6 +61,10 @@ def main():
                               "coalesced streaming read, MI355X_MICROARCH.md HBM section), writes = WRITE_SIZE x 1024",
         workload=cfg["workload"], weighted_kmers=cfg["weighted_kmers"], supermers=cfg["supermers"],
         records_per_launch=roof["records_per_launch"], algorithmic_bytes_per_launch=roof["algorithmic_bytes"],
+        # bench.py reports this file's traffic only while the scatter kernel's source is the one it was measured on
+        kernel_source="fastk_amd/csrc/fk_radix.hip",
+        kernel_source_sha256=hashlib.sha256(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                             "fastk_amd", "csrc", "fk_radix.hip"), "rb").read()).hexdigest(),
         kernels=kern)
     if scat:
         tot = sum(v["read_bytes_total"] + v["write_bytes_total"] for v in scat)

@@ -8,7 +8,7 @@ mkdir -p $out
 cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd - >/dev/null
 B="python3 bench.py --steps 2 --warmup 1 --no-e2e --no-device-leg --no-cpu-baseline ${BENCH_ARGS}"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- $B > $out/bench_line_under_trace.json 2> $out/trace.err
-B1="python3 bench.py --steps 1 --warmup 0 --no-e2e --no-device-leg --no-cpu-baseline ${BENCH_ARGS}"
+B1="python3 bench.py --steps 1 --warmup 0 --no-e2e --no-device-leg --no-cpu-baseline --no-packed-leg ${BENCH_ARGS}"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/fetch -- $B1 > $out/bench_line_fetch.json 2> $out/fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/write -- $B1 > $out/bench_line_write.json 2> $out/write.err
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $out/sq -- $B1 > $out/bench_line_sq.json 2> $out/sq.err
