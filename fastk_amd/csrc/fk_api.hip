@@ -1538,9 +1538,12 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
                   void *out = fk_slot(ctx, FK_SLOT_SM_A, std::max(run, gmax) * w.smer_stride);
                   if (out == NULL) { rc = FK_ENOMEM; break; }
                   sm_a = out;
+                  // (the passes write the first digit stream of every bucket's grouping sort beside the records)
+                  sm_dig = (w.smer_stride == 20) ? (uint8_t *) fk_slot(ctx, FK_SLOT_SM_DIG, ctx->slot_cap[FK_SLOT_SM_A] / w.smer_stride + 64)
+                                                 : NULL;
                   hipEventRecord(gev[0], s);
                   rc = fkx_split_planned(ctx, d_reads, nbytes, out, ctx->slot_cap[FK_SLOT_SM_A] / w.smer_stride,
-                                         lo, cnt, &nig, gb[g], gb[g + 1], replay ? (g == 0 ? 1 : 2) : 0, pk);
+                                         lo, cnt, &nig, gb[g], gb[g + 1], replay ? (g == 0 ? 1 : 2) : 0, pk, sm_dig);
                   if (replay && g == 0 && rc == FK_OK && !ctx->ent_valid)
                     replay = false;                 // the entries did not fit: full passes for the other groups
                   hipEventRecord(gev[1], s);
@@ -1568,7 +1571,7 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
               for (int b = gb[g]; b < gb[g + 1] && rc == FK_OK; b++)
                 { tot += cnt[b];
                   rc = count_bucket(ctx, (char *) sm_a + lo[b] * w.smer_stride, cnt[b], res, false, NULL,
-                                    &ntab, NULL, &tm, ns_max);
+                                    &ntab, NULL, &tm, ns_max, sm_dig != NULL ? sm_dig + lo[b] : NULL);
                 }
             }
           hipEventDestroy(gev[0]);

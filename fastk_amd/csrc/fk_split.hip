@@ -944,7 +944,15 @@ __global__ __launch_bounds__(SP_THREADS) void k_split_replay(SplitArgs a)
         }
 #endif
       if (sww == 5)
-        sp_put_record5(arr, st, L, ((u32) (n - 1)) << lensh, lenw, dst);
+        { sp_rec5 rr;
+          sp_put_record5(arr, st, L, ((u32) (n - 1)) << lensh, lenw, rr.w);
+          *(sp_rec5 *) dst = rr;
+          if (a.dig != NULL)                                   // first digit of the grouping sort, as k_split writes it
+            { u32 ha, hb;
+              fk_rec_hash<5>(rr.w, 20, ha, hb);
+              a.dig[slot] = (uint8_t) (hb & 0xffu);
+            }
+        }
       else
       for (int q = 0; q < sww; q++)
         { u32 x = 0;
@@ -1497,7 +1505,7 @@ int fkx_split_planned(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_
   a.tile_stride = 1;
   a.ent = NULL; a.ent_cursor = ctx->d_cursors + ((size_t) 256 << SP_LSTREAMS) * FK_CURSOR_STRIDE; a.tile_ent = NULL; a.ent_cap = 0;
   a.gb0 = b0; a.gb1 = b1;
-  a.dig = (mode == 0 && !group && ctx->wid.smer_stride == 20) ? d_dig : NULL;
+  a.dig = (ctx->wid.smer_stride == 20) ? d_dig : NULL;      // (a group pass writes the digits of the records it emits)
   { const int rcp = sp_packed_args(ctx, a, (mode == 2 && pk != NULL) ? NULL : pk, ntiles);   // (a replay pass needs no tile index)
     if (rcp != FK_OK) return (rcp);
   }
