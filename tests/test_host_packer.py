@@ -15,6 +15,7 @@ def test_reader_thread_packer_matches_restatement(tmp_path):
     assert os.path.exists(os.path.join(lib, "libfastk_amd.so")), "build fastk_amd/csrc first"
     exe = str(tmp_path / "host_packer_check")
     subprocess.run(["gcc", "-O2", "-Wall", "-o", exe, os.path.join(ROOT, "tests", "csrc", "host_packer_check.c"),
+                    os.path.join(ROOT, "fastk_amd", "csrc", "host", "input_formats.c"),      # (the driver's SAM / BAM readers)
                     "-L" + lib, "-lfastk_amd", "-lz", "-lpthread", "-Wl,-rpath," + lib], check=True)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "packer OK" in out.stdout, out.stdout + out.stderr
