@@ -351,7 +351,7 @@ def device_leg(args, cfg, fastk_amd, ctx_gen, glen, nreads, L, local_rank):
                    packed=dict(value=inst / times["packed"][-1], unit="k-mers/s", seconds=round(times["packed"][-1], 3),
                                first_run_seconds=round(times["packed"][0], 3), h2d_bytes=int(cbytes + 4 * nreads),
                                definition="the same with the reads in two bits per base in pinned host memory "
-                                          "(fk_push_packed: codes + read lengths; the device restores the ASCII reads in HBM)"))
+                                          "(fk_push_packed: codes + read lengths; the reads stay packed in HBM and are split in that form)"))
     lib.fk_host_free(host)
     lib.fk_host_free(hcodes)
     return out
