@@ -865,7 +865,11 @@ static void scan_text_packed(Feeder *f, const char *path, int fastq)
     { void *m = mmap(NULL,(size_t) size,PROT_READ,MAP_SHARED,fd,0);
       if (m != MAP_FAILED) job.map = (const char *) m;
     }
-  nthr = (ncpu > 64) ? 64 : (int) ncpu;
+  /* 32 readers at most: the pushes are DMA reads of host memory, and host memory is what the packers themselves keep
+     busy (150 GB of text in, 37.5 GB of codes out) -- a 17 MB block crosses PCIe at 56 GB/s on an idle host and at
+     23 GB/s beside 48 threads that write memory (tools/probe/h2d_probe.cpp); 24-32 readers scan the file in 1.03-1.05 s,
+     48-64 in 1.11-1.18 s (FASTK_AMD_READERS overrides) */
+  nthr = (ncpu > 32) ? 32 : (int) ncpu;
   if (RANK >= 0 && NGPUS > 1) nthr /= NGPUS;
   if (getenv("FASTK_AMD_READERS") != NULL && atoi(getenv("FASTK_AMD_READERS")) > 0)
     nthr = atoi(getenv("FASTK_AMD_READERS"));
