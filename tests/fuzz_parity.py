@@ -14,6 +14,7 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("FASTK_AMD_TEST_KNOBS", "1")                   # (chunk sizes and spill limits are test knobs)
 import fastk_amd                                                     # noqa: E402
 from oracle import orc                                               # noqa: E402
 
