@@ -311,6 +311,7 @@ int fkx_collapse(fk_ctx *ctx, const void *d_kmers, int64_t n, void *d_out, int64
                  int64_t *nout, int64_t *overflow);
 int fkx_pinned_alloc(void **out, int64_t bytes);     // large buffers: huge pages touched in parallel + hipHostRegister
 int fkx_pinned_free(void *p);
+int fkx_reserve_host_table(fk_ctx *ctx, int64_t bytes);      // ctx->h_table: pinned host memory for the result table
 int fkx_aggregate(fk_ctx *ctx, const void *d_grouped, int64_t n, int cutoff, int64_t *hist,
                   int64_t *max_inst, int64_t *ndistinct, void *d_table, int64_t cap, int64_t *ntable);
 int fkx_parse_fastq(fk_ctx *ctx, const void *d_raw, int64_t nbytes, int flags, int *phase, void *d_dst,
