@@ -283,6 +283,10 @@ __device__ __forceinline__ void sp_mark_tile(const SplitArgs &a, int64_t t0, int
   for (int64_t j = (int64_t) m.s_lo + tid; j < (int64_t) m.s_hi; j += SP_THREADS)
     { if (j != (int64_t) m.s_lo + tid)
         { s = a.inv[2 * j]; n = a.inv[2 * j + 1]; }
+      // (the bracket may hold a stretch that lies wholly behind the tile -- the first one that ENDS behind the next
+      //  tile may begin anywhere: the distances are compared in 64 bits before anything is narrowed)
+      if (s >= tend || s + n <= t0)
+        continue;
       const int lo = (int) ((s > t0 ? s : t0) - t0), hi = (int) ((s + n < tend ? s + n : tend) - t0);
       for (int w = lo >> 5; hi > lo && w <= ((hi - 1) >> 5); w++)
         { const int b0 = (w << 5) > lo ? 0 : lo - (w << 5);
@@ -1078,23 +1082,46 @@ static void sp_launch(SplitArgs a, int64_t ngrid, hipStream_t s)
 }
 
 // For every tile, where its walk through the two sorted lists of a packed read set begins: the first read whose last
-// position is not in front of the tile, the first invalid stretch that does not end in front of it.  One thread per
-// list element writes the tiles that begin inside it (a 15 kbp read: four) -- entries left at 0xffffffff: nothing.
+// position is not in front of the tile, the first invalid stretch that does not end in front of it (0xffffffff: none).
+// One thread per 64 consecutive tiles: a binary search finds the element for its first tile, the others follow by
+// walking the list forward -- the work is tiles + elements whatever the shape of the data (the first version gave every
+// list element the tiles that begin inside it: one stretch of N at the end of 150 G positions was one thread writing
+// 36 M entries).
+#define SP_TIDX_CH 64
 __global__ __launch_bounds__(256) void k_pk_tidx(const int64_t *__restrict__ roff, int64_t nreads, const int64_t *__restrict__ inv,
                                                  int64_t ninv, int64_t ntiles, int64_t tile_len, u32 *__restrict__ tidx)
-{ const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
-  if (i < nreads)
-    { const int64_t p = (i == 0) ? -1 : roff[i] - 1, e = roff[i + 1] - 1;       // last positions of reads i-1 and i
-      const int64_t tf = (p < 0) ? 0 : p / tile_len + 1;
-      for (int64_t t = tf; t < ntiles && t * tile_len <= e; t++)
-        tidx[2 * t] = (u32) i;
-    }
-  if (i < ninv)
-    { const int64_t p = (i == 0) ? -1 : inv[2 * i - 2] + inv[2 * i - 1] - 1, e = inv[2 * i] + inv[2 * i + 1] - 1;
-      const int64_t tf = (p < 0) ? 0 : p / tile_len + 1;
-      for (int64_t t = tf; t < ntiles && t * tile_len <= e; t++)
-        tidx[2 * t + 1] = (u32) i;
-    }
+{ const int64_t c = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  const int64_t t_lo = c * SP_TIDX_CH, t_hi = (t_lo + SP_TIDX_CH < ntiles) ? t_lo + SP_TIDX_CH : ntiles;
+  if (t_lo >= ntiles)
+    return;
+  { // reads: last position of read j = roff[j + 1] - 1, non-decreasing
+    const int64_t p0 = t_lo * tile_len;
+    int64_t lo = 0, hi = nreads;
+    while (lo < hi)
+      { const int64_t mid = (lo + hi) >> 1;
+        if (roff[mid + 1] - 1 < p0) lo = mid + 1; else hi = mid;
+      }
+    int64_t j = lo;
+    for (int64_t t = t_lo; t < t_hi; t++)
+      { while (j < nreads && roff[j + 1] - 1 < t * tile_len)
+          j += 1;
+        tidx[2 * t] = (j < nreads) ? (u32) j : 0xffffffffu;
+      }
+  }
+  { // stretches: last position of stretch j = inv[2 j] + inv[2 j + 1] - 1, increasing
+    const int64_t p0 = t_lo * tile_len;
+    int64_t lo = 0, hi = ninv;
+    while (lo < hi)
+      { const int64_t mid = (lo + hi) >> 1;
+        if (inv[2 * mid] + inv[2 * mid + 1] - 1 < p0) lo = mid + 1; else hi = mid;
+      }
+    int64_t j = lo;
+    for (int64_t t = t_lo; t < t_hi; t++)
+      { while (j < ninv && inv[2 * j] + inv[2 * j + 1] - 1 < t * tile_len)
+          j += 1;
+        tidx[2 * t + 1] = (j < ninv) ? (u32) j : 0xffffffffu;
+      }
+  }
 }
 
 // pk != NULL: the split kernels of `a` take packed reads; builds the tile index in its arena slot
@@ -1113,8 +1140,8 @@ static int sp_packed_args(fk_ctx *ctx, SplitArgs &a, const fk_pkview *pk, int64_
     return (FK_ENOMEM);
   hipStream_t s = ctx->stream;
   FK_HIP(ctx, hipMemsetAsync(tidx, 0xff, (size_t) (ntiles + 2) * 8, s));
-  const int64_t n = (pk->nreads > pk->ninv) ? pk->nreads : pk->ninv;
-  hipLaunchKernelGGL(k_pk_tidx, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, pk->roff, pk->nreads, pk->inv, pk->ninv,
+  const int64_t nch = (ntiles + SP_TIDX_CH - 1) / SP_TIDX_CH;        // (entries ntiles, ntiles + 1 keep the memset's "none")
+  hipLaunchKernelGGL(k_pk_tidx, dim3((unsigned) ((nch + 255) / 256)), dim3(256), 0, s, pk->roff, pk->nreads, pk->inv, pk->ninv,
                      ntiles, (int64_t) SP_TILE, tidx);
   FK_LAUNCH_CHECK(ctx);
   a.roff = pk->roff; a.nreads = pk->nreads; a.inv = pk->inv; a.ninv = pk->ninv; a.tidx = tidx;

@@ -469,6 +469,31 @@ def test_packed_and_ascii_splitters_agree_on_ragged_reads():
     assert np.array_equal(a.table, b.table) and np.array_equal(b.table, exp.table)
 
 
+def test_packed_reads_beyond_2_31_positions():
+    """15 M reads of 150 bp = 2.25 G positions, packed on the device, with ONE invalid stretch: the last two positions.
+    Every tile's bracket of the stretch list then holds a stretch that lies up to 2.25 G positions behind it (round 4's
+    first tile loader narrowed that distance to 32 bits: at BASELINE configs[1] -- 5 G positions, a two-position pad
+    behind the last pushed block -- it marked bases of 43 % of the tiles invalid).  Instances, conservation, and the same
+    histogram as the ASCII splitter on the same reads (whose last read ends in two N's)."""
+    import ctypes as C
+    L, k, nreads, glen = 150, 40, 15_000_000, 50_000_000
+    with fastk_amd.Context(kmer=k, table_cutoff=2) as ctx:
+        buf, nbytes = ctx.synth_reads(77, glen, L, 1000, 0, nreads)
+        codes = ctx.alloc(nreads * L // 4 + 64)
+        ctx._ck(ctx.L.fk_pack_fixed_reads(ctx.h, buf.ptr, nreads, L, codes.ptr))
+        roff = ctx.alloc((nreads + 1) * 8).upload(np.arange(nreads + 1, dtype=np.int64) * L)
+        inv = ctx.alloc(16).upload(np.array([nreads * L - 2, 2], dtype=np.int64))
+        b = ctx.count_device_packed(codes.ptr, nreads * L, roff.ptr, nreads, inv.ptr, 1, fetch_table=False)
+        # the same reads as ASCII, the last two bases of the last read made N
+        ctx._ck(ctx.L.fk_copy_to_device(ctx.h, buf.ptr + nbytes - 3, np.frombuffer(b"NN", dtype=np.uint8).ctypes.data, 2))
+        a = ctx.count_device_reads(buf.ptr, nbytes, fetch_table=False)
+    expect = nreads * (L - k + 1) - 2
+    assert a.ninst == b.ninst == expect, (a.ninst, b.ninst, expect)
+    hb = b.hist.astype(np.int64)
+    assert int((hb[1:0x7fff] * np.arange(1, 0x7fff)).sum()) + int(b.max_inst) == expect
+    assert np.array_equal(a.hist, b.hist) and a.ntable == b.ntable
+
+
 def test_packed_pushes_of_changing_shape():
     """a block of one long read followed by a block of many short reads (more read offsets than the first
     block's staging held), then a block with many N stretches -- and the forms of a run do not mix."""
