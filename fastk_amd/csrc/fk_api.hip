@@ -38,7 +38,19 @@ void *fk_slot(fk_ctx *ctx, int slot, int64_t nbytes)
   // super-mer grouping change W by a few records) does not re-allocate multi-GB buffers
   nbytes += nbytes / 32 + (1 << 20);
   void *p = NULL;
-  if (hipMalloc(&p, (size_t) nbytes) != hipSuccess)
+  hipError_t me = hipMalloc(&p, (size_t) nbytes);
+  if (me != hipSuccess && slot != FK_SLOT_SM_DIG && ctx->slot_ptr[FK_SLOT_SM_DIG] != NULL)
+    { // The splitter's digit stream (a byte per super-mer record: 3 GB and more) only saves the grouping sort a pass
+      // over the records: when memory runs short it goes first.  ctx->dig_lost tells the pipeline that the streams of
+      // the buckets still to come are gone (fk_radix.hip and count_bucket look at it before they use one).
+      (void) hipGetLastError();
+      hipFree(ctx->slot_ptr[FK_SLOT_SM_DIG]);
+      ctx->slot_ptr[FK_SLOT_SM_DIG] = NULL;
+      ctx->slot_cap[FK_SLOT_SM_DIG] = 0;
+      ctx->dig_lost = true;
+      me = hipMalloc(&p, (size_t) nbytes);
+    }
+  if (me != hipSuccess)
     { size_t fr = 0, tot = 0;
       int64_t held = 0;
       char    big[256] = "";

@@ -68,7 +68,7 @@ static int count_bucket(fk_ctx *ctx, void *sm_in, int64_t ns, fk_result *res, bo
       bool    dd = false;
       if (lds_dedup)
         { void *grouped = sm_in;
-          ctx->pre_dig = dig; ctx->pre_dig_n = ns;
+          ctx->pre_dig = ctx->dig_lost ? NULL : dig; ctx->pre_dig_n = ns;
           if ((rc = fkx_group(ctx, ns, sm_in, sm_b, w.smer_stride, w.smer_stride, 2, &grouped)) != FK_OK)
             break;
           res->passes_super      = ctx->sort_stats.passes;
@@ -282,7 +282,14 @@ static int count_bucket(fk_ctx *ctx, void *sm_in, int64_t ns, fk_result *res, bo
                     }
                   if (hipMalloc(&nbuf, (size_t) ncap) != hipSuccess)
                     { ncap = need + (1 << 20);                // no room for the extrapolation: what is needed now
-                      if (hipMalloc(&nbuf, (size_t) ncap) != hipSuccess)
+                      if (hipMalloc(&nbuf, (size_t) ncap) != hipSuccess && ctx->slot_ptr[FK_SLOT_SM_DIG] != NULL)
+                        { (void) hipGetLastError();           // ... and the splitter's digit streams go first (fk_slot)
+                          hipFree(ctx->slot_ptr[FK_SLOT_SM_DIG]);
+                          ctx->slot_ptr[FK_SLOT_SM_DIG] = NULL;
+                          ctx->slot_cap[FK_SLOT_SM_DIG] = 0;
+                          ctx->dig_lost = true;
+                        }
+                      if (nbuf == NULL && hipMalloc(&nbuf, (size_t) ncap) != hipSuccess)
                         { fk_set_error(ctx, "out of HBM: cannot allocate %lld bytes for the table records", (long long) ncap);
                           rc = FK_ENOMEM;
                           break;
@@ -449,6 +456,7 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
   do
     { void *sm_a = NULL;
       uint8_t *sm_dig = NULL;            // first digit stream of the super-mer grouping, from a one-pass split
+      ctx->dig_lost = false;
       int64_t ns = 0, ni = 0;
       int64_t bc[256] = { 0 }, bo[256] = { 0 };
       int     nbk = 1;
@@ -653,8 +661,9 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
                   if (out == NULL) { rc = FK_ENOMEM; break; }
                   sm_a = out;
                   // (the passes write the first digit stream of every bucket's grouping sort beside the records)
-                  sm_dig = (w.smer_stride == 20) ? (uint8_t *) fk_slot(ctx, FK_SLOT_SM_DIG, ctx->slot_cap[FK_SLOT_SM_A] / w.smer_stride + 64)
-                                                 : NULL;
+                  sm_dig = (w.smer_stride == 20 && !ctx->dig_lost)
+                           ? (uint8_t *) fk_slot(ctx, FK_SLOT_SM_DIG, ctx->slot_cap[FK_SLOT_SM_A] / w.smer_stride + 64) : NULL;
+                  if (sm_dig == NULL) ctx->err[0] = 0;     // (optional: without it the grouping sort makes the stream itself)
                   hipEventRecord(gev[0], s);
                   rc = fkx_split_planned(ctx, d_reads, nbytes, out, ctx->slot_cap[FK_SLOT_SM_A] / w.smer_stride,
                                          lo, cnt, &nig, gb[g], gb[g + 1], replay ? (g == 0 ? 1 : 2) : 0, pk, sm_dig);

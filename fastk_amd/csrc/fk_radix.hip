@@ -1029,7 +1029,9 @@ static int lsd_sort_stream_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, c
   // and the stream of digit 0 behind
   // ... or the splitter the stream of hash digit 0 of whole super-mer records, beside the records (no histograms:
   // k_rx_superscan sums the digit totals from the tile histograms)
-  const uint8_t *pre_dig = (HASHED && ctx->pre_dig != NULL && ctx->pre_dig_n == n && bytes[0] == 0 && hbytes == RW * 4)
+  // (the slots above are reserved first: if that took the digit stream's memory, dig_lost says so and the records'
+  //  own pass makes the stream as before)
+  const uint8_t *pre_dig = (HASHED && !ctx->dig_lost && ctx->pre_dig != NULL && ctx->pre_dig_n == n && bytes[0] == 0 && hbytes == RW * 4)
                            ? ctx->pre_dig : NULL;
   ctx->pre_dig = NULL;
   const bool pre = (pre_dig != NULL)

@@ -1313,9 +1313,9 @@ int fkx_split_fast(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void **d_ou
           if (out == NULL)
             return (FK_ENOMEM);
           cap = ctx->slot_cap[FK_SLOT_SM_A] / stride;          // use the headroom too
-          a.dig = want_dig ? (uint8_t *) fk_slot(ctx, FK_SLOT_SM_DIG, cap + 64) : NULL;
+          a.dig = (want_dig && !ctx->dig_lost) ? (uint8_t *) fk_slot(ctx, FK_SLOT_SM_DIG, cap + 64) : NULL;
           if (want_dig && a.dig == NULL)
-            return (FK_ENOMEM);
+            ctx->err[0] = 0;                             // (optional: the grouping sort then makes the stream itself)
           FK_HIP(ctx, hipMemsetAsync(ctx->d_scratch, 0, 1032 * sizeof(u64), s));
           a.out = (u32 *) out; a.cap = cap; a.tile_stride = 1;
           if (sp_cursors(ctx) == NULL)
@@ -1358,9 +1358,9 @@ int fkx_split_fast(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void **d_ou
         { void *out = fk_slot(ctx, FK_SLOT_SM_A, cap * stride);
           if (out == NULL)
             return (FK_ENOMEM);
-          uint8_t *dg = want_dig ? (uint8_t *) fk_slot(ctx, FK_SLOT_SM_DIG, cap + 64) : NULL;
+          uint8_t *dg = (want_dig && !ctx->dig_lost) ? (uint8_t *) fk_slot(ctx, FK_SLOT_SM_DIG, cap + 64) : NULL;
           if (want_dig && dg == NULL)
-            return (FK_ENOMEM);
+            ctx->err[0] = 0;                             // (optional: the grouping sort then makes the stream itself)
           rc = fkx_split_planned(ctx, d_bases, nbytes, out, cap, offs, bc, ninst, 0, -1, 0, pk, dg);
           if (rc == FK_OK && d_dig != NULL)
             *d_dig = dg;
