@@ -661,6 +661,566 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_ag_count2 (round 4): the same result with no counting sort.  What bounds k_ag_count is the SUM of its
+// vector instructions and its LDS traffic, phase by phase (every wave is in the same phase, so one never hides
+// the other) -- this version has fewer of both:
+//   A   a record is stored at its OWN position (j * 1024 + tid: a linear 16-byte write, no bank conflicts) and
+//       writes that position into head[cell] with a plain 16-bit store.  The stores of a cell race; whichever
+//       stays is a complete position, and any record of the cell is as good a representative as any other -- no
+//       returning atomic, no scan of the counters, no second pass that moves the records (steps A, S, B above)
+//   C1  every record compares itself with its cell's representative: the same k-mer -> its weight goes there
+//       (one LDS add) and it is dead; the representative itself is that k-mer's leader
+//   C2  the records of the other k-mers of a shared cell (one in ten) are COMPACTED: their positions go into a
+//       list, and one thread per list entry (not eight sparsely filled steps per thread) runs elections on
+//       further hash bits -- racing 16-bit stores into a table of 2048, the record that stays is the leader of
+//       all that are equal to it -- until a round finds nobody left (two tables in turn, one barrier per round)
+//   H   as before, except that the table candidates are compacted too: their positions go into a list and thread
+//       i writes candidate i (coalesced 12-byte stores, one histogram update per candidate instead of eight
+//       predicated steps per thread) when the cutoff is 3 or more (the default -t4)
+// Chunks of bins beyond a fill, selections, limits, saturation: exactly as in k_ag_count.
+#define AG2_TSZ 2048
+
+template <int KW> struct AgCfg2
+{ static constexpr int HB = 1536;                      // LDS-private histogram bins
+  static constexpr size_t LDS = (size_t) AgCfg<KW>::CAP * AgCfg<KW>::SDW * 4 + AgCfg<KW>::CAP * 2 + 2 * AG2_TSZ * 2
+                                + HB * 4 + 256;
+};
+
+template <int KW>
+__global__ __launch_bounds__(AG_THREADS) void k_ag_count2(const u32 *__restrict__ recs,
+                                                          const u64 *__restrict__ bounds, int kbytes,
+                                                          int cutoff, u64 *__restrict__ hist_g,
+                                                          u64 *__restrict__ scal, u32 *__restrict__ table,
+                                                          int cap_eff, int limit, int gshift, u32 sat, u64 tcap)
+{ constexpr int CAP = AgCfg<KW>::CAP;
+  constexpr int NS  = AgCfg<KW>::NS;
+  constexpr int SDW = AgCfg<KW>::SDW;
+  constexpr int HB  = AgCfg2<KW>::HB;
+  extern __shared__ uint4 ag_lds[];
+  u32      *slot    = (u32 *) ag_lds;                      // [CAP][SDW] key + count, record j of thread t at j * 1024 + t
+  uint16_t *head    = (uint16_t *) (slot + CAP * SDW);     // [CAP] cell -> a record of it; then lists of positions
+  uint16_t *etab    = head + CAP;                          // [2][AG2_TSZ] election tables, used in turn
+  u32      *lhist   = (u32 *) (etab + 2 * AG2_TSZ);        // [HB]
+  u32      *sh_tmp  = lhist + HB;                          // [2][AG_WAVES]
+  u64      *sh_base = (u64 *) (sh_tmp + 2 * AG_WAVES);
+  u32      *sh_flag = (u32 *) (sh_base + 1);               // [3] "somebody is still looking for a leader", by round
+  const int tid = threadIdx.x;
+  const u32 lane = fk_lane();
+#define AG_TID(t) u32 t = (u32) tid; asm volatile("" : "+v"(t))
+
+  for (int i = tid; i < HB; i += AG_THREADS)
+    lhist[i] = 0;
+  if (tid < 3)
+    sh_flag[tid] = 0;
+  u64 my_max = 0;
+  u32 my_distinct = 0, my_rounds = 0;
+  u32 R0 = 1, flip = 0;
+  u32 e1 = 0, e3 = 0;                           // election round counter, mod 2 and mod 3 (never reset)
+#ifdef FK_ABLATION
+  u64 ph[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tlast = __builtin_readcyclecounter();
+#endif
+  u32 kmask[KW];
+#pragma unroll
+  for (int w = 0; w < KW; w++)
+    kmask[w] = (4 * w + 4 <= kbytes) ? 0xffffffffu : (4 * w < kbytes) ? ((1u << (8 * (kbytes - 4 * w))) - 1u) : 0u;
+  __syncthreads();
+
+  // The emit of a selection is DEFERRED: its table space is reserved at once, but the histogram and table work runs
+  // at the top of the next fill, behind the loads of that fill's records -- the trip to memory (a sixth of a bin's time
+  // when it is waited for) is covered by it.  One load site and one emit site: fetching the next bin "ahead" from a
+  // second site made the register allocator copy the loaded registers on the spot, i.e. wait for them there.
+  u32  v[NS];                                  // counts by position of the fill that is being / still to be emitted
+  bool pending = false;
+  u32  e_tot = 0, e_toff = 0;
+  u64  e_tbase = 0;
+  const bool tab   = (cutoff > 0);
+  const bool dense = (cutoff >= 3);            // every table candidate has a count above 2
+
+  // the deferred part of an emit: histogram, then the candidates' sweep (table entries of e_tot candidates at e_tbase)
+  auto emit_rest = [&]()
+    { { u32 n1 = 0, n2 = 0, n3 = 0;
+        const bool b3 = dense && cutoff >= 4;           // count 3 by ballot too
+#pragma unroll
+        for (int j = 0; j < NS; j++)
+          { const u32 vv = v[j];
+            n1 += (u32) __popcll(__ballot(vv == 1u));
+            n2 += (u32) __popcll(__ballot(vv == 2u));
+            if (b3)
+              n3 += (u32) __popcll(__ballot(vv == 3u));
+          }
+        if (lane == 0)
+          { if (n1 != 0) atomicAdd(&lhist[1], n1);
+            if (n2 != 0) atomicAdd(&lhist[2], n2);
+            if (n3 != 0) atomicAdd(&lhist[3], n3);
+          }
+        if (!dense || cutoff > 4)                       // counts that neither a ballot nor the candidates' sweep sees
+          { const u32 lo = b3 ? 4u : 3u;
+#pragma unroll
+            for (int j = 0; j < NS; j++)
+              { const u32 vv = v[j];
+                if (vv >= lo && !(dense && vv >= (u32) cutoff))
+                  { if (vv >= sat)
+                      my_max += vv;
+                    const u32 cc = min(vv, 0x7fffu);
+                    if (cc < HB) atomicAdd(&lhist[cc], 1u);
+                    else         atomicAdd(&hist_g[cc], 1ull);
+                  }
+              }
+          }
+      }
+      if (dense)
+        { // the candidates' positions, in table order, over the head region
+          u32 o = e_toff;
+          AG_TID(t);
+#pragma unroll
+          for (int j = 0; j < NS; j++)
+            if (v[j] >= (u32) cutoff)
+              head[o++] = (uint16_t) ((u32) (j * AG_THREADS) + t);
+        }
+      AG_T(5);
+      if (tab)
+        { if (tid == 0)
+            *sh_base = e_tbase;
+          __syncthreads();
+          AG_T(6);
+          const u64  tb0  = *sh_base;
+          const bool full = (e_tot > 0 && tb0 + e_tot > tcap);
+          if (full)
+            { if (tid == 0)
+                atomicAdd(&scal[6], 1ull);
+            }
+          if (dense)
+            { if (!full)
+                for (u32 i = (u32) tid; i < e_tot; i += AG_THREADS)
+                  { const u32 *sp = slot + (u32) head[i] * SDW;
+                    u32 kd[KW], vv;
+                    if (SDW == 4)
+                      { const uint4 q = *(const uint4 *) sp;
+                        kd[0] = q.x;
+                        if (KW > 1) kd[KW > 1 ? 1 : 0] = q.y;
+                        if (KW > 2) kd[KW > 2 ? 2 : 0] = q.z;
+                        vv = q.w;
+                      }
+                    else
+                      {
+#pragma unroll
+                        for (int w = 0; w < KW; w++)
+                          kd[w] = sp[w];
+                        vv = sp[SDW - 1];
+                      }
+                    if (vv >= sat)
+                      my_max += vv;
+                    const u32 cc = min(vv, 0x7fffu);
+                    if (cc < HB) atomicAdd(&lhist[cc], 1u);
+                    else         atomicAdd(&hist_g[cc], 1ull);
+                    ag_rec<KW> ro;
+#pragma unroll
+                    for (int w = 0; w < KW - 1; w++)
+                      ro.w[w] = kd[w];
+                    ro.w[KW - 1] = kd[KW - 1] | (cc << 16);
+                    *(ag_rec<KW> *) (table + (tb0 + i) * KW) = ro;
+                  }
+            }
+          else if (!full && e_tot > 0)
+            { u64 o = tb0 + e_toff;
+              AG_TID(t);
+#pragma unroll
+              for (int j = 0; j < NS; j++)
+                if (v[j] >= (u32) cutoff)
+                  { const u32 *sp = slot + ((u32) (j * AG_THREADS) + t) * SDW;
+                    ag_rec<KW> ro;
+#pragma unroll
+                    for (int w = 0; w < KW - 1; w++)
+                      ro.w[w] = sp[w];
+                    ro.w[KW - 1] = sp[KW - 1] | (min(v[j], 0x7fffu) << 16);
+                    *(ag_rec<KW> *) (table + o * KW) = ro;
+                    o += 1;
+                  }
+            }
+        }
+      AG_T(7);
+    };
+  const u32 nbins = (u32) (AG_BINS >> gshift);
+#define AG_BOUNDS_OF(b) bounds[(size_t) min((b) + ag_opaque(lane & 1u), nbins) << gshift]
+  u32 bin = blockIdx.x;
+  int64_t beg = 0, end = 0;
+  u64 nxv = 0;
+#define AG_SCALAR64(x, l) ((int64_t) (((u64) (u32) __builtin_amdgcn_readlane((int) ((x) >> 32), l) << 32) \
+                                       | (u32) __builtin_amdgcn_readlane((int) (x), l)))
+  { const u64 b0 = (bin < nbins) ? AG_BOUNDS_OF(bin) : 0ull;
+    nxv = (bin + gridDim.x < nbins) ? AG_BOUNDS_OF(bin + gridDim.x) : 0ull;
+    beg = AG_SCALAR64(b0, 0);
+    end = AG_SCALAR64(b0, 1);
+  }
+  for (; bin < nbins; bin += gridDim.x)
+    { int64_t nx_beg = 0, nx_end = 0;
+      bool    have_nx = false;
+#define AG_ADVANCE() do { if (!have_nx) { nx_beg = AG_SCALAR64(nxv, 0); nx_end = AG_SCALAR64(nxv, 1); have_nx = true; \
+                                           nxv = (bin + 2 * gridDim.x < nbins) ? AG_BOUNDS_OF(bin + 2 * gridDim.x) : 0ull; } } while (0)
+      if (beg < end)
+      {
+      bool bin_ovf = false, failed = false;
+      u32  bin_fill = 0;
+      for (u32 r0 = 0; r0 < R0 && !failed; r0++)
+      { u32 R = R0, r = r0;
+      for (;;)
+        { u64     round_max = 0;
+          int64_t pos = beg;
+          u32     carried = 0, vmask = 0;
+          bool    ovf = false;
+          u32     key[NS][KW], wgt[NS];
+          for (;;)
+            { // ---- fill the register slots (as in k_ag_count)
+              u32 isnew = 0;
+              if (carried == 0)
+                { const int64_t room = end - pos;
+                  const u32 nnew = (room < (int64_t) cap_eff) ? (u32) room : (u32) cap_eff;
+                  { const u32 *bp = recs + pos * KW;
+                    AG_TID(t);
+#pragma unroll
+                    for (int j = 0; j < NS; j++)
+                      { const u32 L = min((u32) (j * AG_THREADS) + t, nnew - 1);
+                        const ag_rec<KW> rr = *(const ag_rec<KW> *) (bp + L * KW);
+#pragma unroll
+                        for (int w = 0; w < KW; w++)
+                          key[j][w] = rr.w[w];
+                      }
+                  }
+                  if (pending)                     // the previous selection's histogram and table work, while these travel
+                    { emit_rest();
+                      pending = false;
+                    }
+#pragma unroll
+                  for (int j = 0; j < NS; j++)
+                    if ((u32) (j * AG_THREADS + tid) < nnew)
+                      isnew |= (1u << j);
+                  pos += nnew;
+                }
+              else
+                { u32 fr = 0;
+#pragma unroll
+                  for (int j = 0; j < NS; j++)
+                    if ((u32) (j * AG_THREADS + tid) < (u32) cap_eff && !((vmask >> j) & 1u))
+                      fr |= (1u << j);
+                  u32 totfree;
+                  u32 k = ag_block_exscan((u32) __popc(fr), sh_tmp + (flip ^= AG_WAVES), &totfree);
+                  const int64_t room = end - pos;
+                  const u32 nnew = (room < (int64_t) totfree) ? (u32) room : totfree;
+#pragma unroll
+                  for (int j = 0; j < NS; j++)
+                    if ((fr >> j) & 1u)
+                      { if (k < nnew)
+                          { const ag_rec<KW> rr = *(const ag_rec<KW> *) (recs + (pos + k) * KW);
+#pragma unroll
+                            for (int w = 0; w < KW; w++)
+                              key[j][w] = rr.w[w];
+                            isnew |= (1u << j);
+                          }
+                        k += 1;
+                      }
+                  pos += nnew;
+                }
+#ifdef FK_ABLATION
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+              __syncthreads();                   // (the candidates' sweep of the previous fill has read its slots and list)
+              AG_T(0);
+
+              // ---- A: every record to its own slot, its position into the head of its cell
+              u32 cj[NS];
+              { AG_TID(t);
+#pragma unroll
+                for (int j = 0; j < NS; j++)
+                  { if ((isnew >> j) & 1u)
+                      { wgt[j] = key[j][KW - 1] >> 16;
+#pragma unroll
+                        for (int w = 0; w < KW; w++)
+                          key[j][w] &= kmask[w];
+                      }
+                    cj[j] = 0;
+                    if (((isnew | vmask) >> j) & 1u)
+                      { if (R > 1 && ((isnew >> j) & 1u))
+                          { u32 ha, hb;
+                            fk_rec_hash<KW>(key[j], kbytes, ha, hb);
+                            if (((hb >> 16) & (R - 1)) != r)
+                              continue;
+                          }
+                        vmask |= (1u << j);
+                        cj[j] = ag_cellhash<KW>(key[j]) & (CAP - 1);
+                        const u32 P = (u32) (j * AG_THREADS) + t;
+                        u32 *sp = slot + P * SDW;
+                        if (SDW == 4)
+                          *(uint4 *) sp = make_uint4(key[j][0], KW > 1 ? key[j][KW > 1 ? 1 : 0] : 0u,
+                                                     KW > 2 ? key[j][KW > 2 ? 2 : 0] : 0u, wgt[j]);
+                        else
+                          { *(uint4 *) sp = make_uint4(key[j][0], key[j][1], key[j][2], key[j][KW > 3 ? 3 : 0]);
+                            *(uint4 *) (sp + 4) = make_uint4(KW > 4 ? key[j][KW > 4 ? 4 : 0] : 0u, KW > 5 ? key[j][KW > 5 ? 5 : 0] : 0u,
+                                                             KW > 6 ? key[j][KW > 6 ? 6 : 0] : 0u, wgt[j]);
+                          }
+                        head[cj[j]] = (uint16_t) P;
+                      }
+                  }
+              }
+              __syncthreads();
+              AG_T(1);
+
+              // ---- C1: compare with the cell's representative
+              u32 need = 0, dead = 0;
+              { u32 L[NS];
+#pragma unroll
+                for (int j = 0; j < NS; j++)
+                  L[j] = ((vmask >> j) & 1u) ? (u32) head[cj[j]] : 0u;
+                AG_TID(t);
+#pragma unroll
+                for (int g = 0; g < NS; g += 4)
+                  { uint4 s0[4], s1[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                      { s0[i] = *(const uint4 *) (slot + L[g + i] * SDW);
+                        if (SDW == 8) s1[i] = *(const uint4 *) (slot + L[g + i] * SDW + 4);
+                      }
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                      { const int j = g + i;
+                        u32 e = s0[i].x ^ key[j][0];
+                        if (KW > 1) e |= s0[i].y ^ key[j][KW > 1 ? 1 : 0];
+                        if (KW > 2) e |= s0[i].z ^ key[j][KW > 2 ? 2 : 0];
+                        if (KW > 3) e |= s0[i].w ^ key[j][KW > 3 ? 3 : 0];
+                        if (KW > 4) e |= s1[i].x ^ key[j][KW > 4 ? 4 : 0];
+                        if (KW > 5) e |= s1[i].y ^ key[j][KW > 5 ? 5 : 0];
+                        if (KW > 6) e |= s1[i].z ^ key[j][KW > 6 ? 6 : 0];
+                        if (((vmask >> j) & 1u) && L[j] != (u32) (j * AG_THREADS) + t)
+                          { if (e == 0)
+                              { atomicAdd(slot + L[j] * SDW + (SDW - 1), wgt[j]);
+                                dead |= (1u << j);
+                              }
+                            else
+                              need |= (1u << j);
+                          }
+                      }
+                  }
+              }
+              // the records still without a leader, compacted: positions into a list over the (now dead) heads
+              u32 nneed;
+              { u32 kq = ag_block_exscan((u32) __popc(need), sh_tmp + (flip ^= AG_WAVES), &nneed);
+                AG_TID(t);
+#pragma unroll
+                for (int j = 0; j < NS; j++)
+                  if ((need >> j) & 1u)
+                    head[kq++] = (uint16_t) ((u32) (j * AG_THREADS) + t);
+              }
+              AG_T(2);
+
+              // ---- C2: elections, one thread per list entry (the registers of the records are free now)
+              if (nneed > 0)
+                { __syncthreads();
+                  u32 act = 0, P2[NS], hh[NS];
+#pragma unroll
+                  for (int k = 0; k < NS; k++)
+                    { P2[k] = 0; hh[k] = 0;
+                      if ((u32) (k * AG_THREADS) < nneed)
+                        { const u32 i = (u32) (k * AG_THREADS) + ag_opaque((u32) tid);
+                          if (i < nneed)
+                            { P2[k] = head[i];
+                              const u32 *sp = slot + P2[k] * SDW;
+                              if (SDW == 4)
+                                { const uint4 q = *(const uint4 *) sp;
+                                  key[k][0] = q.x;
+                                  if (KW > 1) key[k][KW > 1 ? 1 : 0] = q.y;
+                                  if (KW > 2) key[k][KW > 2 ? 2 : 0] = q.z;
+                                  wgt[k] = q.w;
+                                }
+                              else
+                                {
+#pragma unroll
+                                  for (int w = 0; w < KW; w++)
+                                    key[k][w] = sp[w];
+                                  wgt[k] = sp[SDW - 1];
+                                }
+                              hh[k] = ag_cellhash<KW>(key[k]) >> 13;
+                              act |= (1u << k);
+                            }
+                        }
+                    }
+                  for (;;)
+                    { uint16_t *tb = etab + e1 * AG2_TSZ;
+                      u32 hx[NS];
+#pragma unroll
+                      for (int k = 0; k < NS; k++)
+                        { hx[k] = 0;
+                          if ((u32) (k * AG_THREADS) < nneed && ((act >> k) & 1u))
+                            { const u32 x = (hh[k] + 0x632be5abu * (e3 + 3 * e1 + 1)) * 0x9E3779B1u;
+                              hx[k] = (x >> 16) & (AG2_TSZ - 1);
+                              tb[hx[k]] = (uint16_t) P2[k];
+                            }
+                        }
+                      if (act != 0) sh_flag[e3] = 1;
+                      if (tid == 0) sh_flag[(e3 == 2) ? 0 : e3 + 1] = 0;
+                      __syncthreads();
+                      const bool any = (sh_flag[e3] != 0);
+                      e1 ^= 1;
+                      e3 = (e3 == 2) ? 0 : e3 + 1;
+                      if (!any)
+                        break;
+#pragma unroll
+                      for (int k = 0; k < NS; k++)
+                        if ((u32) (k * AG_THREADS) < nneed && ((act >> k) & 1u))
+                          { const u32 m = tb[hx[k]];
+                            if (m == P2[k])
+                              act &= ~(1u << k);                   // the leader
+                            else
+                              { const u32 *sp = slot + m * SDW;
+                                u32 e = 0;
+                                if (SDW == 4)
+                                  { const uint4 q = *(const uint4 *) sp;
+                                    e = q.x ^ key[k][0];
+                                    if (KW > 1) e |= q.y ^ key[k][KW > 1 ? 1 : 0];
+                                    if (KW > 2) e |= q.z ^ key[k][KW > 2 ? 2 : 0];
+                                  }
+                                else
+                                  {
+#pragma unroll
+                                    for (int w = 0; w < KW; w++)
+                                      e |= sp[w] ^ key[k][w];
+                                  }
+                                if (e == 0)
+                                  { atomicAdd(slot + m * SDW + (SDW - 1), wgt[k]);
+                                    slot[P2[k] * SDW + (SDW - 1)] = 0;
+                                    act &= ~(1u << k);
+                                  }
+                              }
+                          }
+                    }
+                }
+              AG_T(3);
+              AG_T(4);
+
+              // ---- harvest: the counts of the leaders
+              { AG_TID(t);
+                const u32 live = vmask & ~dead;
+#pragma unroll
+                for (int j = 0; j < NS; j++)
+                  v[j] = ((live >> j) & 1u) ? slot[((u32) (j * AG_THREADS) + t) * SDW + (SDW - 1)] : 0u;
+              }
+              if (pos >= end)
+                break;
+              // more of the bin to come: the leaders stay where they are and carry their counts
+              u32 nl = 0, D;
+#pragma unroll
+              for (int j = 0; j < NS; j++)
+                nl += (v[j] != 0);
+              ag_block_exscan(nl, sh_tmp + (flip ^= AG_WAVES), &D);
+              if (D > (u32) limit)
+                { ovf = true;
+                  break;
+                }
+              vmask = 0;
+              AG_TID(tc);
+#pragma unroll
+              for (int j = 0; j < NS; j++)
+                if (v[j] != 0)
+                  { const u32 *sp = slot + ((u32) (j * AG_THREADS) + tc) * SDW;
+                    vmask |= (1u << j);
+#pragma unroll
+                    for (int w = 0; w < KW; w++)
+                      key[j][w] = sp[w];
+                    if (v[j] >= AG_HIGH)
+                      { v[j] -= AG_CUT;
+                        round_max += AG_CUT;
+                      }
+                    wgt[j] = v[j];
+                  }
+              carried = D;
+              my_rounds += (tid == 0);
+            }
+          if (ovf)
+            { my_rounds += (tid == 0);
+              bin_ovf = true;
+              __syncthreads();
+              if (R >= AG_MAXR)
+                { if (tid == 0)
+                    atomicAdd(&scal[3], 1ull);
+                  failed = true;
+                  break;
+                }
+              R <<= 1;
+              continue;
+            }
+
+          AG_ADVANCE();
+          // ---- emit, first part: the table space of the candidates (a global atomic whose result is looked at in the
+          // deferred part); the harvest loop above has left the counts in v[]
+          my_max += round_max;
+          { u32 nq = 0, nlead = 0;
+#pragma unroll
+            for (int j = 0; j < NS; j++)
+              { const u32 vv = v[j];
+                nlead += (vv != 0);
+                nq    += (tab && vv >= (u32) cutoff);
+              }
+            e_tot = 0; e_toff = 0; e_tbase = 0;
+            if (tab)
+              { e_toff = ag_block_exscan(nq, sh_tmp + (flip ^= AG_WAVES), &e_tot);
+                if (tid == 0 && e_tot > 0)
+                  e_tbase = atomicAdd(&scal[2], (u64) e_tot);
+              }
+            my_distinct += nlead;
+            if (R0 > 1)
+              { u32 D;
+                ag_block_exscan(nlead, sh_tmp + (flip ^= AG_WAVES), &D);
+                bin_fill = max(bin_fill, D);
+              }
+          }
+          pending = true;
+
+          while (R > R0 && r >= (R >> 1))
+            { r -= (R >> 1);
+              R >>= 1;
+            }
+          if (R == R0)
+            break;
+          r += (R >> 1);
+        }
+      }
+      if (bin_ovf)
+        R0 = min(R0 << 1, (u32) AG_MAXR);
+      else if (R0 > 1 && bin_fill * 9 < (u32) limit * 4)
+        R0 >>= 1;
+      }
+      AG_ADVANCE();
+      beg = nx_beg; end = nx_end;
+    }
+#undef AG_ADVANCE
+  if (pending)
+    emit_rest();
+#undef AG_SCALAR64
+#undef AG_BOUNDS_OF
+#undef AG_TID
+
+  __syncthreads();
+  for (int i = tid; i < HB; i += AG_THREADS)
+    if (lhist[i] != 0)
+      atomicAdd(&hist_g[i], (u64) lhist[i]);
+  u64 d = my_distinct, rd = my_rounds;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+    { my_max += __shfl_down(my_max, o, 64);
+      d      += __shfl_down(d, o, 64);
+      rd     += __shfl_down(rd, o, 64);
+    }
+  if (lane == 0)
+    { if (my_max) atomicAdd(&scal[0], my_max);
+      if (d)      atomicAdd(&scal[1], d);
+      if (rd)     atomicAdd(&scal[5], rd);
+    }
+#ifdef FK_ABLATION
+  if (tid == 0)
+    for (int k = 0; k < 8; k++)
+      atomicAdd(&scal[8 + k], ph[k]);
+#endif
+}
+
 // bins merged per fill: 2^gshift, the largest group whose expected size stays within 7/16 of a fill when doubled
 template <int KW>
 static int ag_gshift(int64_t n)
@@ -688,10 +1248,12 @@ static int aggr_t(fk_ctx *ctx, const void *d_grouped, int64_t n, int cutoff, int
     return (FK_ENOMEM);
   u64 *d_scal = d_hist + FK_HIST_BINS;
   static bool attr_set[8] = { false };
-  const size_t lds = AgCfg<KW>::LDS;
+  const size_t lds = AgCfg<KW>::LDS, lds2 = AgCfg2<KW>::LDS;
   if (!attr_set[KW])
     { auto kern = k_ag_count<KW, false>;
       FK_HIP(ctx, hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+      auto kern2 = k_ag_count2<KW>;
+      FK_HIP(ctx, hipFuncSetAttribute((const void *) kern2, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds2));
       attr_set[KW] = true;
     }
   FK_HIP(ctx, hipMemsetAsync(d_hist, 0, (FK_HIST_BINS + AG_NSCAL) * 8, s));
@@ -710,9 +1272,14 @@ static int aggr_t(fk_ctx *ctx, const void *d_grouped, int64_t n, int cutoff, int
   if (ctx->dbg_aggr_limit > 0 && ctx->dbg_aggr_limit < cap_eff)
     cap_eff = ctx->dbg_aggr_limit < 4 ? 4 : ctx->dbg_aggr_limit;
   const int limit = cap_eff * 3 / 4;
-  hipLaunchKernelGGL((k_ag_count<KW, false>), dim3((unsigned) cus), dim3(AG_THREADS), lds, s, (const u32 *) d_grouped,
-                     (const u64 *) d_bounds, ctx->wid.kmer_bytes, cutoff, d_hist, d_scal, (u32 *) d_table, cap_eff, limit, ctx->dbg_aggr_variant, gshift,
-                     (u32) (ctx->aggr_sat > 0 ? ctx->aggr_sat : 0x7fff), (u64) cap);
+  if (ctx->dbg_aggr_engine == 1 || ctx->dbg_aggr_variant != 0)     // the counting sort of round 3 (kept for comparison)
+    hipLaunchKernelGGL((k_ag_count<KW, false>), dim3((unsigned) cus), dim3(AG_THREADS), lds, s, (const u32 *) d_grouped,
+                       (const u64 *) d_bounds, ctx->wid.kmer_bytes, cutoff, d_hist, d_scal, (u32 *) d_table, cap_eff, limit, ctx->dbg_aggr_variant, gshift,
+                       (u32) (ctx->aggr_sat > 0 ? ctx->aggr_sat : 0x7fff), (u64) cap);
+  else
+    hipLaunchKernelGGL((k_ag_count2<KW>), dim3((unsigned) cus), dim3(AG_THREADS), lds2, s, (const u32 *) d_grouped,
+                       (const u64 *) d_bounds, ctx->wid.kmer_bytes, cutoff, d_hist, d_scal, (u32 *) d_table, cap_eff, limit, gshift,
+                       (u32) (ctx->aggr_sat > 0 ? ctx->aggr_sat : 0x7fff), (u64) cap);
   FK_LAUNCH_CHECK(ctx);
   u64 *h = ctx->h_scratch;                       // pinned, 64 KB + 64 KB: the histogram needs 256 KB
   u64 *hh = (u64 *) malloc((FK_HIST_BINS + AG_NSCAL) * 8);
@@ -743,7 +1310,7 @@ static int aggr_t(fk_ctx *ctx, const void *d_grouped, int64_t n, int cutoff, int
     { fprintf(stderr, "ag phases (cycles of thread 0, all workgroups) n=%lld:", (long long) n);
       for (int k = 0; k < 8; k++)
         fprintf(stderr, " %llu", (unsigned long long) hh[FK_HIST_BINS + 8 + k]);
-      fprintf(stderr, "  (load, A, scan, B, C, harvest+hist, table reserve, table write)\n");
+      fprintf(stderr, "  (engine 1: load, A, scan, B, C, harvest+hist, table reserve, table write; engine 2: load, A, C1, C2, -, harvest+hist, reserve, write)\n");
     }
 #endif
   free(hh);

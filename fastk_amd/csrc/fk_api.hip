@@ -604,6 +604,10 @@ extern "C" int fk_debug_set(fk_ctx *ctx, const char *key, int64_t value)
       return (FK_EUNSUPPORTED);
 #endif
     }
+  if (strcmp(key, "aggr_engine") == 0)      // 1: the counting-sort aggregation of round 3; 0: k_ag_count2
+    { ctx->dbg_aggr_engine = (int) value;
+      return (FK_OK);
+    }
   if (strcmp(key, "aggr_limit") == 0)
     { ctx->dbg_aggr_limit = (int) value;
       return (FK_OK);

@@ -221,6 +221,7 @@ struct fk_ctx
   int        dbg_aggr_variant;    // ablations of k_ag_count (wrong results), see fk_debug_set
   int        dbg_table_prefix;    // >= 2: bytes the table sort's LSD passes cover before the tie repair
   int        dbg_aggr_gshift;     // > 0: merge 2^(this - 1) bins per table fill instead of the automatic choice
+  int        dbg_aggr_engine;     // 1: k_ag_count (counting sort in LDS, round 3) instead of k_ag_count2
   int        dbg_aggr_limit;      // > 0: pretend the LDS table of fk_aggr.hip takes only this many k-mers
   int64_t    aggr_extra_rounds;   // bins x rounds that had to be split in the last aggregation
   int        num_cus;
