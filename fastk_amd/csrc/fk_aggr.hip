@@ -679,12 +679,15 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
 //       i writes candidate i (coalesced 12-byte stores, one histogram update per candidate instead of eight
 //       predicated steps per thread) when the cutoff is 3 or more (the default -t4)
 // Chunks of bins beyond a fill, selections, limits, saturation: exactly as in k_ag_count.
-#define AG2_TSZ 2048
+#define AG2_TSZ  2048                   // entries of one of the workgroup's two election tables (fallback)
+#define AG2_LCAP 256                    // entries of a wave's list
+#define AG2_TW   128                    // entries of a wave's election table
 
 template <int KW> struct AgCfg2
-{ static constexpr int HB = 1536;                      // LDS-private histogram bins
-  static constexpr size_t LDS = (size_t) AgCfg<KW>::CAP * AgCfg<KW>::SDW * 4 + AgCfg<KW>::CAP * 2 + 2 * AG2_TSZ * 2
-                                + HB * 4 + 256;
+{ static constexpr int HB = 768;                       // LDS-private histogram bins
+  static constexpr size_t LDS = (size_t) AgCfg<KW>::CAP * AgCfg<KW>::SDW * 4 + AgCfg<KW>::CAP * 2
+                                + AG_WAVES * (AG2_LCAP + AG2_TW) * 2 + HB * 4 + 256;
+  static_assert(AG_WAVES * (AG2_LCAP + AG2_TW) >= 2 * AG2_TSZ, "the workgroup's tables lie over the waves' lists and tables");
 };
 
 template <int KW>
@@ -692,7 +695,7 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count2(const u32 *__restrict_
                                                           const u64 *__restrict__ bounds, int kbytes,
                                                           int cutoff, u64 *__restrict__ hist_g,
                                                           u64 *__restrict__ scal, u32 *__restrict__ table,
-                                                          int cap_eff, int limit, int gshift, u32 sat, u64 tcap)
+                                                          int cap_eff, int limit, int gshift, u32 sat, u64 tcap, int lcap)
 { constexpr int CAP = AgCfg<KW>::CAP;
   constexpr int NS  = AgCfg<KW>::NS;
   constexpr int SDW = AgCfg<KW>::SDW;
@@ -700,18 +703,22 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count2(const u32 *__restrict_
   extern __shared__ uint4 ag_lds[];
   u32      *slot    = (u32 *) ag_lds;                      // [CAP][SDW] key + count, record j of thread t at j * 1024 + t
   uint16_t *head    = (uint16_t *) (slot + CAP * SDW);     // [CAP] cell -> a record of it; then lists of positions
-  uint16_t *etab    = head + CAP;                          // [2][AG2_TSZ] election tables, used in turn
-  u32      *lhist   = (u32 *) (etab + 2 * AG2_TSZ);        // [HB]
+  uint16_t *wl      = head + CAP;                          // [AG_WAVES][AG2_LCAP] the waves' lists of records to elect leaders for
+  uint16_t *wt      = wl + AG_WAVES * AG2_LCAP;            // [AG_WAVES][AG2_TW] the waves' election tables
+  uint16_t *etab    = wl;                                  // [2][AG2_TSZ] the workgroup's election tables (instead of both)
+  u32      *lhist   = (u32 *) (wt + AG_WAVES * AG2_TW);    // [HB]
   u32      *sh_tmp  = lhist + HB;                          // [2][AG_WAVES]
   u64      *sh_base = (u64 *) (sh_tmp + 2 * AG_WAVES);
   u32      *sh_flag = (u32 *) (sh_base + 1);               // [3] "somebody is still looking for a leader", by round
+  u32      *lcnt    = sh_flag + 3;                         // [AG_WAVES] entries of the waves' lists
+  u32      *sh_ovf  = lcnt + AG_WAVES;                     // a list was full
   const int tid = threadIdx.x;
   const u32 lane = fk_lane();
 #define AG_TID(t) u32 t = (u32) tid; asm volatile("" : "+v"(t))
 
   for (int i = tid; i < HB; i += AG_THREADS)
     lhist[i] = 0;
-  if (tid < 3)
+  if (tid < 3 + AG_WAVES + 1)
     sh_flag[tid] = 0;
   u64 my_max = 0;
   u32 my_distinct = 0, my_rounds = 0;
@@ -947,7 +954,7 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count2(const u32 *__restrict_
                               continue;
                           }
                         vmask |= (1u << j);
-                        cj[j] = ag_cellhash<KW>(key[j]) & (CAP - 1);
+                        cj[j] = ag_cellhash<KW>(key[j]);
                         const u32 P = (u32) (j * AG_THREADS) + t;
                         u32 *sp = slot + P * SDW;
                         if (SDW == 4)
@@ -958,7 +965,7 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count2(const u32 *__restrict_
                             *(uint4 *) (sp + 4) = make_uint4(KW > 4 ? key[j][KW > 4 ? 4 : 0] : 0u, KW > 5 ? key[j][KW > 5 ? 5 : 0] : 0u,
                                                              KW > 6 ? key[j][KW > 6 ? 6 : 0] : 0u, wgt[j]);
                           }
-                        head[cj[j]] = (uint16_t) P;
+                        head[cj[j] & (CAP - 1)] = (uint16_t) P;
                       }
                   }
               }
@@ -970,7 +977,7 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count2(const u32 *__restrict_
               { u32 L[NS];
 #pragma unroll
                 for (int j = 0; j < NS; j++)
-                  L[j] = ((vmask >> j) & 1u) ? (u32) head[cj[j]] : 0u;
+                  L[j] = ((vmask >> j) & 1u) ? (u32) head[cj[j] & (CAP - 1)] : 0u;
                 AG_TID(t);
 #pragma unroll
                 for (int g = 0; g < NS; g += 4)
@@ -1001,28 +1008,33 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count2(const u32 *__restrict_
                       }
                   }
               }
-              // the records still without a leader, compacted: positions into a list over the (now dead) heads
-              u32 nneed;
-              { u32 kq = ag_block_exscan((u32) __popc(need), sh_tmp + (flip ^= AG_WAVES), &nneed);
-                AG_TID(t);
+              // The records still without a leader (one in ten: other k-mers of a shared cell) are dealt to the WAVES by four
+              // further hash bits -- all records of a k-mer to the same wave -- so that the elections need no workgroup
+              // barriers: a wave's LDS operations execute in order, and nobody else touches its list and its table.
+              { AG_TID(t);
 #pragma unroll
                 for (int j = 0; j < NS; j++)
                   if ((need >> j) & 1u)
-                    head[kq++] = (uint16_t) ((u32) (j * AG_THREADS) + t);
+                    { const u32 w   = (cj[j] >> 13) & (AG_WAVES - 1);
+                      const u32 idx = atomicAdd(&lcnt[w], 1u);
+                      if (idx < (u32) lcap) wl[w * AG2_LCAP + idx] = (uint16_t) ((u32) (j * AG_THREADS) + t);
+                      else                  *sh_ovf = 1;
+                    }
               }
+              __syncthreads();
               AG_T(2);
-
-              // ---- C2: elections, one thread per list entry (the registers of the records are free now)
-              if (nneed > 0)
-                { __syncthreads();
-                  u32 act = 0, P2[NS], hh[NS];
+              if (*sh_ovf == 0)
+                { const u32 wave = (u32) tid >> 6;
+                  const u32 n = (u32) __builtin_amdgcn_readfirstlane((int) lcnt[wave]);
+                  if (lane == 0) lcnt[wave] = 0;
+                  u32 act = 0, P2[AG2_LCAP / 64], hh[AG2_LCAP / 64];
 #pragma unroll
-                  for (int k = 0; k < NS; k++)
+                  for (int k = 0; k < AG2_LCAP / 64; k++)
                     { P2[k] = 0; hh[k] = 0;
-                      if ((u32) (k * AG_THREADS) < nneed)
-                        { const u32 i = (u32) (k * AG_THREADS) + ag_opaque((u32) tid);
-                          if (i < nneed)
-                            { P2[k] = head[i];
+                      if ((u32) (k * 64) < n)
+                        { const u32 i = (u32) (k * 64) + lane;
+                          if (i < n)
+                            { P2[k] = wl[wave * AG2_LCAP + i];
                               const u32 *sp = slot + P2[k] * SDW;
                               if (SDW == 4)
                                 { const uint4 q = *(const uint4 *) sp;
@@ -1038,35 +1050,27 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count2(const u32 *__restrict_
                                     key[k][w] = sp[w];
                                   wgt[k] = sp[SDW - 1];
                                 }
-                              hh[k] = ag_cellhash<KW>(key[k]) >> 13;
+                              hh[k] = ag_cellhash<KW>(key[k]) >> 17;
                               act |= (1u << k);
                             }
                         }
                     }
-                  for (;;)
-                    { uint16_t *tb = etab + e1 * AG2_TSZ;
-                      u32 hx[NS];
+                  uint16_t *tw = wt + wave * AG2_TW;
+                  u32 rd = 1;
+                  while (__ballot(act != 0) != 0)
+                    { u32 hx[AG2_LCAP / 64];
 #pragma unroll
-                      for (int k = 0; k < NS; k++)
+                      for (int k = 0; k < AG2_LCAP / 64; k++)
                         { hx[k] = 0;
-                          if ((u32) (k * AG_THREADS) < nneed && ((act >> k) & 1u))
-                            { const u32 x = (hh[k] + 0x632be5abu * (e3 + 3 * e1 + 1)) * 0x9E3779B1u;
-                              hx[k] = (x >> 16) & (AG2_TSZ - 1);
-                              tb[hx[k]] = (uint16_t) P2[k];
+                          if ((act >> k) & 1u)
+                            { hx[k] = (((hh[k] + 0x632be5abu * rd) * 0x9E3779B1u) >> 16) & (AG2_TW - 1);
+                              tw[hx[k]] = (uint16_t) P2[k];
                             }
                         }
-                      if (act != 0) sh_flag[e3] = 1;
-                      if (tid == 0) sh_flag[(e3 == 2) ? 0 : e3 + 1] = 0;
-                      __syncthreads();
-                      const bool any = (sh_flag[e3] != 0);
-                      e1 ^= 1;
-                      e3 = (e3 == 2) ? 0 : e3 + 1;
-                      if (!any)
-                        break;
 #pragma unroll
-                      for (int k = 0; k < NS; k++)
-                        if ((u32) (k * AG_THREADS) < nneed && ((act >> k) & 1u))
-                          { const u32 m = tb[hx[k]];
+                      for (int k = 0; k < AG2_LCAP / 64; k++)
+                        if ((act >> k) & 1u)
+                          { const u32 m = tw[hx[k]];
                             if (m == P2[k])
                               act &= ~(1u << k);                   // the leader
                             else
@@ -1091,8 +1095,57 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count2(const u32 *__restrict_
                                   }
                               }
                           }
+                      rd += 1;
                     }
                 }
+              else
+                { // some wave's list is full (lcap records): elections of the whole workgroup, two tables in turn and one
+                  // barrier per round, until a round finds nobody left (the lists and tables of the waves are not in use)
+                  if (lane == 0) lcnt[(u32) tid >> 6] = 0;
+                  // the records elect among themselves where they are, eight sparse steps per thread and round
+                  bool first = true;
+                  for (;;)
+                    { uint16_t *tb = etab + e1 * AG2_TSZ;
+                      const u32 rmul = 0x632be5abu * (e3 + 3 * e1 + 1);
+                      { AG_TID(t);
+#pragma unroll
+                        for (int j = 0; j < NS; j++)
+                          if ((need >> j) & 1u)
+                            tb[((((cj[j] >> 13) + rmul) * 0x9E3779B1u) >> 16) & (AG2_TSZ - 1)] = (uint16_t) ((u32) (j * AG_THREADS) + t);
+                      }
+                      if (need != 0) sh_flag[e3] = 1;
+                      if (tid == 0) sh_flag[(e3 == 2) ? 0 : e3 + 1] = 0;
+                      __syncthreads();
+                      const bool any = (sh_flag[e3] != 0);
+                      if (first && tid == 0) *sh_ovf = 0;          // (everybody has read it)
+                      first = false;
+                      e1 ^= 1;
+                      e3 = (e3 == 2) ? 0 : e3 + 1;
+                      if (!any)
+                        break;
+                      AG_TID(t);
+#pragma unroll
+                      for (int j = 0; j < NS; j++)
+                        if ((need >> j) & 1u)
+                          { const u32 m = tb[((((cj[j] >> 13) + rmul) * 0x9E3779B1u) >> 16) & (AG2_TSZ - 1)];
+                            if (m == (u32) (j * AG_THREADS) + t)
+                              need &= ~(1u << j);                  // the leader
+                            else
+                              { const u32 *sp = slot + m * SDW;
+                                u32 e = 0;
+#pragma unroll
+                                for (int w = 0; w < KW; w++)
+                                  e |= sp[w] ^ key[j][w];
+                                if (e == 0)
+                                  { atomicAdd(slot + m * SDW + (SDW - 1), wgt[j]);
+                                    dead |= (1u << j);
+                                    need &= ~(1u << j);
+                                  }
+                              }
+                          }
+                    }
+                }
+              __syncthreads();
               AG_T(3);
               AG_T(4);
 
@@ -1279,7 +1332,8 @@ static int aggr_t(fk_ctx *ctx, const void *d_grouped, int64_t n, int cutoff, int
   else
     hipLaunchKernelGGL((k_ag_count2<KW>), dim3((unsigned) cus), dim3(AG_THREADS), lds2, s, (const u32 *) d_grouped,
                        (const u64 *) d_bounds, ctx->wid.kmer_bytes, cutoff, d_hist, d_scal, (u32 *) d_table, cap_eff, limit, gshift,
-                       (u32) (ctx->aggr_sat > 0 ? ctx->aggr_sat : 0x7fff), (u64) cap);
+                       (u32) (ctx->aggr_sat > 0 ? ctx->aggr_sat : 0x7fff), (u64) cap,
+                       ctx->dbg_aggr_engine == 2 ? 2 : AG2_LCAP);      // (engine 2: tiny lists, the fallback elections run)
   FK_LAUNCH_CHECK(ctx);
   u64 *h = ctx->h_scratch;                       // pinned, 64 KB + 64 KB: the histogram needs 256 KB
   u64 *hh = (u64 *) malloc((FK_HIST_BINS + AG_NSCAL) * 8);

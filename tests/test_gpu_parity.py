@@ -247,6 +247,20 @@ def test_count_unsorted_bit_exact(name, small_table):
     """fk_count_unsorted_kmers (hash grouping + LDS aggregation + table sort) on the weighted k-mer
     list in RANDOM order reproduces the reference's histogram and table.  small_table shrinks the
     LDS table to eight k-mers so that bins must be split into rounds."""
+    _count_unsorted_case(name, small_table, 0)
+
+
+@pytest.mark.parametrize("engine", [1, 2])
+@pytest.mark.parametrize("small_table", [False, True])
+@pytest.mark.parametrize("name", ["edge_k40_t4_T1", "edge_k51_t1_T4", "synth_illumina_k40_t1_T4"])
+def test_count_unsorted_other_aggregation_routes(name, small_table, engine):
+    """The same through k_ag_count (engine 1: the counting sort in LDS of round 3, kept for comparison) and
+    through k_ag_count2 with wave lists of two entries (engine 2), so that the elections of the whole
+    workgroup -- the route taken when a wave's list is full -- decide nearly every fill."""
+    _count_unsorted_case(name, small_table, engine)
+
+
+def _count_unsorted_case(name, small_table, engine):
     case, bases, boff = util.load_case(name)
     k, cutoff = case["k"], case["cutoff"]
     P = orc.params(k)
@@ -261,6 +275,7 @@ def test_count_unsorted_bit_exact(name, small_table):
         distinct = len(np.unique(kl[:, :P.kmer_bytes], axis=0)) if len(kl) else 0
         limit = 8 if small_table else 0
         ctx.debug_set("aggr_limit", limit)
+        ctx.debug_set("aggr_engine", engine)
         hist, mi, nd, nt, tp = ctx.count_unsorted(a.ptr, t.ptr, len(kl), cutoff)
         if small_table and distinct > 65536 * 6:
             assert ctx.debug_get("aggr_extra_rounds") > 0
