@@ -69,13 +69,15 @@ __device__ __forceinline__ u32 ag_opaque(u32 x) { asm volatile("" : "+v"(x)); re
 // one bin over the cells -- a poor spread costs time, never correctness -- and is independent of the bin's own bits.
 template <int KW>
 __device__ __forceinline__ u32 ag_cellhash(const u32 (&key)[KW])
-{ u32 h = 0x9E3779B9u;
+{ // a sum of 24-bit products of the key's pieces with odd constants (v_mad_u32_u24: three instructions per dword),
+  // then a finish that brings the high bits -- which depend on everything -- down into the cell and the wave bits
+  u32 h = 0x9E3779B9u;
 #pragma unroll
   for (int w = 0; w < KW; w++)
-    { const u32 x = key[w] ^ h;
-      h = __umul24(x, 0x5bd1e9u + 0x22a3c4u * (u32) w) + __umul24(x >> 8, 0x3c6ef3u + 0x1b56c2u * (u32) w);
-      h ^= h >> 15;
+    { h = __umul24(key[w], 0x5bd1e9u + 0x22a3c4u * (u32) w) + h;
+      h = __umul24(key[w] >> 8, 0x3c6ef3u + 0x1b56c2u * (u32) w) + h;
     }
+  h ^= h >> 15;
   h = __umul24(h, 0x2f0b4fu) ^ __umul24(h >> 8, 0x68e31du);
   return (h ^ (h >> 13));
 }
