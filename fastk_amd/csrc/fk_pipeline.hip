@@ -29,6 +29,40 @@ static double ms_between(hipEvent_t a, hipEvent_t b)
 //   final = false (bucket streaming): the table records of this bucket, in no particular order, are
 //                  appended to the slot FK_SLOT_TABLE at record *ntab (grown as needed).
 // sm_in is clobbered (it is one half of the grouping's ping-pong pair).
+// A bucket's records gathered from the chunks of a chunked ingest with ONE launch: piece c of the bucket (its records in
+// chunk c's slab) is src[c], its place among the bucket's dwords begins at off[c] (off[npieces] = the total); a piece
+// that is not in HBM (spilled: copied by hipMemcpyAsync) has src[c] = NULL.  One copy call per chunk and bucket was
+// 8,298 calls of ~20 MB at configs[2]: 208 ms of copy kernels too short to reach the memory's rate, and as much again
+// in the gaps between them.  Records are 4-byte aligned, not more: dword copies (the L1 rate is not what bounds this).
+#define GA_THREADS 256
+#define GA_BLOCK   (GA_THREADS * 64)               // dwords of the destination per workgroup
+
+__global__ __launch_bounds__(GA_THREADS) void k_gather_pieces(const u32 *const *__restrict__ src,
+                                                              const int64_t *__restrict__ off, int npieces,
+                                                              u32 *__restrict__ dst)
+{ const int64_t total = off[npieces];
+  const int64_t lo = (int64_t) blockIdx.x * GA_BLOCK;
+  if (lo >= total)
+    return;
+  const int64_t hi = (lo + GA_BLOCK < total) ? lo + GA_BLOCK : total;
+  int p = 0;                                       // the piece that holds dword lo
+  { int a = 0, b = npieces;
+    while (a + 1 < b)
+      { const int m = (a + b) >> 1;
+        if (off[m] <= lo) a = m; else b = m;
+      }
+    p = a;
+  }
+  int64_t pend = off[p + 1];
+  for (int64_t i = lo + threadIdx.x; i < hi; i += GA_THREADS)
+    { while (i >= pend)
+        pend = off[++p + 1];
+      const u32 *sp = src[p];
+      if (sp != NULL)
+        dst[i] = sp[i - off[p]];
+    }
+}
+
 struct fk_stage_ms { double group_s, expand, radix_k, aggr; };
 
 // dig != NULL: the stream of hash digit 0 of the ns records, written by the splitter beside them.
@@ -566,20 +600,56 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
       ctx->acc_ns = 0;
       ctx->acc_ns_total = ns;
       // chunked ingest: a bucket's records are gathered from the chunks right before it is counted
+      bool gather_tab_sent = false;
       auto gather = [&](int b, void **ptr) -> int
         { char *g = (char *) fk_slot(ctx, FK_SLOT_SM_G, ns_max * w.smer_stride);
           if (g == NULL)
             return (FK_ENOMEM);
+          // the pieces in HBM with one kernel (tables of all buckets: made and sent once, on the first call)
+          const int     nc = ctx->nchunks;
+          const size_t  tb = (size_t) nc * 8 + (size_t) (nc + 1) * 8;           // per bucket: nc sources, nc + 1 offsets
+          char *d_tab = (char *) fk_slot(ctx, FK_SLOT_GATHER, (int64_t) tb * nbk);
+          if (d_tab == NULL)
+            return (FK_ENOMEM);
+          if (!gather_tab_sent)
+            { char *h = (char *) malloc(tb * nbk);
+              if (h == NULL)
+                return (FK_ENOMEM);
+              for (int x = 0; x < nbk; x++)
+                { const void **hs = (const void **) (h + tb * x);
+                  int64_t     *ho = (int64_t *) (h + tb * x + (size_t) nc * 8);
+                  int64_t r = 0;
+                  for (int c = 0; c < nc; c++)
+                    { const fk_chunk *ch = &ctx->chunks[c];
+                      hs[c] = (ch->on_host || ch->cnt[x] == 0) ? NULL : ch->run[x];
+                      ho[c] = r;
+                      r += ch->cnt[x] * (w.smer_stride / 4);
+                    }
+                  ho[nc] = r;
+                }
+              const hipError_t e = hipMemcpyAsync(d_tab, h, tb * nbk, hipMemcpyHostToDevice, s);
+              const hipError_t e2 = hipStreamSynchronize(s);      // (pageable source: gone when this returns)
+              free(h);
+              if (e != hipSuccess || e2 != hipSuccess)
+                return (FK_EHIP);
+              gather_tab_sent = true;
+            }
           int64_t run = 0;
-          for (int c = 0; c < ctx->nchunks; c++)
+          for (int c = 0; c < nc; c++)
             { const fk_chunk *ch = &ctx->chunks[c];
-              if (ch->cnt[b] > 0
-                  && hipMemcpyAsync(g + run * w.smer_stride, ch->run[b],
-                                    (size_t) (ch->cnt[b] * w.smer_stride),
-                                    ch->on_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, s)
-                     != hipSuccess)
+              if (ch->cnt[b] > 0 && ch->on_host
+                  && hipMemcpyAsync(g + run * w.smer_stride, ch->run[b], (size_t) (ch->cnt[b] * w.smer_stride),
+                                    hipMemcpyHostToDevice, s) != hipSuccess)
                 return (FK_EHIP);
               run += ch->cnt[b];
+            }
+          if (run > 0)
+            { const int64_t ndw = run * (w.smer_stride / 4);
+              hipLaunchKernelGGL(k_gather_pieces, dim3((unsigned) ((ndw + GA_BLOCK - 1) / GA_BLOCK)), dim3(GA_THREADS), 0, s,
+                                 (const u32 *const *) (d_tab + tb * b), (const int64_t *) (d_tab + tb * b + (size_t) nc * 8),
+                                 nc, (u32 *) g);
+              if (hipGetLastError() != hipSuccess)
+                return (FK_EHIP);
             }
           *ptr = g;
           return (FK_OK);
