@@ -38,7 +38,10 @@ void *fk_slot(fk_ctx *ctx, int slot, int64_t nbytes)
   // super-mer grouping change W by a few records) does not re-allocate multi-GB buffers
   nbytes += nbytes / 32 + (1 << 20);
   void *p = NULL;
+  const double w0 = fk_wall();
   hipError_t me = hipMalloc(&p, (size_t) nbytes);
+  if (nbytes > (1ll << 30) && getenv("FK_FINISH_TIMING") != NULL)
+    fprintf(stderr, "  finish timing: slot %d: hipMalloc of %.1f GB took %.3f s\n", slot, (double) nbytes / 1e9, fk_wall() - w0);
   if (me != hipSuccess && slot != FK_SLOT_SM_DIG && ctx->slot_ptr[FK_SLOT_SM_DIG] != NULL)
     { // The splitter's digit stream (a byte per super-mer record: 3 GB and more) only saves the grouping sort a pass
       // over the records: when memory runs short it goes first.  ctx->dig_lost tells the pipeline that the streams of

@@ -37,6 +37,8 @@ static double ms_between(hipEvent_t a, hipEvent_t b)
 #define GA_THREADS 256
 #define GA_BLOCK   (GA_THREADS * 64)               // dwords of the destination per workgroup
 
+struct __attribute__((packed, aligned(4))) ga_quad { u32 w[4]; };    // 16 bytes at a 4-byte aligned address: one dwordx4
+
 __global__ __launch_bounds__(GA_THREADS) void k_gather_pieces(const u32 *const *__restrict__ src,
                                                               const int64_t *__restrict__ off, int npieces,
                                                               u32 *__restrict__ dst)
@@ -54,12 +56,25 @@ __global__ __launch_bounds__(GA_THREADS) void k_gather_pieces(const u32 *const *
     p = a;
   }
   int64_t pend = off[p + 1];
-  for (int64_t i = lo + threadIdx.x; i < hi; i += GA_THREADS)
+  for (int64_t i = lo + 4 * (int64_t) threadIdx.x; i < hi; i += 4 * GA_THREADS)
     { while (i >= pend)
         pend = off[++p + 1];
-      const u32 *sp = src[p];
-      if (sp != NULL)
-        dst[i] = sp[i - off[p]];
+      if (i + 4 <= pend && i + 4 <= hi)            // four dwords of one piece
+        { const u32 *sp = src[p];
+          if (sp != NULL)
+            *(ga_quad *) (dst + i) = *(const ga_quad *) (sp + (i - off[p]));
+        }
+      else                                         // a piece (or the bucket) ends inside: dword by dword
+        { int     q = p;
+          int64_t qend = pend;
+          for (int64_t j = i; j < i + 4 && j < hi; j++)
+            { while (j >= qend)
+                qend = off[++q + 1];
+              const u32 *sp = src[q];
+              if (sp != NULL)
+                dst[j] = sp[j - off[q]];
+            }
+        }
     }
 }
 
@@ -149,9 +164,20 @@ static int count_bucket(fk_ctx *ctx, void *sm_in, int64_t ns, fk_result *res, bo
       res->nweighted += nw;
       res->ndistinct_super += nd;
       if (nw > 0)
-        { // (slots grow on demand: hipMalloc / hipFree of tens of GB take well under a millisecond here,
-          // and buckets balanced by work differ too much in density for a prediction to be worth it)
-          const int64_t want = nw;
+        { // The k-mer slots are sized for the LARGEST bucket at once (this one's k-mers per super-mer applied to the largest
+          // bucket's records): hipMalloc and hipFree take well under a millisecond each, but memory a process has freed is
+          // wiped by the driver in the background (~34 GB/s) and an allocation that needs it waits -- slots that grew five
+          // times over the 57 buckets of configs[2] left 38 GB of such memory behind, and the table sort's 37 GB buffer
+          // then took 0.43 s to get (FK_FINISH_TIMING; every run of FastK_amd is a first run).
+          int64_t want = nw;
+          if (ns_max > ns && ns > 0 && ctx->slot_cap[FK_SLOT_KM_A] < nw * w.kmer_stride)
+            { const int64_t big = (int64_t) ((double) nw * ((double) ns_max / (double) ns) * 1.05);
+              size_t fr = 0, tot = 0;                      // (only with room to spare: a run that is short of memory grows on demand)
+              if (hipMemGetInfo(&fr, &tot) == hipSuccess
+                  && (int64_t) fr + ctx->slot_cap[FK_SLOT_KM_A] + ctx->slot_cap[FK_SLOT_KM_B]
+                     > 2 * big * w.kmer_stride + (int64_t) tot / 8)
+                want = big;
+            }
           if (ctx->dbg_verbose)
             fprintf(stderr, "  bucket sizing: %lld records (%lld after de-duplication), largest bucket ~%lld, "
                             "%lld weighted k-mers, buffers for %lld\n", (long long) ns, (long long) nsx,
@@ -314,7 +340,11 @@ static int count_bucket(fk_ctx *ctx, void *sm_in, int64_t ns, fk_result *res, bo
                       const int64_t all = (int64_t) (std::min(by_sm, by_bk) * 1.10) * w.kmer_stride;
                       if (all > ncap) ncap = all + (1 << 20);
                     }
-                  if (hipMalloc(&nbuf, (size_t) ncap) != hipSuccess)
+                  const double wm = fk_wall();
+                  const hipError_t me = hipMalloc(&nbuf, (size_t) ncap);
+                  if (getenv("FK_FINISH_TIMING") != NULL)
+                    fprintf(stderr, "  finish timing: table slot: hipMalloc of %.1f GB took %.3f s\n", (double) ncap / 1e9, fk_wall() - wm);
+                  if (me != hipSuccess)
                     { ncap = need + (1 << 20);                // no room for the extrapolation: what is needed now
                       if (hipMalloc(&nbuf, (size_t) ncap) != hipSuccess && ctx->slot_ptr[FK_SLOT_SM_DIG] != NULL)
                         { (void) hipGetLastError();           // ... and the splitter's digit streams go first (fk_slot)
