@@ -86,7 +86,7 @@ def main():
     t0 = time.time()
     for it in range(iters):
         k = int(rng.choice([12, 15, 16, 17, 21, 25, 31, 32, 33, 40, 47, 48, 51, 55, 63, 64]))
-        cutoff = int(rng.choice([1, 1, 2, 3]))
+        cutoff = int(rng.choice([1, 1, 2, 3, 4, 6]))
         nb = int(rng.choice([1, 1, 2, 3, 7]))
         reads = make_reads(rng, k)
         bases, boff = orc.block_from_reads(reads)

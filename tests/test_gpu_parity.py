@@ -286,6 +286,24 @@ def _count_unsorted_case(name, small_table, engine):
     util.check_against_golden(case, hist, mi + ovf, tab)
 
 
+@pytest.mark.parametrize("cutoff", [3, 5, 9, 20])
+def test_pipeline_with_cutoffs_around_and_above_four(cutoff):
+    """k_ag_count2 counts the k-mers seen once, twice and three times by ballots, sweeps the table candidates and
+    has a third route for counts between four and the cutoff: every combination, the whole path against the oracle
+    on a read set with coverage (counts from 1 to 26)."""
+    case, bases, boff = util.load_case("synth_illumina_k40_t1_T4")
+    k = case["k"]
+    exp = orc.fastk(k, bases, boff, cutoff=cutoff)
+    with fastk_amd.Context(kmer=k, table_cutoff=cutoff, nbuckets=3) as ctx:
+        ctx.push_block(bases, np.asarray(boff - boff[0], dtype=np.int32))
+        res = ctx.finish()
+        assert res.ninst == exp.ninst
+        assert np.array_equal(res.hist, exp.hist)
+        assert res.max_inst == exp.max_inst
+        assert res.ntable == exp.ntable and exp.ntable > 0
+        assert np.array_equal(res.table, exp.table)
+
+
 def test_count_unsorted_exact_max_inst_for_huge_counts(ctx40):
     """One k-mer with 100,000 records of weight 0x7fff (3.3e9 instances, beyond 32 bits) next to
     ordinary ones: the count saturates at 0x7fff and max_inst is exact (MSDsort.c:498-506)."""
