@@ -664,22 +664,26 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_ag_count2 (round 4): the same result with no counting sort.  What bounds k_ag_count is the SUM of its
-// vector instructions and its LDS traffic, phase by phase (every wave is in the same phase, so one never hides
-// the other) -- this version has fewer of both:
+// k_ag_count2 (round 4): the same result with no counting sort.  Every phase of k_ag_count is a chain of dependent
+// LDS round trips that all sixteen waves walk at the same time (nothing hides a trip) -- this
+// version has fewer links in the chain and lets the waves walk part of it on their own:
 //   A   a record is stored at its OWN position (j * 1024 + tid: a linear 16-byte write, no bank conflicts) and
 //       writes that position into head[cell] with a plain 16-bit store.  The stores of a cell race; whichever
 //       stays is a complete position, and any record of the cell is as good a representative as any other -- no
 //       returning atomic, no scan of the counters, no second pass that moves the records (steps A, S, B above)
 //   C1  every record compares itself with its cell's representative: the same k-mer -> its weight goes there
 //       (one LDS add) and it is dead; the representative itself is that k-mer's leader
-//   C2  the records of the other k-mers of a shared cell (one in ten) are COMPACTED: their positions go into a
-//       list, and one thread per list entry (not eight sparsely filled steps per thread) runs elections on
-//       further hash bits -- racing 16-bit stores into a table of 2048, the record that stays is the leader of
-//       all that are equal to it -- until a round finds nobody left (two tables in turn, one barrier per round)
+//   C2  the records of the other k-mers of a shared cell (one in ten) are dealt to the WAVES by four further hash
+//       bits (all records of a k-mer to the same wave; an LDS counter per wave hands out the places in its list).
+//       One barrier, then every wave elects the leaders of its records on its own: racing 16-bit stores into the
+//       wave's table of 128, the record that stays is the leader of all that are equal to it, the others of other
+//       k-mers go on to the next round with another hash -- a wave's LDS operations execute in order and nobody
+//       else touches its list and table, so the rounds need no workgroup barrier.  A full list sets a flag: the
+//       fill then elects workgroup-wide (two tables of 2048 in turn, one barrier per round)
 //   H   as before, except that the table candidates are compacted too: their positions go into a list and thread
 //       i writes candidate i (coalesced 12-byte stores, one histogram update per candidate instead of eight
-//       predicated steps per thread) when the cutoff is 3 or more (the default -t4)
+//       predicated steps per thread) when the cutoff is 3 or more (the default -t4); and the whole emit of a
+//       selection is deferred to the top of the next fill, behind the loads of that fill's records
 // Chunks of bins beyond a fill, selections, limits, saturation: exactly as in k_ag_count.
 #define AG2_TSZ  2048                   // entries of one of the workgroup's two election tables (fallback)
 #define AG2_LCAP 256                    // entries of a wave's list
