@@ -6,6 +6,9 @@ profile stage.  Every iteration compares histogram, max_inst, instance count, ta
 profiles bit for bit.
 
   python tests/fuzz_parity.py [iterations=100] [seed=1]
+  FUZZ_ONLY=<n> [FUZZ_FROM=<m>] python tests/fuzz_parity.py <iterations> <seed>
+                                     only iteration n (or m .. n) of that run: the random draws of the iterations before
+                                     are replayed without the GPU
 """
 import os
 import sys
@@ -83,17 +86,54 @@ def main():
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.default_rng(seed)
+    only = int(os.environ["FUZZ_ONLY"]) if "FUZZ_ONLY" in os.environ else None
+    first = int(os.environ.get("FUZZ_FROM", only if only is not None else 0))     # (FUZZ_FROM=<m>: iterations m .. n)
     t0 = time.time()
     for it in range(iters):
+        dry = only is not None and not (first <= it <= only)
+        if only is not None and it > only:
+            break
         k = int(rng.choice([12, 15, 16, 17, 21, 25, 31, 32, 33, 40, 47, 48, 51, 55, 63, 64]))
         cutoff = int(rng.choice([1, 1, 2, 3, 4, 6]))
         nb = int(rng.choice([1, 1, 2, 3, 7]))
         reads = make_reads(rng, k)
         bases, boff = orc.block_from_reads(reads)
-        exp = orc.fastk(k, bases, boff, cutoff=cutoff)
+        exp = None if dry else orc.fastk(k, bases, boff, cutoff=cutoff)
         chunk = int(rng.choice([0, 0, max(4096, len(bases) // 5)]))
         spill = chunk > 0 and rng.random() < 0.5
         desc = dict(it=it, k=k, cutoff=cutoff, nb=nb, nreads=len(reads), nbytes=len(bases), chunk=chunk, spill=bool(spill))
+        if dry:                                                      # the draws of this iteration, nothing else
+            nreads = len(boff) - 1
+            nthreads = int(rng.integers(1, 4))
+            cuts = sorted(int(x) for x in rng.integers(0, nreads + 1, size=nthreads - 1))
+            cuts = [0] + cuts + [nreads]
+            cur = cuts[:-1].copy()
+            while any(cur[t] < cuts[t + 1] for t in range(nthreads)):
+                t = int(rng.integers(0, nthreads))
+                if cur[t] >= cuts[t + 1]:
+                    continue
+                cur[t] = min(cuts[t + 1], cur[t] + int(rng.integers(1, 400)))
+            if it % 2 == 1:
+                lo = 0
+                while lo < nreads:
+                    lo = min(nreads, lo + int(rng.integers(1, 600)))
+            if it % 3 == 0 and all(len(r) > 0 for r in reads):
+                fastq = bool(rng.random() < 0.5)
+                width = int(rng.choice([0, 0, 7, 60, 100]))
+                tlen = 0
+                for i, r in enumerate(reads):
+                    if fastq:
+                        rng.integers(33, 75, size=len(r), dtype=np.uint8)
+                        tlen += len(b"@r%d extra+@ text\n" % i) + 2 * len(r) + 4
+                    else:
+                        tlen += len(b">r%d ACGT>acgt\n" % i)
+                        tlen += (len(r) + (len(r) + width - 1) // width) if width else len(r) + 1
+                if rng.random() < 0.3 and not fastq:
+                    tlen -= 1
+                p0 = 0
+                while p0 < tlen:
+                    p0 += int(rng.integers(1, max(2, tlen // int(rng.integers(1, 12)))))
+            continue
         try:
             with fastk_amd.Context(kmer=k, table_cutoff=cutoff, nbuckets=nb) as ctx:
                 if chunk:
