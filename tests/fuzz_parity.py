@@ -102,7 +102,8 @@ def main():
         chunk = int(rng.choice([0, 0, max(4096, len(bases) // 5)]))
         spill = chunk > 0 and rng.random() < 0.5
         desc = dict(it=it, k=k, cutoff=cutoff, nb=nb, nreads=len(reads), nbytes=len(bases), chunk=chunk, spill=bool(spill))
-        if dry:                                                      # the draws of this iteration, nothing else
+        if dry or "FUZZ_ORACLE_ONLY" in os.environ:                  # the draws of this iteration, nothing else (FUZZ_ORACLE_ONLY:
+                                                                     # the oracle has run on it -- for runs of the oracle under a sanitizer)
             nreads = len(boff) - 1
             nthreads = int(rng.integers(1, 4))
             cuts = sorted(int(x) for x in rng.integers(0, nreads + 1, size=nthreads - 1))
