@@ -131,7 +131,12 @@ int fkx_pinned_free(void *p)
   pthread_mutex_unlock(&g_pin_lock);
   if (!mine)
     return (hipHostFree(p) == hipSuccess ? FK_OK : FK_EHIP);
-  (void) hipHostUnregister(p);
+  if (hipHostUnregister(p) != hipSuccess)
+    { // still mapped for the device: a copy engine may yet write here.  The pages are left alone (leaked) rather
+      // than handed back to malloc, where the next owner would see the late write.
+      (void) hipGetLastError();
+      return (FK_EHIP);
+    }
   free(p);
   return (FK_OK);
 }
@@ -368,10 +373,19 @@ extern "C" void fk_destroy(fk_ctx *ctx)
     return;
   hipSetDevice(ctx->device);
   (void) fkx_flush_join(ctx);
+  // Nothing this context queued may still be running when its host buffers go back to the allocator: the copy and
+  // compute streams, and the part writers' streams, whose strip kernels store into the pinned staging freed below
+  // (a writer that failed half-way leaves its next piece in flight).  The context's own streams one by one (a stream
+  // the caller installed with fk_set_stream is the caller's to keep alive), then the device as a whole for the rest.
   if (ctx->copy_stream != NULL)
     hipStreamSynchronize(ctx->copy_stream);
   if (ctx->stream != NULL)
     hipStreamSynchronize(ctx->stream);
+  for (int i = 0; i < 4; i++)
+    if (ctx->wstream[i] != NULL)
+      hipStreamSynchronize(ctx->wstream[i]);
+  (void) hipDeviceSynchronize();
+  (void) hipGetLastError();
   hipFree(ctx->d_mbucket); hipFree(ctx->d_mbucket_pass); hipFree(ctx->d_scratch); hipFree(ctx->d_cursors); hipFree(ctx->d_plan);
   if (ctx->h_mbucket_pass) hipHostFree(ctx->h_mbucket_pass);
   if (ctx->h_scratch) hipHostFree(ctx->h_scratch);
@@ -650,6 +664,14 @@ extern "C" int fk_debug_get(fk_ctx *ctx, const char *key, int64_t *value)
     }
   if (strcmp(key, "table_sort_ties") == 0)
     { *value = ctx->tsort_ties;
+      return (FK_OK);
+    }
+  // where the pushed reads of a resident run lie in HBM and how many bytes they take: for harnesses that compare the
+  // device copy with what they pushed (tests/fuzz_parity.py)
+  if (strcmp(key, "reads_ptr") == 0 || strcmp(key, "reads_len") == 0)
+    { if (getenv("FASTK_AMD_TEST_KNOBS") == NULL)
+        return (FK_EINVAL);
+      *value = (key[6] == 'p') ? (int64_t) (uintptr_t) ctx->d_reads : ctx->reads_len;
       return (FK_OK);
     }
   return (FK_EINVAL);

@@ -534,7 +534,8 @@ extern "C" int fk_push_packed(fk_ctx *ctx, const uint8_t *codes, int64_t nbases,
           || (ninv + pad > 0
               && hipMemcpyAsync(st->inv + 2 * st->ninv, hinv, (size_t) (ninv + pad) * 16, hipMemcpyHostToDevice, ps) != hipSuccess))
         { fk_set_error(ctx, "fk_push_packed: host to device copy failed");
-          rc = FK_EHIP;
+          (void) hipStreamSynchronize(ps);                 // the copies queued before the failing one still read the caller's
+          rc = FK_EHIP;                                    // codes and h_pk: neither may be reused before they are through
           break;
         }
       if (hipStreamSynchronize(ps) != hipSuccess)          // the caller may reuse its buffers once we return

@@ -256,6 +256,8 @@ extern "C" int fk_write_ktab_device(fk_ctx *ctx, const fk_result *res, int nthre
       if (ctx->dbg_verbose)
         fprintf(stderr, "  .ktab part %d: %lld entries; waited %.3f s for the device, %.3f s in write()\n", t + 1, (long long) cnt,
                 t_wait, t_write);
+      if (!ok && cnt > 0)                                 // a piece may still be on its way into the staging: nobody may
+        (void) hipStreamSynchronize(st);                  // reuse or free that memory before it has landed
       for (int i = 0; i < 2; i++)
         if (ev[i]) hipEventDestroy(ev[i]);
       if (close(fd) != 0) ok = false;

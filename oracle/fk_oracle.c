@@ -1052,3 +1052,64 @@ char *orc_load_fastx(const char *path, int64_t **boffp, int64_t *nreadsp)
   *nreadsp = nr;
   return (bases);
 }
+
+
+/* ---- profile decoder (libfastk.c:1657-1780, Fetch_Profile) ---------------------------------------
+   First count in one byte (< 128) or two (top bit set, 15 bits); then per code byte x:
+   00nnnnnn a run of n more copies of the current count; 01dddddd a 6-bit signed difference;
+   1ddddddd dddddddd a 15-bit difference added modulo 2^15 (a set 0x40 bit keeps the sign bits,
+   :1743-1749). */
+int64_t orc_profile_decode_stream(const uint8_t *data, const int64_t *ends, int64_t n, uint8_t *out, int64_t cap)
+{ int64_t need = 0, prev = 0, r;
+  for (int pass = 0; pass < 2; pass++)
+    { uint8_t *o = out;
+      prev = 0;
+      for (r = 0; r < n; r++)
+        { const uint8_t *p = data + prev, *q = data + ends[r];
+          int32_t len = 0;
+          uint16_t d = 0, x;
+          uint8_t *lenp = o;
+          prev = ends[r];
+          if (pass) o += 4;
+          if (p < q)
+            { x = *p++;
+              if (x & 0x80)
+                { if (p >= q) return -1;
+                  d = (uint16_t) (((x & 0x7f) << 8) | *p++);
+                }
+              else
+                d = x;
+              if (pass) { memcpy(o, &d, 2); o += 2; }
+              len = 1;
+              while (p < q)
+                { x = *p++;
+                  if ((x & 0xc0) == 0)
+                    { if (pass)
+                        for (int i = 0; i < x; i++) { memcpy(o, &d, 2); o += 2; }
+                      len += x;
+                    }
+                  else
+                    { if (x & 0x80)
+                        { if (p >= q) return -1;
+                          if (x & 0x40) x = (uint16_t) (x << 8);
+                          else          x = (uint16_t) ((x << 8) & 0x7fff);
+                          x |= *p++;
+                          d = (uint16_t) ((d + x) & 0x7fff);
+                        }
+                      else if (x & 0x20)
+                        d = (uint16_t) (d + ((x & 0x1fu) | 0xffe0u));
+                      else
+                        d = (uint16_t) (d + (x & 0x1fu));
+                      if (pass) { memcpy(o, &d, 2); o += 2; }
+                      len += 1;
+                    }
+                }
+            }
+          if (pass) memcpy(lenp, &len, 4);
+          else need += 4 + 2 * (int64_t) len;
+        }
+      if (pass == 0 && (out == NULL || cap < need))
+        return need;
+    }
+  return need;
+}

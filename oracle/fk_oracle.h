@@ -130,6 +130,12 @@ char *orc_synth_block(uint64_t seed, uint64_t genome_len, uint32_t read_len, uin
    DATA_BLOCK-style buffer.  Returns malloc'd bases; *boff malloc'd with *nreads+1 entries. */
 char *orc_load_fastx(const char *path, int64_t **boff, int64_t *nreads);
 
+/* Decoder of one profile part (libfastk.c:1657-1780, Fetch_Profile): n profiles whose END offsets in
+   data are ends[0..n).  Writes, per read, int32 length + that many u16 counts (little-endian) -- the byte
+   stream orc.profiles_digest hashes -- and returns the bytes that stream takes; nothing is written when
+   out is NULL or cap is too small.  Returns -1 on a profile that ends inside a two-byte code. */
+int64_t orc_profile_decode_stream(const uint8_t *data, const int64_t *ends, int64_t n, uint8_t *out, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

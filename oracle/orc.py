@@ -86,6 +86,8 @@ def lib():
                                       C.c_int64, C.c_void_p]
         L.orc_load_fastx.restype = C.c_void_p
         L.orc_load_fastx.argtypes = [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+        L.orc_profile_decode_stream.restype = C.c_int64
+        L.orc_profile_decode_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
         L.free = C.CDLL(None).free
         L.free.argtypes = [C.c_void_p]
         _lib = L
@@ -698,6 +700,39 @@ def profiles_digest(count_lists):
         h.update(struct.pack("<i", len(a)))
         h.update(a.tobytes())
     return h.hexdigest()
+
+
+def profiles_digest_files(outdir, root, batch=1 << 20):
+    """profiles_digest of a whole <root>.prof (stub + hidden parts) without a Python loop per count: the parts
+    are decoded by the C restatement of Fetch_Profile, a batch of reads at a time.  Returns (reads, encoded
+    bytes, k-mer positions, sha256) -- for data sets whose decoded profiles do not fit a Python list."""
+    L = lib()
+    kmer, nparts = struct.unpack("<ii", open(os.path.join(outdir, root + ".prof"), "rb").read(8))
+    h = hashlib.sha256()
+    nreads = nbytes = npos = 0
+    for t in range(1, nparts + 1):
+        px = open(os.path.join(outdir, ".%s.pidx.%d" % (root, t)), "rb").read()
+        k2, = struct.unpack("<i", px[:4])
+        b, n = struct.unpack("<qq", px[4:20])
+        assert k2 == kmer and b == nreads, (k2, kmer, b, nreads)
+        offs = np.frombuffer(px[20:20 + 8 * n], dtype=np.int64)
+        data = np.fromfile(os.path.join(outdir, ".%s.prof.%d" % (root, t)), dtype=np.uint8)
+        assert n == 0 or offs[-1] == len(data)
+        for r0 in range(0, n, batch):
+            ends = offs[r0:r0 + batch]
+            lo = int(offs[r0 - 1]) if r0 else 0
+            rel = np.ascontiguousarray(ends - lo)
+            piece = np.ascontiguousarray(data[lo:int(ends[-1])])
+            need = L.orc_profile_decode_stream(piece.ctypes.data, rel.ctypes.data, len(rel), None, 0)
+            assert need >= 0, "a profile of part %d ends inside a two-byte code" % t
+            out = np.empty(need, dtype=np.uint8)
+            got = L.orc_profile_decode_stream(piece.ctypes.data, rel.ctypes.data, len(rel), out.ctypes.data, need)
+            assert got == need
+            h.update(out)
+            npos += (need - 4 * len(rel)) // 2
+        nreads += n
+        nbytes += len(data)
+    return nreads, nbytes, npos, h.hexdigest()
 
 
 # --------------------------------------------------------------------------- SAM / BAM test inputs

@@ -6,10 +6,18 @@ profile stage.  Every iteration compares histogram, max_inst, instance count, ta
 profiles bit for bit.
 
   python tests/fuzz_parity.py [iterations=100] [seed=1]
+  FUZZ_GUARD=0                       the reads of an iteration in ordinary memory (default: in a mapping of their own between
+                                     two inaccessible pages, read-only once filled -- a host-side writer dies with a stack
+                                     instead of flipping bytes; the array is also compared with its digest after every
+                                     iteration, which catches a writer that does not go through the page tables)
   FUZZ_ONLY=<n> [FUZZ_FROM=<m>] python tests/fuzz_parity.py <iterations> <seed>
                                      only iteration n (or m .. n) of that run: the random draws of the iterations before
                                      are replayed without the GPU
 """
+import ctypes
+import faulthandler
+import hashlib
+import mmap
 import os
 import sys
 import time
@@ -20,6 +28,51 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("FASTK_AMD_TEST_KNOBS", "1")                   # (chunk sizes and spill limits are test knobs)
 import fastk_amd                                                     # noqa: E402
 from oracle import orc                                               # noqa: E402
+
+
+_libc = ctypes.CDLL(None, use_errno=True)
+_libc.mprotect.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+_PAGE = mmap.PAGESIZE
+
+
+class Guarded:
+    """A byte array in a mapping of its own: [inaccessible page][data, read-only][inaccessible page].  Any CPU store
+    into it -- a late write of the library's host side, of the runtime's staging, of the harness -- is a SIGSEGV with a
+    stack (faulthandler); `intact()` compares with the digest taken at the fill, for writers that bypass the page tables
+    (a copy engine)."""
+
+    def __init__(self, data):
+        n = len(data)
+        self.body = (max(n, 1) + _PAGE - 1) // _PAGE * _PAGE
+        self.map = mmap.mmap(-1, self.body + 2 * _PAGE)
+        self.base = ctypes.addressof(ctypes.c_char.from_buffer(self.map))
+        whole = np.frombuffer(self.map, dtype=np.uint8)
+        self.array = whole[_PAGE:_PAGE + n]
+        self.array[:] = data
+        self.sha = hashlib.sha256(self.array).digest()
+        for off, ln, prot in ((0, _PAGE, 0), (_PAGE, self.body, 1), (_PAGE + self.body, _PAGE, 0)):
+            if _libc.mprotect(self.base + off, ln, prot) != 0:
+                raise OSError(ctypes.get_errno(), "mprotect")
+
+    def intact(self):
+        return hashlib.sha256(self.array).digest() == self.sha
+
+    def release(self):
+        _libc.mprotect(self.base, self.body + 2 * _PAGE, 3)
+        del self.array                       # (the mapping itself goes when the last view of it does)
+
+
+def device_reads_differ(ctx, bases):
+    """positions where the context's device copy of the pushed reads differs from the host array (None: not resident)"""
+    try:
+        ptr, n = ctx.debug_get("reads_ptr"), ctx.debug_get("reads_len")
+    except Exception:                                                # noqa: BLE001
+        return None
+    if not ptr or n != len(bases):
+        return None
+    dev = np.empty(n, dtype=np.uint8)
+    ctx._ck(ctx.L.fk_copy_to_host(ctx.h, dev.ctypes.data, ptr, n))
+    return np.nonzero(dev != np.asarray(bases))[0]
 
 
 def make_reads(rng, k):
@@ -82,14 +135,18 @@ def pack_reads(bases, boff):
     return ((q[:, 0] << 6) | (q[:, 1] << 4) | (q[:, 2] << 2) | q[:, 3]).astype(np.uint8), nb, rlen, inv
 
 
-def main():
-    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+def run(iters, seed, only=None, first=None, guard=True, quiet=False, max_bytes=None, budget_s=None):
+    """iters iterations of the draw sequence of `seed` (only / first: see the module text).  guard: the reads of every
+    iteration in a Guarded mapping.  max_bytes: iterations whose reads take more are drawn but not run (the bounded
+    pytest leg).  budget_s: stop after that many seconds.  Returns the number of iterations that ran on the GPU."""
     rng = np.random.default_rng(seed)
-    only = int(os.environ["FUZZ_ONLY"]) if "FUZZ_ONLY" in os.environ else None
-    first = int(os.environ.get("FUZZ_FROM", only if only is not None else 0))     # (FUZZ_FROM=<m>: iterations m .. n)
+    if first is None:
+        first = only if only is not None else 0
     t0 = time.time()
+    ran = 0
     for it in range(iters):
+        if budget_s is not None and time.time() - t0 > budget_s:
+            break
         dry = only is not None and not (first <= it <= only)
         if only is not None and it > only:
             break
@@ -98,12 +155,20 @@ def main():
         nb = int(rng.choice([1, 1, 2, 3, 7]))
         reads = make_reads(rng, k)
         bases, boff = orc.block_from_reads(reads)
+        if max_bytes is not None and len(bases) > max_bytes:
+            dry = True
+        g = None
+        if guard and not dry:
+            g = Guarded(bases)
+            bases = g.array
         exp = None if dry else orc.fastk(k, bases, boff, cutoff=cutoff)
         chunk = int(rng.choice([0, 0, max(4096, len(bases) // 5)]))
         spill = chunk > 0 and rng.random() < 0.5
         desc = dict(it=it, k=k, cutoff=cutoff, nb=nb, nreads=len(reads), nbytes=len(bases), chunk=chunk, spill=bool(spill))
         if dry or "FUZZ_ORACLE_ONLY" in os.environ:                  # the draws of this iteration, nothing else (FUZZ_ORACLE_ONLY:
                                                                      # the oracle has run on it -- for runs of the oracle under a sanitizer)
+            if g is not None:
+                g.release()
             nreads = len(boff) - 1
             nthreads = int(rng.integers(1, 4))
             cuts = sorted(int(x) for x in rng.integers(0, nreads + 1, size=nthreads - 1))
@@ -163,6 +228,11 @@ def main():
                     data, offs = ctx.make_profiles()
                     want = orc.profile_counts(k, bases, boff, exp.table)
                     raw = data.tobytes()
+                    if len(offs) != len(want) + 1:
+                        d = device_reads_differ(ctx, bases)
+                        print("profile count %d for %d reads; device copy of the reads: %s" % (len(offs) - 1, len(want),
+                              "not comparable" if d is None else "%d bytes differ from the host array%s"
+                              % (len(d), "" if len(d) == 0 else ", first at " + str(d[:16].tolist()))), flush=True)
                     assert len(offs) == len(want) + 1, "profile count"
                     for i, x in enumerate(want):
                         assert raw[offs[i]:offs[i + 1]] == orc.profile_encode(x), "profile of read %d" % i
@@ -246,14 +316,30 @@ def main():
                     assert res.ninst == exp.ninst and np.array_equal(res.hist, exp.hist), "text parser: hist"
                     assert np.array_equal(res.table, exp.table), "text parser: table"
         except Exception as e:                                      # noqa: BLE001
-            print("FAILED", desc, repr(e))
+            print("FAILED", dict(desc, seed=seed), repr(e), "; the host array of the reads is",
+                  "not guarded" if g is None else ("intact" if g.intact() else "CHANGED since it was filled"), flush=True)
             os.makedirs("gpurun_out", exist_ok=True)
-            np.save("gpurun_out/fuzz_fail_bases.npy", bases)
-            np.save("gpurun_out/fuzz_fail_boff.npy", boff)
+            np.save("gpurun_out/fuzz_fail_bases_%d_%d.npy" % (seed, it), np.array(bases))
+            np.save("gpurun_out/fuzz_fail_boff_%d_%d.npy" % (seed, it), boff)
             raise
-        if it % 10 == 9:
+        if g is not None:
+            assert g.intact(), "iteration %d of seed %d: the host array of the reads changed under the run" % (it, seed)
+            g.release()
+        ran += 1
+        if it % 10 == 9 and not quiet:
             print("iteration %d ok (%.1f s)" % (it + 1, time.time() - t0), flush=True)
-    print("all %d iterations equal to the oracle (seed %d, %.1f s)" % (iters, seed, time.time() - t0))
+    return ran
+
+
+def main():
+    faulthandler.enable(all_threads=True)
+    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    only = int(os.environ["FUZZ_ONLY"]) if "FUZZ_ONLY" in os.environ else None
+    first = int(os.environ["FUZZ_FROM"]) if "FUZZ_FROM" in os.environ else None      # (FUZZ_FROM=<m>: iterations m .. n)
+    t0 = time.time()
+    ran = run(iters, seed, only=only, first=first, guard=os.environ.get("FUZZ_GUARD", "1") != "0")
+    print("all %d iterations equal to the oracle (seed %d, %d on the GPU, %.1f s)" % (iters, seed, ran, time.time() - t0))
 
 
 if __name__ == "__main__":

@@ -115,6 +115,14 @@ LARGE_CASES = [
 HUGE_CASES = [
     dict(name="hifi50x200M_k40_t4_T8", kind="huge", k=40, cutoff=4, T=8, fmt="fasta",
          synth=dict(seed=20251001, genome_len=200000000, read_len=15000, err_ppm=2000, nreads=666666)),
+    # BASELINE configs[1] at FULL size (50x of a 100 Mbp genome in 150 bp reads: 33.3 M reads, 3.70 G k-mer
+    # instances; the reads test_full_size_properties_configs1 generates on the device)
+    dict(name="configs1_k40_t1_T4", kind="huge", k=40, cutoff=1, T=4, fmt="fasta",
+         synth=dict(seed=20251001, genome_len=100000000, read_len=150, err_ppm=1000, nreads=33333333)),
+    # BASELINE configs[4] at the stated scale of 1/1000 (100x of a 32 Mbp genome, k=51 -t1 -p: 21.3 M reads;
+    # the reads of test_configs4_scaled_slice_k51_profiles_with_spill), with the digest of the decoded profiles
+    dict(name="configs4slice_k51_t1_T4_p", kind="huge", k=51, cutoff=1, T=4, fmt="fasta", prof=True,
+         synth=dict(seed=4051, genome_len=32000000, read_len=150, err_ppm=1000, nreads=21333333)),
 ]
 
 
@@ -176,7 +184,8 @@ def main():
             orc.write_fasta(path, bases, boff, width=0 if case["kind"] == "edge" else 100)
         else:
             orc.write_fastq(path, bases, boff)
-        orc.run_ref_fastk(path, k, case["cutoff"], case["T"], d, extra=tuple(case.get("ref_extra", ())))
+        orc.run_ref_fastk(path, k, case["cutoff"], case["T"], d,
+                          extra=tuple(case.get("ref_extra", ())) + (("-p",) if case.get("prof") else ()))
         h = orc.read_hist(os.path.join(d, "x.hist"))
         t = orc.read_ktab(os.path.join(d, "x"))
         nz = np.nonzero(h["hist"])[0]
@@ -193,6 +202,9 @@ def main():
                             for i in range(max(0, t["nels"] - 8), t["nels"])]),
             file_sha256={f: sha_file(os.path.join(d, f)) for f in files},
         )
+        if case.get("prof"):          # a -p run above fixture size: the decoded profiles by the C decoder, part by part
+            nr, nb, npos, dig = orc.profiles_digest_files(d, "x")
+            exp["prof"] = dict(nreads=nr, ref_bytes=nb, kmer_positions=npos, decoded_sha256=dig)
         if case["kind"] in ("large", "huge"):
             meta = dict(case)
             meta["expected"] = exp

@@ -1,0 +1,31 @@
+"""A bounded leg of tests/fuzz_parity.py in front of the driver: fixed seeds, a few hundred iterations of the randomised
+differential run (random k, read mixes, bucket counts, chunked ingest with and without spill, packed pushes, the profile
+stage, the text parsers) against the CPU oracle, bit for bit -- with the reads of every iteration in a read-only
+mapping between two inaccessible pages, so that a stray host-side write into the caller's buffer ("what's
+weak" 1) ends the run with a stack instead of passing unseen."""
+import faulthandler
+import os
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,iters", [(20261007, 120), (5, 120), (777, 120)])
+def test_fuzz_bounded(seed, iters):
+    import fuzz_parity
+    faulthandler.enable(all_threads=True)
+    # iterations whose reads take more than 300 KB are drawn and passed over (their oracle runs take seconds)
+    ran = fuzz_parity.run(iters, seed, guard=True, quiet=True, max_bytes=300_000, budget_s=40)
+    assert ran >= 40, "only %d iterations ran in the time given" % ran
+
+
+def test_guard_catches_a_host_write():
+    """the harness itself: a store into a guarded array is a fault, not a silent change (checked in a child process)"""
+    import subprocess
+    code = ("import sys; sys.path.insert(0, %r); import numpy as np, fuzz_parity as f; "
+            "g = f.Guarded(np.arange(5000, dtype=np.uint8)); assert g.intact(); "
+            "import ctypes; ctypes.memset(g.array.ctypes.data + 100, 0, 4)") % os.path.dirname(os.path.abspath(__file__))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert p.returncode != 0 and p.returncode in (-11, 139), (p.returncode, p.stderr[-300:])

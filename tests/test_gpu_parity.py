@@ -2087,6 +2087,7 @@ def test_full_size_properties_configs1():
     instances), distinct k-mers == sum(hist) == table entries at cutoff 1, strictly increasing
     table, table counts reproduce the histogram, and the bucket-streamed run (4 buckets, other code
     path: planned split, per-bucket aggregation, union sort) gives the identical histogram and table."""
+    import json, os
     L, glen, k = 150, 100_000_000, 40
     nreads = int(50 * glen / L)
     nbytes = nreads * (L + 1)
@@ -2106,6 +2107,12 @@ def test_full_size_properties_configs1():
     a, b = results
     assert np.array_equal(a.hist, b.hist) and a.max_inst == b.max_inst
     assert np.array_equal(a.table, b.table)
+    # ... and against reference FastK itself on these very reads (tests/golden/make_golden.py --only=configs1_k40_t1_T4:
+    # 33.3 M reads through oracle/_ref/FastK -k40 -t1 -T4): histogram bins, .hist file bytes, entry count, index width
+    # and the canonical .ktab stream (count.c:1893-1910, table.c:485-498)
+    case = json.load(open(os.path.join(util.GOLDEN, "configs1_k40_t1_T4.json")))
+    assert case["synth"] == dict(seed=20251001, genome_len=glen, read_len=L, err_ppm=1000, nreads=nreads)
+    util.check_against_golden(case, a.hist, a.max_inst, a.table)
     t = a.table
     # strictly increasing keys: compare as big-endian integers, 8 + 2 bytes
     hi = t[:, :8].copy().view(">u8").ravel()
@@ -2193,7 +2200,7 @@ def test_configs4_scaled_slice_k51_profiles_with_spill(tmp_path):
     ~3/4 of the 28-byte super-mer records go through pinned host memory and come back bucket by bucket, and
     the profiles take the second pass over the input.  Checked: conservation, sum(hist) = table entries at
     -t1, and .hist / .ktab / every .prof file byte-identical to the all-resident run of the same command."""
-    import os, subprocess
+    import json, os, subprocess
     L, glen, k = 150, 32_000_000, 51
     nreads = int(100 * glen / L)
     bases, boff = orc.synth_block(4051, glen, L, 1000, 0, nreads)
@@ -2213,6 +2220,24 @@ def test_configs4_scaled_slice_k51_profiles_with_spill(tmp_path):
         if mem:
             assert "minimizer bucket" in p.stderr                     # the budget really chunked the run
     assert outs["res"] == outs["mem"] and len(outs["res"]) == 2 + 4 + 1 + 8
+    # ... and the REFERENCE's results for these very reads (tests/golden/make_golden.py --only=configs4slice_k51_t1_T4_p:
+    # oracle/_ref/FastK -k51 -t1 -T4 -p on the 21.3 M reads): .hist bytes, the canonical .ktab stream, and the digest of
+    # every read's DECODED profile (the reference's bytes depend on its super-mer cuts; merge.c:880-930)
+    gold = json.load(open(os.path.join(util.GOLDEN, "configs4slice_k51_t1_T4_p.json")))
+    assert gold["synth"] == dict(seed=4051, genome_len=glen, read_len=L, err_ppm=1000, nreads=nreads) and gold["k"] == k
+
+    def against_reference(dd, what):
+        exp = gold["expected"]
+        assert util.sha_file(dd / "x.hist") == exp["hist_sha256"], what + ": .hist is not the reference's"
+        tt = orc.read_ktab(str(dd / "x"))
+        assert (tt["nels"], tt["ibytes"]) == (exp["ktab"]["nels"], exp["ktab"]["ibytes"]), what
+        assert tt["stream_sha256"] == exp["ktab"]["stream_sha256"], what + ": the .ktab stream is not the reference's"
+        del tt
+        nr, _, npos, dig = orc.profiles_digest_files(str(dd), "x")
+        assert (nr, npos) == (exp["prof"]["nreads"], exp["prof"]["kmer_positions"]), what
+        assert dig == exp["prof"]["decoded_sha256"], what + ": the decoded profiles are not the reference's"
+
+    against_reference(tmp_path / "mem", "one GPU, -M2")
     # ... and as BASELINE states it, on several GPUs: -G2 -p -M2 on the one-GPU rig (two ranks share the device, each
     # with a 2 GB budget for its stripe).  The ranks cut their parts elsewhere, so the comparison is on contents:
     # .hist bytes, the canonical .ktab stream, and every read's profile bytes in file order.
@@ -2245,6 +2270,8 @@ def test_configs4_scaled_slice_k51_profiles_with_spill(tmp_path):
         oa, da = prof_bytes(tmp_path / "mem")
         ob, db = prof_bytes(d)
         assert len(oa) == nreads + 1 and np.array_equal(oa, ob) and np.array_equal(da, db), "the ranks' profiles differ from the one-GPU run's"
+        del oa, da, ob, db
+        against_reference(d, "-G2 -M2")
     h = orc.read_hist(str(tmp_path / "mem" / "x.hist"))
     hist = np.asarray(h["hist"], dtype=np.int64)
     cnt = np.arange(h["low"], h["low"] + len(hist))

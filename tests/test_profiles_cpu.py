@@ -65,6 +65,11 @@ def test_oracle_profiles_match_reference(name, tmp_path):
         assert len(mine) <= len(e)                      # canonical is never longer
         ncanon += (mine == e)
     assert ncanon > 0.5 * len(enc)                       # most reads are byte-identical anyway
+    # the C decoder that digests the profiles of the cases above fixture size (orc.profiles_digest_files, batches of 777
+    # reads) gives the digest the Python decoder gives, which is the golden one
+    nr, nb, npos, dig = orc.profiles_digest_files(d, "r", batch=777)
+    assert (nr, nb, npos) == (len(enc), sum(len(e) for e in enc), sum(len(x) for x in exp))
+    assert dig == orc.profiles_digest(exp) == case["expected"]["prof"]["decoded_sha256"]
 
     # the library's writer, read by the reference's Profex: same listing as for the reference's files
     blobs = [orc.profile_encode(x) for x in exp]
