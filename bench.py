@@ -242,12 +242,9 @@ def cpu_baseline(args, cfg):
                 out["hist_sha256_equals_golden"] = (h == case["expected"]["hist_sha256"])
         # the reference on the timed configuration itself was run once (tools/cpu_baseline_full.py, ~6 min of host time:
         # not something the default run repeats): its record, when committed, rides along
-        full = os.path.join(ROOT, "profiles", "r04_cpu_baseline_configs2_full.json")
-        if os.path.exists(full):
-            try:
-                out["full_size_run"] = json.load(open(full))
-            except Exception:
-                pass
+        full = reference_full_size_record()
+        if full is not None:
+            out["full_size_run"] = dict(full, measured_in_this_run=False)
         return out
     finally:
         subprocess.run(["rm", "-rf", d])
@@ -382,6 +379,47 @@ def write_synth_file(ctx_gen, path, fastq, seed, glen, L, err_ppm, nreads):
     piece.free()
 
 
+def ktab_stream_sha256(d, root):
+    """sha256 of a .ktab's canonical stream: the stub's prefix index (from byte 16) followed by the payloads of the hidden
+    parts (from byte 12 of each), in part order -- the bytes that do not depend on how many parts the table was cut into
+    (table.c:485-498; the digest the golden fixtures carry as ktab.stream_sha256).  Returns (digest, entries, parts)."""
+    import hashlib
+    import struct
+    h = hashlib.sha256()
+    with open(os.path.join(d, root + ".ktab"), "rb") as f:
+        head = f.read(16)
+        nparts = struct.unpack("<iiii", head)[1]
+        while True:
+            b = f.read(1 << 26)
+            if not b:
+                break
+            h.update(b)
+    nels = 0
+    for t in range(1, nparts + 1):
+        with open(os.path.join(d, ".%s.ktab.%d" % (root, t)), "rb") as f:
+            nels += struct.unpack("<iq", f.read(12))[1]
+            while True:
+                b = f.read(1 << 26)
+                if not b:
+                    break
+                h.update(b)
+    return h.hexdigest(), nels, nparts
+
+
+def reference_full_size_record():
+    """the newest committed record of reference FastK on configs[2] itself (tools/cpu_baseline_full.py)"""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_cpu_baseline_configs2_full.json")), reverse=True):
+        try:
+            r = json.load(open(f))
+            if "hist_file_sha256" in r:
+                r["record"] = os.path.basename(f)
+                return r
+        except Exception:
+            pass
+    return None
+
+
 def e2e_leg(args, cfg, fastk_amd, ctx_gen, L):
     """SURVEY 8(d) end to end: FASTA file (RAM disk) -> .hist + .ktab files through bin/FastK_amd."""
     glen = int(cfg["genome_mbp"] * 1e6 * args.scale * args.e2e_scale)
@@ -424,8 +462,24 @@ def e2e_leg(args, cfg, fastk_amd, ctx_gen, L):
         inst = nreads * (L - args.kmer + 1)
         out_bytes = sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d)
                         if f.startswith("out") or f.startswith(".out"))
+        # the files of the last run against reference FastK's on the same 150 G bases (a committed record of ONE reference
+        # run at full size: .hist bytes and the canonical .ktab stream; count.c:1893-1910, table.c:485-498)
+        parity = {}
+        ref = reference_full_size_record()
+        if ref is not None and ref.get("scale") == args.scale * args.e2e_scale and ref.get("kmer_instances") == inst:
+            import hashlib
+            t0 = time.perf_counter()
+            hs = hashlib.sha256(open(os.path.join(d, "out.hist"), "rb").read()).hexdigest()
+            parity["hist_equals_reference"] = (hs == ref["hist_file_sha256"])
+            if "ktab_stream_sha256" in ref:
+                dig, nels, _ = ktab_stream_sha256(d, "out")
+                parity["ktab_stream_equals_reference"] = (dig == ref["ktab_stream_sha256"] and nels == ref["table_entries"])
+                parity["ktab_stream_sha256"] = dig
+            parity["reference_record"] = ref["record"]
+            parity["digest_seconds"] = round(time.perf_counter() - t0, 1)
         return dict(value=inst / min(times), unit="k-mers/s", seconds=round(min(times), 3),
-                    scale=args.scale * args.e2e_scale, kmer_instances=inst, input_bytes=fbytes, phases=phases,
+                    seconds_median=round(sorted(times)[len(times) // 2], 3), seconds_all=[round(x, 3) for x in times],
+                    scale=args.scale * args.e2e_scale, kmer_instances=inst, input_bytes=fbytes, phases=phases, **parity,
                     output_bytes=out_bytes, seconds_back_to_back=round(back_to_back, 3), pause_seconds=args.e2e_pause,
                     command=" ".join(os.path.basename(c) if c == exe else
                                                              ("<file>" if c == path else c) for c in cmd[:-2]),
@@ -911,10 +965,12 @@ def main():
         try:
             out["value_packed_resident"] = packed_resident_leg(args, cfg, fastk_amd, torch, dev, local_rank, reads, nbytes,
                                                                per, L, ceiling, ceiling_kernel)
+        except Exception as e:                                   # (a resource failure of the leg; a WRONG result is not one)
+            out["value_packed_resident"] = dict(failed=repr(e)[-600:])
+        # parity of the two input forms is not a leg that may fail quietly: another histogram ends the run without a line
+        if "histogram_sha256" in out["value_packed_resident"]:
             assert out["value_packed_resident"]["histogram_sha256"] == out["histogram_sha256"], \
                 "the packed-resident step gives another histogram than the ASCII-resident one"
-        except Exception as e:
-            out["value_packed_resident"] = dict(failed=repr(e)[-600:])
         log(args, "packed-resident leg", out["value_packed_resident"])
     del reads
     torch.cuda.empty_cache()

@@ -38,25 +38,45 @@ __global__ __launch_bounds__(256) void k_prefix_ends(const unsigned char *__rest
 }
 
 // cnt table records -> the bytes they take in a .ktab part file (table.c:162-342): the k-mer without its first ib bytes,
-// then the count; pw = kb - ib + 2 bytes each, four output bytes a thread
+// then the count; pw = kb - ib + 2 bytes each.  `out` is pinned HOST memory: what the kernel stores crosses PCIe, so it
+// stores nothing narrower than 16 bytes (a wave = 1 KB of consecutive addresses).  A workgroup takes KS_E entries:
+// their records come into LDS with 16-byte loads from the aligned address below the first one, every thread then
+// gathers the 16 bytes of an output quad from LDS -- the entry of its first byte by one multiply (magic = ceil(2^32 /
+// pw); exact for offsets below 2^15 * 16) -- and stores it.  (Round 4's kernel stored a dword per thread after an
+// integer division: 1.02 s of kernel time for the 27 GB of configs[2], twice what the link needs.)  The last quad of a
+// launch may run up to 15 bytes past cnt * pw: the staging pieces are rounded up to 256 bytes.
+#define KS_E 2048
 __global__ __launch_bounds__(256) void k_ktab_strip(const unsigned char *__restrict__ t, int64_t cnt, int stride, int ib, int kb,
-                                                    unsigned char *__restrict__ out)
-{ const int pw = kb - ib + 2;
-  const int64_t o = ((int64_t) blockIdx.x * 256 + threadIdx.x) * 4, total = cnt * pw;
-  if (o >= total)
-    return;
-  int64_t i = o / pw;
-  int     j = (int) (o - i * pw);
-  u32 v = 0;
+                                                    u32 magic, unsigned char *__restrict__ out)
+{ extern __shared__ __attribute__((aligned(16))) unsigned char ks_lds[];      // KS_E * stride + 64 bytes
+  const int     pw  = kb - ib + 2, tid = threadIdx.x;
+  const int64_t e0  = (int64_t) blockIdx.x * KS_E;
+  const int     ne  = (cnt - e0 < KS_E) ? (int) (cnt - e0) : KS_E;
+  const unsigned char *src = t + e0 * stride;
+  const int     mis = (int) ((uintptr_t) src & 15);
+  const uint4  *g   = (const uint4 *) (src - mis);
+  const int     nby = ne * stride + mis, n16 = nby >> 4;      // (the loads begin up to 15 bytes below the first record --
+  for (int i = tid; i < n16; i += 256)                         //  never below the table: its buffer is 16-byte aligned --
+    ((uint4 *) ks_lds)[i] = g[i];                              //  and end with the last record: the tail comes byte by byte)
+  if (tid < (nby & 15))
+    ks_lds[(n16 << 4) + tid] = ((const unsigned char *) g)[(n16 << 4) + tid];
+  __syncthreads();
+  const unsigned char *l = ks_lds + mis;
+  const int nout = ne * pw, kx = kb - ib;
+  uint4 *o4 = (uint4 *) (out + e0 * pw);                    // KS_E * pw is a multiple of 16
+  for (int q = tid; q * 16 < nout; q += 256)
+    { const u32 o = (u32) q * 16u;
+      u32 i = __umulhi(o, magic);
+      int j = (int) (o - i * (u32) pw);
+      u32 w[4] = { 0u, 0u, 0u, 0u };
 #pragma unroll
-  for (int q = 0; q < 4; q++)
-    { if (o + q < total)
-        { const unsigned char c = (j < kb - ib) ? t[i * stride + ib + j] : t[i * stride + stride - 2 + (j - (kb - ib))];
-          v |= (u32) c << (8 * q);
+      for (int b = 0; b < 16; b++)
+        { const int at = (int) i * stride + ((j < kx) ? ib + j : stride - 2 + (j - kx));
+          w[b >> 2] |= (u32) l[at] << (8 * (b & 3));
+          if (++j == pw) { j = 0; i += 1; }
         }
-      if (++j == pw) { j = 0; i += 1; }
+      o4[q] = make_uint4(w[0], w[1], w[2], w[3]);
     }
-  *(u32 *) (out + o) = v;
 }
 
 #define KTAB_PIECE_BYTES (16ll << 20)       // of table records per piece of a part writer
@@ -227,9 +247,9 @@ extern "C" int fk_write_ktab_device(fk_ctx *ctx, const fk_result *res, int nthre
       unsigned char *pin[2] = { h_stage + pbytes * (2 * ln), h_stage + pbytes * (2 * ln + 1) };
       auto fetch = [&](int64_t x, int which) -> bool
         { const int64_t m = std::min(hi, x + piece) - x;
-          const int64_t words = (m * pw + 3) / 4;
-          hipLaunchKernelGGL(k_ktab_strip, dim3((unsigned) ((words + 255) / 256)), dim3(256), 0, st, table + x * ST, m, ST, ib,
-                             (int) w.kmer_bytes, pin[which]);                // stored across PCIe as it is made
+          hipLaunchKernelGGL(k_ktab_strip, dim3((unsigned) ((m + KS_E - 1) / KS_E)), dim3(256), (size_t) KS_E * ST + 64, st,
+                             table + x * ST, m, ST, ib, (int) w.kmer_bytes, (u32) ((0x100000000ull + (u64) pw - 1) / (u64) pw),
+                             pin[which]);                                    // stored across PCIe as it is made
           return (hipGetLastError() == hipSuccess && hipEventRecord(ev[which], st) == hipSuccess);
         };
       int which = 0;

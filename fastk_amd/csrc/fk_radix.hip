@@ -356,6 +356,17 @@ __global__ __launch_bounds__(RX_THREADS) void k_radix_pass(const u32 *__restrict
 // HBM bytes per pass: 2*n*R (records) + 2*n (digit stream) + ~1.4 % tables.
 #define RX_CH 16
 #define RX_SC 256
+// -DFK_ABLATION builds (WRONG output; tools/scatter_ablation.py): bits of the scatter kernels' `unstable` argument, set
+// from fk_debug_set("radix_variant", bits) -- what a pass would cost without one of its parts
+#define RX_ABL_NOHASH 0x100     // hashed passes: the next pass's digit is a byte of the record, not a hash of it
+#define RX_ABL_LINEAR 0x200     // the records leave in tile order (whole lines, no scatter): the bound of any write combining
+#define RX_ABL_NOPERM 0x400     // sorted slot p takes record p (no LDS gather)
+#define RX_ABL_NORANK 0x800     // no ranking: every record gets rank 0 of its wave's bin (no ballots, no LDS atomics)
+#ifdef FK_ABLATION
+#define RX_ABL_BITS(ctx) ((ctx)->dbg_radix_engine != 1 ? ((ctx)->dbg_radix_variant & 0xf00) : 0)
+#else
+#define RX_ABL_BITS(ctx) 0
+#endif
 
 template <int ITEMS>
 __global__ __launch_bounds__(RX_THREADS) void k_rx_tilehist(const uint8_t *__restrict__ dig, int64_t n,
@@ -544,7 +555,16 @@ __global__ __launch_bounds__(RX_THREADS) void k_rx_scatter(const u32 *__restrict
   u32 old[ITEMS];
   // unstable (first pass of a hashed grouping: nothing depends on the order inside a bin): one LDS
   // atomic per record instead of the 8-ballot match -- the kernel is bound by instruction issue
-  if (HASHED && unstable)
+#ifdef FK_ABLATION
+  if (unstable & RX_ABL_NORANK)
+    {
+#pragma unroll
+      for (int it = 0; it < ITEMS; it++)
+        info[it] = (u32) tdig[wbase + it * 64 + lane];
+    }
+  else
+#endif
+  if (HASHED && (unstable & 1))
     {
 #pragma unroll
       for (int it = 0; it < ITEMS; it++)
@@ -618,14 +638,24 @@ __global__ __launch_bounds__(RX_THREADS) void k_rx_scatter(const u32 *__restrict
   for (int it = 0; it < ITEMS; it++)
     { const int p = it * RX_THREADS + tid;
       if (FULL || p < tn)
-        { const int     sr = perm[p];
+        {
+#ifdef FK_ABLATION
+          const int     sr = (unstable & RX_ABL_NOPERM) ? p : perm[p];
+          const u32     d  = tdig[sr];
+          const int64_t o  = (unstable & RX_ABL_LINEAR) ? tstart + p : goff[d] + p;
+#else
+          const int     sr = perm[p];
           const u32     d  = tdig[sr];
           const int64_t o  = goff[d] + p;
+#endif
           rx_rec<RW> r = *(const rx_rec<RW> *) (recs + sr * RW);
           *(rx_rec<RW> *) (dst + o * RW) = r;
           if (next_byte >= 0)
-            { const u32 nd = HASHED ? rx_hash_digit<RW>(r.w, next_byte, hbytes)
-                                    : (u32) lbytes[sr * RW * 4 + next_byte];
+            { u32 nd = HASHED ? rx_hash_digit<RW>(r.w, next_byte, hbytes)
+                              : (u32) lbytes[sr * RW * 4 + next_byte];
+#ifdef FK_ABLATION
+              if (HASHED && (unstable & RX_ABL_NOHASH)) nd = r.w[0] >> 24;
+#endif
               nextdig[o] = (uint8_t) nd;
             }
         }
@@ -753,7 +783,16 @@ __global__ __launch_bounds__(RXW_THREADS) void k_rx_scatter_w(const u32 *__restr
       const int wbase = wave * 64 * ITEMS;
       u32 info[ITEMS];
       u32 old[ITEMS];
-      if (HASHED && unstable)
+#ifdef FK_ABLATION
+      if (unstable & RX_ABL_NORANK)
+        {
+#pragma unroll
+          for (int it = 0; it < ITEMS; it++)
+            info[it] = (u32) tdig[wbase + it * 64 + lane];
+        }
+      else
+#endif
+      if (HASHED && (unstable & 1))
         {
 #pragma unroll
           for (int it = 0; it < ITEMS; it++)
@@ -840,14 +879,24 @@ __global__ __launch_bounds__(RXW_THREADS) void k_rx_scatter_w(const u32 *__restr
       for (int it = 0; it < ITEMS; it++)
         { const int p = it * RXW_THREADS + tid;
           if (p < tn)
-            { const int     sr = perm[p];
+            {
+#ifdef FK_ABLATION
+              const int     sr = (unstable & RX_ABL_NOPERM) ? p : perm[p];
+              const u32     d  = tdig[sr];
+              const int64_t o  = (unstable & RX_ABL_LINEAR) ? tstart + p : goff[d] + p;
+#else
+              const int     sr = perm[p];
               const u32     d  = tdig[sr];
               const int64_t o  = goff[d] + p;
+#endif
               rx_rec<RW> r = *(const rx_rec<RW> *) (recs + sr * RW);
               *(rx_rec<RW> *) (dst + o * RW) = r;
               if (next_byte >= 0)
-                { const u32 nd = HASHED ? rx_hash_digit<RW>(r.w, next_byte, hbytes)
-                                        : (u32) lbytes[sr * RW * 4 + next_byte];
+                { u32 nd = HASHED ? rx_hash_digit<RW>(r.w, next_byte, hbytes)
+                                  : (u32) lbytes[sr * RW * 4 + next_byte];
+#ifdef FK_ABLATION
+                  if (HASHED && (unstable & RX_ABL_NOHASH)) nd = r.w[0] >> 24;
+#endif
                   nextdig[o] = (uint8_t) nd;
                 }
             }
@@ -1145,13 +1194,13 @@ static int lsd_sort_stream_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, c
                            dim3(RX_THREADS), lds_bytes, s,
                            (const u32 *) src, trg, n, run[i], nextb, (const uint16_t *) tilepfx,
                            (const u32 *) chunkpfx, (const u64 *) superpfx, (const uint8_t *) dcur, dnext, ntiles,
-                           hbytes, (HASHED && i == 0 && ctx->dbg_radix_engine != 4) ? 1 : 0);
+                           hbytes, ((HASHED && i == 0 && ctx->dbg_radix_engine != 4) ? 1 : 0) | RX_ABL_BITS(ctx));
       else
         hipLaunchKernelGGL((k_rx_scatter_w<RW, ITEMS, HASHED>), dim3(sgrid),
                            dim3(RXW_THREADS), lds_bytes, s,
                            (const u32 *) src, trg, n, nextb, (const uint16_t *) tilepfx,
                            (const u32 *) chunkpfx, (const u64 *) superpfx, (const uint8_t *) dcur, dnext, ntiles,
-                           hbytes, (HASHED && i == 0 && ctx->dbg_radix_engine != 4) ? 1 : 0);
+                           hbytes, ((HASHED && i == 0 && ctx->dbg_radix_engine != 4) ? 1 : 0) | RX_ABL_BITS(ctx));
       FK_HIP(ctx, hipEventRecord(ctx->pass_ev[2 * i + 1], s));
       FK_LAUNCH_CHECK(ctx);
       u32 *t = src; src = trg; trg = t;

@@ -134,6 +134,7 @@ extern "C" void fk_shard_destroy(fk_shard *sh)
 { if (sh == NULL) return;
   hipSetDevice(sh->ctx->device);
   if (sh->xs) hipStreamSynchronize(sh->xs);
+  if (sh->ctx->stream) hipStreamSynchronize(sh->ctx->stream);      // (the gather's D2H into g_host runs on the context's stream)
   if (sh->comm) g_rccl.CommDestroy(sh->comm);
   for (int i = 0; i < 2; i++)
     { if (sh->xev[i]) hipEventDestroy(sh->xev[i]);
@@ -714,7 +715,17 @@ extern "C" int fk_shard_profiles(fk_shard *sh, const void *d_bases, int64_t nbyt
   std::vector<int64_t> all((size_t) W * nb);
   if ((rc = allgather_i64(sh, bc, nb, all.data())) != FK_OK) return (rc);
 
+  // A step that can fail on ONE rank (a stream synchronisation, a look-up, the scatter) never returns on its own: its
+  // code is carried into the next agreement, so that every rank leaves the call together -- a rank that returned between
+  // two collectives left its peers in the next one for good.
   bool first = true;
+  int  carry = FK_OK;
+  auto sync = [&](hipStream_t st)
+    { if (hipStreamSynchronize(st) != hipSuccess && carry == FK_OK)
+        { fk_set_error(ctx, "fk_shard_profiles: hipStreamSynchronize failed: %s", hipGetErrorString(hipGetLastError()));
+          carry = FK_EHIP;
+        }
+    };
   for (int r = 0; r < R; r++)
     { // ---- records of the round's buckets to their owners
       char   *sp[256], *rp[256];
@@ -724,7 +735,11 @@ extern "C" int fk_shard_profiles(fk_shard *sh, const void *d_bases, int64_t nbyt
         { seg[p + 1] = seg[p] + all[(size_t) p * nb + r * W + me];
           nin = seg[p + 1];
         }
-      int lrc = reserve_inbox(sh, 0, std::max<int64_t>(nin, 1) * stride);
+      int lrc = (carry != FK_OK) ? carry : reserve_inbox(sh, 0, std::max<int64_t>(nin, 1) * stride);
+      if (lrc == FK_OK)
+        { sync(ctx->stream);
+          lrc = carry;
+        }
       if ((rc = agree(sh, lrc)) != FK_OK) return (rc);
       for (int p = 0; p < W; p++)
         { const int b = r * W + p;
@@ -733,13 +748,12 @@ extern "C" int fk_shard_profiles(fk_shard *sh, const void *d_bases, int64_t nbyt
           rp[p] = (char *) sh->inbox[0] + seg[p] * stride;
           rb[p] = (seg[p + 1] - seg[p]) * stride;
         }
-      FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-      if ((rc = exchange(sh, sp, sb, rp, rb)) != FK_OK) return (rc);
-      FK_HIP(ctx, hipStreamSynchronize(sh->xs));
+      if ((rc = exchange(sh, sp, sb, rp, rb)) != FK_OK) return (rc);       // (a collective: it fails on every rank or on none)
+      sync(sh->xs);
 
       // ---- the owner looks them up, source by source (the counts of a source stay together)
       std::vector<int64_t> nis(W, 0), allni((size_t) W * W);
-      lrc = FK_OK;
+      lrc = carry;
       for (int p = 0; p < W && lrc == FK_OK; p++)
         lrc = fk_profile_lookup_supermers(ctx, (char *) sh->inbox[0] + seg[p] * stride, seg[p + 1] - seg[p], NULL, 0, &nis[p]);
       int64_t ctot = 0, coff[257];
@@ -760,29 +774,31 @@ extern "C" int fk_shard_profiles(fk_shard *sh, const void *d_bases, int64_t nbyt
       back[0] = 0;
       for (int o = 0; o < W; o++) back[o + 1] = back[o] + allni[(size_t) o * W + me];
       uint16_t *cin = (uint16_t *) pf_reserve(sh, 3, std::max<int64_t>(back[W], 1) * 2);
-      if ((rc = agree(sh, cin == NULL ? FK_ENOMEM : FK_OK)) != FK_OK) return (rc);
+      lrc = (cin == NULL) ? FK_ENOMEM : FK_OK;
+      if (lrc == FK_OK)
+        { sync(ctx->stream);
+          lrc = carry;
+        }
+      if ((rc = agree(sh, lrc)) != FK_OK) return (rc);
       for (int p = 0; p < W; p++)
         { sp[p] = (char *) (cout + coff[p]);
           sb[p] = nis[p] * 2;
           rp[p] = (char *) (cin + back[p]);
           rb[p] = (back[p + 1] - back[p]) * 2;
         }
-      FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
       if ((rc = exchange(sh, sp, sb, rp, rb)) != FK_OK) return (rc);
-      FK_HIP(ctx, hipStreamSynchronize(sh->xs));
-      for (int o = 0; o < W && nbytes > 0; o++)
+      sync(sh->xs);
+      for (int o = 0; o < W && nbytes > 0 && carry == FK_OK; o++)
         { const int b = r * W + o;
           if (bc[b] == 0 && !first)
             continue;
-          if ((rc = fk_profile_scatter(ctx, outbox + off[b] * stride, pos + off[b], bc[b], cin + back[o], nbytes, first ? 1 : 0))
-              != FK_OK)
-            return (rc);                        // (every rank is past the round's collectives: no peer waits for this one)
-          first = false;
+          carry = fk_profile_scatter(ctx, outbox + off[b] * stride, pos + off[b], bc[b], cin + back[o], nbytes, first ? 1 : 0);
+          first = false;                          // (a failure rides into the next round's agreement, or the one below)
         }
     }
-  if (nbytes == 0)
-    return (FK_OK);
-  return fk_profile_encode(ctx, d_bases, nbytes, out);
+  if ((rc = agree(sh, carry)) != FK_OK) return (rc);
+  rc = (nbytes == 0) ? FK_OK : fk_profile_encode(ctx, d_bases, nbytes, out);
+  return (agree(sh, rc));                         // (the encoder is the last thing that can fail on one rank alone)
 }
 
 /* The .prof files of a sharded run: every rank holds the profiles of a contiguous range of the data set's reads (in file

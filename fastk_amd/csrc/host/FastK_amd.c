@@ -174,11 +174,30 @@ static void *release_thread(void *arg)
   return (NULL);
 }
 
+/* a range of the data set's reads only (the profile pass of a -G rank): is the read being scanned outside it? */
+static inline int read_dropped(const Feeder *f)
+{ return (f->rd_hi > 0 && (f->rd_seen < f->rd_lo || f->rd_seen >= f->rd_hi)); }
+
+/* ... and has the scan passed the range's last read?  (the scanners stop there: the rest would be parsed and dropped) */
+static inline int range_done(const Feeder *f)
+{ return (f->rd_hi > 0 && f->rd_seen >= f->rd_hi); }
+
 static inline void add_base(Feeder *f, int c)
-{ if (COMPRESS)                           /* -c: homopolymer compression, io.c:284-294,558 */
+{ if (read_dropped(f))                    /* not this rank's read: its bases are not kept at all -- a long one would */
+    return;                               /*  otherwise fill the block and trip the "read is longer than" exit below */
+  if (COMPRESS)                           /* -c: homopolymer compression, io.c:284-294,558 */
     { if (c == f->lastc)
         return;
       f->lastc = c;
+    }
+  if (f->olen >= f->cap_bytes-2 && f->to_profiles && f->nreads > 0)
+    { /* profile pass: the complete reads of the block go first, the read being scanned moves to the front of the
+         empty block (a read of more than a MB that arrives on a nearly full block is not "longer than a block") */
+      const int64_t start = f->boff[f->nreads], part = f->olen-start;
+      f->olen = start;
+      flush_block(f,0);
+      memmove(f->bases,f->bases+start,(size_t) part);
+      f->olen = part;
     }
   if (f->olen >= f->cap_bytes-2)
     { /* the read is longer than a block: close it here, continue with a K-1 overlap */
@@ -202,12 +221,9 @@ static inline void add_base(Feeder *f, int c)
 static inline void end_read(Feeder *f)
 { f->lastc = 0;
   if (f->rd_hi > 0)                       /* a range of the data set's reads only: the others are parsed and dropped */
-    { const int64_t idx = f->rd_seen++;
+    { const int64_t idx = f->rd_seen++;   /* (add_base kept none of their bases) */
       if (idx < f->rd_lo || idx >= f->rd_hi)
-        { f->totbps -= f->olen - f->boff[f->nreads];
-          f->olen = f->boff[f->nreads];
-          return;
-        }
+        return;
     }
   f->bases[f->olen++] = 0;
   f->nreads += 1;
@@ -923,7 +939,7 @@ static void scan_file(Feeder *f, const char *path, int fastq)
       exit (1);
     }
   gzbuffer(in,1 << 20);
-  while ((n = gzread(in,buf,sizeof(buf))) > 0)
+  while (!range_done(f) && (n = gzread(in,buf,sizeof(buf))) > 0)
     for (i = 0; i < n; i++)
       { int c = buf[i];
         switch (state)
@@ -953,6 +969,7 @@ static void scan_file(Feeder *f, const char *path, int fastq)
    through these two calls. */
 void feeder_base(Feeder *f, int c)   { add_base(f,c); }
 void feeder_end_read(Feeder *f)      { end_read(f); }
+int  feeder_done(const Feeder *f)    { return (range_done(f)); }
 const char *feeder_prog_name(void)   { return (Prog_Name); }
 
 /* -G<n>: the parent never touches a GPU.  It starts n copies of this program, one per GPU, each told its rank
@@ -1394,7 +1411,7 @@ int main(int argc, char *argv[])
             { fprintf(stderr,"%s: Out of memory\n",Prog_Name); exit (1); }
           pf.boff[0] = 0;
           if (pf.rd_hi > pf.rd_lo)
-            for (i = 1; i <= nfiles; i++)
+            for (i = 1; i <= nfiles && !range_done(&pf); i++)
               { if (ftype == 2) scan_sam(&pf,argv[i]);
                 else if (ftype == 3) scan_bam(&pf,argv[i]);
                 else scan_file(&pf,argv[i],ftype);

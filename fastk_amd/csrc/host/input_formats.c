@@ -47,6 +47,8 @@ void scan_sam(Feeder *f, const char *path)
             break;
           len += strlen(line+len);
         }
+      if (feeder_done(f))
+        break;
       if (line[0] == '@' || line[0] == '\n' || line[0] == '\0')
         continue;
       p = strchr(line,'\t');
@@ -117,7 +119,7 @@ void scan_bam(Feeder *f, const char *path)
       if (l + 4 > dmax) data = realloc(data,dmax = (size_t) l + 1024);
       bam_need(in,data,(int) l + 4,path);                     /* name, l_ref */
     }
-  while (bam_need(in,x,36,path))
+  while (!feeder_done(f) && bam_need(in,x,36,path))
     { int32_t  ldata  = (int32_t) le32(x) - 32;
       int      lname  = x[12];
       int      lcigar = x[16] | (x[17] << 8);

@@ -7,6 +7,7 @@ typedef struct Feeder Feeder;            /* the block feeder of FastK_amd.c */
 
 void        feeder_base(Feeder *f, int c);      /* one base of the current read (-c compression, block cuts apply) */
 void        feeder_end_read(Feeder *f);
+int         feeder_done(const Feeder *f);       /* the read range this feeder keeps lies behind the scan: stop reading */
 const char *feeder_prog_name(void);
 
 void scan_sam(Feeder *f, const char *path);     /* io.c:1424-1495 */

@@ -56,6 +56,12 @@ def test_files_byte_identical_to_reference(k, T, cutoff, fmt, tmp_path):
     orc.write_outputs(res, cutoff, T, od, "x")
     for f in ["x.hist", "x.ktab"] + [".x.ktab.%d" % (t + 1) for t in range(T)]:
         assert open(os.path.join(d, f), "rb").read() == open(os.path.join(od, f), "rb").read(), f
+    # the streamed digest bench.py and tools/cpu_baseline_full.py take of tables too large to load (the reference's
+    # 27 GB of parts at configs[2]) is the canonical-stream digest of the golden fixtures
+    import bench
+    dig, nels, nparts = bench.ktab_stream_sha256(d, "x")
+    t = orc.read_ktab(os.path.join(d, "x"))
+    assert (dig, nels, nparts) == (t["stream_sha256"], t["nels"], T)
     # the reference's own checker accepts the oracle's table
     import subprocess
     out = subprocess.run([os.path.join(orc.REF_DIR, "Tabex"), "-C", os.path.join(od, "x")],

@@ -6,7 +6,7 @@ histogram = instances) and records its sha256 -- the same bytes bench.py's hist_
 GPU path and the reference can be compared at the full size.  Needs ~400 GB of RAM (the file 150 GB, the reference's
 bit-stuffed super-mer files and table parts ~100 GB, its sort memory 12 GB).
 
-  python tools/cpu_baseline_full.py [--threads 32] [--scale 1.0] > profiles/r04_cpu_baseline_configs2_full.json
+  python tools/cpu_baseline_full.py [--threads 32] [--scale 1.0] > profiles/r05_cpu_baseline_configs2_full.json
 """
 import argparse
 import hashlib
@@ -70,7 +70,12 @@ def main():
             with open(os.path.join(d, f), "rb") as fh:
                 fh.seek(4)
                 nels += int(np.frombuffer(fh.read(8), dtype=np.int64)[0])
+        t0 = time.perf_counter()
+        stream, nels2, nparts = bench.ktab_stream_sha256(d, "reads")
+        t_dig = time.perf_counter() - t0
+        assert nels2 == nels and nparts == len(parts)
         print(json.dumps(dict(
+            ktab_stream_sha256=stream, ktab_parts=nparts, stream_digest_seconds=round(t_dig, 1),
             value=inst / dt, unit="k-mers/s", kind="reference", cores=args.threads, host_threads=os.cpu_count(),
             seconds=round(dt, 1), kmer_instances=inst, instances_in_histogram=conserved,
             conserved=(conserved == inst), hist_len=len(raw), hist_file_sha256=hashlib.sha256(raw).hexdigest(),
