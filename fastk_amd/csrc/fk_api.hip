@@ -591,6 +591,11 @@ extern "C" int fk_debug_set(fk_ctx *ctx, const char *key, int64_t value)
     { ctx->dbg_radix_engine = (int) value;
       return (FK_OK);
     }
+  if (strcmp(key, "slab_bytes") == 0)       // size of the chunk store's slabs (fk_ingest.hip)
+    { if (value < 0) return (FK_EINVAL);
+      ctx->dbg_slab_bytes = value;
+      return (FK_OK);
+    }
   if (strcmp(key, "smer_stage") == 0)       // 1: four grouping passes + run detection instead of LDS de-duplication
     { ctx->dbg_smer_stage = (int) value;
       return (FK_OK);

@@ -223,6 +223,9 @@ struct fk_ctx
   int        dbg_aggr_gshift;     // > 0: merge 2^(this - 1) bins per table fill instead of the automatic choice
   int        dbg_aggr_engine;     // 1: k_ag_count (counting sort in LDS, round 3) instead of k_ag_count2
   int        dbg_aggr_limit;      // > 0: pretend the LDS table of fk_aggr.hip takes only this many k-mers
+  int64_t    dbg_slab_bytes;      // > 0: size of a slab of the chunk store instead of FK_SLAB_BYTES (8 GiB, which the driver
+                                  //      clears on allocation: a harness that makes thousands of chunked contexts on
+                                  //      kilobytes of reads, or dozens side by side on one GPU, asks for small ones)
   int64_t    aggr_extra_rounds;   // bins x rounds that had to be split in the last aggregation
   int        num_cus;
   int        aggr_sat;            // > 0: count that makes a k-mer's instances go to max_inst (merge: 0x8000)

@@ -84,11 +84,9 @@ __global__ __launch_bounds__(EX_THREADS) void k_ex_expand(const u32 *__restrict_
                                                           const u64 *__restrict__ tile_koff,
                                                           u32 *__restrict__ out,
                                                           u64 *__restrict__ overflow, int64_t ntiles,
-                                                          uint8_t *__restrict__ dig,
-                                                          u64 *__restrict__ dhist, int kbytes)
+                                                          uint8_t *__restrict__ dig, int kbytes)
 { constexpr int RS = RW + (DD ? 1 : 0);             // dwords per input record
   __shared__ __attribute__((aligned(16))) u32 recs[(EX_TILE + 1) * RS];   // big-endian value words (+1 guard)
-  __shared__ u32 lh[512];                // dig != NULL: histograms of hash digits 0 and 1 of the k-mers
   __shared__ uint16_t hoff[EX_TILE + 2]; // first k-mer of head h inside the tile (a tile holds < 2^16 k-mers: 1024 x (k - 6))
   __shared__ uint16_t hrec[EX_TILE];     // record index of head h
   __shared__ uint16_t hct[EX_TILE];      // its clipped multiplicity
@@ -103,11 +101,7 @@ __global__ __launch_bounds__(EX_THREADS) void k_ex_expand(const u32 *__restrict_
   constexpr bool STAGE = (OW <= 3);
   __shared__ u32 sout[STAGE ? EX_THREADS / 64 : 1][STAGE ? 64 * EX_G * OW : 1];
 
-  if (dig != NULL)
-    { lh[threadIdx.x] = 0;
-      lh[256 + threadIdx.x] = 0;
-    }
-  // persistent workgroups: the digit histograms are flushed once per workgroup, not once per tile
+  // persistent workgroups
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
   {
   __syncthreads();
@@ -263,12 +257,11 @@ __global__ __launch_bounds__(EX_THREADS) void k_ex_expand(const u32 *__restrict_
           for (int q = 0; q < OW; q++)
             x.w[q] = (q < KN) ? __builtin_bswap32(use_f ? f[q < KN ? q : 0] : r[q < KN ? q : 0]) : 0u;
           if (dig != NULL)
-            { // the k-mer stage groups these records by a hash of their key bytes next: hand it the
-              // first digit stream and the histograms of its two digits (saves a pass over W)
+            { // the k-mer stage groups these records by a hash of their key bytes next: hand it the first
+              // digit stream (saves a pass over W).  No histograms beside it: k_rx_superscan sums the digit totals
+              // from the tile histograms (round 4) -- the two LDS atomics per k-mer that kept them here were dead work
               u32 ha, hb;
               fk_rec_hash<OW>(x.w, kbytes, ha, hb);
-              atomicAdd(&lh[hb & 0xffu], 1u);
-              atomicAdd(&lh[256 + ((hb >> 8) & 0xffu)], 1u);
               dgs |= (u64) (hb & 0xffu) << (8 * g);
             }
           x.w[OW - 1] |= ct << 16;                     // uint16 weight in the record's last two bytes
@@ -324,11 +317,6 @@ __global__ __launch_bounds__(EX_THREADS) void k_ex_expand(const u32 *__restrict_
         }
     }
   }
-  if (dig != NULL)
-    { __syncthreads();
-      if (lh[threadIdx.x])       atomicAdd(&dhist[threadIdx.x], (u64) lh[threadIdx.x]);
-      if (lh[256 + threadIdx.x]) atomicAdd(&dhist[256 + threadIdx.x], (u64) lh[256 + threadIdx.x]);
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -399,20 +387,19 @@ static int expand_t(fk_ctx *ctx, const void *d_smers, int64_t n, void *d_out, in
         hipLaunchKernelGGL((k_ex_expand<RW, KN, OW, true>), dim3((unsigned) std::min<int64_t>(ntiles, egrid)), \
                            dim3(EX_THREADS), 0, s,                                                      \
                            (const u32 *) d_smers, n, K, len_byte, (const u64 *) d_koff, (u32 *) d_out, \
-                           d_tot + 2, ntiles, d_dig, ctx->d_digit_hist, ctx->wid.kmer_bytes);          \
+                           d_tot + 2, ntiles, d_dig, ctx->wid.kmer_bytes);                             \
       else                                                                                             \
         hipLaunchKernelGGL((k_ex_expand<RW, KN, OW, false>), dim3((unsigned) std::min<int64_t>(ntiles, egrid)), \
                            dim3(EX_THREADS), 0, s,                                                      \
                            (const u32 *) d_smers, n, K, len_byte, (const u64 *) d_koff, (u32 *) d_out, \
-                           d_tot + 2, ntiles, d_dig, ctx->d_digit_hist, ctx->wid.kmer_bytes);          \
+                           d_tot + 2, ntiles, d_dig, ctx->wid.kmer_bytes);                             \
     } while (0)
-      // hash_stream: also emit what the hashed grouping of the k-mers needs (digit stream + histograms)
+      // hash_stream: also emit what the hashed grouping of the k-mers needs (the stream of hash digit 0)
       uint8_t *d_dig = NULL;
       const int64_t egrid = 8ll * (ctx->num_cus > 0 ? ctx->num_cus : 256);
       if (hash_stream)
         { d_dig = (uint8_t *) fk_slot(ctx, FK_SLOT_DIG_A, *nweighted + 64);
           if (d_dig == NULL) { rc = FK_ENOMEM; break; }
-          if (hipMemsetAsync(ctx->d_digit_hist, 0, 32 * 256 * sizeof(u64), s) != hipSuccess) { rc = FK_EHIP; break; }
         }
       if (ow != kn && ow != kn + 1)
         { fk_set_error(ctx, "k = %d: %d k-mer words do not fit records of %d words", K, kn, ow);

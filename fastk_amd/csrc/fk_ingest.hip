@@ -112,7 +112,7 @@ void *fkx_slab_alloc(fk_ctx *ctx, int64_t bytes)
   int64_t held = 0;
   for (int i = 0; i < ctx->nslabs; i++)
     held += ctx->slabs[i].cap;
-  int64_t cap = std::max<int64_t>(FK_SLAB_BYTES, bytes);
+  int64_t cap = std::max<int64_t>(ctx->dbg_slab_bytes > 0 ? ctx->dbg_slab_bytes : FK_SLAB_BYTES, bytes);
   if (ctx->spill_limit > 0 && held + cap > ctx->spill_limit)
     cap = std::max<int64_t>(ctx->spill_limit - held, 0);        // the last slab may be smaller
   if (cap < bytes)

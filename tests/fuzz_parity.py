@@ -204,6 +204,7 @@ def run(iters, seed, only=None, first=None, guard=True, quiet=False, max_bytes=N
             with fastk_amd.Context(kmer=k, table_cutoff=cutoff, nbuckets=nb) as ctx:
                 if chunk:
                     ctx.debug_set("chunk_bytes", chunk)
+                    ctx.debug_set("slab_bytes", 32 << 20)             # (not the 8 GiB a real run's store begins with)
                     if spill:
                         ctx.debug_set("spill_limit", max(4096, len(bases) // 20))
                 nreads = len(boff) - 1
@@ -241,6 +242,7 @@ def run(iters, seed, only=None, first=None, guard=True, quiet=False, max_bytes=N
                 with fastk_amd.Context(kmer=k, table_cutoff=cutoff, nbuckets=nb) as ctx:
                     if chunk:
                         ctx.debug_set("chunk_bytes", chunk)
+                        ctx.debug_set("slab_bytes", 32 << 20)
                     nreads = len(boff) - 1
                     lo = 0
                     while lo < nreads:
