@@ -29,7 +29,7 @@ EXPORTS = [
     "fk_write_ktab_range", "fk_write_ktab_stub", "fk_split_supermers_emit_pos", "fk_profile_lookup_supermers",
     "fk_profile_scatter", "fk_profile_encode", "fk_reset", "fk_shard_unique_id", "fk_shard_create",
     "fk_release_device", "fk_set_sort_memory", "fk_finish_device", "fk_write_ktab_device", "fk_push_packed", "fk_pack_fixed_reads", "fk_copy_rate", "fk_shard_count", "fk_shard_gather", "fk_shard_write", "fk_shard_destroy", "fk_shard_count_device", "fk_shard_local_result",
-    "fk_count_device_packed", "fk_shard_get_stats", "fk_shard_profiles", "fk_shard_write_prof", "fk_write_prof_range", "fk_shard_sum_i64",
+    "fk_count_device_packed", "fk_shard_get_stats", "fk_shard_set_write_cutoff", "fk_shard_profiles", "fk_shard_write_prof", "fk_write_prof_range", "fk_shard_sum_i64",
 ]
 
 
@@ -72,7 +72,8 @@ class CProfiles(C.Structure):
 class ShardStats(C.Structure):
     _fields_ = [("comm_ranks", C.c_int), ("rounds", C.c_int), ("sent_bytes", C.c_int64), ("recv_bytes", C.c_int64),
                 ("kept_bytes", C.c_int64), ("exchange_ms", C.c_double), ("gather_sent_bytes", C.c_int64),
-                ("gather_exchange_ms", C.c_double), ("gather_sort_ms", C.c_double), ("gather_d2h_ms", C.c_double)]
+                ("gather_exchange_ms", C.c_double), ("gather_sort_ms", C.c_double), ("gather_d2h_ms", C.c_double),
+                ("table_entries_written", C.c_int64)]
 
 
 class SortStats(C.Structure):
@@ -130,6 +131,7 @@ def load_library():
     L.fk_shard_write.argtypes = [vp, C.POINTER(CResult), ci, C.c_char_p, C.c_char_p]
     L.fk_shard_gather.argtypes = [vp, C.POINTER(CResult), ci, C.POINTER(vp), C.POINTER(i64)]
     L.fk_shard_get_stats.argtypes = [vp, C.POINTER(ShardStats)]
+    L.fk_shard_set_write_cutoff.argtypes = [vp, ci]
     L.fk_shard_destroy.argtypes = [vp]
     L.fk_shard_destroy.restype = None
     L.fk_count_device_reads.argtypes = [vp, vp, i64, ci, C.POINTER(CResult)]

@@ -93,6 +93,8 @@ struct fk_shard
   int64_t     g_n;                // entries gathered (-1: none)
   int         g_nparts, g_ib;
   int         g_split[257];
+  int         write_cutoff;       // > table_cutoff of the context: entries below it do not leave this rank (fk_shard_set_write_cutoff)
+  int64_t     g_total;            // entries of the whole table that C3 moved (all ranks; = res->ntable without a write cutoff)
   // fk_shard_profiles: records + positions of the piece, counts made for the others, counts that came back
   void       *pf_buf[4];
   int64_t     pf_cap[4];
@@ -104,6 +106,7 @@ struct fk_shard
 // all ranks learn whether any of them failed: every rank passes its own rc and gets the first failure (its own,
 // or FK_EHIP for a peer's) -- so that a rank that ran out of memory does not leave the others in a collective
 static int allreduce_i64(fk_shard *sh, int64_t *vals, int n);
+static void *pf_reserve(fk_shard *sh, int i, int64_t bytes);
 static int agree(fk_shard *sh, int rc)
 { int64_t bad = (rc != FK_OK) ? 1 : 0;
   const int rc2 = allreduce_i64(sh, &bad, 1);
@@ -520,6 +523,82 @@ static int shard_count(fk_shard *sh, const void *d_reads, int64_t reads_len, fk_
   return (FK_OK);
 }
 
+
+extern "C" int fk_shard_set_write_cutoff(fk_shard *sh, int cutoff)
+{ if (sh == NULL || cutoff < 0 || cutoff > 0x7fff) return (FK_EINVAL);
+  sh->write_cutoff = cutoff;
+  return (FK_OK);
+}
+
+// ---- the write cutoff: the entries of a sorted device table whose count reaches `cutoff`, in order --------------------
+// (records of `stw` dwords, the count in the upper half of the last one).  Three small kernels: survivors per tile of
+// 256, their exclusive scan (k_exscan_tiles), the compaction; then the first-byte bounds of what is left.
+__global__ __launch_bounds__(256) void k_shf_count(const u32 *__restrict__ t, int64_t n, int stw, u32 cutoff, u32 *__restrict__ cnt)
+{ const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  const bool keep = (i < n) && ((t[i * stw + stw - 1] >> 16) >= cutoff);
+  const u32 c = (u32) __syncthreads_count(keep ? 1 : 0);
+  if (threadIdx.x == 0) cnt[blockIdx.x] = c;
+}
+
+__global__ __launch_bounds__(256) void k_shf_compact(const u32 *__restrict__ t, int64_t n, int stw, u32 cutoff,
+                                                      const u64 *__restrict__ off, u32 *__restrict__ out)
+{ __shared__ u32 tmp[8];
+  const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  const bool keep = (i < n) && ((t[i * stw + stw - 1] >> 16) >= cutoff);
+  u32 tot;
+  const u32 ex = fk_block_exscan_256<u32>(keep ? 1u : 0u, tmp, &tot);
+  if (keep)
+    { const u64 o = off[blockIdx.x] + ex;
+      for (int w = 0; w < stw; w++)
+        out[o * stw + w] = t[i * stw + w];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_shf_bounds(const unsigned char *__restrict__ t, int64_t n, int stride, int64_t *__restrict__ bounds)
+{ const int b = threadIdx.x;                                  // bounds[b] = first record whose first key byte is >= b
+  int64_t lo = 0, hi = n;
+  while (lo < hi)
+    { const int64_t mid = (lo + hi) >> 1;
+      if (t[mid * stride] < b) lo = mid + 1; else hi = mid;
+    }
+  bounds[b] = lo;
+  if (b == 0) bounds[256] = n;
+}
+
+// this rank's table without the entries below sh->write_cutoff: *tab (a buffer of the shard) and pre[0..256]
+static int shard_filter_table(fk_shard *sh, const char **tab, int64_t *pre)
+{ fk_ctx *ctx = sh->ctx;
+  const fk_widths &w = ctx->wid;
+  const int64_t n = ctx->last_ntab;
+  const int stw = w.kmer_stride / 4;
+  hipStream_t s = ctx->stream;
+  const int64_t nt = (n + 255) / 256;
+  u32 *cnt = (u32 *) fk_slot(ctx, FK_SLOT_PF_ZC, std::max<int64_t>(nt, 1) * 4 + 64);
+  u64 *off = (u64 *) fk_slot(ctx, FK_SLOT_PF_ZO, std::max<int64_t>(nt, 1) * 8 + 64);
+  if (cnt == NULL || off == NULL) return (FK_ENOMEM);
+  for (int x = 0; x <= 256; x++) pre[x] = 0;
+  if (n == 0)
+    return (FK_OK);
+  hipLaunchKernelGGL(k_shf_count, dim3((unsigned) nt), dim3(256), 0, s, (const u32 *) ctx->last_table, n, stw, (u32) sh->write_cutoff, cnt);
+  hipLaunchKernelGGL(k_exscan_tiles, dim3(1), dim3(256), 0, s, (const u32 *) cnt, nt, off, ctx->d_scratch);
+  FK_LAUNCH_CHECK(ctx);
+  FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch, ctx->d_scratch, 8, hipMemcpyDeviceToHost, s));
+  FK_HIP(ctx, hipStreamSynchronize(s));
+  const int64_t keep = (int64_t) ctx->h_scratch[0];
+  char *out = (char *) pf_reserve(sh, 0, std::max<int64_t>(keep, 1) * w.kmer_stride);
+  if (out == NULL) return (FK_ENOMEM);
+  hipLaunchKernelGGL(k_shf_compact, dim3((unsigned) nt), dim3(256), 0, s, (const u32 *) ctx->last_table, n, stw, (u32) sh->write_cutoff,
+                     (const u64 *) off, (u32 *) out);
+  int64_t *d_b = (int64_t *) (ctx->d_scratch + 8);
+  hipLaunchKernelGGL(k_shf_bounds, dim3(1), dim3(256), 0, s, (const unsigned char *) out, keep, w.kmer_stride, d_b);
+  FK_LAUNCH_CHECK(ctx);
+  FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch, d_b, 257 * 8, hipMemcpyDeviceToHost, s));
+  FK_HIP(ctx, hipStreamSynchronize(s));
+  for (int x = 0; x <= 256; x++) pre[x] = (int64_t) ctx->h_scratch[x];
+  *tab = out;
+  return (FK_OK);
+}
+
 /* C3, the final gather after fk_shard_count: rank d receives the entries of the first-byte ranges of parts
    d*m .. d*m+m-1 (m = nparts / world; the boundaries are Table_Split's, count.c:1560-1565, over the all-reduced
    census) from every rank's sorted table -- a second exchange over RCCL --, orders its `world` runs of disjoint
@@ -558,6 +637,17 @@ extern "C" int fk_shard_gather(fk_shard *sh, const fk_result *res, int nparts, c
                    (long long) ctx->last_ntab);
       return (FK_ESTATE);
     }
+  sh->g_total = res->ntable;
+  if (sh->write_cutoff > ctx->prm.table_cutoff)
+    { // -t<n> beside -p: the table in HBM keeps every k-mer for the look-ups, the files take those that reach n
+      int64_t tot = 0;
+      int frc = shard_filter_table(sh, &tab, pre);
+      if ((rc = agree(sh, frc)) != FK_OK) return (rc);
+      tot = pre[256];
+      if ((rc = allreduce_i64(sh, &tot, 1)) != FK_OK) return (rc);
+      sh->g_total = tot;
+    }
+  sh->st.table_entries_written = sh->g_total;
   std::vector<int64_t> mine(W), all((size_t) W * W);
   for (int d = 0; d < W; d++)
     mine[d] = pre[split[(d + 1) * m]] - pre[split[d * m]];
@@ -639,7 +729,7 @@ extern "C" int fk_shard_gather(fk_shard *sh, const fk_result *res, int nparts, c
   sh->st.gather_d2h_ms      = 1e3 * (fk_wall() - g2);
   sh->g_n = nin;
   sh->g_nparts = nparts;
-  sh->g_ib = fk_ktab_idx_bytes(ctx->prm.kmer, res->ntable);
+  sh->g_ib = fk_ktab_idx_bytes(ctx->prm.kmer, sh->g_total);
   if (table) *table = sh->g_host;
   if (nentries) *nentries = nin;
   return (FK_OK);
@@ -832,7 +922,7 @@ extern "C" int fk_shard_write(fk_shard *sh, const fk_result *res, int nparts, co
 { if (sh == NULL || res == NULL || dir == NULL || root == NULL) return (FK_EINVAL);
   fk_ctx *ctx = sh->ctx;
   const int W = sh->world, me = sh->rank;
-  const int cutoff = ctx->prm.table_cutoff;
+  const int cutoff = (sh->write_cutoff > ctx->prm.table_cutoff) ? sh->write_cutoff : ctx->prm.table_cutoff;
   FK_HIP(ctx, hipSetDevice(ctx->device));
   if (me == 0)
     { char path[4096];
@@ -876,9 +966,9 @@ extern "C" int fk_shard_write(fk_shard *sh, const fk_result *res, int nparts, co
   hipFree(d_pc);
   int64_t tot = 0;
   for (int64_t i = 0; i < npre; i++) tot += pc[(size_t) i];
-  if (tot != res->ntable)
+  if (tot != sh->g_total)
     { fk_set_error(ctx, "sharded run: the table exchange lost entries (%lld written, %lld counted)", (long long) tot,
-                   (long long) res->ntable);
+                   (long long) sh->g_total);
       return (FK_EHIP);
     }
   if (me == 0)

@@ -1183,11 +1183,7 @@ int main(int argc, char *argv[])
 
 
   if (NGPUS > 1 && (EXACT || PRO_NAME != NULL))
-    { fprintf(stderr,"%s: -x and -p:<table> run on one GPU (-G%d takes -t, -p and -M)\n",Prog_Name,NGPUS);
-      exit (1);
-    }
-  if (NGPUS > 1 && PROFILE && DO_TABLE > 1)
-    { fprintf(stderr,"%s: -G%d -p keeps every k-mer (the profiles look them up): -t1 or no table with it\n",Prog_Name,NGPUS);
+    { fprintf(stderr,"%s: -x and -p:<table> run on one GPU (-G%d takes -t, -p -- also together -- and -M)\n",Prog_Name,NGPUS);
       exit (1);
     }
   if (NGPUS > 1 && RANK < 0)
@@ -1268,6 +1264,9 @@ int main(int argc, char *argv[])
       share_unique_id(id);
       if (fk_shard_create(ctx,RANK,NGPUS,id,&shard) != FK_OK)
         die(ctx,"fk_shard_create");
+      if (PROFILE && DO_TABLE > 1          /* -t<n> -p: counted with cutoff 1 for the look-ups, the files keep count >= n */
+          && fk_shard_set_write_cutoff(shard,DO_TABLE) != FK_OK)
+        die(ctx,"fk_shard_set_write_cutoff");
     }
 
   memset(&feed,0,sizeof(feed));

@@ -487,8 +487,15 @@ typedef struct
     double  exchange_ms;         /*     device time of the sends / receives (they overlap the counting)  */
     int64_t gather_sent_bytes;   /* C3: table entries sent to other ranks                                */
     double  gather_exchange_ms, gather_sort_ms, gather_d2h_ms;   /* C3 by phase, wall clock             */
+    int64_t table_entries_written; /* C3: entries of the whole table that passed the write cutoff (all ranks)    */
   } fk_shard_stats;
 int  fk_shard_get_stats(fk_shard *sh, fk_shard_stats *st);
+/* A table cutoff for the FILES only (FastK -t<n> with -p, FastK.c:491-540: the profiles look every k-mer up, the
+   .ktab keeps those that occur n or more times): the context counts with table_cutoff 1, and fk_shard_gather /
+   fk_shard_write drop the entries below `cutoff` from this rank's table before the second exchange (what the one-GPU
+   driver and the shim do at the write, host/gpu_path.c:113-128).  The table in HBM -- the dictionary of
+   fk_shard_profiles -- keeps every k-mer.  0 or 1: write what was counted.  Every rank passes the same value. */
+int  fk_shard_set_write_cutoff(fk_shard *sh, int cutoff);
 /* vals[0..n) summed element-wise over all ranks, in place (host memory). */
 int  fk_shard_sum_i64(fk_shard *sh, int64_t *vals, int n);
 void fk_shard_destroy(fk_shard *sh);

@@ -1335,7 +1335,11 @@ def _prof_stream(d, root):
 
 
 @pytest.mark.parametrize("name,fmt,ranks,budget", [("synth_illumina_k51_t1_T4", "fastq", 2, True), ("synth_illumina_k40_t1_T4", "fastq", 4, True),
-                                                    ("edge_k40_t1_T4", "fasta", 2, False), ("edge_k51_t1_T4", "fasta", 2, True)])
+                                                    ("edge_k40_t1_T4", "fasta", 2, False), ("edge_k51_t1_T4", "fasta", 2, True),
+                                                    # -t<n> beside -p (the reference's FastK.c:491-540 in one main()): counted with
+                                                    # cutoff 1 for the look-ups, the .ktab keeps what reaches n (fk_shard_set_write_cutoff)
+                                                    ("edge_k40_t4_T1", "fasta", 2, False), ("synth_hifi_k40_t4_T8", "fasta", 4, True),
+                                                    ("edge_k21_t2_T3", "fasta", 2, True)])
 def test_c_driver_sharded_with_profiles_and_budget(name, fmt, ranks, budget, tmp_path):
     """FastK_amd -G<n> -t1 -p [-M1]: BASELINE configs[4]'s options through the C host on several ranks (the one-GPU rig).
     The counting pass of every rank splits its stripe chunk by chunk (the test shrinks the chunks and the HBM share
@@ -1347,16 +1351,18 @@ def test_c_driver_sharded_with_profiles_and_budget(name, fmt, ranks, budget, tmp
     import os, subprocess
     case, bases, boff = util.load_case(name)
     exp = case["expected"]
-    assert case["cutoff"] == 1 and "prof" in exp
+    assert "prof" in exp
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(root, "fastk_amd", "bin", "FastK_amd")
     path = str(tmp_path / ("reads." + fmt))
     if case["kind"] == "edge":
         orc.write_fasta(path, bases, boff)
-    else:
+    elif len(set(np.diff(boff))) == 1:
         util.write_fastx(path, bases, boff, fmt == "fastq")
+    else:
+        orc.write_fasta(path, bases, boff, width=100)
     T = 4
-    args = ["-k%d" % case["k"], "-t1", "-p", "-T%d" % T]
+    args = ["-k%d" % case["k"], "-t%d" % case["cutoff"], "-p", "-T%d" % T]
     one, many = tmp_path / "one", tmp_path / "many"
     one.mkdir(); many.mkdir()
     subprocess.run([exe] + args + ["-N" + str(one / "x"), path], check=True)
