@@ -29,7 +29,7 @@ EXPORTS = [
     "fk_write_ktab_range", "fk_write_ktab_stub", "fk_split_supermers_emit_pos", "fk_profile_lookup_supermers",
     "fk_profile_scatter", "fk_profile_encode", "fk_reset", "fk_shard_unique_id", "fk_shard_create",
     "fk_release_device", "fk_set_sort_memory", "fk_finish_device", "fk_write_ktab_device", "fk_push_packed", "fk_pack_fixed_reads", "fk_copy_rate", "fk_shard_count", "fk_shard_gather", "fk_shard_write", "fk_shard_destroy", "fk_shard_count_device", "fk_shard_local_result",
-    "fk_count_device_packed", "fk_shard_get_stats", "fk_shard_set_write_cutoff", "fk_shard_profiles", "fk_shard_write_prof", "fk_write_prof_range", "fk_shard_sum_i64",
+    "fk_count_device_packed", "fk_shard_get_stats", "fk_shard_set_write_cutoff", "fk_shard_count_device_packed", "fk_shard_profiles", "fk_shard_write_prof", "fk_write_prof_range", "fk_shard_sum_i64",
 ]
 
 
@@ -127,6 +127,7 @@ def load_library():
     L.fk_shard_create.argtypes = [vp, ci, ci, C.c_char_p, C.POINTER(vp)]
     L.fk_shard_count.argtypes = [vp, C.POINTER(CResult)]
     L.fk_shard_count_device.argtypes = [vp, vp, i64, C.POINTER(CResult)]
+    L.fk_shard_count_device_packed.argtypes = [vp, vp, i64, vp, i64, vp, i64, C.POINTER(CResult)]
     L.fk_shard_local_result.argtypes = [vp, C.POINTER(CResult)]
     L.fk_shard_write.argtypes = [vp, C.POINTER(CResult), ci, C.c_char_p, C.c_char_p]
     L.fk_shard_gather.argtypes = [vp, C.POINTER(CResult), ci, C.POINTER(vp), C.POINTER(i64)]
@@ -584,6 +585,13 @@ class Shard:
             self.ctx._ck(self.ctx.L.fk_shard_count(self.h, C.byref(r)))
         else:
             self.ctx._ck(self.ctx.L.fk_shard_count_device(self.h, ptr, nbytes, C.byref(r)))
+        return Result(r, self.ctx.w.kmer_word)
+
+    def count_packed(self, codes_ptr, nbases, roff_ptr, nreads, inv_ptr=None, ninv=0):
+        """The same over a stripe resident in two bits per base (the arguments of Context.count_device_packed)."""
+        r = CResult()
+        self.ctx._ck(self.ctx.L.fk_shard_count_device_packed(self.h, codes_ptr, nbases, roff_ptr, nreads, inv_ptr, ninv,
+                                                             C.byref(r)))
         return Result(r, self.ctx.w.kmer_word)
 
     def local_result(self):

@@ -580,6 +580,10 @@ extern "C" int fk_debug_set(fk_ctx *ctx, const char *key, int64_t value)
     { ctx->dbg_radix_items = (int) value;
       return (FK_OK);
     }
+  if (strcmp(key, "scatter_abl") == 0)     // ablated stream-engine scatters: WRONG output (tools/scatter_ablation.py)
+    { ctx->dbg_scatter_abl = (int) value;
+      return (FK_OK);
+    }
 #else
   if (strcmp(key, "radix_variant") == 0 || strcmp(key, "radix_items") == 0 || (strcmp(key, "radix_engine") == 0 && value == 1))
     { fk_set_error(ctx, "fk_debug_set(%s): the look-back radix engine and its ablations are only in builds made with "

@@ -211,6 +211,7 @@ struct fk_ctx
   // so that a repeated workload performs no hipMalloc/hipFree inside the hot path
   int        dbg_radix_variant;   // measurement aids, see fk_debug_set
   int        dbg_radix_items;
+  int        dbg_scatter_abl;     // -DFK_ABLATION builds: RX_ABL_* bits of the stream engine's scatter kernels (fk_radix.hip)
   int        dbg_radix_engine;    // 1 = look-back engine instead of the stream engine
   int        dbg_kmer_stage;      // 1 = sort-collapse-sort k-mer stage instead of hash aggregation
   int        dbg_verbose;

@@ -993,6 +993,25 @@ static int fkx_profile_encode(fk_ctx *ctx, const uint8_t *bases, int64_t nbytes,
   const int64_t nzero = (int64_t) ctx->h_scratch[0];
   lastb = *((uint8_t *) ctx->h_scratch + 8);
   const int64_t nreads = nzero + (lastb != 0 ? 1 : 0);
+  if (getenv("FK_PF_CHECK") != NULL)
+    { // harness aid (tests/fuzz_parity.py under tools/fuzz_many.sh): the read terminators counted again on the host from a
+      // BLOCKING copy of the buffer, and the tile counts added up again -- which of the three disagrees when a run
+      // reports another number of profiles than reads?
+      std::vector<uint8_t> hb((size_t) nbytes);
+      std::vector<u32> hz((size_t) nz);
+      if (hipMemcpy(hb.data(), bases, (size_t) nbytes, hipMemcpyDeviceToHost) == hipSuccess
+          && hipMemcpy(hz.data(), zc, (size_t) nz * 4, hipMemcpyDeviceToHost) == hipSuccess)
+        { int64_t cz = 0, sz = 0, runs = 0;
+          for (int64_t i = 0; i < nbytes; i++) cz += (hb[(size_t) i] == 0);
+          for (int64_t i = 0; i < nz; i++) sz += hz[(size_t) i];
+          for (int64_t i = 3; i < nbytes; i++)
+            if (hb[(size_t) i] == 0 && hb[(size_t) i - 1] == 0 && hb[(size_t) i - 2] == 0 && hb[(size_t) i - 3] == 0) runs += 1;
+          fprintf(stderr, "FK_PF_CHECK %s: total from the device %lld, tile counts add up to %lld, a blocking copy of the %lld "
+                          "bytes holds %lld zeros (%lld places with four in a row), last byte %d\n",
+                  (cz == nzero && sz == nzero) ? "ok" : "MISMATCH", (long long) nzero, (long long) sz, (long long) nbytes,
+                  (long long) cz, (long long) runs, (int) lastb);
+        }
+    }
   *nreads_out = nreads;
   if (nreads == 0)
     return (FK_OK);

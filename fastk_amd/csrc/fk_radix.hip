@@ -357,13 +357,13 @@ __global__ __launch_bounds__(RX_THREADS) void k_radix_pass(const u32 *__restrict
 #define RX_CH 16
 #define RX_SC 256
 // -DFK_ABLATION builds (WRONG output; tools/scatter_ablation.py): bits of the scatter kernels' `unstable` argument, set
-// from fk_debug_set("radix_variant", bits) -- what a pass would cost without one of its parts
+// from fk_debug_set("scatter_abl", bits) -- what a pass would cost without one of its parts
 #define RX_ABL_NOHASH 0x100     // hashed passes: the next pass's digit is a byte of the record, not a hash of it
 #define RX_ABL_LINEAR 0x200     // the records leave in tile order (whole lines, no scatter): the bound of any write combining
 #define RX_ABL_NOPERM 0x400     // sorted slot p takes record p (no LDS gather)
 #define RX_ABL_NORANK 0x800     // no ranking: every record gets rank 0 of its wave's bin (no ballots, no LDS atomics)
 #ifdef FK_ABLATION
-#define RX_ABL_BITS(ctx) ((ctx)->dbg_radix_engine != 1 ? ((ctx)->dbg_radix_variant & 0xf00) : 0)
+#define RX_ABL_BITS(ctx) ((ctx)->dbg_scatter_abl & 0xf00)
 #else
 #define RX_ABL_BITS(ctx) 0
 #endif

@@ -356,6 +356,27 @@ extern "C" int fk_shard_count_device(fk_shard *sh, const void *d_bases, int64_t 
   return shard_count(sh, d_bases, nbytes, res);
 }
 
+/* ... and over reads resident in two bits per base (the arguments of fk_count_device_packed): the rank's stripe is
+   split as it is, a quarter of the bytes of the ASCII form beside the records of the exchange. */
+extern "C" int fk_shard_count_device_packed(fk_shard *sh, const void *d_codes, int64_t nbases, const int64_t *d_roff,
+                                            int64_t nreads, const int64_t *d_inv, int64_t ninv, fk_result *res)
+{ if (sh == NULL || res == NULL || nbases < 0 || nreads < 0 || ninv < 0 || (nreads > 0 && (d_codes == NULL || d_roff == NULL))
+      || (ninv > 0 && d_inv == NULL))
+    return (FK_EINVAL);
+  fk_ctx *ctx = sh->ctx;
+  if (((uintptr_t) d_codes & 3) != 0)
+    { fk_set_error(ctx, "fk_shard_count_device_packed: the codes must be 4-byte aligned");
+      return (FK_EINVAL);
+    }
+  FK_HIP(ctx, hipSetDevice(ctx->device));
+  FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (nreads == 0)
+    return shard_count(sh, d_codes, 0, res);
+  fk_pkview pv;
+  pv.roff = d_roff; pv.nreads = nreads; pv.inv = d_inv; pv.ninv = ninv;
+  return shard_count(sh, d_codes, nbases, res, &pv);
+}
+
 // chunked: the records are the chunks of the budgeted ingest (fk_ingest.hip) -- per bucket one run per chunk, in the
 // slab store or spilled to pinned host memory; a round's buckets are gathered into one of two round buffers right
 // before they travel (the role of the gather in front of a bucket's count in the one-GPU budgeted run).

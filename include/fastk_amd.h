@@ -459,6 +459,9 @@ int  fk_shard_count(fk_shard *sh, fk_result *res);
 /* fk_shard_count over a stripe that is already resident in HBM and stays owned by the caller (16-byte aligned;
    any byte that is not acgtACGT separates reads), the sharded twin of fk_count_device_reads */
 int  fk_shard_count_device(fk_shard *sh, const void *d_bases, int64_t nbytes, fk_result *res);
+/* The same over a stripe resident in two bits per base (the arguments of fk_count_device_packed). */
+int  fk_shard_count_device_packed(fk_shard *sh, const void *d_codes, int64_t nbases, const int64_t *d_roff, int64_t nreads,
+                                  const int64_t *d_inv, int64_t ninv, fk_result *res);
 /* this rank's own share of the last fk_shard_count (counts and per-kernel device times; table NULL) */
 int  fk_shard_local_result(fk_shard *sh, fk_result *res);
 /* C3 alone, the final gather of the north-star ("... per-GPU sort+count, then a final gather"; the reference's

@@ -36,7 +36,7 @@ def main():
         b = torch.empty_like(a)
         rows = {}
         for name, bits in BITS.items():
-            ctx.debug_set("radix_variant", bits)
+            ctx.debug_set("scatter_abl", bits)
             best = None
             for _ in range(3):
                 ctx.group(a.data_ptr(), b.data_ptr(), n, rsize)
@@ -47,7 +47,7 @@ def main():
                     best = (ms, tot)
             rows[name] = dict(scatter_ms=round(best[0], 4), pass_ms_with_helpers=round(best[1], 4),
                               GBs=round(2 * n * rsize / (best[0] * 1e-3) / 1e9, 1))
-        ctx.debug_set("radix_variant", 0)
+        ctx.debug_set("scatter_abl", 0)
         for name in rows:
             rows[name]["vs_real"] = round(rows[name]["scatter_ms"] / rows["real"]["scatter_ms"], 3)
         out["R%d" % rsize] = dict(n=n, **rows)
