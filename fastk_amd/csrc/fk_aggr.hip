@@ -1345,10 +1345,8 @@ static int aggr_t(fk_ctx *ctx, const void *d_grouped, int64_t n, int cutoff, int
   u64 *hh = (u64 *) malloc((FK_HIST_BINS + AG_NSCAL) * 8);
   if (hh == NULL) return (FK_ENOMEM);
   (void) h;
-  if (hipMemcpyAsync(hh, d_hist, (FK_HIST_BINS + AG_NSCAL) * 8, hipMemcpyDeviceToHost, s) != hipSuccess
-      || hipStreamSynchronize(s) != hipSuccess)
+  if (fkx_d2h_pageable(ctx, s, hh, d_hist, (FK_HIST_BINS + AG_NSCAL) * 8) != FK_OK)      // (hh is malloc'ed: no asynchronous copy)
     { free(hh);
-      fk_set_error(ctx, "aggregate: HIP failure: %s", hipGetErrorString(hipGetLastError()));
       return (FK_EHIP);
     }
   if (hh[FK_HIST_BINS + 3] != 0)

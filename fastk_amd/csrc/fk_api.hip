@@ -141,6 +141,20 @@ int fkx_pinned_free(void *p)
   return (FK_OK);
 }
 
+int fkx_d2h_pageable(fk_ctx *ctx, hipStream_t s, void *dst, const void *d_src, size_t nbytes)
+{ FK_HIP(ctx, hipStreamSynchronize(s));
+  if (nbytes > 0)
+    FK_HIP(ctx, hipMemcpy(dst, d_src, nbytes, hipMemcpyDeviceToHost));
+  return (FK_OK);
+}
+
+int fkx_h2d_pageable(fk_ctx *ctx, hipStream_t s, void *d_dst, const void *src, size_t nbytes)
+{ FK_HIP(ctx, hipStreamSynchronize(s));            // (what the stream still does with the destination comes first)
+  if (nbytes > 0)
+    FK_HIP(ctx, hipMemcpy(d_dst, src, nbytes, hipMemcpyHostToDevice));
+  return (FK_OK);
+}
+
 int fkx_reserve_host_table(fk_ctx *ctx, int64_t bytes)
 { if (ctx->h_table_cap >= bytes)
     return (FK_OK);
@@ -543,16 +557,12 @@ extern "C" int fk_device_free(fk_ctx *ctx, void *d_ptr)
 
 extern "C" int fk_copy_to_device(fk_ctx *ctx, void *d_dst, const void *src, int64_t nbytes)
 { if (ctx == NULL) return (FK_EINVAL);
-  FK_HIP(ctx, hipMemcpyAsync(d_dst, src, (size_t) nbytes, hipMemcpyHostToDevice, ctx->stream));
-  FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return (FK_OK);
+  return fkx_h2d_pageable(ctx, ctx->stream, d_dst, src, (size_t) nbytes);
 }
 
 extern "C" int fk_copy_to_host(fk_ctx *ctx, void *dst, const void *d_src, int64_t nbytes)
 { if (ctx == NULL) return (FK_EINVAL);
-  FK_HIP(ctx, hipMemcpyAsync(dst, d_src, (size_t) nbytes, hipMemcpyDeviceToHost, ctx->stream));
-  FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return (FK_OK);
+  return fkx_d2h_pageable(ctx, ctx->stream, dst, d_src, (size_t) nbytes);
 }
 
 /* Test and measurement knobs (never used by the product path).  Every knob of a normal build keeps
@@ -910,8 +920,9 @@ extern "C" int fk_merge_tables(fk_ctx *ctx, const uint8_t *records, int64_t n, i
       if (c >= 0x7fff) { c = 0x8000; nsat += 1; }
       memcpy(o + w.kmer_stride - 2, &c, 2);
     }
-  FK_HIP(ctx, hipMemcpyAsync(d_a, stage.data(), stage.size(), hipMemcpyHostToDevice, s));
-  FK_HIP(ctx, hipStreamSynchronize(s));
+  { const int hrc = fkx_h2d_pageable(ctx, s, d_a, stage.data(), stage.size());
+    if (hrc != FK_OK) return (hrc);
+  }
   void *grouped = d_a;
   int rc = fkx_group(ctx, n, d_a, d_b, w.kmer_stride, w.kmer_bytes, 2, &grouped);
   if (rc != FK_OK) return (rc);
@@ -935,8 +946,9 @@ extern "C" int fk_merge_tables(fk_ctx *ctx, const uint8_t *records, int64_t n, i
   if (fkx_reserve_host_table(ctx, bytes) != FK_OK)
     return (FK_ENOMEM);
   std::vector<uint8_t> back((size_t) nt * w.kmer_stride);
-  FK_HIP(ctx, hipMemcpyAsync(back.data(), sorted, back.size(), hipMemcpyDeviceToHost, s));
-  FK_HIP(ctx, hipStreamSynchronize(s));
+  { const int hrc = fkx_d2h_pageable(ctx, s, back.data(), sorted, back.size());
+    if (hrc != FK_OK) return (hrc);
+  }
   for (int64_t i = 0; i < nt; i++)
     { memcpy(ctx->h_table + i * w.kmer_word, back.data() + i * w.kmer_stride, w.kmer_bytes);
       memcpy(ctx->h_table + i * w.kmer_word + w.kmer_bytes, back.data() + i * w.kmer_stride + w.kmer_stride - 2, 2);

@@ -315,6 +315,14 @@ int fkx_count(fk_ctx *ctx, const void *d_kmers, int64_t nweighted, int cutoff, i
               void *d_table, int64_t cap, int64_t *ntable);
 int fkx_collapse(fk_ctx *ctx, const void *d_kmers, int64_t n, void *d_out, int64_t cap,
                  int64_t *nout, int64_t *overflow);
+// Copies between device memory and PAGEABLE host memory (a caller's buffer, malloc'ed results, a std::vector, a stack
+// variable).  Never hipMemcpyAsync: the stream is waited for, then a blocking hipMemcpy moves the bytes -- complete in
+// both memories when the call returns.  (Round 5: with dozens of processes on one GPU, data that hipMemcpyAsync(DeviceTo
+// Host) had brought into malloc'ed memory was at times not all there when hipStreamSynchronize returned: histograms and
+// downloads came back with stale stretches.  Pinned buffers -- h_scratch, the result table, the staging -- take
+// asynchronous copies as before.)
+int fkx_d2h_pageable(fk_ctx *ctx, hipStream_t s, void *dst, const void *d_src, size_t nbytes);
+int fkx_h2d_pageable(fk_ctx *ctx, hipStream_t s, void *d_dst, const void *src, size_t nbytes);
 int fkx_pinned_alloc(void **out, int64_t bytes);     // large buffers: huge pages touched in parallel + hipHostRegister
 int fkx_pinned_free(void *p);
 int fkx_reserve_host_table(fk_ctx *ctx, int64_t bytes);      // ctx->h_table: pinned host memory for the result table

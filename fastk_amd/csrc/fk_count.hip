@@ -524,8 +524,7 @@ static int count_t(fk_ctx *ctx, void *d_kmers, int64_t n, int cutoff, int sorted
       hipLaunchKernelGGL(k_exscan_tiles, dim3(1), dim3(256), 0, s, (const u32 *) d_ent, ntiles,
                          d_off, d_scal + 2);
       if (hipGetLastError() != hipSuccess) { rc = FK_EHIP; break; }
-      if (hipMemcpyAsync(h, d_hist, (FK_HIST_BINS + 8) * 8, hipMemcpyDeviceToHost, s) != hipSuccess
-          || hipStreamSynchronize(s) != hipSuccess)
+      if (fkx_d2h_pageable(ctx, s, h, d_hist, (FK_HIST_BINS + 8) * 8) != FK_OK)                // (h is malloc'ed)
         { rc = FK_EHIP; break; }
       if (h[FK_HIST_BINS + 3] != 0)
         { rc = FK_ESTATE;          // heterogeneous prefix run outside the LDS window: caller sorts on

@@ -676,12 +676,10 @@ extern "C" int fk_push_fastq(fk_ctx *ctx, const char *raw, int64_t nbytes, int f
       // one byte in front of the text: the last byte of the previous piece (homopolymer compression)
       d_raw = (char *) d_raw + 16;
       const unsigned char lastb = (unsigned char) ((*line_phase >> 8) & 0xff);
-      if (hipMemcpyAsync((char *) d_raw - 1, &lastb, 1, hipMemcpyHostToDevice, ctx->stream) != hipSuccess
-          || hipMemcpyAsync(d_raw, raw, (size_t) nbytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
-        { fk_set_error(ctx, "fk_push_fastq: host to device copy failed");
-          rc = FK_EHIP;
-          break;
-        }
+      // (a stack variable and the caller's text, which may be pageable: blocking copies)
+      if ((rc = fkx_h2d_pageable(ctx, ctx->stream, (char *) d_raw - 1, &lastb, 1)) != FK_OK
+          || (rc = fkx_h2d_pageable(ctx, ctx->stream, d_raw, raw, (size_t) nbytes)) != FK_OK)
+        break;
       int64_t kept = 0, nr = 0;
       if ((rc = fkx_parse_fastq(ctx, d_raw, nbytes, flags, line_phase, ctx->d_reads + ctx->reads_len, &kept, &nr)) != FK_OK)
         break;
@@ -718,11 +716,8 @@ extern "C" int fk_push_fasta(fk_ctx *ctx, const char *raw, int64_t nbytes, int l
       if (nbytes > 0)
         { void *d_raw = fk_slot(ctx, FK_SLOT_RAW, nbytes + 64);
           if (d_raw == NULL) { rc = FK_ENOMEM; break; }
-          if (hipMemcpyAsync(d_raw, raw, (size_t) nbytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
-            { fk_set_error(ctx, "fk_push_fasta: host to device copy failed");
-              rc = FK_EHIP;
-              break;
-            }
+          if ((rc = fkx_h2d_pageable(ctx, ctx->stream, d_raw, raw, (size_t) nbytes)) != FK_OK)
+            break;
           if ((rc = fkx_parse_fasta(ctx, d_raw, nbytes, *state, ctx->d_reads + ctx->reads_len, &kept, &nr)) != FK_OK)
             break;
           // the state after this piece, from the host copy of the text

@@ -132,17 +132,16 @@ static int ktab_prefix_index(fk_ctx *ctx, int64_t n, int ib)
         { int64_t *d_b = (int64_t *) ctx->d_scratch;
           hipLaunchKernelGGL(k_first_byte_bounds, dim3(1), dim3(256), 0, ctx->stream, (const unsigned char *) ctx->last_table, n,
                              ctx->wid.kmer_stride, d_b);
-          e = hipMemcpyAsync(ctx->ktab_first, d_b, 257 * 8, hipMemcpyDeviceToHost, ctx->stream);
+          if (hipGetLastError() != hipSuccess || fkx_d2h_pageable(ctx, ctx->stream, ctx->ktab_first, d_b, 257 * 8) != FK_OK)
+            e = hipErrorUnknown;                           // (ktab_first lies in the context: pageable)
         }
       if (e == hipSuccess)
         { hipLaunchKernelGGL(k_prefix_ends, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, ctx->stream,
                              (const unsigned char *) ctx->last_table, n, ctx->wid.kmer_stride, ib, d_ends);
           e = hipGetLastError();
         }
-      if (e == hipSuccess)
-        e = hipMemcpyAsync(ctx->ktab_ends, d_ends, (size_t) npre * 8, hipMemcpyDeviceToHost, ctx->stream);
-      if (e == hipSuccess)
-        e = hipStreamSynchronize(ctx->stream);
+      if (e == hipSuccess && fkx_d2h_pageable(ctx, ctx->stream, ctx->ktab_ends, d_ends, (size_t) npre * 8) != FK_OK)
+        e = hipErrorUnknown;                               // (calloc'ed)
       if (own)
         hipFree(d_ends);
       if (e != hipSuccess)

@@ -568,8 +568,8 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
               ctx->exact_tran_set = true;
               int64_t *d_roff = (int64_t *) fk_slot(ctx, FK_SLOT_ROFF, (nreads + 1) * 8);
               if (d_roff == NULL) { rc = FK_ENOMEM; break; }
-              if (hipMemcpyAsync(d_roff, h_roff, (size_t) (nreads + 1) * 8, hipMemcpyHostToDevice, s) != hipSuccess)
-                { rc = FK_EHIP; break; }
+              if ((rc = fkx_h2d_pageable(ctx, s, d_roff, h_roff, (size_t) (nreads + 1) * 8)) != FK_OK)
+                break;
               // how many buckets the reference would use (FastK.c:417-429: the k-mer records of the whole input,
               // extrapolated from the training block, over the sort memory) and, with more than one, its scheme
               ctx->scheme_nparts = 1;

@@ -1004,12 +1004,18 @@ static int fkx_profile_encode(fk_ctx *ctx, const uint8_t *bases, int64_t nbytes,
         { int64_t cz = 0, sz = 0, runs = 0;
           for (int64_t i = 0; i < nbytes; i++) cz += (hb[(size_t) i] == 0);
           for (int64_t i = 0; i < nz; i++) sz += hz[(size_t) i];
-          for (int64_t i = 3; i < nbytes; i++)
-            if (hb[(size_t) i] == 0 && hb[(size_t) i - 1] == 0 && hb[(size_t) i - 2] == 0 && hb[(size_t) i - 3] == 0) runs += 1;
+          char where[256] = "";
+          for (int64_t i = 1; i < nbytes; i++)
+            if (hb[(size_t) i] == 0 && hb[(size_t) i - 1] == 0)
+              { if (runs < 8)
+                  snprintf(where + strlen(where), sizeof(where) - strlen(where), " %lld(+%d)", (long long) i,
+                           (int) (((uintptr_t) bases + (uintptr_t) i) & 63));
+                runs += 1;
+              }
           fprintf(stderr, "FK_PF_CHECK %s: total from the device %lld, tile counts add up to %lld, a blocking copy of the %lld "
-                          "bytes holds %lld zeros (%lld places with four in a row), last byte %d\n",
+                          "bytes holds %lld zeros (%lld places with two in a row:%s), last byte %d\n",
                   (cz == nzero && sz == nzero) ? "ok" : "MISMATCH", (long long) nzero, (long long) sz, (long long) nbytes,
-                  (long long) cz, (long long) runs, (int) lastb);
+                  (long long) cz, (long long) runs, where, (int) lastb);
         }
     }
   *nreads_out = nreads;
@@ -1021,7 +1027,10 @@ static int fkx_profile_encode(fk_ctx *ctx, const uint8_t *bases, int64_t nbytes,
                      (const u64 *) zo, ends);
   FK_LAUNCH_CHECK(ctx);
   if (lastb != 0)
-    FK_HIP(ctx, hipMemcpyAsync(ends + nzero, &nbytes, 8, hipMemcpyHostToDevice, s));
+    { // (the source is a stack variable: a blocking copy, ordered behind the kernel above)
+      const int hrc = fkx_h2d_pageable(ctx, s, ends + nzero, &nbytes, 8);
+      if (hrc != FK_OK) return (hrc);
+    }
 
   // 4. codec: lengths, offsets, bytes
   u32 *lens = (u32 *) fk_slot(ctx, FK_SLOT_PF_LEN, nreads * 4 + 64);
@@ -1056,8 +1065,9 @@ static int fkx_profile_encode(fk_ctx *ctx, const uint8_t *bases, int64_t nbytes,
       FK_LAUNCH_CHECK(ctx);
       std::vector<u32> nrun((size_t) nreads);
       std::vector<u64> rid0((size_t) nreads);
-      FK_HIP(ctx, hipMemcpyAsync(nrun.data(), lens, (size_t) nreads * 4, hipMemcpyDeviceToHost, s));
-      FK_HIP(ctx, hipStreamSynchronize(s));
+      { const int hrc = fkx_d2h_pageable(ctx, s, nrun.data(), lens, (size_t) nreads * 4);
+        if (hrc != FK_OK) return (hrc);
+      }
       { std::vector<u64> run_of_tid(4096, 0);
         int64_t r = 0;
         for (int64_t b = 0; b < ctx->nblocks; b++)
@@ -1068,8 +1078,9 @@ static int fkx_profile_encode(fk_ctx *ctx, const uint8_t *bases, int64_t nbytes,
       }
       u64 *d_rid0 = (u64 *) fk_slot(ctx, FK_SLOT_PF_RID, nreads * 8 + 64);
       if (d_rid0 == NULL) return (FK_ENOMEM);
-      FK_HIP(ctx, hipMemcpyAsync(d_rid0, rid0.data(), (size_t) nreads * 8, hipMemcpyHostToDevice, s));
-      FK_HIP(ctx, hipStreamSynchronize(s));
+      { const int hrc = fkx_h2d_pageable(ctx, s, d_rid0, rid0.data(), (size_t) nreads * 8);
+        if (hrc != FK_OK) return (hrc);
+      }
       xa.rid0 = d_rid0;
       hipLaunchKernelGGL(k_pf_exact<1>, dim3(xnb), dim3(PX_THREADS), 0, s, xa);
     }
@@ -1087,7 +1098,7 @@ static int fkx_profile_encode(fk_ctx *ctx, const uint8_t *bases, int64_t nbytes,
   }
   FK_LAUNCH_CHECK(ctx);
   FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch, offs + nreads, 8, hipMemcpyDeviceToHost, s));
-  FK_HIP(ctx, hipStreamSynchronize(s));       // also keeps the stack variable nbytes alive for the copy above
+  FK_HIP(ctx, hipStreamSynchronize(s));
   const int64_t nprof = (int64_t) ctx->h_scratch[0];
   uint8_t *data = (uint8_t *) fk_slot(ctx, FK_SLOT_PF_OUT, nprof + 64);
   if (data == NULL) return (FK_ENOMEM);

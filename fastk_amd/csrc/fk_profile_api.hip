@@ -83,11 +83,11 @@ static int profiles_to_host(fk_ctx *ctx, int64_t *nreads_io, int64_t *nprof_io, 
     }
   ctx->h_prof_off[0] = 0;
   if (nreads > 0)
-    { if (nprof > 0)
-        FK_HIP(ctx, hipMemcpyAsync(ctx->h_prof, d_data, (size_t) nprof, hipMemcpyDeviceToHost, ctx->stream));
-      FK_HIP(ctx, hipMemcpyAsync(ctx->h_prof_off, d_offs, (size_t) (nreads + 1) * 8, hipMemcpyDeviceToHost,
-                                 ctx->stream));
-      FK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    { int hrc = fkx_d2h_pageable(ctx, ctx->stream, ctx->h_prof, d_data, (size_t) nprof);       // (both malloc'ed)
+      if (hrc == FK_OK)
+        hrc = fkx_d2h_pageable(ctx, ctx->stream, ctx->h_prof_off, d_offs, (size_t) (nreads + 1) * 8);
+      if (hrc != FK_OK)
+        return (hrc);
     }
   // Blocks pushed by several input threads interleave in HBM; the data set's read order is thread 0's
   // reads, then thread 1's, ... (io.c gives every thread a contiguous range of the input), and the
@@ -205,15 +205,17 @@ extern "C" int fk_set_table(fk_ctx *ctx, const uint8_t *records, int64_t n)
       if (d_t == NULL)
         return (FK_ENOMEM);
       if (w.kmer_word == w.kmer_stride)
-        FK_HIP(ctx, hipMemcpyAsync(d_t, records, (size_t) n * w.kmer_stride, hipMemcpyHostToDevice, s));
+        { const int hrc = fkx_h2d_pageable(ctx, s, d_t, records, (size_t) n * w.kmer_stride);       // (the caller's memory)
+          if (hrc != FK_OK) return (hrc);
+        }
       else
         { std::vector<uint8_t> stage((size_t) n * w.kmer_stride, 0);
           for (int64_t i = 0; i < n; i++)
             { memcpy(stage.data() + i * w.kmer_stride, records + i * w.kmer_word, w.kmer_bytes);
               memcpy(stage.data() + i * w.kmer_stride + w.kmer_stride - 2, records + i * w.kmer_word + w.kmer_bytes, 2);
             }
-          FK_HIP(ctx, hipMemcpyAsync(d_t, stage.data(), stage.size(), hipMemcpyHostToDevice, s));
-          FK_HIP(ctx, hipStreamSynchronize(s));
+          const int hrc = fkx_h2d_pageable(ctx, s, d_t, stage.data(), stage.size());
+          if (hrc != FK_OK) return (hrc);
         }
       FK_HIP(ctx, hipStreamSynchronize(s));
       ctx->last_table = d_t;

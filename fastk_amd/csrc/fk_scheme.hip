@@ -157,7 +157,7 @@ int fkx_train_scheme(fk_ctx *ctx, const void *d_bases, const int64_t *d_roff, in
       std::vector<int> trie((size_t) states);
       for (int i = 0; i < states; i++)
         trie[i] = (count[i] < 0) ? (int) count[i] : 0;
-      if (hipMemcpyAsync(d_trie, trie.data(), (size_t) states * 4, hipMemcpyHostToDevice, s) != hipSuccess
+      if (fkx_h2d_pageable(ctx, s, d_trie, trie.data(), (size_t) states * 4) != FK_OK
           || hipMemsetAsync(d_cnt, 0, (size_t) states * 8 + 8, s) != hipSuccess)
         { rc = FK_EHIP; break; }
       SchemeArgs a;
@@ -176,8 +176,7 @@ int fkx_train_scheme(fk_ctx *ctx, const void *d_bases, const int64_t *d_roff, in
         hipLaunchKernelGGL(k_scheme_census, dim3((unsigned) ((train + SC_THREADS - 1) / SC_THREADS)), dim3(SC_THREADS), 0, s, a);
       std::vector<u64> hc((size_t) states + 1);
       if (hipGetLastError() != hipSuccess
-          || hipMemcpyAsync(hc.data(), d_cnt, (size_t) states * 8 + 8, hipMemcpyDeviceToHost, s) != hipSuccess
-          || hipStreamSynchronize(s) != hipSuccess)
+          || fkx_d2h_pageable(ctx, s, hc.data(), d_cnt, (size_t) states * 8 + 8) != FK_OK)
         { rc = FK_EHIP; break; }
       ktot = 0;
       for (int i = 0; i < states; i++)

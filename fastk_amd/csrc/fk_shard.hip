@@ -976,10 +976,9 @@ extern "C" int fk_shard_write(fk_shard *sh, const fk_result *res, int nparts, co
       return (rc);
     }
   // per-prefix entry counts of all ranks -> rank 0 writes the stub
-  if (hipMemcpyAsync(d_pc, pc.data(), (size_t) npre * 8, hipMemcpyHostToDevice, sh->xs) != hipSuccess
+  if (fkx_h2d_pageable(ctx, sh->xs, d_pc, pc.data(), (size_t) npre * 8) != FK_OK
       || g_rccl.AllReduce(d_pc, d_pc, (size_t) npre, ncclInt64, ncclSum, sh->comm, sh->xs) != ncclSuccess
-      || hipMemcpyAsync(pc.data(), d_pc, (size_t) npre * 8, hipMemcpyDeviceToHost, sh->xs) != hipSuccess
-      || hipStreamSynchronize(sh->xs) != hipSuccess)
+      || fkx_d2h_pageable(ctx, sh->xs, pc.data(), d_pc, (size_t) npre * 8) != FK_OK)
     { hipFree(d_pc);
       fk_set_error(ctx, "fk_shard_write: reducing the prefix counts failed");
       return (FK_EHIP);

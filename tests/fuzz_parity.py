@@ -62,17 +62,28 @@ class Guarded:
         del self.array                       # (the mapping itself goes when the last view of it does)
 
 
-def device_reads_differ(ctx, bases):
-    """positions where the context's device copy of the pushed reads differs from the host array (None: not resident)"""
+def device_reads_report(ctx, pushed):
+    """the context's device copy of the pushed reads against what was pushed, block by block in push order: a text of
+    what differs where (None: the reads are not resident)"""
     try:
         ptr, n = ctx.debug_get("reads_ptr"), ctx.debug_get("reads_len")
     except Exception:                                                # noqa: BLE001
         return None
-    if not ptr or n != len(bases):
-        return None
+    want = np.concatenate([np.asarray(b) for b in pushed]) if pushed else np.zeros(0, dtype=np.uint8)
+    if not ptr or n != len(want):
+        return "reads_len %d, %d bytes were pushed" % (n, len(want))
     dev = np.empty(n, dtype=np.uint8)
     ctx._ck(ctx.L.fk_copy_to_host(ctx.h, dev.ctypes.data, ptr, n))
-    return np.nonzero(dev != np.asarray(bases))[0]
+    d = np.nonzero(dev != want)[0]
+    starts = np.cumsum([0] + [len(b) for b in pushed])
+    txt = "%d of %d bytes differ from the %d blocks pushed (zeros: device %d, pushed %d)" \
+          % (len(d), n, len(pushed), int((dev == 0).sum()), int((want == 0).sum()))
+    for p in d[:12].tolist():
+        blk = int(np.searchsorted(starts, p, side="right") - 1)
+        txt += "\n    at %d (block %d + %d of %d; address mod 64 = %d): device %s  pushed %s" \
+               % (p, blk, p - int(starts[blk]), len(pushed[blk]), (ptr + p) % 64,
+                  bytes(dev[max(0, p - 6):p + 10]), bytes(want[max(0, p - 6):p + 10]))
+    return txt
 
 
 def make_reads(rng, k):
@@ -212,6 +223,7 @@ def run(iters, seed, only=None, first=None, guard=True, quiet=False, max_bytes=N
                 cuts = sorted(int(x) for x in rng.integers(0, nreads + 1, size=nthreads - 1))
                 cuts = [0] + cuts + [nreads]
                 cur = cuts[:-1].copy()
+                pushed = []
                 while any(cur[t] < cuts[t + 1] for t in range(nthreads)):
                     t = int(rng.integers(0, nthreads))
                     if cur[t] >= cuts[t + 1]:
@@ -219,6 +231,7 @@ def run(iters, seed, only=None, first=None, guard=True, quiet=False, max_bytes=N
                     hi = min(cuts[t + 1], cur[t] + int(rng.integers(1, 400)))
                     lo = cur[t]
                     ctx.push_block(bases[boff[lo]:boff[hi]], (boff[lo:hi + 1] - boff[lo]).astype(np.int32), tid=t)
+                    pushed.append(bases[boff[lo]:boff[hi]])
                     cur[t] = hi
                 res = ctx.finish()
                 assert res.ninst == exp.ninst, "ninst"
@@ -230,10 +243,11 @@ def run(iters, seed, only=None, first=None, guard=True, quiet=False, max_bytes=N
                     want = orc.profile_counts(k, bases, boff, exp.table)
                     raw = data.tobytes()
                     if len(offs) != len(want) + 1:
-                        d = device_reads_differ(ctx, bases)
-                        print("profile count %d for %d reads; device copy of the reads: %s" % (len(offs) - 1, len(want),
-                              "not comparable" if d is None else "%d bytes differ from the host array%s"
-                              % (len(d), "" if len(d) == 0 else ", first at " + str(d[:16].tolist()))), flush=True)
+                        print("profile count %d for %d reads; device copy of the reads: %s"
+                              % (len(offs) - 1, len(want), device_reads_report(ctx, pushed)), flush=True)
+                        data2, offs2 = ctx.make_profiles()          # ... and once more, now
+                        print("    a second fk_make_profiles right away: %d profiles; device copy now: %s"
+                              % (len(offs2) - 1, device_reads_report(ctx, pushed)), flush=True)
                     assert len(offs) == len(want) + 1, "profile count"
                     for i, x in enumerate(want):
                         assert raw[offs[i]:offs[i + 1]] == orc.profile_encode(x), "profile of read %d" % i
