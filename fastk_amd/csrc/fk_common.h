@@ -237,6 +237,7 @@ struct fk_ctx
   int64_t    pre_hist_n;       // > 0: d_digit_hist (hash digits 0,1) and the DIG_A stream are valid for
                                // this many records (written by the expansion), see lsd_sort_stream_t
   bool       dig_lost;         // the digit stream slot was given up for memory (fk_slot): no bucket of this run may use one
+  int64_t    dig2_off;         // bytes from a pointer into the splitter's digit stream to the same record's hash digit 1
   const uint8_t *pre_dig;      // != NULL: the stream of hash digit 0 of the pre_dig_n super-mer records the next grouping
   int64_t    pre_dig_n;        // sorts, written by the splitter beside the records (fk_split.hip)
   int64_t    ex_nweighted, ex_ndistinct;   // totals of the last expand sizing call

@@ -762,7 +762,8 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
                   sm_a = out;
                   // (the passes write the first digit stream of every bucket's grouping sort beside the records)
                   sm_dig = (w.smer_stride == 20 && !ctx->dig_lost)
-                           ? (uint8_t *) fk_slot(ctx, FK_SLOT_SM_DIG, ctx->slot_cap[FK_SLOT_SM_A] / w.smer_stride + 64) : NULL;
+                           ? (uint8_t *) fk_slot(ctx, FK_SLOT_SM_DIG, 2 * (ctx->slot_cap[FK_SLOT_SM_A] / w.smer_stride + 64)) : NULL;
+                  ctx->dig2_off = ctx->slot_cap[FK_SLOT_SM_A] / w.smer_stride + 64;       // (second plane: hash digit 1)
                   if (sm_dig == NULL) ctx->err[0] = 0;     // (optional: without it the grouping sort makes the stream itself)
                   hipEventRecord(gev[0], s);
                   rc = fkx_split_planned(ctx, d_reads, nbytes, out, ctx->slot_cap[FK_SLOT_SM_A] / w.smer_stride,

@@ -690,8 +690,11 @@ __global__ __launch_bounds__(RXW_THREADS) void k_rx_scatter_w(const u32 *__restr
                                                               const u64 *__restrict__ superpfx,
                                                               const uint8_t *__restrict__ curdig,
                                                               uint8_t *__restrict__ nextdig,
-                                                              int64_t ntiles, int hbytes, int unstable)
-{ constexpr int TILE = RXW_THREADS * ITEMS;
+                                                              int64_t ntiles, int hbytes, int unstable,
+                                                              const uint8_t *__restrict__ carry)
+{ // carry != NULL: the digit the NEXT pass sorts on exists already, record by record in the order of src (the producer
+  // of the records hashed them once and wrote both digits); it travels with the records instead of being hashed again
+  constexpr int TILE = RXW_THREADS * ITEMS;
   static_assert((RX_CH - 1) * TILE < 65536 || RW < 4, "u16 tile prefixes inside a chunk");
   constexpr int NV   = ITEMS * RW / 4;
   constexpr int ND   = ITEMS / 4;
@@ -705,6 +708,7 @@ __global__ __launch_bounds__(RXW_THREADS) void k_rx_scatter_w(const u32 *__restr
   u32      *tmp32    = binstart + 256;                                 // 8
   uint16_t *perm     = (uint16_t *) (tmp32 + 8);                       // TILE: sorted slot -> record
   uint8_t  *tdig     = (uint8_t *) (perm + TILE);                      // TILE: this pass's digit per record
+  uint8_t  *tcar     = tdig + TILE;                                    // TILE: the next pass's, when it is carried
 
   const int tid  = threadIdx.x;
   const int lane = tid & 63;
@@ -718,14 +722,14 @@ __global__ __launch_bounds__(RXW_THREADS) void k_rx_scatter_w(const u32 *__restr
   const int64_t tbase = (int64_t) (blockIdx.x & 7) * per;
 
   uint4 v[NV];
-  u32   dg[ND];
+  u32   dg[ND], dc[ND];
   u64   gp = 0;
 #pragma unroll
   for (int q = 0; q < NV; q++)
     v[q] = make_uint4(0, 0, 0, 0);
 #pragma unroll
   for (int q = 0; q < ND; q++)
-    dg[q] = 0;
+    dg[q] = dc[q] = 0;
 #define RXW_FETCH(T)                                                                              \
   { const int64_t t_ = (T);                                                                       \
     if ((t_ + 1) * TILE <= n)                                                                     \
@@ -737,6 +741,12 @@ __global__ __launch_bounds__(RXW_THREADS) void k_rx_scatter_w(const u32 *__restr
         _Pragma("unroll")                                                                         \
         for (int q = 0; q < ND; q++)                                                              \
           dg[q] = gd[q];                                                                          \
+        if (carry != NULL)                                                                        \
+          { const u32 *gc = (const u32 *) (carry + t_ * TILE) + tid * ND;                         \
+            _Pragma("unroll")                                                                     \
+            for (int q = 0; q < ND; q++)                                                          \
+              dc[q] = gc[q];                                                                      \
+          }                                                                                       \
       }                                                                                           \
     if (tid < 256)                                                                                \
       gp = superpfx[(t_ / (RX_CH * RX_SC)) * 256 + tid] + (u64) chunkpfx[(t_ / RX_CH) * 256 + tid] \
@@ -761,6 +771,12 @@ __global__ __launch_bounds__(RXW_THREADS) void k_rx_scatter_w(const u32 *__restr
 #pragma unroll
           for (int j = 0; j < ND; j++)
             ld[j] = dg[j];
+          if (carry != NULL)
+            { u32 *lc = (u32 *) tcar + tid * ND;
+#pragma unroll
+              for (int j = 0; j < ND; j++)
+                lc[j] = dc[j];
+            }
         }
       else
         { const u32 *gsrc = src + tstart * RW;
@@ -768,6 +784,9 @@ __global__ __launch_bounds__(RXW_THREADS) void k_rx_scatter_w(const u32 *__restr
             recs[i] = gsrc[i];
           for (int i = tid; i < tn; i += RXW_THREADS)
             tdig[i] = curdig[tstart + i];
+          if (carry != NULL)
+            for (int i = tid; i < tn; i += RXW_THREADS)
+              tcar[i] = carry[tstart + i];
         }
       const u64 gpre = gp;
       for (int i = tid; i < RXW_WAVES * 256; i += RXW_THREADS)
@@ -892,11 +911,16 @@ __global__ __launch_bounds__(RXW_THREADS) void k_rx_scatter_w(const u32 *__restr
               rx_rec<RW> r = *(const rx_rec<RW> *) (recs + sr * RW);
               *(rx_rec<RW> *) (dst + o * RW) = r;
               if (next_byte >= 0)
-                { u32 nd = HASHED ? rx_hash_digit<RW>(r.w, next_byte, hbytes)
+                { u32 nd;
+                  if (carry != NULL)
+                    nd = tcar[sr];
+                  else
+                    { nd = HASHED ? rx_hash_digit<RW>(r.w, next_byte, hbytes)
                                   : (u32) lbytes[sr * RW * 4 + next_byte];
 #ifdef FK_ABLATION
-                  if (HASHED && (unstable & RX_ABL_NOHASH)) nd = r.w[0] >> 24;
+                      if (HASHED && (unstable & RX_ABL_NOHASH)) nd = r.w[0] >> 24;
 #endif
+                    }
                   nextdig[o] = (uint8_t) nd;
                 }
             }
@@ -909,7 +933,7 @@ __global__ __launch_bounds__(RXW_THREADS) void k_rx_scatter_w(const u32 *__restr
 
 template <int RW, int ITEMS> static size_t rx_wide_lds_bytes()
 { return ((size_t) RXW_THREADS * ITEMS * RW * 4 + 256 * 8 + RXW_WAVES * 256 * 4 + 256 * 4 + 8 * 4
-          + (size_t) RXW_THREADS * ITEMS * 3 + 16);
+          + (size_t) RXW_THREADS * ITEMS * 4 + 16);          // (perm 2 bytes; this pass's digit 1; the carried one 1)
 }
 
 #ifdef FK_ABLATION
@@ -1154,6 +1178,11 @@ static int lsd_sort_stream_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, c
       FK_LAUNCH_CHECK(ctx);
     }
 
+  // the splitter's second digit plane (hash digit 1 of every record, fk_split.hip): the first pass carries it along
+  // (fk_debug_set("radix_engine", 5): it hashes the records again, as before round 5 -- the tests run both)
+  const uint8_t *carry0 = (HASHED && pre_dig != NULL && ctx->dig2_off > 0 && nrun >= 2 && run[0] == 0 && run[1] == 1
+                           && ctx->dbg_radix_engine != 5)
+                          ? pre_dig + ctx->dig2_off : NULL;
   size_t lds_bytes;
   if constexpr (WT == RX_THREADS) lds_bytes = rx_stream_lds_bytes<RW, ITEMS>();
   else lds_bytes = rx_wide_lds_bytes<RW, ITEMS>();
@@ -1200,7 +1229,8 @@ static int lsd_sort_stream_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, c
                            dim3(RXW_THREADS), lds_bytes, s,
                            (const u32 *) src, trg, n, nextb, (const uint16_t *) tilepfx,
                            (const u32 *) chunkpfx, (const u64 *) superpfx, (const uint8_t *) dcur, dnext, ntiles,
-                           hbytes, ((HASHED && i == 0 && ctx->dbg_radix_engine != 4) ? 1 : 0) | RX_ABL_BITS(ctx));
+                           hbytes, ((HASHED && i == 0 && ctx->dbg_radix_engine != 4) ? 1 : 0) | RX_ABL_BITS(ctx),
+                           (i == 0) ? carry0 : (const uint8_t *) NULL);
       FK_HIP(ctx, hipEventRecord(ctx->pass_ev[2 * i + 1], s));
       FK_LAUNCH_CHECK(ctx);
       u32 *t = src; src = trg; trg = t;

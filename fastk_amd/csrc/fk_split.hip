@@ -94,6 +94,9 @@ struct SplitArgs
   uint8_t  *dig;            // != NULL (20-byte records, one-pass emit): byte 0 of the hash of every record, at the record's
                             // slot -- the first digit stream of the grouping sort that follows (fk_radix.hip), made
                             // while the record is in registers instead of by a pass of its own over all records
+  uint8_t  *dig2;           // ... and byte 1 of the same hash, a second plane indexed alike (dig + fk_ctx.dig2_off): the first
+                            // pass of the grouping sort carries it to the records' new places instead of hashing all
+                            // twenty bytes again (round 5: that hash was 28 % of the pass, profiles/r05_scatter_ablation.json)
 };
 
 __device__ __forceinline__ u32 sp_window(const u32 *arr, int off)
@@ -653,7 +656,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
                       if (a.dig != NULL)
                         { u32 ha, hb;
                           fk_rec_hash<5>((h == 0) ? r0.w : r1.w, 20, ha, hb);
-                          if (h == 0) d0 = hb & 0xffu; else d1 = hb & 0xffu;
+                          if (h == 0) d0 = hb & 0xffffu; else d1 = hb & 0xffffu;
                         }
                     }
                 }
@@ -694,7 +697,10 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
               if (sww == 5)
                 { *(sp_rec5 *) dst = (h == 0) ? r0 : r1;
                   if (a.dig != NULL)
-                    a.dig[slot] = (uint8_t) ((h == 0) ? d0 : d1);
+                    { const u32 dd = (h == 0) ? d0 : d1;
+                      a.dig[slot]  = (uint8_t) dd;
+                      a.dig2[slot] = (uint8_t) (dd >> 8);
+                    }
                 }
               else
                 put_generic(i, flip, (int) ((m >> 13) & 0x7fu), dst);
@@ -733,7 +739,8 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
               sp_put_record5(flip ? rcw : fwd, flip ? (R - (i + L)) : i, L, ((u32) (n - 1)) << lensh, lenw, rr.w);
               u32 ha, hb;
               fk_rec_hash<5>(rr.w, 20, ha, hb);
-              a.dig[slot] = (uint8_t) (hb & 0xffu);
+              a.dig[slot]  = (uint8_t) (hb & 0xffu);
+              a.dig2[slot] = (uint8_t) ((hb >> 8) & 0xffu);
             }
         }
     }
@@ -954,7 +961,8 @@ __global__ __launch_bounds__(SP_THREADS) void k_split_replay(SplitArgs a)
           if (a.dig != NULL)                                   // first digit of the grouping sort, as k_split writes it
             { u32 ha, hb;
               fk_rec_hash<5>(rr.w, 20, ha, hb);
-              a.dig[slot] = (uint8_t) (hb & 0xffu);
+              a.dig[slot]  = (uint8_t) (hb & 0xffu);
+              a.dig2[slot] = (uint8_t) ((hb >> 8) & 0xffu);
             }
         }
       else
@@ -981,7 +989,8 @@ __global__ __launch_bounds__(SP_THREADS) void k_split_replay(SplitArgs a)
 #define SP_CT 1024
 __global__ __launch_bounds__(SP_CT) void k_split_compact(u32 *__restrict__ out, int sww, const u64 *__restrict__ cursor,
                                                          int cstride, int lstreams, const u64 *__restrict__ rbase, int b0,
-                                                         const u32 *__restrict__ overflowed, uint8_t *__restrict__ dig)
+                                                         const u32 *__restrict__ overflowed, uint8_t *__restrict__ dig,
+                                                         uint8_t *__restrict__ dig2)
 { const int b = b0 + blockIdx.x, C = 1 << lstreams, tid = threadIdx.x;
   __shared__ u64 L[1 << SP_LSTREAMS];
   if (*overflowed == 1u)                 // a region was too small: records were dropped, the caller starts over
@@ -1006,9 +1015,12 @@ __global__ __launch_bounds__(SP_CT) void k_split_compact(u32 *__restrict__ out, 
         if (src != dst && dig != NULL)                  // the records' digit bytes move with them (a chunk: <= 1024 of them)
           { const u64 nr = n / (u64) sww, sr = src / (u64) sww, dr = dst / (u64) sww;
             const uint8_t v = ((u64) tid < nr) ? dig[sr + tid] : (uint8_t) 0;
+            const uint8_t v2 = ((u64) tid < nr) ? dig2[sr + tid] : (uint8_t) 0;
             __syncthreads();
             if ((u64) tid < nr)
-              dig[dr + tid] = v;
+              { dig[dr + tid] = v;
+                dig2[dr + tid] = v2;
+              }
             __threadfence_block();
             __syncthreads();
           }
@@ -1050,7 +1062,7 @@ static int sp_finish_streams(fk_ctx *ctx, const SplitArgs &a, int b0, int b1, in
 { hipStream_t s = ctx->stream;
   const int C = 1 << a.lstreams;
   hipLaunchKernelGGL(k_split_compact, dim3((unsigned) (b1 - b0)), dim3(SP_CT), 0, s, a.out, a.sww, (const u64 *) a.cursor,
-                     a.cstride, a.lstreams, a.rbase, b0, (const u32 *) a.overflowed, a.dig);
+                     a.cstride, a.lstreams, a.rbase, b0, (const u32 *) a.overflowed, a.dig, a.dig2);
   FK_LAUNCH_CHECK(ctx);
   u64 *h = ctx->h_scratch + 8192;                  // pinned; (b1 - b0) * C <= 2048 words
   FK_HIP(ctx, hipMemcpy2DAsync(h, sizeof(u64), a.cursor + ((size_t) b0 << a.lstreams) * a.cstride, (size_t) a.cstride * sizeof(u64),
@@ -1313,9 +1325,11 @@ int fkx_split_fast(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void **d_ou
           if (out == NULL)
             return (FK_ENOMEM);
           cap = ctx->slot_cap[FK_SLOT_SM_A] / stride;          // use the headroom too
-          a.dig = (want_dig && !ctx->dig_lost) ? (uint8_t *) fk_slot(ctx, FK_SLOT_SM_DIG, cap + 64) : NULL;
+          a.dig = (want_dig && !ctx->dig_lost) ? (uint8_t *) fk_slot(ctx, FK_SLOT_SM_DIG, 2 * (cap + 64)) : NULL;
           if (want_dig && a.dig == NULL)
             ctx->err[0] = 0;                             // (optional: the grouping sort then makes the stream itself)
+          ctx->dig2_off = cap + 64;                      // the plane of the second digit lies behind the first one's
+          a.dig2 = (a.dig != NULL) ? a.dig + ctx->dig2_off : NULL;
           FK_HIP(ctx, hipMemsetAsync(ctx->d_scratch, 0, 1032 * sizeof(u64), s));
           a.out = (u32 *) out; a.cap = cap; a.tile_stride = 1;
           if (sp_cursors(ctx) == NULL)
@@ -1343,7 +1357,7 @@ int fkx_split_fast(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void **d_ou
               bucket_counts[0] = *nsuper;
               return (FK_OK);
             }
-          a.dig = NULL;
+          a.dig = NULL; a.dig2 = NULL;
           a.cursor = d_cursor; a.cstride = 1; a.lstreams = 0;
           // estimate too small (very uneven input): exact path below
         }
@@ -1358,9 +1372,10 @@ int fkx_split_fast(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void **d_ou
         { void *out = fk_slot(ctx, FK_SLOT_SM_A, cap * stride);
           if (out == NULL)
             return (FK_ENOMEM);
-          uint8_t *dg = (want_dig && !ctx->dig_lost) ? (uint8_t *) fk_slot(ctx, FK_SLOT_SM_DIG, cap + 64) : NULL;
+          uint8_t *dg = (want_dig && !ctx->dig_lost) ? (uint8_t *) fk_slot(ctx, FK_SLOT_SM_DIG, 2 * (cap + 64)) : NULL;
           if (want_dig && dg == NULL)
             ctx->err[0] = 0;                             // (optional: the grouping sort then makes the stream itself)
+          ctx->dig2_off = cap + 64;
           rc = fkx_split_planned(ctx, d_bases, nbytes, out, cap, offs, bc, ninst, 0, -1, 0, pk, dg);
           if (rc == FK_OK && d_dig != NULL)
             *d_dig = dg;
@@ -1533,6 +1548,7 @@ int fkx_split_planned(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_
   a.ent = NULL; a.ent_cursor = ctx->d_cursors + ((size_t) 256 << SP_LSTREAMS) * FK_CURSOR_STRIDE; a.tile_ent = NULL; a.ent_cap = 0;
   a.gb0 = b0; a.gb1 = b1;
   a.dig = (ctx->wid.smer_stride == 20) ? d_dig : NULL;      // (a group pass writes the digits of the records it emits)
+  a.dig2 = (a.dig != NULL) ? a.dig + ctx->dig2_off : NULL;   // (the caller made the slot two planes wide and set dig2_off)
   { const int rcp = sp_packed_args(ctx, a, (mode == 2 && pk != NULL) ? NULL : pk, ntiles);   // (a replay pass needs no tile index)
     if (rcp != FK_OK) return (rcp);
   }

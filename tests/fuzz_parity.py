@@ -86,6 +86,33 @@ def device_reads_report(ctx, pushed):
     return txt
 
 
+class Canaries:
+    """A ring of byte arrays filled with 'a' that turns over with the heap: a few are checked, freed and allocated again every
+    iteration.  A byte that changes was written by something that does not own it (round 5: aligned 32-bit zeros turned up
+    in the harness's own data about once per 2,000 iterations with 32 processes on one GPU)."""
+
+    def __init__(self, n=64, seed=1):
+        self.rng = np.random.default_rng(seed)
+        self.ring = [self._new() for _ in range(n)]
+        self.hits = 0
+
+    def _new(self):
+        return np.full(int(self.rng.integers(1024, 1 << 21)), 0x61, dtype=np.uint8)
+
+    def turn(self, where, k=6):
+        for _ in range(k):
+            i = int(self.rng.integers(0, len(self.ring)))
+            a = self.ring[i]
+            bad = np.nonzero(a != 0x61)[0]
+            if len(bad):
+                self.hits += 1
+                print("CANARY %s: %d bytes changed in an array of %d at 0x%x: %s" % (
+                    where, len(bad), len(a), a.ctypes.data,
+                    ", ".join("+%d (mod 64 = %d) = 0x%02x" % (int(p), (a.ctypes.data + int(p)) % 64, int(a[p])) for p in bad[:12])),
+                    flush=True)
+            self.ring[i] = self._new()
+
+
 def make_reads(rng, k):
     glen = int(rng.integers(500, 40000))
     genome = rng.integers(0, 4, size=glen)
@@ -155,7 +182,10 @@ def run(iters, seed, only=None, first=None, guard=True, quiet=False, max_bytes=N
         first = only if only is not None else 0
     t0 = time.time()
     ran = 0
+    can = Canaries(seed=seed) if os.environ.get("FUZZ_CANARY", "1") != "0" else None
     for it in range(iters):
+        if can is not None:
+            can.turn("seed %d before iteration %d" % (seed, it))
         if budget_s is not None and time.time() - t0 > budget_s:
             break
         dry = only is not None and not (first <= it <= only)
