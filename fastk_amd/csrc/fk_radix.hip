@@ -933,8 +933,8 @@ __global__ __launch_bounds__(RXW_THREADS) void k_rx_scatter_w(const u32 *__restr
 
 template <int RW, int ITEMS> static size_t rx_wide_lds_bytes()
 { return ((size_t) RXW_THREADS * ITEMS * RW * 4 + 256 * 8 + RXW_WAVES * 256 * 4 + 256 * 4 + 8 * 4
-          + (size_t) RXW_THREADS * ITEMS * 4 + 16);          // (perm 2 bytes; this pass's digit 1; the carried one 1)
-}
+          + (size_t) RXW_THREADS * ITEMS * (RW == 5 ? 4 : 3) + 16);   // (perm 2 bytes; this pass's digit 1; the carried one 1 --
+}                                                                        //  only 20-byte records ever bring one: 32-byte tiles fill the LDS)
 
 #ifdef FK_ABLATION
 template <int RW, int ITEMS> static size_t rx_lds_bytes(bool hashed)
@@ -1180,7 +1180,7 @@ static int lsd_sort_stream_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, c
 
   // the splitter's second digit plane (hash digit 1 of every record, fk_split.hip): the first pass carries it along
   // (fk_debug_set("radix_engine", 5): it hashes the records again, as before round 5 -- the tests run both)
-  const uint8_t *carry0 = (HASHED && pre_dig != NULL && ctx->dig2_off > 0 && nrun >= 2 && run[0] == 0 && run[1] == 1
+  const uint8_t *carry0 = (HASHED && RW == 5 && pre_dig != NULL && ctx->dig2_off > 0 && nrun >= 2 && run[0] == 0 && run[1] == 1
                            && ctx->dbg_radix_engine != 5)
                           ? pre_dig + ctx->dig2_off : NULL;
   size_t lds_bytes;
