@@ -141,6 +141,34 @@ int fkx_pinned_free(void *p)
   return (FK_OK);
 }
 
+static pthread_mutex_t g_stream_lock = PTHREAD_MUTEX_INITIALIZER;
+static std::vector<std::pair<int, hipStream_t> > g_stream_pool;      // idle streams, by device
+
+int fkx_stream_get(int device, hipStream_t *s)
+{ *s = NULL;
+  pthread_mutex_lock(&g_stream_lock);
+  for (size_t i = 0; i < g_stream_pool.size(); i++)
+    if (g_stream_pool[i].first == device)
+      { *s = g_stream_pool[i].second;
+        g_stream_pool[i] = g_stream_pool.back();
+        g_stream_pool.pop_back();
+        break;
+      }
+  pthread_mutex_unlock(&g_stream_lock);
+  if (*s != NULL)
+    return (FK_OK);
+  return (hipStreamCreateWithFlags(s, hipStreamNonBlocking) == hipSuccess ? FK_OK : FK_EHIP);
+}
+
+void fkx_stream_put(int device, hipStream_t s)
+{ if (s == NULL)
+    return;
+  (void) hipStreamSynchronize(s);                    // (what goes into the pool is idle)
+  pthread_mutex_lock(&g_stream_lock);
+  g_stream_pool.push_back(std::make_pair(device, s));
+  pthread_mutex_unlock(&g_stream_lock);
+}
+
 int fkx_d2h_pageable(fk_ctx *ctx, hipStream_t s, void *dst, const void *d_src, size_t nbytes)
 { FK_HIP(ctx, hipStreamSynchronize(s));
   if (nbytes > 0)
@@ -348,9 +376,12 @@ extern "C" int fk_create(const fk_params *p, fk_ctx **out)
   }
 #define CK(call) do { if ((call) != hipSuccess) { fk_set_error(NULL, "fk_create: %s failed", #call); \
                                                     fk_destroy(ctx); return (FK_EHIP); } } while (0)
-  CK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  if (fkx_stream_get(ctx->device, &ctx->stream) != FK_OK || fkx_stream_get(ctx->device, &ctx->copy_stream) != FK_OK)
+    { fk_set_error(NULL, "fk_create: hipStreamCreateWithFlags failed");
+      fk_destroy(ctx);
+      return (FK_EHIP);
+    }
   ctx->own_stream = true;
-  CK(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
   CK(hipEventCreateWithFlags(&ctx->reads_ev, hipEventDisableTiming));
   CK(hipEventCreate(&ctx->ev0));
   CK(hipEventCreate(&ctx->ev1));
@@ -411,7 +442,7 @@ extern "C" void fk_destroy(fk_ctx *ctx)
   if (ctx->h_pk) hipHostFree(ctx->h_pk);
   hipFree(ctx->d_min_part);
   free(ctx->min_part);
-  if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
+  fkx_stream_put(ctx->device, ctx->copy_stream);      // (streams go back to the pool, never to hipStreamDestroy: fk_common.h)
   if (ctx->reads_ev) hipEventDestroy(ctx->reads_ev);
   free(ctx->h_prof);
   free(ctx->h_prof_off);
@@ -429,7 +460,7 @@ extern "C" void fk_destroy(fk_ctx *ctx)
   for (int i = 0; i < 128; i++)
     if (ctx->pass_ev[i]) hipEventDestroy(ctx->pass_ev[i]);
   if (ctx->own_stream && ctx->stream != NULL)
-    hipStreamDestroy(ctx->stream);
+    fkx_stream_put(ctx->device, ctx->stream);
   for (int i = 0; i < ctx->nchunks; i++)
     fkx_free_chunk(ctx, &ctx->chunks[i]);
   free(ctx->chunks);
@@ -446,7 +477,7 @@ extern "C" void fk_destroy(fk_ctx *ctx)
   free(ctx->ktab_ends);
   if (ctx->h_wstage) hipHostFree(ctx->h_wstage);
   for (int i = 0; i < 4; i++)
-    if (ctx->wstream[i]) hipStreamDestroy(ctx->wstream[i]);
+    fkx_stream_put(ctx->device, ctx->wstream[i]);
   if (ctx->push_lock)
     { pthread_mutex_destroy((pthread_mutex_t *) ctx->push_lock);
       free(ctx->push_lock);
@@ -526,9 +557,7 @@ extern "C" int fk_set_sort_memory(fk_ctx *ctx, int64_t sort_memory, double input
 extern "C" int fk_set_stream(fk_ctx *ctx, void *hip_stream)
 { if (ctx == NULL) return (FK_EINVAL);
   if (ctx->own_stream && ctx->stream != NULL)
-    { hipStreamSynchronize(ctx->stream);
-      hipStreamDestroy(ctx->stream);
-    }
+    fkx_stream_put(ctx->device, ctx->stream);
   ctx->stream = (hipStream_t) hip_stream;
   ctx->own_stream = false;
   return (FK_OK);
@@ -687,6 +716,12 @@ extern "C" int fk_debug_get(fk_ctx *ctx, const char *key, int64_t *value)
     }
   // where the pushed reads of a resident run lie in HBM and how many bytes they take: for harnesses that compare the
   // device copy with what they pushed (tests/fuzz_parity.py)
+  if (strcmp(key, "stream_pool") == 0)      // idle streams in the process-wide pool (fkx_stream_get / _put)
+    { pthread_mutex_lock(&g_stream_lock);
+      *value = (int64_t) g_stream_pool.size();
+      pthread_mutex_unlock(&g_stream_lock);
+      return (FK_OK);
+    }
   if (strcmp(key, "reads_ptr") == 0 || strcmp(key, "reads_len") == 0)
     { if (getenv("FASTK_AMD_TEST_KNOBS") == NULL)
         return (FK_EINVAL);

@@ -324,6 +324,14 @@ int fkx_collapse(fk_ctx *ctx, const void *d_kmers, int64_t n, void *d_out, int64
 // asynchronous copies as before.)
 int fkx_d2h_pageable(fk_ctx *ctx, hipStream_t s, void *dst, const void *d_src, size_t nbytes);
 int fkx_h2d_pageable(fk_ctx *ctx, hipStream_t s, void *d_dst, const void *src, size_t nbytes);
+// Streams are never destroyed: a context (or shard) takes its non-blocking streams from a process-wide pool and gives
+// them back, idle, when it goes.  Round 5: with the HIP runtime PyTorch-ROCm bundles (the one a Python host of this
+// library runs on), the 920-byte stream object that hipStreamDestroy frees was still written afterwards by the runtime's
+// own bookkeeping -- a counter at +152 decremented, a 32-bit word stored -- and under load (32 processes on one GPU)
+// that memory had by then been handed out again by malloc: aligned 32-bit zeros in data the caller had just built
+// (tests/csrc/freeguard.c names the block and the hipStreamDestroy of fk_destroy that freed it).
+int  fkx_stream_get(int device, hipStream_t *s);
+void fkx_stream_put(int device, hipStream_t s);
 int fkx_pinned_alloc(void **out, int64_t bytes);     // large buffers: huge pages touched in parallel + hipHostRegister
 int fkx_pinned_free(void *p);
 int fkx_reserve_host_table(fk_ctx *ctx, int64_t bytes);      // ctx->h_table: pinned host memory for the result table

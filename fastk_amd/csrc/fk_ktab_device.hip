@@ -90,7 +90,11 @@ static int ktab_staging(fk_ctx *ctx, int nthreads, int ib)
 { const int64_t need = ktab_piece_bytes(ctx, ib) * 2 * nthreads;
   for (int i = 0; i < 4; i++)
     if (ctx->wstream[i] == NULL)
-      FK_HIP(ctx, hipStreamCreateWithFlags(&ctx->wstream[i], hipStreamNonBlocking));
+      { if (fkx_stream_get(ctx->device, &ctx->wstream[i]) != FK_OK)
+          { fk_set_error(ctx, "fk_write_ktab_device: no stream for the part writers");
+            return (FK_EHIP);
+          }
+      }
   if (ctx->wstage_cap >= need)
     return (FK_OK);
   if (ctx->h_wstage) hipHostFree(ctx->h_wstage);
@@ -224,7 +228,11 @@ extern "C" int fk_write_ktab_device(fk_ctx *ctx, const fk_result *res, int nthre
   if (n > 0)
     for (int i = 0; i < 4; i++)
       if (ctx->wstream[i] == NULL)
-        FK_HIP(ctx, hipStreamCreateWithFlags(&ctx->wstream[i], hipStreamNonBlocking));
+        { if (fkx_stream_get(ctx->device, &ctx->wstream[i]) != FK_OK)
+          { fk_set_error(ctx, "fk_write_ktab_device: no stream for the part writers");
+            return (FK_EHIP);
+          }
+      }
   const int lanes = (n > 0) ? (int) std::min<int64_t>(nthreads, std::max<int64_t>(ctx->wstage_cap / (2 * pbytes), 1)) : nthreads;
   unsigned char *h_stage = ctx->h_wstage;
   const double tw1 = fk_wall();

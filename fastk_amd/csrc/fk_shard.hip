@@ -143,7 +143,7 @@ extern "C" void fk_shard_destroy(fk_shard *sh)
     { if (sh->xev[i]) hipEventDestroy(sh->xev[i]);
       if (sh->inbox[i]) hipFree(sh->inbox[i]);
     }
-  if (sh->xs) hipStreamDestroy(sh->xs);
+  fkx_stream_put(sh->ctx->device, sh->xs);
   if (sh->d_small) hipFree(sh->d_small);
   if (sh->h_small) hipHostFree(sh->h_small);
   for (int i = 0; i < 2; i++)
@@ -197,7 +197,7 @@ extern "C" int fk_shard_create(fk_ctx *ctx, int rank, int world, const char *id1
       }
   }
   sh->small_cap = (int64_t) world * ctx->prm.nbuckets + 2 * (FK_HIST_BINS + 1024);
-  if (hipStreamCreateWithFlags(&sh->xs, hipStreamNonBlocking) != hipSuccess
+  if (fkx_stream_get(ctx->device, &sh->xs) != FK_OK
       || hipEventCreateWithFlags(&sh->xev[0], hipEventDisableTiming) != hipSuccess
       || hipEventCreateWithFlags(&sh->xev[1], hipEventDisableTiming) != hipSuccess
       || hipMalloc((void **) &sh->d_small, (size_t) sh->small_cap * 8) != hipSuccess

@@ -29,3 +29,18 @@ def test_guard_catches_a_host_write():
             "import ctypes; ctypes.memset(g.array.ctypes.data + 100, 0, 4)") % os.path.dirname(os.path.abspath(__file__))
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     assert p.returncode != 0 and p.returncode in (-11, 139), (p.returncode, p.stderr[-300:])
+
+
+@pytest.mark.gpu
+def test_contexts_return_their_streams_to_the_pool():
+    """fk_destroy never calls hipStreamDestroy (round 5: the runtime kept writing into the stream object it had freed,
+    tests/csrc/freeguard.c): a context's streams go back to a process-wide pool and the next context runs on them."""
+    import fastk_amd
+    with fastk_amd.Context(kmer=21) as a:
+        n0 = a.debug_get("stream_pool")
+    with fastk_amd.Context(kmer=21) as b:
+        assert b.debug_get("stream_pool") == n0              # b took the two streams a gave back
+        with fastk_amd.Context(kmer=21) as c:
+            assert c.debug_get("stream_pool") == max(n0 - 2, 0)
+    with fastk_amd.Context(kmer=21) as d:
+        assert d.debug_get("stream_pool") == max(n0, 2)
