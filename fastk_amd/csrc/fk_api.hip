@@ -56,6 +56,7 @@ void *fk_slot(fk_ctx *ctx, int slot, int64_t nbytes)
   if (me != hipSuccess)
     { size_t fr = 0, tot = 0;
       int64_t held = 0;
+      (void) hipGetLastError();                 // (the failure is reported here: it must not surface again at the next launch check)
       char    big[256] = "";
       hipMemGetInfo(&fr, &tot);
       for (int i = 0; i < FK_NSLOTS; i++)
@@ -70,6 +71,26 @@ void *fk_slot(fk_ctx *ctx, int slot, int64_t nbytes)
     }
   ctx->slot_ptr[slot] = p;
   ctx->slot_cap[slot] = nbytes;
+  return (p);
+}
+
+uint8_t *fkx_dig_slot(fk_ctx *ctx, int64_t cap)
+{ ctx->dig2_off = 0;
+  if (ctx->dig_lost)
+    return (NULL);
+  const int64_t one = cap + 64;
+  uint8_t *p = NULL;
+  if (!ctx->dig_one_plane && getenv("FASTK_AMD_ONE_DIGIT_PLANE") == NULL)
+    p = (uint8_t *) fk_slot(ctx, FK_SLOT_SM_DIG, 2 * one);
+  if (p != NULL)
+    { ctx->dig2_off = one;
+      return (p);
+    }
+  ctx->dig_one_plane = true;                       // (no second try: a slot that is freed and allocated again every pass
+                                                   //  waits for the driver's wipe of what it gave back)
+  p = (uint8_t *) fk_slot(ctx, FK_SLOT_SM_DIG, one);
+  if (p == NULL)
+    ctx->err[0] = 0;                             // (optional: the grouping sort then makes the stream itself)
   return (p);
 }
 

@@ -238,6 +238,7 @@ struct fk_ctx
                                // this many records (written by the expansion), see lsd_sort_stream_t
   bool       dig_lost;         // the digit stream slot was given up for memory (fk_slot): no bucket of this run may use one
   int64_t    dig2_off;         // bytes from a pointer into the splitter's digit stream to the same record's hash digit 1
+  bool       dig_one_plane;    // a two-plane digit slot did not fit once: this context stays with one plane
   const uint8_t *pre_dig;      // != NULL: the stream of hash digit 0 of the pre_dig_n super-mer records the next grouping
   int64_t    pre_dig_n;        // sorts, written by the splitter beside the records (fk_split.hip)
   int64_t    ex_nweighted, ex_ndistinct;   // totals of the last expand sizing call
@@ -255,6 +256,9 @@ enum { FK_SLOT_SM_A = 0, FK_SLOT_SM_B, FK_SLOT_KM_A, FK_SLOT_KM_B, FK_SLOT_EX_HE
 
 // returns a device buffer of at least nbytes for the given purpose (NULL + error set on failure)
 void *fk_slot(fk_ctx *ctx, int slot, int64_t nbytes);
+// the splitter's digit stream for `cap` records: two planes (hash digits 0 and 1; ctx->dig2_off = distance between them)
+// when the memory is there, one (dig2_off = 0) when only that fits, NULL when neither does -- the stream is an option
+uint8_t *fkx_dig_slot(fk_ctx *ctx, int64_t cap);
 
 void fk_set_error(fk_ctx *ctx, const char *fmt, ...);
 

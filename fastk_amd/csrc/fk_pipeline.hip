@@ -761,10 +761,7 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
                   if (out == NULL) { rc = FK_ENOMEM; break; }
                   sm_a = out;
                   // (the passes write the first digit stream of every bucket's grouping sort beside the records)
-                  sm_dig = (w.smer_stride == 20 && !ctx->dig_lost)
-                           ? (uint8_t *) fk_slot(ctx, FK_SLOT_SM_DIG, 2 * (ctx->slot_cap[FK_SLOT_SM_A] / w.smer_stride + 64)) : NULL;
-                  ctx->dig2_off = ctx->slot_cap[FK_SLOT_SM_A] / w.smer_stride + 64;       // (second plane: hash digit 1)
-                  if (sm_dig == NULL) ctx->err[0] = 0;     // (optional: without it the grouping sort makes the stream itself)
+                  sm_dig = (w.smer_stride == 20) ? fkx_dig_slot(ctx, ctx->slot_cap[FK_SLOT_SM_A] / w.smer_stride) : NULL;
                   hipEventRecord(gev[0], s);
                   rc = fkx_split_planned(ctx, d_reads, nbytes, out, ctx->slot_cap[FK_SLOT_SM_A] / w.smer_stride,
                                          lo, cnt, &nig, gb[g], gb[g + 1], replay ? (g == 0 ? 1 : 2) : 0, pk, sm_dig);

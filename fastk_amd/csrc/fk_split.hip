@@ -699,7 +699,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
                   if (a.dig != NULL)
                     { const u32 dd = (h == 0) ? d0 : d1;
                       a.dig[slot]  = (uint8_t) dd;
-                      a.dig2[slot] = (uint8_t) (dd >> 8);
+                      if (a.dig2 != NULL) a.dig2[slot] = (uint8_t) (dd >> 8);
                     }
                 }
               else
@@ -740,7 +740,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
               u32 ha, hb;
               fk_rec_hash<5>(rr.w, 20, ha, hb);
               a.dig[slot]  = (uint8_t) (hb & 0xffu);
-              a.dig2[slot] = (uint8_t) ((hb >> 8) & 0xffu);
+              if (a.dig2 != NULL) a.dig2[slot] = (uint8_t) ((hb >> 8) & 0xffu);
             }
         }
     }
@@ -962,7 +962,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_split_replay(SplitArgs a)
             { u32 ha, hb;
               fk_rec_hash<5>(rr.w, 20, ha, hb);
               a.dig[slot]  = (uint8_t) (hb & 0xffu);
-              a.dig2[slot] = (uint8_t) ((hb >> 8) & 0xffu);
+              if (a.dig2 != NULL) a.dig2[slot] = (uint8_t) ((hb >> 8) & 0xffu);
             }
         }
       else
@@ -1015,11 +1015,11 @@ __global__ __launch_bounds__(SP_CT) void k_split_compact(u32 *__restrict__ out, 
         if (src != dst && dig != NULL)                  // the records' digit bytes move with them (a chunk: <= 1024 of them)
           { const u64 nr = n / (u64) sww, sr = src / (u64) sww, dr = dst / (u64) sww;
             const uint8_t v = ((u64) tid < nr) ? dig[sr + tid] : (uint8_t) 0;
-            const uint8_t v2 = ((u64) tid < nr) ? dig2[sr + tid] : (uint8_t) 0;
+            const uint8_t v2 = ((u64) tid < nr && dig2 != NULL) ? dig2[sr + tid] : (uint8_t) 0;
             __syncthreads();
             if ((u64) tid < nr)
               { dig[dr + tid] = v;
-                dig2[dr + tid] = v2;
+                if (dig2 != NULL) dig2[dr + tid] = v2;
               }
             __threadfence_block();
             __syncthreads();
@@ -1325,11 +1325,8 @@ int fkx_split_fast(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void **d_ou
           if (out == NULL)
             return (FK_ENOMEM);
           cap = ctx->slot_cap[FK_SLOT_SM_A] / stride;          // use the headroom too
-          a.dig = (want_dig && !ctx->dig_lost) ? (uint8_t *) fk_slot(ctx, FK_SLOT_SM_DIG, 2 * (cap + 64)) : NULL;
-          if (want_dig && a.dig == NULL)
-            ctx->err[0] = 0;                             // (optional: the grouping sort then makes the stream itself)
-          ctx->dig2_off = cap + 64;                      // the plane of the second digit lies behind the first one's
-          a.dig2 = (a.dig != NULL) ? a.dig + ctx->dig2_off : NULL;
+          a.dig = want_dig ? fkx_dig_slot(ctx, cap) : NULL;      // (the plane of the second digit lies behind the first one's)
+          a.dig2 = (a.dig != NULL && ctx->dig2_off > 0) ? a.dig + ctx->dig2_off : NULL;
           FK_HIP(ctx, hipMemsetAsync(ctx->d_scratch, 0, 1032 * sizeof(u64), s));
           a.out = (u32 *) out; a.cap = cap; a.tile_stride = 1;
           if (sp_cursors(ctx) == NULL)
@@ -1372,10 +1369,7 @@ int fkx_split_fast(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void **d_ou
         { void *out = fk_slot(ctx, FK_SLOT_SM_A, cap * stride);
           if (out == NULL)
             return (FK_ENOMEM);
-          uint8_t *dg = (want_dig && !ctx->dig_lost) ? (uint8_t *) fk_slot(ctx, FK_SLOT_SM_DIG, 2 * (cap + 64)) : NULL;
-          if (want_dig && dg == NULL)
-            ctx->err[0] = 0;                             // (optional: the grouping sort then makes the stream itself)
-          ctx->dig2_off = cap + 64;
+          uint8_t *dg = want_dig ? fkx_dig_slot(ctx, cap) : NULL;
           rc = fkx_split_planned(ctx, d_bases, nbytes, out, cap, offs, bc, ninst, 0, -1, 0, pk, dg);
           if (rc == FK_OK && d_dig != NULL)
             *d_dig = dg;
@@ -1548,7 +1542,7 @@ int fkx_split_planned(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_
   a.ent = NULL; a.ent_cursor = ctx->d_cursors + ((size_t) 256 << SP_LSTREAMS) * FK_CURSOR_STRIDE; a.tile_ent = NULL; a.ent_cap = 0;
   a.gb0 = b0; a.gb1 = b1;
   a.dig = (ctx->wid.smer_stride == 20) ? d_dig : NULL;      // (a group pass writes the digits of the records it emits)
-  a.dig2 = (a.dig != NULL) ? a.dig + ctx->dig2_off : NULL;   // (the caller made the slot two planes wide and set dig2_off)
+  a.dig2 = (a.dig != NULL && ctx->dig2_off > 0) ? a.dig + ctx->dig2_off : NULL;   // (fkx_dig_slot made the planes)
   { const int rcp = sp_packed_args(ctx, a, (mode == 2 && pk != NULL) ? NULL : pk, ntiles);   // (a replay pass needs no tile index)
     if (rcp != FK_OK) return (rcp);
   }
