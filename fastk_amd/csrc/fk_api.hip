@@ -80,7 +80,11 @@ uint8_t *fkx_dig_slot(fk_ctx *ctx, int64_t cap)
     return (NULL);
   const int64_t one = cap + 64;
   uint8_t *p = NULL;
-  if (!ctx->dig_one_plane && getenv("FASTK_AMD_ONE_DIGIT_PLANE") == NULL)
+  // The second plane is OFF unless FASTK_AMD_TWO_DIGIT_PLANES=1 asks for it: measured at configs[2] it costs the packed
+  // splitter 21 ms per step (a second scattered byte store per record) and buys the first grouping pass nothing -- with
+  // the digit carried or hashed the pass takes the same 0.35 ms per 35 M records (FK_SORT_TIMING=1): the pass is bound
+  // by its write pattern, not by the hash.  (The ablation that promised 28 % had made the records sorted: DESIGN 11.)
+  if (!ctx->dig_one_plane && getenv("FASTK_AMD_TWO_DIGIT_PLANES") != NULL)
     p = (uint8_t *) fk_slot(ctx, FK_SLOT_SM_DIG, 2 * one);
   if (p != NULL)
     { ctx->dig2_off = one;
@@ -88,6 +92,7 @@ uint8_t *fkx_dig_slot(fk_ctx *ctx, int64_t cap)
     }
   ctx->dig_one_plane = true;                       // (no second try: a slot that is freed and allocated again every pass
                                                    //  waits for the driver's wipe of what it gave back)
+  ctx->dig2_off = 0;
   p = (uint8_t *) fk_slot(ctx, FK_SLOT_SM_DIG, one);
   if (p == NULL)
     ctx->err[0] = 0;                             // (optional: the grouping sort then makes the stream itself)

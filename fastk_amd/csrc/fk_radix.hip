@@ -1248,6 +1248,16 @@ static int lsd_sort_stream_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, c
         sc += ms;
       }
     ctx->sort_stats.scatter_ms_total = sc;
+    if (getenv("FK_SORT_TIMING") != NULL)
+      { fprintf(stderr, "  sort timing: n %lld, R %d, %s, %d passes, digit stream %s, second digit %s:", (long long) n, RW * 4,
+                HASHED ? "hashed" : "keys", nrun, pre_dig != NULL ? "from the producer" : "made here",
+                carry0 != NULL ? "carried" : "hashed / read in the pass");
+        for (int i = 0; i < nrun; i++)
+          { FK_HIP(ctx, hipEventElapsedTime(&ms, ctx->pass_ev[2 * i], ctx->pass_ev[2 * i + 1]));
+            fprintf(stderr, " %.3f ms", ms);
+          }
+        fprintf(stderr, "\n");
+      }
   }
   *result = (void *) src;
   return (FK_OK);

@@ -453,10 +453,15 @@ def test_count_device_packed_matches_reference_golden(name):
     (no ASCII anywhere) -- one bucket; 5 buckets in one pass; 7 buckets in 3 split passes with entry replay and
     without.  Same histogram and table as the reference."""
     case, bases, boff = util.load_case(name)
-    # (radix_engine 5: the first grouping pass of the super-mers hashes every record again for its second digit, as
-    #  before round 5, instead of carrying the splitter's second digit plane along -- both give the same bins)
+    # ("planes": the splitter also writes hash digit 1 of every record and the first grouping pass of the super-mers
+    #  carries it along instead of hashing the record again -- round 5's experiment, off by default (it did not pay))
+    import os
     for kw, dbg in ((dict(), {}), (dict(nbuckets=5), {}), (dict(nbuckets=7, split_passes=3), {}),
-                    (dict(nbuckets=7, split_passes=3), {"split_replay": 0}), (dict(nbuckets=5), {"radix_engine": 5})):
+                    (dict(nbuckets=7, split_passes=3), {"split_replay": 0}), (dict(nbuckets=5), {"planes": 1})):
+        if dbg.pop("planes", 0):
+            os.environ["FASTK_AMD_TWO_DIGIT_PLANES"] = "1"
+        else:
+            os.environ.pop("FASTK_AMD_TWO_DIGIT_PLANES", None)
         with fastk_amd.Context(kmer=case["k"], table_cutoff=case["cutoff"], nthreads=case["T"], **kw) as ctx:
             for key, val in dbg.items():
                 ctx.debug_set(key, val)
@@ -466,6 +471,7 @@ def test_count_device_packed_matches_reference_golden(name):
             for b in bufs:
                 if b is not None:
                     b.free()
+    os.environ.pop("FASTK_AMD_TWO_DIGIT_PLANES", None)
 
 
 def test_packed_and_ascii_splitters_agree_on_ragged_reads():
