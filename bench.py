@@ -17,8 +17,8 @@ N > 1 (default --config 3) = BASELINE.json configs[3]: the SAME 3 Gbp HiFi-shape
 (strong scaling: the N = 1 line above is its first point), counted through the C engine's sharded entry
 points: rank r owns read stripe r, super-mers travel by minimizer bucket with grouped ncclSend/ncclRecv in
 rounds that overlap the counting, histograms are all-reduced (fk_shard_count_device, fastk_amd/csrc/
-fk_shard.hip).  --config 1 with N > 1 is round 1's weak-scaling run of configs[1] per GPU through the
-torch.distributed harness (fastk_amd/shard.py).
+fk_shard.hip).  --config 1 with N > 1 is configs[1]'s workload PER GPU (weak scaling) through the same C engine
+(round 5: the torch.distributed harness it used to run through is test infrastructure now, tests/shard_model.py).
 
 The line also carries (N = 1):
   roofline      dominant radix kernel (k_rx_scatter over the weighted k-mer records): algorithmic
@@ -94,7 +94,7 @@ def parse():
     ap.add_argument("--e2e-scale", type=float, default=1.0,
                     help="value_e2e runs on this fraction of the genome (1 = the full 150 GB FASTA)")
     ap.add_argument("--force-shard", action="store_true",
-                    help="run the sharded (all-to-all) path even on one GPU: exercises RCCL + shard.py")
+                    help="run the sharded path (fk_shard_*: split, exchange, count, gather) even on one GPU")
     ap.add_argument("--stream-buckets", type=int, default=None,
                     help="minimizer buckets counted one after the other, N=1 only")
     ap.add_argument("--split-passes", type=int, default=None,
@@ -534,14 +534,14 @@ def shim_leg(args, cfg):
         subprocess.run(["rm", "-rf", d])
 
 
-def main_config3(args, cfg, torch, fastk_amd, dist, rank, local_rank, world, dev):
+def main_config3(args, cfg, torch, fastk_amd, dist, rank, local_rank, world, dev, weak=False):
     """BASELINE configs[3]: the 50x HiFi-shaped 3 Gbp set of configs[2], striped over the GPUs (rank r generates
     reads r*n/world ..), counted through the C engine's sharded entry points (fk_shard_count_device: planned
     split, grouped ncclSend/ncclRecv of the records in overlapped rounds, per-rank counting, ncclAllReduce).
     Total work is fixed: strong scaling.  One process per GPU; torch.distributed only hands the RCCL id round
     and provides the barrier of the timing contract."""
     L = cfg["read_len"]
-    glen = int(cfg["genome_mbp"] * 1e6 * args.scale)
+    glen = int(cfg["genome_mbp"] * 1e6 * args.scale) * (world if weak else 1)
     total_reads = int(cfg["coverage"] * glen / L) // world * world
     per = total_reads // world
     first = rank * per
@@ -653,13 +653,13 @@ def main_config3(args, cfg, torch, fastk_amd, dist, rank, local_rank, world, dev
     out = dict(metric="canonical k-mers/sec (k=%d, whole hot path incl. the final gather of the table to host memory, reads resident "
                       "in HBM %s)" % (args.kmer, "as 0-terminated ASCII" if codes is None else "in two bits per base"),
                value=last.ninst / (dt / args.steps), unit="k-mers/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
-               ms_per_step=1e3 * dt / args.steps, higher_is_better=True, scaling="strong", vs_baseline=None,
+               ms_per_step=1e3 * dt / args.steps, higher_is_better=True, scaling="weak" if weak else "strong", vs_baseline=None,
                dtype="u8", data="synthetic",
                gather_ms=round(1e3 * gather_s / args.steps, 3), count_ms=round(1e3 * (dt - gather_s) / args.steps, 3),
                rccl_ranks=per_rank[0]["comm_ranks"], exchange=per_rank,
                hist_file_sha256=hist_file_sha256(args.kmer, last.hist, last.max_inst),
                value_without_gather=last.ninst / max((dt - gather_s) / args.steps, 1e-9),
-               config=dict(workload=cfg["label"] % (cfg["genome_mbp"] * args.scale, "", args.kmer) + scale_note,
+               config=dict(workload=cfg["label"] % (cfg["genome_mbp"] * args.scale, " per GPU" if weak else "", args.kmer) + scale_note,
                            reads_per_gpu=per, bases_per_gpu=per * L, kmer_instances=int(last.ninst),
                            supermers=int(last.nsuper), weighted_kmers=int(last.nweighted),
                            distinct_kmers=int(last.ndistinct), table_entries=int(last.ntable), table_cutoff=cfg["cutoff"],
@@ -744,13 +744,18 @@ def roofline_record(loc, w, cfg_id, ceiling, ceiling_kernel):
                     pass_total_achieved=gbs(algo_s, loc.ms_pass_super)))
 
 
+def train_buckets(ctx, reads, nbytes, sample_bytes=8 << 20):
+    """Balance the minimizer buckets on a sample of the reads (scheme set-up, like Determine_Scheme: not a step)."""
+    sample = reads[:min(nbytes, sample_bytes)].cpu().numpy()
+    ctx.set_bucket_weights(ctx.bucket_census(sample))
+
+
 def packed_resident_leg(args, cfg, fastk_amd, torch, dev, local_rank, reads, nbytes, per, L, ceiling, ceiling_kernel):
     """The same step with the reads resident in TWO BITS PER BASE (fk_count_device_packed): 37.5 GB instead of 150 GB,
     so that every super-mer record fits beside them -- one split pass, no replay -- and the splitter's tile loader
     converts nothing.  The caller's ASCII reads are packed on the device first (not timed: the form is the leg's
     input) and released; returns the record for the JSON line."""
     import hashlib
-    from fastk_amd import shard
     nbases = per * L
     ctx = fastk_amd.Context(kmer=args.kmer, table_cutoff=cfg["cutoff"], nthreads=4, device=local_rank,
                             nbuckets=max(1, cfg["buckets"]), split_passes=1)
@@ -767,10 +772,9 @@ def packed_resident_leg(args, cfg, fastk_amd, torch, dev, local_rank, reads, nby
 
 def _packed_resident_leg(args, cfg, ctx, torch, dev, reads, nbytes, per, L, ceiling, ceiling_kernel):
     import hashlib
-    from fastk_amd import shard
     nbases = per * L
     if cfg["buckets"] > 1:
-        shard.HipEngine(ctx, dev).train_buckets(reads[:nbytes], sample_bytes=8 << 20)
+        train_buckets(ctx, reads, nbytes)
     codes = torch.empty((nbases + 3) // 4 + 64, dtype=torch.uint8, device=dev)
     ctx._ck(ctx.L.fk_pack_fixed_reads(ctx.h, reads.data_ptr(), per, L, codes.data_ptr()))
     roff = torch.arange(per + 1, dtype=torch.int64, device=dev) * L
@@ -822,7 +826,6 @@ def main():
 
     import torch
     import fastk_amd
-    from fastk_amd import shard
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
@@ -855,8 +858,11 @@ def main():
     args.e2e_threads = 32 if cfg_id == 2 else 4
     args.e2e_mem_gb = 256 if cfg_id == 2 else 64
 
-    if cfg_id == 3:
-        return main_config3(args, cfg, torch, fastk_amd, dist if sharded else None, rank, local_rank, world, dev)
+    if cfg_id == 3 or sharded:
+        # every sharded run goes through the C engine (fk_shard_*): configs[3] -- the configs[2] set striped over the GPUs,
+        # strong scaling -- or, with --config 1, configs[1]'s workload PER GPU (weak scaling: genome and reads grow with N)
+        return main_config3(args, cfg, torch, fastk_amd, dist if sharded else None, rank, local_rank, world, dev,
+                            weak=(cfg_id != 3))
 
     L = cfg["read_len"]
     glen = int(cfg["genome_mbp"] * 1e6 * args.scale) * world
@@ -879,17 +885,12 @@ def main():
     ctx._ck(ctx.L.fk_synth_reads(ctx.h, args.seed, glen, L, cfg["err_ppm"], first, per,
                                  reads.data_ptr()))
     torch.cuda.synchronize()
-    engine = shard.HipEngine(ctx, dev)
-    if sharded or nbuckets > 1:
-        engine.train_buckets(reads[:nbytes], sample_bytes=(2 << 20) if sharded else (8 << 20))
-        # (scheme set-up on a sample, like Determine_Scheme: not a step)
+    assert not sharded                                 # (every sharded run went to main_config3 above: one rank, one context here)
+    if nbuckets > 1:
+        train_buckets(ctx, reads, nbytes)              # (scheme set-up on a sample, like Determine_Scheme: not a step)
 
     def step(verify=False):
-        if not sharded:
-            return ctx.count_device_reads(reads.data_ptr(), nbytes, fetch_table=False)
-        if args.exchange_rounds > 1:
-            return shard.count_sharded_rounds(engine, reads[:nbytes], args.exchange_rounds, verify=verify)
-        return shard.count_sharded(engine, reads[:nbytes], verify=verify)
+        return ctx.count_device_reads(reads.data_ptr(), nbytes, fetch_table=False)
 
     def barrier():
         torch.cuda.synchronize()

@@ -358,7 +358,7 @@ __global__ __launch_bounds__(RX_THREADS) void k_radix_pass(const u32 *__restrict
 #define RX_SC 256
 // -DFK_ABLATION builds (WRONG output; tools/scatter_ablation.py): bits of the scatter kernels' `unstable` argument, set
 // from fk_debug_set("scatter_abl", bits) -- what a pass would cost without one of its parts
-#define RX_ABL_NOHASH 0x100     // hashed passes: the next pass's digit is a byte of the record, not a hash of it
+#define RX_ABL_NOHASH 0x100     // hashed passes: the next pass's digit is a byte of the record (another one every pass), not a hash of it
 #define RX_ABL_LINEAR 0x200     // the records leave in tile order (whole lines, no scatter): the bound of any write combining
 #define RX_ABL_NOPERM 0x400     // sorted slot p takes record p (no LDS gather)
 #define RX_ABL_NORANK 0x800     // no ranking: every record gets rank 0 of its wave's bin (no ballots, no LDS atomics)
@@ -654,7 +654,7 @@ __global__ __launch_bounds__(RX_THREADS) void k_rx_scatter(const u32 *__restrict
             { u32 nd = HASHED ? rx_hash_digit<RW>(r.w, next_byte, hbytes)
                               : (u32) lbytes[sr * RW * 4 + next_byte];
 #ifdef FK_ABLATION
-              if (HASHED && (unstable & RX_ABL_NOHASH)) nd = r.w[0] >> 24;
+              if (HASHED && (unstable & RX_ABL_NOHASH)) nd = (r.w[0] >> (8 * (next_byte & 3))) & 0xffu;   // (a byte that differs from pass to pass: the same byte every time would leave the records SORTED after two passes and the later ones would write whole lines -- the first version of this ablation measured that, not the hash)
 #endif
               nextdig[o] = (uint8_t) nd;
             }
@@ -918,7 +918,7 @@ __global__ __launch_bounds__(RXW_THREADS) void k_rx_scatter_w(const u32 *__restr
                     { nd = HASHED ? rx_hash_digit<RW>(r.w, next_byte, hbytes)
                                   : (u32) lbytes[sr * RW * 4 + next_byte];
 #ifdef FK_ABLATION
-                      if (HASHED && (unstable & RX_ABL_NOHASH)) nd = r.w[0] >> 24;
+                      if (HASHED && (unstable & RX_ABL_NOHASH)) nd = (r.w[0] >> (8 * (next_byte & 3))) & 0xffu;   // (a byte that differs from pass to pass: the same byte every time would leave the records SORTED after two passes and the later ones would write whole lines -- the first version of this ablation measured that, not the hash)
 #endif
                     }
                   nextdig[o] = (uint8_t) nd;

@@ -1,4 +1,9 @@
-"""Minimizer-bucket sharding of the counting path across the GPUs of one node.
+"""TEST INFRASTRUCTURE: a model of the sharded run's protocol (C1 bucket exchange, C2 all-reduce, C3 final gather, the two
+profile routes) over torch.distributed, behind a small engine interface -- so that the exchange logic runs on CPU with
+gloo and a checker engine built from the oracle (tests/test_shard_gloo.py, world size 2), and on RCCL ranks sharing
+one GPU with the HIP stages (tools/ranks_on_one_gpu.py).  The PRODUCT's implementation of C1-C3 is the C engine,
+fastk_amd/csrc/fk_shard.hip (fk_shard_*: RCCL called from C) -- what `FastK_amd -G<n>` and `bench.py --gpus N` run; until
+round 5 this module lived in the package (fastk_amd/shard.py) and bench.py's --config 1 ran through it.
 
 One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  Every rank splits its
 own stripe of reads into super-mers grouped by bucket; bucket b belongs to rank b (a bucket is a
@@ -15,7 +20,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from .api import Context, HIST_BINS
+from fastk_amd.api import Context, HIST_BINS
 
 
 class HipEngine:
@@ -297,7 +302,7 @@ def write_table_sharded(table, wfirst, ntable, kmer, cutoff, parts_per_rank, out
     global entry count (fixes the index width).  sort_fn orders the received runs (HipEngine.sort_table).
     The files are what fk_write_ktab writes from the merged table with nthreads = world x
     parts_per_rank.  outdir must be shared by the ranks."""
-    from . import api
+    from fastk_amd import api
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" \

@@ -1,4 +1,4 @@
-"""The N>1 path on CPU: world_size-2 gloo run of fastk_amd.shard.count_sharded with a checker
+"""The N>1 path on CPU: world_size-2 gloo run of tests.shard_model.count_sharded with a checker
 engine built from the oracle (tests may use the oracle; the product engine is HipEngine).
 Verifies the exchange logic: bucket -> rank routing, all-to-all-v sizes, histogram all-reduce."""
 import os
@@ -185,7 +185,7 @@ def _worker(rank, world, port, name, q, outdir, rounds=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from fastk_amd import shard
+    from tests import shard_model as shard
     shard.MAX_PAIR_BYTES = 4096       # force the multi-round exchange
     case, bases, boff = util.load_case(name)
     nreads = len(boff) - 1
@@ -258,7 +258,7 @@ def _prof_worker(rank, world, port, name, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from fastk_amd import shard
+    from tests import shard_model as shard
     shard.MAX_PAIR_BYTES = 4096
     case, bases, boff = util.load_case(name)
     nreads = len(boff) - 1
@@ -302,7 +302,7 @@ def _xprof_worker(rank, world, port, name, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from fastk_amd import shard
+    from tests import shard_model as shard
     shard.MAX_PAIR_BYTES = 4096
     case, bases, boff = util.load_case(name)
     nreads = len(boff) - 1

@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch                                                         # noqa: E402
 import torch.distributed as dist                                     # noqa: E402
 import fastk_amd                                                     # noqa: E402
-from fastk_amd import shard                                          # noqa: E402
+from tests import shard_model as shard                                          # noqa: E402
 
 cov = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 G = int(sys.argv[2]) if len(sys.argv) > 2 else 100_000_000

@@ -38,7 +38,7 @@ def worker():
     import torch
     import torch.distributed as dist
     import fastk_amd
-    from fastk_amd import shard
+    from tests import shard_model as shard
 
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)

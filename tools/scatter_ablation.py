@@ -5,8 +5,8 @@ with ABLATION=1 first: `make -C fastk_amd/csrc ABLATION=1 -B`, and rebuild witho
 A hashed two-pass grouping (fk_group_records: the pipeline's sort of the weighted k-mers, R = 12, and of the super-mers,
 R = 20) of n random records, scatter kernels timed by the library's own event pairs (fk_get_sort_stats), with the
 ablation bits of fk_radix.hip set one at a time -- the OUTPUT IS WRONG, the times bound what removing that part can buy:
-  nohash   the next pass's digit is a byte of the record instead of a hash of it (a second digit stream carried from the
-           producer would remove the hash from the first pass)
+  nohash   the next pass's digit is a byte of the record (another byte every pass) instead of a hash of it: what carrying
+           a second digit stream from the producer could save at most
   linear   the records leave in tile order: whole lines, no scatter (the bound of any write combining through LDS)
   noperm   no LDS gather by the permutation
   norank   no ballots / LDS atomics

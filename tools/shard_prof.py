@@ -3,7 +3,7 @@ sys.path.insert(0, "/root/repo")
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
 import torch, torch.distributed as dist
 import fastk_amd
-from fastk_amd import shard
+from tests import shard_model as shard
 torch.cuda.set_device(0)
 dev = torch.device("cuda", 0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
