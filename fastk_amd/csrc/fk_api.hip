@@ -502,7 +502,6 @@ extern "C" void fk_destroy(fk_ctx *ctx)
   free(ctx->h_roff);
   free(ctx->ktab_ends);
   if (ctx->h_wstage) hipHostFree(ctx->h_wstage);
-  hipFree(ctx->d_wstage);
   for (int i = 0; i < 4; i++)
     fkx_stream_put(ctx->device, ctx->wstream[i]);
   if (ctx->push_lock)

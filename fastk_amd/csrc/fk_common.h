@@ -158,8 +158,6 @@ struct fk_ctx
   int64_t    ktab_first[257];   // ... and where every first key byte begins
   unsigned char *h_wstage;      // pinned staging of the part writers (two pieces each), made before the release starts
   int64_t    wstage_cap;
-  unsigned char *d_wstage;      // ... and its twin in HBM: the strip kernel writes there and a copy engine brings the piece over
-  int64_t    d_wstage_cap;      //     (kernel stores across PCIe ran at about half the link's rate); NULL: the kernel stores to h_wstage
   hipStream_t wstream[4];       // ... and their streams (writer t uses wstream[t % 4]; creating one per writer takes longer than the writing)
   int64_t    ktab_ends_ntab;
   int        ktab_ends_ib;

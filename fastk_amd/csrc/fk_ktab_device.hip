@@ -106,16 +106,6 @@ static int ktab_staging(fk_ctx *ctx, int nthreads, int ib)
       return (FK_ENOMEM);
     }
   ctx->wstage_cap = need;
-  // the device twin: optional (after a run that fills the HBM it may not fit: the strip kernel then stores across PCIe)
-  if (ctx->d_wstage != NULL) hipFree(ctx->d_wstage);
-  ctx->d_wstage = NULL;
-  ctx->d_wstage_cap = 0;
-  if (getenv("FASTK_AMD_KTAB_HOST_STORES") == NULL && hipMalloc((void **) &ctx->d_wstage, (size_t) need) == hipSuccess)
-    ctx->d_wstage_cap = need;
-  else
-    { (void) hipGetLastError();
-      ctx->d_wstage = NULL;
-    }
   return (FK_OK);
 }
 
@@ -262,22 +252,12 @@ extern "C" int fk_write_ktab_device(fk_ctx *ctx, const fk_result *res, int nthre
               && hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) == hipSuccess);
       const int ln = t % lanes;                           // (parts t, t + lanes, ... are written one after the other)
       unsigned char *pin[2] = { h_stage + pbytes * (2 * ln), h_stage + pbytes * (2 * ln + 1) };
-      unsigned char *dpin[2] = { NULL, NULL };              // the pieces' places in HBM, when the device twin exists
-      if (ctx->d_wstage != NULL && ctx->d_wstage_cap >= pbytes * (2 * ln + 2))
-        { dpin[0] = ctx->d_wstage + pbytes * (2 * ln); dpin[1] = ctx->d_wstage + pbytes * (2 * ln + 1); }
       auto fetch = [&](int64_t x, int which) -> bool
         { const int64_t m = std::min(hi, x + piece) - x;
           hipLaunchKernelGGL(k_ktab_strip, dim3((unsigned) ((m + KS_E - 1) / KS_E)), dim3(256), (size_t) KS_E * ST + 64, st,
                              table + x * ST, m, ST, ib, (int) w.kmer_bytes, (u32) ((0x100000000ull + (u64) pw - 1) / (u64) pw),
-                             dpin[which] != NULL ? dpin[which] : pin[which]);
-          if (hipGetLastError() != hipSuccess)
-            return (false);
-          // made in HBM, brought over by a copy engine (57 GB/s; the kernel's own stores across PCIe reached ~30); without
-          // the device twin the kernel has stored into the pinned buffer itself
-          if (dpin[which] != NULL
-              && hipMemcpyAsync(pin[which], dpin[which], (size_t) ((m * pw + 15) & ~15ll), hipMemcpyDeviceToHost, st) != hipSuccess)
-            return (false);
-          return (hipEventRecord(ev[which], st) == hipSuccess);
+                             pin[which]);                                    // stored across PCIe as it is made
+          return (hipGetLastError() == hipSuccess && hipEventRecord(ev[which], st) == hipSuccess);
         };
       int which = 0;
       double t_wait = 0., t_write = 0.;
