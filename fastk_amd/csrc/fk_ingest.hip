@@ -529,7 +529,19 @@ extern "C" int fk_push_packed(fk_ctx *ctx, const uint8_t *codes, int64_t nbases,
       // (a copy KERNEL reading the pinned block across PCIe instead of hipMemcpyAsync was tried in round 4: 1.40 s
       //  instead of 1.15 s inside the 2,236 pushes of configs[2] -- the ~32 GB/s of these 17 MB blocks is not the
       //  copy engine's set-up)
-      if ((cbytes > 0 && hipMemcpyAsync(ctx->d_reads + ctx->reads_len, codes, (size_t) cbytes, hipMemcpyHostToDevice, ps) != hipSuccess)
+      // the caller's codes: asynchronously only from memory the runtime knows as pinned (FastK_amd's reader threads pack
+      // into fk_host_alloc'ed buffers); from pageable memory with a blocking copy (fkx_h2d_pageable, fk_common.h)
+      bool pinned_src = false;
+      { hipPointerAttribute_t at;
+        if (cbytes > 0 && hipPointerGetAttributes(&at, codes) == hipSuccess)
+          pinned_src = (at.type == hipMemoryTypeHost);
+        else
+          (void) hipGetLastError();
+      }
+      if (cbytes > 0 && !pinned_src && (rc = fkx_h2d_pageable(ctx, ps, ctx->d_reads + ctx->reads_len, codes, (size_t) cbytes)) != FK_OK)
+        break;
+      if ((cbytes > 0 && pinned_src
+           && hipMemcpyAsync(ctx->d_reads + ctx->reads_len, codes, (size_t) cbytes, hipMemcpyHostToDevice, ps) != hipSuccess)
           || hipMemcpyAsync(st->roff + st->nreads, hro, (size_t) (nreads + 1) * 8, hipMemcpyHostToDevice, ps) != hipSuccess
           || (ninv + pad > 0
               && hipMemcpyAsync(st->inv + 2 * st->ninv, hinv, (size_t) (ninv + pad) * 16, hipMemcpyHostToDevice, ps) != hipSuccess))

@@ -44,15 +44,9 @@ __device__ __forceinline__ int xs_code(unsigned ch)
   return ok ? (int) (x ^ (x >> 1)) : 4;
 }
 
-// The ring of the last 2 * nextpow2(K) minimizer values of a thread lives in LDS, entry i of thread t at ring[i * T + t]
-// (consecutive threads, consecutive banks): as a private array indexed at run time it was scratch memory, a trip to the
-// caches for every position and every step of a rescan (round 5: the kernel's time halved).  T = blockDim.x: 128 threads
-// for k <= 64, 64 beyond (64 KB either way).
 template <bool EMIT>
 __global__ __launch_bounds__(XS_THREADS) void k_split_exact(ExactArgs a)
-{ extern __shared__ u32 xs_ring[];
-  const int T = (int) blockDim.x;
-  const int64_t r = (int64_t) blockIdx.x * T + threadIdx.x;
+{ const int64_t r = (int64_t) blockIdx.x * XS_THREADS + threadIdx.x;
   if (r >= a.nreads)
     return;
   const int K   = a.kmer;
@@ -72,7 +66,7 @@ __global__ __launch_bounds__(XS_THREADS) void k_split_exact(ExactArgs a)
   while (rmsk < K) rmsk <<= 1;
   rmsk = 2 * rmsk - 1;
 
-  u32 *ring = xs_ring + threadIdx.x;      // (min(c,u) << 1) | (u < c); entry i at ring[(i & rmsk) * T]
+  u32 ring[XS_RING];                      // (min(c,u) << 1) | (u < c)
   const int t0 = a.tran[0], t1 = a.tran[1], t2 = a.tran[2], t3 = a.tran[3];
   auto fwv = [&](int code) -> unsigned { return (unsigned) (code == 1 ? t1 : code == 2 ? t2 : code == 3 ? t3 : t0); };
   auto rcv = [&](int code) -> unsigned { return (unsigned) (code == 1 ? t2 : code == 2 ? t1 : code == 3 ? t0 : t3) << (2 * PL1); };
@@ -129,7 +123,7 @@ __global__ __launch_bounds__(XS_THREADS) void k_split_exact(ExactArgs a)
       if (p >= PL1)
         { const unsigned fl = (u < c);
           mp = fl ? u : c;
-          ring[(p & rmsk) * T] = (mp << 1) | fl;
+          ring[p & rmsk] = (mp << 1) | fl;
           if (mp < mc)
             { m = p; mc = mp; }
         }
@@ -151,7 +145,7 @@ __global__ __launch_bounds__(XS_THREADS) void k_split_exact(ExactArgs a)
           u = (u >> 2) | rcv(code);
           const unsigned fl = (u < c);
           mp = fl ? u : c;
-          ring[(p & rmsk) * T] = (mp << 1) | fl;
+          ring[p & rmsk] = (mp << 1) | fl;
           force   = (p - m >= MS);
           closing = force || (mp < mc);
         }
@@ -176,14 +170,14 @@ __global__ __launch_bounds__(XS_THREADS) void k_split_exact(ExactArgs a)
           else
             n = p - last;
           if (n > 0)
-            emit(last, n, ring[(m & rmsk) * T] & 1, mc);
+            emit(last, n, ring[m & rmsk] & 1, mc);
           if (done)
             break;
           if (force)                                         // split.c:1304-1320
             { m += 1;
-              mc = ring[(m & rmsk) * T] >> 1;
+              mc = ring[m & rmsk] >> 1;
               for (int j = m + 1; j <= p; j++)
-                { const unsigned v = ring[(j & rmsk) * T] >> 1;
+                { const unsigned v = ring[j & rmsk] >> 1;
                   if (v <= mc)
                     { m = j; mc = v; }
                 }
@@ -288,14 +282,9 @@ int fkx_split_exact(fk_ctx *ctx, const void *d_bases, const int64_t *d_roff, int
   a.pad_len = 5 + ((nparts > 1) ? ctx->scheme_pad : 0);
   a.pad2 = (nparts > 1) ? 2 * ctx->scheme_pad : 0;
   a.trie = (nparts > 1) ? ctx->d_min_part : NULL;
-  int rsz = 1;                                   // entries of a thread's ring: 2 * nextpow2(K)
-  while (rsz < a.kmer) rsz <<= 1;
-  rsz *= 2;
-  const int T = (rsz <= 128) ? XS_THREADS : XS_THREADS / 2;
-  const size_t lds = (size_t) rsz * T * sizeof(u32);
-  const unsigned grid = (unsigned) ((nreads + T - 1) / T);
+  const unsigned grid = (unsigned) ((nreads + XS_THREADS - 1) / XS_THREADS);
   FK_HIP(ctx, hipMemsetAsync(d_inst, 0, 72 * sizeof(u64), s));
-  hipLaunchKernelGGL(k_split_exact<false>, dim3(grid), dim3(T), lds, s, a);
+  hipLaunchKernelGGL(k_split_exact<false>, dim3(grid), dim3(XS_THREADS), 0, s, a);
   hipLaunchKernelGGL(k_exscan_tiles, dim3(1), dim3(256), 0, s, (const u32 *) d_cnt, nreads * nparts, d_off,
                      d_inst + 64);
   FK_LAUNCH_CHECK(ctx);
@@ -321,7 +310,7 @@ int fkx_split_exact(fk_ctx *ctx, const void *d_bases, const int64_t *d_roff, int
     return (FK_ENOMEM);
   a.out = (u32 *) out;
   FK_HIP(ctx, hipMemsetAsync(d_inst, 0, 72 * sizeof(u64), s));
-  hipLaunchKernelGGL(k_split_exact<true>, dim3(grid), dim3(T), lds, s, a);
+  hipLaunchKernelGGL(k_split_exact<true>, dim3(grid), dim3(XS_THREADS), 0, s, a);
   FK_LAUNCH_CHECK(ctx);
   *d_out = out;
   return (FK_OK);
