@@ -14,7 +14,7 @@
 typedef unsigned long long u64;
 typedef unsigned int       u32;
 
-#define FK_NSLOTS 53
+#define FK_NSLOTS 56
 
 // Reads in two bits per base (fk_push_packed, fk_count_device_packed): the splitter's tile loader reads this form
 // directly.  codes = 16 bases per little-endian dword, the first base in the two high bits of the first byte (a c g t =
@@ -211,6 +211,7 @@ struct fk_ctx
   // so that a repeated workload performs no hipMalloc/hipFree inside the hot path
   int        dbg_radix_variant;   // measurement aids, see fk_debug_set
   int        dbg_radix_items;
+  int        dbg_exact_segments;  // -1: the exact splitter keeps one thread per read (no segments inside long reads)
   int        dbg_scatter_abl;     // -DFK_ABLATION builds: RX_ABL_* bits of the stream engine's scatter kernels (fk_radix.hip)
   int        dbg_radix_engine;    // 1 = look-back engine instead of the stream engine
   int        dbg_kmer_stage;      // 1 = sort-collapse-sort k-mer stage instead of hash aggregation
@@ -252,7 +253,7 @@ enum { FK_SLOT_SM_A = 0, FK_SLOT_SM_B, FK_SLOT_KM_A, FK_SLOT_KM_B, FK_SLOT_EX_HE
        FK_SLOT_RAW, FK_SLOT_FQ_INFO, FK_SLOT_FQ_PHASE, FK_SLOT_FQ_OFF, FK_SLOT_TIE_A, FK_SLOT_TIE_B,
        FK_SLOT_TIE_POS, FK_SLOT_SM_D, FK_SLOT_PF_IDX, FK_SLOT_PF_CNT, FK_SLOT_PF_ZC, FK_SLOT_PF_ZO,
        FK_SLOT_PF_ENDS, FK_SLOT_PF_LEN, FK_SLOT_PF_OFF, FK_SLOT_PF_OUT, FK_SLOT_ENT, FK_SLOT_TENT, FK_SLOT_TCNT, FK_SLOT_CBASE, FK_SLOT_PF_RID,
-       FK_SLOT_PK_TIDX, FK_SLOT_PK_ASCII, FK_SLOT_SM_DIG, FK_SLOT_GATHER };
+       FK_SLOT_PK_TIDX, FK_SLOT_PK_ASCII, FK_SLOT_SM_DIG, FK_SLOT_GATHER, FK_SLOT_XS_READS, FK_SLOT_XS_BLOCKS };
 
 // returns a device buffer of at least nbytes for the given purpose (NULL + error set on failure)
 void *fk_slot(fk_ctx *ctx, int slot, int64_t nbytes);

@@ -35,6 +35,15 @@ struct ExactArgs
   int       pad2;               // 2 * PAD
   const int *trie;              // Min_Part: < 0 children at -trie[x] + base, else bucket; NULL: one bucket
   int       nparts;
+  // segments (round 5): the unit of a thread is a stretch of a read that begins where the reference's state is known
+  // whatever came before -- at the read's start, or at a position whose minimizer value is strictly below every value of
+  // the MAX_SUPER positions in front of it (then `mp < mc` holds whatever mc is, the super-mer in progress is closed
+  // there and the next one starts with m = p, mc = mp, last = p) with no non-acgt base within 2K positions in front of it
+  // (then nothing of the N bookkeeping reaches across).  k_xs_find picks at most one such position per XS_BLOCK positions.
+  int64_t   nseg;               // threads of the split kernels (= nreads when seg_read is NULL: one segment per read)
+  const u32 *seg_read;          // [nseg] read of segment i
+  const u32 *seg_p0;            // [nseg] its first position in the read (0: the read's start)
+  const u32 *seg_p1;            // [nseg] the position it ends WITH (the next segment's first), 0xffffffff: the read's end
 };
 
 __device__ __forceinline__ int xs_code(unsigned ch)
@@ -46,9 +55,12 @@ __device__ __forceinline__ int xs_code(unsigned ch)
 
 template <bool EMIT>
 __global__ __launch_bounds__(XS_THREADS) void k_split_exact(ExactArgs a)
-{ const int64_t r = (int64_t) blockIdx.x * XS_THREADS + threadIdx.x;
-  if (r >= a.nreads)
+{ const int64_t sg = (int64_t) blockIdx.x * XS_THREADS + threadIdx.x;      // the segment: cnt / off are indexed by it
+  if (sg >= a.nseg)
     return;
+  const int64_t r  = (a.seg_read != NULL) ? (int64_t) a.seg_read[sg] : sg;
+  const int     p0 = (a.seg_read != NULL) ? (int) a.seg_p0[sg] : 0;
+  const u32     p1 = (a.seg_read != NULL) ? a.seg_p1[sg] : 0xffffffffu;
   const int K   = a.kmer;
   const int KM1 = K - 1;
   const int PL1 = a.pad_len - 1;
@@ -59,7 +71,7 @@ __global__ __launch_bounds__(XS_THREADS) void k_split_exact(ExactArgs a)
   if (q < K)
     { if (!EMIT)
         for (int b = 0; b < a.nparts; b++)
-          a.cnt[(int64_t) b * a.nreads + r] = 0;
+          a.cnt[(int64_t) b * a.nseg + sg] = 0;
       return;
     }
   int rmsk = 1;
@@ -94,7 +106,7 @@ __global__ __launch_bounds__(XS_THREADS) void k_split_exact(ExactArgs a)
       if (EMIT)
         { const unsigned char *b = s + (first_end - KM1);
           const int L = n - 1 + K;
-          u32 *dst = a.out + (a.off[(int64_t) bk * a.nreads + r] + nrec[bk]) * (u64) a.sww;
+          u32 *dst = a.out + (a.off[(int64_t) bk * a.nseg + sg] + nrec[bk]) * (u64) a.sww;
           for (int w = 0; w < a.sww; w++)
             { u32 x = 0;
               for (int j = 0; j < 16; j++)
@@ -116,6 +128,21 @@ __global__ __launch_bounds__(XS_THREADS) void k_split_exact(ExactArgs a)
   unsigned c = 0, u = 0, mp = 0, mc = vmsk + 1u;
   int m = 0, p;
   int ilo = -1, ihi = -1, phi = -1;
+  int  last = KM1;
+  if (p0 > 0)
+    { // a segment that begins at a position where the reference's state does not depend on what came before: the
+      // rolling codes of the pad_len bases that end there (all acgt), m = p0, mc = its value, last = p0, no N pending
+      for (p = p0 - PL1; p <= p0; p++)
+        { const int code = xs_code(s[p]);
+          c = ((c << 2) | fwv(code)) & vmsk;
+          u = (u >> 2) | rcv(code);
+        }
+      const unsigned fl = (u < c);
+      mp = fl ? u : c;
+      ring[p0 & rmsk] = (mp << 1) | fl;
+      m = p0; mc = mp; last = p0;
+    }
+  else
   for (p = 0; p < K; p++)                                   // split.c:1096-1134
     { const int code = xs_code(s[p]);
       c = ((c << 2) | fwv(code)) & vmsk;
@@ -134,9 +161,8 @@ __global__ __launch_bounds__(XS_THREADS) void k_split_exact(ExactArgs a)
         }
     }
 
-  int  last = KM1;
   bool done = false;
-  for (p = K; !done; p++)                                   // split.c:1136-1347
+  for (p = (p0 > 0 ? p0 + 1 : K); !done; p++)               // split.c:1136-1347
     { int  code = 0;
       bool closing, force;
       if (p < q)
@@ -171,7 +197,7 @@ __global__ __launch_bounds__(XS_THREADS) void k_split_exact(ExactArgs a)
             n = p - last;
           if (n > 0)
             emit(last, n, ring[m & rmsk] & 1, mc);
-          if (done)
+          if (done || (u32) p == p1)                         // (the next segment begins here, with the state this closing leaves)
             break;
           if (force)                                         // split.c:1304-1320
             { m += 1;
@@ -195,9 +221,95 @@ __global__ __launch_bounds__(XS_THREADS) void k_split_exact(ExactArgs a)
 
   if (!EMIT)
     for (int b = 0; b < a.nparts; b++)
-      a.cnt[(int64_t) b * a.nreads + r] = nrec[b];
+      a.cnt[(int64_t) b * a.nseg + sg] = nrec[b];
   if (ninst != 0)
-    atomicAdd(&a.inst[r & 63], ninst);
+    atomicAdd(&a.inst[sg & 63], ninst);
+}
+
+// ---- segment starts ------------------------------------------------------------------------------------------------
+// A read of q positions has max(1, ceil(q / XS_BLOCK)) blocks; block 0 begins the read's first segment, every later block
+// looks for ONE position p inside itself where a segment may begin (see ExactArgs): the minimizer value of p -- computed
+// exactly as k_split_exact computes it -- strictly below the values of the MAX_SUPER positions in front of it, and no
+// non-acgt base among the 2K positions up to p.  A block without such a position (low complexity, N runs) begins none: its
+// positions belong to the segment in front of it.  Any choice is right; more of them is only more threads.
+#define XS_BLOCK 1024
+
+__global__ __launch_bounds__(256) void k_xs_blocks(const int64_t *__restrict__ roff, int64_t nreads, int bc_prefix, int kmer,
+                                                   u32 *__restrict__ nblk)
+{ const int64_t r = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (r >= nreads) return;
+  const int64_t q = (roff[r + 1] - roff[r]) - 1 - bc_prefix;
+  nblk[r] = (q < kmer || q <= XS_BLOCK) ? 1u : (u32) ((q + XS_BLOCK - 1) / XS_BLOCK);
+}
+
+// one thread per read: the read of each of its blocks
+__global__ __launch_bounds__(256) void k_xs_blkread(const u32 *__restrict__ nblk, const u64 *__restrict__ boff, int64_t nreads,
+                                                    u32 *__restrict__ blk_read, u32 *__restrict__ blk_j)
+{ const int64_t r = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (r >= nreads) return;
+  const u64 o = boff[r];
+  for (u32 j = 0; j < nblk[r]; j++)
+    { blk_read[o + j] = (u32) r;
+      blk_j[o + j] = j;
+    }
+}
+
+// one thread per block: where its segment begins (0xffffffff: nowhere), and 1 / 0 into flag
+__global__ __launch_bounds__(128) void k_xs_find(ExactArgs a, const u32 *__restrict__ blk_read, const u32 *__restrict__ blk_j,
+                                                 int64_t nblocks, u32 *__restrict__ blk_p0, u32 *__restrict__ flag)
+{ const int64_t bi = (int64_t) blockIdx.x * 128 + threadIdx.x;
+  if (bi >= nblocks) return;
+  const int64_t r = blk_read[bi];
+  const u32 j = blk_j[bi];
+  if (j == 0)
+    { blk_p0[bi] = 0; flag[bi] = 1; return; }
+  const int K = a.kmer, PL1 = a.pad_len - 1, MS = K - PL1;
+  const u32 vmsk = (1u << (2 * a.pad_len)) - 1u;
+  const unsigned char *s = a.bases + a.roff[r] + a.bc_prefix;
+  const int q = (int) (a.roff[r + 1] - a.roff[r]) - 1 - a.bc_prefix;
+  const int t0 = a.tran[0], t1 = a.tran[1], t2 = a.tran[2], t3 = a.tran[3];
+  auto fwv = [&](int code) -> unsigned { return (unsigned) (code == 1 ? t1 : code == 2 ? t2 : code == 3 ? t3 : t0); };
+  auto rcv = [&](int code) -> unsigned { return (unsigned) (code == 1 ? t2 : code == 2 ? t1 : code == 3 ? t0 : t3) << (2 * PL1); };
+  const int lo = (int) j * XS_BLOCK;                          // candidates lo <= p < hi (p < q: the loop region of the read)
+  const int hi = (lo + XS_BLOCK < q) ? lo + XS_BLOCK : q;
+  u32 win[64];                                               // the values of the last 64 positions (MS <= 60 for k <= 64)
+  unsigned c = 0, u = 0;
+  int bad = -1;                                              // the last position that holds no acgt
+  u32 found = 0xffffffffu;
+  const int start = lo - 2 * K - PL1;                        // (lo >= 1024 > 2K + pad: inside the read)
+  for (int p = start; p < hi; p++)
+    { const int code = xs_code(s[p]);
+      c = ((c << 2) | fwv(code)) & vmsk;
+      u = (u >> 2) | rcv(code);
+      if (code >= 4) bad = p;
+      const u32 v = (u < c) ? u : c;
+      if (p >= lo && p - bad > 2 * K)
+        { bool ok = true;
+          for (int d = 1; d <= MS; d++)
+            if (win[(p - d) & 63] <= v) { ok = false; break; }
+          if (ok) { found = (u32) p; break; }
+        }
+      win[p & 63] = v;
+    }
+  blk_p0[bi] = found;
+  flag[bi] = (found != 0xffffffffu) ? 1u : 0u;
+}
+
+// the blocks that begin a segment, in order: segment i = (read, first position), and where it ends
+__global__ __launch_bounds__(256) void k_xs_segs(const u32 *__restrict__ blk_read, const u32 *__restrict__ blk_p0,
+                                                 const u32 *__restrict__ flag, const u64 *__restrict__ soff, int64_t nblocks,
+                                                 u32 *__restrict__ seg_read, u32 *__restrict__ seg_p0)
+{ const int64_t bi = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (bi >= nblocks || flag[bi] == 0) return;
+  seg_read[soff[bi]] = blk_read[bi];
+  seg_p0[soff[bi]] = blk_p0[bi];
+}
+
+__global__ __launch_bounds__(256) void k_xs_ends(const u32 *__restrict__ seg_read, const u32 *__restrict__ seg_p0, int64_t nseg,
+                                                 u32 *__restrict__ seg_p1)
+{ const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (i >= nseg) return;
+  seg_p1[i] = (i + 1 < nseg && seg_read[i + 1] == seg_read[i]) ? seg_p0[i + 1] : 0xffffffffu;
 }
 
 // byte histogram of bases[lo,hi)                                       frequency_thread, split.c:95-112
@@ -259,10 +371,8 @@ int fkx_split_exact(fk_ctx *ctx, const void *d_bases, const int64_t *d_roff, int
     return (FK_OK);
   if (ctx->prm.kmer > 128 || ctx->prm.kmer < 8 || nparts > XS_MAXPARTS)
     return (FK_EUNSUPPORTED);
-  u32 *d_cnt = (u32 *) fk_slot(ctx, FK_SLOT_EX_HEADS, nreads * nparts * 4);
-  u64 *d_off = (u64 *) fk_slot(ctx, FK_SLOT_EX_KOFF, (nreads * nparts + 1) * 8);
-  if (d_cnt == NULL || d_off == NULL)
-    return (FK_ENOMEM);
+  u32 *d_cnt = NULL;
+  u64 *d_off = NULL;
   u64 *d_inst = ctx->d_scratch + 2048;          // [64] instances, [64] = total records
   ExactArgs a;
   a.bases = (const unsigned char *) d_bases;
@@ -282,15 +392,63 @@ int fkx_split_exact(fk_ctx *ctx, const void *d_bases, const int64_t *d_roff, int
   a.pad_len = 5 + ((nparts > 1) ? ctx->scheme_pad : 0);
   a.pad2 = (nparts > 1) ? 2 * ctx->scheme_pad : 0;
   a.trie = (nparts > 1) ? ctx->d_min_part : NULL;
-  const unsigned grid = (unsigned) ((nreads + XS_THREADS - 1) / XS_THREADS);
+  // ---- segments: long reads are cut where the reference's state is known (ExactArgs; fk_debug_set("exact_segments", 0)
+  //      keeps one thread per read)
+  int64_t nseg = nreads;
+  a.nseg = nreads; a.seg_read = a.seg_p0 = a.seg_p1 = NULL;
+  if (ctx->prm.kmer <= 64 && ctx->dbg_exact_segments >= 0 && nreads < 0x7fffffffll)
+    { const unsigned gr = (unsigned) ((nreads + 255) / 256);
+      char *rb = (char *) fk_slot(ctx, FK_SLOT_XS_READS, nreads * 4 + (nreads + 1) * 8 + 256);
+      if (rb == NULL) return (FK_ENOMEM);
+      u32 *d_nblk = (u32 *) rb;
+      u64 *d_boff = (u64 *) (rb + ((nreads * 4 + 63) & ~63ll));
+      hipLaunchKernelGGL(k_xs_blocks, dim3(gr), dim3(256), 0, s, d_roff, nreads, a.bc_prefix, a.kmer, d_nblk);
+      hipLaunchKernelGGL(k_exscan_tiles, dim3(1), dim3(256), 0, s, (const u32 *) d_nblk, nreads, d_boff, ctx->d_scratch + 2200);
+      FK_LAUNCH_CHECK(ctx);
+      FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch + 2200, ctx->d_scratch + 2200, 8, hipMemcpyDeviceToHost, s));
+      FK_HIP(ctx, hipStreamSynchronize(s));
+      const int64_t nblocks = (int64_t) ctx->h_scratch[2200];
+      if (nblocks > nreads && nblocks < 0x7fffffffll)          // (some read is longer than a block)
+        { const int64_t nb4 = (nblocks * 4 + 63) & ~63ll;
+          char *bb = (char *) fk_slot(ctx, FK_SLOT_XS_BLOCKS, 7 * nb4 + (nblocks + 1) * 8 + 256);
+          if (bb == NULL) return (FK_ENOMEM);
+          u32 *blk_read = (u32 *) bb, *blk_j = (u32 *) (bb + nb4), *blk_p0 = (u32 *) (bb + 2 * nb4), *flag = (u32 *) (bb + 3 * nb4);
+          u32 *seg_read = (u32 *) (bb + 4 * nb4), *seg_p0 = (u32 *) (bb + 5 * nb4), *seg_p1 = (u32 *) (bb + 6 * nb4);
+          u64 *soff = (u64 *) (bb + 7 * nb4);
+          const unsigned gb = (unsigned) ((nblocks + 255) / 256);
+          hipLaunchKernelGGL(k_xs_blkread, dim3(gr), dim3(256), 0, s, (const u32 *) d_nblk, (const u64 *) d_boff, nreads, blk_read, blk_j);
+          hipLaunchKernelGGL(k_xs_find, dim3((unsigned) ((nblocks + 127) / 128)), dim3(128), 0, s, a, (const u32 *) blk_read,
+                             (const u32 *) blk_j, nblocks, blk_p0, flag);
+          hipLaunchKernelGGL(k_exscan_tiles, dim3(1), dim3(256), 0, s, (const u32 *) flag, nblocks, soff, ctx->d_scratch + 2201);
+          hipLaunchKernelGGL(k_xs_segs, dim3(gb), dim3(256), 0, s, (const u32 *) blk_read, (const u32 *) blk_p0, (const u32 *) flag,
+                             (const u64 *) soff, nblocks, seg_read, seg_p0);
+          FK_LAUNCH_CHECK(ctx);
+          FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch + 2201, ctx->d_scratch + 2201, 8, hipMemcpyDeviceToHost, s));
+          FK_HIP(ctx, hipStreamSynchronize(s));
+          nseg = (int64_t) ctx->h_scratch[2201];
+          hipLaunchKernelGGL(k_xs_ends, dim3((unsigned) ((nseg + 255) / 256)), dim3(256), 0, s, (const u32 *) seg_read,
+                             (const u32 *) seg_p0, nseg, seg_p1);
+          FK_LAUNCH_CHECK(ctx);
+          a.nseg = nseg; a.seg_read = seg_read; a.seg_p0 = seg_p0; a.seg_p1 = seg_p1;
+          if (ctx->dbg_verbose)
+            fprintf(stderr, "  exact split: %lld reads in %lld segments\n", (long long) nreads, (long long) nseg);
+        }
+    }
+  d_cnt = (u32 *) fk_slot(ctx, FK_SLOT_EX_HEADS, nseg * nparts * 4);
+  d_off = (u64 *) fk_slot(ctx, FK_SLOT_EX_KOFF, (nseg * nparts + 1) * 8);
+  if (d_cnt == NULL || d_off == NULL)
+    return (FK_ENOMEM);
+  a.cnt = d_cnt;
+  a.off = d_off;
+  const unsigned grid = (unsigned) ((nseg + XS_THREADS - 1) / XS_THREADS);
   FK_HIP(ctx, hipMemsetAsync(d_inst, 0, 72 * sizeof(u64), s));
   hipLaunchKernelGGL(k_split_exact<false>, dim3(grid), dim3(XS_THREADS), 0, s, a);
-  hipLaunchKernelGGL(k_exscan_tiles, dim3(1), dim3(256), 0, s, (const u32 *) d_cnt, nreads * nparts, d_off,
+  hipLaunchKernelGGL(k_exscan_tiles, dim3(1), dim3(256), 0, s, (const u32 *) d_cnt, nseg * nparts, d_off,
                      d_inst + 64);
   FK_LAUNCH_CHECK(ctx);
   FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch, d_inst, 72 * sizeof(u64), hipMemcpyDeviceToHost, s));
   for (int b = 1; b < nparts; b++)                       // where bucket b starts: the scan at its first read
-    FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch + 128 + b, d_off + (int64_t) b * nreads, 8, hipMemcpyDeviceToHost, s));
+    FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch + 128 + b, d_off + (int64_t) b * nseg, 8, hipMemcpyDeviceToHost, s));
   FK_HIP(ctx, hipStreamSynchronize(s));
   const int64_t ns = (int64_t) ctx->h_scratch[64];
   int64_t ni = 0;
