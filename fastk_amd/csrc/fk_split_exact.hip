@@ -44,6 +44,7 @@ struct ExactArgs
   const u32 *seg_read;          // [nseg] read of segment i
   const u32 *seg_p0;            // [nseg] its first position in the read (0: the read's start)
   const u32 *seg_p1;            // [nseg] the position it ends WITH (the next segment's first), 0xffffffff: the read's end
+  int       defer;              // the emit pass leaves notes, k_xs_pack writes the records (records of >= 2 words)
 };
 
 __device__ __forceinline__ int xs_code(unsigned ch)
@@ -83,6 +84,20 @@ __global__ __launch_bounds__(XS_THREADS) void k_split_exact(ExactArgs a)
   auto fwv = [&](int code) -> unsigned { return (unsigned) (code == 1 ? t1 : code == 2 ? t2 : code == 3 ? t3 : t0); };
   auto rcv = [&](int code) -> unsigned { return (unsigned) (code == 1 ? t2 : code == 2 ? t1 : code == 3 ? t0 : t3) << (2 * PL1); };
 
+  // the bases of the scan come 16 at a time (an aligned uint4 that stays in registers until the scan leaves it): a byte
+  // load per position was a trip to the cache per position of every lane
+  uint4 ch = make_uint4(0u, 0u, 0u, 0u);
+  uintptr_t ch_at = ~(uintptr_t) 0;
+  auto base_at = [&](int pp) -> unsigned
+    { const uintptr_t ad = (uintptr_t) (s + pp);
+      if ((ad >> 4) != ch_at)
+        { ch = *(const uint4 *) (ad & ~(uintptr_t) 15);
+          ch_at = ad >> 4;
+        }
+      const unsigned o = (unsigned) (ad & 15);
+      const u32 w = (o < 8) ? (o < 4 ? ch.x : ch.y) : (o < 12 ? ch.z : ch.w);
+      return ((w >> (8 * (o & 3))) & 0xffu);
+    };
   u32 nrec[XS_MAXPARTS];                  // records of this read so far, per bucket
   for (int b = 0; b < a.nparts; b++)
     nrec[b] = 0;
@@ -103,7 +118,15 @@ __global__ __launch_bounds__(XS_THREADS) void k_split_exact(ExactArgs a)
               y -= 2;
             }
         }
-      if (EMIT)
+      if (EMIT && a.defer)
+        { // where the super-mer lies and how long it is, left in its own record slot: k_xs_pack turns the note into the
+          // record with every lane at work -- packing here held the whole wave at each closing of any of its lanes
+          u32 *dst = a.out + (a.off[(int64_t) bk * a.nseg + sg] + nrec[bk]) * (u64) a.sww;
+          const u64 at = (u64) (s - a.bases) + (u64) (first_end - KM1);
+          dst[0] = (u32) at;
+          dst[1] = (u32) (at >> 32) | ((u32) (n - 1) << 16) | ((u32) flip << 31);
+        }
+      else if (EMIT)
         { const unsigned char *b = s + (first_end - KM1);
           const int L = n - 1 + K;
           u32 *dst = a.out + (a.off[(int64_t) bk * a.nseg + sg] + nrec[bk]) * (u64) a.sww;
@@ -133,7 +156,7 @@ __global__ __launch_bounds__(XS_THREADS) void k_split_exact(ExactArgs a)
     { // a segment that begins at a position where the reference's state does not depend on what came before: the
       // rolling codes of the pad_len bases that end there (all acgt), m = p0, mc = its value, last = p0, no N pending
       for (p = p0 - PL1; p <= p0; p++)
-        { const int code = xs_code(s[p]);
+        { const int code = xs_code(base_at(p));
           c = ((c << 2) | fwv(code)) & vmsk;
           u = (u >> 2) | rcv(code);
         }
@@ -144,7 +167,7 @@ __global__ __launch_bounds__(XS_THREADS) void k_split_exact(ExactArgs a)
     }
   else
   for (p = 0; p < K; p++)                                   // split.c:1096-1134
-    { const int code = xs_code(s[p]);
+    { const int code = xs_code(base_at(p));
       c = ((c << 2) | fwv(code)) & vmsk;
       u = (u >> 2) | rcv(code);
       if (p >= PL1)
@@ -166,7 +189,7 @@ __global__ __launch_bounds__(XS_THREADS) void k_split_exact(ExactArgs a)
     { int  code = 0;
       bool closing, force;
       if (p < q)
-        { code = xs_code(s[p]);
+        { code = xs_code(base_at(p));
           c = ((c << 2) | fwv(code)) & vmsk;
           u = (u >> 2) | rcv(code);
           const unsigned fl = (u < c);
@@ -226,13 +249,53 @@ __global__ __launch_bounds__(XS_THREADS) void k_split_exact(ExactArgs a)
     atomicAdd(&a.inst[sg & 63], ninst);
 }
 
+// one thread per record slot: the note k_split_exact<true> left there (first base, k-mers, orientation) becomes the
+// record -- bases 2-bit packed from the high end of big-endian words, reverse-complemented when the minimizer was taken
+// on the other strand, the count of k-mers less one in the byte after them (split.c:1234-1301)
+__global__ __launch_bounds__(256) void k_xs_pack(ExactArgs a, int64_t ns)
+{ const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (i >= ns) return;
+  u32 *dst = a.out + i * (int64_t) a.sww;
+  const u32 d0 = dst[0], d1 = dst[1];
+  const unsigned char *b = a.bases + ((((u64) (d1 & 0xffffu)) << 32) | d0);
+  const int n = (int) ((d1 >> 16) & 0x7fffu) + 1;
+  const bool flip = (d1 >> 31) != 0;
+  const int L = n - 1 + a.kmer;
+  const int lenw  = a.smer_bytes >> 2;
+  const int lensh = 24 - 8 * (a.smer_bytes & 3);
+  uint4 ch = make_uint4(0u, 0u, 0u, 0u);
+  uintptr_t ch_at = ~(uintptr_t) 0;
+  auto base_at = [&](int pp) -> unsigned
+    { const uintptr_t ad = (uintptr_t) (b + pp);
+      if ((ad >> 4) != ch_at)
+        { ch = *(const uint4 *) (ad & ~(uintptr_t) 15);
+          ch_at = ad >> 4;
+        }
+      const unsigned o = (unsigned) (ad & 15);
+      const u32 w = (o < 8) ? (o < 4 ? ch.x : ch.y) : (o < 12 ? ch.z : ch.w);
+      return ((w >> (8 * (o & 3))) & 0xffu);
+    };
+  for (int w = 0; w < a.sww; w++)
+    { u32 x = 0;
+      const int i0 = 16 * w;
+      const int e = (L - i0 < 16) ? L - i0 : 16;
+      for (int j = 0; j < e; j++)
+        { const int c = flip ? 3 - xs_code(base_at(L - 1 - i0 - j)) : xs_code(base_at(i0 + j));
+          x |= ((u32) (c & 3)) << (30 - 2 * j);
+        }
+      if (w == lenw)
+        x |= ((u32) (n - 1)) << lensh;
+      dst[w] = __builtin_bswap32(x);
+    }
+}
+
 // ---- segment starts ------------------------------------------------------------------------------------------------
 // A read of q positions has max(1, ceil(q / XS_BLOCK)) blocks; block 0 begins the read's first segment, every later block
 // looks for ONE position p inside itself where a segment may begin (see ExactArgs): the minimizer value of p -- computed
 // exactly as k_split_exact computes it -- strictly below the values of the MAX_SUPER positions in front of it, and no
 // non-acgt base among the 2K positions up to p.  A block without such a position (low complexity, N runs) begins none: its
 // positions belong to the segment in front of it.  Any choice is right; more of them is only more threads.
-#define XS_BLOCK 1024
+#define XS_BLOCK 256
 
 __global__ __launch_bounds__(256) void k_xs_blocks(const int64_t *__restrict__ roff, int64_t nreads, int bc_prefix, int kmer,
                                                    u32 *__restrict__ nblk)
@@ -276,7 +339,7 @@ __global__ __launch_bounds__(128) void k_xs_find(ExactArgs a, const u32 *__restr
   unsigned c = 0, u = 0;
   int bad = -1;                                              // the last position that holds no acgt
   u32 found = 0xffffffffu;
-  const int start = lo - 2 * K - PL1;                        // (lo >= 1024 > 2K + pad: inside the read)
+  const int start = lo - 2 * K - PL1;                        // (lo >= XS_BLOCK = 256 > 2K + pad for k <= 64: inside the read)
   for (int p = start; p < hi; p++)
     { const int code = xs_code(s[p]);
       c = ((c << 2) | fwv(code)) & vmsk;
@@ -389,6 +452,7 @@ int fkx_split_exact(fk_ctx *ctx, const void *d_bases, const int64_t *d_roff, int
   a.out = NULL;
   a.inst = d_inst;
   a.nparts = nparts;
+  a.defer = (a.sww >= 2) ? 1 : 0;
   a.pad_len = 5 + ((nparts > 1) ? ctx->scheme_pad : 0);
   a.pad2 = (nparts > 1) ? 2 * ctx->scheme_pad : 0;
   a.trie = (nparts > 1) ? ctx->d_min_part : NULL;
@@ -469,6 +533,8 @@ int fkx_split_exact(fk_ctx *ctx, const void *d_bases, const int64_t *d_roff, int
   a.out = (u32 *) out;
   FK_HIP(ctx, hipMemsetAsync(d_inst, 0, 72 * sizeof(u64), s));
   hipLaunchKernelGGL(k_split_exact<true>, dim3(grid), dim3(XS_THREADS), 0, s, a);
+  if (a.defer)
+    hipLaunchKernelGGL(k_xs_pack, dim3((unsigned) ((ns + 255) / 256)), dim3(256), 0, s, a, ns);
   FK_LAUNCH_CHECK(ctx);
   *d_out = out;
   return (FK_OK);
