@@ -17,6 +17,7 @@
 #define XS_THREADS 128
 #define XS_RING    256          // >= 2 * nextpow2(K) for K <= 128 (MOD_LEN, FastK.c:446-450)
 #define XS_MAXPARTS FK_EXACT_MAXPARTS
+#define XS_DQ      8            // entries of the minimizer chain kept in registers (k_split_exact)
 
 struct ExactArgs
 { const unsigned char *bases;
@@ -79,7 +80,11 @@ __global__ __launch_bounds__(XS_THREADS) void k_split_exact(ExactArgs a)
   while (rmsk < K) rmsk <<= 1;
   rmsk = 2 * rmsk - 1;
 
-  u32 ring[XS_RING];                      // (min(c,u) << 1) | (u < c)
+  u32 ring[XS_RING];                      // (min(c,u) << 1) | (u < c) of position j at (j - pofs) & rmsk
+  // pofs: every lane of a wave is at the same ring index in the same turn of the main loop (its first turn is index K for
+  // a read's start and for a segment inside a read alike), so that the scratch store of a turn is one row of the wave's
+  // ring and not 64 rows -- indexed by the position itself it was a cache line per lane and turn
+  const int pofs = (p0 > 0) ? p0 + 1 - K : 0;
   const int t0 = a.tran[0], t1 = a.tran[1], t2 = a.tran[2], t3 = a.tran[3];
   auto fwv = [&](int code) -> unsigned { return (unsigned) (code == 1 ? t1 : code == 2 ? t2 : code == 3 ? t3 : t0); };
   auto rcv = [&](int code) -> unsigned { return (unsigned) (code == 1 ? t2 : code == 2 ? t1 : code == 3 ? t0 : t3) << (2 * PL1); };
@@ -148,6 +153,44 @@ __global__ __launch_bounds__(XS_THREADS) void k_split_exact(ExactArgs a)
       ninst += (u64) n;
     };
 
+  // The forced rescan (split.c:1304-1320) wants the rightmost minimum of the positions behind m.  Walking the ring for it
+  // held the whole wave for MAX_SUPER scratch loads at almost every turn (some lane of 64 is always forcing), so the
+  // answer is kept ready instead: dq = the first XS_DQ entries of the chain "rightmost minimum of (m, p], rightmost
+  // minimum of what lies behind that one, ..." (values strictly increasing), in registers, statically indexed.  A new
+  // position drops the entries it is <= of and goes to the end; `inc` says that entries beyond the ones kept exist and
+  // are not known (all larger than the last one kept).  Only when a forced closing finds nothing kept does it walk the
+  // ring as before.
+  u32  dv[XS_DQ];                          // (value << 1) | flip, as in the ring
+  int  dp[XS_DQ];                          // position
+  int  cnt = 0;
+  bool inc = false;
+  unsigned mfl = 0;                        // orientation bit of the current minimizer m
+#pragma unroll
+  for (int i = 0; i < XS_DQ; i++)
+    { dv[i] = 0; dp[i] = 0; }
+  auto dq_push = [&](int pos, u32 e)
+    { const unsigned v = e >> 1;
+      int keep = 0;
+#pragma unroll
+      for (int i = 0; i < XS_DQ; i++)
+        keep += (i < cnt && (dv[i] >> 1) < v) ? 1 : 0;
+      if (keep < cnt)
+        inc = false;                       // (everything behind a dropped entry is larger than it: dropped as well)
+      cnt = keep;
+      if (!inc)
+        { if (cnt < XS_DQ)
+            {
+#pragma unroll
+              for (int i = 0; i < XS_DQ; i++)
+                if (i == cnt)
+                  { dv[i] = e; dp[i] = pos; }
+              cnt += 1;
+            }
+          else
+            inc = true;
+        }
+    };
+
   unsigned c = 0, u = 0, mp = 0, mc = vmsk + 1u;
   int m = 0, p;
   int ilo = -1, ihi = -1, phi = -1;
@@ -162,8 +205,8 @@ __global__ __launch_bounds__(XS_THREADS) void k_split_exact(ExactArgs a)
         }
       const unsigned fl = (u < c);
       mp = fl ? u : c;
-      ring[p0 & rmsk] = (mp << 1) | fl;
-      m = p0; mc = mp; last = p0;
+      ring[(p0 - pofs) & rmsk] = (mp << 1) | fl;
+      m = p0; mc = mp; mfl = fl; last = p0;
     }
   else
   for (p = 0; p < K; p++)                                   // split.c:1096-1134
@@ -173,9 +216,11 @@ __global__ __launch_bounds__(XS_THREADS) void k_split_exact(ExactArgs a)
       if (p >= PL1)
         { const unsigned fl = (u < c);
           mp = fl ? u : c;
-          ring[p & rmsk] = (mp << 1) | fl;
+          ring[(p - pofs) & rmsk] = (mp << 1) | fl;
           if (mp < mc)
-            { m = p; mc = mp; }
+            { m = p; mc = mp; mfl = fl; cnt = 0; inc = false; }
+          else
+            dq_push(p, (mp << 1) | fl);
         }
       if (code >= 4)
         { if (p > ihi)
@@ -188,13 +233,14 @@ __global__ __launch_bounds__(XS_THREADS) void k_split_exact(ExactArgs a)
   for (p = (p0 > 0 ? p0 + 1 : K); !done; p++)               // split.c:1136-1347
     { int  code = 0;
       bool closing, force;
+      unsigned fl = 0;
       if (p < q)
         { code = xs_code(base_at(p));
           c = ((c << 2) | fwv(code)) & vmsk;
           u = (u >> 2) | rcv(code);
-          const unsigned fl = (u < c);
+          fl = (u < c);
           mp = fl ? u : c;
-          ring[p & rmsk] = (mp << 1) | fl;
+          ring[(p - pofs) & rmsk] = (mp << 1) | fl;
           force   = (p - m >= MS);
           closing = force || (mp < mc);
         }
@@ -219,21 +265,36 @@ __global__ __launch_bounds__(XS_THREADS) void k_split_exact(ExactArgs a)
           else
             n = p - last;
           if (n > 0)
-            emit(last, n, ring[m & rmsk] & 1, mc);
+            emit(last, n, (int) mfl, mc);
           if (done || (u32) p == p1)                         // (the next segment begins here, with the state this closing leaves)
             break;
-          if (force)                                         // split.c:1304-1320
-            { m += 1;
-              mc = ring[m & rmsk] >> 1;
-              for (int j = m + 1; j <= p; j++)
-                { const unsigned v = ring[j & rmsk] >> 1;
-                  if (v <= mc)
-                    { m = j; mc = v; }
+          last = p;
+        }
+      // the minimizer after position p (split.c:1304-1320: `<=` on the forced rescan, the rightmost minimum behind m)
+      if (mp < mc)                                           // (forced or not: p is below everything in the window)
+        { m = p; mc = mp; mfl = fl; cnt = 0; inc = false; }
+      else
+        { dq_push(p, (mp << 1) | fl);
+          if (force)
+            { if (cnt > 0)
+                { m = dp[0]; mc = dv[0] >> 1; mfl = dv[0] & 1u;
+#pragma unroll
+                  for (int i = 0; i + 1 < XS_DQ; i++)
+                    { dv[i] = dv[i + 1]; dp[i] = dp[i + 1]; }
+                  cnt -= 1;
+                }
+              else                                           // (inc: nothing kept of what lies behind m)
+                { m += 1;
+                  u32 e = ring[(m - pofs) & rmsk];
+                  for (int j = m + 1; j <= p; j++)
+                    { const u32 x = ring[(j - pofs) & rmsk];
+                      if ((x >> 1) <= (e >> 1))
+                        { m = j; e = x; }
+                    }
+                  mc = e >> 1; mfl = e & 1u;
+                  inc = (m < p);
                 }
             }
-          else
-            { m = p; mc = mp; }
-          last = p;
         }
       if (code >= 4)                                         // split.c:1323-1330
         { if (p > ihi)
