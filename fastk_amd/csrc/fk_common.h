@@ -253,7 +253,7 @@ enum { FK_SLOT_SM_A = 0, FK_SLOT_SM_B, FK_SLOT_KM_A, FK_SLOT_KM_B, FK_SLOT_EX_HE
        FK_SLOT_RAW, FK_SLOT_FQ_INFO, FK_SLOT_FQ_PHASE, FK_SLOT_FQ_OFF, FK_SLOT_TIE_A, FK_SLOT_TIE_B,
        FK_SLOT_TIE_POS, FK_SLOT_SM_D, FK_SLOT_PF_IDX, FK_SLOT_PF_CNT, FK_SLOT_PF_ZC, FK_SLOT_PF_ZO,
        FK_SLOT_PF_ENDS, FK_SLOT_PF_LEN, FK_SLOT_PF_OFF, FK_SLOT_PF_OUT, FK_SLOT_ENT, FK_SLOT_TENT, FK_SLOT_TCNT, FK_SLOT_CBASE, FK_SLOT_PF_RID,
-       FK_SLOT_PK_TIDX, FK_SLOT_PK_ASCII, FK_SLOT_SM_DIG, FK_SLOT_GATHER, FK_SLOT_XS_READS, FK_SLOT_XS_BLOCKS };
+       FK_SLOT_PK_TIDX, FK_SLOT_PK_ASCII, FK_SLOT_SM_DIG, FK_SLOT_GATHER, FK_SLOT_XS_READS, FK_SLOT_XS_BLOCKS, FK_SLOT_XS_SCAN };
 
 // returns a device buffer of at least nbytes for the given purpose (NULL + error set on failure)
 void *fk_slot(fk_ctx *ctx, int slot, int64_t nbytes);

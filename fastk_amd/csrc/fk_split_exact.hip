@@ -310,6 +310,18 @@ __global__ __launch_bounds__(XS_THREADS) void k_split_exact(ExactArgs a)
     atomicAdd(&a.inst[sg & 63], ninst);
 }
 
+__device__ __forceinline__ u32 xs_code16(const uint4 x)
+{ // 16 ASCII bases -> 16 two-bit codes, the first base in the top bits (a 0, c 1, g 2, t 3; either case).  Per word of 4:
+  // bits 2:1 of each byte with g and t exchanged, then the four fields gathered into the top byte by one multiply
+  // (fields at bit 0, 8, 16, 24 times 2^30 + 2^20 + 2^10 + 1 land at 30, 28, 26, 24; no two partial products overlap)
+  auto four = [](u32 w) -> u32
+    { const u32 t = (w >> 1) & 0x03030303u;
+      const u32 c = t ^ ((t >> 1) & 0x01010101u);
+      return ((c * 0x40100401u) >> 24);
+    };
+  return ((four(x.x) << 24) | (four(x.y) << 16) | (four(x.z) << 8) | four(x.w));
+}
+
 // one thread per record slot: the note k_split_exact<true> left there (first base, k-mers, orientation) becomes the
 // record -- bases 2-bit packed from the high end of big-endian words, reverse-complemented when the minimizer was taken
 // on the other strand, the count of k-mers less one in the byte after them (split.c:1234-1301)
@@ -324,29 +336,33 @@ __global__ __launch_bounds__(256) void k_xs_pack(ExactArgs a, int64_t ns)
   const int L = n - 1 + a.kmer;
   const int lenw  = a.smer_bytes >> 2;
   const int lensh = 24 - 8 * (a.smer_bytes & 3);
-  uint4 ch = make_uint4(0u, 0u, 0u, 0u);
-  uintptr_t ch_at = ~(uintptr_t) 0;
-  auto base_at = [&](int pp) -> unsigned
-    { const uintptr_t ad = (uintptr_t) (b + pp);
-      if ((ad >> 4) != ch_at)
-        { ch = *(const uint4 *) (ad & ~(uintptr_t) 15);
-          ch_at = ad >> 4;
-        }
-      const unsigned o = (unsigned) (ad & 15);
-      const u32 w = (o < 8) ? (o < 4 ? ch.x : ch.y) : (o < 12 ? ch.z : ch.w);
-      return ((w >> (8 * (o & 3))) & 0xffu);
+  // the bases as a stream of aligned 16-byte pieces: forward from the piece that holds b[0], or -- the minimizer on the other
+  // strand -- backward from the piece that holds b[L-1], each piece reversed and complemented; the record's words are that
+  // stream shifted by the bases of the first piece that lie outside the super-mer
+  const uintptr_t a0 = (uintptr_t) b, a1 = (uintptr_t) (b + (L - 1));
+  const int64_t c0 = (int64_t) (a0 >> 4), c1 = (int64_t) (a1 >> 4);
+  const int sh = 2 * (int) (flip ? 15 - (a1 & 15) : (a0 & 15));
+  auto piece = [&](int k) -> u32
+    { const int64_t c = flip ? c1 - k : c0 + k;
+      if (c < c0 || c > c1)
+        return (0u);
+      const u32 x = xs_code16(*(const uint4 *) ((uintptr_t) c << 4));
+      if (!flip)
+        return (x);
+      const u32 r = __brev(x);                                         // (order reversed, the two bits of a base too)
+      return (~(((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1)));
     };
+  u32 cur = piece(0);
   for (int w = 0; w < a.sww; w++)
-    { u32 x = 0;
-      const int i0 = 16 * w;
-      const int e = (L - i0 < 16) ? L - i0 : 16;
-      for (int j = 0; j < e; j++)
-        { const int c = flip ? 3 - xs_code(base_at(L - 1 - i0 - j)) : xs_code(base_at(i0 + j));
-          x |= ((u32) (c & 3)) << (30 - 2 * j);
-        }
+    { const u32 nxt = piece(w + 1);
+      u32 x = (sh == 0) ? cur : ((cur << sh) | (nxt >> (32 - sh)));
+      const int valid = L - 16 * w;
+      if (valid < 16)
+        x = (valid <= 0) ? 0u : (x & ~(0xffffffffu >> (2 * valid)));
       if (w == lenw)
         x |= ((u32) (n - 1)) << lensh;
       dst[w] = __builtin_bswap32(x);
+      cur = nxt;
     }
 }
 
@@ -356,7 +372,7 @@ __global__ __launch_bounds__(256) void k_xs_pack(ExactArgs a, int64_t ns)
 // exactly as k_split_exact computes it -- strictly below the values of the MAX_SUPER positions in front of it, and no
 // non-acgt base among the 2K positions up to p.  A block without such a position (low complexity, N runs) begins none: its
 // positions belong to the segment in front of it.  Any choice is right; more of them is only more threads.
-#define XS_BLOCK 256
+#define XS_BLOCK 512
 
 __global__ __launch_bounds__(256) void k_xs_blocks(const int64_t *__restrict__ roff, int64_t nreads, int bc_prefix, int kmer,
                                                    u32 *__restrict__ nblk)
@@ -400,9 +416,18 @@ __global__ __launch_bounds__(128) void k_xs_find(ExactArgs a, const u32 *__restr
   unsigned c = 0, u = 0;
   int bad = -1;                                              // the last position that holds no acgt
   u32 found = 0xffffffffu;
-  const int start = lo - 2 * K - PL1;                        // (lo >= XS_BLOCK = 256 > 2K + pad for k <= 64: inside the read)
+  const int start = lo - 2 * K - PL1;                        // (lo >= XS_BLOCK = 512 > 2K + pad for k <= 64: inside the read)
+  uint4 ch = make_uint4(0u, 0u, 0u, 0u);
+  uintptr_t ch_at = ~(uintptr_t) 0;
   for (int p = start; p < hi; p++)
-    { const int code = xs_code(s[p]);
+    { const uintptr_t ad = (uintptr_t) (s + p);              // (16 bases a load, as in k_split_exact)
+      if ((ad >> 4) != ch_at)
+        { ch = *(const uint4 *) (ad & ~(uintptr_t) 15);
+          ch_at = ad >> 4;
+        }
+      const unsigned o = (unsigned) (ad & 15);
+      const u32 cw = (o < 8) ? (o < 4 ? ch.x : ch.y) : (o < 12 ? ch.z : ch.w);
+      const int code = xs_code((cw >> (8 * (o & 3))) & 0xffu);
       c = ((c << 2) | fwv(code)) & vmsk;
       u = (u >> 2) | rcv(code);
       if (code >= 4) bad = p;
@@ -481,6 +506,61 @@ int fkx_train_tran(fk_ctx *ctx, const void *d_bases, const int64_t *h_roff, int6
   return (FK_OK);
 }
 
+// ---- exclusive scan of many counts -------------------------------------------------------------------------------------
+// k_exscan_tiles is one workgroup (made for a few thousand tile counts); the exact splitter scans a count per segment and
+// bucket -- millions.  Tiles of 4096 counts: their sums, the scan of the sums by k_exscan_tiles, the scan inside each tile.
+__global__ __launch_bounds__(256) void k_xs_tilesum(const u32 *__restrict__ in, int64_t n, u32 *__restrict__ tsum)
+{ __shared__ u64 tmp[8];
+  const int64_t i0 = (int64_t) blockIdx.x * 4096 + (int64_t) threadIdx.x * 16;
+  u64 mine = 0;
+  for (int k = 0; k < 16; k++)
+    mine += (i0 + k < n) ? in[i0 + k] : 0u;
+  u64 tot;
+  fk_block_exscan_256<u64>(mine, tmp, &tot);
+  if (threadIdx.x == 0)
+    tsum[blockIdx.x] = (u32) tot;
+}
+
+__global__ __launch_bounds__(256) void k_xs_tilescan(const u32 *__restrict__ in, int64_t n, const u64 *__restrict__ toff,
+                                                     u64 *__restrict__ out)
+{ __shared__ u64 tmp[8];
+  const int64_t i0 = (int64_t) blockIdx.x * 4096 + (int64_t) threadIdx.x * 16;
+  u32 v[16];
+  u64 mine = 0;
+#pragma unroll
+  for (int k = 0; k < 16; k++)
+    { v[k] = (i0 + k < n) ? in[i0 + k] : 0u;
+      mine += v[k];
+    }
+  u64 tot;
+  u64 run = toff[blockIdx.x] + fk_block_exscan_256<u64>(mine, tmp, &tot);
+#pragma unroll
+  for (int k = 0; k < 16; k++)
+    { if (i0 + k < n)
+        out[i0 + k] = run;
+      run += v[k];
+    }
+}
+
+// out[i] = in[0] + .. + in[i-1] for i < n, *total = the sum (a tile's sum must fit 32 bits: counts of records)
+static int xs_exscan(fk_ctx *ctx, const u32 *in, int64_t n, u64 *out, u64 *total)
+{ hipStream_t s = ctx->stream;
+  if (n <= 32768)
+    { hipLaunchKernelGGL(k_exscan_tiles, dim3(1), dim3(256), 0, s, in, n, out, total);
+      return (FK_OK);
+    }
+  const int64_t nt = (n + 4095) / 4096;
+  const int64_t t4 = (nt * 4 + 63) & ~63ll;
+  char *tb = (char *) fk_slot(ctx, FK_SLOT_XS_SCAN, t4 + nt * 8 + 64);
+  if (tb == NULL) return (FK_ENOMEM);
+  u32 *tsum = (u32 *) tb;
+  u64 *toff = (u64 *) (tb + t4);
+  hipLaunchKernelGGL(k_xs_tilesum, dim3((unsigned) nt), dim3(256), 0, s, in, n, tsum);
+  hipLaunchKernelGGL(k_exscan_tiles, dim3(1), dim3(256), 0, s, (const u32 *) tsum, nt, toff, total);
+  hipLaunchKernelGGL(k_xs_tilescan, dim3((unsigned) nt), dim3(256), 0, s, in, n, (const u64 *) toff, out);
+  return (FK_OK);
+}
+
 /* bucket_counts / bucket_offs (records): the super-mers come out grouped by bucket when the context holds a scheme
    (ctx->scheme_nparts > 1, fkx_train_scheme); one bucket otherwise. */
 int fkx_split_exact(fk_ctx *ctx, const void *d_bases, const int64_t *d_roff, int64_t nreads,
@@ -528,7 +608,7 @@ int fkx_split_exact(fk_ctx *ctx, const void *d_bases, const int64_t *d_roff, int
       u32 *d_nblk = (u32 *) rb;
       u64 *d_boff = (u64 *) (rb + ((nreads * 4 + 63) & ~63ll));
       hipLaunchKernelGGL(k_xs_blocks, dim3(gr), dim3(256), 0, s, d_roff, nreads, a.bc_prefix, a.kmer, d_nblk);
-      hipLaunchKernelGGL(k_exscan_tiles, dim3(1), dim3(256), 0, s, (const u32 *) d_nblk, nreads, d_boff, ctx->d_scratch + 2200);
+      if (xs_exscan(ctx, (const u32 *) d_nblk, nreads, d_boff, ctx->d_scratch + 2200) != FK_OK) return (FK_ENOMEM);
       FK_LAUNCH_CHECK(ctx);
       FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch + 2200, ctx->d_scratch + 2200, 8, hipMemcpyDeviceToHost, s));
       FK_HIP(ctx, hipStreamSynchronize(s));
@@ -544,7 +624,7 @@ int fkx_split_exact(fk_ctx *ctx, const void *d_bases, const int64_t *d_roff, int
           hipLaunchKernelGGL(k_xs_blkread, dim3(gr), dim3(256), 0, s, (const u32 *) d_nblk, (const u64 *) d_boff, nreads, blk_read, blk_j);
           hipLaunchKernelGGL(k_xs_find, dim3((unsigned) ((nblocks + 127) / 128)), dim3(128), 0, s, a, (const u32 *) blk_read,
                              (const u32 *) blk_j, nblocks, blk_p0, flag);
-          hipLaunchKernelGGL(k_exscan_tiles, dim3(1), dim3(256), 0, s, (const u32 *) flag, nblocks, soff, ctx->d_scratch + 2201);
+          if (xs_exscan(ctx, (const u32 *) flag, nblocks, soff, ctx->d_scratch + 2201) != FK_OK) return (FK_ENOMEM);
           hipLaunchKernelGGL(k_xs_segs, dim3(gb), dim3(256), 0, s, (const u32 *) blk_read, (const u32 *) blk_p0, (const u32 *) flag,
                              (const u64 *) soff, nblocks, seg_read, seg_p0);
           FK_LAUNCH_CHECK(ctx);
@@ -568,8 +648,7 @@ int fkx_split_exact(fk_ctx *ctx, const void *d_bases, const int64_t *d_roff, int
   const unsigned grid = (unsigned) ((nseg + XS_THREADS - 1) / XS_THREADS);
   FK_HIP(ctx, hipMemsetAsync(d_inst, 0, 72 * sizeof(u64), s));
   hipLaunchKernelGGL(k_split_exact<false>, dim3(grid), dim3(XS_THREADS), 0, s, a);
-  hipLaunchKernelGGL(k_exscan_tiles, dim3(1), dim3(256), 0, s, (const u32 *) d_cnt, nseg * nparts, d_off,
-                     d_inst + 64);
+  if (xs_exscan(ctx, (const u32 *) d_cnt, nseg * nparts, d_off, d_inst + 64) != FK_OK) return (FK_ENOMEM);
   FK_LAUNCH_CHECK(ctx);
   FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch, d_inst, 72 * sizeof(u64), hipMemcpyDeviceToHost, s));
   for (int b = 1; b < nparts; b++)                       // where bucket b starts: the scan at its first read
