@@ -1,4 +1,4 @@
-// fk_split_exact.hip -- the reference's OWN super-mer rule, one thread per read.
+// fk_split_exact.hip -- the reference's OWN super-mer rule, a thread per stretch of a read.
 //
 // The position-parallel splitter (fk_split.hip) is free to cut super-mers differently because no
 // count depends on the cuts.  One thing does: the first-byte boundaries of the hidden .ktab part
@@ -8,10 +8,21 @@
 // Distribute_Block itself (split.c:1016-1393): rolling canonical 5-mer under the frequency-ranked
 // base order (Tran/Cran, split.c:529-575, 630-639), strict < on arrival, <= on the forced rescan
 // after MAX_SUPER k-mers, the clipping around non-ACGT bases (split.c:1167-1232) and the
-// end-of-read flush (split.c:1342-1347) -- sequentially per read, as the reference must, with
-// reads spread over threads.  With the scheme of fk_scheme.hip (padded minimizers, prefix trie, leaves dealt to
-// NPARTS buckets) also for inputs the reference cuts into several buckets: the super-mers come out grouped by bucket.
-// For blocks cut like io.c cuts them.  A compatibility mode: ~10x slower than the default splitter.
+// end-of-read flush (split.c:1342-1347).  With the scheme of fk_scheme.hip (padded minimizers, prefix trie, leaves
+// dealt to NPARTS buckets) also for inputs the reference cuts into several buckets: the super-mers come out grouped by
+// bucket.  For blocks cut like io.c cuts them.
+//
+// The rule is sequential along a read; what runs in parallel (round 5):
+//   * segments -- a read is cut at positions where the reference's state does not depend on what came before
+//     (k_xs_find: a minimizer value strictly below the MAX_SUPER values in front of it, no non-acgt base within 2K), one
+//     candidate per XS_BLOCK positions; a thread of k_split_exact follows one segment (a whole read when k > 64);
+//   * the walk itself keeps the chain of minimizers behind the current one in registers, so a forced closing is a register
+//     move and not a walk over the ring of the last 2K values (the ring is still written, for the rare closing that finds
+//     the chain run out), and the lanes of a wave write the same ring row in the same turn;
+//   * the emit pass leaves an 8-byte note per super-mer in its record slot; k_xs_pack, one thread per record, turns the
+//     notes into records 16 bases at a time.
+// Two walks (count per segment and bucket, scan, emit) as before.  1 G bases of 15 kbp reads: 516 ms at the start of round 5,
+// 24 ms now (kernels: two walks 13 ms, k_xs_find 4 ms, k_xs_pack 1 ms); the default splitter's stage is 9 ms.
 #include "fk_common.h"
 
 #define XS_THREADS 128
@@ -45,6 +56,7 @@ struct ExactArgs
   const u32 *seg_read;          // [nseg] read of segment i
   const u32 *seg_p0;            // [nseg] its first position in the read (0: the read's start)
   const u32 *seg_p1;            // [nseg] the position it ends WITH (the next segment's first), 0xffffffff: the read's end
+  int       dq_cap;             // entries of the minimizer chain k_split_exact keeps (XS_DQ; fk_debug_set("exact_chain") less)
   int       defer;              // the emit pass leaves notes, k_xs_pack writes the records (records of >= 2 words)
 };
 
@@ -178,7 +190,7 @@ __global__ __launch_bounds__(XS_THREADS) void k_split_exact(ExactArgs a)
         inc = false;                       // (everything behind a dropped entry is larger than it: dropped as well)
       cnt = keep;
       if (!inc)
-        { if (cnt < XS_DQ)
+        { if (cnt < a.dq_cap)
             {
 #pragma unroll
               for (int i = 0; i < XS_DQ; i++)
@@ -594,6 +606,7 @@ int fkx_split_exact(fk_ctx *ctx, const void *d_bases, const int64_t *d_roff, int
   a.inst = d_inst;
   a.nparts = nparts;
   a.defer = (a.sww >= 2) ? 1 : 0;
+  a.dq_cap = (ctx->dbg_exact_chain >= 1 && ctx->dbg_exact_chain < XS_DQ) ? ctx->dbg_exact_chain : XS_DQ;
   a.pad_len = 5 + ((nparts > 1) ? ctx->scheme_pad : 0);
   a.pad2 = (nparts > 1) ? 2 * ctx->scheme_pad : 0;
   a.trie = (nparts > 1) ? ctx->d_min_part : NULL;

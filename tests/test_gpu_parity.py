@@ -1689,6 +1689,27 @@ def test_exact_parts_mode_reproduces_reference_files(name, tmp_path):
         assert got == digest, fname
 
 
+@pytest.mark.parametrize("knobs", [dict(exact_chain=1), dict(exact_chain=2), dict(exact_segments=0),
+                                   dict(exact_chain=1, exact_segments=0)], ids=lambda d: ",".join("%s=%d" % kv for kv in d.items()))
+@pytest.mark.parametrize("name", ["edge_k40_t1_T4", "synth_hifi_k40_t4_T8", "synth_illumina_k51_t1_T4", "edge_k21_t2_T3"])
+def test_exact_splitter_paths_give_the_same_files(name, knobs, tmp_path):
+    """k_split_exact keeps the chain of minimizers behind the current one in registers (8 entries) and walks its ring, as
+    the reference does at every forced closing (split.c:1304-1320), only when that chain ran out; long reads are cut into
+    segments where the reference's state is known.  With the chain shortened to 1 or 2 entries the ring walk is the common
+    path, without segments a thread follows a whole read: every output file is still the reference's."""
+    case, bases, boff = util.load_case(name)
+    with fastk_amd.Context(kmer=case["k"], table_cutoff=case["cutoff"], nthreads=case["T"], exact_parts=True) as ctx:
+        for key, v in knobs.items():
+            ctx.debug_set(key, v)
+        _push_in_pieces(ctx, bases, boff, 2)
+        res = ctx.finish()
+        util.check_against_golden(case, res.hist, res.max_inst, res.table)
+        ctx.write_hist(res, str(tmp_path / "x.hist"))
+        ctx.write_ktab(res, str(tmp_path), "x")
+    for fname, digest in case["expected"]["file_sha256"].items():
+        assert util.sha_file(tmp_path / fname) == digest, fname
+
+
 @pytest.mark.parametrize("name,fmt", [("edge_k40_t1_T4", "fasta"), ("synth_illumina_k51_t1_T4", "fasta"),
                                       ("synth_hifi_k40_t4_T8", "fasta")])
 def test_reference_main_over_gpu_shim(name, fmt, tmp_path):
