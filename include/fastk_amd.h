@@ -76,7 +76,7 @@ typedef struct
                               so that the hidden .ktab part files get the reference's first-byte
                               boundaries (Table_Split, count.c:1560-1565) -- byte-identical files
                               whenever the reference would use one bucket (k-mers fit -M);
-                              needs fk_push_block (read offsets); ~10x slower split           */
+                              needs fk_push_block (read offsets); the split stage ~2.6x the default one's           */
     int     split_passes;  /* fk_count_device_reads on reads that stay resident, nbuckets > 1: split the
                               reads this many times, each pass emitting the super-mers of one group of
                               buckets only, so that 1/split_passes of the super-mer records are in HBM
