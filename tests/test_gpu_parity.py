@@ -1,5 +1,6 @@
 """Parity of the HIP path (through the C-ABI, libfastk_amd.so) against the CPU oracle and the
 golden vectors captured from the reference.  Needs a real MI355X: run with -m gpu."""
+import os
 import numpy as np
 import pytest
 
@@ -1708,6 +1709,65 @@ def test_exact_splitter_paths_give_the_same_files(name, knobs, tmp_path):
         ctx.write_ktab(res, str(tmp_path), "x")
     for fname, digest in case["expected"]["file_sha256"].items():
         assert util.sha_file(tmp_path / fname) == digest, fname
+
+
+def _low_complexity_reads(seed, nreads=260, lengths=(40, 60, 150, 400, 1500, 6000)):
+    """Reads made of what breaks ties in a minimizer scheme: homopolymers, di-/tri-/tetra-nucleotide repeats (among
+    them the ones equal to their own reverse complement), copies of one short motif with a few substitutions, runs of N,
+    random stretches in between -- 40 to 6000 bases, so that some are cut into segments by the exact splitter."""
+    rng = np.random.default_rng(seed)
+    units = ["A", "T", "C", "AC", "AT", "CG", "GA", "AAT", "ACG", "ACGT", "AATT", "GATC", "AACCGGTT", "ACACACGT"]
+    reads = []
+    for _ in range(nreads):
+        want = int(rng.choice(lengths))
+        parts, n = [], 0
+        while n < want:
+            kind = rng.integers(0, 10)
+            ln = int(rng.integers(5, 300))
+            if kind < 6:
+                u = units[int(rng.integers(0, len(units)))]
+                piece = np.frombuffer((u * (ln // len(u) + 1))[:ln].encode(), dtype=np.uint8).copy()
+                if kind >= 4 and ln > 10:                       # a few substitutions
+                    for q in rng.integers(0, ln, size=max(1, ln // 40)):
+                        piece[q] = ord("ACGT"[int(rng.integers(0, 4))])
+            elif kind < 9:
+                piece = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=ln)]
+            else:
+                piece = np.full(int(rng.integers(1, 60)), ord("N"), dtype=np.uint8)
+            parts.append(piece)
+            n += len(piece)
+        reads.append(np.concatenate(parts)[:want].tobytes())
+    return orc.block_from_reads(reads)
+
+
+@pytest.mark.parametrize("knobs", [dict(), dict(exact_chain=1), dict(exact_segments=0)],
+                         ids=lambda d: ",".join("%s=%d" % kv for kv in d.items()) or "default")
+@pytest.mark.parametrize("k,T,seed", [(40, 4, 1), (21, 1, 2), (51, 3, 3), (64, 2, 4), (33, 8, 5), (40, 2, 106), (27, 4, 107)])
+def test_exact_splitter_on_low_complexity_reads(k, T, seed, knobs, tmp_path):
+    """The reference run live (oracle/_ref/FastK) on reads full of ties -- equal minimizer values inside one window are
+    what the `<` on arrival / `<=` on the forced rescan of split.c:1149,1306-1315 decide, and what the register chain
+    of k_split_exact has to reproduce -- against exact_parts: every output file byte for byte."""
+    if not orc.have_ref():
+        util.no_reference("oracle/_ref/FastK not built (needs the reference sources at build time)")
+    bases, boff = _low_complexity_reads(20260000 + seed) if seed < 100 else \
+                  _low_complexity_reads(20260000 + seed, 60, (39, 5000, 30000, 120000))     # (many segments per read)
+    ref = tmp_path / "ref"
+    ref.mkdir()
+    orc.write_fasta(str(ref / "x.fasta"), bases, boff, width=0)
+    orc.run_ref_fastk(str(ref / "x.fasta"), k, 1, T, str(ref))
+    ours = tmp_path / "ours"
+    ours.mkdir()
+    with fastk_amd.Context(kmer=k, table_cutoff=1, nthreads=T, exact_parts=True) as ctx:
+        for key, v in knobs.items():
+            ctx.debug_set(key, v)
+        _push_in_pieces(ctx, bases, boff, 2)
+        res = ctx.finish()
+        ctx.write_hist(res, str(ours / "x.hist"))
+        ctx.write_ktab(res, str(ours), "x")
+    names = sorted(f for f in os.listdir(ref) if f != "x.fasta")
+    assert "x.hist" in names and "x.ktab" in names and len(names) == 2 + T, names
+    for f in names:
+        assert open(ours / f, "rb").read() == open(ref / f, "rb").read(), f
 
 
 @pytest.mark.parametrize("name,fmt", [("edge_k40_t1_T4", "fasta"), ("synth_illumina_k51_t1_T4", "fasta"),
