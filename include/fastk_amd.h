@@ -537,8 +537,11 @@ typedef struct
   } fk_sort_stats;
 int fk_get_sort_stats(fk_ctx *ctx, fk_sort_stats *st);
 
-/* Measurement aid for profiles/: selects ablated kernel variants; results are
-   invalid while a non-zero variant is set.  The product path never calls it. */
+/* Measurement and test aid: selects ablated kernel variants for profiles/ (results are invalid while a non-zero
+   variant is set) and alternative routes with the SAME results for the tests ("aggr_engine", "radix_engine",
+   "slab_bytes", "exact_segments" 0: the exact splitter follows whole reads, "exact_chain" 1..7: it keeps that many
+   entries of its minimizer chain in registers, so that the ring walk behind it is exercised).  The product path never
+   calls it. */
 int fk_debug_set(fk_ctx *ctx, const char *key, int64_t value);
 /* Reads back a counter of the last run ("aggr_extra_rounds": bin rounds that had to be split). */
 int fk_debug_get(fk_ctx *ctx, const char *key, int64_t *value);
