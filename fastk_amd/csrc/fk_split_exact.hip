@@ -67,7 +67,8 @@ __device__ __forceinline__ int xs_code(unsigned ch)
   return ok ? (int) (x ^ (x >> 1)) : 4;
 }
 
-template <bool EMIT>
+// ONE: a single bucket (no scheme) -- the per-bucket record counters are one register, there is no trie to walk
+template <bool EMIT, bool ONE>
 __global__ __launch_bounds__(XS_THREADS) void k_split_exact(ExactArgs a)
 { const int64_t sg = (int64_t) blockIdx.x * XS_THREADS + threadIdx.x;      // the segment: cnt / off are indexed by it
   if (sg >= a.nseg)
@@ -115,9 +116,10 @@ __global__ __launch_bounds__(XS_THREADS) void k_split_exact(ExactArgs a)
       const u32 w = (o < 8) ? (o < 4 ? ch.x : ch.y) : (o < 12 ? ch.z : ch.w);
       return ((w >> (8 * (o & 3))) & 0xffu);
     };
-  u32 nrec[XS_MAXPARTS];                  // records of this read so far, per bucket
-  for (int b = 0; b < a.nparts; b++)
+  u32 nrec[ONE ? 1 : XS_MAXPARTS];        // records of this read so far, per bucket
+  for (int b = 0; b < (ONE ? 1 : a.nparts); b++)
     nrec[b] = 0;
+  const u64 off0 = (EMIT && ONE) ? a.off[sg] : 0ull;
   u64 ninst = 0;
   const int lenw  = a.smer_bytes >> 2;
   const int lensh = 24 - 8 * (a.smer_bytes & 3);
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(XS_THREADS) void k_split_exact(ExactArgs a)
   auto emit = [&](int first_end, int n, int flip, u32 mval)
     { // k-mers ending at first_end .. first_end+n-1: bases s[first_end-KM1 .. first_end+n-1]; mval: their minimizer
       int bk = 0;
-      if (a.trie != NULL)                                    // split.c:1149-1157
+      if (!ONE && a.trie != NULL)                            // split.c:1149-1157
         { int o = (int) (mval >> a.pad2);
           bk = a.trie[o];
           int y = a.pad2 - 2;
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(XS_THREADS) void k_split_exact(ExactArgs a)
       if (EMIT && a.defer)
         { // where the super-mer lies and how long it is, left in its own record slot: k_xs_pack turns the note into the
           // record with every lane at work -- packing here held the whole wave at each closing of any of its lanes
-          u32 *dst = a.out + (a.off[(int64_t) bk * a.nseg + sg] + nrec[bk]) * (u64) a.sww;
+          u32 *dst = a.out + ((ONE ? off0 : a.off[(int64_t) bk * a.nseg + sg]) + nrec[ONE ? 0 : bk]) * (u64) a.sww;
           const u64 at = (u64) (s - a.bases) + (u64) (first_end - KM1);
           dst[0] = (u32) at;
           dst[1] = (u32) (at >> 32) | ((u32) (n - 1) << 16) | ((u32) flip << 31);
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(XS_THREADS) void k_split_exact(ExactArgs a)
       else if (EMIT)
         { const unsigned char *b = s + (first_end - KM1);
           const int L = n - 1 + K;
-          u32 *dst = a.out + (a.off[(int64_t) bk * a.nseg + sg] + nrec[bk]) * (u64) a.sww;
+          u32 *dst = a.out + ((ONE ? off0 : a.off[(int64_t) bk * a.nseg + sg]) + nrec[ONE ? 0 : bk]) * (u64) a.sww;
           for (int w = 0; w < a.sww; w++)
             { u32 x = 0;
               for (int j = 0; j < 16; j++)
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(XS_THREADS) void k_split_exact(ExactArgs a)
               dst[w] = __builtin_bswap32(x);
             }
         }
-      nrec[bk] += 1;
+      nrec[ONE ? 0 : bk] += 1;
       ninst += (u64) n;
     };
 
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(XS_THREADS) void k_split_exact(ExactArgs a)
     }
 
   if (!EMIT)
-    for (int b = 0; b < a.nparts; b++)
+    for (int b = 0; b < (ONE ? 1 : a.nparts); b++)
       a.cnt[(int64_t) b * a.nseg + sg] = nrec[b];
   if (ninst != 0)
     atomicAdd(&a.inst[sg & 63], ninst);
@@ -660,7 +662,10 @@ int fkx_split_exact(fk_ctx *ctx, const void *d_bases, const int64_t *d_roff, int
   a.off = d_off;
   const unsigned grid = (unsigned) ((nseg + XS_THREADS - 1) / XS_THREADS);
   FK_HIP(ctx, hipMemsetAsync(d_inst, 0, 72 * sizeof(u64), s));
-  hipLaunchKernelGGL(k_split_exact<false>, dim3(grid), dim3(XS_THREADS), 0, s, a);
+  if (nparts == 1)
+    hipLaunchKernelGGL((k_split_exact<false, true>), dim3(grid), dim3(XS_THREADS), 0, s, a);
+  else
+    hipLaunchKernelGGL((k_split_exact<false, false>), dim3(grid), dim3(XS_THREADS), 0, s, a);
   if (xs_exscan(ctx, (const u32 *) d_cnt, nseg * nparts, d_off, d_inst + 64) != FK_OK) return (FK_ENOMEM);
   FK_LAUNCH_CHECK(ctx);
   FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch, d_inst, 72 * sizeof(u64), hipMemcpyDeviceToHost, s));
@@ -685,7 +690,10 @@ int fkx_split_exact(fk_ctx *ctx, const void *d_bases, const int64_t *d_roff, int
     return (FK_ENOMEM);
   a.out = (u32 *) out;
   FK_HIP(ctx, hipMemsetAsync(d_inst, 0, 72 * sizeof(u64), s));
-  hipLaunchKernelGGL(k_split_exact<true>, dim3(grid), dim3(XS_THREADS), 0, s, a);
+  if (nparts == 1)
+    hipLaunchKernelGGL((k_split_exact<true, true>), dim3(grid), dim3(XS_THREADS), 0, s, a);
+  else
+    hipLaunchKernelGGL((k_split_exact<true, false>), dim3(grid), dim3(XS_THREADS), 0, s, a);
   if (a.defer)
     hipLaunchKernelGGL(k_xs_pack, dim3((unsigned) ((ns + 255) / 256)), dim3(256), 0, s, a, ns);
   FK_LAUNCH_CHECK(ctx);
