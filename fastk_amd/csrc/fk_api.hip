@@ -660,7 +660,7 @@ extern "C" int fk_debug_set(fk_ctx *ctx, const char *key, int64_t value)
     { ctx->dbg_radix_engine = (int) value;
       return (FK_OK);
     }
-  if (strcmp(key, "exact_chain") == 0)      // 1..7: entries of the minimizer chain the exact splitter keeps in registers
+  if (strcmp(key, "exact_chain") == 0)      // 1..5: entries of the minimizer chain the exact splitter keeps in registers
     { ctx->dbg_exact_chain = (int) value;
       return (FK_OK);
     }

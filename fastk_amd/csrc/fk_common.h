@@ -212,7 +212,7 @@ struct fk_ctx
   int        dbg_radix_variant;   // measurement aids, see fk_debug_set
   int        dbg_radix_items;
   int        dbg_exact_segments;  // -1: the exact splitter keeps one thread per read (no segments inside long reads)
-  int        dbg_exact_chain;     // 1..7: the exact splitter keeps that many entries of its minimizer chain (tests: the ring walk behind it)
+  int        dbg_exact_chain;     // 1..5: the exact splitter keeps that many entries of its minimizer chain (tests: the ring walk behind it)
   int        dbg_scatter_abl;     // -DFK_ABLATION builds: RX_ABL_* bits of the stream engine's scatter kernels (fk_radix.hip)
   int        dbg_radix_engine;    // 1 = look-back engine instead of the stream engine
   int        dbg_kmer_stage;      // 1 = sort-collapse-sort k-mer stage instead of hash aggregation

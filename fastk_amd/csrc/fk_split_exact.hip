@@ -22,13 +22,13 @@
 //   * the emit pass leaves an 8-byte note per super-mer in its record slot; k_xs_pack, one thread per record, turns the
 //     notes into records 16 bases at a time.
 // Two walks (count per segment and bucket, scan, emit) as before.  1 G bases of 15 kbp reads: 516 ms at the start of round 5,
-// 24 ms now (kernels: two walks 13 ms, k_xs_find 4 ms, k_xs_pack 1 ms); the default splitter's stage is 9 ms.
+// 20 ms now (kernels: two walks 9.6 ms, k_xs_find 4.3 ms, k_xs_pack 1 ms); the default splitter's stage is 9.5 ms.
 #include "fk_common.h"
 
 #define XS_THREADS 128
 #define XS_RING    256          // >= 2 * nextpow2(K) for K <= 128 (MOD_LEN, FastK.c:446-450)
 #define XS_MAXPARTS FK_EXACT_MAXPARTS
-#define XS_DQ      8            // entries of the minimizer chain kept in registers (k_split_exact)
+#define XS_DQ      6            // entries of the minimizer chain kept in registers (k_split_exact)
 
 struct ExactArgs
 { const unsigned char *bases;

@@ -76,7 +76,7 @@ typedef struct
                               so that the hidden .ktab part files get the reference's first-byte
                               boundaries (Table_Split, count.c:1560-1565) -- byte-identical files
                               whenever the reference would use one bucket (k-mers fit -M);
-                              needs fk_push_block (read offsets); the split stage ~2.6x the default one's           */
+                              needs fk_push_block (read offsets); the split stage ~2x the default one's           */
     int     split_passes;  /* fk_count_device_reads on reads that stay resident, nbuckets > 1: split the
                               reads this many times, each pass emitting the super-mers of one group of
                               buckets only, so that 1/split_passes of the super-mer records are in HBM
@@ -539,7 +539,7 @@ int fk_get_sort_stats(fk_ctx *ctx, fk_sort_stats *st);
 
 /* Measurement and test aid: selects ablated kernel variants for profiles/ (results are invalid while a non-zero
    variant is set) and alternative routes with the SAME results for the tests ("aggr_engine", "radix_engine",
-   "slab_bytes", "exact_segments" 0: the exact splitter follows whole reads, "exact_chain" 1..7: it keeps that many
+   "slab_bytes", "exact_segments" 0: the exact splitter follows whole reads, "exact_chain" 1..5: it keeps that many
    entries of its minimizer chain in registers, so that the ring walk behind it is exercised).  The product path never
    calls it. */
 int fk_debug_set(fk_ctx *ctx, const char *key, int64_t value);

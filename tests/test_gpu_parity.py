@@ -1694,7 +1694,7 @@ def test_exact_parts_mode_reproduces_reference_files(name, tmp_path):
                                    dict(exact_chain=1, exact_segments=0)], ids=lambda d: ",".join("%s=%d" % kv for kv in d.items()))
 @pytest.mark.parametrize("name", ["edge_k40_t1_T4", "synth_hifi_k40_t4_T8", "synth_illumina_k51_t1_T4", "edge_k21_t2_T3"])
 def test_exact_splitter_paths_give_the_same_files(name, knobs, tmp_path):
-    """k_split_exact keeps the chain of minimizers behind the current one in registers (8 entries) and walks its ring, as
+    """k_split_exact keeps the chain of minimizers behind the current one in registers (6 entries) and walks its ring, as
     the reference does at every forced closing (split.c:1304-1320), only when that chain ran out; long reads are cut into
     segments where the reference's state is known.  With the chain shortened to 1 or 2 entries the ring walk is the common
     path, without segments a thread follows a whole read: every output file is still the reference's."""
