@@ -22,7 +22,7 @@
 //   * the emit pass leaves an 8-byte note per super-mer in its record slot; k_xs_pack, one thread per record, turns the
 //     notes into records 16 bases at a time.
 // Two walks (count per segment and bucket, scan, emit) as before.  1 G bases of 15 kbp reads: 516 ms at the start of round 5,
-// 20 ms now (kernels: two walks 9.6 ms, k_xs_find 4.3 ms, k_xs_pack 1 ms); the default splitter's stage is 9.5 ms.
+// 18 ms now (kernels: two walks 9.5 ms, k_xs_find 2.2 ms, k_xs_pack 1 ms); the default splitter's stage is 10 ms.
 #include "fk_common.h"
 
 #define XS_THREADS 128
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256) void k_xs_pack(ExactArgs a, int64_t ns)
 // exactly as k_split_exact computes it -- strictly below the values of the MAX_SUPER positions in front of it, and no
 // non-acgt base among the 2K positions up to p.  A block without such a position (low complexity, N runs) begins none: its
 // positions belong to the segment in front of it.  Any choice is right; more of them is only more threads.
-#define XS_BLOCK 512
+#define XS_BLOCK 1024
 
 __global__ __launch_bounds__(256) void k_xs_blocks(const int64_t *__restrict__ roff, int64_t nreads, int bc_prefix, int kmer,
                                                    u32 *__restrict__ nblk)
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(128) void k_xs_find(ExactArgs a, const u32 *__restr
   unsigned c = 0, u = 0;
   int bad = -1;                                              // the last position that holds no acgt
   u32 found = 0xffffffffu;
-  const int start = lo - 2 * K - PL1;                        // (lo >= XS_BLOCK = 512 > 2K + pad for k <= 64: inside the read)
+  const int start = lo - 2 * K - PL1;                        // (lo >= XS_BLOCK = 1024 > 2K + pad for k <= 64: inside the read)
   uint4 ch = make_uint4(0u, 0u, 0u, 0u);
   uintptr_t ch_at = ~(uintptr_t) 0;
   for (int p = start; p < hi; p++)
