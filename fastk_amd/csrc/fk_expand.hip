@@ -435,7 +435,8 @@ int fkx_expand(fk_ctx *ctx, const void *d_smers, int64_t nsuper, void *d_out, in
                int64_t *nweighted, int64_t *ndistinct, int64_t *overflow, bool reuse_counts,
                bool hash_stream, bool dedup)
 { switch (ctx->wid.smer_stride >> 2)
-  { case 2: return expand_t<2>(ctx, d_smers, nsuper, d_out, cap, nweighted, ndistinct, overflow, reuse_counts, hash_stream, dedup);
+  { case 1: return expand_t<1>(ctx, d_smers, nsuper, d_out, cap, nweighted, ndistinct, overflow, reuse_counts, hash_stream, dedup);   // (k = 8)
+    case 2: return expand_t<2>(ctx, d_smers, nsuper, d_out, cap, nweighted, ndistinct, overflow, reuse_counts, hash_stream, dedup);
     case 3: return expand_t<3>(ctx, d_smers, nsuper, d_out, cap, nweighted, ndistinct, overflow, reuse_counts, hash_stream, dedup);
     case 4: return expand_t<4>(ctx, d_smers, nsuper, d_out, cap, nweighted, ndistinct, overflow, reuse_counts, hash_stream, dedup);
     case 5: return expand_t<5>(ctx, d_smers, nsuper, d_out, cap, nweighted, ndistinct, overflow, reuse_counts, hash_stream, dedup);

@@ -1711,6 +1711,24 @@ def test_exact_splitter_paths_give_the_same_files(name, knobs, tmp_path):
         assert util.sha_file(tmp_path / fname) == digest, fname
 
 
+@pytest.mark.parametrize("exact", [False, True], ids=["default", "exact_parts"])
+@pytest.mark.parametrize("k", [8, 9, 11, 12])
+def test_smallest_kmer_sizes(k, exact):
+    """k = 8 is the lower limit fk_create accepts: its super-mers are records of ONE 32-bit word (11 bases and the length
+    byte), the only k whose records are -- the expansion was not built for them until round 5 (`super-mer stride 4 not
+    built`).  Random reads of 5 to 400 bases against the oracle, default splitter and exact_parts."""
+    rng = np.random.default_rng(800 + k)
+    reads = [bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=int(rng.integers(5, 400)))])
+             for _ in range(300)]
+    bases, boff = orc.block_from_reads(reads)
+    o = orc.fastk(k, bases, boff, cutoff=1, nthreads=2)
+    with fastk_amd.Context(kmer=k, table_cutoff=1, nthreads=2, exact_parts=exact) as ctx:
+        ctx.push_block(bases, boff.astype(np.int32))
+        res = ctx.finish()
+    assert np.array_equal(res.hist, o.hist) and res.max_inst == o.max_inst
+    assert np.array_equal(res.table, o.table)
+
+
 def _low_complexity_reads(seed, nreads=260, lengths=(40, 60, 150, 400, 1500, 6000)):
     """Reads made of what breaks ties in a minimizer scheme: homopolymers, di-/tri-/tetra-nucleotide repeats (among
     them the ones equal to their own reverse complement), copies of one short motif with a few substitutions, runs of N,
@@ -1742,7 +1760,8 @@ def _low_complexity_reads(seed, nreads=260, lengths=(40, 60, 150, 400, 1500, 600
 
 @pytest.mark.parametrize("knobs", [dict(), dict(exact_chain=1), dict(exact_segments=0)],
                          ids=lambda d: ",".join("%s=%d" % kv for kv in d.items()) or "default")
-@pytest.mark.parametrize("k,T,seed", [(40, 4, 1), (21, 1, 2), (51, 3, 3), (64, 2, 4), (33, 8, 5), (40, 2, 106), (27, 4, 107)])
+@pytest.mark.parametrize("k,T,seed", [(40, 4, 1), (21, 1, 2), (51, 3, 3), (64, 2, 4), (33, 8, 5), (40, 2, 106), (27, 4, 107),
+                                      (8, 2, 8), (12, 4, 9), (16, 1, 10)])     # (k = 8: one-word records, packed in the walk)
 def test_exact_splitter_on_low_complexity_reads(k, T, seed, knobs, tmp_path):
     """The reference run live (oracle/_ref/FastK) on reads full of ties -- equal minimizer values inside one window are
     what the `<` on arrival / `<=` on the forced rescan of split.c:1149,1306-1315 decide, and what the register chain
