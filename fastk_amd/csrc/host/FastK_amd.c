@@ -135,7 +135,7 @@ static void flush_block(Feeder *f, int rem)
         }
       else if (fk_make_profiles(f->ctx,f->d_piece,f->olen,&pr) != FK_OK)
         die(f->ctx,"fk_make_profiles");
-      if (f->pbytes+pr.nbytes > f->pbytes_cap)
+      if (f->pdata == NULL || f->pbytes+pr.nbytes > f->pbytes_cap)    /* (a piece of reads shorter than k has profiles of no bytes) */
         { f->pbytes_cap = (f->pbytes+pr.nbytes)*2 + (1 << 20);
           f->pdata = realloc(f->pdata,(size_t) f->pbytes_cap);
         }

@@ -1729,6 +1729,32 @@ def test_smallest_kmer_sizes(k, exact):
     assert np.array_equal(res.table, o.table)
 
 
+@pytest.mark.parametrize("what", ["three reads, one shorter than k, -p", "short reads only, -p", "two reads for four ranks",
+                                  "reads shorter than k among others, -t2 -p"])
+def test_cli_degenerate_inputs_one_gpu_and_sharded(what):
+    """Files so small that a rank of FastK_amd -G4 gets no read, or only reads without a k-mer (their profiles have no
+    bytes: round 5 found the driver calling that `Out of memory`): FastK_amd, -G2 and -G4 (ranks sharing the GPU) and the
+    reference itself agree on .hist, the .ktab stream and the decoded profiles (tools/cli_degenerate_probe.py holds more
+    of these).  Where the reference dies of the input (only reads shorter than k) ours agree among themselves."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("cli_degenerate_probe", os.path.join(root, "tools", "cli_degenerate_probe.py"))
+    probe = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(probe)
+    if not os.path.exists(probe.REF):
+        util.no_reference("oracle/_ref/FastK not built")
+    rng = np.random.default_rng(11)
+    r = lambda n: probe.rnd(rng, n)
+    reads, flags = {"three reads, one shorter than k, -p": ([r(100), r(30), r(3000)], ("-t1", "-p")),
+                    "short reads only, -p": ([r(30), r(20)], ("-t1", "-p")),
+                    "two reads for four ranks": ([r(200), r(200)], ("-t1",)),
+                    "reads shorter than k among others, -t2 -p": ([r(100)] * 2 + [r(30), r(3000), r(41)], ("-t2", "-p"))}[what]
+    ok, res = probe.case(what, reads, flags=flags)
+    if not ok and any(m in str(res) for m in _RCCL_RIG_ERRORS):
+        pytest.skip("RCCL would not bring up several ranks on one GPU here")
+    assert ok, res
+
+
 def _low_complexity_reads(seed, nreads=260, lengths=(40, 60, 150, 400, 1500, 6000)):
     """Reads made of what breaks ties in a minimizer scheme: homopolymers, di-/tri-/tetra-nucleotide repeats (among
     them the ones equal to their own reverse complement), copies of one short motif with a few substitutions, runs of N,
