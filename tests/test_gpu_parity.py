@@ -1755,6 +1755,21 @@ def test_cli_degenerate_inputs_one_gpu_and_sharded(what):
     assert ok, res
 
 
+def test_exact_parts_long_reads_in_several_buckets():
+    """The two halves of the exact splitter that the other tests take one at a time: long reads (cut into segments) AND a
+    sort memory so small that the reference deals the minimizers to several buckets (the trie walk per super-mer).
+    200 M bases in 15 kbp reads, FastK_amd -x -M1 (-T4: 3 buckets) and -M2 (-T3) against the reference run live with the
+    same options: every output file, hidden parts included (tools/exact_long_reads_buckets_probe.py)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not orc.have_ref():
+        util.no_reference("oracle/_ref/FastK not built")
+    spec = importlib.util.spec_from_file_location("xlb", os.path.join(root, "tools", "exact_long_reads_buckets_probe.py"))
+    probe = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(probe)
+    assert probe.run(200.0, 15000) == 0
+
+
 def _low_complexity_reads(seed, nreads=260, lengths=(40, 60, 150, 400, 1500, 6000)):
     """Reads made of what breaks ties in a minimizer scheme: homopolymers, di-/tri-/tetra-nucleotide repeats (among
     them the ones equal to their own reverse complement), copies of one short motif with a few substitutions, runs of N,
