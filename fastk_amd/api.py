@@ -265,7 +265,7 @@ class Context:
         self.L.fk_default_params(C.byref(p))
         p.kmer, p.table_cutoff, p.nthreads = kmer, table_cutoff, nthreads
         p.bc_prefix, p.device, p.nbuckets = bc_prefix, device, nbuckets
-        p.exact_parts = 1 if exact_parts else 0
+        p.exact_parts = int(exact_parts)        # (True / 1; 2: a run that will make profiles, see fk_params.exact_parts)
         p.hbm_budget = int(hbm_budget)
         p.split_passes = int(split_passes)
         self.params = p

@@ -57,6 +57,9 @@ struct ExactArgs
   const u32 *seg_p0;            // [nseg] its first position in the read (0: the read's start)
   const u32 *seg_p1;            // [nseg] the position it ends WITH (the next segment's first), 0xffffffff: the read's end
   int       dq_cap;             // entries of the minimizer chain k_split_exact keeps (XS_DQ; fk_debug_set("exact_chain") less)
+  int       noflip;             // exact_parts = 2 (a run with profiles): the records keep the read's strand, as the reference's
+                                // do under -p (split.c:1245: Stuff_Seq(..., 0, ...)) -- a super-mer and its reverse complement
+                                // are then two records, and the first-byte census that cuts the .ktab parts sees both
   int       defer;              // the emit pass leaves notes, k_xs_pack writes the records (records of >= 2 words)
 };
 
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(XS_THREADS) void k_split_exact(ExactArgs a)
           else
             n = p - last;
           if (n > 0)
-            emit(last, n, (int) mfl, mc);
+            emit(last, n, a.noflip ? 0 : (int) mfl, mc);
           if (done || (u32) p == p1)                         // (the next segment begins here, with the state this closing leaves)
             break;
           last = p;
@@ -608,6 +611,7 @@ int fkx_split_exact(fk_ctx *ctx, const void *d_bases, const int64_t *d_roff, int
   a.inst = d_inst;
   a.nparts = nparts;
   a.defer = (a.sww >= 2) ? 1 : 0;
+  a.noflip = (ctx->prm.exact_parts == 2) ? 1 : 0;
   a.dq_cap = (ctx->dbg_exact_chain >= 1 && ctx->dbg_exact_chain < XS_DQ) ? ctx->dbg_exact_chain : XS_DQ;
   a.pad_len = 5 + ((nparts > 1) ? ctx->scheme_pad : 0);
   a.pad2 = (nparts > 1) ? 2 * ctx->scheme_pad : 0;

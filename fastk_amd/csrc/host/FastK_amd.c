@@ -100,6 +100,12 @@ struct Feeder
     uint8_t *pdata;
     int64_t *poffs;
     int64_t  pbytes, pbytes_cap, preads, preads_cap;
+    /* -x -p on one plain file: the reads are dealt to the input threads the reference would use (io.c:2420-2521: ITHREADS
+       byte ranges of the file, each moved to the next record start), because its .prof parts are those ranges and its
+       run numbers count per input thread (merge.c:263-267) */
+    int      tid;            /* input thread of the block being filled (fk_push_block's tid) */
+    int      nstarts;        /* 0: everything is thread 0's */
+    off_t    starts[256];    /* file offset of the first record of thread t */
   };
 
 static void die(fk_ctx *ctx, const char *what)
@@ -157,7 +163,7 @@ static void flush_block(Feeder *f, int rem)
     ;                               /* another rank's block (any division of the reads gives the same counts; a piece
                                        of a read cut at a block edge carries its K-1 overlap, so it is dealt like any
                                        other block -- every rank pushing it would count its k-mers NGPUS times) */
-  else if (fk_push_block(f->ctx,f->bases,f->boff,f->nreads,rem,0) != FK_OK)
+  else if (fk_push_block(f->ctx,f->bases,f->boff,f->nreads,rem,f->tid) != FK_OK)
     die(f->ctx,"fk_push_block");
   f->nreads  = 0;
   f->olen    = 0;
@@ -928,11 +934,82 @@ static void scan_text_packed(Feeder *f, const char *path, int fastq)
   close(fd);
 }
 
+/* Where the reference's thread that is given byte `from` of a plain file begins (fast_nearest, io.c:409-490; -1: nowhere).
+   FASTA: the first '>' behind a newline that is read at or behind `from` -- a '>' AT `from` is passed over, whatever is in
+   front of it.  FASTQ: the first '@' behind a newline whose line was neither a single character nor ended in '+' (the
+   quality line of a record may begin with '@'; the separator line in front of it is "+"). */
+static off_t io_nearest(int fd, off_t from, off_t size, int fastq)
+{ enum { WIN = 1 << 16 };
+  static char win[WIN];
+  off_t pos = from;
+  int   nl_1 = 1, nl_2 = 1, pl_1 = 1, alive = 0, fk1 = 0;
+  while (pos < size)
+    { ssize_t n = pread(fd,win,WIN,pos), i;
+      if (n <= 0) break;
+      for (i = 0; i < n; i++)
+        { const char c = win[i];
+          if (fastq)
+            { if (c == '@' && alive) return (pos+i);
+              alive = (c == '\n' && !(nl_2 || pl_1));
+              nl_2 = nl_1;
+              nl_1 = (c == '\n');
+              pl_1 = (c == '+');
+            }
+          else if (fk1)
+            { if (c == '>') return (pos+i);
+              if (c != '\n') fk1 = 0;
+            }
+          else if (c == '\n')
+            fk1 = 1;
+        }
+      pos += n;
+    }
+  return (-1);
+}
+
+/* The input threads the reference would read this plain file with, and where each of them begins (io.c:2420-2521): as many
+   as -T unless that leaves a thread less than 2 % of an IO block (200,000 bytes) -- then one per 200,000 bytes, at least
+   one --, thread i at the first record start at or behind byte i * size / threads; an i whose byte lies at or in front
+   of the previous thread's start gets no thread.  Only the .prof parts and their run numbers depend on it. */
+static void input_threads(Feeder *f, const char *path, int fastq)
+{ struct stat st;
+  int     fd = open(path,O_RDONLY), it, i;
+  int64_t work;
+  f->nstarts = 0;
+  if (fd < 0 || fstat(fd,&st) != 0)
+    { if (fd >= 0) close(fd);
+      return;
+    }
+  work = (int64_t) st.st_size;
+  if ((double) (work/NTHREADS) < .02*10000000ll)
+    { it = (int) ((double) work/(.02*10000000ll));
+      if (it <= 0) it = 1;
+    }
+  else
+    it = NTHREADS;
+  if (it > 256) it = 256;
+  for (i = 0; i < it; i++)
+    { const off_t b = (off_t) (((int64_t) i*work)/it);
+      off_t at;
+      if (f->nstarts > 0 && b <= f->starts[f->nstarts-1])
+        continue;
+      at = (b == 0) ? 0 : io_nearest(fd,b,st.st_size,fastq);
+      if (at < 0)                          /* no record behind b: the threads end here */
+        break;
+      f->starts[f->nstarts++] = at;
+    }
+  close(fd);
+  if (f->nstarts > 0) f->starts[0] = 0;
+}
+
 static void scan_file(Feeder *f, const char *path, int fastq)
 { gzFile  in = gzopen(path,"rb");
   static unsigned char buf[1 << 20];
   int     state = 0;    /* 0 record start, 1 header, 2 fastq seq, 3 '+' line, 4 quality, 5 fasta seq, 6 fasta eol */
   int     n, i;
+  off_t   base = 0;     /* bytes of the file in front of buf */
+#define RECORD_AT(off) do { while (f->tid+1 < f->nstarts && (off) >= f->starts[f->tid+1])   \
+                              { flush_block(f,0); f->tid += 1; } } while (0)
 
   if (in == NULL)
     { fprintf(stderr,"%s: Cannot open %s for reading\n",Prog_Name,path);
@@ -940,20 +1017,23 @@ static void scan_file(Feeder *f, const char *path, int fastq)
     }
   gzbuffer(in,1 << 20);
   while (!range_done(f) && (n = gzread(in,buf,sizeof(buf))) > 0)
-    for (i = 0; i < n; i++)
+   { for (i = 0; i < n; i++)
       { int c = buf[i];
         switch (state)
-        { case 0: state = 1; break;
+        { case 0: RECORD_AT(base+i); state = 1; break;
           case 1: if (c == '\n') state = fastq ? 2 : 5; break;
           case 2: if (c != '\n') add_base(f,c); else { end_read(f); state = 3; } break;
           case 3: if (c == '\n') state = 4; break;
           case 4: if (c == '\n') state = 0; break;
-          case 6: if (c == '>') { end_read(f); state = 1; }
+          case 6: if (c == '>') { end_read(f); RECORD_AT(base+i); state = 1; }
                   else if (c != '\n') { add_base(f,c); state = 5; }
                   break;
           case 5: if (c == '\n') state = 6; else add_base(f,c); break;
         }
       }
+     base += n;
+   }
+#undef RECORD_AT
   if (state == 6)
     end_read(f);
   else if (state == 5 || state == 2)     /* the file ends inside a sequence line: the reference ends a read only at the */
@@ -1194,7 +1274,7 @@ int main(int argc, char *argv[])
   fk_default_params(&prm);
   prm.kmer = KMER; prm.table_cutoff = PROFILE ? 1 : DO_TABLE;   /* -p looks every k-mer up */
   prm.nthreads = NTHREADS; prm.bc_prefix = BC_PREFIX;
-  prm.exact_parts = EXACT;
+  prm.exact_parts = EXACT ? (PROFILE ? 2 : 1) : 0;   /* (2: with -p the reference's super-mers stay on the read's strand) */
   if (MEM_GB > 0 && !EXACT)
     { /* bases ~ file bytes (FASTA), half of them (FASTQ), x4 when gzipped; the super-mers (~1 byte
          per base) stay in HBM up to half the budget and spill to host memory beyond, a bucket's
@@ -1327,7 +1407,10 @@ int main(int argc, char *argv[])
                && !(NGPUS > 1 && strlen(argv[i]) > 3 && strcmp(argv[i]+strlen(argv[i])-3,".gz") == 0))
         scan_text_on_device(&feed,argv[i],q);
       else
-        scan_file(&feed,argv[i],q);
+        { if (EXACT && PROFILE && nfiles == 1 && q <= 1 && !(strlen(argv[i]) > 3 && strcmp(argv[i]+strlen(argv[i])-3,".gz") == 0))
+            input_threads(&feed,argv[i],q);
+          scan_file(&feed,argv[i],q);
+        }
     }
   flush_block(&feed,0);
   if (OUT_NAME != NULL)                   /* -N, FastK.c:406-409 */
@@ -1485,7 +1568,8 @@ int main(int argc, char *argv[])
         }
       else if (fk_make_profiles(ctx,NULL,0,&pr) != FK_OK)
         die(ctx,"fk_make_profiles");
-      if (fk_write_prof(&pr,KMER,NTHREADS,dir,root) != FK_OK)
+      /* -x -p on one plain file: one part per input thread of the reference (input_threads), else one per -T thread */
+      if (fk_write_prof(&pr,KMER,(feed.nstarts > 0 && pr.nsplit == feed.nstarts) ? pr.nsplit : NTHREADS,dir,root) != FK_OK)
         die(ctx,"writing .prof");
       if (VERBOSE)
         fprintf(stderr,"  Profiles of %lld reads in %lld bytes (%.3f s)\n",(long long) pr.nreads,

@@ -38,7 +38,7 @@ int Determine_Scheme(DATA_BLOCK *block)
   /* Fast by default: the position-parallel splitter; .hist, the .ktab stub and the concatenated part payloads are
      the reference's byte for byte, only the hidden part files are cut at other first bytes.  FASTK_AMD_EXACT=1 in
      the environment (or -DFASTK_AMD_EXACT at build time) replays the reference's own super-mer cuts instead: every
-     file byte-identical, the split ~10x slower. */
+     file byte-identical, the split stage ~2x the default one's. */
 #ifdef FASTK_AMD_EXACT
   p.exact_parts = 1;
 #else
@@ -46,6 +46,8 @@ int Determine_Scheme(DATA_BLOCK *block)
     p.exact_parts = (e != NULL && e[0] != '\0' && e[0] != '0');
   }
 #endif
+  if (p.exact_parts && DO_PROFILE)  /* with -p the reference keeps its super-mers on the read's strand (split.c:1245) */
+    p.exact_parts = 2;
   if (fk_create(&p,&GPU) != FK_OK)
     die("fk_create");
   if (p.exact_parts)                /* the reference's buckets (NPARTS of FastK.c:417-429) under its own scheme */

@@ -76,7 +76,10 @@ typedef struct
                               so that the hidden .ktab part files get the reference's first-byte
                               boundaries (Table_Split, count.c:1560-1565) -- byte-identical files
                               whenever the reference would use one bucket (k-mers fit -M);
-                              needs fk_push_block (read offsets); the split stage ~2x the default one's           */
+                              needs fk_push_block (read offsets); the split stage ~2x the default one's.
+                              2: the same for a run that will make profiles (-p): the reference then keeps
+                              its super-mers on the read's strand (split.c:1245), a super-mer and its reverse
+                              complement stay two records, and the parts are cut by THAT list's census       */
     int     split_passes;  /* fk_count_device_reads on reads that stay resident, nbuckets > 1: split the
                               reads this many times, each pass emitting the super-mers of one group of
                               buckets only, so that 1/split_passes of the super-mer records are in HBM

@@ -1770,6 +1770,23 @@ def test_exact_parts_long_reads_in_several_buckets():
     assert probe.run(200.0, 15000) == 0
 
 
+def test_exact_parts_with_profiles_every_file_of_the_reference():
+    """-x -p: under -p the reference keeps its super-mers on the read's strand (split.c:1245, Stuff_Seq(..., 0, ...)), so a
+    super-mer and its reverse complement are two records, the weighted k-mer list is another one and the hidden .ktab
+    parts are cut at other first bytes than in a run without -p -- fk_params.exact_parts = 2; and its .prof parts are the
+    byte ranges its input threads read (io.c:2420-2521, fast_nearest), with run numbers per thread.  FastK_amd -x -p and
+    the reference's main() over the shim (FASTK_AMD_EXACT=1 -p) against the reference run live on reads full of ties,
+    one and several input threads, FASTA and FASTQ: every file (tools/exact_prof_low_complexity_probe.py)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not (orc.have_ref() and os.path.exists(os.path.join(orc.REF_DIR, "FastK_gpu"))):
+        util.no_reference("oracle/_ref/FastK, FastK_gpu not built")
+    spec = importlib.util.spec_from_file_location("xp", os.path.join(root, "tools", "exact_prof_low_complexity_probe.py"))
+    probe = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(probe)
+    assert probe.run() == 0
+
+
 def _low_complexity_reads(seed, nreads=260, lengths=(40, 60, 150, 400, 1500, 6000)):
     """Reads made of what breaks ties in a minimizer scheme: homopolymers, di-/tri-/tetra-nucleotide repeats (among
     them the ones equal to their own reverse complement), copies of one short motif with a few substitutions, runs of N,
@@ -1884,8 +1901,24 @@ def test_reference_main_with_profiles_over_gpu_shim(name, tmp_path):
     subprocess.run([exe, "-k%d" % k, "-t%d" % case["cutoff"], "-T%d" % case["T"], "-p",
                     "-P" + str(tmp_path), path], check=True, cwd=str(tmp_path), env=dict(os.environ, FASTK_AMD_EXACT="1"),
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    # (the golden's .ktab digests are those of a run WITHOUT -p: .hist, the stub and the canonical stream do not depend on
+    # -p, the hidden parts do -- under -p the reference keeps its super-mers on the read's strand, split.c:1245, and cuts
+    # the parts by that list's census; they are compared with the reference run live below)
     for fname, digest in case["expected"]["file_sha256"].items():
-        assert hashlib.sha256(open(tmp_path / fname, "rb").read()).hexdigest() == digest, fname
+        if not fname.startswith(".x.ktab."):
+            assert hashlib.sha256(open(tmp_path / fname, "rb").read()).hexdigest() == digest, fname
+    assert orc.read_ktab(str(tmp_path / "x"))["stream_sha256"] == case["expected"]["ktab"]["stream_sha256"]
+    if orc.have_ref():
+        live = tmp_path / "live"
+        live.mkdir()
+        os.link(path, live / os.path.basename(path))
+        subprocess.run([os.path.join(orc.REF_DIR, "FastK"), "-k%d" % k, "-t%d" % case["cutoff"], "-T%d" % case["T"], "-p",
+                        "-P" + str(live), str(live / os.path.basename(path))], check=True, cwd=str(live),
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        names = sorted(f for f in os.listdir(live) if f != os.path.basename(path))
+        assert len(names) >= 4 + case["T"]
+        for f in names:
+            assert util.sha_file(live / f) == util.sha_file(tmp_path / f), f
     # in exact mode the .prof files are the reference's too, byte for byte: its super-mer junctions (a difference of -31
     # takes two bytes there, merge.c:456,590) and its panel flushes (a pending run is written out every 1024 NPARTS
     # runs per input thread, merge.c:263-267,706-716) are replayed by k_pf_exact
