@@ -1787,6 +1787,20 @@ def test_exact_parts_with_profiles_every_file_of_the_reference():
     assert probe.run() == 0
 
 
+def test_exact_parts_with_the_other_options():
+    """-x with -bc<n>, -c, -t<n>, each with and without -p, FASTA and FASTQ: FastK_amd and the reference's main() over the
+    shim against the reference run live with the same options on reads full of ties -- every output file
+    (tools/exact_flags_probe.py)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not (orc.have_ref() and os.path.exists(os.path.join(orc.REF_DIR, "FastK_gpu"))):
+        util.no_reference("oracle/_ref/FastK, FastK_gpu not built")
+    spec = importlib.util.spec_from_file_location("xf", os.path.join(root, "tools", "exact_flags_probe.py"))
+    probe = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(probe)
+    assert probe.run() == 0
+
+
 def _low_complexity_reads(seed, nreads=260, lengths=(40, 60, 150, 400, 1500, 6000)):
     """Reads made of what breaks ties in a minimizer scheme: homopolymers, di-/tri-/tetra-nucleotide repeats (among
     them the ones equal to their own reverse complement), copies of one short motif with a few substitutions, runs of N,
