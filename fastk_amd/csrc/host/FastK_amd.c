@@ -105,7 +105,9 @@ struct Feeder
        run numbers count per input thread (merge.c:263-267) */
     int      tid;            /* input thread of the block being filled (fk_push_block's tid) */
     int      nstarts;        /* 0: everything is thread 0's */
-    off_t    starts[256];    /* file offset of the first record of thread t */
+    int      st_file[256];   /* thread t begins in input file st_file[t] (0-based) ... */
+    off_t    starts[256];    /* ... at this offset: the first byte of a record */
+    int      cur_file;       /* the file being scanned */
   };
 
 static void die(fk_ctx *ctx, const char *what)
@@ -967,20 +969,38 @@ static off_t io_nearest(int fd, off_t from, off_t size, int fastq)
   return (-1);
 }
 
-/* The input threads the reference would read this plain file with, and where each of them begins (io.c:2420-2521): as many
-   as -T unless that leaves a thread less than 2 % of an IO block (200,000 bytes) -- then one per 200,000 bytes, at least
-   one --, thread i at the first record start at or behind byte i * size / threads; an i whose byte lies at or in front
-   of the previous thread's start gets no thread.  Only the .prof parts and their run numbers depend on it. */
-static void input_threads(Feeder *f, const char *path, int fastq)
-{ struct stat st;
-  int     fd = open(path,O_RDONLY), it, i;
-  int64_t work;
+/* The input threads the reference would read these FASTA / FASTQ files with, and where each of them begins
+   (io.c:2340-2521).  Any file compressed: whole files, one thread per file up to 1.5 x -T files, else -T threads of
+   nfiles / T files each.  Plain files: as many threads as -T unless that leaves a thread less than 2 % of an IO block
+   (200,000 bytes) -- then one per 200,000 bytes, at least one --; thread i at the first record start fast_nearest finds
+   behind byte i * (all bytes) / threads, the files taken as one; an i whose byte lies at or in front of the previous
+   thread's start gets no thread.  Only the .prof parts and their run numbers depend on it. */
+static void input_threads(Feeder *f, char **paths, int nfiles, int fastq)
+{ int64_t size[256], work = 0, w;
+  int     zipped = 0, it, i, fi;
   f->nstarts = 0;
-  if (fd < 0 || fstat(fd,&st) != 0)
-    { if (fd >= 0) close(fd);
+  if (nfiles > 256)
+    return;
+  for (i = 0; i < nfiles; i++)
+    { struct stat st;
+      size_t pl = strlen(paths[i]);
+      if (stat(paths[i],&st) != 0)
+        return;
+      size[i] = (int64_t) st.st_size;
+      work += size[i];
+      if (pl > 3 && strcmp(paths[i]+pl-3,".gz") == 0)
+        zipped = 1;
+    }
+  if (zipped)
+    { it = (nfiles <= 1.5*NTHREADS) ? nfiles : NTHREADS;
+      if (it > 256) it = 256;
+      for (i = 0; i < it; i++)
+        { f->st_file[i] = (int) (((int64_t) i*nfiles)/it);
+          f->starts[i]  = 0;
+        }
+      f->nstarts = it;
       return;
     }
-  work = (int64_t) st.st_size;
   if ((double) (work/NTHREADS) < .02*10000000ll)
     { it = (int) ((double) work/(.02*10000000ll));
       if (it <= 0) it = 1;
@@ -988,18 +1008,37 @@ static void input_threads(Feeder *f, const char *path, int fastq)
   else
     it = NTHREADS;
   if (it > 256) it = 256;
+  fi = 0;
+  w  = size[0];
   for (i = 0; i < it; i++)
-    { const off_t b = (off_t) (((int64_t) i*work)/it);
-      off_t at;
-      if (f->nstarts > 0 && b <= f->starts[f->nstarts-1])
+    { const int64_t target = ((int64_t) i*work)/it;
+      int64_t b;
+      off_t   at;
+      while ((double) w < (double) target - .01*10000000ll && fi+1 < nfiles)
+        { fi += 1;
+          w  += size[fi];
+        }
+      b = target - (w-size[fi]);
+      if (b < 0) b = 0;
+      if (f->nstarts > 0 && (fi < f->st_file[f->nstarts-1] || (fi == f->st_file[f->nstarts-1] && b <= f->starts[f->nstarts-1])))
         continue;
-      at = (b == 0) ? 0 : io_nearest(fd,b,st.st_size,fastq);
-      if (at < 0)                          /* no record behind b: the threads end here */
-        break;
-      f->starts[f->nstarts++] = at;
+      if (b == 0)
+        { f->st_file[f->nstarts] = fi; f->starts[f->nstarts++] = 0; }
+      else
+        { int fd = open(paths[fi],O_RDONLY);
+          at = (fd >= 0) ? io_nearest(fd,(off_t) b,(off_t) size[fi],fastq) : -1;
+          if (fd >= 0) close(fd);
+          if (at < 0)                      /* no record behind b in this file: the next file's first, if there is one */
+            { if (fi+1 >= nfiles)
+                break;
+              f->st_file[f->nstarts] = fi+1; f->starts[f->nstarts++] = 0;
+            }
+          else
+            { f->st_file[f->nstarts] = fi; f->starts[f->nstarts++] = at; }
+        }
     }
-  close(fd);
-  if (f->nstarts > 0) f->starts[0] = 0;
+  if (f->nstarts > 0)
+    { f->st_file[0] = 0; f->starts[0] = 0; }
 }
 
 static void scan_file(Feeder *f, const char *path, int fastq)
@@ -1008,7 +1047,8 @@ static void scan_file(Feeder *f, const char *path, int fastq)
   int     state = 0;    /* 0 record start, 1 header, 2 fastq seq, 3 '+' line, 4 quality, 5 fasta seq, 6 fasta eol */
   int     n, i;
   off_t   base = 0;     /* bytes of the file in front of buf */
-#define RECORD_AT(off) do { while (f->tid+1 < f->nstarts && (off) >= f->starts[f->tid+1])   \
+#define RECORD_AT(off) do { while (f->tid+1 < f->nstarts && (f->cur_file > f->st_file[f->tid+1]                          \
+                                                          || (f->cur_file == f->st_file[f->tid+1] && (off) >= f->starts[f->tid+1])))   \
                               { flush_block(f,0); f->tid += 1; } } while (0)
 
   if (in == NULL)
@@ -1407,8 +1447,9 @@ int main(int argc, char *argv[])
                && !(NGPUS > 1 && strlen(argv[i]) > 3 && strcmp(argv[i]+strlen(argv[i])-3,".gz") == 0))
         scan_text_on_device(&feed,argv[i],q);
       else
-        { if (EXACT && PROFILE && nfiles == 1 && q <= 1 && !(strlen(argv[i]) > 3 && strcmp(argv[i]+strlen(argv[i])-3,".gz") == 0))
-            input_threads(&feed,argv[i],q);
+        { if (EXACT && PROFILE && q <= 1 && i == 1)
+            input_threads(&feed,argv+1,nfiles,q);
+          feed.cur_file = i-1;
           scan_file(&feed,argv[i],q);
         }
     }
@@ -1568,7 +1609,7 @@ int main(int argc, char *argv[])
         }
       else if (fk_make_profiles(ctx,NULL,0,&pr) != FK_OK)
         die(ctx,"fk_make_profiles");
-      /* -x -p on one plain file: one part per input thread of the reference (input_threads), else one per -T thread */
+      /* -x -p on FASTA / FASTQ files: one part per input thread of the reference (input_threads), else one per -T thread */
       if (fk_write_prof(&pr,KMER,(feed.nstarts > 0 && pr.nsplit == feed.nstarts) ? pr.nsplit : NTHREADS,dir,root) != FK_OK)
         die(ctx,"writing .prof");
       if (VERBOSE)
