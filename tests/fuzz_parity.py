@@ -328,6 +328,37 @@ def run(iters, seed, only=None, first=None, guard=True, quiet=False, max_bytes=N
                     assert len(offs) == len(want) + 1, "exchanged profile count"
                     for i, x in enumerate(want):
                         assert raw[offs[i]:offs[i + 1]] == orc.profile_encode(x), "exchanged profile of read %d" % i
+            if it % 4 == 1 and exp.ntable > 0:
+                # exact_parts (no random draw: the sequence of the other legs stays what it was): the reference's own
+                # super-mer rule, files against the oracle's writers -- hidden .ktab parts included
+                import shutil
+                import tempfile
+                T = 1 + it % 5
+                ex = orc.fastk(k, bases, boff, cutoff=cutoff, nthreads=T)
+                d = tempfile.mkdtemp(prefix="fkfz")
+                try:
+                    os.mkdir(os.path.join(d, "o"))
+                    os.mkdir(os.path.join(d, "g"))
+                    orc.write_outputs(ex, cutoff, T, os.path.join(d, "o"), "x")
+                    with fastk_amd.Context(kmer=k, table_cutoff=cutoff, nthreads=T, exact_parts=True) as ctx:
+                        if it % 8 == 1:
+                            ctx.debug_set("exact_chain", 1)
+                        nreads = len(boff) - 1
+                        step = max(1, nreads // 3)
+                        for lo in range(0, nreads, step):
+                            hi = min(nreads, lo + step)
+                            ctx.push_block(bases[boff[lo]:boff[hi]], (boff[lo:hi + 1] - boff[lo]).astype(np.int32))
+                        res = ctx.finish()
+                        assert np.array_equal(res.hist, ex.hist) and np.array_equal(res.table, ex.table), "exact_parts: counts"
+                        ctx.write_hist(res, os.path.join(d, "g", "x.hist"))
+                        ctx.write_ktab(res, os.path.join(d, "g"), "x")
+                    names = sorted(os.listdir(os.path.join(d, "o")))
+                    assert names == sorted(os.listdir(os.path.join(d, "g"))), "exact_parts: file names"
+                    for f in names:
+                        assert open(os.path.join(d, "o", f), "rb").read() == open(os.path.join(d, "g", f), "rb").read(), \
+                            "exact_parts: " + f
+                finally:
+                    shutil.rmtree(d, ignore_errors=True)
             if it % 3 == 0 and all(len(r) > 0 for r in reads):
                 # the device text parsers: the same reads as FASTQ / FASTA text, cut at random bytes
                 fastq = bool(rng.random() < 0.5)
