@@ -136,6 +136,13 @@ static void emit_supermer(Emitter *E, const char *s, int n, int flip)
   E->kmers += n;
 }
 
+static int Dist_Profile = 0;            /* a run with -p: the super-mers keep the read's strand (split.c:1245: under
+                                           DO_PROFILE Stuff_Seq is called with flip 0), so a super-mer and its reverse
+                                           complement are two records and the weighted k-mer list -- whose first-byte
+                                           census cuts the .ktab parts, count.c:1560-1565 -- is another one */
+void orc_set_profile_mode(int on)
+{ Dist_Profile = (on != 0); }
+
 static const orc_scheme *Dist_Scheme;   /* set by orc_fastk_parts around its distribute call */
 static uint8_t **Dist_Bucket;           /* bucket of every record emitted (parallel to *out), realloc'd */
 static int64_t  *Dist_Bcap;
@@ -266,7 +273,7 @@ int64_t orc_distribute_block(const orc_params *P, const char *bases, const int64
                         }
                       (*Dist_Bucket)[*nout] = (uint8_t) b;
                     }
-                  emit_supermer(&E,s+(last-(K-1)),n,rflp[m&rmsk]);
+                  emit_supermer(&E,s+(last-(K-1)),n,Dist_Profile ? 0 : rflp[m&rmsk]);
                 }
 
               if (done)

@@ -56,6 +56,10 @@ typedef struct
 /* widths for k with PAD extra minimizer bases (FastK.c:417,446-468; split.c:617-628) */
 void orc_params_init(orc_params *P, int kmer, int pad);
 
+/* 1: the following orc_distribute_block / orc_fastk / orc_fastk_parts calls restate a run with -p (split.c:1245: the
+   super-mers are not turned to their minimizer's strand); counts are the same, the hidden .ktab part boundaries are not */
+void orc_set_profile_mode(int on);
+
 /* base-frequency ranking -> tran[] (split.c:95-112,529-575) over the training block; depends on
    the thread count because the reference counts thread 0's read stripe twice (split.c:536-539) */
 void orc_train_tran(orc_params *P, const char *bases, const int64_t *boff, int64_t nreads,

@@ -51,6 +51,8 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.orc_params_init.argtypes = [C.POINTER(OrcParams), C.c_int, C.c_int]
         L.orc_train_tran.argtypes = [C.POINTER(OrcParams), C.c_void_p, C.c_void_p, C.c_int64, C.c_int]
+        L.orc_set_profile_mode.argtypes = [C.c_int]
+        L.orc_set_profile_mode.restype = None
         L.orc_distribute_block.restype = C.c_int64
         L.orc_distribute_block.argtypes = [C.POINTER(OrcParams), C.c_void_p, C.c_void_p, C.c_int64,
                                            C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
@@ -247,7 +249,9 @@ def fastk_parts(kmer, bases, boff, sort_memory, cutoff=1, bc_prefix=0, nthreads=
     return out
 
 
-def fastk(kmer, bases, boff, cutoff=1, bc_prefix=0, train=True, pad=0, nthreads=4):
+def fastk(kmer, bases, boff, cutoff=1, bc_prefix=0, train=True, pad=0, nthreads=4, profile=False):
+    """profile: restate a run with -p -- the super-mers keep the read's strand (split.c:1245), which changes wfirst (the
+    census that cuts the hidden .ktab parts) and nothing else of the result."""
     L = lib()
     P = params(kmer, pad)
     bases = np.ascontiguousarray(bases, dtype=np.uint8)
@@ -255,8 +259,12 @@ def fastk(kmer, bases, boff, cutoff=1, bc_prefix=0, train=True, pad=0, nthreads=
     if train:
         L.orc_train_tran(C.byref(P), bases.ctypes.data, boff.ctypes.data, len(boff) - 1, nthreads)
     R = OrcResult()
-    L.orc_fastk(C.byref(P), bases.ctypes.data, boff.ctypes.data, len(boff) - 1, bc_prefix, cutoff,
-                C.byref(R))
+    L.orc_set_profile_mode(1 if profile else 0)
+    try:
+        L.orc_fastk(C.byref(P), bases.ctypes.data, boff.ctypes.data, len(boff) - 1, bc_prefix, cutoff,
+                    C.byref(R))
+    finally:
+        L.orc_set_profile_mode(0)
     out = Result(kmer, R, P.kmer_word)
     out.params = P
     L.orc_result_free(C.byref(R))

@@ -334,13 +334,14 @@ def run(iters, seed, only=None, first=None, guard=True, quiet=False, max_bytes=N
                 import shutil
                 import tempfile
                 T = 1 + it % 5
-                ex = orc.fastk(k, bases, boff, cutoff=cutoff, nthreads=T)
+                prof = (it % 8 == 5)            # as in a run with -p: the super-mers keep the read's strand (exact_parts = 2)
+                ex = orc.fastk(k, bases, boff, cutoff=cutoff, nthreads=T, profile=prof)
                 d = tempfile.mkdtemp(prefix="fkfz")
                 try:
                     os.mkdir(os.path.join(d, "o"))
                     os.mkdir(os.path.join(d, "g"))
                     orc.write_outputs(ex, cutoff, T, os.path.join(d, "o"), "x")
-                    with fastk_amd.Context(kmer=k, table_cutoff=cutoff, nthreads=T, exact_parts=True) as ctx:
+                    with fastk_amd.Context(kmer=k, table_cutoff=cutoff, nthreads=T, exact_parts=2 if prof else 1) as ctx:
                         if it % 8 == 1:
                             ctx.debug_set("exact_chain", 1)
                         nreads = len(boff) - 1

@@ -69,6 +69,59 @@ def test_files_byte_identical_to_reference(k, T, cutoff, fmt, tmp_path):
     assert "Table is OK" in out.stdout + out.stderr
 
 
+def _tie_heavy_reads(seed, nreads, lengths):
+    """homopolymers, tandem repeats (some equal to their reverse complement), N runs, random stretches"""
+    rng = np.random.default_rng(seed)
+    units = ["A", "T", "C", "AC", "AT", "CG", "GA", "AAT", "ACG", "ACGT", "AATT", "GATC", "AACCGGTT", "ACACACGT"]
+    reads = []
+    for _ in range(nreads):
+        want = int(rng.choice(lengths))
+        parts, n = [], 0
+        while n < want:
+            kind = rng.integers(0, 10)
+            ln = int(rng.integers(5, 300))
+            if kind < 6:
+                u = units[int(rng.integers(0, len(units)))]
+                piece = np.frombuffer((u * (ln // len(u) + 1))[:ln].encode(), dtype=np.uint8).copy()
+                if kind >= 4 and ln > 10:
+                    for q in rng.integers(0, ln, size=max(1, ln // 40)):
+                        piece[q] = ord("ACGT"[int(rng.integers(0, 4))])
+            elif kind < 9:
+                piece = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=ln)]
+            else:
+                piece = np.full(int(rng.integers(1, 60)), ord("N"), dtype=np.uint8)
+            parts.append(piece)
+            n += len(piece)
+        reads.append(np.concatenate(parts)[:want].tobytes())
+    return orc.block_from_reads(reads)
+
+
+@pytest.mark.parametrize("profile", [False, True], ids=["plain", "with -p"])
+@pytest.mark.parametrize("k,T,seed,shape", [(40, 4, 31, (260, (40, 60, 150, 400, 1500, 6000))), (21, 2, 32, (260, (40, 60, 150, 400, 1500))),
+                                            (51, 3, 33, (40, (39, 5000, 30000))), (12, 1, 34, (200, (5, 12, 13, 100, 900))),
+                                            (8, 2, 35, (200, (8, 9, 40, 300)))])
+def test_oracle_on_reads_full_of_ties_and_in_profile_mode(k, T, seed, shape, profile, tmp_path):
+    """Pins two things the random reads above do not reach.  Ties: equal minimizer values inside one window (`<` on
+    arrival, `<=` on the forced rescan, split.c:1149,1306-1315) decide the super-mer cuts, hence the distinct super-mers,
+    hence the first-byte census that places the hidden .ktab part boundaries.  And -p: the reference then keeps its
+    super-mers on the read's strand (split.c:1245: Stuff_Seq(..., 0, ...) under DO_PROFILE) -- a super-mer and its reverse
+    complement are two records and the boundaries move (orc.fastk(profile=True)).  Every .hist / .ktab file of the
+    reference run live with and without -p."""
+    import subprocess
+    bases, boff = _tie_heavy_reads(20260000 + seed, *shape)
+    d = str(tmp_path)
+    path = os.path.join(d, "x.fasta")
+    orc.write_fasta(path, bases, boff)
+    subprocess.run([os.path.join(orc.REF_DIR, "FastK"), "-k%d" % k, "-t1", "-T%d" % T, "-P" + d] + (["-p"] if profile else []) + [path],
+                   check=True, cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    res = orc.fastk(k, bases, boff, cutoff=1, nthreads=T, profile=profile)
+    od = os.path.join(d, "o")
+    os.mkdir(od)
+    orc.write_outputs(res, 1, T, od, "x")
+    for f in ["x.hist", "x.ktab"] + [".x.ktab.%d" % (t + 1) for t in range(T)]:
+        assert open(os.path.join(d, f), "rb").read() == open(os.path.join(od, f), "rb").read(), f
+
+
 @pytest.mark.parametrize("rsize,n,nbytes,T", [(12, 50000, 10, 4), (20, 30011, 19, 3), (16, 1000, 5, 1), (12, 7, 10, 4)])
 def test_oracle_lsd_engine_equals_reference_lsd_sort(rsize, n, nbytes, T):
     """Sort-engine unit parity against the reference's own LSD_Sort (libfkref.so = LSDsort.c compiled
