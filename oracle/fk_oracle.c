@@ -2,7 +2,8 @@
  *
  * TEST INFRASTRUCTURE ONLY (see fk_oracle.h).  Written from SURVEY.md section 3/8 and from
  * reading the reference; every function cites the reference lines whose behaviour it restates.
- * Parity: PINNED against the reference build in oracle/_ref and tests/golden fixtures.
+ * Parity: PINNED against the reference build in oracle/_ref and tests/golden fixtures (also on reads full of minimizer
+ * ties and, orc_set_profile_mode, against runs of the reference with -p: tests/test_oracle_vs_reference.py).
  *
  * Deliberate simplifications (none changes any output byte):
  *   - the bit-stuffed ".T" spill encoding (split.c:828-989, count.c:80-149) is skipped: the
