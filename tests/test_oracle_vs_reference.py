@@ -120,6 +120,12 @@ def test_oracle_on_reads_full_of_ties_and_in_profile_mode(k, T, seed, shape, pro
     orc.write_outputs(res, 1, T, od, "x")
     for f in ["x.hist", "x.ktab"] + [".x.ktab.%d" % (t + 1) for t in range(T)]:
         assert open(os.path.join(d, f), "rb").read() == open(os.path.join(od, f), "rb").read(), f
+    if profile:                                # ... and what a profile IS (orc.profile_counts) against the reference's files
+        kk, enc = orc.read_profiles(d, "x")
+        want = orc.profile_counts(k, bases, boff, res.table)
+        assert kk == k and len(enc) == len(want)
+        for i, e in enumerate(enc):
+            assert list(orc.profile_decode(e)) == list(want[i]), i
 
 
 @pytest.mark.parametrize("rsize,n,nbytes,T", [(12, 50000, 10, 4), (20, 30011, 19, 3), (16, 1000, 5, 1), (12, 7, 10, 4)])
