@@ -128,6 +128,28 @@ def test_oracle_on_reads_full_of_ties_and_in_profile_mode(k, T, seed, shape, pro
             assert list(orc.profile_decode(e)) == list(want[i]), i
 
 
+def test_oracle_scheme_on_long_reads_full_of_ties(tmp_path):
+    """100 M bases of long tie-heavy reads with -M1: the reference deals the minimizers to two buckets (padded-minimizer
+    trie, assign_pieces) and cuts the hidden parts by bucket 0's census; orc.fastk_parts follows -- all six files.  (~40 s:
+    the one slow test of the CPU suite; it is what test_exact_parts_long_reads_in_several_buckets' oracle-free check and
+    the fuzz harness's exact leg lean on for inputs beyond the fixtures.)"""
+    import subprocess
+    bases, boff = _tie_heavy_reads(20260099, 6000, (5000, 15000, 30000))
+    k, T = 40, 4
+    d = str(tmp_path)
+    path = os.path.join(d, "x.fasta")
+    orc.write_fasta(path, bases, boff)
+    p = subprocess.run([os.path.join(orc.REF_DIR, "FastK"), "-k%d" % k, "-t1", "-T%d" % T, "-M1", "-v", "-P" + d, path],
+                       cwd=d, capture_output=True, text=True)
+    assert p.returncode == 0 and "Dividing data into 2 blocks" in p.stderr
+    res = orc.fastk_parts(k, bases, boff, 1000000000, cutoff=1, nthreads=T)
+    od = os.path.join(d, "o")
+    os.mkdir(od)
+    orc.write_outputs(res, 1, T, od, "x")
+    for f in ["x.hist", "x.ktab"] + [".x.ktab.%d" % (t + 1) for t in range(T)]:
+        assert util.sha_file(os.path.join(d, f)) == util.sha_file(os.path.join(od, f)), f
+
+
 @pytest.mark.parametrize("rsize,n,nbytes,T", [(12, 50000, 10, 4), (20, 30011, 19, 3), (16, 1000, 5, 1), (12, 7, 10, 4)])
 def test_oracle_lsd_engine_equals_reference_lsd_sort(rsize, n, nbytes, T):
     """Sort-engine unit parity against the reference's own LSD_Sort (libfkref.so = LSDsort.c compiled
