@@ -944,25 +944,31 @@ static off_t io_nearest(int fd, off_t from, off_t size, int fastq)
 { enum { WIN = 1 << 16 };
   static char win[WIN];
   off_t pos = from;
-  int   nl_1 = 1, nl_2 = 1, pl_1 = 1, alive = 0, fk1 = 0;
+  /* FASTQ: the two characters in front of the one looked at, as "newline?" and "plus?" -- both start as if a separator
+     line had just been read, so that nothing is accepted before a whole line has gone by.  FASTA: has a newline been
+     seen, and is this the character right behind one? */
+  int   before_is_nl = 1, before2_is_nl = 1, before_is_plus = 1;
+  int   at_may_start = 0, behind_nl = 0;
   while (pos < size)
     { ssize_t n = pread(fd,win,WIN,pos), i;
       if (n <= 0) break;
       for (i = 0; i < n; i++)
         { const char c = win[i];
           if (fastq)
-            { if (c == '@' && alive) return (pos+i);
-              alive = (c == '\n' && !(nl_2 || pl_1));
-              nl_2 = nl_1;
-              nl_1 = (c == '\n');
-              pl_1 = (c == '+');
+            { if (at_may_start && c == '@')
+                return (pos+i);
+              /* the next character begins a line that may be a header iff this one is a newline and the line it ends
+                 has at least two characters and does not end in '+' */
+              at_may_start   = (c == '\n') && !before2_is_nl && !before_is_plus;
+              before2_is_nl  = before_is_nl;
+              before_is_nl   = (c == '\n');
+              before_is_plus = (c == '+');
             }
-          else if (fk1)
-            { if (c == '>') return (pos+i);
-              if (c != '\n') fk1 = 0;
+          else
+            { if (behind_nl && c == '>')
+                return (pos+i);
+              behind_nl = (c == '\n');
             }
-          else if (c == '\n')
-            fk1 = 1;
         }
       pos += n;
     }
