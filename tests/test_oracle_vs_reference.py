@@ -128,6 +128,25 @@ def test_oracle_on_reads_full_of_ties_and_in_profile_mode(k, T, seed, shape, pro
             assert list(orc.profile_decode(e)) == list(want[i]), i
 
 
+@pytest.mark.parametrize("k,T,bc,profile,seed", [(40, 4, 8, False, 71), (40, 3, 5, True, 72), (21, 2, 20, False, 73),
+                                                 (51, 5, 1, True, 74), (33, 4, 40, False, 75)])
+def test_oracle_with_a_barcode_prefix_on_reads_full_of_ties(k, T, bc, profile, seed, tmp_path):
+    """-bc<n> (the first n bases of every read do not count, io.c / split.c:1077-1079) beside the ties and -p."""
+    import subprocess
+    bases, boff = _tie_heavy_reads(20260000 + seed, 300, (40, 60, 150, 400, 1500, 6000))
+    d = str(tmp_path)
+    path = os.path.join(d, "x.fasta")
+    orc.write_fasta(path, bases, boff)
+    subprocess.run([os.path.join(orc.REF_DIR, "FastK"), "-k%d" % k, "-t1", "-T%d" % T, "-bc%d" % bc, "-P" + d]
+                   + (["-p"] if profile else []) + [path], check=True, cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    res = orc.fastk(k, bases, boff, cutoff=1, nthreads=T, bc_prefix=bc, profile=profile)
+    od = os.path.join(d, "o")
+    os.mkdir(od)
+    orc.write_outputs(res, 1, T, od, "x")
+    for f in ["x.hist", "x.ktab"] + [".x.ktab.%d" % (t + 1) for t in range(T)]:
+        assert open(os.path.join(d, f), "rb").read() == open(os.path.join(od, f), "rb").read(), f
+
+
 def test_oracle_scheme_on_long_reads_full_of_ties(tmp_path):
     """100 M bases of long tie-heavy reads with -M1: the reference deals the minimizers to two buckets (padded-minimizer
     trie, assign_pieces) and cuts the hidden parts by bucket 0's census; orc.fastk_parts follows -- all six files.  (~40 s:
