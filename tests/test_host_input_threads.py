@@ -19,6 +19,12 @@ from tests import util
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+@pytest.fixture(scope="module", autouse=True)
+def _ref():
+    if not orc.have_ref() and os.path.isdir(orc.REFERENCE_SRC):
+        orc.build(ref=True)
+
+
 @pytest.fixture(scope="module")
 def printer(tmp_path_factory):
     lib = os.path.join(ROOT, "fastk_amd", "lib")
