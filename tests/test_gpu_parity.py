@@ -1768,6 +1768,7 @@ def test_exact_parts_long_reads_in_several_buckets():
     probe = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(probe)
     assert probe.run(200.0, 15000) == 0
+    assert probe.run(200.0, 15000, ("-p",)) == 0         # ... and with profiles: the .prof / .pidx parts of four input threads too
 
 
 def test_exact_parts_with_profiles_every_file_of_the_reference():

@@ -13,7 +13,8 @@ from oracle import orc  # noqa: E402
 from tests import util  # noqa: E402
 
 
-def run(mb=200.0, L=15000):
+def run(mb=200.0, L=15000, extra=()):
+    """extra: further options for both programs (("-p",): profiles too -- the .prof / .pidx parts are compared as well)"""
     nreads = int(mb * 1e6 / L)
     bases, boff = orc.synth_block(20250905, int(mb * 1e6 / 50), L, 2000, 0, nreads)
     d = tempfile.mkdtemp(prefix="fkxl", dir="/dev/shm")
@@ -29,10 +30,10 @@ def run(mb=200.0, L=15000):
                 for f in os.listdir(os.path.join(d, sub)):
                     if f != "x.fasta":
                         os.remove(os.path.join(d, sub, f))
-            p = subprocess.run([os.path.join(orc.REF_DIR, "FastK"), "-k40", "-t1", "-T%d" % T, "-M%d" % mem, "-v", "-P" + os.path.join(d, "ref"),
+            p = subprocess.run([os.path.join(orc.REF_DIR, "FastK"), "-k40", "-t1", "-T%d" % T, "-M%d" % mem, "-v", "-P" + os.path.join(d, "ref")] + list(extra) + [
                                 os.path.join(d, "ref", "x.fasta")], cwd=os.path.join(d, "ref"), capture_output=True, text=True)
             parts = [l for l in (p.stdout + p.stderr).split("\n") if "part" in l.lower() or "bucket" in l.lower()]
-            q = subprocess.run([os.path.join(ROOT, "fastk_amd", "bin", "FastK_amd"), "-k40", "-t1", "-T%d" % T, "-M%d" % mem, "-x", "-v",
+            q = subprocess.run([os.path.join(ROOT, "fastk_amd", "bin", "FastK_amd"), "-k40", "-t1", "-T%d" % T, "-M%d" % mem, "-x", "-v"] + list(extra) + [
                                 os.path.join(d, "ours", "x.fasta")], cwd=os.path.join(d, "ours"), capture_output=True, text=True)
             if p.returncode != 0 or q.returncode != 0:
                 print("-T%d -M%d: reference rc %d, ours rc %d: %s" % (T, mem, p.returncode, q.returncode, (q.stdout + q.stderr)[-400:]))
@@ -53,7 +54,8 @@ def run(mb=200.0, L=15000):
 
 
 def main():
-    bad = run(float(sys.argv[1]) if len(sys.argv) > 1 else 200.0, int(sys.argv[2]) if len(sys.argv) > 2 else 15000)
+    bad = run(float(sys.argv[1]) if len(sys.argv) > 1 else 200.0, int(sys.argv[2]) if len(sys.argv) > 2 else 15000,
+              tuple(sys.argv[3:]))
     print("differences:", bad)
     sys.exit(1 if bad else 0)
 
