@@ -1,6 +1,7 @@
 """FastK_amd -x -p deals the reads of FASTA / FASTQ input to the input threads the reference would use (input_threads,
 io_nearest in fastk_amd/csrc/host/FastK_amd.c; io.c:409-490, 2340-2521), because the reference's .prof parts are those
-threads' read ranges.  Here the function alone -- tests/csrc/input_threads_print.c includes the driver's source -- against
+threads' read ranges.  Here the host side alone -- tests/csrc/input_threads_print.c includes the driver's source, calls
+input_threads and runs the host scanner with fk_push_block replaced by a counter -- against
 the reference run on the same files: the (first read, reads) of every .pidx part it writes.  Random files with what
 misleads a search for record starts: wrapped sequence lines, '>' and '@' inside headers, FASTQ quality lines that begin
 with '@' or '+', several files of different sizes, compressed files, more and fewer threads than the data carries.
@@ -101,7 +102,7 @@ def test_input_threads_are_the_references(case, printer, tmp_path):
         b, n = struct.unpack("<qq", open(os.path.join(d, ".x.pidx.%d" % t), "rb").read(20)[4:])
         ref.append((b, n))
     # ours: where every thread begins -> the index of the read that begins there
-    out = subprocess.run([printer, str(T), "1" if fastq else "0"] + paths, check=True, capture_output=True, text=True).stdout.split()
+    out = subprocess.run([printer, "starts", str(T), "1" if fastq else "0"] + paths, check=True, capture_output=True, text=True).stdout.split()
     begins = []
     for fi, off in zip(out[0::2], out[1::2]):
         fi, off = int(fi), int(off)
@@ -110,3 +111,6 @@ def test_input_threads_are_the_references(case, printer, tmp_path):
     begins.append(first[-1])
     ours = [(begins[t], begins[t + 1] - begins[t]) for t in range(len(begins) - 1)]
     assert ours == ref
+    # ... and the host scanner dealing the reads: the blocks it would push, counted by the thread they are pushed for
+    dealt = subprocess.run([printer, "deal", str(T), "1" if fastq else "0"] + paths, check=True, capture_output=True, text=True).stdout.split()
+    assert [int(x) for x in dealt] == [n for b, n in ref]
