@@ -117,7 +117,8 @@ def make_reads(rng, k):
     glen = int(rng.integers(500, 40000))
     genome = rng.integers(0, 4, size=glen)
     if rng.random() < 0.3:                                           # a repeat-rich genome
-        unit = genome[:int(rng.integers(20, 300))]
+        unit = genome[:int(rng.integers(1, 300))]                   # (from a homopolymer and di- / tri-nucleotide repeats up: ties
+                                                                     # between the minimizers of one window)
         genome = np.concatenate([unit] * (glen // len(unit) + 1))[:glen]
     reads = []
     n = int(rng.integers(1, 1500))
