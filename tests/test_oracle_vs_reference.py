@@ -257,3 +257,23 @@ def test_scheme_equals_the_reference_trainer(tmp_path):
     ref = out.stdout[out.stdout.index("Padded Assignments"):].split("\n", 1)[1]
     assert S.nparts == 2 and S.pad == 0
     assert ref.strip() == mine.strip()
+
+
+def test_reference_build_links_the_real_htslib():
+    """oracle/_ref is the reference with NOTHING resolved to address 0: the seven HTSLIB functions
+    io.c calls for .cram input are defined by libhts.a, compiled from the reference's HTSLIB sources by
+    oracle/Makefile, and libfkref.so links with --no-undefined."""
+    import subprocess
+    syms = ["cram_close", "cram_get_seq", "cram_open", "hgetc2", "hread2", "hseek", "itf8_decode"]
+    ref = os.path.join(os.path.dirname(os.path.abspath(orc.__file__)), "_ref")
+    assert os.path.exists(os.path.join(ref, "libhts.a")), "oracle/_ref/libhts.a missing"
+    for binary in ("FastK", "libfkref.so"):
+        out = subprocess.run(["nm", "--defined-only", os.path.join(ref, binary)], capture_output=True, text=True,
+                             check=True).stdout
+        table = {l.split()[2]: (l.split()[0], l.split()[1]) for l in out.splitlines() if len(l.split()) == 3}
+        for s in syms:
+            assert s in table, (binary, s, "not defined")
+            addr, kind = table[s]
+            assert kind in "Tt" and int(addr, 16) != 0, (binary, s, addr, kind)
+    mk = open(os.path.join(os.path.dirname(ref), "Makefile")).read()
+    assert "--defsym" not in mk and "unresolved-symbols" not in mk
