@@ -195,6 +195,39 @@ void fkx_stream_put(int device, hipStream_t s)
   pthread_mutex_unlock(&g_stream_lock);
 }
 
+struct fk_pooled_event { int device; bool timing; hipEvent_t ev; };
+static std::vector<fk_pooled_event> g_event_pool;          // idle events (under g_stream_lock)
+
+int fkx_event_get(int device, bool timing, hipEvent_t *e)
+{ *e = NULL;
+  pthread_mutex_lock(&g_stream_lock);
+  for (size_t i = 0; i < g_event_pool.size(); i++)
+    if (g_event_pool[i].device == device && g_event_pool[i].timing == timing)
+      { *e = g_event_pool[i].ev;
+        g_event_pool[i] = g_event_pool.back();
+        g_event_pool.pop_back();
+        break;
+      }
+  pthread_mutex_unlock(&g_stream_lock);
+  if (*e != NULL)
+    return (FK_OK);
+  const hipError_t rc = timing ? hipEventCreate(e) : hipEventCreateWithFlags(e, hipEventDisableTiming);
+  if (rc != hipSuccess)
+    *e = NULL;
+  return (rc == hipSuccess ? FK_OK : FK_EHIP);
+}
+
+void fkx_event_put(int device, bool timing, hipEvent_t *e)
+{ if (e == NULL || *e == NULL)
+    return;
+  (void) hipEventSynchronize(*e);                    // (what goes into the pool is complete; never recorded: returns at once)
+  fk_pooled_event p; p.device = device; p.timing = timing; p.ev = *e;
+  pthread_mutex_lock(&g_stream_lock);
+  g_event_pool.push_back(p);
+  pthread_mutex_unlock(&g_stream_lock);
+  *e = NULL;
+}
+
 int fkx_d2h_pageable(fk_ctx *ctx, hipStream_t s, void *dst, const void *d_src, size_t nbytes)
 { FK_HIP(ctx, hipStreamSynchronize(s));
   if (nbytes > 0)
@@ -402,17 +435,25 @@ extern "C" int fk_create(const fk_params *p, fk_ctx **out)
   }
 #define CK(call) do { if ((call) != hipSuccess) { fk_set_error(NULL, "fk_create: %s failed", #call); \
                                                     fk_destroy(ctx); return (FK_EHIP); } } while (0)
-  if (fkx_stream_get(ctx->device, &ctx->stream) != FK_OK || fkx_stream_get(ctx->device, &ctx->copy_stream) != FK_OK)
+  if (fkx_stream_get(ctx->device, &ctx->stream) != FK_OK)
     { fk_set_error(NULL, "fk_create: hipStreamCreateWithFlags failed");
       fk_destroy(ctx);
       return (FK_EHIP);
     }
-  ctx->own_stream = true;
-  CK(hipEventCreateWithFlags(&ctx->reads_ev, hipEventDisableTiming));
-  CK(hipEventCreate(&ctx->ev0));
-  CK(hipEventCreate(&ctx->ev1));
-  CK(hipEventCreate(&ctx->stage_ev[0]));
-  CK(hipEventCreate(&ctx->stage_ev[1]));
+  ctx->own_stream = true;                            // (set before anything else can fail: fk_destroy returns the stream to the pool)
+  if (fkx_stream_get(ctx->device, &ctx->copy_stream) != FK_OK)
+    { fk_set_error(NULL, "fk_create: hipStreamCreateWithFlags failed");
+      fk_destroy(ctx);
+      return (FK_EHIP);
+    }
+#define CKE(call) do { if ((call) != FK_OK) { fk_set_error(NULL, "fk_create: %s failed", #call); \
+                                               fk_destroy(ctx); return (FK_EHIP); } } while (0)
+  CKE(fkx_event_get(ctx->device, false, &ctx->reads_ev));
+  CKE(fkx_event_get(ctx->device, true, &ctx->ev0));
+  CKE(fkx_event_get(ctx->device, true, &ctx->ev1));
+  CKE(fkx_event_get(ctx->device, true, &ctx->stage_ev[0]));
+  CKE(fkx_event_get(ctx->device, true, &ctx->stage_ev[1]));
+#undef CKE
   CK(hipMalloc((void **) &ctx->d_mbucket, FK_NRANKS));
   CK(hipMalloc((void **) &ctx->d_mbucket_pass, FK_NRANKS));
   CK(hipHostMalloc((void **) &ctx->h_mbucket_pass, FK_NRANKS, hipHostMallocDefault));
@@ -455,7 +496,9 @@ extern "C" void fk_destroy(fk_ctx *ctx)
   for (int i = 0; i < 4; i++)
     if (ctx->wstream[i] != NULL)
       hipStreamSynchronize(ctx->wstream[i]);
-  (void) hipDeviceSynchronize();
+  // (no hipDeviceSynchronize: these are all the streams a context queues work on -- the pushes use copy_stream or
+  // stream, the flush helper was joined above -- and a host with other contexts or work of its own on the device
+  // must not stall on them; ADVICE r5.  The stream / event pools assume that the host never calls hipDeviceReset.)
   (void) hipGetLastError();
   hipFree(ctx->d_mbucket); hipFree(ctx->d_mbucket_pass); hipFree(ctx->d_scratch); hipFree(ctx->d_cursors); hipFree(ctx->d_plan);
   if (ctx->h_mbucket_pass) hipHostFree(ctx->h_mbucket_pass);
@@ -469,7 +512,7 @@ extern "C" void fk_destroy(fk_ctx *ctx)
   hipFree(ctx->d_min_part);
   free(ctx->min_part);
   fkx_stream_put(ctx->device, ctx->copy_stream);      // (streams go back to the pool, never to hipStreamDestroy: fk_common.h)
-  if (ctx->reads_ev) hipEventDestroy(ctx->reads_ev);
+  fkx_event_put(ctx->device, false, &ctx->reads_ev);   // (events too: fk_common.h)
   free(ctx->h_prof);
   free(ctx->h_prof_off);
   free(ctx->h_prof_split);
@@ -479,12 +522,12 @@ extern "C" void fk_destroy(fk_ctx *ctx)
       hipFree(ctx->slot_ptr[i]);
   for (int i = 0; i < 2; i++)
     { if (ctx->h_stage[i]) fkx_pinned_free(ctx->h_stage[i]);
-      if (ctx->stage_ev[i]) hipEventDestroy(ctx->stage_ev[i]);
+      fkx_event_put(ctx->device, true, &ctx->stage_ev[i]);
     }
-  if (ctx->ev0) hipEventDestroy(ctx->ev0);
-  if (ctx->ev1) hipEventDestroy(ctx->ev1);
+  fkx_event_put(ctx->device, true, &ctx->ev0);
+  fkx_event_put(ctx->device, true, &ctx->ev1);
   for (int i = 0; i < 128; i++)
-    if (ctx->pass_ev[i]) hipEventDestroy(ctx->pass_ev[i]);
+    fkx_event_put(ctx->device, true, &ctx->pass_ev[i]);
   if (ctx->own_stream && ctx->stream != NULL)
     fkx_stream_put(ctx->device, ctx->stream);
   for (int i = 0; i < ctx->nchunks; i++)
@@ -750,6 +793,12 @@ extern "C" int fk_debug_get(fk_ctx *ctx, const char *key, int64_t *value)
     }
   // where the pushed reads of a resident run lie in HBM and how many bytes they take: for harnesses that compare the
   // device copy with what they pushed (tests/fuzz_parity.py)
+  if (strcmp(key, "event_pool") == 0)       // idle events in the process-wide pool (fkx_event_get / _put)
+    { pthread_mutex_lock(&g_stream_lock);
+      *value = (int64_t) g_event_pool.size();
+      pthread_mutex_unlock(&g_stream_lock);
+      return (FK_OK);
+    }
   if (strcmp(key, "stream_pool") == 0)      // idle streams in the process-wide pool (fkx_stream_get / _put)
     { pthread_mutex_lock(&g_stream_lock);
       *value = (int64_t) g_stream_pool.size();

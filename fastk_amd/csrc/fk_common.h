@@ -324,10 +324,10 @@ int fkx_collapse(fk_ctx *ctx, const void *d_kmers, int64_t n, void *d_out, int64
                  int64_t *nout, int64_t *overflow);
 // Copies between device memory and PAGEABLE host memory (a caller's buffer, malloc'ed results, a std::vector, a stack
 // variable).  Never hipMemcpyAsync: the stream is waited for, then a blocking hipMemcpy moves the bytes -- complete in
-// both memories when the call returns.  (Round 5: with dozens of processes on one GPU, data that hipMemcpyAsync(DeviceTo
-// Host) had brought into malloc'ed memory was at times not all there when hipStreamSynchronize returned: histograms and
-// downloads came back with stale stretches.  Pinned buffers -- h_scratch, the result table, the staging -- take
-// asynchronous copies as before.)
+// both memories when the call returns.  A conservative rule kept from round 5's investigation of corrupted host data:
+// the asynchronous copies were suspected first and probed (138,624 of them, none wrong); the confirmed cause was the
+// runtime's write into a stream object it had freed (next comment), hence the stream pool.  Pinned buffers -- h_scratch,
+// the result table, the staging -- take asynchronous copies as before.
 int fkx_d2h_pageable(fk_ctx *ctx, hipStream_t s, void *dst, const void *d_src, size_t nbytes);
 int fkx_h2d_pageable(fk_ctx *ctx, hipStream_t s, void *d_dst, const void *src, size_t nbytes);
 // Streams are never destroyed: a context (or shard) takes its non-blocking streams from a process-wide pool and gives
@@ -338,6 +338,11 @@ int fkx_h2d_pageable(fk_ctx *ctx, hipStream_t s, void *d_dst, const void *src, s
 // (tests/csrc/freeguard.c names the block and the hipStreamDestroy of fk_destroy that freed it).
 int  fkx_stream_get(int device, hipStream_t *s);
 void fkx_stream_put(int device, hipStream_t s);
+// Events likewise (round 6): the same runtime, the same class of object -- no hipEventDestroy anywhere in the library.
+// An event comes from a process-wide pool (one list per device and kind: with timing / hipEventDisableTiming) and goes
+// back complete (fkx_event_put waits for it); a pointer that is NULL is skipped and the caller's copy is cleared.
+int  fkx_event_get(int device, bool timing, hipEvent_t *e);
+void fkx_event_put(int device, bool timing, hipEvent_t *e);
 int fkx_pinned_alloc(void **out, int64_t bytes);     // large buffers: huge pages touched in parallel + hipHostRegister
 int fkx_pinned_free(void *p);
 int fkx_reserve_host_table(fk_ctx *ctx, int64_t bytes);      // ctx->h_table: pinned host memory for the result table

@@ -248,8 +248,8 @@ extern "C" int fk_write_ktab_device(fk_ctx *ctx, const fk_result *res, int nthre
       bool ok = (write(fd, &kmer, 4) == 4 && write(fd, &cnt, 8) == 8);
       if (ok && cnt > 0)
         ok = (hipSetDevice(ctx->device) == hipSuccess
-              && hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) == hipSuccess
-              && hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) == hipSuccess);
+              && fkx_event_get(ctx->device, false, &ev[0]) == FK_OK
+              && fkx_event_get(ctx->device, false, &ev[1]) == FK_OK);
       const int ln = t % lanes;                           // (parts t, t + lanes, ... are written one after the other)
       unsigned char *pin[2] = { h_stage + pbytes * (2 * ln), h_stage + pbytes * (2 * ln + 1) };
       auto fetch = [&](int64_t x, int which) -> bool
@@ -286,7 +286,7 @@ extern "C" int fk_write_ktab_device(fk_ctx *ctx, const fk_result *res, int nthre
       if (!ok && cnt > 0)                                 // a piece may still be on its way into the staging: nobody may
         (void) hipStreamSynchronize(st);                  // reuse or free that memory before it has landed
       for (int i = 0; i < 2; i++)
-        if (ev[i]) hipEventDestroy(ev[i]);
+        fkx_event_put(ctx->device, false, &ev[i]);
       if (close(fd) != 0) ok = false;
       if (!ok) prc[t] = FK_EINVAL;
     };
@@ -330,9 +330,12 @@ extern "C" int fk_copy_rate(fk_ctx *ctx, void *d_dst, const void *d_src, int64_t
   FK_HIP(ctx, hipSetDevice(ctx->device));
   const int64_t n = nbytes / 16;
   if ((n + 1023) / 1024 > 0x7fffffffll) return (FK_EINVAL);
-  hipEvent_t e0, e1;
-  FK_HIP(ctx, hipEventCreate(&e0));
-  FK_HIP(ctx, hipEventCreate(&e1));
+  hipEvent_t e0 = NULL, e1 = NULL;
+  if (fkx_event_get(ctx->device, true, &e0) != FK_OK || fkx_event_get(ctx->device, true, &e1) != FK_OK)
+    { fkx_event_put(ctx->device, true, &e0);
+      fk_set_error(ctx, "fk_copy_rate: cannot create events");
+      return (FK_EHIP);
+    }
   float best = 0.f;
   for (int r = 0; r <= reps; r++)                         // the first run is not timed
     { hipEventRecord(e0, ctx->stream);
@@ -341,7 +344,7 @@ extern "C" int fk_copy_rate(fk_ctx *ctx, void *d_dst, const void *d_src, int64_t
       const hipError_t le = hipGetLastError();
       hipEventRecord(e1, ctx->stream);
       if (le != hipSuccess || hipEventSynchronize(e1) != hipSuccess)
-        { hipEventDestroy(e0); hipEventDestroy(e1);
+        { fkx_event_put(ctx->device, true, &e0); fkx_event_put(ctx->device, true, &e1);
           fk_set_error(ctx, "fk_copy_rate: the copy kernel failed: %s", hipGetErrorString(le));
           return (FK_EHIP);
         }
@@ -349,7 +352,9 @@ extern "C" int fk_copy_rate(fk_ctx *ctx, void *d_dst, const void *d_src, int64_t
       hipEventElapsedTime(&ms, e0, e1);
       if (r > 0 && (best == 0.f || ms < best)) best = ms;
     }
-  hipEventDestroy(e0); hipEventDestroy(e1);
+  float keep = best;
+  fkx_event_put(ctx->device, true, &e0); fkx_event_put(ctx->device, true, &e1);
+  best = keep;
   *gbps = 2.0 * (double) (n * 16) / ((double) best * 1e-3) / 1e9;
   return (FK_OK);
 }

@@ -87,14 +87,16 @@ static int count_bucket(fk_ctx *ctx, void *sm_in, int64_t ns, fk_result *res, bo
 { const fk_widths &w = ctx->wid;
   hipStream_t s = ctx->stream;
   const int cutoff = ctx->prm.table_cutoff;
-  hipEvent_t ev[4];
+  hipEvent_t ev[4] = { NULL, NULL, NULL, NULL };
   int rc = FK_OK;
 
   if (ns <= 0)
     return (FK_OK);
-  for (int i = 0; i < 4; i++)
-    if (hipEventCreate(&ev[i]) != hipSuccess)
+  for (int i = 0; i < 4; i++)                  // (pooled: no event is ever destroyed, fk_common.h)
+    if (fkx_event_get(ctx->device, true, &ev[i]) != FK_OK)
       { fk_set_error(ctx, "fk_finish: cannot create events");
+        for (int j = 0; j < i; j++)
+          fkx_event_put(ctx->device, true, &ev[j]);
         return (FK_EHIP);
       }
   do
@@ -391,7 +393,7 @@ static int count_bucket(fk_ctx *ctx, void *sm_in, int64_t ns, fk_result *res, bo
     }
   while (0);
   for (int i = 0; i < 4; i++)
-    hipEventDestroy(ev[i]);
+    fkx_event_put(ctx->device, true, &ev[i]);
   return (rc);
 }
 
@@ -411,14 +413,16 @@ static int sort_union_table(fk_ctx *ctx, int64_t ntab, fk_result *res, void **ta
   }
   int64_t census[256];
   if (tmp == NULL) return (FK_ENOMEM);
-  hipEvent_t te[2];                              // (the sort itself records ctx->ev0 / ev1)
-  if (hipEventCreate(&te[0]) != hipSuccess || hipEventCreate(&te[1]) != hipSuccess)
-    return (FK_EHIP);
+  hipEvent_t te[2] = { NULL, NULL };             // (the sort itself records ctx->ev0 / ev1)
+  if (fkx_event_get(ctx->device, true, &te[0]) != FK_OK || fkx_event_get(ctx->device, true, &te[1]) != FK_OK)
+    { fkx_event_put(ctx->device, true, &te[0]);
+      return (FK_EHIP);
+    }
   hipEventRecord(te[0], s);
   *table = ctx->slot_ptr[FK_SLOT_TABLE];
   int rc = fkx_sort_table(ctx, ntab, ctx->slot_ptr[FK_SLOT_TABLE], tmp, table, census);
   if (rc != FK_OK)
-    { hipEventDestroy(te[0]); hipEventDestroy(te[1]);
+    { fkx_event_put(ctx->device, true, &te[0]); fkx_event_put(ctx->device, true, &te[1]);
       return (rc);
     }
   res->passes_final   = ctx->sort_stats.passes;
@@ -429,7 +433,7 @@ static int sort_union_table(fk_ctx *ctx, int64_t ntab, fk_result *res, void **ta
   hipEventSynchronize(te[1]);
   tm->radix_k += ms_between(te[0], te[1]);
   res->ms_table_sort += ms_between(te[0], te[1]);
-  hipEventDestroy(te[0]); hipEventDestroy(te[1]);
+  fkx_event_put(ctx->device, true, &te[0]); fkx_event_put(ctx->device, true, &te[1]);
   return (FK_OK);
 }
 
@@ -508,13 +512,15 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
                  int64_t nreads = 0, const fk_pkview *pk = NULL)
 { const fk_widths &w = ctx->wid;
   hipStream_t s = ctx->stream;
-  hipEvent_t ev[3];
+  hipEvent_t ev[3] = { NULL, NULL, NULL };
   int rc = FK_OK;
 
   memset(res, 0, sizeof(*res));
   for (int i = 0; i < 3; i++)
-    if (hipEventCreate(&ev[i]) != hipSuccess)
+    if (fkx_event_get(ctx->device, true, &ev[i]) != FK_OK)
       { fk_set_error(ctx, "fk_finish: cannot create events");
+        for (int j = 0; j < i; j++)
+          fkx_event_put(ctx->device, true, &ev[j]);
         return (FK_EHIP);
       }
   do
@@ -742,9 +748,11 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
                   ctx->err[0] = 0;
                 }
             }
-          hipEvent_t gev[2];
-          if (hipEventCreate(&gev[0]) != hipSuccess || hipEventCreate(&gev[1]) != hipSuccess)
-            { rc = FK_EHIP; break; }
+          hipEvent_t gev[2] = { NULL, NULL };
+          if (fkx_event_get(ctx->device, true, &gev[0]) != FK_OK || fkx_event_get(ctx->device, true, &gev[1]) != FK_OK)
+            { fkx_event_put(ctx->device, true, &gev[0]);
+              rc = FK_EHIP; break;
+            }
           for (int g = 0; g < ngroups && rc == FK_OK; g++)
             { int64_t lo[257], cnt[256], nig = 0;
               double  grow = 1.0;
@@ -795,8 +803,8 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
                                     &ntab, NULL, &tm, ns_max, sm_dig != NULL ? sm_dig + lo[b] : NULL);
                 }
             }
-          hipEventDestroy(gev[0]);
-          hipEventDestroy(gev[1]);
+          fkx_event_put(ctx->device, true, &gev[0]);
+          fkx_event_put(ctx->device, true, &gev[1]);
           if (rc != FK_OK)
             break;
           res->nsuper = tot;
@@ -862,7 +870,7 @@ int fkx_pipeline(fk_ctx *ctx, const void *d_reads, int64_t nbytes, void *d_smers
     }
   while (0);
   for (int i = 0; i < 3; i++)
-    hipEventDestroy(ev[i]);
+    fkx_event_put(ctx->device, true, &ev[i]);
   if (rc == FK_EHIP && ctx->err[0] == 0)
     fk_set_error(ctx, "fk_finish: HIP failure: %s", hipGetErrorString(hipGetLastError()));
   return (rc);

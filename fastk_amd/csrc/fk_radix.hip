@@ -1205,8 +1205,11 @@ static int lsd_sort_stream_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, c
   FK_HIP(ctx, hipEventRecord(ctx->ev0, s));
   for (int i = 0; i < nrun; i++)
     if (ctx->pass_ev[2 * i] == NULL)
-      { FK_HIP(ctx, hipEventCreate(&ctx->pass_ev[2 * i]));
-        FK_HIP(ctx, hipEventCreate(&ctx->pass_ev[2 * i + 1]));
+      { if (fkx_event_get(ctx->device, true, &ctx->pass_ev[2 * i]) != FK_OK
+            || fkx_event_get(ctx->device, true, &ctx->pass_ev[2 * i + 1]) != FK_OK)
+          { fk_set_error(ctx, "sort: cannot create events");
+            return (FK_EHIP);
+          }
       }
   for (int i = 0; i < nrun; i++)
     { const int nextb = (i + 1 < nrun) ? run[i + 1] : -1;

@@ -296,8 +296,8 @@ int fkx_train_scheme(fk_ctx *ctx, const void *d_bases, const int64_t *d_roff, in
   ctx->d_min_part = NULL;
   if (hipMalloc((void **) &ctx->d_min_part, (size_t) states * 4) != hipSuccess)
     return (FK_ENOMEM);
-  FK_HIP(ctx, hipMemcpyAsync(ctx->d_min_part, ctx->min_part, (size_t) states * 4, hipMemcpyHostToDevice, s));
-  FK_HIP(ctx, hipStreamSynchronize(s));
+  if (fkx_h2d_pageable(ctx, s, ctx->d_min_part, ctx->min_part, (size_t) states * 4) != FK_OK)    // (min_part is malloc'ed)
+    return (FK_EHIP);
   ctx->scheme_pad = PAD;
   ctx->scheme_states = states;
   ctx->scheme_nparts = NPARTS;

@@ -140,7 +140,7 @@ extern "C" void fk_shard_destroy(fk_shard *sh)
   if (sh->ctx->stream) hipStreamSynchronize(sh->ctx->stream);      // (the gather's D2H into g_host runs on the context's stream)
   if (sh->comm) g_rccl.CommDestroy(sh->comm);
   for (int i = 0; i < 2; i++)
-    { if (sh->xev[i]) hipEventDestroy(sh->xev[i]);
+    { fkx_event_put(sh->ctx->device, false, &sh->xev[i]);
       if (sh->inbox[i]) hipFree(sh->inbox[i]);
     }
   fkx_stream_put(sh->ctx->device, sh->xs);
@@ -150,7 +150,7 @@ extern "C" void fk_shard_destroy(fk_shard *sh)
     if (sh->g_dev[i]) hipFree(sh->g_dev[i]);
   if (sh->g_host) fkx_pinned_free(sh->g_host);
   for (int i = 0; i < 2 * 256; i++)
-    if (sh->tev[i]) hipEventDestroy(sh->tev[i]);
+    fkx_event_put(sh->ctx->device, true, &sh->tev[i]);
   for (int i = 0; i < 4; i++)
     if (sh->pf_buf[i]) hipFree(sh->pf_buf[i]);
   free(sh);
@@ -198,8 +198,8 @@ extern "C" int fk_shard_create(fk_ctx *ctx, int rank, int world, const char *id1
   }
   sh->small_cap = (int64_t) world * ctx->prm.nbuckets + 2 * (FK_HIST_BINS + 1024);
   if (fkx_stream_get(ctx->device, &sh->xs) != FK_OK
-      || hipEventCreateWithFlags(&sh->xev[0], hipEventDisableTiming) != hipSuccess
-      || hipEventCreateWithFlags(&sh->xev[1], hipEventDisableTiming) != hipSuccess
+      || fkx_event_get(ctx->device, false, &sh->xev[0]) != FK_OK
+      || fkx_event_get(ctx->device, false, &sh->xev[1]) != FK_OK
       || hipMalloc((void **) &sh->d_small, (size_t) sh->small_cap * 8) != hipSuccess
       || hipHostMalloc((void **) &sh->h_small, (size_t) sh->small_cap * 8, hipHostMallocDefault) != hipSuccess)
     { fk_set_error(ctx, "fk_shard_create: cannot set up streams and buffers");
@@ -481,8 +481,10 @@ static int shard_count(fk_shard *sh, const void *d_reads, int64_t reads_len, fk_
           else         { sh->st.sent_bytes += sb[p]; sh->st.recv_bytes += rb[p]; }
         }
       for (int i = 0; i < 2; i++)
-        if (sh->tev[2 * r + i] == NULL)
-          FK_HIP(ctx, hipEventCreate(&sh->tev[2 * r + i]));
+        if (sh->tev[2 * r + i] == NULL && fkx_event_get(ctx->device, true, &sh->tev[2 * r + i]) != FK_OK)
+          { fk_set_error(ctx, "fk_shard_count: cannot create events");
+            return (FK_EHIP);
+          }
       FK_HIP(ctx, hipEventRecord(sh->tev[2 * r], sh->xs));
       int e = exchange(sh, sp, sb, rp, rb);
       if (e != FK_OK) return (e);

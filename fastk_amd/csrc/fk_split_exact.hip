@@ -526,7 +526,10 @@ int fkx_train_tran(fk_ctx *ctx, const void *d_bases, const int64_t *h_roff, int6
 // ---- exclusive scan of many counts -------------------------------------------------------------------------------------
 // k_exscan_tiles is one workgroup (made for a few thousand tile counts); the exact splitter scans a count per segment and
 // bucket -- millions.  Tiles of 4096 counts: their sums, the scan of the sums by k_exscan_tiles, the scan inside each tile.
-__global__ __launch_bounds__(256) void k_xs_tilesum(const u32 *__restrict__ in, int64_t n, u32 *__restrict__ tsum)
+// (a tile's sum is kept in 32 bits; one that does not fit -- 4096 consecutive counts of a million each: unsegmented,
+// very long low-complexity reads -- raises *ovf, which every caller reads back with the total)
+__global__ __launch_bounds__(256) void k_xs_tilesum(const u32 *__restrict__ in, int64_t n, u32 *__restrict__ tsum,
+                                                    u64 *__restrict__ ovf)
 { __shared__ u64 tmp[8];
   const int64_t i0 = (int64_t) blockIdx.x * 4096 + (int64_t) threadIdx.x * 16;
   u64 mine = 0;
@@ -535,7 +538,10 @@ __global__ __launch_bounds__(256) void k_xs_tilesum(const u32 *__restrict__ in, 
   u64 tot;
   fk_block_exscan_256<u64>(mine, tmp, &tot);
   if (threadIdx.x == 0)
-    tsum[blockIdx.x] = (u32) tot;
+    { tsum[blockIdx.x] = (u32) tot;
+      if ((tot >> 32) != 0)
+        atomicMax((unsigned long long *) ovf, 1ull);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_xs_tilescan(const u32 *__restrict__ in, int64_t n, const u64 *__restrict__ toff,
@@ -560,6 +566,14 @@ __global__ __launch_bounds__(256) void k_xs_tilescan(const u32 *__restrict__ in,
 }
 
 // out[i] = in[0] + .. + in[i-1] for i < n, *total = the sum (a tile's sum must fit 32 bits: counts of records)
+#define XS_OVF_WORD 2210          // d_scratch / h_scratch word: "a tile sum of xs_exscan did not fit 32 bits"
+static int xs_overflowed(fk_ctx *ctx)
+{ if (ctx->h_scratch[XS_OVF_WORD] == 0)
+    return (FK_OK);
+  fk_set_error(ctx, "exact split: more than 2^32 records in 4096 consecutive segments");
+  return (FK_EUNSUPPORTED);
+}
+
 static int xs_exscan(fk_ctx *ctx, const u32 *in, int64_t n, u64 *out, u64 *total)
 { hipStream_t s = ctx->stream;
   if (n <= 32768)
@@ -572,7 +586,7 @@ static int xs_exscan(fk_ctx *ctx, const u32 *in, int64_t n, u64 *out, u64 *total
   if (tb == NULL) return (FK_ENOMEM);
   u32 *tsum = (u32 *) tb;
   u64 *toff = (u64 *) (tb + t4);
-  hipLaunchKernelGGL(k_xs_tilesum, dim3((unsigned) nt), dim3(256), 0, s, in, n, tsum);
+  hipLaunchKernelGGL(k_xs_tilesum, dim3((unsigned) nt), dim3(256), 0, s, in, n, tsum, ctx->d_scratch + XS_OVF_WORD);
   hipLaunchKernelGGL(k_exscan_tiles, dim3(1), dim3(256), 0, s, (const u32 *) tsum, nt, toff, total);
   hipLaunchKernelGGL(k_xs_tilescan, dim3((unsigned) nt), dim3(256), 0, s, in, n, (const u64 *) toff, out);
   return (FK_OK);
@@ -592,6 +606,7 @@ int fkx_split_exact(fk_ctx *ctx, const void *d_bases, const int64_t *d_roff, int
     return (FK_OK);
   if (ctx->prm.kmer > 128 || ctx->prm.kmer < 8 || nparts > XS_MAXPARTS)
     return (FK_EUNSUPPORTED);
+  FK_HIP(ctx, hipMemsetAsync(ctx->d_scratch + XS_OVF_WORD, 0, 8, s));
   u32 *d_cnt = NULL;
   u64 *d_off = NULL;
   u64 *d_inst = ctx->d_scratch + 2048;          // [64] instances, [64] = total records
@@ -630,7 +645,9 @@ int fkx_split_exact(fk_ctx *ctx, const void *d_bases, const int64_t *d_roff, int
       if (xs_exscan(ctx, (const u32 *) d_nblk, nreads, d_boff, ctx->d_scratch + 2200) != FK_OK) return (FK_ENOMEM);
       FK_LAUNCH_CHECK(ctx);
       FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch + 2200, ctx->d_scratch + 2200, 8, hipMemcpyDeviceToHost, s));
+      FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch + XS_OVF_WORD, ctx->d_scratch + XS_OVF_WORD, 8, hipMemcpyDeviceToHost, s));
       FK_HIP(ctx, hipStreamSynchronize(s));
+      if (xs_overflowed(ctx) != FK_OK) return (FK_EUNSUPPORTED);
       const int64_t nblocks = (int64_t) ctx->h_scratch[2200];
       if (nblocks > nreads && nblocks < 0x7fffffffll)          // (some read is longer than a block)
         { const int64_t nb4 = (nblocks * 4 + 63) & ~63ll;
@@ -648,7 +665,9 @@ int fkx_split_exact(fk_ctx *ctx, const void *d_bases, const int64_t *d_roff, int
                              (const u64 *) soff, nblocks, seg_read, seg_p0);
           FK_LAUNCH_CHECK(ctx);
           FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch + 2201, ctx->d_scratch + 2201, 8, hipMemcpyDeviceToHost, s));
+          FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch + XS_OVF_WORD, ctx->d_scratch + XS_OVF_WORD, 8, hipMemcpyDeviceToHost, s));
           FK_HIP(ctx, hipStreamSynchronize(s));
+          if (xs_overflowed(ctx) != FK_OK) return (FK_EUNSUPPORTED);
           nseg = (int64_t) ctx->h_scratch[2201];
           hipLaunchKernelGGL(k_xs_ends, dim3((unsigned) ((nseg + 255) / 256)), dim3(256), 0, s, (const u32 *) seg_read,
                              (const u32 *) seg_p0, nseg, seg_p1);
@@ -675,7 +694,9 @@ int fkx_split_exact(fk_ctx *ctx, const void *d_bases, const int64_t *d_roff, int
   FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch, d_inst, 72 * sizeof(u64), hipMemcpyDeviceToHost, s));
   for (int b = 1; b < nparts; b++)                       // where bucket b starts: the scan at its first read
     FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch + 128 + b, d_off + (int64_t) b * nseg, 8, hipMemcpyDeviceToHost, s));
+  FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch + XS_OVF_WORD, ctx->d_scratch + XS_OVF_WORD, 8, hipMemcpyDeviceToHost, s));
   FK_HIP(ctx, hipStreamSynchronize(s));
+  if (xs_overflowed(ctx) != FK_OK) return (FK_EUNSUPPORTED);
   const int64_t ns = (int64_t) ctx->h_scratch[64];
   int64_t ni = 0;
   for (int x = 0; x < 64; x++)

@@ -44,3 +44,32 @@ def test_contexts_return_their_streams_to_the_pool():
             assert c.debug_get("stream_pool") == max(n0 - 2, 0)
     with fastk_amd.Context(kmer=21) as d:
         assert d.debug_get("stream_pool") == max(n0, 2)
+
+
+@pytest.mark.gpu
+def test_contexts_return_their_events_to_the_pool():
+    """... and no hipEventDestroy either (round 6, VERDICT r5: the same runtime, the same class of object): the events of a
+    context, of a bucket's stage timers, of the part writers go back to a process-wide pool; a second run of the same
+    work creates no new ones."""
+    import numpy as np
+    import fastk_amd
+    from oracle import orc
+    bases, boff = orc.synth_block(11, 30000, 150, 2000, 0, 3000)
+    def run():
+        with fastk_amd.Context(kmer=31, table_cutoff=1, nthreads=4) as ctx:
+            ctx.push_block(bases, boff.astype(np.int32))
+            res = ctx.finish()
+            n = ctx.debug_get("event_pool")
+        return res, n
+    r1, _ = run()
+    with fastk_amd.Context(kmer=21) as c:
+        idle1 = c.debug_get("event_pool")
+    r2, _ = run()
+    with fastk_amd.Context(kmer=21) as c:
+        idle2 = c.debug_get("event_pool")
+    assert idle1 > 0 and idle2 == idle1, (idle1, idle2)       # everything came back, nothing new was made
+    assert np.array_equal(r1.hist, r2.hist) and np.array_equal(r1.table, r2.table)
+    import subprocess, os
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fastk_amd", "lib", "libfastk_amd.so")
+    und = subprocess.run(["nm", "-D", "--undefined-only", lib], capture_output=True, text=True, check=True).stdout
+    assert "hipEventDestroy" not in und and "hipStreamDestroy" not in und
