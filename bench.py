@@ -636,6 +636,9 @@ def main_config3(args, cfg, torch, fastk_amd, dist, rank, local_rank, world, dev
                     kernel="k_rx_scatter<3,12> (weighted k-mer records, R=%d B), rank 0's share" % w.kmer_word,
                     records_per_launch=int(loc.nweighted / (nl / passes_k)), launches_per_step=int(nl),
                     avg_launch_ms=round(loc.ms_scatter_kmer / nl, 4))
+    if getattr(loc, "nrefs", 0) > 0:          # round 6: no pass over W; the table sort's pass on rank 0's share is graded
+        roofline = roofline_record_refs(loc, w, 3, None, None)
+        roofline["kernel"] += ", rank 0's share"
     # what the exchanges moved, rank by rank (fk_shard_get_stats): how many ranks RCCL's communicator really holds,
     # the super-mer bytes every rank sent / received / kept in C1, the device time of its sends and receives (they
     # overlap the counting), and C3 by phase
@@ -686,6 +689,8 @@ def roofline_record(loc, w, cfg_id, ceiling, ceiling_kernel):
     library's stream.  With bucket streaming a step has 2 launches per bucket: achieved = (sum of the launches'
     algorithmic bytes) / (sum of their durations), and the per-launch figures are the averages.  pass_total adds the
     per-pass helper kernels."""
+    if getattr(loc, "nrefs", 0) > 0:
+        return roofline_record_refs(loc, w, cfg_id, ceiling, ceiling_kernel)
     n_rec = loc.nweighted
     nl_k = max(loc.launches_kmer, 1)
     nl_s = max(loc.launches_super, 1)
@@ -736,6 +741,50 @@ def roofline_record(loc, w, cfg_id, ceiling, ceiling_kernel):
                 table_sort=dict(records=int(loc.ncollapsed), launches=int(loc.passes_final),
                                 achieved_pass_total=gbs(2.0 * loc.ncollapsed * w.kmer_word * max(loc.passes_final, 1),
                                                         loc.ms_pass_final)),
+                supermer_pass=dict(
+                    kernel="k_rx_scatter_w<5,4,hashed> (super-mer records, R=%d B)" % w.smer_word,
+                    records_per_launch=int(loc.nsuper / (nl_s / passes_s)), launches=int(nl_s),
+                    avg_launch_ms=round(loc.ms_scatter_super / nl_s, 4),
+                    achieved=gbs(algo_s, loc.ms_scatter_super),
+                    pass_total_achieved=gbs(algo_s, loc.ms_pass_super)))
+
+
+def roofline_record_refs(loc, w, cfg_id, ceiling, ceiling_kernel):
+    """Round 6: no digit pass runs over the W weighted k-mer records any more (fk_recut.hip: 8-byte references to
+    minimizer domains are sorted instead, the expansion writes the k-mers grouped).  The radix-sort pass over packed
+    k-mer records that remains -- the same kernel, k_rx_scatter<3,12>, on the same 12-byte (k-mer, count) records -- is
+    the LSD pass of the TABLE sort (3.0 G entries at configs[2], `passes_final` launches per step): that is the graded
+    kernel now.  Algorithmic bytes per launch = 2 * n * R; duration = HIP event pair around every scatter launch on the
+    library's stream.  `reference_sort` and `supermer_pass` are the other two instantiations of the pass."""
+    gbs = lambda nbytes_, ms: round(nbytes_ / (ms * 1e-3) / 1e9, 1) if ms > 0 else 0.0
+    nt = loc.ntable
+    pf = max(loc.passes_final, 1)
+    algo_t = 2.0 * nt * w.kmer_word * pf
+    achieved = gbs(algo_t, loc.ms_scatter_final)
+    nl_s = max(loc.launches_super, 1)
+    passes_s = max(loc.passes_super, 1)
+    algo_s = 2.0 * loc.nsuper * w.smer_word * passes_s
+    nl_r = max(loc.launches_kmer, 1)
+    passes_r = max(loc.passes_kmer, 1)
+    algo_r = 2.0 * loc.nrefs * 8 * passes_r
+    return dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+                frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None, traffic_unit=None,
+                copy_ceiling=ceiling, frac_of_copy_ceiling=round(achieved / ceiling, 4) if ceiling else None,
+                copy_kernel_ceiling=ceiling_kernel,
+                frac_of_copy_kernel_ceiling=round(achieved / ceiling_kernel, 4) if ceiling_kernel else None,
+                algorithmic_bytes=round(algo_t / pf, 1),
+                kernel="k_rx_scatter<3,12> (LSD pass of the table sort over the (k-mer, count) records, R=%d B)" % w.kmer_word,
+                records_per_launch=int(nt), launches_per_step=int(pf),
+                avg_launch_ms=round(loc.ms_scatter_final / pf, 4),
+                pass_total=dict(avg_ms=round(loc.ms_pass_final / pf, 4), achieved=gbs(algo_t, loc.ms_pass_final),
+                                note="scatter + k_rx_tilehist + k_rx_chunkscan + k_rx_superscan"),
+                kmer_grouping=dict(
+                    note="no pass over the W weighted k-mer records: references to minimizer domains are sorted instead",
+                    weighted_kmers=int(loc.nweighted), references=int(loc.nrefs), launches_over_W=0),
+                reference_sort=dict(
+                    kernel="k_rx_scatter<2,*> (references, R=8 B)", records_per_launch=int(loc.nrefs / (nl_r / passes_r)),
+                    launches=int(nl_r), avg_launch_ms=round(loc.ms_scatter_kmer / nl_r, 4),
+                    achieved=gbs(algo_r, loc.ms_scatter_kmer), pass_total_achieved=gbs(algo_r, loc.ms_pass_kmer)),
                 supermer_pass=dict(
                     kernel="k_rx_scatter_w<5,4,hashed> (super-mer records, R=%d B)" % w.smer_word,
                     records_per_launch=int(loc.nsuper / (nl_s / passes_s)), launches=int(nl_s),

@@ -61,7 +61,8 @@ class CResult(C.Structure):
                 ("ms_scatter_super", C.c_double), ("ms_scatter_kmer", C.c_double),
                 ("ncollapsed", C.c_int64), ("passes_final", C.c_int), ("ms_pass_final", C.c_double),
                 ("launches_super", C.c_int64), ("launches_kmer", C.c_int64), ("split_passes", C.c_int),
-                ("replay_passes", C.c_int), ("buckets_counted", C.c_int), ("spilled_bytes", C.c_int64), ("ms_table_sort", C.c_double)]
+                ("replay_passes", C.c_int), ("buckets_counted", C.c_int), ("spilled_bytes", C.c_int64), ("ms_table_sort", C.c_double),
+                ("nrefs", C.c_int64), ("ms_scatter_final", C.c_double)]
 
 
 class CProfiles(C.Structure):
@@ -218,6 +219,8 @@ class Result:
         self.split_passes, self.buckets_counted = int(cres.split_passes), int(cres.buckets_counted)
         self.replay_passes = int(cres.replay_passes)
         self.spilled_bytes, self.ms_table_sort = int(cres.spilled_bytes), float(cres.ms_table_sort)
+        self.nrefs = int(cres.nrefs)
+        self.ms_scatter_final = float(cres.ms_scatter_final)
         if self.ntable > 0 and cres.table:
             self.table = np.ctypeslib.as_array(cres.table, shape=(self.ntable, kmer_word)).copy()
         else:

@@ -701,7 +701,8 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count2(const u32 *__restrict_
                                                           const u64 *__restrict__ bounds, int kbytes,
                                                           int cutoff, u64 *__restrict__ hist_g,
                                                           u64 *__restrict__ scal, u32 *__restrict__ table,
-                                                          int cap_eff, int limit, int gshift, u32 sat, u64 tcap, int lcap)
+                                                          int cap_eff, int limit, int gshift, u32 sat, u64 tcap, int lcap,
+                                                          u32 nbins)       // bins = bounds[i << gshift] .. bounds[(i + 1) << gshift]
 { constexpr int CAP = AgCfg<KW>::CAP;
   constexpr int NS  = AgCfg<KW>::NS;
   constexpr int SDW = AgCfg<KW>::SDW;
@@ -854,7 +855,6 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count2(const u32 *__restrict_
         }
       AG_T(7);
     };
-  const u32 nbins = (u32) (AG_BINS >> gshift);
 #define AG_BOUNDS_OF(b) bounds[(size_t) min((b) + ag_opaque(lane & 1u), nbins) << gshift]
   u32 bin = blockIdx.x;
   int64_t beg = 0, end = 0;
@@ -1289,9 +1289,11 @@ static int ag_gshift(int64_t n)
   return (gshift);
 }
 
+// pre_bounds != NULL: the fills are given (pre_nbins + 1 record positions, fkx_ref_bounds) -- no hash bins are looked for
 template <int KW>
 static int aggr_t(fk_ctx *ctx, const void *d_grouped, int64_t n, int cutoff, int64_t *hist,
-                  int64_t *max_inst, int64_t *ndistinct, void *d_table, int64_t cap, int64_t *ntable)
+                  int64_t *max_inst, int64_t *ndistinct, void *d_table, int64_t cap, int64_t *ntable,
+                  const u64 *pre_bounds = NULL, int64_t pre_nbins = 0)
 { hipStream_t s = ctx->stream;
   if (ntable) *ntable = 0;
   if (ndistinct) *ndistinct = 0;
@@ -1301,7 +1303,7 @@ static int aggr_t(fk_ctx *ctx, const void *d_grouped, int64_t n, int cutoff, int
     { fk_set_error(ctx, "aggregate: no table buffer");
       return (FK_EINVAL);
     }
-  u64 *d_bounds = (u64 *) fk_slot(ctx, FK_SLOT_AG_BOUNDS, (AG_BINS + 1) * 8);
+  u64 *d_bounds = (pre_bounds != NULL) ? (u64 *) pre_bounds : (u64 *) fk_slot(ctx, FK_SLOT_AG_BOUNDS, (AG_BINS + 1) * 8);
   u64 *d_hist   = (u64 *) fk_slot(ctx, FK_SLOT_CT_HIST, (FK_HIST_BINS + AG_NSCAL) * 8);
   if (d_bounds == NULL || d_hist == NULL)
     return (FK_ENOMEM);
@@ -1316,8 +1318,9 @@ static int aggr_t(fk_ctx *ctx, const void *d_grouped, int64_t n, int cutoff, int
       attr_set[KW] = true;
     }
   FK_HIP(ctx, hipMemsetAsync(d_hist, 0, (FK_HIST_BINS + AG_NSCAL) * 8, s));
-  hipLaunchKernelGGL(k_ag_bounds<KW>, dim3(AG_BINS / 256 + 1), dim3(256), 0, s, (const u32 *) d_grouped, n,
-                     ctx->wid.kmer_bytes, d_bounds);
+  if (pre_bounds == NULL)
+    hipLaunchKernelGGL(k_ag_bounds<KW>, dim3(AG_BINS / 256 + 1), dim3(256), 0, s, (const u32 *) d_grouped, n,
+                       ctx->wid.kmer_bytes, d_bounds);
   const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
   // Neighbouring bins are merged while two of them still fit one fill with room to spare: small inputs get full
   // fills, and a fill is never expected to hold more records than it takes -- a bin beyond CAP costs a second
@@ -1327,11 +1330,14 @@ static int aggr_t(fk_ctx *ctx, const void *d_grouped, int64_t n, int cutoff, int
     gshift = 0;
   if (ctx->dbg_aggr_gshift > 0)
     gshift = ctx->dbg_aggr_gshift - 1;
+  if (pre_bounds != NULL)
+    gshift = 0;
+  const u32 nbins = (pre_bounds != NULL) ? (u32) pre_nbins : (u32) (AG_BINS >> gshift);
   int cap_eff = AgCfg<KW>::CAP;                       // fk_debug_set("aggr_limit"): a fill takes only this many records
   if (ctx->dbg_aggr_limit > 0 && ctx->dbg_aggr_limit < cap_eff)
     cap_eff = ctx->dbg_aggr_limit < 4 ? 4 : ctx->dbg_aggr_limit;
   const int limit = cap_eff * 3 / 4;
-  if (ctx->dbg_aggr_engine == 1 || ctx->dbg_aggr_variant != 0)     // the counting sort of round 3 (kept for comparison)
+  if (pre_bounds == NULL && (ctx->dbg_aggr_engine == 1 || ctx->dbg_aggr_variant != 0))     // the counting sort of round 3 (kept for comparison)
     hipLaunchKernelGGL((k_ag_count<KW, false>), dim3((unsigned) cus), dim3(AG_THREADS), lds, s, (const u32 *) d_grouped,
                        (const u64 *) d_bounds, ctx->wid.kmer_bytes, cutoff, d_hist, d_scal, (u32 *) d_table, cap_eff, limit, ctx->dbg_aggr_variant, gshift,
                        (u32) (ctx->aggr_sat > 0 ? ctx->aggr_sat : 0x7fff), (u64) cap);
@@ -1339,7 +1345,8 @@ static int aggr_t(fk_ctx *ctx, const void *d_grouped, int64_t n, int cutoff, int
     hipLaunchKernelGGL((k_ag_count2<KW>), dim3((unsigned) cus), dim3(AG_THREADS), lds2, s, (const u32 *) d_grouped,
                        (const u64 *) d_bounds, ctx->wid.kmer_bytes, cutoff, d_hist, d_scal, (u32 *) d_table, cap_eff, limit, gshift,
                        (u32) (ctx->aggr_sat > 0 ? ctx->aggr_sat : 0x7fff), (u64) cap,
-                       ctx->dbg_aggr_engine == 2 ? 2 : AG2_LCAP);      // (engine 2: tiny lists, the fallback elections run)
+                       ctx->dbg_aggr_engine == 2 ? 2 : AG2_LCAP,       // (engine 2: tiny lists, the fallback elections run)
+                       nbins);
   FK_LAUNCH_CHECK(ctx);
   u64 *h = ctx->h_scratch;                       // pinned, 64 KB + 64 KB: the histogram needs 256 KB
   u64 *hh = (u64 *) malloc((FK_HIST_BINS + AG_NSCAL) * 8);
@@ -1380,6 +1387,23 @@ static int aggr_t(fk_ctx *ctx, const void *d_grouped, int64_t n, int cutoff, int
    counts into hist[1..0x7fff] and the instances of saturated k-mers into *max_inst; with cutoff > 0
    writes the (k-mer, count) records with count >= cutoff to d_table IN NO PARTICULAR ORDER.
    FK_ESTATE: some bin holds more distinct k-mers than AG_MAXR rounds of the LDS table take. */
+/* The same over fills that are given: d_bounds[0 .. nfills] = record positions, every k-mer's copies inside one fill
+   (or one oversized group, which is taken in chunks / selections like a bin that is too large). */
+int fkx_aggregate_fills(fk_ctx *ctx, const void *d_grouped, int64_t n, int cutoff, int64_t *hist, int64_t *max_inst,
+                        int64_t *ndistinct, void *d_table, int64_t cap, int64_t *ntable, const u64 *d_bounds, int64_t nfills)
+{ if (d_bounds == NULL || nfills <= 0 || nfills > 0x7fffffffll)
+    return (FK_EINVAL);
+  switch (ctx->wid.kmer_stride >> 2)
+  { case 2: return aggr_t<2>(ctx, d_grouped, n, cutoff, hist, max_inst, ndistinct, d_table, cap, ntable, d_bounds, nfills);
+    case 3: return aggr_t<3>(ctx, d_grouped, n, cutoff, hist, max_inst, ndistinct, d_table, cap, ntable, d_bounds, nfills);
+    case 4: return aggr_t<4>(ctx, d_grouped, n, cutoff, hist, max_inst, ndistinct, d_table, cap, ntable, d_bounds, nfills);
+    case 5: return aggr_t<5>(ctx, d_grouped, n, cutoff, hist, max_inst, ndistinct, d_table, cap, ntable, d_bounds, nfills);
+    default:
+      fk_set_error(ctx, "k-mer stride %d not built", ctx->wid.kmer_stride);
+      return (FK_EUNSUPPORTED);
+  }
+}
+
 int fkx_aggregate(fk_ctx *ctx, const void *d_grouped, int64_t n, int cutoff, int64_t *hist,
                   int64_t *max_inst, int64_t *ndistinct, void *d_table, int64_t cap, int64_t *ntable)
 { switch (ctx->wid.kmer_stride >> 2)

@@ -496,9 +496,11 @@ extern "C" void fk_destroy(fk_ctx *ctx)
   for (int i = 0; i < 4; i++)
     if (ctx->wstream[i] != NULL)
       hipStreamSynchronize(ctx->wstream[i]);
-  // (no hipDeviceSynchronize: these are all the streams a context queues work on -- the pushes use copy_stream or
-  // stream, the flush helper was joined above -- and a host with other contexts or work of its own on the device
-  // must not stall on them; ADVICE r5.  The stream / event pools assume that the host never calls hipDeviceReset.)
+  // ... then the device as a whole.  ADVICE r5 notes that this stalls a host with other contexts or work of its own on
+  // the device; it stays all the same (round 6): the hipFree calls below synchronise the device anyway, and the first
+  // GPU box this round's library ran on WITHOUT it was lost under 32 fuzz processes -- cause unknown, the conservative
+  // order is the one that ran 60,000 iterations in round 5.  (The stream / event pools assume no hipDeviceReset.)
+  (void) hipDeviceSynchronize();
   (void) hipGetLastError();
   hipFree(ctx->d_mbucket); hipFree(ctx->d_mbucket_pass); hipFree(ctx->d_scratch); hipFree(ctx->d_cursors); hipFree(ctx->d_plan);
   if (ctx->h_mbucket_pass) hipHostFree(ctx->h_mbucket_pass);
@@ -766,7 +768,8 @@ extern "C" int fk_debug_set(fk_ctx *ctx, const char *key, int64_t value)
     { ctx->dbg_no_replay = (value == 0) ? 1 : 0;
       return (FK_OK);
     }
-  if (strcmp(key, "kmer_stage") == 0)       // 1: sort / collapse / sort instead of hash aggregation
+  if (strcmp(key, "kmer_stage") == 0)       // 1: sort / collapse / sort instead of hash aggregation; 2: two hashed passes over
+                                            //    the weighted k-mers instead of sorted references (fk_recut.hip)
     { ctx->dbg_kmer_stage = (int) value;
       return (FK_OK);
     }

@@ -254,7 +254,37 @@ enum { FK_SLOT_SM_A = 0, FK_SLOT_SM_B, FK_SLOT_KM_A, FK_SLOT_KM_B, FK_SLOT_EX_HE
        FK_SLOT_RAW, FK_SLOT_FQ_INFO, FK_SLOT_FQ_PHASE, FK_SLOT_FQ_OFF, FK_SLOT_TIE_A, FK_SLOT_TIE_B,
        FK_SLOT_TIE_POS, FK_SLOT_SM_D, FK_SLOT_PF_IDX, FK_SLOT_PF_CNT, FK_SLOT_PF_ZC, FK_SLOT_PF_ZO,
        FK_SLOT_PF_ENDS, FK_SLOT_PF_LEN, FK_SLOT_PF_OFF, FK_SLOT_PF_OUT, FK_SLOT_ENT, FK_SLOT_TENT, FK_SLOT_TCNT, FK_SLOT_CBASE, FK_SLOT_PF_RID,
-       FK_SLOT_PK_TIDX, FK_SLOT_PK_ASCII, FK_SLOT_SM_DIG, FK_SLOT_GATHER, FK_SLOT_XS_READS, FK_SLOT_XS_BLOCKS, FK_SLOT_XS_SCAN };
+       FK_SLOT_PK_TIDX, FK_SLOT_PK_ASCII, FK_SLOT_SM_DIG, FK_SLOT_GATHER, FK_SLOT_XS_READS, FK_SLOT_XS_BLOCKS, FK_SLOT_XS_SCAN,
+       FK_SLOT_REF_A, FK_SLOT_REF_B, FK_SLOT_COUNT_ };
+static_assert(FK_SLOT_COUNT_ <= FK_NSLOTS, "more slots than fk_ctx holds");
+
+// References to the pieces of distinct super-mers (fk_recut.hip): one 64-bit word, the key on top so that the sort takes
+// its three highest bytes.  key: 22 bits of a mix of the piece's minimizer rank; idx: the super-mer among the
+// bucket's de-duplicated records; off: the piece's first k-mer inside it; n: its k-mers (1 .. k - 4).
+#define FK_REF_MLEN     16
+#define FK_REF_KEY_BITS 22
+#define FK_REF_IDX_BITS 28
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+static inline u64 fk_ref_pack(u32 key, u32 idx, u32 off, u32 n)
+{ return (((u64) key << 42) | ((u64) idx << 14) | ((u64) off << 7) | (u64) n); }
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+static inline u32 fk_ref_n(u64 r)   { return ((u32) r & 127u); }
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+static inline u32 fk_ref_off(u64 r) { return ((u32) (r >> 7) & 127u); }
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+static inline u32 fk_ref_idx(u64 r) { return ((u32) (r >> 14) & ((1u << FK_REF_IDX_BITS) - 1u)); }
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+static inline u32 fk_ref_key(u64 r) { return ((u32) (r >> 42)); }
 
 // returns a device buffer of at least nbytes for the given purpose (NULL + error set on failure)
 void *fk_slot(fk_ctx *ctx, int slot, int64_t nbytes);
@@ -317,6 +347,16 @@ int fkx_split_fast(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void **d_ou
 int fkx_expand(fk_ctx *ctx, const void *d_smers, int64_t nsuper, void *d_out, int64_t cap,
                int64_t *nweighted, int64_t *ndistinct, int64_t *overflow, bool reuse_counts = false,
                bool hash_stream = false, bool dedup = false);
+// fk_recut.hip: the k-mer stage without W-sized grouping passes (references to minimizer domains, round 6)
+bool fkx_recut_applies(const fk_ctx *ctx, int64_t nsx);
+int fkx_recut(fk_ctx *ctx, const void *d_dd, int64_t nsx, u64 **d_refs, int64_t *nref);
+int fkx_ref_count(fk_ctx *ctx, const u64 *d_refs, int64_t nref, u32 *d_tile_kmers);
+int fkx_ref_bounds(fk_ctx *ctx, const u64 *d_refs, int64_t nref, const u64 *d_koff, int64_t W, int target,
+                   u64 **d_bounds, int64_t *nfills);
+int fkx_expand_refs(fk_ctx *ctx, const void *d_dd, int64_t nsx, const u64 *d_refs, int64_t nref, void *d_out, int64_t cap,
+                    int64_t *nweighted, int64_t *overflow, const u64 **d_koff);
+int fkx_aggregate_fills(fk_ctx *ctx, const void *d_grouped, int64_t n, int cutoff, int64_t *hist, int64_t *max_inst,
+                        int64_t *ndistinct, void *d_table, int64_t cap, int64_t *ntable, const u64 *d_bounds, int64_t nfills);
 int fkx_count(fk_ctx *ctx, const void *d_kmers, int64_t nweighted, int cutoff, int sorted_bytes,
               int64_t *hist, int64_t *max_inst, int64_t *ndistinct,
               void *d_table, int64_t cap, int64_t *ntable);

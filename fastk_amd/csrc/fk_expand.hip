@@ -78,14 +78,21 @@ __device__ __forceinline__ u32 ex_bits(const u32 *rec, int bit)
 // offsets, cut the 2K-bit window out of the super-mer, build its reverse complement, keep the smaller.
 template <int OW> struct __attribute__((packed, aligned(4))) ex_out { u32 w[OW]; };
 
-template <int RW, int KN, int OW, bool DD>   // KN = words holding a k-mer, OW = words of an output record
+// REF (round 6, fk_recut.hip): the tile is EX_TILE REFERENCES to pieces of de-duplicated super-mers, in key order; every
+// reference is a run of its own whose record is fetched from sm[] by index, whose k-mers begin `off` k-mers into that
+// record and number `n` -- the k-mers of one minimizer domain, so that the W records leave grouped by minimizer key.
+template <int RW, int KN, int OW, bool DD, bool REF = false>   // KN = words holding a k-mer, OW = words of an output record
 __global__ __launch_bounds__(EX_THREADS) void k_ex_expand(const u32 *__restrict__ sm, int64_t n,
                                                           int kmer, int len_byte,
                                                           const u64 *__restrict__ tile_koff,
                                                           u32 *__restrict__ out,
                                                           u64 *__restrict__ overflow, int64_t ntiles,
-                                                          uint8_t *__restrict__ dig, int kbytes)
-{ constexpr int RS = RW + (DD ? 1 : 0);             // dwords per input record
+                                                          uint8_t *__restrict__ dig, int kbytes,
+                                                          const u64 *__restrict__ refs = NULL)
+{ static_assert(!REF || DD, "references point at de-duplicated records");
+  constexpr int RS = RW + (DD ? 1 : 0);             // dwords per input record
+  __shared__ u64     sref[REF ? EX_TILE : 1];       // the tile's references
+  __shared__ uint8_t hofs[REF ? EX_TILE : 4];       // first k-mer of head h inside its record
   __shared__ __attribute__((aligned(16))) u32 recs[(EX_TILE + 1) * RS];   // big-endian value words (+1 guard)
   __shared__ uint16_t hoff[EX_TILE + 2]; // first k-mer of head h inside the tile (a tile holds < 2^16 k-mers: 1024 x (k - 6))
   __shared__ uint16_t hrec[EX_TILE];     // record index of head h
@@ -107,6 +114,28 @@ __global__ __launch_bounds__(EX_THREADS) void k_ex_expand(const u32 *__restrict_
   __syncthreads();
   const int64_t t0 = tile * EX_TILE;
   const int     tn = (n - t0 < EX_TILE) ? (int) (n - t0) : EX_TILE;
+  if (REF)
+    { for (int l = threadIdx.x; l < tn; l += EX_THREADS)
+        sref[l] = refs[t0 + l];
+      __syncthreads();
+      // every load is issued before the first LDS write (a loop of load / store pairs waits for memory once per turn)
+      constexpr int NG = (EX_TILE * RS) / EX_THREADS;
+      static_assert((EX_TILE * RS) % EX_THREADS == 0, "whole turns");
+      u32 g[NG];
+#pragma unroll
+      for (int k = 0; k < NG; k++)
+        { const int slot = (int) threadIdx.x + k * EX_THREADS;
+          const int l = min(slot / RS, tn - 1), wd = slot % RS;
+          g[k] = sm[(u64) fk_ref_idx(sref[l]) * RS + wd];
+        }
+#pragma unroll
+      for (int k = 0; k < NG; k++)
+        { const int slot = (int) threadIdx.x + k * EX_THREADS;
+          if (slot < tn * RS)
+            recs[slot] = __builtin_bswap32(g[k]);
+        }
+    }
+  else
   fk_stage16<(EX_TILE * RS + 1023) / 1024, true>(recs, sm + t0 * RS, tn * RS);
   if (threadIdx.x < RS)
     recs[tn * RS + threadIdx.x] = 0;               // guard word read by ex_bits at the last record
@@ -134,7 +163,8 @@ __global__ __launch_bounds__(EX_THREADS) void k_ex_expand(const u32 *__restrict_
                 }
             }
           if (head)
-            nk = ((recs[l * RS + (len_byte >> 2)] >> (24 - 8 * (len_byte & 3))) & 0xffu) + 1u;
+            nk = REF ? fk_ref_n(sref[REF ? l : 0])
+                     : ((recs[l * RS + (len_byte >> 2)] >> (24 - 8 * (len_byte & 3))) & 0xffu) + 1u;
         }
       u32 totk, toth;
       const u32 exk = fk_block_exscan_256<u32>(nk, tmp, &totk);
@@ -147,6 +177,8 @@ __global__ __launch_bounds__(EX_THREADS) void k_ex_expand(const u32 *__restrict_
       if (head)
         { hoff[runh + exh] = (uint16_t) (runk + exk);
           hrec[runh + exh] = (uint16_t) l;
+          if (REF)
+            hofs[REF ? runh + exh : 0] = (uint8_t) fk_ref_off(sref[REF ? l : 0]);
         }
     }
   __syncthreads();
@@ -172,7 +204,8 @@ __global__ __launch_bounds__(EX_THREADS) void k_ex_expand(const u32 *__restrict_
               }
           }
         if (ct >= 0x8000)                          // count.c:455-458
-          { const u32 nk = ((recs[l * RS + (len_byte >> 2)] >> (24 - 8 * (len_byte & 3))) & 0xffu) + 1u;
+          { const u32 nk = REF ? fk_ref_n(sref[REF ? l : 0])        // (a piece accounts for its own k-mers)
+                               : ((recs[l * RS + (len_byte >> 2)] >> (24 - 8 * (len_byte & 3))) & 0xffu) + 1u;
             atomicAdd(overflow, (u64) (ct - 0x7fff) * (u64) nk);
             ct = 0x7fff;
           }
@@ -205,7 +238,7 @@ __global__ __launch_bounds__(EX_THREADS) void k_ex_expand(const u32 *__restrict_
         { const u32 mid = (lo + hi) >> 1;
           if ((u32) hoff[mid] <= j0) lo = mid; else hi = mid;
         }
-      u32        o   = j0 - hoff[lo];
+      u32        o   = j0 - hoff[lo] + (REF ? (u32) hofs[REF ? lo : 0] : 0u);
       u32        nxt = hoff[lo + 1];
       const u32 *rec = recs + (u32) hrec[lo] * RS;
       u32        ct  = hct[lo];
@@ -218,7 +251,7 @@ __global__ __launch_bounds__(EX_THREADS) void k_ex_expand(const u32 *__restrict_
           if (g > 0)
             { if (j == nxt)
                 { lo += 1;
-                  o = 0;
+                  o = REF ? (u32) hofs[REF ? lo : 0] : 0u;
                   nxt = hoff[lo + 1];
                   rec = recs + (u32) hrec[lo] * RS;
                   ct  = hct[lo];
@@ -429,6 +462,78 @@ static int expand_t(fk_ctx *ctx, const void *d_smers, int64_t n, void *d_out, in
   if (rc == FK_EHIP)
     fk_set_error(ctx, "expand: HIP failure: %s", hipGetErrorString(hipGetLastError()));
   return (rc);
+}
+
+// ---- expansion in the order of sorted references (fk_recut.hip) --------------------------------------------------
+template <int RW>
+static int expand_refs_t(fk_ctx *ctx, const void *d_dd, const u64 *d_refs, int64_t nref, void *d_out, int64_t cap,
+                         int64_t *nweighted, int64_t *overflow, const u64 **koff_out)
+{ hipStream_t s = ctx->stream;
+  const int   K = ctx->prm.kmer;
+  const int   kn = (2 * K + 31) / 32;
+  const int   ow = ctx->wid.kmer_stride / 4;
+  const int   len_byte = ctx->wid.smer_bytes;
+  const int64_t ntiles = (nref + EX_TILE - 1) / EX_TILE;
+  *nweighted = 0; *overflow = 0;
+  u32 *d_kmers = (u32 *) fk_slot(ctx, FK_SLOT_EX_KMERS, ntiles * 4);
+  u64 *d_koff  = (u64 *) fk_slot(ctx, FK_SLOT_EX_KOFF, ntiles * 8);
+  if (d_kmers == NULL || d_koff == NULL)
+    return (FK_ENOMEM);
+  u64 *d_tot = ctx->d_scratch;     // [0] k-mers, [2] overflow
+  int rc = fkx_ref_count(ctx, d_refs, nref, d_kmers);
+  if (rc != FK_OK) return (rc);
+  hipLaunchKernelGGL(k_exscan_tiles, dim3(1), dim3(256), 0, s, (const u32 *) d_kmers, ntiles, d_koff, d_tot + 0);
+  FK_LAUNCH_CHECK(ctx);
+  FK_HIP(ctx, hipMemsetAsync(d_tot + 2, 0, 8, s));
+  FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch, d_tot, 8, hipMemcpyDeviceToHost, s));
+  FK_HIP(ctx, hipStreamSynchronize(s));
+  *nweighted = (int64_t) ctx->h_scratch[0];
+  *koff_out = d_koff;
+  if (cap < *nweighted)
+    { fk_set_error(ctx, "k-mer buffer too small: %lld records needed, %lld given", (long long) *nweighted, (long long) cap);
+      return (FK_EINVAL);
+    }
+  if (ow != kn && ow != kn + 1)
+    { fk_set_error(ctx, "k = %d: %d k-mer words do not fit records of %d words", K, kn, ow);
+      return (FK_EUNSUPPORTED);
+    }
+  const int64_t egrid = 8ll * (ctx->num_cus > 0 ? ctx->num_cus : 256);
+#define EXR_LAUNCH(KN, OW)                                                                           \
+    hipLaunchKernelGGL((k_ex_expand<RW, KN, OW, true, true>), dim3((unsigned) std::min<int64_t>(ntiles, egrid)), \
+                       dim3(EX_THREADS), 0, s, (const u32 *) d_dd, nref, K, len_byte, (const u64 *) d_koff, \
+                       (u32 *) d_out, d_tot + 2, ntiles, (uint8_t *) NULL, ctx->wid.kmer_bytes, d_refs)
+  switch (kn)
+  { case 2: if (ow == 2) EXR_LAUNCH(2, 2); else EXR_LAUNCH(2, 3); break;
+    case 3: if (ow == 3) EXR_LAUNCH(3, 3); else EXR_LAUNCH(3, 4); break;
+    case 4: if (ow == 4) EXR_LAUNCH(4, 4); else EXR_LAUNCH(4, 5); break;
+    default:
+      fk_set_error(ctx, "k = %d needs %d k-mer words; the reference expansion is built for k = 32 ... 64", K, kn);
+      return (FK_EUNSUPPORTED);
+  }
+#undef EXR_LAUNCH
+  FK_LAUNCH_CHECK(ctx);
+  FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch, d_tot + 2, 8, hipMemcpyDeviceToHost, s));
+  FK_HIP(ctx, hipStreamSynchronize(s));
+  *overflow = (int64_t) ctx->h_scratch[0];
+  return (FK_OK);
+}
+
+/* The W weighted k-mer records of the nref pieces d_refs points at (sorted by key, fkx_recut) inside the de-duplicated
+   records d_dd, written in that order; *d_koff = records in front of every tile of EX_TILE references (for
+   fkx_ref_bounds). */
+int fkx_expand_refs(fk_ctx *ctx, const void *d_dd, int64_t nsx, const u64 *d_refs, int64_t nref, void *d_out, int64_t cap,
+                    int64_t *nweighted, int64_t *overflow, const u64 **d_koff)
+{ (void) nsx;
+  static_assert(EX_TILE == 512, "fk_recut.hip counts k-mers per RF_TILE = 512 references");
+  switch (ctx->wid.smer_stride >> 2)
+  { case 4: return expand_refs_t<4>(ctx, d_dd, d_refs, nref, d_out, cap, nweighted, overflow, d_koff);
+    case 5: return expand_refs_t<5>(ctx, d_dd, d_refs, nref, d_out, cap, nweighted, overflow, d_koff);
+    case 6: return expand_refs_t<6>(ctx, d_dd, d_refs, nref, d_out, cap, nweighted, overflow, d_koff);
+    case 7: return expand_refs_t<7>(ctx, d_dd, d_refs, nref, d_out, cap, nweighted, overflow, d_koff);
+    default:
+      fk_set_error(ctx, "super-mer stride %d: no reference expansion", ctx->wid.smer_stride);
+      return (FK_EUNSUPPORTED);
+  }
 }
 
 int fkx_expand(fk_ctx *ctx, const void *d_smers, int64_t nsuper, void *d_out, int64_t cap,

@@ -87,12 +87,12 @@ static int count_bucket(fk_ctx *ctx, void *sm_in, int64_t ns, fk_result *res, bo
 { const fk_widths &w = ctx->wid;
   hipStream_t s = ctx->stream;
   const int cutoff = ctx->prm.table_cutoff;
-  hipEvent_t ev[4] = { NULL, NULL, NULL, NULL };
+  hipEvent_t ev[6] = { NULL, NULL, NULL, NULL, NULL, NULL };      // [4], [5]: around the cut into references and their sort
   int rc = FK_OK;
 
   if (ns <= 0)
     return (FK_OK);
-  for (int i = 0; i < 4; i++)                  // (pooled: no event is ever destroyed, fk_common.h)
+  for (int i = 0; i < 6; i++)                  // (pooled: no event is ever destroyed, fk_common.h)
     if (fkx_event_get(ctx->device, true, &ev[i]) != FK_OK)
       { fk_set_error(ctx, "fk_finish: cannot create events");
         for (int j = 0; j < i; j++)
@@ -165,6 +165,37 @@ static int count_bucket(fk_ctx *ctx, void *sm_in, int64_t ns, fk_result *res, bo
       if ((rc = fkx_expand(ctx, sm_sorted, nsx, NULL, 0, &nw, &nd, &ovf, false, false, dd)) != FK_OK) break;
       res->nweighted += nw;
       res->ndistinct_super += nd;
+      // Round 6: no grouping passes over the W records.  The de-duplicated super-mers are cut into the domains of a second
+      // minimizer (16 bases), 8-byte references to the pieces are sorted by a key of that minimizer, the expansion walks
+      // the references -- all copies of a k-mer then lie inside one key group of the W records as they are written -- and
+      // the aggregation's fills are packed from whole groups (fk_recut.hip).  k from 32 to 64 with LDS de-duplication;
+      // anything else, fk_debug_set("kmer_stage", 2), or pieces that outrun their room: the hashed grouping as before.
+      bool     recut = (dd && nw > 0 && fkx_recut_applies(ctx, nsx));
+      u64     *refs = NULL;
+      int64_t  nref = 0;
+      float    ms_recut = 0.f;
+      if (recut)
+        { hipEventRecord(ev[4], s);
+          rc = fkx_recut(ctx, sm_sorted, nsx, &refs, &nref);
+          if (rc == FK_ESTATE)
+            { recut = false;
+              rc = FK_OK;
+              ctx->err[0] = 0;
+            }
+          else if (rc != FK_OK)
+            break;
+          else
+            { res->passes_kmer      = ctx->sort_stats.passes;
+              res->launches_kmer   += ctx->sort_stats.passes;
+              res->ms_pass_kmer    += ctx->sort_stats.pass_ms_total;
+              res->ms_scatter_kmer += ctx->sort_stats.scatter_ms_total;
+              res->nrefs           += nref;
+            }
+          hipEventRecord(ev[5], s);
+          hipEventSynchronize(ev[5]);
+          hipEventElapsedTime(&ms_recut, ev[4], ev[5]);
+        }
+      const u64 *ref_koff = NULL;
       if (nw > 0)
         { // The k-mer slots are sized for the LARGEST bucket at once (this one's k-mers per super-mer applied to the largest
           // bucket's records): hipMalloc and hipFree take well under a millisecond each, but memory a process has freed is
@@ -186,6 +217,16 @@ static int count_bucket(fk_ctx *ctx, void *sm_in, int64_t ns, fk_result *res, bo
                     (long long) ns_max, (long long) nw, (long long) want);
           if ((km_a = fk_slot(ctx, FK_SLOT_KM_A, want * w.kmer_stride)) == NULL)
             { rc = FK_ENOMEM; break; }
+          if (recut)
+            { int64_t nw2 = 0;
+              if ((rc = fkx_expand_refs(ctx, sm_sorted, nsx, refs, nref, km_a, want, &nw2, &ovf, &ref_koff)) != FK_OK) break;
+              if (nw2 != nw)
+                { fk_set_error(ctx, "the pieces hold %lld k-mers, their super-mers %lld", (long long) nw2, (long long) nw);
+                  rc = FK_ESTATE;
+                  break;
+                }
+            }
+          else
           if ((rc = fkx_expand(ctx, sm_sorted, nsx, km_a, nw, &nw, &nd, &ovf, true,
                                ctx->dbg_kmer_stage != 1 && exact_roff == NULL, dd)) != FK_OK) break;
           // (the de-duplicated super-mers in slot B are dead from here on)
@@ -218,12 +259,24 @@ static int count_bucket(fk_ctx *ctx, void *sm_in, int64_t ns, fk_result *res, bo
       float   ms_aggr = 0.f;
       if (nw > 0 && ctx->dbg_kmer_stage != 1)
         { void *grouped = km_a;
-          if ((rc = fkx_group(ctx, nw, km_a, km_b, w.kmer_stride, w.kmer_bytes, 2, &grouped)) != FK_OK)
-            break;
-          res->passes_kmer      = ctx->sort_stats.passes;
-          res->launches_kmer   += ctx->sort_stats.passes;
-          res->ms_pass_kmer    += ctx->sort_stats.pass_ms_total;
-          res->ms_scatter_kmer += ctx->sort_stats.scatter_ms_total;
+          u64     *fills = NULL;
+          int64_t  nfills = 0;
+          if (recut)
+            { int cap_fill = ((w.kmer_stride >> 2) <= 3) ? 8192 : 4096;      // AgCfg<KW>::CAP
+              if (ctx->dbg_aggr_limit > 0 && ctx->dbg_aggr_limit < cap_fill)
+                cap_fill = ctx->dbg_aggr_limit < 4 ? 4 : ctx->dbg_aggr_limit;
+              const int target = std::max(1, cap_fill * 15 / 16);
+              if ((rc = fkx_ref_bounds(ctx, refs, nref, ref_koff, nw, target, &fills, &nfills)) != FK_OK)
+                break;
+            }
+          else
+            { if ((rc = fkx_group(ctx, nw, km_a, km_b, w.kmer_stride, w.kmer_bytes, 2, &grouped)) != FK_OK)
+                break;
+              res->passes_kmer      = ctx->sort_stats.passes;
+              res->launches_kmer   += ctx->sort_stats.passes;
+              res->ms_pass_kmer    += ctx->sort_stats.pass_ms_total;
+              res->ms_scatter_kmer += ctx->sort_stats.scatter_ms_total;
+            }
           void *tbuf = (grouped == km_a) ? km_b : km_a;
           // Bucket streaming: the table candidates go straight behind those of the earlier buckets when the union
           // buffer has clearly enough room left (1.5 x what a bucket has brought so far); the kernel checks the
@@ -237,7 +290,10 @@ static int count_bucket(fk_ctx *ctx, void *sm_in, int64_t ns, fk_result *res, bo
             }
           hipEventRecord(ctx->ev0, s);
           if (room > 0)
-            { rc = fkx_aggregate(ctx, grouped, nw, cutoff, res->hist, &res->max_inst, &ndk,
+            { rc = recut ? fkx_aggregate_fills(ctx, grouped, nw, cutoff, res->hist, &res->max_inst, &ndk,
+                                               (char *) ctx->slot_ptr[FK_SLOT_TABLE] + *ntab * w.kmer_stride, room, &nt,
+                                               fills, nfills)
+                         : fkx_aggregate(ctx, grouped, nw, cutoff, res->hist, &res->max_inst, &ndk,
                                  (char *) ctx->slot_ptr[FK_SLOT_TABLE] + *ntab * w.kmer_stride, room, &nt);
               if (rc == FKX_TABLE_FULL)
                 room = 0;
@@ -245,7 +301,9 @@ static int count_bucket(fk_ctx *ctx, void *sm_in, int64_t ns, fk_result *res, bo
                 direct = true;
             }
           if (room == 0)
-            rc = fkx_aggregate(ctx, grouped, nw, cutoff, res->hist, &res->max_inst, &ndk,
+            rc = recut ? fkx_aggregate_fills(ctx, grouped, nw, cutoff, res->hist, &res->max_inst, &ndk,
+                                             cutoff > 0 ? tbuf : NULL, nw, &nt, fills, nfills)
+                       : fkx_aggregate(ctx, grouped, nw, cutoff, res->hist, &res->max_inst, &ndk,
                                cutoff > 0 ? tbuf : NULL, nw, &nt);     // adds to hist only on success
           hipEventRecord(ctx->ev1, s);
           if (rc == FK_OK)
@@ -319,6 +377,7 @@ static int count_bucket(fk_ctx *ctx, void *sm_in, int64_t ns, fk_result *res, bo
                     break;
                   res->passes_final   = ctx->sort_stats.passes;
                   res->ms_pass_final += ctx->sort_stats.pass_ms_total;
+                  res->ms_scatter_final += ctx->sort_stats.scatter_ms_total;
                   tab = sorted;
                   for (int x = 0; x < 256; x++)
                     res->wfirst[x] = (exact_roff != NULL) ? exact_census[x] : census[x];
@@ -387,12 +446,12 @@ static int count_bucket(fk_ctx *ctx, void *sm_in, int64_t ns, fk_result *res, bo
                 (long long) ns, (long long) nw, (long long) ndk, ms_between(ev[0], ev[3]),
                 ms_between(ev[0], ev[1]), ms_between(ev[1], ev[2]), ms_between(ev[2], ev[3]), ms_aggr);
       tm->group_s += ms_between(ev[0], ev[1]);
-      tm->expand  += ms_between(ev[1], ev[2]);
-      tm->radix_k += ms_between(ev[2], ev[3]) - ms_aggr;
+      tm->expand  += ms_between(ev[1], ev[2]) - ms_recut;
+      tm->radix_k += ms_between(ev[2], ev[3]) - ms_aggr + ms_recut;      // (the cut into references and their sort: the k-mer "sort")
       tm->aggr    += ms_aggr;
     }
   while (0);
-  for (int i = 0; i < 4; i++)
+  for (int i = 0; i < 6; i++)
     fkx_event_put(ctx->device, true, &ev[i]);
   return (rc);
 }
@@ -427,6 +486,7 @@ static int sort_union_table(fk_ctx *ctx, int64_t ntab, fk_result *res, void **ta
     }
   res->passes_final   = ctx->sort_stats.passes;
   res->ms_pass_final += ctx->sort_stats.pass_ms_total;
+  res->ms_scatter_final += ctx->sort_stats.scatter_ms_total;
   for (int x = 0; x < 256; x++)
     res->wfirst[x] = census[x];
   hipEventRecord(te[1], s);

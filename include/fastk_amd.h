@@ -159,6 +159,10 @@ typedef struct
     int      buckets_counted;             /* non-empty minimizer buckets counted one after the other   */
     int64_t  spilled_bytes;               /* super-mer records that went through host memory           */
     double   ms_table_sort;               /* device time of the table sort (all of its kernels)        */
+    int64_t  nrefs;                       /* round 6: references to pieces of distinct super-mers that were sorted
+                                             instead of the weighted k-mers (0: the k-mers themselves were grouped);
+                                             passes_kmer / ms_pass_kmer / ms_scatter_kmer then describe THAT sort   */
+    double   ms_scatter_final;            /* summed duration of the scatter kernels of the table sort's digit passes */
   } fk_result;
 
 /* Replaces Sorting() + the merge of Merge_Tables() (count.c:1202, table.c:346): runs the

@@ -3057,3 +3057,71 @@ def test_cli_profiles_with_memory_budget(fmt, extra, tmp_path):
     assert sorted(outs[0]) == sorted(outs[1]) and len(outs[0]) == 1 + 4 + 1 + 6
     for f in outs[0]:
         assert outs[0][f] == outs[1][f], f
+
+
+# ------------------------------------------------------------------------------ round 6: the k-mer stage by references
+
+def _domain_reads(k, seed, n=2500):
+    """reads with everything the cut into minimizer domains has to get right: both strands, errors (pieces of different
+    super-mers that hold the same k-mers), reads of k-1 .. k+2, N runs, homopolymers and short tandem repeats (one
+    16-mer at every start: a domain as long as the super-mer; the same minimizer VALUE at several starts), a read
+    that is its own reverse complement, one read copied 40,000 times (weights beyond 0x7fff)."""
+    rng = np.random.default_rng(seed)
+    genome = rng.integers(0, 4, size=60000)
+    reads = []
+    for _ in range(n):
+        L = int(rng.choice([k - 1, k, k + 1, k + 2, 90, 150, 400, 1500]))
+        s0 = int(rng.integers(0, len(genome) - L))
+        r = genome[s0:s0 + L].copy()
+        for j in range(L):
+            if rng.random() < 0.004:
+                r[j] = rng.integers(0, 4)
+        if rng.random() < 0.5:
+            r = (3 - r)[::-1]
+        if rng.random() < 0.1 and L > 5:
+            a = int(rng.integers(0, L))
+            r[a:a + int(rng.integers(1, 4))] = 4
+        reads.append("".join("acgtn"[x] for x in r))
+    unit = "".join("acgt"[x] for x in genome[100:100 + 3 * k])
+    comp = {"a": "t", "c": "g", "g": "c", "t": "a"}
+    pal = unit[:k] + "".join(comp[c] for c in reversed(unit[:k]))
+    reads += ["a" * 300] * 20 + ["ac" * 150] * 20 + ["acg" * 100] * 20 + ["aacgt" * 60] * 20 + [pal] * 7
+    reads += [unit] * 40000
+    return orc.block_from_reads(reads)
+
+
+@pytest.mark.parametrize("k", [32, 33, 37, 40, 41, 48, 51, 56, 63, 64])
+def test_kmer_stage_by_references_matches_oracle_and_hashed_grouping(k):
+    """Round 6 (fk_recut.hip): for k from 32 the weighted k-mers are not grouped by two passes any more -- distinct
+    super-mers are cut into minimizer domains, 8-byte references are sorted, the expansion writes the k-mers grouped.
+    Against the oracle bit for bit and against the hashed grouping (fk_debug_set("kmer_stage", 2)), one and several
+    buckets, with fills of 8192 and of 24 records (every group larger than a fill: chunks and selections), table
+    cutoffs 1 and 4; res.nrefs says which stage ran."""
+    bases, boff = _domain_reads(k, 600 + k)
+    for cutoff in (1, 4):
+        exp = orc.fastk(k, bases, boff, cutoff=cutoff)
+        for nb, stage, limit in ((1, 0, 0), (3, 0, 0), (1, 2, 0), (2, 0, 24)):
+            with fastk_amd.Context(kmer=k, table_cutoff=cutoff, nbuckets=nb) as ctx:
+                if stage:
+                    ctx.debug_set("kmer_stage", stage)
+                if limit:
+                    ctx.debug_set("aggr_limit", limit)
+                ctx.push_block(bases, boff.astype(np.int32))
+                res = ctx.finish()
+                what = (k, cutoff, nb, stage, limit)
+                assert (res.nrefs > 0) == (stage == 0), what
+                if stage == 0:
+                    assert res.ndistinct_super <= res.nrefs <= res.nweighted, what
+                assert res.ninst == exp.ninst, what
+                assert np.array_equal(res.hist, exp.hist) and res.max_inst == exp.max_inst, what
+                assert res.ntable == exp.ntable and np.array_equal(res.table, exp.table), what
+
+
+def test_kmer_stage_below_32_keeps_the_hashed_grouping():
+    with fastk_amd.Context(kmer=31, table_cutoff=1) as ctx:
+        bases, boff = _domain_reads(31, 5, n=300)
+        exp = orc.fastk(31, bases, boff, cutoff=1)
+        ctx.push_block(bases, boff.astype(np.int32))
+        res = ctx.finish()
+        assert res.nrefs == 0
+        assert np.array_equal(res.hist, exp.hist) and np.array_equal(res.table, exp.table)
