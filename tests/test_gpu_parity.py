@@ -3109,8 +3109,9 @@ def test_kmer_stage_by_references_matches_oracle_and_hashed_grouping(k):
                 ctx.push_block(bases, boff.astype(np.int32))
                 res = ctx.finish()
                 what = (k, cutoff, nb, stage, limit)
-                assert (res.nrefs > 0) == (stage == 0), what
-                if stage == 0:
+                by_refs = (stage == 0 and ctx.w.smer_stride // 4 <= 7)        # (wider super-mer records, k from 61: no LDS
+                assert (res.nrefs > 0) == by_refs, what                       #  de-duplication, hence no references)
+                if by_refs:
                     assert res.ndistinct_super <= res.nrefs <= res.nweighted, what
                 assert res.ninst == exp.ninst, what
                 assert np.array_equal(res.hist, exp.hist) and res.max_inst == exp.max_inst, what
