@@ -220,7 +220,14 @@ int fkx_event_get(int device, bool timing, hipEvent_t *e)
 void fkx_event_put(int device, bool timing, hipEvent_t *e)
 { if (e == NULL || *e == NULL)
     return;
-  (void) hipEventSynchronize(*e);                    // (what goes into the pool is complete; never recorded: returns at once)
+  // What goes into the pool is complete (never recorded counts as complete).  An event that is still pending -- only on
+  // an error path: a stream that waits for a peer that has died -- is neither waited for (hipEventDestroy never blocked
+  // either, and the caller is on its way out) nor destroyed: its handle is dropped, the object stays alive.
+  if (hipEventQuery(*e) != hipSuccess)
+    { (void) hipGetLastError();
+      *e = NULL;
+      return;
+    }
   fk_pooled_event p; p.device = device; p.timing = timing; p.ev = *e;
   pthread_mutex_lock(&g_stream_lock);
   g_event_pool.push_back(p);

@@ -380,7 +380,8 @@ int  fkx_stream_get(int device, hipStream_t *s);
 void fkx_stream_put(int device, hipStream_t s);
 // Events likewise (round 6): the same runtime, the same class of object -- no hipEventDestroy anywhere in the library.
 // An event comes from a process-wide pool (one list per device and kind: with timing / hipEventDisableTiming) and goes
-// back complete (fkx_event_put waits for it); a pointer that is NULL is skipped and the caller's copy is cleared.
+// back when it is complete (fkx_event_put asks, it does not wait: a pending one is dropped alive); a pointer that is
+// NULL is skipped and the caller's copy is cleared.
 int  fkx_event_get(int device, bool timing, hipEvent_t *e);
 void fkx_event_put(int device, bool timing, hipEvent_t *e);
 int fkx_pinned_alloc(void **out, int64_t bytes);     // large buffers: huge pages touched in parallel + hipHostRegister

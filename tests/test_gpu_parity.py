@@ -3126,3 +3126,54 @@ def test_kmer_stage_below_32_keeps_the_hashed_grouping():
         res = ctx.finish()
         assert res.nrefs == 0
         assert np.array_equal(res.hist, exp.hist) and np.array_equal(res.table, exp.table)
+
+
+def _device_count():
+    import ctypes
+    for name in ("libamdhip64.so", "libamdhip64.so.7", "libamdhip64.so.6"):
+        try:
+            lib = ctypes.CDLL(name)
+        except OSError:
+            continue
+        n = ctypes.c_int(0)
+        if lib.hipGetDeviceCount(ctypes.byref(n)) == 0:
+            return n.value
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.parametrize("ranks,opts,name,fmt", [(2, [], "synth_hifi_k40_t4_T8", "fasta"), (2, ["-p"], "synth_illumina_k51_t1_T4", "fastq"),
+                                                 (4, [], "configs0_k40_t1_T4", "fastq"), (8, ["-M2"], "configs0_k40_t1_T4", "fastq")])
+def test_c_driver_sharded_on_distinct_devices(ranks, opts, name, fmt, tmp_path):
+    """FastK_amd -G<n> with every rank on a DEVICE OF ITS OWN (device = local rank, RCCL's peer-to-peer transports over
+    xGMI): what no box of this pool can run -- they have one GPU, where the -G tests let the ranks share it over RCCL's
+    socket transport -- and what the driver's 8-GPU node runs before its scaling bench does.
+    Skipped below `ranks` devices.  Every file byte-identical to the one-GPU run with the same -T, .hist and canonical
+    .ktab stream the REFERENCE's (golden digests), decoded profiles the reference's where -p is given."""
+    import os, subprocess
+    ndev = _device_count()
+    if ndev < ranks:
+        pytest.skip("%d device(s) here; the test needs %d" % (ndev, ranks))
+    case, bases, boff = util.load_case(name)
+    exp = case["expected"]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "fastk_amd", "bin", "FastK_amd")
+    path = str(tmp_path / ("reads." + fmt))
+    util.write_fastx(path, bases, boff, fmt == "fastq")
+    T = 8
+    args = ["-k%d" % case["k"], "-t%d" % case["cutoff"], "-T%d" % T] + opts
+    one, many = tmp_path / "one", tmp_path / "many"
+    one.mkdir(); many.mkdir()
+    subprocess.run([exe] + [a for a in args if not a.startswith("-M")] + ["-N" + str(one / "x"), path], check=True)
+    env = {k: v for k, v in os.environ.items() if k != "FK_RANKS_SHARE_GPU"}
+    p = subprocess.run([exe] + args + ["-v", "-G%d" % ranks, "-N" + str(many / "x"), path], env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    assert util.sha_file(many / "x.hist") == exp["hist_sha256"]
+    t = orc.read_ktab(str(many / "x"))
+    assert t["stream_sha256"] == exp["ktab"]["stream_sha256"] and t["nels"] == exp["ktab"]["nels"]
+    for f in sorted(os.listdir(one)):
+        if "ktab" in f or f.endswith(".hist"):
+            assert util.sha_file(one / f) == util.sha_file(many / f), f
+    if "-p" in opts:
+        assert _prof_stream(one, "x") == _prof_stream(many, "x")
