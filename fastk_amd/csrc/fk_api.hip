@@ -467,7 +467,6 @@ extern "C" int fk_create(const fk_params *p, fk_ctx **out)
   CK(hipMalloc((void **) &ctx->d_scratch, 65536));
   CK(hipHostMalloc((void **) &ctx->h_scratch, 65536 + 32 * 256 * 8, hipHostMallocDefault));
   CK(hipMalloc((void **) &ctx->d_digit_hist, 32 * 256 * sizeof(u64)));
-  CK(hipMalloc((void **) &ctx->d_ticket, 64 * sizeof(u32)));
   if (ctx->prm.hbm_budget > 0 && !ctx->prm.exact_parts)
     ctx->chunk_bytes = std::min<int64_t>(std::max<int64_t>(ctx->prm.hbm_budget / 32, 64ll << 20), 2ll << 30);
   if (ctx->prm.hbm_budget > 0)
@@ -512,7 +511,7 @@ extern "C" void fk_destroy(fk_ctx *ctx)
   hipFree(ctx->d_mbucket); hipFree(ctx->d_mbucket_pass); hipFree(ctx->d_scratch); hipFree(ctx->d_cursors); hipFree(ctx->d_plan);
   if (ctx->h_mbucket_pass) hipHostFree(ctx->h_mbucket_pass);
   if (ctx->h_scratch) hipHostFree(ctx->h_scratch);
-  hipFree(ctx->d_digit_hist); hipFree(ctx->d_status); hipFree(ctx->d_ticket);
+  hipFree(ctx->d_digit_hist);
   hipFree(ctx->d_reads);
   hipFree(ctx->d_reads_alt);
   for (int i = 0; i < 2; i++)
@@ -688,24 +687,14 @@ extern "C" int fk_debug_set(fk_ctx *ctx, const char *key, int64_t value)
           return (FK_EUNSUPPORTED);
         }
     }
+  if (strcmp(key, "radix_variant") == 0 || strcmp(key, "radix_items") == 0 || (strcmp(key, "radix_engine") == 0 && value == 1))
+    { fk_set_error(ctx, "fk_debug_set(%s): the look-back radix engine and its ablated variants were removed in round 6", key);
+      return (FK_EUNSUPPORTED);
+    }
 #ifdef FK_ABLATION
-  if (strcmp(key, "radix_variant") == 0)   // ablated look-back kernels: WRONG output, isolates one cost each
-    { ctx->dbg_radix_variant = (int) value;
-      return (FK_OK);
-    }
-  if (strcmp(key, "radix_items") == 0)
-    { ctx->dbg_radix_items = (int) value;
-      return (FK_OK);
-    }
   if (strcmp(key, "scatter_abl") == 0)     // ablated stream-engine scatters: WRONG output (tools/scatter_ablation.py)
     { ctx->dbg_scatter_abl = (int) value;
       return (FK_OK);
-    }
-#else
-  if (strcmp(key, "radix_variant") == 0 || strcmp(key, "radix_items") == 0 || (strcmp(key, "radix_engine") == 0 && value == 1))
-    { fk_set_error(ctx, "fk_debug_set(%s): the look-back radix engine and its ablations are only in builds made with "
-                        "-DFK_ABLATION (make -C fastk_amd/csrc ABLATION=1)", key);
-      return (FK_EUNSUPPORTED);
     }
 #endif
   if (strcmp(key, "radix_engine") == 0)    // 2 / 3: narrow / wide stream tiles whatever the width, 4: stable first pass

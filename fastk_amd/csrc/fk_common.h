@@ -120,9 +120,6 @@ struct fk_ctx
 
   // radix sort workspace
   u64       *d_digit_hist; // [32*256]
-  u64       *d_status;     // look-back status words
-  int64_t    status_cap;   // in u64 words
-  u32       *d_ticket;     // [64] tile tickets
   fk_sort_stats sort_stats;
   u64        rx_attr_done; // wide scatter instantiations whose dynamic-LDS attribute is set on this context's device
   int        rx_top_pbytes;// fkx_lsd_sort_top: leading bytes the records are in order on afterwards
@@ -209,12 +206,11 @@ struct fk_ctx
 
   // HBM arena: one cached allocation per purpose, grown on demand and kept until fk_destroy,
   // so that a repeated workload performs no hipMalloc/hipFree inside the hot path
-  int        dbg_radix_variant;   // measurement aids, see fk_debug_set
-  int        dbg_radix_items;
+  // measurement aids, see fk_debug_set
   int        dbg_exact_segments;  // -1: the exact splitter keeps one thread per read (no segments inside long reads)
   int        dbg_exact_chain;     // 1..5: the exact splitter keeps that many entries of its minimizer chain (tests: the ring walk behind it)
   int        dbg_scatter_abl;     // -DFK_ABLATION builds: RX_ABL_* bits of the stream engine's scatter kernels (fk_radix.hip)
-  int        dbg_radix_engine;    // 1 = look-back engine instead of the stream engine
+  int        dbg_radix_engine;    // 2 / 3: narrow / wide stream tiles whatever the record width; 4: stable first pass; 5: no carried digit
   int        dbg_kmer_stage;      // 1 = sort-collapse-sort k-mer stage instead of hash aggregation
   int        dbg_verbose;
   int        dbg_no_replay;       // 1: multi-pass split without entry replay

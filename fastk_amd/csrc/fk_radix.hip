@@ -12,9 +12,9 @@
 // of the records (2*n*R bytes) plus 2n bytes of digit stream.  Every pass is stable, so LSD order over a
 // byte list reproduces LSD_Sort bit for bit.
 //
-// The first engine -- ONE kernel per pass with decoupled look-back over status words, and seven ablated
-// VARIANTs of it whose output is wrong on purpose -- is measurement ballast: it is only compiled with
-// -DFK_ABLATION (make ABLATION=1) and is not part of the shipped library.
+// (The first engine -- ONE kernel per pass with decoupled look-back over status words, 2.3 TB/s against this one's
+// 4.5, and its ablated variants -- was deleted in round 6; DESIGN.md section 4 keeps what was learnt from it.  -DFK_ABLATION
+// (make ABLATION=1) still builds the scatter kernels' own ablation bits, RX_ABL_*, for tools/scatter_ablation.py.)
 #include "fk_common.h"
 #include <type_traits>
 
@@ -113,229 +113,6 @@ __global__ __launch_bounds__(RX_THREADS) void k_digit_hist(const u32 *__restrict
     if (h[i] != 0)
       atomicAdd(&out[i], (u64) h[i]);
 }
-
-#ifdef FK_ABLATION
-// ---------------------------------------------------------------------------------------------
-// one stable 8-bit digit pass
-// VARIANT is a measurement aid (fk_debug_set "radix_variant"); only 0 produces a sorted result:
-//   1 = no look-back (offsets interpolated from the global histogram: real store pattern, no waits)
-//   2 = no ranking, no look-back (tile streamed through LDS, linear store)
-//   3 = real ranking and LDS permutation, no look-back, linear store
-//   4 = as 1, but every XCD works on one contiguous range of tiles (L2 write-combining test)
-template <int RW, int ITEMS, int VARIANT, bool HASHED>
-__global__ __launch_bounds__(RX_THREADS) void k_radix_pass(const u32 *__restrict__ src,
-                                                           u32 *__restrict__ dst, int64_t n,
-                                                           int byte_idx,
-                                                           const u64 *__restrict__ ghist,
-                                                           u64 *status, u32 *ticket, u32 epoch)
-{ constexpr int TILE = RX_THREADS * ITEMS;
-
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  u32      *recs     = (u32 *) smem;                                   // TILE*RW, never reordered
-  int64_t  *goff     = (int64_t *) (smem + (size_t) TILE * RW * 4);    // 256
-  u64      *tmp64    = (u64 *) (goff + 256);                           // 8
-  u32      *whist    = (u32 *) (tmp64 + 8);                            // 4*256
-  u32      *binstart = whist + RX_WAVES * 256;                         // 256
-  u32      *tmp32    = binstart + 256;                                 // 8
-  u32      *s_tile   = tmp32 + 8;                                      // 4 (keeps perm 16-B aligned)
-  uint16_t *perm     = (uint16_t *) (s_tile + 4);                      // TILE: sorted slot -> record
-  u32      *perm32   = (u32 *) (s_tile + 4);                           // HASHED: record | digit << 16
-
-  const int tid  = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-
-  if (tid == 0)
-    { if (VARIANT == 4)
-        { // measurement: XCD x (= blockIdx % 8, observed dispatch) takes a contiguous range of tiles
-          const u32 per = (gridDim.x + 7) / 8;
-          *s_tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-        }
-      else
-        *s_tile = atomicAdd(ticket, 1u);
-    }
-  for (int i = tid; i < RX_WAVES * 256; i += RX_THREADS)
-    whist[i] = 0;
-  __syncthreads();
-
-  const u32     tile   = *s_tile;
-  if (VARIANT == 4 && tile >= gridDim.x)
-    return;
-  const int64_t tstart = (int64_t) tile * TILE;
-  const int     tn     = (n - tstart < TILE) ? (int) (n - tstart) : TILE;
-  const int     ndw    = tn * RW;
-
-  { const u32   *gsrc = src + tstart * RW;
-    const uint4 *g4   = (const uint4 *) gsrc;
-    uint4       *l4   = (uint4 *) recs;
-    if (tn == TILE)
-      { // full tile: every 16-byte load is issued before the first LDS write, so the workgroup
-        // keeps its whole tile in flight instead of one load per thread at a time
-        static_assert((ITEMS * RW) % 4 == 0, "tile must be a whole number of 16-byte loads per thread");
-        constexpr int NV = ITEMS * RW / 4;
-        uint4 v[NV];
-#pragma unroll
-        for (int k = 0; k < NV; k++)
-          v[k] = g4[tid + k * RX_THREADS];
-#pragma unroll
-        for (int k = 0; k < NV; k++)
-          l4[tid + k * RX_THREADS] = v[k];
-      }
-    else
-      { const int n4 = ndw >> 2;
-        for (int i = tid; i < n4; i += RX_THREADS)
-          l4[i] = g4[i];
-        for (int i = (n4 << 2) + tid; i < ndw; i += RX_THREADS)
-          recs[i] = gsrc[i];
-      }
-  }
-  __syncthreads();
-
-  const int  wbase = wave * 64 * ITEMS;
-  const u64  lt    = fk_lanemask_lt();
-  const unsigned char *lbytes = (const unsigned char *) smem;
-
-  // (a) digit of each record, its match mask inside the wave, and ONE LDS atomic per distinct
-  //     digit per item.  The atomics are issued back to back without waiting for their results:
-  //     a wave's LDS operations execute in order, so item i sees the counts of items < i and the
-  //     ranks are stable.  info = d | below << 8 | leader << 16
-  u32 info[ITEMS];
-  u32 old[ITEMS];
-#pragma unroll
-  for (int it = 0; it < ITEMS; it++)
-    { const int  r     = wbase + it * 64 + lane;
-      const bool valid = (r < tn);
-      u32 d = !valid ? 0u : HASHED ? rx_hash_digit<RW>(recs + r * RW, byte_idx, RW * 4)
-                                   : (u32) lbytes[r * RW * 4 + byte_idx];
-      if (VARIANT == 5) d &= 0x7fu;          // measurement: 128 / 64 bins (longer runs per bin)
-      if (VARIANT == 6) d &= 0x3fu;
-      u64 mask = __ballot(valid);
-#pragma unroll
-      for (int b = 0; b < 8; b++)
-        { const bool bit = (d >> b) & 1u;
-          const u64  bm  = __ballot(bit);
-          mask &= bit ? bm : ~bm;
-        }
-      const u32 below  = (u32) __popcll(mask & lt);
-      const u32 leader = valid ? (u32) (__ffsll((unsigned long long) mask) - 1) : (u32) lane;
-      info[it] = d | (below << 8) | (leader << 16);
-      old[it] = 0;
-      if (VARIANT != 2 && valid && below == 0)
-        old[it] = atomicAdd(&whist[wave * 256 + d], (u32) __popcll(mask));
-    }
-  if (VARIANT != 2)
-    {
-      // (c) the leader's base reaches the other lanes of its digit through the LDS crossbar
-#pragma unroll
-      for (int it = 0; it < ITEMS; it++)
-        { const u32 e    = info[it];
-          const u32 base = (u32) __shfl((int) old[it], (int) ((e >> 16) & 0xffu), 64);
-          info[it] = (e & 0xffu) | ((base + ((e >> 8) & 0xffu)) << 8);     // d | rank-in-wave << 8
-        }
-    }
-  __syncthreads();
-
-  // digit `tid`: exclusive prefix over the waves, tile total, bin start, global offset
-  { u32 run = 0;
-#pragma unroll
-    for (int w = 0; w < RX_WAVES; w++)
-      { const u32 t = whist[w * 256 + tid];
-        whist[w * 256 + tid] = run;
-        run += t;
-      }
-    const u32 total = run;
-    u32 tsum;
-    const u32 bstart = fk_block_exscan_256<u32>(total, tmp32, &tsum);
-    u64 gsum;
-    const u64 gcnt   = ghist[tid];
-    const u64 gbase  = fk_block_exscan_256<u64>(gcnt, tmp64, &gsum);
-    binstart[tid] = bstart;
-
-    u64 excl = 0;
-    if (VARIANT == 1 || VARIANT >= 4)
-      { excl = (gcnt * (u64) tile) / (u64) gridDim.x;
-        if (excl + total > gcnt) excl = (gcnt > total) ? gcnt - total : 0;
-      }
-    else if (VARIANT != 0)
-      excl = 0;
-    else if (tile == 0)
-      __hip_atomic_store(&status[tid], st_pack(epoch, ST_PFX, total), __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
-    else
-      { u64 *mine = status + (size_t) tile * 256 + tid;
-        __hip_atomic_store(mine, st_pack(epoch, ST_AGG, total), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-        int64_t look = (int64_t) tile - 1;
-        while (true)
-          { const u64 s = __hip_atomic_load(status + (size_t) look * 256 + tid, __ATOMIC_RELAXED,
-                                            __HIP_MEMORY_SCOPE_AGENT);
-            const u64 flag = (s >> 54) & 3ull;
-            if ((u32) (s >> 56) != epoch || flag == 0)
-              { __builtin_amdgcn_s_sleep(1);
-                continue;
-              }
-            excl += (s & ST_VAL);
-            if (flag == ST_PFX)
-              break;
-            look -= 1;
-          }
-        __hip_atomic_store(mine, st_pack(epoch, ST_PFX, excl + total), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-      }
-    goff[tid] = (int64_t) (gbase + excl) - (int64_t) bstart;
-  }
-  __syncthreads();
-
-  // sorted slot -> source record (the records themselves stay where the load put them)
-#pragma unroll
-  for (int it = 0; it < ITEMS; it++)
-    { const int r = wbase + it * 64 + lane;
-      if (r < tn)
-        { const u32 e   = info[it];
-          const u32 d   = e & 0xffu;
-          const u32 pos = (VARIANT == 2) ? (u32) r : binstart[d] + whist[wave * 256 + d] + (e >> 8);
-          if (HASHED)
-            perm32[pos] = (u32) r | (d << 16);
-          else
-            perm[pos] = (uint16_t) r;
-        }
-    }
-  __syncthreads();
-
-  // every bin's run leaves as consecutive dwords
-#pragma unroll 4
-  for (int j = tid; j < ndw; j += RX_THREADS)
-    { const int p   = j / RW;
-      const int w   = j - p * RW;
-      int sr;
-      u32 d;
-      if (HASHED)
-        { const u32 e = perm32[p];
-          sr = (int) (e & 0xffffu);
-          d  = e >> 16;
-        }
-      else
-        { sr = perm[p];
-          d  = lbytes[sr * RW * 4 + byte_idx];
-          if (VARIANT == 5) d &= 0x7fu;
-          if (VARIANT == 6) d &= 0x3fu;
-        }
-      int64_t g = (goff[d] + p) * RW + w;
-      if (VARIANT == 2 || VARIANT == 3)
-        g = (tstart + p) * RW + w;
-      if (VARIANT == 7)
-        { // measurement: same 256 short runs, but shuffled inside the tile's own 36 KB window
-          int q = (int) (((d * 37u) & 255u) * (u32) ITEMS) + (p - (int) binstart[d]);
-          if (q >= tn) q = tn - 1;
-          g = (tstart + q) * RW + w;
-        }
-      if ((VARIANT == 1 || VARIANT >= 4) && (g < 0 || g >= n * RW))
-        g = (tstart + p) * RW + w;
-      dst[g] = recs[sr * RW + w];
-    }
-}
-
-#endif   // FK_ABLATION
 
 // =============================================================================================
 // Dependency-free digit pass ("stream" engine, the default).
@@ -949,112 +726,6 @@ template <int RW, int ITEMS> static size_t rx_stream_lds_bytes()
           + 8 * 4 + 16 + (size_t) RX_THREADS * ITEMS * 3 + 16);
 }
 
-#ifdef FK_ABLATION
-// hashed: bytes[] index the record hash (rx_hash_digit) instead of the record itself
-template <int RW, int ITEMS, bool HASHED>
-static int lsd_sort_t(fk_ctx *ctx, int64_t n, void *d_src, void *d_trg, const int *bytes,
-                      int nbytes, void **result)
-{ constexpr int TILE = RX_THREADS * ITEMS;
-  const int64_t ntiles = (n + TILE - 1) / TILE;
-  hipStream_t   s = ctx->stream;
-  u32 want = 0;
-
-  ctx->sort_stats.passes = 0;
-  ctx->sort_stats.nelem  = n;
-  ctx->sort_stats.rsize  = RW * 4;
-  ctx->sort_stats.pass_ms_total = 0.;
-  ctx->sort_stats.hist_ms = 0.;
-  *result = d_src;
-  if (n == 0 || nbytes == 0)
-    return (FK_OK);
-  if (nbytes > 60)
-    { fk_set_error(ctx, "too many key bytes (%d)", nbytes);
-      return (FK_EINVAL);
-    }
-  for (int i = 0; i < nbytes; i++)
-    { if (bytes[i] < 0 || bytes[i] >= (HASHED ? 8 : RW * 4))
-        { fk_set_error(ctx, "key byte %d outside record of %d bytes", bytes[i], RW * 4);
-          return (FK_EINVAL);
-        }
-      want |= (1u << bytes[i]);
-    }
-
-  if (ntiles * 256 > ctx->status_cap)
-    { if (ctx->d_status != NULL)
-        FK_HIP(ctx, hipFree(ctx->d_status));
-      ctx->d_status = NULL;
-      ctx->status_cap = 0;
-      FK_HIP(ctx, hipMalloc((void **) &ctx->d_status, (size_t) ntiles * 256 * 8));
-      ctx->status_cap = ntiles * 256;
-    }
-  FK_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, (size_t) ntiles * 256 * 8, s));
-  FK_HIP(ctx, hipMemsetAsync(ctx->d_ticket, 0, 64 * sizeof(u32), s));
-  FK_HIP(ctx, hipMemsetAsync(ctx->d_digit_hist, 0, 32 * 256 * sizeof(u64), s));
-
-  FK_HIP(ctx, hipEventRecord(ctx->ev0, s));
-  { int64_t nb = (n + RX_THREADS - 1) / RX_THREADS;
-    if (nb > 1024) nb = 1024;
-    if (HASHED)
-      hipLaunchKernelGGL(k_hash_hist<RW>, dim3((unsigned) nb), dim3(RX_THREADS), 0, s,
-                         (const u32 *) d_src, n, 8, ctx->d_digit_hist, (uint8_t *) NULL, 0, RW * 4);
-    else
-      hipLaunchKernelGGL(k_digit_hist<RW>, dim3((unsigned) nb), dim3(RX_THREADS), 0, s,
-                         (const u32 *) d_src, n, want, ctx->d_digit_hist, (uint8_t *) NULL, 0);
-    FK_LAUNCH_CHECK(ctx);
-  }
-  FK_HIP(ctx, hipEventRecord(ctx->ev1, s));
-  FK_HIP(ctx, hipMemcpyAsync(ctx->h_scratch, ctx->d_digit_hist, (size_t) (HASHED ? 8 : RW * 4) * 256 * 8,
-                             hipMemcpyDeviceToHost, s));
-  FK_HIP(ctx, hipStreamSynchronize(s));
-  { float ms = 0.f;
-    FK_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-    ctx->sort_stats.hist_ms = ms;
-  }
-
-  const size_t lds_bytes = rx_lds_bytes<RW, ITEMS>(HASHED);
-  u32 *src = (u32 *) d_src, *trg = (u32 *) d_trg;
-  int  passes = 0;
-  FK_HIP(ctx, hipEventRecord(ctx->ev0, s));
-  for (int i = 0; i < nbytes; i++)
-    { const u64 *h = ctx->h_scratch + (size_t) bytes[i] * 256;
-      bool constant = false;
-      for (int x = 0; x < 256; x++)
-        if (h[x] == (u64) n)
-          constant = true;
-      if (constant)
-        continue;        // every record carries the same digit: the pass is the identity
-#define RX_LAUNCH(V)                                                                              \
-      hipLaunchKernelGGL((k_radix_pass<RW, ITEMS, V, HASHED>), dim3((unsigned) ntiles), dim3(RX_THREADS), \
-                         lds_bytes, s, (const u32 *) src, trg, n, bytes[i],                         \
-                         (const u64 *) (ctx->d_digit_hist + (size_t) bytes[i] * 256),               \
-                         ctx->d_status, ctx->d_ticket + passes, (u32) (passes + 1))
-      if (ctx->dbg_radix_variant == 1) RX_LAUNCH(1);
-      else if (ctx->dbg_radix_variant == 2) RX_LAUNCH(2);
-      else if (ctx->dbg_radix_variant == 3) RX_LAUNCH(3);
-      else if (ctx->dbg_radix_variant == 4) RX_LAUNCH(4);
-      else if (ctx->dbg_radix_variant == 5) RX_LAUNCH(5);
-      else if (ctx->dbg_radix_variant == 6) RX_LAUNCH(6);
-      else if (ctx->dbg_radix_variant == 7) RX_LAUNCH(7);
-      else RX_LAUNCH(0);
-#undef RX_LAUNCH
-      FK_LAUNCH_CHECK(ctx);
-      passes += 1;
-      u32 *t = src; src = trg; trg = t;
-    }
-  FK_HIP(ctx, hipEventRecord(ctx->ev1, s));
-  FK_HIP(ctx, hipStreamSynchronize(s));
-  { float ms = 0.f;
-    FK_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-    ctx->sort_stats.pass_ms_total = ms;
-    ctx->sort_stats.scatter_ms_total = ms;
-    ctx->sort_stats.passes = passes;
-  }
-  *result = (void *) src;
-  return (FK_OK);
-}
-
-#endif   // FK_ABLATION
-
 // top > 0 (the MSD engine, fk_tsort.hip): of the non-constant digits only the `top` most significant -- the last
 // `top` of bytes[] -- are passes; ctx->rx_top_pbytes = bytes the records are then in order on.
 template <int RW, int ITEMS, bool HASHED, int WT>
@@ -1276,31 +947,14 @@ static int sort_dispatch(fk_ctx *ctx, int64_t nelem, void *d_src, void *d_trg, i
   // wide (1024-thread, persistent) tiles pay off for records of 16 bytes and more; narrower records
   // are bound by instruction issue, not by the write pattern, and do better with 4 workgroups per CU
   const bool narrow = (ctx->dbg_radix_engine == 2) || (rsize < 16 && ctx->dbg_radix_engine != 3);
-#ifdef FK_ABLATION
-  const int it = ctx->dbg_radix_items;      // measurement aid: alternative tile sizes for R = 12, 20
-  const bool lookback = (ctx->dbg_radix_engine == 1 || ctx->dbg_radix_variant != 0 || it != 0);
-#define RX_CASE(RW) return (lookback ? lsd_sort_t<RW, RxCfg<RW>::ITEMS, HASHED>(ctx, nelem, d_src, d_trg, bytes, nbytes, result) \
-                     : narrow ? lsd_sort_stream_t<RW, RxCfg<RW>::ITEMS, HASHED, RX_THREADS>(ctx, nelem, d_src, d_trg, bytes, nbytes, result, hbytes, top) \
-                              : lsd_sort_stream_t<RW, RxCfgW<RW>::ITEMS, HASHED, RXW_THREADS>(ctx, nelem, d_src, d_trg, bytes, nbytes, result, hbytes, top))
-#else
 #define RX_CASE(RW) return (narrow ? lsd_sort_stream_t<RW, RxCfg<RW>::ITEMS, HASHED, RX_THREADS>(ctx, nelem, d_src, d_trg, bytes, nbytes, result, hbytes, top) \
                                    : lsd_sort_stream_t<RW, RxCfgW<RW>::ITEMS, HASHED, RXW_THREADS>(ctx, nelem, d_src, d_trg, bytes, nbytes, result, hbytes, top))
-#endif
   switch (rsize >> 2)
   { case 1: RX_CASE(1);
     case 2: RX_CASE(2);
-    case 3:
-#ifdef FK_ABLATION
-      if (!HASHED && it == 8)  return lsd_sort_t<3, 8, HASHED>(ctx, nelem, d_src, d_trg, bytes, nbytes, result);
-      if (!HASHED && it == 16) return lsd_sort_t<3, 16, HASHED>(ctx, nelem, d_src, d_trg, bytes, nbytes, result);
-#endif
-      RX_CASE(3);
+    case 3: RX_CASE(3);
     case 4: RX_CASE(4);
-    case 5:
-#ifdef FK_ABLATION
-      if (!HASHED && it == 16) return lsd_sort_t<5, 12, HASHED>(ctx, nelem, d_src, d_trg, bytes, nbytes, result);
-#endif
-      RX_CASE(5);
+    case 5: RX_CASE(5);
     case 6: RX_CASE(6);
     case 7: RX_CASE(7);
     default: RX_CASE(8);
@@ -1329,13 +983,6 @@ int fkx_group(fk_ctx *ctx, int64_t nelem, void *d_src, void *d_trg, int rsize, i
 { static const int bytes[8] = { 0, 1, 2, 3, 4, 5, 6, 7 };
   if (npasses < 1 || npasses > 8 || key_bytes < 1 || key_bytes > rsize)
     return (FK_EINVAL);
-#ifdef FK_ABLATION
-  const bool lookback = (ctx->dbg_radix_engine == 1 || ctx->dbg_radix_variant != 0 || ctx->dbg_radix_items != 0);
-  if (lookback && key_bytes != rsize)
-    { fk_set_error(ctx, "the look-back engine hashes whole records only");
-      return (FK_EUNSUPPORTED);
-    }
-#endif
   return sort_dispatch<true>(ctx, nelem, d_src, d_trg, rsize, bytes, npasses, result, key_bytes);
 }
 
