@@ -1,7 +1,12 @@
 // fk_common.h -- shared declarations for the gfx950 k-mer counting library (internal).
 #pragma once
 
+#ifdef FK_HOST_EMU                     // tests/csrc/hip_emu.h: a kernel's source run on the CPU by the CPU tests (not shipped)
+#include "hip_emu.h"
+#else
 #include <hip/hip_runtime.h>
+#define FK_DYN_LDS(type, name) extern __shared__ type name[]
+#endif
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>

@@ -352,6 +352,7 @@ __global__ __launch_bounds__(EX_THREADS) void k_ex_expand(const u32 *__restrict_
   }
 }
 
+#ifndef FK_HOST_EMU      // (the CPU tests run the kernels above through tests/csrc/hip_emu.h; what follows talks to the HIP runtime)
 // ---------------------------------------------------------------------------------------------
 template <int RW>
 static int expand_t(fk_ctx *ctx, const void *d_smers, int64_t n, void *d_out, int64_t cap,
@@ -553,3 +554,4 @@ int fkx_expand(fk_ctx *ctx, const void *d_smers, int64_t nsuper, void *d_out, in
       return (FK_EUNSUPPORTED);
   }
 }
+#endif   // FK_HOST_EMU

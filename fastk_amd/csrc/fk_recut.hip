@@ -63,7 +63,7 @@ __global__ __launch_bounds__(RC_THREADS) void k_recut(const u32 *__restrict__ dd
 { constexpr int RS   = RW + 1;
   constexpr int PMAX = RcCfg<RW>::PMAX;
   constexpr int NMAX = RcCfg<RW>::NMAX;
-  extern __shared__ u32 rc_col[];                    // [rows][RC_THREADS]: the thread's window minima, by start
+  FK_DYN_LDS(u32, rc_col);                           // [rows][RC_THREADS]: the thread's window minima, by start
   __shared__ u64 stage[RC_STAGE];
   __shared__ u32 s_cnt;
   __shared__ u64 s_base;
@@ -251,6 +251,7 @@ __global__ __launch_bounds__(256) void k_ref_bounds(const u64 *__restrict__ refs
   bounds[f] = (b >= nref) ? W : rb_prefix(refs, koff, b);
 }
 
+#ifndef FK_HOST_EMU      // (the CPU tests run the kernels above through tests/csrc/hip_emu.h; what follows talks to the HIP runtime)
 // ---------------------------------------------------------------------------------------------------------------------
 bool fkx_recut_applies(const fk_ctx *ctx, int64_t nsx)
 { const int rw = ctx->wid.smer_stride >> 2;
@@ -339,3 +340,4 @@ int fkx_ref_count(fk_ctx *ctx, const u64 *d_refs, int64_t nref, u32 *d_tile_kmer
   FK_LAUNCH_CHECK(ctx);
   return (FK_OK);
 }
+#endif   // FK_HOST_EMU
