@@ -54,3 +54,26 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".c", ".cpp")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in text.replace("no CPU", ""), os.path.join(dirpath, f)
+
+
+def test_bench_roofline_record_of_the_reference_stage():
+    """bench.py's roofline object when no pass runs over the weighted k-mers (fk_result.nrefs > 0, round 6): the graded
+    kernel is the table sort's digit pass; figures checked on a synthetic result (no GPU involved)."""
+    import types
+    import bench
+    loc = types.SimpleNamespace(nrefs=2_786_531_096, ntable=3_000_010_434, passes_final=4, ms_scatter_final=70.7544,
+                                ms_pass_final=75.4956, launches_super=96, passes_super=2, nsuper=8_633_378_085,
+                                ms_scatter_super=191.07, ms_pass_super=202.68, launches_kmer=144, passes_kmer=3,
+                                ms_scatter_kmer=33.51, ms_pass_kmer=44.32, nweighted=22_204_340_673)
+    w = types.SimpleNamespace(kmer_word=12, smer_word=20)
+    r = bench.roofline_record(loc, w, 2, 5415.9, 5617.2)
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["traffic"] is None
+    assert r["launches_per_step"] == 4 and r["records_per_launch"] == loc.ntable
+    assert abs(r["achieved"] - 2.0 * loc.ntable * 12 * 4 / 70.7544e-3 / 1e9) < 1.0
+    assert abs(r["frac"] - r["achieved"] / 8000.0) < 1e-3 and 0.5 < r["frac"] < 0.52
+    assert r["kmer_grouping"]["launches_over_W"] == 0 and r["kmer_grouping"]["references"] == loc.nrefs
+    assert r["reference_sort"]["launches"] == 144 and r["supermer_pass"]["launches"] == 96
+    loc.nrefs = 0                                   # the hashed grouping: round 5's record
+    loc.ncollapsed = loc.ntable
+    r5 = bench.roofline_record(loc, w, 2, 5415.9, 5617.2)
+    assert "weighted k-mer records" in r5["kernel"] and r5["launches_per_step"] == 144
