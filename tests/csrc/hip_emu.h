@@ -140,6 +140,14 @@ static inline unsigned emu_brev32(unsigned x)
   return (__builtin_bswap32(x));
 }
 #define __builtin_bitreverse32 emu_brev32
+static inline unsigned __brev(unsigned x) { return (emu_brev32(x)); }
+static inline int __popc(unsigned x) { return (__builtin_popcount(x)); }
+static inline int __popcll(unsigned long long x) { return (__builtin_popcountll(x)); }
+static inline int __clz(int x) { return (x == 0 ? 32 : __builtin_clz((unsigned) x)); }
+static inline int __ffs(int x) { return (__builtin_ffs(x)); }
+static inline int __ffsll(long long x) { return (__builtin_ffsll(x)); }
+static inline unsigned __umulhi(unsigned a, unsigned b) { return ((unsigned) (((unsigned long long) a * b) >> 32)); }
+static inline unsigned atomicOr(unsigned *p, unsigned v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
 using std::min;
 using std::max;
 static inline unsigned min(unsigned a, int b) { return (a < (unsigned) b ? a : (unsigned) b); }
