@@ -6,6 +6,7 @@
 #else
 #include <hip/hip_runtime.h>
 #define FK_DYN_LDS(type, name) extern __shared__ type name[]
+#define FK_DYN_LDS_ALIGNED(type, name, al) extern __shared__ __attribute__((aligned(al))) type name[]
 #endif
 #include <stdint.h>
 #include <stdio.h>

@@ -315,7 +315,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_split(SplitArgs a)
   // per bucket: stream position of the tile's records (u64), records counted (u32), records placed (u32) -- sized
   // by the launch for the context's bucket count: with the 4 KB that 256 buckets take a CU holds six workgroups,
   // with the 768 bytes of 48 buckets seven
-  extern __shared__ __attribute__((aligned(8))) unsigned char sp_dyn[];
+  FK_DYN_LDS_ALIGNED(unsigned char, sp_dyn, 8);
   __shared__ u32      tmp32[8];
   __shared__ u32      nother, nother2;
   __shared__ u64      ebase;
@@ -1046,6 +1046,7 @@ __global__ __launch_bounds__(SP_CT) void k_split_compact(u32 *__restrict__ out, 
       }
 }
 
+#ifndef FK_HOST_EMU      // (host halves stay out of the CPU tests' build of the kernels, tests/csrc/hip_emu.h)
 // the cursors of the streamed emit: (256 buckets x 2^SP_LSTREAMS streams + 64 entry sub-regions), 4 KB apart
 static u64 *sp_cursors(fk_ctx *ctx)
 { if (ctx->d_cursors == NULL
@@ -1093,6 +1094,8 @@ static void sp_launch(SplitArgs a, int64_t ngrid, hipStream_t s)
     }
 }
 
+#endif   // FK_HOST_EMU
+
 // For every tile, where its walk through the two sorted lists of a packed read set begins: the first read whose last
 // position is not in front of the tile, the first invalid stretch that does not end in front of it (0xffffffff: none).
 // One thread per 64 consecutive tiles: a binary search finds the element for its first tile, the others follow by
@@ -1136,6 +1139,7 @@ __global__ __launch_bounds__(256) void k_pk_tidx(const int64_t *__restrict__ rof
   }
 }
 
+#ifndef FK_HOST_EMU
 // pk != NULL: the split kernels of `a` take packed reads; builds the tile index in its arena slot
 static int sp_packed_args(fk_ctx *ctx, SplitArgs &a, const fk_pkview *pk, int64_t ntiles)
 { a.roff = NULL; a.nreads = 0; a.inv = NULL; a.ninv = 0; a.tidx = NULL;
@@ -1640,3 +1644,4 @@ int fkx_split_planned(fk_ctx *ctx, const void *d_bases, int64_t nbytes, void *d_
   *ninst = t;
   return (FK_OK);
 }
+#endif   // FK_HOST_EMU

@@ -83,18 +83,18 @@ static inline void __syncthreads() { emu_g->all.wait(); }
 static inline void emu_wave_barrier() { emu_g->wave[threadIdx.x >> 6].wait(); }
 #define __builtin_amdgcn_wave_barrier emu_wave_barrier
 #define FK_DYN_LDS(type, name) type *name = (type *) emu_g->dyn_lds
+#define FK_DYN_LDS_ALIGNED(type, name, al) type *name = (type *) emu_g->dyn_lds
 
 template <typename T>
 static inline T __shfl_up(T x, unsigned o, int width = 64)
-{ (void) width;
-  static_assert(sizeof(T) <= 8, "shuffles of up to 64 bits");
+{ static_assert(sizeof(T) <= 8, "shuffles of up to 64 bits");
   const unsigned w = threadIdx.x >> 6, l = threadIdx.x & 63u;
   unsigned long long v = 0;
   memcpy(&v, &x, sizeof(T));
   emu_g->xchg[w][l] = v;
   emu_g->wave[w].wait();
   T y = x;
-  if (l >= o)
+  if ((l & (unsigned) (width - 1)) >= o)               /* (inside segments of `width` lanes) */
     { v = emu_g->xchg[w][l - o]; memcpy(&y, &v, sizeof(T)); }
   emu_g->wave[w].wait();
   return (y);
@@ -132,6 +132,16 @@ static inline unsigned __funnelshift_l(unsigned lo, unsigned hi, unsigned s)
 { s &= 31u; return (unsigned) (((((unsigned long long) hi) << 32) | lo) << s >> 32); }
 static inline unsigned __funnelshift_r(unsigned lo, unsigned hi, unsigned s)
 { s &= 31u; return (unsigned) ((((((unsigned long long) hi) << 32) | lo) >> s) & 0xffffffffull); }
+static inline unsigned __builtin_amdgcn_perm(unsigned s0, unsigned s1, unsigned sel)     /* v_perm_b32: bytes of {s0, s1} */
+{ const unsigned long long src = (((unsigned long long) s0) << 32) | s1;
+  unsigned r = 0;
+  for (int i = 0; i < 4; i++)
+    { const unsigned c = (sel >> (8 * i)) & 0xffu;
+      const unsigned b = (c < 8) ? (unsigned) ((src >> (8 * c)) & 0xffu) : (c == 12 ? 0u : (c > 12 ? 0xffu : 0u));
+      r |= b << (8 * i);
+    }
+  return (r);
+}
 static inline unsigned __umul24(unsigned a, unsigned b) { return ((a & 0xffffffu) * (b & 0xffffffu)); }
 static inline unsigned emu_brev32(unsigned x)
 { x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
@@ -147,6 +157,7 @@ static inline int __clz(int x) { return (x == 0 ? 32 : __builtin_clz((unsigned) 
 static inline int __ffs(int x) { return (__builtin_ffs(x)); }
 static inline int __ffsll(long long x) { return (__builtin_ffsll(x)); }
 static inline unsigned __umulhi(unsigned a, unsigned b) { return ((unsigned) (((unsigned long long) a * b) >> 32)); }
+static inline void __threadfence_block() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 static inline unsigned atomicOr(unsigned *p, unsigned v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
 using std::min;
 using std::max;
