@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void k_ag_bounds(const u32 *__restrict__ recs,
 
 // a value the optimiser cannot see through (keeps it from hoisting address arithmetic out of the bin loop and
 // spilling the results)
-__device__ __forceinline__ u32 ag_opaque(u32 x) { asm volatile("" : "+v"(x)); return (x); }
+__device__ __forceinline__ u32 ag_opaque(u32 x) { FK_OPAQUE(x); return (x); }
 
 // Cell of the counting sort (low 13 bits) and 12 further bits for step C2: a hash of the key made of full-rate 24-bit
 // multiplies (fk_rec_hash's 64-bit products are a quarter of the kernel's arithmetic).  It only spreads the k-mers of
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
 { constexpr int CAP = AgCfg<KW>::CAP;
   constexpr int NS  = AgCfg<KW>::NS;
   constexpr int SDW = AgCfg<KW>::SDW;
-  extern __shared__ uint4 ag_lds[];
+  FK_DYN_LDS(uint4, ag_lds);
   u32 *slot    = (u32 *) ag_lds;                           // [CAP][SDW] key + count, by sorted position
   u32 *cell    = slot + CAP * SDW;                         // [CAP / 2] cell counters -> offsets, 16 bits each
   u32 *lhist   = cell + CAP / 2;                           // [AG_HB]
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
   const u32 lane = fk_lane();
   // thread index that the optimiser cannot see through: used where a phase derives per-record addresses from it,
   // so that the 8 x 3 address registers are computed where they are used instead of being kept (spilled) all along
-#define AG_TID(t) u32 t = (u32) tid; asm volatile("" : "+v"(t))
+#define AG_TID(t) u32 t = (u32) tid; FK_OPAQUE(t)
 
   for (int i = tid; i < CAP / 2; i += AG_THREADS)
     cell[i] = 0;
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
                 const u32 d = min(ag_opaque((u32) tid) * 32u, nd - 1);
                 // (a plain load that the empty asm below keeps alive -- a volatile one becomes a FLAT load with
                 // system scope, and a flat load counts as an LDS operation too: LDS waits behind it sit out its trip)
-                asm volatile("" :: "v"(touch));                                // (the previous one has long arrived)
+                FK_KEEP(touch);                                // (the previous one has long arrived)
                 touch = recs[nx_beg * KW + d];
               }
           }
@@ -634,7 +634,7 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count(const u32 *__restrict__
       beg = nx_beg; end = nx_end;
     }
 #undef AG_ADVANCE
-  asm volatile("" :: "v"(touch));
+  FK_KEEP(touch);
 #undef AG_SCALAR64
 #undef AG_BOUNDS_OF
 #undef AG_TID
@@ -707,7 +707,7 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count2(const u32 *__restrict_
   constexpr int NS  = AgCfg<KW>::NS;
   constexpr int SDW = AgCfg<KW>::SDW;
   constexpr int HB  = AgCfg2<KW>::HB;
-  extern __shared__ uint4 ag_lds[];
+  FK_DYN_LDS(uint4, ag_lds);
   u32      *slot    = (u32 *) ag_lds;                      // [CAP][SDW] key + count, record j of thread t at j * 1024 + t
   uint16_t *head    = (uint16_t *) (slot + CAP * SDW);     // [CAP] cell -> a record of it; then lists of positions
   uint16_t *wl      = head + CAP;                          // [AG_WAVES][AG2_LCAP] the waves' lists of records to elect leaders for
@@ -721,7 +721,7 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count2(const u32 *__restrict_
   u32      *sh_ovf  = lcnt + AG_WAVES;                     // a list was full
   const int tid = threadIdx.x;
   const u32 lane = fk_lane();
-#define AG_TID(t) u32 t = (u32) tid; asm volatile("" : "+v"(t))
+#define AG_TID(t) u32 t = (u32) tid; FK_OPAQUE(t)
 
   for (int i = tid; i < HB; i += AG_THREADS)
     lhist[i] = 0;
@@ -1073,6 +1073,7 @@ __global__ __launch_bounds__(AG_THREADS) void k_ag_count2(const u32 *__restrict_
                               tw[hx[k]] = (uint16_t) P2[k];
                             }
                         }
+                      FK_EMU_WAVE_SYNC();        // (the wave's stores above are all done before its loads below: LDS operations of a wave execute in order)
 #pragma unroll
                       for (int k = 0; k < AG2_LCAP / 64; k++)
                         if ((act >> k) & 1u)

@@ -55,6 +55,23 @@ __global__ __launch_bounds__(256) void k_dd_bounds(const u32 *__restrict__ recs,
   bounds[b] = (u64) lo;
 }
 
+#ifdef FK_HOST_EMU
+// (tests/csrc/hip_emu.h: the four accesses below as plain C++ for the CPU tests; `base` / `addr` are byte offsets into the
+//  workgroup's dynamic LDS there, the overflow flag is reached through a pointer the kernel leaves)
+static u32 *emu_dd_flag;
+template <int SLOTS>
+static inline void dd_read_slots(u32 base, u32 slot, uint4 (&v)[4])
+{ const uint4 *t = (const uint4 *) ((const char *) emu_g->dyn_lds + base);
+  for (int i = 0; i < 4; i++) v[i] = t[(slot + i) & (SLOTS - 1)];
+}
+static inline void dd_write_slot(u32 addr, uint4 v) { *(uint4 *) ((char *) emu_g->dyn_lds + addr) = v; }
+template <int SLOTS>
+static inline void dd_read_slots_flag(u32 base, u32 slot, uint4 (&v)[4], u32 fldd_addr, u32 &flag)
+{ (void) fldd_addr; flag = *emu_dd_flag; dd_read_slots<SLOTS>(base, slot, v); }
+template <int SLOTS>
+static inline void dd_read_slots2_flag(u32 base, u32 slota, u32 slotb, uint4 (&va)[4], uint4 (&vb)[4], u32 fldd_addr, u32 &flag)
+{ (void) fldd_addr; flag = *emu_dd_flag; dd_read_slots<SLOTS>(base, slota, va); dd_read_slots<SLOTS>(base, slotb, vb); }
+#else
 // DD_P table slots starting at `slot` as DD_P single ds_read_b128: a slot's key and count word must
 // come from ONE LDS access (see k_dd_table); plain C++ loads of a uint4 may be split by the compiler
 // into a 96-bit and a 32-bit read, which lets a reader pair a stale key with a published count.
@@ -119,6 +136,8 @@ __device__ __forceinline__ void dd_read_slots2_flag(u32 base, u32 slota, u32 slo
                : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b0), "v"(b1), "v"(b2), "v"(b3), "v"(fldd_addr)
                : "memory");
 }
+
+#endif   // FK_HOST_EMU
 
 // The first of the DD_P slots just read that settles a probe: empty (kind 1), being written (2) or
 // holding this key's first three dwords (3); act = DD_P, kind 0 when none does.  Written without
@@ -189,13 +208,22 @@ __global__ __launch_bounds__(DD_THREADS) void k_dd_table(const u32 *__restrict__
                                                          int LIMIT, int gshift, u64 tcap)
 { constexpr int SLOTS = DdCfg<KW>::SLOTS;
   constexpr int U = DD_BATCH;
-  extern __shared__ uint4 dd_lds[];
+  FK_DYN_LDS(uint4, dd_lds);
   uint4 *A     = dd_lds;                                   // [SLOTS]
   // LDS byte address of the table for the inline-asm reads (low half of the flat address)
+#ifdef FK_HOST_EMU
+  const u32 lds_base = 0;
+#else
   const u32 lds_base = (u32) (uintptr_t) dd_lds;
+#endif
   uint4 *B     = dd_lds + SLOTS;                           // [SLOTS] when KW > 3
   __shared__ u32 sh_claimed, sh_ovf, sh_next, sh_tmp[DD_WAVES];
+#ifdef FK_HOST_EMU
+  const u32 ovf_addr = 0;
+  emu_dd_flag = &sh_ovf;
+#else
   const u32 ovf_addr = (u32) (uintptr_t) &sh_ovf;
+#endif
   __shared__ u64 sh_base;
   const int tid = threadIdx.x;
 
@@ -443,7 +471,7 @@ __global__ __launch_bounds__(DD_THREADS) void k_dd_table(const u32 *__restrict__
                             slot = s;                                // its key is being written: look again
                           else
                             slot = (slot + DD_P) & (SLOTS - 1);
-                          const u64 cm = __ballot(created);
+                          const u64 cm = FK_BALLOT_ACTIVE(created);      // (over the lanes still in this loop)
                           if (cm != 0ull && fk_lane() == (u32) (__ffsll((long long) cm) - 1))
                             { const u32 k = (u32) __popcll(cm);
                               if (atomicAdd(&sh_claimed, k) + k > (u32) LIMIT)

@@ -352,7 +352,7 @@ __global__ __launch_bounds__(EX_THREADS) void k_ex_expand(const u32 *__restrict_
   }
 }
 
-#ifndef FK_HOST_EMU      // (the CPU tests run the kernels above through tests/csrc/hip_emu.h; what follows talks to the HIP runtime)
+#if !defined(FK_HOST_EMU) || defined(FK_EMU_FULL)      // (the CPU tests run the kernels above through tests/csrc/hip_emu.h; what follows talks to the HIP runtime)
 // ---------------------------------------------------------------------------------------------
 template <int RW>
 static int expand_t(fk_ctx *ctx, const void *d_smers, int64_t n, void *d_out, int64_t cap,

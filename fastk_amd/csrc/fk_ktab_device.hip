@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void k_prefix_ends(const unsigned char *__rest
 #define KS_E 2048
 __global__ __launch_bounds__(256) void k_ktab_strip(const unsigned char *__restrict__ t, int64_t cnt, int stride, int ib, int kb,
                                                     u32 magic, unsigned char *__restrict__ out)
-{ extern __shared__ __attribute__((aligned(16))) unsigned char ks_lds[];      // KS_E * stride + 64 bytes
+{ FK_DYN_LDS_ALIGNED(unsigned char, ks_lds, 16);                             // KS_E * stride + 64 bytes
   const int     pw  = kb - ib + 2, tid = threadIdx.x;
   const int64_t e0  = (int64_t) blockIdx.x * KS_E;
   const int     ne  = (cnt - e0 < KS_E) ? (int) (cnt - e0) : KS_E;

@@ -256,7 +256,7 @@ __global__ __launch_bounds__(RX_THREADS) void k_rx_scatter(const u32 *__restrict
                                                            int64_t ntiles, int hbytes, int unstable)
 { constexpr int TILE = RX_THREADS * ITEMS;
 
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  FK_DYN_LDS_ALIGNED(unsigned char, smem, 16);
   u32      *recs     = (u32 *) smem;                                   // TILE*RW, never reordered
   int64_t  *goff     = (int64_t *) (smem + (size_t) TILE * RW * 4);    // 256
   u64      *tmp64    = (u64 *) (goff + 256);                           // 8
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(RXW_THREADS) void k_rx_scatter_w(const u32 *__restr
   constexpr int ND   = ITEMS / 4;
   static_assert((ITEMS * RW) % 4 == 0 && ITEMS % 4 == 0, "tile must split into 16-byte and 4-byte loads");
 
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  FK_DYN_LDS_ALIGNED(unsigned char, smem, 16);
   u32      *recs     = (u32 *) smem;                                   // TILE*RW, never reordered
   int64_t  *goff     = (int64_t *) (smem + (size_t) TILE * RW * 4);    // 256
   u32      *whist    = (u32 *) (goff + 256);                           // RXW_WAVES*256

@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void k_ref_bounds(const u64 *__restrict__ refs
   bounds[f] = (b >= nref) ? W : rb_prefix(refs, koff, b);
 }
 
-#ifndef FK_HOST_EMU      // (the CPU tests run the kernels above through tests/csrc/hip_emu.h; what follows talks to the HIP runtime)
+#if !defined(FK_HOST_EMU) || defined(FK_EMU_FULL)      // (the CPU tests run the kernels above through tests/csrc/hip_emu.h; what follows talks to the HIP runtime)
 // ---------------------------------------------------------------------------------------------------------------------
 bool fkx_recut_applies(const fk_ctx *ctx, int64_t nsx)
 { const int rw = ctx->wid.smer_stride >> 2;

@@ -1046,7 +1046,7 @@ __global__ __launch_bounds__(SP_CT) void k_split_compact(u32 *__restrict__ out, 
       }
 }
 
-#ifndef FK_HOST_EMU      // (host halves stay out of the CPU tests' build of the kernels, tests/csrc/hip_emu.h)
+#if !defined(FK_HOST_EMU) || defined(FK_EMU_FULL)      // (host halves stay out of the CPU tests' build of the kernels, tests/csrc/hip_emu.h)
 // the cursors of the streamed emit: (256 buckets x 2^SP_LSTREAMS streams + 64 entry sub-regions), 4 KB apart
 static u64 *sp_cursors(fk_ctx *ctx)
 { if (ctx->d_cursors == NULL
@@ -1139,7 +1139,7 @@ __global__ __launch_bounds__(256) void k_pk_tidx(const int64_t *__restrict__ rof
   }
 }
 
-#ifndef FK_HOST_EMU
+#if !defined(FK_HOST_EMU) || defined(FK_EMU_FULL)
 // pk != NULL: the split kernels of `a` take packed reads; builds the tile index in its arena slot
 static int sp_packed_args(fk_ctx *ctx, SplitArgs &a, const fk_pkview *pk, int64_t ntiles)
 { a.roff = NULL; a.nreads = 0; a.inv = NULL; a.ninv = 0; a.tidx = NULL;

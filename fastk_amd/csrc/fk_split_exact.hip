@@ -491,7 +491,7 @@ __global__ __launch_bounds__(256) void k_base_freq(const unsigned char *__restri
     atomicAdd(&out[threadIdx.x], (u64) h[threadIdx.x]);
 }
 
-#ifndef FK_HOST_EMU      // (host halves stay out of the CPU tests' build of the kernels, tests/csrc/hip_emu.h)
+#if !defined(FK_HOST_EMU) || defined(FK_EMU_FULL)      // (host halves stay out of the CPU tests' build of the kernels, tests/csrc/hip_emu.h)
 // Tran ranking as Determine_Scheme computes it (split.c:529-575), including its quirk: the per-thread
 // byte counts are summed INTO thread 0's own vector from j = 0 (split.c:536-539), so read stripe 0 of
 // the training block counts twice.  train_reads = reads of the first block (Get_First_Block).
@@ -568,7 +568,7 @@ __global__ __launch_bounds__(256) void k_xs_tilescan(const u32 *__restrict__ in,
 }
 
 // out[i] = in[0] + .. + in[i-1] for i < n, *total = the sum (a tile's sum must fit 32 bits: counts of records)
-#ifndef FK_HOST_EMU
+#if !defined(FK_HOST_EMU) || defined(FK_EMU_FULL)
 #define XS_OVF_WORD 2210          // d_scratch / h_scratch word: "a tile sum of xs_exscan did not fit 32 bits"
 static int xs_overflowed(fk_ctx *ctx)
 { if (ctx->h_scratch[XS_OVF_WORD] == 0)

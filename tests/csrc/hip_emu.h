@@ -55,6 +55,7 @@ static inline const char *hipGetErrorString(hipError_t) { return "emulated"; }
    arrived.  One at a time and in a fixed order: a run is deterministic, atomics need no hardware, and code that silently
    relies on the lanes of a wave moving in lockstep between two barriers fails the same way every time. */
 #include <ucontext.h>
+#include <pthread.h>
 #include <sys/mman.h>
 
 struct emu_fiber
@@ -111,6 +112,18 @@ static inline void __syncthreads()
   emu_yield();
 }
 
+static inline int __syncthreads_count(int pred)      /* the workgroup's barrier + how many work-items brought a true */
+{ static unsigned acc[2];
+  static unsigned gen;
+  emu_group *g = emu_g;
+  if (g->at_all == 0) acc[gen & 1] = 0;              /* the first to arrive */
+  const unsigned my = gen & 1;
+  acc[my] += pred ? 1u : 0u;
+  if (g->at_all + 1 == g->alive) gen += 1;           /* the last one turns the page before anybody goes on */
+  __syncthreads();
+  return ((int) acc[my]);
+}
+
 static inline void emu_wave_barrier()
 { emu_group *g = emu_g;
   const unsigned w = g->cur->tid >> 6;
@@ -122,6 +135,12 @@ static inline void emu_wave_barrier()
 #define __builtin_amdgcn_wave_barrier emu_wave_barrier
 #define FK_DYN_LDS(type, name) type *name = (type *) emu_g->dyn_lds
 #define FK_DYN_LDS_ALIGNED(type, name, al) type *name = (type *) emu_g->dyn_lds
+#define FK_OPAQUE(x) ((void) (x))
+#define FK_EMU_WAVE_SYNC() emu_wave_barrier()
+/* a ballot among the lanes the hardware's exec mask keeps in a divergent loop: here every lane sees itself alone (the one
+   use sums the set bits into a workgroup counter through the lowest set lane: the same total) */
+#define FK_BALLOT_ACTIVE(p) ((p) ? (1ull << (threadIdx.x & 63u)) : 0ull)
+#define FK_KEEP(x)   ((void) (x))
 
 template <typename T>
 static inline T __shfl_up(T x, unsigned o, int width = 64)
@@ -247,3 +266,114 @@ static inline unsigned atomicOr(unsigned *p, unsigned v) { return __atomic_fetch
 using std::min;
 using std::max;
 static inline unsigned min(unsigned a, int b) { return (a < (unsigned) b ? a : (unsigned) b); }
+
+/* ---- wave collectives (every lane of the wave takes part: the kernels call them in wave-uniform control flow) ------------ */
+template <typename T>
+static inline void emu_wave_gather(T x, T (&all)[64])
+{ static_assert(sizeof(T) <= 8, "up to 64 bits");
+  const unsigned w = threadIdx.x >> 6, l = threadIdx.x & 63u;
+  unsigned long long v = 0;
+  memcpy(&v, &x, sizeof(T));
+  emu_g->xchg[w][l] = v;
+  emu_wave_barrier();
+  const unsigned n = emu_g->nthreads - 64 * w < 64 ? emu_g->nthreads - 64 * w : 64;
+  for (unsigned i = 0; i < 64; i++)
+    { unsigned long long u = (i < n) ? emu_g->xchg[w][i] : 0ull; memcpy(&all[i], &u, sizeof(T)); }
+  emu_wave_barrier();
+}
+static inline unsigned long long __ballot(int pred)
+{ unsigned all[64];
+  emu_wave_gather<unsigned>(pred ? 1u : 0u, all);
+  unsigned long long m = 0;
+  for (int i = 0; i < 64; i++) if (all[i]) m |= 1ull << i;
+  return (m);
+}
+template <typename T> static inline T __shfl(T x, int src, int width = 64)
+{ T all[64]; emu_wave_gather<T>(x, all);
+  const unsigned l = threadIdx.x & 63u;
+  return (all[(l & ~(unsigned) (width - 1)) | ((unsigned) src & (unsigned) (width - 1))]);
+}
+template <typename T> static inline T __shfl_down(T x, unsigned o, int width = 64)
+{ T all[64]; emu_wave_gather<T>(x, all);
+  const unsigned l = threadIdx.x & 63u;
+  return (((l & (unsigned) (width - 1)) + o < (unsigned) width) ? all[l + o] : x);
+}
+template <typename T> static inline T __shfl_xor(T x, int m, int width = 64)
+{ T all[64]; emu_wave_gather<T>(x, all);
+  (void) width;
+  return (all[(threadIdx.x & 63u) ^ (unsigned) m]);
+}
+static inline int __builtin_amdgcn_readlane(int x, int l) { int all[64]; emu_wave_gather<int>(x, all); return (all[l & 63]); }
+static inline int __builtin_amdgcn_readfirstlane(int x) { int all[64]; emu_wave_gather<int>(x, all); return (all[0]); }
+/* v_mov_dpp with the controls the kernels use: row_shr:1..15 (0x111..0x11f), row_bcast:15 (0x142), row_bcast:31 (0x143);
+   a lane whose source lies outside its row (or whose row is masked out) keeps `old` */
+static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl)
+{ int all[64]; emu_wave_gather<int>(src, all);
+  (void) bank_mask; (void) bound_ctrl;
+  const unsigned l = threadIdx.x & 63u, row = l >> 4;
+  if (!((row_mask >> row) & 1)) return (old);
+  if (ctrl >= 0x111 && ctrl <= 0x11f)
+    { const unsigned s = (unsigned) ctrl - 0x110;
+      return (((l & 15u) >= s) ? all[l - s] : old);
+    }
+  if (ctrl == 0x142) return ((row & 1u) ? all[(row << 4) - 1] : old);        /* lane 15 of the row in front -> rows 1, 3 */
+  if (ctrl == 0x143) return ((row >= 2) ? all[31] : old);                     /* lane 31 -> rows 2, 3 */
+  fprintf(stderr, "hip_emu: DPP control 0x%x is not emulated\n", ctrl);
+  abort();
+}
+static inline int atomicMin(int *p, int v) { int o = *p; if (v < o) *p = v; return (o); }
+static inline int atomicMax(int *p, int v) { int o = *p; if (v > o) *p = v; return (o); }
+static inline int atomicAdd(int *p, int v) { int o = *p; *p = o + v; return (o); }
+static inline unsigned atomicMin(unsigned *p, unsigned v) { unsigned o = *p; if (v < o) *p = v; return (o); }
+static inline unsigned atomicMax(unsigned *p, unsigned v) { unsigned o = *p; if (v > o) *p = v; return (o); }
+static inline unsigned atomicCAS(unsigned *p, unsigned cmp, unsigned v) { unsigned o = *p; if (o == cmp) *p = v; return (o); }
+static inline unsigned long long atomicCAS(unsigned long long *p, unsigned long long cmp, unsigned long long v)
+{ unsigned long long o = *p; if (o == cmp) *p = v; return (o); }
+
+/* ---- the runtime, for the host halves of the .hip files (-DFK_EMU_FULL): device memory is host memory, streams and events
+        do nothing, a launch runs the kernel to its end ------------------------------------------------------------------- */
+#ifdef FK_EMU_FULL
+#define hipErrorUnknown 999
+#define hipErrorNotReady 600
+enum { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyHostToHost = 0, hipMemcpyDefault = 4 };
+#define hipStreamNonBlocking 1
+#define hipEventDisableTiming 2
+#define hipHostMallocDefault 0
+#define hipHostRegisterDefault 0
+#define hipFuncAttributeMaxDynamicSharedMemorySize 8
+enum { hipMemoryTypeHost = 1, hipMemoryTypeDevice = 2 };
+struct hipPointerAttribute_t { int type; };
+struct hipDeviceProp_t { char gcnArchName[64]; int multiProcessorCount; size_t totalGlobalMem; };
+static inline hipError_t hipMalloc(void **p, size_t n) { *p = aligned_alloc(256, (n + 255 + 256) & ~(size_t) 255); return (*p ? 0 : 2); }
+static inline hipError_t hipFree(void *p) { free(p); return (0); }
+static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { return (hipMalloc(p, n)); }
+static inline hipError_t hipHostFree(void *p) { free(p); return (0); }
+static inline hipError_t hipHostRegister(void *, size_t, unsigned) { return (0); }
+static inline hipError_t hipHostUnregister(void *) { return (0); }
+static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, int) { memmove(d, s, n); return (0); }
+static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, int, hipStream_t) { memmove(d, s, n); return (0); }
+static inline hipError_t hipMemcpy2DAsync(void *d, size_t dp, const void *s, size_t sp, size_t w, size_t h, int, hipStream_t)
+{ for (size_t r = 0; r < h; r++) memmove((char *) d + r * dp, (const char *) s + r * sp, w); return (0); }
+static inline hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return (0); }
+static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return (0); }
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = malloc(8); return (0); }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return (0); }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return (0); }
+static inline hipError_t hipDeviceSynchronize() { return (0); }
+static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = malloc(8); return (0); }
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = malloc(8); return (0); }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return (0); }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return (0); }
+static inline hipError_t hipEventQuery(hipEvent_t) { return (0); }
+static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0.001f; return (0); }
+static inline hipError_t hipGetLastError() { return (0); }
+static inline hipError_t hipSetDevice(int) { return (0); }
+static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return (0); }
+static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int)
+{ memset(p, 0, sizeof(*p)); strcpy(p->gcnArchName, "gfx950 (tests/csrc/hip_emu.h)"); p->multiProcessorCount = 2; p->totalGlobalMem = (size_t) 8 << 30; return (0); }
+static inline hipError_t hipFuncSetAttribute(const void *, int, int) { return (0); }
+static inline hipError_t hipMemGetInfo(size_t *f, size_t *t) { *f = *t = (size_t) 8 << 30; return (0); }
+static inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t *a, const void *) { a->type = hipMemoryTypeHost; return (0); }
+#define hipLaunchKernelGGL(kern, grid, block, lds, stream, ...) \
+  do { const dim3 g_ = (grid), b_ = (block); (void) (stream); emu_launch(g_.x, b_.x, (size_t) (lds), [=] { kern(__VA_ARGS__); }); } while (0)
+#endif
