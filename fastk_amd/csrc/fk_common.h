@@ -8,6 +8,7 @@
 #define FK_DYN_LDS(type, name) extern __shared__ type name[]
 #define FK_DYN_LDS_ALIGNED(type, name, al) extern __shared__ __attribute__((aligned(al))) type name[]
 #define FK_BALLOT_ACTIVE(p) __ballot(p)                // a ballot inside a loop that the lanes of a wave leave one by one
+#define FK_WAVE_UNIFORM(x) (x)                         // a value every lane of a wave reads in the same instruction
 #define FK_EMU_WAVE_SYNC() ((void) 0)                  // (tests/csrc/hip_emu.h: where a kernel counts on a wave's lanes moving together)
 #define FK_OPAQUE(x) asm volatile("" : "+v"(x))       // a value the optimiser cannot see through
 #define FK_KEEP(x)   asm volatile("" :: "v"(x))        // a value that must be computed

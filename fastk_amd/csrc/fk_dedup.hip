@@ -279,7 +279,7 @@ __global__ __launch_bounds__(DD_THREADS) void k_dd_table(const u32 *__restrict__
               }
           }
           while (base < end)
-            { if (*(volatile u32 *) &sh_ovf)
+            { if (FK_WAVE_UNIFORM(*(volatile u32 *) &sh_ovf))       // (one LDS read for the wave: its lanes leave together)
                 break;
               { u32 g = 0;
                 if (lane == 0) g = atomicAdd(&sh_next, 1u);

@@ -21,6 +21,15 @@ os.environ.setdefault("FK_REQUIRE_REF", "1")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # FASTK_AMD_EMU=1 (tests/test_emu_suite.py sets it for the child pytest it starts): the `gpu` tests run WITHOUT a GPU
+    # against tests/csrc/libfastk_emu.so -- the library's own sources compiled for the CPU under tests/csrc/hip_emu.h
+    # (work-items as fibers, a stand-in HIP runtime).  Test infrastructure like the oracle: nothing in fastk_amd/ knows
+    # about it; the product's loader is pointed at the other file from here, for this process only.
+    if os.environ.get("FASTK_AMD_EMU") == "1":
+        sys.path.insert(0, os.path.join(ROOT, "tests", "csrc"))
+        import build_emu_lib
+        import fastk_amd.api as api
+        api.LIB_PATH = build_emu_lib.build()
 
 
 @pytest.fixture(scope="session", autouse=True)

@@ -1,17 +1,31 @@
-/* Test harness (not shipped): just enough of the HIP kernel language to run a kernel's SOURCE on the CPU.
+/* Test harness (not shipped): the HIP kernel language -- and, with -DFK_EMU_FULL, the HIP runtime -- on the CPU.
  *
- *   g++ -std=c++17 -O1 -pthread -DFK_HOST_EMU -shared -fPIC -I fastk_amd/csrc -I tests/csrc tests/csrc/recut_emu.cpp
+ * fastk_amd/csrc/fk_common.h includes this file instead of <hip/hip_runtime.h> when FK_HOST_EMU is defined.  Two uses:
+ *   * a kernel's SOURCE run by a small driver (tests/csrc/recut_emu.cpp, xs_emu.cpp, split_emu.cpp: -DFK_HOST_EMU; the
+ *     .hip files keep the host halves that talk to the runtime behind #if !defined(FK_HOST_EMU) || defined(FK_EMU_FULL));
+ *   * the WHOLE library -- every .hip file, kernels and host code, the same C-ABI -- as tests/csrc/libfastk_emu.so
+ *     (tests/csrc/build_emu_lib.py: -DFK_HOST_EMU -DFK_EMU_FULL), so that the parity tests that need only a small input can
+ *     run without a GPU (FASTK_AMD_EMU=1, tests/conftest.py, tests/test_emu_suite.py).
  *
- * fastk_amd/csrc/fk_common.h includes this file instead of <hip/hip_runtime.h> when FK_HOST_EMU is defined; the .hip
- * files keep their host halves (the ones that talk to the HIP runtime) behind #ifndef FK_HOST_EMU.  A launch runs the
- * workgroups ONE AFTER THE OTHER, every work-item of a workgroup as a fiber of the calling thread: __syncthreads() parks
- * a work-item until all of the workgroup's have arrived, the wave barrier and __shfl_up until the 64 of its wave have,
- * `__shared__` variables are function-local statics (one workgroup at a time, so one copy is the workgroup's), dynamic
- * LDS is a buffer the launch hands out, atomics are plain read-modify-writes.  What it can show: index arithmetic, record layouts, barriers in the right
- * places, loops that end -- on the inputs the CPU tests give it.  What it cannot: anything about speed, about memory
- * ordering between waves beyond barriers, or about the real compiler.  Round 6 (the GPU pool closed after two boxes were
- * lost to the test suite): the kernels of the k-mer stage by references run through this against the oracle
- * (tests/test_recut_emu.py); on the MI355X the same stage had been checked against the oracle before (profiles/r06_b_*). */
+ * Kernel language.  A launch runs the workgroups ONE AFTER THE OTHER, every work-item of a workgroup as a fiber of the
+ * calling thread (ucontext): __syncthreads() parks a work-item until all of the workgroup's that are still alive have
+ * arrived, the wave barrier and the wave collectives (__shfl*, __ballot, readlane / readfirstlane, the DPP controls the
+ * kernels use) until the 64 of its wave have; `__shared__` variables are function-local statics (one workgroup at a time,
+ * so one copy is the workgroup's), dynamic LDS is a buffer the launch hands out (FK_DYN_LDS), atomics are plain
+ * read-modify-writes.  One work-item at a time and in a fixed order: a run is deterministic, and code that counts on the
+ * lanes of a wave moving in lockstep BETWEEN two collectives fails the same way every time -- the three places of the
+ * library that do are marked in the sources with macros that cost the device nothing (fk_common.h): FK_EMU_WAVE_SYNC()
+ * (k_ag_count2's wave-local elections: a wave's LDS stores are all done before its loads), FK_WAVE_UNIFORM(x) (k_dd_table's
+ * overflow flag: one LDS read for the whole wave), FK_BALLOT_ACTIVE(p) (a ballot among the lanes the exec mask keeps in a
+ * divergent loop); k_dd_table's four inline-asm LDS accesses have plain C++ twins under FK_HOST_EMU.  The device code is
+ * unchanged by all of this to the last instruction (hipcc -S --cuda-device-only before / after).
+ *
+ * Runtime (-DFK_EMU_FULL).  Device memory is host memory, streams and events do nothing, a launch runs the kernel to its
+ * end, one device "gfx950 (tests/csrc/hip_emu.h)" with 8 compute units.
+ *
+ * What it can show: index arithmetic, record layouts, barriers in the right places, loops that end, host orchestration --
+ * on the inputs the tests give it.  What it cannot: anything about speed, about memory ordering on a real chip, about
+ * the real compiler, the real runtime (streams, events, pinned memory) or RCCL. */
 #pragma once
 #include <algorithm>
 #include <atomic>
@@ -79,7 +93,9 @@ struct emu_group
 
 extern thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 extern thread_local emu_group *emu_g;
+extern thread_local const char *emu_kernel;            /* the kernel a launch runs, for the messages */
 #ifdef FK_EMU_DEFINE
+thread_local const char *emu_kernel = "?";
 thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 thread_local emu_group *emu_g = nullptr;
 #endif
@@ -137,6 +153,7 @@ static inline void emu_wave_barrier()
 #define FK_DYN_LDS_ALIGNED(type, name, al) type *name = (type *) emu_g->dyn_lds
 #define FK_OPAQUE(x) ((void) (x))
 #define FK_EMU_WAVE_SYNC() emu_wave_barrier()
+#define FK_WAVE_UNIFORM(x) ((unsigned) __builtin_amdgcn_readfirstlane((int) (x)))
 /* a ballot among the lanes the hardware's exec mask keeps in a divergent loop: here every lane sees itself alone (the one
    use sums the set bits into a workgroup counter through the lowest set lane: the same total) */
 #define FK_BALLOT_ACTIVE(p) ((p) ? (1ull << (threadIdx.x & 63u)) : 0ull)
@@ -214,8 +231,10 @@ static inline void emu_launch(unsigned grid, unsigned block, size_t dyn_lds_byte
                 if (fib[t].state == 3) done += 1;
               }
           if (!ran && done < block)
-            { fprintf(stderr, "hip_emu: workgroup %u is stuck: %u of %u work-items wait at a barrier that the others never reach "
-                              "(%u at the workgroup's)\n", b, block - done, block, g.at_all);
+            { fprintf(stderr, "hip_emu: %s: workgroup %u is stuck: %u of %u work-items wait at a barrier that the others never reach "
+                              "(%u at the workgroup's; at their wave's:", emu_kernel, b, block - done, block, g.at_all);
+              for (unsigned w = 0; w < 16; w++) if (g.at_wave[w]) fprintf(stderr, " wave %u: %u of %u", w, g.at_wave[w], g.wave_alive[w]);
+              fprintf(stderr, ")\n");
               abort();
             }
         }
@@ -370,10 +389,11 @@ static inline hipError_t hipGetLastError() { return (0); }
 static inline hipError_t hipSetDevice(int) { return (0); }
 static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return (0); }
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int)
-{ memset(p, 0, sizeof(*p)); strcpy(p->gcnArchName, "gfx950 (tests/csrc/hip_emu.h)"); p->multiProcessorCount = 2; p->totalGlobalMem = (size_t) 8 << 30; return (0); }
+{ memset(p, 0, sizeof(*p)); strcpy(p->gcnArchName, "gfx950 (tests/csrc/hip_emu.h)"); p->multiProcessorCount = 8; p->totalGlobalMem = (size_t) 8 << 30; return (0); }
 static inline hipError_t hipFuncSetAttribute(const void *, int, int) { return (0); }
 static inline hipError_t hipMemGetInfo(size_t *f, size_t *t) { *f = *t = (size_t) 8 << 30; return (0); }
 static inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t *a, const void *) { a->type = hipMemoryTypeHost; return (0); }
 #define hipLaunchKernelGGL(kern, grid, block, lds, stream, ...) \
-  do { const dim3 g_ = (grid), b_ = (block); (void) (stream); emu_launch(g_.x, b_.x, (size_t) (lds), [=] { kern(__VA_ARGS__); }); } while (0)
+  do { const dim3 g_ = (grid), b_ = (block); (void) (stream); emu_kernel = #kern; \
+       emu_launch(g_.x, b_.x, (size_t) (lds), [=] { kern(__VA_ARGS__); }); } while (0)
 #endif
