@@ -42,6 +42,21 @@ def build(force=False):
     return OUT
 
 
+def build_driver(name):
+    """host/<name>.c linked against libfastk_emu.so: the C drivers of the CLI tests, on the CPU"""
+    lib = build()
+    bindir = os.path.join(HERE, "_emu_bin")
+    os.makedirs(bindir, exist_ok=True)
+    exe = os.path.join(bindir, name)
+    srcs = [os.path.join(SRC, "host", name + ".c")]
+    if name == "FastK_amd":
+        srcs.append(os.path.join(SRC, "host", "input_formats.c"))
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max([os.path.getmtime(lib)] + [os.path.getmtime(x) for x in srcs]):
+        subprocess.check_call(["gcc", "-O2", "-w", "-o", exe] + srcs + ["-L" + HERE, "-lfastk_emu", "-lz", "-lpthread", "-lstdc++",
+                               "-Wl,-rpath," + HERE])
+    return exe
+
+
 def _wait(procs):
     while procs:
         name, p = procs.pop(0)

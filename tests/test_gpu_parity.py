@@ -765,7 +765,7 @@ def test_homopolymer_compression_device_host_reference(name, tmp_path):
         assert np.array_equal(res.hist, exp.hist) and res.max_inst == exp.max_inst
         assert np.array_equal(res.table, exp.table)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "fastk_amd", "bin", "FastK_amd")
+    exe = util.driver_exe("FastK_amd")
     digests = []
     for extra in ([], ["-H"]):
         subprocess.run([exe, "-k%d" % k, "-t%d" % case["cutoff"], "-c", "-N" + str(tmp_path / "o")] + extra + [path],
@@ -789,8 +789,8 @@ def test_table_merge_matches_reference_fastmerge(name, tmp_path):
     case, bases, boff = util.load_case(name)
     k = case["k"]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "fastk_amd", "bin", "FastK_amd")
-    mrg = os.path.join(root, "fastk_amd", "bin", "Fastmerge_amd")
+    exe = util.driver_exe("FastK_amd")
+    mrg = util.driver_exe("Fastmerge_amd")
     nreads = len(boff) - 1
     cuts = [0, nreads // 3, 2 * nreads // 3, nreads]
     srcs = []
@@ -852,7 +852,7 @@ def test_cli_memory_option(tmp_path):
     import hashlib, os, subprocess
     case, bases, boff = util.load_case("synth_illumina_k40_t1_T4")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "fastk_amd", "bin", "FastK_amd")
+    exe = util.driver_exe("FastK_amd")
     path = str(tmp_path / "reads.fastq")
     orc.write_fastq(path, bases, boff)
     p = subprocess.run([exe, "-k40", "-t1", "-T4", "-M1", "-v", path], cwd=str(tmp_path),
@@ -989,7 +989,7 @@ def test_cli_outputs_match_reference(name, fmt, gz, tmp_path):
     import gzip, hashlib, os, subprocess
     case, bases, boff = util.load_case(name)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "fastk_amd", "bin", "FastK_amd")
+    exe = util.driver_exe("FastK_amd")
     assert os.path.exists(exe), "build fastk_amd/csrc first"
     path = str(tmp_path / ("reads." + fmt))
     (orc.write_fasta if fmt == "fasta" else orc.write_fastq)(path, bases, boff)
@@ -1032,7 +1032,7 @@ def test_cli_reader_threads_pack_the_text(name, fmt, width, piece, tmp_path):
     import hashlib, os, subprocess
     case, bases, boff = util.load_case(name)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "fastk_amd", "bin", "FastK_amd")
+    exe = util.driver_exe("FastK_amd")
     path = str(tmp_path / ("reads." + fmt))
     if fmt == "fasta":
         orc.write_fasta(path, bases, boff, **({"width": width} if width else {}))
@@ -1062,7 +1062,7 @@ def test_cli_several_input_files(name, tmp_path):
     import gzip, hashlib, os, subprocess
     case, bases, boff = util.load_case(name)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "fastk_amd", "bin", "FastK_amd")
+    exe = util.driver_exe("FastK_amd")
     raw = bytes(bases)
     reads = [raw[boff[i]:boff[i + 1] - 1] for i in range(len(boff) - 1)]
     cuts = [0, len(reads) // 3, len(reads) // 3 + len(reads) // 5, len(reads)]
@@ -1092,7 +1092,7 @@ def test_cli_one_long_record(tmp_path):
     (io.c:557-570), the device parser takes it as text -- same .hist bytes and table, and every 40-mer counted once."""
     import hashlib, os, subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "fastk_amd", "bin", "FastK_amd")
+    exe = util.driver_exe("FastK_amd")
     rng = np.random.default_rng(7)
     L = 12_000_000
     seq = np.frombuffer(b"acgt", dtype=np.uint8)[rng.integers(0, 4, size=L)].copy()
@@ -1171,7 +1171,7 @@ def test_cli_text_parsers_agree_on_odd_files(kind, quirks, tmp_path):
     and the host scanner still follow the reference; the device parser reads FASTA as FASTA and is left out."""
     import hashlib, os, subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "fastk_amd", "bin", "FastK_amd")
+    exe = util.driver_exe("FastK_amd")
     path = str(tmp_path / ("odd." + kind))
     with open(path, "w") as f:
         f.write(_odd_text(kind, quirks))
@@ -1310,7 +1310,7 @@ def test_c_driver_sharded_over_rccl_writes_the_one_gpu_files(name, fmt, ranks, t
     case, bases, boff = util.load_case(name)
     exp = case["expected"]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "fastk_amd", "bin", "FastK_amd")
+    exe = util.driver_exe("FastK_amd")
     path = str(tmp_path / ("reads." + fmt))
     if case["kind"] == "edge":
         orc.write_fasta(path, bases, boff)
@@ -1363,7 +1363,7 @@ def test_c_driver_sharded_with_profiles_and_budget(name, fmt, ranks, budget, tmp
     exp = case["expected"]
     assert "prof" in exp
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "fastk_amd", "bin", "FastK_amd")
+    exe = util.driver_exe("FastK_amd")
     path = str(tmp_path / ("reads." + fmt))
     if case["kind"] == "edge":
         orc.write_fasta(path, bases, boff)
@@ -1416,7 +1416,7 @@ def test_c_driver_sharded_deals_pieces_of_long_reads(how, tmp_path):
                 r[same] = acgt[(np.searchsorted(acgt, r[same]) + 1 + (same & 1)) % 4]
                 same = np.nonzero(r[1:] == r[:-1])[0] + 1
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "fastk_amd", "bin", "FastK_amd")
+    exe = util.driver_exe("FastK_amd")
     path = str(tmp_path / ("long.fa.gz" if how == "gz" else "long.fa"))
     with (gzip.open(path, "wb", compresslevel=1) if how == "gz" else open(path, "wb")) as f:
         for i, r in enumerate(reads):
@@ -2103,7 +2103,7 @@ def test_exact_parts_follows_the_reference_scheme_to_several_buckets(name, tmp_p
     path = str(tmp_path / ("x." + case["fmt"]))
     util.write_fastx(path, bases, boff, case["fmt"] == "fastq")
     args = ["-k%d" % k, "-t%d" % cutoff, "-T%d" % T, "-M%d" % mem]
-    for cmd in ([os.path.join(root, "fastk_amd", "bin", "FastK_amd")] + args + ["-x", path],
+    for cmd in ([util.driver_exe("FastK_amd")] + args + ["-x", path],
                 [os.path.join(orc.REF_DIR, "FastK_gpu")] + args + ["-P" + str(tmp_path), path]):
         if not os.path.exists(cmd[0]):
             continue
@@ -2124,7 +2124,7 @@ def test_drivers_against_reference_digests_above_fixture_size(name, tmp_path):
     case, bases, boff = util.load_case(name)
     exp = case["expected"]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "fastk_amd", "bin", "FastK_amd")
+    exe = util.driver_exe("FastK_amd")
     path = str(tmp_path / ("x." + case["fmt"]))
     util.write_fastx(path, bases, boff, case["fmt"] == "fastq")
     args = ["-k%d" % case["k"], "-t%d" % case["cutoff"], "-T%d" % case["T"]]
@@ -2217,7 +2217,7 @@ def test_reference_digests_above_4GiB(tmp_path):
     finally:
         lib.fk_host_free(host)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "fastk_amd", "bin", "FastK_amd")
+    exe = util.driver_exe("FastK_amd")
     args = ["-k%d" % k, "-t%d" % cutoff, "-T%d" % T]
     for what, extra, env in (("one GPU", ["-M64"], None), ("-G2", ["-G2"], dict(os.environ, FK_RANKS_SHARE_GPU="1"))):
         d = tmp_path / what.strip("-").replace(" ", "")
@@ -2437,7 +2437,7 @@ def test_configs4_scaled_slice_k51_profiles_with_spill(tmp_path):
     nreads = int(100 * glen / L)
     bases, boff = orc.synth_block(4051, glen, L, 1000, 0, nreads)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "fastk_amd", "bin", "FastK_amd")
+    exe = util.driver_exe("FastK_amd")
     path = str(tmp_path / "x.fastq")
     util.write_fastx(path, bases, boff, True)
     del bases
@@ -2622,7 +2622,7 @@ def test_cli_profiles_option(name, fmt, tmp_path):
     case, bases, boff = util.load_case(name)
     k = case["k"]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "fastk_amd", "bin", "FastK_amd")
+    exe = util.driver_exe("FastK_amd")
     path = str(tmp_path / ("reads." + fmt))
     (orc.write_fasta if fmt == "fasta" else orc.write_fastq)(path, bases, boff)
     subprocess.run([exe, "-k%d" % k, "-t%d" % case["cutoff"], "-T%d" % case["T"], "-p", "-v", path],
@@ -2684,7 +2684,7 @@ def test_relative_profiles_against_another_table(tmp_path):
     orc.write_fasta(pb, basesB, boffB)
     orc.write_fasta(pa, basesA, boffA)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "fastk_amd", "bin", "FastK_amd")
+    exe = util.driver_exe("FastK_amd")
     subprocess.run([exe, "-k%d" % k, "-t2", "-T2", pb], check=True, cwd=d)
     subprocess.run([exe, "-k%d" % k, "-T%d" % T, "-p:B", "-v", pa], check=True, cwd=d)
     assert not os.path.exists(os.path.join(d, "A.hist"))                 # only profiles are produced
@@ -2811,7 +2811,7 @@ def test_cli_reads_sam_and_bam(kind, tmp_path):
     path = os.path.join(d, "x." + kind)
     (orc.write_sam if kind == "sam" else orc.write_bam)(path, reads, flags)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "fastk_amd", "bin", "FastK_amd")
+    exe = util.driver_exe("FastK_amd")
     subprocess.run([exe, "-k%d" % k, "-t1", "-T%d" % T, "-p", "-Nmine", path], check=True, cwd=d)
     kept = [r for r, f in zip(reads, flags) if not (f & 0x900)]
     kept = [orc.sam_bases(r) for r in kept] if kind == "sam" else \
@@ -2842,7 +2842,7 @@ def test_cli_output_naming_follows_reference(tmp_path):
     nreads = len(boff) - 1
     half = nreads // 2
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "fastk_amd", "bin", "FastK_amd")
+    exe = util.driver_exe("FastK_amd")
     ref = os.path.join(orc.REF_DIR, "FastK")
     if not os.path.exists(ref):
         util.no_reference("reference build not available")
@@ -2976,7 +2976,7 @@ def test_cli_profiles_of_homopolymer_compressed_reads(fmt, tmp_path):
     if not os.path.exists(ref):
         util.no_reference("reference build not available")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "fastk_amd", "bin", "FastK_amd")
+    exe = util.driver_exe("FastK_amd")
     outs = []
     for tool, name in ((exe, "g"), (ref, "r")):
         d = str(tmp_path / name)
@@ -3008,7 +3008,7 @@ def test_barcode_prefix_and_compression_with_profiles(flags, tmp_path):
     if not os.path.exists(ref):
         util.no_reference("reference build not available")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    tools = [("r", ref), ("a", os.path.join(root, "fastk_amd", "bin", "FastK_amd"))]
+    tools = [("r", ref), ("a", util.driver_exe("FastK_amd"))]
     if os.path.exists(shim):
         tools.append(("s", shim))
     outs = {}
@@ -3037,7 +3037,7 @@ def test_cli_profiles_with_memory_budget(fmt, extra, tmp_path):
     import os, subprocess
     case, bases, boff = util.load_case("synth_illumina_k40_t1_T4")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "fastk_amd", "bin", "FastK_amd")
+    exe = util.driver_exe("FastK_amd")
     reads = [bases[boff[i]:boff[i + 1] - 1].tobytes().decode() for i in range(len(boff) - 1)]
     outs = []
     for name, mem in (("res", []), ("mem", ["-M1"])):
@@ -3157,7 +3157,7 @@ def test_c_driver_sharded_on_distinct_devices(ranks, opts, name, fmt, tmp_path):
     case, bases, boff = util.load_case(name)
     exp = case["expected"]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "fastk_amd", "bin", "FastK_amd")
+    exe = util.driver_exe("FastK_amd")
     path = str(tmp_path / ("reads." + fmt))
     util.write_fastx(path, bases, boff, fmt == "fastq")
     T = 8

@@ -59,6 +59,18 @@ def load_case(name):
     return case, bases, boff
 
 
+def driver_exe(name):
+    """fastk_amd/bin/<name> (FastK_amd, Fastmerge_amd) -- or, in a test process started with FASTK_AMD_EMU=1, the same C
+    source linked against the CPU-emulated library (tests/csrc/build_emu_lib.py): test infrastructure, see tests/conftest.py"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if os.environ.get("FASTK_AMD_EMU") == "1":
+        import sys
+        sys.path.insert(0, os.path.join(root, "tests", "csrc"))
+        import build_emu_lib
+        return build_emu_lib.build_driver(name)
+    return os.path.join(root, "fastk_amd", "bin", name)
+
+
 def golden_table(name, kmer):
     p = os.path.join(GOLDEN, name + ".table.gz")
     if not os.path.exists(p):
